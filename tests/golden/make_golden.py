@@ -1,0 +1,112 @@
+#!/usr/bin/env python3
+"""Regenerates tests/golden/*.json and tests/golden/data/* from the reference checkout.
+
+Run in the build container only (needs /root/reference, read as text/data):
+
+    python tests/golden/make_golden.py
+
+What it collects (data only -- expected values and test input files, no code):
+
+* kmer_golden.json : the known-answer arrays of the reference's own unit test
+  src/common/test/test_kmer.cpp (TestKmerGenerationChar2 :416-462,
+  TestKmerGenerationChar3 :562-648, TestKmerComparison1 :654-693,
+  TestKmerReverse112 :699-756).
+* parse_golden.json : the TestFileInfo tables (records, k-mers, bytes) of
+  src/io/test/mpi_test_fastq_seq_parse.cpp:446-459 (K=35, DNA5) and
+  src/io/test/mpi_test_fasta_seq_parse.cpp:398-403.
+* data/* : the small input files of test/data those tables refer to.
+* survey_known_answers.json is written by hand from SURVEY.md section 8(c)
+  (values obtained there by running reference-compiled code) and is not
+  touched by this script.
+"""
+import json
+import os
+import re
+import shutil
+
+REF = os.environ.get("KMERIND_REFERENCE", "/root/reference")
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _block(text, start_marker, end_marker=None):
+    i = text.index(start_marker)
+    j = text.index(end_marker, i) if end_marker else len(text)
+    return text[i:j]
+
+
+def _array(block, name):
+    m = re.search(r"\b" + re.escape(name) + r"\s*\[[^\]]*\]\s*=\s*\{([^}]*)\}", block, re.S)
+    if not m:
+        raise KeyError(name)
+    body = re.sub(r"//[^\n]*", "", m.group(1))
+    return [int(tok, 0) for tok in re.findall(r"0x[0-9a-fA-F]+|\d+", body)]
+
+
+def kmer_golden():
+    src = open(os.path.join(REF, "src/common/test/test_kmer.cpp")).read()
+    out = {"source": "src/common/test/test_kmer.cpp"}
+
+    b = _block(src, "TEST(KmerGeneration, TestKmerGenerationChar2)", "template<typename Alphabet, int K>")
+    out["char2"] = {
+        "alphabet": "DNA", "bits": 2, "ks": [31, 28, 13, 4, 1],
+        "codes": _array(b, "kmer_data"),
+        "kmer_ex": [hex(v) for v in _array(b, "kmer_ex")],
+        "rule": "kmer(K) after consuming codes[0..K-1+i] == kmer_ex[i] >> ((32-K)*2)",
+    }
+    b = _block(src, "TEST(KmerGeneration, TestKmerGenerationChar3)", "TEST(KmerComparison")
+    out["char3"] = {
+        "alphabet": "DNA5", "bits": 3, "ks": [21, 20, 13, 9, 1],
+        "codes": _array(b, "kmer_data_8"),
+        "kmer_ex": [hex(v) for v in _array(b, "kmer_ex")],
+        "rule": "kmer(K) after consuming codes[0..K-1+i] == kmer_ex[i] >> ((21-K)*3)",
+    }
+    b = _block(src, "TEST(KmerComparison, TestKmerComparison1)", "TEST(KmerReverse")
+    out["compare"] = {
+        "k": 41, "alphabet": "DNA", "word_bits": 16,
+        "kmer": _array(b, "kmer_val"), "smaller4": _array(b, "kmer_val_s4"),
+        "greater3": _array(b, "kmer_val_g3"), "g3s4": _array(b, "kmer_val_g3s4"),
+        "expect": ["kmer > smaller4", "greater3 > kmer", "kmer > g3s4", "greater3 > g3s4", "smaller4 < g3s4"],
+    }
+    b = _block(src, "TEST(KmerReverse, TestKmerReverse112)")
+    out["reverse112"] = {
+        "word_bits": 16,
+        "in": _array(b, "kmer_val"),
+        "dna_k56": _array(b, "kmer_ex"),
+        "dna5_k37": _array(b, "kmer_ex_3"),
+    }
+    return out
+
+
+def parse_golden():
+    out = {"fastq": {"k": 35, "alphabet": "DNA5", "source": "src/io/test/mpi_test_fastq_seq_parse.cpp:446-459", "files": []},
+           "fasta": {"k": None, "alphabet": "DNA5", "source": "src/io/test/mpi_test_fasta_seq_parse.cpp:398-403", "files": []}}
+    fq = open(os.path.join(REF, "src/io/test/mpi_test_fastq_seq_parse.cpp")).read()
+    b = _block(fq, "INSTANTIATE_TEST_CASE_P(Bliss, FASTQParseTest", "));")
+    for m in re.finditer(r"^\s*TestFileInfo\((\d+),\s*(\d+),\s*(\d+),\s*std::string\(\"/test/data/([^\"]+)\"\)", b, re.M):
+        out["fastq"]["files"].append({"file": m.group(4), "records": int(m.group(1)), "kmers": int(m.group(2)), "bytes": int(m.group(3))})
+    fa = open(os.path.join(REF, "src/io/test/mpi_test_fasta_seq_parse.cpp")).read()
+    km = re.search(r"class FASTAParseTest.*?kmer_size\s*=\s*(\d+)", fa, re.S)
+    out["fasta"]["k"] = int(km.group(1)) if km else None
+    b = _block(fa, "INSTANTIATE_TEST_CASE_P(Bliss, FASTAParseTest", "));")
+    for m in re.finditer(r"^\s*TestFileInfo\((\d+),\s*(\d+),\s*(\d+),\s*std::string\(\"/test/data/([^\"]+)\"\)", b, re.M):
+        out["fasta"]["files"].append({"file": m.group(4), "records": int(m.group(1)), "kmers": int(m.group(2)), "bytes": int(m.group(3))})
+    return out
+
+
+def main():
+    with open(os.path.join(HERE, "kmer_golden.json"), "w") as f:
+        json.dump(kmer_golden(), f, indent=1)
+    pg = parse_golden()
+    with open(os.path.join(HERE, "parse_golden.json"), "w") as f:
+        json.dump(pg, f, indent=1)
+    os.makedirs(os.path.join(HERE, "data"), exist_ok=True)
+    names = {e["file"] for sect in pg.values() for e in sect["files"]}
+    for name in sorted(names):
+        src = os.path.join(REF, "test/data", name)
+        if os.path.exists(src) and os.path.getsize(src) < 200_000:
+            shutil.copyfile(src, os.path.join(HERE, "data", name))
+    print("wrote golden fixtures for", len(names), "files")
+
+
+if __name__ == "__main__":
+    main()
