@@ -1,0 +1,190 @@
+/*
+ * kmerind_hip.h -- C ABI of libkmerind_hip.so, the MI355X (gfx950) k-mer index core.
+ *
+ * This is the drop-in boundary for ONE path of ParBLiSS/kmerind:
+ *   FASTA/FASTQ bytes -> k-mer tuples -> (strand transform) -> hash / rank ->
+ *   bucket partition -> per-bucket reduce -> count / find / erase.
+ *
+ * The reference exposes that path as C++ templates, not as an FFI
+ * (bliss::index::kmer::Index<MapType,KmerParser>, src/index/kmer_index.hpp:98-394).
+ * Each entry point below names the reference function(s) it replaces; the C++
+ * facade in include/kmerind/ re-creates the reference's class / alias names on
+ * top of these calls.
+ *
+ * Conventions
+ *   - every function returns kmi_status (0 = OK); kmi_last_error(ctx) gives text.
+ *     The facade maps KMI_ERR_INVALID -> std::invalid_argument,
+ *     KMI_ERR_PARSE -> std::logic_error (the exceptions the reference throws,
+ *     kmer_index.hpp:245-254, fastq_loader.hpp:350-363).
+ *   - plain pointers and sizes only; no C++ or torch types cross the ABI.
+ *   - "_host" entry points take/return host memory exactly like the reference's
+ *     std::vector based API; "_dev" entry points take device pointers that are
+ *     already resident in HBM (what bench.py times).
+ *   - k-mers are the reference's Kmer<K,Alphabet,uint64_t> object bytes:
+ *     n_words little-endian 64-bit words, data[0] least significant, newest base
+ *     in the low bits, pad bits zero (src/common/kmer.hpp:116-177).
+ *   - one context = one GPU = one "rank" (replaces mxx::comm); all calls on a
+ *     context are issued from one host thread, like one MPI rank.
+ *   - there is no CPU fallback: without a usable HIP device every entry point
+ *     fails with KMI_ERR_DEVICE.
+ */
+#ifndef KMERIND_HIP_H
+#define KMERIND_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+  KMI_OK = 0,
+  KMI_ERR_INVALID = 1, /* bad argument / unsupported configuration */
+  KMI_ERR_DEVICE = 2,  /* HIP runtime failure, no device */
+  KMI_ERR_PARSE = 3,   /* malformed FASTQ/FASTA (reference throws std::logic_error) */
+  KMI_ERR_NOMEM = 4,
+  KMI_ERR_OVERFLOW = 5 /* id overflow (sequence.hpp:177-183) or capacity exceeded */
+} kmi_status;
+
+enum { KMI_ALPHA_DNA = 0, KMI_ALPHA_DNA5 = 1 };                 /* alphabets.hpp:127-185, 212-285 (DNA5 == DNA6) */
+enum { KMI_STRAND_SINGLE = 0, KMI_STRAND_CANONICAL = 1, KMI_STRAND_BIMOLECULE = 2 }; /* kmer_index.hpp:436-481 */
+enum { KMI_HASH_MURMUR = 0, KMI_HASH_FARM = 1 };                /* kmer_hash.hpp:242-311 */
+enum { KMI_FMT_FASTQ = 0, KMI_FMT_FASTA = 1 };
+enum { KMI_INDEX_COUNT = 0, KMI_INDEX_POSITION = 1, KMI_INDEX_POSQUAL = 2 }; /* kmer_index.hpp:399-411 */
+
+/* The compile-time parameters of the reference's Index<Map,Parser> as a runtime struct. */
+typedef struct {
+  uint32_t k;          /* Kmer<K,...>::size */
+  uint32_t alphabet;   /* KMI_ALPHA_* */
+  uint32_t strand;     /* KMI_STRAND_*: Single / Canonical / Bimolecule HashMapParams */
+  uint32_t dist_hash;  /* KMI_HASH_*: DistHash (rank assignment), Prefix=true variant */
+  uint32_t store_hash; /* KMI_HASH_*: StoreHash; accepted for API parity, placement on the
+                          GPU is internal and does not change results */
+  uint32_t index_kind; /* KMI_INDEX_* */
+  uint32_t seq_format; /* KMI_FMT_* */
+  uint32_t farm_ndebug;/* 0: farmhash as the reference's default RelWithDebInfo build computes it
+                          (DebugTweak active, CMakeLists.txt:26,200-204); 1: -DNDEBUG behaviour */
+} kmi_config;
+
+typedef struct kmi_ctx kmi_ctx;     /* replaces mxx::comm + per-rank state */
+typedef struct kmi_index kmi_index; /* replaces MapType (dsc::counting_*_map etc.) */
+
+/* ---- context ------------------------------------------------------------ */
+/* Index(const mxx::comm&) (kmer_index.hpp:115): device = HIP ordinal, rank/nranks =
+ * comm.rank()/comm.size(). stream = hipStream_t (NULL = default stream). */
+kmi_status kmi_ctx_create(int device, int rank, int nranks, void *stream, kmi_ctx **out);
+kmi_status kmi_ctx_destroy(kmi_ctx *ctx);
+const char *kmi_last_error(const kmi_ctx *ctx);
+/* derived Kmer shape (padding.hpp:67-90): words per k-mer, hashed byte length */
+kmi_status kmi_kmer_shape(const kmi_config *cfg, uint32_t *n_words, uint32_t *n_bits, uint32_t *n_bytes);
+void kmi_free_host(void *p);
+kmi_status kmi_device_alloc(kmi_ctx *ctx, size_t bytes, void **dptr);
+kmi_status kmi_device_free(kmi_ctx *ctx, void *dptr);
+kmi_status kmi_copy_to_device(kmi_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
+kmi_status kmi_copy_to_host(kmi_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
+kmi_status kmi_synchronize(kmi_ctx *ctx);
+
+/* ---- L2: k-mer value ops on arrays (parity surface for kmer.hpp / kmer_transform.hpp) */
+/* Kmer::reverse_complement (kmer.hpp:1118-1127) on n k-mers */
+kmi_status kmi_revcomp_host(kmi_ctx *ctx, const kmi_config *cfg, const uint64_t *in, size_t n, uint64_t *out);
+/* transform::lex_less (kmer_transform.hpp:108-116) */
+kmi_status kmi_canonical_host(kmi_ctx *ctx, const kmi_config *cfg, const uint64_t *in, size_t n, uint64_t *out);
+/* hash::murmur / hash::farm <Kmer,Prefix> (kmer_hash.hpp:242-311) */
+kmi_status kmi_hash_host(kmi_ctx *ctx, const kmi_config *cfg, uint32_t which, int prefix,
+                         const uint64_t *in, size_t n, uint64_t *out);
+/* KeyToRank (distributed_unordered_map.hpp:148-170): DistHash(DistTrans(k)) % nranks */
+kmi_status kmi_key_to_rank_host(kmi_ctx *ctx, const kmi_config *cfg, const uint64_t *in, size_t n,
+                                uint32_t nranks, uint32_t *ranks);
+
+/* ---- L3: file bytes -> tuples.  KmerFileHelper::read_file_* / parse_file_data_old /
+ * read_block_old (kmer_file_helper.hpp:110-186,441-482,588-633) + the tuple parsers
+ * (kmer_parser.hpp:85-294,303-569,577-900,909-1083).
+ * `bytes` is a record-aligned partition whose first byte sits at `file_offset`;
+ * tuples come back in file order, as parsed (no strand transform), like the reference. */
+typedef struct {
+  uint64_t n_tuples;
+  uint64_t n_seqs;
+  uint64_t *kmers;  /* n_tuples * n_words */
+  uint64_t *ids;    /* Short/LongSequenceKmerId (sequence.hpp:127-296) or NULL */
+  float *quals;     /* k-mer quality (quality_score_iterator.hpp:166-173) or NULL */
+} kmi_tuples;
+
+kmi_status kmi_extract_host(kmi_ctx *ctx, const kmi_config *cfg, const uint8_t *bytes, size_t n_bytes,
+                            uint64_t file_offset, kmi_tuples *out /* buffers malloc'd; kmi_tuples_free */);
+void kmi_tuples_free(kmi_tuples *t);
+/* device form: bytes_dev 16-byte aligned, out_kmers_dev capacity in tuples (use
+ * kmi_extract_count_dev first, or pass an upper bound n_bytes). */
+kmi_status kmi_extract_count_dev(kmi_ctx *ctx, const kmi_config *cfg, const uint8_t *bytes_dev, size_t n_bytes,
+                                 uint64_t *n_tuples, uint64_t *n_seqs);
+kmi_status kmi_extract_dev(kmi_ctx *ctx, const kmi_config *cfg, const uint8_t *bytes_dev, size_t n_bytes,
+                           uint64_t file_offset, uint64_t *out_kmers_dev, uint64_t *out_ids_dev,
+                           size_t out_capacity, uint64_t *n_tuples, uint64_t *n_seqs);
+
+/* ---- L4: the exchange step of imxx::distribute (incremental_mxx.hpp:1039-1109):
+ * assign_to_buckets + bucket_to_permutation + permute on the device. Output is the
+ * send buffer grouped by destination rank (stable inside a rank), counts[nranks] on
+ * the host. The all-to-all itself is done by the caller (RCCL through
+ * torch.distributed in kmerind_amd.dist, or ncclSend/ncclRecv from C++). */
+kmi_status kmi_route_dev(kmi_ctx *ctx, const kmi_config *cfg, const uint64_t *keys_dev, size_t n,
+                         uint32_t nranks, uint64_t *out_keys_dev, uint64_t *send_counts_host);
+
+/* ---- L4/L5: the map behind Index<MapType,Parser> ---------------------------- */
+kmi_status kmi_index_create(kmi_ctx *ctx, const kmi_config *cfg, kmi_index **out);
+kmi_status kmi_index_destroy(kmi_index *idx);
+/* Index::insert(std::vector<Kmer>&) for counting maps on ONE rank: InputTransform +
+ * local reduce (distributed_unordered_map.hpp:1697-1745,1826-1884). Keys must already
+ * belong to this rank when nranks > 1 (i.e. after the exchange). */
+kmi_status kmi_index_insert_host(kmi_index *idx, const uint64_t *kmers, size_t n);
+kmi_status kmi_index_insert_dev(kmi_index *idx, const uint64_t *kmers_dev, size_t n);
+/* Index::build_mmap/build_posix for nranks == 1: read_file + insert fused on the
+ * device (kmer_index.hpp:239-372). */
+kmi_status kmi_index_build_host(kmi_index *idx, const uint8_t *bytes, size_t n_bytes, uint64_t file_offset);
+kmi_status kmi_index_build_dev(kmi_index *idx, const uint8_t *bytes_dev, size_t n_bytes, uint64_t file_offset);
+/* MapType::local_size() / size() on one rank (distributed_map_base.hpp:227-245) */
+kmi_status kmi_index_local_size(kmi_index *idx, uint64_t *n);
+/* MapType::to_vector() (distributed_map_base.hpp:202-217): keys n*n_words, counts n; order unspecified */
+kmi_status kmi_index_export_host(kmi_index *idx, uint64_t *keys, uint32_t *counts, size_t capacity, uint64_t *n);
+
+typedef struct {
+  uint64_t n;
+  uint64_t *keys;   /* n * n_words: the transformed (e.g. canonical) query keys */
+  uint64_t *values; /* count(): 0/1 presence (db.count(k)); find(): stored count */
+} kmi_results;
+void kmi_results_free(kmi_results *r);
+/* Index::count (kmer_index.hpp:142-145 -> distributed_unordered_map.hpp:880-983):
+ * one entry per DISTINCT transformed query key, value = number of map entries with
+ * that key (0 or 1 for a counting map). */
+kmi_status kmi_index_count_host(kmi_index *idx, const uint64_t *queries, size_t nq, kmi_results *out);
+/* Index::find (kmer_index.hpp:132-135 -> :564-687): (key, stored value) of the
+ * distinct transformed query keys that are present. */
+kmi_status kmi_index_find_host(kmi_index *idx, const uint64_t *queries, size_t nq, kmi_results *out);
+/* Index::erase (kmer_index.hpp:147-149 -> :719-779) */
+kmi_status kmi_index_erase_host(kmi_index *idx, const uint64_t *queries, size_t nq, uint64_t *n_erased);
+/* device-resident query forms used by bench.py (results stay on the device):
+ * out_keys_dev/out_values_dev capacity nq; *n_out distinct results */
+kmi_status kmi_index_count_dev(kmi_index *idx, const uint64_t *queries_dev, size_t nq,
+                               uint64_t *out_keys_dev, uint64_t *out_values_dev, uint64_t *n_out);
+kmi_status kmi_index_find_dev(kmi_index *idx, const uint64_t *queries_dev, size_t nq,
+                              uint64_t *out_keys_dev, uint64_t *out_values_dev, uint64_t *n_out);
+
+/* ---- measurement support --------------------------------------------------- */
+/* per-kernel HIP-event timing on the context's stream (bench.py roofline leg) */
+kmi_status kmi_profile_enable(kmi_ctx *ctx, int on);
+kmi_status kmi_profile_reset(kmi_ctx *ctx);
+/* writes up to cap records; returns count in *n. name points to static storage. */
+typedef struct { const char *name; double total_ms; uint64_t launches; uint64_t units; } kmi_kernel_time;
+kmi_status kmi_profile_get(kmi_ctx *ctx, kmi_kernel_time *out, size_t cap, size_t *n);
+
+/* deterministic synthetic inputs of SURVEY.md 8(d) (host side, splitmix64):
+ * genome of g bases, r reads of read_len as 4-line FASTQ records with a 9-digit id
+ * (315 bytes per 150-bp record). reads [first_read, first_read + n_reads) of the
+ * data set defined by (seed, genome_len). Returns bytes written. */
+size_t kmi_synth_fastq_bytes(uint64_t n_reads, uint32_t read_len);
+kmi_status kmi_synth_fastq(uint64_t seed, uint64_t genome_len, uint32_t read_len, uint64_t first_read,
+                           uint64_t n_reads, uint8_t *out, size_t out_capacity, uint32_t threads);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KMERIND_HIP_H */

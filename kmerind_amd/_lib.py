@@ -1,0 +1,102 @@
+"""ctypes binding of libkmerind_hip.so (the C ABI declared in include/kmerind_hip.h).
+
+There is no CPU fallback: if the shared library is missing this module raises at import,
+and every call fails with KMI_ERR_DEVICE when no HIP device is usable."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libkmerind_hip.so")
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        "kmerind_amd: %s is missing. Build it with `make -C kmerind_amd/csrc` "
+        "(or python -c 'import __graft_entry__ as g; g.build()'). There is no CPU fallback." % LIB_PATH)
+
+lib = C.CDLL(LIB_PATH)
+
+OK, ERR_INVALID, ERR_DEVICE, ERR_PARSE, ERR_NOMEM, ERR_OVERFLOW = range(6)
+ALPHA_DNA, ALPHA_DNA5 = 0, 1
+STRAND_SINGLE, STRAND_CANONICAL, STRAND_BIMOLECULE = 0, 1, 2
+HASH_MURMUR, HASH_FARM = 0, 1
+FMT_FASTQ, FMT_FASTA = 0, 1
+INDEX_COUNT, INDEX_POSITION, INDEX_POSQUAL = 0, 1, 2
+
+
+class Config(C.Structure):
+    _fields_ = [("k", C.c_uint32), ("alphabet", C.c_uint32), ("strand", C.c_uint32),
+                ("dist_hash", C.c_uint32), ("store_hash", C.c_uint32), ("index_kind", C.c_uint32),
+                ("seq_format", C.c_uint32), ("farm_ndebug", C.c_uint32)]
+
+
+class Tuples(C.Structure):
+    _fields_ = [("n_tuples", C.c_uint64), ("n_seqs", C.c_uint64), ("kmers", C.POINTER(C.c_uint64)),
+                ("ids", C.POINTER(C.c_uint64)), ("quals", C.POINTER(C.c_float))]
+
+
+class Results(C.Structure):
+    _fields_ = [("n", C.c_uint64), ("keys", C.POINTER(C.c_uint64)), ("values", C.POINTER(C.c_uint64))]
+
+
+class KernelTime(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("total_ms", C.c_double), ("launches", C.c_uint64), ("units", C.c_uint64)]
+
+
+_P = C.c_void_p
+_CFG = C.POINTER(Config)
+_sz = C.c_size_t
+_u64 = C.c_uint64
+_u32 = C.c_uint32
+
+# every symbol include/kmerind_hip.h declares, with its signature
+SIGNATURES = {
+    "kmi_ctx_create": (C.c_int, [C.c_int, C.c_int, C.c_int, _P, C.POINTER(_P)]),
+    "kmi_ctx_destroy": (C.c_int, [_P]),
+    "kmi_last_error": (C.c_char_p, [_P]),
+    "kmi_kmer_shape": (C.c_int, [_CFG, C.POINTER(_u32), C.POINTER(_u32), C.POINTER(_u32)]),
+    "kmi_free_host": (None, [_P]),
+    "kmi_device_alloc": (C.c_int, [_P, _sz, C.POINTER(_P)]),
+    "kmi_device_free": (C.c_int, [_P, _P]),
+    "kmi_copy_to_device": (C.c_int, [_P, _P, _P, _sz]),
+    "kmi_copy_to_host": (C.c_int, [_P, _P, _P, _sz]),
+    "kmi_synchronize": (C.c_int, [_P]),
+    "kmi_revcomp_host": (C.c_int, [_P, _CFG, _P, _sz, _P]),
+    "kmi_canonical_host": (C.c_int, [_P, _CFG, _P, _sz, _P]),
+    "kmi_hash_host": (C.c_int, [_P, _CFG, _u32, C.c_int, _P, _sz, _P]),
+    "kmi_key_to_rank_host": (C.c_int, [_P, _CFG, _P, _sz, _u32, _P]),
+    "kmi_extract_host": (C.c_int, [_P, _CFG, _P, _sz, _u64, C.POINTER(Tuples)]),
+    "kmi_tuples_free": (None, [C.POINTER(Tuples)]),
+    "kmi_extract_count_dev": (C.c_int, [_P, _CFG, _P, _sz, C.POINTER(_u64), C.POINTER(_u64)]),
+    "kmi_extract_dev": (C.c_int, [_P, _CFG, _P, _sz, _u64, _P, _P, _sz, C.POINTER(_u64), C.POINTER(_u64)]),
+    "kmi_route_dev": (C.c_int, [_P, _CFG, _P, _sz, _u32, _P, _P]),
+    "kmi_index_create": (C.c_int, [_P, _CFG, C.POINTER(_P)]),
+    "kmi_index_destroy": (C.c_int, [_P]),
+    "kmi_index_insert_host": (C.c_int, [_P, _P, _sz]),
+    "kmi_index_insert_dev": (C.c_int, [_P, _P, _sz]),
+    "kmi_index_build_host": (C.c_int, [_P, _P, _sz, _u64]),
+    "kmi_index_build_dev": (C.c_int, [_P, _P, _sz, _u64]),
+    "kmi_index_local_size": (C.c_int, [_P, C.POINTER(_u64)]),
+    "kmi_index_export_host": (C.c_int, [_P, _P, _P, _sz, C.POINTER(_u64)]),
+    "kmi_results_free": (None, [C.POINTER(Results)]),
+    "kmi_index_count_host": (C.c_int, [_P, _P, _sz, C.POINTER(Results)]),
+    "kmi_index_find_host": (C.c_int, [_P, _P, _sz, C.POINTER(Results)]),
+    "kmi_index_erase_host": (C.c_int, [_P, _P, _sz, C.POINTER(_u64)]),
+    "kmi_index_count_dev": (C.c_int, [_P, _P, _sz, _P, _P, C.POINTER(_u64)]),
+    "kmi_index_find_dev": (C.c_int, [_P, _P, _sz, _P, _P, C.POINTER(_u64)]),
+    "kmi_profile_enable": (C.c_int, [_P, C.c_int]),
+    "kmi_profile_reset": (C.c_int, [_P]),
+    "kmi_profile_get": (C.c_int, [_P, C.POINTER(KernelTime), _sz, C.POINTER(_sz)]),
+    "kmi_synth_fastq_bytes": (_sz, [_u64, _u32]),
+    "kmi_synth_fastq": (C.c_int, [_u64, _u64, _u32, _u64, _u64, _P, _sz, _u32]),
+}
+
+for _name, (_res, _args) in SIGNATURES.items():
+    _fn = getattr(lib, _name)   # AttributeError here = the library does not export a declared symbol
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+
+class KmiError(RuntimeError):
+    def __init__(self, status, msg):
+        super().__init__("kmerind_hip status %d: %s" % (status, msg))
+        self.status = status

@@ -1,0 +1,232 @@
+"""Host-side mirror of the reference's operator interface for the k-mer index path.
+
+Names follow the reference: CountIndex.insert / count / find / erase / size / local_size /
+build (bliss::index::kmer::Index, src/index/kmer_index.hpp:98-394) and
+KmerFileHelper.read_file (src/io/kmer_file_helper.hpp:550-633) -> Context.read_file."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _lib as L
+
+lib = L.lib
+
+
+def make_config(k, alphabet="DNA", strand="canonical", dist_hash="murmur", store_hash="murmur",
+                index_kind="count", seq_format="fastq", farm_ndebug=False):
+    alpha = {"DNA": L.ALPHA_DNA, "DNA5": L.ALPHA_DNA5, "DNA6": L.ALPHA_DNA5}[alphabet]
+    st = {"single": L.STRAND_SINGLE, "canonical": L.STRAND_CANONICAL, "bimolecule": L.STRAND_BIMOLECULE}[strand]
+    hs = {"murmur": L.HASH_MURMUR, "farm": L.HASH_FARM}
+    kind = {"count": L.INDEX_COUNT, "position": L.INDEX_POSITION, "posqual": L.INDEX_POSQUAL}[index_kind]
+    fmt = {"fastq": L.FMT_FASTQ, "fasta": L.FMT_FASTA}[seq_format]
+    return L.Config(k, alpha, st, hs[dist_hash], hs[store_hash], kind, fmt, int(bool(farm_ndebug)))
+
+
+def _u64(a, n_words=None):
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    if n_words is not None:
+        a = a.reshape(-1, n_words)
+    return a
+
+
+class Context:
+    """One GPU = one rank (stands where the reference takes an mxx::comm)."""
+
+    def __init__(self, device=0, rank=0, nranks=1, stream=None):
+        h = C.c_void_p()
+        st = lib.kmi_ctx_create(device, rank, nranks, C.c_void_p(stream or 0), C.byref(h))
+        if st != L.OK:
+            raise L.KmiError(st, "kmi_ctx_create failed (no usable HIP device? there is no CPU fallback)")
+        self.h = h
+        self.rank, self.nranks, self.device = rank, nranks, device
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib.kmi_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def check(self, st):
+        if st != L.OK:
+            raise L.KmiError(st, (lib.kmi_last_error(self.h) or b"").decode())
+
+    @staticmethod
+    def shape(cfg):
+        nw, nb, nby = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        if lib.kmi_kmer_shape(C.byref(cfg), C.byref(nw), C.byref(nb), C.byref(nby)) != L.OK:
+            raise ValueError("invalid k-mer configuration")
+        return nw.value, nb.value, nby.value
+
+    # ---- device memory helpers (raw pointers; bench.py may pass torch data_ptr() instead)
+    def alloc(self, nbytes):
+        p = C.c_void_p()
+        self.check(lib.kmi_device_alloc(self.h, nbytes, C.byref(p)))
+        return p.value
+
+    def free(self, dptr):
+        self.check(lib.kmi_device_free(self.h, C.c_void_p(dptr)))
+
+    def to_device(self, dptr, arr):
+        arr = np.ascontiguousarray(arr)
+        self.check(lib.kmi_copy_to_device(self.h, C.c_void_p(dptr), arr.ctypes.data_as(C.c_void_p), arr.nbytes))
+
+    def to_host(self, arr, dptr):
+        self.check(lib.kmi_copy_to_host(self.h, arr.ctypes.data_as(C.c_void_p), C.c_void_p(dptr), arr.nbytes))
+
+    def synchronize(self):
+        self.check(lib.kmi_synchronize(self.h))
+
+    # ---- array-level k-mer ops
+    def _array_op(self, fn, cfg, kmers, out_dtype, per_key, *extra):
+        nw = self.shape(cfg)[0]
+        kmers = _u64(kmers, nw)
+        n = kmers.shape[0]
+        out = np.zeros((n, nw) if per_key else n, dtype=out_dtype)
+        self.check(fn(self.h, C.byref(cfg), *extra[:2], kmers.ctypes.data_as(C.c_void_p), n, *extra[2:],
+                      out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def revcomp(self, cfg, kmers):
+        return self._array_op(lib.kmi_revcomp_host, cfg, kmers, np.uint64, True)
+
+    def canonical(self, cfg, kmers):
+        return self._array_op(lib.kmi_canonical_host, cfg, kmers, np.uint64, True)
+
+    def hash(self, cfg, which, prefix, kmers):
+        which = {"murmur": L.HASH_MURMUR, "farm": L.HASH_FARM}.get(which, which)
+        return self._array_op(lib.kmi_hash_host, cfg, kmers, np.uint64, False, which, int(prefix))
+
+    def key_to_rank(self, cfg, kmers, nranks):
+        nw = self.shape(cfg)[0]
+        kmers = _u64(kmers, nw)
+        out = np.zeros(kmers.shape[0], dtype=np.uint32)
+        self.check(lib.kmi_key_to_rank_host(self.h, C.byref(cfg), kmers.ctypes.data_as(C.c_void_p), kmers.shape[0],
+                                            nranks, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    # ---- KmerFileHelper::read_file_* equivalent on an in-memory, record-aligned partition
+    def read_file(self, cfg, data, file_offset=0):
+        """returns (kmers[n, n_words], n_seqs) in file order, as parsed (no strand transform)"""
+        buf = np.frombuffer(bytes(data), dtype=np.uint8) if isinstance(data, (bytes, bytearray)) else \
+            np.ascontiguousarray(data, dtype=np.uint8)
+        t = L.Tuples()
+        self.check(lib.kmi_extract_host(self.h, C.byref(cfg), buf.ctypes.data_as(C.c_void_p), buf.size, file_offset,
+                                        C.byref(t)))
+        nw = self.shape(cfg)[0]
+        n = t.n_tuples
+        kmers = np.ctypeslib.as_array(t.kmers, shape=(n * nw,)).copy().reshape(n, nw) if n else \
+            np.zeros((0, nw), dtype=np.uint64)
+        nseq = t.n_seqs
+        lib.kmi_tuples_free(C.byref(t))
+        return kmers, nseq
+
+    # ---- profiling
+    def profile(self, on=True):
+        self.check(lib.kmi_profile_enable(self.h, int(on)))
+
+    def profile_reset(self):
+        self.check(lib.kmi_profile_reset(self.h))
+
+    def profile_get(self):
+        arr = (L.KernelTime * 64)()
+        n = C.c_size_t()
+        self.check(lib.kmi_profile_get(self.h, arr, 64, C.byref(n)))
+        return [{"name": arr[i].name.decode(), "total_ms": arr[i].total_ms, "launches": arr[i].launches,
+                 "units": arr[i].units} for i in range(min(n.value, 64))]
+
+
+class CountIndex:
+    """bliss::index::kmer::CountIndex<counting map> on one rank (kmer_index.hpp:409-410)."""
+
+    def __init__(self, ctx, cfg):
+        self.ctx, self.cfg = ctx, cfg
+        self.n_words = ctx.shape(cfg)[0]
+        h = C.c_void_p()
+        ctx.check(lib.kmi_index_create(ctx.h, C.byref(cfg), C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib.kmi_index_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def insert(self, kmers):
+        kmers = _u64(kmers, self.n_words)
+        self.ctx.check(lib.kmi_index_insert_host(self.h, kmers.ctypes.data_as(C.c_void_p), kmers.shape[0]))
+
+    def insert_device(self, dptr, n):
+        self.ctx.check(lib.kmi_index_insert_dev(self.h, C.c_void_p(dptr), n))
+
+    def build(self, data, file_offset=0):
+        buf = np.frombuffer(bytes(data), dtype=np.uint8) if isinstance(data, (bytes, bytearray)) else \
+            np.ascontiguousarray(data, dtype=np.uint8)
+        self.ctx.check(lib.kmi_index_build_host(self.h, buf.ctypes.data_as(C.c_void_p), buf.size, file_offset))
+
+    def build_device(self, dptr, nbytes, file_offset=0):
+        self.ctx.check(lib.kmi_index_build_dev(self.h, C.c_void_p(dptr), nbytes, file_offset))
+
+    def local_size(self):
+        n = C.c_uint64()
+        self.ctx.check(lib.kmi_index_local_size(self.h, C.byref(n)))
+        return n.value
+
+    size = local_size  # single-rank view; kmerind_amd.dist adds the all-reduce
+
+    def to_vector(self):
+        n = self.local_size()
+        keys = np.zeros((n, self.n_words), dtype=np.uint64)
+        counts = np.zeros(n, dtype=np.uint32)
+        got = C.c_uint64()
+        self.ctx.check(lib.kmi_index_export_host(self.h, keys.ctypes.data_as(C.c_void_p),
+                                                 counts.ctypes.data_as(C.c_void_p), n, C.byref(got)))
+        return keys[:got.value], counts[:got.value]
+
+    def _query(self, fn, q):
+        q = _u64(q, self.n_words)
+        r = L.Results()
+        self.ctx.check(fn(self.h, q.ctypes.data_as(C.c_void_p), q.shape[0], C.byref(r)))
+        n = r.n
+        if n:
+            keys = np.ctypeslib.as_array(r.keys, shape=(n * self.n_words,)).copy().reshape(n, self.n_words)
+            vals = np.ctypeslib.as_array(r.values, shape=(n,)).copy()
+        else:
+            keys = np.zeros((0, self.n_words), dtype=np.uint64)
+            vals = np.zeros(0, dtype=np.uint64)
+        lib.kmi_results_free(C.byref(r))
+        return keys, vals
+
+    def count(self, q):
+        return self._query(lib.kmi_index_count_host, q)
+
+    def find(self, q):
+        return self._query(lib.kmi_index_find_host, q)
+
+    def erase(self, q):
+        q = _u64(q, self.n_words)
+        n = C.c_uint64()
+        self.ctx.check(lib.kmi_index_erase_host(self.h, q.ctypes.data_as(C.c_void_p), q.shape[0], C.byref(n)))
+        return n.value
+
+
+def synth_fastq(seed, genome_len, n_reads, read_len=150, first_read=0, threads=None):
+    """SURVEY.md 8(d) synthetic FASTQ as a numpy uint8 array (host)."""
+    nbytes = lib.kmi_synth_fastq_bytes(n_reads, read_len)
+    out = np.empty(nbytes, dtype=np.uint8)
+    threads = threads or min(16, os.cpu_count() or 1)
+    st = lib.kmi_synth_fastq(seed, genome_len, read_len, first_read, n_reads, out.ctypes.data_as(C.c_void_p), nbytes,
+                             threads)
+    if st != L.OK:
+        raise ValueError("kmi_synth_fastq: bad arguments")
+    return out

@@ -1,0 +1,304 @@
+// kmi_api.hip -- C ABI: context, memory, profiling, array-level k-mer ops, extract entry points
+#include <stdlib.h>
+
+#include <algorithm>
+
+#include "kmi_block.h"
+#include "kmi_internal.h"
+
+namespace kmi {
+
+// ---------------------------------------------------------------------------
+// workspace + profiling
+// ---------------------------------------------------------------------------
+kmi_status ws_get(kmi_ctx *ctx, WsSlot slot, size_t bytes, void **out) {
+  kmi_ctx::Buf &b = ctx->ws[slot];
+  if (bytes == 0) bytes = 256;
+  if (b.cap < bytes) {
+    if (b.p) { KMI_HIP(ctx, hipStreamSynchronize(ctx->stream)); KMI_HIP(ctx, hipFree(b.p)); b.p = nullptr; b.cap = 0; }
+    size_t cap = bytes + bytes / 16 + 4096;
+    hipError_t e = hipMalloc(&b.p, cap);
+    if (e != hipSuccess) { b.p = nullptr; return set_err(ctx, KMI_ERR_NOMEM, "hipMalloc failed: %s", hipGetErrorString(e)); }
+    b.cap = cap;
+  }
+  *out = b.p;
+  return KMI_OK;
+}
+
+void ws_release(kmi_ctx *ctx, WsSlot slot) {
+  kmi_ctx::Buf &b = ctx->ws[slot];
+  if (b.p) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(b.p); b.p = nullptr; b.cap = 0; }
+}
+
+static hipEvent_t get_event(kmi_ctx *ctx) {
+  if (!ctx->event_pool.empty()) { hipEvent_t e = ctx->event_pool.back(); ctx->event_pool.pop_back(); return e; }
+  hipEvent_t e; (void)hipEventCreate(&e); return e;
+}
+
+void prof_begin(kmi_ctx *ctx, const char *name, uint64_t units) {
+  ProfRec r; r.name = name; r.units = units; r.e0 = get_event(ctx); r.e1 = get_event(ctx);
+  (void)hipEventRecord(r.e0, ctx->stream);
+  ctx->prof_pending.push_back(r);
+}
+
+void prof_end(kmi_ctx *ctx) { (void)hipEventRecord(ctx->prof_pending.back().e1, ctx->stream); }
+
+static void prof_flush(kmi_ctx *ctx) {
+  if (ctx->prof_pending.empty()) return;
+  (void)hipStreamSynchronize(ctx->stream);
+  for (ProfRec &r : ctx->prof_pending) {
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, r.e0, r.e1);
+    bool found = false;
+    for (ProfAgg &a : ctx->prof_agg)
+      if (strcmp(a.name, r.name) == 0) { a.total_ms += ms; a.launches += 1; a.units += r.units; found = true; break; }
+    if (!found) ctx->prof_agg.push_back(ProfAgg{r.name, (double)ms, 1, r.units});
+    ctx->event_pool.push_back(r.e0); ctx->event_pool.push_back(r.e1);
+  }
+  ctx->prof_pending.clear();
+}
+
+// ---------------------------------------------------------------------------
+// array-level k-mer ops (parity surface)
+// ---------------------------------------------------------------------------
+enum ArrayOp { OP_REVCOMP = 0, OP_CANONICAL = 1, OP_HASH = 2, OP_RANK = 3 };
+
+template <int NW, int BITS>
+__global__ __launch_bounds__(256) void kmer_array_op_kernel(const uint64_t *__restrict__ in, uint64_t n, KShape shape, int op,
+                                                            uint32_t which, bool prefix, bool farm_ndebug, uint32_t strand,
+                                                            uint32_t nranks, uint64_t *__restrict__ out64,
+                                                            uint32_t *__restrict__ out32) {
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    uint64_t k[NW], r[NW];
+#pragma unroll
+    for (int w = 0; w < NW; ++w) k[w] = in[i * NW + w];
+    if (op == OP_REVCOMP) {
+      revcomp_words<NW, BITS>(k, r, shape);
+#pragma unroll
+      for (int w = 0; w < NW; ++w) out64[i * NW + w] = r[w];
+    } else if (op == OP_CANONICAL) {
+      canonical_words<NW, BITS>(k, r, shape);
+#pragma unroll
+      for (int w = 0; w < NW; ++w) out64[i * NW + w] = r[w];
+    } else if (op == OP_HASH) {
+      out64[i] = kmer_hash<NW>(k, shape, which, prefix, farm_ndebug);
+    } else {
+      // KeyToRank: DistHash(DistTrans(k)) % p ; DistTrans = lex_less only for bimolecule
+      if (strand == KMI_STRAND_BIMOLECULE) { canonical_words<NW, BITS>(k, r, shape);
+#pragma unroll
+        for (int w = 0; w < NW; ++w) k[w] = r[w]; }
+      out32[i] = (uint32_t)(kmer_hash<NW>(k, shape, which, true, farm_ndebug) % nranks);
+    }
+  }
+}
+
+template <int NW, int BITS>
+static kmi_status array_op_impl(kmi_ctx *ctx, const kmi_config *cfg, KShape shape, int op, uint32_t which, bool prefix,
+                                uint32_t nranks, const uint64_t *in_dev, size_t n, uint64_t *out64, uint32_t *out32) {
+  unsigned grid = (unsigned)std::min<size_t>((n + 255) / 256, 2048);
+  if (grid == 0) return KMI_OK;
+  ProfScope ps(ctx, "kmer_array_op", n);
+  hipLaunchKernelGGL((kmer_array_op_kernel<NW, BITS>), dim3(grid), dim3(256), 0, ctx->stream, in_dev, (uint64_t)n, shape, op,
+                     which, prefix, cfg->farm_ndebug != 0, cfg->strand, nranks, out64, out32);
+  KMI_HIP(ctx, hipGetLastError());
+  return KMI_OK;
+}
+
+static kmi_status array_op_dev(kmi_ctx *ctx, const kmi_config *cfg, int op, uint32_t which, bool prefix, uint32_t nranks,
+                               const uint64_t *in_dev, size_t n, uint64_t *out64, uint32_t *out32) {
+  KShape shape;
+  if (!valid_config(cfg, &shape)) return set_err(ctx, KMI_ERR_INVALID, "bad kmi_config");
+  KMI_DISPATCH(shape, array_op_impl, ctx, cfg, shape, op, which, prefix, nranks, in_dev, n, out64, out32);
+}
+
+static kmi_status array_op_host(kmi_ctx *ctx, const kmi_config *cfg, int op, uint32_t which, bool prefix, uint32_t nranks,
+                                const uint64_t *in, size_t n, void *out) {
+  if (!ctx) return KMI_ERR_INVALID;
+  KShape shape;
+  if (!valid_config(cfg, &shape)) return set_err(ctx, KMI_ERR_INVALID, "bad kmi_config");
+  if (n == 0) return KMI_OK;
+  if (!in || !out) return set_err(ctx, KMI_ERR_INVALID, "null buffer");
+  if (op == OP_RANK && nranks == 0) return set_err(ctx, KMI_ERR_INVALID, "nranks must be > 0");
+  KMI_HIP(ctx, hipSetDevice(ctx->device));
+  const size_t in_bytes = n * shape.n_words * sizeof(uint64_t);
+  const size_t out_bytes = (op == OP_RANK) ? n * sizeof(uint32_t) : (op == OP_HASH ? n * sizeof(uint64_t) : in_bytes);
+  void *din, *dout;
+  KMI_TRY(ws_get(ctx, WS_INPUT, in_bytes, &din));
+  KMI_TRY(ws_get(ctx, WS_OUTPUT, out_bytes, &dout));
+  KMI_HIP(ctx, hipMemcpyAsync(din, in, in_bytes, hipMemcpyHostToDevice, ctx->stream));
+  KMI_TRY(array_op_dev(ctx, cfg, op, which, prefix, nranks, (const uint64_t *)din, n, (uint64_t *)dout, (uint32_t *)dout));
+  KMI_HIP(ctx, hipMemcpyAsync(out, dout, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+  KMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return KMI_OK;
+}
+
+}  // namespace kmi
+
+using namespace kmi;
+
+extern "C" {
+
+kmi_status kmi_ctx_create(int device, int rank, int nranks, void *stream, kmi_ctx **out) {
+  if (!out || nranks <= 0 || rank < 0 || rank >= nranks) return KMI_ERR_INVALID;
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return KMI_ERR_DEVICE;
+  if (hipSetDevice(device) != hipSuccess) return KMI_ERR_DEVICE;
+  kmi_ctx *ctx = new kmi_ctx();
+  ctx->device = device; ctx->rank = rank; ctx->nranks = nranks; ctx->stream = (hipStream_t)stream;
+  if (hipMalloc((void **)&ctx->d_flags, sizeof(uint32_t) * 16) != hipSuccess ||
+      hipMalloc((void **)&ctx->d_totals, sizeof(uint64_t) * 16) != hipSuccess ||
+      hipHostMalloc((void **)&ctx->h_totals, sizeof(uint64_t) * 16, hipHostMallocDefault) != hipSuccess) {
+    delete ctx;
+    return KMI_ERR_DEVICE;
+  }
+  (void)hipMemset(ctx->d_flags, 0, sizeof(uint32_t) * 16);
+  (void)hipMemset(ctx->d_totals, 0, sizeof(uint64_t) * 16);
+  *out = ctx;
+  return KMI_OK;
+}
+
+kmi_status kmi_ctx_destroy(kmi_ctx *ctx) {
+  if (!ctx) return KMI_OK;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  for (int s = 0; s < WS_NUM_SLOTS; ++s) if (ctx->ws[s].p) (void)hipFree(ctx->ws[s].p);
+  for (ProfRec &r : ctx->prof_pending) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+  for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
+  if (ctx->d_flags) (void)hipFree(ctx->d_flags);
+  if (ctx->d_totals) (void)hipFree(ctx->d_totals);
+  if (ctx->h_totals) (void)hipHostFree(ctx->h_totals);
+  delete ctx;
+  return KMI_OK;
+}
+
+const char *kmi_last_error(const kmi_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+kmi_status kmi_kmer_shape(const kmi_config *cfg, uint32_t *n_words, uint32_t *n_bits, uint32_t *n_bytes) {
+  KShape s;
+  if (!valid_config(cfg, &s)) return KMI_ERR_INVALID;
+  if (n_words) *n_words = s.n_words;
+  if (n_bits) *n_bits = s.n_bits;
+  if (n_bytes) *n_bytes = s.n_bytes;
+  return KMI_OK;
+}
+
+void kmi_free_host(void *p) { free(p); }
+
+kmi_status kmi_device_alloc(kmi_ctx *ctx, size_t bytes, void **dptr) {
+  if (!ctx || !dptr) return KMI_ERR_INVALID;
+  KMI_HIP(ctx, hipSetDevice(ctx->device));
+  hipError_t e = hipMalloc(dptr, bytes ? bytes : 256);
+  if (e != hipSuccess) return set_err(ctx, KMI_ERR_NOMEM, "hipMalloc failed: %s", hipGetErrorString(e));
+  return KMI_OK;
+}
+
+kmi_status kmi_device_free(kmi_ctx *ctx, void *dptr) {
+  if (!ctx) return KMI_ERR_INVALID;
+  if (dptr) { KMI_HIP(ctx, hipStreamSynchronize(ctx->stream)); KMI_HIP(ctx, hipFree(dptr)); }
+  return KMI_OK;
+}
+
+kmi_status kmi_copy_to_device(kmi_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes) {
+  if (!ctx) return KMI_ERR_INVALID;
+  KMI_HIP(ctx, hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, ctx->stream));
+  KMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return KMI_OK;
+}
+
+kmi_status kmi_copy_to_host(kmi_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes) {
+  if (!ctx) return KMI_ERR_INVALID;
+  KMI_HIP(ctx, hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  KMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return KMI_OK;
+}
+
+kmi_status kmi_synchronize(kmi_ctx *ctx) {
+  if (!ctx) return KMI_ERR_INVALID;
+  KMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return KMI_OK;
+}
+
+kmi_status kmi_revcomp_host(kmi_ctx *ctx, const kmi_config *cfg, const uint64_t *in, size_t n, uint64_t *out) {
+  return array_op_host(ctx, cfg, OP_REVCOMP, 0, false, 1, in, n, out);
+}
+kmi_status kmi_canonical_host(kmi_ctx *ctx, const kmi_config *cfg, const uint64_t *in, size_t n, uint64_t *out) {
+  return array_op_host(ctx, cfg, OP_CANONICAL, 0, false, 1, in, n, out);
+}
+kmi_status kmi_hash_host(kmi_ctx *ctx, const kmi_config *cfg, uint32_t which, int prefix, const uint64_t *in, size_t n,
+                         uint64_t *out) {
+  if (which > 1) return set_err(ctx, KMI_ERR_INVALID, "unknown hash");
+  return array_op_host(ctx, cfg, OP_HASH, which, prefix != 0, 1, in, n, out);
+}
+kmi_status kmi_key_to_rank_host(kmi_ctx *ctx, const kmi_config *cfg, const uint64_t *in, size_t n, uint32_t nranks,
+                                uint32_t *ranks) {
+  if (!cfg) return KMI_ERR_INVALID;
+  return array_op_host(ctx, cfg, OP_RANK, cfg->dist_hash, true, nranks, in, n, ranks);
+}
+
+// ---- extract
+kmi_status kmi_extract_count_dev(kmi_ctx *ctx, const kmi_config *cfg, const uint8_t *bytes_dev, size_t n_bytes,
+                                 uint64_t *n_tuples, uint64_t *n_seqs) {
+  if (!ctx) return KMI_ERR_INVALID;
+  KMI_HIP(ctx, hipSetDevice(ctx->device));
+  return extract_count(ctx, cfg, bytes_dev, n_bytes, n_tuples, n_seqs);
+}
+
+kmi_status kmi_extract_dev(kmi_ctx *ctx, const kmi_config *cfg, const uint8_t *bytes_dev, size_t n_bytes,
+                           uint64_t file_offset, uint64_t *out_kmers_dev, uint64_t *out_ids_dev, size_t out_capacity,
+                           uint64_t *n_tuples, uint64_t *n_seqs) {
+  if (!ctx) return KMI_ERR_INVALID;
+  KMI_HIP(ctx, hipSetDevice(ctx->device));
+  return extract_run(ctx, cfg, bytes_dev, n_bytes, file_offset, out_kmers_dev, out_ids_dev, out_capacity, false, n_tuples,
+                     n_seqs);
+}
+
+kmi_status kmi_extract_host(kmi_ctx *ctx, const kmi_config *cfg, const uint8_t *bytes, size_t n_bytes, uint64_t file_offset,
+                            kmi_tuples *out) {
+  if (!ctx || !out) return KMI_ERR_INVALID;
+  memset(out, 0, sizeof(*out));
+  KShape shape;
+  if (!valid_config(cfg, &shape)) return set_err(ctx, KMI_ERR_INVALID, "bad kmi_config");
+  if (n_bytes == 0) return KMI_OK;
+  if (!bytes) return set_err(ctx, KMI_ERR_INVALID, "null buffer");
+  KMI_HIP(ctx, hipSetDevice(ctx->device));
+  void *din;
+  KMI_TRY(ws_get(ctx, WS_INPUT, n_bytes + 64, &din));
+  KMI_HIP(ctx, hipMemcpyAsync(din, bytes, n_bytes, hipMemcpyHostToDevice, ctx->stream));
+  uint64_t nt = 0, ns = 0;
+  KMI_TRY(extract_count(ctx, cfg, (const uint8_t *)din, n_bytes, &nt, &ns));
+  void *dout;
+  const size_t out_bytes = (size_t)nt * shape.n_words * sizeof(uint64_t);
+  KMI_TRY(ws_get(ctx, WS_OUTPUT, out_bytes, &dout));
+  KMI_TRY(extract_run(ctx, cfg, (const uint8_t *)din, n_bytes, file_offset, (uint64_t *)dout, nullptr, (size_t)nt, false, &nt,
+                      &ns));
+  out->n_tuples = nt; out->n_seqs = ns;
+  out->kmers = (uint64_t *)malloc(out_bytes ? out_bytes : 8);
+  if (!out->kmers) return set_err(ctx, KMI_ERR_NOMEM, "host malloc failed");
+  if (out_bytes) KMI_HIP(ctx, hipMemcpyAsync(out->kmers, dout, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+  KMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return KMI_OK;
+}
+
+void kmi_tuples_free(kmi_tuples *t) {
+  if (!t) return;
+  free(t->kmers); free(t->ids); free(t->quals);
+  memset(t, 0, sizeof(*t));
+}
+
+// ---- profiling
+kmi_status kmi_profile_enable(kmi_ctx *ctx, int on) { if (!ctx) return KMI_ERR_INVALID; prof_flush(ctx); ctx->prof = on != 0; return KMI_OK; }
+kmi_status kmi_profile_reset(kmi_ctx *ctx) { if (!ctx) return KMI_ERR_INVALID; prof_flush(ctx); ctx->prof_agg.clear(); return KMI_OK; }
+kmi_status kmi_profile_get(kmi_ctx *ctx, kmi_kernel_time *out, size_t cap, size_t *n) {
+  if (!ctx || !n) return KMI_ERR_INVALID;
+  prof_flush(ctx);
+  size_t m = std::min(cap, ctx->prof_agg.size());
+  for (size_t i = 0; i < m; ++i) {
+    out[i].name = ctx->prof_agg[i].name; out[i].total_ms = ctx->prof_agg[i].total_ms;
+    out[i].launches = ctx->prof_agg[i].launches; out[i].units = ctx->prof_agg[i].units;
+  }
+  *n = ctx->prof_agg.size();
+  return KMI_OK;
+}
+
+}  // extern "C"

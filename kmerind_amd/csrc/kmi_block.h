@@ -1,0 +1,51 @@
+// kmi_block.h -- workgroup-level primitives for 64-wide wavefronts (gfx950).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace kmi {
+
+constexpr int kWave = 64;
+
+__device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & (kWave - 1); }
+__device__ __forceinline__ uint32_t wave_id() { return threadIdx.x >> 6; }
+
+// inclusive scan across the 64 lanes of a wavefront
+template <typename T> __device__ __forceinline__ T wave_inclusive_scan(T v) {
+#pragma unroll
+  for (int d = 1; d < kWave; d <<= 1) {
+    T o = __shfl_up(v, d, kWave);
+    if ((int)lane_id() >= d) v += o;
+  }
+  return v;
+}
+
+template <typename T> __device__ __forceinline__ T wave_reduce_sum(T v) {
+#pragma unroll
+  for (int d = kWave / 2; d > 0; d >>= 1) v += __shfl_xor(v, d, kWave);
+  return v;
+}
+
+// Exclusive scan of one value per thread over the whole workgroup.
+// `scratch` must hold (blockDim.x/64 + 1) elements of T in LDS. Returns the exclusive
+// prefix of this thread; *total receives the workgroup sum. Contains two barriers and
+// may be called repeatedly with the same scratch (a trailing barrier protects reuse).
+template <typename T> __device__ __forceinline__ T block_exclusive_scan(T v, T *scratch, T *total) {
+  const uint32_t nw = blockDim.x >> 6;
+  T inc = wave_inclusive_scan(v);
+  if (lane_id() == kWave - 1) scratch[wave_id()] = inc;
+  __syncthreads();
+  if (wave_id() == 0) {
+    T w = (lane_id() < nw) ? scratch[lane_id()] : T(0);
+    T winc = wave_inclusive_scan(w);
+    if (lane_id() < nw) scratch[lane_id()] = winc - w;   // exclusive prefix of each wave
+    if (lane_id() == nw - 1) scratch[nw] = winc;          // total
+  }
+  __syncthreads();
+  T res = scratch[wave_id()] + inc - v;
+  if (total) *total = scratch[nw];
+  __syncthreads();
+  return res;
+}
+
+}  // namespace kmi

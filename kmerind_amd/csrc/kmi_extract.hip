@@ -1,0 +1,410 @@
+// kmi_extract.hip -- FASTQ bytes -> k-mer tuples on the device.
+//
+// Replaces the reference's per-read iterator stack
+//   SequencesIterator (src/io/sequence_iterator.hpp:96-300)
+//     -> FASTQParser::get_next_record (src/io/fastq_loader.hpp:389-467)
+//     -> KmerParser / KmerCountTupleParser::operator() (src/io/kmer_parser.hpp:85-294,909-1083)
+//     -> KmerGenerationIterator / Kmer::nextFromChar (src/common/kmer_iterators.hpp:67-116,
+//        src/common/kmer.hpp:731-741)
+// driven by KmerFileHelper::read_block_old (src/io/kmer_file_helper.hpp:110-186).
+//
+// Formulation (MI355X-first, no per-read sequential walk):
+//   * A "line" is a maximal run of non-EOL bytes; FASTQ gives line index % 4 the role
+//     (0 '@' header, 1 sequence, 2 '+', 3 quality) because get_next_record always consumes
+//     4 lines and skips any number of EOLs between them.
+//   * pass 1 (scan_tiles): every tile counts its line starts and, for each of the 4 possible
+//     role phases, how many k-windows without an EOL start in it.
+//   * pass 2 (scan over tiles, one workgroup): line base and output offset per tile.
+//   * pass 3 (extract): the tile's bytes become a packed stream of COMPLEMENT codes in LDS
+//     (2 or 3 bits per base). A little-endian k-window over that stream is the reverse
+//     complement k-mer; the forward k-mer is its bit/group reversal (v_bfrev). Valid windows
+//     are ranked with a workgroup scan, staged in LDS in file order and written out with
+//     fully coalesced stores.
+// Every thread owns C consecutive bytes (16 for one-word k-mers): one 16-byte global load,
+// all later indexing is compile-time so nothing spills.
+#include "kmi_block.h"
+#include "kmi_internal.h"
+
+namespace kmi {
+
+template <int NW, int BITS> struct ExCfg {
+  static constexpr int C = (NW == 1) ? 16 : 8;                 // bytes per thread
+  static constexpr int NT = (NW <= 2) ? 512 : 256;             // threads per workgroup
+  static constexpr int TILE = NT * C;                          // bytes per tile
+  static constexpr int KMAX = 64 * NW / BITS;                  // largest k for this word count
+  static constexpr int HALO_CHUNKS = (KMAX - 1 + C - 1) / C;
+  static constexpr int CHUNKS = NT + HALO_CHUNKS;
+  static constexpr int NE = (C - 1 + KMAX + 63) / 64;          // eol words per thread (normalised)
+  static constexpr int E_RAW = 2 * NE + 1;                     // raw eol dwords per thread
+  static constexpr int NR = (BITS * (C - 1) + 64 * NW + 31) / 32 + 1;  // normalised stream dwords
+  static constexpr int S_RAW = NR + 1;
+  static constexpr int EOL_DW = (CHUNKS * C + 31) / 32 + E_RAW + 1;
+  static constexpr int STREAM_DW = (CHUNKS * C * BITS + 31) / 32 + S_RAW + 1;
+  static constexpr uint32_t CMASK = (1u << C) - 1u;
+};
+
+struct TileInfo {
+  uint32_t lines;     // line starts in the tile
+  uint32_t win[4];    // EOL-free k-windows starting in the tile, by (local line count & 3)
+};
+
+// ---- chunk load: C bytes at byte offset g (zero-filled past n_bytes); returns #valid bytes
+template <int C> __device__ __forceinline__ int load_chunk(const uint8_t *__restrict__ bytes, uint64_t n_bytes, uint64_t g,
+                                                          uint32_t (&dw)[C / 4]) {
+  if (g + C <= n_bytes) {
+    if constexpr (C == 16) {
+      uint4 v = *reinterpret_cast<const uint4 *>(bytes + g);
+      dw[0] = v.x; dw[1] = v.y; dw[2] = v.z; dw[3] = v.w;
+    } else {
+      uint2 v = *reinterpret_cast<const uint2 *>(bytes + g);
+      dw[0] = v.x; dw[1] = v.y;
+    }
+    return C;
+  }
+#pragma unroll
+  for (int i = 0; i < C / 4; ++i) dw[i] = 0;
+  int n = (g < n_bytes) ? (int)(n_bytes - g) : 0;
+  for (int i = 0; i < n; ++i) dw[i >> 2] |= (uint32_t)bytes[g + i] << (8 * (i & 3));
+  return n;
+}
+
+template <int C> __device__ __forceinline__ void store_eol_bits(uint32_t *s_eol, int chunk, uint32_t eol) {
+  if constexpr (C == 16) reinterpret_cast<uint16_t *>(s_eol)[chunk] = (uint16_t)eol;
+  else reinterpret_cast<uint8_t *>(s_eol)[chunk] = (uint8_t)eol;
+}
+
+template <int BITS, int C> __device__ __forceinline__ void store_stream_bits(uint32_t *s_stream, int chunk, uint64_t st) {
+  constexpr int NB = BITS * C / 8;  // bytes per chunk: 4, 6, 2 or 3
+  if constexpr (NB == 4) {
+    s_stream[chunk] = (uint32_t)st;
+  } else if constexpr (NB == 2) {
+    reinterpret_cast<uint16_t *>(s_stream)[chunk] = (uint16_t)st;
+  } else if constexpr (NB == 6) {
+    uint16_t *p = reinterpret_cast<uint16_t *>(s_stream) + 3 * chunk;
+    p[0] = (uint16_t)st; p[1] = (uint16_t)(st >> 16); p[2] = (uint16_t)(st >> 32);
+  } else {
+    uint8_t *p = reinterpret_cast<uint8_t *>(s_stream) + NB * chunk;
+#pragma unroll
+    for (int i = 0; i < NB; ++i) p[i] = (uint8_t)(st >> (8 * i));
+  }
+}
+
+// per-thread view of the EOL bit array: bits [C*j, C*j + C-1+KMAX) normalised to bit 0
+template <int NW, int BITS> __device__ __forceinline__ void load_eol_view(const uint32_t *s_eol, int j,
+                                                                         uint64_t (&e)[ExCfg<NW, BITS>::NE]) {
+  using Cfg = ExCfg<NW, BITS>;
+  const int bit0 = Cfg::C * j, d0 = bit0 >> 5, sh = bit0 & 31;
+  uint32_t raw[Cfg::E_RAW];
+#pragma unroll
+  for (int i = 0; i < Cfg::E_RAW; ++i) raw[i] = s_eol[d0 + i];
+#pragma unroll
+  for (int w = 0; w < Cfg::NE; ++w) {
+    uint32_t lo = sh ? ((raw[2 * w] >> sh) | (raw[2 * w + 1] << (32 - sh))) : raw[2 * w];
+    uint32_t hi = sh ? ((raw[2 * w + 1] >> sh) | (raw[2 * w + 2] << (32 - sh))) : raw[2 * w + 1];
+    e[w] = ((uint64_t)hi << 32) | lo;
+  }
+}
+
+template <int NW, int BITS> __device__ __forceinline__ void load_stream_view(const uint32_t *s_stream, int j,
+                                                                            uint32_t (&r)[ExCfg<NW, BITS>::NR]) {
+  using Cfg = ExCfg<NW, BITS>;
+  const int bit0 = Cfg::C * BITS * j, d0 = bit0 >> 5, sh = bit0 & 31;
+  uint32_t raw[Cfg::S_RAW];
+#pragma unroll
+  for (int i = 0; i < Cfg::S_RAW; ++i) raw[i] = s_stream[d0 + i];
+#pragma unroll
+  for (int i = 0; i < Cfg::NR; ++i) r[i] = sh ? ((raw[i] >> sh) | (raw[i + 1] << (32 - sh))) : raw[i];
+}
+
+// common front end of passes 1 and 3: classify own chunk (+ halo chunk), publish the EOL bits
+// (and optionally the stream), derive line starts and the block-exclusive line count.
+template <int NW, int BITS, bool WITH_STREAM>
+__device__ __forceinline__ void tile_front(const uint8_t *__restrict__ bytes, uint64_t n_bytes, uint64_t tile0,
+                                           uint32_t *s_eol, uint32_t *s_stream, uint32_t *s_scan,
+                                           uint32_t (&dw)[ExCfg<NW, BITS>::C / 4], uint32_t &eol, uint32_t &ls,
+                                           uint32_t &lines_before_local, uint32_t &lines_total) {
+  using Cfg = ExCfg<NW, BITS>;
+  constexpr int C = Cfg::C;
+  const int j = threadIdx.x;
+  uint64_t st;
+  int nv = load_chunk<C>(bytes, n_bytes, tile0 + (uint64_t)j * C, dw);
+  classify_chunk<BITS, C>(dw, nv, eol, st);
+  store_eol_bits<C>(s_eol, j, eol);
+  if (WITH_STREAM) store_stream_bits<BITS, C>(s_stream, j, st);
+  if (j < Cfg::HALO_CHUNKS) {
+    uint32_t hdw[C / 4]; uint32_t he; uint64_t hs;
+    int hnv = load_chunk<C>(bytes, n_bytes, tile0 + (uint64_t)(Cfg::NT + j) * C, hdw);
+    classify_chunk<BITS, C>(hdw, hnv, he, hs);
+    store_eol_bits<C>(s_eol, Cfg::NT + j, he);
+    if (WITH_STREAM) store_stream_bits<BITS, C>(s_stream, Cfg::NT + j, hs);
+  }
+  __syncthreads();
+  bool prev_eol;
+  if (j > 0) {
+    const int pb = C * j - 1;
+    prev_eol = (s_eol[pb >> 5] >> (pb & 31)) & 1u;
+  } else {
+    // the partition starts at a record start: treat the byte before it as EOL
+    prev_eol = (tile0 == 0) ? true : is_eol(bytes[tile0 - 1]);
+  }
+  ls = line_starts(eol, prev_eol, Cfg::CMASK);
+  lines_before_local = block_exclusive_scan<uint32_t>((uint32_t)__builtin_popcount(ls), s_scan, &lines_total);
+}
+
+// ---------------------------------------------------------------------------
+// pass 1
+// ---------------------------------------------------------------------------
+template <int NW, int BITS>
+__global__ __launch_bounds__((ExCfg<NW, BITS>::NT)) void fastq_scan_tiles_kernel(const uint8_t *__restrict__ bytes,
+                                                                               uint64_t n_bytes, uint32_t k,
+                                                                               TileInfo *__restrict__ info) {
+  using Cfg = ExCfg<NW, BITS>;
+  __shared__ uint32_t s_eol[Cfg::EOL_DW];
+  __shared__ uint32_t s_scan[Cfg::NT / 64 + 2];
+  __shared__ uint32_t s_cnt[2];
+  const uint64_t tile0 = (uint64_t)blockIdx.x * Cfg::TILE;
+  if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
+  uint32_t dw[Cfg::C / 4], eol, ls, lbl, ltot;
+  tile_front<NW, BITS, false>(bytes, n_bytes, tile0, s_eol, nullptr, s_scan, dw, eol, ls, lbl, ltot);
+
+  uint64_t e[Cfg::NE];
+  load_eol_view<NW, BITS>(s_eol, threadIdx.x, e);
+  smear_right<Cfg::NE>(e, k);
+  const uint32_t cand = ~(uint32_t)e[0] & Cfg::CMASK;
+
+  // windows by local phase: 16-bit fields (phase 0,1) and (phase 2,3)
+  uint32_t lo = 0, hi = 0;
+  {
+    uint32_t cur = lbl, start = 0, rest = ls;
+    while (true) {
+      uint32_t q = rest ? (uint32_t)__builtin_ctz(rest) : (uint32_t)Cfg::C;
+      uint32_t seg = (q >= 32 ? ~0u : ((1u << q) - 1u)) & ~((1u << start) - 1u) & Cfg::CMASK;
+      uint32_t c = (uint32_t)__builtin_popcount(cand & seg);
+      uint32_t ph = cur & 3u;
+      if (ph < 2) lo += c << (16 * ph); else hi += c << (16 * (ph - 2));
+      if (!rest) break;
+      cur += 1; start = q; rest &= rest - 1u;
+    }
+  }
+  lo = wave_reduce_sum(lo); hi = wave_reduce_sum(hi);
+  if (lane_id() == 0) { atomicAdd(&s_cnt[0], lo); atomicAdd(&s_cnt[1], hi); }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    TileInfo ti;
+    ti.lines = ltot;
+    ti.win[0] = s_cnt[0] & 0xffffu; ti.win[1] = s_cnt[0] >> 16;
+    ti.win[2] = s_cnt[1] & 0xffffu; ti.win[3] = s_cnt[1] >> 16;
+    info[blockIdx.x] = ti;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// pass 2: one workgroup scans the tile records
+// totals[0] = lines, totals[1] = tuples, totals[2] = sequences (lines with index % 4 == 1)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void fastq_scan_offsets_kernel(const TileInfo *__restrict__ info, uint64_t n_tiles,
+                                                                 uint32_t *__restrict__ line_base,
+                                                                 uint64_t *__restrict__ out_off,
+                                                                 uint64_t *__restrict__ totals) {
+  __shared__ uint64_t s_scan[1024 / 64 + 2];
+  const uint64_t per = (n_tiles + 1023) / 1024;
+  const uint64_t t0 = (uint64_t)threadIdx.x * per;
+  const uint64_t t1 = (t0 + per < n_tiles) ? t0 + per : n_tiles;
+  uint64_t lines = 0;
+  for (uint64_t t = t0; t < t1; ++t) lines += info[t].lines;
+  uint64_t total_lines;
+  uint64_t lb = block_exclusive_scan<uint64_t>(lines, s_scan, &total_lines);
+  uint64_t cnt = 0, l = lb;
+  for (uint64_t t = t0; t < t1; ++t) {
+    line_base[t] = (uint32_t)(l & 0xffffffffu);
+    cnt += info[t].win[(2u - (uint32_t)l) & 3u];
+    l += info[t].lines;
+  }
+  uint64_t total;
+  uint64_t off = block_exclusive_scan<uint64_t>(cnt, s_scan, &total);
+  l = lb;
+  for (uint64_t t = t0; t < t1; ++t) {
+    out_off[t] = off;
+    off += info[t].win[(2u - (uint32_t)l) & 3u];
+    l += info[t].lines;
+  }
+  if (threadIdx.x == 0) {
+    out_off[n_tiles] = total;
+    totals[0] = total_lines;
+    totals[1] = total;
+    totals[2] = (total_lines + 2) / 4;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// pass 3
+// flags[0] bit0: a header line does not start with '@'; bit1: a third line does not start with '+'
+// ---------------------------------------------------------------------------
+template <int NW, int BITS>
+__global__ __launch_bounds__((ExCfg<NW, BITS>::NT)) void fastq_extract_kernel(
+    const uint8_t *__restrict__ bytes, uint64_t n_bytes, KShape shape, uint32_t strand, bool apply_strand,
+    const uint32_t *__restrict__ line_base, const uint64_t *__restrict__ out_off, uint64_t out_capacity,
+    uint64_t *__restrict__ out_kmers, uint32_t *__restrict__ flags) {
+  using Cfg = ExCfg<NW, BITS>;
+  constexpr int C = Cfg::C;
+  __shared__ uint32_t s_eol[Cfg::EOL_DW];
+  __shared__ uint32_t s_stream[Cfg::STREAM_DW];
+  __shared__ uint32_t s_scan[Cfg::NT / 64 + 2];
+  __shared__ uint64_t s_out[Cfg::TILE * NW];
+  const uint64_t tile0 = (uint64_t)blockIdx.x * Cfg::TILE;
+  uint32_t dw[C / 4], eol, ls, lbl, ltot;
+  tile_front<NW, BITS, true>(bytes, n_bytes, tile0, s_eol, s_stream, s_scan, dw, eol, ls, lbl, ltot);
+
+  const uint32_t lines_before = line_base[blockIdx.x] + lbl;
+
+  // FASTQ marker checks (fastq_loader.hpp:421-422,437-438)
+  {
+    uint32_t cur = lines_before, rest = ls, bad = 0;
+    while (rest) {
+      uint32_t q = (uint32_t)__builtin_ctz(rest);
+      uint32_t ch = (dw[q >> 2] >> (8 * (q & 3))) & 0xffu;
+      uint32_t role = cur & 3u;   // index of the line that starts here
+      if (role == 0 && ch != '@') bad |= 1u;
+      if (role == 2 && ch != '+') bad |= 2u;
+      cur += 1; rest &= rest - 1u;
+    }
+    // get_next_record refuses a partition that does not begin with '@' (fastq_loader.hpp:392-393)
+    if (blockIdx.x == 0 && threadIdx.x == 0 && (dw[0] & 0xffu) != '@') bad |= 1u;
+    if (bad) atomicOr(&flags[0], bad);
+  }
+
+  uint64_t e[Cfg::NE];
+  load_eol_view<NW, BITS>(s_eol, threadIdx.x, e);
+  smear_right<Cfg::NE>(e, shape.k);
+  const uint32_t valid = ~(uint32_t)e[0] & fastq_seq_role_mask(lines_before, ls, Cfg::CMASK);
+
+  uint32_t total;
+  uint32_t rank = block_exclusive_scan<uint32_t>((uint32_t)__builtin_popcount(valid), s_scan, &total);
+
+  if (valid) {
+    uint32_t r[Cfg::NR];
+    load_stream_view<NW, BITS>(s_stream, threadIdx.x, r);
+#pragma unroll
+    for (int p = 0; p < C; ++p) {
+      if ((valid >> p) & 1u) {
+        uint64_t rc[NW], fw[NW], key[NW];
+        window_words<NW, Cfg::NR>(r, BITS * p, shape, rc);
+        fwd_from_rc<NW, BITS>(rc, fw, shape);
+        if (apply_strand && strand != 0) {
+          bool lt = less_words<NW>(fw, rc);
+#pragma unroll
+          for (int w = 0; w < NW; ++w) key[w] = lt ? fw[w] : rc[w];
+        } else {
+#pragma unroll
+          for (int w = 0; w < NW; ++w) key[w] = fw[w];
+        }
+#pragma unroll
+        for (int w = 0; w < NW; ++w) s_out[(uint64_t)rank * NW + w] = key[w];
+        ++rank;
+      }
+    }
+  }
+  __syncthreads();
+  const uint64_t base = out_off[blockIdx.x];
+  const uint32_t nwords = total * NW;
+  if (base + total > out_capacity) {
+    if (threadIdx.x == 0) atomicOr(&flags[1], 1u);
+    return;
+  }
+  uint64_t *dst = out_kmers + base * NW;
+  for (uint32_t i = threadIdx.x; i < nwords; i += Cfg::NT) dst[i] = s_out[i];
+}
+
+// ---------------------------------------------------------------------------
+// host drivers
+// ---------------------------------------------------------------------------
+template <int NW, int BITS>
+static kmi_status scan_impl(kmi_ctx *ctx, const uint8_t *bytes_dev, size_t n_bytes, const KShape &shape,
+                            uint64_t *n_tiles_out, TileInfo **info_out, uint32_t **base_out, uint64_t **off_out) {
+  using Cfg = ExCfg<NW, BITS>;
+  const uint64_t n_tiles = (n_bytes + Cfg::TILE - 1) / Cfg::TILE;
+  void *p;
+  KMI_TRY(ws_get(ctx, WS_TILE_INFO, sizeof(TileInfo) * (n_tiles + 1), &p));
+  TileInfo *info = (TileInfo *)p;
+  KMI_TRY(ws_get(ctx, WS_TILE_BASE, sizeof(uint32_t) * (n_tiles + 1), &p));
+  uint32_t *base = (uint32_t *)p;
+  KMI_TRY(ws_get(ctx, WS_TILE_OFF, sizeof(uint64_t) * (n_tiles + 2), &p));
+  uint64_t *off = (uint64_t *)p;
+  if (n_tiles > 0) {
+    ProfScope ps(ctx, "fastq_scan_tiles", n_bytes);
+    hipLaunchKernelGGL((fastq_scan_tiles_kernel<NW, BITS>), dim3((unsigned)n_tiles), dim3(Cfg::NT), 0, ctx->stream,
+                       bytes_dev, (uint64_t)n_bytes, shape.k, info);
+  }
+  {
+    ProfScope ps(ctx, "fastq_scan_offsets", n_tiles);
+    hipLaunchKernelGGL(fastq_scan_offsets_kernel, dim3(1), dim3(1024), 0, ctx->stream, info, n_tiles, base, off,
+                       ctx->d_totals);
+  }
+  KMI_HIP(ctx, hipGetLastError());
+  *n_tiles_out = n_tiles; *info_out = info; *base_out = base; *off_out = off;
+  return KMI_OK;
+}
+
+static kmi_status read_totals(kmi_ctx *ctx, uint64_t *n_tuples, uint64_t *n_seqs) {
+  KMI_HIP(ctx, hipMemcpyAsync(ctx->h_totals, ctx->d_totals, sizeof(uint64_t) * 4, hipMemcpyDeviceToHost, ctx->stream));
+  KMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (n_tuples) *n_tuples = ctx->h_totals[1];
+  if (n_seqs) *n_seqs = ctx->h_totals[2];
+  return KMI_OK;
+}
+
+template <int NW, int BITS>
+static kmi_status extract_count_impl(kmi_ctx *ctx, const uint8_t *bytes_dev, size_t n_bytes, KShape shape,
+                                     uint64_t *n_tuples, uint64_t *n_seqs) {
+  uint64_t n_tiles; TileInfo *info; uint32_t *base; uint64_t *off;
+  KMI_TRY((scan_impl<NW, BITS>(ctx, bytes_dev, n_bytes, shape, &n_tiles, &info, &base, &off)));
+  return read_totals(ctx, n_tuples, n_seqs);
+}
+
+template <int NW, int BITS>
+static kmi_status extract_run_impl(kmi_ctx *ctx, const kmi_config *cfg, const uint8_t *bytes_dev, size_t n_bytes,
+                                   KShape shape, uint64_t *out_kmers_dev, size_t out_capacity, bool apply_strand,
+                                   uint64_t *n_tuples, uint64_t *n_seqs) {
+  using Cfg = ExCfg<NW, BITS>;
+  uint64_t n_tiles; TileInfo *info; uint32_t *base; uint64_t *off;
+  KMI_HIP(ctx, hipMemsetAsync(ctx->d_flags, 0, sizeof(uint32_t) * 16, ctx->stream));
+  KMI_TRY((scan_impl<NW, BITS>(ctx, bytes_dev, n_bytes, shape, &n_tiles, &info, &base, &off)));
+  if (n_tiles > 0) {
+    ProfScope ps(ctx, "fastq_extract", n_bytes);
+    hipLaunchKernelGGL((fastq_extract_kernel<NW, BITS>), dim3((unsigned)n_tiles), dim3(Cfg::NT), 0, ctx->stream,
+                       bytes_dev, (uint64_t)n_bytes, shape, cfg->strand, apply_strand, base, off,
+                       (uint64_t)out_capacity, out_kmers_dev, ctx->d_flags);
+  }
+  KMI_HIP(ctx, hipGetLastError());
+  uint32_t flags[2];
+  KMI_HIP(ctx, hipMemcpyAsync(flags, ctx->d_flags, sizeof(flags), hipMemcpyDeviceToHost, ctx->stream));
+  KMI_TRY(read_totals(ctx, n_tuples, n_seqs));
+  if (flags[0] & 1u) return set_err(ctx, KMI_ERR_PARSE, "FASTQ: missing @ on first line of a record");
+  if (flags[0] & 2u) return set_err(ctx, KMI_ERR_PARSE, "FASTQ: missing + on third line of a record");
+  if (flags[1]) return set_err(ctx, KMI_ERR_OVERFLOW, "extract: output capacity too small");
+  return KMI_OK;
+}
+
+kmi_status extract_count(kmi_ctx *ctx, const kmi_config *cfg, const uint8_t *bytes_dev, size_t n_bytes,
+                         uint64_t *n_tuples, uint64_t *n_seqs) {
+  KShape shape;
+  if (!valid_config(cfg, &shape)) return set_err(ctx, KMI_ERR_INVALID, "bad kmi_config");
+  if (cfg->seq_format != KMI_FMT_FASTQ) return set_err(ctx, KMI_ERR_INVALID, "only FASTQ is implemented on the device yet");
+  if (n_bytes == 0) { if (n_tuples) *n_tuples = 0; if (n_seqs) *n_seqs = 0; return KMI_OK; }
+  KMI_DISPATCH(shape, extract_count_impl, ctx, bytes_dev, n_bytes, shape, n_tuples, n_seqs);
+}
+
+kmi_status extract_run(kmi_ctx *ctx, const kmi_config *cfg, const uint8_t *bytes_dev, size_t n_bytes,
+                       uint64_t file_offset, uint64_t *out_kmers_dev, uint64_t *out_ids_dev, size_t out_capacity,
+                       bool apply_strand, uint64_t *n_tuples, uint64_t *n_seqs) {
+  (void)file_offset;
+  KShape shape;
+  if (!valid_config(cfg, &shape)) return set_err(ctx, KMI_ERR_INVALID, "bad kmi_config");
+  if (cfg->seq_format != KMI_FMT_FASTQ) return set_err(ctx, KMI_ERR_INVALID, "only FASTQ is implemented on the device yet");
+  if (out_ids_dev) return set_err(ctx, KMI_ERR_INVALID, "position ids are not implemented on the device yet");
+  if (n_bytes == 0) { if (n_tuples) *n_tuples = 0; if (n_seqs) *n_seqs = 0; return KMI_OK; }
+  KMI_DISPATCH(shape, extract_run_impl, ctx, cfg, bytes_dev, n_bytes, shape, out_kmers_dev, out_capacity, apply_strand,
+               n_tuples, n_seqs);
+}
+
+}  // namespace kmi

@@ -1,0 +1,142 @@
+// kmi_internal.h -- host-side context, workspace and launch helpers (not part of the ABI)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/kmerind_hip.h"
+#include "kmi_device.h"
+
+namespace kmi {
+
+enum WsSlot {
+  WS_TILE_INFO = 0,   // per-tile scan records
+  WS_TILE_BASE,       // per-tile line bases
+  WS_TILE_OFF,        // per-tile output offsets
+  WS_KEYS_A,          // key ping buffer
+  WS_KEYS_B,          // key pong buffer
+  WS_HIST,            // fine histogram / offsets
+  WS_WGHIST,          // per-workgroup coarse histograms
+  WS_CURSOR,          // coarse / fine cursors
+  WS_TMP_KEYS,        // per-bucket reduce output (keys)
+  WS_TMP_VALS,        // per-bucket reduce output (values)
+  WS_BUCKET_CNT,      // per-bucket distinct counts
+  WS_BUCKET_OFF,      // scanned
+  WS_QUERY_A,
+  WS_QUERY_B,
+  WS_INPUT,           // host-entry staging of input bytes / keys
+  WS_OUTPUT,          // host-entry staging of outputs
+  WS_OUTPUT2,
+  WS_MISC,
+  WS_NUM_SLOTS
+};
+
+struct ProfRec {
+  const char *name;
+  hipEvent_t e0, e1;
+  uint64_t units;
+};
+
+struct ProfAgg {
+  const char *name;
+  double total_ms;
+  uint64_t launches, units;
+};
+
+}  // namespace kmi
+
+struct kmi_ctx {
+  int device = 0, rank = 0, nranks = 1;
+  hipStream_t stream = nullptr;
+  std::string err;
+  struct Buf { void *p = nullptr; size_t cap = 0; } ws[kmi::WS_NUM_SLOTS];
+  uint32_t *d_flags = nullptr;   // [16] error / overflow flags
+  uint64_t *d_totals = nullptr;  // [16] small device scalars
+  uint64_t *h_totals = nullptr;  // pinned mirror
+  bool prof = false;
+  std::vector<kmi::ProfRec> prof_pending;
+  std::vector<kmi::ProfAgg> prof_agg;
+  std::vector<hipEvent_t> event_pool;
+};
+
+namespace kmi {
+
+inline kmi_status set_err(kmi_ctx *ctx, kmi_status st, const char *fmt, const char *a = "", const char *b = "") {
+  if (ctx) {
+    char buf[512];
+    snprintf(buf, sizeof(buf), fmt, a, b);
+    ctx->err = buf;
+  }
+  return st;
+}
+
+#define KMI_HIP(ctx, call)                                                              \
+  do {                                                                                  \
+    hipError_t e__ = (call);                                                            \
+    if (e__ != hipSuccess) return kmi::set_err((ctx), KMI_ERR_DEVICE, "%s failed: %s", #call, hipGetErrorString(e__)); \
+  } while (0)
+
+#define KMI_TRY(expr)                       \
+  do {                                      \
+    kmi_status s__ = (expr);                \
+    if (s__ != KMI_OK) return s__;          \
+  } while (0)
+
+// workspace slot of at least `bytes` (contents are not preserved when it grows)
+kmi_status ws_get(kmi_ctx *ctx, WsSlot slot, size_t bytes, void **out);
+void ws_release(kmi_ctx *ctx, WsSlot slot);
+
+// profiling hooks around one kernel launch
+void prof_begin(kmi_ctx *ctx, const char *name, uint64_t units);
+void prof_end(kmi_ctx *ctx);
+
+struct ProfScope {
+  kmi_ctx *c;
+  ProfScope(kmi_ctx *ctx, const char *name, uint64_t units) : c(ctx) { if (c->prof) prof_begin(c, name, units); }
+  ~ProfScope() { if (c->prof) prof_end(c); }
+};
+
+inline bool valid_config(const kmi_config *cfg, KShape *shape) {
+  if (!cfg || cfg->k == 0) return false;
+  uint32_t bits = cfg->alphabet == KMI_ALPHA_DNA ? 2 : (cfg->alphabet == KMI_ALPHA_DNA5 ? 3 : 0);
+  if (!bits) return false;
+  KShape s = make_shape(cfg->k, bits);
+  if (s.n_words > (uint32_t)kMaxWords) return false;
+  if (cfg->strand > 2 || cfg->dist_hash > 1 || cfg->store_hash > 1 || cfg->seq_format > 1 || cfg->index_kind > 2) return false;
+  if (shape) *shape = s;
+  return true;
+}
+
+// dispatch on (n_words, bits)
+#define KMI_DISPATCH(shape, FN, ...)                                                   \
+  do {                                                                                 \
+    if ((shape).bits == 2) {                                                           \
+      switch ((shape).n_words) {                                                       \
+        case 1: return FN<1, 2>(__VA_ARGS__);                                          \
+        case 2: return FN<2, 2>(__VA_ARGS__);                                          \
+        case 3: return FN<3, 2>(__VA_ARGS__);                                          \
+        case 4: return FN<4, 2>(__VA_ARGS__);                                          \
+      }                                                                                \
+    } else {                                                                           \
+      switch ((shape).n_words) {                                                       \
+        case 1: return FN<1, 3>(__VA_ARGS__);                                          \
+        case 2: return FN<2, 3>(__VA_ARGS__);                                          \
+        case 3: return FN<3, 3>(__VA_ARGS__);                                          \
+        case 4: return FN<4, 3>(__VA_ARGS__);                                          \
+      }                                                                                \
+    }                                                                                  \
+    return KMI_ERR_INVALID;                                                            \
+  } while (0)
+
+// ---- entry points implemented across the .hip files
+kmi_status extract_count(kmi_ctx *ctx, const kmi_config *cfg, const uint8_t *bytes_dev, size_t n_bytes,
+                         uint64_t *n_tuples, uint64_t *n_seqs);
+kmi_status extract_run(kmi_ctx *ctx, const kmi_config *cfg, const uint8_t *bytes_dev, size_t n_bytes,
+                       uint64_t file_offset, uint64_t *out_kmers_dev, uint64_t *out_ids_dev, size_t out_capacity,
+                       bool apply_strand, uint64_t *n_tuples, uint64_t *n_seqs);
+
+}  // namespace kmi

@@ -1,0 +1,166 @@
+"""GPU parity (through the C ABI) of the array-level k-mer ops and of FASTQ extraction
+against the CPU oracle and the committed golden fixtures."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from tests import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+SHAPES = [(31, "DNA"), (21, "DNA"), (32, "DNA"), (1, "DNA"), (63, "DNA"), (96, "DNA"),
+          (21, "DNA5"), (35, "DNA5"), (63, "DNA5"), (13, "DNA5")]
+ALPHA = {"DNA": orc.DNA, "DNA5": orc.DNA5}
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import kmerind_amd as K
+    c = K.Context(0)
+    yield c
+    c.close()
+
+
+def _random_kmers(s, n, seed):
+    rng = np.random.default_rng(seed)
+    km = rng.integers(0, 1 << 63, size=(n, s.n_words), dtype=np.uint64) * np.uint64(2) + \
+        rng.integers(0, 2, size=(n, s.n_words), dtype=np.uint64)
+    pad = s.n_words * 64 - s.n_bits
+    km[:, -1] &= np.uint64((1 << (64 - pad)) - 1)
+    return km
+
+
+@pytest.mark.parametrize("k,alpha", SHAPES)
+def test_revcomp_canonical_hash_rank(ctx, k, alpha):
+    import kmerind_amd as K
+    s = orc.kspec(k, ALPHA[alpha])
+    km = _random_kmers(s, 5000, k)
+    for strand in ("canonical", "bimolecule"):
+        cfg = K.make_config(k, alpha, strand=strand)
+        assert (ctx.revcomp(cfg, km) == orc.revcomp(s, km)).all()
+        assert (ctx.canonical(cfg, km) == orc.canonical(s, km)).all()
+        for which, w in (("murmur", orc.MURMUR), ("farm", orc.FARM)):
+            for prefix in (True, False):
+                assert (ctx.hash(cfg, which, prefix, km) == orc.kmer_hash(s, w, prefix, km)).all(), (which, prefix)
+        for p in (1, 2, 3, 8):
+            st = orc.BIMOLECULE if strand == "bimolecule" else orc.CANONICAL
+            assert (ctx.key_to_rank(cfg, km, p) == orc.key_to_rank(s, orc.MURMUR, st, km, p)).all()
+    cfgf = K.make_config(k, alpha, dist_hash="farm", farm_ndebug=True)
+    orc.lib.orc_set_farm_ndebug(1)
+    try:
+        assert (ctx.hash(cfgf, "farm", True, km) == orc.kmer_hash(s, orc.FARM, True, km)).all()
+        assert (ctx.key_to_rank(cfgf, km, 5) == orc.key_to_rank(s, orc.FARM, orc.CANONICAL, km, 5)).all()
+    finally:
+        orc.lib.orc_set_farm_ndebug(0)
+
+
+def test_known_answers_on_device(ctx):
+    import kmerind_amd as K
+    ka = json.load(open(os.path.join(GOLD, "survey_known_answers.json")))["k31_dna"]
+    cfg = K.make_config(31, "DNA")
+    km = np.array([[int(ka["first_kmer"], 16)]], dtype=np.uint64)
+    assert int(ctx.revcomp(cfg, km)[0, 0]) == int(ka["revcomp"], 16)
+    assert int(ctx.canonical(cfg, km)[0, 0]) == int(ka["revcomp"], 16)
+    assert int(ctx.hash(cfg, "murmur", True, km)[0]) == int(ka["murmur_prefix"], 16)
+    assert int(ctx.hash(cfg, "murmur", False, km)[0]) == int(ka["murmur_store"], 16)
+    assert int(ctx.hash(cfg, "farm", True, km)[0]) == int(ka["farm_prefix"], 16)
+    assert int(ctx.hash(cfg, "farm", False, km)[0]) == int(ka["farm_store"], 16)
+
+
+FASTQ_FILES = ["test.small.fastq", "test.medium.fastq", "natural.fastq", "natural.withN.fastq",
+               "test.debruijn.tiny.fastq", "test.unitiq1.fastq", "test.unitiqs.fastq", "test.unitiq1.short2.fastq"]
+
+
+@pytest.mark.parametrize("k,alpha", [(31, "DNA"), (21, "DNA"), (35, "DNA5"), (63, "DNA"), (63, "DNA5"), (15, "DNA5")])
+def test_extract_golden_files(ctx, k, alpha):
+    import kmerind_amd as K
+    s = orc.kspec(k, ALPHA[alpha])
+    cfg = K.make_config(k, alpha)
+    for name in FASTQ_FILES:
+        data = open(os.path.join(GOLD, "data", name), "rb").read()
+        ex = orc.extract(s, data, orc.FASTQ)
+        kmers, nseq = ctx.read_file(cfg, data)
+        assert nseq == ex["n_seqs"], name
+        assert kmers.shape == ex["kmers"].shape, name
+        assert (kmers == ex["kmers"]).all(), name
+
+
+def test_extract_reference_table_counts(ctx):
+    """TestFileInfo table of mpi_test_fastq_seq_parse.cpp:446-459 (K=35, DNA5) on the device"""
+    import kmerind_amd as K
+    pg = json.load(open(os.path.join(GOLD, "parse_golden.json")))["fastq"]
+    cfg = K.make_config(pg["k"], "DNA5")
+    for e in pg["files"]:
+        path = os.path.join(GOLD, "data", e["file"])
+        if not os.path.exists(path):
+            continue
+        kmers, nseq = ctx.read_file(cfg, open(path, "rb").read())
+        assert (nseq, kmers.shape[0]) == (e["records"], e["kmers"]), e
+
+
+def _ragged_fastq(rng, n_reads, eol=b"\n", max_len=400):
+    recs = []
+    for i in range(n_reads):
+        ln = int(rng.integers(0, max_len)) if i % 7 else int(rng.integers(0, 40))
+        seq = bytes(rng.choice(list(b"ACGTNacgtn"), size=ln, p=[.22, .22, .22, .22, .02, .02, .02, .02, .02, .02]).tolist()) if ln else b""
+        qual = bytes(rng.integers(33, 74, size=ln, dtype=np.uint8).tolist())
+        if ln == 0:
+            continue  # an empty sequence line would collapse the 4-line structure
+        extra = eol * int(rng.integers(1, 3))
+        recs.append(b"@r%d" % i + extra + seq + eol + b"+" + eol + qual + extra)
+    return b"".join(recs)
+
+
+@pytest.mark.parametrize("eol", [b"\n", b"\r\n"])
+@pytest.mark.parametrize("k,alpha", [(31, "DNA"), (63, "DNA5"), (5, "DNA"), (32, "DNA")])
+def test_extract_ragged_reads(ctx, k, alpha, eol):
+    import kmerind_amd as K
+    rng = np.random.default_rng(k)
+    data = _ragged_fastq(rng, 900, eol)
+    s = orc.kspec(k, ALPHA[alpha])
+    ex = orc.extract(s, data, orc.FASTQ)
+    kmers, nseq = ctx.read_file(K.make_config(k, alpha), data)
+    assert nseq == ex["n_seqs"]
+    assert kmers.shape == ex["kmers"].shape
+    assert (kmers == ex["kmers"]).all()
+
+
+def test_extract_edge_cases(ctx):
+    import kmerind_amd as K
+    from kmerind_amd import _lib as L
+    cfg = K.make_config(31, "DNA")
+    kmers, nseq = ctx.read_file(cfg, b"")
+    assert kmers.shape[0] == 0 and nseq == 0
+    # reads shorter than k emit nothing but still count as sequences
+    data = b"@a\nACGT\n+\nIIII\n@b\n" + b"ACGT" * 10 + b"\n+\n" + b"I" * 40 + b"\n"
+    s = orc.kspec(31, orc.DNA)
+    ex = orc.extract(s, data, orc.FASTQ)
+    kmers, nseq = ctx.read_file(cfg, data)
+    assert nseq == ex["n_seqs"] == 2 and kmers.shape[0] == ex["kmers"].shape[0] == 10
+    assert (kmers == ex["kmers"]).all()
+    # truncated last record (no quality line): the reference still emits its k-mers
+    data = b"@a\n" + b"ACGT" * 10 + b"\n+\n" + b"I" * 40 + b"\n@b\n" + b"TTGCA" * 9 + b"\n"
+    ex = orc.extract(s, data, orc.FASTQ)
+    kmers, nseq = ctx.read_file(cfg, data)
+    assert (kmers == ex["kmers"]).all() and nseq == ex["n_seqs"]
+    # malformed: header without '@' / third line without '+'
+    for bad in (b"a\nACGT\n+\nIIII\n", b"@a\nACGT\n-\nIIII\n", b"\n@a\nACGT\n+\nIIII\n"):
+        with pytest.raises(ValueError):
+            orc.extract(s, bad, orc.FASTQ)
+        with pytest.raises(L.KmiError) as ei:
+            ctx.read_file(cfg, bad)
+        assert ei.value.status == L.ERR_PARSE
+
+
+def test_extract_synthetic_reads_multi_tile(ctx):
+    import kmerind_amd as K
+    data = K.synth_fastq(seed=2, genome_len=200_000, n_reads=3000)
+    for k, alpha in ((31, "DNA"), (63, "DNA5")):
+        s = orc.kspec(k, ALPHA[alpha])
+        ex = orc.extract(s, data, orc.FASTQ)
+        kmers, nseq = ctx.read_file(K.make_config(k, alpha), data)
+        assert nseq == 3000 and kmers.shape[0] == 3000 * (150 - k + 1)
+        assert (kmers == ex["kmers"]).all()
