@@ -1,20 +1,996 @@
-// placeholder while the index kernels are being written
+// kmi_index.hip -- the map behind Index<MapType,Parser>: insert / count / find / erase.
+//
+// Reference path replaced (one rank):
+//   counting_unordered_map::insert(vector<Key>)   distributed_unordered_map.hpp:1826-1884
+//   reduction_unordered_map::local_insert         :1603-1618   (count[key] += v)
+//   unordered_map_base::count / find / erase      :880-983, :564-687, :719-779
+//   fsc::unique (query dedup)                     fsc_container_utils.hpp:306-320
+//   imxx::distribute bucketing                    incremental_mxx.hpp:273-364,595-640 (kmi_route_dev)
+//
+// GPU formulation. A node-based hash table with one malloc per key is the wrong shape for
+// HBM; the map is a two-level hash partition followed by an LDS-resident reduce:
+//   place_hash(key) (32 bit)  -> coarse bucket = top 8 bits, fine bucket = top 15 bits
+//   K1  histogram   : per-workgroup LDS histogram of the 32768 fine buckets (privatised,
+//                     flushed once with coalesced atomics) + per-workgroup coarse counts
+//   K2  scatter     : keys -> 256 coarse buckets. Each tile is bucket-sorted in LDS so a
+//                     bucket's keys leave as one contiguous run (coalesced stores); output
+//                     ranges come from the per-workgroup counts, so there are no global
+//                     atomics and no collisions between workgroups.
+//   P2  scatter     : one workgroup per coarse bucket splits it into its 128 fine buckets.
+//   C   reduce      : one workgroup per fine bucket builds an open-addressing table in LDS
+//                     (key -> count), merging the bucket of the existing index, and emits the
+//                     distinct (key,count) pairs. Buckets whose distinct keys exceed the LDS
+//                     table are reduced in several passes over disjoint key subsets.
+//   queries use the same machinery: partition the query keys, build the LDS table from the
+//   (deduplicated) queries of a bucket, stream the index bucket against it.
+// The stored index is (bucket_off[32769], keys[], counts[]): entries of a fine bucket are
+// contiguous; order inside a bucket is unspecified, like the reference's unordered_map.
+#include <stdlib.h>
+
+#include <algorithm>
+
+#include "kmi_block.h"
 #include "kmi_internal.h"
-using namespace kmi;
-extern "C" {
-kmi_status kmi_route_dev(kmi_ctx *ctx, const kmi_config *, const uint64_t *, size_t, uint32_t, uint64_t *, uint64_t *) { return set_err(ctx, KMI_ERR_INVALID, "not implemented"); }
-kmi_status kmi_index_create(kmi_ctx *ctx, const kmi_config *, kmi_index **) { return set_err(ctx, KMI_ERR_INVALID, "not implemented"); }
-kmi_status kmi_index_destroy(kmi_index *) { return KMI_ERR_INVALID; }
-kmi_status kmi_index_insert_host(kmi_index *, const uint64_t *, size_t) { return KMI_ERR_INVALID; }
-kmi_status kmi_index_insert_dev(kmi_index *, const uint64_t *, size_t) { return KMI_ERR_INVALID; }
-kmi_status kmi_index_build_host(kmi_index *, const uint8_t *, size_t, uint64_t) { return KMI_ERR_INVALID; }
-kmi_status kmi_index_build_dev(kmi_index *, const uint8_t *, size_t, uint64_t) { return KMI_ERR_INVALID; }
-kmi_status kmi_index_local_size(kmi_index *, uint64_t *) { return KMI_ERR_INVALID; }
-kmi_status kmi_index_export_host(kmi_index *, uint64_t *, uint32_t *, size_t, uint64_t *) { return KMI_ERR_INVALID; }
-void kmi_results_free(kmi_results *r) { if (r) { free(r->keys); free(r->values); memset(r, 0, sizeof(*r)); } }
-kmi_status kmi_index_count_host(kmi_index *, const uint64_t *, size_t, kmi_results *) { return KMI_ERR_INVALID; }
-kmi_status kmi_index_find_host(kmi_index *, const uint64_t *, size_t, kmi_results *) { return KMI_ERR_INVALID; }
-kmi_status kmi_index_erase_host(kmi_index *, const uint64_t *, size_t, uint64_t *) { return KMI_ERR_INVALID; }
-kmi_status kmi_index_count_dev(kmi_index *, const uint64_t *, size_t, uint64_t *, uint64_t *, uint64_t *) { return KMI_ERR_INVALID; }
-kmi_status kmi_index_find_dev(kmi_index *, const uint64_t *, size_t, uint64_t *, uint64_t *, uint64_t *) { return KMI_ERR_INVALID; }
+
+namespace kmi {
+
+constexpr int kFineBits = 15;
+constexpr int kNumFine = 1 << kFineBits;     // 32768 fine buckets
+constexpr int kCoarseBits = 8;
+constexpr int kNumCoarse = 1 << kCoarseBits; // 256
+constexpr int kSubPerCoarse = kNumFine / kNumCoarse;  // 128
+constexpr int kSlotBits = 32 - kFineBits;    // low 17 bits pick the LDS slot
+constexpr int kPartThreads = 1024;           // K1/K2/P2 workgroup size
+constexpr int kPartGroups = 256;             // K1/K2 workgroups (one per CU)
+
+__host__ __device__ inline uint32_t fine_of(uint32_t h) { return h >> kSlotBits; }
+__host__ __device__ inline uint32_t coarse_of(uint32_t h) { return h >> (32 - kCoarseBits); }
+
+template <int NW> struct PartCfg {
+  static constexpr int TILE = 8192 / NW;                 // keys per LDS tile (64 KB of key words)
+  static constexpr int PER_THREAD = TILE / kPartThreads; // 8, 4, 2, 2
+};
+template <> struct PartCfg<3> { static constexpr int TILE = 2048; static constexpr int PER_THREAD = 2; };
+
+enum BucketMode { BUCKET_COARSE = 0, BUCKET_SUB = 1, BUCKET_RANK = 2 };
+
+struct BucketFn {
+  int mode; KShape shape; uint32_t dist_hash; bool farm_ndebug; uint32_t nranks;
+};
+
+template <int NW> __device__ __forceinline__ uint32_t bucket_of(const uint64_t (&key)[NW], const BucketFn &f) {
+  if (f.mode == BUCKET_RANK) return (uint32_t)(kmer_hash<NW>(key, f.shape, f.dist_hash, true, f.farm_ndebug) % f.nranks);
+  uint32_t h = place_hash<NW>(key);
+  return f.mode == BUCKET_COARSE ? coarse_of(h) : (fine_of(h) & (kSubPerCoarse - 1));
 }
+
+template <int NW, int BITS> __device__ __forceinline__ void load_key(const uint64_t *__restrict__ keys, uint64_t i, const KShape &s,
+                                                                    uint32_t strand, bool transform, uint64_t (&k)[NW]) {
+  uint64_t raw[NW];
+#pragma unroll
+  for (int w = 0; w < NW; ++w) raw[w] = keys[i * NW + w];
+  if (transform) strand_key<NW, BITS>(raw, k, s, strand);
+  else {
+#pragma unroll
+    for (int w = 0; w < NW; ++w) k[w] = raw[w];
+  }
+}
+
+// chunk of keys owned by workgroup w of `groups` (multiple of the tile size)
+__host__ __device__ inline uint64_t part_chunk(uint64_t n, uint32_t groups, uint32_t tile) {
+  uint64_t c = (n + groups - 1) / groups;
+  return (c + tile - 1) / tile * tile;
+}
+
+// ---------------------------------------------------------------------------
+// K1: histograms
+// ---------------------------------------------------------------------------
+template <int NW, int BITS>
+__global__ __launch_bounds__(kPartThreads) void hist_fine_kernel(const uint64_t *__restrict__ keys, uint64_t n, KShape shape,
+                                                                uint32_t strand, bool transform,
+                                                                uint32_t *__restrict__ fine_hist,     // [kNumFine] global
+                                                                uint32_t *__restrict__ wg_hist) {     // [groups][256]
+  __shared__ uint32_t s_hist[kNumFine];
+  for (int i = threadIdx.x; i < kNumFine; i += kPartThreads) s_hist[i] = 0;
+  __syncthreads();
+  const uint64_t chunk = part_chunk(n, gridDim.x, PartCfg<NW>::TILE);
+  const uint64_t b = (uint64_t)blockIdx.x * chunk;
+  const uint64_t e = (b + chunk < n) ? b + chunk : n;
+  for (uint64_t i = b + threadIdx.x; i < e; i += kPartThreads) {
+    uint64_t k[NW];
+    load_key<NW, BITS>(keys, i, shape, strand, transform, k);
+    atomicAdd(&s_hist[fine_of(place_hash<NW>(k))], 1u);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < kNumFine; i += kPartThreads) {
+    uint32_t v = s_hist[i];
+    if (v) atomicAdd(&fine_hist[i], v);
+  }
+  if (threadIdx.x < kNumCoarse) {
+    uint32_t s = 0;
+    for (int i = 0; i < kSubPerCoarse; ++i) s += s_hist[threadIdx.x * kSubPerCoarse + ((i + threadIdx.x) & (kSubPerCoarse - 1))];
+    wg_hist[(uint64_t)blockIdx.x * kNumCoarse + threadIdx.x] = s;
+  }
+}
+
+template <int NW, int BITS>
+__global__ __launch_bounds__(kPartThreads) void hist_rank_kernel(const uint64_t *__restrict__ keys, uint64_t n, KShape shape,
+                                                                uint32_t strand, BucketFn fn, uint32_t *__restrict__ wg_hist) {
+  __shared__ uint32_t s_hist[kNumCoarse];
+  if (threadIdx.x < kNumCoarse) s_hist[threadIdx.x] = 0;
+  __syncthreads();
+  const uint64_t chunk = part_chunk(n, gridDim.x, PartCfg<NW>::TILE);
+  const uint64_t b = (uint64_t)blockIdx.x * chunk;
+  const uint64_t e = (b + chunk < n) ? b + chunk : n;
+  for (uint64_t i = b + threadIdx.x; i < e; i += kPartThreads) {
+    uint64_t k[NW];
+    load_key<NW, BITS>(keys, i, shape, strand, true, k);
+    atomicAdd(&s_hist[bucket_of<NW>(k, fn)], 1u);
+  }
+  __syncthreads();
+  if (threadIdx.x < kNumCoarse) wg_hist[(uint64_t)blockIdx.x * kNumCoarse + threadIdx.x] = s_hist[threadIdx.x];
+}
+
+// ---------------------------------------------------------------------------
+// offsets: fine_off = exclusive scan of fine_hist (u64, kNumFine+1 entries);
+//          wg_off[w][c] = fine_off[c*128] + sum_{w'<w} wg_hist[w'][c]
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void fine_offsets_kernel(const uint32_t *__restrict__ fine_hist, const uint32_t *__restrict__ wg_hist,
+                                                           uint32_t groups, uint64_t *__restrict__ fine_off,
+                                                           uint64_t *__restrict__ wg_off) {
+  __shared__ uint64_t s_scan[1024 / 64 + 2];
+  __shared__ uint64_t s_coarse[kNumCoarse];
+  constexpr int PER = kNumFine / 1024;  // 32 fine buckets per thread; a coarse bucket = 4 threads
+  uint64_t loc[PER], sum = 0;
+#pragma unroll
+  for (int i = 0; i < PER; ++i) { loc[i] = fine_hist[threadIdx.x * PER + i]; sum += loc[i]; }
+  uint64_t total;
+  uint64_t off = block_exclusive_scan<uint64_t>(sum, s_scan, &total);
+  if ((threadIdx.x & 3u) == 0) s_coarse[threadIdx.x >> 2] = off;
+#pragma unroll
+  for (int i = 0; i < PER; ++i) { fine_off[threadIdx.x * PER + i] = off; off += loc[i]; }
+  if (threadIdx.x == 0) fine_off[kNumFine] = total;
+  __syncthreads();
+  if (wg_off && threadIdx.x < kNumCoarse) {
+    uint64_t o = s_coarse[threadIdx.x];
+    for (uint32_t w = 0; w < groups; ++w) {
+      wg_off[(uint64_t)w * kNumCoarse + threadIdx.x] = o;
+      o += wg_hist[(uint64_t)w * kNumCoarse + threadIdx.x];
+    }
+  }
+}
+
+// rank mode: bucket_off[r] (nbuckets+1) and wg_off[w][r]
+__global__ __launch_bounds__(256) void rank_offsets_kernel(const uint32_t *__restrict__ wg_hist, uint32_t groups, uint32_t nbuckets,
+                                                          uint64_t *__restrict__ bucket_cnt, uint64_t *__restrict__ wg_off) {
+  __shared__ uint64_t s_scan[256 / 64 + 2];
+  uint64_t tot = 0;
+  if (threadIdx.x < nbuckets)
+    for (uint32_t w = 0; w < groups; ++w) tot += wg_hist[(uint64_t)w * kNumCoarse + threadIdx.x];
+  uint64_t total;
+  uint64_t off = block_exclusive_scan<uint64_t>(tot, s_scan, &total);
+  if (threadIdx.x < nbuckets) {
+    bucket_cnt[threadIdx.x] = tot;
+    uint64_t o = off;
+    for (uint32_t w = 0; w < groups; ++w) {
+      wg_off[(uint64_t)w * kNumCoarse + threadIdx.x] = o;
+      o += wg_hist[(uint64_t)w * kNumCoarse + threadIdx.x];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// K2 / P2: tile-wise bucket sort in LDS + contiguous runs out
+// ---------------------------------------------------------------------------
+template <int NW, int BITS>
+__device__ __forceinline__ void scatter_range(const uint64_t *__restrict__ in, uint64_t begin, uint64_t end, uint64_t *__restrict__ out,
+                                              const KShape &shape, uint32_t strand, bool transform, const BucketFn &fn,
+                                              uint64_t *s_stage, uint8_t *s_bkt, uint32_t *s_cnt, uint32_t *s_lofs,
+                                              uint64_t *s_cursor, uint32_t *s_scan) {
+  constexpr int TILE = PartCfg<NW>::TILE;
+  constexpr int PT = PartCfg<NW>::PER_THREAD;
+  for (uint64_t t0 = begin; t0 < end; t0 += TILE) {
+    const uint32_t nt = (uint32_t)((end - t0 < (uint64_t)TILE) ? (end - t0) : (uint64_t)TILE);
+    if (threadIdx.x < kNumCoarse) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    uint64_t k[PT][NW];
+    uint32_t bk[PT], rk[PT];
+#pragma unroll
+    for (int j = 0; j < PT; ++j) {
+      const uint32_t li = j * kPartThreads + threadIdx.x;
+      bk[j] = 0xffffffffu;
+      if (li < nt) {
+        load_key<NW, BITS>(in, t0 + li, shape, strand, transform, k[j]);
+        bk[j] = bucket_of<NW>(k[j], fn);
+        rk[j] = atomicAdd(&s_cnt[bk[j]], 1u);
+      }
+    }
+    __syncthreads();
+    uint32_t c = (threadIdx.x < kNumCoarse) ? s_cnt[threadIdx.x] : 0u;
+    uint32_t lo = block_exclusive_scan<uint32_t>(c, s_scan, (uint32_t *)nullptr);
+    if (threadIdx.x < kNumCoarse) s_lofs[threadIdx.x] = lo;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < PT; ++j) {
+      if (bk[j] != 0xffffffffu) {
+        const uint32_t pos = s_lofs[bk[j]] + rk[j];
+#pragma unroll
+        for (int w = 0; w < NW; ++w) s_stage[(uint64_t)pos * NW + w] = k[j][w];
+        s_bkt[pos] = (uint8_t)bk[j];
+      }
+    }
+    __syncthreads();
+    for (uint32_t s = threadIdx.x; s < nt; s += kPartThreads) {
+      const uint32_t b = s_bkt[s];
+      const uint64_t dst = s_cursor[b] + (s - s_lofs[b]);
+#pragma unroll
+      for (int w = 0; w < NW; ++w) out[dst * NW + w] = s_stage[(uint64_t)s * NW + w];
+    }
+    __syncthreads();
+    if (threadIdx.x < kNumCoarse) s_cursor[threadIdx.x] += s_cnt[threadIdx.x];
+    __syncthreads();
+  }
+}
+
+#define KMI_SCATTER_LDS(NW)                                        \
+  __shared__ uint64_t s_stage[PartCfg<NW>::TILE * NW];             \
+  __shared__ uint8_t s_bkt[PartCfg<NW>::TILE];                     \
+  __shared__ uint32_t s_cnt[kNumCoarse];                           \
+  __shared__ uint32_t s_lofs[kNumCoarse];                          \
+  __shared__ uint64_t s_cursor[kNumCoarse];                        \
+  __shared__ uint32_t s_scan[kPartThreads / 64 + 2];
+
+// K2: workgroup w scatters its chunk of the input by coarse bucket (or by rank)
+template <int NW, int BITS>
+__global__ __launch_bounds__(kPartThreads) void scatter_chunks_kernel(const uint64_t *__restrict__ in, uint64_t n, uint64_t *__restrict__ out,
+                                                                     KShape shape, uint32_t strand, bool transform, BucketFn fn,
+                                                                     const uint64_t *__restrict__ wg_off) {
+  KMI_SCATTER_LDS(NW)
+  if (threadIdx.x < kNumCoarse) s_cursor[threadIdx.x] = wg_off[(uint64_t)blockIdx.x * kNumCoarse + threadIdx.x];
+  __syncthreads();
+  const uint64_t chunk = part_chunk(n, gridDim.x, PartCfg<NW>::TILE);
+  const uint64_t b = (uint64_t)blockIdx.x * chunk;
+  const uint64_t e = (b + chunk < n) ? b + chunk : n;
+  if (b < e) scatter_range<NW, BITS>(in, b, e, out, shape, strand, transform, fn, s_stage, s_bkt, s_cnt, s_lofs, s_cursor, s_scan);
+}
+
+// P2: workgroup c splits coarse bucket c into its fine buckets
+template <int NW, int BITS>
+__global__ __launch_bounds__(kPartThreads) void scatter_fine_kernel(const uint64_t *__restrict__ in, uint64_t *__restrict__ out, KShape shape,
+                                                                   const uint64_t *__restrict__ fine_off) {
+  KMI_SCATTER_LDS(NW)
+  const uint32_t c = blockIdx.x;
+  if (threadIdx.x < kNumCoarse)
+    s_cursor[threadIdx.x] = (threadIdx.x < kSubPerCoarse) ? fine_off[c * kSubPerCoarse + threadIdx.x] : 0ull;
+  __syncthreads();
+  const uint64_t b = fine_off[c * kSubPerCoarse], e = fine_off[(c + 1) * kSubPerCoarse];
+  BucketFn fn; fn.mode = BUCKET_SUB; fn.shape = shape; fn.dist_hash = 0; fn.farm_ndebug = false; fn.nranks = 1;
+  if (b < e) scatter_range<NW, BITS>(in, b, e, out, shape, 0u, false, fn, s_stage, s_bkt, s_cnt, s_lofs, s_cursor, s_scan);
+}
+
+// ---------------------------------------------------------------------------
+// LDS table
+// ---------------------------------------------------------------------------
+template <int NW> struct TabCfg {
+  // slots; sized so that two workgroups fit in one CU's 160 KB for one-word keys
+  static constexpr int CAP = (NW == 1) ? 6656 : (NW == 2 ? 4608 : (NW == 3 ? 3584 : 2816));
+  static constexpr int LIMIT = CAP * 3 / 4;
+  static constexpr int NT = 512;
+};
+constexpr int kMaxProbe = 192;   // longer probe sequences than this mean the LDS table is overloaded
+constexpr uint32_t kMaxPasses = 1u << 16;
+constexpr uint64_t kEmptyKey = ~0ull;
+
+// one LDS atomic per wavefront: every lane that `want`s a slot gets a distinct index
+__device__ __forceinline__ uint32_t wave_alloc(uint32_t *ctr, bool want) {
+  const unsigned long long m = __ballot(want);
+  if (m == 0ull) return 0u;
+  const int leader = __ffsll((long long)m) - 1;
+  uint32_t base = 0;
+  if ((int)lane_id() == leader) base = atomicAdd(ctr, (uint32_t)__popcll(m));
+  base = __shfl(base, leader, kWave);
+  return base + (uint32_t)__popcll(m & ((1ull << lane_id()) - 1ull));
+}
+constexpr uint32_t kTagEmpty = 0u, kTagLock = 1u;
+
+template <int NW> struct LdsTable {
+  uint64_t *keys;      // [CAP*NW]
+  uint32_t *vals;      // [CAP]
+  uint32_t *tags;      // [CAP] (NW > 1 only)
+  uint32_t *distinct;  // counter
+  uint32_t *overflow;  // flag
+  uint32_t *special;   // value of the key that equals the empty sentinel (NW == 1)
+  uint32_t *special_set;
+};
+
+template <int NW> __device__ __forceinline__ void table_clear(const LdsTable<NW> &t) {
+  constexpr int CAP = TabCfg<NW>::CAP;
+  for (int i = threadIdx.x; i < CAP; i += blockDim.x) {
+    t.vals[i] = 0;
+    if (NW == 1) t.keys[i] = kEmptyKey; else t.tags[i] = kTagEmpty;
+  }
+  if (threadIdx.x == 0) { *t.distinct = 0; *t.overflow = 0; *t.special = 0; *t.special_set = 0; }
+}
+
+__device__ __forceinline__ uint32_t slot_of(uint32_t h, int cap) {
+  return (uint32_t)(((uint64_t)(h & ((1u << kSlotBits) - 1u)) * (uint32_t)cap) >> kSlotBits);
+}
+
+// find-or-insert; returns slot (or -1 when the table overflowed / special key). `inserted` tells a new key.
+template <int NW> __device__ __forceinline__ int table_upsert(const LdsTable<NW> &t, const uint64_t (&key)[NW], uint32_t h) {
+  constexpr int CAP = TabCfg<NW>::CAP;
+  uint32_t slot = slot_of(h, CAP);
+  if (NW == 1) {
+    if (key[0] == kEmptyKey) { *t.special_set = 1; return -2; }
+    for (int probes = 0; probes < CAP; ++probes) {
+      unsigned long long old = atomicCAS((unsigned long long *)&t.keys[slot], (unsigned long long)kEmptyKey, (unsigned long long)key[0]);
+      if (old == kEmptyKey || old == key[0]) {
+        if (probes >= kMaxProbe) *t.overflow = 1;   // table too loaded: redo the bucket in more passes
+        return (int)slot;
+      }
+      slot = (slot + 1 == (uint32_t)CAP) ? 0u : slot + 1;
+    }
+    *t.overflow = 1;
+    return -1;
+  } else {
+    const uint32_t tagv = h | 0x80000000u;
+    int probes = 0;
+    while (probes < CAP) {
+      uint32_t tg = __atomic_load_n(&t.tags[slot], __ATOMIC_RELAXED);
+      if (tg == kTagEmpty) {
+        uint32_t old = atomicCAS(&t.tags[slot], kTagEmpty, kTagLock);
+        if (old == kTagEmpty) {
+#pragma unroll
+          for (int w = 0; w < NW; ++w) t.keys[(uint64_t)slot * NW + w] = key[w];
+          __threadfence_block();
+          atomicExch(&t.tags[slot], tagv);
+          if (probes >= kMaxProbe) *t.overflow = 1;
+          return (int)slot;
+        }
+        continue;  // somebody else took it: look again
+      }
+      if (tg == kTagLock) continue;  // being written by another lane
+      if (tg == tagv) {
+        bool eq = true;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) eq &= (t.keys[(uint64_t)slot * NW + w] == key[w]);
+        if (eq) { if (probes >= kMaxProbe) *t.overflow = 1; return (int)slot; }
+      }
+      slot = (slot + 1 == (uint32_t)CAP) ? 0u : slot + 1;
+      ++probes;
+    }
+    *t.overflow = 1;
+    return -1;
+  }
+}
+
+// lookup only; returns slot or -1
+template <int NW> __device__ __forceinline__ int table_find(const LdsTable<NW> &t, const uint64_t (&key)[NW], uint32_t h) {
+  constexpr int CAP = TabCfg<NW>::CAP;
+  uint32_t slot = slot_of(h, CAP);
+  if (NW == 1) {
+    if (key[0] == kEmptyKey) return *t.special_set ? -2 : -1;
+    for (int probes = 0; probes < CAP; ++probes) {
+      uint64_t k = t.keys[slot];
+      if (k == key[0]) return (int)slot;
+      if (k == kEmptyKey) return -1;
+      slot = (slot + 1 == (uint32_t)CAP) ? 0u : slot + 1;
+    }
+    return -1;
+  } else {
+    const uint32_t tagv = h | 0x80000000u;
+    for (int probes = 0; probes < CAP; ++probes) {
+      uint32_t tg = t.tags[slot];
+      if (tg == kTagEmpty) return -1;
+      if (tg == tagv) {
+        bool eq = true;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) eq &= (t.keys[(uint64_t)slot * NW + w] == key[w]);
+        if (eq) return (int)slot;
+      }
+      slot = (slot + 1 == (uint32_t)CAP) ? 0u : slot + 1;
+    }
+    return -1;
+  }
+}
+
+template <int NW> __device__ __forceinline__ bool slot_used(const LdsTable<NW> &t, int slot) {
+  return NW == 1 ? (t.keys[slot] != kEmptyKey) : (t.tags[slot] != kTagEmpty);
+}
+
+// which reduction pass a key belongs to when a bucket needs several
+__device__ __forceinline__ uint32_t pass_of(uint32_t h, uint32_t npass) {
+  return npass == 1 ? 0u : (uint32_t)(((uint64_t)(h * 0x9E3779B1u) * npass) >> 32);
+}
+
+#define KMI_TABLE_LDS(NW)                                                   \
+  __shared__ uint64_t s_tk[TabCfg<NW>::CAP * NW];                           \
+  __shared__ uint32_t s_tv[TabCfg<NW>::CAP];                                \
+  __shared__ uint32_t s_tt[(NW == 1) ? 1 : TabCfg<NW>::CAP];               \
+  __shared__ uint32_t s_ctl[8];                                             \
+  LdsTable<NW> tab;                                                         \
+  tab.keys = s_tk; tab.vals = s_tv; tab.tags = s_tt; tab.distinct = &s_ctl[0]; tab.overflow = &s_ctl[1]; \
+  tab.special = &s_ctl[2]; tab.special_set = &s_ctl[3];
+
+// ---------------------------------------------------------------------------
+// C: per fine bucket reduce  (new keys weight 1, old entries weight = their count)
+// output to tmp arrays at tmp_off[b] = new_off[b] + old_off[b]; out_cnt[b] = distinct
+// ---------------------------------------------------------------------------
+template <int NW>
+__global__ __launch_bounds__((TabCfg<NW>::NT)) void bucket_reduce_kernel(const uint64_t *__restrict__ new_keys, const uint64_t *__restrict__ new_off,
+                                                                        const uint64_t *__restrict__ old_keys, const uint32_t *__restrict__ old_vals,
+                                                                        const uint64_t *__restrict__ old_off, uint64_t *__restrict__ tmp_keys,
+                                                                        uint32_t *__restrict__ tmp_vals, uint32_t *__restrict__ out_cnt,
+                                                                        uint32_t *__restrict__ flags) {
+  KMI_TABLE_LDS(NW)
+  constexpr int CAP = TabCfg<NW>::CAP;
+  const uint32_t b = blockIdx.x;
+  const uint64_t nb = new_off[b], ne = new_off[b + 1];
+  const uint64_t ob = old_off ? old_off[b] : 0ull, oe = old_off ? old_off[b + 1] : 0ull;
+  if (nb == ne && ob == oe) { if (threadIdx.x == 0) out_cnt[b] = 0; return; }
+  const uint64_t tmp0 = nb + ob;
+  uint32_t *s_out = &s_ctl[4];
+  uint32_t npass = 1;
+  while (true) {
+    if (threadIdx.x == 0) *s_out = 0;
+    bool failed = false;
+    for (uint32_t pass = 0; pass < npass && !failed; ++pass) {
+      table_clear<NW>(tab);
+      __syncthreads();
+      for (uint64_t i = ob + threadIdx.x; i < oe; i += blockDim.x) {
+        uint64_t k[NW];
+#pragma unroll
+        for (int w = 0; w < NW; ++w) k[w] = old_keys[i * NW + w];
+        const uint32_t h = place_hash<NW>(k);
+        if (pass_of(h, npass) != pass) continue;
+        int s = table_upsert<NW>(tab, k, h);
+        if (s >= 0) atomicAdd(&tab.vals[s], old_vals[i]);
+        else if (s == -2) atomicAdd(tab.special, old_vals[i]);
+      }
+      for (uint64_t i = nb + threadIdx.x; i < ne; i += blockDim.x) {
+        uint64_t k[NW];
+#pragma unroll
+        for (int w = 0; w < NW; ++w) k[w] = new_keys[i * NW + w];
+        const uint32_t h = place_hash<NW>(k);
+        if (pass_of(h, npass) != pass) continue;
+        int s = table_upsert<NW>(tab, k, h);
+        if (s >= 0) atomicAdd(&tab.vals[s], 1u);
+        else if (s == -2) atomicAdd(tab.special, 1u);
+      }
+      __syncthreads();
+      if (*tab.overflow) { failed = true; break; }
+      for (int s = threadIdx.x; s < CAP; s += blockDim.x) {
+        const bool used = slot_used<NW>(tab, s);
+        const uint32_t pos = wave_alloc(s_out, used);
+        if (used) {
+#pragma unroll
+          for (int w = 0; w < NW; ++w) tmp_keys[(tmp0 + pos) * NW + w] = tab.keys[(uint64_t)s * NW + w];
+          tmp_vals[tmp0 + pos] = tab.vals[s];
+        }
+      }
+      __syncthreads();
+      if (NW == 1 && threadIdx.x == 0 && *tab.special_set) {
+        const uint32_t pos = atomicAdd(s_out, 1u);
+        tmp_keys[(tmp0 + pos) * NW] = kEmptyKey;
+        tmp_vals[tmp0 + pos] = *tab.special;
+      }
+      __syncthreads();
+    }
+    if (!failed) break;
+    npass *= 2;
+    if (npass > kMaxPasses) { if (threadIdx.x == 0) { atomicOr(&flags[2], 1u); *s_out = 0; } __syncthreads(); break; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out_cnt[b] = *s_out;
+}
+
+// scan of per-bucket counts -> offsets (kNumFine+1) ; totals[slot] = total
+__global__ __launch_bounds__(1024) void bucket_offsets_kernel(const uint32_t *__restrict__ cnt, uint64_t *__restrict__ off,
+                                                             uint64_t *__restrict__ totals, int slot) {
+  __shared__ uint64_t s_scan[1024 / 64 + 2];
+  constexpr int PER = kNumFine / 1024;
+  uint64_t loc[PER], sum = 0;
+#pragma unroll
+  for (int i = 0; i < PER; ++i) { loc[i] = cnt[threadIdx.x * PER + i]; sum += loc[i]; }
+  uint64_t total;
+  uint64_t o = block_exclusive_scan<uint64_t>(sum, s_scan, &total);
+#pragma unroll
+  for (int i = 0; i < PER; ++i) { off[threadIdx.x * PER + i] = o; o += loc[i]; }
+  if (threadIdx.x == 0) { off[kNumFine] = total; totals[slot] = total; }
+}
+
+// compaction copy: bucket b's `cnt[b]` entries from tmp (at src_off_a[b] + src_off_b[b]) to final (dst_off[b])
+template <int NW, typename V>
+__global__ __launch_bounds__(256) void bucket_compact_kernel(const uint64_t *__restrict__ tmp_keys, const V *__restrict__ tmp_vals,
+                                                            const uint64_t *__restrict__ src_off_a, const uint64_t *__restrict__ src_off_b,
+                                                            const uint64_t *__restrict__ dst_off, uint64_t *__restrict__ keys,
+                                                            V *__restrict__ vals) {
+  const uint32_t b = blockIdx.x;
+  const uint64_t d0 = dst_off[b], n = dst_off[b + 1] - d0;
+  const uint64_t s0 = src_off_a[b] + (src_off_b ? src_off_b[b] : 0ull);
+  for (uint64_t i = threadIdx.x; i < n * NW; i += blockDim.x) keys[d0 * NW + i] = tmp_keys[s0 * NW + i];
+  for (uint64_t i = threadIdx.x; i < n; i += blockDim.x) vals[d0 + i] = tmp_vals[s0 + i];
+}
+
+// ---------------------------------------------------------------------------
+// Q: per fine bucket query. mode 0 = count (emit every distinct query key with 0/1),
+// 1 = find (emit (key, stored count) of hits), 2 = erase (emit surviving index entries)
+// ---------------------------------------------------------------------------
+enum QueryMode { Q_COUNT = 0, Q_FIND = 1, Q_ERASE = 2 };
+
+template <int NW>
+__global__ __launch_bounds__((TabCfg<NW>::NT)) void bucket_query_kernel(int mode, const uint64_t *__restrict__ q_keys, const uint64_t *__restrict__ q_off,
+                                                                       const uint64_t *__restrict__ idx_keys, const uint32_t *__restrict__ idx_vals,
+                                                                       const uint64_t *__restrict__ idx_off, uint64_t *__restrict__ tmp_keys,
+                                                                       uint64_t *__restrict__ tmp_vals64, uint32_t *__restrict__ tmp_vals32,
+                                                                       uint32_t *__restrict__ out_cnt, uint32_t *__restrict__ flags) {
+  KMI_TABLE_LDS(NW)
+  constexpr int CAP = TabCfg<NW>::CAP;
+  const uint32_t b = blockIdx.x;
+  const uint64_t qb = q_off[b], qe = q_off[b + 1];
+  const uint64_t ib = idx_off ? idx_off[b] : 0ull, ie = idx_off ? idx_off[b + 1] : 0ull;
+  // output slot base: count/find results are bounded by the bucket's queries, erase survivors by its entries
+  const uint64_t tmp0 = (mode == Q_ERASE) ? ib : qb;
+  uint32_t *s_out = &s_ctl[4];
+  if (qb == qe) {
+    if (mode == Q_ERASE) {
+      // nothing to erase here: all entries survive
+      for (uint64_t i = threadIdx.x; i < (ie - ib) * NW; i += blockDim.x) tmp_keys[ib * NW + i] = idx_keys[ib * NW + i];
+      for (uint64_t i = threadIdx.x; i < (ie - ib); i += blockDim.x) tmp_vals32[ib + i] = idx_vals[ib + i];
+      if (threadIdx.x == 0) out_cnt[b] = (uint32_t)(ie - ib);
+    } else if (threadIdx.x == 0) out_cnt[b] = 0;
+    return;
+  }
+  uint32_t npass = 1;
+  while (true) {
+    if (threadIdx.x == 0) *s_out = 0;
+    bool failed = false;
+    for (uint32_t pass = 0; pass < npass && !failed; ++pass) {
+      table_clear<NW>(tab);
+      __syncthreads();
+      for (uint64_t i = qb + threadIdx.x; i < qe; i += blockDim.x) {
+        uint64_t k[NW];
+#pragma unroll
+        for (int w = 0; w < NW; ++w) k[w] = q_keys[i * NW + w];
+        const uint32_t h = place_hash<NW>(k);
+        if (pass_of(h, npass) != pass) continue;
+        (void)table_upsert<NW>(tab, k, h);
+      }
+      __syncthreads();
+      if (*tab.overflow) { failed = true; break; }
+      // stream the index bucket against the query table
+      for (uint64_t i = ib + threadIdx.x; i < ie; i += blockDim.x) {
+        uint64_t k[NW];
+#pragma unroll
+        for (int w = 0; w < NW; ++w) k[w] = idx_keys[i * NW + w];
+        const uint32_t h = place_hash<NW>(k);
+        if (pass_of(h, npass) != pass) continue;
+        const int s = table_find<NW>(tab, k, h);
+        const bool hit = (s >= 0) || (s == -2);
+        if (mode == Q_COUNT) {
+          if (s >= 0) tab.vals[s] = 1u; else if (s == -2) *tab.special = 1u;
+        } else if (mode == Q_FIND) {
+          const uint32_t pos = wave_alloc(s_out, hit);
+          if (hit) {
+#pragma unroll
+            for (int w = 0; w < NW; ++w) tmp_keys[(tmp0 + pos) * NW + w] = k[w];
+            tmp_vals64[tmp0 + pos] = idx_vals[i];
+          }
+        } else {
+          const uint32_t pos = wave_alloc(s_out, !hit);
+          if (!hit) {
+#pragma unroll
+            for (int w = 0; w < NW; ++w) tmp_keys[(tmp0 + pos) * NW + w] = k[w];
+            tmp_vals32[tmp0 + pos] = idx_vals[i];
+          }
+        }
+      }
+      __syncthreads();
+      if (mode == Q_COUNT) {
+        for (int s = threadIdx.x; s < CAP; s += blockDim.x) {
+          const bool used = slot_used<NW>(tab, s);
+          const uint32_t pos = wave_alloc(s_out, used);
+          if (used) {
+#pragma unroll
+            for (int w = 0; w < NW; ++w) tmp_keys[(tmp0 + pos) * NW + w] = tab.keys[(uint64_t)s * NW + w];
+            tmp_vals64[tmp0 + pos] = tab.vals[s];
+          }
+        }
+        if (NW == 1 && threadIdx.x == 0 && *tab.special_set) {
+          const uint32_t pos = atomicAdd(s_out, 1u);
+          tmp_keys[(tmp0 + pos) * NW] = kEmptyKey;
+          tmp_vals64[tmp0 + pos] = *tab.special;
+        }
+      }
+      __syncthreads();
+    }
+    if (!failed) break;
+    npass *= 2;
+    if (npass > kMaxPasses) { if (threadIdx.x == 0) { atomicOr(&flags[2], 1u); *s_out = 0; } __syncthreads(); break; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out_cnt[b] = *s_out;
+}
+
+}  // namespace kmi
+
+// ===========================================================================
+// host side
+// ===========================================================================
+using namespace kmi;
+
+struct kmi_index {
+  kmi_ctx *ctx = nullptr;
+  kmi_config cfg{};
+  KShape shape{};
+  uint64_t *keys = nullptr;       // [n_entries * n_words]
+  uint32_t *vals = nullptr;       // [n_entries]
+  uint64_t *bucket_off = nullptr; // [kNumFine + 1]
+  uint64_t n_entries = 0;
+  bool has_data = false;
+};
+
+namespace kmi {
+
+struct Partitioned {
+  uint64_t *keys;      // fine-partitioned keys (WS_KEYS_B or WS_QUERY_B)
+  uint64_t *fine_off;  // [kNumFine+1]
+};
+
+// K1 + offsets + K2 + P2 on `n` keys; result in slot `slot_b`, scratch in `slot_a`
+template <int NW, int BITS>
+static kmi_status partition_impl(kmi_ctx *ctx, const kmi_config *cfg, KShape shape, const uint64_t *keys_dev, size_t n, bool transform,
+                                 WsSlot slot_a, WsSlot slot_b, Partitioned *out) {
+  void *p;
+  const size_t key_bytes = (n ? n : 1) * NW * sizeof(uint64_t);
+  KMI_TRY(ws_get(ctx, slot_a, key_bytes, &p)); uint64_t *buf_a = (uint64_t *)p;
+  KMI_TRY(ws_get(ctx, slot_b, key_bytes, &p)); uint64_t *buf_b = (uint64_t *)p;
+  KMI_TRY(ws_get(ctx, WS_HIST, sizeof(uint32_t) * kNumFine + sizeof(uint64_t) * (kNumFine + 1) * 2 + 256, &p));
+  uint32_t *fine_hist = (uint32_t *)p;
+  // two offset arrays live behind the histogram: [0] for inserts, [1] for queries
+  uint64_t *fine_off = (uint64_t *)((char *)p + sizeof(uint32_t) * kNumFine) + (slot_b == WS_QUERY_B ? (kNumFine + 1) : 0);
+  KMI_TRY(ws_get(ctx, WS_WGHIST, sizeof(uint32_t) * kPartGroups * kNumCoarse, &p)); uint32_t *wg_hist = (uint32_t *)p;
+  KMI_TRY(ws_get(ctx, WS_CURSOR, sizeof(uint64_t) * kPartGroups * kNumCoarse, &p)); uint64_t *wg_off = (uint64_t *)p;
+  KMI_HIP(ctx, hipMemsetAsync(fine_hist, 0, sizeof(uint32_t) * kNumFine, ctx->stream));
+  {
+    ProfScope ps(ctx, "hist_fine", n);
+    hipLaunchKernelGGL((hist_fine_kernel<NW, BITS>), dim3(kPartGroups), dim3(kPartThreads), 0, ctx->stream, keys_dev, (uint64_t)n, shape,
+                       cfg->strand, transform, fine_hist, wg_hist);
+  }
+  {
+    ProfScope ps(ctx, "fine_offsets", kNumFine);
+    hipLaunchKernelGGL(fine_offsets_kernel, dim3(1), dim3(1024), 0, ctx->stream, fine_hist, wg_hist, (uint32_t)kPartGroups, fine_off, wg_off);
+  }
+  BucketFn fn; fn.mode = BUCKET_COARSE; fn.shape = shape; fn.dist_hash = 0; fn.farm_ndebug = false; fn.nranks = 1;
+  {
+    ProfScope ps(ctx, "scatter_coarse", n);
+    hipLaunchKernelGGL((scatter_chunks_kernel<NW, BITS>), dim3(kPartGroups), dim3(kPartThreads), 0, ctx->stream, keys_dev, (uint64_t)n, buf_a,
+                       shape, cfg->strand, transform, fn, wg_off);
+  }
+  {
+    ProfScope ps(ctx, "scatter_fine", n);
+    hipLaunchKernelGGL((scatter_fine_kernel<NW, BITS>), dim3(kNumCoarse), dim3(kPartThreads), 0, ctx->stream, buf_a, buf_b, shape, fine_off);
+  }
+  KMI_HIP(ctx, hipGetLastError());
+  out->keys = buf_b; out->fine_off = fine_off;
+  return KMI_OK;
+}
+
+static kmi_status read_total(kmi_ctx *ctx, int slot, uint64_t *v) {
+  uint32_t flag = 0;
+  KMI_HIP(ctx, hipMemcpyAsync(ctx->h_totals + slot, ctx->d_totals + slot, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+  KMI_HIP(ctx, hipMemcpyAsync(&flag, ctx->d_flags + 2, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+  KMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  *v = ctx->h_totals[slot];
+  if (flag) {
+    KMI_HIP(ctx, hipMemsetAsync(ctx->d_flags + 2, 0, sizeof(uint32_t), ctx->stream));
+    return set_err(ctx, KMI_ERR_OVERFLOW, "a bucket could not be reduced within the pass limit");
+  }
+  return KMI_OK;
+}
+
+// replace the index arrays by the compacted content of tmp
+template <int NW>
+static kmi_status adopt_tmp(kmi_index *idx, const uint64_t *tmp_keys, const uint32_t *tmp_vals, const uint64_t *src_a, const uint64_t *src_b,
+                            const uint32_t *out_cnt) {
+  kmi_ctx *ctx = idx->ctx;
+  uint64_t *new_off = nullptr;
+  KMI_HIP(ctx, hipMalloc((void **)&new_off, sizeof(uint64_t) * (kNumFine + 1)));
+  {
+    ProfScope ps(ctx, "bucket_offsets", kNumFine);
+    hipLaunchKernelGGL(bucket_offsets_kernel, dim3(1), dim3(1024), 0, ctx->stream, out_cnt, new_off, ctx->d_totals, 4);
+  }
+  uint64_t total = 0;
+  KMI_TRY(read_total(ctx, 4, &total));
+  uint64_t *nk = nullptr; uint32_t *nv = nullptr;
+  hipError_t e1 = hipMalloc((void **)&nk, (total ? total : 1) * NW * sizeof(uint64_t));
+  hipError_t e2 = hipMalloc((void **)&nv, (total ? total : 1) * sizeof(uint32_t));
+  if (e1 != hipSuccess || e2 != hipSuccess) {
+    if (nk) (void)hipFree(nk);
+    if (nv) (void)hipFree(nv);
+    (void)hipFree(new_off);
+    return set_err(ctx, KMI_ERR_NOMEM, "hipMalloc failed for the index arrays");
+  }
+  {
+    ProfScope ps(ctx, "bucket_compact", total);
+    hipLaunchKernelGGL((bucket_compact_kernel<NW, uint32_t>), dim3(kNumFine), dim3(256), 0, ctx->stream, tmp_keys, tmp_vals, src_a, src_b,
+                       (const uint64_t *)new_off, nk, nv);
+  }
+  KMI_HIP(ctx, hipGetLastError());
+  KMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (idx->keys) (void)hipFree(idx->keys);
+  if (idx->vals) (void)hipFree(idx->vals);
+  if (idx->bucket_off) (void)hipFree(idx->bucket_off);
+  idx->keys = nk; idx->vals = nv; idx->bucket_off = new_off; idx->n_entries = total; idx->has_data = true;
+  return KMI_OK;
+}
+
+template <int NW, int BITS>
+static kmi_status insert_impl(kmi_index *idx, const uint64_t *keys_dev, size_t n, bool transform) {
+  kmi_ctx *ctx = idx->ctx;
+  if (n == 0) return KMI_OK;
+  Partitioned part;
+  KMI_TRY((partition_impl<NW, BITS>(ctx, &idx->cfg, idx->shape, keys_dev, n, transform, WS_KEYS_A, WS_KEYS_B, &part)));
+  void *p;
+  const uint64_t cap = n + idx->n_entries;
+  KMI_TRY(ws_get(ctx, WS_TMP_KEYS, cap * NW * sizeof(uint64_t), &p)); uint64_t *tmp_keys = (uint64_t *)p;
+  KMI_TRY(ws_get(ctx, WS_TMP_VALS, cap * sizeof(uint64_t), &p)); uint32_t *tmp_vals = (uint32_t *)p;
+  KMI_TRY(ws_get(ctx, WS_BUCKET_CNT, sizeof(uint32_t) * kNumFine, &p)); uint32_t *out_cnt = (uint32_t *)p;
+  {
+    ProfScope ps(ctx, "bucket_reduce", n);
+    hipLaunchKernelGGL((bucket_reduce_kernel<NW>), dim3(kNumFine), dim3(TabCfg<NW>::NT), 0, ctx->stream, (const uint64_t *)part.keys,
+                       (const uint64_t *)part.fine_off, (const uint64_t *)idx->keys, (const uint32_t *)idx->vals,
+                       (const uint64_t *)(idx->has_data ? idx->bucket_off : nullptr), tmp_keys, tmp_vals, out_cnt, ctx->d_flags);
+  }
+  KMI_HIP(ctx, hipGetLastError());
+  return adopt_tmp<NW>(idx, tmp_keys, tmp_vals, part.fine_off, idx->has_data ? idx->bucket_off : nullptr, out_cnt);
+}
+
+static kmi_status index_insert(kmi_index *idx, const uint64_t *keys_dev, size_t n, bool transform) {
+  KMI_DISPATCH(idx->shape, insert_impl, idx, keys_dev, n, transform);
+}
+
+// queries: results compacted into out_keys_dev / out_vals_dev (u64), *n_out results
+template <int NW, int BITS>
+static kmi_status query_impl(kmi_index *idx, int mode, const uint64_t *q_dev, size_t nq, uint64_t *out_keys_dev, uint64_t *out_vals_dev,
+                             uint64_t *n_out) {
+  kmi_ctx *ctx = idx->ctx;
+  if (n_out) *n_out = 0;
+  if (nq == 0) return KMI_OK;
+  Partitioned part;
+  KMI_TRY((partition_impl<NW, BITS>(ctx, &idx->cfg, idx->shape, q_dev, nq, true, WS_QUERY_A, WS_QUERY_B, &part)));
+  void *p;
+  const uint64_t cap = (mode == Q_ERASE) ? std::max<uint64_t>(idx->n_entries, 1) : nq;
+  KMI_TRY(ws_get(ctx, WS_TMP_KEYS, cap * NW * sizeof(uint64_t), &p)); uint64_t *tmp_keys = (uint64_t *)p;
+  KMI_TRY(ws_get(ctx, WS_TMP_VALS, cap * sizeof(uint64_t), &p)); void *tmp_vals = p;
+  KMI_TRY(ws_get(ctx, WS_BUCKET_CNT, sizeof(uint32_t) * kNumFine, &p)); uint32_t *out_cnt = (uint32_t *)p;
+  {
+    ProfScope ps(ctx, mode == Q_COUNT ? "bucket_query_count" : (mode == Q_FIND ? "bucket_query_find" : "bucket_query_erase"), nq);
+    hipLaunchKernelGGL((bucket_query_kernel<NW>), dim3(kNumFine), dim3(TabCfg<NW>::NT), 0, ctx->stream, mode, (const uint64_t *)part.keys,
+                       (const uint64_t *)part.fine_off, (const uint64_t *)idx->keys, (const uint32_t *)idx->vals,
+                       (const uint64_t *)(idx->has_data ? idx->bucket_off : nullptr), tmp_keys, (uint64_t *)tmp_vals, (uint32_t *)tmp_vals,
+                       out_cnt, ctx->d_flags);
+  }
+  KMI_HIP(ctx, hipGetLastError());
+  if (mode == Q_ERASE) {
+    const uint64_t before = idx->n_entries;
+    if (!idx->has_data) return KMI_OK;
+    KMI_TRY((adopt_tmp<NW>(idx, tmp_keys, (const uint32_t *)tmp_vals, idx->bucket_off, nullptr, out_cnt)));
+    if (n_out) *n_out = before - idx->n_entries;
+    return KMI_OK;
+  }
+  KMI_TRY(ws_get(ctx, WS_BUCKET_OFF, sizeof(uint64_t) * (kNumFine + 1), &p)); uint64_t *res_off = (uint64_t *)p;
+  {
+    ProfScope ps(ctx, "bucket_offsets", kNumFine);
+    hipLaunchKernelGGL(bucket_offsets_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const uint32_t *)out_cnt, res_off, ctx->d_totals, 5);
+  }
+  {
+    ProfScope ps(ctx, "bucket_compact", nq);
+    hipLaunchKernelGGL((bucket_compact_kernel<NW, uint64_t>), dim3(kNumFine), dim3(256), 0, ctx->stream, (const uint64_t *)tmp_keys,
+                       (const uint64_t *)tmp_vals, (const uint64_t *)part.fine_off, (const uint64_t *)nullptr, (const uint64_t *)res_off,
+                       out_keys_dev, out_vals_dev);
+  }
+  KMI_HIP(ctx, hipGetLastError());
+  uint64_t total = 0;
+  KMI_TRY(read_total(ctx, 5, &total));
+  if (n_out) *n_out = total;
+  return KMI_OK;
+}
+
+static kmi_status index_query(kmi_index *idx, int mode, const uint64_t *q_dev, size_t nq, uint64_t *out_keys_dev, uint64_t *out_vals_dev,
+                              uint64_t *n_out) {
+  KMI_DISPATCH(idx->shape, query_impl, idx, mode, q_dev, nq, out_keys_dev, out_vals_dev, n_out);
+}
+
+// imxx::distribute bucketing by destination rank
+template <int NW, int BITS>
+static kmi_status route_impl(kmi_ctx *ctx, const kmi_config *cfg, KShape shape, const uint64_t *keys_dev, size_t n, uint32_t nranks,
+                             uint64_t *out_keys_dev, uint64_t *send_counts_host) {
+  void *p;
+  KMI_TRY(ws_get(ctx, WS_WGHIST, sizeof(uint32_t) * kPartGroups * kNumCoarse, &p)); uint32_t *wg_hist = (uint32_t *)p;
+  KMI_TRY(ws_get(ctx, WS_CURSOR, sizeof(uint64_t) * kPartGroups * kNumCoarse, &p)); uint64_t *wg_off = (uint64_t *)p;
+  KMI_TRY(ws_get(ctx, WS_MISC, sizeof(uint64_t) * kNumCoarse, &p)); uint64_t *cnt = (uint64_t *)p;
+  BucketFn fn; fn.mode = BUCKET_RANK; fn.shape = shape; fn.dist_hash = cfg->dist_hash; fn.farm_ndebug = cfg->farm_ndebug != 0; fn.nranks = nranks;
+  {
+    ProfScope ps(ctx, "hist_rank", n);
+    hipLaunchKernelGGL((hist_rank_kernel<NW, BITS>), dim3(kPartGroups), dim3(kPartThreads), 0, ctx->stream, keys_dev, (uint64_t)n, shape,
+                       cfg->strand, fn, wg_hist);
+  }
+  {
+    ProfScope ps(ctx, "rank_offsets", nranks);
+    hipLaunchKernelGGL(rank_offsets_kernel, dim3(1), dim3(256), 0, ctx->stream, (const uint32_t *)wg_hist, (uint32_t)kPartGroups, nranks, cnt, wg_off);
+  }
+  {
+    ProfScope ps(ctx, "scatter_rank", n);
+    hipLaunchKernelGGL((scatter_chunks_kernel<NW, BITS>), dim3(kPartGroups), dim3(kPartThreads), 0, ctx->stream, keys_dev, (uint64_t)n,
+                       out_keys_dev, shape, cfg->strand, true, fn, (const uint64_t *)wg_off);
+  }
+  KMI_HIP(ctx, hipGetLastError());
+  KMI_HIP(ctx, hipMemcpyAsync(send_counts_host, cnt, sizeof(uint64_t) * nranks, hipMemcpyDeviceToHost, ctx->stream));
+  KMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return KMI_OK;
+}
+
+}  // namespace kmi
+
+extern "C" {
+
+kmi_status kmi_route_dev(kmi_ctx *ctx, const kmi_config *cfg, const uint64_t *keys_dev, size_t n, uint32_t nranks,
+                         uint64_t *out_keys_dev, uint64_t *send_counts_host) {
+  if (!ctx) return KMI_ERR_INVALID;
+  KShape shape;
+  if (!valid_config(cfg, &shape)) return set_err(ctx, KMI_ERR_INVALID, "bad kmi_config");
+  if (nranks == 0 || nranks > (uint32_t)kNumCoarse || !send_counts_host) return set_err(ctx, KMI_ERR_INVALID, "nranks must be in 1..256");
+  KMI_HIP(ctx, hipSetDevice(ctx->device));
+  if (n == 0) { for (uint32_t r = 0; r < nranks; ++r) send_counts_host[r] = 0; return KMI_OK; }
+  KMI_DISPATCH(shape, route_impl, ctx, cfg, shape, keys_dev, n, nranks, out_keys_dev, send_counts_host);
+}
+
+kmi_status kmi_index_create(kmi_ctx *ctx, const kmi_config *cfg, kmi_index **out) {
+  if (!ctx || !out) return KMI_ERR_INVALID;
+  KShape shape;
+  if (!valid_config(cfg, &shape)) return set_err(ctx, KMI_ERR_INVALID, "bad kmi_config");
+  if (cfg->index_kind != KMI_INDEX_COUNT) return set_err(ctx, KMI_ERR_INVALID, "only the count index is implemented on the device yet");
+  kmi_index *idx = new kmi_index();
+  idx->ctx = ctx; idx->cfg = *cfg; idx->shape = shape;
+  *out = idx;
+  return KMI_OK;
+}
+
+kmi_status kmi_index_destroy(kmi_index *idx) {
+  if (!idx) return KMI_OK;
+  (void)hipSetDevice(idx->ctx->device);
+  (void)hipStreamSynchronize(idx->ctx->stream);
+  if (idx->keys) (void)hipFree(idx->keys);
+  if (idx->vals) (void)hipFree(idx->vals);
+  if (idx->bucket_off) (void)hipFree(idx->bucket_off);
+  delete idx;
+  return KMI_OK;
+}
+
+kmi_status kmi_index_insert_dev(kmi_index *idx, const uint64_t *kmers_dev, size_t n) {
+  if (!idx) return KMI_ERR_INVALID;
+  KMI_HIP(idx->ctx, hipSetDevice(idx->ctx->device));
+  return index_insert(idx, kmers_dev, n, true);
+}
+
+kmi_status kmi_index_insert_host(kmi_index *idx, const uint64_t *kmers, size_t n) {
+  if (!idx) return KMI_ERR_INVALID;
+  kmi_ctx *ctx = idx->ctx;
+  if (n == 0) return KMI_OK;
+  if (!kmers) return set_err(ctx, KMI_ERR_INVALID, "null buffer");
+  KMI_HIP(ctx, hipSetDevice(ctx->device));
+  void *din;
+  const size_t bytes = n * idx->shape.n_words * sizeof(uint64_t);
+  KMI_TRY(ws_get(ctx, WS_INPUT, bytes, &din));
+  KMI_HIP(ctx, hipMemcpyAsync(din, kmers, bytes, hipMemcpyHostToDevice, ctx->stream));
+  return index_insert(idx, (const uint64_t *)din, n, true);
+}
+
+kmi_status kmi_index_build_dev(kmi_index *idx, const uint8_t *bytes_dev, size_t n_bytes, uint64_t file_offset) {
+  if (!idx) return KMI_ERR_INVALID;
+  kmi_ctx *ctx = idx->ctx;
+  KMI_HIP(ctx, hipSetDevice(ctx->device));
+  if (n_bytes == 0) return KMI_OK;
+  uint64_t nt = 0, ns = 0;
+  KMI_TRY(extract_count(ctx, &idx->cfg, bytes_dev, n_bytes, &nt, &ns));
+  void *dk;
+  KMI_TRY(ws_get(ctx, WS_OUTPUT, (size_t)(nt ? nt : 1) * idx->shape.n_words * sizeof(uint64_t), &dk));
+  KMI_TRY(extract_run(ctx, &idx->cfg, bytes_dev, n_bytes, file_offset, (uint64_t *)dk, nullptr, (size_t)nt, true, &nt, &ns));
+  return index_insert(idx, (const uint64_t *)dk, (size_t)nt, false);
+}
+
+kmi_status kmi_index_build_host(kmi_index *idx, const uint8_t *bytes, size_t n_bytes, uint64_t file_offset) {
+  if (!idx) return KMI_ERR_INVALID;
+  kmi_ctx *ctx = idx->ctx;
+  if (n_bytes == 0) return KMI_OK;
+  if (!bytes) return set_err(ctx, KMI_ERR_INVALID, "null buffer");
+  KMI_HIP(ctx, hipSetDevice(ctx->device));
+  void *din;
+  KMI_TRY(ws_get(ctx, WS_INPUT, n_bytes + 64, &din));
+  KMI_HIP(ctx, hipMemcpyAsync(din, bytes, n_bytes, hipMemcpyHostToDevice, ctx->stream));
+  return kmi_index_build_dev(idx, (const uint8_t *)din, n_bytes, file_offset);
+}
+
+kmi_status kmi_index_local_size(kmi_index *idx, uint64_t *n) {
+  if (!idx || !n) return KMI_ERR_INVALID;
+  *n = idx->n_entries;
+  return KMI_OK;
+}
+
+kmi_status kmi_index_export_host(kmi_index *idx, uint64_t *keys, uint32_t *counts, size_t capacity, uint64_t *n) {
+  if (!idx || !n) return KMI_ERR_INVALID;
+  kmi_ctx *ctx = idx->ctx;
+  *n = 0;
+  if (idx->n_entries == 0) return KMI_OK;
+  if (capacity < idx->n_entries) return set_err(ctx, KMI_ERR_OVERFLOW, "export: capacity too small");
+  KMI_HIP(ctx, hipSetDevice(ctx->device));
+  if (keys) KMI_HIP(ctx, hipMemcpyAsync(keys, idx->keys, idx->n_entries * idx->shape.n_words * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+  if (counts) KMI_HIP(ctx, hipMemcpyAsync(counts, idx->vals, idx->n_entries * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+  KMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  *n = idx->n_entries;
+  return KMI_OK;
+}
+
+void kmi_results_free(kmi_results *r) {
+  if (!r) return;
+  free(r->keys); free(r->values);
+  memset(r, 0, sizeof(*r));
+}
+
+static kmi_status query_host(kmi_index *idx, int mode, const uint64_t *queries, size_t nq, kmi_results *out, uint64_t *n_erased) {
+  if (!idx) return KMI_ERR_INVALID;
+  kmi_ctx *ctx = idx->ctx;
+  if (out) memset(out, 0, sizeof(*out));
+  if (n_erased) *n_erased = 0;
+  if (nq == 0) return KMI_OK;
+  if (!queries) return set_err(ctx, KMI_ERR_INVALID, "null buffer");
+  KMI_HIP(ctx, hipSetDevice(ctx->device));
+  const uint32_t nw = idx->shape.n_words;
+  void *dq, *dk = nullptr, *dv = nullptr;
+  KMI_TRY(ws_get(ctx, WS_INPUT, nq * nw * sizeof(uint64_t), &dq));
+  KMI_HIP(ctx, hipMemcpyAsync(dq, queries, nq * nw * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+  if (mode != Q_ERASE) {
+    KMI_TRY(ws_get(ctx, WS_OUTPUT, nq * nw * sizeof(uint64_t), &dk));
+    KMI_TRY(ws_get(ctx, WS_OUTPUT2, nq * sizeof(uint64_t), &dv));
+  }
+  uint64_t n = 0;
+  KMI_TRY(index_query(idx, mode, (const uint64_t *)dq, nq, (uint64_t *)dk, (uint64_t *)dv, &n));
+  if (mode == Q_ERASE) { if (n_erased) *n_erased = n; return KMI_OK; }
+  out->n = n;
+  out->keys = (uint64_t *)malloc((n ? n : 1) * nw * sizeof(uint64_t));
+  out->values = (uint64_t *)malloc((n ? n : 1) * sizeof(uint64_t));
+  if (!out->keys || !out->values) return set_err(ctx, KMI_ERR_NOMEM, "host malloc failed");
+  if (n) {
+    KMI_HIP(ctx, hipMemcpyAsync(out->keys, dk, n * nw * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+    KMI_HIP(ctx, hipMemcpyAsync(out->values, dv, n * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+    KMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  return KMI_OK;
+}
+
+kmi_status kmi_index_count_host(kmi_index *idx, const uint64_t *queries, size_t nq, kmi_results *out) {
+  if (!out) return KMI_ERR_INVALID;
+  return query_host(idx, Q_COUNT, queries, nq, out, nullptr);
+}
+kmi_status kmi_index_find_host(kmi_index *idx, const uint64_t *queries, size_t nq, kmi_results *out) {
+  if (!out) return KMI_ERR_INVALID;
+  return query_host(idx, Q_FIND, queries, nq, out, nullptr);
+}
+kmi_status kmi_index_erase_host(kmi_index *idx, const uint64_t *queries, size_t nq, uint64_t *n_erased) {
+  return query_host(idx, Q_ERASE, queries, nq, nullptr, n_erased);
+}
+kmi_status kmi_index_count_dev(kmi_index *idx, const uint64_t *queries_dev, size_t nq, uint64_t *out_keys_dev, uint64_t *out_values_dev,
+                               uint64_t *n_out) {
+  if (!idx) return KMI_ERR_INVALID;
+  KMI_HIP(idx->ctx, hipSetDevice(idx->ctx->device));
+  return index_query(idx, Q_COUNT, queries_dev, nq, out_keys_dev, out_values_dev, n_out);
+}
+kmi_status kmi_index_find_dev(kmi_index *idx, const uint64_t *queries_dev, size_t nq, uint64_t *out_keys_dev, uint64_t *out_values_dev,
+                              uint64_t *n_out) {
+  if (!idx) return KMI_ERR_INVALID;
+  KMI_HIP(idx->ctx, hipSetDevice(idx->ctx->device));
+  return index_query(idx, Q_FIND, queries_dev, nq, out_keys_dev, out_values_dev, n_out);
+}
+
+}  // extern "C"

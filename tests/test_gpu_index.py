@@ -1,0 +1,194 @@
+"""GPU parity of the count index (insert / build / count / find / erase / to_vector) through
+the C ABI against the CPU oracle's restatement of counting_unordered_map."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from tests import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+ALPHA = {"DNA": orc.DNA, "DNA5": orc.DNA5}
+STRAND = {"single": orc.SINGLE, "canonical": orc.CANONICAL, "bimolecule": orc.BIMOLECULE}
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import kmerind_amd as K
+    c = K.Context(0)
+    yield c
+    c.close()
+
+
+def _same_map(idx, omap):
+    keys, counts = idx.to_vector()
+    ok, oc = omap.export()
+    assert keys.shape == ok.shape
+    a = orc.sorted_pairs(keys, counts)
+    b = orc.sorted_pairs(ok, oc)
+    assert (a[0] == b[0]).all() and (a[1] == b[1]).all()
+
+
+def test_known_answers_count_index(ctx):
+    import kmerind_amd as K
+    ka = json.load(open(os.path.join(GOLD, "survey_known_answers.json")))
+    for case in ka["count_index"]:
+        data = open(os.path.join(GOLD, "data", case["file"]), "rb").read()
+        for strand, key in (("single", "min_single"), ("canonical", "min_canonical")):
+            idx = K.CountIndex(ctx, K.make_config(case["k"], "DNA", strand=strand))
+            idx.build(data)
+            keys, counts = idx.to_vector()
+            assert idx.local_size() == case["distinct"] == keys.shape[0]
+            assert set(counts.tolist()) == {case["each_count"]}
+            if key in case:
+                assert int(keys[:, 0].min()) == int(case[key], 16)
+            idx.close()
+
+
+@pytest.mark.parametrize("k,alpha", [(31, "DNA"), (21, "DNA"), (32, "DNA"), (63, "DNA"), (63, "DNA5"), (21, "DNA5"), (96, "DNA")])
+@pytest.mark.parametrize("strand", ["single", "canonical", "bimolecule"])
+def test_build_matches_oracle(ctx, k, alpha, strand):
+    import kmerind_amd as K
+    s = orc.kspec(k, ALPHA[alpha])
+    data = K.synth_fastq(seed=k, genome_len=4000, n_reads=1500)   # ~50x coverage: many repeats
+    cfg = K.make_config(k, alpha, strand=strand)
+    ex = orc.extract(s, data, orc.FASTQ)
+    om = orc.CountMap(s, STRAND[strand])
+    om.insert(ex["kmers"])
+    idx = K.CountIndex(ctx, cfg)
+    idx.build(data)
+    _same_map(idx, om)
+    # second batch through insert(): counts accumulate, new keys appear
+    data2 = K.synth_fastq(seed=k, genome_len=4000, n_reads=700, first_read=1000)
+    ex2 = orc.extract(s, data2, orc.FASTQ)
+    om.insert(ex2["kmers"])
+    idx.insert(ex2["kmers"])
+    _same_map(idx, om)
+    idx.close()
+
+
+def test_queries_match_oracle(ctx):
+    import kmerind_amd as K
+    for k, alpha, strand in ((31, "DNA", "canonical"), (63, "DNA5", "canonical"), (31, "DNA", "single"), (63, "DNA", "bimolecule")):
+        s = orc.kspec(k, ALPHA[alpha])
+        rng = np.random.default_rng(k)
+        data = K.synth_fastq(seed=9, genome_len=20000, n_reads=2000)
+        ex = orc.extract(s, data, orc.FASTQ)
+        om = orc.CountMap(s, STRAND[strand])
+        om.insert(ex["kmers"])
+        idx = K.CountIndex(ctx, K.make_config(k, alpha, strand=strand))
+        idx.insert(ex["kmers"])
+        present = ex["kmers"][rng.integers(0, ex["kmers"].shape[0], size=5000)]
+        absent = orc.extract(s, K.synth_fastq(seed=77, genome_len=20000, n_reads=40), orc.FASTQ)["kmers"]
+        q = np.concatenate([present, absent, present[:100]])
+        for fn in ("count", "find"):
+            gk, gv = getattr(idx, fn)(q)
+            ok, ov = getattr(om, fn)(q)
+            a, b = orc.sorted_pairs(gk, gv), orc.sorted_pairs(ok, ov.astype(np.uint64))
+            assert a[0].shape == b[0].shape, (fn, k)
+            assert (a[0] == b[0]).all() and (a[1] == b[1]).all(), (fn, k)
+        # erase a subset, then the maps must still agree
+        er = present[:2000]
+        n_gpu = idx.erase(er)
+        n_cpu = om.erase(er)
+        assert n_gpu == n_cpu
+        _same_map(idx, om)
+        gk, gv = idx.count(q)
+        ok, ov = om.count(q)
+        a, b = orc.sorted_pairs(gk, gv), orc.sorted_pairs(ok, ov)
+        assert (a[0] == b[0]).all() and (a[1] == b[1]).all()
+        idx.close()
+
+
+def test_empty_and_tiny_inputs(ctx):
+    import kmerind_amd as K
+    cfg = K.make_config(31, "DNA")
+    idx = K.CountIndex(ctx, cfg)
+    assert idx.local_size() == 0
+    idx.insert(np.zeros((0, 1), dtype=np.uint64))
+    idx.build(b"")
+    k, v = idx.count(np.array([[5]], dtype=np.uint64))
+    assert k.shape[0] == 1 and v.tolist() == [0]
+    k, v = idx.find(np.array([[5]], dtype=np.uint64))
+    assert k.shape[0] == 0
+    assert idx.erase(np.array([[5]], dtype=np.uint64)) == 0
+    idx.insert(np.array([[5], [5], [7]], dtype=np.uint64))
+    keys, counts = idx.to_vector()
+    s = orc.kspec(31)
+    exp = orc.canonical(s, np.array([[5], [7]], dtype=np.uint64))
+    a = orc.sorted_pairs(keys, counts)
+    b = orc.sorted_pairs(exp, np.array([2, 1], dtype=np.uint32))
+    assert (a[0] == b[0]).all() and (a[1] == b[1]).all()
+    idx.close()
+
+
+def test_all_ones_key_and_heavy_hitter(ctx):
+    """k=32 single strand: the all-T k-mer is the LDS table's empty sentinel; one key repeated 200k times"""
+    import kmerind_amd as K
+    cfg = K.make_config(32, "DNA", strand="single")
+    idx = K.CountIndex(ctx, cfg)
+    allT = np.uint64(0xFFFFFFFFFFFFFFFF)
+    rng = np.random.default_rng(1)
+    other = rng.integers(0, 1 << 62, size=5000, dtype=np.uint64)
+    keys = np.concatenate([np.full(200_000, allT, dtype=np.uint64), other, np.full(3, np.uint64(12345))]).reshape(-1, 1)
+    idx.insert(keys)
+    s = orc.kspec(32)
+    om = orc.CountMap(s, orc.SINGLE)
+    om.insert(keys)
+    _same_map(idx, om)
+    gk, gv = idx.find(np.array([[allT], [12345], [999]], dtype=np.uint64))
+    got = dict(zip(gk[:, 0].tolist(), gv.tolist()))
+    assert got == {int(allT): 200_000, 12345: 3}
+    idx.close()
+
+
+def test_many_distinct_keys_multi_pass_buckets(ctx):
+    """3M distinct keys -> ~92 per fine bucket is easy; force table overflow with 40M? no: use a
+    skewed set where one fine bucket gets > table capacity distinct keys."""
+    import kmerind_amd as K
+    from kmerind_amd import core
+    cfg = K.make_config(31, "DNA", strand="single")
+    rng = np.random.default_rng(5)
+    keys = rng.integers(0, 1 << 62, size=3_000_000, dtype=np.uint64).reshape(-1, 1)
+    idx = K.CountIndex(ctx, cfg)
+    idx.insert(keys)
+    uk, uc = np.unique(keys[:, 0], return_counts=True)
+    gk, gc = idx.to_vector()
+    order = np.argsort(gk[:, 0])
+    assert (gk[order, 0] == uk).all() and (gc[order] == uc).all()
+    idx.close()
+
+
+def test_route_matches_key_to_rank(ctx):
+    import ctypes as C
+    import kmerind_amd as K
+    from kmerind_amd import _lib as L
+    for k, alpha, strand, dh in ((31, "DNA", "canonical", "murmur"), (63, "DNA5", "bimolecule", "farm"), (21, "DNA", "single", "murmur")):
+        cfg = K.make_config(k, alpha, strand=strand, dist_hash=dh)
+        s = orc.kspec(k, ALPHA[alpha])
+        ex = orc.extract(s, K.synth_fastq(seed=3, genome_len=50000, n_reads=800), orc.FASTQ)["kmers"]
+        n, nw = ex.shape
+        for p in (1, 2, 5, 8):
+            din, dout = ctx.alloc(ex.nbytes), ctx.alloc(ex.nbytes)
+            ctx.to_device(din, ex)
+            counts = np.zeros(p, dtype=np.uint64)
+            ctx.check(L.lib.kmi_route_dev(ctx.h, C.byref(cfg), C.c_void_p(din), n, p, C.c_void_p(dout),
+                                          counts.ctypes.data_as(C.c_void_p)))
+            out = np.zeros_like(ex)
+            ctx.to_host(out, dout)
+            ctx.free(din); ctx.free(dout)
+            # reference: transform_input, then rank = DistHash(DistTrans(key)) % p
+            tk = ex if strand == "single" else orc.canonical(s, ex)
+            ranks = orc.key_to_rank(s, orc.MURMUR if dh == "murmur" else orc.FARM, STRAND[strand], tk, p)
+            assert counts.tolist() == np.bincount(ranks, minlength=p).tolist()
+            off = 0
+            for r in range(p):
+                seg = out[off:off + int(counts[r])]
+                exp = tk[ranks == r]
+                a = seg[np.lexsort([seg[:, w] for w in range(nw)])]
+                b = exp[np.lexsort([exp[:, w] for w in range(nw)])]
+                assert (a == b).all()
+                off += int(counts[r])
