@@ -1,0 +1,172 @@
+#!/usr/bin/env python3
+"""k-mers/s indexed (k=31 DNA CountIndex, 150 bp synthetic FASTQ) on N MI355X GPUs.
+
+One step = one pass of the hot path over one batch: FASTQ bytes resident in HBM ->
+k-mer extraction -> canonical strand -> (N>1: KeyToRank routing + RCCL all-to-all) ->
+count-index build. N=1 workload = BASELINE.json configs[1]: 10 M reads / 1.2e9 k-mers.
+N>1 is weak scaling: every rank gets its own 10 M reads of a genome N times as long.
+
+Prints ONE JSON line (rank 0) with `roofline` (dominant kernel, HIP-event timed on the
+launch stream inside the timed region) and `cpu_baseline` (the oracle's restatement of
+the reference MPI path on the host cores, bounded sample)."""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+B_ALG = 10.625          # algorithmic HBM bytes read per k-mer: 315/120 + 8
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--reads", type=int, default=10_000_000, help="reads per GPU (config 2: 10 M)")
+    ap.add_argument("--genome", type=int, default=100_000_000, help="genome bases per GPU")
+    ap.add_argument("--k", type=int, default=31)
+    ap.add_argument("--cpu-sample-reads", type=int, default=500_000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import kmerind_amd as K
+    from kmerind_amd import _lib as L
+    from kmerind_amd import dist as kdist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    k, read_len = args.k, 150
+    kmers_per_read = read_len - k + 1
+    n_reads = args.reads
+    genome_len = args.genome * world
+    seed = 2 if world == 1 else 3
+
+    stream = torch.cuda.current_stream(dev)
+    ctx = K.Context(device=local_rank, rank=rank, nranks=world, stream=stream.cuda_stream)
+    cfg = K.make_config(k, "DNA", strand="canonical", dist_hash="murmur", store_hash="murmur")
+
+    host = K.synth_fastq(seed, genome_len, n_reads, read_len, first_read=rank * n_reads)
+    nbytes = int(host.nbytes)
+    d_bytes = torch.from_numpy(host).to(dev)
+    idx = K.CountIndex(ctx, cfg)
+    n_kmers = n_reads * kmers_per_read
+
+    if world > 1:
+        d_keys = torch.empty((n_kmers, 1), dtype=torch.int64, device=dev)
+        d_send = torch.empty((n_kmers, 1), dtype=torch.int64, device=dev)
+        counts = np.zeros(world, dtype=np.uint64)
+        nt, ns = C.c_uint64(), C.c_uint64()
+
+    def step():
+        idx.clear()
+        if world == 1:
+            idx.build_device(d_bytes.data_ptr(), nbytes)
+            return
+        ctx.check(L.lib.kmi_extract_dev(ctx.h, C.byref(cfg), C.c_void_p(d_bytes.data_ptr()), nbytes, 0,
+                                        C.c_void_p(d_keys.data_ptr()), None, n_kmers, C.byref(nt), C.byref(ns)))
+        ctx.check(L.lib.kmi_route_dev(ctx.h, C.byref(cfg), C.c_void_p(d_keys.data_ptr()), nt.value, world,
+                                      C.c_void_p(d_send.data_ptr()), counts.ctypes.data_as(C.c_void_p)))
+        recv, _ = kdist.exchange_keys(d_send[: nt.value], [int(c) for c in counts])
+        idx.insert_device(recv.data_ptr(), recv.shape[0])
+
+    def sync():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    ctx.profile(True)
+    ctx.profile_reset()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    prof = ctx.profile_get()
+    ctx.profile(False)
+
+    local_distinct = idx.local_size()
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        distinct = kdist.global_size(local_distinct, device=dev)
+    else:
+        distinct = local_distinct
+
+    if rank == 0:
+        total_kmers = n_kmers * world
+        ms_per_step = elapsed * 1e3 / args.steps
+        value = total_kmers * args.steps / elapsed
+        prof = [p for p in prof if p["launches"] > 0]
+        dom = max(prof, key=lambda p: p["total_ms"]) if prof else None
+        roofline = None
+        if dom:
+            avg_ms = dom["total_ms"] / dom["launches"]
+            achieved = n_kmers * B_ALG / (avg_ms * 1e-3) / 1e9
+            roofline = {"bound": "hbm", "kernel": dom["name"], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                        "avg_kernel_ms": round(avg_ms, 4),
+                        "alg_bytes_per_launch": n_kmers * B_ALG,
+                        "pipeline_frac": round(n_kmers * B_ALG / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                        "kernels_ms_per_step": {p["name"]: round(p["total_ms"] / args.steps, 4) for p in
+                                                sorted(prof, key=lambda p: -p["total_ms"])}}
+        out = {"metric": "kmers_per_sec_indexed", "value": value, "unit": "k-mers/s", "n_gpus": world,
+               "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+               "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+               "config": {"workload": "k=%d DNA CountIndex (canonical), %d synthetic %d-bp reads per GPU as 315-byte "
+                                      "FASTQ records, genome %d bp, seed %d" % (k, n_reads, read_len, genome_len, seed),
+                          "kmers_per_step": total_kmers, "distinct_kmers": distinct,
+                          "exchange": "none (1 rank)" if world == 1 else "RCCL all_to_all_single (counts + payload)"},
+               "roofline": roofline}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(host, args, k, n_reads)
+        print(json.dumps(out), flush=True)
+
+    idx.close()
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(host, args, k, n_reads):
+    """oracle = CPU restatement of the reference path (thread ranks + in-memory all-to-all),
+    timed on the host cores over the first `cpu_sample_reads` reads of the same FASTQ."""
+    from tests import oracle as orc
+    sample = min(args.cpu_sample_reads, n_reads)
+    # the GPU box gives one GPU a 16-core CPU share even though more logical CPUs are visible
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = max(1, min(avail, 16))
+    rec = 315
+    sec, nk, nd = orc.bench_count_index(host[: sample * rec], k, orc.CANONICAL, cores)
+    return {"value": nk / sec, "unit": "k-mers/s", "cores": cores, "kind": "port",
+            "sample": "first %d reads (%d k-mers) of the same FASTQ; %d thread-ranks, murmur KeyToRank + in-memory "
+                      "all-to-all + chained hash map; %.2f s" % (sample, nk, cores, sec)}
+
+
+if __name__ == "__main__":
+    main()

@@ -141,6 +141,8 @@ kmi_status kmi_index_insert_dev(kmi_index *idx, const uint64_t *kmers_dev, size_
  * device (kmer_index.hpp:239-372). */
 kmi_status kmi_index_build_host(kmi_index *idx, const uint8_t *bytes, size_t n_bytes, uint64_t file_offset);
 kmi_status kmi_index_build_dev(kmi_index *idx, const uint8_t *bytes_dev, size_t n_bytes, uint64_t file_offset);
+/* MapType::clear() (distributed_map_base.hpp:267-272) */
+kmi_status kmi_index_clear(kmi_index *idx);
 /* MapType::local_size() / size() on one rank (distributed_map_base.hpp:227-245) */
 kmi_status kmi_index_local_size(kmi_index *idx, uint64_t *n);
 /* MapType::to_vector() (distributed_map_base.hpp:202-217): keys n*n_words, counts n; order unspecified */

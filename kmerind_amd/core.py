@@ -177,6 +177,9 @@ class CountIndex:
     def build_device(self, dptr, nbytes, file_offset=0):
         self.ctx.check(lib.kmi_index_build_dev(self.h, C.c_void_p(dptr), nbytes, file_offset))
 
+    def clear(self):
+        self.ctx.check(lib.kmi_index_clear(self.h))
+
     def local_size(self):
         n = C.c_uint64()
         self.ctx.check(lib.kmi_index_local_size(self.h, C.byref(n)))

@@ -734,7 +734,7 @@ static kmi_status insert_impl(kmi_index *idx, const uint64_t *keys_dev, size_t n
   void *p;
   const uint64_t cap = n + idx->n_entries;
   KMI_TRY(ws_get(ctx, WS_TMP_KEYS, cap * NW * sizeof(uint64_t), &p)); uint64_t *tmp_keys = (uint64_t *)p;
-  KMI_TRY(ws_get(ctx, WS_TMP_VALS, cap * sizeof(uint64_t), &p)); uint32_t *tmp_vals = (uint32_t *)p;
+  KMI_TRY(ws_get(ctx, WS_TMP_VALS, cap * sizeof(uint32_t), &p)); uint32_t *tmp_vals = (uint32_t *)p;
   KMI_TRY(ws_get(ctx, WS_BUCKET_CNT, sizeof(uint32_t) * kNumFine, &p)); uint32_t *out_cnt = (uint32_t *)p;
   {
     ProfScope ps(ctx, "bucket_reduce", n);
@@ -910,6 +910,18 @@ kmi_status kmi_index_build_host(kmi_index *idx, const uint8_t *bytes, size_t n_b
   KMI_TRY(ws_get(ctx, WS_INPUT, n_bytes + 64, &din));
   KMI_HIP(ctx, hipMemcpyAsync(din, bytes, n_bytes, hipMemcpyHostToDevice, ctx->stream));
   return kmi_index_build_dev(idx, (const uint8_t *)din, n_bytes, file_offset);
+}
+
+kmi_status kmi_index_clear(kmi_index *idx) {
+  if (!idx) return KMI_ERR_INVALID;
+  kmi_ctx *ctx = idx->ctx;
+  KMI_HIP(ctx, hipSetDevice(ctx->device));
+  KMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (idx->keys) (void)hipFree(idx->keys);
+  if (idx->vals) (void)hipFree(idx->vals);
+  if (idx->bucket_off) (void)hipFree(idx->bucket_off);
+  idx->keys = nullptr; idx->vals = nullptr; idx->bucket_off = nullptr; idx->n_entries = 0; idx->has_data = false;
+  return KMI_OK;
 }
 
 kmi_status kmi_index_local_size(kmi_index *idx, uint64_t *n) {

@@ -50,8 +50,15 @@ void *worker(void *vp) {
     p += 9; *p++ = '\n';
     const uint64_t start = splitmix64(rs + 64 * r) % (g.genome_len - L + 1);
     const bool rc = splitmix64(rs + 64 * r + 1) & 1;
-    if (!rc) for (uint32_t i = 0; i < L; ++i) p[i] = (uint8_t)ACGT[g.base(start + i, gs)];
-    else for (uint32_t i = 0; i < L; ++i) p[i] = (uint8_t)ACGT[3u - g.base(start + L - 1 - i, gs)];
+    {
+      // walk the genome words once (32 bases per splitmix64 call)
+      uint64_t gi = start, word = splitmix64(gs + (gi >> 5));
+      for (uint32_t i = 0; i < L; ++i, ++gi) {
+        if ((gi & 31) == 0 && i) word = splitmix64(gs + (gi >> 5));
+        const uint32_t c = (uint32_t)(word >> (2 * (gi & 31))) & 3u;
+        if (!rc) p[i] = (uint8_t)ACGT[c]; else p[L - 1 - i] = (uint8_t)ACGT[3u - c];
+      }
+    }
     p += L; *p++ = '\n'; *p++ = '+'; *p++ = '\n';
     for (uint32_t i = 0; i < L; i += 8) {
       uint64_t q = splitmix64(rs + 64 * r + 2 + (i >> 3));

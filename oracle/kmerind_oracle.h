@@ -78,6 +78,9 @@ void orc_kmer_from_ascii(const orc_kspec *s, const uint8_t *chars, uint64_t *out
 /* batch forms over n k-mers stored contiguously (n * n_words words) */
 void orc_kmers_revcomp(const orc_kspec *s, const uint64_t *in, size_t n, uint64_t *out);
 void orc_kmers_canonical(const orc_kspec *s, const uint64_t *in, size_t n, uint64_t *out);
+/* SWAR form the reference executes for DNA (bitgroup_ops.hpp:489-515); baseline driver only */
+void orc_kmer_revcomp_fast(const orc_kspec *s, const uint64_t *in, uint64_t *out);
+void orc_kmers_revcomp_fast(const orc_kspec *s, const uint64_t *in, size_t n, uint64_t *out);
 
 /* ---- hashes */
 /* MurmurHash3_x64_128: ext/smhasher/MurmurHash3.cpp:255-335 */
