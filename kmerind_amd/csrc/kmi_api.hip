@@ -249,7 +249,7 @@ kmi_status kmi_extract_dev(kmi_ctx *ctx, const kmi_config *cfg, const uint8_t *b
                            uint64_t *n_tuples, uint64_t *n_seqs) {
   if (!ctx) return KMI_ERR_INVALID;
   KMI_HIP(ctx, hipSetDevice(ctx->device));
-  return extract_run(ctx, cfg, bytes_dev, n_bytes, file_offset, out_kmers_dev, out_ids_dev, out_capacity, false, n_tuples,
+  return extract_run(ctx, cfg, bytes_dev, n_bytes, file_offset, out_kmers_dev, out_ids_dev, out_capacity, false, false, n_tuples,
                      n_seqs);
 }
 
@@ -270,7 +270,7 @@ kmi_status kmi_extract_host(kmi_ctx *ctx, const kmi_config *cfg, const uint8_t *
   void *dout;
   const size_t out_bytes = (size_t)nt * shape.n_words * sizeof(uint64_t);
   KMI_TRY(ws_get(ctx, WS_OUTPUT, out_bytes, &dout));
-  KMI_TRY(extract_run(ctx, cfg, (const uint8_t *)din, n_bytes, file_offset, (uint64_t *)dout, nullptr, (size_t)nt, false, &nt,
+  KMI_TRY(extract_run(ctx, cfg, (const uint8_t *)din, n_bytes, file_offset, (uint64_t *)dout, nullptr, (size_t)nt, false, true, &nt,
                       &ns));
   out->n_tuples = nt; out->n_seqs = ns;
   out->kmers = (uint64_t *)malloc(out_bytes ? out_bytes : 8);

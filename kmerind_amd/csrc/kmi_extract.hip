@@ -199,41 +199,77 @@ __global__ __launch_bounds__((ExCfg<NW, BITS>::NT)) void fastq_scan_tiles_kernel
 }
 
 // ---------------------------------------------------------------------------
-// pass 2: one workgroup scans the tile records
+// pass 2: offsets over tiles. A tile maps the incoming line count b (mod 4) to b + lines and
+// contributes win[(2 - b) & 3] tuples, so a run of tiles is summarised by (lines, tuples for
+// each of the 4 possible incoming phases) and the summaries compose associatively:
+//   (a) every block of 1024 tiles reduces to one summary,
+//   (b) one workgroup scans the block summaries,
+//   (c) every block re-scans its tiles from the block's base.
 // totals[0] = lines, totals[1] = tuples, totals[2] = sequences (lines with index % 4 == 1)
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void fastq_scan_offsets_kernel(const TileInfo *__restrict__ info, uint64_t n_tiles,
-                                                                 uint32_t *__restrict__ line_base,
-                                                                 uint64_t *__restrict__ out_off,
+struct TileSum { uint64_t lines; uint64_t cnt[4]; };
+
+__global__ __launch_bounds__(1024) void fastq_offsets_reduce_kernel(const TileInfo *__restrict__ info, uint64_t n_tiles,
+                                                                   TileSum *__restrict__ sums) {
+  __shared__ uint32_t s_scan[1024 / 64 + 2];
+  __shared__ uint32_t s_cnt[4];
+  const uint64_t t = (uint64_t)blockIdx.x * 1024 + threadIdx.x;
+  TileInfo ti; ti.lines = 0; ti.win[0] = ti.win[1] = ti.win[2] = ti.win[3] = 0;
+  if (t < n_tiles) ti = info[t];
+  if (threadIdx.x < 4) s_cnt[threadIdx.x] = 0;
+  uint32_t tot;
+  const uint32_t lb = block_exclusive_scan<uint32_t>(ti.lines, s_scan, &tot);
+#pragma unroll
+  for (uint32_t r = 0; r < 4; ++r) {
+    uint32_t c = wave_reduce_sum(ti.win[(2u - r - lb) & 3u]);
+    if (lane_id() == 0) atomicAdd(&s_cnt[r], c);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    TileSum o; o.lines = tot;
+    for (int r = 0; r < 4; ++r) o.cnt[r] = s_cnt[r];
+    sums[blockIdx.x] = o;
+  }
+}
+
+// in place: sums[b] becomes {lines before block b, tuples before block b, -, -, -}
+__global__ __launch_bounds__(1024) void fastq_offsets_scan_kernel(TileSum *__restrict__ sums, uint64_t n_blocks,
+                                                                 uint64_t n_tiles, uint64_t *__restrict__ out_off,
                                                                  uint64_t *__restrict__ totals) {
   __shared__ uint64_t s_scan[1024 / 64 + 2];
-  const uint64_t per = (n_tiles + 1023) / 1024;
-  const uint64_t t0 = (uint64_t)threadIdx.x * per;
-  const uint64_t t1 = (t0 + per < n_tiles) ? t0 + per : n_tiles;
-  uint64_t lines = 0;
-  for (uint64_t t = t0; t < t1; ++t) lines += info[t].lines;
-  uint64_t total_lines;
-  uint64_t lb = block_exclusive_scan<uint64_t>(lines, s_scan, &total_lines);
-  uint64_t cnt = 0, l = lb;
-  for (uint64_t t = t0; t < t1; ++t) {
-    line_base[t] = (uint32_t)(l & 0xffffffffu);
-    cnt += info[t].win[(2u - (uint32_t)l) & 3u];
-    l += info[t].lines;
-  }
-  uint64_t total;
-  uint64_t off = block_exclusive_scan<uint64_t>(cnt, s_scan, &total);
-  l = lb;
-  for (uint64_t t = t0; t < t1; ++t) {
-    out_off[t] = off;
-    off += info[t].win[(2u - (uint32_t)l) & 3u];
-    l += info[t].lines;
+  uint64_t carry_lines = 0, carry_cnt = 0;
+  for (uint64_t b0 = 0; b0 < n_blocks; b0 += 1024) {
+    const uint64_t b = b0 + threadIdx.x;
+    TileSum ts; ts.lines = 0; ts.cnt[0] = ts.cnt[1] = ts.cnt[2] = ts.cnt[3] = 0;
+    if (b < n_blocks) ts = sums[b];
+    uint64_t tl, tc;
+    const uint64_t lb = carry_lines + block_exclusive_scan<uint64_t>(ts.lines, s_scan, &tl);
+    const uint64_t c = ts.cnt[(uint32_t)lb & 3u];
+    const uint64_t cb = carry_cnt + block_exclusive_scan<uint64_t>(c, s_scan, &tc);
+    if (b < n_blocks) { ts.lines = lb; ts.cnt[0] = cb; sums[b] = ts; }
+    carry_lines += tl; carry_cnt += tc;
   }
   if (threadIdx.x == 0) {
-    out_off[n_tiles] = total;
-    totals[0] = total_lines;
-    totals[1] = total;
-    totals[2] = (total_lines + 2) / 4;
+    out_off[n_tiles] = carry_cnt;
+    totals[0] = carry_lines;
+    totals[1] = carry_cnt;
+    totals[2] = (carry_lines + 2) / 4;
   }
+}
+
+__global__ __launch_bounds__(1024) void fastq_offsets_apply_kernel(const TileInfo *__restrict__ info, uint64_t n_tiles,
+                                                                  const TileSum *__restrict__ sums,
+                                                                  uint32_t *__restrict__ line_base,
+                                                                  uint64_t *__restrict__ out_off) {
+  __shared__ uint32_t s_scan[1024 / 64 + 2];
+  const uint64_t t = (uint64_t)blockIdx.x * 1024 + threadIdx.x;
+  TileInfo ti; ti.lines = 0; ti.win[0] = ti.win[1] = ti.win[2] = ti.win[3] = 0;
+  if (t < n_tiles) ti = info[t];
+  const TileSum base = sums[blockIdx.x];
+  const uint32_t lb = (uint32_t)base.lines + block_exclusive_scan<uint32_t>(ti.lines, s_scan, (uint32_t *)nullptr);
+  const uint32_t c = ti.win[(2u - lb) & 3u];
+  const uint32_t co = block_exclusive_scan<uint32_t>(c, s_scan, (uint32_t *)nullptr);
+  if (t < n_tiles) { line_base[t] = lb; out_off[t] = base.cnt[0] + co; }
 }
 
 // ---------------------------------------------------------------------------
@@ -320,7 +356,8 @@ __global__ __launch_bounds__((ExCfg<NW, BITS>::NT)) void fastq_extract_kernel(
 // ---------------------------------------------------------------------------
 template <int NW, int BITS>
 static kmi_status scan_impl(kmi_ctx *ctx, const uint8_t *bytes_dev, size_t n_bytes, const KShape &shape,
-                            uint64_t *n_tiles_out, TileInfo **info_out, uint32_t **base_out, uint64_t **off_out) {
+                            uint64_t *n_tiles_out, TileInfo **info_out, uint32_t **base_out, uint64_t **off_out,
+                            bool reuse = false) {
   using Cfg = ExCfg<NW, BITS>;
   const uint64_t n_tiles = (n_bytes + Cfg::TILE - 1) / Cfg::TILE;
   void *p;
@@ -330,15 +367,29 @@ static kmi_status scan_impl(kmi_ctx *ctx, const uint8_t *bytes_dev, size_t n_byt
   uint32_t *base = (uint32_t *)p;
   KMI_TRY(ws_get(ctx, WS_TILE_OFF, sizeof(uint64_t) * (n_tiles + 2), &p));
   uint64_t *off = (uint64_t *)p;
+  *n_tiles_out = n_tiles; *info_out = info; *base_out = base; *off_out = off;
+  if (reuse) return KMI_OK;   // the scan of these very bytes is still in the workspace
   if (n_tiles > 0) {
     ProfScope ps(ctx, "fastq_scan_tiles", n_bytes);
     hipLaunchKernelGGL((fastq_scan_tiles_kernel<NW, BITS>), dim3((unsigned)n_tiles), dim3(Cfg::NT), 0, ctx->stream,
                        bytes_dev, (uint64_t)n_bytes, shape.k, info);
   }
   {
+    const uint64_t n_blocks = (n_tiles + 1023) / 1024;
+    void *ps_;
+    KMI_TRY(ws_get(ctx, WS_MISC, sizeof(TileSum) * (n_blocks + 1), &ps_));
+    TileSum *sums = (TileSum *)ps_;
     ProfScope ps(ctx, "fastq_scan_offsets", n_tiles);
-    hipLaunchKernelGGL(fastq_scan_offsets_kernel, dim3(1), dim3(1024), 0, ctx->stream, info, n_tiles, base, off,
+    if (n_blocks > 0) {
+      hipLaunchKernelGGL(fastq_offsets_reduce_kernel, dim3((unsigned)n_blocks), dim3(1024), 0, ctx->stream,
+                         (const TileInfo *)info, n_tiles, sums);
+    }
+    hipLaunchKernelGGL(fastq_offsets_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, sums, n_blocks, n_tiles, off,
                        ctx->d_totals);
+    if (n_blocks > 0) {
+      hipLaunchKernelGGL(fastq_offsets_apply_kernel, dim3((unsigned)n_blocks), dim3(1024), 0, ctx->stream,
+                         (const TileInfo *)info, n_tiles, (const TileSum *)sums, base, off);
+    }
   }
   KMI_HIP(ctx, hipGetLastError());
   *n_tiles_out = n_tiles; *info_out = info; *base_out = base; *off_out = off;
@@ -364,11 +415,11 @@ static kmi_status extract_count_impl(kmi_ctx *ctx, const uint8_t *bytes_dev, siz
 template <int NW, int BITS>
 static kmi_status extract_run_impl(kmi_ctx *ctx, const kmi_config *cfg, const uint8_t *bytes_dev, size_t n_bytes,
                                    KShape shape, uint64_t *out_kmers_dev, size_t out_capacity, bool apply_strand,
-                                   uint64_t *n_tuples, uint64_t *n_seqs) {
+                                   bool scan_done, uint64_t *n_tuples, uint64_t *n_seqs) {
   using Cfg = ExCfg<NW, BITS>;
   uint64_t n_tiles; TileInfo *info; uint32_t *base; uint64_t *off;
   KMI_HIP(ctx, hipMemsetAsync(ctx->d_flags, 0, sizeof(uint32_t) * 16, ctx->stream));
-  KMI_TRY((scan_impl<NW, BITS>(ctx, bytes_dev, n_bytes, shape, &n_tiles, &info, &base, &off)));
+  KMI_TRY((scan_impl<NW, BITS>(ctx, bytes_dev, n_bytes, shape, &n_tiles, &info, &base, &off, scan_done)));
   if (n_tiles > 0) {
     ProfScope ps(ctx, "fastq_extract", n_bytes);
     hipLaunchKernelGGL((fastq_extract_kernel<NW, BITS>), dim3((unsigned)n_tiles), dim3(Cfg::NT), 0, ctx->stream,
@@ -396,7 +447,7 @@ kmi_status extract_count(kmi_ctx *ctx, const kmi_config *cfg, const uint8_t *byt
 
 kmi_status extract_run(kmi_ctx *ctx, const kmi_config *cfg, const uint8_t *bytes_dev, size_t n_bytes,
                        uint64_t file_offset, uint64_t *out_kmers_dev, uint64_t *out_ids_dev, size_t out_capacity,
-                       bool apply_strand, uint64_t *n_tuples, uint64_t *n_seqs) {
+                       bool apply_strand, bool scan_done, uint64_t *n_tuples, uint64_t *n_seqs) {
   (void)file_offset;
   KShape shape;
   if (!valid_config(cfg, &shape)) return set_err(ctx, KMI_ERR_INVALID, "bad kmi_config");
@@ -404,7 +455,7 @@ kmi_status extract_run(kmi_ctx *ctx, const kmi_config *cfg, const uint8_t *bytes
   if (out_ids_dev) return set_err(ctx, KMI_ERR_INVALID, "position ids are not implemented on the device yet");
   if (n_bytes == 0) { if (n_tuples) *n_tuples = 0; if (n_seqs) *n_seqs = 0; return KMI_OK; }
   KMI_DISPATCH(shape, extract_run_impl, ctx, cfg, bytes_dev, n_bytes, shape, out_kmers_dev, out_capacity, apply_strand,
-               n_tuples, n_seqs);
+               scan_done, n_tuples, n_seqs);
 }
 
 }  // namespace kmi

@@ -41,7 +41,10 @@ constexpr int kNumCoarse = 1 << kCoarseBits; // 256
 constexpr int kSubPerCoarse = kNumFine / kNumCoarse;  // 128
 constexpr int kSlotBits = 32 - kFineBits;    // low 17 bits pick the LDS slot
 constexpr int kPartThreads = 1024;           // K1/K2/P2 workgroup size
-constexpr int kPartGroups = 256;             // K1/K2 workgroups (one per CU)
+constexpr int kPartGroups = 512;             // K1/K2 workgroups (two per CU)
+constexpr int kFineParts = 2;                // P2 workgroups per coarse bucket; part h = K2 groups [h*256, (h+1)*256)
+constexpr int kGroupsPerPart = kPartGroups / kFineParts;
+constexpr int kLoadBatch = 8;                // independent key loads kept in flight per thread
 
 __host__ __device__ inline uint32_t fine_of(uint32_t h) { return h >> kSlotBits; }
 __host__ __device__ inline uint32_t coarse_of(uint32_t h) { return h >> (32 - kCoarseBits); }
@@ -88,7 +91,7 @@ __host__ __device__ inline uint64_t part_chunk(uint64_t n, uint32_t groups, uint
 template <int NW, int BITS>
 __global__ __launch_bounds__(kPartThreads) void hist_fine_kernel(const uint64_t *__restrict__ keys, uint64_t n, KShape shape,
                                                                 uint32_t strand, bool transform,
-                                                                uint32_t *__restrict__ fine_hist,     // [kNumFine] global
+                                                                uint32_t *__restrict__ fine_hist,     // [kFineParts][kNumFine] global
                                                                 uint32_t *__restrict__ wg_hist) {     // [groups][256]
   __shared__ uint32_t s_hist[kNumFine];
   for (int i = threadIdx.x; i < kNumFine; i += kPartThreads) s_hist[i] = 0;
@@ -96,15 +99,37 @@ __global__ __launch_bounds__(kPartThreads) void hist_fine_kernel(const uint64_t 
   const uint64_t chunk = part_chunk(n, gridDim.x, PartCfg<NW>::TILE);
   const uint64_t b = (uint64_t)blockIdx.x * chunk;
   const uint64_t e = (b + chunk < n) ? b + chunk : n;
-  for (uint64_t i = b + threadIdx.x; i < e; i += kPartThreads) {
-    uint64_t k[NW];
-    load_key<NW, BITS>(keys, i, shape, strand, transform, k);
-    atomicAdd(&s_hist[fine_of(place_hash<NW>(k))], 1u);
+  constexpr int U = (NW == 1) ? kLoadBatch : (NW == 2 ? 4 : 2);
+  for (uint64_t i0 = b; i0 < e; i0 += (uint64_t)kPartThreads * U) {
+    uint64_t raw[U][NW];
+    bool ok[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint64_t i = i0 + (uint64_t)u * kPartThreads + threadIdx.x;
+      ok[u] = i < e;
+      if (ok[u]) {
+#pragma unroll
+        for (int w = 0; w < NW; ++w) raw[u][w] = keys[i * NW + w];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (ok[u]) {
+        uint64_t k[NW];
+        if (transform) strand_key<NW, BITS>(raw[u], k, shape, strand);
+        else {
+#pragma unroll
+          for (int w = 0; w < NW; ++w) k[w] = raw[u][w];
+        }
+        atomicAdd(&s_hist[fine_of(place_hash<NW>(k))], 1u);
+      }
+    }
   }
   __syncthreads();
+  uint32_t *part_hist = fine_hist + (uint64_t)(blockIdx.x / kGroupsPerPart) * kNumFine;
   for (int i = threadIdx.x; i < kNumFine; i += kPartThreads) {
     uint32_t v = s_hist[i];
-    if (v) atomicAdd(&fine_hist[i], v);
+    if (v) atomicAdd(&part_hist[i], v);
   }
   if (threadIdx.x < kNumCoarse) {
     uint32_t s = 0;
@@ -137,18 +162,29 @@ __global__ __launch_bounds__(kPartThreads) void hist_rank_kernel(const uint64_t 
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void fine_offsets_kernel(const uint32_t *__restrict__ fine_hist, const uint32_t *__restrict__ wg_hist,
                                                            uint32_t groups, uint64_t *__restrict__ fine_off,
+                                                           uint64_t *__restrict__ part_off,   // [kFineParts][kNumFine] or null
                                                            uint64_t *__restrict__ wg_off) {
   __shared__ uint64_t s_scan[1024 / 64 + 2];
   __shared__ uint64_t s_coarse[kNumCoarse];
   constexpr int PER = kNumFine / 1024;  // 32 fine buckets per thread; a coarse bucket = 4 threads
-  uint64_t loc[PER], sum = 0;
+  uint32_t loc[kFineParts][PER];
+  uint64_t sum = 0;
 #pragma unroll
-  for (int i = 0; i < PER; ++i) { loc[i] = fine_hist[threadIdx.x * PER + i]; sum += loc[i]; }
+  for (int h = 0; h < kFineParts; ++h)
+#pragma unroll
+    for (int i = 0; i < PER; ++i) { loc[h][i] = fine_hist[(uint64_t)h * kNumFine + threadIdx.x * PER + i]; sum += loc[h][i]; }
   uint64_t total;
   uint64_t off = block_exclusive_scan<uint64_t>(sum, s_scan, &total);
   if ((threadIdx.x & 3u) == 0) s_coarse[threadIdx.x >> 2] = off;
 #pragma unroll
-  for (int i = 0; i < PER; ++i) { fine_off[threadIdx.x * PER + i] = off; off += loc[i]; }
+  for (int i = 0; i < PER; ++i) {
+    fine_off[threadIdx.x * PER + i] = off;
+#pragma unroll
+    for (int h = 0; h < kFineParts; ++h) {
+      if (part_off) part_off[(uint64_t)h * kNumFine + threadIdx.x * PER + i] = off;
+      off += loc[h][i];
+    }
+  }
   if (threadIdx.x == 0) fine_off[kNumFine] = total;
   __syncthreads();
   if (wg_off && threadIdx.x < kNumCoarse) {
@@ -254,16 +290,18 @@ __global__ __launch_bounds__(kPartThreads) void scatter_chunks_kernel(const uint
   if (b < e) scatter_range<NW, BITS>(in, b, e, out, shape, strand, transform, fn, s_stage, s_bkt, s_cnt, s_lofs, s_cursor, s_scan);
 }
 
-// P2: workgroup c splits coarse bucket c into its fine buckets
+// P2: workgroup (c, h) splits the part of coarse bucket c that K2 groups [h*256,(h+1)*256) wrote
 template <int NW, int BITS>
 __global__ __launch_bounds__(kPartThreads) void scatter_fine_kernel(const uint64_t *__restrict__ in, uint64_t *__restrict__ out, KShape shape,
-                                                                   const uint64_t *__restrict__ fine_off) {
+                                                                   const uint64_t *__restrict__ fine_off, const uint64_t *__restrict__ part_off,
+                                                                   const uint64_t *__restrict__ wg_off) {
   KMI_SCATTER_LDS(NW)
-  const uint32_t c = blockIdx.x;
+  const uint32_t c = blockIdx.x / kFineParts, h = blockIdx.x % kFineParts;
   if (threadIdx.x < kNumCoarse)
-    s_cursor[threadIdx.x] = (threadIdx.x < kSubPerCoarse) ? fine_off[c * kSubPerCoarse + threadIdx.x] : 0ull;
+    s_cursor[threadIdx.x] = (threadIdx.x < kSubPerCoarse) ? part_off[(uint64_t)h * kNumFine + c * kSubPerCoarse + threadIdx.x] : 0ull;
   __syncthreads();
-  const uint64_t b = fine_off[c * kSubPerCoarse], e = fine_off[(c + 1) * kSubPerCoarse];
+  const uint64_t b = wg_off[(uint64_t)(h * kGroupsPerPart) * kNumCoarse + c];
+  const uint64_t e = (h + 1 < (uint32_t)kFineParts) ? wg_off[(uint64_t)((h + 1) * kGroupsPerPart) * kNumCoarse + c] : fine_off[(c + 1) * kSubPerCoarse];
   BucketFn fn; fn.mode = BUCKET_SUB; fn.shape = shape; fn.dist_hash = 0; fn.farm_ndebug = false; fn.nranks = 1;
   if (b < e) scatter_range<NW, BITS>(in, b, e, out, shape, 0u, false, fn, s_stage, s_bkt, s_cnt, s_lofs, s_cursor, s_scan);
 }
@@ -403,6 +441,28 @@ __device__ __forceinline__ uint32_t pass_of(uint32_t h, uint32_t npass) {
   return npass == 1 ? 0u : (uint32_t)(((uint64_t)(h * 0x9E3779B1u) * npass) >> 32);
 }
 
+// visit keys[b, e) with U independent loads per thread in flight; f(key words, index)
+template <int NW, int U, typename F>
+__device__ __forceinline__ void for_each_key(const uint64_t *__restrict__ keys, uint64_t b, uint64_t e, F f) {
+  for (uint64_t i0 = b; i0 < e; i0 += (uint64_t)blockDim.x * U) {
+    uint64_t raw[U][NW];
+    bool ok[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint64_t i = i0 + (uint64_t)u * blockDim.x + threadIdx.x;
+      ok[u] = i < e;
+      if (ok[u]) {
+#pragma unroll
+        for (int w = 0; w < NW; ++w) raw[u][w] = keys[i * NW + w];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (ok[u]) f(raw[u], i0 + (uint64_t)u * blockDim.x + threadIdx.x);
+  }
+}
+template <int NW> struct BatchOf { static constexpr int U = (NW == 1) ? kLoadBatch : (NW == 2 ? 4 : 2); };
+
 #define KMI_TABLE_LDS(NW)                                                   \
   __shared__ uint64_t s_tk[TabCfg<NW>::CAP * NW];                           \
   __shared__ uint32_t s_tv[TabCfg<NW>::CAP];                                \
@@ -437,26 +497,20 @@ __global__ __launch_bounds__((TabCfg<NW>::NT)) void bucket_reduce_kernel(const u
     for (uint32_t pass = 0; pass < npass && !failed; ++pass) {
       table_clear<NW>(tab);
       __syncthreads();
-      for (uint64_t i = ob + threadIdx.x; i < oe; i += blockDim.x) {
-        uint64_t k[NW];
-#pragma unroll
-        for (int w = 0; w < NW; ++w) k[w] = old_keys[i * NW + w];
+      for_each_key<NW, BatchOf<NW>::U>(old_keys, ob, oe, [&](const uint64_t (&k)[NW], uint64_t i) {
         const uint32_t h = place_hash<NW>(k);
-        if (pass_of(h, npass) != pass) continue;
+        if (pass_of(h, npass) != pass) return;
         int s = table_upsert<NW>(tab, k, h);
         if (s >= 0) atomicAdd(&tab.vals[s], old_vals[i]);
         else if (s == -2) atomicAdd(tab.special, old_vals[i]);
-      }
-      for (uint64_t i = nb + threadIdx.x; i < ne; i += blockDim.x) {
-        uint64_t k[NW];
-#pragma unroll
-        for (int w = 0; w < NW; ++w) k[w] = new_keys[i * NW + w];
+      });
+      for_each_key<NW, BatchOf<NW>::U>(new_keys, nb, ne, [&](const uint64_t (&k)[NW], uint64_t) {
         const uint32_t h = place_hash<NW>(k);
-        if (pass_of(h, npass) != pass) continue;
+        if (pass_of(h, npass) != pass) return;
         int s = table_upsert<NW>(tab, k, h);
         if (s >= 0) atomicAdd(&tab.vals[s], 1u);
         else if (s == -2) atomicAdd(tab.special, 1u);
-      }
+      });
       __syncthreads();
       if (*tab.overflow) { failed = true; break; }
       for (int s = threadIdx.x; s < CAP; s += blockDim.x) {
@@ -548,14 +602,11 @@ __global__ __launch_bounds__((TabCfg<NW>::NT)) void bucket_query_kernel(int mode
     for (uint32_t pass = 0; pass < npass && !failed; ++pass) {
       table_clear<NW>(tab);
       __syncthreads();
-      for (uint64_t i = qb + threadIdx.x; i < qe; i += blockDim.x) {
-        uint64_t k[NW];
-#pragma unroll
-        for (int w = 0; w < NW; ++w) k[w] = q_keys[i * NW + w];
+      for_each_key<NW, BatchOf<NW>::U>(q_keys, qb, qe, [&](const uint64_t (&k)[NW], uint64_t) {
         const uint32_t h = place_hash<NW>(k);
-        if (pass_of(h, npass) != pass) continue;
+        if (pass_of(h, npass) != pass) return;
         (void)table_upsert<NW>(tab, k, h);
-      }
+      });
       __syncthreads();
       if (*tab.overflow) { failed = true; break; }
       // stream the index bucket against the query table
@@ -645,13 +696,15 @@ static kmi_status partition_impl(kmi_ctx *ctx, const kmi_config *cfg, KShape sha
   const size_t key_bytes = (n ? n : 1) * NW * sizeof(uint64_t);
   KMI_TRY(ws_get(ctx, slot_a, key_bytes, &p)); uint64_t *buf_a = (uint64_t *)p;
   KMI_TRY(ws_get(ctx, slot_b, key_bytes, &p)); uint64_t *buf_b = (uint64_t *)p;
-  KMI_TRY(ws_get(ctx, WS_HIST, sizeof(uint32_t) * kNumFine + sizeof(uint64_t) * (kNumFine + 1) * 2 + 256, &p));
+  KMI_TRY(ws_get(ctx, WS_HIST, sizeof(uint32_t) * kNumFine * kFineParts + sizeof(uint64_t) * ((kNumFine + 1) * 2 + kNumFine * kFineParts) + 256, &p));
   uint32_t *fine_hist = (uint32_t *)p;
-  // two offset arrays live behind the histogram: [0] for inserts, [1] for queries
-  uint64_t *fine_off = (uint64_t *)((char *)p + sizeof(uint32_t) * kNumFine) + (slot_b == WS_QUERY_B ? (kNumFine + 1) : 0);
+  // offset arrays live behind the histogram: [0] for inserts, [1] for queries, then the per-part offsets
+  uint64_t *off_base = (uint64_t *)((char *)p + sizeof(uint32_t) * kNumFine * kFineParts);
+  uint64_t *fine_off = off_base + (slot_b == WS_QUERY_B ? (kNumFine + 1) : 0);
+  uint64_t *part_off = off_base + 2 * (kNumFine + 1);
   KMI_TRY(ws_get(ctx, WS_WGHIST, sizeof(uint32_t) * kPartGroups * kNumCoarse, &p)); uint32_t *wg_hist = (uint32_t *)p;
   KMI_TRY(ws_get(ctx, WS_CURSOR, sizeof(uint64_t) * kPartGroups * kNumCoarse, &p)); uint64_t *wg_off = (uint64_t *)p;
-  KMI_HIP(ctx, hipMemsetAsync(fine_hist, 0, sizeof(uint32_t) * kNumFine, ctx->stream));
+  KMI_HIP(ctx, hipMemsetAsync(fine_hist, 0, sizeof(uint32_t) * kNumFine * kFineParts, ctx->stream));
   {
     ProfScope ps(ctx, "hist_fine", n);
     hipLaunchKernelGGL((hist_fine_kernel<NW, BITS>), dim3(kPartGroups), dim3(kPartThreads), 0, ctx->stream, keys_dev, (uint64_t)n, shape,
@@ -659,7 +712,7 @@ static kmi_status partition_impl(kmi_ctx *ctx, const kmi_config *cfg, KShape sha
   }
   {
     ProfScope ps(ctx, "fine_offsets", kNumFine);
-    hipLaunchKernelGGL(fine_offsets_kernel, dim3(1), dim3(1024), 0, ctx->stream, fine_hist, wg_hist, (uint32_t)kPartGroups, fine_off, wg_off);
+    hipLaunchKernelGGL(fine_offsets_kernel, dim3(1), dim3(1024), 0, ctx->stream, fine_hist, wg_hist, (uint32_t)kPartGroups, fine_off, part_off, wg_off);
   }
   BucketFn fn; fn.mode = BUCKET_COARSE; fn.shape = shape; fn.dist_hash = 0; fn.farm_ndebug = false; fn.nranks = 1;
   {
@@ -669,7 +722,8 @@ static kmi_status partition_impl(kmi_ctx *ctx, const kmi_config *cfg, KShape sha
   }
   {
     ProfScope ps(ctx, "scatter_fine", n);
-    hipLaunchKernelGGL((scatter_fine_kernel<NW, BITS>), dim3(kNumCoarse), dim3(kPartThreads), 0, ctx->stream, buf_a, buf_b, shape, fine_off);
+    hipLaunchKernelGGL((scatter_fine_kernel<NW, BITS>), dim3(kNumCoarse * kFineParts), dim3(kPartThreads), 0, ctx->stream, buf_a, buf_b, shape,
+                       (const uint64_t *)fine_off, (const uint64_t *)part_off, (const uint64_t *)wg_off);
   }
   KMI_HIP(ctx, hipGetLastError());
   out->keys = buf_b; out->fine_off = fine_off;
@@ -896,7 +950,7 @@ kmi_status kmi_index_build_dev(kmi_index *idx, const uint8_t *bytes_dev, size_t 
   KMI_TRY(extract_count(ctx, &idx->cfg, bytes_dev, n_bytes, &nt, &ns));
   void *dk;
   KMI_TRY(ws_get(ctx, WS_OUTPUT, (size_t)(nt ? nt : 1) * idx->shape.n_words * sizeof(uint64_t), &dk));
-  KMI_TRY(extract_run(ctx, &idx->cfg, bytes_dev, n_bytes, file_offset, (uint64_t *)dk, nullptr, (size_t)nt, true, &nt, &ns));
+  KMI_TRY(extract_run(ctx, &idx->cfg, bytes_dev, n_bytes, file_offset, (uint64_t *)dk, nullptr, (size_t)nt, true, true, &nt, &ns));
   return index_insert(idx, (const uint64_t *)dk, (size_t)nt, false);
 }
 

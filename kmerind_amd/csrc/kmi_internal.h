@@ -137,6 +137,6 @@ kmi_status extract_count(kmi_ctx *ctx, const kmi_config *cfg, const uint8_t *byt
                          uint64_t *n_tuples, uint64_t *n_seqs);
 kmi_status extract_run(kmi_ctx *ctx, const kmi_config *cfg, const uint8_t *bytes_dev, size_t n_bytes,
                        uint64_t file_offset, uint64_t *out_kmers_dev, uint64_t *out_ids_dev, size_t out_capacity,
-                       bool apply_strand, uint64_t *n_tuples, uint64_t *n_seqs);
+                       bool apply_strand, bool scan_done, uint64_t *n_tuples, uint64_t *n_seqs);
 
 }  // namespace kmi
