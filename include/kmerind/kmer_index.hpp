@@ -1,0 +1,408 @@
+// kmerind/kmer_index.hpp -- header-only C++ facade over libkmerind_hip.so that keeps the
+// reference's spelling for the k-mer index path, so code written against
+//   bliss::common::Kmer<K, Alphabet, Word>                    (src/common/kmer.hpp:116-177)
+//   bliss::index::kmer::Index<MapType, KmerParser>            (src/index/kmer_index.hpp:98-394)
+//   bliss::index::kmer::CountIndex / CountIndex2 / KmerIndex  (src/index/kmer_index.hpp:399-411)
+//   ::dsc::counting_unordered_map / counting_densehash_map    (src/containers/distributed_*_map.hpp)
+//   bliss::index::kmer::{SingleStrand,Canonical,Bimolecule}HashMapParams (kmer_index.hpp:436-481)
+//   bliss::io::KmerFileHelper::read_file_posix / _mmap        (src/io/kmer_file_helper.hpp:588-633)
+// compiles against this header and runs on an MI355X. Only what sits on that path is
+// mirrored; everything is host C++ that forwards to the C ABI in ../kmerind_hip.h.
+//
+// Differences a maintainer must know (also in INTEGRATION.md):
+//   * mxx::comm is replaced by kmerind::comm {device, rank, size}; with size > 1 the caller
+//     provides the all-to-all (kmerind::comm::exchange), e.g. RCCL ncclSend/ncclRecv.
+//   * MapType template arguments are tag types: they only select the kmi_config.
+//   * insert()/count()/find()/erase() leave their argument vector unchanged (the reference
+//     leaves it in an unspecified state).
+//   * errors: KMI_ERR_INVALID -> std::invalid_argument, KMI_ERR_PARSE -> std::logic_error,
+//     anything else -> std::runtime_error, like the reference's exception types.
+#ifndef KMERIND_KMER_INDEX_HPP
+#define KMERIND_KMER_INDEX_HPP
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <functional>
+#include <stdexcept>
+#include <string>
+#include <type_traits>
+#include <utility>
+#include <vector>
+
+#include "../kmerind_hip.h"
+
+// ---------------------------------------------------------------------------
+// communicator stand-in
+// ---------------------------------------------------------------------------
+namespace kmerind {
+
+struct comm {
+  int device = 0;
+  int rank_ = 0;
+  int size_ = 1;
+  void *stream = nullptr;
+  // all-to-all of k-mer words between ranks, required only when size() > 1:
+  // (send words grouped by destination, send counts in k-mers [size], n_words) -> received words
+  std::function<std::vector<uint64_t>(const std::vector<uint64_t> &, const std::vector<uint64_t> &, uint32_t)> exchange;
+  std::function<uint64_t(uint64_t)> allreduce_sum;
+
+  comm() = default;
+  explicit comm(int dev, int r = 0, int s = 1) : device(dev), rank_(r), size_(s) {}
+  int rank() const { return rank_; }
+  int size() const { return size_; }
+  void barrier() const {}
+};
+
+inline void check(kmi_ctx *ctx, kmi_status st) {
+  if (st == KMI_OK) return;
+  std::string msg = std::string("kmerind_hip: ") + (ctx ? kmi_last_error(ctx) : "error");
+  if (st == KMI_ERR_INVALID) throw std::invalid_argument(msg);
+  if (st == KMI_ERR_PARSE) throw std::logic_error(msg);
+  throw std::runtime_error(msg + " (status " + std::to_string((int)st) + ")");
+}
+
+}  // namespace kmerind
+
+// ---------------------------------------------------------------------------
+// bliss::common : alphabets and the packed k-mer value type
+// ---------------------------------------------------------------------------
+namespace bliss {
+namespace common {
+
+using WordType = uint64_t;  // base_types.hpp:36
+
+struct DNA { static constexpr unsigned SIZE = 4; static constexpr unsigned BITS = 2; static constexpr uint32_t KMI = KMI_ALPHA_DNA; };
+struct DNA6 { static constexpr unsigned SIZE = 8; static constexpr unsigned BITS = 3; static constexpr uint32_t KMI = KMI_ALPHA_DNA5; };
+using DNA5 = DNA6;  // alphabets.hpp:746-747
+
+template <typename A> struct AlphabetTraits {
+  static constexpr unsigned getSize() { return A::SIZE; }
+  static constexpr unsigned getBitsPerChar() { return A::BITS; }
+};
+
+// Same object layout as the reference: WORD_TYPE data[nWords], data[0] least significant,
+// newest base in the low bits, pad bits zero, no alignment attribute (kmer.hpp:177).
+template <unsigned int KMER_SIZE, typename ALPHABET, typename WORD_TYPE = WordType>
+class Kmer {
+  static_assert(std::is_same<WORD_TYPE, uint64_t>::value, "the MI355X path stores k-mers in 64-bit words");
+
+ public:
+  static constexpr unsigned int size = KMER_SIZE;
+  static constexpr unsigned int bitsPerChar = ALPHABET::BITS;
+  static constexpr unsigned int nBits = size * bitsPerChar;
+  static constexpr unsigned int nWords = (nBits + 63) / 64;
+  static constexpr unsigned int nBytes = (nBits + 7) / 8;
+  using KmerWordType = WORD_TYPE;
+  using KmerAlphabet = ALPHABET;
+
+  explicit Kmer(bool clear = true) { if (clear) std::memset(data, 0, sizeof(data)); }
+  explicit Kmer(const WORD_TYPE *words) { std::memcpy(data, words, sizeof(data)); sanitize(); }
+
+  const WORD_TYPE *getData() const { return data; }
+  WORD_TYPE *getDataRef() { return data; }
+  const WORD_TYPE *getConstData() const { return data; }
+
+  // Kmer::nextFromChar (kmer.hpp:731-741): c is an alphabet code, not ASCII
+  void nextFromChar(unsigned char c) {
+    for (int w = (int)nWords - 1; w > 0; --w) data[w] = (data[w] << bitsPerChar) | (data[w - 1] >> (64 - bitsPerChar));
+    data[0] = (data[0] << bitsPerChar) | (static_cast<WORD_TYPE>(c) & ((WORD_TYPE(1) << bitsPerChar) - 1));
+    sanitize();
+  }
+  void sanitize() {
+    constexpr unsigned inv_pad = 64 - (nWords * 64 - nBits);
+    if (inv_pad < 64) data[nWords - 1] &= ((WORD_TYPE(1) << inv_pad) - 1);
+  }
+
+  bool operator==(const Kmer &o) const { return std::memcmp(data, o.data, sizeof(data)) == 0; }
+  bool operator!=(const Kmer &o) const { return !(*this == o); }
+  bool operator<(const Kmer &o) const {  // kmer.hpp:820-823: compare from the most significant word
+    for (int w = (int)nWords - 1; w >= 0; --w)
+      if (data[w] != o.data[w]) return data[w] < o.data[w];
+    return false;
+  }
+  bool operator>(const Kmer &o) const { return o < *this; }
+  bool operator<=(const Kmer &o) const { return !(o < *this); }
+  bool operator>=(const Kmer &o) const { return !(*this < o); }
+
+ private:
+  WORD_TYPE data[nWords];
+};
+
+struct ShortSequenceKmerId { size_t id; };  // sequence.hpp:127-209 (layout only)
+struct LongSequenceKmerId { size_t id; };   // sequence.hpp:231-296
+
+}  // namespace common
+
+// transform / hash tags (kmer_transform.hpp:90-145, kmer_hash.hpp:242-311)
+namespace transform { template <typename K> struct identity {}; }
+namespace kmer {
+namespace transform { template <typename K> struct lex_less {}; template <typename K> struct xor_rev_comp {}; }
+namespace hash {
+template <typename K, bool Prefix = false> struct murmur { static constexpr uint32_t KMI = KMI_HASH_MURMUR; };
+template <typename K, bool Prefix = false> struct farm { static constexpr uint32_t KMI = KMI_HASH_FARM; };
+}  // namespace hash
+}  // namespace kmer
+
+// sequence / tuple parser tags (fastq_loader.hpp, fasta_loader.hpp, kmer_parser.hpp)
+namespace io {
+template <typename Iter> struct FASTQParser { static constexpr uint32_t KMI = KMI_FMT_FASTQ; };
+template <typename Iter> struct FASTAParser { static constexpr uint32_t KMI = KMI_FMT_FASTA; };
+template <typename Iter, template <typename> class Parser> struct SequencesIterator {};
+}  // namespace io
+}  // namespace bliss
+
+// ---------------------------------------------------------------------------
+// ::dsc map tags (distributed_map_base.hpp:87-143 DistributedMapParams)
+// ---------------------------------------------------------------------------
+namespace dsc {
+
+template <typename Key, template <typename> class InputTrans, template <typename> class DistTrans,
+          template <typename> class DistHash, template <typename> class DistEqual, template <typename> class StoreTrans,
+          template <typename> class StoreHash, template <typename> class StoreEqual>
+struct HashMapParams {
+  static constexpr bool input_is_lex_less = std::is_same<InputTrans<Key>, ::bliss::kmer::transform::lex_less<Key>>::value;
+  static constexpr bool store_is_lex_less = std::is_same<StoreTrans<Key>, ::bliss::kmer::transform::lex_less<Key>>::value;
+  static constexpr uint32_t strand = input_is_lex_less ? KMI_STRAND_CANONICAL : (store_is_lex_less ? KMI_STRAND_BIMOLECULE : KMI_STRAND_SINGLE);
+  static constexpr uint32_t dist_hash = DistHash<Key>::KMI;
+  static constexpr uint32_t store_hash = StoreHash<Key>::KMI;
+};
+
+template <typename Key, typename T, template <typename> class MapParams>
+struct counting_unordered_map {
+  using key_type = Key; using mapped_type = T; using params = MapParams<Key>;
+  static constexpr uint32_t index_kind = KMI_INDEX_COUNT;
+};
+template <typename Key, typename T, template <typename> class MapParams, typename SpecialKeys = void>
+struct counting_densehash_map : counting_unordered_map<Key, T, MapParams> {};
+
+}  // namespace dsc
+
+// ---------------------------------------------------------------------------
+// bliss::index::kmer
+// ---------------------------------------------------------------------------
+namespace bliss {
+namespace index {
+namespace kmer {
+
+template <typename K> using DistHashMurmur = ::bliss::kmer::hash::murmur<K, true>;
+template <typename K> using DistHashFarm = ::bliss::kmer::hash::farm<K, true>;
+template <typename K> using StoreHashMurmur = ::bliss::kmer::hash::murmur<K, false>;
+template <typename K> using StoreHashFarm = ::bliss::kmer::hash::farm<K, false>;
+
+template <typename Key, template <typename> class DistHash = DistHashMurmur, template <typename> class StoreHash = StoreHashMurmur,
+          template <typename> class DistTrans = ::bliss::transform::identity>
+using SingleStrandHashMapParams = ::dsc::HashMapParams<Key, ::bliss::transform::identity, DistTrans, DistHash, ::std::equal_to,
+                                                      ::bliss::transform::identity, StoreHash, ::std::equal_to>;
+template <typename Key, template <typename> class DistHash = DistHashMurmur, template <typename> class StoreHash = StoreHashMurmur>
+using CanonicalHashMapParams = ::dsc::HashMapParams<Key, ::bliss::kmer::transform::lex_less, ::bliss::transform::identity, DistHash,
+                                                   ::std::equal_to, ::bliss::transform::identity, StoreHash, ::std::equal_to>;
+template <typename Key, template <typename> class DistHash = DistHashMurmur, template <typename> class StoreHash = StoreHashMurmur>
+using BimoleculeHashMapParams = ::dsc::HashMapParams<Key, ::bliss::transform::identity, ::bliss::kmer::transform::lex_less, DistHash,
+                                                    ::std::equal_to, ::bliss::kmer::transform::lex_less, StoreHash, ::std::equal_to>;
+
+// tuple parsers (kmer_parser.hpp:85-294, 909-1083): value_type is what read_file_* produces
+template <typename KmerType> struct KmerParser { using value_type = KmerType; using kmer_type = KmerType; static constexpr size_t window_size = KmerType::size; };
+template <typename TupleType> struct KmerCountTupleParser {
+  using value_type = TupleType; using kmer_type = typename std::tuple_element<0, TupleType>::type;
+  static constexpr size_t window_size = kmer_type::size;
+};
+
+namespace detail {
+template <typename MapType> kmi_config make_config(uint32_t fmt) {
+  using Key = typename MapType::key_type;
+  kmi_config c;
+  c.k = Key::size; c.alphabet = Key::KmerAlphabet::KMI; c.strand = MapType::params::strand;
+  c.dist_hash = MapType::params::dist_hash; c.store_hash = MapType::params::store_hash;
+  c.index_kind = MapType::index_kind; c.seq_format = fmt; c.farm_ndebug = 0;
+  return c;
+}
+inline std::vector<uint8_t> read_whole_file(const std::string &filename) {
+  FILE *f = std::fopen(filename.c_str(), "rb");
+  if (!f) throw std::invalid_argument("cannot open " + filename);
+  std::fseek(f, 0, SEEK_END); long n = std::ftell(f); std::fseek(f, 0, SEEK_SET);
+  std::vector<uint8_t> buf((size_t)(n > 0 ? n : 0));
+  if (n > 0 && std::fread(buf.data(), 1, (size_t)n, f) != (size_t)n) { std::fclose(f); throw std::runtime_error("short read on " + filename); }
+  std::fclose(f);
+  return buf;
+}
+inline uint32_t format_of(const std::string &filename) {  // kmer_index.hpp:243-254
+  auto ends = [&](const char *e) { size_t l = std::strlen(e); return filename.size() >= l && filename.compare(filename.size() - l, l, e) == 0; };
+  if (ends(".fastq") || ends(".fq")) return KMI_FMT_FASTQ;
+  if (ends(".fasta") || ends(".fa")) return KMI_FMT_FASTA;
+  throw std::invalid_argument("input filename extension is not supported.");
+}
+template <typename Kmer> const uint64_t *words_of(const std::vector<Kmer> &v) { return reinterpret_cast<const uint64_t *>(v.data()); }
+template <typename Kmer, typename T> std::vector<uint64_t> words_of_pairs(const std::vector<std::pair<Kmer, T>> &v) {
+  std::vector<uint64_t> w(v.size() * Kmer::nWords);
+  for (size_t i = 0; i < v.size(); ++i) std::memcpy(&w[i * Kmer::nWords], v[i].first.getData(), sizeof(uint64_t) * Kmer::nWords);
+  return w;
+}
+}  // namespace detail
+
+template <typename MapType, typename KmerParserT>
+class Index {
+ public:
+  using KmerType = typename MapType::key_type;
+  using ValueType = typename MapType::mapped_type;
+  using TupleType = std::pair<KmerType, ValueType>;
+  using Alphabet = typename KmerType::KmerAlphabet;
+  using KmerParserType = KmerParserT;
+  static_assert(sizeof(KmerType) == KmerType::nWords * sizeof(uint64_t), "Kmer must be a plain word array");
+
+  explicit Index(const ::kmerind::comm &_comm) : comm(_comm) {
+    cfg = detail::make_config<MapType>(KMI_FMT_FASTQ);
+    ::kmerind::check(nullptr, kmi_ctx_create(comm.device, comm.rank(), comm.size(), comm.stream, &ctx));
+    ::kmerind::check(ctx, kmi_index_create(ctx, &cfg, &idx));
+  }
+  Index(const Index &) = delete;
+  Index &operator=(const Index &) = delete;
+  virtual ~Index() { if (idx) kmi_index_destroy(idx); if (ctx) kmi_ctx_destroy(ctx); }
+
+  // Index::insert (kmer_index.hpp:200-225): vector<Kmer> or vector<pair<Kmer,count>> (the count parser's tuples)
+  void insert(std::vector<KmerType> &temp) { insert_words(detail::words_of(temp), temp.size()); }
+  void insert(std::vector<TupleType> &temp) { auto w = detail::words_of_pairs(temp); insert_words(w.data(), temp.size()); }
+
+  // Index::count (:142-145): one (key, 0|1) per distinct transformed query key
+  std::vector<std::pair<KmerType, size_t>> count(std::vector<KmerType> &query) const {
+    kmi_results r{};
+    std::vector<uint64_t> q = route_queries(query);
+    ::kmerind::check(ctx, kmi_index_count_host(idx, q.data(), q.size() / KmerType::nWords, &r));
+    std::vector<std::pair<KmerType, size_t>> out(r.n);
+    for (uint64_t i = 0; i < r.n; ++i) out[i] = std::make_pair(KmerType(r.keys + i * KmerType::nWords), (size_t)r.values[i]);
+    kmi_results_free(&r);
+    return out;
+  }
+  // Index::find (:132-135): (key, stored value) of present query keys
+  std::vector<TupleType> find(std::vector<KmerType> &query) const {
+    kmi_results r{};
+    std::vector<uint64_t> q = route_queries(query);
+    ::kmerind::check(ctx, kmi_index_find_host(idx, q.data(), q.size() / KmerType::nWords, &r));
+    std::vector<TupleType> out(r.n);
+    for (uint64_t i = 0; i < r.n; ++i) out[i] = std::make_pair(KmerType(r.keys + i * KmerType::nWords), (ValueType)r.values[i]);
+    kmi_results_free(&r);
+    return out;
+  }
+  // Index::erase (:147-149)
+  void erase(std::vector<KmerType> &query) {
+    uint64_t n = 0;
+    std::vector<uint64_t> q = route_queries(query);
+    ::kmerind::check(ctx, kmi_index_erase_host(idx, q.data(), q.size() / KmerType::nWords, &n));
+  }
+
+  size_t local_size() const { uint64_t n = 0; ::kmerind::check(ctx, kmi_index_local_size(idx, &n)); return (size_t)n; }
+  size_t size() const { size_t n = local_size(); return (comm.size() > 1 && comm.allreduce_sum) ? (size_t)comm.allreduce_sum(n) : n; }
+
+  // MapType::to_vector (distributed_map_base.hpp:202-217)
+  std::vector<TupleType> to_vector() const {
+    uint64_t n = local_size(), got = 0;
+    std::vector<uint64_t> keys(n * KmerType::nWords + 1);
+    std::vector<uint32_t> cnt(n + 1);
+    ::kmerind::check(ctx, kmi_index_export_host(idx, keys.data(), cnt.data(), n, &got));
+    std::vector<TupleType> out(got);
+    for (uint64_t i = 0; i < got; ++i) out[i] = std::make_pair(KmerType(&keys[i * KmerType::nWords]), (ValueType)cnt[i]);
+    return out;
+  }
+
+  // Index::build_posix / build_mmap (:239-372): read_file + insert; the extension check is the reference's
+  template <template <typename> class SeqParser, template <typename, template <typename> class> class SeqIterType>
+  void build_posix(const std::string &filename, void * /*MPI_Comm*/ = nullptr) { build_file<SeqParser>(filename); }
+  template <template <typename> class SeqParser, template <typename, template <typename> class> class SeqIterType>
+  void build_mmap(const std::string &filename, void * = nullptr) { build_file<SeqParser>(filename); }
+
+  kmi_ctx *context() const { return ctx; }
+  const kmi_config &config() const { return cfg; }
+
+ protected:
+  template <template <typename> class SeqParser> void build_file(const std::string &filename) {
+    uint32_t fmt = detail::format_of(filename);
+    if (fmt != SeqParser<const unsigned char *>::KMI) throw std::invalid_argument("Specified File Parser template parameter does not support files with this extension.");
+    if (comm.size() > 1) throw std::invalid_argument("build_* with size() > 1: partition the file per rank and use read_file + insert");
+    std::vector<uint8_t> bytes = detail::read_whole_file(filename);
+    kmi_config c = cfg; c.seq_format = fmt;
+    (void)c;
+    ::kmerind::check(ctx, kmi_index_build_host(idx, bytes.data(), bytes.size(), 0));
+  }
+  void insert_words(const uint64_t *words, size_t n) {
+    if (comm.size() == 1) { ::kmerind::check(ctx, kmi_index_insert_host(idx, words, n)); return; }
+    std::vector<uint64_t> mine = route_words(words, n);
+    ::kmerind::check(ctx, kmi_index_insert_host(idx, mine.data(), mine.size() / KmerType::nWords));
+  }
+  // imxx::distribute for size() > 1: KeyToRank on the device, all-to-all by the caller's exchange
+  std::vector<uint64_t> route_words(const uint64_t *words, size_t n) const {
+    if (!comm.exchange) throw std::invalid_argument("comm.size() > 1 needs comm.exchange (all-to-all of k-mer words)");
+    const uint32_t p = (uint32_t)comm.size(), nw = KmerType::nWords;
+    std::vector<uint64_t> canon(n * nw);
+    std::vector<uint32_t> ranks(n);
+    if (n) {
+      if (cfg.strand == KMI_STRAND_SINGLE) std::memcpy(canon.data(), words, sizeof(uint64_t) * n * nw);
+      else ::kmerind::check(ctx, kmi_canonical_host(ctx, &cfg, words, n, canon.data()));
+      ::kmerind::check(ctx, kmi_key_to_rank_host(ctx, &cfg, canon.data(), n, p, ranks.data()));
+    }
+    std::vector<uint64_t> counts(p, 0), offs(p, 0), send(n * nw);
+    for (size_t i = 0; i < n; ++i) ++counts[ranks[i]];
+    for (uint32_t r = 1; r < p; ++r) offs[r] = offs[r - 1] + counts[r - 1];
+    for (size_t i = 0; i < n; ++i) std::memcpy(&send[(offs[ranks[i]]++) * nw], &canon[i * nw], sizeof(uint64_t) * nw);  // stable
+    return comm.exchange(send, counts, nw);
+  }
+  std::vector<uint64_t> route_queries(const std::vector<KmerType> &query) const {
+    const uint64_t *w = detail::words_of(query);
+    if (comm.size() == 1) return std::vector<uint64_t>(w, w + query.size() * KmerType::nWords);
+    return route_words(w, query.size());
+  }
+
+  ::kmerind::comm comm;
+  kmi_config cfg;
+  kmi_ctx *ctx = nullptr;
+  kmi_index *idx = nullptr;
+};
+
+template <typename MapType> using KmerIndex = Index<MapType, KmerParser<typename MapType::key_type>>;
+template <typename MapType> using CountIndex = Index<MapType, KmerCountTupleParser<std::pair<typename MapType::key_type, typename MapType::mapped_type>>>;
+template <typename MapType> using CountIndex2 = Index<MapType, KmerParser<typename MapType::key_type>>;
+
+}  // namespace kmer
+}  // namespace index
+
+// ---------------------------------------------------------------------------
+// bliss::io::KmerFileHelper::read_file_* (kmer_file_helper.hpp:550-633)
+// ---------------------------------------------------------------------------
+namespace io {
+struct KmerFileHelper {
+  template <typename KmerParser, template <typename> class SeqParser, template <typename, template <typename> class> class SeqIterType>
+  static std::pair<size_t, size_t> read_file_posix(const std::string &filename, std::vector<typename KmerParser::value_type> &result,
+                                                   const ::kmerind::comm &comm) {
+    using Kmer = typename KmerParser::kmer_type;
+    kmi_config c; std::memset(&c, 0, sizeof(c));
+    c.k = Kmer::size; c.alphabet = Kmer::KmerAlphabet::KMI; c.seq_format = SeqParser<const unsigned char *>::KMI;
+    if (comm.size() > 1) throw std::invalid_argument("read_file_* with size() > 1: pass each rank its own record-aligned partition");
+    std::vector<uint8_t> bytes = ::bliss::index::kmer::detail::read_whole_file(filename);
+    kmi_ctx *ctx = nullptr;
+    ::kmerind::check(nullptr, kmi_ctx_create(comm.device, comm.rank(), comm.size(), comm.stream, &ctx));
+    kmi_tuples t{};
+    kmi_status st = kmi_extract_host(ctx, &c, bytes.data(), bytes.size(), 0, &t);
+    if (st != KMI_OK) { std::string m = kmi_last_error(ctx); kmi_ctx_destroy(ctx); if (st == KMI_ERR_PARSE) throw std::logic_error(m); throw std::invalid_argument(m); }
+    const size_t before = result.size();
+    result.reserve(before + t.n_tuples);
+    for (uint64_t i = 0; i < t.n_tuples; ++i) result.push_back(make_value<typename KmerParser::value_type, Kmer>(t.kmers + i * Kmer::nWords));
+    std::pair<size_t, size_t> r((size_t)t.n_seqs, (size_t)t.n_tuples);
+    kmi_tuples_free(&t);
+    kmi_ctx_destroy(ctx);
+    return r;
+  }
+  template <typename KmerParser, template <typename> class SeqParser, template <typename, template <typename> class> class SeqIterType>
+  static std::pair<size_t, size_t> read_file_mmap(const std::string &filename, std::vector<typename KmerParser::value_type> &result,
+                                                  const ::kmerind::comm &comm) {
+    return read_file_posix<KmerParser, SeqParser, SeqIterType>(filename, result, comm);
+  }
+
+ private:
+  template <typename V, typename Kmer> static typename std::enable_if<std::is_same<V, Kmer>::value, V>::type make_value(const uint64_t *w) { return Kmer(w); }
+  template <typename V, typename Kmer> static typename std::enable_if<!std::is_same<V, Kmer>::value, V>::type make_value(const uint64_t *w) {
+    return V(Kmer(w), typename V::second_type(1));  // KmerCountTupleParser zips the k-mer with a constant 1 (kmer_parser.hpp:1008-1081)
+  }
+};
+}  // namespace io
+}  // namespace bliss
+
+#endif  // KMERIND_KMER_INDEX_HPP

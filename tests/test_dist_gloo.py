@@ -1,0 +1,72 @@
+"""world_size-2 rehearsal of the N>1 path on CPU tensors (gloo): record-aligned sharding,
+KeyToRank routing and the all-to-all exchange wrapper that bench.py runs over RCCL.
+The GPU compute is replaced by the oracle here -- as the checker's stand-in only -- so what
+is exercised is the product's host logic: kmerind_amd.fileio and kmerind_amd.dist."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from tests import oracle as orc
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, data, k, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from kmerind_amd import dist as kdist
+        from kmerind_amd import fileio
+        s = orc.kspec(k)
+        b, e = fileio.partition_fastq(data, world)[rank]
+        ex = orc.extract(s, data[b:e], orc.FASTQ, file_offset=b)
+        keys = orc.canonical(s, ex["kmers"])                       # transform_input
+        ranks = orc.key_to_rank(s, orc.MURMUR, orc.CANONICAL, keys, world)
+        order = np.argsort(ranks, kind="stable")                    # stable bucket permutation
+        send = torch.from_numpy(keys[order].view(np.int64))
+        counts = np.bincount(ranks, minlength=world).tolist()
+        recv, recv_counts = kdist.exchange_keys(send, counts)
+        m = orc.CountMap(s, orc.SINGLE)
+        m.insert(recv.numpy().view(np.uint64))
+        total = kdist.global_size(m.size())
+        mine_k, mine_c = m.export()
+        ret[rank] = (mine_k.copy(), mine_c.copy(), total, recv_counts, counts, ex["kmers"].shape[0])
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_build_over_gloo_matches_single_rank(world):
+    import kmerind_amd as K
+    k = 31
+    data = bytes(K.synth_fastq(seed=3, genome_len=20_000, n_reads=600))
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), data, k, ret), nprocs=world, join=True)
+    s = orc.kspec(k)
+    ex = orc.extract(s, data, orc.FASTQ)
+    ref = orc.CountMap(s, orc.CANONICAL)
+    ref.insert(ex["kmers"])
+    rk, rc = ref.export()
+    keys = np.concatenate([ret[r][0] for r in range(world)])
+    cnts = np.concatenate([ret[r][1] for r in range(world)])
+    assert sum(ret[r][5] for r in range(world)) == ex["kmers"].shape[0]
+    a, b = orc.sorted_pairs(keys, cnts), orc.sorted_pairs(rk, rc)
+    assert a[0].shape == b[0].shape and (a[0] == b[0]).all() and (a[1] == b[1]).all()
+    for r in range(world):
+        assert ret[r][2] == ref.size()                              # MapType::size() = allreduce
+        # every key a rank owns hashes to that rank (KeyToRank), as in the reference
+        assert (orc.key_to_rank(s, orc.MURMUR, orc.CANONICAL, ret[r][0], world) == r).all()
+        # all2all(counts): what r receives from src is what src sent to r
+        assert ret[r][3] == [ret[src][4][r] for src in range(world)]
