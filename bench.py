@@ -33,6 +33,8 @@ def main():
     ap.add_argument("--k", type=int, default=31)
     ap.add_argument("--cpu-sample-reads", type=int, default=500_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo = rehearsal of the N>1 flow with ranks sharing one GPU (exchange staged through the host)")
     args = ap.parse_args()
 
     import numpy as np
@@ -48,10 +50,15 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    if args.backend == "gloo":
+        local_rank = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
 
     k, read_len = args.k, 150
     kmers_per_read = read_len - k + 1
@@ -84,7 +91,11 @@ def main():
                                         C.c_void_p(d_keys.data_ptr()), None, n_kmers, C.byref(nt), C.byref(ns)))
         ctx.check(L.lib.kmi_route_dev(ctx.h, C.byref(cfg), C.c_void_p(d_keys.data_ptr()), nt.value, world,
                                       C.c_void_p(d_send.data_ptr()), counts.ctypes.data_as(C.c_void_p)))
-        recv, _ = kdist.exchange_keys(d_send[: nt.value], [int(c) for c in counts])
+        if args.backend == "nccl":
+            recv, _ = kdist.exchange_keys(d_send[: nt.value], [int(c) for c in counts])
+        else:
+            recv, _ = kdist.exchange_keys(d_send[: nt.value].cpu(), [int(c) for c in counts])
+            recv = recv.to(dev)
         idx.insert_device(recv.data_ptr(), recv.shape[0])
 
     def sync():
@@ -108,10 +119,11 @@ def main():
 
     local_distinct = idx.local_size()
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        cdev = dev if args.backend == "nccl" else torch.device("cpu")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        distinct = kdist.global_size(local_distinct, device=dev)
+        distinct = kdist.global_size(local_distinct, device=cdev)
     else:
         distinct = local_distinct
 

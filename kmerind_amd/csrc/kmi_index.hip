@@ -29,8 +29,7 @@
 
 #include <algorithm>
 
-#include "kmi_block.h"
-#include "kmi_internal.h"
+#include "kmi_extract.h"
 
 namespace kmi {
 
@@ -156,6 +155,23 @@ __global__ __launch_bounds__(kPartThreads) void hist_rank_kernel(const uint64_t 
   if (threadIdx.x < kNumCoarse) wg_hist[(uint64_t)blockIdx.x * kNumCoarse + threadIdx.x] = s_hist[threadIdx.x];
 }
 
+// wg_off[w][c] = base[c] + sum_{w' < w} wg_hist[w'][c] for c < ncols: one wavefront per column,
+// 64 groups per step, carried wave scan
+__device__ __forceinline__ void column_offsets(const uint32_t *__restrict__ wg_hist, uint32_t groups, uint32_t ncols,
+                                               const uint64_t *base /* LDS or global */, uint64_t *__restrict__ wg_off) {
+  const uint32_t nwaves = blockDim.x >> 6;
+  for (uint32_t c = wave_id(); c < ncols; c += nwaves) {
+    uint64_t carry = base[c];
+    for (uint32_t w0 = 0; w0 < groups; w0 += kWave) {
+      const uint32_t w = w0 + lane_id();
+      const uint64_t v = (w < groups) ? wg_hist[(uint64_t)w * kNumCoarse + c] : 0ull;
+      const uint64_t inc = wave_inclusive_scan(v);
+      if (w < groups) wg_off[(uint64_t)w * kNumCoarse + c] = carry + inc - v;
+      carry += __shfl(inc, kWave - 1, kWave);
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------
 // offsets: fine_off = exclusive scan of fine_hist (u64, kNumFine+1 entries);
 //          wg_off[w][c] = fine_off[c*128] + sum_{w'<w} wg_hist[w'][c]
@@ -187,48 +203,61 @@ __global__ __launch_bounds__(1024) void fine_offsets_kernel(const uint32_t *__re
   }
   if (threadIdx.x == 0) fine_off[kNumFine] = total;
   __syncthreads();
-  if (wg_off && threadIdx.x < kNumCoarse) {
-    uint64_t o = s_coarse[threadIdx.x];
-    for (uint32_t w = 0; w < groups; ++w) {
-      wg_off[(uint64_t)w * kNumCoarse + threadIdx.x] = o;
-      o += wg_hist[(uint64_t)w * kNumCoarse + threadIdx.x];
-    }
-  }
+  if (wg_off) column_offsets(wg_hist, groups, kNumCoarse, s_coarse, wg_off);
 }
 
 // rank mode: bucket_off[r] (nbuckets+1) and wg_off[w][r]
-__global__ __launch_bounds__(256) void rank_offsets_kernel(const uint32_t *__restrict__ wg_hist, uint32_t groups, uint32_t nbuckets,
-                                                          uint64_t *__restrict__ bucket_cnt, uint64_t *__restrict__ wg_off) {
-  __shared__ uint64_t s_scan[256 / 64 + 2];
-  uint64_t tot = 0;
-  if (threadIdx.x < nbuckets)
-    for (uint32_t w = 0; w < groups; ++w) tot += wg_hist[(uint64_t)w * kNumCoarse + threadIdx.x];
+__global__ __launch_bounds__(1024) void rank_offsets_kernel(const uint32_t *__restrict__ wg_hist, uint32_t groups, uint32_t nbuckets,
+                                                           uint64_t *__restrict__ bucket_cnt, uint64_t *__restrict__ wg_off) {
+  __shared__ uint64_t s_scan[1024 / 64 + 2];
+  __shared__ uint64_t s_base[kNumCoarse];
+  __shared__ uint64_t s_tot[kNumCoarse];
+  for (uint32_t c = wave_id(); c < nbuckets; c += (blockDim.x >> 6)) {
+    uint64_t v = 0;
+    for (uint32_t w = lane_id(); w < groups; w += kWave) v += wg_hist[(uint64_t)w * kNumCoarse + c];
+    v = wave_reduce_sum(v);
+    if (lane_id() == 0) s_tot[c] = v;
+  }
+  __syncthreads();
+  const uint64_t tot = (threadIdx.x < nbuckets) ? s_tot[threadIdx.x] : 0ull;
   uint64_t total;
   uint64_t off = block_exclusive_scan<uint64_t>(tot, s_scan, &total);
-  if (threadIdx.x < nbuckets) {
-    bucket_cnt[threadIdx.x] = tot;
-    uint64_t o = off;
-    for (uint32_t w = 0; w < groups; ++w) {
-      wg_off[(uint64_t)w * kNumCoarse + threadIdx.x] = o;
-      o += wg_hist[(uint64_t)w * kNumCoarse + threadIdx.x];
-    }
-  }
+  if (threadIdx.x < nbuckets) { bucket_cnt[threadIdx.x] = tot; s_base[threadIdx.x] = off; }
+  __syncthreads();
+  column_offsets(wg_hist, groups, nbuckets, s_base, wg_off);
 }
 
 // ---------------------------------------------------------------------------
-// K2 / P2: tile-wise bucket sort in LDS + contiguous runs out
+// K2 / P2: tile-wise bucket sort in LDS + contiguous runs out.
+// Per tile: (S0) hash + rank by LDS atomic, (S1) 256-counter scan by the first four waves,
+// (S2) publish local offsets and global bases, (S3) keys into the bucket-sorted stage,
+// (S4) contiguous copy-out. Four barriers per tile; the running output cursor of bucket b lives
+// in a register of thread b; the next tile's keys are already in flight during S1-S4.
 // ---------------------------------------------------------------------------
 template <int NW, int BITS>
 __device__ __forceinline__ void scatter_range(const uint64_t *__restrict__ in, uint64_t begin, uint64_t end, uint64_t *__restrict__ out,
                                               const KShape &shape, uint32_t strand, bool transform, const BucketFn &fn,
+                                              uint64_t cursor /* of bucket threadIdx.x, threads < 256 */,
                                               uint64_t *s_stage, uint8_t *s_bkt, uint32_t *s_cnt, uint32_t *s_lofs,
-                                              uint64_t *s_cursor, uint32_t *s_scan) {
+                                              uint64_t *s_gbase, uint32_t *s_part) {
   constexpr int TILE = PartCfg<NW>::TILE;
   constexpr int PT = PartCfg<NW>::PER_THREAD;
+  if (threadIdx.x < kNumCoarse) s_cnt[threadIdx.x] = 0;
+  __syncthreads();
+  uint64_t raw[PT][NW];
+  auto load_tile = [&](uint64_t t0) {
+#pragma unroll
+    for (int j = 0; j < PT; ++j) {
+      const uint64_t i = t0 + (uint64_t)j * kPartThreads + threadIdx.x;
+      if (i < end) {
+#pragma unroll
+        for (int w = 0; w < NW; ++w) raw[j][w] = in[i * NW + w];
+      }
+    }
+  };
+  load_tile(begin);
   for (uint64_t t0 = begin; t0 < end; t0 += TILE) {
     const uint32_t nt = (uint32_t)((end - t0 < (uint64_t)TILE) ? (end - t0) : (uint64_t)TILE);
-    if (threadIdx.x < kNumCoarse) s_cnt[threadIdx.x] = 0;
-    __syncthreads();
     uint64_t k[PT][NW];
     uint32_t bk[PT], rk[PT];
 #pragma unroll
@@ -236,15 +265,34 @@ __device__ __forceinline__ void scatter_range(const uint64_t *__restrict__ in, u
       const uint32_t li = j * kPartThreads + threadIdx.x;
       bk[j] = 0xffffffffu;
       if (li < nt) {
-        load_key<NW, BITS>(in, t0 + li, shape, strand, transform, k[j]);
+        if (transform) strand_key<NW, BITS>(raw[j], k[j], shape, strand);
+        else {
+#pragma unroll
+          for (int w = 0; w < NW; ++w) k[j][w] = raw[j][w];
+        }
         bk[j] = bucket_of<NW>(k[j], fn);
         rk[j] = atomicAdd(&s_cnt[bk[j]], 1u);
       }
     }
+    if (t0 + TILE < end) load_tile(t0 + TILE);   // in flight until the next iteration needs it
     __syncthreads();
-    uint32_t c = (threadIdx.x < kNumCoarse) ? s_cnt[threadIdx.x] : 0u;
-    uint32_t lo = block_exclusive_scan<uint32_t>(c, s_scan, (uint32_t *)nullptr);
-    if (threadIdx.x < kNumCoarse) s_lofs[threadIdx.x] = lo;
+    uint32_t c = 0, inc = 0;
+    if (threadIdx.x < kNumCoarse) {              // waves 0..3, whole waves
+      c = s_cnt[threadIdx.x];
+      s_cnt[threadIdx.x] = 0;
+      inc = wave_inclusive_scan(c);
+      if (lane_id() == kWave - 1) s_part[wave_id()] = inc;
+    }
+    __syncthreads();
+    if (threadIdx.x < kNumCoarse) {
+      uint32_t pre = 0;
+#pragma unroll
+      for (uint32_t w = 0; w < kNumCoarse / kWave; ++w) pre += (w < wave_id()) ? s_part[w] : 0u;
+      const uint32_t lo = pre + inc - c;
+      s_lofs[threadIdx.x] = lo;
+      s_gbase[threadIdx.x] = cursor - lo;
+      cursor += c;
+    }
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < PT; ++j) {
@@ -257,14 +305,12 @@ __device__ __forceinline__ void scatter_range(const uint64_t *__restrict__ in, u
     }
     __syncthreads();
     for (uint32_t s = threadIdx.x; s < nt; s += kPartThreads) {
-      const uint32_t b = s_bkt[s];
-      const uint64_t dst = s_cursor[b] + (s - s_lofs[b]);
+      const uint64_t dst = s_gbase[s_bkt[s]] + s;
 #pragma unroll
       for (int w = 0; w < NW; ++w) out[dst * NW + w] = s_stage[(uint64_t)s * NW + w];
     }
-    __syncthreads();
-    if (threadIdx.x < kNumCoarse) s_cursor[threadIdx.x] += s_cnt[threadIdx.x];
-    __syncthreads();
+    // no barrier here: the next tile's S0 only touches s_cnt (reset in S1 above) and its S2/S3
+    // writes are separated from this copy-out by the two barriers in between
   }
 }
 
@@ -273,8 +319,8 @@ __device__ __forceinline__ void scatter_range(const uint64_t *__restrict__ in, u
   __shared__ uint8_t s_bkt[PartCfg<NW>::TILE];                     \
   __shared__ uint32_t s_cnt[kNumCoarse];                           \
   __shared__ uint32_t s_lofs[kNumCoarse];                          \
-  __shared__ uint64_t s_cursor[kNumCoarse];                        \
-  __shared__ uint32_t s_scan[kPartThreads / 64 + 2];
+  __shared__ uint64_t s_gbase[kNumCoarse];                         \
+  __shared__ uint32_t s_part[kNumCoarse / kWave];
 
 // K2: workgroup w scatters its chunk of the input by coarse bucket (or by rank)
 template <int NW, int BITS>
@@ -282,12 +328,11 @@ __global__ __launch_bounds__(kPartThreads) void scatter_chunks_kernel(const uint
                                                                      KShape shape, uint32_t strand, bool transform, BucketFn fn,
                                                                      const uint64_t *__restrict__ wg_off) {
   KMI_SCATTER_LDS(NW)
-  if (threadIdx.x < kNumCoarse) s_cursor[threadIdx.x] = wg_off[(uint64_t)blockIdx.x * kNumCoarse + threadIdx.x];
-  __syncthreads();
+  const uint64_t cursor = (threadIdx.x < kNumCoarse) ? wg_off[(uint64_t)blockIdx.x * kNumCoarse + threadIdx.x] : 0ull;
   const uint64_t chunk = part_chunk(n, gridDim.x, PartCfg<NW>::TILE);
   const uint64_t b = (uint64_t)blockIdx.x * chunk;
   const uint64_t e = (b + chunk < n) ? b + chunk : n;
-  if (b < e) scatter_range<NW, BITS>(in, b, e, out, shape, strand, transform, fn, s_stage, s_bkt, s_cnt, s_lofs, s_cursor, s_scan);
+  if (b < e) scatter_range<NW, BITS>(in, b, e, out, shape, strand, transform, fn, cursor, s_stage, s_bkt, s_cnt, s_lofs, s_gbase, s_part);
 }
 
 // P2: workgroup (c, h) splits the part of coarse bucket c that K2 groups [h*256,(h+1)*256) wrote
@@ -297,13 +342,162 @@ __global__ __launch_bounds__(kPartThreads) void scatter_fine_kernel(const uint64
                                                                    const uint64_t *__restrict__ wg_off) {
   KMI_SCATTER_LDS(NW)
   const uint32_t c = blockIdx.x / kFineParts, h = blockIdx.x % kFineParts;
-  if (threadIdx.x < kNumCoarse)
-    s_cursor[threadIdx.x] = (threadIdx.x < kSubPerCoarse) ? part_off[(uint64_t)h * kNumFine + c * kSubPerCoarse + threadIdx.x] : 0ull;
-  __syncthreads();
+  const uint64_t cursor = (threadIdx.x < kSubPerCoarse) ? part_off[(uint64_t)h * kNumFine + c * kSubPerCoarse + threadIdx.x] : 0ull;
   const uint64_t b = wg_off[(uint64_t)(h * kGroupsPerPart) * kNumCoarse + c];
   const uint64_t e = (h + 1 < (uint32_t)kFineParts) ? wg_off[(uint64_t)((h + 1) * kGroupsPerPart) * kNumCoarse + c] : fine_off[(c + 1) * kSubPerCoarse];
   BucketFn fn; fn.mode = BUCKET_SUB; fn.shape = shape; fn.dist_hash = 0; fn.farm_ndebug = false; fn.nranks = 1;
-  if (b < e) scatter_range<NW, BITS>(in, b, e, out, shape, 0u, false, fn, s_stage, s_bkt, s_cnt, s_lofs, s_cursor, s_scan);
+  if (b < e) scatter_range<NW, BITS>(in, b, e, out, shape, 0u, false, fn, cursor, s_stage, s_bkt, s_cnt, s_lofs, s_gbase, s_part);
+}
+
+
+// ---------------------------------------------------------------------------
+// Fused build (Index::build_* on one rank): the k-mers are generated from the FASTQ tiles
+// inside the histogram pass (E1) and again inside the coarse scatter pass (E2), so the
+// extracted tuple array never exists in HBM: 2 x 2.6 B/k-mer of input reads replace
+// 8 W + 8 R + 8 R of key traffic. Workgroup w owns the same contiguous run of tiles in both.
+// ---------------------------------------------------------------------------
+template <int NW, int BITS>
+__global__ __launch_bounds__((ExCfgWide<NW, BITS>::NT)) void fastq_hist_kernel(const uint8_t *__restrict__ bytes, uint64_t n_bytes, uint64_t n_tiles,
+                                                                              KShape shape, uint32_t strand,
+                                                                              const uint32_t *__restrict__ line_base,
+                                                                              uint32_t *__restrict__ fine_hist, uint32_t *__restrict__ wg_hist) {
+  using Cfg = ExCfgWide<NW, BITS>;
+  __shared__ uint32_t s_hist[kNumFine];
+  __shared__ uint32_t s_eol[Cfg::EOL_DW];
+  __shared__ uint32_t s_stream[Cfg::STREAM_DW];
+  __shared__ uint32_t s_scan[Cfg::NT / 64 + 2];
+  for (int i = threadIdx.x; i < kNumFine; i += Cfg::NT) s_hist[i] = 0;
+  __syncthreads();
+  const uint64_t per = (n_tiles + gridDim.x - 1) / gridDim.x;
+  const uint64_t tb = (uint64_t)blockIdx.x * per;
+  const uint64_t te = (tb + per < n_tiles) ? tb + per : n_tiles;
+  for (uint64_t t = tb; t < te; ++t) {
+    uint32_t dw[Cfg::C / 4], eol, ls, lbl, ltot;
+    tile_front<Cfg, true>(bytes, n_bytes, t * Cfg::TILE, s_eol, s_stream, s_scan, dw, eol, ls, lbl, ltot);
+    const uint32_t lines_before = line_base[t] + lbl;
+    uint64_t e[Cfg::NE];
+    load_eol_view<Cfg>(s_eol, threadIdx.x, e);
+    smear_right<Cfg::NE>(e, shape.k);
+    const uint32_t valid = ~(uint32_t)e[0] & fastq_seq_role_mask(lines_before, ls, Cfg::CMASK);
+    for_each_chunk_kmer<Cfg>(s_stream, valid, shape, [&](int, const uint64_t (&rc)[NW], const uint64_t (&fw)[NW]) {
+      const bool use_fw = (strand == 0) || less_words<NW>(fw, rc);
+      uint64_t key[NW];
+#pragma unroll
+      for (int w = 0; w < NW; ++w) key[w] = use_fw ? fw[w] : rc[w];
+      atomicAdd(&s_hist[fine_of(place_hash<NW>(key))], 1u);
+    });
+    __syncthreads();   // the next tile overwrites s_eol / s_stream
+  }
+  uint32_t *part_hist = fine_hist + (uint64_t)(blockIdx.x / kGroupsPerPart) * kNumFine;
+  for (int i = threadIdx.x; i < kNumFine; i += Cfg::NT) {
+    uint32_t v = s_hist[i];
+    if (v) atomicAdd(&part_hist[i], v);
+  }
+  for (int c = threadIdx.x; c < kNumCoarse; c += Cfg::NT) {
+    uint32_t sum = 0;
+    for (int i = 0; i < kSubPerCoarse; ++i) sum += s_hist[c * kSubPerCoarse + ((i + c) & (kSubPerCoarse - 1))];
+    wg_hist[(uint64_t)blockIdx.x * kNumCoarse + c] = sum;
+  }
+}
+
+template <int NW, int BITS>
+__global__ __launch_bounds__((ExCfg<NW, BITS>::NT), (NW == 1 ? 4 : 2)) void fastq_scatter_kernel(const uint8_t *__restrict__ bytes, uint64_t n_bytes, uint64_t n_tiles,
+                                                                             KShape shape, uint32_t strand,
+                                                                             const uint32_t *__restrict__ line_base,
+                                                                             const uint64_t *__restrict__ wg_off, uint64_t *__restrict__ out,
+                                                                             uint32_t *__restrict__ flags) {
+  using Cfg = ExCfg<NW, BITS>;
+  constexpr int C = Cfg::C;
+  static_assert(Cfg::TILE <= PartCfg<NW>::TILE, "stage must hold every window of a tile");
+  static_assert(Cfg::NT >= kNumCoarse, "one thread per coarse bucket");
+  __shared__ uint64_t s_stage[Cfg::TILE * NW];
+  __shared__ uint8_t s_bkt[Cfg::TILE];
+  __shared__ uint32_t s_eol[Cfg::EOL_DW];
+  __shared__ uint32_t s_stream[Cfg::STREAM_DW];
+  __shared__ uint32_t s_scan[Cfg::NT / 64 + 2];
+  __shared__ uint32_t s_cnt[kNumCoarse];
+  __shared__ uint32_t s_lofs[kNumCoarse];
+  __shared__ uint64_t s_gbase[kNumCoarse];
+  __shared__ uint32_t s_part[kNumCoarse / kWave + 1];
+  uint64_t cursor = (threadIdx.x < kNumCoarse) ? wg_off[(uint64_t)blockIdx.x * kNumCoarse + threadIdx.x] : 0ull;
+  if (threadIdx.x < kNumCoarse) s_cnt[threadIdx.x] = 0;
+  const uint64_t per = (n_tiles + gridDim.x - 1) / gridDim.x;
+  const uint64_t tb = (uint64_t)blockIdx.x * per;
+  const uint64_t te = (tb + per < n_tiles) ? tb + per : n_tiles;
+  for (uint64_t t = tb; t < te; ++t) {
+    uint32_t dw[C / 4], eol, ls, lbl, ltot;
+    tile_front<Cfg, true>(bytes, n_bytes, t * Cfg::TILE, s_eol, s_stream, s_scan, dw, eol, ls, lbl, ltot);
+    const uint32_t lines_before = line_base[t] + lbl;
+    {
+      const uint32_t bad = fastq_marker_errors<Cfg>(dw, lines_before, ls, t == 0 && threadIdx.x == 0);
+      if (bad) atomicOr(&flags[0], bad);
+    }
+    uint64_t e[Cfg::NE];
+    load_eol_view<Cfg>(s_eol, threadIdx.x, e);
+    smear_right<Cfg::NE>(e, shape.k);
+    const uint32_t valid = ~(uint32_t)e[0] & fastq_seq_role_mask(lines_before, ls, Cfg::CMASK);
+    // S0: keys of this chunk, their coarse bucket and rank inside (tile, bucket)
+    uint64_t key[C][NW];
+    uint32_t bkrk[C];   // bucket << 16 | rank  (rank < 8192)
+    if (valid) {
+      uint32_t r[Cfg::NR];
+      load_stream_view<Cfg>(s_stream, threadIdx.x, r);
+#pragma unroll
+      for (int p = 0; p < C; ++p) {
+        if ((valid >> p) & 1u) {
+          uint64_t rc[NW], fw[NW];
+          window_words<NW, Cfg::NR>(r, BITS * p, shape, rc);
+          fwd_from_rc<NW, BITS>(rc, fw, shape);
+          const bool use_fw = (strand == 0) || less_words<NW>(fw, rc);
+#pragma unroll
+          for (int w = 0; w < NW; ++w) key[p][w] = use_fw ? fw[w] : rc[w];
+          const uint32_t b = coarse_of(place_hash<NW>(key[p]));
+          bkrk[p] = (b << 16) | atomicAdd(&s_cnt[b], 1u);
+        }
+      }
+    }
+    __syncthreads();
+    uint32_t c = 0, inc = 0;
+    if (threadIdx.x < kNumCoarse) {
+      c = s_cnt[threadIdx.x];
+      s_cnt[threadIdx.x] = 0;
+      inc = wave_inclusive_scan(c);
+      if (lane_id() == kWave - 1) s_part[wave_id()] = inc;
+    }
+    __syncthreads();
+    if (threadIdx.x < kNumCoarse) {
+      uint32_t pre = 0;
+#pragma unroll
+      for (uint32_t w = 0; w < kNumCoarse / kWave; ++w) pre += (w < wave_id()) ? s_part[w] : 0u;
+      const uint32_t lo = pre + inc - c;
+      s_lofs[threadIdx.x] = lo;
+      s_gbase[threadIdx.x] = cursor - lo;
+      cursor += c;
+      if (threadIdx.x == kNumCoarse - 1) s_part[kNumCoarse / kWave] = lo + c;   // keys in this tile
+    }
+    __syncthreads();
+    if (valid) {
+#pragma unroll
+      for (int p = 0; p < C; ++p) {
+        if ((valid >> p) & 1u) {
+          const uint32_t b = bkrk[p] >> 16;
+          const uint32_t pos = s_lofs[b] + (bkrk[p] & 0xffffu);
+#pragma unroll
+          for (int w = 0; w < NW; ++w) s_stage[(uint64_t)pos * NW + w] = key[p][w];
+          s_bkt[pos] = (uint8_t)b;
+        }
+      }
+    }
+    __syncthreads();
+    const uint32_t nt = s_part[kNumCoarse / kWave];
+    for (uint32_t s = threadIdx.x; s < nt; s += Cfg::NT) {
+      const uint64_t dst = s_gbase[s_bkt[s]] + s;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) out[dst * NW + w] = s_stage[(uint64_t)s * NW + w];
+    }
+    // tile_front of the next tile starts with a barrier-separated phase: stage / offsets are not
+    // rewritten before every thread has left this copy-out
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -402,6 +596,81 @@ template <int NW> __device__ __forceinline__ int table_upsert(const LdsTable<NW>
   }
 }
 
+// which reduction pass a key belongs to when a bucket needs several
+__device__ __forceinline__ uint32_t pass_of(uint32_t h, uint32_t npass) {
+  return npass == 1 ? 0u : (uint32_t)(((uint64_t)(h * 0x9E3779B1u) * npass) >> 32);
+}
+
+// NW == 1: continue a linear probe that already failed at `slot` (first probe done by the caller)
+__device__ __forceinline__ int table_upsert_continue1(const LdsTable<1> &t, uint64_t key, uint32_t slot) {
+  constexpr int CAP = TabCfg<1>::CAP;
+  for (int probes = 1; probes < CAP; ++probes) {
+    slot = (slot + 1 == (uint32_t)CAP) ? 0u : slot + 1;
+    unsigned long long old = atomicCAS((unsigned long long *)&t.keys[slot], (unsigned long long)kEmptyKey, (unsigned long long)key);
+    if (old == kEmptyKey || old == key) {
+      if (probes >= kMaxProbe) *t.overflow = 1;
+      return (int)slot;
+    }
+  }
+  *t.overflow = 1;
+  return -1;
+}
+
+// NW == 1 insert of keys[b, e) with weight 1: U keys per thread; the U first probes (64-bit LDS
+// compare-and-swap) are issued back to back so their latencies overlap, only keys whose home slot
+// is taken by another key fall into the serial probe loop.
+template <int U>
+__device__ __forceinline__ void table_insert_stream1(const LdsTable<1> &t, const uint64_t *__restrict__ keys, uint64_t b, uint64_t e,
+                                                     uint32_t npass, uint32_t pass) {
+  constexpr int CAP = TabCfg<1>::CAP;
+  const uint64_t step = (uint64_t)blockDim.x * U;
+  uint64_t nxt[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const uint64_t i = b + (uint64_t)u * blockDim.x + threadIdx.x;
+    nxt[u] = (i < e) ? keys[i] : kEmptyKey;
+  }
+  for (uint64_t i0 = b; i0 < e; i0 += step) {
+    uint64_t k[U];
+    bool act[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint64_t i = i0 + (uint64_t)u * blockDim.x + threadIdx.x;
+      act[u] = i < e;
+      k[u] = nxt[u];
+    }
+    if (i0 + step < e) {   // next batch in flight while this one goes through the table
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const uint64_t i = i0 + step + (uint64_t)u * blockDim.x + threadIdx.x;
+        nxt[u] = (i < e) ? keys[i] : kEmptyKey;
+      }
+    }
+    uint32_t slot[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint64_t kk[1] = {k[u]};
+      const uint32_t h = place_hash<1>(kk);
+      slot[u] = slot_of(h, CAP);
+      act[u] = act[u] && (pass_of(h, npass) == pass);
+      if (act[u] && k[u] == kEmptyKey) { *t.special_set = 1; atomicAdd(t.special, 1u); act[u] = false; }
+    }
+    unsigned long long old[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      old[u] = atomicCAS((unsigned long long *)&t.keys[slot[u]], (unsigned long long)kEmptyKey,
+                         (unsigned long long)(act[u] ? k[u] : kEmptyKey));
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (act[u]) {
+        int sidx = (int)slot[u];
+        if (!(old[u] == kEmptyKey || old[u] == k[u])) sidx = table_upsert_continue1(t, k[u], slot[u]);
+        if (sidx >= 0) atomicAdd(&t.vals[sidx], 1u);
+      }
+    }
+  }
+}
+
 // lookup only; returns slot or -1
 template <int NW> __device__ __forceinline__ int table_find(const LdsTable<NW> &t, const uint64_t (&key)[NW], uint32_t h) {
   constexpr int CAP = TabCfg<NW>::CAP;
@@ -434,11 +703,6 @@ template <int NW> __device__ __forceinline__ int table_find(const LdsTable<NW> &
 
 template <int NW> __device__ __forceinline__ bool slot_used(const LdsTable<NW> &t, int slot) {
   return NW == 1 ? (t.keys[slot] != kEmptyKey) : (t.tags[slot] != kTagEmpty);
-}
-
-// which reduction pass a key belongs to when a bucket needs several
-__device__ __forceinline__ uint32_t pass_of(uint32_t h, uint32_t npass) {
-  return npass == 1 ? 0u : (uint32_t)(((uint64_t)(h * 0x9E3779B1u) * npass) >> 32);
 }
 
 // visit keys[b, e) with U independent loads per thread in flight; f(key words, index)
@@ -504,13 +768,16 @@ __global__ __launch_bounds__((TabCfg<NW>::NT)) void bucket_reduce_kernel(const u
         if (s >= 0) atomicAdd(&tab.vals[s], old_vals[i]);
         else if (s == -2) atomicAdd(tab.special, old_vals[i]);
       });
-      for_each_key<NW, BatchOf<NW>::U>(new_keys, nb, ne, [&](const uint64_t (&k)[NW], uint64_t) {
-        const uint32_t h = place_hash<NW>(k);
-        if (pass_of(h, npass) != pass) return;
-        int s = table_upsert<NW>(tab, k, h);
-        if (s >= 0) atomicAdd(&tab.vals[s], 1u);
-        else if (s == -2) atomicAdd(tab.special, 1u);
-      });
+      if constexpr (NW == 1) {
+        table_insert_stream1<kLoadBatch>(tab, new_keys, nb, ne, npass, pass);
+      } else {
+        for_each_key<NW, BatchOf<NW>::U>(new_keys, nb, ne, [&](const uint64_t (&k)[NW], uint64_t) {
+          const uint32_t h = place_hash<NW>(k);
+          if (pass_of(h, npass) != pass) return;
+          int s = table_upsert<NW>(tab, k, h);
+          if (s >= 0) atomicAdd(&tab.vals[s], 1u);
+        });
+      }
       __syncthreads();
       if (*tab.overflow) { failed = true; break; }
       for (int s = threadIdx.x; s < CAP; s += blockDim.x) {
@@ -688,45 +955,61 @@ struct Partitioned {
   uint64_t *fine_off;  // [kNumFine+1]
 };
 
+struct PartWs {
+  uint64_t *buf_a, *buf_b;
+  uint32_t *fine_hist;   // [kFineParts][kNumFine]
+  uint64_t *fine_off;    // [kNumFine + 1]
+  uint64_t *part_off;    // [kFineParts][kNumFine]
+  uint32_t *wg_hist;     // [kPartGroups][kNumCoarse]
+  uint64_t *wg_off;      // [kPartGroups][kNumCoarse]
+};
+
+static kmi_status get_part_ws(kmi_ctx *ctx, size_t n, int nw, WsSlot slot_a, WsSlot slot_b, PartWs *w) {
+  void *p;
+  const size_t key_bytes = (n ? n : 1) * nw * sizeof(uint64_t);
+  KMI_TRY(ws_get(ctx, slot_a, key_bytes, &p)); w->buf_a = (uint64_t *)p;
+  KMI_TRY(ws_get(ctx, slot_b, key_bytes, &p)); w->buf_b = (uint64_t *)p;
+  KMI_TRY(ws_get(ctx, WS_HIST, sizeof(uint32_t) * kNumFine * kFineParts + sizeof(uint64_t) * ((kNumFine + 1) * 2 + kNumFine * kFineParts) + 256, &p));
+  w->fine_hist = (uint32_t *)p;
+  // offset arrays live behind the histogram: [0] for inserts, [1] for queries, then the per-part offsets
+  uint64_t *off_base = (uint64_t *)((char *)p + sizeof(uint32_t) * kNumFine * kFineParts);
+  w->fine_off = off_base + (slot_b == WS_QUERY_B ? (kNumFine + 1) : 0);
+  w->part_off = off_base + 2 * (kNumFine + 1);
+  KMI_TRY(ws_get(ctx, WS_WGHIST, sizeof(uint32_t) * kPartGroups * kNumCoarse, &p)); w->wg_hist = (uint32_t *)p;
+  KMI_TRY(ws_get(ctx, WS_CURSOR, sizeof(uint64_t) * kPartGroups * kNumCoarse, &p)); w->wg_off = (uint64_t *)p;
+  return KMI_OK;
+}
+
 // K1 + offsets + K2 + P2 on `n` keys; result in slot `slot_b`, scratch in `slot_a`
 template <int NW, int BITS>
 static kmi_status partition_impl(kmi_ctx *ctx, const kmi_config *cfg, KShape shape, const uint64_t *keys_dev, size_t n, bool transform,
                                  WsSlot slot_a, WsSlot slot_b, Partitioned *out) {
-  void *p;
-  const size_t key_bytes = (n ? n : 1) * NW * sizeof(uint64_t);
-  KMI_TRY(ws_get(ctx, slot_a, key_bytes, &p)); uint64_t *buf_a = (uint64_t *)p;
-  KMI_TRY(ws_get(ctx, slot_b, key_bytes, &p)); uint64_t *buf_b = (uint64_t *)p;
-  KMI_TRY(ws_get(ctx, WS_HIST, sizeof(uint32_t) * kNumFine * kFineParts + sizeof(uint64_t) * ((kNumFine + 1) * 2 + kNumFine * kFineParts) + 256, &p));
-  uint32_t *fine_hist = (uint32_t *)p;
-  // offset arrays live behind the histogram: [0] for inserts, [1] for queries, then the per-part offsets
-  uint64_t *off_base = (uint64_t *)((char *)p + sizeof(uint32_t) * kNumFine * kFineParts);
-  uint64_t *fine_off = off_base + (slot_b == WS_QUERY_B ? (kNumFine + 1) : 0);
-  uint64_t *part_off = off_base + 2 * (kNumFine + 1);
-  KMI_TRY(ws_get(ctx, WS_WGHIST, sizeof(uint32_t) * kPartGroups * kNumCoarse, &p)); uint32_t *wg_hist = (uint32_t *)p;
-  KMI_TRY(ws_get(ctx, WS_CURSOR, sizeof(uint64_t) * kPartGroups * kNumCoarse, &p)); uint64_t *wg_off = (uint64_t *)p;
-  KMI_HIP(ctx, hipMemsetAsync(fine_hist, 0, sizeof(uint32_t) * kNumFine * kFineParts, ctx->stream));
+  PartWs w;
+  KMI_TRY(get_part_ws(ctx, n, NW, slot_a, slot_b, &w));
+  KMI_HIP(ctx, hipMemsetAsync(w.fine_hist, 0, sizeof(uint32_t) * kNumFine * kFineParts, ctx->stream));
   {
     ProfScope ps(ctx, "hist_fine", n);
     hipLaunchKernelGGL((hist_fine_kernel<NW, BITS>), dim3(kPartGroups), dim3(kPartThreads), 0, ctx->stream, keys_dev, (uint64_t)n, shape,
-                       cfg->strand, transform, fine_hist, wg_hist);
+                       cfg->strand, transform, w.fine_hist, w.wg_hist);
   }
   {
     ProfScope ps(ctx, "fine_offsets", kNumFine);
-    hipLaunchKernelGGL(fine_offsets_kernel, dim3(1), dim3(1024), 0, ctx->stream, fine_hist, wg_hist, (uint32_t)kPartGroups, fine_off, part_off, wg_off);
+    hipLaunchKernelGGL(fine_offsets_kernel, dim3(1), dim3(1024), 0, ctx->stream, w.fine_hist, w.wg_hist, (uint32_t)kPartGroups, w.fine_off,
+                       w.part_off, w.wg_off);
   }
   BucketFn fn; fn.mode = BUCKET_COARSE; fn.shape = shape; fn.dist_hash = 0; fn.farm_ndebug = false; fn.nranks = 1;
   {
     ProfScope ps(ctx, "scatter_coarse", n);
-    hipLaunchKernelGGL((scatter_chunks_kernel<NW, BITS>), dim3(kPartGroups), dim3(kPartThreads), 0, ctx->stream, keys_dev, (uint64_t)n, buf_a,
-                       shape, cfg->strand, transform, fn, wg_off);
+    hipLaunchKernelGGL((scatter_chunks_kernel<NW, BITS>), dim3(kPartGroups), dim3(kPartThreads), 0, ctx->stream, keys_dev, (uint64_t)n, w.buf_a,
+                       shape, cfg->strand, transform, fn, w.wg_off);
   }
   {
     ProfScope ps(ctx, "scatter_fine", n);
-    hipLaunchKernelGGL((scatter_fine_kernel<NW, BITS>), dim3(kNumCoarse * kFineParts), dim3(kPartThreads), 0, ctx->stream, buf_a, buf_b, shape,
-                       (const uint64_t *)fine_off, (const uint64_t *)part_off, (const uint64_t *)wg_off);
+    hipLaunchKernelGGL((scatter_fine_kernel<NW, BITS>), dim3(kNumCoarse * kFineParts), dim3(kPartThreads), 0, ctx->stream, w.buf_a, w.buf_b, shape,
+                       (const uint64_t *)w.fine_off, (const uint64_t *)w.part_off, (const uint64_t *)w.wg_off);
   }
   KMI_HIP(ctx, hipGetLastError());
-  out->keys = buf_b; out->fine_off = fine_off;
+  out->keys = w.buf_b; out->fine_off = w.fine_off;
   return KMI_OK;
 }
 
@@ -779,12 +1062,10 @@ static kmi_status adopt_tmp(kmi_index *idx, const uint64_t *tmp_keys, const uint
   return KMI_OK;
 }
 
-template <int NW, int BITS>
-static kmi_status insert_impl(kmi_index *idx, const uint64_t *keys_dev, size_t n, bool transform) {
+// C + compaction: fold the fine-partitioned keys into the index
+template <int NW>
+static kmi_status reduce_and_adopt(kmi_index *idx, const Partitioned &part, size_t n) {
   kmi_ctx *ctx = idx->ctx;
-  if (n == 0) return KMI_OK;
-  Partitioned part;
-  KMI_TRY((partition_impl<NW, BITS>(ctx, &idx->cfg, idx->shape, keys_dev, n, transform, WS_KEYS_A, WS_KEYS_B, &part)));
   void *p;
   const uint64_t cap = n + idx->n_entries;
   KMI_TRY(ws_get(ctx, WS_TMP_KEYS, cap * NW * sizeof(uint64_t), &p)); uint64_t *tmp_keys = (uint64_t *)p;
@@ -798,6 +1079,66 @@ static kmi_status insert_impl(kmi_index *idx, const uint64_t *keys_dev, size_t n
   }
   KMI_HIP(ctx, hipGetLastError());
   return adopt_tmp<NW>(idx, tmp_keys, tmp_vals, part.fine_off, idx->has_data ? idx->bucket_off : nullptr, out_cnt);
+}
+
+template <int NW, int BITS>
+static kmi_status insert_impl(kmi_index *idx, const uint64_t *keys_dev, size_t n, bool transform) {
+  kmi_ctx *ctx = idx->ctx;
+  if (n == 0) return KMI_OK;
+  Partitioned part;
+  KMI_TRY((partition_impl<NW, BITS>(ctx, &idx->cfg, idx->shape, keys_dev, n, transform, WS_KEYS_A, WS_KEYS_B, &part)));
+  return reduce_and_adopt<NW>(idx, part, n);
+}
+
+// Index::build_* on one rank, fused: FASTQ tiles -> histogram, FASTQ tiles -> coarse buckets
+template <int NW, int BITS>
+static kmi_status build_fused_impl(kmi_index *idx, const uint8_t *bytes_dev, size_t n_bytes) {
+  kmi_ctx *ctx = idx->ctx;
+  uint64_t n_tiles = 0, n = 0, n_seqs = 0;
+  uint32_t tile_bytes = 0;
+  const uint32_t *line_base = nullptr;
+  KMI_HIP(ctx, hipMemsetAsync(ctx->d_flags, 0, sizeof(uint32_t) * 16, ctx->stream));
+  KMI_TRY(fastq_scan(ctx, &idx->cfg, bytes_dev, n_bytes, &n_tiles, &tile_bytes, &line_base, &n, &n_seqs));
+  if (n == 0) {
+    // nothing to insert, but malformed input must still be reported: run the plain extract checks
+    uint64_t a, b;
+    return extract_run(ctx, &idx->cfg, bytes_dev, n_bytes, 0, nullptr, nullptr, 0, true, true, &a, &b);
+  }
+  PartWs w;
+  KMI_TRY(get_part_ws(ctx, n, NW, WS_KEYS_A, WS_KEYS_B, &w));
+  KMI_HIP(ctx, hipMemsetAsync(w.fine_hist, 0, sizeof(uint32_t) * kNumFine * kFineParts, ctx->stream));
+  {
+    ProfScope ps(ctx, "fastq_hist", n);
+    hipLaunchKernelGGL((fastq_hist_kernel<NW, BITS>), dim3(kPartGroups), dim3(ExCfgWide<NW, BITS>::NT), 0, ctx->stream, bytes_dev,
+                       (uint64_t)n_bytes, n_tiles, idx->shape, idx->cfg.strand, line_base, w.fine_hist, w.wg_hist);
+  }
+  {
+    ProfScope ps(ctx, "fine_offsets", kNumFine);
+    hipLaunchKernelGGL(fine_offsets_kernel, dim3(1), dim3(1024), 0, ctx->stream, w.fine_hist, w.wg_hist, (uint32_t)kPartGroups, w.fine_off,
+                       w.part_off, w.wg_off);
+  }
+  {
+    ProfScope ps(ctx, "fastq_scatter", n);
+    hipLaunchKernelGGL((fastq_scatter_kernel<NW, BITS>), dim3(kPartGroups), dim3(ExCfg<NW, BITS>::NT), 0, ctx->stream, bytes_dev,
+                       (uint64_t)n_bytes, n_tiles, idx->shape, idx->cfg.strand, line_base, (const uint64_t *)w.wg_off, w.buf_a, ctx->d_flags);
+  }
+  {
+    ProfScope ps(ctx, "scatter_fine", n);
+    hipLaunchKernelGGL((scatter_fine_kernel<NW, BITS>), dim3(kNumCoarse * kFineParts), dim3(kPartThreads), 0, ctx->stream, w.buf_a, w.buf_b,
+                       idx->shape, (const uint64_t *)w.fine_off, (const uint64_t *)w.part_off, (const uint64_t *)w.wg_off);
+  }
+  KMI_HIP(ctx, hipGetLastError());
+  uint32_t flags0 = 0;
+  KMI_HIP(ctx, hipMemcpyAsync(&flags0, ctx->d_flags, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+  KMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (flags0 & 1u) return set_err(ctx, KMI_ERR_PARSE, "FASTQ: missing @ on first line of a record");
+  if (flags0 & 2u) return set_err(ctx, KMI_ERR_PARSE, "FASTQ: missing + on third line of a record");
+  Partitioned part; part.keys = w.buf_b; part.fine_off = w.fine_off;
+  return reduce_and_adopt<NW>(idx, part, (size_t)n);
+}
+
+static kmi_status index_build_fused(kmi_index *idx, const uint8_t *bytes_dev, size_t n_bytes) {
+  KMI_DISPATCH(idx->shape, build_fused_impl, idx, bytes_dev, n_bytes);
 }
 
 static kmi_status index_insert(kmi_index *idx, const uint64_t *keys_dev, size_t n, bool transform) {
@@ -872,7 +1213,7 @@ static kmi_status route_impl(kmi_ctx *ctx, const kmi_config *cfg, KShape shape, 
   }
   {
     ProfScope ps(ctx, "rank_offsets", nranks);
-    hipLaunchKernelGGL(rank_offsets_kernel, dim3(1), dim3(256), 0, ctx->stream, (const uint32_t *)wg_hist, (uint32_t)kPartGroups, nranks, cnt, wg_off);
+    hipLaunchKernelGGL(rank_offsets_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const uint32_t *)wg_hist, (uint32_t)kPartGroups, nranks, cnt, wg_off);
   }
   {
     ProfScope ps(ctx, "scatter_rank", n);
@@ -944,14 +1285,10 @@ kmi_status kmi_index_insert_host(kmi_index *idx, const uint64_t *kmers, size_t n
 kmi_status kmi_index_build_dev(kmi_index *idx, const uint8_t *bytes_dev, size_t n_bytes, uint64_t file_offset) {
   if (!idx) return KMI_ERR_INVALID;
   kmi_ctx *ctx = idx->ctx;
+  (void)file_offset;   // only position indexes need it
   KMI_HIP(ctx, hipSetDevice(ctx->device));
   if (n_bytes == 0) return KMI_OK;
-  uint64_t nt = 0, ns = 0;
-  KMI_TRY(extract_count(ctx, &idx->cfg, bytes_dev, n_bytes, &nt, &ns));
-  void *dk;
-  KMI_TRY(ws_get(ctx, WS_OUTPUT, (size_t)(nt ? nt : 1) * idx->shape.n_words * sizeof(uint64_t), &dk));
-  KMI_TRY(extract_run(ctx, &idx->cfg, bytes_dev, n_bytes, file_offset, (uint64_t *)dk, nullptr, (size_t)nt, true, true, &nt, &ns));
-  return index_insert(idx, (const uint64_t *)dk, (size_t)nt, false);
+  return index_build_fused(idx, bytes_dev, n_bytes);
 }
 
 kmi_status kmi_index_build_host(kmi_index *idx, const uint8_t *bytes, size_t n_bytes, uint64_t file_offset) {
