@@ -10,6 +10,12 @@ constexpr int kWave = 64;
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & (kWave - 1); }
 __device__ __forceinline__ uint32_t wave_id() { return threadIdx.x >> 6; }
 
+// Workgroup barrier that orders LDS traffic only: waits for this wave's outstanding LDS operations
+// (lgkmcnt) and then s_barrier. Unlike __syncthreads() it does not drain vmcnt, so global loads
+// issued before it (software prefetch of the next tile) stay in flight across the barrier. Every
+// barrier in these kernels guards LDS data only; HBM results are consumed by later launches.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // inclusive scan across the 64 lanes of a wavefront
 template <typename T> __device__ __forceinline__ T wave_inclusive_scan(T v) {
 #pragma unroll
@@ -30,21 +36,21 @@ template <typename T> __device__ __forceinline__ T wave_reduce_sum(T v) {
 // `scratch` must hold (blockDim.x/64 + 1) elements of T in LDS. Returns the exclusive
 // prefix of this thread; *total receives the workgroup sum. Contains two barriers and
 // may be called repeatedly with the same scratch (a trailing barrier protects reuse).
-template <typename T> __device__ __forceinline__ T block_exclusive_scan(T v, T *scratch, T *total) {
+template <typename T, bool TRAILING_SYNC = true> __device__ __forceinline__ T block_exclusive_scan(T v, T *scratch, T *total) {
   const uint32_t nw = blockDim.x >> 6;
   T inc = wave_inclusive_scan(v);
   if (lane_id() == kWave - 1) scratch[wave_id()] = inc;
-  __syncthreads();
+  lds_barrier();
   if (wave_id() == 0) {
     T w = (lane_id() < nw) ? scratch[lane_id()] : T(0);
     T winc = wave_inclusive_scan(w);
     if (lane_id() < nw) scratch[lane_id()] = winc - w;   // exclusive prefix of each wave
     if (lane_id() == nw - 1) scratch[nw] = winc;          // total
   }
-  __syncthreads();
+  lds_barrier();
   T res = scratch[wave_id()] + inc - v;
   if (total) *total = scratch[nw];
-  __syncthreads();
+  if (TRAILING_SYNC) lds_barrier();   // without it the caller must not reuse `scratch` before another barrier
   return res;
 }
 

@@ -31,6 +31,7 @@ template <int NW, int BITS> using ExCfgWide = ExCfgT<NW, BITS, 8, ExCfg<NW, BITS
 struct TileInfo {
   uint32_t lines;     // line starts in the tile
   uint32_t win[4];    // EOL-free k-windows starting in the tile, by (local line count & 3)
+  uint32_t marks;     // bit r: a line with (local line index & 3) == r does not start with '@'; bit 4+r: ... with '+'
 };
 
 // ---- chunk load: C bytes at byte offset g (zero-filled past n_bytes); returns #valid bytes
@@ -97,29 +98,80 @@ template <typename Cfg> __device__ __forceinline__ void load_stream_view(const u
   for (int i = 0; i < Cfg::NR; ++i) r[i] = sh ? ((raw[i] >> sh) | (raw[i + 1] << (32 - sh))) : raw[i];
 }
 
-// common front end of passes 1 and 3: classify own chunk (+ halo chunk), publish the EOL bits
-// (and optionally the stream), derive line starts and the block-exclusive line count.
-template <typename Cfg, bool WITH_STREAM>
-__device__ __forceinline__ void tile_front(const uint8_t *__restrict__ bytes, uint64_t n_bytes, uint64_t tile0,
-                                           uint32_t *s_eol, uint32_t *s_stream, uint32_t *s_scan,
-                                           uint32_t (&dw)[Cfg::C / 4], uint32_t &eol, uint32_t &ls,
-                                           uint32_t &lines_before_local, uint32_t &lines_total) {
+// ---------------------------------------------------------------------------
+// The scan pass materialises the "2-bit pack" stage once: a bitmap of EOL bytes (1 bit per input
+// byte) and the packed COMPLEMENT-code stream (BITS per input byte), both plain little-endian
+// bit streams in HBM (1/8 + BITS/8 bytes per input byte). Every later pass starts from these
+// instead of re-classifying the raw bytes.
+// ---------------------------------------------------------------------------
+struct PackedInput {
+  const uint8_t *eol;      // bit i  <=> input byte i is an EOL (bytes past the end count as EOL)
+  const uint8_t *stream;   // bits [BITS*i, BITS*i+BITS) = complement code of input byte i
+  uint64_t n_bytes;        // input length
+  uint64_t n_cover;        // bytes covered by the arrays (multiple of the scan tile)
+};
+
+template <int C> __device__ __forceinline__ uint32_t read_eol_unit(const uint8_t *__restrict__ pk, uint64_t g) {
+  if constexpr (C == 16) return reinterpret_cast<const uint16_t *>(pk)[g];
+  else return pk[g];
+}
+template <int C> __device__ __forceinline__ void write_eol_unit(uint8_t *__restrict__ pk, uint64_t g, uint32_t e) {
+  if constexpr (C == 16) reinterpret_cast<uint16_t *>(pk)[g] = (uint16_t)e;
+  else pk[g] = (uint8_t)e;
+}
+template <int BITS, int C> __device__ __forceinline__ uint64_t read_stream_unit(const uint8_t *__restrict__ pk, uint64_t g) {
+  constexpr int NB = BITS * C / 8;
+  if constexpr (NB == 4) return reinterpret_cast<const uint32_t *>(pk)[g];
+  else if constexpr (NB == 2) return reinterpret_cast<const uint16_t *>(pk)[g];
+  else if constexpr (NB == 6) {
+    const uint16_t *p = reinterpret_cast<const uint16_t *>(pk) + 3 * g;
+    return (uint64_t)p[0] | ((uint64_t)p[1] << 16) | ((uint64_t)p[2] << 32);
+  } else {
+    const uint8_t *p = pk + (uint64_t)NB * g;
+    uint64_t v = 0;
+#pragma unroll
+    for (int i = 0; i < NB; ++i) v |= (uint64_t)p[i] << (8 * i);
+    return v;
+  }
+}
+template <int BITS, int C> __device__ __forceinline__ void write_stream_unit(uint8_t *__restrict__ pk, uint64_t g, uint64_t st) {
+  constexpr int NB = BITS * C / 8;
+  if constexpr (NB == 4) reinterpret_cast<uint32_t *>(pk)[g] = (uint32_t)st;
+  else if constexpr (NB == 2) reinterpret_cast<uint16_t *>(pk)[g] = (uint16_t)st;
+  else if constexpr (NB == 6) {
+    uint16_t *p = reinterpret_cast<uint16_t *>(pk) + 3 * g;
+    p[0] = (uint16_t)st; p[1] = (uint16_t)(st >> 16); p[2] = (uint16_t)(st >> 32);
+  } else {
+    uint8_t *p = pk + (uint64_t)NB * g;
+#pragma unroll
+    for (int i = 0; i < NB; ++i) p[i] = (uint8_t)(st >> (8 * i));
+  }
+}
+
+// front end of the scan pass: classify the raw bytes of this thread's chunk (+ halo), publish
+// EOL bits in LDS, write the packed arrays, derive line starts and the block-exclusive line count
+template <typename Cfg>
+__device__ __forceinline__ void tile_front_bytes(const uint8_t *__restrict__ bytes, uint64_t n_bytes, uint64_t tile,
+                                                 uint8_t *__restrict__ pk_eol, uint8_t *__restrict__ pk_stream,
+                                                 uint32_t *s_eol, uint32_t *s_scan, uint32_t (&dw)[Cfg::C / 4],
+                                                 uint32_t &eol, uint32_t &ls, uint32_t &lines_before_local, uint32_t &lines_total) {
   constexpr int C = Cfg::C;
   constexpr int BITS = Cfg::BITS;
   const int j = threadIdx.x;
+  const uint64_t tile0 = tile * Cfg::TILE;
   uint64_t st;
   int nv = load_chunk<C>(bytes, n_bytes, tile0 + (uint64_t)j * C, dw);
   classify_chunk<BITS, C>(dw, nv, eol, st);
   store_eol_bits<C>(s_eol, j, eol);
-  if (WITH_STREAM) store_stream_bits<BITS, C>(s_stream, j, st);
+  write_eol_unit<C>(pk_eol, tile * Cfg::NT + j, eol);
+  write_stream_unit<BITS, C>(pk_stream, tile * Cfg::NT + j, st);
   if (j < Cfg::HALO_CHUNKS) {
     uint32_t hdw[C / 4]; uint32_t he; uint64_t hs;
     int hnv = load_chunk<C>(bytes, n_bytes, tile0 + (uint64_t)(Cfg::NT + j) * C, hdw);
     classify_chunk<BITS, C>(hdw, hnv, he, hs);
     store_eol_bits<C>(s_eol, Cfg::NT + j, he);
-    if (WITH_STREAM) store_stream_bits<BITS, C>(s_stream, Cfg::NT + j, hs);
   }
-  __syncthreads();
+  lds_barrier();
   bool prev_eol;
   if (j > 0) {
     const int pb = C * j - 1;
@@ -132,40 +184,161 @@ __device__ __forceinline__ void tile_front(const uint8_t *__restrict__ bytes, ui
   lines_before_local = block_exclusive_scan<uint32_t>((uint32_t)__builtin_popcount(ls), s_scan, &lines_total);
 }
 
-
-// Visit every valid k-mer start of this thread's chunk in position order.
-// f(p, rc words, fwd words) with p the byte index inside the chunk; `valid` from the caller.
-template <typename Cfg, typename F>
-__device__ __forceinline__ void for_each_chunk_kmer(const uint32_t *s_stream, uint32_t valid, const KShape &shape, F f) {
-  constexpr int NW = Cfg::NW, BITS = Cfg::BITS;
-  if (!valid) return;
-  uint32_t r[Cfg::NR];
-  load_stream_view<Cfg>(s_stream, threadIdx.x, r);
-#pragma unroll
-  for (int p = 0; p < Cfg::C; ++p) {
-    if ((valid >> p) & 1u) {
-      uint64_t rc[NW], fw[NW];
-      window_words<NW, Cfg::NR>(r, BITS * p, shape, rc);
-      fwd_from_rc<NW, BITS>(rc, fw, shape);
-      f(p, rc, fw);
-    }
+// front end of every later pass: the tile's packed units (+ halo) go straight into LDS
+template <typename Cfg>
+__device__ __forceinline__ void tile_front_packed(const PackedInput &in, uint64_t tile, uint32_t *s_eol, uint32_t *s_stream,
+                                                  uint32_t *s_scan, uint32_t &eol, uint32_t &ls, uint32_t &lines_before_local,
+                                                  uint32_t &lines_total) {
+  constexpr int C = Cfg::C;
+  constexpr int BITS = Cfg::BITS;
+  const int j = threadIdx.x;
+  const uint64_t n_units = in.n_cover / C;
+  const uint64_t g = tile * Cfg::NT + j;
+  eol = Cfg::CMASK;
+  uint64_t st = 0;
+  if (g < n_units) { eol = read_eol_unit<C>(in.eol, g); st = read_stream_unit<BITS, C>(in.stream, g); }
+  store_eol_bits<C>(s_eol, j, eol);
+  store_stream_bits<BITS, C>(s_stream, j, st);
+  if (j < Cfg::HALO_CHUNKS) {
+    const uint64_t gh = tile * Cfg::NT + Cfg::NT + j;
+    uint32_t he = Cfg::CMASK; uint64_t hs = 0;
+    if (gh < n_units) { he = read_eol_unit<C>(in.eol, gh); hs = read_stream_unit<BITS, C>(in.stream, gh); }
+    store_eol_bits<C>(s_eol, Cfg::NT + j, he);
+    store_stream_bits<BITS, C>(s_stream, Cfg::NT + j, hs);
   }
+  lds_barrier();
+  bool prev_eol;
+  if (j > 0) {
+    const int pb = C * j - 1;
+    prev_eol = (s_eol[pb >> 5] >> (pb & 31)) & 1u;
+  } else {
+    prev_eol = (g == 0) ? true : ((read_eol_unit<C>(in.eol, g - 1) >> (C - 1)) & 1u);
+  }
+  ls = line_starts(eol, prev_eol, Cfg::CMASK);
+  lines_before_local = block_exclusive_scan<uint32_t>((uint32_t)__builtin_popcount(ls), s_scan, &lines_total);
 }
 
-// FASTQ marker checks of one chunk (fastq_loader.hpp:392-393,421-422,437-438): returns flag bits
+// Software-pipelined form of tile_front_packed for workgroups that walk consecutive tiles: the
+// units of tile t+2 are requested while tile t is processed. Loads are unconditional (clamped
+// index) so that no select / phi forces an early s_waitcnt; validity is applied when the
+// registers are published. The halo of tile t is the head of tile t+1, i.e. already in registers.
+template <typename Cfg> struct TileUnits { uint32_t eol; uint64_t st; bool ok; };
+
 template <typename Cfg>
-__device__ __forceinline__ uint32_t fastq_marker_errors(const uint32_t (&dw)[Cfg::C / 4], uint32_t lines_before, uint32_t ls, bool first_chunk) {
-  uint32_t cur = lines_before, rest = ls, bad = 0;
-  while (rest) {
-    uint32_t q = (uint32_t)__builtin_ctz(rest);
-    uint32_t ch = (dw[q >> 2] >> (8 * (q & 3))) & 0xffu;
-    uint32_t role = cur & 3u;   // index of the line that starts here
-    if (role == 0 && ch != '@') bad |= 1u;
-    if (role == 2 && ch != '+') bad |= 2u;
-    cur += 1; rest &= rest - 1u;
+__device__ __forceinline__ void tile_units_load(const PackedInput &in, uint64_t tile, uint64_t n_tiles, TileUnits<Cfg> &u) {
+  u.ok = tile < n_tiles;
+  const uint64_t g = (u.ok ? tile : 0ull) * Cfg::NT + threadIdx.x;
+  u.eol = read_eol_unit<Cfg::C>(in.eol, g);
+  u.st = read_stream_unit<Cfg::BITS, Cfg::C>(in.stream, g);
+}
+
+// EOL status of the byte just before `tile` (true at the partition start)
+template <typename Cfg>
+__device__ __forceinline__ uint32_t tile_prev_eol(const PackedInput &in, uint64_t tile) {
+  if (tile == 0) return 1u;
+  return (read_eol_unit<Cfg::C>(in.eol, tile * Cfg::NT - 1) >> (Cfg::C - 1)) & 1u;
+}
+
+// publish tile `cur` (+ its halo = head of `nxt`) to LDS, one barrier inside; returns the line
+// starts of this thread's chunk. *s_prev carries the EOL status of the last byte of the previous tile.
+template <typename Cfg>
+__device__ __forceinline__ uint32_t tile_units_publish(const TileUnits<Cfg> &cur, const TileUnits<Cfg> &nxt, uint32_t *s_eol,
+                                                       uint32_t *s_stream, uint32_t *s_prev, uint32_t &eol_out) {
+  constexpr int C = Cfg::C;
+  constexpr int BITS = Cfg::BITS;
+  const int j = threadIdx.x;
+  const uint32_t eol = cur.ok ? cur.eol : Cfg::CMASK;
+  store_eol_bits<C>(s_eol, j, eol);
+  store_stream_bits<BITS, C>(s_stream, j, cur.st);
+  if (j < Cfg::HALO_CHUNKS) {
+    store_eol_bits<C>(s_eol, Cfg::NT + j, nxt.ok ? nxt.eol : Cfg::CMASK);
+    store_stream_bits<BITS, C>(s_stream, Cfg::NT + j, nxt.st);
   }
-  if (first_chunk && (dw[0] & 0xffu) != '@') bad |= 1u;
-  return bad;
+  lds_barrier();
+  bool prev_eol;
+  if (j > 0) {
+    const int pb = C * j - 1;
+    prev_eol = (s_eol[pb >> 5] >> (pb & 31)) & 1u;
+  } else {
+    prev_eol = *s_prev != 0;
+  }
+  eol_out = eol;
+  return line_starts(eol, prev_eol, Cfg::CMASK);
+}
+
+// valid k-mer starts of this thread's chunk
+template <typename Cfg>
+__device__ __forceinline__ uint32_t chunk_valid_mask(const uint32_t *s_eol, uint32_t ls, uint32_t lines_before, uint32_t k) {
+  uint64_t e[Cfg::NE];
+  load_eol_view<Cfg>(s_eol, threadIdx.x, e);
+  smear_right<Cfg::NE>(e, k);
+  return ~(uint32_t)e[0] & fastq_seq_role_mask(lines_before, ls, Cfg::CMASK);
+}
+
+// per-wavefront window list (no workgroup barrier): s_wpos points at this wave's 64*C slots;
+// returns the number of windows of the wave
+template <typename Cfg>
+__device__ __forceinline__ uint32_t wave_window_list(uint32_t valid, uint16_t *s_wpos) {
+  const uint32_t cnt = (uint32_t)__builtin_popcount(valid);
+  const uint32_t inc = wave_inclusive_scan(cnt);
+  uint32_t rank = inc - cnt;
+  const uint32_t base = threadIdx.x * Cfg::C;
+  while (valid) {
+    s_wpos[rank++] = (uint16_t)(base + (uint32_t)__builtin_ctz(valid));
+    valid &= valid - 1u;
+  }
+  __builtin_amdgcn_wave_barrier();   // the list is read by other lanes of this wave next
+  return __shfl(inc, kWave - 1, kWave);
+}
+
+// Compacted list of the tile's k-mer start positions (byte index inside the tile), in file
+// order: s_pos[0..total). Every lane of the later window loop then has real work, instead of
+// the ~38 % of lanes that sit on a sequence line.
+template <typename Cfg>
+__device__ __forceinline__ uint32_t tile_window_list(const uint32_t *s_eol, uint32_t ls, uint32_t lines_before, uint32_t k,
+                                                     uint16_t *s_pos, uint32_t *s_scan) {
+  uint64_t e[Cfg::NE];
+  load_eol_view<Cfg>(s_eol, threadIdx.x, e);
+  smear_right<Cfg::NE>(e, k);
+  uint32_t valid = ~(uint32_t)e[0] & fastq_seq_role_mask(lines_before, ls, Cfg::CMASK);
+  uint32_t total;
+  uint32_t rank = block_exclusive_scan<uint32_t>((uint32_t)__builtin_popcount(valid), s_scan, &total);
+  const uint32_t base = threadIdx.x * Cfg::C;
+  while (valid) {
+    s_pos[rank++] = (uint16_t)(base + (uint32_t)__builtin_ctz(valid));
+    valid &= valid - 1u;
+  }
+  lds_barrier();
+  return total;
+}
+
+// k-mer whose first base is tile byte `pos`: reverse complement = the little-endian window of the
+// complement stream, forward = its group reversal
+template <typename Cfg>
+__device__ __forceinline__ void window_at(const uint32_t *s_stream, uint32_t pos, const KShape &shape,
+                                          uint64_t (&rc)[Cfg::NW], uint64_t (&fw)[Cfg::NW]) {
+  constexpr int NW = Cfg::NW, BITS = Cfg::BITS;
+  const uint32_t bit = BITS * pos, d = bit >> 5, sh = bit & 31u;
+  uint32_t raw[2 * NW + 1];
+#pragma unroll
+  for (int i = 0; i < 2 * NW + 1; ++i) raw[i] = s_stream[d + i];
+#pragma unroll
+  for (int w = 0; w < NW; ++w) {
+    const uint32_t lo = __builtin_amdgcn_alignbit(raw[2 * w + 1], raw[2 * w], sh);
+    const uint32_t hi = __builtin_amdgcn_alignbit(raw[2 * w + 2], raw[2 * w + 1], sh);
+    rc[w] = ((uint64_t)hi << 32) | lo;
+  }
+  mask_words<NW>(rc, shape);
+  fwd_from_rc<NW, BITS>(rc, fw, shape);
+}
+
+// key stored by the map for a parsed k-mer (kmer_index.hpp:436-481): forward strand, or the
+// smaller of forward / reverse complement
+template <int NW>
+__device__ __forceinline__ void select_strand(const uint64_t (&rc)[NW], const uint64_t (&fw)[NW], bool canonical, uint64_t (&key)[NW]) {
+  const bool use_fw = !canonical || less_words<NW>(fw, rc);
+#pragma unroll
+  for (int w = 0; w < NW; ++w) key[w] = use_fw ? fw[w] : rc[w];
 }
 
 }  // namespace kmi

@@ -32,43 +32,54 @@ namespace kmi {
 template <int NW, int BITS>
 __global__ __launch_bounds__((ExCfg<NW, BITS>::NT)) void fastq_scan_tiles_kernel(const uint8_t *__restrict__ bytes,
                                                                                uint64_t n_bytes, uint32_t k,
-                                                                               TileInfo *__restrict__ info) {
+                                                                               uint8_t *__restrict__ pk_eol,
+                                                                               uint8_t *__restrict__ pk_stream,
+                                                                               TileInfo *__restrict__ info,
+                                                                               uint32_t *__restrict__ flags) {
   using Cfg = ExCfg<NW, BITS>;
   __shared__ uint32_t s_eol[Cfg::EOL_DW];
   __shared__ uint32_t s_scan[Cfg::NT / 64 + 2];
-  __shared__ uint32_t s_cnt[2];
-  const uint64_t tile0 = (uint64_t)blockIdx.x * Cfg::TILE;
-  if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
+  __shared__ uint32_t s_cnt[3];
+  if (threadIdx.x < 3) s_cnt[threadIdx.x] = 0;
   uint32_t dw[Cfg::C / 4], eol, ls, lbl, ltot;
-  tile_front<Cfg, false>(bytes, n_bytes, tile0, s_eol, nullptr, s_scan, dw, eol, ls, lbl, ltot);
+  tile_front_bytes<Cfg>(bytes, n_bytes, blockIdx.x, pk_eol, pk_stream, s_eol, s_scan, dw, eol, ls, lbl, ltot);
 
   uint64_t e[Cfg::NE];
   load_eol_view<Cfg>(s_eol, threadIdx.x, e);
   smear_right<Cfg::NE>(e, k);
   const uint32_t cand = ~(uint32_t)e[0] & Cfg::CMASK;
 
-  // windows by local phase: 16-bit fields (phase 0,1) and (phase 2,3)
-  uint32_t lo = 0, hi = 0;
+  // windows by local phase: 16-bit fields (phase 0,1) and (phase 2,3); marker bits by local phase
+  uint32_t lo = 0, hi = 0, marks = 0;
   {
     uint32_t cur = lbl, start = 0, rest = ls;
     while (true) {
       uint32_t q = rest ? (uint32_t)__builtin_ctz(rest) : (uint32_t)Cfg::C;
-      uint32_t seg = (q >= 32 ? ~0u : ((1u << q) - 1u)) & ~((1u << start) - 1u) & Cfg::CMASK;
+      uint32_t seg = ((1u << q) - 1u) & ~((1u << start) - 1u) & Cfg::CMASK;
       uint32_t c = (uint32_t)__builtin_popcount(cand & seg);
       uint32_t ph = cur & 3u;
       if (ph < 2) lo += c << (16 * ph); else hi += c << (16 * (ph - 2));
       if (!rest) break;
+      // the line that starts at q has local index `cur` (fastq_loader.hpp:421-422,437-438)
+      const uint32_t ch = (dw[q >> 2] >> (8 * (q & 3))) & 0xffu;
+      if (ch != '@') marks |= 1u << (cur & 3u);
+      if (ch != '+') marks |= 16u << (cur & 3u);
       cur += 1; start = q; rest &= rest - 1u;
     }
   }
+  // get_next_record refuses a partition that does not begin with '@' (fastq_loader.hpp:392-393)
+  if (blockIdx.x == 0 && threadIdx.x == 0 && (dw[0] & 0xffu) != '@') atomicOr(&flags[0], 1u);
   lo = wave_reduce_sum(lo); hi = wave_reduce_sum(hi);
-  if (lane_id() == 0) { atomicAdd(&s_cnt[0], lo); atomicAdd(&s_cnt[1], hi); }
-  __syncthreads();
+#pragma unroll
+  for (int d = kWave / 2; d > 0; d >>= 1) marks |= __shfl_xor(marks, d, kWave);
+  if (lane_id() == 0) { atomicAdd(&s_cnt[0], lo); atomicAdd(&s_cnt[1], hi); atomicOr(&s_cnt[2], marks); }
+  lds_barrier();
   if (threadIdx.x == 0) {
     TileInfo ti;
     ti.lines = ltot;
     ti.win[0] = s_cnt[0] & 0xffffu; ti.win[1] = s_cnt[0] >> 16;
     ti.win[2] = s_cnt[1] & 0xffffu; ti.win[3] = s_cnt[1] >> 16;
+    ti.marks = s_cnt[2];
     info[blockIdx.x] = ti;
   }
 }
@@ -89,7 +100,7 @@ __global__ __launch_bounds__(1024) void fastq_offsets_reduce_kernel(const TileIn
   __shared__ uint32_t s_scan[1024 / 64 + 2];
   __shared__ uint32_t s_cnt[4];
   const uint64_t t = (uint64_t)blockIdx.x * 1024 + threadIdx.x;
-  TileInfo ti; ti.lines = 0; ti.win[0] = ti.win[1] = ti.win[2] = ti.win[3] = 0;
+  TileInfo ti; ti.lines = 0; ti.win[0] = ti.win[1] = ti.win[2] = ti.win[3] = 0; ti.marks = 0;
   if (t < n_tiles) ti = info[t];
   if (threadIdx.x < 4) s_cnt[threadIdx.x] = 0;
   uint32_t tot;
@@ -99,7 +110,7 @@ __global__ __launch_bounds__(1024) void fastq_offsets_reduce_kernel(const TileIn
     uint32_t c = wave_reduce_sum(ti.win[(2u - r - lb) & 3u]);
     if (lane_id() == 0) atomicAdd(&s_cnt[r], c);
   }
-  __syncthreads();
+  lds_barrier();
   if (threadIdx.x == 0) {
     TileSum o; o.lines = tot;
     for (int r = 0; r < 4; ++r) o.cnt[r] = s_cnt[r];
@@ -135,75 +146,68 @@ __global__ __launch_bounds__(1024) void fastq_offsets_scan_kernel(TileSum *__res
 __global__ __launch_bounds__(1024) void fastq_offsets_apply_kernel(const TileInfo *__restrict__ info, uint64_t n_tiles,
                                                                   const TileSum *__restrict__ sums,
                                                                   uint32_t *__restrict__ line_base,
-                                                                  uint64_t *__restrict__ out_off) {
+                                                                  uint64_t *__restrict__ out_off,
+                                                                  uint32_t *__restrict__ flags) {
   __shared__ uint32_t s_scan[1024 / 64 + 2];
   const uint64_t t = (uint64_t)blockIdx.x * 1024 + threadIdx.x;
-  TileInfo ti; ti.lines = 0; ti.win[0] = ti.win[1] = ti.win[2] = ti.win[3] = 0;
+  TileInfo ti; ti.lines = 0; ti.win[0] = ti.win[1] = ti.win[2] = ti.win[3] = 0; ti.marks = 0;
   if (t < n_tiles) ti = info[t];
   const TileSum base = sums[blockIdx.x];
   const uint32_t lb = (uint32_t)base.lines + block_exclusive_scan<uint32_t>(ti.lines, s_scan, (uint32_t *)nullptr);
   const uint32_t c = ti.win[(2u - lb) & 3u];
   const uint32_t co = block_exclusive_scan<uint32_t>(c, s_scan, (uint32_t *)nullptr);
-  if (t < n_tiles) { line_base[t] = lb; out_off[t] = base.cnt[0] + co; }
+  if (t < n_tiles) {
+    line_base[t] = lb; out_off[t] = base.cnt[0] + co;
+    // header lines are the ones with (lb + local index) % 4 == 0, '+' lines == 2
+    uint32_t bad = 0;
+    if ((ti.marks >> ((0u - lb) & 3u)) & 1u) bad |= 1u;
+    if ((ti.marks >> (4u + ((2u - lb) & 3u))) & 1u) bad |= 2u;
+    if (bad) atomicOr(&flags[0], bad);
+  }
 }
 
 // ---------------------------------------------------------------------------
-// pass 3
-// flags[0] bit0: a header line does not start with '@'; bit1: a third line does not start with '+'
+// pass 3: tuples in file order. Work is re-distributed over the tile's compacted window list,
+// so consecutive lanes produce consecutive tuples and the stores are coalesced without staging.
 // ---------------------------------------------------------------------------
 template <int NW, int BITS>
 __global__ __launch_bounds__((ExCfg<NW, BITS>::NT)) void fastq_extract_kernel(
-    const uint8_t *__restrict__ bytes, uint64_t n_bytes, KShape shape, uint32_t strand, bool apply_strand,
-    const uint32_t *__restrict__ line_base, const uint64_t *__restrict__ out_off, uint64_t out_capacity,
-    uint64_t *__restrict__ out_kmers, uint32_t *__restrict__ flags) {
+    PackedInput in, KShape shape, bool canonical, const uint32_t *__restrict__ line_base,
+    const uint64_t *__restrict__ out_off, uint64_t out_capacity, uint64_t *__restrict__ out_kmers, uint32_t *__restrict__ flags) {
   using Cfg = ExCfg<NW, BITS>;
-  constexpr int C = Cfg::C;
   __shared__ uint32_t s_eol[Cfg::EOL_DW];
   __shared__ uint32_t s_stream[Cfg::STREAM_DW];
   __shared__ uint32_t s_scan[Cfg::NT / 64 + 2];
-  __shared__ uint64_t s_out[Cfg::TILE * NW];
-  const uint64_t tile0 = (uint64_t)blockIdx.x * Cfg::TILE;
-  uint32_t dw[C / 4], eol, ls, lbl, ltot;
-  tile_front<Cfg, true>(bytes, n_bytes, tile0, s_eol, s_stream, s_scan, dw, eol, ls, lbl, ltot);
-
-  const uint32_t lines_before = line_base[blockIdx.x] + lbl;
-
-  {
-    const uint32_t bad = fastq_marker_errors<Cfg>(dw, lines_before, ls, blockIdx.x == 0 && threadIdx.x == 0);
-    if (bad) atomicOr(&flags[0], bad);
-  }
-
-  uint64_t e[Cfg::NE];
-  load_eol_view<Cfg>(s_eol, threadIdx.x, e);
-  smear_right<Cfg::NE>(e, shape.k);
-  const uint32_t valid = ~(uint32_t)e[0] & fastq_seq_role_mask(lines_before, ls, Cfg::CMASK);
-
-  uint32_t total;
-  uint32_t rank = block_exclusive_scan<uint32_t>((uint32_t)__builtin_popcount(valid), s_scan, &total);
-
-  for_each_chunk_kmer<Cfg>(s_stream, valid, shape, [&](int, const uint64_t (&rc)[NW], const uint64_t (&fw)[NW]) {
-    const bool use_fw = !(apply_strand && strand != 0) || less_words<NW>(fw, rc);
-#pragma unroll
-    for (int w = 0; w < NW; ++w) s_out[(uint64_t)rank * NW + w] = use_fw ? fw[w] : rc[w];
-    ++rank;
-  });
-  __syncthreads();
+  __shared__ uint16_t s_pos[Cfg::TILE];
+  uint32_t eol, ls, lbl, ltot;
+  tile_front_packed<Cfg>(in, blockIdx.x, s_eol, s_stream, s_scan, eol, ls, lbl, ltot);
+  const uint32_t total = tile_window_list<Cfg>(s_eol, ls, line_base[blockIdx.x] + lbl, shape.k, s_pos, s_scan);
   const uint64_t base = out_off[blockIdx.x];
-  const uint32_t nwords = total * NW;
   if (base + total > out_capacity) {
-    if (threadIdx.x == 0) atomicOr(&flags[1], 1u);
+    if (threadIdx.x == 0 && total) atomicOr(&flags[1], 1u);
     return;
   }
-  uint64_t *dst = out_kmers + base * NW;
-  for (uint32_t i = threadIdx.x; i < nwords; i += Cfg::NT) dst[i] = s_out[i];
+  for (uint32_t q = threadIdx.x; q < total; q += Cfg::NT) {
+    uint64_t rc[NW], fw[NW], key[NW];
+    window_at<Cfg>(s_stream, s_pos[q], shape, rc, fw);
+    select_strand<NW>(rc, fw, canonical, key);
+#pragma unroll
+    for (int w = 0; w < NW; ++w) out_kmers[(base + q) * NW + w] = key[w];
+  }
 }
 
 // ---------------------------------------------------------------------------
 // host drivers
 // ---------------------------------------------------------------------------
+struct ScanResult {
+  uint64_t n_tiles;
+  uint32_t *line_base;
+  uint64_t *out_off;
+  PackedInput packed;
+};
+
 template <int NW, int BITS>
-static kmi_status scan_impl(kmi_ctx *ctx, const uint8_t *bytes_dev, size_t n_bytes, const KShape &shape,
-                            uint64_t *n_tiles_out, TileInfo **info_out, uint32_t **base_out, uint64_t **off_out,
+static kmi_status scan_impl(kmi_ctx *ctx, const uint8_t *bytes_dev, size_t n_bytes, const KShape &shape, ScanResult *r,
                             bool reuse = false) {
   using Cfg = ExCfg<NW, BITS>;
   const uint64_t n_tiles = (n_bytes + Cfg::TILE - 1) / Cfg::TILE;
@@ -214,12 +218,18 @@ static kmi_status scan_impl(kmi_ctx *ctx, const uint8_t *bytes_dev, size_t n_byt
   uint32_t *base = (uint32_t *)p;
   KMI_TRY(ws_get(ctx, WS_TILE_OFF, sizeof(uint64_t) * (n_tiles + 2), &p));
   uint64_t *off = (uint64_t *)p;
-  *n_tiles_out = n_tiles; *info_out = info; *base_out = base; *off_out = off;
+  const uint64_t n_cover = n_tiles * Cfg::TILE;
+  KMI_TRY(ws_get(ctx, WS_PK_EOL, n_cover / 8 + 64, &p));
+  uint8_t *pk_eol = (uint8_t *)p;
+  KMI_TRY(ws_get(ctx, WS_PK_STREAM, n_cover * BITS / 8 + 64, &p));
+  uint8_t *pk_stream = (uint8_t *)p;
+  r->n_tiles = n_tiles; r->line_base = base; r->out_off = off;
+  r->packed.eol = pk_eol; r->packed.stream = pk_stream; r->packed.n_bytes = n_bytes; r->packed.n_cover = n_cover;
   if (reuse) return KMI_OK;   // the scan of these very bytes is still in the workspace
   if (n_tiles > 0) {
     ProfScope ps(ctx, "fastq_scan_tiles", n_bytes);
     hipLaunchKernelGGL((fastq_scan_tiles_kernel<NW, BITS>), dim3((unsigned)n_tiles), dim3(Cfg::NT), 0, ctx->stream,
-                       bytes_dev, (uint64_t)n_bytes, shape.k, info);
+                       bytes_dev, (uint64_t)n_bytes, shape.k, pk_eol, pk_stream, info, ctx->d_flags);
   }
   {
     const uint64_t n_blocks = (n_tiles + 1023) / 1024;
@@ -235,27 +245,32 @@ static kmi_status scan_impl(kmi_ctx *ctx, const uint8_t *bytes_dev, size_t n_byt
                        ctx->d_totals);
     if (n_blocks > 0) {
       hipLaunchKernelGGL(fastq_offsets_apply_kernel, dim3((unsigned)n_blocks), dim3(1024), 0, ctx->stream,
-                         (const TileInfo *)info, n_tiles, (const TileSum *)sums, base, off);
+                         (const TileInfo *)info, n_tiles, (const TileSum *)sums, base, off, ctx->d_flags);
     }
   }
   KMI_HIP(ctx, hipGetLastError());
-  *n_tiles_out = n_tiles; *info_out = info; *base_out = base; *off_out = off;
   return KMI_OK;
 }
 
+// totals + FASTQ marker verdict of the last scan
 static kmi_status read_totals(kmi_ctx *ctx, uint64_t *n_tuples, uint64_t *n_seqs) {
+  uint32_t flags0 = 0;
   KMI_HIP(ctx, hipMemcpyAsync(ctx->h_totals, ctx->d_totals, sizeof(uint64_t) * 4, hipMemcpyDeviceToHost, ctx->stream));
+  KMI_HIP(ctx, hipMemcpyAsync(&flags0, ctx->d_flags, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
   KMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
   if (n_tuples) *n_tuples = ctx->h_totals[1];
   if (n_seqs) *n_seqs = ctx->h_totals[2];
+  if (flags0 & 1u) return set_err(ctx, KMI_ERR_PARSE, "FASTQ: missing @ on first line of a record");
+  if (flags0 & 2u) return set_err(ctx, KMI_ERR_PARSE, "FASTQ: missing + on third line of a record");
   return KMI_OK;
 }
 
 template <int NW, int BITS>
 static kmi_status extract_count_impl(kmi_ctx *ctx, const uint8_t *bytes_dev, size_t n_bytes, KShape shape,
                                      uint64_t *n_tuples, uint64_t *n_seqs) {
-  uint64_t n_tiles; TileInfo *info; uint32_t *base; uint64_t *off;
-  KMI_TRY((scan_impl<NW, BITS>(ctx, bytes_dev, n_bytes, shape, &n_tiles, &info, &base, &off)));
+  ScanResult r;
+  KMI_HIP(ctx, hipMemsetAsync(ctx->d_flags, 0, sizeof(uint32_t) * 16, ctx->stream));
+  KMI_TRY((scan_impl<NW, BITS>(ctx, bytes_dev, n_bytes, shape, &r)));
   return read_totals(ctx, n_tuples, n_seqs);
 }
 
@@ -264,41 +279,38 @@ static kmi_status extract_run_impl(kmi_ctx *ctx, const kmi_config *cfg, const ui
                                    KShape shape, uint64_t *out_kmers_dev, size_t out_capacity, bool apply_strand,
                                    bool scan_done, uint64_t *n_tuples, uint64_t *n_seqs) {
   using Cfg = ExCfg<NW, BITS>;
-  uint64_t n_tiles; TileInfo *info; uint32_t *base; uint64_t *off;
-  KMI_HIP(ctx, hipMemsetAsync(ctx->d_flags, 0, sizeof(uint32_t) * 16, ctx->stream));
-  KMI_TRY((scan_impl<NW, BITS>(ctx, bytes_dev, n_bytes, shape, &n_tiles, &info, &base, &off, scan_done)));
-  if (n_tiles > 0) {
+  ScanResult r;
+  if (!scan_done) KMI_HIP(ctx, hipMemsetAsync(ctx->d_flags, 0, sizeof(uint32_t) * 16, ctx->stream));
+  KMI_TRY((scan_impl<NW, BITS>(ctx, bytes_dev, n_bytes, shape, &r, scan_done)));
+  if (r.n_tiles > 0) {
     ProfScope ps(ctx, "fastq_extract", n_bytes);
-    hipLaunchKernelGGL((fastq_extract_kernel<NW, BITS>), dim3((unsigned)n_tiles), dim3(Cfg::NT), 0, ctx->stream,
-                       bytes_dev, (uint64_t)n_bytes, shape, cfg->strand, apply_strand, base, off,
-                       (uint64_t)out_capacity, out_kmers_dev, ctx->d_flags);
+    hipLaunchKernelGGL((fastq_extract_kernel<NW, BITS>), dim3((unsigned)r.n_tiles), dim3(Cfg::NT), 0, ctx->stream,
+                       r.packed, shape, apply_strand && cfg->strand != KMI_STRAND_SINGLE, (const uint32_t *)r.line_base,
+                       (const uint64_t *)r.out_off, (uint64_t)out_capacity, out_kmers_dev, ctx->d_flags);
   }
   KMI_HIP(ctx, hipGetLastError());
-  uint32_t flags[2];
-  KMI_HIP(ctx, hipMemcpyAsync(flags, ctx->d_flags, sizeof(flags), hipMemcpyDeviceToHost, ctx->stream));
+  uint32_t flag1 = 0;
+  KMI_HIP(ctx, hipMemcpyAsync(&flag1, ctx->d_flags + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
   KMI_TRY(read_totals(ctx, n_tuples, n_seqs));
-  if (flags[0] & 1u) return set_err(ctx, KMI_ERR_PARSE, "FASTQ: missing @ on first line of a record");
-  if (flags[0] & 2u) return set_err(ctx, KMI_ERR_PARSE, "FASTQ: missing + on third line of a record");
-  if (flags[1]) return set_err(ctx, KMI_ERR_OVERFLOW, "extract: output capacity too small");
+  if (flag1) return set_err(ctx, KMI_ERR_OVERFLOW, "extract: output capacity too small");
   return KMI_OK;
 }
 
 template <int NW, int BITS>
-static kmi_status fastq_scan_impl(kmi_ctx *ctx, const uint8_t *bytes_dev, size_t n_bytes, KShape shape, uint64_t *n_tiles,
-                                  uint32_t *tile_bytes, const uint32_t **line_base, uint64_t *n_tuples, uint64_t *n_seqs) {
-  TileInfo *info; uint32_t *base; uint64_t *off;
-  KMI_TRY((scan_impl<NW, BITS>(ctx, bytes_dev, n_bytes, shape, n_tiles, &info, &base, &off)));
-  *line_base = base;
-  *tile_bytes = ExCfg<NW, BITS>::TILE;
-  return read_totals(ctx, n_tuples, n_seqs);
+static kmi_status fastq_scan_impl(kmi_ctx *ctx, const uint8_t *bytes_dev, size_t n_bytes, KShape shape, FastqScan *out) {
+  ScanResult r;
+  KMI_HIP(ctx, hipMemsetAsync(ctx->d_flags, 0, sizeof(uint32_t) * 16, ctx->stream));
+  KMI_TRY((scan_impl<NW, BITS>(ctx, bytes_dev, n_bytes, shape, &r)));
+  out->n_tiles = r.n_tiles; out->line_base = r.line_base;
+  out->pk_eol = r.packed.eol; out->pk_stream = r.packed.stream; out->n_bytes = r.packed.n_bytes; out->n_cover = r.packed.n_cover;
+  return read_totals(ctx, &out->n_tuples, &out->n_seqs);
 }
 
-kmi_status fastq_scan(kmi_ctx *ctx, const kmi_config *cfg, const uint8_t *bytes_dev, size_t n_bytes, uint64_t *n_tiles,
-                      uint32_t *tile_bytes, const uint32_t **line_base, uint64_t *n_tuples, uint64_t *n_seqs) {
+kmi_status fastq_scan(kmi_ctx *ctx, const kmi_config *cfg, const uint8_t *bytes_dev, size_t n_bytes, FastqScan *out) {
   KShape shape;
   if (!valid_config(cfg, &shape)) return set_err(ctx, KMI_ERR_INVALID, "bad kmi_config");
   if (cfg->seq_format != KMI_FMT_FASTQ) return set_err(ctx, KMI_ERR_INVALID, "only FASTQ is implemented on the device yet");
-  KMI_DISPATCH(shape, fastq_scan_impl, ctx, bytes_dev, n_bytes, shape, n_tiles, tile_bytes, line_base, n_tuples, n_seqs);
+  KMI_DISPATCH(shape, fastq_scan_impl, ctx, bytes_dev, n_bytes, shape, out);
 }
 
 kmi_status extract_count(kmi_ctx *ctx, const kmi_config *cfg, const uint8_t *bytes_dev, size_t n_bytes,

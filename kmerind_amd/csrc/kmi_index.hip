@@ -94,7 +94,7 @@ __global__ __launch_bounds__(kPartThreads) void hist_fine_kernel(const uint64_t 
                                                                 uint32_t *__restrict__ wg_hist) {     // [groups][256]
   __shared__ uint32_t s_hist[kNumFine];
   for (int i = threadIdx.x; i < kNumFine; i += kPartThreads) s_hist[i] = 0;
-  __syncthreads();
+  lds_barrier();
   const uint64_t chunk = part_chunk(n, gridDim.x, PartCfg<NW>::TILE);
   const uint64_t b = (uint64_t)blockIdx.x * chunk;
   const uint64_t e = (b + chunk < n) ? b + chunk : n;
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(kPartThreads) void hist_fine_kernel(const uint64_t 
       }
     }
   }
-  __syncthreads();
+  lds_barrier();
   uint32_t *part_hist = fine_hist + (uint64_t)(blockIdx.x / kGroupsPerPart) * kNumFine;
   for (int i = threadIdx.x; i < kNumFine; i += kPartThreads) {
     uint32_t v = s_hist[i];
@@ -142,7 +142,7 @@ __global__ __launch_bounds__(kPartThreads) void hist_rank_kernel(const uint64_t 
                                                                 uint32_t strand, BucketFn fn, uint32_t *__restrict__ wg_hist) {
   __shared__ uint32_t s_hist[kNumCoarse];
   if (threadIdx.x < kNumCoarse) s_hist[threadIdx.x] = 0;
-  __syncthreads();
+  lds_barrier();
   const uint64_t chunk = part_chunk(n, gridDim.x, PartCfg<NW>::TILE);
   const uint64_t b = (uint64_t)blockIdx.x * chunk;
   const uint64_t e = (b + chunk < n) ? b + chunk : n;
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(kPartThreads) void hist_rank_kernel(const uint64_t 
     load_key<NW, BITS>(keys, i, shape, strand, true, k);
     atomicAdd(&s_hist[bucket_of<NW>(k, fn)], 1u);
   }
-  __syncthreads();
+  lds_barrier();
   if (threadIdx.x < kNumCoarse) wg_hist[(uint64_t)blockIdx.x * kNumCoarse + threadIdx.x] = s_hist[threadIdx.x];
 }
 
@@ -202,7 +202,7 @@ __global__ __launch_bounds__(1024) void fine_offsets_kernel(const uint32_t *__re
     }
   }
   if (threadIdx.x == 0) fine_off[kNumFine] = total;
-  __syncthreads();
+  lds_barrier();
   if (wg_off) column_offsets(wg_hist, groups, kNumCoarse, s_coarse, wg_off);
 }
 
@@ -218,12 +218,12 @@ __global__ __launch_bounds__(1024) void rank_offsets_kernel(const uint32_t *__re
     v = wave_reduce_sum(v);
     if (lane_id() == 0) s_tot[c] = v;
   }
-  __syncthreads();
+  lds_barrier();
   const uint64_t tot = (threadIdx.x < nbuckets) ? s_tot[threadIdx.x] : 0ull;
   uint64_t total;
   uint64_t off = block_exclusive_scan<uint64_t>(tot, s_scan, &total);
   if (threadIdx.x < nbuckets) { bucket_cnt[threadIdx.x] = tot; s_base[threadIdx.x] = off; }
-  __syncthreads();
+  lds_barrier();
   column_offsets(wg_hist, groups, nbuckets, s_base, wg_off);
 }
 
@@ -243,16 +243,15 @@ __device__ __forceinline__ void scatter_range(const uint64_t *__restrict__ in, u
   constexpr int TILE = PartCfg<NW>::TILE;
   constexpr int PT = PartCfg<NW>::PER_THREAD;
   if (threadIdx.x < kNumCoarse) s_cnt[threadIdx.x] = 0;
-  __syncthreads();
+  lds_barrier();
   uint64_t raw[PT][NW];
-  auto load_tile = [&](uint64_t t0) {
+  auto load_tile = [&](uint64_t t0) {   // unconditional (clamped) loads: nothing forces an early wait
 #pragma unroll
     for (int j = 0; j < PT; ++j) {
-      const uint64_t i = t0 + (uint64_t)j * kPartThreads + threadIdx.x;
-      if (i < end) {
+      uint64_t i = t0 + (uint64_t)j * kPartThreads + threadIdx.x;
+      i = (i < end) ? i : end - 1;
 #pragma unroll
-        for (int w = 0; w < NW; ++w) raw[j][w] = in[i * NW + w];
-      }
+      for (int w = 0; w < NW; ++w) raw[j][w] = in[i * NW + w];
     }
   };
   load_tile(begin);
@@ -275,7 +274,7 @@ __device__ __forceinline__ void scatter_range(const uint64_t *__restrict__ in, u
       }
     }
     if (t0 + TILE < end) load_tile(t0 + TILE);   // in flight until the next iteration needs it
-    __syncthreads();
+    lds_barrier();
     uint32_t c = 0, inc = 0;
     if (threadIdx.x < kNumCoarse) {              // waves 0..3, whole waves
       c = s_cnt[threadIdx.x];
@@ -283,7 +282,7 @@ __device__ __forceinline__ void scatter_range(const uint64_t *__restrict__ in, u
       inc = wave_inclusive_scan(c);
       if (lane_id() == kWave - 1) s_part[wave_id()] = inc;
     }
-    __syncthreads();
+    lds_barrier();
     if (threadIdx.x < kNumCoarse) {
       uint32_t pre = 0;
 #pragma unroll
@@ -293,7 +292,7 @@ __device__ __forceinline__ void scatter_range(const uint64_t *__restrict__ in, u
       s_gbase[threadIdx.x] = cursor - lo;
       cursor += c;
     }
-    __syncthreads();
+    lds_barrier();
 #pragma unroll
     for (int j = 0; j < PT; ++j) {
       if (bk[j] != 0xffffffffu) {
@@ -303,7 +302,7 @@ __device__ __forceinline__ void scatter_range(const uint64_t *__restrict__ in, u
         s_bkt[pos] = (uint8_t)bk[j];
       }
     }
-    __syncthreads();
+    lds_barrier();
     for (uint32_t s = threadIdx.x; s < nt; s += kPartThreads) {
       const uint64_t dst = s_gbase[s_bkt[s]] + s;
 #pragma unroll
@@ -357,8 +356,7 @@ __global__ __launch_bounds__(kPartThreads) void scatter_fine_kernel(const uint64
 // 8 W + 8 R + 8 R of key traffic. Workgroup w owns the same contiguous run of tiles in both.
 // ---------------------------------------------------------------------------
 template <int NW, int BITS>
-__global__ __launch_bounds__((ExCfgWide<NW, BITS>::NT)) void fastq_hist_kernel(const uint8_t *__restrict__ bytes, uint64_t n_bytes, uint64_t n_tiles,
-                                                                              KShape shape, uint32_t strand,
+__global__ __launch_bounds__((ExCfgWide<NW, BITS>::NT)) void fastq_hist_kernel(PackedInput in, uint64_t n_tiles, KShape shape, bool canonical,
                                                                               const uint32_t *__restrict__ line_base,
                                                                               uint32_t *__restrict__ fine_hist, uint32_t *__restrict__ wg_hist) {
   using Cfg = ExCfgWide<NW, BITS>;
@@ -366,27 +364,35 @@ __global__ __launch_bounds__((ExCfgWide<NW, BITS>::NT)) void fastq_hist_kernel(c
   __shared__ uint32_t s_eol[Cfg::EOL_DW];
   __shared__ uint32_t s_stream[Cfg::STREAM_DW];
   __shared__ uint32_t s_scan[Cfg::NT / 64 + 2];
+  __shared__ uint16_t s_pos[Cfg::TILE];
   for (int i = threadIdx.x; i < kNumFine; i += Cfg::NT) s_hist[i] = 0;
-  __syncthreads();
+  lds_barrier();
   const uint64_t per = (n_tiles + gridDim.x - 1) / gridDim.x;
   const uint64_t tb = (uint64_t)blockIdx.x * per;
   const uint64_t te = (tb + per < n_tiles) ? tb + per : n_tiles;
+  uint16_t *s_wpos = s_pos + wave_id() * (kWave * Cfg::C);   // this wave's slice of the window list
+  __shared__ uint32_t s_prev;
+  TileUnits<Cfg> cur, nxt, nn;
+  tile_units_load<Cfg>(in, tb, te > tb ? n_tiles : 0, cur);
+  tile_units_load<Cfg>(in, tb + 1, n_tiles, nxt);
+  if (threadIdx.x == 0) s_prev = (tb < te) ? tile_prev_eol<Cfg>(in, tb) : 1u;
   for (uint64_t t = tb; t < te; ++t) {
-    uint32_t dw[Cfg::C / 4], eol, ls, lbl, ltot;
-    tile_front<Cfg, true>(bytes, n_bytes, t * Cfg::TILE, s_eol, s_stream, s_scan, dw, eol, ls, lbl, ltot);
-    const uint32_t lines_before = line_base[t] + lbl;
-    uint64_t e[Cfg::NE];
-    load_eol_view<Cfg>(s_eol, threadIdx.x, e);
-    smear_right<Cfg::NE>(e, shape.k);
-    const uint32_t valid = ~(uint32_t)e[0] & fastq_seq_role_mask(lines_before, ls, Cfg::CMASK);
-    for_each_chunk_kmer<Cfg>(s_stream, valid, shape, [&](int, const uint64_t (&rc)[NW], const uint64_t (&fw)[NW]) {
-      const bool use_fw = (strand == 0) || less_words<NW>(fw, rc);
-      uint64_t key[NW];
-#pragma unroll
-      for (int w = 0; w < NW; ++w) key[w] = use_fw ? fw[w] : rc[w];
+    uint32_t eol;
+    const uint32_t ls = tile_units_publish<Cfg>(cur, nxt, s_eol, s_stream, &s_prev, eol);
+    tile_units_load<Cfg>(in, t + 2, n_tiles, nn);   // in flight during two tiles of work
+    uint32_t ltot;
+    const uint32_t lbl = block_exclusive_scan<uint32_t, false>((uint32_t)__builtin_popcount(ls), s_scan, &ltot);
+    if (threadIdx.x == Cfg::NT - 1) s_prev = (eol >> (Cfg::C - 1)) & 1u;   // read again only after the next barriers
+    const uint32_t valid = chunk_valid_mask<Cfg>(s_eol, ls, line_base[t] + lbl, shape.k);
+    const uint32_t wtotal = wave_window_list<Cfg>(valid, s_wpos);
+    for (uint32_t q = lane_id(); q < wtotal; q += kWave) {
+      uint64_t rc[NW], fw[NW], key[NW];
+      window_at<Cfg>(s_stream, s_wpos[q], shape, rc, fw);
+      select_strand<NW>(rc, fw, canonical, key);
       atomicAdd(&s_hist[fine_of(place_hash<NW>(key))], 1u);
-    });
-    __syncthreads();   // the next tile overwrites s_eol / s_stream
+    }
+    lds_barrier();   // the next tile overwrites s_eol / s_stream (and s_scan is free again)
+    cur = nxt; nxt = nn;
   }
   uint32_t *part_hist = fine_hist + (uint64_t)(blockIdx.x / kGroupsPerPart) * kNumFine;
   for (int i = threadIdx.x; i < kNumFine; i += Cfg::NT) {
@@ -401,16 +407,14 @@ __global__ __launch_bounds__((ExCfgWide<NW, BITS>::NT)) void fastq_hist_kernel(c
 }
 
 template <int NW, int BITS>
-__global__ __launch_bounds__((ExCfg<NW, BITS>::NT), (NW == 1 ? 4 : 2)) void fastq_scatter_kernel(const uint8_t *__restrict__ bytes, uint64_t n_bytes, uint64_t n_tiles,
-                                                                             KShape shape, uint32_t strand,
+__global__ __launch_bounds__((ExCfg<NW, BITS>::NT)) void fastq_scatter_kernel(PackedInput in, uint64_t n_tiles, KShape shape, bool canonical,
                                                                              const uint32_t *__restrict__ line_base,
-                                                                             const uint64_t *__restrict__ wg_off, uint64_t *__restrict__ out,
-                                                                             uint32_t *__restrict__ flags) {
+                                                                             const uint64_t *__restrict__ wg_off, uint64_t *__restrict__ out) {
   using Cfg = ExCfg<NW, BITS>;
-  constexpr int C = Cfg::C;
+  constexpr int MAXQ = Cfg::C;   // windows per thread: TILE / NT
   static_assert(Cfg::TILE <= PartCfg<NW>::TILE, "stage must hold every window of a tile");
   static_assert(Cfg::NT >= kNumCoarse, "one thread per coarse bucket");
-  __shared__ uint64_t s_stage[Cfg::TILE * NW];
+  __shared__ uint64_t s_stage[Cfg::TILE * NW];   // its first bytes double as the window list (dead before S3)
   __shared__ uint8_t s_bkt[Cfg::TILE];
   __shared__ uint32_t s_eol[Cfg::EOL_DW];
   __shared__ uint32_t s_stream[Cfg::STREAM_DW];
@@ -418,45 +422,41 @@ __global__ __launch_bounds__((ExCfg<NW, BITS>::NT), (NW == 1 ? 4 : 2)) void fast
   __shared__ uint32_t s_cnt[kNumCoarse];
   __shared__ uint32_t s_lofs[kNumCoarse];
   __shared__ uint64_t s_gbase[kNumCoarse];
-  __shared__ uint32_t s_part[kNumCoarse / kWave + 1];
+  __shared__ uint32_t s_part[kNumCoarse / kWave];
+  uint16_t *s_pos = reinterpret_cast<uint16_t *>(s_stage);
   uint64_t cursor = (threadIdx.x < kNumCoarse) ? wg_off[(uint64_t)blockIdx.x * kNumCoarse + threadIdx.x] : 0ull;
   if (threadIdx.x < kNumCoarse) s_cnt[threadIdx.x] = 0;
   const uint64_t per = (n_tiles + gridDim.x - 1) / gridDim.x;
   const uint64_t tb = (uint64_t)blockIdx.x * per;
   const uint64_t te = (tb + per < n_tiles) ? tb + per : n_tiles;
+  __shared__ uint32_t s_prev;
+  TileUnits<Cfg> cur, nxt, nn;
+  tile_units_load<Cfg>(in, tb, te > tb ? n_tiles : 0, cur);
+  tile_units_load<Cfg>(in, tb + 1, n_tiles, nxt);
+  if (threadIdx.x == 0) s_prev = (tb < te) ? tile_prev_eol<Cfg>(in, tb) : 1u;
   for (uint64_t t = tb; t < te; ++t) {
-    uint32_t dw[C / 4], eol, ls, lbl, ltot;
-    tile_front<Cfg, true>(bytes, n_bytes, t * Cfg::TILE, s_eol, s_stream, s_scan, dw, eol, ls, lbl, ltot);
-    const uint32_t lines_before = line_base[t] + lbl;
-    {
-      const uint32_t bad = fastq_marker_errors<Cfg>(dw, lines_before, ls, t == 0 && threadIdx.x == 0);
-      if (bad) atomicOr(&flags[0], bad);
-    }
-    uint64_t e[Cfg::NE];
-    load_eol_view<Cfg>(s_eol, threadIdx.x, e);
-    smear_right<Cfg::NE>(e, shape.k);
-    const uint32_t valid = ~(uint32_t)e[0] & fastq_seq_role_mask(lines_before, ls, Cfg::CMASK);
-    // S0: keys of this chunk, their coarse bucket and rank inside (tile, bucket)
-    uint64_t key[C][NW];
-    uint32_t bkrk[C];   // bucket << 16 | rank  (rank < 8192)
-    if (valid) {
-      uint32_t r[Cfg::NR];
-      load_stream_view<Cfg>(s_stream, threadIdx.x, r);
+    uint32_t eol;
+    const uint32_t ls = tile_units_publish<Cfg>(cur, nxt, s_eol, s_stream, &s_prev, eol);
+    tile_units_load<Cfg>(in, t + 2, n_tiles, nn);
+    uint32_t ltot;
+    const uint32_t lbl = block_exclusive_scan<uint32_t>((uint32_t)__builtin_popcount(ls), s_scan, &ltot);
+    if (threadIdx.x == Cfg::NT - 1) s_prev = (eol >> (Cfg::C - 1)) & 1u;
+    const uint32_t total = tile_window_list<Cfg>(s_eol, ls, line_base[t] + lbl, shape.k, s_pos, s_scan);
+    // S0: keys of windows q = tid, tid + NT, ...; coarse bucket and rank inside (tile, bucket)
+    uint64_t key[MAXQ][NW];
+    uint32_t bkrk[MAXQ];   // bucket << 16 | rank
 #pragma unroll
-      for (int p = 0; p < C; ++p) {
-        if ((valid >> p) & 1u) {
-          uint64_t rc[NW], fw[NW];
-          window_words<NW, Cfg::NR>(r, BITS * p, shape, rc);
-          fwd_from_rc<NW, BITS>(rc, fw, shape);
-          const bool use_fw = (strand == 0) || less_words<NW>(fw, rc);
-#pragma unroll
-          for (int w = 0; w < NW; ++w) key[p][w] = use_fw ? fw[w] : rc[w];
-          const uint32_t b = coarse_of(place_hash<NW>(key[p]));
-          bkrk[p] = (b << 16) | atomicAdd(&s_cnt[b], 1u);
-        }
+    for (int m = 0; m < MAXQ; ++m) {
+      const uint32_t q = m * Cfg::NT + threadIdx.x;
+      if (q < total) {
+        uint64_t rc[NW], fw[NW];
+        window_at<Cfg>(s_stream, s_pos[q], shape, rc, fw);
+        select_strand<NW>(rc, fw, canonical, key[m]);
+        const uint32_t b = coarse_of(place_hash<NW>(key[m]));
+        bkrk[m] = (b << 16) | atomicAdd(&s_cnt[b], 1u);
       }
     }
-    __syncthreads();
+    lds_barrier();
     uint32_t c = 0, inc = 0;
     if (threadIdx.x < kNumCoarse) {
       c = s_cnt[threadIdx.x];
@@ -464,7 +464,7 @@ __global__ __launch_bounds__((ExCfg<NW, BITS>::NT), (NW == 1 ? 4 : 2)) void fast
       inc = wave_inclusive_scan(c);
       if (lane_id() == kWave - 1) s_part[wave_id()] = inc;
     }
-    __syncthreads();
+    lds_barrier();
     if (threadIdx.x < kNumCoarse) {
       uint32_t pre = 0;
 #pragma unroll
@@ -473,30 +473,27 @@ __global__ __launch_bounds__((ExCfg<NW, BITS>::NT), (NW == 1 ? 4 : 2)) void fast
       s_lofs[threadIdx.x] = lo;
       s_gbase[threadIdx.x] = cursor - lo;
       cursor += c;
-      if (threadIdx.x == kNumCoarse - 1) s_part[kNumCoarse / kWave] = lo + c;   // keys in this tile
     }
-    __syncthreads();
-    if (valid) {
+    lds_barrier();   // also: every read of the window list (aliasing the stage) is done
 #pragma unroll
-      for (int p = 0; p < C; ++p) {
-        if ((valid >> p) & 1u) {
-          const uint32_t b = bkrk[p] >> 16;
-          const uint32_t pos = s_lofs[b] + (bkrk[p] & 0xffffu);
+    for (int m = 0; m < MAXQ; ++m) {
+      const uint32_t q = m * Cfg::NT + threadIdx.x;
+      if (q < total) {
+        const uint32_t b = bkrk[m] >> 16;
+        const uint32_t pos = s_lofs[b] + (bkrk[m] & 0xffffu);
 #pragma unroll
-          for (int w = 0; w < NW; ++w) s_stage[(uint64_t)pos * NW + w] = key[p][w];
-          s_bkt[pos] = (uint8_t)b;
-        }
+        for (int w = 0; w < NW; ++w) s_stage[(uint64_t)pos * NW + w] = key[m][w];
+        s_bkt[pos] = (uint8_t)b;
       }
     }
-    __syncthreads();
-    const uint32_t nt = s_part[kNumCoarse / kWave];
-    for (uint32_t s = threadIdx.x; s < nt; s += Cfg::NT) {
+    lds_barrier();
+    for (uint32_t s = threadIdx.x; s < total; s += Cfg::NT) {
       const uint64_t dst = s_gbase[s_bkt[s]] + s;
 #pragma unroll
       for (int w = 0; w < NW; ++w) out[dst * NW + w] = s_stage[(uint64_t)s * NW + w];
     }
-    // tile_front of the next tile starts with a barrier-separated phase: stage / offsets are not
-    // rewritten before every thread has left this copy-out
+    lds_barrier();   // the next tile's window list overwrites the stage
+    cur = nxt; nxt = nn;
   }
 }
 
@@ -623,12 +620,13 @@ template <int U>
 __device__ __forceinline__ void table_insert_stream1(const LdsTable<1> &t, const uint64_t *__restrict__ keys, uint64_t b, uint64_t e,
                                                      uint32_t npass, uint32_t pass) {
   constexpr int CAP = TabCfg<1>::CAP;
+  if (b >= e) return;
   const uint64_t step = (uint64_t)blockDim.x * U;
   uint64_t nxt[U];
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     const uint64_t i = b + (uint64_t)u * blockDim.x + threadIdx.x;
-    nxt[u] = (i < e) ? keys[i] : kEmptyKey;
+    nxt[u] = keys[(i < e) ? i : e - 1];
   }
   for (uint64_t i0 = b; i0 < e; i0 += step) {
     uint64_t k[U];
@@ -643,7 +641,7 @@ __device__ __forceinline__ void table_insert_stream1(const LdsTable<1> &t, const
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const uint64_t i = i0 + step + (uint64_t)u * blockDim.x + threadIdx.x;
-        nxt[u] = (i < e) ? keys[i] : kEmptyKey;
+        nxt[u] = keys[(i < e) ? i : e - 1];   // clamped, validity applied when consumed
       }
     }
     uint32_t slot[U];
@@ -760,7 +758,7 @@ __global__ __launch_bounds__((TabCfg<NW>::NT)) void bucket_reduce_kernel(const u
     bool failed = false;
     for (uint32_t pass = 0; pass < npass && !failed; ++pass) {
       table_clear<NW>(tab);
-      __syncthreads();
+      lds_barrier();
       for_each_key<NW, BatchOf<NW>::U>(old_keys, ob, oe, [&](const uint64_t (&k)[NW], uint64_t i) {
         const uint32_t h = place_hash<NW>(k);
         if (pass_of(h, npass) != pass) return;
@@ -778,7 +776,7 @@ __global__ __launch_bounds__((TabCfg<NW>::NT)) void bucket_reduce_kernel(const u
           if (s >= 0) atomicAdd(&tab.vals[s], 1u);
         });
       }
-      __syncthreads();
+      lds_barrier();
       if (*tab.overflow) { failed = true; break; }
       for (int s = threadIdx.x; s < CAP; s += blockDim.x) {
         const bool used = slot_used<NW>(tab, s);
@@ -789,18 +787,18 @@ __global__ __launch_bounds__((TabCfg<NW>::NT)) void bucket_reduce_kernel(const u
           tmp_vals[tmp0 + pos] = tab.vals[s];
         }
       }
-      __syncthreads();
+      lds_barrier();
       if (NW == 1 && threadIdx.x == 0 && *tab.special_set) {
         const uint32_t pos = atomicAdd(s_out, 1u);
         tmp_keys[(tmp0 + pos) * NW] = kEmptyKey;
         tmp_vals[tmp0 + pos] = *tab.special;
       }
-      __syncthreads();
+      lds_barrier();
     }
     if (!failed) break;
     npass *= 2;
-    if (npass > kMaxPasses) { if (threadIdx.x == 0) { atomicOr(&flags[2], 1u); *s_out = 0; } __syncthreads(); break; }
-    __syncthreads();
+    if (npass > kMaxPasses) { if (threadIdx.x == 0) { atomicOr(&flags[2], 1u); *s_out = 0; } lds_barrier(); break; }
+    lds_barrier();
   }
   if (threadIdx.x == 0) out_cnt[b] = *s_out;
 }
@@ -868,13 +866,13 @@ __global__ __launch_bounds__((TabCfg<NW>::NT)) void bucket_query_kernel(int mode
     bool failed = false;
     for (uint32_t pass = 0; pass < npass && !failed; ++pass) {
       table_clear<NW>(tab);
-      __syncthreads();
+      lds_barrier();
       for_each_key<NW, BatchOf<NW>::U>(q_keys, qb, qe, [&](const uint64_t (&k)[NW], uint64_t) {
         const uint32_t h = place_hash<NW>(k);
         if (pass_of(h, npass) != pass) return;
         (void)table_upsert<NW>(tab, k, h);
       });
-      __syncthreads();
+      lds_barrier();
       if (*tab.overflow) { failed = true; break; }
       // stream the index bucket against the query table
       for (uint64_t i = ib + threadIdx.x; i < ie; i += blockDim.x) {
@@ -903,7 +901,7 @@ __global__ __launch_bounds__((TabCfg<NW>::NT)) void bucket_query_kernel(int mode
           }
         }
       }
-      __syncthreads();
+      lds_barrier();
       if (mode == Q_COUNT) {
         for (int s = threadIdx.x; s < CAP; s += blockDim.x) {
           const bool used = slot_used<NW>(tab, s);
@@ -920,12 +918,12 @@ __global__ __launch_bounds__((TabCfg<NW>::NT)) void bucket_query_kernel(int mode
           tmp_vals64[tmp0 + pos] = *tab.special;
         }
       }
-      __syncthreads();
+      lds_barrier();
     }
     if (!failed) break;
     npass *= 2;
-    if (npass > kMaxPasses) { if (threadIdx.x == 0) { atomicOr(&flags[2], 1u); *s_out = 0; } __syncthreads(); break; }
-    __syncthreads();
+    if (npass > kMaxPasses) { if (threadIdx.x == 0) { atomicOr(&flags[2], 1u); *s_out = 0; } lds_barrier(); break; }
+    lds_barrier();
   }
   if (threadIdx.x == 0) out_cnt[b] = *s_out;
 }
@@ -1094,23 +1092,20 @@ static kmi_status insert_impl(kmi_index *idx, const uint64_t *keys_dev, size_t n
 template <int NW, int BITS>
 static kmi_status build_fused_impl(kmi_index *idx, const uint8_t *bytes_dev, size_t n_bytes) {
   kmi_ctx *ctx = idx->ctx;
-  uint64_t n_tiles = 0, n = 0, n_seqs = 0;
-  uint32_t tile_bytes = 0;
-  const uint32_t *line_base = nullptr;
-  KMI_HIP(ctx, hipMemsetAsync(ctx->d_flags, 0, sizeof(uint32_t) * 16, ctx->stream));
-  KMI_TRY(fastq_scan(ctx, &idx->cfg, bytes_dev, n_bytes, &n_tiles, &tile_bytes, &line_base, &n, &n_seqs));
-  if (n == 0) {
-    // nothing to insert, but malformed input must still be reported: run the plain extract checks
-    uint64_t a, b;
-    return extract_run(ctx, &idx->cfg, bytes_dev, n_bytes, 0, nullptr, nullptr, 0, true, true, &a, &b);
-  }
+  FastqScan sc;
+  KMI_TRY(fastq_scan(ctx, &idx->cfg, bytes_dev, n_bytes, &sc));   // reports malformed FASTQ
+  const uint64_t n = sc.n_tuples, n_tiles = sc.n_tiles;
+  if (n == 0) return KMI_OK;
+  PackedInput in; in.eol = sc.pk_eol; in.stream = sc.pk_stream; in.n_bytes = sc.n_bytes; in.n_cover = sc.n_cover;
+  const uint32_t *line_base = sc.line_base;
+  const bool canonical = idx->cfg.strand != KMI_STRAND_SINGLE;
   PartWs w;
   KMI_TRY(get_part_ws(ctx, n, NW, WS_KEYS_A, WS_KEYS_B, &w));
   KMI_HIP(ctx, hipMemsetAsync(w.fine_hist, 0, sizeof(uint32_t) * kNumFine * kFineParts, ctx->stream));
   {
     ProfScope ps(ctx, "fastq_hist", n);
-    hipLaunchKernelGGL((fastq_hist_kernel<NW, BITS>), dim3(kPartGroups), dim3(ExCfgWide<NW, BITS>::NT), 0, ctx->stream, bytes_dev,
-                       (uint64_t)n_bytes, n_tiles, idx->shape, idx->cfg.strand, line_base, w.fine_hist, w.wg_hist);
+    hipLaunchKernelGGL((fastq_hist_kernel<NW, BITS>), dim3(kPartGroups), dim3(ExCfgWide<NW, BITS>::NT), 0, ctx->stream, in,
+                       n_tiles, idx->shape, canonical, line_base, w.fine_hist, w.wg_hist);
   }
   {
     ProfScope ps(ctx, "fine_offsets", kNumFine);
@@ -1119,8 +1114,8 @@ static kmi_status build_fused_impl(kmi_index *idx, const uint8_t *bytes_dev, siz
   }
   {
     ProfScope ps(ctx, "fastq_scatter", n);
-    hipLaunchKernelGGL((fastq_scatter_kernel<NW, BITS>), dim3(kPartGroups), dim3(ExCfg<NW, BITS>::NT), 0, ctx->stream, bytes_dev,
-                       (uint64_t)n_bytes, n_tiles, idx->shape, idx->cfg.strand, line_base, (const uint64_t *)w.wg_off, w.buf_a, ctx->d_flags);
+    hipLaunchKernelGGL((fastq_scatter_kernel<NW, BITS>), dim3(kPartGroups), dim3(ExCfg<NW, BITS>::NT), 0, ctx->stream, in,
+                       n_tiles, idx->shape, canonical, line_base, (const uint64_t *)w.wg_off, w.buf_a);
   }
   {
     ProfScope ps(ctx, "scatter_fine", n);
@@ -1128,11 +1123,6 @@ static kmi_status build_fused_impl(kmi_index *idx, const uint8_t *bytes_dev, siz
                        idx->shape, (const uint64_t *)w.fine_off, (const uint64_t *)w.part_off, (const uint64_t *)w.wg_off);
   }
   KMI_HIP(ctx, hipGetLastError());
-  uint32_t flags0 = 0;
-  KMI_HIP(ctx, hipMemcpyAsync(&flags0, ctx->d_flags, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-  KMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  if (flags0 & 1u) return set_err(ctx, KMI_ERR_PARSE, "FASTQ: missing @ on first line of a record");
-  if (flags0 & 2u) return set_err(ctx, KMI_ERR_PARSE, "FASTQ: missing + on third line of a record");
   Partitioned part; part.keys = w.buf_b; part.fine_off = w.fine_off;
   return reduce_and_adopt<NW>(idx, part, (size_t)n);
 }

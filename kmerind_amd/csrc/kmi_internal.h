@@ -32,6 +32,8 @@ enum WsSlot {
   WS_OUTPUT,          // host-entry staging of outputs
   WS_OUTPUT2,
   WS_MISC,
+  WS_PK_EOL,          // EOL bitmap of the scanned input
+  WS_PK_STREAM,       // packed complement-code stream of the scanned input
   WS_NUM_SLOTS
 };
 
@@ -139,8 +141,12 @@ kmi_status extract_run(kmi_ctx *ctx, const kmi_config *cfg, const uint8_t *bytes
                        uint64_t file_offset, uint64_t *out_kmers_dev, uint64_t *out_ids_dev, size_t out_capacity,
                        bool apply_strand, bool scan_done, uint64_t *n_tuples, uint64_t *n_seqs);
 
-// tile scan of a FASTQ partition: per-tile line bases stay in the workspace (device pointer returned)
-kmi_status fastq_scan(kmi_ctx *ctx, const kmi_config *cfg, const uint8_t *bytes_dev, size_t n_bytes, uint64_t *n_tiles,
-                      uint32_t *tile_bytes, const uint32_t **line_base, uint64_t *n_tuples, uint64_t *n_seqs);
+// tile scan of a FASTQ partition; the packed arrays and per-tile line bases stay in the workspace
+struct FastqScan {
+  uint64_t n_tiles, n_tuples, n_seqs, n_bytes, n_cover;
+  const uint32_t *line_base;
+  const uint8_t *pk_eol, *pk_stream;
+};
+kmi_status fastq_scan(kmi_ctx *ctx, const kmi_config *cfg, const uint8_t *bytes_dev, size_t n_bytes, FastqScan *out);
 
 }  // namespace kmi
