@@ -293,9 +293,64 @@ template <int NW> KMI_HD uint32_t place_hash(const uint64_t (&key)[NW]) {
 // ---------------------------------------------------------------------------
 // eol : bit i set <=> byte i is '\n' or '\r' (bytes at or past `n_valid` count as EOL)
 // stream: complement codes, base i at bits [BITS*i, BITS*i+BITS)
+// ---- four bytes at a time (SWAR + v_perm_b32 byte look-up) ----------------------------------
+// perm(hi, lo, sel): result byte i = byte sel_i of the 8-byte table {lo (0..3), hi (4..7)}
+KMI_HD uint32_t byte_perm(uint32_t hi, uint32_t lo, uint32_t sel) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_perm(hi, lo, sel);
+#else
+  uint64_t tab = ((uint64_t)hi << 32) | lo;
+  uint32_t r = 0;
+  for (int i = 0; i < 4; ++i) r |= (uint32_t)((tab >> (8 * ((sel >> (8 * i)) & 7u))) & 0xffu) << (8 * i);
+  return r;
+#endif
+}
+// 0x80 in every byte of y that is zero (exact, no borrow artefacts)
+KMI_HD uint32_t zero_bytes(uint32_t y) { return ~(((y & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | y | 0x7F7F7F7Fu); }
+// bit i of the result = bit 7 of byte i
+KMI_HD uint32_t byte_msbs(uint32_t m) { return (((m >> 7) & 0x01010101u) * 0x01020408u) >> 24; }
+
+// classify the four bytes of w: eol4 = one bit per byte, packed = 4 complement codes (4*BITS bits)
+template <int BITS> KMI_HD void classify_dword(uint32_t w, uint32_t &eol4, uint32_t &packed) {
+  eol4 = byte_msbs(zero_bytes(w ^ 0x0A0A0A0Au) | zero_bytes(w ^ 0x0D0D0D0Du));
+  const uint32_t x = w & 0xDFDFDFDFu;                 // fold case
+  const uint32_t idx = (x >> 1) & 0x07070707u;        // A->0 C->1 T->2 G->3 X->4 N->7
+  if (BITS == 2) {
+    // a byte is a base iff it equals the letter its index stands for
+    const uint32_t expect = byte_perm(0xFFFFFFFFu, 0x47544341u, idx);            // 'A','C','T','G'
+    const uint32_t ok = zero_bytes(x ^ expect);                                  // 0x80 per base byte
+    const uint32_t lut = byte_perm(0x03030303u, 0x01000203u, idx);               // complement: A3 C2 T0 G1, rest 3
+    const uint32_t vm = (ok >> 7) * 3u;                                          // 0x03 per base byte
+    const uint32_t cc = (lut & vm) | (0x03030303u & ~vm);                        // non-bases count as A -> complement 3
+    const uint32_t p1 = cc | (cc >> 6);
+    packed = (p1 | (p1 >> 12)) & 0xFFu;
+  } else {
+    const uint32_t expect = byte_perm(0x4EFFFF58u, 0x47544341u, idx);            // idx4 'X', idx7 'N'
+    const uint32_t ok = zero_bytes(x ^ expect);
+    const uint32_t lut = byte_perm(0x07020207u, 0x03010604u, idx);               // rev3 of A1 C3 T4 G6 -> 4 6 1 3, N/X 7
+    const uint32_t vm = (ok >> 7) * 7u;
+    const uint32_t gap = zero_bytes(w ^ 0x2D2D2D2Du) | zero_bytes(w ^ 0x2E2E2E2Eu);   // '-' '.' -> code 0
+    const uint32_t dflt = 0x02020202u & ~((gap >> 7) * 7u);                      // everything else -> 2 (its own reversal)
+    const uint32_t cc = (lut & vm) | (dflt & ~vm);
+    const uint32_t p1 = (cc & 0x00070007u) | ((cc >> 5) & 0x00380038u);
+    packed = (p1 | (p1 >> 10)) & 0xFFFu;
+  }
+}
+
 // `dw` holds the chunk's bytes little-endian, 4 per dword.
 template <int BITS, int C> KMI_HD void classify_chunk(const uint32_t (&dw)[C / 4], int n_valid, uint32_t &eol, uint64_t &stream) {
   uint32_t e = 0; uint64_t s = 0;
+  if (n_valid == C) {
+#pragma unroll
+    for (int i = 0; i < C / 4; ++i) {
+      uint32_t e4, p4;
+      classify_dword<BITS>(dw[i], e4, p4);
+      e |= e4 << (4 * i);
+      s |= (uint64_t)p4 << (4 * BITS * i);
+    }
+    eol = e; stream = s;
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < C; ++i) {
     uint32_t c = (i < n_valid) ? ((dw[i >> 2] >> (8 * (i & 3))) & 0xffu) : (uint32_t)'\n';
