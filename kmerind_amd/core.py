@@ -111,8 +111,9 @@ class Context:
         return out
 
     # ---- KmerFileHelper::read_file_* equivalent on an in-memory, record-aligned partition
-    def read_file(self, cfg, data, file_offset=0):
-        """returns (kmers[n, n_words], n_seqs) in file order, as parsed (no strand transform)"""
+    def read_file(self, cfg, data, file_offset=0, with_ids=False):
+        """returns (kmers[n, n_words], n_seqs) in file order, as parsed (no strand transform);
+        with_ids (position index kinds): (kmers, ids, n_seqs), ids = Short/LongSequenceKmerId words"""
         buf = np.frombuffer(bytes(data), dtype=np.uint8) if isinstance(data, (bytes, bytearray)) else \
             np.ascontiguousarray(data, dtype=np.uint8)
         t = L.Tuples()
@@ -123,7 +124,15 @@ class Context:
         kmers = np.ctypeslib.as_array(t.kmers, shape=(n * nw,)).copy().reshape(n, nw) if n else \
             np.zeros((0, nw), dtype=np.uint64)
         nseq = t.n_seqs
+        ids = None
+        if with_ids:
+            if not t.ids:
+                lib.kmi_tuples_free(C.byref(t))
+                raise ValueError("ids need a position index kind in the config")
+            ids = np.ctypeslib.as_array(t.ids, shape=(n,)).copy() if n else np.zeros(0, dtype=np.uint64)
         lib.kmi_tuples_free(C.byref(t))
+        if with_ids:
+            return kmers, ids, nseq
         return kmers, nseq
 
     # ---- profiling

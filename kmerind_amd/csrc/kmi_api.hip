@@ -267,15 +267,19 @@ kmi_status kmi_extract_host(kmi_ctx *ctx, const kmi_config *cfg, const uint8_t *
   KMI_HIP(ctx, hipMemcpyAsync(din, bytes, n_bytes, hipMemcpyHostToDevice, ctx->stream));
   uint64_t nt = 0, ns = 0;
   KMI_TRY(extract_count(ctx, cfg, (const uint8_t *)din, n_bytes, &nt, &ns));
-  void *dout;
+  void *dout, *dids = nullptr;
   const size_t out_bytes = (size_t)nt * shape.n_words * sizeof(uint64_t);
+  const bool want_ids = cfg->index_kind != KMI_INDEX_COUNT;
   KMI_TRY(ws_get(ctx, WS_OUTPUT, out_bytes, &dout));
-  KMI_TRY(extract_run(ctx, cfg, (const uint8_t *)din, n_bytes, file_offset, (uint64_t *)dout, nullptr, (size_t)nt, false, true, &nt,
-                      &ns));
+  if (want_ids) KMI_TRY(ws_get(ctx, WS_OUTPUT2, (size_t)nt * sizeof(uint64_t), &dids));
+  KMI_TRY(extract_run(ctx, cfg, (const uint8_t *)din, n_bytes, file_offset, (uint64_t *)dout, (uint64_t *)dids, (size_t)nt, false, true,
+                      &nt, &ns));
   out->n_tuples = nt; out->n_seqs = ns;
   out->kmers = (uint64_t *)malloc(out_bytes ? out_bytes : 8);
-  if (!out->kmers) return set_err(ctx, KMI_ERR_NOMEM, "host malloc failed");
+  if (want_ids) out->ids = (uint64_t *)malloc(nt ? nt * sizeof(uint64_t) : 8);
+  if (!out->kmers || (want_ids && !out->ids)) return set_err(ctx, KMI_ERR_NOMEM, "host malloc failed");
   if (out_bytes) KMI_HIP(ctx, hipMemcpyAsync(out->kmers, dout, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+  if (want_ids && nt) KMI_HIP(ctx, hipMemcpyAsync(out->ids, dids, nt * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
   KMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return KMI_OK;
 }

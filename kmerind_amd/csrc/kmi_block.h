@@ -54,4 +54,37 @@ template <typename T, bool TRAILING_SYNC = true> __device__ __forceinline__ T bl
   return res;
 }
 
+template <typename T> __device__ __forceinline__ T wave_inclusive_max(T v) {
+#pragma unroll
+  for (int d = 1; d < kWave; d <<= 1) {
+    T o = __shfl_up(v, d, kWave);
+    if ((int)lane_id() >= d) v = (o > v) ? o : v;
+  }
+  return v;
+}
+
+// Exclusive running maximum over the workgroup (identity 0). scratch: blockDim.x/64 + 1 elements.
+template <typename T> __device__ __forceinline__ T block_exclusive_max(T v, T *scratch, T *total) {
+  const uint32_t nw = blockDim.x >> 6;
+  T inc = wave_inclusive_max(v);
+  if (lane_id() == kWave - 1) scratch[wave_id()] = inc;
+  lds_barrier();
+  if (wave_id() == 0) {
+    T w = (lane_id() < nw) ? scratch[lane_id()] : T(0);
+    T winc = wave_inclusive_max(w);
+    T wexc = __shfl_up(winc, 1, kWave);
+    if (lane_id() == 0) wexc = T(0);
+    if (lane_id() < nw) scratch[lane_id()] = wexc;
+    if (lane_id() == nw - 1) scratch[nw] = winc;
+  }
+  lds_barrier();
+  T prev = __shfl_up(inc, 1, kWave);          // inclusive max of the lanes before this one
+  if (lane_id() == 0) prev = T(0);
+  T base = scratch[wave_id()];
+  T res = (base > prev) ? base : prev;
+  if (total) *total = scratch[nw];
+  lds_barrier();
+  return res;
+}
+
 }  // namespace kmi

@@ -32,6 +32,7 @@ struct TileInfo {
   uint32_t lines;     // line starts in the tile
   uint32_t win[4];    // EOL-free k-windows starting in the tile, by (local line count & 3)
   uint32_t marks;     // bit r: a line with (local line index & 3) == r does not start with '@'; bit 4+r: ... with '+'
+  uint32_t last[4];   // 1 + tile position of the last line start with (local line index & 3) == r, 0 = none
 };
 
 // ---- chunk load: C bytes at byte offset g (zero-filled past n_bytes); returns #valid bytes

@@ -40,7 +40,9 @@ __global__ __launch_bounds__((ExCfg<NW, BITS>::NT)) void fastq_scan_tiles_kernel
   __shared__ uint32_t s_eol[Cfg::EOL_DW];
   __shared__ uint32_t s_scan[Cfg::NT / 64 + 2];
   __shared__ uint32_t s_cnt[3];
+  __shared__ uint32_t s_last[4];
   if (threadIdx.x < 3) s_cnt[threadIdx.x] = 0;
+  if (threadIdx.x < 4) s_last[threadIdx.x] = 0;
   uint32_t dw[Cfg::C / 4], eol, ls, lbl, ltot;
   tile_front_bytes<Cfg>(bytes, n_bytes, blockIdx.x, pk_eol, pk_stream, s_eol, s_scan, dw, eol, ls, lbl, ltot);
 
@@ -51,6 +53,7 @@ __global__ __launch_bounds__((ExCfg<NW, BITS>::NT)) void fastq_scan_tiles_kernel
 
   // windows by local phase: 16-bit fields (phase 0,1) and (phase 2,3); marker bits by local phase
   uint32_t lo = 0, hi = 0, marks = 0;
+  uint32_t last[4] = {0, 0, 0, 0};
   {
     uint32_t cur = lbl, start = 0, rest = ls;
     while (true) {
@@ -64,6 +67,9 @@ __global__ __launch_bounds__((ExCfg<NW, BITS>::NT)) void fastq_scan_tiles_kernel
       const uint32_t ch = (dw[q >> 2] >> (8 * (q & 3))) & 0xffu;
       if (ch != '@') marks |= 1u << (cur & 3u);
       if (ch != '+') marks |= 16u << (cur & 3u);
+      const uint32_t lp = threadIdx.x * Cfg::C + q + 1u;
+#pragma unroll
+      for (uint32_t r = 0; r < 4; ++r) last[r] = ((cur & 3u) == r) ? lp : last[r];
       cur += 1; start = q; rest &= rest - 1u;
     }
   }
@@ -72,7 +78,16 @@ __global__ __launch_bounds__((ExCfg<NW, BITS>::NT)) void fastq_scan_tiles_kernel
   lo = wave_reduce_sum(lo); hi = wave_reduce_sum(hi);
 #pragma unroll
   for (int d = kWave / 2; d > 0; d >>= 1) marks |= __shfl_xor(marks, d, kWave);
-  if (lane_id() == 0) { atomicAdd(&s_cnt[0], lo); atomicAdd(&s_cnt[1], hi); atomicOr(&s_cnt[2], marks); }
+#pragma unroll
+  for (uint32_t r = 0; r < 4; ++r) {
+#pragma unroll
+    for (int d = kWave / 2; d > 0; d >>= 1) { uint32_t o = __shfl_xor(last[r], d, kWave); last[r] = o > last[r] ? o : last[r]; }
+  }
+  if (lane_id() == 0) {
+    atomicAdd(&s_cnt[0], lo); atomicAdd(&s_cnt[1], hi); atomicOr(&s_cnt[2], marks);
+#pragma unroll
+    for (uint32_t r = 0; r < 4; ++r) if (last[r]) atomicMax(&s_last[r], last[r]);
+  }
   lds_barrier();
   if (threadIdx.x == 0) {
     TileInfo ti;
@@ -80,6 +95,7 @@ __global__ __launch_bounds__((ExCfg<NW, BITS>::NT)) void fastq_scan_tiles_kernel
     ti.win[0] = s_cnt[0] & 0xffffu; ti.win[1] = s_cnt[0] >> 16;
     ti.win[2] = s_cnt[1] & 0xffffu; ti.win[3] = s_cnt[1] >> 16;
     ti.marks = s_cnt[2];
+    for (int r = 0; r < 4; ++r) ti.last[r] = s_last[r];
     info[blockIdx.x] = ti;
   }
 }
@@ -93,14 +109,16 @@ __global__ __launch_bounds__((ExCfg<NW, BITS>::NT)) void fastq_scan_tiles_kernel
 //   (c) every block re-scans its tiles from the block's base.
 // totals[0] = lines, totals[1] = tuples, totals[2] = sequences (lines with index % 4 == 1)
 // ---------------------------------------------------------------------------
-struct TileSum { uint64_t lines; uint64_t cnt[4]; };
+struct TileSum { uint64_t lines; uint64_t cnt[4]; uint64_t hdr[4]; };   // hdr: 1 + byte position of the last header line start, by incoming phase
 
-__global__ __launch_bounds__(1024) void fastq_offsets_reduce_kernel(const TileInfo *__restrict__ info, uint64_t n_tiles,
+__global__ __launch_bounds__(1024) void fastq_offsets_reduce_kernel(const TileInfo *__restrict__ info, uint64_t n_tiles, uint32_t tile_bytes,
                                                                    TileSum *__restrict__ sums) {
   __shared__ uint32_t s_scan[1024 / 64 + 2];
   __shared__ uint32_t s_cnt[4];
+  __shared__ unsigned long long s_hdr[4];
+  if (threadIdx.x < 4) s_hdr[threadIdx.x] = 0ull;
   const uint64_t t = (uint64_t)blockIdx.x * 1024 + threadIdx.x;
-  TileInfo ti; ti.lines = 0; ti.win[0] = ti.win[1] = ti.win[2] = ti.win[3] = 0; ti.marks = 0;
+  TileInfo ti; ti.lines = 0; ti.win[0] = ti.win[1] = ti.win[2] = ti.win[3] = 0; ti.marks = 0; ti.last[0] = ti.last[1] = ti.last[2] = ti.last[3] = 0;
   if (t < n_tiles) ti = info[t];
   if (threadIdx.x < 4) s_cnt[threadIdx.x] = 0;
   uint32_t tot;
@@ -109,10 +127,17 @@ __global__ __launch_bounds__(1024) void fastq_offsets_reduce_kernel(const TileIn
   for (uint32_t r = 0; r < 4; ++r) {
     uint32_t c = wave_reduce_sum(ti.win[(2u - r - lb) & 3u]);
     if (lane_id() == 0) atomicAdd(&s_cnt[r], c);
+    // header lines of this tile if r lines precede the block: local index == -(r + lb) mod 4
+    const uint32_t l = ti.last[(0u - r - lb) & 3u];
+    unsigned long long h = l ? (unsigned long long)t * tile_bytes + l : 0ull;
+#pragma unroll
+    for (int d = kWave / 2; d > 0; d >>= 1) { unsigned long long o = __shfl_xor(h, d, kWave); h = o > h ? o : h; }
+    if (lane_id() == 0 && h) atomicMax(&s_hdr[r], h);
   }
   lds_barrier();
   if (threadIdx.x == 0) {
     TileSum o; o.lines = tot;
+    for (int r = 0; r < 4; ++r) o.hdr[r] = s_hdr[r];
     for (int r = 0; r < 4; ++r) o.cnt[r] = s_cnt[r];
     sums[blockIdx.x] = o;
   }
@@ -123,17 +148,20 @@ __global__ __launch_bounds__(1024) void fastq_offsets_scan_kernel(TileSum *__res
                                                                  uint64_t n_tiles, uint64_t *__restrict__ out_off,
                                                                  uint64_t *__restrict__ totals) {
   __shared__ uint64_t s_scan[1024 / 64 + 2];
-  uint64_t carry_lines = 0, carry_cnt = 0;
+  uint64_t carry_lines = 0, carry_cnt = 0, carry_hdr = 0;
   for (uint64_t b0 = 0; b0 < n_blocks; b0 += 1024) {
     const uint64_t b = b0 + threadIdx.x;
-    TileSum ts; ts.lines = 0; ts.cnt[0] = ts.cnt[1] = ts.cnt[2] = ts.cnt[3] = 0;
+    TileSum ts; ts.lines = 0; ts.cnt[0] = ts.cnt[1] = ts.cnt[2] = ts.cnt[3] = 0; ts.hdr[0] = ts.hdr[1] = ts.hdr[2] = ts.hdr[3] = 0;
     if (b < n_blocks) ts = sums[b];
     uint64_t tl, tc;
     const uint64_t lb = carry_lines + block_exclusive_scan<uint64_t>(ts.lines, s_scan, &tl);
     const uint64_t c = ts.cnt[(uint32_t)lb & 3u];
     const uint64_t cb = carry_cnt + block_exclusive_scan<uint64_t>(c, s_scan, &tc);
-    if (b < n_blocks) { ts.lines = lb; ts.cnt[0] = cb; sums[b] = ts; }
-    carry_lines += tl; carry_cnt += tc;
+    uint64_t th;
+    uint64_t hb = block_exclusive_max<uint64_t>(ts.hdr[(uint32_t)lb & 3u], s_scan, &th);
+    hb = hb > carry_hdr ? hb : carry_hdr;
+    if (b < n_blocks) { ts.lines = lb; ts.cnt[0] = cb; ts.hdr[0] = hb; sums[b] = ts; }
+    carry_lines += tl; carry_cnt += tc; carry_hdr = th > carry_hdr ? th : carry_hdr;
   }
   if (threadIdx.x == 0) {
     out_off[n_tiles] = carry_cnt;
@@ -143,20 +171,25 @@ __global__ __launch_bounds__(1024) void fastq_offsets_scan_kernel(TileSum *__res
   }
 }
 
-__global__ __launch_bounds__(1024) void fastq_offsets_apply_kernel(const TileInfo *__restrict__ info, uint64_t n_tiles,
-                                                                  const TileSum *__restrict__ sums,
+__global__ __launch_bounds__(1024) void fastq_offsets_apply_kernel(const TileInfo *__restrict__ info, uint64_t n_tiles, uint32_t tile_bytes,
+                                                                  const TileSum *__restrict__ sums, uint64_t *__restrict__ hdr_base,
                                                                   uint32_t *__restrict__ line_base,
                                                                   uint64_t *__restrict__ out_off,
                                                                   uint32_t *__restrict__ flags) {
   __shared__ uint32_t s_scan[1024 / 64 + 2];
   const uint64_t t = (uint64_t)blockIdx.x * 1024 + threadIdx.x;
-  TileInfo ti; ti.lines = 0; ti.win[0] = ti.win[1] = ti.win[2] = ti.win[3] = 0; ti.marks = 0;
+  TileInfo ti; ti.lines = 0; ti.win[0] = ti.win[1] = ti.win[2] = ti.win[3] = 0; ti.marks = 0; ti.last[0] = ti.last[1] = ti.last[2] = ti.last[3] = 0;
   if (t < n_tiles) ti = info[t];
   const TileSum base = sums[blockIdx.x];
   const uint32_t lb = (uint32_t)base.lines + block_exclusive_scan<uint32_t>(ti.lines, s_scan, (uint32_t *)nullptr);
   const uint32_t c = ti.win[(2u - lb) & 3u];
   const uint32_t co = block_exclusive_scan<uint32_t>(c, s_scan, (uint32_t *)nullptr);
+  __shared__ uint64_t s_scan64[1024 / 64 + 2];
+  const uint32_t hl = ti.last[(0u - lb) & 3u];
+  uint64_t hb = block_exclusive_max<uint64_t>(hl ? t * tile_bytes + hl : 0ull, s_scan64, (uint64_t *)nullptr);
+  hb = hb > base.hdr[0] ? hb : base.hdr[0];
   if (t < n_tiles) {
+    hdr_base[t] = hb;   // 1 + byte position of the last record start before this tile (0 = none)
     line_base[t] = lb; out_off[t] = base.cnt[0] + co;
     // header lines are the ones with (lb + local index) % 4 == 0, '+' lines == 2
     uint32_t bad = 0;
@@ -170,29 +203,59 @@ __global__ __launch_bounds__(1024) void fastq_offsets_apply_kernel(const TileInf
 // pass 3: tuples in file order. Work is re-distributed over the tile's compacted window list,
 // so consecutive lanes produce consecutive tuples and the stores are coalesced without staging.
 // ---------------------------------------------------------------------------
-template <int NW, int BITS>
+template <int NW, int BITS, bool WITH_IDS>
 __global__ __launch_bounds__((ExCfg<NW, BITS>::NT)) void fastq_extract_kernel(
-    PackedInput in, KShape shape, bool canonical, const uint32_t *__restrict__ line_base,
-    const uint64_t *__restrict__ out_off, uint64_t out_capacity, uint64_t *__restrict__ out_kmers, uint32_t *__restrict__ flags) {
+    PackedInput in, KShape shape, bool canonical, const uint32_t *__restrict__ line_base, const uint64_t *__restrict__ hdr_base,
+    uint64_t file_offset, const uint64_t *__restrict__ out_off, uint64_t out_capacity, uint64_t *__restrict__ out_kmers,
+    uint64_t *__restrict__ out_ids, uint32_t *__restrict__ flags) {
   using Cfg = ExCfg<NW, BITS>;
   __shared__ uint32_t s_eol[Cfg::EOL_DW];
   __shared__ uint32_t s_stream[Cfg::STREAM_DW];
   __shared__ uint32_t s_scan[Cfg::NT / 64 + 2];
   __shared__ uint16_t s_pos[Cfg::TILE];
+  __shared__ uint16_t s_hmask[WITH_IDS ? Cfg::NT : 1];   // record-start bits of every chunk
+  __shared__ uint16_t s_hexcl[WITH_IDS ? Cfg::NT : 1];   // 1 + tile position of the last record start in earlier chunks
   uint32_t eol, ls, lbl, ltot;
   tile_front_packed<Cfg>(in, blockIdx.x, s_eol, s_stream, s_scan, eol, ls, lbl, ltot);
-  const uint32_t total = tile_window_list<Cfg>(s_eol, ls, line_base[blockIdx.x] + lbl, shape.k, s_pos, s_scan);
+  const uint32_t lines_before = line_base[blockIdx.x] + lbl;
+  if (WITH_IDS) {
+    // record starts = line starts whose line index % 4 == 0 (the '@' line)
+    uint32_t cur = lines_before, rest = ls, hm = 0, hlast = 0;
+    while (rest) {
+      const uint32_t q = (uint32_t)__builtin_ctz(rest);
+      if ((cur & 3u) == 0u) { hm |= 1u << q; hlast = threadIdx.x * Cfg::C + q + 1u; }
+      cur += 1; rest &= rest - 1u;
+    }
+    s_hmask[threadIdx.x] = (uint16_t)hm;
+    s_hexcl[threadIdx.x] = (uint16_t)block_exclusive_max<uint32_t>(hlast, s_scan, (uint32_t *)nullptr);
+  }
+  const uint32_t total = tile_window_list<Cfg>(s_eol, ls, lines_before, shape.k, s_pos, s_scan);
   const uint64_t base = out_off[blockIdx.x];
   if (base + total > out_capacity) {
     if (threadIdx.x == 0 && total) atomicOr(&flags[1], 1u);
     return;
   }
+  const uint64_t tile0 = (uint64_t)blockIdx.x * Cfg::TILE;
   for (uint32_t q = threadIdx.x; q < total; q += Cfg::NT) {
     uint64_t rc[NW], fw[NW], key[NW];
-    window_at<Cfg>(s_stream, s_pos[q], shape, rc, fw);
+    const uint32_t pos = s_pos[q];
+    window_at<Cfg>(s_stream, pos, shape, rc, fw);
     select_strand<NW>(rc, fw, canonical, key);
 #pragma unroll
     for (int w = 0; w < NW; ++w) out_kmers[(base + q) * NW + w] = key[w];
+    if (WITH_IDS) {
+      // ShortSequenceKmerId (sequence.hpp:156-157): record file offset << 16 | offset of the k-mer's
+      // first base from the record start (kmer_parser.hpp:378-386)
+      const uint32_t j = pos / Cfg::C, p = pos % Cfg::C;
+      const uint32_t m = (uint32_t)s_hmask[j] & ((2u << p) - 1u);
+      uint64_t rec;   // 1 + byte position (relative to the buffer) of the record start
+      if (m) rec = tile0 + j * Cfg::C + (31u - (uint32_t)__builtin_clz(m)) + 1u;
+      else if (s_hexcl[j]) rec = tile0 + s_hexcl[j];
+      else rec = hdr_base[blockIdx.x];
+      const uint64_t rec_off = file_offset + rec - 1u, d = tile0 + pos - (rec - 1u);
+      if (rec == 0 || d > 0xFFFFu) atomicOr(&flags[3], 1u);   // ShortSequenceKmerId increment overflow (sequence.hpp:177-183)
+      out_ids[base + q] = ((rec_off & 0xFFFFFFFFFFull) << 16) | (d & 0xFFFFull);
+    }
   }
 }
 
@@ -203,6 +266,7 @@ struct ScanResult {
   uint64_t n_tiles;
   uint32_t *line_base;
   uint64_t *out_off;
+  uint64_t *hdr_base;
   PackedInput packed;
 };
 
@@ -218,12 +282,14 @@ static kmi_status scan_impl(kmi_ctx *ctx, const uint8_t *bytes_dev, size_t n_byt
   uint32_t *base = (uint32_t *)p;
   KMI_TRY(ws_get(ctx, WS_TILE_OFF, sizeof(uint64_t) * (n_tiles + 2), &p));
   uint64_t *off = (uint64_t *)p;
+  KMI_TRY(ws_get(ctx, WS_TILE_HDR, sizeof(uint64_t) * (n_tiles + 1), &p));
+  uint64_t *hdr = (uint64_t *)p;
   const uint64_t n_cover = n_tiles * Cfg::TILE;
   KMI_TRY(ws_get(ctx, WS_PK_EOL, n_cover / 8 + 64, &p));
   uint8_t *pk_eol = (uint8_t *)p;
   KMI_TRY(ws_get(ctx, WS_PK_STREAM, n_cover * BITS / 8 + 64, &p));
   uint8_t *pk_stream = (uint8_t *)p;
-  r->n_tiles = n_tiles; r->line_base = base; r->out_off = off;
+  r->n_tiles = n_tiles; r->line_base = base; r->out_off = off; r->hdr_base = hdr;
   r->packed.eol = pk_eol; r->packed.stream = pk_stream; r->packed.n_bytes = n_bytes; r->packed.n_cover = n_cover;
   if (reuse) return KMI_OK;   // the scan of these very bytes is still in the workspace
   if (n_tiles > 0) {
@@ -239,13 +305,13 @@ static kmi_status scan_impl(kmi_ctx *ctx, const uint8_t *bytes_dev, size_t n_byt
     ProfScope ps(ctx, "fastq_scan_offsets", n_tiles);
     if (n_blocks > 0) {
       hipLaunchKernelGGL(fastq_offsets_reduce_kernel, dim3((unsigned)n_blocks), dim3(1024), 0, ctx->stream,
-                         (const TileInfo *)info, n_tiles, sums);
+                         (const TileInfo *)info, n_tiles, (uint32_t)Cfg::TILE, sums);
     }
     hipLaunchKernelGGL(fastq_offsets_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, sums, n_blocks, n_tiles, off,
                        ctx->d_totals);
     if (n_blocks > 0) {
       hipLaunchKernelGGL(fastq_offsets_apply_kernel, dim3((unsigned)n_blocks), dim3(1024), 0, ctx->stream,
-                         (const TileInfo *)info, n_tiles, (const TileSum *)sums, base, off, ctx->d_flags);
+                         (const TileInfo *)info, n_tiles, (uint32_t)Cfg::TILE, (const TileSum *)sums, hdr, base, off, ctx->d_flags);
     }
   }
   KMI_HIP(ctx, hipGetLastError());
@@ -276,23 +342,31 @@ static kmi_status extract_count_impl(kmi_ctx *ctx, const uint8_t *bytes_dev, siz
 
 template <int NW, int BITS>
 static kmi_status extract_run_impl(kmi_ctx *ctx, const kmi_config *cfg, const uint8_t *bytes_dev, size_t n_bytes,
-                                   KShape shape, uint64_t *out_kmers_dev, size_t out_capacity, bool apply_strand,
-                                   bool scan_done, uint64_t *n_tuples, uint64_t *n_seqs) {
+                                   KShape shape, uint64_t file_offset, uint64_t *out_kmers_dev, uint64_t *out_ids_dev,
+                                   size_t out_capacity, bool apply_strand, bool scan_done, uint64_t *n_tuples, uint64_t *n_seqs) {
   using Cfg = ExCfg<NW, BITS>;
   ScanResult r;
   if (!scan_done) KMI_HIP(ctx, hipMemsetAsync(ctx->d_flags, 0, sizeof(uint32_t) * 16, ctx->stream));
   KMI_TRY((scan_impl<NW, BITS>(ctx, bytes_dev, n_bytes, shape, &r, scan_done)));
   if (r.n_tiles > 0) {
     ProfScope ps(ctx, "fastq_extract", n_bytes);
-    hipLaunchKernelGGL((fastq_extract_kernel<NW, BITS>), dim3((unsigned)r.n_tiles), dim3(Cfg::NT), 0, ctx->stream,
-                       r.packed, shape, apply_strand && cfg->strand != KMI_STRAND_SINGLE, (const uint32_t *)r.line_base,
-                       (const uint64_t *)r.out_off, (uint64_t)out_capacity, out_kmers_dev, ctx->d_flags);
+    const bool canonical = apply_strand && cfg->strand != KMI_STRAND_SINGLE;
+    if (out_ids_dev) {
+      hipLaunchKernelGGL((fastq_extract_kernel<NW, BITS, true>), dim3((unsigned)r.n_tiles), dim3(Cfg::NT), 0, ctx->stream,
+                         r.packed, shape, canonical, (const uint32_t *)r.line_base, (const uint64_t *)r.hdr_base, file_offset,
+                         (const uint64_t *)r.out_off, (uint64_t)out_capacity, out_kmers_dev, out_ids_dev, ctx->d_flags);
+    } else {
+      hipLaunchKernelGGL((fastq_extract_kernel<NW, BITS, false>), dim3((unsigned)r.n_tiles), dim3(Cfg::NT), 0, ctx->stream,
+                         r.packed, shape, canonical, (const uint32_t *)r.line_base, (const uint64_t *)r.hdr_base, file_offset,
+                         (const uint64_t *)r.out_off, (uint64_t)out_capacity, out_kmers_dev, (uint64_t *)nullptr, ctx->d_flags);
+    }
   }
   KMI_HIP(ctx, hipGetLastError());
-  uint32_t flag1 = 0;
-  KMI_HIP(ctx, hipMemcpyAsync(&flag1, ctx->d_flags + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+  uint32_t fl[4] = {0, 0, 0, 0};
+  KMI_HIP(ctx, hipMemcpyAsync(fl, ctx->d_flags, sizeof(fl), hipMemcpyDeviceToHost, ctx->stream));
   KMI_TRY(read_totals(ctx, n_tuples, n_seqs));
-  if (flag1) return set_err(ctx, KMI_ERR_OVERFLOW, "extract: output capacity too small");
+  if (fl[1]) return set_err(ctx, KMI_ERR_OVERFLOW, "extract: output capacity too small");
+  if (fl[3]) return set_err(ctx, KMI_ERR_OVERFLOW, "ShortSequenceKmerId increment overflow (k-mer more than 65535 bytes into its record)");
   return KMI_OK;
 }
 
@@ -325,14 +399,12 @@ kmi_status extract_count(kmi_ctx *ctx, const kmi_config *cfg, const uint8_t *byt
 kmi_status extract_run(kmi_ctx *ctx, const kmi_config *cfg, const uint8_t *bytes_dev, size_t n_bytes,
                        uint64_t file_offset, uint64_t *out_kmers_dev, uint64_t *out_ids_dev, size_t out_capacity,
                        bool apply_strand, bool scan_done, uint64_t *n_tuples, uint64_t *n_seqs) {
-  (void)file_offset;
   KShape shape;
   if (!valid_config(cfg, &shape)) return set_err(ctx, KMI_ERR_INVALID, "bad kmi_config");
   if (cfg->seq_format != KMI_FMT_FASTQ) return set_err(ctx, KMI_ERR_INVALID, "only FASTQ is implemented on the device yet");
-  if (out_ids_dev) return set_err(ctx, KMI_ERR_INVALID, "position ids are not implemented on the device yet");
   if (n_bytes == 0) { if (n_tuples) *n_tuples = 0; if (n_seqs) *n_seqs = 0; return KMI_OK; }
-  KMI_DISPATCH(shape, extract_run_impl, ctx, cfg, bytes_dev, n_bytes, shape, out_kmers_dev, out_capacity, apply_strand,
-               scan_done, n_tuples, n_seqs);
+  KMI_DISPATCH(shape, extract_run_impl, ctx, cfg, bytes_dev, n_bytes, shape, file_offset, out_kmers_dev, out_ids_dev, out_capacity,
+               apply_strand, scan_done, n_tuples, n_seqs);
 }
 
 }  // namespace kmi

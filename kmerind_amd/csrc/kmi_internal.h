@@ -32,6 +32,7 @@ enum WsSlot {
   WS_OUTPUT,          // host-entry staging of outputs
   WS_OUTPUT2,
   WS_MISC,
+  WS_TILE_HDR,        // per-tile position of the last record start before the tile
   WS_PK_EOL,          // EOL bitmap of the scanned input
   WS_PK_STREAM,       // packed complement-code stream of the scanned input
   WS_NUM_SLOTS

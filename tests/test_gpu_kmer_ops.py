@@ -164,3 +164,33 @@ def test_extract_synthetic_reads_multi_tile(ctx):
         kmers, nseq = ctx.read_file(K.make_config(k, alpha), data)
         assert nseq == 3000 and kmers.shape[0] == 3000 * (150 - k + 1)
         assert (kmers == ex["kmers"]).all()
+
+
+@pytest.mark.parametrize("k,alpha", [(31, "DNA"), (21, "DNA"), (63, "DNA5"), (3, "DNA")])
+def test_extract_position_ids(ctx, k, alpha):
+    """KmerPositionTupleParser on FASTQ: ShortSequenceKmerId of every tuple (kmer_parser.hpp:303-569)"""
+    import kmerind_amd as K
+    s = orc.kspec(k, ALPHA[alpha])
+    cfg = K.make_config(k, alpha, index_kind="position")
+    rng = np.random.default_rng(k)
+    inputs = [open(os.path.join(GOLD, "data", n), "rb").read() for n in ("test.small.fastq", "natural.fastq", "test.unitiq1.fastq")]
+    inputs.append(_ragged_fastq(rng, 700, b"\n"))
+    inputs.append(_ragged_fastq(rng, 300, b"\r\n", max_len=40))
+    inputs.append(bytes(K.synth_fastq(seed=4, genome_len=100_000, n_reads=2500)))
+    for data in inputs:
+        for off in (0, 123_456_789_012):
+            ex = orc.extract(s, data, orc.FASTQ, file_offset=off, want_ids=True)
+            kmers, ids, nseq = ctx.read_file(cfg, data, file_offset=off, with_ids=True)
+            assert nseq == ex["n_seqs"] and kmers.shape == ex["kmers"].shape
+            assert (kmers == ex["kmers"]).all()
+            assert (ids == ex["ids"]).all()
+
+
+def test_position_id_overflow_is_reported(ctx):
+    import kmerind_amd as K
+    from kmerind_amd import _lib as L
+    cfg = K.make_config(21, "DNA", index_kind="position")
+    long_read = b"@r\n" + b"ACGT" * 20000 + b"\n+\n" + b"I" * 80000 + b"\n"
+    with pytest.raises(L.KmiError) as ei:
+        ctx.read_file(cfg, long_read, with_ids=True)
+    assert ei.value.status == L.ERR_OVERFLOW
