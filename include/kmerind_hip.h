@@ -170,6 +170,18 @@ kmi_status kmi_index_count_dev(kmi_index *idx, const uint64_t *queries_dev, size
 kmi_status kmi_index_find_dev(kmi_index *idx, const uint64_t *queries_dev, size_t nq,
                               uint64_t *out_keys_dev, uint64_t *out_values_dev, uint64_t *n_out);
 
+/* ---- multimap maps: PositionIndex / PositionQualityIndex (kmer_index.hpp:402-406) over
+ * ::dsc::unordered_multimap (distributed_unordered_map.hpp:1466-1515). An index created with
+ * index_kind POSITION stores every (k-mer, value) tuple; value = 1 u64 (Short/LongSequenceKmerId),
+ * POSQUAL = 2 u64 (id, quality float in the low 32 bits of the second word).
+ * kmi_index_build_* on such an index parses with KmerPositionTupleParser semantics.
+ * count() returns the multiplicity, find() every (key, value) whose key is queried, erase() removes
+ * all of them; kmi_results.values then holds n * value_words words. */
+kmi_status kmi_index_insert_tuples_host(kmi_index *idx, const uint64_t *kmers, const uint64_t *values, size_t n);
+/* records_dev: n records of (n_words key words, value words), i.e. std::pair<Kmer, value> objects */
+kmi_status kmi_index_insert_tuples_dev(kmi_index *idx, const uint64_t *records_dev, size_t n);
+kmi_status kmi_index_export_tuples_host(kmi_index *idx, uint64_t *keys, uint64_t *values, size_t capacity, uint64_t *n);
+
 /* ---- measurement support --------------------------------------------------- */
 /* per-kernel HIP-event timing on the context's stream (bench.py roofline leg) */
 kmi_status kmi_profile_enable(kmi_ctx *ctx, int on);

@@ -84,6 +84,9 @@ SIGNATURES = {
     "kmi_index_erase_host": (C.c_int, [_P, _P, _sz, C.POINTER(_u64)]),
     "kmi_index_count_dev": (C.c_int, [_P, _P, _sz, _P, _P, C.POINTER(_u64)]),
     "kmi_index_find_dev": (C.c_int, [_P, _P, _sz, _P, _P, C.POINTER(_u64)]),
+    "kmi_index_insert_tuples_host": (C.c_int, [_P, _P, _P, _sz]),
+    "kmi_index_insert_tuples_dev": (C.c_int, [_P, _P, _sz]),
+    "kmi_index_export_tuples_host": (C.c_int, [_P, _P, _P, _sz, C.POINTER(_u64)]),
     "kmi_profile_enable": (C.c_int, [_P, C.c_int]),
     "kmi_profile_reset": (C.c_int, [_P]),
     "kmi_profile_get": (C.c_int, [_P, C.POINTER(KernelTime), _sz, C.POINTER(_sz)]),

@@ -232,6 +232,50 @@ class CountIndex:
         return n.value
 
 
+class PositionIndex(CountIndex):
+    """bliss::index::kmer::PositionIndex<unordered_multimap> on one rank (kmer_index.hpp:402-403):
+    every (k-mer, ShortSequenceKmerId) tuple is kept."""
+
+    def __init__(self, ctx, cfg):
+        if cfg.index_kind == L.INDEX_COUNT:
+            raise ValueError("PositionIndex needs index_kind='position'")
+        super().__init__(ctx, cfg)
+        self.value_words = 1 if cfg.index_kind == L.INDEX_POSITION else 2
+
+    def insert(self, kmers, values):
+        kmers = _u64(kmers, self.n_words)
+        values = np.ascontiguousarray(values, dtype=np.uint64).reshape(kmers.shape[0], self.value_words)
+        self.ctx.check(lib.kmi_index_insert_tuples_host(self.h, kmers.ctypes.data_as(C.c_void_p),
+                                                        values.ctypes.data_as(C.c_void_p), kmers.shape[0]))
+
+    def to_vector(self):
+        n = self.local_size()
+        keys = np.zeros((n, self.n_words), dtype=np.uint64)
+        vals = np.zeros((n, self.value_words), dtype=np.uint64)
+        got = C.c_uint64()
+        self.ctx.check(lib.kmi_index_export_tuples_host(self.h, keys.ctypes.data_as(C.c_void_p),
+                                                        vals.ctypes.data_as(C.c_void_p), n, C.byref(got)))
+        return keys[:got.value], vals[:got.value]
+
+    def _query(self, fn, q):
+        q = _u64(q, self.n_words)
+        r = L.Results()
+        self.ctx.check(fn(self.h, q.ctypes.data_as(C.c_void_p), q.shape[0], C.byref(r)))
+        n, vw = r.n, self.value_words
+        if n:
+            keys = np.ctypeslib.as_array(r.keys, shape=(n * self.n_words,)).copy().reshape(n, self.n_words)
+            vals = np.ctypeslib.as_array(r.values, shape=(n * vw,)).copy().reshape(n, vw)
+        else:
+            keys = np.zeros((0, self.n_words), dtype=np.uint64)
+            vals = np.zeros((0, vw), dtype=np.uint64)
+        lib.kmi_results_free(C.byref(r))
+        return keys, vals
+
+    def count(self, q):
+        keys, vals = self._query(lib.kmi_index_count_host, q)
+        return keys, vals[:, 0]
+
+
 def synth_fastq(seed, genome_len, n_reads, read_len=150, first_read=0, threads=None):
     """SURVEY.md 8(d) synthetic FASTQ as a numpy uint8 array (host)."""
     nbytes = lib.kmi_synth_fastq_bytes(n_reads, read_len)

@@ -48,11 +48,11 @@ constexpr int kLoadBatch = 8;                // independent key loads kept in fl
 __host__ __device__ inline uint32_t fine_of(uint32_t h) { return h >> kSlotBits; }
 __host__ __device__ inline uint32_t coarse_of(uint32_t h) { return h >> (32 - kCoarseBits); }
 
-template <int NW> struct PartCfg {
-  static constexpr int TILE = 8192 / NW;                 // keys per LDS tile (64 KB of key words)
-  static constexpr int PER_THREAD = TILE / kPartThreads; // 8, 4, 2, 2
+// LDS tile of the partition kernels by record width RW (key words + value words): 64 KB of records
+template <int RW> struct PartCfg {
+  static constexpr int TILE = (RW == 1) ? 8192 : (RW == 2 ? 4096 : (RW <= 4 ? 2048 : 1024));   // records per tile
+  static constexpr int PER_THREAD = TILE / kPartThreads;                                         // 8, 4, 2, 1
 };
-template <> struct PartCfg<3> { static constexpr int TILE = 2048; static constexpr int PER_THREAD = 2; };
 
 enum BucketMode { BUCKET_COARSE = 0, BUCKET_SUB = 1, BUCKET_RANK = 2 };
 
@@ -87,7 +87,7 @@ __host__ __device__ inline uint64_t part_chunk(uint64_t n, uint32_t groups, uint
 // ---------------------------------------------------------------------------
 // K1: histograms
 // ---------------------------------------------------------------------------
-template <int NW, int BITS>
+template <int NW, int BITS, int VW = 0>
 __global__ __launch_bounds__(kPartThreads) void hist_fine_kernel(const uint64_t *__restrict__ keys, uint64_t n, KShape shape,
                                                                 uint32_t strand, bool transform,
                                                                 uint32_t *__restrict__ fine_hist,     // [kFineParts][kNumFine] global
@@ -95,7 +95,7 @@ __global__ __launch_bounds__(kPartThreads) void hist_fine_kernel(const uint64_t 
   __shared__ uint32_t s_hist[kNumFine];
   for (int i = threadIdx.x; i < kNumFine; i += kPartThreads) s_hist[i] = 0;
   lds_barrier();
-  const uint64_t chunk = part_chunk(n, gridDim.x, PartCfg<NW>::TILE);
+  const uint64_t chunk = part_chunk(n, gridDim.x, PartCfg<NW + VW>::TILE);
   const uint64_t b = (uint64_t)blockIdx.x * chunk;
   const uint64_t e = (b + chunk < n) ? b + chunk : n;
   constexpr int U = (NW == 1) ? kLoadBatch : (NW == 2 ? 4 : 2);
@@ -108,7 +108,7 @@ __global__ __launch_bounds__(kPartThreads) void hist_fine_kernel(const uint64_t 
       ok[u] = i < e;
       if (ok[u]) {
 #pragma unroll
-        for (int w = 0; w < NW; ++w) raw[u][w] = keys[i * NW + w];
+        for (int w = 0; w < NW; ++w) raw[u][w] = keys[i * (NW + VW) + w];
       }
     }
 #pragma unroll
@@ -234,40 +234,47 @@ __global__ __launch_bounds__(1024) void rank_offsets_kernel(const uint32_t *__re
 // (S4) contiguous copy-out. Four barriers per tile; the running output cursor of bucket b lives
 // in a register of thread b; the next tile's keys are already in flight during S1-S4.
 // ---------------------------------------------------------------------------
-template <int NW, int BITS>
+template <int NW, int BITS, int VW = 0>
 __device__ __forceinline__ void scatter_range(const uint64_t *__restrict__ in, uint64_t begin, uint64_t end, uint64_t *__restrict__ out,
                                               const KShape &shape, uint32_t strand, bool transform, const BucketFn &fn,
                                               uint64_t cursor /* of bucket threadIdx.x, threads < 256 */,
                                               uint64_t *s_stage, uint8_t *s_bkt, uint32_t *s_cnt, uint32_t *s_lofs,
                                               uint64_t *s_gbase, uint32_t *s_part) {
-  constexpr int TILE = PartCfg<NW>::TILE;
-  constexpr int PT = PartCfg<NW>::PER_THREAD;
+  constexpr int RW = NW + VW;   // record = key words followed by value words
+  constexpr int TILE = PartCfg<RW>::TILE;
+  constexpr int PT = PartCfg<RW>::PER_THREAD;
   if (threadIdx.x < kNumCoarse) s_cnt[threadIdx.x] = 0;
   lds_barrier();
-  uint64_t raw[PT][NW];
+  uint64_t raw[PT][RW];
   auto load_tile = [&](uint64_t t0) {   // unconditional (clamped) loads: nothing forces an early wait
 #pragma unroll
     for (int j = 0; j < PT; ++j) {
       uint64_t i = t0 + (uint64_t)j * kPartThreads + threadIdx.x;
       i = (i < end) ? i : end - 1;
 #pragma unroll
-      for (int w = 0; w < NW; ++w) raw[j][w] = in[i * NW + w];
+      for (int w = 0; w < RW; ++w) raw[j][w] = in[i * RW + w];
     }
   };
   load_tile(begin);
   for (uint64_t t0 = begin; t0 < end; t0 += TILE) {
     const uint32_t nt = (uint32_t)((end - t0 < (uint64_t)TILE) ? (end - t0) : (uint64_t)TILE);
     uint64_t k[PT][NW];
+    uint64_t v[PT][VW ? VW : 1];
     uint32_t bk[PT], rk[PT];
 #pragma unroll
     for (int j = 0; j < PT; ++j) {
       const uint32_t li = j * kPartThreads + threadIdx.x;
       bk[j] = 0xffffffffu;
       if (li < nt) {
-        if (transform) strand_key<NW, BITS>(raw[j], k[j], shape, strand);
+        uint64_t kr[NW];
+#pragma unroll
+        for (int w = 0; w < NW; ++w) kr[w] = raw[j][w];
+#pragma unroll
+        for (int w = 0; w < VW; ++w) v[j][w] = raw[j][NW + w];
+        if (transform) strand_key<NW, BITS>(kr, k[j], shape, strand);
         else {
 #pragma unroll
-          for (int w = 0; w < NW; ++w) k[j][w] = raw[j][w];
+          for (int w = 0; w < NW; ++w) k[j][w] = kr[w];
         }
         bk[j] = bucket_of<NW>(k[j], fn);
         rk[j] = atomicAdd(&s_cnt[bk[j]], 1u);
@@ -298,7 +305,9 @@ __device__ __forceinline__ void scatter_range(const uint64_t *__restrict__ in, u
       if (bk[j] != 0xffffffffu) {
         const uint32_t pos = s_lofs[bk[j]] + rk[j];
 #pragma unroll
-        for (int w = 0; w < NW; ++w) s_stage[(uint64_t)pos * NW + w] = k[j][w];
+        for (int w = 0; w < NW; ++w) s_stage[(uint64_t)pos * RW + w] = k[j][w];
+#pragma unroll
+        for (int w = 0; w < VW; ++w) s_stage[(uint64_t)pos * RW + NW + w] = v[j][w];
         s_bkt[pos] = (uint8_t)bk[j];
       }
     }
@@ -306,46 +315,46 @@ __device__ __forceinline__ void scatter_range(const uint64_t *__restrict__ in, u
     for (uint32_t s = threadIdx.x; s < nt; s += kPartThreads) {
       const uint64_t dst = s_gbase[s_bkt[s]] + s;
 #pragma unroll
-      for (int w = 0; w < NW; ++w) out[dst * NW + w] = s_stage[(uint64_t)s * NW + w];
+      for (int w = 0; w < RW; ++w) out[dst * RW + w] = s_stage[(uint64_t)s * RW + w];
     }
     // no barrier here: the next tile's S0 only touches s_cnt (reset in S1 above) and its S2/S3
     // writes are separated from this copy-out by the two barriers in between
   }
 }
 
-#define KMI_SCATTER_LDS(NW)                                        \
-  __shared__ uint64_t s_stage[PartCfg<NW>::TILE * NW];             \
-  __shared__ uint8_t s_bkt[PartCfg<NW>::TILE];                     \
+#define KMI_SCATTER_LDS(RW)                                        \
+  __shared__ uint64_t s_stage[PartCfg<RW>::TILE * (RW)];           \
+  __shared__ uint8_t s_bkt[PartCfg<RW>::TILE];                     \
   __shared__ uint32_t s_cnt[kNumCoarse];                           \
   __shared__ uint32_t s_lofs[kNumCoarse];                          \
   __shared__ uint64_t s_gbase[kNumCoarse];                         \
   __shared__ uint32_t s_part[kNumCoarse / kWave];
 
 // K2: workgroup w scatters its chunk of the input by coarse bucket (or by rank)
-template <int NW, int BITS>
+template <int NW, int BITS, int VW = 0>
 __global__ __launch_bounds__(kPartThreads) void scatter_chunks_kernel(const uint64_t *__restrict__ in, uint64_t n, uint64_t *__restrict__ out,
                                                                      KShape shape, uint32_t strand, bool transform, BucketFn fn,
                                                                      const uint64_t *__restrict__ wg_off) {
-  KMI_SCATTER_LDS(NW)
+  KMI_SCATTER_LDS(NW + VW)
   const uint64_t cursor = (threadIdx.x < kNumCoarse) ? wg_off[(uint64_t)blockIdx.x * kNumCoarse + threadIdx.x] : 0ull;
-  const uint64_t chunk = part_chunk(n, gridDim.x, PartCfg<NW>::TILE);
+  const uint64_t chunk = part_chunk(n, gridDim.x, PartCfg<NW + VW>::TILE);
   const uint64_t b = (uint64_t)blockIdx.x * chunk;
   const uint64_t e = (b + chunk < n) ? b + chunk : n;
-  if (b < e) scatter_range<NW, BITS>(in, b, e, out, shape, strand, transform, fn, cursor, s_stage, s_bkt, s_cnt, s_lofs, s_gbase, s_part);
+  if (b < e) scatter_range<NW, BITS, VW>(in, b, e, out, shape, strand, transform, fn, cursor, s_stage, s_bkt, s_cnt, s_lofs, s_gbase, s_part);
 }
 
 // P2: workgroup (c, h) splits the part of coarse bucket c that K2 groups [h*256,(h+1)*256) wrote
-template <int NW, int BITS>
+template <int NW, int BITS, int VW = 0>
 __global__ __launch_bounds__(kPartThreads) void scatter_fine_kernel(const uint64_t *__restrict__ in, uint64_t *__restrict__ out, KShape shape,
                                                                    const uint64_t *__restrict__ fine_off, const uint64_t *__restrict__ part_off,
                                                                    const uint64_t *__restrict__ wg_off) {
-  KMI_SCATTER_LDS(NW)
+  KMI_SCATTER_LDS(NW + VW)
   const uint32_t c = blockIdx.x / kFineParts, h = blockIdx.x % kFineParts;
   const uint64_t cursor = (threadIdx.x < kSubPerCoarse) ? part_off[(uint64_t)h * kNumFine + c * kSubPerCoarse + threadIdx.x] : 0ull;
   const uint64_t b = wg_off[(uint64_t)(h * kGroupsPerPart) * kNumCoarse + c];
   const uint64_t e = (h + 1 < (uint32_t)kFineParts) ? wg_off[(uint64_t)((h + 1) * kGroupsPerPart) * kNumCoarse + c] : fine_off[(c + 1) * kSubPerCoarse];
   BucketFn fn; fn.mode = BUCKET_SUB; fn.shape = shape; fn.dist_hash = 0; fn.farm_ndebug = false; fn.nranks = 1;
-  if (b < e) scatter_range<NW, BITS>(in, b, e, out, shape, 0u, false, fn, cursor, s_stage, s_bkt, s_cnt, s_lofs, s_gbase, s_part);
+  if (b < e) scatter_range<NW, BITS, VW>(in, b, e, out, shape, 0u, false, fn, cursor, s_stage, s_bkt, s_cnt, s_lofs, s_gbase, s_part);
 }
 
 
@@ -837,25 +846,45 @@ __global__ __launch_bounds__(256) void bucket_compact_kernel(const uint64_t *__r
 // ---------------------------------------------------------------------------
 enum QueryMode { Q_COUNT = 0, Q_FIND = 1, Q_ERASE = 2 };
 
-template <int NW>
+// VW = 0: counting map (values are u32 counts in idx_vals32); VW > 0: multimap (every entry carries
+// VW 64-bit value words in idx_mvals, a key may occur many times). Output value stride OW = max(1, VW).
+template <int NW, int VW>
 __global__ __launch_bounds__((TabCfg<NW>::NT)) void bucket_query_kernel(int mode, const uint64_t *__restrict__ q_keys, const uint64_t *__restrict__ q_off,
-                                                                       const uint64_t *__restrict__ idx_keys, const uint32_t *__restrict__ idx_vals,
+                                                                       const uint64_t *__restrict__ idx_keys, const uint32_t *__restrict__ idx_vals32,
+                                                                       const uint64_t *__restrict__ idx_mvals,
                                                                        const uint64_t *__restrict__ idx_off, uint64_t *__restrict__ tmp_keys,
                                                                        uint64_t *__restrict__ tmp_vals64, uint32_t *__restrict__ tmp_vals32,
                                                                        uint32_t *__restrict__ out_cnt, uint32_t *__restrict__ flags) {
   KMI_TABLE_LDS(NW)
   constexpr int CAP = TabCfg<NW>::CAP;
+  constexpr int OW = VW ? VW : 1;
   const uint32_t b = blockIdx.x;
   const uint64_t qb = q_off[b], qe = q_off[b + 1];
   const uint64_t ib = idx_off ? idx_off[b] : 0ull, ie = idx_off ? idx_off[b + 1] : 0ull;
-  // output slot base: count/find results are bounded by the bucket's queries, erase survivors by its entries
-  const uint64_t tmp0 = (mode == Q_ERASE) ? ib : qb;
+  // output slot base: count results are bounded by the bucket's queries; erase survivors and multimap
+  // find hits by the bucket's entries
+  const bool by_entries = (mode == Q_ERASE) || (VW > 0 && mode == Q_FIND);
+  const uint64_t tmp0 = by_entries ? ib : qb;
   uint32_t *s_out = &s_ctl[4];
+  auto emit_entry = [&](uint32_t pos, const uint64_t (&k)[NW], uint64_t i) {
+#pragma unroll
+    for (int w = 0; w < NW; ++w) tmp_keys[(tmp0 + pos) * NW + w] = k[w];
+    if constexpr (VW == 0) {
+      if (mode == Q_ERASE) tmp_vals32[tmp0 + pos] = idx_vals32[i]; else tmp_vals64[tmp0 + pos] = idx_vals32[i];
+    } else {
+#pragma unroll
+      for (int w = 0; w < VW; ++w) tmp_vals64[(tmp0 + pos) * VW + w] = idx_mvals[i * VW + w];
+    }
+  };
   if (qb == qe) {
     if (mode == Q_ERASE) {
       // nothing to erase here: all entries survive
-      for (uint64_t i = threadIdx.x; i < (ie - ib) * NW; i += blockDim.x) tmp_keys[ib * NW + i] = idx_keys[ib * NW + i];
-      for (uint64_t i = threadIdx.x; i < (ie - ib); i += blockDim.x) tmp_vals32[ib + i] = idx_vals[ib + i];
+      for (uint64_t i = ib + threadIdx.x; i < ie; i += blockDim.x) {
+        uint64_t k[NW];
+#pragma unroll
+        for (int w = 0; w < NW; ++w) k[w] = idx_keys[i * NW + w];
+        emit_entry((uint32_t)(i - ib), k, i);
+      }
       if (threadIdx.x == 0) out_cnt[b] = (uint32_t)(ie - ib);
     } else if (threadIdx.x == 0) out_cnt[b] = 0;
     return;
@@ -884,21 +913,14 @@ __global__ __launch_bounds__((TabCfg<NW>::NT)) void bucket_query_kernel(int mode
         const int s = table_find<NW>(tab, k, h);
         const bool hit = (s >= 0) || (s == -2);
         if (mode == Q_COUNT) {
-          if (s >= 0) tab.vals[s] = 1u; else if (s == -2) *tab.special = 1u;
+          // db.count(k): number of entries with this key (0/1 for a map, multiplicity for a multimap)
+          if (s >= 0) atomicAdd(&tab.vals[s], 1u); else if (s == -2) atomicAdd(tab.special, 1u);
         } else if (mode == Q_FIND) {
           const uint32_t pos = wave_alloc(s_out, hit);
-          if (hit) {
-#pragma unroll
-            for (int w = 0; w < NW; ++w) tmp_keys[(tmp0 + pos) * NW + w] = k[w];
-            tmp_vals64[tmp0 + pos] = idx_vals[i];
-          }
+          if (hit) emit_entry(pos, k, i);
         } else {
           const uint32_t pos = wave_alloc(s_out, !hit);
-          if (!hit) {
-#pragma unroll
-            for (int w = 0; w < NW; ++w) tmp_keys[(tmp0 + pos) * NW + w] = k[w];
-            tmp_vals32[tmp0 + pos] = idx_vals[i];
-          }
+          if (!hit) emit_entry(pos, k, i);
         }
       }
       lds_barrier();
@@ -909,13 +931,13 @@ __global__ __launch_bounds__((TabCfg<NW>::NT)) void bucket_query_kernel(int mode
           if (used) {
 #pragma unroll
             for (int w = 0; w < NW; ++w) tmp_keys[(tmp0 + pos) * NW + w] = tab.keys[(uint64_t)s * NW + w];
-            tmp_vals64[tmp0 + pos] = tab.vals[s];
+            tmp_vals64[(tmp0 + pos) * OW] = tab.vals[s];
           }
         }
         if (NW == 1 && threadIdx.x == 0 && *tab.special_set) {
           const uint32_t pos = atomicAdd(s_out, 1u);
           tmp_keys[(tmp0 + pos) * NW] = kEmptyKey;
-          tmp_vals64[tmp0 + pos] = *tab.special;
+          tmp_vals64[(tmp0 + pos) * OW] = *tab.special;
         }
       }
       lds_barrier();
@@ -926,6 +948,43 @@ __global__ __launch_bounds__((TabCfg<NW>::NT)) void bucket_query_kernel(int mode
     lds_barrier();
   }
   if (threadIdx.x == 0) out_cnt[b] = *s_out;
+}
+
+// multimap insert: bucket b of the new index = old entries of b followed by the new records of b
+template <int NW, int VW>
+__global__ __launch_bounds__(256) void bucket_concat_kernel(const uint64_t *__restrict__ recs, const uint64_t *__restrict__ new_off,
+                                                           const uint64_t *__restrict__ old_keys, const uint64_t *__restrict__ old_vals,
+                                                           const uint64_t *__restrict__ old_off, uint64_t *__restrict__ dst_off,
+                                                           uint64_t *__restrict__ keys, uint64_t *__restrict__ vals) {
+  constexpr int RW = NW + VW;
+  const uint32_t b = blockIdx.x;
+  const uint64_t nb = new_off[b], nn = new_off[b + 1] - nb;
+  const uint64_t ob = old_off ? old_off[b] : 0ull, on = old_off ? old_off[b + 1] - ob : 0ull;
+  const uint64_t d0 = nb + ob;
+  if (threadIdx.x == 0) {
+    dst_off[b] = d0;
+    if (b == kNumFine - 1) dst_off[kNumFine] = d0 + nn + on;
+  }
+  for (uint64_t i = threadIdx.x; i < on * NW; i += blockDim.x) keys[d0 * NW + i] = old_keys[ob * NW + i];
+  for (uint64_t i = threadIdx.x; i < on * VW; i += blockDim.x) vals[d0 * VW + i] = old_vals[ob * VW + i];
+  const uint64_t d1 = d0 + on;
+  for (uint64_t i = threadIdx.x; i < nn; i += blockDim.x) {
+#pragma unroll
+    for (int w = 0; w < NW; ++w) keys[(d1 + i) * NW + w] = recs[(nb + i) * RW + w];
+#pragma unroll
+    for (int w = 0; w < VW; ++w) vals[(d1 + i) * VW + w] = recs[(nb + i) * RW + NW + w];
+  }
+}
+
+// compaction copy with VW value words per entry
+template <int NW, int VW>
+__global__ __launch_bounds__(256) void bucket_compact_words_kernel(const uint64_t *__restrict__ tmp_keys, const uint64_t *__restrict__ tmp_vals,
+                                                                  const uint64_t *__restrict__ src_off, const uint64_t *__restrict__ dst_off,
+                                                                  uint64_t *__restrict__ keys, uint64_t *__restrict__ vals) {
+  const uint32_t b = blockIdx.x;
+  const uint64_t d0 = dst_off[b], n = dst_off[b + 1] - d0, s0 = src_off[b];
+  for (uint64_t i = threadIdx.x; i < n * NW; i += blockDim.x) keys[d0 * NW + i] = tmp_keys[s0 * NW + i];
+  for (uint64_t i = threadIdx.x; i < n * VW; i += blockDim.x) vals[d0 * VW + i] = tmp_vals[s0 * VW + i];
 }
 
 }  // namespace kmi
@@ -940,7 +999,9 @@ struct kmi_index {
   kmi_config cfg{};
   KShape shape{};
   uint64_t *keys = nullptr;       // [n_entries * n_words]
-  uint32_t *vals = nullptr;       // [n_entries]
+  uint32_t *vals = nullptr;       // [n_entries] counts (counting map)
+  uint64_t *mvals = nullptr;      // [n_entries * val_words] values (multimap)
+  uint32_t val_words = 0;         // 0: counting map; 1: position id; 2: position id + quality
   uint64_t *bucket_off = nullptr; // [kNumFine + 1]
   uint64_t n_entries = 0;
   bool has_data = false;
@@ -979,15 +1040,15 @@ static kmi_status get_part_ws(kmi_ctx *ctx, size_t n, int nw, WsSlot slot_a, WsS
 }
 
 // K1 + offsets + K2 + P2 on `n` keys; result in slot `slot_b`, scratch in `slot_a`
-template <int NW, int BITS>
+template <int NW, int BITS, int VW = 0>
 static kmi_status partition_impl(kmi_ctx *ctx, const kmi_config *cfg, KShape shape, const uint64_t *keys_dev, size_t n, bool transform,
                                  WsSlot slot_a, WsSlot slot_b, Partitioned *out) {
   PartWs w;
-  KMI_TRY(get_part_ws(ctx, n, NW, slot_a, slot_b, &w));
+  KMI_TRY(get_part_ws(ctx, n, NW + VW, slot_a, slot_b, &w));
   KMI_HIP(ctx, hipMemsetAsync(w.fine_hist, 0, sizeof(uint32_t) * kNumFine * kFineParts, ctx->stream));
   {
     ProfScope ps(ctx, "hist_fine", n);
-    hipLaunchKernelGGL((hist_fine_kernel<NW, BITS>), dim3(kPartGroups), dim3(kPartThreads), 0, ctx->stream, keys_dev, (uint64_t)n, shape,
+    hipLaunchKernelGGL((hist_fine_kernel<NW, BITS, VW>), dim3(kPartGroups), dim3(kPartThreads), 0, ctx->stream, keys_dev, (uint64_t)n, shape,
                        cfg->strand, transform, w.fine_hist, w.wg_hist);
   }
   {
@@ -998,12 +1059,12 @@ static kmi_status partition_impl(kmi_ctx *ctx, const kmi_config *cfg, KShape sha
   BucketFn fn; fn.mode = BUCKET_COARSE; fn.shape = shape; fn.dist_hash = 0; fn.farm_ndebug = false; fn.nranks = 1;
   {
     ProfScope ps(ctx, "scatter_coarse", n);
-    hipLaunchKernelGGL((scatter_chunks_kernel<NW, BITS>), dim3(kPartGroups), dim3(kPartThreads), 0, ctx->stream, keys_dev, (uint64_t)n, w.buf_a,
+    hipLaunchKernelGGL((scatter_chunks_kernel<NW, BITS, VW>), dim3(kPartGroups), dim3(kPartThreads), 0, ctx->stream, keys_dev, (uint64_t)n, w.buf_a,
                        shape, cfg->strand, transform, fn, w.wg_off);
   }
   {
     ProfScope ps(ctx, "scatter_fine", n);
-    hipLaunchKernelGGL((scatter_fine_kernel<NW, BITS>), dim3(kNumCoarse * kFineParts), dim3(kPartThreads), 0, ctx->stream, w.buf_a, w.buf_b, shape,
+    hipLaunchKernelGGL((scatter_fine_kernel<NW, BITS, VW>), dim3(kNumCoarse * kFineParts), dim3(kPartThreads), 0, ctx->stream, w.buf_a, w.buf_b, shape,
                        (const uint64_t *)w.fine_off, (const uint64_t *)w.part_off, (const uint64_t *)w.wg_off);
   }
   KMI_HIP(ctx, hipGetLastError());
@@ -1135,32 +1196,107 @@ static kmi_status index_insert(kmi_index *idx, const uint64_t *keys_dev, size_t 
   KMI_DISPATCH(idx->shape, insert_impl, idx, keys_dev, n, transform);
 }
 
-// queries: results compacted into out_keys_dev / out_vals_dev (u64), *n_out results
-template <int NW, int BITS>
-static kmi_status query_impl(kmi_index *idx, int mode, const uint64_t *q_dev, size_t nq, uint64_t *out_keys_dev, uint64_t *out_vals_dev,
-                             uint64_t *n_out) {
+static void free_index_arrays(kmi_index *idx) {
+  if (idx->keys) (void)hipFree(idx->keys);
+  if (idx->vals) (void)hipFree(idx->vals);
+  if (idx->mvals) (void)hipFree(idx->mvals);
+  if (idx->bucket_off) (void)hipFree(idx->bucket_off);
+  idx->keys = nullptr; idx->vals = nullptr; idx->mvals = nullptr; idx->bucket_off = nullptr;
+}
+
+static kmi_status alloc_mm_arrays(kmi_ctx *ctx, uint64_t total, int nw, int vw, uint64_t **nk, uint64_t **nv, uint64_t **noff) {
+  *nk = *nv = *noff = nullptr;
+  hipError_t e0 = hipMalloc((void **)noff, sizeof(uint64_t) * (kNumFine + 1));
+  hipError_t e1 = hipMalloc((void **)nk, (total ? total : 1) * nw * sizeof(uint64_t));
+  hipError_t e2 = hipMalloc((void **)nv, (total ? total : 1) * vw * sizeof(uint64_t));
+  if (e0 != hipSuccess || e1 != hipSuccess || e2 != hipSuccess) {
+    if (*nk) (void)hipFree(*nk);
+    if (*nv) (void)hipFree(*nv);
+    if (*noff) (void)hipFree(*noff);
+    return set_err(ctx, KMI_ERR_NOMEM, "hipMalloc failed for the index arrays");
+  }
+  return KMI_OK;
+}
+
+// unordered_multimap::insert (distributed_unordered_map.hpp:1466-1515): every (key, value) is kept
+template <int NW, int BITS, int VW>
+static kmi_status mm_insert_vw(kmi_index *idx, const uint64_t *recs_dev, size_t n, bool transform) {
   kmi_ctx *ctx = idx->ctx;
+  if (n == 0) return KMI_OK;
+  Partitioned part;
+  KMI_TRY((partition_impl<NW, BITS, VW>(ctx, &idx->cfg, idx->shape, recs_dev, n, transform, WS_KEYS_A, WS_KEYS_B, &part)));
+  const uint64_t total = n + idx->n_entries;
+  uint64_t *nk, *nv, *noff;
+  KMI_TRY(alloc_mm_arrays(ctx, total, NW, VW, &nk, &nv, &noff));
+  {
+    ProfScope ps(ctx, "bucket_concat", n);
+    hipLaunchKernelGGL((bucket_concat_kernel<NW, VW>), dim3(kNumFine), dim3(256), 0, ctx->stream, (const uint64_t *)part.keys,
+                       (const uint64_t *)part.fine_off, (const uint64_t *)idx->keys, (const uint64_t *)idx->mvals,
+                       (const uint64_t *)(idx->has_data ? idx->bucket_off : nullptr), noff, nk, nv);
+  }
+  KMI_HIP(ctx, hipGetLastError());
+  KMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  free_index_arrays(idx);
+  idx->keys = nk; idx->mvals = nv; idx->bucket_off = noff; idx->n_entries = total; idx->has_data = true;
+  return KMI_OK;
+}
+
+template <int NW, int BITS>
+static kmi_status mm_insert_impl(kmi_index *idx, const uint64_t *recs_dev, size_t n, bool transform) {
+  if (idx->val_words == 1) return mm_insert_vw<NW, BITS, 1>(idx, recs_dev, n, transform);
+  if (idx->val_words == 2) return mm_insert_vw<NW, BITS, 2>(idx, recs_dev, n, transform);
+  return set_err(idx->ctx, KMI_ERR_INVALID, "not a multimap index");
+}
+
+static kmi_status index_insert_records(kmi_index *idx, const uint64_t *recs_dev, size_t n, bool transform) {
+  KMI_DISPATCH(idx->shape, mm_insert_impl, idx, recs_dev, n, transform);
+}
+
+// queries: results compacted into out_keys_dev / out_vals_dev (max(1, val_words) u64 per result)
+template <int NW, int BITS, int VW>
+static kmi_status query_vw(kmi_index *idx, int mode, const uint64_t *q_dev, size_t nq, uint64_t *out_keys_dev, uint64_t *out_vals_dev,
+                           uint64_t out_capacity, uint64_t *n_out) {
+  kmi_ctx *ctx = idx->ctx;
+  constexpr int OW = VW ? VW : 1;
   if (n_out) *n_out = 0;
   if (nq == 0) return KMI_OK;
+  if (mode == Q_ERASE && !idx->has_data) return KMI_OK;
   Partitioned part;
   KMI_TRY((partition_impl<NW, BITS>(ctx, &idx->cfg, idx->shape, q_dev, nq, true, WS_QUERY_A, WS_QUERY_B, &part)));
   void *p;
-  const uint64_t cap = (mode == Q_ERASE) ? std::max<uint64_t>(idx->n_entries, 1) : nq;
+  const bool by_entries = (mode == Q_ERASE) || (VW > 0 && mode == Q_FIND);
+  const uint64_t cap = by_entries ? std::max<uint64_t>(idx->n_entries, 1) : nq;
   KMI_TRY(ws_get(ctx, WS_TMP_KEYS, cap * NW * sizeof(uint64_t), &p)); uint64_t *tmp_keys = (uint64_t *)p;
-  KMI_TRY(ws_get(ctx, WS_TMP_VALS, cap * sizeof(uint64_t), &p)); void *tmp_vals = p;
+  KMI_TRY(ws_get(ctx, WS_TMP_VALS, cap * OW * sizeof(uint64_t), &p)); void *tmp_vals = p;
   KMI_TRY(ws_get(ctx, WS_BUCKET_CNT, sizeof(uint32_t) * kNumFine, &p)); uint32_t *out_cnt = (uint32_t *)p;
   {
     ProfScope ps(ctx, mode == Q_COUNT ? "bucket_query_count" : (mode == Q_FIND ? "bucket_query_find" : "bucket_query_erase"), nq);
-    hipLaunchKernelGGL((bucket_query_kernel<NW>), dim3(kNumFine), dim3(TabCfg<NW>::NT), 0, ctx->stream, mode, (const uint64_t *)part.keys,
-                       (const uint64_t *)part.fine_off, (const uint64_t *)idx->keys, (const uint32_t *)idx->vals,
+    hipLaunchKernelGGL((bucket_query_kernel<NW, VW>), dim3(kNumFine), dim3(TabCfg<NW>::NT), 0, ctx->stream, mode, (const uint64_t *)part.keys,
+                       (const uint64_t *)part.fine_off, (const uint64_t *)idx->keys, (const uint32_t *)idx->vals, (const uint64_t *)idx->mvals,
                        (const uint64_t *)(idx->has_data ? idx->bucket_off : nullptr), tmp_keys, (uint64_t *)tmp_vals, (uint32_t *)tmp_vals,
                        out_cnt, ctx->d_flags);
   }
   KMI_HIP(ctx, hipGetLastError());
+  const uint64_t *src_off = (by_entries && idx->has_data) ? idx->bucket_off : part.fine_off;
   if (mode == Q_ERASE) {
     const uint64_t before = idx->n_entries;
-    if (!idx->has_data) return KMI_OK;
-    KMI_TRY((adopt_tmp<NW>(idx, tmp_keys, (const uint32_t *)tmp_vals, idx->bucket_off, nullptr, out_cnt)));
+    if (VW == 0) {
+      KMI_TRY((adopt_tmp<NW>(idx, tmp_keys, (const uint32_t *)tmp_vals, idx->bucket_off, nullptr, out_cnt)));
+    } else {
+      KMI_TRY(ws_get(ctx, WS_BUCKET_OFF, sizeof(uint64_t) * (kNumFine + 1), &p)); uint64_t *res_off = (uint64_t *)p;
+      hipLaunchKernelGGL(bucket_offsets_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const uint32_t *)out_cnt, res_off, ctx->d_totals, 4);
+      uint64_t total = 0;
+      KMI_TRY(read_total(ctx, 4, &total));
+      uint64_t *nk, *nv, *noff;
+      KMI_TRY(alloc_mm_arrays(ctx, total, NW, OW, &nk, &nv, &noff));
+      KMI_HIP(ctx, hipMemcpyAsync(noff, res_off, sizeof(uint64_t) * (kNumFine + 1), hipMemcpyDeviceToDevice, ctx->stream));
+      hipLaunchKernelGGL((bucket_compact_words_kernel<NW, OW>), dim3(kNumFine), dim3(256), 0, ctx->stream, (const uint64_t *)tmp_keys,
+                         (const uint64_t *)tmp_vals, (const uint64_t *)idx->bucket_off, (const uint64_t *)res_off, nk, nv);
+      KMI_HIP(ctx, hipGetLastError());
+      KMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      free_index_arrays(idx);
+      idx->keys = nk; idx->mvals = nv; idx->bucket_off = noff; idx->n_entries = total;
+    }
     if (n_out) *n_out = before - idx->n_entries;
     return KMI_OK;
   }
@@ -1169,22 +1305,36 @@ static kmi_status query_impl(kmi_index *idx, int mode, const uint64_t *q_dev, si
     ProfScope ps(ctx, "bucket_offsets", kNumFine);
     hipLaunchKernelGGL(bucket_offsets_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const uint32_t *)out_cnt, res_off, ctx->d_totals, 5);
   }
-  {
-    ProfScope ps(ctx, "bucket_compact", nq);
-    hipLaunchKernelGGL((bucket_compact_kernel<NW, uint64_t>), dim3(kNumFine), dim3(256), 0, ctx->stream, (const uint64_t *)tmp_keys,
-                       (const uint64_t *)tmp_vals, (const uint64_t *)part.fine_off, (const uint64_t *)nullptr, (const uint64_t *)res_off,
-                       out_keys_dev, out_vals_dev);
-  }
-  KMI_HIP(ctx, hipGetLastError());
   uint64_t total = 0;
   KMI_TRY(read_total(ctx, 5, &total));
   if (n_out) *n_out = total;
+  if (total > out_capacity) return set_err(ctx, KMI_ERR_OVERFLOW, "query: result capacity too small");
+  {
+    ProfScope ps(ctx, "bucket_compact", total);
+    hipLaunchKernelGGL((bucket_compact_words_kernel<NW, OW>), dim3(kNumFine), dim3(256), 0, ctx->stream, (const uint64_t *)tmp_keys,
+                       (const uint64_t *)tmp_vals, src_off, (const uint64_t *)res_off, out_keys_dev, out_vals_dev);
+  }
+  KMI_HIP(ctx, hipGetLastError());
+  KMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return KMI_OK;
 }
 
+template <int NW, int BITS>
+static kmi_status query_impl(kmi_index *idx, int mode, const uint64_t *q_dev, size_t nq, uint64_t *out_keys_dev, uint64_t *out_vals_dev,
+                             uint64_t out_capacity, uint64_t *n_out) {
+  if (idx->val_words == 0) return query_vw<NW, BITS, 0>(idx, mode, q_dev, nq, out_keys_dev, out_vals_dev, out_capacity, n_out);
+  if (idx->val_words == 1) return query_vw<NW, BITS, 1>(idx, mode, q_dev, nq, out_keys_dev, out_vals_dev, out_capacity, n_out);
+  return query_vw<NW, BITS, 2>(idx, mode, q_dev, nq, out_keys_dev, out_vals_dev, out_capacity, n_out);
+}
+
 static kmi_status index_query(kmi_index *idx, int mode, const uint64_t *q_dev, size_t nq, uint64_t *out_keys_dev, uint64_t *out_vals_dev,
-                              uint64_t *n_out) {
-  KMI_DISPATCH(idx->shape, query_impl, idx, mode, q_dev, nq, out_keys_dev, out_vals_dev, n_out);
+                              uint64_t out_capacity, uint64_t *n_out) {
+  KMI_DISPATCH(idx->shape, query_impl, idx, mode, q_dev, nq, out_keys_dev, out_vals_dev, out_capacity, n_out);
+}
+
+// results of a multimap find are bounded by the entries, everything else by the queries
+static uint64_t query_result_bound(const kmi_index *idx, int mode, size_t nq) {
+  return (idx->val_words > 0 && mode == Q_FIND) ? idx->n_entries : (uint64_t)nq;
 }
 
 // imxx::distribute bucketing by destination rank
@@ -1235,9 +1385,9 @@ kmi_status kmi_index_create(kmi_ctx *ctx, const kmi_config *cfg, kmi_index **out
   if (!ctx || !out) return KMI_ERR_INVALID;
   KShape shape;
   if (!valid_config(cfg, &shape)) return set_err(ctx, KMI_ERR_INVALID, "bad kmi_config");
-  if (cfg->index_kind != KMI_INDEX_COUNT) return set_err(ctx, KMI_ERR_INVALID, "only the count index is implemented on the device yet");
   kmi_index *idx = new kmi_index();
   idx->ctx = ctx; idx->cfg = *cfg; idx->shape = shape;
+  idx->val_words = cfg->index_kind == KMI_INDEX_COUNT ? 0u : (cfg->index_kind == KMI_INDEX_POSITION ? 1u : 2u);
   *out = idx;
   return KMI_OK;
 }
@@ -1246,15 +1396,14 @@ kmi_status kmi_index_destroy(kmi_index *idx) {
   if (!idx) return KMI_OK;
   (void)hipSetDevice(idx->ctx->device);
   (void)hipStreamSynchronize(idx->ctx->stream);
-  if (idx->keys) (void)hipFree(idx->keys);
-  if (idx->vals) (void)hipFree(idx->vals);
-  if (idx->bucket_off) (void)hipFree(idx->bucket_off);
+  free_index_arrays(idx);
   delete idx;
   return KMI_OK;
 }
 
 kmi_status kmi_index_insert_dev(kmi_index *idx, const uint64_t *kmers_dev, size_t n) {
   if (!idx) return KMI_ERR_INVALID;
+  if (idx->val_words) return set_err(idx->ctx, KMI_ERR_INVALID, "a position index takes (k-mer, value) tuples: kmi_index_insert_tuples_*");
   KMI_HIP(idx->ctx, hipSetDevice(idx->ctx->device));
   return index_insert(idx, kmers_dev, n, true);
 }
@@ -1262,6 +1411,7 @@ kmi_status kmi_index_insert_dev(kmi_index *idx, const uint64_t *kmers_dev, size_
 kmi_status kmi_index_insert_host(kmi_index *idx, const uint64_t *kmers, size_t n) {
   if (!idx) return KMI_ERR_INVALID;
   kmi_ctx *ctx = idx->ctx;
+  if (idx->val_words) return set_err(ctx, KMI_ERR_INVALID, "a position index takes (k-mer, value) tuples: kmi_index_insert_tuples_*");
   if (n == 0) return KMI_OK;
   if (!kmers) return set_err(ctx, KMI_ERR_INVALID, "null buffer");
   KMI_HIP(ctx, hipSetDevice(ctx->device));
@@ -1272,13 +1422,38 @@ kmi_status kmi_index_insert_host(kmi_index *idx, const uint64_t *kmers, size_t n
   return index_insert(idx, (const uint64_t *)din, n, true);
 }
 
+// records (key, id) of a FASTQ partition for the position index
+__global__ __launch_bounds__(256) void interleave_records_kernel(const uint64_t *__restrict__ keys, const uint64_t *__restrict__ ids, uint64_t n,
+                                                                uint32_t nw, uint32_t vw, uint64_t *__restrict__ recs) {
+  const uint32_t rw = nw + vw;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    for (uint32_t w = 0; w < nw; ++w) recs[i * rw + w] = keys[i * nw + w];
+    recs[i * rw + nw] = ids[i];
+    for (uint32_t w = 1; w < vw; ++w) recs[i * rw + nw + w] = 0;
+  }
+}
+
 kmi_status kmi_index_build_dev(kmi_index *idx, const uint8_t *bytes_dev, size_t n_bytes, uint64_t file_offset) {
   if (!idx) return KMI_ERR_INVALID;
   kmi_ctx *ctx = idx->ctx;
-  (void)file_offset;   // only position indexes need it
   KMI_HIP(ctx, hipSetDevice(ctx->device));
   if (n_bytes == 0) return KMI_OK;
-  return index_build_fused(idx, bytes_dev, n_bytes);
+  if (idx->val_words == 0) return index_build_fused(idx, bytes_dev, n_bytes);
+  if (idx->val_words != 1) return set_err(ctx, KMI_ERR_INVALID, "build of a position+quality index is not implemented on the device yet");
+  // PositionIndex: KmerPositionTupleParser tuples (kmer, ShortSequenceKmerId) -> multimap insert
+  const uint32_t nw = idx->shape.n_words;
+  uint64_t nt = 0, ns = 0;
+  KMI_TRY(extract_count(ctx, &idx->cfg, bytes_dev, n_bytes, &nt, &ns));
+  if (nt == 0) return KMI_OK;
+  void *dk, *di, *dr;
+  KMI_TRY(ws_get(ctx, WS_OUTPUT, (size_t)nt * nw * sizeof(uint64_t), &dk));
+  KMI_TRY(ws_get(ctx, WS_OUTPUT2, (size_t)nt * sizeof(uint64_t), &di));
+  KMI_TRY(extract_run(ctx, &idx->cfg, bytes_dev, n_bytes, file_offset, (uint64_t *)dk, (uint64_t *)di, (size_t)nt, false, true, &nt, &ns));
+  KMI_TRY(ws_get(ctx, WS_INPUT2, (size_t)nt * (nw + 1) * sizeof(uint64_t), &dr));
+  hipLaunchKernelGGL(interleave_records_kernel, dim3(2048), dim3(256), 0, ctx->stream, (const uint64_t *)dk, (const uint64_t *)di, nt, nw, 1u,
+                     (uint64_t *)dr);
+  KMI_HIP(ctx, hipGetLastError());
+  return index_insert_records(idx, (const uint64_t *)dr, (size_t)nt, true);
 }
 
 kmi_status kmi_index_build_host(kmi_index *idx, const uint8_t *bytes, size_t n_bytes, uint64_t file_offset) {
@@ -1298,10 +1473,8 @@ kmi_status kmi_index_clear(kmi_index *idx) {
   kmi_ctx *ctx = idx->ctx;
   KMI_HIP(ctx, hipSetDevice(ctx->device));
   KMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  if (idx->keys) (void)hipFree(idx->keys);
-  if (idx->vals) (void)hipFree(idx->vals);
-  if (idx->bucket_off) (void)hipFree(idx->bucket_off);
-  idx->keys = nullptr; idx->vals = nullptr; idx->bucket_off = nullptr; idx->n_entries = 0; idx->has_data = false;
+  free_index_arrays(idx);
+  idx->n_entries = 0; idx->has_data = false;
   return KMI_OK;
 }
 
@@ -1315,6 +1488,7 @@ kmi_status kmi_index_export_host(kmi_index *idx, uint64_t *keys, uint32_t *count
   if (!idx || !n) return KMI_ERR_INVALID;
   kmi_ctx *ctx = idx->ctx;
   *n = 0;
+  if (idx->val_words) return set_err(ctx, KMI_ERR_INVALID, "a position index exports tuples: kmi_index_export_tuples_host");
   if (idx->n_entries == 0) return KMI_OK;
   if (capacity < idx->n_entries) return set_err(ctx, KMI_ERR_OVERFLOW, "export: capacity too small");
   KMI_HIP(ctx, hipSetDevice(ctx->device));
@@ -1339,24 +1513,25 @@ static kmi_status query_host(kmi_index *idx, int mode, const uint64_t *queries, 
   if (nq == 0) return KMI_OK;
   if (!queries) return set_err(ctx, KMI_ERR_INVALID, "null buffer");
   KMI_HIP(ctx, hipSetDevice(ctx->device));
-  const uint32_t nw = idx->shape.n_words;
+  const uint32_t nw = idx->shape.n_words, ow = idx->val_words ? idx->val_words : 1u;
+  const uint64_t bound = query_result_bound(idx, mode, nq);
   void *dq, *dk = nullptr, *dv = nullptr;
   KMI_TRY(ws_get(ctx, WS_INPUT, nq * nw * sizeof(uint64_t), &dq));
   KMI_HIP(ctx, hipMemcpyAsync(dq, queries, nq * nw * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
   if (mode != Q_ERASE) {
-    KMI_TRY(ws_get(ctx, WS_OUTPUT, nq * nw * sizeof(uint64_t), &dk));
-    KMI_TRY(ws_get(ctx, WS_OUTPUT2, nq * sizeof(uint64_t), &dv));
+    KMI_TRY(ws_get(ctx, WS_OUTPUT, (bound ? bound : 1) * nw * sizeof(uint64_t), &dk));
+    KMI_TRY(ws_get(ctx, WS_OUTPUT2, (bound ? bound : 1) * ow * sizeof(uint64_t), &dv));
   }
   uint64_t n = 0;
-  KMI_TRY(index_query(idx, mode, (const uint64_t *)dq, nq, (uint64_t *)dk, (uint64_t *)dv, &n));
+  KMI_TRY(index_query(idx, mode, (const uint64_t *)dq, nq, (uint64_t *)dk, (uint64_t *)dv, bound, &n));
   if (mode == Q_ERASE) { if (n_erased) *n_erased = n; return KMI_OK; }
   out->n = n;
   out->keys = (uint64_t *)malloc((n ? n : 1) * nw * sizeof(uint64_t));
-  out->values = (uint64_t *)malloc((n ? n : 1) * sizeof(uint64_t));
+  out->values = (uint64_t *)malloc((n ? n : 1) * ow * sizeof(uint64_t));
   if (!out->keys || !out->values) return set_err(ctx, KMI_ERR_NOMEM, "host malloc failed");
   if (n) {
     KMI_HIP(ctx, hipMemcpyAsync(out->keys, dk, n * nw * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
-    KMI_HIP(ctx, hipMemcpyAsync(out->values, dv, n * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+    KMI_HIP(ctx, hipMemcpyAsync(out->values, dv, n * ow * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
     KMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
   }
   return KMI_OK;
@@ -1377,13 +1552,60 @@ kmi_status kmi_index_count_dev(kmi_index *idx, const uint64_t *queries_dev, size
                                uint64_t *n_out) {
   if (!idx) return KMI_ERR_INVALID;
   KMI_HIP(idx->ctx, hipSetDevice(idx->ctx->device));
-  return index_query(idx, Q_COUNT, queries_dev, nq, out_keys_dev, out_values_dev, n_out);
+  return index_query(idx, Q_COUNT, queries_dev, nq, out_keys_dev, out_values_dev, nq, n_out);
 }
 kmi_status kmi_index_find_dev(kmi_index *idx, const uint64_t *queries_dev, size_t nq, uint64_t *out_keys_dev, uint64_t *out_values_dev,
                               uint64_t *n_out) {
   if (!idx) return KMI_ERR_INVALID;
   KMI_HIP(idx->ctx, hipSetDevice(idx->ctx->device));
-  return index_query(idx, Q_FIND, queries_dev, nq, out_keys_dev, out_values_dev, n_out);
+  return index_query(idx, Q_FIND, queries_dev, nq, out_keys_dev, out_values_dev, query_result_bound(idx, Q_FIND, nq), n_out);
+}
+
+// ---- multimap (PositionIndex / PositionQualityIndex) entry points
+kmi_status kmi_index_insert_tuples_dev(kmi_index *idx, const uint64_t *records_dev, size_t n) {
+  if (!idx) return KMI_ERR_INVALID;
+  if (idx->val_words == 0) return set_err(idx->ctx, KMI_ERR_INVALID, "insert_tuples needs a position index");
+  KMI_HIP(idx->ctx, hipSetDevice(idx->ctx->device));
+  return index_insert_records(idx, records_dev, n, true);
+}
+
+kmi_status kmi_index_insert_tuples_host(kmi_index *idx, const uint64_t *kmers, const uint64_t *values, size_t n) {
+  if (!idx) return KMI_ERR_INVALID;
+  kmi_ctx *ctx = idx->ctx;
+  if (idx->val_words == 0) return set_err(ctx, KMI_ERR_INVALID, "insert_tuples needs a position index");
+  if (n == 0) return KMI_OK;
+  if (!kmers || !values) return set_err(ctx, KMI_ERR_INVALID, "null buffer");
+  KMI_HIP(ctx, hipSetDevice(ctx->device));
+  const uint32_t nw = idx->shape.n_words, vw = idx->val_words, rw = nw + vw;
+  // interleave into records (key words, value words) -- the layout of std::pair<Kmer, value>
+  uint64_t *rec = (uint64_t *)malloc(n * rw * sizeof(uint64_t));
+  if (!rec) return set_err(ctx, KMI_ERR_NOMEM, "host malloc failed");
+  for (size_t i = 0; i < n; ++i) {
+    memcpy(rec + i * rw, kmers + i * nw, nw * sizeof(uint64_t));
+    memcpy(rec + i * rw + nw, values + i * vw, vw * sizeof(uint64_t));
+  }
+  void *din;
+  kmi_status st = ws_get(ctx, WS_INPUT, n * rw * sizeof(uint64_t), &din);
+  if (st == KMI_OK && hipMemcpy(din, rec, n * rw * sizeof(uint64_t), hipMemcpyHostToDevice) != hipSuccess)
+    st = set_err(ctx, KMI_ERR_DEVICE, "hipMemcpy failed");
+  free(rec);
+  if (st != KMI_OK) return st;
+  return index_insert_records(idx, (const uint64_t *)din, n, true);
+}
+
+kmi_status kmi_index_export_tuples_host(kmi_index *idx, uint64_t *keys, uint64_t *values, size_t capacity, uint64_t *n) {
+  if (!idx || !n) return KMI_ERR_INVALID;
+  kmi_ctx *ctx = idx->ctx;
+  *n = 0;
+  if (idx->val_words == 0) return set_err(ctx, KMI_ERR_INVALID, "export_tuples needs a position index");
+  if (idx->n_entries == 0) return KMI_OK;
+  if (capacity < idx->n_entries) return set_err(ctx, KMI_ERR_OVERFLOW, "export: capacity too small");
+  KMI_HIP(ctx, hipSetDevice(ctx->device));
+  if (keys) KMI_HIP(ctx, hipMemcpyAsync(keys, idx->keys, idx->n_entries * idx->shape.n_words * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+  if (values) KMI_HIP(ctx, hipMemcpyAsync(values, idx->mvals, idx->n_entries * idx->val_words * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+  KMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  *n = idx->n_entries;
+  return KMI_OK;
 }
 
 }  // extern "C"

@@ -31,6 +31,7 @@ enum WsSlot {
   WS_INPUT,           // host-entry staging of input bytes / keys
   WS_OUTPUT,          // host-entry staging of outputs
   WS_OUTPUT2,
+  WS_INPUT2,
   WS_MISC,
   WS_TILE_HDR,        // per-tile position of the last record start before the tile
   WS_PK_EOL,          // EOL bitmap of the scanned input

@@ -750,6 +750,117 @@ size_t orc_count_map_erase(orc_count_map *m, const uint64_t *queries, size_t nq)
   return erased;
 }
 
+
+/* ------------------------------------------------------------------------ */
+/* multimap (unordered_multimap semantics for PositionIndex)                 */
+/* ------------------------------------------------------------------------ */
+/* ::dsc::unordered_multimap (distributed_unordered_map.hpp:1466-1515): insert keeps every
+ * (key, value); LocalCount = db.count(k) = multiplicity (:231-238); LocalFind emits the whole
+ * equal_range (:1100-1131); erase removes all entries of a key (:1292-1328). Values are
+ * `vw` 64-bit words (1 = Short/LongSequenceKmerId). */
+typedef struct mm_node { struct mm_node *next; uint64_t hash; uint64_t data[]; /* key words, value words */ } mm_node;
+struct orc_multi_map {
+  orc_kspec spec; uint32_t strand, store_hash, vw;
+  mm_node **buckets; size_t n_buckets, size;
+};
+
+orc_multi_map *orc_multi_map_create(const orc_kspec *s, uint32_t strand, uint32_t store_hash, uint32_t value_words) {
+  orc_multi_map *m = (orc_multi_map *)calloc(1, sizeof(*m));
+  m->spec = *s; m->strand = strand; m->store_hash = store_hash; m->vw = value_words;
+  m->n_buckets = 1024; m->buckets = (mm_node **)calloc(m->n_buckets, sizeof(mm_node *));
+  return m;
+}
+void orc_multi_map_destroy(orc_multi_map *m) {
+  if (!m) return;
+  for (size_t b = 0; b < m->n_buckets; ++b) { mm_node *nd = m->buckets[b]; while (nd) { mm_node *nx = nd->next; free(nd); nd = nx; } }
+  free(m->buckets); free(m);
+}
+static void mm_rehash(orc_multi_map *m) {
+  size_t nb = m->n_buckets * 2;
+  mm_node **nbk = (mm_node **)calloc(nb, sizeof(mm_node *));
+  for (size_t b = 0; b < m->n_buckets; ++b) {
+    mm_node *nd = m->buckets[b];
+    while (nd) { mm_node *nx = nd->next; size_t j = nd->hash & (nb - 1); nd->next = nbk[j]; nbk[j] = nd; nd = nx; }
+  }
+  free(m->buckets); m->buckets = nbk; m->n_buckets = nb;
+}
+static void mm_transform(const orc_multi_map *m, const uint64_t *in, uint64_t *out) {
+  if (m->strand == ORC_STRAND_SINGLE) memcpy(out, in, m->spec.n_words * sizeof(uint64_t));
+  else orc_kmer_canonical(&m->spec, in, out);
+}
+void orc_multi_map_insert(orc_multi_map *m, const uint64_t *kmers, const uint64_t *values, size_t n) {
+  const uint32_t nw = m->spec.n_words;
+  uint64_t t[ORC_MAX_WORDS];
+  for (size_t i = 0; i < n; ++i) {
+    mm_transform(m, kmers + i * nw, t);
+    if (m->size + 1 > m->n_buckets) mm_rehash(m);
+    mm_node *nd = (mm_node *)malloc(sizeof(mm_node) + (nw + m->vw) * sizeof(uint64_t));
+    nd->hash = orc_kmer_hash(&m->spec, m->store_hash, 0, t);
+    memcpy(nd->data, t, nw * sizeof(uint64_t));
+    memcpy(nd->data + nw, values + i * m->vw, m->vw * sizeof(uint64_t));
+    size_t b = nd->hash & (m->n_buckets - 1);
+    nd->next = m->buckets[b]; m->buckets[b] = nd; ++m->size;
+  }
+}
+size_t orc_multi_map_size(const orc_multi_map *m) { return m->size; }
+size_t orc_multi_map_export(const orc_multi_map *m, uint64_t *keys, uint64_t *values) {
+  const uint32_t nw = m->spec.n_words; size_t j = 0;
+  for (size_t b = 0; b < m->n_buckets; ++b)
+    for (mm_node *nd = m->buckets[b]; nd; nd = nd->next) {
+      if (keys) memcpy(keys + j * nw, nd->data, nw * sizeof(uint64_t));
+      if (values) memcpy(values + j * m->vw, nd->data + nw, m->vw * sizeof(uint64_t));
+      ++j;
+    }
+  return j;
+}
+/* distinct transformed query keys via a counting map, then per key the equal_range */
+size_t orc_multi_map_count(const orc_multi_map *m, const uint64_t *queries, size_t nq, uint64_t *out_keys, uint64_t *out_counts) {
+  orc_count_map *u = orc_count_map_create(&m->spec, m->strand, m->store_hash);
+  orc_count_map_insert(u, queries, nq);
+  const uint32_t nw = m->spec.n_words; size_t j = 0;
+  for (size_t b = 0; b < u->n_buckets; ++b)
+    for (cm_node *q = u->buckets[b]; q; q = q->next) {
+      uint64_t c = 0;
+      for (mm_node *nd = m->buckets[q->hash & (m->n_buckets - 1)]; nd; nd = nd->next)
+        if (nd->hash == q->hash && orc_kmer_equal(&m->spec, nd->data, q->key)) ++c;
+      if (out_keys) memcpy(out_keys + j * nw, q->key, nw * sizeof(uint64_t));
+      if (out_counts) out_counts[j] = c;
+      ++j;
+    }
+  orc_count_map_destroy(u);
+  return j;
+}
+size_t orc_multi_map_find(const orc_multi_map *m, const uint64_t *queries, size_t nq, uint64_t *out_keys, uint64_t *out_values, size_t cap) {
+  orc_count_map *u = orc_count_map_create(&m->spec, m->strand, m->store_hash);
+  orc_count_map_insert(u, queries, nq);
+  const uint32_t nw = m->spec.n_words; size_t j = 0;
+  for (size_t b = 0; b < u->n_buckets; ++b)
+    for (cm_node *q = u->buckets[b]; q; q = q->next)
+      for (mm_node *nd = m->buckets[q->hash & (m->n_buckets - 1)]; nd; nd = nd->next)
+        if (nd->hash == q->hash && orc_kmer_equal(&m->spec, nd->data, q->key)) {
+          if (j < cap) {
+            if (out_keys) memcpy(out_keys + j * nw, nd->data, nw * sizeof(uint64_t));
+            if (out_values) memcpy(out_values + j * m->vw, nd->data + nw, m->vw * sizeof(uint64_t));
+          }
+          ++j;
+        }
+  orc_count_map_destroy(u);
+  return j;
+}
+size_t orc_multi_map_erase(orc_multi_map *m, const uint64_t *queries, size_t nq) {
+  uint64_t t[ORC_MAX_WORDS]; size_t erased = 0;
+  for (size_t i = 0; i < nq; ++i) {
+    mm_transform(m, queries + i * m->spec.n_words, t);
+    uint64_t h = orc_kmer_hash(&m->spec, m->store_hash, 0, t);
+    mm_node **pp = &m->buckets[h & (m->n_buckets - 1)];
+    while (*pp) {
+      if ((*pp)->hash == h && orc_kmer_equal(&m->spec, (*pp)->data, t)) { mm_node *d = *pp; *pp = d->next; free(d); --m->size; ++erased; }
+      else pp = &(*pp)->next;
+    }
+  }
+  return erased;
+}
+
 /* ------------------------------------------------------------------------ */
 /* CPU baseline driver                                                      */
 /* ------------------------------------------------------------------------ */

@@ -161,6 +161,18 @@ size_t orc_count_map_find(const orc_count_map *m, const uint64_t *queries, size_
 /* erase(): :719-779 */
 size_t orc_count_map_erase(orc_count_map *m, const uint64_t *queries, size_t nq);
 
+/* ---- multimap (::dsc::unordered_multimap semantics, distributed_unordered_map.hpp:1466-1515,
+ * :231-238, :1100-1131, :1292-1328) for PositionIndex / PositionQualityIndex */
+typedef struct orc_multi_map orc_multi_map;
+orc_multi_map *orc_multi_map_create(const orc_kspec *s, uint32_t strand, uint32_t store_hash, uint32_t value_words);
+void orc_multi_map_destroy(orc_multi_map *m);
+void orc_multi_map_insert(orc_multi_map *m, const uint64_t *kmers, const uint64_t *values, size_t n);
+size_t orc_multi_map_size(const orc_multi_map *m);
+size_t orc_multi_map_export(const orc_multi_map *m, uint64_t *keys, uint64_t *values);
+size_t orc_multi_map_count(const orc_multi_map *m, const uint64_t *queries, size_t nq, uint64_t *out_keys, uint64_t *out_counts);
+size_t orc_multi_map_find(const orc_multi_map *m, const uint64_t *queries, size_t nq, uint64_t *out_keys, uint64_t *out_values, size_t cap);
+size_t orc_multi_map_erase(orc_multi_map *m, const uint64_t *queries, size_t nq);
+
 /* ---- CPU baseline driver ("port" of the reference MPI path with T thread-ranks):
  * per rank parse (record-aligned byte range) -> KeyToRank (murmur h[1] % T) ->
  * stable bucket -> in-memory exchange -> per-rank counting map insert.

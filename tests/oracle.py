@@ -82,6 +82,20 @@ lib.orc_count_map_find.argtypes = [C.c_void_p, _u64p, C.c_size_t, C.c_void_p, C.
 lib.orc_count_map_find.restype = C.c_size_t
 lib.orc_count_map_erase.argtypes = [C.c_void_p, _u64p, C.c_size_t]
 lib.orc_count_map_erase.restype = C.c_size_t
+lib.orc_multi_map_create.argtypes = [_SP, C.c_uint32, C.c_uint32, C.c_uint32]
+lib.orc_multi_map_create.restype = C.c_void_p
+lib.orc_multi_map_destroy.argtypes = [C.c_void_p]
+lib.orc_multi_map_insert.argtypes = [C.c_void_p, _u64p, _u64p, C.c_size_t]
+lib.orc_multi_map_size.argtypes = [C.c_void_p]
+lib.orc_multi_map_size.restype = C.c_size_t
+lib.orc_multi_map_export.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+lib.orc_multi_map_export.restype = C.c_size_t
+lib.orc_multi_map_count.argtypes = [C.c_void_p, _u64p, C.c_size_t, C.c_void_p, C.c_void_p]
+lib.orc_multi_map_count.restype = C.c_size_t
+lib.orc_multi_map_find.argtypes = [C.c_void_p, _u64p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t]
+lib.orc_multi_map_find.restype = C.c_size_t
+lib.orc_multi_map_erase.argtypes = [C.c_void_p, _u64p, C.c_size_t]
+lib.orc_multi_map_erase.restype = C.c_size_t
 lib.orc_bench_count_index.argtypes = [_u8p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32,
                                       C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
 lib.orc_bench_count_index.restype = C.c_double
@@ -212,6 +226,60 @@ class CountMap:
     def erase(self, q):
         q = np.ascontiguousarray(q, dtype=np.uint64).reshape(-1, self.s.n_words)
         return lib.orc_count_map_erase(self.h, q, q.shape[0])
+
+
+class MultiMap:
+    """::dsc::unordered_multimap restatement (PositionIndex): values are `vw` u64 words"""
+
+    def __init__(self, s, strand=CANONICAL, vw=1, store_hash=MURMUR):
+        self.s, self.vw = s, vw
+        self.h = lib.orc_multi_map_create(C.byref(s), strand, store_hash, vw)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib.orc_multi_map_destroy(self.h)
+            self.h = None
+
+    def insert(self, kmers, values):
+        kmers = np.ascontiguousarray(kmers, dtype=np.uint64).reshape(-1, self.s.n_words)
+        values = np.ascontiguousarray(values, dtype=np.uint64).reshape(kmers.shape[0], self.vw)
+        lib.orc_multi_map_insert(self.h, kmers, values, kmers.shape[0])
+
+    def size(self):
+        return lib.orc_multi_map_size(self.h)
+
+    def export(self):
+        n = self.size()
+        keys = np.zeros((n, self.s.n_words), dtype=np.uint64)
+        vals = np.zeros((n, self.vw), dtype=np.uint64)
+        lib.orc_multi_map_export(self.h, _ptr(keys), _ptr(vals))
+        return keys, vals
+
+    def count(self, q):
+        q = np.ascontiguousarray(q, dtype=np.uint64).reshape(-1, self.s.n_words)
+        keys = np.zeros((q.shape[0], self.s.n_words), dtype=np.uint64)
+        cnt = np.zeros(q.shape[0], dtype=np.uint64)
+        n = lib.orc_multi_map_count(self.h, q, q.shape[0], _ptr(keys), _ptr(cnt))
+        return keys[:n], cnt[:n]
+
+    def find(self, q):
+        q = np.ascontiguousarray(q, dtype=np.uint64).reshape(-1, self.s.n_words)
+        n = lib.orc_multi_map_find(self.h, q, q.shape[0], None, None, 0)
+        keys = np.zeros((n, self.s.n_words), dtype=np.uint64)
+        vals = np.zeros((n, self.vw), dtype=np.uint64)
+        lib.orc_multi_map_find(self.h, q, q.shape[0], _ptr(keys), _ptr(vals), n)
+        return keys, vals
+
+    def erase(self, q):
+        q = np.ascontiguousarray(q, dtype=np.uint64).reshape(-1, self.s.n_words)
+        return lib.orc_multi_map_erase(self.h, q, q.shape[0])
+
+
+def sorted_rows(*cols):
+    """rows (concatenated 2-D columns) in lexicographic order, for multiset comparison"""
+    m = np.concatenate([np.asarray(c, dtype=np.uint64).reshape(len(cols[0]), -1) for c in cols], axis=1)
+    order = np.lexsort([m[:, i] for i in range(m.shape[1] - 1, -1, -1)])
+    return m[order]
 
 
 def sorted_pairs(keys, vals):

@@ -1,0 +1,101 @@
+"""GPU parity of the PositionIndex (multimap) path: KmerPositionTupleParser tuples -> insert ->
+count / find / erase, against the oracle's unordered_multimap restatement."""
+import os
+
+import numpy as np
+import pytest
+
+from tests import oracle as orc
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+ALPHA = {"DNA": orc.DNA, "DNA5": orc.DNA5}
+STRAND = {"single": orc.SINGLE, "canonical": orc.CANONICAL, "bimolecule": orc.BIMOLECULE}
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import kmerind_amd as K
+    c = K.Context(0)
+    yield c
+    c.close()
+
+
+def _same(idx, om):
+    gk, gv = idx.to_vector()
+    ok, ov = om.export()
+    assert gk.shape == ok.shape
+    assert (orc.sorted_rows(gk, gv) == orc.sorted_rows(ok, ov)).all()
+
+
+@pytest.mark.parametrize("k,alpha,strand", [(31, "DNA", "canonical"), (21, "DNA", "single"), (63, "DNA5", "canonical"),
+                                            (63, "DNA", "bimolecule"), (15, "DNA5", "single")])
+def test_position_index_build_insert_query(ctx, k, alpha, strand):
+    import kmerind_amd as K
+    s = orc.kspec(k, ALPHA[alpha])
+    cfg = K.make_config(k, alpha, strand=strand, index_kind="position")
+    data = bytes(K.synth_fastq(seed=k, genome_len=3000, n_reads=1200))
+    ex = orc.extract(s, data, orc.FASTQ, want_ids=True)
+    om = orc.MultiMap(s, STRAND[strand])
+    om.insert(ex["kmers"], ex["ids"])
+    idx = K.PositionIndex(ctx, cfg)
+    idx.build(data)                                     # KmerPositionTupleParser + multimap insert on the device
+    assert idx.local_size() == ex["kmers"].shape[0]
+    _same(idx, om)
+    # a second batch through insert(tuples) at another file offset
+    data2 = bytes(K.synth_fastq(seed=k, genome_len=3000, n_reads=500, first_read=5000))
+    ex2 = orc.extract(s, data2, orc.FASTQ, file_offset=1 << 33, want_ids=True)
+    om.insert(ex2["kmers"], ex2["ids"])
+    idx.insert(ex2["kmers"], ex2["ids"])
+    _same(idx, om)
+    # queries: present (with repeats), absent
+    rng = np.random.default_rng(k)
+    present = ex["kmers"][rng.integers(0, ex["kmers"].shape[0], size=3000)]
+    absent = orc.extract(s, bytes(K.synth_fastq(seed=99, genome_len=50000, n_reads=30)), orc.FASTQ)["kmers"]
+    q = np.concatenate([present, absent, present[:50]])
+    gk, gc = idx.count(q)
+    ok, oc = om.count(q)
+    assert (orc.sorted_rows(gk, gc) == orc.sorted_rows(ok, oc)).all()
+    fk, fv = idx.find(q)
+    ek, ev = om.find(q)
+    assert fk.shape == ek.shape and fk.shape[0] > q.shape[0]      # many positions per k-mer
+    assert (orc.sorted_rows(fk, fv) == orc.sorted_rows(ek, ev)).all()
+    n_gpu, n_cpu = idx.erase(present[:1000]), om.erase(present[:1000])
+    assert n_gpu == n_cpu and idx.local_size() == om.size()
+    _same(idx, om)
+    idx.close()
+
+
+def test_position_index_on_reference_files(ctx):
+    import kmerind_amd as K
+    s = orc.kspec(21, orc.DNA)
+    cfg = K.make_config(21, "DNA", strand="canonical", index_kind="position")
+    for name in ("test.small.fastq", "natural.fastq"):
+        data = open(os.path.join(GOLD, "data", name), "rb").read()
+        ex = orc.extract(s, data, orc.FASTQ, want_ids=True)
+        om = orc.MultiMap(s, orc.CANONICAL)
+        om.insert(ex["kmers"], ex["ids"])
+        idx = K.PositionIndex(ctx, cfg)
+        idx.build(data)
+        _same(idx, om)
+        # every stored id points at the k-mer's text in the file (mpi_test_fastq_seq_parse.cpp:235-330)
+        keys, ids = idx.to_vector()
+        for key, i in list(zip(keys, ids[:, 0]))[:300]:
+            pos = ((int(i) >> 16) & 0xFFFFFFFFFF) + (int(i) & 0xFFFF)
+            fwd = orc.kmers_from_string(s, data[pos:pos + 21])
+            assert orc.canonical(s, fwd)[0].tolist() == key.tolist()
+        idx.close()
+
+
+def test_position_index_api_guards(ctx):
+    import kmerind_amd as K
+    from kmerind_amd import _lib as L
+    cfg = K.make_config(31, "DNA", index_kind="position")
+    idx = K.PositionIndex(ctx, cfg)
+    with pytest.raises(L.KmiError):
+        K.CountIndex.insert(idx, np.zeros((3, 1), dtype=np.uint64))      # key-only insert is for counting maps
+    k, v = idx.find(np.array([[7]], dtype=np.uint64))
+    assert k.shape[0] == 0
+    k, c = idx.count(np.array([[7], [7]], dtype=np.uint64))
+    assert k.shape[0] == 1 and c.tolist() == [0]
+    idx.close()
