@@ -64,8 +64,16 @@ template <typename Key> using MapParams = ::bliss::index::kmer::BimoleculeHashMa
 template <typename Key> using MapParams = ::bliss::index::kmer::CanonicalHashMapParams<Key, DistHash, StoreHash>;
 #endif
 
+#if defined(pINDEX_POS)
+using ValType = bliss::common::ShortSequenceKmerId;
+using MapType = ::dsc::unordered_multimap<KmerType, ValType, MapParams>;
+using IndexType = bliss::index::kmer::PositionIndex<MapType>;
+static unsigned long long val_of(const ValType &v) { return (unsigned long long)v.get_pos(); }
+#else
 using MapType = ::dsc::counting_unordered_map<KmerType, CountType, MapParams>;
 using IndexType = bliss::index::kmer::CountIndex<MapType>;
+static unsigned long long val_of(const CountType &v) { return v; }
+#endif
 
 static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
@@ -122,7 +130,7 @@ int main(int argc, char **argv) {
       t = now();
       auto found = idx.find(lquery);
       unsigned long long sum = 0;
-      for (auto &f : found) sum += f.second;
+      for (auto &f : found) sum += val_of(f.second);
       std::printf("[TIME] find\t%f\t%zu\n", now() - t, found.size());
       std::printf("find results %zu sum %llu\n", found.size(), sum);
     }

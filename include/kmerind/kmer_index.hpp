@@ -129,8 +129,27 @@ class Kmer {
   WORD_TYPE data[nWords];
 };
 
-struct ShortSequenceKmerId { size_t id; };  // sequence.hpp:127-209 (layout only)
-struct LongSequenceKmerId { size_t id; };   // sequence.hpp:231-296
+// sequence.hpp:127-209 / :231-296 -- same single-word layout and accessors
+struct ShortSequenceKmerId {
+  size_t id = 0;
+  ShortSequenceKmerId() = default;
+  explicit ShortSequenceKmerId(size_t raw) : id(raw) {}
+  size_t get_id() const { return (id >> 16) & 0x000000FFFFFFFFFFull; }
+  size_t get_pos() const { return get_id() + (id & 0xFFFF); }
+  uint8_t get_file_id() const { return (uint8_t)(id >> 56); }
+  bool operator==(const ShortSequenceKmerId &o) const { return id == o.id; }
+  bool operator<(const ShortSequenceKmerId &o) const { return id < o.id; }
+};
+struct LongSequenceKmerId {
+  size_t id = 0;
+  LongSequenceKmerId() = default;
+  explicit LongSequenceKmerId(size_t raw) : id(raw) {}
+  size_t get_id() const { return (id >> 40) & 0xFFFF; }
+  size_t get_pos() const { return id & 0x000000FFFFFFFFFFull; }
+  uint8_t get_file_id() const { return (uint8_t)(id >> 56); }
+  bool operator==(const LongSequenceKmerId &o) const { return id == o.id; }
+  bool operator<(const LongSequenceKmerId &o) const { return id < o.id; }
+};
 
 }  // namespace common
 
@@ -175,6 +194,15 @@ struct counting_unordered_map {
 };
 template <typename Key, typename T, template <typename> class MapParams, typename SpecialKeys = void>
 struct counting_densehash_map : counting_unordered_map<Key, T, MapParams> {};
+// multimaps (distributed_unordered_map.hpp:1466-1515): T is the position id type
+template <typename Key, typename T, template <typename> class MapParams>
+struct unordered_multimap {
+  using key_type = Key; using mapped_type = T; using params = MapParams<Key>;
+  static constexpr uint32_t index_kind = KMI_INDEX_POSITION;
+  static_assert(sizeof(T) == sizeof(uint64_t), "position ids are one 64-bit word");
+};
+template <typename Key, typename T, template <typename> class MapParams, typename SpecialKeys = void>
+struct densehash_multimap : unordered_multimap<Key, T, MapParams> {};
 
 }  // namespace dsc
 
@@ -208,6 +236,11 @@ template <typename TupleType> struct KmerCountTupleParser {
   static constexpr size_t window_size = kmer_type::size;
 };
 
+template <typename TupleType> struct KmerPositionTupleParser {   // kmer_parser.hpp:303-569
+  using value_type = TupleType; using kmer_type = typename std::tuple_element<0, TupleType>::type;
+  static constexpr size_t window_size = kmer_type::size;
+};
+
 namespace detail {
 template <typename MapType> kmi_config make_config(uint32_t fmt) {
   using Key = typename MapType::key_type;
@@ -232,6 +265,8 @@ inline uint32_t format_of(const std::string &filename) {  // kmer_index.hpp:243-
   if (ends(".fasta") || ends(".fa")) return KMI_FMT_FASTA;
   throw std::invalid_argument("input filename extension is not supported.");
 }
+template <typename V> typename std::enable_if<std::is_arithmetic<V>::value, V>::type value_of(uint64_t w) { return (V)w; }
+template <typename V> typename std::enable_if<!std::is_arithmetic<V>::value, V>::type value_of(uint64_t w) { return V((size_t)w); }
 template <typename Kmer> const uint64_t *words_of(const std::vector<Kmer> &v) { return reinterpret_cast<const uint64_t *>(v.data()); }
 template <typename Kmer, typename T> std::vector<uint64_t> words_of_pairs(const std::vector<std::pair<Kmer, T>> &v) {
   std::vector<uint64_t> w(v.size() * Kmer::nWords);
@@ -261,7 +296,15 @@ class Index {
 
   // Index::insert (kmer_index.hpp:200-225): vector<Kmer> or vector<pair<Kmer,count>> (the count parser's tuples)
   void insert(std::vector<KmerType> &temp) { insert_words(detail::words_of(temp), temp.size()); }
-  void insert(std::vector<TupleType> &temp) { auto w = detail::words_of_pairs(temp); insert_words(w.data(), temp.size()); }
+  void insert(std::vector<TupleType> &temp) {
+    auto w = detail::words_of_pairs(temp);
+    if (MapType::index_kind == KMI_INDEX_COUNT) { insert_words(w.data(), temp.size()); return; }
+    // multimap: (k-mer, position id) tuples
+    if (comm.size() > 1) throw std::invalid_argument("multimap insert with size() > 1 is not wired through comm.exchange yet");
+    std::vector<uint64_t> vals(temp.size());
+    for (size_t i = 0; i < temp.size(); ++i) std::memcpy(&vals[i], &temp[i].second, sizeof(uint64_t));
+    ::kmerind::check(ctx, kmi_index_insert_tuples_host(idx, w.data(), vals.data(), temp.size()));
+  }
 
   // Index::count (:142-145): one (key, 0|1) per distinct transformed query key
   std::vector<std::pair<KmerType, size_t>> count(std::vector<KmerType> &query) const {
@@ -279,7 +322,7 @@ class Index {
     std::vector<uint64_t> q = route_queries(query);
     ::kmerind::check(ctx, kmi_index_find_host(idx, q.data(), q.size() / KmerType::nWords, &r));
     std::vector<TupleType> out(r.n);
-    for (uint64_t i = 0; i < r.n; ++i) out[i] = std::make_pair(KmerType(r.keys + i * KmerType::nWords), (ValueType)r.values[i]);
+    for (uint64_t i = 0; i < r.n; ++i) out[i] = std::make_pair(KmerType(r.keys + i * KmerType::nWords), detail::value_of<ValueType>(r.values[i]));
     kmi_results_free(&r);
     return out;
   }
@@ -296,11 +339,18 @@ class Index {
   // MapType::to_vector (distributed_map_base.hpp:202-217)
   std::vector<TupleType> to_vector() const {
     uint64_t n = local_size(), got = 0;
+    if (MapType::index_kind != KMI_INDEX_COUNT) {
+      std::vector<uint64_t> keys(n * KmerType::nWords + 1), vals(n + 1);
+      ::kmerind::check(ctx, kmi_index_export_tuples_host(idx, keys.data(), vals.data(), n, &got));
+      std::vector<TupleType> out(got);
+      for (uint64_t i = 0; i < got; ++i) out[i] = std::make_pair(KmerType(&keys[i * KmerType::nWords]), detail::value_of<ValueType>(vals[i]));
+      return out;
+    }
     std::vector<uint64_t> keys(n * KmerType::nWords + 1);
     std::vector<uint32_t> cnt(n + 1);
     ::kmerind::check(ctx, kmi_index_export_host(idx, keys.data(), cnt.data(), n, &got));
     std::vector<TupleType> out(got);
-    for (uint64_t i = 0; i < got; ++i) out[i] = std::make_pair(KmerType(&keys[i * KmerType::nWords]), (ValueType)cnt[i]);
+    for (uint64_t i = 0; i < got; ++i) out[i] = std::make_pair(KmerType(&keys[i * KmerType::nWords]), detail::value_of<ValueType>(cnt[i]));
     return out;
   }
 
@@ -360,6 +410,7 @@ class Index {
 template <typename MapType> using KmerIndex = Index<MapType, KmerParser<typename MapType::key_type>>;
 template <typename MapType> using CountIndex = Index<MapType, KmerCountTupleParser<std::pair<typename MapType::key_type, typename MapType::mapped_type>>>;
 template <typename MapType> using CountIndex2 = Index<MapType, KmerParser<typename MapType::key_type>>;
+template <typename MapType> using PositionIndex = Index<MapType, KmerPositionTupleParser<std::pair<typename MapType::key_type, typename MapType::mapped_type>>>;
 
 }  // namespace kmer
 }  // namespace index
@@ -375,6 +426,7 @@ struct KmerFileHelper {
     using Kmer = typename KmerParser::kmer_type;
     kmi_config c; std::memset(&c, 0, sizeof(c));
     c.k = Kmer::size; c.alphabet = Kmer::KmerAlphabet::KMI; c.seq_format = SeqParser<const unsigned char *>::KMI;
+    c.index_kind = tuple_kind<typename KmerParser::value_type, Kmer>();
     if (comm.size() > 1) throw std::invalid_argument("read_file_* with size() > 1: pass each rank its own record-aligned partition");
     std::vector<uint8_t> bytes = ::bliss::index::kmer::detail::read_whole_file(filename);
     kmi_ctx *ctx = nullptr;
@@ -384,7 +436,8 @@ struct KmerFileHelper {
     if (st != KMI_OK) { std::string m = kmi_last_error(ctx); kmi_ctx_destroy(ctx); if (st == KMI_ERR_PARSE) throw std::logic_error(m); throw std::invalid_argument(m); }
     const size_t before = result.size();
     result.reserve(before + t.n_tuples);
-    for (uint64_t i = 0; i < t.n_tuples; ++i) result.push_back(make_value<typename KmerParser::value_type, Kmer>(t.kmers + i * Kmer::nWords));
+    for (uint64_t i = 0; i < t.n_tuples; ++i)
+      result.push_back(make_value<typename KmerParser::value_type, Kmer>(t.kmers + i * Kmer::nWords, t.ids ? t.ids[i] : 1));
     std::pair<size_t, size_t> r((size_t)t.n_seqs, (size_t)t.n_tuples);
     kmi_tuples_free(&t);
     kmi_ctx_destroy(ctx);
@@ -397,9 +450,14 @@ struct KmerFileHelper {
   }
 
  private:
-  template <typename V, typename Kmer> static typename std::enable_if<std::is_same<V, Kmer>::value, V>::type make_value(const uint64_t *w) { return Kmer(w); }
-  template <typename V, typename Kmer> static typename std::enable_if<!std::is_same<V, Kmer>::value, V>::type make_value(const uint64_t *w) {
-    return V(Kmer(w), typename V::second_type(1));  // KmerCountTupleParser zips the k-mer with a constant 1 (kmer_parser.hpp:1008-1081)
+  template <typename V, typename Kmer> static typename std::enable_if<std::is_same<V, Kmer>::value, uint32_t>::type tuple_kind() { return KMI_INDEX_COUNT; }
+  template <typename V, typename Kmer> static typename std::enable_if<!std::is_same<V, Kmer>::value, uint32_t>::type tuple_kind() {
+    return std::is_arithmetic<typename V::second_type>::value ? KMI_INDEX_COUNT : KMI_INDEX_POSITION;
+  }
+  template <typename V, typename Kmer> static typename std::enable_if<std::is_same<V, Kmer>::value, V>::type make_value(const uint64_t *w, uint64_t) { return Kmer(w); }
+  // KmerCountTupleParser zips the k-mer with a constant 1 (kmer_parser.hpp:1008-1081); KmerPositionTupleParser with its id
+  template <typename V, typename Kmer> static typename std::enable_if<!std::is_same<V, Kmer>::value, V>::type make_value(const uint64_t *w, uint64_t v) {
+    return V(Kmer(w), ::bliss::index::kmer::detail::value_of<typename V::second_type>(v));
   }
 };
 }  // namespace io

@@ -68,3 +68,25 @@ def test_bad_extension_is_invalid_argument(tmp_path):
     bad.write_bytes(b"x\nACGT\n+\nIIII\n")
     out = subprocess.run([exe, "-F", str(bad)], capture_output=True, text=True, timeout=120)
     assert out.returncode == 1 and "missing @" in out.stderr
+
+
+def test_position_index_harness_matches_oracle():
+    """PositionIndex<unordered_multimap<Kmer<21,DNA>, ShortSequenceKmerId>> through the facade"""
+    path = os.path.join(DATA, "natural.fastq")
+    ratio = 4
+    got = _run("bench_pos_k21_dna", path, ratio)
+    s = orc.kspec(21)
+    data = open(path, "rb").read()
+    ex = orc.extract(s, data, orc.FASTQ, want_ids=True)
+    m = orc.MultiMap(s, orc.CANONICAL)
+    m.insert(ex["kmers"], ex["ids"])
+    q = ex["kmers"][: ex["kmers"].shape[0] // ratio]
+    ck, cv = m.count(q)
+    fk, fv = m.find(q)
+    pos = ((fv[:, 0] >> np.uint64(16)) & np.uint64(0xFFFFFFFFFF)) + (fv[:, 0] & np.uint64(0xFFFF))
+    assert got["total"] == (ex["kmers"].shape[0],)
+    assert got["distinct"] == (m.size(),)
+    assert got["count"] == (ck.shape[0], int(cv.sum()))
+    assert got["find"] == (fk.shape[0], int(pos.sum()))
+    m.erase(q)
+    assert got["after_erase"] == (m.size(),)
