@@ -77,8 +77,8 @@ template <int BITS, int C> __device__ __forceinline__ void store_stream_bits(uin
 }
 
 // per-thread view of the EOL bit array: bits [C*j, C*j + C-1+KMAX) normalised to bit 0
-template <typename Cfg> __device__ __forceinline__ void load_eol_view(const uint32_t *s_eol, int j, uint64_t (&e)[Cfg::NE]) {
-  const int bit0 = Cfg::C * j, d0 = bit0 >> 5, sh = bit0 & 31;
+template <typename Cfg> __device__ __forceinline__ void load_eol_view(const uint32_t *s_eol, int j, uint64_t (&e)[Cfg::NE], int skip = 0) {
+  const int bit0 = Cfg::C * j + skip, d0 = bit0 >> 5, sh = bit0 & 31;
   uint32_t raw[Cfg::E_RAW];
 #pragma unroll
   for (int i = 0; i < Cfg::E_RAW; ++i) raw[i] = s_eol[d0 + i];
@@ -274,6 +274,37 @@ __device__ __forceinline__ uint32_t chunk_valid_mask(const uint32_t *s_eol, uint
   load_eol_view<Cfg>(s_eol, threadIdx.x, e);
   smear_right<Cfg::NE>(e, k);
   return ~(uint32_t)e[0] & fastq_seq_role_mask(lines_before, ls, Cfg::CMASK);
+}
+
+// FASTA (compacted character space, s_eol holds the record-start bits): window r is valid iff no
+// record starts at r+1 .. r+k-1 and r + k <= n_chars
+template <typename Cfg>
+__device__ __forceinline__ uint32_t chunk_valid_mask_fasta(const uint32_t *s_eol, uint32_t k, uint64_t tile0, uint64_t n_chars) {
+  uint64_t e[Cfg::NE];
+  load_eol_view<Cfg>(s_eol, threadIdx.x, e, 1);
+  uint32_t blocked = 0;
+  if (k > 1) { smear_right<Cfg::NE>(e, k - 1); blocked = (uint32_t)e[0]; }
+  const uint64_t g = tile0 + (uint64_t)threadIdx.x * Cfg::C;
+  uint32_t room = 0;   // positions p with g + p + k <= n_chars
+  if (g + k <= n_chars) {
+    const uint64_t lim = n_chars - k - g + 1;
+    room = lim >= (uint64_t)Cfg::C ? Cfg::CMASK : ((1u << (uint32_t)lim) - 1u);
+  }
+  return ~blocked & room & Cfg::CMASK;
+}
+
+// window list from a ready valid mask (one workgroup scan + barrier)
+template <typename Cfg>
+__device__ __forceinline__ uint32_t tile_window_list_from(uint32_t valid, uint16_t *s_pos, uint32_t *s_scan) {
+  uint32_t total;
+  uint32_t rank = block_exclusive_scan<uint32_t>((uint32_t)__builtin_popcount(valid), s_scan, &total);
+  const uint32_t base = threadIdx.x * Cfg::C;
+  while (valid) {
+    s_pos[rank++] = (uint16_t)(base + (uint32_t)__builtin_ctz(valid));
+    valid &= valid - 1u;
+  }
+  lds_barrier();
+  return total;
 }
 
 // per-wavefront window list (no workgroup barrier): s_wpos points at this wave's 64*C slots;

@@ -203,6 +203,55 @@ __global__ __launch_bounds__(1024) void fastq_offsets_apply_kernel(const TileInf
 // pass 3: tuples in file order. Work is re-distributed over the tile's compacted window list,
 // so consecutive lanes produce consecutive tuples and the stores are coalesced without staging.
 // ---------------------------------------------------------------------------
+// FASTA: the same pass over the compacted character stream (in.eol = record-start bits, in.n_bytes = characters)
+template <int NW, int BITS, bool WITH_IDS>
+__global__ __launch_bounds__((ExCfg<NW, BITS>::NT)) void fasta_extract_kernel(
+    PackedInput in, KShape shape, bool canonical, const uint64_t *__restrict__ ids_by_rank, const uint64_t *__restrict__ out_off,
+    uint64_t out_capacity, uint64_t *__restrict__ out_kmers, uint64_t *__restrict__ out_ids, uint32_t *__restrict__ flags) {
+  using Cfg = ExCfg<NW, BITS>;
+  __shared__ uint32_t s_eol[Cfg::EOL_DW];
+  __shared__ uint32_t s_stream[Cfg::STREAM_DW];
+  __shared__ uint32_t s_scan[Cfg::NT / 64 + 2];
+  __shared__ uint16_t s_pos[Cfg::TILE];
+  uint32_t eol, ls, lbl, ltot;
+  tile_front_packed<Cfg>(in, blockIdx.x, s_eol, s_stream, s_scan, eol, ls, lbl, ltot);
+  const uint64_t tile0 = (uint64_t)blockIdx.x * Cfg::TILE;
+  const uint32_t total = tile_window_list_from<Cfg>(chunk_valid_mask_fasta<Cfg>(s_eol, shape.k, tile0, in.n_bytes), s_pos, s_scan);
+  const uint64_t base = out_off[blockIdx.x];
+  if (base + total > out_capacity) {
+    if (threadIdx.x == 0 && total) atomicOr(&flags[1], 1u);
+    return;
+  }
+  for (uint32_t q = threadIdx.x; q < total; q += Cfg::NT) {
+    uint64_t rc[NW], fw[NW], key[NW];
+    const uint32_t pos = s_pos[q];
+    window_at<Cfg>(s_stream, pos, shape, rc, fw);
+    select_strand<NW>(rc, fw, canonical, key);
+#pragma unroll
+    for (int w = 0; w < NW; ++w) out_kmers[(base + q) * NW + w] = key[w];
+    if (WITH_IDS) out_ids[base + q] = ids_by_rank[tile0 + pos];
+  }
+}
+
+// valid windows per tile of the compacted stream (TileInfo.win filled for every phase)
+template <int NW, int BITS>
+__global__ __launch_bounds__((ExCfg<NW, BITS>::NT)) void fasta_count_tiles_kernel(PackedInput in, uint32_t k, TileInfo *__restrict__ info) {
+  using Cfg = ExCfg<NW, BITS>;
+  __shared__ uint32_t s_eol[Cfg::EOL_DW];
+  __shared__ uint32_t s_stream[Cfg::STREAM_DW];
+  __shared__ uint32_t s_scan[Cfg::NT / 64 + 2];
+  uint32_t eol, ls, lbl, ltot;
+  tile_front_packed<Cfg>(in, blockIdx.x, s_eol, s_stream, s_scan, eol, ls, lbl, ltot);
+  const uint32_t valid = chunk_valid_mask_fasta<Cfg>(s_eol, k, (uint64_t)blockIdx.x * Cfg::TILE, in.n_bytes);
+  uint32_t total;
+  (void)block_exclusive_scan<uint32_t>((uint32_t)__builtin_popcount(valid), s_scan, &total);
+  if (threadIdx.x == 0) {
+    TileInfo ti; ti.lines = 0; ti.marks = 0;
+    for (int r = 0; r < 4; ++r) { ti.win[r] = total; ti.last[r] = 0; }
+    info[blockIdx.x] = ti;
+  }
+}
+
 template <int NW, int BITS, bool WITH_IDS>
 __global__ __launch_bounds__((ExCfg<NW, BITS>::NT)) void fastq_extract_kernel(
     PackedInput in, KShape shape, bool canonical, const uint32_t *__restrict__ line_base, const uint64_t *__restrict__ hdr_base,
@@ -262,6 +311,25 @@ __global__ __launch_bounds__((ExCfg<NW, BITS>::NT)) void fastq_extract_kernel(
 // ---------------------------------------------------------------------------
 // host drivers
 // ---------------------------------------------------------------------------
+// offsets over the tile records (reduce per 1024 tiles, scan of the block summaries, apply)
+static kmi_status launch_tile_offsets(kmi_ctx *ctx, const TileInfo *info, uint64_t n_tiles, uint32_t tile_bytes, uint64_t *hdr,
+                                      uint32_t *base, uint64_t *off) {
+  const uint64_t n_blocks = (n_tiles + 1023) / 1024;
+  void *ps_;
+  KMI_TRY(ws_get(ctx, WS_MISC, sizeof(TileSum) * (n_blocks + 1), &ps_));
+  TileSum *sums = (TileSum *)ps_;
+  ProfScope ps(ctx, "fastq_scan_offsets", n_tiles);
+  if (n_blocks > 0) {
+    hipLaunchKernelGGL(fastq_offsets_reduce_kernel, dim3((unsigned)n_blocks), dim3(1024), 0, ctx->stream, info, n_tiles, tile_bytes, sums);
+  }
+  hipLaunchKernelGGL(fastq_offsets_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, sums, n_blocks, n_tiles, off, ctx->d_totals);
+  if (n_blocks > 0) {
+    hipLaunchKernelGGL(fastq_offsets_apply_kernel, dim3((unsigned)n_blocks), dim3(1024), 0, ctx->stream, info, n_tiles, tile_bytes,
+                       (const TileSum *)sums, hdr, base, off, ctx->d_flags);
+  }
+  return KMI_OK;
+}
+
 struct ScanResult {
   uint64_t n_tiles;
   uint32_t *line_base;
@@ -297,23 +365,7 @@ static kmi_status scan_impl(kmi_ctx *ctx, const uint8_t *bytes_dev, size_t n_byt
     hipLaunchKernelGGL((fastq_scan_tiles_kernel<NW, BITS>), dim3((unsigned)n_tiles), dim3(Cfg::NT), 0, ctx->stream,
                        bytes_dev, (uint64_t)n_bytes, shape.k, pk_eol, pk_stream, info, ctx->d_flags);
   }
-  {
-    const uint64_t n_blocks = (n_tiles + 1023) / 1024;
-    void *ps_;
-    KMI_TRY(ws_get(ctx, WS_MISC, sizeof(TileSum) * (n_blocks + 1), &ps_));
-    TileSum *sums = (TileSum *)ps_;
-    ProfScope ps(ctx, "fastq_scan_offsets", n_tiles);
-    if (n_blocks > 0) {
-      hipLaunchKernelGGL(fastq_offsets_reduce_kernel, dim3((unsigned)n_blocks), dim3(1024), 0, ctx->stream,
-                         (const TileInfo *)info, n_tiles, (uint32_t)Cfg::TILE, sums);
-    }
-    hipLaunchKernelGGL(fastq_offsets_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, sums, n_blocks, n_tiles, off,
-                       ctx->d_totals);
-    if (n_blocks > 0) {
-      hipLaunchKernelGGL(fastq_offsets_apply_kernel, dim3((unsigned)n_blocks), dim3(1024), 0, ctx->stream,
-                         (const TileInfo *)info, n_tiles, (uint32_t)Cfg::TILE, (const TileSum *)sums, hdr, base, off, ctx->d_flags);
-    }
-  }
+  KMI_TRY(launch_tile_offsets(ctx, info, n_tiles, (uint32_t)Cfg::TILE, hdr, base, off));
   KMI_HIP(ctx, hipGetLastError());
   return KMI_OK;
 }
@@ -387,12 +439,63 @@ kmi_status fastq_scan(kmi_ctx *ctx, const kmi_config *cfg, const uint8_t *bytes_
   KMI_DISPATCH(shape, fastq_scan_impl, ctx, bytes_dev, n_bytes, shape, out);
 }
 
+// ---- FASTA: byte-space scan + compaction (kmi_fasta.hip), then count / extract over the compacted stream
+template <int NW, int BITS>
+static kmi_status fasta_extract_impl(kmi_ctx *ctx, const kmi_config *cfg, const uint8_t *bytes_dev, size_t n_bytes, KShape shape,
+                                     uint64_t file_offset, uint64_t *out_kmers_dev, uint64_t *out_ids_dev, size_t out_capacity,
+                                     bool apply_strand, bool count_only, uint64_t *n_tuples, uint64_t *n_seqs) {
+  using Cfg = ExCfg<NW, BITS>;
+  FastaScan fs;
+  KMI_HIP(ctx, hipMemsetAsync(ctx->d_flags, 0, sizeof(uint32_t) * 16, ctx->stream));
+  KMI_TRY(fasta_scan(ctx, cfg, bytes_dev, n_bytes, file_offset, out_ids_dev != nullptr, &fs));
+  PackedInput in; in.eol = fs.pk_break; in.stream = fs.pk_stream; in.n_bytes = fs.n_chars; in.n_cover = fs.n_cover;
+  const uint64_t n_tiles = (fs.n_chars + Cfg::TILE - 1) / Cfg::TILE;
+  void *p;
+  KMI_TRY(ws_get(ctx, WS_TILE_INFO, sizeof(TileInfo) * (n_tiles + 1), &p)); TileInfo *info = (TileInfo *)p;
+  KMI_TRY(ws_get(ctx, WS_TILE_BASE, sizeof(uint32_t) * (n_tiles + 1), &p)); uint32_t *base = (uint32_t *)p;
+  KMI_TRY(ws_get(ctx, WS_TILE_OFF, sizeof(uint64_t) * (n_tiles + 2), &p)); uint64_t *off = (uint64_t *)p;
+  KMI_TRY(ws_get(ctx, WS_TILE_HDR, sizeof(uint64_t) * (n_tiles + 1), &p)); uint64_t *hdr = (uint64_t *)p;
+  if (n_tiles > 0) {
+    ProfScope ps(ctx, "fasta_count_tiles", fs.n_chars);
+    hipLaunchKernelGGL((fasta_count_tiles_kernel<NW, BITS>), dim3((unsigned)n_tiles), dim3(Cfg::NT), 0, ctx->stream, in, shape.k, info);
+  }
+  KMI_TRY(launch_tile_offsets(ctx, info, n_tiles, (uint32_t)Cfg::TILE, hdr, base, off));
+  if (!count_only && n_tiles > 0) {
+    ProfScope ps(ctx, "fasta_extract", fs.n_chars);
+    const bool canonical = apply_strand && cfg->strand != KMI_STRAND_SINGLE;
+    if (out_ids_dev)
+      hipLaunchKernelGGL((fasta_extract_kernel<NW, BITS, true>), dim3((unsigned)n_tiles), dim3(Cfg::NT), 0, ctx->stream, in, shape, canonical,
+                         fs.ids_by_rank, (const uint64_t *)off, (uint64_t)out_capacity, out_kmers_dev, out_ids_dev, ctx->d_flags);
+    else
+      hipLaunchKernelGGL((fasta_extract_kernel<NW, BITS, false>), dim3((unsigned)n_tiles), dim3(Cfg::NT), 0, ctx->stream, in, shape, canonical,
+                         (const uint64_t *)nullptr, (const uint64_t *)off, (uint64_t)out_capacity, out_kmers_dev, (uint64_t *)nullptr,
+                         ctx->d_flags);
+  }
+  KMI_HIP(ctx, hipGetLastError());
+  uint32_t fl[4] = {0, 0, 0, 0};
+  KMI_HIP(ctx, hipMemcpyAsync(fl, ctx->d_flags, sizeof(fl), hipMemcpyDeviceToHost, ctx->stream));
+  KMI_HIP(ctx, hipMemcpyAsync(ctx->h_totals, ctx->d_totals, sizeof(uint64_t) * 4, hipMemcpyDeviceToHost, ctx->stream));
+  KMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (n_tuples) *n_tuples = ctx->h_totals[1];
+  if (n_seqs) *n_seqs = fs.n_seqs;
+  if (fl[1]) return set_err(ctx, KMI_ERR_OVERFLOW, "extract: output capacity too small");
+  return KMI_OK;
+}
+
+static kmi_status fasta_extract(kmi_ctx *ctx, const kmi_config *cfg, const uint8_t *bytes_dev, size_t n_bytes, KShape shape,
+                                uint64_t file_offset, uint64_t *out_kmers_dev, uint64_t *out_ids_dev, size_t out_capacity, bool apply_strand,
+                                bool count_only, uint64_t *n_tuples, uint64_t *n_seqs) {
+  KMI_DISPATCH(shape, fasta_extract_impl, ctx, cfg, bytes_dev, n_bytes, shape, file_offset, out_kmers_dev, out_ids_dev, out_capacity,
+               apply_strand, count_only, n_tuples, n_seqs);
+}
+
 kmi_status extract_count(kmi_ctx *ctx, const kmi_config *cfg, const uint8_t *bytes_dev, size_t n_bytes,
                          uint64_t *n_tuples, uint64_t *n_seqs) {
   KShape shape;
   if (!valid_config(cfg, &shape)) return set_err(ctx, KMI_ERR_INVALID, "bad kmi_config");
-  if (cfg->seq_format != KMI_FMT_FASTQ) return set_err(ctx, KMI_ERR_INVALID, "only FASTQ is implemented on the device yet");
   if (n_bytes == 0) { if (n_tuples) *n_tuples = 0; if (n_seqs) *n_seqs = 0; return KMI_OK; }
+  if (cfg->seq_format == KMI_FMT_FASTA)
+    return fasta_extract(ctx, cfg, bytes_dev, n_bytes, shape, 0, nullptr, nullptr, 0, false, true, n_tuples, n_seqs);
   KMI_DISPATCH(shape, extract_count_impl, ctx, bytes_dev, n_bytes, shape, n_tuples, n_seqs);
 }
 
@@ -401,8 +504,10 @@ kmi_status extract_run(kmi_ctx *ctx, const kmi_config *cfg, const uint8_t *bytes
                        bool apply_strand, bool scan_done, uint64_t *n_tuples, uint64_t *n_seqs) {
   KShape shape;
   if (!valid_config(cfg, &shape)) return set_err(ctx, KMI_ERR_INVALID, "bad kmi_config");
-  if (cfg->seq_format != KMI_FMT_FASTQ) return set_err(ctx, KMI_ERR_INVALID, "only FASTQ is implemented on the device yet");
   if (n_bytes == 0) { if (n_tuples) *n_tuples = 0; if (n_seqs) *n_seqs = 0; return KMI_OK; }
+  if (cfg->seq_format == KMI_FMT_FASTA)
+    return fasta_extract(ctx, cfg, bytes_dev, n_bytes, shape, file_offset, out_kmers_dev, out_ids_dev, out_capacity, apply_strand, false,
+                         n_tuples, n_seqs);
   KMI_DISPATCH(shape, extract_run_impl, ctx, cfg, bytes_dev, n_bytes, shape, file_offset, out_kmers_dev, out_ids_dev, out_capacity,
                apply_strand, scan_done, n_tuples, n_seqs);
 }

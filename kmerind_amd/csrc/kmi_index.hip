@@ -1438,7 +1438,17 @@ kmi_status kmi_index_build_dev(kmi_index *idx, const uint8_t *bytes_dev, size_t 
   kmi_ctx *ctx = idx->ctx;
   KMI_HIP(ctx, hipSetDevice(ctx->device));
   if (n_bytes == 0) return KMI_OK;
-  if (idx->val_words == 0) return index_build_fused(idx, bytes_dev, n_bytes);
+  if (idx->val_words == 0 && idx->cfg.seq_format == KMI_FMT_FASTQ) return index_build_fused(idx, bytes_dev, n_bytes);
+  if (idx->val_words == 0) {
+    // FASTA count index: tuples from the compacted-stream extract, then the key insert path
+    uint64_t nt = 0, ns = 0;
+    KMI_TRY(extract_count(ctx, &idx->cfg, bytes_dev, n_bytes, &nt, &ns));
+    if (nt == 0) return KMI_OK;
+    void *dk;
+    KMI_TRY(ws_get(ctx, WS_OUTPUT, (size_t)nt * idx->shape.n_words * sizeof(uint64_t), &dk));
+    KMI_TRY(extract_run(ctx, &idx->cfg, bytes_dev, n_bytes, file_offset, (uint64_t *)dk, nullptr, (size_t)nt, true, true, &nt, &ns));
+    return index_insert(idx, (const uint64_t *)dk, (size_t)nt, false);
+  }
   if (idx->val_words != 1) return set_err(ctx, KMI_ERR_INVALID, "build of a position+quality index is not implemented on the device yet");
   // PositionIndex: KmerPositionTupleParser tuples (kmer, ShortSequenceKmerId) -> multimap insert
   const uint32_t nw = idx->shape.n_words;

@@ -34,6 +34,7 @@ enum WsSlot {
   WS_INPUT2,
   WS_MISC,
   WS_TILE_HDR,        // per-tile position of the last record start before the tile
+  WS_FA_IDS,          // LongSequenceKmerId of every compacted FASTA character
   WS_PK_EOL,          // EOL bitmap of the scanned input
   WS_PK_STREAM,       // packed complement-code stream of the scanned input
   WS_NUM_SLOTS
@@ -150,5 +151,15 @@ struct FastqScan {
   const uint8_t *pk_eol, *pk_stream;
 };
 kmi_status fastq_scan(kmi_ctx *ctx, const kmi_config *cfg, const uint8_t *bytes_dev, size_t n_bytes, FastqScan *out);
+
+// FASTA: byte-space passes -> compacted character stream (kmi_fasta.hip)
+struct FastaScan {
+  uint64_t n_chars, n_seqs, n_cover;
+  const uint8_t *pk_break;     // bit r: character r is the first of a record
+  const uint8_t *pk_stream;    // BITS per character, complement codes
+  const uint64_t *ids_by_rank; // or null
+};
+kmi_status fasta_scan(kmi_ctx *ctx, const kmi_config *cfg, const uint8_t *bytes_dev, size_t n_bytes, uint64_t file_offset, bool want_ids,
+                      FastaScan *out);
 
 }  // namespace kmi

@@ -430,54 +430,51 @@ long orc_fastq_records(const uint8_t *bytes, size_t n, uint64_t file_offset,
   return count;
 }
 
-/* FASTAParser: header lines start with '>' or ';' at a line start; the sequence
- * is every byte from the end of the (last consecutive) header line up to the
- * next header line start, EOLs included (src/io/fasta_loader.hpp:485-604 builds
- * the (rec_start, seq_start, seq_end, seq_id) tuples; :618-723 serves them).
+/* FASTAParser::init_parser (serial form, src/io/fasta_loader.hpp:485-604) restated literally:
+ *  - a line start is the buffer start and every byte that follows a '\n' (a '\r' does not end a line);
+ *    its flag is 1 when the byte there is '>' or ';';
+ *  - a sentinel (end, 1) is appended and runs of equal flags are collapsed (std::unique);
+ *  - if the first group is a non-header group it is skipped;
+ *  - then (header start, first non-header line start, next header start) triples are emitted with
+ *    sequence index k/2 (k = position of the middle element in the collapsed list), so a leading
+ *    orphan group shifts the indices by one;
+ * get_next_record (:618-723) serves [pos2, pos3) as the sequence of record (pos, index).
  * Whole-buffer (single partition) form. */
 long orc_fasta_records(const uint8_t *bytes, size_t n, uint64_t file_offset,
                        orc_record *out, size_t out_cap) {
+  if (n == 0) return 0;
+  /* collapsed (position, flag) list */
+  size_t cap = 16, m = 0;
+  size_t *pos = (size_t *)malloc(cap * sizeof(size_t));
+  uint8_t *flg = (uint8_t *)malloc(cap);
+#define FA_PUSH(P, F) do { uint8_t f__ = (F); if (m == 0 || flg[m - 1] != f__) { \
+    if (m == cap) { cap *= 2; pos = (size_t *)realloc(pos, cap * sizeof(size_t)); flg = (uint8_t *)realloc(flg, cap); } \
+    pos[m] = (P); flg[m] = f__; ++m; } } while (0)
+  FA_PUSH(0, (bytes[0] == ';' || bytes[0] == '>') ? 1 : 0);
+  for (size_t i = 1; i < n; ++i)
+    if (bytes[i - 1] == '\n') FA_PUSH(i, (bytes[i] == ';' || bytes[i] == '>') ? 1 : 0);
+  FA_PUSH(n, 1);
+#undef FA_PUSH
   long count = 0;
-  size_t i = 0;
-  /* locate header line starts */
-  while (i < n) {
-    /* i is at a line start */
-    if (bytes[i] == '>' || bytes[i] == ';') {
-      size_t rec_start = i;
-      /* consume consecutive header lines */
-      size_t j = i;
-      while (j < n && (bytes[j] == '>' || bytes[j] == ';')) {
-        j = find_eol(bytes, j, n);
-        /* step over exactly the EOL run that ends this header line */
-        j = find_non_eol(bytes, j, n);
-      }
-      size_t seq_start = j;
-      /* sequence runs to next header line start */
-      size_t e = seq_start;
-      while (e < n) {
-        size_t le = find_eol(bytes, e, n);
-        size_t nx = find_non_eol(bytes, le, n);
-        e = nx;
-        if (nx < n && (bytes[nx] == '>' || bytes[nx] == ';')) break;
-      }
-      size_t seq_end = e; /* start of next header, or n */
-      if (out && (size_t)count < out_cap) {
-        orc_record *r = &out[count];
-        r->record_offset = file_offset + rec_start;
-        r->record_size = seq_end - rec_start;
-        r->seq_begin = file_offset + seq_start;
-        r->seq_end = file_offset + seq_end;
-        r->qual_begin = r->qual_end = 0;
-        r->seq_index = (uint64_t)count;
-      }
-      ++count;
-      i = seq_end;
-    } else {
-      /* bytes before the first header: skip the line */
-      i = find_eol(bytes, i, n);
-      i = find_non_eol(bytes, i, n);
+  size_t k = 0;
+  if (flg[k] == 0) ++k;
+  size_t p0 = (k < m) ? pos[k] : n;
+  ++k;
+  for (; k + 1 < m; k += 2) {
+    size_t p2 = pos[k], p3 = pos[k + 1];
+    if (out && (size_t)count < out_cap) {
+      orc_record *r = &out[count];
+      r->record_offset = file_offset + p0;
+      r->record_size = p3 - p0;
+      r->seq_begin = file_offset + p2;
+      r->seq_end = file_offset + p3;
+      r->qual_begin = r->qual_end = 0;
+      r->seq_index = (uint64_t)(k / 2);
     }
+    ++count;
+    p0 = p3;
   }
+  free(pos); free(flg);
   return count;
 }
 

@@ -1,0 +1,133 @@
+"""GPU parity of the FASTA path: init_parser record rules, k-mer windows across line breaks,
+LongSequenceKmerId, count / position index builds -- against the oracle and the reference's
+TestFileInfo table (src/io/test/mpi_test_fasta_seq_parse.cpp:398-403)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from tests import oracle as orc
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+ALPHA = {"DNA": orc.DNA, "DNA5": orc.DNA5}
+FILES = ["test.fasta", "test2.fasta", "natural.fasta", "natural.withN.fasta", "test.unitiqs.fasta"]
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import kmerind_amd as K
+    c = K.Context(0)
+    yield c
+    c.close()
+
+
+def test_reference_table_counts(ctx):
+    import kmerind_amd as K
+    pg = json.load(open(os.path.join(GOLD, "parse_golden.json")))["fasta"]
+    cfg = K.make_config(pg["k"], "DNA5", seq_format="fasta")
+    n = 0
+    for e in pg["files"]:
+        path = os.path.join(GOLD, "data", e["file"])
+        if not os.path.exists(path):
+            continue
+        kmers, nseq = ctx.read_file(cfg, open(path, "rb").read())
+        assert (nseq, kmers.shape[0]) == (e["records"], e["kmers"]), e
+        n += 1
+    assert n >= 4
+
+
+@pytest.mark.parametrize("k,alpha", [(31, "DNA"), (35, "DNA5"), (63, "DNA5"), (63, "DNA"), (4, "DNA"), (1, "DNA5")])
+def test_extract_matches_oracle_on_reference_files(ctx, k, alpha):
+    import kmerind_amd as K
+    s = orc.kspec(k, ALPHA[alpha])
+    cfg = K.make_config(k, alpha, seq_format="fasta", index_kind="position")
+    for name in FILES:
+        data = open(os.path.join(GOLD, "data", name), "rb").read()
+        for off in (0, 1 << 35):
+            ex = orc.extract(s, data, orc.FASTA, file_offset=off, want_ids=True)
+            kmers, ids, nseq = ctx.read_file(cfg, data, file_offset=off, with_ids=True)
+            assert nseq == ex["n_seqs"], name
+            assert kmers.shape == ex["kmers"].shape, name
+            assert (kmers == ex["kmers"]).all(), name
+            assert (ids == ex["ids"]).all(), name
+
+
+def _synthetic_fasta(rng, n_rec, line=80, eol=b"\n", orphan=False, max_len=3000):
+    out = []
+    if orphan:
+        out.append(b"ACGTACGT" + eol + b"TTTT" + eol)
+    for i in range(n_rec):
+        out.append(b">chr%d some description" % i + eol)
+        if i % 11 == 3:
+            out.append(b";a comment line that belongs to the header group" + eol)
+        ln = int(rng.integers(0, max_len)) if i % 5 else int(rng.integers(0, 70))
+        seq = bytes(rng.choice(list(b"ACGTNacgt-"), size=ln, p=[.23, .23, .23, .23, .02, .015, .015, .015, .01, .005]).tolist())
+        w = line if i % 3 else int(rng.integers(1, 30))
+        for j in range(0, ln, w):
+            out.append(seq[j:j + w] + eol)
+        if i % 7 == 0:
+            out.append(eol)              # blank line inside the sequence group
+    return b"".join(out)
+
+
+@pytest.mark.parametrize("eol,orphan", [(b"\n", False), (b"\r\n", False), (b"\n", True)])
+@pytest.mark.parametrize("k,alpha", [(31, "DNA"), (63, "DNA5"), (21, "DNA5")])
+def test_extract_synthetic_multiline(ctx, k, alpha, eol, orphan):
+    import kmerind_amd as K
+    rng = np.random.default_rng(k + len(eol))
+    data = _synthetic_fasta(rng, 120, eol=eol, orphan=orphan)
+    s = orc.kspec(k, ALPHA[alpha])
+    ex = orc.extract(s, data, orc.FASTA, want_ids=True)
+    cfg = K.make_config(k, alpha, seq_format="fasta", index_kind="position")
+    kmers, ids, nseq = ctx.read_file(cfg, data, with_ids=True)
+    assert nseq == ex["n_seqs"] and kmers.shape == ex["kmers"].shape
+    assert (kmers == ex["kmers"]).all()
+    assert (ids == ex["ids"]).all()
+
+
+def test_fasta_edge_cases(ctx):
+    import kmerind_amd as K
+    s = orc.kspec(5, orc.DNA)
+    cfg = K.make_config(5, "DNA", seq_format="fasta", index_kind="position")
+    cases = [b">only a header\n", b"no header at all\nACGTACGT\n", b">a\nACG\n>b\nACGTACGTAC\n>c\n\n>d\nAAAAAA",
+             b">a\rACGTACGT\r>b\rTTTTTTTT\r",            # '\r' alone does not end a line
+             b">a\n" + b"ACGTTGCA" * 3000 + b"\n",        # one long line, many tiles
+             b">a\n" + b"A\n" * 5000]                     # one base per line
+    for data in cases:
+        ex = orc.extract(s, data, orc.FASTA, want_ids=True)
+        kmers, ids, nseq = ctx.read_file(cfg, data, with_ids=True)
+        assert nseq == ex["n_seqs"], data[:30]
+        assert kmers.shape == ex["kmers"].shape, data[:30]
+        assert (kmers == ex["kmers"]).all() and (ids == ex["ids"]).all(), data[:30]
+
+
+def test_fasta_count_and_position_index(ctx):
+    import kmerind_amd as K
+    rng = np.random.default_rng(8)
+    base = _synthetic_fasta(rng, 40, max_len=1500)
+    data = base + base.replace(b">chr", b">dup")          # every sequence twice
+    for k, alpha in ((31, "DNA"), (63, "DNA5")):
+        s = orc.kspec(k, ALPHA[alpha])
+        ex = orc.extract(s, data, orc.FASTA, want_ids=True)
+        om = orc.CountMap(s, orc.CANONICAL)
+        om.insert(ex["kmers"])
+        idx = K.CountIndex(ctx, K.make_config(k, alpha, seq_format="fasta"))
+        idx.build(data)
+        gk, gc = idx.to_vector()
+        ok, oc = om.export()
+        a, b = orc.sorted_pairs(gk, gc), orc.sorted_pairs(ok, oc)
+        assert a[0].shape == b[0].shape and (a[0] == b[0]).all() and (a[1] == b[1]).all()
+        idx.close()
+        mm = orc.MultiMap(s, orc.CANONICAL)
+        mm.insert(ex["kmers"], ex["ids"])
+        pidx = K.PositionIndex(ctx, K.make_config(k, alpha, seq_format="fasta", index_kind="position"))
+        pidx.build(data)
+        pk, pv = pidx.to_vector()
+        mk, mv = mm.export()
+        assert (orc.sorted_rows(pk, pv) == orc.sorted_rows(mk, mv)).all()
+        fk, fv = pidx.find(ex["kmers"][:200])
+        ek, ev = mm.find(ex["kmers"][:200])
+        assert (orc.sorted_rows(fk, fv) == orc.sorted_rows(ek, ev)).all()
+        pidx.close()
