@@ -111,7 +111,7 @@ class Context:
         return out
 
     # ---- KmerFileHelper::read_file_* equivalent on an in-memory, record-aligned partition
-    def read_file(self, cfg, data, file_offset=0, with_ids=False):
+    def read_file(self, cfg, data, file_offset=0, with_ids=False, with_quals=False):
         """returns (kmers[n, n_words], n_seqs) in file order, as parsed (no strand transform);
         with_ids (position index kinds): (kmers, ids, n_seqs), ids = Short/LongSequenceKmerId words"""
         buf = np.frombuffer(bytes(data), dtype=np.uint8) if isinstance(data, (bytes, bytearray)) else \
@@ -130,7 +130,17 @@ class Context:
                 lib.kmi_tuples_free(C.byref(t))
                 raise ValueError("ids need a position index kind in the config")
             ids = np.ctypeslib.as_array(t.ids, shape=(n,)).copy() if n else np.zeros(0, dtype=np.uint64)
+        if with_quals and not with_ids:
+            with_ids = True
+        quals = None
+        if with_quals:
+            if not t.quals:
+                lib.kmi_tuples_free(C.byref(t))
+                raise ValueError("qualities need index_kind='posqual'")
+            quals = np.ctypeslib.as_array(t.quals, shape=(n,)).copy() if n else np.zeros(0, dtype=np.float32)
         lib.kmi_tuples_free(C.byref(t))
+        if with_quals:
+            return kmers, ids, quals, nseq
         if with_ids:
             return kmers, ids, nseq
         return kmers, nseq

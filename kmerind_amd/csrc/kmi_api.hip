@@ -153,6 +153,7 @@ kmi_status kmi_ctx_create(int device, int rank, int nranks, void *stream, kmi_ct
     return KMI_ERR_DEVICE;
   }
   (void)hipMemset(ctx->d_flags, 0, sizeof(uint32_t) * 16);
+  if (upload_quality_lut(ctx) != KMI_OK) { kmi_ctx_destroy(ctx); return KMI_ERR_DEVICE; }
   (void)hipMemset(ctx->d_totals, 0, sizeof(uint64_t) * 16);
   *out = ctx;
   return KMI_OK;
@@ -267,19 +268,23 @@ kmi_status kmi_extract_host(kmi_ctx *ctx, const kmi_config *cfg, const uint8_t *
   KMI_HIP(ctx, hipMemcpyAsync(din, bytes, n_bytes, hipMemcpyHostToDevice, ctx->stream));
   uint64_t nt = 0, ns = 0;
   KMI_TRY(extract_count(ctx, cfg, (const uint8_t *)din, n_bytes, &nt, &ns));
-  void *dout, *dids = nullptr;
+  void *dout, *dids = nullptr, *dq = nullptr;
   const size_t out_bytes = (size_t)nt * shape.n_words * sizeof(uint64_t);
   const bool want_ids = cfg->index_kind != KMI_INDEX_COUNT;
+  const bool want_quals = cfg->index_kind == KMI_INDEX_POSQUAL;
   KMI_TRY(ws_get(ctx, WS_OUTPUT, out_bytes, &dout));
   if (want_ids) KMI_TRY(ws_get(ctx, WS_OUTPUT2, (size_t)nt * sizeof(uint64_t), &dids));
+  if (want_quals) KMI_TRY(ws_get(ctx, WS_INPUT2, (size_t)nt * sizeof(float) + 16, &dq));
   KMI_TRY(extract_run(ctx, cfg, (const uint8_t *)din, n_bytes, file_offset, (uint64_t *)dout, (uint64_t *)dids, (size_t)nt, false, true,
-                      &nt, &ns));
+                      &nt, &ns, (float *)dq));
   out->n_tuples = nt; out->n_seqs = ns;
   out->kmers = (uint64_t *)malloc(out_bytes ? out_bytes : 8);
   if (want_ids) out->ids = (uint64_t *)malloc(nt ? nt * sizeof(uint64_t) : 8);
-  if (!out->kmers || (want_ids && !out->ids)) return set_err(ctx, KMI_ERR_NOMEM, "host malloc failed");
+  if (want_quals) out->quals = (float *)malloc(nt ? nt * sizeof(float) : 8);
+  if (!out->kmers || (want_ids && !out->ids) || (want_quals && !out->quals)) return set_err(ctx, KMI_ERR_NOMEM, "host malloc failed");
   if (out_bytes) KMI_HIP(ctx, hipMemcpyAsync(out->kmers, dout, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
   if (want_ids && nt) KMI_HIP(ctx, hipMemcpyAsync(out->ids, dids, nt * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+  if (want_quals && nt) KMI_HIP(ctx, hipMemcpyAsync(out->quals, dq, nt * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
   KMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return KMI_OK;
 }

@@ -22,6 +22,8 @@
 //     fully coalesced stores.
 // Every thread owns C consecutive bytes (16 for one-word k-mers): one 16-byte global load,
 // all later indexing is compile-time so nothing spills.
+#include <math.h>
+
 #include "kmi_extract.h"
 
 namespace kmi {
@@ -252,11 +254,83 @@ __global__ __launch_bounds__((ExCfg<NW, BITS>::NT)) void fasta_count_tiles_kerne
   }
 }
 
+// ---------------------------------------------------------------------------
+// k-mer quality (PositionQualityIndex): QualityScoreSlidingWindow<.., Illumina18QualityScoreCodec<float>>
+// (src/index/quality_score_iterator.hpp:67-173, src/index/quality_scores.hpp:88-341,529).
+// The value is a sequential float running sum (add the entering log2-probability, subtract the
+// leaving one) followed by exp2, so it is replayed in exactly that order: one lane walks one read.
+// Reads are found by the extract pass: the lane that owns the first window of a read records
+// (position of the read's first base, output offset of its first tuple).
+// ---------------------------------------------------------------------------
+__constant__ float c_qual_lut[96];
+__constant__ uint64_t c_exp2_tab[32];   // T[i] = bits(2^(i/32)) - (i << 47)
+
+// std::exp2(float) as the reference's libm computes it: the published exp2f of glibc >= 2.27
+// (Szabolcs Nagy / ARM optimized routines): x = k/32 + r, 2^x = 2^(k/32) * p(r) in double,
+// p(r) = C0 r^3 + C1 r^2 + C2 r + 1, one rounding to float at the end. tests/cpu/exp2f_check.c
+// compares the same restatement with the host libm on 2e7 inputs.
+__device__ __forceinline__ float exp2f_libm(float x) {
+  if (x <= -150.0f) return 0.0f;
+  const double C0 = 0x1.c6af84b912394p-5, C1 = 0x1.ebfce50fac4f3p-3, C2 = 0x1.62e42ff0c52d6p-1;
+  const double SHIFT = 0x1.8p+52 / 32;
+  const double xd = (double)x;
+  double kd = xd + SHIFT;
+  const uint64_t ki = (uint64_t)__double_as_longlong(kd);
+  kd -= SHIFT;
+  const double r = xd - kd;
+  const uint64_t t = c_exp2_tab[ki & 31u] + (ki << (52 - 5));
+  const double sc = __longlong_as_double((long long)t);
+  const double z = fma(C0, r, C1);
+  const double r2 = r * r;
+  double y = fma(C2, r, 1.0);
+  y = fma(z, r2, y);
+  y = y * sc;
+  return (float)y;
+}
+
+struct ReadDesc { uint64_t seq_pos, out_off; };
+
+__global__ __launch_bounds__(256) void fastq_quality_kernel(const uint8_t *__restrict__ bytes, uint64_t n_bytes, uint32_t k,
+                                                           const ReadDesc *__restrict__ reads, const uint32_t *__restrict__ n_reads,
+                                                           float *__restrict__ out) {
+  const uint64_t nr = *n_reads;
+  for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < nr; r += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t sp = reads[r].seq_pos;
+    uint64_t o = reads[r].out_off;
+    uint64_t len = 0;
+    while (sp + len < n_bytes && !is_eol(bytes[sp + len])) ++len;
+    uint64_t q = sp + len;
+    while (q < n_bytes && is_eol(bytes[q])) ++q;       // to the '+' line
+    while (q < n_bytes && !is_eol(bytes[q])) ++q;      // over it
+    while (q < n_bytes && is_eol(bytes[q])) ++q;       // to the quality line
+    auto decode = [&](uint64_t i) -> float {
+      const uint64_t p = q + i;
+      if (p >= n_bytes) return c_qual_lut[0];
+      const uint32_t c = bytes[p];
+      return (c >= 33u && c < 33u + 96u) ? c_qual_lut[c - 33u] : c_qual_lut[0];
+    };
+    const float lo = c_qual_lut[0], hi = c_qual_lut[95];
+    float sum = 0.0f;
+    uint32_t bad = 0;
+    for (uint32_t i = 0; i < k; ++i) {               // init(): quality_score_iterator.hpp:99-115
+      const float v = decode(i);
+      if (v > lo && v < hi) sum += v; else ++bad;
+    }
+    out[o++] = bad ? 0.0f : exp2f_libm(sum);  // getValue(): :166-173
+    for (uint64_t j = k; j < len; ++j) {              // next(): :127-159
+      const float ov = decode(j - k), nv = decode(j);
+      if (ov > lo && ov < hi) sum -= ov; else --bad;
+      if (nv > lo && nv < hi) sum += nv; else ++bad;
+      out[o++] = bad ? 0.0f : exp2f_libm(sum);
+    }
+  }
+}
+
 template <int NW, int BITS, bool WITH_IDS>
 __global__ __launch_bounds__((ExCfg<NW, BITS>::NT)) void fastq_extract_kernel(
     PackedInput in, KShape shape, bool canonical, const uint32_t *__restrict__ line_base, const uint64_t *__restrict__ hdr_base,
     uint64_t file_offset, const uint64_t *__restrict__ out_off, uint64_t out_capacity, uint64_t *__restrict__ out_kmers,
-    uint64_t *__restrict__ out_ids, uint32_t *__restrict__ flags) {
+    uint64_t *__restrict__ out_ids, ReadDesc *__restrict__ reads, uint32_t *__restrict__ n_reads, uint32_t *__restrict__ flags) {
   using Cfg = ExCfg<NW, BITS>;
   __shared__ uint32_t s_eol[Cfg::EOL_DW];
   __shared__ uint32_t s_stream[Cfg::STREAM_DW];
@@ -264,9 +338,11 @@ __global__ __launch_bounds__((ExCfg<NW, BITS>::NT)) void fastq_extract_kernel(
   __shared__ uint16_t s_pos[Cfg::TILE];
   __shared__ uint16_t s_hmask[WITH_IDS ? Cfg::NT : 1];   // record-start bits of every chunk
   __shared__ uint16_t s_hexcl[WITH_IDS ? Cfg::NT : 1];   // 1 + tile position of the last record start in earlier chunks
+  __shared__ uint16_t s_lsmask[WITH_IDS ? Cfg::NT : 1];  // line-start bits of every chunk
   uint32_t eol, ls, lbl, ltot;
   tile_front_packed<Cfg>(in, blockIdx.x, s_eol, s_stream, s_scan, eol, ls, lbl, ltot);
   const uint32_t lines_before = line_base[blockIdx.x] + lbl;
+  if (WITH_IDS) s_lsmask[threadIdx.x] = (uint16_t)ls;
   if (WITH_IDS) {
     // record starts = line starts whose line index % 4 == 0 (the '@' line)
     uint32_t cur = lines_before, rest = ls, hm = 0, hlast = 0;
@@ -304,6 +380,12 @@ __global__ __launch_bounds__((ExCfg<NW, BITS>::NT)) void fastq_extract_kernel(
       const uint64_t rec_off = file_offset + rec - 1u, d = tile0 + pos - (rec - 1u);
       if (rec == 0 || d > 0xFFFFu) atomicOr(&flags[3], 1u);   // ShortSequenceKmerId increment overflow (sequence.hpp:177-183)
       out_ids[base + q] = ((rec_off & 0xFFFFFFFFFFull) << 16) | (d & 0xFFFFull);
+      // first window of its read (the window starts on the line start of the sequence line)
+      if (reads && ((s_lsmask[j] >> p) & 1u)) {
+        const uint32_t slot = atomicAdd(n_reads, 1u);
+        ReadDesc rd; rd.seq_pos = tile0 + pos; rd.out_off = base + q;
+        reads[slot] = rd;
+      }
     }
   }
 }
@@ -395,7 +477,8 @@ static kmi_status extract_count_impl(kmi_ctx *ctx, const uint8_t *bytes_dev, siz
 template <int NW, int BITS>
 static kmi_status extract_run_impl(kmi_ctx *ctx, const kmi_config *cfg, const uint8_t *bytes_dev, size_t n_bytes,
                                    KShape shape, uint64_t file_offset, uint64_t *out_kmers_dev, uint64_t *out_ids_dev,
-                                   size_t out_capacity, bool apply_strand, bool scan_done, uint64_t *n_tuples, uint64_t *n_seqs) {
+                                   float *out_quals_dev, size_t out_capacity, bool apply_strand, bool scan_done, uint64_t *n_tuples,
+                                   uint64_t *n_seqs) {
   using Cfg = ExCfg<NW, BITS>;
   ScanResult r;
   if (!scan_done) KMI_HIP(ctx, hipMemsetAsync(ctx->d_flags, 0, sizeof(uint32_t) * 16, ctx->stream));
@@ -403,14 +486,28 @@ static kmi_status extract_run_impl(kmi_ctx *ctx, const kmi_config *cfg, const ui
   if (r.n_tiles > 0) {
     ProfScope ps(ctx, "fastq_extract", n_bytes);
     const bool canonical = apply_strand && cfg->strand != KMI_STRAND_SINGLE;
+    ReadDesc *reads = nullptr;
+    uint32_t *n_reads = ctx->d_flags + 8;
+    if (out_quals_dev) {
+      // one descriptor per read that has at least one window; sequences <= lines / 4 + 1
+      void *pr;
+      KMI_TRY(ws_get(ctx, WS_READS, sizeof(ReadDesc) * (n_bytes / 4 + 16), &pr));
+      reads = (ReadDesc *)pr;
+    }
     if (out_ids_dev) {
       hipLaunchKernelGGL((fastq_extract_kernel<NW, BITS, true>), dim3((unsigned)r.n_tiles), dim3(Cfg::NT), 0, ctx->stream,
                          r.packed, shape, canonical, (const uint32_t *)r.line_base, (const uint64_t *)r.hdr_base, file_offset,
-                         (const uint64_t *)r.out_off, (uint64_t)out_capacity, out_kmers_dev, out_ids_dev, ctx->d_flags);
+                         (const uint64_t *)r.out_off, (uint64_t)out_capacity, out_kmers_dev, out_ids_dev, reads, n_reads, ctx->d_flags);
     } else {
       hipLaunchKernelGGL((fastq_extract_kernel<NW, BITS, false>), dim3((unsigned)r.n_tiles), dim3(Cfg::NT), 0, ctx->stream,
                          r.packed, shape, canonical, (const uint32_t *)r.line_base, (const uint64_t *)r.hdr_base, file_offset,
-                         (const uint64_t *)r.out_off, (uint64_t)out_capacity, out_kmers_dev, (uint64_t *)nullptr, ctx->d_flags);
+                         (const uint64_t *)r.out_off, (uint64_t)out_capacity, out_kmers_dev, (uint64_t *)nullptr, (ReadDesc *)nullptr,
+                         (uint32_t *)nullptr, ctx->d_flags);
+    }
+    if (out_quals_dev) {
+      ProfScope pq(ctx, "fastq_quality", n_bytes);
+      hipLaunchKernelGGL(fastq_quality_kernel, dim3(2048), dim3(256), 0, ctx->stream, bytes_dev, (uint64_t)n_bytes, shape.k,
+                         (const ReadDesc *)reads, (const uint32_t *)n_reads, out_quals_dev);
     }
   }
   KMI_HIP(ctx, hipGetLastError());
@@ -489,6 +586,24 @@ static kmi_status fasta_extract(kmi_ctx *ctx, const kmi_config *cfg, const uint8
                apply_strand, count_only, n_tuples, n_seqs);
 }
 
+// Illumina18QualityScoreCodec<float>::DecodeLUT by its generating formula (quality_scores.hpp:111-112):
+// log2(1 - 10^(-q/10)) in long double, entry 0 = lowest(), entries 94 and 95 = 0
+kmi_status upload_quality_lut(kmi_ctx *ctx) {
+  float lut[96];
+  lut[0] = -3.402823466e+38F;
+  for (int q = 1; q < 94; ++q) lut[q] = (float)(double)log2l(1.0L - exp2l((long double)q * log2l(10.0L) / (-10.0L)));
+  lut[94] = 0.0f; lut[95] = 0.0f;
+  KMI_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(c_qual_lut), lut, sizeof(lut)));
+  uint64_t tab[32];
+  for (int i = 0; i < 32; ++i) {
+    const double v = (double)exp2l((long double)i / 32.0L);
+    uint64_t u; memcpy(&u, &v, sizeof(u));
+    tab[i] = u - ((uint64_t)i << 47);
+  }
+  KMI_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(c_exp2_tab), tab, sizeof(tab)));
+  return KMI_OK;
+}
+
 kmi_status extract_count(kmi_ctx *ctx, const kmi_config *cfg, const uint8_t *bytes_dev, size_t n_bytes,
                          uint64_t *n_tuples, uint64_t *n_seqs) {
   KShape shape;
@@ -501,15 +616,17 @@ kmi_status extract_count(kmi_ctx *ctx, const kmi_config *cfg, const uint8_t *byt
 
 kmi_status extract_run(kmi_ctx *ctx, const kmi_config *cfg, const uint8_t *bytes_dev, size_t n_bytes,
                        uint64_t file_offset, uint64_t *out_kmers_dev, uint64_t *out_ids_dev, size_t out_capacity,
-                       bool apply_strand, bool scan_done, uint64_t *n_tuples, uint64_t *n_seqs) {
+                       bool apply_strand, bool scan_done, uint64_t *n_tuples, uint64_t *n_seqs, float *out_quals_dev) {
   KShape shape;
   if (!valid_config(cfg, &shape)) return set_err(ctx, KMI_ERR_INVALID, "bad kmi_config");
   if (n_bytes == 0) { if (n_tuples) *n_tuples = 0; if (n_seqs) *n_seqs = 0; return KMI_OK; }
+  if (out_quals_dev && (!out_ids_dev || cfg->seq_format != KMI_FMT_FASTQ))
+    return set_err(ctx, KMI_ERR_INVALID, "k-mer qualities need FASTQ input and are produced together with the ids");
   if (cfg->seq_format == KMI_FMT_FASTA)
     return fasta_extract(ctx, cfg, bytes_dev, n_bytes, shape, file_offset, out_kmers_dev, out_ids_dev, out_capacity, apply_strand, false,
                          n_tuples, n_seqs);
-  KMI_DISPATCH(shape, extract_run_impl, ctx, cfg, bytes_dev, n_bytes, shape, file_offset, out_kmers_dev, out_ids_dev, out_capacity,
-               apply_strand, scan_done, n_tuples, n_seqs);
+  KMI_DISPATCH(shape, extract_run_impl, ctx, cfg, bytes_dev, n_bytes, shape, file_offset, out_kmers_dev, out_ids_dev, out_quals_dev,
+               out_capacity, apply_strand, scan_done, n_tuples, n_seqs);
 }
 
 }  // namespace kmi

@@ -1423,13 +1423,15 @@ kmi_status kmi_index_insert_host(kmi_index *idx, const uint64_t *kmers, size_t n
 }
 
 // records (key, id) of a FASTQ partition for the position index
-__global__ __launch_bounds__(256) void interleave_records_kernel(const uint64_t *__restrict__ keys, const uint64_t *__restrict__ ids, uint64_t n,
-                                                                uint32_t nw, uint32_t vw, uint64_t *__restrict__ recs) {
+__global__ __launch_bounds__(256) void interleave_records_kernel(const uint64_t *__restrict__ keys, const uint64_t *__restrict__ ids,
+                                                                const float *__restrict__ quals, uint64_t n, uint32_t nw, uint32_t vw,
+                                                                uint64_t *__restrict__ recs) {
   const uint32_t rw = nw + vw;
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
     for (uint32_t w = 0; w < nw; ++w) recs[i * rw + w] = keys[i * nw + w];
     recs[i * rw + nw] = ids[i];
-    for (uint32_t w = 1; w < vw; ++w) recs[i * rw + nw + w] = 0;
+    // std::pair<id, float>: the float sits in the low half of the second word, padding above it is zero
+    if (vw > 1) recs[i * rw + nw + 1] = quals ? (uint64_t)__float_as_uint(quals[i]) : 0ull;
   }
 }
 
@@ -1449,19 +1451,20 @@ kmi_status kmi_index_build_dev(kmi_index *idx, const uint8_t *bytes_dev, size_t 
     KMI_TRY(extract_run(ctx, &idx->cfg, bytes_dev, n_bytes, file_offset, (uint64_t *)dk, nullptr, (size_t)nt, true, true, &nt, &ns));
     return index_insert(idx, (const uint64_t *)dk, (size_t)nt, false);
   }
-  if (idx->val_words != 1) return set_err(ctx, KMI_ERR_INVALID, "build of a position+quality index is not implemented on the device yet");
-  // PositionIndex: KmerPositionTupleParser tuples (kmer, ShortSequenceKmerId) -> multimap insert
-  const uint32_t nw = idx->shape.n_words;
+  // PositionIndex / PositionQualityIndex: KmerPosition(Quality)TupleParser tuples -> multimap insert
+  const uint32_t nw = idx->shape.n_words, vw = idx->val_words;
   uint64_t nt = 0, ns = 0;
   KMI_TRY(extract_count(ctx, &idx->cfg, bytes_dev, n_bytes, &nt, &ns));
   if (nt == 0) return KMI_OK;
-  void *dk, *di, *dr;
+  void *dk, *di, *dr, *dq = nullptr;
   KMI_TRY(ws_get(ctx, WS_OUTPUT, (size_t)nt * nw * sizeof(uint64_t), &dk));
   KMI_TRY(ws_get(ctx, WS_OUTPUT2, (size_t)nt * sizeof(uint64_t), &di));
-  KMI_TRY(extract_run(ctx, &idx->cfg, bytes_dev, n_bytes, file_offset, (uint64_t *)dk, (uint64_t *)di, (size_t)nt, false, true, &nt, &ns));
-  KMI_TRY(ws_get(ctx, WS_INPUT2, (size_t)nt * (nw + 1) * sizeof(uint64_t), &dr));
-  hipLaunchKernelGGL(interleave_records_kernel, dim3(2048), dim3(256), 0, ctx->stream, (const uint64_t *)dk, (const uint64_t *)di, nt, nw, 1u,
-                     (uint64_t *)dr);
+  if (vw == 2) KMI_TRY(ws_get(ctx, WS_QUALS, (size_t)nt * sizeof(float) + 16, &dq));
+  KMI_TRY(extract_run(ctx, &idx->cfg, bytes_dev, n_bytes, file_offset, (uint64_t *)dk, (uint64_t *)di, (size_t)nt, false, true, &nt, &ns,
+                      (float *)dq));
+  KMI_TRY(ws_get(ctx, WS_INPUT2, (size_t)nt * (nw + vw) * sizeof(uint64_t), &dr));
+  hipLaunchKernelGGL(interleave_records_kernel, dim3(2048), dim3(256), 0, ctx->stream, (const uint64_t *)dk, (const uint64_t *)di,
+                     (const float *)dq, nt, nw, vw, (uint64_t *)dr);
   KMI_HIP(ctx, hipGetLastError());
   return index_insert_records(idx, (const uint64_t *)dr, (size_t)nt, true);
 }

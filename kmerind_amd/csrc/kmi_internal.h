@@ -34,6 +34,8 @@ enum WsSlot {
   WS_INPUT2,
   WS_MISC,
   WS_TILE_HDR,        // per-tile position of the last record start before the tile
+  WS_QUALS,           // k-mer qualities of the extracted tuples
+  WS_READS,           // read descriptors for the quality pass
   WS_FA_IDS,          // LongSequenceKmerId of every compacted FASTA character
   WS_PK_EOL,          // EOL bitmap of the scanned input
   WS_PK_STREAM,       // packed complement-code stream of the scanned input
@@ -142,7 +144,8 @@ kmi_status extract_count(kmi_ctx *ctx, const kmi_config *cfg, const uint8_t *byt
                          uint64_t *n_tuples, uint64_t *n_seqs);
 kmi_status extract_run(kmi_ctx *ctx, const kmi_config *cfg, const uint8_t *bytes_dev, size_t n_bytes,
                        uint64_t file_offset, uint64_t *out_kmers_dev, uint64_t *out_ids_dev, size_t out_capacity,
-                       bool apply_strand, bool scan_done, uint64_t *n_tuples, uint64_t *n_seqs);
+                       bool apply_strand, bool scan_done, uint64_t *n_tuples, uint64_t *n_seqs, float *out_quals_dev = nullptr);
+kmi_status upload_quality_lut(kmi_ctx *ctx);
 
 // tile scan of a FASTQ partition; the packed arrays and per-tile line bases stay in the workspace
 struct FastqScan {

@@ -93,7 +93,29 @@ def parse_golden():
     return out
 
 
+def quality_lut():
+    """Illumina18QualityScoreCodec<float>::DecodeLUT (src/index/quality_scores.hpp:113-211) as data:
+    96 values; entry 0 = lowest(); MinScore = 0 keeps the literals of entries 1 and 2."""
+    src = open(os.path.join(REF, "src/index/quality_scores.hpp")).read()
+    b = _block(src, "static constexpr LUTType DecodeLUT = {{", "}};")
+    vals = []
+    for line in b.splitlines()[1:]:
+        line = line.split("//")[0].strip().rstrip(",")
+        if not line:
+            continue
+        if "lowest()" in line and "?" not in line:
+            vals.append("lowest")
+        elif "?" in line:
+            vals.append(line.split(":")[-1].strip())
+        else:
+            vals.append(line)
+    assert len(vals) == 96, len(vals)
+    return {"source": "src/index/quality_scores.hpp:113-211", "codec": "QualityScoreCodec<float,33,126,0>", "decode_lut": vals}
+
+
 def main():
+    with open(os.path.join(HERE, "quality_lut.json"), "w") as f:
+        json.dump(quality_lut(), f, indent=1)
     with open(os.path.join(HERE, "kmer_golden.json"), "w") as f:
         json.dump(kmer_golden(), f, indent=1)
     pg = parse_golden()

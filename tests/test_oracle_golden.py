@@ -248,3 +248,28 @@ def test_cpu_baseline_driver_agrees_across_thread_counts():
     r1 = orc.bench_count_index(data, 21, orc.CANONICAL, 1)
     r3 = orc.bench_count_index(data, 21, orc.CANONICAL, 3)
     assert r1[1:] == (5600, 40) and r3[1:] == (5600, 40)
+
+
+def test_quality_lut_matches_reference_literals():
+    """Illumina18QualityScoreCodec<float>::DecodeLUT (quality_scores.hpp:113-211)"""
+    g = _load("quality_lut.json")["decode_lut"]
+    assert len(g) == 96
+    for q, v in enumerate(g):
+        exp = np.float32(np.finfo(np.float32).min) if v == "lowest" else np.float32(float(v))
+        got = np.float32(orc.lib.orc_qual_lut(33 + q))
+        assert exp.tobytes() == got.tobytes(), q
+
+
+def test_quality_window_direct_recomputation():
+    """src/index/test/test_quality_score_iterator.cpp: sliding values vs direct recomputation (to fp tolerance)"""
+    rng = np.random.default_rng(5)
+    k = 21
+    s = orc.kspec(k, orc.DNA)
+    seq = bytes(rng.choice(list(b"ACGT"), size=120).tolist())
+    q = rng.integers(35, 74, size=120, dtype=np.uint8)
+    data = b"@r\n" + seq + b"\n+\n" + bytes(q.tolist()) + b"\n"
+    ex = orc.extract(s, data, orc.FASTQ, want_quals=True)
+    lut = np.array([orc.lib.orc_qual_lut(int(c)) for c in range(33, 129)], dtype=np.float64)
+    for j, got in enumerate(ex["quals"]):
+        direct = 2.0 ** lut[q[j:j + k].astype(int) - 33].sum()
+        assert abs(float(got) - direct) <= 1e-5 * direct
