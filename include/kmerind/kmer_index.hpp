@@ -411,6 +411,9 @@ template <typename MapType> using KmerIndex = Index<MapType, KmerParser<typename
 template <typename MapType> using CountIndex = Index<MapType, KmerCountTupleParser<std::pair<typename MapType::key_type, typename MapType::mapped_type>>>;
 template <typename MapType> using CountIndex2 = Index<MapType, KmerParser<typename MapType::key_type>>;
 template <typename MapType> using PositionIndex = Index<MapType, KmerPositionTupleParser<std::pair<typename MapType::key_type, typename MapType::mapped_type>>>;
+// PositionQualityIndex (kmer_index.hpp:405-406): value = std::pair<ShortSequenceKmerId, float>. The C ABI carries it as two
+// 64-bit words (id, float bits in the low half of the second word) = the object bytes of that pair; use
+// kmi_index_create(index_kind = KMI_INDEX_POSQUAL) + kmi_index_build_* / kmi_index_insert_tuples_* directly.
 
 }  // namespace kmer
 }  // namespace index

@@ -129,6 +129,10 @@ kmi_status kmi_extract_dev(kmi_ctx *ctx, const kmi_config *cfg, const uint8_t *b
 kmi_status kmi_route_dev(kmi_ctx *ctx, const kmi_config *cfg, const uint64_t *keys_dev, size_t n,
                          uint32_t nranks, uint64_t *out_keys_dev, uint64_t *send_counts_host);
 
+/* same for (k-mer, value) records of the position indexes: value_words 64-bit words follow each key */
+kmi_status kmi_route_tuples_dev(kmi_ctx *ctx, const kmi_config *cfg, const uint64_t *records_dev, size_t n,
+                                uint32_t nranks, uint32_t value_words, uint64_t *out_records_dev, uint64_t *send_counts_host);
+
 /* ---- L4/L5: the map behind Index<MapType,Parser> ---------------------------- */
 kmi_status kmi_index_create(kmi_ctx *ctx, const kmi_config *cfg, kmi_index **out);
 kmi_status kmi_index_destroy(kmi_index *idx);

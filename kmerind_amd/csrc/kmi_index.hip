@@ -137,18 +137,20 @@ __global__ __launch_bounds__(kPartThreads) void hist_fine_kernel(const uint64_t 
   }
 }
 
-template <int NW, int BITS>
+template <int NW, int BITS, int VW = 0>
 __global__ __launch_bounds__(kPartThreads) void hist_rank_kernel(const uint64_t *__restrict__ keys, uint64_t n, KShape shape,
                                                                 uint32_t strand, BucketFn fn, uint32_t *__restrict__ wg_hist) {
   __shared__ uint32_t s_hist[kNumCoarse];
   if (threadIdx.x < kNumCoarse) s_hist[threadIdx.x] = 0;
   lds_barrier();
-  const uint64_t chunk = part_chunk(n, gridDim.x, PartCfg<NW>::TILE);
+  const uint64_t chunk = part_chunk(n, gridDim.x, PartCfg<NW + VW>::TILE);
   const uint64_t b = (uint64_t)blockIdx.x * chunk;
   const uint64_t e = (b + chunk < n) ? b + chunk : n;
   for (uint64_t i = b + threadIdx.x; i < e; i += kPartThreads) {
-    uint64_t k[NW];
-    load_key<NW, BITS>(keys, i, shape, strand, true, k);
+    uint64_t raw[NW], k[NW];
+#pragma unroll
+    for (int w = 0; w < NW; ++w) raw[w] = keys[i * (NW + VW) + w];
+    strand_key<NW, BITS>(raw, k, shape, strand);
     atomicAdd(&s_hist[bucket_of<NW>(k, fn)], 1u);
   }
   lds_barrier();
@@ -1338,9 +1340,9 @@ static uint64_t query_result_bound(const kmi_index *idx, int mode, size_t nq) {
 }
 
 // imxx::distribute bucketing by destination rank
-template <int NW, int BITS>
-static kmi_status route_impl(kmi_ctx *ctx, const kmi_config *cfg, KShape shape, const uint64_t *keys_dev, size_t n, uint32_t nranks,
-                             uint64_t *out_keys_dev, uint64_t *send_counts_host) {
+template <int NW, int BITS, int VW>
+static kmi_status route_vw(kmi_ctx *ctx, const kmi_config *cfg, KShape shape, const uint64_t *keys_dev, size_t n, uint32_t nranks,
+                           uint64_t *out_keys_dev, uint64_t *send_counts_host) {
   void *p;
   KMI_TRY(ws_get(ctx, WS_WGHIST, sizeof(uint32_t) * kPartGroups * kNumCoarse, &p)); uint32_t *wg_hist = (uint32_t *)p;
   KMI_TRY(ws_get(ctx, WS_CURSOR, sizeof(uint64_t) * kPartGroups * kNumCoarse, &p)); uint64_t *wg_off = (uint64_t *)p;
@@ -1348,7 +1350,7 @@ static kmi_status route_impl(kmi_ctx *ctx, const kmi_config *cfg, KShape shape, 
   BucketFn fn; fn.mode = BUCKET_RANK; fn.shape = shape; fn.dist_hash = cfg->dist_hash; fn.farm_ndebug = cfg->farm_ndebug != 0; fn.nranks = nranks;
   {
     ProfScope ps(ctx, "hist_rank", n);
-    hipLaunchKernelGGL((hist_rank_kernel<NW, BITS>), dim3(kPartGroups), dim3(kPartThreads), 0, ctx->stream, keys_dev, (uint64_t)n, shape,
+    hipLaunchKernelGGL((hist_rank_kernel<NW, BITS, VW>), dim3(kPartGroups), dim3(kPartThreads), 0, ctx->stream, keys_dev, (uint64_t)n, shape,
                        cfg->strand, fn, wg_hist);
   }
   {
@@ -1357,7 +1359,7 @@ static kmi_status route_impl(kmi_ctx *ctx, const kmi_config *cfg, KShape shape, 
   }
   {
     ProfScope ps(ctx, "scatter_rank", n);
-    hipLaunchKernelGGL((scatter_chunks_kernel<NW, BITS>), dim3(kPartGroups), dim3(kPartThreads), 0, ctx->stream, keys_dev, (uint64_t)n,
+    hipLaunchKernelGGL((scatter_chunks_kernel<NW, BITS, VW>), dim3(kPartGroups), dim3(kPartThreads), 0, ctx->stream, keys_dev, (uint64_t)n,
                        out_keys_dev, shape, cfg->strand, true, fn, (const uint64_t *)wg_off);
   }
   KMI_HIP(ctx, hipGetLastError());
@@ -1366,9 +1368,29 @@ static kmi_status route_impl(kmi_ctx *ctx, const kmi_config *cfg, KShape shape, 
   return KMI_OK;
 }
 
+template <int NW, int BITS>
+static kmi_status route_impl(kmi_ctx *ctx, const kmi_config *cfg, KShape shape, const uint64_t *keys_dev, size_t n, uint32_t nranks,
+                             uint32_t value_words, uint64_t *out_keys_dev, uint64_t *send_counts_host) {
+  if (value_words == 0) return route_vw<NW, BITS, 0>(ctx, cfg, shape, keys_dev, n, nranks, out_keys_dev, send_counts_host);
+  if (value_words == 1) return route_vw<NW, BITS, 1>(ctx, cfg, shape, keys_dev, n, nranks, out_keys_dev, send_counts_host);
+  if (value_words == 2) return route_vw<NW, BITS, 2>(ctx, cfg, shape, keys_dev, n, nranks, out_keys_dev, send_counts_host);
+  return set_err(ctx, KMI_ERR_INVALID, "value_words must be 0, 1 or 2");
+}
+
 }  // namespace kmi
 
 extern "C" {
+
+kmi_status kmi_route_tuples_dev(kmi_ctx *ctx, const kmi_config *cfg, const uint64_t *records_dev, size_t n, uint32_t nranks,
+                                uint32_t value_words, uint64_t *out_records_dev, uint64_t *send_counts_host) {
+  if (!ctx) return KMI_ERR_INVALID;
+  KShape shape;
+  if (!valid_config(cfg, &shape)) return set_err(ctx, KMI_ERR_INVALID, "bad kmi_config");
+  if (nranks == 0 || nranks > (uint32_t)kNumCoarse || !send_counts_host) return set_err(ctx, KMI_ERR_INVALID, "nranks must be in 1..256");
+  KMI_HIP(ctx, hipSetDevice(ctx->device));
+  if (n == 0) { for (uint32_t r = 0; r < nranks; ++r) send_counts_host[r] = 0; return KMI_OK; }
+  KMI_DISPATCH(shape, route_impl, ctx, cfg, shape, records_dev, n, nranks, value_words, out_records_dev, send_counts_host);
+}
 
 kmi_status kmi_route_dev(kmi_ctx *ctx, const kmi_config *cfg, const uint64_t *keys_dev, size_t n, uint32_t nranks,
                          uint64_t *out_keys_dev, uint64_t *send_counts_host) {
@@ -1378,7 +1400,7 @@ kmi_status kmi_route_dev(kmi_ctx *ctx, const kmi_config *cfg, const uint64_t *ke
   if (nranks == 0 || nranks > (uint32_t)kNumCoarse || !send_counts_host) return set_err(ctx, KMI_ERR_INVALID, "nranks must be in 1..256");
   KMI_HIP(ctx, hipSetDevice(ctx->device));
   if (n == 0) { for (uint32_t r = 0; r < nranks; ++r) send_counts_host[r] = 0; return KMI_OK; }
-  KMI_DISPATCH(shape, route_impl, ctx, cfg, shape, keys_dev, n, nranks, out_keys_dev, send_counts_host);
+  KMI_DISPATCH(shape, route_impl, ctx, cfg, shape, keys_dev, n, nranks, 0u, out_keys_dev, send_counts_host);
 }
 
 kmi_status kmi_index_create(kmi_ctx *ctx, const kmi_config *cfg, kmi_index **out) {

@@ -99,3 +99,33 @@ def test_position_index_api_guards(ctx):
     k, c = idx.count(np.array([[7], [7]], dtype=np.uint64))
     assert k.shape[0] == 1 and c.tolist() == [0]
     idx.close()
+
+
+def test_route_tuples_matches_key_to_rank(ctx):
+    """imxx::distribute on (k-mer, id) records: grouped by KeyToRank, payload carried along"""
+    import ctypes as C
+    import kmerind_amd as K
+    from kmerind_amd import _lib as L
+    k, p = 31, 5
+    s = orc.kspec(k, orc.DNA)
+    cfg = K.make_config(k, "DNA", strand="canonical", index_kind="position")
+    ex = orc.extract(s, bytes(K.synth_fastq(seed=2, genome_len=30000, n_reads=900)), orc.FASTQ, want_ids=True)
+    rec = np.ascontiguousarray(np.concatenate([ex["kmers"], ex["ids"][:, None]], axis=1))
+    n = rec.shape[0]
+    din, dout = ctx.alloc(rec.nbytes), ctx.alloc(rec.nbytes)
+    ctx.to_device(din, rec)
+    counts = np.zeros(p, dtype=np.uint64)
+    ctx.check(L.lib.kmi_route_tuples_dev(ctx.h, C.byref(cfg), C.c_void_p(din), n, p, 1, C.c_void_p(dout),
+                                         counts.ctypes.data_as(C.c_void_p)))
+    out = np.zeros_like(rec)
+    ctx.to_host(out, dout)
+    ctx.free(din); ctx.free(dout)
+    canon = orc.canonical(s, ex["kmers"])
+    ranks = orc.key_to_rank(s, orc.MURMUR, orc.CANONICAL, canon, p)
+    assert counts.tolist() == np.bincount(ranks, minlength=p).tolist()
+    off = 0
+    for r in range(p):
+        seg = out[off:off + int(counts[r])]
+        exp = np.concatenate([canon[ranks == r], ex["ids"][ranks == r][:, None]], axis=1)
+        assert (orc.sorted_rows(seg) == orc.sorted_rows(exp)).all()
+        off += int(counts[r])
