@@ -6,7 +6,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libkmerind_hip.so")
+# KMERIND_HIP_LIB points at another build of the same library (e.g. an installed copy)
+LIB_PATH = os.environ.get("KMERIND_HIP_LIB") or os.path.join(_HERE, "libkmerind_hip.so")
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(

@@ -524,7 +524,7 @@ static kmi_status fastq_scan_impl(kmi_ctx *ctx, const uint8_t *bytes_dev, size_t
   ScanResult r;
   KMI_HIP(ctx, hipMemsetAsync(ctx->d_flags, 0, sizeof(uint32_t) * 16, ctx->stream));
   KMI_TRY((scan_impl<NW, BITS>(ctx, bytes_dev, n_bytes, shape, &r)));
-  out->n_tiles = r.n_tiles; out->line_base = r.line_base;
+  out->n_tiles = r.n_tiles; out->line_base = r.line_base; out->tile_off = r.out_off;
   out->pk_eol = r.packed.eol; out->pk_stream = r.packed.stream; out->n_bytes = r.packed.n_bytes; out->n_cover = r.packed.n_cover;
   return read_totals(ctx, &out->n_tuples, &out->n_seqs);
 }

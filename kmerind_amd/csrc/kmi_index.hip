@@ -43,6 +43,7 @@ constexpr int kPartThreads = 1024;           // K1/K2/P2 workgroup size
 constexpr int kPartGroups = 512;             // K1/K2 workgroups (two per CU)
 constexpr int kFineParts = 2;                // P2 workgroups per coarse bucket; part h = K2 groups [h*256, (h+1)*256)
 constexpr int kGroupsPerPart = kPartGroups / kFineParts;
+constexpr int kListGroups = 2048;            // workgroups of the window-list pass (small LDS footprint: eight per CU)
 constexpr int kLoadBatch = 8;                // independent key loads kept in flight per thread
 
 __host__ __device__ inline uint32_t fine_of(uint32_t h) { return h >> kSlotBits; }
@@ -366,145 +367,280 @@ __global__ __launch_bounds__(kPartThreads) void scatter_fine_kernel(const uint64
 // extracted tuple array never exists in HBM: 2 x 2.6 B/k-mer of input reads replace
 // 8 W + 8 R + 8 R of key traffic. Workgroup w owns the same contiguous run of tiles in both.
 // ---------------------------------------------------------------------------
+// L: the window list. One pass over the packed input (EOL bitmap + line bases from the scan) does all the
+// per-byte work -- line starts, line roles, EOL-free k-windows -- once, and leaves the tile position of
+// every k-mer window in HBM (2 bytes per k-mer, file order, windows of tile t at tile_off[t]).
 template <int NW, int BITS>
-__global__ __launch_bounds__((ExCfgWide<NW, BITS>::NT)) void fastq_hist_kernel(PackedInput in, uint64_t n_tiles, KShape shape, bool canonical,
-                                                                              const uint32_t *__restrict__ line_base,
-                                                                              uint32_t *__restrict__ fine_hist, uint32_t *__restrict__ wg_hist) {
-  using Cfg = ExCfgWide<NW, BITS>;
-  __shared__ uint32_t s_hist[kNumFine];
+__global__ __launch_bounds__((ExCfg<NW, BITS>::NT)) void fastq_list_kernel(PackedInput in, uint64_t n_tiles, uint32_t k,
+                                                                          const uint32_t *__restrict__ line_base,
+                                                                          const uint64_t *__restrict__ tile_off, uint16_t *__restrict__ win_pos) {
+  using Cfg = ExCfg<NW, BITS>;
   __shared__ uint32_t s_eol[Cfg::EOL_DW];
-  __shared__ uint32_t s_stream[Cfg::STREAM_DW];
   __shared__ uint32_t s_scan[Cfg::NT / 64 + 2];
   __shared__ uint16_t s_pos[Cfg::TILE];
-  for (int i = threadIdx.x; i < kNumFine; i += Cfg::NT) s_hist[i] = 0;
-  lds_barrier();
+  __shared__ uint32_t s_prev;
   const uint64_t per = (n_tiles + gridDim.x - 1) / gridDim.x;
   const uint64_t tb = (uint64_t)blockIdx.x * per;
   const uint64_t te = (tb + per < n_tiles) ? tb + per : n_tiles;
-  uint16_t *s_wpos = s_pos + wave_id() * (kWave * Cfg::C);   // this wave's slice of the window list
-  __shared__ uint32_t s_prev;
-  TileUnits<Cfg> cur, nxt, nn;
-  tile_units_load<Cfg>(in, tb, te > tb ? n_tiles : 0, cur);
-  tile_units_load<Cfg>(in, tb + 1, n_tiles, nxt);
+  auto load_eol = [&](uint64_t tile, uint32_t &e, bool &ok) {   // clamped, validity applied on use
+    ok = tile < n_tiles;
+    e = read_eol_unit<Cfg::C>(in.eol, (ok ? tile : 0ull) * Cfg::NT + threadIdx.x);
+  };
+  uint32_t e_cur, e_nxt, e_nn; bool ok_cur, ok_nxt, ok_nn;
+  load_eol(tb, e_cur, ok_cur); ok_cur = ok_cur && tb < te;
+  load_eol(tb + 1, e_nxt, ok_nxt);
   if (threadIdx.x == 0) s_prev = (tb < te) ? tile_prev_eol<Cfg>(in, tb) : 1u;
   for (uint64_t t = tb; t < te; ++t) {
-    uint32_t eol;
-    const uint32_t ls = tile_units_publish<Cfg>(cur, nxt, s_eol, s_stream, &s_prev, eol);
-    tile_units_load<Cfg>(in, t + 2, n_tiles, nn);   // in flight during two tiles of work
-    uint32_t ltot;
-    const uint32_t lbl = block_exclusive_scan<uint32_t, false>((uint32_t)__builtin_popcount(ls), s_scan, &ltot);
-    if (threadIdx.x == Cfg::NT - 1) s_prev = (eol >> (Cfg::C - 1)) & 1u;   // read again only after the next barriers
-    const uint32_t valid = chunk_valid_mask<Cfg>(s_eol, ls, line_base[t] + lbl, shape.k);
-    const uint32_t wtotal = wave_window_list<Cfg>(valid, s_wpos);
-    for (uint32_t q = lane_id(); q < wtotal; q += kWave) {
-      uint64_t rc[NW], fw[NW], key[NW];
-      window_at<Cfg>(s_stream, s_wpos[q], shape, rc, fw);
-      select_strand<NW>(rc, fw, canonical, key);
-      atomicAdd(&s_hist[fine_of(place_hash<NW>(key))], 1u);
+    const uint32_t eol = ok_cur ? e_cur : Cfg::CMASK;
+    store_eol_bits<Cfg::C>(s_eol, threadIdx.x, eol);
+    if (threadIdx.x < Cfg::HALO_CHUNKS) store_eol_bits<Cfg::C>(s_eol, Cfg::NT + threadIdx.x, ok_nxt ? e_nxt : Cfg::CMASK);
+    lds_barrier();
+    load_eol(t + 2, e_nn, ok_nn);
+    bool prev_eol;
+    if (threadIdx.x > 0) {
+      const int pb = Cfg::C * threadIdx.x - 1;
+      prev_eol = (s_eol[pb >> 5] >> (pb & 31)) & 1u;
+    } else {
+      prev_eol = s_prev != 0;
     }
-    lds_barrier();   // the next tile overwrites s_eol / s_stream (and s_scan is free again)
-    cur = nxt; nxt = nn;
+    const uint32_t ls = line_starts(eol, prev_eol, Cfg::CMASK);
+    uint32_t ltot;
+    const uint32_t lbl = block_exclusive_scan<uint32_t>((uint32_t)__builtin_popcount(ls), s_scan, &ltot);
+    if (threadIdx.x == Cfg::NT - 1) s_prev = (eol >> (Cfg::C - 1)) & 1u;   // read again only after the next barriers
+    const uint32_t total = tile_window_list<Cfg>(s_eol, ls, line_base[t] + lbl, k, s_pos, s_scan);
+    uint16_t *dst = win_pos + tile_off[t];
+    for (uint32_t q = threadIdx.x; q < total; q += Cfg::NT) dst[q] = s_pos[q];
+    lds_barrier();   // the next tile overwrites s_eol and the list
+    e_cur = e_nxt; ok_cur = ok_nxt; e_nxt = e_nn; ok_nxt = ok_nn;
+  }
+}
+
+// geometry of the list-driven passes
+template <int NW, int BITS> struct ListCfg {
+  using Cfg = ExCfg<NW, BITS>;
+  static constexpr int NT = Cfg::NT;
+  static constexpr int MAXQ = 61440 / (8 * NW * NT);       // windows per thread and round (scatter)
+  static constexpr int CAPW = MAXQ * NT;                   // windows per round (stage capacity)
+  static constexpr int RMAX = (BITS == 3) ? 2 : 4;         // scan tiles per round (LDS image of their packed stream)
+  static constexpr int UNITS = RMAX * NT + Cfg::HALO_CHUNKS;
+  static constexpr int STREAM_DW = (UNITS * Cfg::C * BITS + 31) / 32 + 2 * NW + 2;
+  static constexpr int ULOADS = (UNITS + NT - 1) / NT;     // stream units per thread (scatter)
+};
+
+// E1: fine histogram + per-workgroup coarse counts, driven by the window list. A round = the RMAX scan
+// tiles whose packed stream sits in LDS as one image; the image is double-buffered, so there is one
+// barrier per round and the only per-window work is window -> canonical key -> placement hash -> LDS add.
+constexpr int kHistThreads = 1024;
+template <int NW, int BITS>
+__global__ __launch_bounds__(kHistThreads) void fastq_hist_list_kernel(PackedInput in, uint64_t n_tiles, KShape shape, bool canonical,
+                                                                      const uint64_t *__restrict__ tile_off,
+                                                                      const uint16_t *__restrict__ win_pos,
+                                                                      uint32_t *__restrict__ fine_hist, uint32_t *__restrict__ wg_hist) {
+  using Cfg = ExCfg<NW, BITS>;
+  using L = ListCfg<NW, BITS>;
+  constexpr int NT = kHistThreads, RMAX = L::RMAX;
+  constexpr int UL = (L::UNITS + NT - 1) / NT;
+  constexpr int PB = 8;   // window positions in flight per thread
+  __shared__ uint32_t s_hist[kNumFine];
+  __shared__ uint32_t s_stream[2][L::STREAM_DW];
+  for (int i = threadIdx.x; i < kNumFine; i += NT) s_hist[i] = 0;
+  const uint64_t per = (n_tiles + gridDim.x - 1) / gridDim.x;
+  const uint64_t tb = (uint64_t)blockIdx.x * per;
+  const uint64_t te = (tb + per < n_tiles) ? tb + per : n_tiles;
+  const uint64_t last_unit = in.n_cover / Cfg::C - 1;
+  auto load_image = [&](uint64_t t, uint64_t (&st)[UL]) {
+#pragma unroll
+    for (int i = 0; i < UL; ++i) {
+      uint64_t g = t * Cfg::NT + (uint64_t)i * NT + threadIdx.x;
+      g = g < last_unit ? g : last_unit;
+      st[i] = read_stream_unit<BITS, Cfg::C>(in.stream, g);
+    }
+  };
+  auto store_image = [&](uint32_t *img, const uint64_t (&st)[UL]) {
+#pragma unroll
+    for (int i = 0; i < UL; ++i) {
+      const int u = i * NT + threadIdx.x;
+      if (u < L::UNITS) store_stream_bits<BITS, Cfg::C>(img, u, st[i]);
+    }
+  };
+  uint64_t st[UL];
+  if (tb < te) { load_image(tb, st); store_image(s_stream[0], st); }
+  lds_barrier();   // histogram cleared, first image in place
+  int buf = 0;
+  for (uint64_t t = tb; t < te; t += RMAX) {
+    const bool more = t + RMAX < te;
+    if (more) load_image(t + RMAX, st);   // in flight while this round is processed
+    const uint64_t qa = tile_off[t];
+    uint64_t o[RMAX + 1];
+#pragma unroll
+    for (int i = 1; i <= RMAX; ++i) o[i] = tile_off[(t + i < te) ? t + i : te];
+    const uint32_t total = (uint32_t)(o[RMAX] - qa);
+    uint32_t orel[RMAX];
+#pragma unroll
+    for (int i = 1; i < RMAX; ++i) orel[i] = (uint32_t)(o[i] - qa);
+    const uint32_t *img = s_stream[buf];
+    const uint16_t *src = win_pos + qa;
+    for (uint32_t q0 = 0; q0 < total; q0 += NT * PB) {
+      uint32_t p16[PB];
+#pragma unroll
+      for (int m = 0; m < PB; ++m) {
+        uint32_t q = q0 + m * NT + threadIdx.x;
+        q = q < total ? q : total - 1;
+        p16[m] = src[q];
+      }
+#pragma unroll
+      for (int m = 0; m < PB; ++m) {
+        const uint32_t q = q0 + m * NT + threadIdx.x;
+        if (q < total) {
+          uint32_t r = 0;
+#pragma unroll
+          for (int i = 1; i < RMAX; ++i) r += (q >= orel[i]) ? 1u : 0u;
+          uint64_t rc[NW], fw[NW], key[NW];
+          window_at<Cfg>(img, r * Cfg::TILE + p16[m], shape, rc, fw);
+          select_strand<NW>(rc, fw, canonical, key);
+          atomicAdd(&s_hist[fine_of(place_hash<NW>(key))], 1u);
+        }
+      }
+    }
+    if (more) store_image(s_stream[buf ^ 1], st);   // last read two barriers ago
+    lds_barrier();
+    buf ^= 1;
   }
   uint32_t *part_hist = fine_hist + (uint64_t)(blockIdx.x / kGroupsPerPart) * kNumFine;
-  for (int i = threadIdx.x; i < kNumFine; i += Cfg::NT) {
+  for (int i = threadIdx.x; i < kNumFine; i += NT) {
     uint32_t v = s_hist[i];
     if (v) atomicAdd(&part_hist[i], v);
   }
-  for (int c = threadIdx.x; c < kNumCoarse; c += Cfg::NT) {
+  for (int c = threadIdx.x; c < kNumCoarse; c += NT) {
     uint32_t sum = 0;
     for (int i = 0; i < kSubPerCoarse; ++i) sum += s_hist[c * kSubPerCoarse + ((i + c) & (kSubPerCoarse - 1))];
     wg_hist[(uint64_t)blockIdx.x * kNumCoarse + c] = sum;
   }
 }
 
+// E2 from the window list. A round is a run of up to CAPW consecutive windows of this
+// workgroup's tiles (it may start and end inside a tile, and spans at most RMAX scan tiles, whose packed
+// stream is one contiguous LDS image), so the bucket sort always works on a full stage: fewer, longer
+// contiguous runs per coarse bucket and no per-byte work at all.
 template <int NW, int BITS>
-__global__ __launch_bounds__((ExCfg<NW, BITS>::NT)) void fastq_scatter_kernel(PackedInput in, uint64_t n_tiles, KShape shape, bool canonical,
-                                                                             const uint32_t *__restrict__ line_base,
-                                                                             const uint64_t *__restrict__ wg_off, uint64_t *__restrict__ out) {
+__global__ __launch_bounds__((ExCfg<NW, BITS>::NT)) void fastq_scatter_list_kernel(PackedInput in, uint64_t n_tiles, KShape shape, bool canonical,
+                                                                                  const uint64_t *__restrict__ tile_off,
+                                                                                  const uint16_t *__restrict__ win_pos,
+                                                                                  const uint64_t *__restrict__ wg_off, uint64_t *__restrict__ out) {
   using Cfg = ExCfg<NW, BITS>;
-  constexpr int MAXQ = Cfg::C;   // windows per thread: TILE / NT
-  static_assert(Cfg::TILE <= PartCfg<NW>::TILE, "stage must hold every window of a tile");
-  static_assert(Cfg::NT >= kNumCoarse, "one thread per coarse bucket");
-  __shared__ uint64_t s_stage[Cfg::TILE * NW];   // its first bytes double as the window list (dead before S3)
-  __shared__ uint8_t s_bkt[Cfg::TILE];
-  __shared__ uint32_t s_eol[Cfg::EOL_DW];
-  __shared__ uint32_t s_stream[Cfg::STREAM_DW];
-  __shared__ uint32_t s_scan[Cfg::NT / 64 + 2];
+  using L = ListCfg<NW, BITS>;
+  constexpr int NT = L::NT, MAXQ = L::MAXQ, CAPW = L::CAPW, RMAX = L::RMAX;
+  static_assert(NT >= kNumCoarse, "one thread per coarse bucket");
+  static_assert(RMAX * Cfg::TILE < 65536 * 4, "round positions");
+  __shared__ uint64_t s_stage[CAPW * NW];
+  __shared__ uint8_t s_bkt[CAPW];
+  __shared__ uint32_t s_stream[L::STREAM_DW];
   __shared__ uint32_t s_cnt[kNumCoarse];
   __shared__ uint32_t s_lofs[kNumCoarse];
   __shared__ uint64_t s_gbase[kNumCoarse];
   __shared__ uint32_t s_part[kNumCoarse / kWave];
-  uint16_t *s_pos = reinterpret_cast<uint16_t *>(s_stage);
   uint64_t cursor = (threadIdx.x < kNumCoarse) ? wg_off[(uint64_t)blockIdx.x * kNumCoarse + threadIdx.x] : 0ull;
   if (threadIdx.x < kNumCoarse) s_cnt[threadIdx.x] = 0;
   const uint64_t per = (n_tiles + gridDim.x - 1) / gridDim.x;
   const uint64_t tb = (uint64_t)blockIdx.x * per;
   const uint64_t te = (tb + per < n_tiles) ? tb + per : n_tiles;
-  __shared__ uint32_t s_prev;
-  TileUnits<Cfg> cur, nxt, nn;
-  tile_units_load<Cfg>(in, tb, te > tb ? n_tiles : 0, cur);
-  tile_units_load<Cfg>(in, tb + 1, n_tiles, nxt);
-  if (threadIdx.x == 0) s_prev = (tb < te) ? tile_prev_eol<Cfg>(in, tb) : 1u;
-  for (uint64_t t = tb; t < te; ++t) {
-    uint32_t eol;
-    const uint32_t ls = tile_units_publish<Cfg>(cur, nxt, s_eol, s_stream, &s_prev, eol);
-    tile_units_load<Cfg>(in, t + 2, n_tiles, nn);
-    uint32_t ltot;
-    const uint32_t lbl = block_exclusive_scan<uint32_t>((uint32_t)__builtin_popcount(ls), s_scan, &ltot);
-    if (threadIdx.x == Cfg::NT - 1) s_prev = (eol >> (Cfg::C - 1)) & 1u;
-    const uint32_t total = tile_window_list<Cfg>(s_eol, ls, line_base[t] + lbl, shape.k, s_pos, s_scan);
-    // S0: keys of windows q = tid, tid + NT, ...; coarse bucket and rank inside (tile, bucket)
-    uint64_t key[MAXQ][NW];
-    uint32_t bkrk[MAXQ];   // bucket << 16 | rank
+  if (tb >= te) return;
+  const uint64_t q_end = tile_off[te];
+  const uint64_t last_unit = in.n_cover / Cfg::C - 1;
+  uint64_t q0 = tile_off[tb];
+  uint64_t t = tb;
+  while (q0 < q_end) {
+    while (tile_off[t + 1] <= q0) ++t;                 // tile of window q0 (tiles without windows are skipped)
+    // tile boundaries inside the round, relative to q0 (entries past the workgroup's range do not bind)
+    uint64_t o[RMAX + 1];
 #pragma unroll
-    for (int m = 0; m < MAXQ; ++m) {
-      const uint32_t q = m * Cfg::NT + threadIdx.x;
-      if (q < total) {
-        uint64_t rc[NW], fw[NW];
-        window_at<Cfg>(s_stream, s_pos[q], shape, rc, fw);
-        select_strand<NW>(rc, fw, canonical, key[m]);
-        const uint32_t b = coarse_of(place_hash<NW>(key[m]));
-        bkrk[m] = (b << 16) | atomicAdd(&s_cnt[b], 1u);
+    for (int i = 1; i <= RMAX; ++i) o[i] = (t + i <= te) ? tile_off[t + i] : q_end;
+    uint64_t q1 = q0 + CAPW;
+    if (q1 > o[RMAX]) q1 = o[RMAX];
+    if (q1 > q_end) q1 = q_end;
+    const uint32_t total = (uint32_t)(q1 - q0);
+    uint32_t orel[RMAX];
+#pragma unroll
+    for (int i = 1; i < RMAX; ++i) { const uint64_t d = o[i] - q0; orel[i] = d > (uint64_t)CAPW ? (uint32_t)CAPW : (uint32_t)d; }
+    // packed stream of tiles t .. t+RMAX-1 (+ halo) as one LDS image; unit loads are clamped, not guarded
+    {
+      uint64_t st[L::ULOADS];
+#pragma unroll
+      for (int i = 0; i < L::ULOADS; ++i) {
+        uint64_t g = t * NT + (uint64_t)i * NT + threadIdx.x;
+        g = g < last_unit ? g : last_unit;
+        st[i] = read_stream_unit<BITS, Cfg::C>(in.stream, g);
+      }
+      // window positions of this thread: q = tid, tid + NT, ...
+      uint32_t p16[MAXQ];
+#pragma unroll
+      for (int m = 0; m < MAXQ; ++m) {
+        uint32_t q = m * NT + threadIdx.x;
+        q = q < total ? q : total - 1;
+        p16[m] = win_pos[q0 + q];
+      }
+#pragma unroll
+      for (int i = 0; i < L::ULOADS; ++i) {
+        const int u = i * NT + threadIdx.x;
+        if (u < L::UNITS) store_stream_bits<BITS, Cfg::C>(s_stream, u, st[i]);
+      }
+      lds_barrier();
+      // S0: keys, coarse bucket and rank inside (round, bucket)
+      uint64_t key[MAXQ][NW];
+      uint32_t bkrk[MAXQ];
+#pragma unroll
+      for (int m = 0; m < MAXQ; ++m) {
+        const uint32_t q = m * NT + threadIdx.x;
+        if (q < total) {
+          uint32_t r = 0;
+#pragma unroll
+          for (int i = 1; i < RMAX; ++i) r += (q >= orel[i]) ? 1u : 0u;
+          uint64_t rc[NW], fw[NW];
+          window_at<Cfg>(s_stream, r * Cfg::TILE + p16[m], shape, rc, fw);
+          select_strand<NW>(rc, fw, canonical, key[m]);
+          const uint32_t b = coarse_of(place_hash<NW>(key[m]));
+          bkrk[m] = (b << 16) | atomicAdd(&s_cnt[b], 1u);
+        }
+      }
+      lds_barrier();
+      uint32_t c = 0, inc = 0;
+      if (threadIdx.x < kNumCoarse) {
+        c = s_cnt[threadIdx.x];
+        s_cnt[threadIdx.x] = 0;
+        inc = wave_inclusive_scan(c);
+        if (lane_id() == kWave - 1) s_part[wave_id()] = inc;
+      }
+      lds_barrier();
+      if (threadIdx.x < kNumCoarse) {
+        uint32_t pre = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < kNumCoarse / kWave; ++w) pre += (w < wave_id()) ? s_part[w] : 0u;
+        const uint32_t lo = pre + inc - c;
+        s_lofs[threadIdx.x] = lo;
+        s_gbase[threadIdx.x] = cursor - lo;
+        cursor += c;
+      }
+      lds_barrier();
+#pragma unroll
+      for (int m = 0; m < MAXQ; ++m) {
+        const uint32_t q = m * NT + threadIdx.x;
+        if (q < total) {
+          const uint32_t b = bkrk[m] >> 16;
+          const uint32_t pos = s_lofs[b] + (bkrk[m] & 0xffffu);
+#pragma unroll
+          for (int w = 0; w < NW; ++w) s_stage[(uint64_t)pos * NW + w] = key[m][w];
+          s_bkt[pos] = (uint8_t)b;
+        }
       }
     }
     lds_barrier();
-    uint32_t c = 0, inc = 0;
-    if (threadIdx.x < kNumCoarse) {
-      c = s_cnt[threadIdx.x];
-      s_cnt[threadIdx.x] = 0;
-      inc = wave_inclusive_scan(c);
-      if (lane_id() == kWave - 1) s_part[wave_id()] = inc;
-    }
-    lds_barrier();
-    if (threadIdx.x < kNumCoarse) {
-      uint32_t pre = 0;
-#pragma unroll
-      for (uint32_t w = 0; w < kNumCoarse / kWave; ++w) pre += (w < wave_id()) ? s_part[w] : 0u;
-      const uint32_t lo = pre + inc - c;
-      s_lofs[threadIdx.x] = lo;
-      s_gbase[threadIdx.x] = cursor - lo;
-      cursor += c;
-    }
-    lds_barrier();   // also: every read of the window list (aliasing the stage) is done
-#pragma unroll
-    for (int m = 0; m < MAXQ; ++m) {
-      const uint32_t q = m * Cfg::NT + threadIdx.x;
-      if (q < total) {
-        const uint32_t b = bkrk[m] >> 16;
-        const uint32_t pos = s_lofs[b] + (bkrk[m] & 0xffffu);
-#pragma unroll
-        for (int w = 0; w < NW; ++w) s_stage[(uint64_t)pos * NW + w] = key[m][w];
-        s_bkt[pos] = (uint8_t)b;
-      }
-    }
-    lds_barrier();
-    for (uint32_t s = threadIdx.x; s < total; s += Cfg::NT) {
+    for (uint32_t s = threadIdx.x; s < total; s += NT) {
       const uint64_t dst = s_gbase[s_bkt[s]] + s;
 #pragma unroll
       for (int w = 0; w < NW; ++w) out[dst * NW + w] = s_stage[(uint64_t)s * NW + w];
     }
-    lds_barrier();   // the next tile's window list overwrites the stage
-    cur = nxt; nxt = nn;
+    lds_barrier();   // the next round overwrites the stream image and the stage
+    q0 = q1;
   }
 }
 
@@ -513,8 +649,13 @@ __global__ __launch_bounds__((ExCfg<NW, BITS>::NT)) void fastq_scatter_kernel(Pa
 // ---------------------------------------------------------------------------
 template <int NW> struct TabCfg {
   // slots; sized so that two workgroups fit in one CU's 160 KB for one-word keys
-  static constexpr int CAP = (NW == 1) ? 6656 : (NW == 2 ? 4608 : (NW == 3 ? 3584 : 2816));
-  static constexpr int LIMIT = CAP * 3 / 4;
+  static constexpr int CAP = (NW == 1) ? 6656 : (NW == 2 ? 4608 : (NW == 3 ? 3584 : 2816));   // home slots
+  // One-word tables probe linearly WITHOUT wrap-around: a probe sequence that starts near the end runs on
+  // into PAD extra slots, so a probe step is "next address, read, compare" and nothing else. The very last
+  // slot is never filled (an insert that would need it reports overflow), which ends every probe sequence.
+  static constexpr int PAD = (NW == 1) ? 64 : 0;
+  static constexpr int SLOTS = CAP + PAD;
+  static constexpr int LIMIT = CAP * 3 / 4;      // distinct keys per pass before the bucket is split into more passes
   static constexpr int NT = 512;
 };
 constexpr int kMaxProbe = 192;   // longer probe sequences than this mean the LDS table is overloaded
@@ -534,9 +675,9 @@ __device__ __forceinline__ uint32_t wave_alloc(uint32_t *ctr, bool want) {
 constexpr uint32_t kTagEmpty = 0u, kTagLock = 1u;
 
 template <int NW> struct LdsTable {
-  uint64_t *keys;      // [CAP*NW]
-  uint32_t *vals;      // [CAP]
-  uint32_t *tags;      // [CAP] (NW > 1 only)
+  uint64_t *keys;      // [SLOTS*NW]
+  uint32_t *vals;      // [SLOTS]
+  uint32_t *tags;      // [SLOTS] (NW > 1 only)
   uint32_t *distinct;  // counter
   uint32_t *overflow;  // flag
   uint32_t *special;   // value of the key that equals the empty sentinel (NW == 1)
@@ -544,8 +685,8 @@ template <int NW> struct LdsTable {
 };
 
 template <int NW> __device__ __forceinline__ void table_clear(const LdsTable<NW> &t) {
-  constexpr int CAP = TabCfg<NW>::CAP;
-  for (int i = threadIdx.x; i < CAP; i += blockDim.x) {
+  constexpr int SLOTS = TabCfg<NW>::SLOTS;
+  for (int i = threadIdx.x; i < SLOTS; i += blockDim.x) {
     t.vals[i] = 0;
     if (NW == 1) t.keys[i] = kEmptyKey; else t.tags[i] = kTagEmpty;
   }
@@ -562,13 +703,13 @@ template <int NW> __device__ __forceinline__ int table_upsert(const LdsTable<NW>
   uint32_t slot = slot_of(h, CAP);
   if (NW == 1) {
     if (key[0] == kEmptyKey) { *t.special_set = 1; return -2; }
-    for (int probes = 0; probes < CAP; ++probes) {
+    for (int probes = 0; slot < (uint32_t)TabCfg<1>::SLOTS - 1; ++probes, ++slot) {
       unsigned long long old = atomicCAS((unsigned long long *)&t.keys[slot], (unsigned long long)kEmptyKey, (unsigned long long)key[0]);
-      if (old == kEmptyKey || old == key[0]) {
-        if (probes >= kMaxProbe) *t.overflow = 1;   // table too loaded: redo the bucket in more passes
+      if (old == kEmptyKey) {
+        if (atomicAdd(t.distinct, 1u) >= (uint32_t)TabCfg<1>::LIMIT || probes >= kMaxProbe) *t.overflow = 1;   // too loaded: more passes
         return (int)slot;
       }
-      slot = (slot + 1 == (uint32_t)CAP) ? 0u : slot + 1;
+      if (old == key[0]) return (int)slot;
     }
     *t.overflow = 1;
     return -1;
@@ -609,28 +750,17 @@ __device__ __forceinline__ uint32_t pass_of(uint32_t h, uint32_t npass) {
   return npass == 1 ? 0u : (uint32_t)(((uint64_t)(h * 0x9E3779B1u) * npass) >> 32);
 }
 
-// NW == 1: continue a linear probe that already failed at `slot` (first probe done by the caller)
-__device__ __forceinline__ int table_upsert_continue1(const LdsTable<1> &t, uint64_t key, uint32_t slot) {
-  constexpr int CAP = TabCfg<1>::CAP;
-  for (int probes = 1; probes < CAP; ++probes) {
-    slot = (slot + 1 == (uint32_t)CAP) ? 0u : slot + 1;
-    unsigned long long old = atomicCAS((unsigned long long *)&t.keys[slot], (unsigned long long)kEmptyKey, (unsigned long long)key);
-    if (old == kEmptyKey || old == key) {
-      if (probes >= kMaxProbe) *t.overflow = 1;
-      return (int)slot;
-    }
-  }
-  *t.overflow = 1;
-  return -1;
-}
-
-// NW == 1 insert of keys[b, e) with weight 1: U keys per thread; the U first probes (64-bit LDS
-// compare-and-swap) are issued back to back so their latencies overlap, only keys whose home slot
-// is taken by another key fall into the serial probe loop.
+// NW == 1 insert of keys[b, e) with weight 1, U keys per thread and batch. The U home slots are read with
+// plain 64-bit loads issued back to back; a key seen before (the common case at sequencing coverage) then
+// costs that read plus one 32-bit add. Only a key whose home slot holds another key walks on (next address,
+// read, compare), and a compare-and-swap is spent only on an empty slot, i.e. once per distinct key.
+// The walk is the expensive part (every step is a full wave instruction sequence for the few lanes that
+// still probe), hence no wrap-around, no probe counter and no bounds test inside it (see TabCfg).
 template <int U>
 __device__ __forceinline__ void table_insert_stream1(const LdsTable<1> &t, const uint64_t *__restrict__ keys, uint64_t b, uint64_t e,
                                                      uint32_t npass, uint32_t pass) {
   constexpr int CAP = TabCfg<1>::CAP;
+  constexpr uint32_t LAST = TabCfg<1>::SLOTS - 1;
   if (b >= e) return;
   const uint64_t step = (uint64_t)blockDim.x * U;
   uint64_t nxt[U];
@@ -640,6 +770,7 @@ __device__ __forceinline__ void table_insert_stream1(const LdsTable<1> &t, const
     nxt[u] = keys[(i < e) ? i : e - 1];
   }
   for (uint64_t i0 = b; i0 < e; i0 += step) {
+    if (__atomic_load_n(t.overflow, __ATOMIC_RELAXED)) break;   // this pass is lost already: stop filling the table
     uint64_t k[U];
     bool act[U];
 #pragma unroll
@@ -664,17 +795,28 @@ __device__ __forceinline__ void table_insert_stream1(const LdsTable<1> &t, const
       act[u] = act[u] && (pass_of(h, npass) == pass);
       if (act[u] && k[u] == kEmptyKey) { *t.special_set = 1; atomicAdd(t.special, 1u); act[u] = false; }
     }
-    unsigned long long old[U];
+    uint64_t cur[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u)
-      old[u] = atomicCAS((unsigned long long *)&t.keys[slot[u]], (unsigned long long)kEmptyKey,
-                         (unsigned long long)(act[u] ? k[u] : kEmptyKey));
+    for (int u = 0; u < U; ++u) cur[u] = __atomic_load_n(&t.keys[slot[u]], __ATOMIC_RELAXED);
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       if (act[u]) {
-        int sidx = (int)slot[u];
-        if (!(old[u] == kEmptyKey || old[u] == k[u])) sidx = table_upsert_continue1(t, k[u], slot[u]);
-        if (sidx >= 0) atomicAdd(&t.vals[sidx], 1u);
+        uint32_t s = slot[u];
+        uint64_t c = cur[u];
+        for (;;) {
+          while (c != k[u] && c != kEmptyKey) { ++s; c = __atomic_load_n(&t.keys[s], __ATOMIC_RELAXED); }   // the walk
+          if (c == k[u]) break;
+          // empty slot: first sighting of this key (or the table is overloaded)
+          if (s >= LAST || __atomic_load_n(t.distinct, __ATOMIC_RELAXED) >= (uint32_t)TabCfg<1>::LIMIT) { *t.overflow = 1; s = LAST; break; }
+          const unsigned long long old = atomicCAS((unsigned long long *)&t.keys[s], (unsigned long long)kEmptyKey, (unsigned long long)k[u]);
+          if (old == kEmptyKey) {   // count the new key, one LDS add per wavefront
+            const unsigned long long m = __ballot(1);
+            if ((int)lane_id() == __ffsll((long long)m) - 1) atomicAdd(t.distinct, (uint32_t)__popcll(m));
+            break;
+          }
+          c = old;   // lost the slot to another lane: its key is ours (done) or the walk goes on
+        }
+        atomicAdd(&t.vals[s], 1u);   // (slot LAST never holds a key: counts parked there on overflow are never read)
       }
     }
   }
@@ -686,13 +828,11 @@ template <int NW> __device__ __forceinline__ int table_find(const LdsTable<NW> &
   uint32_t slot = slot_of(h, CAP);
   if (NW == 1) {
     if (key[0] == kEmptyKey) return *t.special_set ? -2 : -1;
-    for (int probes = 0; probes < CAP; ++probes) {
+    for (;; ++slot) {   // ends at the latest on the never-filled last slot
       uint64_t k = t.keys[slot];
       if (k == key[0]) return (int)slot;
       if (k == kEmptyKey) return -1;
-      slot = (slot + 1 == (uint32_t)CAP) ? 0u : slot + 1;
     }
-    return -1;
   } else {
     const uint32_t tagv = h | 0x80000000u;
     for (int probes = 0; probes < CAP; ++probes) {
@@ -737,9 +877,9 @@ __device__ __forceinline__ void for_each_key(const uint64_t *__restrict__ keys, 
 template <int NW> struct BatchOf { static constexpr int U = (NW == 1) ? kLoadBatch : (NW == 2 ? 4 : 2); };
 
 #define KMI_TABLE_LDS(NW)                                                   \
-  __shared__ uint64_t s_tk[TabCfg<NW>::CAP * NW];                           \
-  __shared__ uint32_t s_tv[TabCfg<NW>::CAP];                                \
-  __shared__ uint32_t s_tt[(NW == 1) ? 1 : TabCfg<NW>::CAP];               \
+  __shared__ uint64_t s_tk[TabCfg<NW>::SLOTS * NW];                         \
+  __shared__ uint32_t s_tv[TabCfg<NW>::SLOTS];                              \
+  __shared__ uint32_t s_tt[(NW == 1) ? 1 : TabCfg<NW>::SLOTS];             \
   __shared__ uint32_t s_ctl[8];                                             \
   LdsTable<NW> tab;                                                         \
   tab.keys = s_tk; tab.vals = s_tv; tab.tags = s_tt; tab.distinct = &s_ctl[0]; tab.overflow = &s_ctl[1]; \
@@ -756,7 +896,6 @@ __global__ __launch_bounds__((TabCfg<NW>::NT)) void bucket_reduce_kernel(const u
                                                                         uint32_t *__restrict__ tmp_vals, uint32_t *__restrict__ out_cnt,
                                                                         uint32_t *__restrict__ flags) {
   KMI_TABLE_LDS(NW)
-  constexpr int CAP = TabCfg<NW>::CAP;
   const uint32_t b = blockIdx.x;
   const uint64_t nb = new_off[b], ne = new_off[b + 1];
   const uint64_t ob = old_off ? old_off[b] : 0ull, oe = old_off ? old_off[b + 1] : 0ull;
@@ -789,7 +928,7 @@ __global__ __launch_bounds__((TabCfg<NW>::NT)) void bucket_reduce_kernel(const u
       }
       lds_barrier();
       if (*tab.overflow) { failed = true; break; }
-      for (int s = threadIdx.x; s < CAP; s += blockDim.x) {
+      for (int s = threadIdx.x; s < TabCfg<NW>::SLOTS; s += blockDim.x) {
         const bool used = slot_used<NW>(tab, s);
         const uint32_t pos = wave_alloc(s_out, used);
         if (used) {
@@ -858,7 +997,6 @@ __global__ __launch_bounds__((TabCfg<NW>::NT)) void bucket_query_kernel(int mode
                                                                        uint64_t *__restrict__ tmp_vals64, uint32_t *__restrict__ tmp_vals32,
                                                                        uint32_t *__restrict__ out_cnt, uint32_t *__restrict__ flags) {
   KMI_TABLE_LDS(NW)
-  constexpr int CAP = TabCfg<NW>::CAP;
   constexpr int OW = VW ? VW : 1;
   const uint32_t b = blockIdx.x;
   const uint64_t qb = q_off[b], qe = q_off[b + 1];
@@ -927,7 +1065,7 @@ __global__ __launch_bounds__((TabCfg<NW>::NT)) void bucket_query_kernel(int mode
       }
       lds_barrier();
       if (mode == Q_COUNT) {
-        for (int s = threadIdx.x; s < CAP; s += blockDim.x) {
+        for (int s = threadIdx.x; s < TabCfg<NW>::SLOTS; s += blockDim.x) {
           const bool used = slot_used<NW>(tab, s);
           const uint32_t pos = wave_alloc(s_out, used);
           if (used) {
@@ -1164,11 +1302,19 @@ static kmi_status build_fused_impl(kmi_index *idx, const uint8_t *bytes_dev, siz
   const bool canonical = idx->cfg.strand != KMI_STRAND_SINGLE;
   PartWs w;
   KMI_TRY(get_part_ws(ctx, n, NW, WS_KEYS_A, WS_KEYS_B, &w));
+  void *pl;
+  KMI_TRY(ws_get(ctx, WS_WIN_LIST, sizeof(uint16_t) * (n + 64), &pl));
+  uint16_t *win_pos = (uint16_t *)pl;
   KMI_HIP(ctx, hipMemsetAsync(w.fine_hist, 0, sizeof(uint32_t) * kNumFine * kFineParts, ctx->stream));
   {
+    ProfScope ps(ctx, "fastq_list", n);
+    hipLaunchKernelGGL((fastq_list_kernel<NW, BITS>), dim3(kListGroups), dim3(ExCfg<NW, BITS>::NT), 0, ctx->stream, in, n_tiles,
+                       idx->shape.k, line_base, sc.tile_off, win_pos);
+  }
+  {
     ProfScope ps(ctx, "fastq_hist", n);
-    hipLaunchKernelGGL((fastq_hist_kernel<NW, BITS>), dim3(kPartGroups), dim3(ExCfgWide<NW, BITS>::NT), 0, ctx->stream, in,
-                       n_tiles, idx->shape, canonical, line_base, w.fine_hist, w.wg_hist);
+    hipLaunchKernelGGL((fastq_hist_list_kernel<NW, BITS>), dim3(kPartGroups), dim3(kHistThreads), 0, ctx->stream, in, n_tiles, idx->shape,
+                       canonical, sc.tile_off, (const uint16_t *)win_pos, w.fine_hist, w.wg_hist);
   }
   {
     ProfScope ps(ctx, "fine_offsets", kNumFine);
@@ -1177,8 +1323,8 @@ static kmi_status build_fused_impl(kmi_index *idx, const uint8_t *bytes_dev, siz
   }
   {
     ProfScope ps(ctx, "fastq_scatter", n);
-    hipLaunchKernelGGL((fastq_scatter_kernel<NW, BITS>), dim3(kPartGroups), dim3(ExCfg<NW, BITS>::NT), 0, ctx->stream, in,
-                       n_tiles, idx->shape, canonical, line_base, (const uint64_t *)w.wg_off, w.buf_a);
+    hipLaunchKernelGGL((fastq_scatter_list_kernel<NW, BITS>), dim3(kPartGroups), dim3(ExCfg<NW, BITS>::NT), 0, ctx->stream, in,
+                       n_tiles, idx->shape, canonical, sc.tile_off, (const uint16_t *)win_pos, (const uint64_t *)w.wg_off, w.buf_a);
   }
   {
     ProfScope ps(ctx, "scatter_fine", n);

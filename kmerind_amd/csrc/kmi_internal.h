@@ -39,6 +39,7 @@ enum WsSlot {
   WS_FA_IDS,          // LongSequenceKmerId of every compacted FASTA character
   WS_PK_EOL,          // EOL bitmap of the scanned input
   WS_PK_STREAM,       // packed complement-code stream of the scanned input
+  WS_WIN_LIST,        // tile position of every k-mer window, file order (fused build)
   WS_NUM_SLOTS
 };
 
@@ -151,6 +152,7 @@ kmi_status upload_quality_lut(kmi_ctx *ctx);
 struct FastqScan {
   uint64_t n_tiles, n_tuples, n_seqs, n_bytes, n_cover;
   const uint32_t *line_base;
+  const uint64_t *tile_off;   // [n_tiles + 1] k-mer windows before each scan tile
   const uint8_t *pk_eol, *pk_stream;
 };
 kmi_status fastq_scan(kmi_ctx *ctx, const kmi_config *cfg, const uint8_t *bytes_dev, size_t n_bytes, FastqScan *out);
