@@ -367,51 +367,144 @@ __global__ __launch_bounds__(kPartThreads) void scatter_fine_kernel(const uint64
 // extracted tuple array never exists in HBM: 2 x 2.6 B/k-mer of input reads replace
 // 8 W + 8 R + 8 R of key traffic. Workgroup w owns the same contiguous run of tiles in both.
 // ---------------------------------------------------------------------------
-// L: the window list. One pass over the packed input (EOL bitmap + line bases from the scan) does all the
-// per-byte work -- line starts, line roles, EOL-free k-windows -- once, and leaves the tile position of
-// every k-mer window in HBM (2 bytes per k-mer, file order, windows of tile t at tile_off[t]).
-template <int NW, int BITS>
-__global__ __launch_bounds__((ExCfg<NW, BITS>::NT)) void fastq_list_kernel(PackedInput in, uint64_t n_tiles, uint32_t k,
-                                                                          const uint32_t *__restrict__ line_base,
-                                                                          const uint64_t *__restrict__ tile_off, uint16_t *__restrict__ win_pos) {
+// L: the window list. The tile position of every k-mer window goes to HBM once (2 bytes per k-mer, file
+// order, windows of scan tile t at tile_off[t]); the histogram and scatter passes start from it and have no
+// per-byte work left. The pass works per LINE, not per byte, and one WAVEFRONT owns a tile, so there is no
+// workgroup barrier in it: each lane takes WORDS/64 words of the tile's EOL bitmap and finds the line starts
+// in them; a line whose index (from the scan's line bases) says "sequence" becomes a run (first window,
+// number of windows) by looking up the next EOL bit; the wavefront then expands the runs into the list.
+// Windows belong to the tile they start in; a line that began in an earlier tile is picked up by lane 0.
+constexpr int kListThreads = 256;
+template <int NW, int BITS> struct ListPassCfg {
   using Cfg = ExCfg<NW, BITS>;
-  __shared__ uint32_t s_eol[Cfg::EOL_DW];
-  __shared__ uint32_t s_scan[Cfg::NT / 64 + 2];
-  __shared__ uint16_t s_pos[Cfg::TILE];
-  __shared__ uint32_t s_prev;
-  const uint64_t per = (n_tiles + gridDim.x - 1) / gridDim.x;
-  const uint64_t tb = (uint64_t)blockIdx.x * per;
+  static constexpr int TILE = Cfg::TILE;
+  static constexpr int WORDS = TILE / 32;
+  static constexpr int WPL = WORDS / kWave;                    // bitmap words per lane
+  static constexpr int HALO_W = (Cfg::KMAX + 30) / 32 + 1;     // words behind the tile that a k-window of the tile can reach
+  static_assert(WORDS % kWave == 0 && HALO_W <= kWave, "bitmap words map onto the lanes of a wavefront");
+  // a run needs a record of >= k + 7 bytes
+  static uint32_t max_runs(uint32_t k) { return (uint32_t)TILE / (k + 7u) + 2u; }
+  static uint32_t wave_lds_bytes(uint32_t k) { return (4u * (WORDS + HALO_W) + 6u * max_runs(k) + 15u) & ~15u; }
+};
+
+template <int NW, int BITS>
+__global__ __launch_bounds__(kListThreads) void fastq_list_kernel(PackedInput in, uint64_t n_tiles, uint32_t k, uint32_t max_runs,
+                                                                 uint32_t wave_lds_bytes, const uint32_t *__restrict__ line_base,
+                                                                 const uint64_t *__restrict__ tile_off, uint16_t *__restrict__ win_pos) {
+  using P = ListPassCfg<NW, BITS>;
+  constexpr int TILE = P::TILE, WORDS = P::WORDS, WPL = P::WPL, HALO_W = P::HALO_W;
+  extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];
+  uint32_t *s_e = reinterpret_cast<uint32_t *>(s_dyn + (size_t)wave_id() * wave_lds_bytes);   // [WORDS + HALO_W]
+  uint32_t *s_run = s_e + WORDS + HALO_W;                                                      // [max_runs] first window | windows << 16
+  uint16_t *s_off = reinterpret_cast<uint16_t *>(s_run + max_runs);                            // [max_runs] rank of the run's first window
+  const uint32_t *eolw = reinterpret_cast<const uint32_t *>(in.eol);
+  const uint64_t n_words = in.n_cover / 32;
+  const uint64_t n_waves = (uint64_t)gridDim.x * (kListThreads / kWave);
+  const uint64_t wv = (uint64_t)blockIdx.x * (kListThreads / kWave) + wave_id();
+  const uint64_t per = (n_tiles + n_waves - 1) / n_waves;
+  const uint64_t tb = wv * per;
   const uint64_t te = (tb + per < n_tiles) ? tb + per : n_tiles;
-  auto load_eol = [&](uint64_t tile, uint32_t &e, bool &ok) {   // clamped, validity applied on use
-    ok = tile < n_tiles;
-    e = read_eol_unit<Cfg::C>(in.eol, (ok ? tile : 0ull) * Cfg::NT + threadIdx.x);
-  };
-  uint32_t e_cur, e_nxt, e_nn; bool ok_cur, ok_nxt, ok_nn;
-  load_eol(tb, e_cur, ok_cur); ok_cur = ok_cur && tb < te;
-  load_eol(tb + 1, e_nxt, ok_nxt);
-  if (threadIdx.x == 0) s_prev = (tb < te) ? tile_prev_eol<Cfg>(in, tb) : 1u;
-  for (uint64_t t = tb; t < te; ++t) {
-    const uint32_t eol = ok_cur ? e_cur : Cfg::CMASK;
-    store_eol_bits<Cfg::C>(s_eol, threadIdx.x, eol);
-    if (threadIdx.x < Cfg::HALO_CHUNKS) store_eol_bits<Cfg::C>(s_eol, Cfg::NT + threadIdx.x, ok_nxt ? e_nxt : Cfg::CMASK);
-    lds_barrier();
-    load_eol(t + 2, e_nn, ok_nn);
-    bool prev_eol;
-    if (threadIdx.x > 0) {
-      const int pb = Cfg::C * threadIdx.x - 1;
-      prev_eol = (s_eol[pb >> 5] >> (pb & 31)) & 1u;
-    } else {
-      prev_eol = s_prev != 0;
+  const uint32_t lane = lane_id();
+  auto wave_sync = [&]() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); };
+  auto load_words = [&](uint64_t tile, uint32_t (&w)[WPL], uint32_t &h) {   // clamped loads, validity applied here
+#pragma unroll
+    for (int i = 0; i < WPL; ++i) {
+      const uint64_t g = tile * WORDS + (uint64_t)lane * WPL + i;
+      const uint32_t a = eolw[g < n_words ? g : 0];
+      w[i] = (g < n_words) ? a : 0xffffffffu;
     }
-    const uint32_t ls = line_starts(eol, prev_eol, Cfg::CMASK);
-    uint32_t ltot;
-    const uint32_t lbl = block_exclusive_scan<uint32_t>((uint32_t)__builtin_popcount(ls), s_scan, &ltot);
-    if (threadIdx.x == Cfg::NT - 1) s_prev = (eol >> (Cfg::C - 1)) & 1u;   // read again only after the next barriers
-    const uint32_t total = tile_window_list<Cfg>(s_eol, ls, line_base[t] + lbl, k, s_pos, s_scan);
-    uint16_t *dst = win_pos + tile_off[t];
-    for (uint32_t q = threadIdx.x; q < total; q += Cfg::NT) dst[q] = s_pos[q];
-    lds_barrier();   // the next tile overwrites s_eol and the list
-    e_cur = e_nxt; ok_cur = ok_nxt; e_nxt = e_nn; ok_nxt = ok_nn;
+    const uint64_t gh = tile * WORDS + WORDS + lane;
+    const uint32_t b = eolw[gh < n_words ? gh : 0];
+    h = (gh < n_words) ? b : 0xffffffffu;
+  };
+  // first EOL position >= bit `from` in the tile + halo image; TILE + 32 * HALO_W when there is none
+  auto next_eol = [&](uint32_t from) -> uint32_t {
+    uint32_t w = from >> 5;
+    uint32_t bits = s_e[w] & (0xffffffffu << (from & 31u));
+    while (bits == 0u && ++w < (uint32_t)(WORDS + HALO_W)) bits = s_e[w];
+    return bits ? (w << 5) + (uint32_t)__builtin_ctz(bits) : (uint32_t)(TILE + 32 * HALO_W);
+  };
+  // windows of the sequence line that starts (or continues) at tile position s: p in [s, min(e - k, TILE - 1)]
+  auto run_len = [&](uint32_t s) -> uint32_t {
+    const uint32_t e = next_eol(s);
+    if (e < s + k) return 0u;
+    uint32_t last = e - k;
+    if (last > (uint32_t)TILE - 1u) last = TILE - 1;
+    return last - s + 1u;
+  };
+  uint32_t w_cur[WPL], h_cur = 0xffffffffu, w_nxt[WPL], h_nxt;
+#pragma unroll
+  for (int i = 0; i < WPL; ++i) w_cur[i] = 0xffffffffu;
+  if (tb < te) load_words(tb, w_cur, h_cur);
+  uint32_t prev_tile = (tb < te && tb > 0) ? (eolw[tb * WORDS - 1] >> 31) : 1u;   // EOL status of the byte before the tile
+  uint32_t lb = (tb < te) ? line_base[tb] : 0u;
+  uint64_t toff = (tb < te) ? tile_off[tb] : 0ull;
+  for (uint64_t t = tb; t < te; ++t) {
+#pragma unroll
+    for (int i = 0; i < WPL; ++i) s_e[lane * WPL + i] = w_cur[i];
+    if (lane < (uint32_t)HALO_W) s_e[WORDS + lane] = h_cur;
+    wave_sync();
+    load_words(t + 1, w_nxt, h_nxt);   // the next tile's inputs are in flight during this tile
+    const uint32_t lb_nxt = line_base[(t + 1 < n_tiles) ? t + 1 : t];
+    const uint64_t toff_nxt = tile_off[t + 1];
+    uint32_t ls[WPL], nl = 0;
+    {
+      uint32_t prev = lane ? (s_e[lane * WPL - 1] >> 31) : prev_tile;
+#pragma unroll
+      for (int i = 0; i < WPL; ++i) {
+        ls[i] = ~w_cur[i] & ((w_cur[i] << 1) | prev);
+        prev = w_cur[i] >> 31;
+        nl += (uint32_t)__builtin_popcount(ls[i]);
+      }
+    }
+    const uint32_t lbl = wave_inclusive_scan(nl) - nl;
+    const bool carry_in = (lane == 0) && prev_tile == 0u && (w_cur[0] & 1u) == 0u && lb != 0u && ((lb - 1u) & 3u) == 1u;
+    // visit the runs of this lane in file order: f(first window, windows)
+    auto walk = [&](auto f) {
+      if (carry_in) { const uint32_t c = run_len(0u); if (c) f(0u, c); }
+      uint32_t idx = lb + lbl;
+#pragma unroll
+      for (int i = 0; i < WPL; ++i) {
+        uint32_t rest = ls[i];
+        while (rest) {
+          const uint32_t b = (uint32_t)__builtin_ctz(rest);
+          if ((idx & 3u) == 1u) { const uint32_t s0 = (lane * WPL + i) * 32u + b, c = run_len(s0); if (c) f(s0, c); }
+          ++idx; rest &= rest - 1u;
+        }
+      }
+    };
+    uint32_t mine = 0, first = 0;   // runs << 16 | windows; the lane's first run (the only one, normally)
+    walk([&](uint32_t s0, uint32_t c) { if (!mine) first = s0 | (c << 16); mine += (1u << 16) | c; });
+    const uint32_t inc = wave_inclusive_scan(mine);
+    const uint32_t tot = __shfl(inc, kWave - 1, kWave);
+    const uint32_t n_runs = tot >> 16;
+    auto expand = [&](uint32_t sc, uint32_t off) {   // wave-uniform arguments; positions go out two per 32-bit store
+      uint32_t s0 = sc & 0xffffu, c = sc >> 16;
+      uint64_t g = toff + off;                        // list index of the run's first window
+      if (g & 1ull) { if (lane == 0) win_pos[g] = (uint16_t)s0; ++g; ++s0; --c; }
+      uint32_t *dst2 = reinterpret_cast<uint32_t *>(win_pos + g);
+      for (uint32_t q = lane; q < (c >> 1); q += kWave) dst2[q] = (s0 + 2u * q) | ((s0 + 2u * q + 1u) << 16);
+      if ((c & 1u) && lane == 0) win_pos[g + c - 1u] = (uint16_t)(s0 + c - 1u);
+    };
+    if (__all((mine >> 16) <= 1u) && n_runs <= (uint32_t)kWave) {
+      // one run per lane at most: compact the runs across the lanes through the run table slots 0..n_runs-1
+      if (mine) { const uint32_t r = (inc - mine) >> 16; s_run[r] = first; s_off[r] = (uint16_t)((inc - mine) & 0xffffu); }
+      wave_sync();
+      const uint32_t my_sc = (lane < n_runs) ? s_run[lane] : 0u, my_off = (lane < n_runs) ? s_off[lane] : 0u;
+      for (uint32_t r = 0; r < n_runs; ++r) expand(__shfl(my_sc, (int)r, kWave), __shfl(my_off, (int)r, kWave));
+    } else {
+      if (mine) {
+        uint32_t r = (inc - mine) >> 16, off = (inc - mine) & 0xffffu;
+        walk([&](uint32_t s0, uint32_t c) { s_run[r] = s0 | (c << 16); s_off[r] = (uint16_t)off; ++r; off += c; });
+      }
+      wave_sync();
+      for (uint32_t r = 0; r < n_runs; ++r) expand(s_run[r], s_off[r]);
+    }
+    prev_tile = __shfl(w_cur[WPL - 1] >> 31, kWave - 1, kWave);
+    wave_sync();   // the next tile overwrites the bitmap image and the run table
+#pragma unroll
+    for (int i = 0; i < WPL; ++i) w_cur[i] = w_nxt[i];
+    h_cur = h_nxt; lb = lb_nxt; toff = toff_nxt;
   }
 }
 
@@ -1308,8 +1401,10 @@ static kmi_status build_fused_impl(kmi_index *idx, const uint8_t *bytes_dev, siz
   KMI_HIP(ctx, hipMemsetAsync(w.fine_hist, 0, sizeof(uint32_t) * kNumFine * kFineParts, ctx->stream));
   {
     ProfScope ps(ctx, "fastq_list", n);
-    hipLaunchKernelGGL((fastq_list_kernel<NW, BITS>), dim3(kListGroups), dim3(ExCfg<NW, BITS>::NT), 0, ctx->stream, in, n_tiles,
-                       idx->shape.k, line_base, sc.tile_off, win_pos);
+    using LP = ListPassCfg<NW, BITS>;
+    const uint32_t wave_lds = LP::wave_lds_bytes(idx->shape.k);
+    hipLaunchKernelGGL((fastq_list_kernel<NW, BITS>), dim3(kListGroups), dim3(kListThreads), wave_lds * (kListThreads / kWave), ctx->stream, in,
+                       n_tiles, idx->shape.k, LP::max_runs(idx->shape.k), wave_lds, line_base, sc.tile_off, win_pos);
   }
   {
     ProfScope ps(ctx, "fastq_hist", n);
