@@ -182,9 +182,8 @@ __device__ __forceinline__ void column_offsets(const uint32_t *__restrict__ wg_h
 __global__ __launch_bounds__(1024) void fine_offsets_kernel(const uint32_t *__restrict__ fine_hist, const uint32_t *__restrict__ wg_hist,
                                                            uint32_t groups, uint64_t *__restrict__ fine_off,
                                                            uint64_t *__restrict__ part_off,   // [kFineParts][kNumFine] or null
-                                                           uint64_t *__restrict__ wg_off) {
+                                                           uint64_t *__restrict__ coarse_base /* [kNumCoarse] */) {
   __shared__ uint64_t s_scan[1024 / 64 + 2];
-  __shared__ uint64_t s_coarse[kNumCoarse];
   constexpr int PER = kNumFine / 1024;  // 32 fine buckets per thread; a coarse bucket = 4 threads
   uint32_t loc[kFineParts][PER];
   uint64_t sum = 0;
@@ -194,7 +193,7 @@ __global__ __launch_bounds__(1024) void fine_offsets_kernel(const uint32_t *__re
     for (int i = 0; i < PER; ++i) { loc[h][i] = fine_hist[(uint64_t)h * kNumFine + threadIdx.x * PER + i]; sum += loc[h][i]; }
   uint64_t total;
   uint64_t off = block_exclusive_scan<uint64_t>(sum, s_scan, &total);
-  if ((threadIdx.x & 3u) == 0) s_coarse[threadIdx.x >> 2] = off;
+  if ((threadIdx.x & 3u) == 0) coarse_base[threadIdx.x >> 2] = off;
 #pragma unroll
   for (int i = 0; i < PER; ++i) {
     fine_off[threadIdx.x * PER + i] = off;
@@ -205,8 +204,21 @@ __global__ __launch_bounds__(1024) void fine_offsets_kernel(const uint32_t *__re
     }
   }
   if (threadIdx.x == 0) fine_off[kNumFine] = total;
-  lds_barrier();
-  if (wg_off) column_offsets(wg_hist, groups, kNumCoarse, s_coarse, wg_off);
+}
+
+// wg_off[w][c] = coarse_base[c] + sum_{w' < w} wg_hist[w'][c]: one wavefront per coarse bucket, spread over the chip
+__global__ __launch_bounds__(256) void coarse_cursors_kernel(const uint32_t *__restrict__ wg_hist, uint32_t groups,
+                                                            const uint64_t *__restrict__ coarse_base, uint64_t *__restrict__ wg_off) {
+  const uint32_t c = blockIdx.x * (blockDim.x >> 6) + wave_id();
+  if (c >= (uint32_t)kNumCoarse) return;
+  uint64_t carry = coarse_base[c];
+  for (uint32_t w0 = 0; w0 < groups; w0 += kWave) {
+    const uint32_t w = w0 + lane_id();
+    const uint64_t v = (w < groups) ? wg_hist[(uint64_t)w * kNumCoarse + c] : 0ull;
+    const uint64_t inc = wave_inclusive_scan(v);
+    if (w < groups) wg_off[(uint64_t)w * kNumCoarse + c] = carry + inc - v;
+    carry += __shfl(inc, kWave - 1, kWave);
+  }
 }
 
 // rank mode: bucket_off[r] (nbuckets+1) and wg_off[w][r]
@@ -640,38 +652,44 @@ __global__ __launch_bounds__((ExCfg<NW, BITS>::NT)) void fastq_scatter_list_kern
   if (tb >= te) return;
   const uint64_t q_end = tile_off[te];
   const uint64_t last_unit = in.n_cover / Cfg::C - 1;
-  uint64_t q0 = tile_off[tb];
-  uint64_t t = tb;
-  while (q0 < q_end) {
+  // a round: windows [q0, q0 + total) of tiles t .. t + RMAX - 1; orel[i] = rank of tile t+i's first window
+  struct Round { uint64_t t, q0; uint32_t total; uint32_t orel[RMAX]; };
+  auto plan = [&](uint64_t t, uint64_t q0, Round &r) {
     while (tile_off[t + 1] <= q0) ++t;                 // tile of window q0 (tiles without windows are skipped)
-    // tile boundaries inside the round, relative to q0 (entries past the workgroup's range do not bind)
     uint64_t o[RMAX + 1];
 #pragma unroll
-    for (int i = 1; i <= RMAX; ++i) o[i] = (t + i <= te) ? tile_off[t + i] : q_end;
+    for (int i = 1; i <= RMAX; ++i) o[i] = (t + i <= te) ? tile_off[t + i] : q_end;   // past the range: does not bind
     uint64_t q1 = q0 + CAPW;
     if (q1 > o[RMAX]) q1 = o[RMAX];
     if (q1 > q_end) q1 = q_end;
-    const uint32_t total = (uint32_t)(q1 - q0);
-    uint32_t orel[RMAX];
+    r.t = t; r.q0 = q0; r.total = (uint32_t)(q1 - q0);
 #pragma unroll
-    for (int i = 1; i < RMAX; ++i) { const uint64_t d = o[i] - q0; orel[i] = d > (uint64_t)CAPW ? (uint32_t)CAPW : (uint32_t)d; }
-    // packed stream of tiles t .. t+RMAX-1 (+ halo) as one LDS image; unit loads are clamped, not guarded
+    for (int i = 1; i < RMAX; ++i) { const uint64_t d = o[i] - q0; r.orel[i] = d > (uint64_t)CAPW ? (uint32_t)CAPW : (uint32_t)d; }
+  };
+  uint64_t st[L::ULOADS];
+  uint32_t p16[MAXQ];
+  // inputs of a round: the packed stream of its tiles (+ halo) and this thread's window positions
+  // (q = tid, tid + NT, ...); clamped loads, not guarded ones, so nothing forces an early wait
+  auto fetch = [&](const Round &r) {
+#pragma unroll
+    for (int i = 0; i < L::ULOADS; ++i) {
+      uint64_t g = r.t * NT + (uint64_t)i * NT + threadIdx.x;
+      g = g < last_unit ? g : last_unit;
+      st[i] = read_stream_unit<BITS, Cfg::C>(in.stream, g);
+    }
+#pragma unroll
+    for (int m = 0; m < MAXQ; ++m) {
+      uint32_t q = m * NT + threadIdx.x;
+      q = q < r.total ? q : r.total - 1;
+      p16[m] = win_pos[r.q0 + q];
+    }
+  };
+  Round cur, nxt;
+  bool have = tile_off[tb] < q_end;
+  if (have) { plan(tb, tile_off[tb], cur); fetch(cur); }
+  while (have) {
+    const uint32_t total = cur.total;
     {
-      uint64_t st[L::ULOADS];
-#pragma unroll
-      for (int i = 0; i < L::ULOADS; ++i) {
-        uint64_t g = t * NT + (uint64_t)i * NT + threadIdx.x;
-        g = g < last_unit ? g : last_unit;
-        st[i] = read_stream_unit<BITS, Cfg::C>(in.stream, g);
-      }
-      // window positions of this thread: q = tid, tid + NT, ...
-      uint32_t p16[MAXQ];
-#pragma unroll
-      for (int m = 0; m < MAXQ; ++m) {
-        uint32_t q = m * NT + threadIdx.x;
-        q = q < total ? q : total - 1;
-        p16[m] = win_pos[q0 + q];
-      }
 #pragma unroll
       for (int i = 0; i < L::ULOADS; ++i) {
         const int u = i * NT + threadIdx.x;
@@ -687,7 +705,7 @@ __global__ __launch_bounds__((ExCfg<NW, BITS>::NT)) void fastq_scatter_list_kern
         if (q < total) {
           uint32_t r = 0;
 #pragma unroll
-          for (int i = 1; i < RMAX; ++i) r += (q >= orel[i]) ? 1u : 0u;
+          for (int i = 1; i < RMAX; ++i) r += (q >= cur.orel[i]) ? 1u : 0u;
           uint64_t rc[NW], fw[NW];
           window_at<Cfg>(s_stream, r * Cfg::TILE + p16[m], shape, rc, fw);
           select_strand<NW>(rc, fw, canonical, key[m]);
@@ -695,6 +713,9 @@ __global__ __launch_bounds__((ExCfg<NW, BITS>::NT)) void fastq_scatter_list_kern
           bkrk[m] = (b << 16) | atomicAdd(&s_cnt[b], 1u);
         }
       }
+      // the next round's inputs travel while this one is sorted and written out
+      have = cur.q0 + total < q_end;
+      if (have) { plan(cur.t, cur.q0 + total, nxt); fetch(nxt); }
       lds_barrier();
       uint32_t c = 0, inc = 0;
       if (threadIdx.x < kNumCoarse) {
@@ -733,7 +754,7 @@ __global__ __launch_bounds__((ExCfg<NW, BITS>::NT)) void fastq_scatter_list_kern
       for (int w = 0; w < NW; ++w) out[dst * NW + w] = s_stage[(uint64_t)s * NW + w];
     }
     lds_barrier();   // the next round overwrites the stream image and the stage
-    q0 = q1;
+    cur = nxt;
   }
 }
 
@@ -1252,6 +1273,7 @@ struct PartWs {
   uint32_t *fine_hist;   // [kFineParts][kNumFine]
   uint64_t *fine_off;    // [kNumFine + 1]
   uint64_t *part_off;    // [kFineParts][kNumFine]
+  uint64_t *coarse_base; // [kNumCoarse]
   uint32_t *wg_hist;     // [kPartGroups][kNumCoarse]
   uint64_t *wg_off;      // [kPartGroups][kNumCoarse]
 };
@@ -1261,12 +1283,13 @@ static kmi_status get_part_ws(kmi_ctx *ctx, size_t n, int nw, WsSlot slot_a, WsS
   const size_t key_bytes = (n ? n : 1) * nw * sizeof(uint64_t);
   KMI_TRY(ws_get(ctx, slot_a, key_bytes, &p)); w->buf_a = (uint64_t *)p;
   KMI_TRY(ws_get(ctx, slot_b, key_bytes, &p)); w->buf_b = (uint64_t *)p;
-  KMI_TRY(ws_get(ctx, WS_HIST, sizeof(uint32_t) * kNumFine * kFineParts + sizeof(uint64_t) * ((kNumFine + 1) * 2 + kNumFine * kFineParts) + 256, &p));
+  KMI_TRY(ws_get(ctx, WS_HIST, sizeof(uint32_t) * kNumFine * kFineParts + sizeof(uint64_t) * ((kNumFine + 1) * 2 + kNumFine * kFineParts + kNumCoarse) + 256, &p));
   w->fine_hist = (uint32_t *)p;
   // offset arrays live behind the histogram: [0] for inserts, [1] for queries, then the per-part offsets
   uint64_t *off_base = (uint64_t *)((char *)p + sizeof(uint32_t) * kNumFine * kFineParts);
   w->fine_off = off_base + (slot_b == WS_QUERY_B ? (kNumFine + 1) : 0);
   w->part_off = off_base + 2 * (kNumFine + 1);
+  w->coarse_base = w->part_off + (uint64_t)kNumFine * kFineParts;
   KMI_TRY(ws_get(ctx, WS_WGHIST, sizeof(uint32_t) * kPartGroups * kNumCoarse, &p)); w->wg_hist = (uint32_t *)p;
   KMI_TRY(ws_get(ctx, WS_CURSOR, sizeof(uint64_t) * kPartGroups * kNumCoarse, &p)); w->wg_off = (uint64_t *)p;
   return KMI_OK;
@@ -1287,7 +1310,9 @@ static kmi_status partition_impl(kmi_ctx *ctx, const kmi_config *cfg, KShape sha
   {
     ProfScope ps(ctx, "fine_offsets", kNumFine);
     hipLaunchKernelGGL(fine_offsets_kernel, dim3(1), dim3(1024), 0, ctx->stream, w.fine_hist, w.wg_hist, (uint32_t)kPartGroups, w.fine_off,
-                       w.part_off, w.wg_off);
+                       w.part_off, w.coarse_base);
+    hipLaunchKernelGGL(coarse_cursors_kernel, dim3(kNumCoarse / 4), dim3(256), 0, ctx->stream, (const uint32_t *)w.wg_hist, (uint32_t)kPartGroups,
+                       (const uint64_t *)w.coarse_base, w.wg_off);
   }
   BucketFn fn; fn.mode = BUCKET_COARSE; fn.shape = shape; fn.dist_hash = 0; fn.farm_ndebug = false; fn.nranks = 1;
   {
@@ -1414,7 +1439,9 @@ static kmi_status build_fused_impl(kmi_index *idx, const uint8_t *bytes_dev, siz
   {
     ProfScope ps(ctx, "fine_offsets", kNumFine);
     hipLaunchKernelGGL(fine_offsets_kernel, dim3(1), dim3(1024), 0, ctx->stream, w.fine_hist, w.wg_hist, (uint32_t)kPartGroups, w.fine_off,
-                       w.part_off, w.wg_off);
+                       w.part_off, w.coarse_base);
+    hipLaunchKernelGGL(coarse_cursors_kernel, dim3(kNumCoarse / 4), dim3(256), 0, ctx->stream, (const uint32_t *)w.wg_hist, (uint32_t)kPartGroups,
+                       (const uint64_t *)w.coarse_base, w.wg_off);
   }
   {
     ProfScope ps(ctx, "fastq_scatter", n);
