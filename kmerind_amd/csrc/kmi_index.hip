@@ -870,51 +870,45 @@ __device__ __forceinline__ uint32_t pass_of(uint32_t h, uint32_t npass) {
 // read, compare), and a compare-and-swap is spent only on an empty slot, i.e. once per distinct key.
 // The walk is the expensive part (every step is a full wave instruction sequence for the few lanes that
 // still probe), hence no wrap-around, no probe counter and no bounds test inside it (see TabCfg).
-template <int U>
-__device__ __forceinline__ void table_insert_stream1(const LdsTable<1> &t, const uint64_t *__restrict__ keys, uint64_t b, uint64_t e,
+template <int U, bool MULTI>
+__device__ __forceinline__ void table_insert_stream1(const LdsTable<1> &t, const uint64_t *__restrict__ keys /* bucket base */, uint32_t n,
                                                      uint32_t npass, uint32_t pass) {
   constexpr int CAP = TabCfg<1>::CAP;
   constexpr uint32_t LAST = TabCfg<1>::SLOTS - 1;
-  if (b >= e) return;
-  const uint64_t step = (uint64_t)blockDim.x * U;
-  uint64_t nxt[U];
-#pragma unroll
-  for (int u = 0; u < U; ++u) {
-    const uint64_t i = b + (uint64_t)u * blockDim.x + threadIdx.x;
-    nxt[u] = keys[(i < e) ? i : e - 1];
-  }
-  for (uint64_t i0 = b; i0 < e; i0 += step) {
-    if (__atomic_load_n(t.overflow, __ATOMIC_RELAXED)) break;   // this pass is lost already: stop filling the table
-    uint64_t k[U];
-    bool act[U];
+  constexpr uint32_t NT = TabCfg<1>::NT;
+  constexpr uint32_t STEP = NT * U;
+  if (n == 0) return;
+  const uint32_t last = n - 1;
+  // 32-bit indices relative to the bucket, clamped (not guarded) loads, two register sets in ping-pong:
+  // the batch after the one being inserted is always in flight and nothing is copied between them
+  auto load = [&](uint32_t i0, uint64_t (&r)[U]) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const uint64_t i = i0 + (uint64_t)u * blockDim.x + threadIdx.x;
-      act[u] = i < e;
-      k[u] = nxt[u];
+      uint32_t i = i0 + (uint32_t)u * NT + threadIdx.x;
+      i = i < last ? i : last;
+      r[u] = keys[i];
     }
-    if (i0 + step < e) {   // next batch in flight while this one goes through the table
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const uint64_t i = i0 + step + (uint64_t)u * blockDim.x + threadIdx.x;
-        nxt[u] = keys[(i < e) ? i : e - 1];   // clamped, validity applied when consumed
-      }
-    }
-    uint32_t slot[U];
+  };
+  auto insert = [&](uint32_t i0, const uint64_t (&k)[U]) {
+    uint32_t slot[U], actm = 0, spec = 0;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const uint64_t kk[1] = {k[u]};
       const uint32_t h = place_hash<1>(kk);
       slot[u] = slot_of(h, CAP);
-      act[u] = act[u] && (pass_of(h, npass) == pass);
-      if (act[u] && k[u] == kEmptyKey) { *t.special_set = 1; atomicAdd(t.special, 1u); act[u] = false; }
+      bool a = i0 + (uint32_t)u * NT + threadIdx.x < n;
+      if (MULTI) a = a && (pass_of(h, npass) == pass);
+      const bool sp = k[u] == kEmptyKey;
+      actm |= (a && !sp) ? (1u << u) : 0u;
+      spec += (a && sp) ? 1u : 0u;
     }
+    if (spec) { *t.special_set = 1; atomicAdd(t.special, spec); }   // the key that equals the empty marker (k-mers filling all 64 bits only)
     uint64_t cur[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) cur[u] = __atomic_load_n(&t.keys[slot[u]], __ATOMIC_RELAXED);
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      if (act[u]) {
+      if (actm & (1u << u)) {
         uint32_t s = slot[u];
         uint64_t c = cur[u];
         for (;;) {
@@ -932,6 +926,18 @@ __device__ __forceinline__ void table_insert_stream1(const LdsTable<1> &t, const
         }
         atomicAdd(&t.vals[s], 1u);   // (slot LAST never holds a key: counts parked there on overflow are never read)
       }
+    }
+  };
+  uint64_t ka[U], kb[U];
+  load(0u, ka);
+  for (uint32_t i0 = 0; i0 < n; i0 += 2 * STEP) {
+    if (__atomic_load_n(t.overflow, __ATOMIC_RELAXED)) break;   // this pass is lost already: stop filling the table
+    const bool has_b = i0 + STEP < n;
+    if (has_b) load(i0 + STEP, kb);
+    insert(i0, ka);
+    if (has_b) {
+      if (i0 + 2 * STEP < n) load(i0 + 2 * STEP, ka);
+      insert(i0 + STEP, kb);
     }
   }
 }
@@ -1031,7 +1037,8 @@ __global__ __launch_bounds__((TabCfg<NW>::NT)) void bucket_reduce_kernel(const u
         else if (s == -2) atomicAdd(tab.special, old_vals[i]);
       });
       if constexpr (NW == 1) {
-        table_insert_stream1<kLoadBatch>(tab, new_keys, nb, ne, npass, pass);
+        if (npass == 1) table_insert_stream1<kLoadBatch, false>(tab, new_keys + nb, (uint32_t)(ne - nb), 1u, 0u);
+        else table_insert_stream1<kLoadBatch, true>(tab, new_keys + nb, (uint32_t)(ne - nb), npass, pass);
       } else {
         for_each_key<NW, BatchOf<NW>::U>(new_keys, nb, ne, [&](const uint64_t (&k)[NW], uint64_t) {
           const uint32_t h = place_hash<NW>(k);
