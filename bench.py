@@ -19,8 +19,20 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-B_ALG = 10.625          # algorithmic HBM bytes read per k-mer: 315/120 + 8
+B_ALG = 10.625          # whole-job contract figure, HBM bytes read per k-mer: 315/120 + 8
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md)
+# Algorithmic HBM bytes per k-mer of each kernel of the fused build: what the kernel
+# must read + write once, for config 2 (k=31, 315-byte records -> 2.625 input bytes per k-mer, u = distinct /
+# total = 1/12). The roofline entry prices the dominant kernel with its own figure.
+KERNEL_ALG_BYTES = {
+    "fastq_scan_tiles": 2.625 + 2.625 * (2 + 1) / 8,       # raw bytes in; 2-bit stream + EOL bitmap out
+    "fastq_list": 2.625 / 8 + 2.0,                         # EOL bitmap in; 2-byte window position out
+    "fastq_hist": 2.0 + 2.625 * 2 / 8,                     # window list + packed stream in
+    "fastq_scatter": 2.0 + 2.625 * 2 / 8 + 8.0,            # list + stream in; 8-byte key out
+    "scatter_fine": 16.0,                                  # key in, key out
+    "bucket_reduce": 8.0 + 12.0 / 12,                      # key in; (key, count) of each distinct key out
+    "bucket_compact": 2 * 12.0 / 12,
+}
 
 
 def main():
@@ -136,11 +148,14 @@ def main():
         roofline = None
         if dom:
             avg_ms = dom["total_ms"] / dom["launches"]
-            achieved = n_kmers * B_ALG / (avg_ms * 1e-3) / 1e9
+            b_kernel = KERNEL_ALG_BYTES.get(dom["name"], B_ALG)
+            achieved = n_kmers * b_kernel / (avg_ms * 1e-3) / 1e9
             roofline = {"bound": "hbm", "kernel": dom["name"], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                        "traffic": measured_traffic(dom["name"], n_reads),
                         "avg_kernel_ms": round(avg_ms, 4),
-                        "alg_bytes_per_launch": n_kmers * B_ALG,
+                        "alg_bytes_per_kmer": b_kernel,
+                        "alg_bytes_per_launch": n_kmers * b_kernel,
                         "pipeline_frac": round(n_kmers * B_ALG / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                         "kernels_ms_per_step": {p["name"]: round(p["total_ms"] / args.steps, 4) for p in
                                                 sorted(prof, key=lambda p: -p["total_ms"])}}
@@ -160,6 +175,23 @@ def main():
     ctx.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+def measured_traffic(kernel, n_reads):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE,
+    profiles/*_hbm_traffic.json, collected on config 2); None for other workloads or kernels."""
+    import glob
+    if n_reads != 10_000_000:
+        return None
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.json")))
+    if not files:
+        return None
+    try:
+        with open(files[-1]) as f:
+            rec = json.load(f)["kernels"].get(kernel)
+        return rec["hbm_bytes"] if rec else None
+    except (OSError, ValueError, KeyError):
+        return None
 
 
 def cpu_baseline(host, args, k, n_reads):

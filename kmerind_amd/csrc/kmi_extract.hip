@@ -54,8 +54,7 @@ __global__ __launch_bounds__((ExCfg<NW, BITS>::NT)) void fastq_scan_tiles_kernel
   const uint32_t cand = ~(uint32_t)e[0] & Cfg::CMASK;
 
   // windows by local phase: 16-bit fields (phase 0,1) and (phase 2,3); marker bits by local phase
-  uint32_t lo = 0, hi = 0, marks = 0;
-  uint32_t last[4] = {0, 0, 0, 0};
+  uint32_t lo = 0, hi = 0;
   {
     uint32_t cur = lbl, start = 0, rest = ls;
     while (true) {
@@ -65,31 +64,19 @@ __global__ __launch_bounds__((ExCfg<NW, BITS>::NT)) void fastq_scan_tiles_kernel
       uint32_t ph = cur & 3u;
       if (ph < 2) lo += c << (16 * ph); else hi += c << (16 * (ph - 2));
       if (!rest) break;
-      // the line that starts at q has local index `cur` (fastq_loader.hpp:421-422,437-438)
+      // the line that starts at q has local index `cur` (fastq_loader.hpp:421-422,437-438). Line starts are
+      // sparse (one per ~70 bytes), so the few lanes that have one talk to LDS directly.
       const uint32_t ch = (dw[q >> 2] >> (8 * (q & 3))) & 0xffu;
-      if (ch != '@') marks |= 1u << (cur & 3u);
-      if (ch != '+') marks |= 16u << (cur & 3u);
-      const uint32_t lp = threadIdx.x * Cfg::C + q + 1u;
-#pragma unroll
-      for (uint32_t r = 0; r < 4; ++r) last[r] = ((cur & 3u) == r) ? lp : last[r];
+      const uint32_t mk = ((ch != '@') ? 1u : 0u) | ((ch != '+') ? 16u : 0u);
+      atomicOr(&s_cnt[2], mk << (cur & 3u));
+      atomicMax(&s_last[cur & 3u], threadIdx.x * Cfg::C + q + 1u);
       cur += 1; start = q; rest &= rest - 1u;
     }
   }
   // get_next_record refuses a partition that does not begin with '@' (fastq_loader.hpp:392-393)
   if (blockIdx.x == 0 && threadIdx.x == 0 && (dw[0] & 0xffu) != '@') atomicOr(&flags[0], 1u);
   lo = wave_reduce_sum(lo); hi = wave_reduce_sum(hi);
-#pragma unroll
-  for (int d = kWave / 2; d > 0; d >>= 1) marks |= __shfl_xor(marks, d, kWave);
-#pragma unroll
-  for (uint32_t r = 0; r < 4; ++r) {
-#pragma unroll
-    for (int d = kWave / 2; d > 0; d >>= 1) { uint32_t o = __shfl_xor(last[r], d, kWave); last[r] = o > last[r] ? o : last[r]; }
-  }
-  if (lane_id() == 0) {
-    atomicAdd(&s_cnt[0], lo); atomicAdd(&s_cnt[1], hi); atomicOr(&s_cnt[2], marks);
-#pragma unroll
-    for (uint32_t r = 0; r < 4; ++r) if (last[r]) atomicMax(&s_last[r], last[r]);
-  }
+  if (lane_id() == 0) { atomicAdd(&s_cnt[0], lo); atomicAdd(&s_cnt[1], hi); }
   lds_barrier();
   if (threadIdx.x == 0) {
     TileInfo ti;
