@@ -160,6 +160,8 @@ namespace transform { template <typename K> struct lex_less {}; template <typena
 namespace hash {
 template <typename K, bool Prefix = false> struct murmur { static constexpr uint32_t KMI = KMI_HASH_MURMUR; };
 template <typename K, bool Prefix = false> struct farm { static constexpr uint32_t KMI = KMI_HASH_FARM; };
+template <typename K, bool Prefix = false> struct identity { static constexpr uint32_t KMI = KMI_HASH_IDENTITY; };
+template <typename K, bool Prefix = false> struct cpp_std { static constexpr uint32_t KMI = KMI_HASH_STD; };
 }  // namespace hash
 }  // namespace kmer
 

@@ -49,7 +49,8 @@ typedef enum {
 
 enum { KMI_ALPHA_DNA = 0, KMI_ALPHA_DNA5 = 1 };                 /* alphabets.hpp:127-185, 212-285 (DNA5 == DNA6) */
 enum { KMI_STRAND_SINGLE = 0, KMI_STRAND_CANONICAL = 1, KMI_STRAND_BIMOLECULE = 2 }; /* kmer_index.hpp:436-481 */
-enum { KMI_HASH_MURMUR = 0, KMI_HASH_FARM = 1 };                /* kmer_hash.hpp:242-311 */
+enum { KMI_HASH_MURMUR = 0, KMI_HASH_FARM = 1,                  /* kmer_hash.hpp:242-311 */
+       KMI_HASH_IDENTITY = 2, KMI_HASH_STD = 3 };               /* kmer_hash.hpp:205-230, 154-198 (cpp_std, libstdc++) */
 enum { KMI_FMT_FASTQ = 0, KMI_FMT_FASTA = 1 };
 enum { KMI_INDEX_COUNT = 0, KMI_INDEX_POSITION = 1, KMI_INDEX_POSQUAL = 2 }; /* kmer_index.hpp:399-411 */
 
@@ -90,7 +91,8 @@ kmi_status kmi_synchronize(kmi_ctx *ctx);
 kmi_status kmi_revcomp_host(kmi_ctx *ctx, const kmi_config *cfg, const uint64_t *in, size_t n, uint64_t *out);
 /* transform::lex_less (kmer_transform.hpp:108-116) */
 kmi_status kmi_canonical_host(kmi_ctx *ctx, const kmi_config *cfg, const uint64_t *in, size_t n, uint64_t *out);
-/* hash::murmur / hash::farm <Kmer,Prefix> (kmer_hash.hpp:242-311) */
+/* hash::murmur / farm / identity / cpp_std <Kmer,Prefix> (kmer_hash.hpp:154-311); identity and cpp_std with
+ * their default-constructed prefix width (24 / 32 bits); inside KeyToRank they get ceilLog2(nranks) like the reference */
 kmi_status kmi_hash_host(kmi_ctx *ctx, const kmi_config *cfg, uint32_t which, int prefix,
                          const uint64_t *in, size_t n, uint64_t *out);
 /* KeyToRank (distributed_unordered_map.hpp:148-170): DistHash(DistTrans(k)) % nranks */

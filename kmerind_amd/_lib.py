@@ -19,7 +19,7 @@ lib = C.CDLL(LIB_PATH)
 OK, ERR_INVALID, ERR_DEVICE, ERR_PARSE, ERR_NOMEM, ERR_OVERFLOW = range(6)
 ALPHA_DNA, ALPHA_DNA5 = 0, 1
 STRAND_SINGLE, STRAND_CANONICAL, STRAND_BIMOLECULE = 0, 1, 2
-HASH_MURMUR, HASH_FARM = 0, 1
+HASH_MURMUR, HASH_FARM, HASH_IDENTITY, HASH_STD = 0, 1, 2, 3
 FMT_FASTQ, FMT_FASTA = 0, 1
 INDEX_COUNT, INDEX_POSITION, INDEX_POSQUAL = 0, 1, 2
 

@@ -17,7 +17,7 @@ def make_config(k, alphabet="DNA", strand="canonical", dist_hash="murmur", store
                 index_kind="count", seq_format="fastq", farm_ndebug=False):
     alpha = {"DNA": L.ALPHA_DNA, "DNA5": L.ALPHA_DNA5, "DNA6": L.ALPHA_DNA5}[alphabet]
     st = {"single": L.STRAND_SINGLE, "canonical": L.STRAND_CANONICAL, "bimolecule": L.STRAND_BIMOLECULE}[strand]
-    hs = {"murmur": L.HASH_MURMUR, "farm": L.HASH_FARM}
+    hs = {"murmur": L.HASH_MURMUR, "farm": L.HASH_FARM, "identity": L.HASH_IDENTITY, "std": L.HASH_STD}
     kind = {"count": L.INDEX_COUNT, "position": L.INDEX_POSITION, "posqual": L.INDEX_POSQUAL}[index_kind]
     fmt = {"fastq": L.FMT_FASTQ, "fasta": L.FMT_FASTA}[seq_format]
     return L.Config(k, alpha, st, hs[dist_hash], hs[store_hash], kind, fmt, int(bool(farm_ndebug)))
@@ -99,7 +99,7 @@ class Context:
         return self._array_op(lib.kmi_canonical_host, cfg, kmers, np.uint64, True)
 
     def hash(self, cfg, which, prefix, kmers):
-        which = {"murmur": L.HASH_MURMUR, "farm": L.HASH_FARM}.get(which, which)
+        which = {"murmur": L.HASH_MURMUR, "farm": L.HASH_FARM, "identity": L.HASH_IDENTITY, "std": L.HASH_STD}.get(which, which)
         return self._array_op(lib.kmi_hash_host, cfg, kmers, np.uint64, False, which, int(prefix))
 
     def key_to_rank(self, cfg, kmers, nranks):

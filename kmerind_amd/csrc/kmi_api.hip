@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256) void kmer_array_op_kernel(const uint64_t *__re
       if (strand == KMI_STRAND_BIMOLECULE) { canonical_words<NW, BITS>(k, r, shape);
 #pragma unroll
         for (int w = 0; w < NW; ++w) k[w] = r[w]; }
-      out32[i] = (uint32_t)(kmer_hash<NW>(k, shape, which, true, farm_ndebug) % nranks);
+      out32[i] = (uint32_t)(kmer_hash<NW>(k, shape, which, true, farm_ndebug, ceil_log2_u32(nranks)) % nranks);
     }
   }
 }
@@ -228,7 +228,7 @@ kmi_status kmi_canonical_host(kmi_ctx *ctx, const kmi_config *cfg, const uint64_
 }
 kmi_status kmi_hash_host(kmi_ctx *ctx, const kmi_config *cfg, uint32_t which, int prefix, const uint64_t *in, size_t n,
                          uint64_t *out) {
-  if (which > 1) return set_err(ctx, KMI_ERR_INVALID, "unknown hash");
+  if (which > 3) return set_err(ctx, KMI_ERR_INVALID, "unknown hash");
   return array_op_host(ctx, cfg, OP_HASH, which, prefix != 0, 1, in, n, out);
 }
 kmi_status kmi_key_to_rank_host(kmi_ctx *ctx, const kmi_config *cfg, const uint64_t *in, size_t n, uint32_t nranks,

@@ -261,14 +261,58 @@ template <int NW> KMI_HD uint64_t farm_hash64_with_seed(const uint64_t (&key)[NW
   return h;
 }
 
-// bliss::kmer::hash::{murmur,farm}<KMER,Prefix>
-template <int NW> KMI_HD uint64_t kmer_hash(const uint64_t (&key)[NW], const KShape &s, uint32_t which, bool prefix, bool farm_ndebug) {
+// ceilLog2(comm_size): the prefix_bits KeyToRank hands to DistHash's constructor
+// (src/common/bit_ops.hpp:144-152, src/containers/distributed_unordered_map.hpp:153-156)
+KMI_HD uint32_t ceil_log2_u32(uint32_t n) {
+  uint32_t b = 0;
+  while (b < 32u && (1ull << b) < (uint64_t)n) ++b;
+  return b;
+}
+
+// bits [lo, lo + 64) of the k-mer value (zero above the top word)
+template <int NW> KMI_HD uint64_t kmer_bits_from(const uint64_t (&key)[NW], uint32_t lo) {
+  const uint32_t w = lo >> 6, sh = lo & 63u;
+  uint64_t a = 0, b = 0;
+#pragma unroll
+  for (int i = 0; i < NW; ++i) { a = ((uint32_t)i == w) ? key[i] : a; b = ((uint32_t)i == w + 1u) ? key[i] : b; }
+  return sh ? ((a >> sh) | (b << (64u - sh))) : a;
+}
+
+// bliss::kmer::hash::{murmur,farm,identity,cpp_std}<KMER,Prefix>  (src/index/kmer_hash.hpp:156-311)
+// prefix_bits: the constructor argument of identity / cpp_std (0 = the class default, 24 / 32); murmur and farm
+// ignore it, as the reference does.
+template <int NW> KMI_HD uint64_t kmer_hash(const uint64_t (&key)[NW], const KShape &s, uint32_t which, bool prefix, bool farm_ndebug,
+                                            uint32_t prefix_bits = 0) {
   if (which == 0) {
     uint64_t h1, h2;
     murmur3_x64_128<NW>(key, s.n_bytes, 42u, h1, h2);
     return prefix ? h2 : h1;
   }
-  return farm_hash64_with_seed<NW>(key, s.n_bytes, prefix ? 83ull : 42ull, farm_ndebug);
+  if (which == 1) return farm_hash64_with_seed<NW>(key, s.n_bytes, prefix ? 83ull : 42ull, farm_ndebug);
+  if (which == 2) {
+    // identity (kmer_hash.hpp:205-230): Prefix -> getPrefix(min(nBits, prefix_bits)) = the top bits of the k-mer
+    // value (kmer.hpp:1203-1221); else getSuffix(min(nBits, 64)) = the low bits (kmer.hpp:1245-1249)
+    if (!prefix) {
+      const uint32_t sb = s.n_bits < 64u ? s.n_bits : 64u;
+      return sb == 64u ? key[0] : (key[0] & ((1ull << sb) - 1ull));
+    }
+    uint32_t bits = prefix_bits ? prefix_bits : 24u;
+    if (bits > s.n_bits) bits = s.n_bits;
+    if (bits > 64u) bits = 64u;
+    if (bits == 0u) return 0ull;
+    const uint64_t v = kmer_bits_from<NW>(key, s.n_bits - bits);
+    return bits == 64u ? v : (v & ((1ull << bits) - 1ull));
+  }
+  // cpp_std (kmer_hash.hpp:154-198) with 64-bit words and libstdc++'s std::hash<size_t> (the identity):
+  // h = xor of (word << 1); Prefix -> h >> (min(nBits, 64) - min(prefix_bits, nBits))
+  uint64_t h = 0;
+#pragma unroll
+  for (int w = 0; w < NW; ++w) h ^= key[w] << 1;
+  if (!prefix) return h;
+  const uint32_t pb = prefix_bits ? prefix_bits : 32u;
+  const uint32_t hi = s.n_bits < 64u ? s.n_bits : 64u, lo = pb < s.n_bits ? pb : s.n_bits;
+  const uint32_t shift = hi > lo ? hi - lo : 0u;
+  return shift >= 64u ? 0ull : (h >> shift);
 }
 
 // Internal placement hash (NOT part of the reference's observable behaviour): decides

@@ -62,7 +62,7 @@ struct BucketFn {
 };
 
 template <int NW> __device__ __forceinline__ uint32_t bucket_of(const uint64_t (&key)[NW], const BucketFn &f) {
-  if (f.mode == BUCKET_RANK) return (uint32_t)(kmer_hash<NW>(key, f.shape, f.dist_hash, true, f.farm_ndebug) % f.nranks);
+  if (f.mode == BUCKET_RANK) return (uint32_t)(kmer_hash<NW>(key, f.shape, f.dist_hash, true, f.farm_ndebug, ceil_log2_u32(f.nranks)) % f.nranks);
   uint32_t h = place_hash<NW>(key);
   return f.mode == BUCKET_COARSE ? coarse_of(h) : (fine_of(h) & (kSubPerCoarse - 1));
 }

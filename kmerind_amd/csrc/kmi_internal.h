@@ -114,7 +114,7 @@ inline bool valid_config(const kmi_config *cfg, KShape *shape) {
   if (!bits) return false;
   KShape s = make_shape(cfg->k, bits);
   if (s.n_words > (uint32_t)kMaxWords) return false;
-  if (cfg->strand > 2 || cfg->dist_hash > 1 || cfg->store_hash > 1 || cfg->seq_format > 1 || cfg->index_kind > 2) return false;
+  if (cfg->strand > 2 || cfg->dist_hash > 3 || cfg->store_hash > 3 || cfg->seq_format > 1 || cfg->index_kind > 2) return false;
   if (shape) *shape = s;
   return true;
 }

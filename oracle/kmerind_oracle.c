@@ -355,14 +355,66 @@ uint64_t orc_farm_hash64_with_seed(const void *key, size_t len, uint64_t seed) {
   return farm_debug_tweak(hash_len16(h - FK2, seed));
 }
 
-uint64_t orc_kmer_hash(const orc_kspec *s, uint32_t which, int prefix, const uint64_t *kmer) {
+/* ceilLog2 (src/common/bit_ops.hpp:139-152): KeyToRank constructs DistHash with it
+ * (src/containers/distributed_unordered_map.hpp:153-156) */
+static unsigned orc_log2(unsigned n, unsigned p) { return (n <= 1) ? p : orc_log2(n >> 1, p + 1); }
+unsigned orc_ceil_log2(unsigned n) { return (n <= 1) ? 0 : orc_log2(n - 1, 0) + 1; }
+
+/* Kmer::getSuffix / getPrefix for 64-bit words (src/common/kmer.hpp:1245-1249, 1203-1221). getPrefix's two
+ * branches (bits inside the top word; or shift the whole k-mer right by nBits - NumBits and take the suffix)
+ * both yield the top NumBits bits of the nBits-bit value, which is what is computed here bit by bit. */
+static uint64_t orc_get_suffix(const orc_kspec *s, const uint64_t *kmer, unsigned nbits) {
+  (void)s;
+  return nbits >= 64 ? kmer[0] : (kmer[0] & ((1ull << nbits) - 1ull));
+}
+static uint64_t orc_get_prefix(const orc_kspec *s, const uint64_t *kmer, unsigned nbits) {
+  uint64_t v = 0;
+  if (nbits == 0) return 0;   /* the reference shifts by the word width here (undefined); never reached through KeyToRank (p = 1 skips) */
+  for (unsigned i = 0; i < nbits; ++i) {
+    unsigned b = s->n_bits - nbits + i;           /* bit of the k-mer value that lands on result bit i */
+    v |= ((kmer[b >> 6] >> (b & 63u)) & 1ull) << i;
+  }
+  return v;
+}
+
+/* bliss::kmer::hash::{murmur,farm,identity,cpp_std}<KMER,Prefix> (src/index/kmer_hash.hpp:154-311).
+ * prefix_bits = the constructor argument of identity / cpp_std, 0 = the class default (24 / 32).
+ * PARITY UNPINNED for identity and cpp_std: no reference test or fixture holds values for them and kmer_hash.hpp
+ * does not compile here without generated headers; they are restated from the cited lines only. */
+uint64_t orc_kmer_hash_ex(const orc_kspec *s, uint32_t which, int prefix, unsigned prefix_bits, const uint64_t *kmer) {
   if (which == ORC_HASH_MURMUR) {
     uint64_t h[2];
     orc_murmur3_x64_128(kmer, (int)s->n_bytes, 42, h);   /* kmer_hash.hpp:256-275 */
     return prefix ? h[1] : h[0];
   }
-  /* farm: seed 42, Prefix uses (seed << 1) - 1 = 83   (kmer_hash.hpp:301-308) */
-  return orc_farm_hash64_with_seed(kmer, s->n_bytes, prefix ? 83u : 42u);
+  if (which == ORC_HASH_FARM) {
+    /* farm: seed 42, Prefix uses (seed << 1) - 1 = 83   (kmer_hash.hpp:301-308) */
+    return orc_farm_hash64_with_seed(kmer, s->n_bytes, prefix ? 83u : 42u);
+  }
+  if (which == ORC_HASH_IDENTITY) {                       /* kmer_hash.hpp:205-230 */
+    if (prefix) {
+      unsigned bits = prefix_bits ? prefix_bits : 24u;    /* default_init_value */
+      if (bits > s->n_bits) bits = s->n_bits;             /* std::min(KMER::nBits, prefix_bits) */
+      if (bits > 64) bits = 64;
+      return orc_get_prefix(s, kmer, bits);
+    }
+    return orc_get_suffix(s, kmer, s->n_bits > 64 ? 64u : s->n_bits);   /* suffix_bits */
+  }
+  /* cpp_std, kmer_hash.hpp:154-198: size_t = KmerWordType = 8 bytes -> tuples = nWords, leftover = 0;
+   * std::hash<size_t> of libstdc++ is the identity */
+  uint64_t h = 0;
+  for (uint32_t i = 0; i < s->n_words; ++i) h ^= (kmer[i] << 1);
+  if (!prefix) return h;
+  {
+    unsigned pb = prefix_bits ? prefix_bits : 32u;        /* default_init_value */
+    unsigned hi = s->n_bits < 64 ? s->n_bits : 64u, lo = pb < s->n_bits ? pb : s->n_bits;
+    unsigned shift = hi > lo ? hi - lo : 0;
+    return shift >= 64 ? 0 : (h >> shift);
+  }
+}
+
+uint64_t orc_kmer_hash(const orc_kspec *s, uint32_t which, int prefix, const uint64_t *kmer) {
+  return orc_kmer_hash_ex(s, which, prefix, 0, kmer);
 }
 
 void orc_kmers_hash(const orc_kspec *s, uint32_t which, int prefix, const uint64_t *kmers,
@@ -376,7 +428,7 @@ void orc_key_to_rank(const orc_kspec *s, uint32_t dist_hash, uint32_t strand,
   for (size_t i = 0; i < n; ++i) {
     const uint64_t *k = kmers + i * s->n_words;
     if (strand == ORC_STRAND_BIMOLECULE) { orc_kmer_canonical(s, k, t); k = t; }
-    ranks[i] = (uint32_t)(orc_kmer_hash(s, dist_hash, 1, k) % p);
+    ranks[i] = (uint32_t)(orc_kmer_hash_ex(s, dist_hash, 1, orc_ceil_log2(p), k) % p);
   }
 }
 

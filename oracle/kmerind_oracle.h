@@ -37,7 +37,7 @@ extern "C" {
 
 enum { ORC_DNA = 0, ORC_DNA5 = 1 };
 enum { ORC_STRAND_SINGLE = 0, ORC_STRAND_CANONICAL = 1, ORC_STRAND_BIMOLECULE = 2 };
-enum { ORC_HASH_MURMUR = 0, ORC_HASH_FARM = 1 };
+enum { ORC_HASH_MURMUR = 0, ORC_HASH_FARM = 1, ORC_HASH_IDENTITY = 2, ORC_HASH_STD = 3 };
 enum { ORC_FMT_FASTQ = 0, ORC_FMT_FASTA = 1 };
 
 /* Kmer<K, Alphabet, uint64_t> shape: src/common/kmer.hpp:116-177, padding.hpp:67-90 */
@@ -98,6 +98,8 @@ void orc_kmers_hash(const orc_kspec *s, uint32_t which, int prefix, const uint64
 /* KeyToRank: src/containers/distributed_unordered_map.hpp:148-170
  * rank = DistHash(DistTrans(key)) % p ; strand selects DistTrans per
  * src/index/kmer_index.hpp:436-481 (bimolecule -> lex_less, else identity). */
+uint64_t orc_kmer_hash_ex(const orc_kspec *s, uint32_t which, int prefix, unsigned prefix_bits, const uint64_t *kmer);
+unsigned orc_ceil_log2(unsigned n);
 void orc_key_to_rank(const orc_kspec *s, uint32_t dist_hash, uint32_t strand,
                      const uint64_t *kmers, size_t n, uint32_t p, uint32_t *ranks);
 

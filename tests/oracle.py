@@ -15,7 +15,7 @@ _REF = os.path.join(ORACLE_DIR, "_ref", "libkmerind_refhash.so")
 
 DNA, DNA5 = 0, 1
 SINGLE, CANONICAL, BIMOLECULE = 0, 1, 2
-MURMUR, FARM = 0, 1
+MURMUR, FARM, IDENTITY, STD = 0, 1, 2, 3
 FASTQ, FASTA = 0, 1
 
 

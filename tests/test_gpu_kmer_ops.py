@@ -42,12 +42,16 @@ def test_revcomp_canonical_hash_rank(ctx, k, alpha):
         cfg = K.make_config(k, alpha, strand=strand)
         assert (ctx.revcomp(cfg, km) == orc.revcomp(s, km)).all()
         assert (ctx.canonical(cfg, km) == orc.canonical(s, km)).all()
-        for which, w in (("murmur", orc.MURMUR), ("farm", orc.FARM)):
+        for which, w in (("murmur", orc.MURMUR), ("farm", orc.FARM), ("identity", orc.IDENTITY), ("std", orc.STD)):
             for prefix in (True, False):
                 assert (ctx.hash(cfg, which, prefix, km) == orc.kmer_hash(s, w, prefix, km)).all(), (which, prefix)
         for p in (1, 2, 3, 8):
             st = orc.BIMOLECULE if strand == "bimolecule" else orc.CANONICAL
             assert (ctx.key_to_rank(cfg, km, p) == orc.key_to_rank(s, orc.MURMUR, st, km, p)).all()
+    for dh, w in (("identity", orc.IDENTITY), ("std", orc.STD)):   # KeyToRank hands ceilLog2(p) prefix bits to these
+        cfgh = K.make_config(k, alpha, dist_hash=dh)
+        for p in (2, 3, 8, 200):
+            assert (ctx.key_to_rank(cfgh, km, p) == orc.key_to_rank(s, w, orc.CANONICAL, km, p)).all(), (dh, p)
     cfgf = K.make_config(k, alpha, dist_hash="farm", farm_ndebug=True)
     orc.lib.orc_set_farm_ndebug(1)
     try:

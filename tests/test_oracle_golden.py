@@ -273,3 +273,29 @@ def test_quality_window_direct_recomputation():
     for j, got in enumerate(ex["quals"]):
         direct = 2.0 ** lut[q[j:j + k].astype(int) - 33].sum()
         assert abs(float(got) - direct) <= 1e-5 * direct
+
+
+def test_identity_and_std_hashers_follow_the_cited_formulas():
+    """identity / cpp_std (kmer_hash.hpp:154-230) are NOT pinned by any reference fixture; this only checks the
+    oracle against a direct evaluation of the cited definitions on the SURVEY 8(c) 31-mer and a 3-word k-mer."""
+    s = orc.kspec(31, orc.DNA)
+    key = 0x23FAAF4092CD8D03
+    km = np.array([[key]], dtype=np.uint64)
+    M = (1 << 64) - 1
+    assert int(orc.kmer_hash(s, orc.IDENTITY, False, km)[0]) == key                      # getSuffix(min(nBits, 64))
+    assert int(orc.kmer_hash(s, orc.IDENTITY, True, km)[0]) == key >> (62 - 24)          # getPrefix(24): top 24 of 62 bits
+    assert int(orc.kmer_hash(s, orc.STD, False, km)[0]) == (key << 1) & M
+    assert int(orc.kmer_hash(s, orc.STD, True, km)[0]) == ((key << 1) & M) >> (62 - 32)  # shift = min(nBits,64) - min(32,nBits)
+    # KeyToRank: prefix bits = ceilLog2(p)
+    for p, bits in ((2, 1), (3, 2), (8, 3), (9, 4)):
+        assert int(orc.key_to_rank(s, orc.IDENTITY, orc.SINGLE, km, p)[0]) == (key >> (62 - bits)) % p
+        assert int(orc.key_to_rank(s, orc.STD, orc.SINGLE, km, p)[0]) == ((((key << 1) & M) >> (62 - bits)) % p)
+    s3 = orc.kspec(63, orc.DNA5)   # 189 bits in 3 words
+    w = [0x0123456789ABCDEF, 0xFEDCBA9876543210, 0x1555555555555555 & ((1 << 61) - 1)]
+    km3 = np.array([w], dtype=np.uint64)
+    val = w[0] | (w[1] << 64) | (w[2] << 128)
+    assert int(orc.kmer_hash(s3, orc.IDENTITY, False, km3)[0]) == w[0]
+    assert int(orc.kmer_hash(s3, orc.IDENTITY, True, km3)[0]) == val >> (189 - 24)
+    h = ((w[0] << 1) ^ (w[1] << 1) ^ (w[2] << 1)) & M
+    assert int(orc.kmer_hash(s3, orc.STD, False, km3)[0]) == h
+    assert int(orc.kmer_hash(s3, orc.STD, True, km3)[0]) == h >> (64 - 32)
