@@ -28,6 +28,8 @@
 #include <string>
 #include <type_traits>
 #include <utility>
+#include <map>
+#include <algorithm>
 #include <vector>
 
 #include "../kmerind_hip.h"
@@ -335,6 +337,35 @@ class Index {
     ::kmerind::check(ctx, kmi_index_erase_host(idx, q.data(), q.size() / KmerType::nWords, &n));
   }
 
+  // Predicate forms (kmer_index.hpp:156-194 -> map.find/count/erase(query, false, pred) and (pred)). The predicate is a
+  // host functor on a stored (key, value) entry, so it is evaluated on the host over the entries the device returns;
+  // the result sets are the reference's. The forms without a query work on this rank's entries, as in the reference.
+  template <typename Predicate> std::vector<TupleType> find_if(std::vector<KmerType> &query, Predicate const &pred) const {
+    return filtered(find(query), pred);
+  }
+  template <typename Predicate> std::vector<TupleType> find_if(Predicate const &pred) const { return filtered(to_vector(), pred); }
+  template <typename Predicate>
+  std::vector<std::pair<KmerType, size_t>> count_if(std::vector<KmerType> &query, Predicate const &pred) const {
+    std::vector<std::pair<KmerType, size_t>> out = count(query);           // one entry per distinct transformed key
+    std::map<KmerType, size_t> hits;
+    for (const TupleType &e : filtered(find(query), pred)) ++hits[e.first];
+    for (auto &kv : out) { auto it = hits.find(kv.first); kv.second = (it == hits.end()) ? 0 : it->second; }
+    return out;
+  }
+  template <typename Predicate> std::vector<std::pair<KmerType, size_t>> count_if(Predicate const &pred) const {
+    std::map<KmerType, size_t> hits;
+    for (const TupleType &e : filtered(to_vector(), pred)) ++hits[e.first];
+    return std::vector<std::pair<KmerType, size_t>>(hits.begin(), hits.end());
+  }
+  template <typename Predicate> void erase_if(std::vector<KmerType> &query, Predicate const &pred) {
+    std::vector<TupleType> found = find(query);
+    erase_entries(found, pred);
+  }
+  template <typename Predicate> void erase_if(Predicate const &pred) {
+    std::vector<TupleType> all = to_vector();
+    erase_entries(all, pred);
+  }
+
   size_t local_size() const { uint64_t n = 0; ::kmerind::check(ctx, kmi_index_local_size(idx, &n)); return (size_t)n; }
   size_t size() const { size_t n = local_size(); return (comm.size() > 1 && comm.allreduce_sum) ? (size_t)comm.allreduce_sum(n) : n; }
 
@@ -366,13 +397,32 @@ class Index {
   const kmi_config &config() const { return cfg; }
 
  protected:
+  template <typename Predicate> static std::vector<TupleType> filtered(std::vector<TupleType> v, Predicate const &pred) {
+    v.erase(std::remove_if(v.begin(), v.end(), [&](const TupleType &e) { return !pred(e); }), v.end());
+    return v;
+  }
+  // erase the entries of `entries` (all entries of their keys, as find returns them) that satisfy pred. The device
+  // erases by key; for a multimap the entries of those keys that do not satisfy pred are put back.
+  template <typename Predicate> void erase_entries(const std::vector<TupleType> &entries, Predicate const &pred) {
+    std::vector<KmerType> keys;
+    std::vector<TupleType> keep;
+    std::map<KmerType, bool> hit;
+    for (const TupleType &e : entries) if (pred(e)) hit[e.first] = true;
+    if (hit.empty()) return;
+    for (auto &kv : hit) keys.push_back(kv.first);
+    if (MapType::index_kind != KMI_INDEX_COUNT)
+      for (const TupleType &e : entries) if (hit.count(e.first) && !pred(e)) keep.push_back(e);
+    uint64_t n = 0;
+    // entries hold stored (already transformed) keys of this rank: no routing, no second transform needed
+    ::kmerind::check(ctx, kmi_index_erase_host(idx, detail::words_of(keys), keys.size(), &n));
+    if (!keep.empty()) insert(keep);
+  }
   template <template <typename> class SeqParser> void build_file(const std::string &filename) {
     uint32_t fmt = detail::format_of(filename);
     if (fmt != SeqParser<const unsigned char *>::KMI) throw std::invalid_argument("Specified File Parser template parameter does not support files with this extension.");
     if (comm.size() > 1) throw std::invalid_argument("build_* with size() > 1: partition the file per rank and use read_file + insert");
     std::vector<uint8_t> bytes = detail::read_whole_file(filename);
-    kmi_config c = cfg; c.seq_format = fmt;
-    (void)c;
+    ::kmerind::check(ctx, kmi_index_set_seq_format(idx, fmt));
     ::kmerind::check(ctx, kmi_index_build_host(idx, bytes.data(), bytes.size(), 0));
   }
   void insert_words(const uint64_t *words, size_t n) {

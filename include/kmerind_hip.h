@@ -149,6 +149,9 @@ kmi_status kmi_index_build_host(kmi_index *idx, const uint8_t *bytes, size_t n_b
 kmi_status kmi_index_build_dev(kmi_index *idx, const uint8_t *bytes_dev, size_t n_bytes, uint64_t file_offset);
 /* MapType::clear() (distributed_map_base.hpp:267-272) */
 kmi_status kmi_index_clear(kmi_index *idx);
+/* The SeqParser template argument of Index::build_posix / build_mmap / build_mpiio<SeqParser, SeqIterType>
+ * (kmer_index.hpp:239-372): which record grammar the next kmi_index_build_* call parses (KMI_FMT_*). */
+kmi_status kmi_index_set_seq_format(kmi_index *idx, uint32_t seq_format);
 /* MapType::local_size() / size() on one rank (distributed_map_base.hpp:227-245) */
 kmi_status kmi_index_local_size(kmi_index *idx, uint64_t *n);
 /* MapType::to_vector() (distributed_map_base.hpp:202-217): keys n*n_words, counts n; order unspecified */

@@ -78,6 +78,7 @@ SIGNATURES = {
     "kmi_index_build_host": (C.c_int, [_P, _P, _sz, _u64]),
     "kmi_index_build_dev": (C.c_int, [_P, _P, _sz, _u64]),
     "kmi_index_clear": (C.c_int, [_P]),
+    "kmi_index_set_seq_format": (C.c_int, [_P, C.c_uint32]),
     "kmi_index_local_size": (C.c_int, [_P, C.POINTER(_u64)]),
     "kmi_index_export_host": (C.c_int, [_P, _P, _P, _sz, C.POINTER(_u64)]),
     "kmi_results_free": (None, [C.POINTER(Results)]),

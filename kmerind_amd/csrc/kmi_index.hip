@@ -1732,6 +1732,13 @@ __global__ __launch_bounds__(256) void interleave_records_kernel(const uint64_t 
   }
 }
 
+kmi_status kmi_index_set_seq_format(kmi_index *idx, uint32_t seq_format) {
+  if (!idx) return KMI_ERR_INVALID;
+  if (seq_format > KMI_FMT_FASTA) return set_err(idx->ctx, KMI_ERR_INVALID, "unknown sequence format");
+  idx->cfg.seq_format = seq_format;
+  return KMI_OK;
+}
+
 kmi_status kmi_index_build_dev(kmi_index *idx, const uint8_t *bytes_dev, size_t n_bytes, uint64_t file_offset) {
   if (!idx) return KMI_ERR_INVALID;
   kmi_ctx *ctx = idx->ctx;

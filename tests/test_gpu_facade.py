@@ -90,3 +90,61 @@ def test_position_index_harness_matches_oracle():
     assert got["find"] == (fk.shape[0], int(pos.sum()))
     m.erase(q)
     assert got["after_erase"] == (m.size(),)
+
+
+def test_predicate_forms_match_an_independent_computation():
+    """find_if / count_if / erase_if (kmer_index.hpp:156-194), with and without a query vector, and build_posix, on a
+    count index and a position index; expectations computed from the oracle's maps with numpy."""
+    exe = os.path.join(ROOT, "examples", "predicates")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "examples")])
+    path = os.path.join(DATA, "natural.fastq")
+    thr = 2
+    fasta = os.path.join(DATA, "natural.fasta")
+    out = subprocess.run([exe, "-F", path, "-A", fasta, "-T", str(thr)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+
+    def grab(pat):
+        m = re.search(pat, out.stdout)
+        assert m, out.stdout
+        return tuple(int(x) for x in m.groups())
+
+    s = orc.kspec(21)
+    data = open(path, "rb").read()
+    ex = orc.extract(s, data, orc.FASTQ, want_ids=True)
+    kmers = ex["kmers"]
+    cm = orc.CountMap(s, orc.CANONICAL)
+    cm.insert(kmers)
+    keys, cnt = cm.export()
+    freq = cnt >= thr
+    assert grab(r"count size (\d+)") == (keys.shape[0],)
+    assert grab(r"find_if\(pred\) (\d+) sum (\d+)") == (int(freq.sum()), int(cnt[freq].sum()))
+    assert grab(r"count_if\(pred\) (\d+)") == (int(freq.sum()),)
+    q = kmers[: kmers.shape[0] // 2]
+    fk, fv = cm.find(q)
+    fsel = fv >= thr
+    assert grab(r"find_if\(query,pred\) (\d+) sum (\d+)") == (int(fsel.sum()), int(fv[fsel].astype(np.uint64).sum()))
+    ck, _ = cm.count(q)
+    assert grab(r"count_if\(query,pred\) (\d+) present (\d+)") == (ck.shape[0], int(fsel.sum()))
+    after_q = keys.shape[0] - int(fsel.sum())
+    assert grab(r"after erase_if\(query,pred\) (\d+)") == (after_q,)
+    assert grab(r"after erase_if\(pred\) (\d+)") == (int((~freq).sum()),)
+
+    mm = orc.MultiMap(s, orc.CANONICAL)
+    mm.insert(kmers, ex["ids"])
+    mk, mv = mm.export()
+    pos = ((mv[:, 0] >> np.uint64(16)) & np.uint64(0xFFFFFFFFFF)) + (mv[:, 0] & np.uint64(0xFFFF))
+    odd = (pos & np.uint64(1)) != 0
+    assert grab(r"pos size (\d+)") == (mk.shape[0],)
+    assert grab(r"pos find_if\(pred\) (\d+)") == (int(odd.sum()),)
+    # entries of the query's keys with an odd position go away, every other entry stays
+    qk = orc.canonical(s, q)
+    qset = set(map(bytes, np.ascontiguousarray(qk)))
+    in_q = np.array([bytes(r) in qset for r in np.ascontiguousarray(mk)])
+    assert grab(r"pos after erase_if\(query,pred\) (\d+)") == (int(mk.shape[0] - (in_q & odd).sum()),)
+    assert grab(r"pos after erase_if\(pred\) (\d+)") == (int((~odd).sum()),)
+    # build_posix<FASTAParser>: same index type, FASTA grammar
+    fex = orc.extract(s, open(fasta, "rb").read(), orc.FASTA)
+    fm = orc.CountMap(s, orc.CANONICAL)
+    fm.insert(fex["kmers"])
+    assert grab(r"fasta size (\d+) total (\d+)") == (fm.size(), fex["kmers"].shape[0])
