@@ -189,6 +189,154 @@ __global__ __launch_bounds__(1024) void fastq_offsets_apply_kernel(const TileInf
 }
 
 // ---------------------------------------------------------------------------
+// FASTQParser::get_next_record refuses a record whose sequence and quality lines both exist but differ in
+// length (fastq_loader.hpp:454-463). Lines are maximal non-EOL runs, so the check is pure EOL-bitmap work: one
+// wavefront per scan tile finds the line starts in the tile's bitmap words, and every line whose index says
+// "quality" (index % 4 == 3, from the scan's line bases) measures itself forward and the sequence line two lines
+// back by bit scans over the global bitmap (a handful of cached word loads per record).
+// ---------------------------------------------------------------------------
+// Bitmap words come from a per-wavefront LDS image (the tile with 1 KB of context on either side, which holds
+// whole records of ordinary reads) and from HBM only beyond it.
+struct EolBits {
+  const uint32_t *g; uint64_t n_words;        // global bitmap; bit set = EOL; words >= n_words count as all-EOL
+  const uint32_t *img; uint64_t w0; uint32_t nw;   // LDS image of words [w0, w0 + nw)
+  __device__ __forceinline__ uint32_t word(uint64_t wi) const {
+    const uint64_t d = wi - w0;
+    if (d < (uint64_t)nw) return img[d];
+    return wi < n_words ? g[wi] : 0xffffffffu;
+  }
+};
+__device__ __forceinline__ uint64_t eol_next_set(const EolBits &b, uint64_t p) {   // first EOL position >= p
+  uint64_t wi = p >> 5;
+  if (wi >= b.n_words) return p;
+  uint32_t bits = b.word(wi) & (0xffffffffu << (p & 31u));
+  while (bits == 0u) { if (++wi >= b.n_words) return wi << 5; bits = b.word(wi); }
+  return (wi << 5) + (uint32_t)__builtin_ctz(bits);
+}
+template <bool SET> __device__ __forceinline__ int64_t eol_prev(const EolBits &b, int64_t p) {   // last position < p whose EOL bit == SET, -1 if none
+  if (p <= 0 || b.n_words == 0) return -1;
+  uint64_t q = (uint64_t)p - 1;
+  if (q >= b.n_words * 32ull) { if (SET) return (int64_t)q; q = b.n_words * 32ull - 1; }
+  uint64_t wi = q >> 5;
+  uint32_t w = b.word(wi);
+  uint32_t bits = (SET ? w : ~w) & (0xffffffffu >> (31u - (uint32_t)(q & 31u)));
+  while (bits == 0u) { if (wi == 0) return -1; --wi; w = b.word(wi); bits = SET ? w : ~w; }
+  return (int64_t)((wi << 5) + 31u - (uint32_t)__builtin_clz(bits));
+}
+// g = position of the first byte of a quality line
+__device__ __forceinline__ bool fastq_lengths_differ(const EolBits &b, uint64_t g) {
+  const uint64_t len_qual = eol_next_set(b, g) - g;
+  const int64_t plus_last = eol_prev<false>(b, (int64_t)g);          // last byte of the '+' line
+  if (plus_last < 0) return false;
+  const int64_t gap = eol_prev<true>(b, plus_last);                   // an EOL between the sequence and the '+' line
+  if (gap < 0) return false;
+  const int64_t seq_last = eol_prev<false>(b, gap);                   // last byte of the sequence line
+  if (seq_last < 0) return false;
+  const int64_t seq_first = eol_prev<true>(b, seq_last) + 1;          // (-1 + 1 = 0: the sequence line opens the buffer)
+  return (uint64_t)(seq_last - seq_first + 1) != len_qual;
+}
+
+// Dense form: every lane takes a few words of the window (tile + context), line starts (non-EOL after EOL) and
+// line ends (EOL after non-EOL) are ranked with two wave scans and their positions land in two small LDS arrays, so
+// line j of the window is [S[j], E[j + eoff]) and a quality line is compared with the line two ranks before it by
+// plain array reads. Only what the window cannot answer (a record longer than the context, > CAP lines in a window)
+// takes the bit-scan path above.
+template <int TILE>
+__global__ __launch_bounds__(256) void fastq_check_lengths_kernel(const uint32_t *__restrict__ eolw, uint64_t n_words, uint64_t n_tiles,
+                                                                 const uint32_t *__restrict__ line_base, uint32_t *__restrict__ flags) {
+  constexpr int WORDS = TILE / 32;
+  constexpr int CTX = 32;                      // words of context on either side of the tile (1 KB)
+  constexpr int WIN = WORDS + 2 * CTX, WPL = WIN / kWave;
+  constexpr int CAP = 512;                     // lines per window handled by the dense path
+  static_assert(WIN % kWave == 0, "window words map onto the lanes of a wavefront");
+  static_assert(WIN * 32 < 65536, "window positions fit 16 bits");
+  __shared__ uint32_t s_img[256 / kWave][WIN];
+  __shared__ uint16_t s_S[256 / kWave][CAP], s_E[256 / kWave][CAP];
+  uint32_t *img = s_img[wave_id()];
+  uint16_t *S = s_S[wave_id()], *E = s_E[wave_id()];
+  const uint64_t n_waves = (uint64_t)gridDim.x * (blockDim.x / kWave);
+  const uint32_t lane = lane_id();
+  auto wave_sync = [&]() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); };
+  bool bad = false;
+  for (uint64_t t = (uint64_t)blockIdx.x * (blockDim.x / kWave) + wave_id(); t < n_tiles; t += n_waves) {
+    const int64_t gw0 = (int64_t)(t * WORDS) - CTX;   // global word index of window word 0 (negative before the buffer)
+    uint32_t w[WPL];
+#pragma unroll
+    for (int i = 0; i < WPL; ++i) {
+      const int64_t g = gw0 + (int64_t)(lane * WPL + i);
+      w[i] = (g >= 0 && (uint64_t)g < n_words) ? eolw[g] : 0xffffffffu;
+      img[lane * WPL + i] = w[i];
+    }
+    uint32_t prev = __shfl_up(w[WPL - 1] >> 31, 1, kWave);
+    const uint32_t prev_win = (gw0 > 0) ? (eolw[gw0 - 1] >> 31) : 1u;   // EOL status of the byte before the window
+    if (lane == 0) prev = prev_win;
+    uint32_t ls[WPL], le[WPL], ns = 0, ne = 0, nsl = 0, nst = 0;
+#pragma unroll
+    for (int i = 0; i < WPL; ++i) {
+      const uint32_t before = (w[i] << 1) | prev;      // EOL status of each position's predecessor
+      ls[i] = ~w[i] & before;
+      le[i] = w[i] & ~before;
+      prev = w[i] >> 31;
+      const uint32_t c = (uint32_t)__builtin_popcount(ls[i]);
+      const uint32_t ww = lane * WPL + i;
+      ns += c; ne += (uint32_t)__builtin_popcount(le[i]);
+      nsl += (ww < (uint32_t)CTX) ? c : 0u;
+      nst += (ww < (uint32_t)(CTX + WORDS)) ? c : 0u;
+    }
+    // ranks: starts in the low half, ends in the high half of one scan
+    const uint32_t packed = ns | (ne << 16);
+    const uint32_t inc = wave_inclusive_scan(packed);
+    const uint32_t tot = __shfl(inc, kWave - 1, kWave);
+    const uint32_t NS = tot & 0xffffu, NE = tot >> 16;
+    const uint32_t cnt2 = wave_reduce_sum(nsl | (nst << 16));
+    const uint32_t NSL = cnt2 & 0xffffu, NST = cnt2 >> 16;
+    const uint32_t lb = line_base[t];
+    EolBits bm;
+    bm.g = eolw; bm.n_words = n_words; bm.img = img; bm.nw = WIN; bm.w0 = (uint64_t)gw0;
+    wave_sync();   // image complete (the bit-scan path reads it)
+    if (NS <= (uint32_t)CAP && NE <= (uint32_t)CAP) {
+      uint32_t rs = (inc - packed) & 0xffffu, re = (inc - packed) >> 16;
+#pragma unroll
+      for (int i = 0; i < WPL; ++i) {
+        const uint32_t base = (lane * WPL + i) * 32u;
+        uint32_t r = ls[i];
+        while (r) { S[rs++] = (uint16_t)(base + (uint32_t)__builtin_ctz(r)); r &= r - 1u; }
+        r = le[i];
+        while (r) { E[re++] = (uint16_t)(base + (uint32_t)__builtin_ctz(r)); r &= r - 1u; }
+      }
+      wave_sync();
+      const uint32_t eoff = prev_win ? 0u : 1u;   // a line open at the window start owns the first end event
+      for (uint32_t j = NSL + lane; j < NST; j += kWave) {
+        if (((lb + (j - NSL)) & 3u) != 3u) continue;
+        if (j >= 2u && j + eoff < NE) {
+          const uint32_t lq = (uint32_t)E[j + eoff] - (uint32_t)S[j];
+          const uint32_t lsq = (uint32_t)E[j - 2u + eoff] - (uint32_t)S[j - 2u];
+          bad = bad || (lq != lsq);
+        } else {
+          bad = bad || fastq_lengths_differ(bm, (uint64_t)((int64_t)gw0 * 32 + (int64_t)S[j]));
+        }
+      }
+    } else {
+      // crowded window: every line start of the tile proper by bit scans
+      uint32_t idx = lb + ((inc - packed) & 0xffffu) - NSL;   // line index of this lane's first start (meaningful inside the tile)
+#pragma unroll
+      for (int i = 0; i < WPL; ++i) {
+        const uint32_t ww = lane * WPL + i;
+        uint32_t r = ls[i];
+        while (r) {
+          const uint32_t bpos = (uint32_t)__builtin_ctz(r);
+          if (ww >= (uint32_t)CTX && ww < (uint32_t)(CTX + WORDS) && (idx & 3u) == 3u)
+            bad = bad || fastq_lengths_differ(bm, (uint64_t)((int64_t)gw0 * 32 + (int64_t)(ww * 32u + bpos)));
+          ++idx; r &= r - 1u;
+        }
+      }
+    }
+    wave_sync();   // image and event arrays are rewritten for the next tile
+  }
+  if (bad) atomicOr(&flags[0], 4u);
+}
+
+// ---------------------------------------------------------------------------
 // pass 3: tuples in file order. Work is re-distributed over the tile's compacted window list,
 // so consecutive lanes produce consecutive tuples and the stores are coalesced without staging.
 // ---------------------------------------------------------------------------
@@ -435,6 +583,11 @@ static kmi_status scan_impl(kmi_ctx *ctx, const uint8_t *bytes_dev, size_t n_byt
                        bytes_dev, (uint64_t)n_bytes, shape.k, pk_eol, pk_stream, info, ctx->d_flags);
   }
   KMI_TRY(launch_tile_offsets(ctx, info, n_tiles, (uint32_t)Cfg::TILE, hdr, base, off));
+  if (n_tiles > 0) {
+    ProfScope ps(ctx, "fastq_check", n_bytes);
+    hipLaunchKernelGGL((fastq_check_lengths_kernel<Cfg::TILE>), dim3(2048), dim3(256), 0, ctx->stream, (const uint32_t *)pk_eol,
+                       (uint64_t)(n_cover / 32), n_tiles, (const uint32_t *)base, ctx->d_flags);
+  }
   KMI_HIP(ctx, hipGetLastError());
   return KMI_OK;
 }
@@ -449,6 +602,7 @@ static kmi_status read_totals(kmi_ctx *ctx, uint64_t *n_tuples, uint64_t *n_seqs
   if (n_seqs) *n_seqs = ctx->h_totals[2];
   if (flags0 & 1u) return set_err(ctx, KMI_ERR_PARSE, "FASTQ: missing @ on first line of a record");
   if (flags0 & 2u) return set_err(ctx, KMI_ERR_PARSE, "FASTQ: missing + on third line of a record");
+  if (flags0 & 4u) return set_err(ctx, KMI_ERR_PARSE, "FASTQ: truncated record? seq and qual differ in length");
   return KMI_OK;
 }
 

@@ -159,6 +159,71 @@ def test_extract_edge_cases(ctx):
         assert ei.value.status == L.ERR_PARSE
 
 
+def test_fastq_seq_and_qual_must_have_equal_length(ctx):
+    """fastq_loader.hpp:454-463: both lines present but of different length -> the parser throws; a record
+    without a quality line (truncated input) only warns. Checked wherever the bad record sits (tile interior,
+    tile seams, first / last record) and for CRLF line ends."""
+    import kmerind_amd as K
+    from kmerind_amd import _lib as L
+    cfg = K.make_config(21, "DNA")
+    s = orc.kspec(21, orc.DNA)
+    good = bytes(np.asarray(K.synth_fastq(seed=5, genome_len=50_000, n_reads=400)).tobytes())   # 315-byte records, 126 KB = 15+ tiles
+    recs = [good[i:i + 315] for i in range(0, len(good), 315)]
+    kmers, nseq = ctx.read_file(cfg, good)
+    assert nseq == 400
+    for victim in (0, 1, 25, 26, 51, 52, 77, 200, 398, 399):              # 26 records = 8190 bytes: seams nearby
+        for delta in (-1, +1, -100, +3):
+            r = recs[victim]
+            lines = r.split(b"\n")
+            q = lines[3]
+            lines[3] = q[:delta] if delta < 0 else q + b"I" * delta
+            bad = b"".join(recs[:victim]) + b"\n".join(lines) + b"".join(recs[victim + 1:])
+            with pytest.raises(ValueError):
+                orc.extract(s, bad, orc.FASTQ)
+            with pytest.raises(L.KmiError) as ei:
+                ctx.read_file(cfg, bad)
+            assert ei.value.status == L.ERR_PARSE, (victim, delta)
+            idx = K.CountIndex(ctx, cfg)
+            with pytest.raises(L.KmiError):
+                idx.build(bad)
+            idx.close()
+    crlf = good.replace(b"\n", b"\r\n")
+    kmers2, nseq2 = ctx.read_file(cfg, crlf)
+    assert nseq2 == 400 and (kmers2 == kmers).all()
+    bad = crlf[:630 + 170] + b"I" + crlf[630 + 170:]                       # one extra byte inside record 2's lines
+    try:
+        orc.extract(s, bad, orc.FASTQ)
+        oracle_ok = True
+    except ValueError:
+        oracle_ok = False
+    try:
+        ctx.read_file(cfg, bad)
+        dev_ok = True
+    except L.KmiError:
+        dev_ok = False
+    assert oracle_ok == dev_ok
+    # very short reads: thousands of lines per tile (the crowded-window path of the check)
+    tiny = b"".join(b"@r\n" + bytes([b"ACGT"[i % 4]]) * (1 + i % 3) + b"\n+\n" + b"I" * (1 + i % 3) + b"\n" for i in range(6000))
+    c3 = K.make_config(3, "DNA")
+    s3 = orc.kspec(3, orc.DNA)
+    ex = orc.extract(s3, tiny, orc.FASTQ)
+    km, ns = ctx.read_file(c3, tiny)
+    assert ns == ex["n_seqs"] == 6000 and (km == ex["kmers"]).all()
+    for at in (5, 3000, 5999):
+        recs_t = tiny.split(b"@r\n")[1:]
+        recs_t[at] = recs_t[at][:-1] + b"I\n"          # quality one longer than the sequence
+        broken = b"".join(b"@r\n" + r for r in recs_t)
+        with pytest.raises(ValueError):
+            orc.extract(s3, broken, orc.FASTQ)
+        with pytest.raises(L.KmiError):
+            ctx.read_file(c3, broken)
+    # quality line missing altogether at the end: warning only
+    cut = good[: len(good) - 151]
+    ex = orc.extract(s, cut, orc.FASTQ)
+    kmers3, nseq3 = ctx.read_file(cfg, cut)
+    assert nseq3 == ex["n_seqs"] and (kmers3 == ex["kmers"]).all()
+
+
 def test_extract_synthetic_reads_multi_tile(ctx):
     import kmerind_amd as K
     data = K.synth_fastq(seed=2, genome_len=200_000, n_reads=3000)
