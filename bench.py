@@ -32,6 +32,11 @@ KERNEL_ALG_BYTES = {
     "scatter_fine": 16.0,                                  # key in, key out
     "bucket_reduce": 8.0 + 12.0 / 12,                      # key in; (key, count) of each distinct key out
     "bucket_compact": 2 * 12.0 / 12,
+    # N > 1 and insert-from-keys paths
+    "fastq_rank_hist": 2.0 + 2.625 * 2 / 8,
+    "fastq_rank_scatter": 2.0 + 2.625 * 2 / 8 + 8.0,
+    "hist_fine": 8.0,
+    "scatter_coarse": 16.0,
 }
 
 
@@ -45,6 +50,7 @@ def main():
     ap.add_argument("--k", type=int, default=31)
     ap.add_argument("--cpu-sample-reads", type=int, default=500_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--chunks", type=int, default=4, help="N > 1: chunks per step (exchange of one overlaps parsing of the next)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = rehearsal of the N>1 flow with ranks sharing one GPU (exchange staged through the host)")
     args = ap.parse_args()
@@ -89,26 +95,56 @@ def main():
     n_kmers = n_reads * kmers_per_read
 
     if world > 1:
-        d_keys = torch.empty((n_kmers, 1), dtype=torch.int64, device=dev)
-        d_send = torch.empty((n_kmers, 1), dtype=torch.int64, device=dev)
+        # N > 1: the batch goes through in NCH record-aligned chunks. Chunk c is parsed and grouped by destination rank
+        # on the device (kmi_extract_route_dev: read_file + the bucketing half of imxx::distribute, fused) while the
+        # all-to-all of chunk c-1 is still travelling over xGMI on RCCL's stream; every rank then inserts what it
+        # received in one go. Send buffers are double-buffered, the receive buffer takes the chunks back to back.
+        nch = max(1, min(args.chunks, n_reads))
+        rec_bytes = nbytes // n_reads                      # synthetic records have one size (315 bytes)
+        # chunk starts stay 16-byte aligned (the byte kernels load 16 bytes per lane): whole multiples of 16 records
+        bounds = [((n_reads * c // nch) // 16 * 16) * rec_bytes for c in range(nch)] + [nbytes]
+        chunk_kmers = max(((bounds[c + 1] - bounds[c]) // rec_bytes) * kmers_per_read for c in range(nch))
+        d_send = [torch.empty((chunk_kmers + 64, 1), dtype=torch.int64, device=dev) for _ in range(2)]
+        recv_cap = int(n_kmers * 1.25) + 4096              # murmur % p is balanced to a fraction of a percent
+        d_recv = torch.empty((recv_cap, 1), dtype=torch.int64, device=dev)
         counts = np.zeros(world, dtype=np.uint64)
         nt, ns = C.c_uint64(), C.c_uint64()
+        cdev = dev if args.backend == "nccl" else torch.device("cpu")
 
     def step():
         idx.clear()
         if world == 1:
             idx.build_device(d_bytes.data_ptr(), nbytes)
             return
-        ctx.check(L.lib.kmi_extract_dev(ctx.h, C.byref(cfg), C.c_void_p(d_bytes.data_ptr()), nbytes, 0,
-                                        C.c_void_p(d_keys.data_ptr()), None, n_kmers, C.byref(nt), C.byref(ns)))
-        ctx.check(L.lib.kmi_route_dev(ctx.h, C.byref(cfg), C.c_void_p(d_keys.data_ptr()), nt.value, world,
-                                      C.c_void_p(d_send.data_ptr()), counts.ctypes.data_as(C.c_void_p)))
-        if args.backend == "nccl":
-            recv, _ = kdist.exchange_keys(d_send[: nt.value], [int(c) for c in counts])
-        else:
-            recv, _ = kdist.exchange_keys(d_send[: nt.value].cpu(), [int(c) for c in counts])
-            recv = recv.to(dev)
-        idx.insert_device(recv.data_ptr(), recv.shape[0])
+        pos, works = 0, []
+        for c in range(nch):
+            if c >= 2:
+                works[c - 2].wait()                        # the send buffer about to be rewritten has left
+            send = d_send[c & 1]
+            ctx.check(L.lib.kmi_extract_route_dev(ctx.h, C.byref(cfg), C.c_void_p(d_bytes.data_ptr() + bounds[c]),
+                                                  bounds[c + 1] - bounds[c], world, C.c_void_p(send.data_ptr()), send.shape[0],
+                                                  C.byref(nt), C.byref(ns), counts.ctypes.data_as(C.c_void_p)))
+            sc = [int(x) for x in counts]
+            rc = kdist.exchange_counts(sc, device=cdev)
+            n_in = int(sum(rc))
+            if pos + n_in > recv_cap:
+                raise SystemExit("receive buffer too small: %d > %d" % (pos + n_in, recv_cap))
+            if args.backend == "nccl":
+                works.append(dist.all_to_all_single(d_recv[pos:pos + n_in], send[: nt.value], output_split_sizes=rc,
+                                                    input_split_sizes=sc, async_op=True))
+            else:                                          # rehearsal: ranks share one GPU, payload staged through the host
+                r_host = torch.empty((n_in, 1), dtype=torch.int64)
+                dist.all_to_all_single(r_host, send[: nt.value].cpu(), output_split_sizes=rc, input_split_sizes=sc)
+                d_recv[pos:pos + n_in].copy_(r_host)
+
+                class _Done:
+                    def wait(self):
+                        return True
+                works.append(_Done())
+            pos += n_in
+        for w in works[-2:]:
+            w.wait()
+        idx.insert_device(d_recv.data_ptr(), pos)
 
     def sync():
         torch.cuda.synchronize(dev)
@@ -149,13 +185,14 @@ def main():
         if dom:
             avg_ms = dom["total_ms"] / dom["launches"]
             b_kernel = KERNEL_ALG_BYTES.get(dom["name"], B_ALG)
-            achieved = n_kmers * b_kernel / (avg_ms * 1e-3) / 1e9
+            per_launch = n_kmers * args.steps / dom["launches"]      # k-mers one launch processes (N > 1 runs in chunks)
+            achieved = per_launch * b_kernel / (avg_ms * 1e-3) / 1e9
             roofline = {"bound": "hbm", "kernel": dom["name"], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                         "traffic": measured_traffic(dom["name"], n_reads),
                         "avg_kernel_ms": round(avg_ms, 4),
                         "alg_bytes_per_kmer": b_kernel,
-                        "alg_bytes_per_launch": n_kmers * b_kernel,
+                        "alg_bytes_per_launch": per_launch * b_kernel,
                         "pipeline_frac": round(n_kmers * B_ALG / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                         "kernels_ms_per_step": {p["name"]: round(p["total_ms"] / args.steps, 4) for p in
                                                 sorted(prof, key=lambda p: -p["total_ms"])}}
@@ -165,7 +202,9 @@ def main():
                "config": {"workload": "k=%d DNA CountIndex (canonical), %d synthetic %d-bp reads per GPU as 315-byte "
                                       "FASTQ records, genome %d bp, seed %d" % (k, n_reads, read_len, genome_len, seed),
                           "kmers_per_step": total_kmers, "distinct_kmers": distinct,
-                          "exchange": "none (1 rank)" if world == 1 else "RCCL all_to_all_single (counts + payload)"},
+                          "exchange": "none (1 rank)" if world == 1 else
+                          "%s all_to_all_single (counts + payload), %d chunks per step, overlapped with parsing" %
+                          ("RCCL" if args.backend == "nccl" else "gloo (rehearsal)", nch)},
                "roofline": roofline}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(host, args, k, n_reads)

@@ -135,6 +135,14 @@ kmi_status kmi_route_dev(kmi_ctx *ctx, const kmi_config *cfg, const uint64_t *ke
 kmi_status kmi_route_tuples_dev(kmi_ctx *ctx, const kmi_config *cfg, const uint64_t *records_dev, size_t n,
                                 uint32_t nranks, uint32_t value_words, uint64_t *out_records_dev, uint64_t *send_counts_host);
 
+/* read_file_* followed by the bucketing half of imxx::distribute, fused (FASTQ): the k-mers of this rank's reads,
+ * transformed (InputTrans) and grouped by destination rank = DistHash(DistTrans(k)) % nranks, written straight from
+ * the packed input; the tuple array in file order never exists in HBM. Replaces kmi_extract_dev + kmi_route_dev on
+ * the multi-GPU build path (kmer_file_helper.hpp:588-633 + incremental_mxx.hpp:1039-1086). */
+kmi_status kmi_extract_route_dev(kmi_ctx *ctx, const kmi_config *cfg, const uint8_t *bytes_dev, size_t n_bytes, uint32_t nranks,
+                                 uint64_t *out_keys_dev, size_t out_capacity, uint64_t *n_tuples, uint64_t *n_seqs,
+                                 uint64_t *send_counts_host);
+
 /* ---- L4/L5: the map behind Index<MapType,Parser> ---------------------------- */
 kmi_status kmi_index_create(kmi_ctx *ctx, const kmi_config *cfg, kmi_index **out);
 kmi_status kmi_index_destroy(kmi_index *idx);

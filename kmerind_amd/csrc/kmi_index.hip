@@ -30,6 +30,7 @@
 #include <algorithm>
 
 #include "kmi_extract.h"
+#include <type_traits>
 
 namespace kmi {
 
@@ -59,10 +60,19 @@ enum BucketMode { BUCKET_COARSE = 0, BUCKET_SUB = 1, BUCKET_RANK = 2 };
 
 struct BucketFn {
   int mode; KShape shape; uint32_t dist_hash; bool farm_ndebug; uint32_t nranks;
+  uint32_t sub;   // rank mode: sub-buckets per rank (power of two, nranks * sub <= 256)
 };
+// Rank mode spreads every rank over `sub` buckets (bucket = rank * sub + a few high hash bits): the buckets of a rank
+// stay adjacent, so the output is still grouped by rank, but the per-tile LDS counters are 256 distinct addresses
+// instead of p hot ones (with p = 2..8 the same-address LDS atomics were the bottleneck of both rank kernels).
+inline uint32_t rank_sub_buckets(uint32_t nranks) { uint32_t s = 1; while (s * 2u * nranks <= (uint32_t)kNumCoarse) s *= 2u; return s; }
 
 template <int NW> __device__ __forceinline__ uint32_t bucket_of(const uint64_t (&key)[NW], const BucketFn &f) {
-  if (f.mode == BUCKET_RANK) return (uint32_t)(kmer_hash<NW>(key, f.shape, f.dist_hash, true, f.farm_ndebug, ceil_log2_u32(f.nranks)) % f.nranks);
+  if (f.mode == BUCKET_RANK) {
+    const uint64_t h = kmer_hash<NW>(key, f.shape, f.dist_hash, true, f.farm_ndebug, ceil_log2_u32(f.nranks));
+    const uint32_t spread = (uint32_t)((h >> 40) ^ (h >> 13)) * 0x9E3779B1u;   // identity/std hashes have few high bits
+    return (uint32_t)(h % f.nranks) * f.sub + ((spread >> 16) & (f.sub - 1u));
+  }
   uint32_t h = place_hash<NW>(key);
   return f.mode == BUCKET_COARSE ? coarse_of(h) : (fine_of(h) & (kSubPerCoarse - 1));
 }
@@ -221,25 +231,29 @@ __global__ __launch_bounds__(256) void coarse_cursors_kernel(const uint32_t *__r
   }
 }
 
-// rank mode: bucket_off[r] (nbuckets+1) and wg_off[w][r]
-__global__ __launch_bounds__(1024) void rank_offsets_kernel(const uint32_t *__restrict__ wg_hist, uint32_t groups, uint32_t nbuckets,
-                                                           uint64_t *__restrict__ bucket_cnt, uint64_t *__restrict__ wg_off) {
-  __shared__ uint64_t s_scan[1024 / 64 + 2];
-  __shared__ uint64_t s_base[kNumCoarse];
-  __shared__ uint64_t s_tot[kNumCoarse];
-  for (uint32_t c = wave_id(); c < nbuckets; c += (blockDim.x >> 6)) {
-    uint64_t v = 0;
-    for (uint32_t w = lane_id(); w < groups; w += kWave) v += wg_hist[(uint64_t)w * kNumCoarse + c];
-    v = wave_reduce_sum(v);
-    if (lane_id() == 0) s_tot[c] = v;
-  }
-  lds_barrier();
-  const uint64_t tot = (threadIdx.x < nbuckets) ? s_tot[threadIdx.x] : 0ull;
+// rank mode: bucket_cnt[b] and wg_off[w][b] for b < nbuckets, in three small launches spread over the chip:
+// column sums (one wavefront per bucket), scan of the <= 256 sums, per-(workgroup, bucket) cursors
+__global__ __launch_bounds__(256) void rank_totals_kernel(const uint32_t *__restrict__ wg_hist, uint32_t groups, uint32_t nbuckets,
+                                                         uint64_t *__restrict__ bucket_cnt) {
+  const uint32_t c = blockIdx.x * (blockDim.x >> 6) + wave_id();
+  if (c >= nbuckets) return;
+  uint64_t v = 0;
+  for (uint32_t w = lane_id(); w < groups; w += kWave) v += wg_hist[(uint64_t)w * kNumCoarse + c];
+  v = wave_reduce_sum(v);
+  if (lane_id() == 0) bucket_cnt[c] = v;
+}
+__global__ __launch_bounds__(256) void rank_bases_kernel(const uint64_t *__restrict__ bucket_cnt, uint32_t nbuckets, uint64_t *__restrict__ base) {
+  __shared__ uint64_t s_scan[256 / 64 + 2];
+  const uint64_t tot = (threadIdx.x < nbuckets) ? bucket_cnt[threadIdx.x] : 0ull;
   uint64_t total;
-  uint64_t off = block_exclusive_scan<uint64_t>(tot, s_scan, &total);
-  if (threadIdx.x < nbuckets) { bucket_cnt[threadIdx.x] = tot; s_base[threadIdx.x] = off; }
-  lds_barrier();
-  column_offsets(wg_hist, groups, nbuckets, s_base, wg_off);
+  const uint64_t off = block_exclusive_scan<uint64_t>(tot, s_scan, &total);
+  base[threadIdx.x] = off;   // entries >= nbuckets hold the grand total: harmless, never consumed as a cursor
+}
+static void launch_rank_offsets(hipStream_t stream, const uint32_t *wg_hist, uint32_t groups, uint32_t nbuckets, uint64_t *bucket_cnt,
+                                uint64_t *base /* [kNumCoarse] */, uint64_t *wg_off) {
+  hipLaunchKernelGGL(rank_totals_kernel, dim3(kNumCoarse / 4), dim3(256), 0, stream, wg_hist, groups, nbuckets, bucket_cnt);
+  hipLaunchKernelGGL(rank_bases_kernel, dim3(1), dim3(256), 0, stream, (const uint64_t *)bucket_cnt, nbuckets, base);
+  hipLaunchKernelGGL(coarse_cursors_kernel, dim3(kNumCoarse / 4), dim3(256), 0, stream, wg_hist, groups, (const uint64_t *)base, wg_off);
 }
 
 // ---------------------------------------------------------------------------
@@ -368,7 +382,7 @@ __global__ __launch_bounds__(kPartThreads) void scatter_fine_kernel(const uint64
   const uint64_t cursor = (threadIdx.x < kSubPerCoarse) ? part_off[(uint64_t)h * kNumFine + c * kSubPerCoarse + threadIdx.x] : 0ull;
   const uint64_t b = wg_off[(uint64_t)(h * kGroupsPerPart) * kNumCoarse + c];
   const uint64_t e = (h + 1 < (uint32_t)kFineParts) ? wg_off[(uint64_t)((h + 1) * kGroupsPerPart) * kNumCoarse + c] : fine_off[(c + 1) * kSubPerCoarse];
-  BucketFn fn; fn.mode = BUCKET_SUB; fn.shape = shape; fn.dist_hash = 0; fn.farm_ndebug = false; fn.nranks = 1;
+  BucketFn fn; fn.mode = BUCKET_SUB; fn.shape = shape; fn.dist_hash = 0; fn.farm_ndebug = false; fn.nranks = 1; fn.sub = 1;
   if (b < e) scatter_range<NW, BITS, VW>(in, b, e, out, shape, 0u, false, fn, cursor, s_stage, s_bkt, s_cnt, s_lofs, s_gbase, s_part);
 }
 
@@ -623,14 +637,98 @@ __global__ __launch_bounds__(kHistThreads) void fastq_hist_list_kernel(PackedInp
   }
 }
 
+// Rank counts from the window list (the counting half of imxx::distribute fused with read_file): per-workgroup counts
+// of the rank buckets, same tile ownership as the scatter that follows.
+template <int NW, int BITS>
+__global__ __launch_bounds__(512) void fastq_rank_hist_list_kernel(PackedInput in, uint64_t n_tiles, KShape shape, bool canonical,
+                                                                  const uint64_t *__restrict__ tile_off, const uint16_t *__restrict__ win_pos,
+                                                                  BucketFn fn, uint32_t *__restrict__ wg_hist,
+                                                                  uint32_t *__restrict__ win_pb /* position | bucket << 16 */) {
+  using Cfg = ExCfg<NW, BITS>;
+  using L = ListCfg<NW, BITS>;
+  constexpr int NT = 512, RMAX = L::RMAX;
+  constexpr int UL = (L::UNITS + NT - 1) / NT;
+  constexpr int PB = 8;
+  __shared__ uint32_t s_hist[kNumCoarse];
+  __shared__ uint32_t s_stream[2][L::STREAM_DW];
+  if (threadIdx.x < kNumCoarse) s_hist[threadIdx.x] = 0;
+  const uint64_t per = (n_tiles + gridDim.x - 1) / gridDim.x;
+  const uint64_t tb = (uint64_t)blockIdx.x * per;
+  const uint64_t te = (tb + per < n_tiles) ? tb + per : n_tiles;
+  const uint64_t last_unit = in.n_cover / Cfg::C - 1;
+  auto load_image = [&](uint64_t t, uint64_t (&st)[UL]) {
+#pragma unroll
+    for (int i = 0; i < UL; ++i) {
+      uint64_t g = t * Cfg::NT + (uint64_t)i * NT + threadIdx.x;
+      g = g < last_unit ? g : last_unit;
+      st[i] = read_stream_unit<BITS, Cfg::C>(in.stream, g);
+    }
+  };
+  auto store_image = [&](uint32_t *img, const uint64_t (&st)[UL]) {
+#pragma unroll
+    for (int i = 0; i < UL; ++i) {
+      const int u = i * NT + threadIdx.x;
+      if (u < L::UNITS) store_stream_bits<BITS, Cfg::C>(img, u, st[i]);
+    }
+  };
+  uint64_t st[UL];
+  if (tb < te) { load_image(tb, st); store_image(s_stream[0], st); }
+  lds_barrier();
+  int buf = 0;
+  for (uint64_t t = tb; t < te; t += RMAX) {
+    const bool more = t + RMAX < te;
+    if (more) load_image(t + RMAX, st);
+    const uint64_t qa = tile_off[t];
+    uint64_t o[RMAX + 1];
+#pragma unroll
+    for (int i = 1; i <= RMAX; ++i) o[i] = tile_off[(t + i < te) ? t + i : te];
+    const uint32_t total = (uint32_t)(o[RMAX] - qa);
+    uint32_t orel[RMAX];
+#pragma unroll
+    for (int i = 1; i < RMAX; ++i) orel[i] = (uint32_t)(o[i] - qa);
+    const uint32_t *img = s_stream[buf];
+    const uint16_t *src = win_pos + qa;
+    for (uint32_t q0 = 0; q0 < total; q0 += NT * PB) {
+      uint32_t p16[PB];
+#pragma unroll
+      for (int m = 0; m < PB; ++m) {
+        uint32_t q = q0 + m * NT + threadIdx.x;
+        q = q < total ? q : total - 1;
+        p16[m] = src[q];
+      }
+#pragma unroll
+      for (int m = 0; m < PB; ++m) {
+        const uint32_t q = q0 + m * NT + threadIdx.x;
+        if (q < total) {
+          uint32_t r = 0;
+#pragma unroll
+          for (int i = 1; i < RMAX; ++i) r += (q >= orel[i]) ? 1u : 0u;
+          uint64_t rc[NW], fw[NW], key[NW];
+          window_at<Cfg>(img, r * Cfg::TILE + p16[m], shape, rc, fw);
+          select_strand<NW>(rc, fw, canonical, key);
+          const uint32_t b = bucket_of<NW>(key, fn);
+          atomicAdd(&s_hist[b], 1u);
+          win_pb[qa + q] = p16[m] | (b << 16);   // the rank hash (Murmur / Farm) is computed once: the scatter reads it back
+        }
+      }
+    }
+    if (more) store_image(s_stream[buf ^ 1], st);
+    lds_barrier();
+    buf ^= 1;
+  }
+  lds_barrier();
+  if (threadIdx.x < kNumCoarse) wg_hist[(uint64_t)blockIdx.x * kNumCoarse + threadIdx.x] = s_hist[threadIdx.x];
+}
+
 // E2 from the window list. A round is a run of up to CAPW consecutive windows of this
 // workgroup's tiles (it may start and end inside a tile, and spans at most RMAX scan tiles, whose packed
 // stream is one contiguous LDS image), so the bucket sort always works on a full stage: fewer, longer
 // contiguous runs per coarse bucket and no per-byte work at all.
-template <int NW, int BITS>
+// RANK = true: the list entries are 32-bit (position | rank bucket << 16), written by the rank histogram pass.
+template <int NW, int BITS, bool RANK = false>
 __global__ __launch_bounds__((ExCfg<NW, BITS>::NT)) void fastq_scatter_list_kernel(PackedInput in, uint64_t n_tiles, KShape shape, bool canonical,
                                                                                   const uint64_t *__restrict__ tile_off,
-                                                                                  const uint16_t *__restrict__ win_pos,
+                                                                                  const typename std::conditional<RANK, uint32_t, uint16_t>::type *__restrict__ win_pos,
                                                                                   const uint64_t *__restrict__ wg_off, uint64_t *__restrict__ out) {
   using Cfg = ExCfg<NW, BITS>;
   using L = ListCfg<NW, BITS>;
@@ -707,9 +805,9 @@ __global__ __launch_bounds__((ExCfg<NW, BITS>::NT)) void fastq_scatter_list_kern
 #pragma unroll
           for (int i = 1; i < RMAX; ++i) r += (q >= cur.orel[i]) ? 1u : 0u;
           uint64_t rc[NW], fw[NW];
-          window_at<Cfg>(s_stream, r * Cfg::TILE + p16[m], shape, rc, fw);
+          window_at<Cfg>(s_stream, r * Cfg::TILE + (p16[m] & 0xffffu), shape, rc, fw);
           select_strand<NW>(rc, fw, canonical, key[m]);
-          const uint32_t b = coarse_of(place_hash<NW>(key[m]));
+          const uint32_t b = RANK ? (p16[m] >> 16) : coarse_of(place_hash<NW>(key[m]));
           bkrk[m] = (b << 16) | atomicAdd(&s_cnt[b], 1u);
         }
       }
@@ -1321,7 +1419,7 @@ static kmi_status partition_impl(kmi_ctx *ctx, const kmi_config *cfg, KShape sha
     hipLaunchKernelGGL(coarse_cursors_kernel, dim3(kNumCoarse / 4), dim3(256), 0, ctx->stream, (const uint32_t *)w.wg_hist, (uint32_t)kPartGroups,
                        (const uint64_t *)w.coarse_base, w.wg_off);
   }
-  BucketFn fn; fn.mode = BUCKET_COARSE; fn.shape = shape; fn.dist_hash = 0; fn.farm_ndebug = false; fn.nranks = 1;
+  BucketFn fn; fn.mode = BUCKET_COARSE; fn.shape = shape; fn.dist_hash = 0; fn.farm_ndebug = false; fn.nranks = 1; fn.sub = 1;
   {
     ProfScope ps(ctx, "scatter_coarse", n);
     hipLaunchKernelGGL((scatter_chunks_kernel<NW, BITS, VW>), dim3(kPartGroups), dim3(kPartThreads), 0, ctx->stream, keys_dev, (uint64_t)n, w.buf_a,
@@ -1615,22 +1713,37 @@ static uint64_t query_result_bound(const kmi_index *idx, int mode, size_t nq) {
 }
 
 // imxx::distribute bucketing by destination rank
+// per-rank counts = sums over the rank's sub-buckets
+static kmi_status read_rank_counts(kmi_ctx *ctx, const uint64_t *cnt_dev, uint32_t nranks, uint32_t sub, uint64_t *send_counts_host) {
+  uint64_t tmp[kNumCoarse];
+  KMI_HIP(ctx, hipMemcpyAsync(tmp, cnt_dev, sizeof(uint64_t) * nranks * sub, hipMemcpyDeviceToHost, ctx->stream));
+  KMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  for (uint32_t r = 0; r < nranks; ++r) {
+    uint64_t c = 0;
+    for (uint32_t j = 0; j < sub; ++j) c += tmp[r * sub + j];
+    send_counts_host[r] = c;
+  }
+  return KMI_OK;
+}
+
 template <int NW, int BITS, int VW>
 static kmi_status route_vw(kmi_ctx *ctx, const kmi_config *cfg, KShape shape, const uint64_t *keys_dev, size_t n, uint32_t nranks,
                            uint64_t *out_keys_dev, uint64_t *send_counts_host) {
   void *p;
   KMI_TRY(ws_get(ctx, WS_WGHIST, sizeof(uint32_t) * kPartGroups * kNumCoarse, &p)); uint32_t *wg_hist = (uint32_t *)p;
   KMI_TRY(ws_get(ctx, WS_CURSOR, sizeof(uint64_t) * kPartGroups * kNumCoarse, &p)); uint64_t *wg_off = (uint64_t *)p;
-  KMI_TRY(ws_get(ctx, WS_MISC, sizeof(uint64_t) * kNumCoarse, &p)); uint64_t *cnt = (uint64_t *)p;
+  KMI_TRY(ws_get(ctx, WS_MISC, sizeof(uint64_t) * kNumCoarse * 2, &p)); uint64_t *cnt = (uint64_t *)p;
   BucketFn fn; fn.mode = BUCKET_RANK; fn.shape = shape; fn.dist_hash = cfg->dist_hash; fn.farm_ndebug = cfg->farm_ndebug != 0; fn.nranks = nranks;
+  fn.sub = rank_sub_buckets(nranks);
+  const uint32_t nb = nranks * fn.sub;
   {
     ProfScope ps(ctx, "hist_rank", n);
     hipLaunchKernelGGL((hist_rank_kernel<NW, BITS, VW>), dim3(kPartGroups), dim3(kPartThreads), 0, ctx->stream, keys_dev, (uint64_t)n, shape,
                        cfg->strand, fn, wg_hist);
   }
   {
-    ProfScope ps(ctx, "rank_offsets", nranks);
-    hipLaunchKernelGGL(rank_offsets_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const uint32_t *)wg_hist, (uint32_t)kPartGroups, nranks, cnt, wg_off);
+    ProfScope ps(ctx, "rank_offsets", nb);
+    launch_rank_offsets(ctx->stream, (const uint32_t *)wg_hist, (uint32_t)kPartGroups, nb, cnt, cnt + kNumCoarse, wg_off);
   }
   {
     ProfScope ps(ctx, "scatter_rank", n);
@@ -1638,9 +1751,7 @@ static kmi_status route_vw(kmi_ctx *ctx, const kmi_config *cfg, KShape shape, co
                        out_keys_dev, shape, cfg->strand, true, fn, (const uint64_t *)wg_off);
   }
   KMI_HIP(ctx, hipGetLastError());
-  KMI_HIP(ctx, hipMemcpyAsync(send_counts_host, cnt, sizeof(uint64_t) * nranks, hipMemcpyDeviceToHost, ctx->stream));
-  KMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  return KMI_OK;
+  return read_rank_counts(ctx, cnt, nranks, fn.sub, send_counts_host);
 }
 
 template <int NW, int BITS>
@@ -1650,6 +1761,55 @@ static kmi_status route_impl(kmi_ctx *ctx, const kmi_config *cfg, KShape shape, 
   if (value_words == 1) return route_vw<NW, BITS, 1>(ctx, cfg, shape, keys_dev, n, nranks, out_keys_dev, send_counts_host);
   if (value_words == 2) return route_vw<NW, BITS, 2>(ctx, cfg, shape, keys_dev, n, nranks, out_keys_dev, send_counts_host);
   return set_err(ctx, KMI_ERR_INVALID, "value_words must be 0, 1 or 2");
+}
+
+// read_file + the bucketing half of imxx::distribute in one go (FASTQ): keys of this rank's reads, transformed and
+// grouped by destination rank, straight from the window list; the tuple array in file order never exists.
+template <int NW, int BITS>
+static kmi_status extract_route_impl(kmi_ctx *ctx, const kmi_config *cfg, KShape shape, const uint8_t *bytes_dev, size_t n_bytes, uint32_t nranks,
+                                     uint64_t *out_keys_dev, size_t capacity, uint64_t *n_tuples, uint64_t *n_seqs, uint64_t *send_counts_host) {
+  FastqScan sc;
+  KMI_TRY(fastq_scan(ctx, cfg, bytes_dev, n_bytes, &sc));
+  if (n_tuples) *n_tuples = sc.n_tuples;
+  if (n_seqs) *n_seqs = sc.n_seqs;
+  for (uint32_t r = 0; r < nranks; ++r) send_counts_host[r] = 0;
+  const uint64_t n = sc.n_tuples, n_tiles = sc.n_tiles;
+  if (n == 0) return KMI_OK;
+  if (n > capacity) return set_err(ctx, KMI_ERR_OVERFLOW, "extract_route: output capacity too small");
+  PackedInput in; in.eol = sc.pk_eol; in.stream = sc.pk_stream; in.n_bytes = sc.n_bytes; in.n_cover = sc.n_cover;
+  const bool canonical = cfg->strand != KMI_STRAND_SINGLE;
+  void *p;
+  KMI_TRY(ws_get(ctx, WS_WGHIST, sizeof(uint32_t) * kPartGroups * kNumCoarse, &p)); uint32_t *wg_hist = (uint32_t *)p;
+  KMI_TRY(ws_get(ctx, WS_CURSOR, sizeof(uint64_t) * kPartGroups * kNumCoarse, &p)); uint64_t *wg_off = (uint64_t *)p;
+  KMI_TRY(ws_get(ctx, WS_MISC, sizeof(uint64_t) * kNumCoarse * 2, &p)); uint64_t *cnt = (uint64_t *)p;
+  KMI_TRY(ws_get(ctx, WS_WIN_LIST, sizeof(uint16_t) * (n + 64), &p)); uint16_t *win_pos = (uint16_t *)p;
+  KMI_TRY(ws_get(ctx, WS_WIN_LIST2, sizeof(uint32_t) * (n + 64), &p)); uint32_t *win_pb = (uint32_t *)p;
+  BucketFn fn; fn.mode = BUCKET_RANK; fn.shape = shape; fn.dist_hash = cfg->dist_hash; fn.farm_ndebug = cfg->farm_ndebug != 0; fn.nranks = nranks;
+  fn.sub = rank_sub_buckets(nranks);
+  const uint32_t nb = nranks * fn.sub;
+  {
+    ProfScope ps(ctx, "fastq_list", n);
+    using LP = ListPassCfg<NW, BITS>;
+    const uint32_t wave_lds = LP::wave_lds_bytes(shape.k);
+    hipLaunchKernelGGL((fastq_list_kernel<NW, BITS>), dim3(kListGroups), dim3(kListThreads), wave_lds * (kListThreads / kWave), ctx->stream, in,
+                       n_tiles, shape.k, LP::max_runs(shape.k), wave_lds, sc.line_base, sc.tile_off, win_pos);
+  }
+  {
+    ProfScope ps(ctx, "fastq_rank_hist", n);
+    hipLaunchKernelGGL((fastq_rank_hist_list_kernel<NW, BITS>), dim3(kPartGroups), dim3(512), 0, ctx->stream, in, n_tiles, shape, canonical,
+                       sc.tile_off, (const uint16_t *)win_pos, fn, wg_hist, win_pb);
+  }
+  {
+    ProfScope ps(ctx, "rank_offsets", nb);
+    launch_rank_offsets(ctx->stream, (const uint32_t *)wg_hist, (uint32_t)kPartGroups, nb, cnt, cnt + kNumCoarse, wg_off);
+  }
+  {
+    ProfScope ps(ctx, "fastq_rank_scatter", n);
+    hipLaunchKernelGGL((fastq_scatter_list_kernel<NW, BITS, true>), dim3(kPartGroups), dim3(ExCfg<NW, BITS>::NT), 0, ctx->stream, in, n_tiles,
+                       shape, canonical, sc.tile_off, (const uint32_t *)win_pb, (const uint64_t *)wg_off, out_keys_dev);
+  }
+  KMI_HIP(ctx, hipGetLastError());
+  return read_rank_counts(ctx, cnt, nranks, fn.sub, send_counts_host);
 }
 
 }  // namespace kmi
@@ -1676,6 +1836,21 @@ kmi_status kmi_route_dev(kmi_ctx *ctx, const kmi_config *cfg, const uint64_t *ke
   KMI_HIP(ctx, hipSetDevice(ctx->device));
   if (n == 0) { for (uint32_t r = 0; r < nranks; ++r) send_counts_host[r] = 0; return KMI_OK; }
   KMI_DISPATCH(shape, route_impl, ctx, cfg, shape, keys_dev, n, nranks, 0u, out_keys_dev, send_counts_host);
+}
+
+kmi_status kmi_extract_route_dev(kmi_ctx *ctx, const kmi_config *cfg, const uint8_t *bytes_dev, size_t n_bytes, uint32_t nranks,
+                                 uint64_t *out_keys_dev, size_t out_capacity, uint64_t *n_tuples, uint64_t *n_seqs,
+                                 uint64_t *send_counts_host) {
+  if (!ctx) return KMI_ERR_INVALID;
+  KShape shape;
+  if (!valid_config(cfg, &shape)) return set_err(ctx, KMI_ERR_INVALID, "bad kmi_config");
+  if (nranks == 0 || nranks > (uint32_t)kNumCoarse || !send_counts_host) return set_err(ctx, KMI_ERR_INVALID, "nranks must be in 1..256");
+  if (cfg->seq_format != KMI_FMT_FASTQ) return set_err(ctx, KMI_ERR_INVALID, "extract_route: FASTQ only (use kmi_extract_dev + kmi_route_dev)");
+  KMI_HIP(ctx, hipSetDevice(ctx->device));
+  if (n_tuples) *n_tuples = 0;
+  if (n_seqs) *n_seqs = 0;
+  if (n_bytes == 0) { for (uint32_t r = 0; r < nranks; ++r) send_counts_host[r] = 0; return KMI_OK; }
+  KMI_DISPATCH(shape, extract_route_impl, ctx, cfg, shape, bytes_dev, n_bytes, nranks, out_keys_dev, out_capacity, n_tuples, n_seqs, send_counts_host);
 }
 
 kmi_status kmi_index_create(kmi_ctx *ctx, const kmi_config *cfg, kmi_index **out) {

@@ -40,6 +40,7 @@ enum WsSlot {
   WS_PK_EOL,          // EOL bitmap of the scanned input
   WS_PK_STREAM,       // packed complement-code stream of the scanned input
   WS_WIN_LIST,        // tile position of every k-mer window, file order (fused build)
+  WS_WIN_LIST2,       // position | rank bucket << 16 of every window (fused extract + route)
   WS_NUM_SLOTS
 };
 

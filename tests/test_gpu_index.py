@@ -192,3 +192,58 @@ def test_route_matches_key_to_rank(ctx):
                 b = exp[np.lexsort([exp[:, w] for w in range(nw)])]
                 assert (a == b).all()
                 off += int(counts[r])
+
+
+def test_extract_route_fused_matches_extract_then_key_to_rank(ctx):
+    """kmi_extract_route_dev = read_file + the bucketing half of imxx::distribute: per destination rank the same
+    multiset of transformed keys as oracle extract -> transform -> KeyToRank; then the whole multi-rank build replayed
+    on one device (every rank's reads routed, every destination's index built) equals the oracle's single map."""
+    import ctypes as C
+    import kmerind_amd as K
+    from kmerind_amd import _lib as L
+    for k, alpha, strand, dh, p in ((31, "DNA", "canonical", "murmur", 8), (21, "DNA", "single", "farm", 3),
+                                    (63, "DNA5", "canonical", "murmur", 2), (31, "DNA", "bimolecule", "identity", 5)):
+        cfg = K.make_config(k, alpha, strand=strand, dist_hash=dh)
+        s = orc.kspec(k, ALPHA[alpha])
+        hashes = {"murmur": orc.MURMUR, "farm": orc.FARM, "identity": orc.IDENTITY}
+        per_dest = [[] for _ in range(p)]
+        all_kmers = []
+        for r in range(p):                                    # rank r parses its own reads
+            data = np.asarray(K.synth_fastq(seed=7, genome_len=60000, n_reads=500, first_read=r * 500))
+            ex = orc.extract(s, data.tobytes(), orc.FASTQ)["kmers"]
+            all_kmers.append(ex)
+            n, nw = ex.shape
+            dbytes, dout = ctx.alloc(data.nbytes), ctx.alloc(ex.nbytes + 64)
+            ctx.to_device(dbytes, data)
+            counts = np.zeros(p, dtype=np.uint64)
+            nt, ns = C.c_uint64(), C.c_uint64()
+            ctx.check(L.lib.kmi_extract_route_dev(ctx.h, C.byref(cfg), C.c_void_p(dbytes), data.nbytes, p, C.c_void_p(dout), n,
+                                                  C.byref(nt), C.byref(ns), counts.ctypes.data_as(C.c_void_p)))
+            assert nt.value == n and ns.value == 500
+            out = np.zeros_like(ex)
+            ctx.to_host(out, dout)
+            ctx.free(dbytes); ctx.free(dout)
+            tk = ex if strand == "single" else orc.canonical(s, ex)
+            ranks = orc.key_to_rank(s, hashes[dh], STRAND[strand], tk, p)
+            assert counts.tolist() == np.bincount(ranks, minlength=p).tolist()
+            off = 0
+            for d in range(p):
+                seg = out[off:off + int(counts[d])]
+                exp = tk[ranks == d]
+                assert (seg[np.lexsort([seg[:, w] for w in range(nw)])] == exp[np.lexsort([exp[:, w] for w in range(nw)])]).all()
+                per_dest[d].append(seg)
+                off += int(counts[d])
+        m = orc.CountMap(s, STRAND[strand])
+        m.insert(np.concatenate(all_kmers))
+        got_k, got_c = [], []
+        for d in range(p):                                    # destination d inserts what it received
+            idx = K.CountIndex(ctx, cfg)
+            idx.insert(np.concatenate(per_dest[d]))
+            kk, cc = idx.to_vector()
+            got_k.append(kk); got_c.append(cc)
+            idx.close()
+        gk, gc = np.concatenate(got_k), np.concatenate(got_c)
+        ek, ec = m.export()
+        assert gk.shape == ek.shape
+        go, eo = np.lexsort([gk[:, w] for w in range(gk.shape[1])]), np.lexsort([ek[:, w] for w in range(ek.shape[1])])
+        assert (gk[go] == ek[eo]).all() and (gc[go] == ec[eo]).all()
