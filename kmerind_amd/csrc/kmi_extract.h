@@ -373,4 +373,49 @@ __device__ __forceinline__ void select_strand(const uint64_t (&rc)[NW], const ui
   for (int w = 0; w < NW; ++w) key[w] = use_fw ? fw[w] : rc[w];
 }
 
+// ---------------------------------------------------------------------------
+// EOL-bitmap scans used by the seq/qual length rule of FASTQParser::get_next_record (fastq_loader.hpp:454-463)
+// ---------------------------------------------------------------------------
+// Bitmap words come from a per-wavefront LDS image (the tile with 1 KB of context on either side, which holds
+// whole records of ordinary reads) and from HBM only beyond it.
+struct EolBits {
+  const uint32_t *g; uint64_t n_words;        // global bitmap; bit set = EOL; words >= n_words count as all-EOL
+  const uint32_t *img; uint64_t w0; uint32_t nw;   // LDS image of words [w0, w0 + nw)
+  __device__ __forceinline__ uint32_t word(uint64_t wi) const {
+    const uint64_t d = wi - w0;
+    if (d < (uint64_t)nw) return img[d];
+    return wi < n_words ? g[wi] : 0xffffffffu;
+  }
+};
+__device__ __forceinline__ uint64_t eol_next_set(const EolBits &b, uint64_t p) {   // first EOL position >= p
+  uint64_t wi = p >> 5;
+  if (wi >= b.n_words) return p;
+  uint32_t bits = b.word(wi) & (0xffffffffu << (p & 31u));
+  while (bits == 0u) { if (++wi >= b.n_words) return wi << 5; bits = b.word(wi); }
+  return (wi << 5) + (uint32_t)__builtin_ctz(bits);
+}
+template <bool SET> __device__ __forceinline__ int64_t eol_prev(const EolBits &b, int64_t p) {   // last position < p whose EOL bit == SET, -1 if none
+  if (p <= 0 || b.n_words == 0) return -1;
+  uint64_t q = (uint64_t)p - 1;
+  if (q >= b.n_words * 32ull) { if (SET) return (int64_t)q; q = b.n_words * 32ull - 1; }
+  uint64_t wi = q >> 5;
+  uint32_t w = b.word(wi);
+  uint32_t bits = (SET ? w : ~w) & (0xffffffffu >> (31u - (uint32_t)(q & 31u)));
+  while (bits == 0u) { if (wi == 0) return -1; --wi; w = b.word(wi); bits = SET ? w : ~w; }
+  return (int64_t)((wi << 5) + 31u - (uint32_t)__builtin_clz(bits));
+}
+// g = position of the first byte of a quality line
+__device__ __forceinline__ bool fastq_lengths_differ(const EolBits &b, uint64_t g) {
+  const uint64_t len_qual = eol_next_set(b, g) - g;
+  const int64_t plus_last = eol_prev<false>(b, (int64_t)g);          // last byte of the '+' line
+  if (plus_last < 0) return false;
+  const int64_t gap = eol_prev<true>(b, plus_last);                   // an EOL between the sequence and the '+' line
+  if (gap < 0) return false;
+  const int64_t seq_last = eol_prev<false>(b, gap);                   // last byte of the sequence line
+  if (seq_last < 0) return false;
+  const int64_t seq_first = eol_prev<true>(b, seq_last) + 1;          // (-1 + 1 = 0: the sequence line opens the buffer)
+  return (uint64_t)(seq_last - seq_first + 1) != len_qual;
+}
+
+
 }  // namespace kmi

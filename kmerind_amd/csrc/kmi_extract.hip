@@ -195,47 +195,6 @@ __global__ __launch_bounds__(1024) void fastq_offsets_apply_kernel(const TileInf
 // "quality" (index % 4 == 3, from the scan's line bases) measures itself forward and the sequence line two lines
 // back by bit scans over the global bitmap (a handful of cached word loads per record).
 // ---------------------------------------------------------------------------
-// Bitmap words come from a per-wavefront LDS image (the tile with 1 KB of context on either side, which holds
-// whole records of ordinary reads) and from HBM only beyond it.
-struct EolBits {
-  const uint32_t *g; uint64_t n_words;        // global bitmap; bit set = EOL; words >= n_words count as all-EOL
-  const uint32_t *img; uint64_t w0; uint32_t nw;   // LDS image of words [w0, w0 + nw)
-  __device__ __forceinline__ uint32_t word(uint64_t wi) const {
-    const uint64_t d = wi - w0;
-    if (d < (uint64_t)nw) return img[d];
-    return wi < n_words ? g[wi] : 0xffffffffu;
-  }
-};
-__device__ __forceinline__ uint64_t eol_next_set(const EolBits &b, uint64_t p) {   // first EOL position >= p
-  uint64_t wi = p >> 5;
-  if (wi >= b.n_words) return p;
-  uint32_t bits = b.word(wi) & (0xffffffffu << (p & 31u));
-  while (bits == 0u) { if (++wi >= b.n_words) return wi << 5; bits = b.word(wi); }
-  return (wi << 5) + (uint32_t)__builtin_ctz(bits);
-}
-template <bool SET> __device__ __forceinline__ int64_t eol_prev(const EolBits &b, int64_t p) {   // last position < p whose EOL bit == SET, -1 if none
-  if (p <= 0 || b.n_words == 0) return -1;
-  uint64_t q = (uint64_t)p - 1;
-  if (q >= b.n_words * 32ull) { if (SET) return (int64_t)q; q = b.n_words * 32ull - 1; }
-  uint64_t wi = q >> 5;
-  uint32_t w = b.word(wi);
-  uint32_t bits = (SET ? w : ~w) & (0xffffffffu >> (31u - (uint32_t)(q & 31u)));
-  while (bits == 0u) { if (wi == 0) return -1; --wi; w = b.word(wi); bits = SET ? w : ~w; }
-  return (int64_t)((wi << 5) + 31u - (uint32_t)__builtin_clz(bits));
-}
-// g = position of the first byte of a quality line
-__device__ __forceinline__ bool fastq_lengths_differ(const EolBits &b, uint64_t g) {
-  const uint64_t len_qual = eol_next_set(b, g) - g;
-  const int64_t plus_last = eol_prev<false>(b, (int64_t)g);          // last byte of the '+' line
-  if (plus_last < 0) return false;
-  const int64_t gap = eol_prev<true>(b, plus_last);                   // an EOL between the sequence and the '+' line
-  if (gap < 0) return false;
-  const int64_t seq_last = eol_prev<false>(b, gap);                   // last byte of the sequence line
-  if (seq_last < 0) return false;
-  const int64_t seq_first = eol_prev<true>(b, seq_last) + 1;          // (-1 + 1 = 0: the sequence line opens the buffer)
-  return (uint64_t)(seq_last - seq_first + 1) != len_qual;
-}
-
 // Dense form: every lane takes a few words of the window (tile + context), line starts (non-EOL after EOL) and
 // line ends (EOL after non-EOL) are ranked with two wave scans and their positions land in two small LDS arrays, so
 // line j of the window is [S[j], E[j + eoff]) and a quality line is compared with the line two ranks before it by
@@ -557,7 +516,7 @@ struct ScanResult {
 
 template <int NW, int BITS>
 static kmi_status scan_impl(kmi_ctx *ctx, const uint8_t *bytes_dev, size_t n_bytes, const KShape &shape, ScanResult *r,
-                            bool reuse = false) {
+                            bool reuse = false, bool check_lengths = true) {
   using Cfg = ExCfg<NW, BITS>;
   const uint64_t n_tiles = (n_bytes + Cfg::TILE - 1) / Cfg::TILE;
   void *p;
@@ -583,7 +542,7 @@ static kmi_status scan_impl(kmi_ctx *ctx, const uint8_t *bytes_dev, size_t n_byt
                        bytes_dev, (uint64_t)n_bytes, shape.k, pk_eol, pk_stream, info, ctx->d_flags);
   }
   KMI_TRY(launch_tile_offsets(ctx, info, n_tiles, (uint32_t)Cfg::TILE, hdr, base, off));
-  if (n_tiles > 0) {
+  if (n_tiles > 0 && check_lengths) {
     ProfScope ps(ctx, "fastq_check", n_bytes);
     hipLaunchKernelGGL((fastq_check_lengths_kernel<Cfg::TILE>), dim3(2048), dim3(256), 0, ctx->stream, (const uint32_t *)pk_eol,
                        (uint64_t)(n_cover / 32), n_tiles, (const uint32_t *)base, ctx->d_flags);
@@ -661,20 +620,32 @@ static kmi_status extract_run_impl(kmi_ctx *ctx, const kmi_config *cfg, const ui
 }
 
 template <int NW, int BITS>
-static kmi_status fastq_scan_impl(kmi_ctx *ctx, const uint8_t *bytes_dev, size_t n_bytes, KShape shape, FastqScan *out) {
+static kmi_status fastq_scan_impl(kmi_ctx *ctx, const uint8_t *bytes_dev, size_t n_bytes, KShape shape, FastqScan *out, bool check_lengths) {
   ScanResult r;
   KMI_HIP(ctx, hipMemsetAsync(ctx->d_flags, 0, sizeof(uint32_t) * 16, ctx->stream));
-  KMI_TRY((scan_impl<NW, BITS>(ctx, bytes_dev, n_bytes, shape, &r)));
+  KMI_TRY((scan_impl<NW, BITS>(ctx, bytes_dev, n_bytes, shape, &r, false, check_lengths)));
   out->n_tiles = r.n_tiles; out->line_base = r.line_base; out->tile_off = r.out_off;
   out->pk_eol = r.packed.eol; out->pk_stream = r.packed.stream; out->n_bytes = r.packed.n_bytes; out->n_cover = r.packed.n_cover;
   return read_totals(ctx, &out->n_tuples, &out->n_seqs);
 }
 
-kmi_status fastq_scan(kmi_ctx *ctx, const kmi_config *cfg, const uint8_t *bytes_dev, size_t n_bytes, FastqScan *out) {
+// verdict of the seq/qual length rule when the list pass carries it (call after a stream sync point is acceptable: it syncs)
+kmi_status fastq_length_verdict(kmi_ctx *ctx) {
+  uint32_t f = 0;
+  KMI_HIP(ctx, hipMemcpyAsync(&f, ctx->d_flags, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+  KMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (f & 4u) {
+    KMI_HIP(ctx, hipMemsetAsync(ctx->d_flags, 0, sizeof(uint32_t), ctx->stream));
+    return set_err(ctx, KMI_ERR_PARSE, "FASTQ: truncated record? seq and qual differ in length");
+  }
+  return KMI_OK;
+}
+
+kmi_status fastq_scan(kmi_ctx *ctx, const kmi_config *cfg, const uint8_t *bytes_dev, size_t n_bytes, FastqScan *out, bool check_lengths) {
   KShape shape;
   if (!valid_config(cfg, &shape)) return set_err(ctx, KMI_ERR_INVALID, "bad kmi_config");
   if (cfg->seq_format != KMI_FMT_FASTQ) return set_err(ctx, KMI_ERR_INVALID, "only FASTQ is implemented on the device yet");
-  KMI_DISPATCH(shape, fastq_scan_impl, ctx, bytes_dev, n_bytes, shape, out);
+  KMI_DISPATCH(shape, fastq_scan_impl, ctx, bytes_dev, n_bytes, shape, out, check_lengths);
 }
 
 // ---- FASTA: byte-space scan + compaction (kmi_fasta.hip), then count / extract over the compacted stream

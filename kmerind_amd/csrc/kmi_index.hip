@@ -396,33 +396,42 @@ __global__ __launch_bounds__(kPartThreads) void scatter_fine_kernel(const uint64
 // L: the window list. The tile position of every k-mer window goes to HBM once (2 bytes per k-mer, file
 // order, windows of scan tile t at tile_off[t]); the histogram and scatter passes start from it and have no
 // per-byte work left. The pass works per LINE, not per byte, and one WAVEFRONT owns a tile, so there is no
-// workgroup barrier in it: each lane takes WORDS/64 words of the tile's EOL bitmap and finds the line starts
-// in them; a line whose index (from the scan's line bases) says "sequence" becomes a run (first window,
-// number of windows) by looking up the next EOL bit; the wavefront then expands the runs into the list.
-// Windows belong to the tile they start in; a line that began in an earlier tile is picked up by lane 0.
+// workgroup barrier in it. The lanes share the words of the tile's EOL bitmap plus 1 KB of context on either
+// side; line starts (non-EOL after EOL) and line ends (EOL after non-EOL) are ranked with one wave scan and their
+// positions land in two small LDS arrays, so line j of the window is [S[j], E[j + eoff]). A line whose index (from
+// the scan's line bases) says "sequence" becomes a run (first window, number of windows) clipped to the tile; a
+// line that says "quality" is compared with the line two ranks before it (fastq_loader.hpp:454-463); the wavefront
+// then expands the runs into the list. Windows belong to the tile they start in. A window that holds more than
+// CAP lines falls back to per-word bit scans.
 constexpr int kListThreads = 256;
 template <int NW, int BITS> struct ListPassCfg {
   using Cfg = ExCfg<NW, BITS>;
   static constexpr int TILE = Cfg::TILE;
   static constexpr int WORDS = TILE / 32;
-  static constexpr int WPL = WORDS / kWave;                    // bitmap words per lane
-  static constexpr int HALO_W = (Cfg::KMAX + 30) / 32 + 1;     // words behind the tile that a k-window of the tile can reach
-  static_assert(WORDS % kWave == 0 && HALO_W <= kWave, "bitmap words map onto the lanes of a wavefront");
+  static constexpr int CTX = 32;                               // bitmap words of context on either side (1 KB >= k - 1)
+  static constexpr int WIN = WORDS + 2 * CTX;
+  static constexpr int WPL = WIN / kWave;                      // bitmap words per lane
+  static constexpr int CAP = 512;                              // lines per window on the dense path
+  static_assert(WIN % kWave == 0 && WIN * 32 < 65536 && CTX * 32 >= Cfg::KMAX, "window geometry");
   // a run needs a record of >= k + 7 bytes
   static uint32_t max_runs(uint32_t k) { return (uint32_t)TILE / (k + 7u) + 2u; }
-  static uint32_t wave_lds_bytes(uint32_t k) { return (4u * (WORDS + HALO_W) + 6u * max_runs(k) + 15u) & ~15u; }
+  static uint32_t wave_lds_bytes(uint32_t k) { return (4u * WIN + 4u * CAP + 6u * max_runs(k) + 15u) & ~15u; }
 };
 
 template <int NW, int BITS>
 __global__ __launch_bounds__(kListThreads) void fastq_list_kernel(PackedInput in, uint64_t n_tiles, uint32_t k, uint32_t max_runs,
                                                                  uint32_t wave_lds_bytes, const uint32_t *__restrict__ line_base,
-                                                                 const uint64_t *__restrict__ tile_off, uint16_t *__restrict__ win_pos) {
+                                                                 const uint64_t *__restrict__ tile_off, uint16_t *__restrict__ win_pos,
+                                                                 uint32_t *__restrict__ flags) {
   using P = ListPassCfg<NW, BITS>;
-  constexpr int TILE = P::TILE, WORDS = P::WORDS, WPL = P::WPL, HALO_W = P::HALO_W;
+  constexpr int TILE = P::TILE, WORDS = P::WORDS, CTX = P::CTX, WIN = P::WIN, WPL = P::WPL, CAP = P::CAP;
+  constexpr uint32_t T0 = CTX * 32u, T1 = T0 + (uint32_t)TILE, NONE = 0xffff0000u;   // tile proper in window positions
   extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];
-  uint32_t *s_e = reinterpret_cast<uint32_t *>(s_dyn + (size_t)wave_id() * wave_lds_bytes);   // [WORDS + HALO_W]
-  uint32_t *s_run = s_e + WORDS + HALO_W;                                                      // [max_runs] first window | windows << 16
-  uint16_t *s_off = reinterpret_cast<uint16_t *>(s_run + max_runs);                            // [max_runs] rank of the run's first window
+  uint32_t *img = reinterpret_cast<uint32_t *>(s_dyn + (size_t)wave_id() * wave_lds_bytes);   // [WIN] bitmap words of the window
+  uint16_t *S = reinterpret_cast<uint16_t *>(img + WIN);                                      // [CAP] line starts
+  uint16_t *E = S + CAP;                                                                      // [CAP] line ends
+  uint32_t *s_run = reinterpret_cast<uint32_t *>(E + CAP);                                    // [max_runs] first window | windows << 16
+  uint16_t *s_off = reinterpret_cast<uint16_t *>(s_run + max_runs);                           // [max_runs] rank of the run's first window
   const uint32_t *eolw = reinterpret_cast<const uint32_t *>(in.eol);
   const uint64_t n_words = in.n_cover / 32;
   const uint64_t n_waves = (uint64_t)gridDim.x * (kListThreads / kWave);
@@ -432,78 +441,159 @@ __global__ __launch_bounds__(kListThreads) void fastq_list_kernel(PackedInput in
   const uint64_t te = (tb + per < n_tiles) ? tb + per : n_tiles;
   const uint32_t lane = lane_id();
   auto wave_sync = [&]() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); };
-  auto load_words = [&](uint64_t tile, uint32_t (&w)[WPL], uint32_t &h) {   // clamped loads, validity applied here
+  auto load_words = [&](uint64_t tile, uint32_t (&w)[WPL]) {   // window words of `tile`; outside the bitmap = EOL
+    const int64_t g0 = (int64_t)(tile * WORDS) - CTX + (int64_t)(lane * WPL);
 #pragma unroll
     for (int i = 0; i < WPL; ++i) {
-      const uint64_t g = tile * WORDS + (uint64_t)lane * WPL + i;
-      const uint32_t a = eolw[g < n_words ? g : 0];
-      w[i] = (g < n_words) ? a : 0xffffffffu;
+      const int64_t g = g0 + i;
+      const bool ok = g >= 0 && (uint64_t)g < n_words;
+      const uint32_t v = eolw[ok ? g : 0];
+      w[i] = ok ? v : 0xffffffffu;
     }
-    const uint64_t gh = tile * WORDS + WORDS + lane;
-    const uint32_t b = eolw[gh < n_words ? gh : 0];
-    h = (gh < n_words) ? b : 0xffffffffu;
   };
-  // first EOL position >= bit `from` in the tile + halo image; TILE + 32 * HALO_W when there is none
+  // first EOL position >= `from` in the window image; NONE when there is none
   auto next_eol = [&](uint32_t from) -> uint32_t {
     uint32_t w = from >> 5;
-    uint32_t bits = s_e[w] & (0xffffffffu << (from & 31u));
-    while (bits == 0u && ++w < (uint32_t)(WORDS + HALO_W)) bits = s_e[w];
-    return bits ? (w << 5) + (uint32_t)__builtin_ctz(bits) : (uint32_t)(TILE + 32 * HALO_W);
+    uint32_t bits = img[w] & (0xffffffffu << (from & 31u));
+    while (bits == 0u && ++w < (uint32_t)WIN) bits = img[w];
+    return bits ? (w << 5) + (uint32_t)__builtin_ctz(bits) : NONE;
   };
-  // windows of the sequence line that starts (or continues) at tile position s: p in [s, min(e - k, TILE - 1)]
-  auto run_len = [&](uint32_t s) -> uint32_t {
-    const uint32_t e = next_eol(s);
-    if (e < s + k) return 0u;
+  // windows of the sequence line [s, e) that start inside the tile: first window | count << 16 (0 = none)
+  auto clip_run = [&](uint32_t s, uint32_t e) -> uint32_t {
+    const uint32_t first = s > T0 ? s : T0;
+    if (e < first + k) return 0u;
     uint32_t last = e - k;
-    if (last > (uint32_t)TILE - 1u) last = TILE - 1;
-    return last - s + 1u;
+    if (last > T1 - 1u) last = T1 - 1u;
+    return (first - T0) | ((last - first + 1u) << 16);
   };
-  uint32_t w_cur[WPL], h_cur = 0xffffffffu, w_nxt[WPL], h_nxt;
+  uint32_t w_cur[WPL], w_nxt[WPL];
 #pragma unroll
   for (int i = 0; i < WPL; ++i) w_cur[i] = 0xffffffffu;
-  if (tb < te) load_words(tb, w_cur, h_cur);
-  uint32_t prev_tile = (tb < te && tb > 0) ? (eolw[tb * WORDS - 1] >> 31) : 1u;   // EOL status of the byte before the tile
+  if (tb < te) load_words(tb, w_cur);
   uint32_t lb = (tb < te) ? line_base[tb] : 0u;
   uint64_t toff = (tb < te) ? tile_off[tb] : 0ull;
+  bool bad = false;
   for (uint64_t t = tb; t < te; ++t) {
+    const int64_t gw0 = (int64_t)(t * WORDS) - CTX;
 #pragma unroll
-    for (int i = 0; i < WPL; ++i) s_e[lane * WPL + i] = w_cur[i];
-    if (lane < (uint32_t)HALO_W) s_e[WORDS + lane] = h_cur;
-    wave_sync();
-    load_words(t + 1, w_nxt, h_nxt);   // the next tile's inputs are in flight during this tile
+    for (int i = 0; i < WPL; ++i) img[lane * WPL + i] = w_cur[i];
+    const uint32_t prev_win = (gw0 > 0) ? (eolw[gw0 - 1] >> 31) : 1u;   // EOL status of the byte before the window
+    load_words(t + 1, w_nxt);   // the next tile's inputs are in flight during this tile
     const uint32_t lb_nxt = line_base[(t + 1 < n_tiles) ? t + 1 : t];
     const uint64_t toff_nxt = tile_off[t + 1];
-    uint32_t ls[WPL], nl = 0;
-    {
-      uint32_t prev = lane ? (s_e[lane * WPL - 1] >> 31) : prev_tile;
+    uint32_t prev = __shfl_up(w_cur[WPL - 1] >> 31, 1, kWave);
+    if (lane == 0) prev = prev_win;
+    uint32_t ls[WPL], le[WPL], ns = 0, ne = 0, nsl = 0, nst = 0;
 #pragma unroll
-      for (int i = 0; i < WPL; ++i) {
-        ls[i] = ~w_cur[i] & ((w_cur[i] << 1) | prev);
-        prev = w_cur[i] >> 31;
-        nl += (uint32_t)__builtin_popcount(ls[i]);
-      }
+    for (int i = 0; i < WPL; ++i) {
+      const uint32_t before = (w_cur[i] << 1) | prev;   // EOL status of each position's predecessor
+      ls[i] = ~w_cur[i] & before;
+      le[i] = w_cur[i] & ~before;
+      prev = w_cur[i] >> 31;
+      const uint32_t c = (uint32_t)__builtin_popcount(ls[i]);
+      const uint32_t ww = lane * WPL + i;
+      ns += c; ne += (uint32_t)__builtin_popcount(le[i]);
+      nsl += (ww < (uint32_t)CTX) ? c : 0u;
+      nst += (ww < (uint32_t)(CTX + WORDS)) ? c : 0u;
     }
-    const uint32_t lbl = wave_inclusive_scan(nl) - nl;
-    const bool carry_in = (lane == 0) && prev_tile == 0u && (w_cur[0] & 1u) == 0u && lb != 0u && ((lb - 1u) & 3u) == 1u;
-    // visit the runs of this lane in file order: f(first window, windows)
-    auto walk = [&](auto f) {
-      if (carry_in) { const uint32_t c = run_len(0u); if (c) f(0u, c); }
-      uint32_t idx = lb + lbl;
+    const uint32_t packed = ns | (ne << 16);
+    const uint32_t inc = wave_inclusive_scan(packed);
+    const uint32_t tot = __shfl(inc, kWave - 1, kWave);
+    const uint32_t NS = tot & 0xffffu, NE = tot >> 16;
+    const uint32_t cnt2 = wave_reduce_sum(nsl | (nst << 16));
+    const uint32_t NSL = cnt2 & 0xffffu, NST = cnt2 >> 16;   // line starts before the tile / before the tile's end
+    EolBits bm;
+    bm.g = eolw; bm.n_words = n_words; bm.img = img; bm.nw = WIN; bm.w0 = (uint64_t)gw0;
+    const uint64_t win0 = (uint64_t)(gw0 * 32);               // buffer position of window position 0 (wraps for the first tile, used additively)
+    uint32_t n_runs = 0;
+    wave_sync();   // window image complete
+    if (NS <= (uint32_t)CAP && NE <= (uint32_t)CAP) {
+      uint32_t rs = (inc - packed) & 0xffffu, re = (inc - packed) >> 16;
 #pragma unroll
       for (int i = 0; i < WPL; ++i) {
-        uint32_t rest = ls[i];
-        while (rest) {
-          const uint32_t b = (uint32_t)__builtin_ctz(rest);
-          if ((idx & 3u) == 1u) { const uint32_t s0 = (lane * WPL + i) * 32u + b, c = run_len(s0); if (c) f(s0, c); }
-          ++idx; rest &= rest - 1u;
+        const uint32_t base = (lane * WPL + i) * 32u;
+        uint32_t r = ls[i];
+        while (r) { S[rs++] = (uint16_t)(base + (uint32_t)__builtin_ctz(r)); r &= r - 1u; }
+        r = le[i];
+        while (r) { E[re++] = (uint16_t)(base + (uint32_t)__builtin_ctz(r)); r &= r - 1u; }
+      }
+      wave_sync();
+      const uint32_t eoff = prev_win ? 0u : 1u;   // a line open at the window start owns the first end event
+      // candidate lines: c = 0 is the line open at the tile start (the last start before the tile, or the line that
+      // was already open at the window start), c >= 1 are the lines that start inside the tile; line index lb + c - 1
+      const uint32_t ncand = 1u + (NST - NSL);
+      uint32_t win_base = 0;
+      for (uint32_t c0 = 0; c0 < ncand; c0 += kWave) {
+        const uint32_t c = c0 + lane;
+        const int32_t j = (int32_t)(NSL + c) - 1;            // rank among the window's line starts; -1 = open at window start
+        bool exists = c < ncand && (c >= 1u || (lb >= 1u && (j >= 0 || eoff)));
+        const uint32_t role = (lb + c - 1u) & 3u;
+        uint32_t run = 0;
+        if (exists && (role == 1u || role == 3u)) {
+          const uint32_t s0 = (j >= 0) ? (uint32_t)S[j] : 0u;
+          const int32_t je = j + (int32_t)eoff;
+          const uint32_t e0 = (je >= 0 && (uint32_t)je < NE) ? (uint32_t)E[je] : NONE;   // NONE: no EOL up to k - 1 bytes past the tile
+          if (role == 1u) {
+            run = clip_run(s0, e0);
+          } else if (c >= 1u) {                              // a quality line that starts in this tile
+            if (j >= 2 && e0 != NONE) {
+              const uint32_t len_seq = (uint32_t)E[je - 2] - (uint32_t)S[j - 2];
+              bad = bad || (e0 - s0 != len_seq);
+            } else {
+              bad = bad || fastq_lengths_differ(bm, win0 + s0);
+            }
+          }
+        }
+        const uint32_t mine = run ? ((1u << 16) | (run >> 16)) : 0u;
+        const uint32_t sc = wave_inclusive_scan(mine);
+        if (run) { const uint32_t r = n_runs + ((sc - mine) >> 16); s_run[r] = run; s_off[r] = (uint16_t)(win_base + ((sc - mine) & 0xffffu)); }
+        const uint32_t st = __shfl(sc, kWave - 1, kWave);
+        n_runs += st >> 16; win_base += st & 0xffffu;
+      }
+    } else {
+      // crowded window: the lanes walk the line starts of their own words (tile proper only) with bit scans
+      const uint32_t first_idx = lb + ((inc - packed) & 0xffffu) - NSL;   // line index of this lane's first start (meaningful inside the tile)
+      const bool carry_in = (lane == 0) && lb >= 1u && ((lb - 1u) & 3u) == 1u && (img[CTX] & 1u) == 0u &&
+                            ((img[CTX - 1] >> 31) == 0u);               // a sequence line runs across the tile start
+      auto walk = [&](auto f) {
+        if (carry_in) { const uint32_t r = clip_run(T0, next_eol(T0)); if (r) f(r); }
+        uint32_t idx = first_idx;
+#pragma unroll
+        for (int i = 0; i < WPL; ++i) {
+          const uint32_t ww = lane * WPL + i;
+          uint32_t rest = ls[i];
+          while (rest) {
+            const uint32_t s0 = ww * 32u + (uint32_t)__builtin_ctz(rest);
+            if (ww >= (uint32_t)CTX && ww < (uint32_t)(CTX + WORDS)) {
+              if ((idx & 3u) == 1u) { const uint32_t r = clip_run(s0, next_eol(s0)); if (r) f(r); }
+            }
+            ++idx; rest &= rest - 1u;
+          }
+        }
+      };
+      uint32_t mine = 0;
+      walk([&](uint32_t r) { mine += (1u << 16) | (r >> 16); });
+      {   // the length rule for the quality lines of the tile
+        uint32_t idx = first_idx;
+#pragma unroll
+        for (int i = 0; i < WPL; ++i) {
+          const uint32_t ww = lane * WPL + i;
+          uint32_t rest = ls[i];
+          while (rest) {
+            if (ww >= (uint32_t)CTX && ww < (uint32_t)(CTX + WORDS) && (idx & 3u) == 3u)
+              bad = bad || fastq_lengths_differ(bm, win0 + ww * 32u + (uint32_t)__builtin_ctz(rest));
+            ++idx; rest &= rest - 1u;
+          }
         }
       }
-    };
-    uint32_t mine = 0, first = 0;   // runs << 16 | windows; the lane's first run (the only one, normally)
-    walk([&](uint32_t s0, uint32_t c) { if (!mine) first = s0 | (c << 16); mine += (1u << 16) | c; });
-    const uint32_t inc = wave_inclusive_scan(mine);
-    const uint32_t tot = __shfl(inc, kWave - 1, kWave);
-    const uint32_t n_runs = tot >> 16;
+      const uint32_t sc = wave_inclusive_scan(mine);
+      n_runs = __shfl(sc, kWave - 1, kWave) >> 16;
+      if (mine) {
+        uint32_t r = (sc - mine) >> 16, off = (sc - mine) & 0xffffu;
+        walk([&](uint32_t run) { s_run[r] = run; s_off[r] = (uint16_t)off; ++r; off += run >> 16; });
+      }
+    }
+    wave_sync();   // run table complete
     auto expand = [&](uint32_t sc, uint32_t off) {   // wave-uniform arguments; positions go out two per 32-bit store
       uint32_t s0 = sc & 0xffffu, c = sc >> 16;
       uint64_t g = toff + off;                        // list index of the run's first window
@@ -512,26 +602,17 @@ __global__ __launch_bounds__(kListThreads) void fastq_list_kernel(PackedInput in
       for (uint32_t q = lane; q < (c >> 1); q += kWave) dst2[q] = (s0 + 2u * q) | ((s0 + 2u * q + 1u) << 16);
       if ((c & 1u) && lane == 0) win_pos[g + c - 1u] = (uint16_t)(s0 + c - 1u);
     };
-    if (__all((mine >> 16) <= 1u) && n_runs <= (uint32_t)kWave) {
-      // one run per lane at most: compact the runs across the lanes through the run table slots 0..n_runs-1
-      if (mine) { const uint32_t r = (inc - mine) >> 16; s_run[r] = first; s_off[r] = (uint16_t)((inc - mine) & 0xffffu); }
-      wave_sync();
-      const uint32_t my_sc = (lane < n_runs) ? s_run[lane] : 0u, my_off = (lane < n_runs) ? s_off[lane] : 0u;
-      for (uint32_t r = 0; r < n_runs; ++r) expand(__shfl(my_sc, (int)r, kWave), __shfl(my_off, (int)r, kWave));
-    } else {
-      if (mine) {
-        uint32_t r = (inc - mine) >> 16, off = (inc - mine) & 0xffffu;
-        walk([&](uint32_t s0, uint32_t c) { s_run[r] = s0 | (c << 16); s_off[r] = (uint16_t)off; ++r; off += c; });
-      }
-      wave_sync();
-      for (uint32_t r = 0; r < n_runs; ++r) expand(s_run[r], s_off[r]);
+    for (uint32_t r0 = 0; r0 < n_runs; r0 += kWave) {
+      const uint32_t nr = (n_runs - r0 < (uint32_t)kWave) ? n_runs - r0 : (uint32_t)kWave;
+      const uint32_t my_sc = (lane < nr) ? s_run[r0 + lane] : 0u, my_off = (lane < nr) ? s_off[r0 + lane] : 0u;
+      for (uint32_t r = 0; r < nr; ++r) expand(__shfl(my_sc, (int)r, kWave), __shfl(my_off, (int)r, kWave));
     }
-    prev_tile = __shfl(w_cur[WPL - 1] >> 31, kWave - 1, kWave);
-    wave_sync();   // the next tile overwrites the bitmap image and the run table
+    wave_sync();   // the next tile overwrites the image, the event arrays and the run table
 #pragma unroll
     for (int i = 0; i < WPL; ++i) w_cur[i] = w_nxt[i];
-    h_cur = h_nxt; lb = lb_nxt; toff = toff_nxt;
+    lb = lb_nxt; toff = toff_nxt;
   }
+  if (bad) atomicOr(&flags[0], 4u);
 }
 
 // geometry of the list-driven passes
@@ -1451,7 +1532,7 @@ static kmi_status read_total(kmi_ctx *ctx, int slot, uint64_t *v) {
 // replace the index arrays by the compacted content of tmp
 template <int NW>
 static kmi_status adopt_tmp(kmi_index *idx, const uint64_t *tmp_keys, const uint32_t *tmp_vals, const uint64_t *src_a, const uint64_t *src_b,
-                            const uint32_t *out_cnt) {
+                            const uint32_t *out_cnt, bool fastq_verdict = false) {
   kmi_ctx *ctx = idx->ctx;
   uint64_t *new_off = nullptr;
   KMI_HIP(ctx, hipMalloc((void **)&new_off, sizeof(uint64_t) * (kNumFine + 1)));
@@ -1460,7 +1541,9 @@ static kmi_status adopt_tmp(kmi_index *idx, const uint64_t *tmp_keys, const uint
     hipLaunchKernelGGL(bucket_offsets_kernel, dim3(1), dim3(1024), 0, ctx->stream, out_cnt, new_off, ctx->d_totals, 4);
   }
   uint64_t total = 0;
-  KMI_TRY(read_total(ctx, 4, &total));
+  kmi_status st_total = read_total(ctx, 4, &total);
+  if (st_total == KMI_OK && fastq_verdict) st_total = fastq_length_verdict(ctx);   // the index stays as it was on a parse error
+  if (st_total != KMI_OK) { (void)hipFree(new_off); return st_total; }
   uint64_t *nk = nullptr; uint32_t *nv = nullptr;
   hipError_t e1 = hipMalloc((void **)&nk, (total ? total : 1) * NW * sizeof(uint64_t));
   hipError_t e2 = hipMalloc((void **)&nv, (total ? total : 1) * sizeof(uint32_t));
@@ -1486,7 +1569,7 @@ static kmi_status adopt_tmp(kmi_index *idx, const uint64_t *tmp_keys, const uint
 
 // C + compaction: fold the fine-partitioned keys into the index
 template <int NW>
-static kmi_status reduce_and_adopt(kmi_index *idx, const Partitioned &part, size_t n) {
+static kmi_status reduce_and_adopt(kmi_index *idx, const Partitioned &part, size_t n, bool fastq_verdict = false) {
   kmi_ctx *ctx = idx->ctx;
   void *p;
   const uint64_t cap = n + idx->n_entries;
@@ -1500,7 +1583,7 @@ static kmi_status reduce_and_adopt(kmi_index *idx, const Partitioned &part, size
                        (const uint64_t *)(idx->has_data ? idx->bucket_off : nullptr), tmp_keys, tmp_vals, out_cnt, ctx->d_flags);
   }
   KMI_HIP(ctx, hipGetLastError());
-  return adopt_tmp<NW>(idx, tmp_keys, tmp_vals, part.fine_off, idx->has_data ? idx->bucket_off : nullptr, out_cnt);
+  return adopt_tmp<NW>(idx, tmp_keys, tmp_vals, part.fine_off, idx->has_data ? idx->bucket_off : nullptr, out_cnt, fastq_verdict);
 }
 
 template <int NW, int BITS>
@@ -1517,7 +1600,7 @@ template <int NW, int BITS>
 static kmi_status build_fused_impl(kmi_index *idx, const uint8_t *bytes_dev, size_t n_bytes) {
   kmi_ctx *ctx = idx->ctx;
   FastqScan sc;
-  KMI_TRY(fastq_scan(ctx, &idx->cfg, bytes_dev, n_bytes, &sc));   // reports malformed FASTQ
+  KMI_TRY(fastq_scan(ctx, &idx->cfg, bytes_dev, n_bytes, &sc, false));   // reports malformed FASTQ (the length rule rides on the list pass)
   const uint64_t n = sc.n_tuples, n_tiles = sc.n_tiles;
   if (n == 0) return KMI_OK;
   PackedInput in; in.eol = sc.pk_eol; in.stream = sc.pk_stream; in.n_bytes = sc.n_bytes; in.n_cover = sc.n_cover;
@@ -1534,7 +1617,7 @@ static kmi_status build_fused_impl(kmi_index *idx, const uint8_t *bytes_dev, siz
     using LP = ListPassCfg<NW, BITS>;
     const uint32_t wave_lds = LP::wave_lds_bytes(idx->shape.k);
     hipLaunchKernelGGL((fastq_list_kernel<NW, BITS>), dim3(kListGroups), dim3(kListThreads), wave_lds * (kListThreads / kWave), ctx->stream, in,
-                       n_tiles, idx->shape.k, LP::max_runs(idx->shape.k), wave_lds, line_base, sc.tile_off, win_pos);
+                       n_tiles, idx->shape.k, LP::max_runs(idx->shape.k), wave_lds, line_base, sc.tile_off, win_pos, ctx->d_flags);
   }
   {
     ProfScope ps(ctx, "fastq_hist", n);
@@ -1560,7 +1643,7 @@ static kmi_status build_fused_impl(kmi_index *idx, const uint8_t *bytes_dev, siz
   }
   KMI_HIP(ctx, hipGetLastError());
   Partitioned part; part.keys = w.buf_b; part.fine_off = w.fine_off;
-  return reduce_and_adopt<NW>(idx, part, (size_t)n);
+  return reduce_and_adopt<NW>(idx, part, (size_t)n, true);
 }
 
 static kmi_status index_build_fused(kmi_index *idx, const uint8_t *bytes_dev, size_t n_bytes) {
@@ -1769,7 +1852,7 @@ template <int NW, int BITS>
 static kmi_status extract_route_impl(kmi_ctx *ctx, const kmi_config *cfg, KShape shape, const uint8_t *bytes_dev, size_t n_bytes, uint32_t nranks,
                                      uint64_t *out_keys_dev, size_t capacity, uint64_t *n_tuples, uint64_t *n_seqs, uint64_t *send_counts_host) {
   FastqScan sc;
-  KMI_TRY(fastq_scan(ctx, cfg, bytes_dev, n_bytes, &sc));
+  KMI_TRY(fastq_scan(ctx, cfg, bytes_dev, n_bytes, &sc, false));
   if (n_tuples) *n_tuples = sc.n_tuples;
   if (n_seqs) *n_seqs = sc.n_seqs;
   for (uint32_t r = 0; r < nranks; ++r) send_counts_host[r] = 0;
@@ -1792,7 +1875,7 @@ static kmi_status extract_route_impl(kmi_ctx *ctx, const kmi_config *cfg, KShape
     using LP = ListPassCfg<NW, BITS>;
     const uint32_t wave_lds = LP::wave_lds_bytes(shape.k);
     hipLaunchKernelGGL((fastq_list_kernel<NW, BITS>), dim3(kListGroups), dim3(kListThreads), wave_lds * (kListThreads / kWave), ctx->stream, in,
-                       n_tiles, shape.k, LP::max_runs(shape.k), wave_lds, sc.line_base, sc.tile_off, win_pos);
+                       n_tiles, shape.k, LP::max_runs(shape.k), wave_lds, sc.line_base, sc.tile_off, win_pos, ctx->d_flags);
   }
   {
     ProfScope ps(ctx, "fastq_rank_hist", n);
@@ -1809,7 +1892,8 @@ static kmi_status extract_route_impl(kmi_ctx *ctx, const kmi_config *cfg, KShape
                        shape, canonical, sc.tile_off, (const uint32_t *)win_pb, (const uint64_t *)wg_off, out_keys_dev);
   }
   KMI_HIP(ctx, hipGetLastError());
-  return read_rank_counts(ctx, cnt, nranks, fn.sub, send_counts_host);
+  KMI_TRY(read_rank_counts(ctx, cnt, nranks, fn.sub, send_counts_host));
+  return fastq_length_verdict(ctx);   // the length rule rode on the list pass
 }
 
 }  // namespace kmi

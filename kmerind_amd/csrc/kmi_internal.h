@@ -156,7 +156,10 @@ struct FastqScan {
   const uint64_t *tile_off;   // [n_tiles + 1] k-mer windows before each scan tile
   const uint8_t *pk_eol, *pk_stream;
 };
-kmi_status fastq_scan(kmi_ctx *ctx, const kmi_config *cfg, const uint8_t *bytes_dev, size_t n_bytes, FastqScan *out);
+// check_lengths = false: the caller runs fastq_list_kernel, which carries the seq/qual length rule, and asks for
+// fastq_length_verdict afterwards
+kmi_status fastq_scan(kmi_ctx *ctx, const kmi_config *cfg, const uint8_t *bytes_dev, size_t n_bytes, FastqScan *out, bool check_lengths = true);
+kmi_status fastq_length_verdict(kmi_ctx *ctx);
 
 // FASTA: byte-space passes -> compacted character stream (kmi_fasta.hip)
 struct FastaScan {
