@@ -50,6 +50,7 @@ def main():
     ap.add_argument("--k", type=int, default=31)
     ap.add_argument("--cpu-sample-reads", type=int, default=500_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the extract-only / insert-only / query rates (outside the timed steps)")
     ap.add_argument("--chunks", type=int, default=4, help="N > 1: chunks per step (exchange of one overlaps parsing of the next)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = rehearsal of the N>1 flow with ranks sharing one GPU (exchange staged through the host)")
@@ -206,6 +207,8 @@ def main():
                           "%s all_to_all_single (counts + payload), %d chunks per step, overlapped with parsing" %
                           ("RCCL" if args.backend == "nccl" else "gloo (rehearsal)", nch)},
                "roofline": roofline}
+        if world == 1 and not args.no_extra:
+            out["extra"] = extra_rates(ctx, cfg, idx, d_bytes, nbytes, n_kmers, dev, torch)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(host, args, k, n_reads)
         print(json.dumps(out), flush=True)
@@ -214,6 +217,62 @@ def main():
     ctx.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+def extra_rates(ctx, cfg, idx, d_bytes, nbytes, n_kmers, dev, torch):
+    """The other sections the reference's benchmark times (BenchmarkKmerIndex.cpp:526-581), outside the timed steps, two
+    runs each, HBM-resident operands: read (extract only), insert (from an extracted tuple array), count and find of
+    10 M query k-mers (5 M present, 5 M random 62-bit values)."""
+    import kmerind_amd as K
+    from kmerind_amd import _lib as L
+
+    def timed(fn, reps=2):
+        fn()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize(dev)
+        return (time.perf_counter() - t0) / reps
+
+    d_keys = torch.empty((n_kmers + 64, 1), dtype=torch.int64, device=dev)
+    nt, ns = C.c_uint64(), C.c_uint64()
+
+    def extract():
+        ctx.check(L.lib.kmi_extract_dev(ctx.h, C.byref(cfg), C.c_void_p(d_bytes.data_ptr()), nbytes, 0, C.c_void_p(d_keys.data_ptr()),
+                                        None, n_kmers, C.byref(nt), C.byref(ns)))
+    t_extract = timed(extract)
+    idx2 = K.CountIndex(ctx, cfg)
+
+    def insert():
+        idx2.clear()
+        idx2.insert_device(d_keys.data_ptr(), nt.value)
+    t_insert = timed(insert)
+    idx2.close()
+    nq = min(10_000_000, n_kmers)
+    g = torch.Generator(device=dev)
+    g.manual_seed(5)
+    q = torch.empty((nq, 1), dtype=torch.int64, device=dev)
+    q[: nq // 2] = d_keys[torch.randint(0, n_kmers, (nq // 2,), device=dev, generator=g)]
+    q[nq // 2:] = torch.randint(0, 1 << 62, (nq - nq // 2, 1), device=dev, generator=g, dtype=torch.int64)
+    ok = torch.empty((nq, 1), dtype=torch.int64, device=dev)
+    ov = torch.empty((nq,), dtype=torch.int64, device=dev)
+    n_out = C.c_uint64()
+
+    def count():
+        ctx.check(L.lib.kmi_index_count_dev(idx.h, C.c_void_p(q.data_ptr()), nq, C.c_void_p(ok.data_ptr()), C.c_void_p(ov.data_ptr()),
+                                            C.byref(n_out)))
+    t_count = timed(count)
+    n_distinct_q = n_out.value
+
+    def find():
+        ctx.check(L.lib.kmi_index_find_dev(idx.h, C.c_void_p(q.data_ptr()), nq, C.c_void_p(ok.data_ptr()), C.c_void_p(ov.data_ptr()),
+                                           C.byref(n_out)))
+    t_find = timed(find)
+    return {"extract_only_kmers_per_s": n_kmers / t_extract, "insert_only_kmers_per_s": n_kmers / t_insert,
+            "count_queries_per_s": nq / t_count, "find_queries_per_s": nq / t_find, "queries": nq,
+            "distinct_query_keys": n_distinct_q, "found": n_out.value,
+            "note": "outside the timed steps; 2 runs each after one warm-up; operands resident in HBM"}
 
 
 def measured_traffic(kernel, n_reads):

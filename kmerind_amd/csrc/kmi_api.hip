@@ -164,6 +164,8 @@ kmi_status kmi_ctx_destroy(kmi_ctx *ctx) {
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   for (int s = 0; s < WS_NUM_SLOTS; ++s) if (ctx->ws[s].p) (void)hipFree(ctx->ws[s].p);
+  for (auto &b : ctx->spare) (void)hipFree(b.p);
+  ctx->spare.clear();
   for (ProfRec &r : ctx->prof_pending) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
   for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
   if (ctx->d_flags) (void)hipFree(ctx->d_flags);

@@ -1445,7 +1445,9 @@ struct kmi_index {
   uint64_t *bucket_off = nullptr; // [kNumFine + 1]
   uint64_t n_entries = 0;
   bool has_data = false;
+  size_t keys_bytes = 0, vals_bytes = 0, mvals_bytes = 0;   // sizes of the blocks above (for the context's spare list)
 };
+constexpr size_t kOffBytes = sizeof(uint64_t) * ((size_t)1 << 15) + sizeof(uint64_t);
 
 namespace kmi {
 
@@ -1535,7 +1537,7 @@ static kmi_status adopt_tmp(kmi_index *idx, const uint64_t *tmp_keys, const uint
                             const uint32_t *out_cnt, bool fastq_verdict = false) {
   kmi_ctx *ctx = idx->ctx;
   uint64_t *new_off = nullptr;
-  KMI_HIP(ctx, hipMalloc((void **)&new_off, sizeof(uint64_t) * (kNumFine + 1)));
+  KMI_HIP(ctx, pool_alloc(ctx, (void **)&new_off, kOffBytes));
   {
     ProfScope ps(ctx, "bucket_offsets", kNumFine);
     hipLaunchKernelGGL(bucket_offsets_kernel, dim3(1), dim3(1024), 0, ctx->stream, out_cnt, new_off, ctx->d_totals, 4);
@@ -1543,14 +1545,15 @@ static kmi_status adopt_tmp(kmi_index *idx, const uint64_t *tmp_keys, const uint
   uint64_t total = 0;
   kmi_status st_total = read_total(ctx, 4, &total);
   if (st_total == KMI_OK && fastq_verdict) st_total = fastq_length_verdict(ctx);   // the index stays as it was on a parse error
-  if (st_total != KMI_OK) { (void)hipFree(new_off); return st_total; }
+  if (st_total != KMI_OK) { pool_free(ctx, new_off, kOffBytes); return st_total; }
   uint64_t *nk = nullptr; uint32_t *nv = nullptr;
-  hipError_t e1 = hipMalloc((void **)&nk, (total ? total : 1) * NW * sizeof(uint64_t));
-  hipError_t e2 = hipMalloc((void **)&nv, (total ? total : 1) * sizeof(uint32_t));
+  const size_t kb = (total ? total : 1) * NW * sizeof(uint64_t), vb = (total ? total : 1) * sizeof(uint32_t);
+  hipError_t e1 = pool_alloc(ctx, (void **)&nk, kb);
+  hipError_t e2 = pool_alloc(ctx, (void **)&nv, vb);
   if (e1 != hipSuccess || e2 != hipSuccess) {
-    if (nk) (void)hipFree(nk);
-    if (nv) (void)hipFree(nv);
-    (void)hipFree(new_off);
+    if (nk) pool_free(ctx, nk, kb);
+    if (nv) pool_free(ctx, nv, vb);
+    pool_free(ctx, new_off, kOffBytes);
     return set_err(ctx, KMI_ERR_NOMEM, "hipMalloc failed for the index arrays");
   }
   {
@@ -1560,10 +1563,11 @@ static kmi_status adopt_tmp(kmi_index *idx, const uint64_t *tmp_keys, const uint
   }
   KMI_HIP(ctx, hipGetLastError());
   KMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  if (idx->keys) (void)hipFree(idx->keys);
-  if (idx->vals) (void)hipFree(idx->vals);
-  if (idx->bucket_off) (void)hipFree(idx->bucket_off);
+  pool_free(ctx, idx->keys, idx->keys_bytes);
+  pool_free(ctx, idx->vals, idx->vals_bytes);
+  pool_free(ctx, idx->bucket_off, kOffBytes);
   idx->keys = nk; idx->vals = nv; idx->bucket_off = new_off; idx->n_entries = total; idx->has_data = true;
+  idx->keys_bytes = kb; idx->vals_bytes = vb;
   return KMI_OK;
 }
 
@@ -1655,28 +1659,32 @@ static kmi_status index_insert(kmi_index *idx, const uint64_t *keys_dev, size_t 
 }
 
 static void free_index_arrays(kmi_index *idx) {
-  if (idx->keys) (void)hipFree(idx->keys);
-  if (idx->vals) (void)hipFree(idx->vals);
-  if (idx->mvals) (void)hipFree(idx->mvals);
-  if (idx->bucket_off) (void)hipFree(idx->bucket_off);
+  kmi_ctx *ctx = idx->ctx;
+  pool_free(ctx, idx->keys, idx->keys_bytes);
+  pool_free(ctx, idx->vals, idx->vals_bytes);
+  pool_free(ctx, idx->mvals, idx->mvals_bytes);
+  pool_free(ctx, idx->bucket_off, kOffBytes);
   idx->keys = nullptr; idx->vals = nullptr; idx->mvals = nullptr; idx->bucket_off = nullptr;
+  idx->keys_bytes = idx->vals_bytes = idx->mvals_bytes = 0;
 }
 
-static kmi_status alloc_mm_arrays(kmi_ctx *ctx, uint64_t total, int nw, int vw, uint64_t **nk, uint64_t **nv, uint64_t **noff) {
+static kmi_status alloc_mm_arrays(kmi_ctx *ctx, uint64_t total, int nw, int vw, uint64_t **nk, uint64_t **nv, uint64_t **noff, size_t *kb,
+                                  size_t *vb) {
   *nk = *nv = *noff = nullptr;
-  hipError_t e0 = hipMalloc((void **)noff, sizeof(uint64_t) * (kNumFine + 1));
-  hipError_t e1 = hipMalloc((void **)nk, (total ? total : 1) * nw * sizeof(uint64_t));
-  hipError_t e2 = hipMalloc((void **)nv, (total ? total : 1) * vw * sizeof(uint64_t));
+  *kb = (total ? total : 1) * nw * sizeof(uint64_t);
+  *vb = (total ? total : 1) * vw * sizeof(uint64_t);
+  hipError_t e0 = pool_alloc(ctx, (void **)noff, kOffBytes);
+  hipError_t e1 = pool_alloc(ctx, (void **)nk, *kb);
+  hipError_t e2 = pool_alloc(ctx, (void **)nv, *vb);
   if (e0 != hipSuccess || e1 != hipSuccess || e2 != hipSuccess) {
-    if (*nk) (void)hipFree(*nk);
-    if (*nv) (void)hipFree(*nv);
-    if (*noff) (void)hipFree(*noff);
+    if (*nk) pool_free(ctx, *nk, *kb);
+    if (*nv) pool_free(ctx, *nv, *vb);
+    if (*noff) pool_free(ctx, *noff, kOffBytes);
     return set_err(ctx, KMI_ERR_NOMEM, "hipMalloc failed for the index arrays");
   }
   return KMI_OK;
 }
 
-// unordered_multimap::insert (distributed_unordered_map.hpp:1466-1515): every (key, value) is kept
 template <int NW, int BITS, int VW>
 static kmi_status mm_insert_vw(kmi_index *idx, const uint64_t *recs_dev, size_t n, bool transform) {
   kmi_ctx *ctx = idx->ctx;
@@ -1685,7 +1693,8 @@ static kmi_status mm_insert_vw(kmi_index *idx, const uint64_t *recs_dev, size_t 
   KMI_TRY((partition_impl<NW, BITS, VW>(ctx, &idx->cfg, idx->shape, recs_dev, n, transform, WS_KEYS_A, WS_KEYS_B, &part)));
   const uint64_t total = n + idx->n_entries;
   uint64_t *nk, *nv, *noff;
-  KMI_TRY(alloc_mm_arrays(ctx, total, NW, VW, &nk, &nv, &noff));
+  size_t kb, vb;
+  KMI_TRY(alloc_mm_arrays(ctx, total, NW, VW, &nk, &nv, &noff, &kb, &vb));
   {
     ProfScope ps(ctx, "bucket_concat", n);
     hipLaunchKernelGGL((bucket_concat_kernel<NW, VW>), dim3(kNumFine), dim3(256), 0, ctx->stream, (const uint64_t *)part.keys,
@@ -1696,6 +1705,7 @@ static kmi_status mm_insert_vw(kmi_index *idx, const uint64_t *recs_dev, size_t 
   KMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
   free_index_arrays(idx);
   idx->keys = nk; idx->mvals = nv; idx->bucket_off = noff; idx->n_entries = total; idx->has_data = true;
+  idx->keys_bytes = kb; idx->mvals_bytes = vb;
   return KMI_OK;
 }
 
@@ -1746,7 +1756,8 @@ static kmi_status query_vw(kmi_index *idx, int mode, const uint64_t *q_dev, size
       uint64_t total = 0;
       KMI_TRY(read_total(ctx, 4, &total));
       uint64_t *nk, *nv, *noff;
-      KMI_TRY(alloc_mm_arrays(ctx, total, NW, OW, &nk, &nv, &noff));
+      size_t kb, vb;
+      KMI_TRY(alloc_mm_arrays(ctx, total, NW, OW, &nk, &nv, &noff, &kb, &vb));
       KMI_HIP(ctx, hipMemcpyAsync(noff, res_off, sizeof(uint64_t) * (kNumFine + 1), hipMemcpyDeviceToDevice, ctx->stream));
       hipLaunchKernelGGL((bucket_compact_words_kernel<NW, OW>), dim3(kNumFine), dim3(256), 0, ctx->stream, (const uint64_t *)tmp_keys,
                          (const uint64_t *)tmp_vals, (const uint64_t *)idx->bucket_off, (const uint64_t *)res_off, nk, nv);
@@ -1754,6 +1765,7 @@ static kmi_status query_vw(kmi_index *idx, int mode, const uint64_t *q_dev, size
       KMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
       free_index_arrays(idx);
       idx->keys = nk; idx->mvals = nv; idx->bucket_off = noff; idx->n_entries = total;
+      idx->keys_bytes = kb; idx->mvals_bytes = vb;
     }
     if (n_out) *n_out = before - idx->n_entries;
     return KMI_OK;

@@ -70,9 +70,34 @@ struct kmi_ctx {
   std::vector<kmi::ProfRec> prof_pending;
   std::vector<kmi::ProfAgg> prof_agg;
   std::vector<hipEvent_t> event_pool;
+  // released index arrays kept for the next build of the same size (a repeated build / clear cycle then never
+  // reaches hipMalloc / hipFree, whose cost on a loaded node is unpredictable)
+  struct Spare { void *p; size_t bytes; };
+  std::vector<Spare> spare;
 };
 
 namespace kmi {
+
+// device blocks of the index arrays: exact-size reuse from the context's spare list, else hipMalloc
+inline hipError_t pool_alloc(kmi_ctx *ctx, void **p, size_t bytes) {
+  if (bytes == 0) bytes = 256;
+  for (size_t i = 0; i < ctx->spare.size(); ++i)
+    if (ctx->spare[i].bytes == bytes) { *p = ctx->spare[i].p; ctx->spare.erase(ctx->spare.begin() + (long)i); return hipSuccess; }
+  hipError_t e = hipMalloc(p, bytes);
+  if (e != hipSuccess && !ctx->spare.empty()) {   // give the cached blocks back and retry once
+    for (auto &b : ctx->spare) (void)hipFree(b.p);
+    ctx->spare.clear();
+    e = hipMalloc(p, bytes);
+  }
+  return e;
+}
+inline void pool_free(kmi_ctx *ctx, void *p, size_t bytes) {
+  if (!p) return;
+  if (bytes == 0) bytes = 256;
+  constexpr size_t kMaxSpare = 6;
+  if (ctx->spare.size() >= kMaxSpare) { (void)hipFree(ctx->spare.front().p); ctx->spare.erase(ctx->spare.begin()); }
+  ctx->spare.push_back({p, bytes});
+}
 
 inline kmi_status set_err(kmi_ctx *ctx, kmi_status st, const char *fmt, const char *a = "", const char *b = "") {
   if (ctx) {
