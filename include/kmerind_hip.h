@@ -86,6 +86,24 @@ kmi_status kmi_copy_to_device(kmi_ctx *ctx, void *dst_dev, const void *src_host,
 kmi_status kmi_copy_to_host(kmi_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
 kmi_status kmi_synchronize(kmi_ctx *ctx);
 
+/* ---- FASTA input split over ranks ------------------------------------------------------------------
+ * What FASTAParser::init_parser learns about its block from the neighbouring ranks (fasta_loader.hpp:232-456,
+ * 485-604) and the valid range / overlap rule of the k-mer parsers (kmer_parser.hpp:112-157, overlap = k - 1,
+ * kmer_file_helper.hpp:563), as plain numbers the caller supplies for the NEXT FASTA extract / build calls on this
+ * context: the buffer is bytes [file_offset, file_offset + n_bytes) of the file, only k-mers whose first base lies
+ * in its first `valid_bytes` bytes are produced (the rest of the buffer is the overlap the last windows read), and
+ * the line-kind machine starts in `start_state` instead of "file start". NULL restores whole-file behaviour. */
+enum { KMI_FA_OUTSIDE = 0, KMI_FA_HEADER = 1, KMI_FA_SEQUENCE = 2 };
+typedef struct {
+  uint64_t valid_bytes;     /* k-mers start in [0, valid_bytes) of the buffer */
+  uint32_t start_state;     /* KMI_FA_*: kind of the line that byte 0 of the buffer sits on (OUTSIDE = before any header) */
+  uint32_t at_line_start;   /* 1: byte 0 is the first byte of a line (file start or the byte before it is '\n') */
+  uint64_t records_before;  /* records (header group -> sequence group transitions) that start before the buffer */
+  uint32_t index_shift;     /* 1 when the FILE begins with non-header lines (init_parser's k/2 rule), else 0 */
+  uint32_t reserved;
+} kmi_fasta_partition;
+kmi_status kmi_ctx_set_fasta_partition(kmi_ctx *ctx, const kmi_fasta_partition *part);
+
 /* ---- L2: k-mer value ops on arrays (parity surface for kmer.hpp / kmer_transform.hpp) */
 /* Kmer::reverse_complement (kmer.hpp:1118-1127) on n k-mers */
 kmi_status kmi_revcomp_host(kmi_ctx *ctx, const kmi_config *cfg, const uint64_t *in, size_t n, uint64_t *out);

@@ -24,6 +24,11 @@ FMT_FASTQ, FMT_FASTA = 0, 1
 INDEX_COUNT, INDEX_POSITION, INDEX_POSQUAL = 0, 1, 2
 
 
+class FastaPartition(C.Structure):
+    _fields_ = [("valid_bytes", C.c_uint64), ("start_state", C.c_uint32), ("at_line_start", C.c_uint32),
+                ("records_before", C.c_uint64), ("index_shift", C.c_uint32), ("reserved", C.c_uint32)]
+
+
 class Config(C.Structure):
     _fields_ = [("k", C.c_uint32), ("alphabet", C.c_uint32), ("strand", C.c_uint32),
                 ("dist_hash", C.c_uint32), ("store_hash", C.c_uint32), ("index_kind", C.c_uint32),
@@ -53,6 +58,7 @@ _u32 = C.c_uint32
 SIGNATURES = {
     "kmi_ctx_create": (C.c_int, [C.c_int, C.c_int, C.c_int, _P, C.POINTER(_P)]),
     "kmi_ctx_destroy": (C.c_int, [_P]),
+    "kmi_ctx_set_fasta_partition": (C.c_int, [_P, _P]),
     "kmi_last_error": (C.c_char_p, [_P]),
     "kmi_kmer_shape": (C.c_int, [_CFG, C.POINTER(_u32), C.POINTER(_u32), C.POINTER(_u32)]),
     "kmi_free_host": (None, [_P]),

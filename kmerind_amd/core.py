@@ -145,6 +145,16 @@ class Context:
             return kmers, ids, nseq
         return kmers, nseq
 
+    def set_fasta_partition(self, part=None):
+        """what FASTAParser::init_parser learns from the neighbouring ranks, for the next FASTA extract / build calls
+        (a dict from kmerind_amd.fileio.partition_fasta); None = whole file"""
+        if part is None:
+            self.check(lib.kmi_ctx_set_fasta_partition(self.h, None))
+            return
+        fp = L.FastaPartition(part["valid_bytes"], part["start_state"], part["at_line_start"], part["records_before"],
+                              part["index_shift"], 0)
+        self.check(lib.kmi_ctx_set_fasta_partition(self.h, C.byref(fp)))
+
     # ---- profiling
     def profile(self, on=True):
         self.check(lib.kmi_profile_enable(self.h, int(on)))

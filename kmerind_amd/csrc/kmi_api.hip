@@ -177,6 +177,15 @@ kmi_status kmi_ctx_destroy(kmi_ctx *ctx) {
 
 const char *kmi_last_error(const kmi_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 
+kmi_status kmi_ctx_set_fasta_partition(kmi_ctx *ctx, const kmi_fasta_partition *part) {
+  if (!ctx) return KMI_ERR_INVALID;
+  if (!part) { ctx->fa_part_set = false; return KMI_OK; }
+  if (part->start_state > KMI_FA_SEQUENCE || part->index_shift > 1u) return set_err(ctx, KMI_ERR_INVALID, "bad kmi_fasta_partition");
+  ctx->fa_part = *part;
+  ctx->fa_part_set = true;
+  return KMI_OK;
+}
+
 kmi_status kmi_kmer_shape(const kmi_config *cfg, uint32_t *n_words, uint32_t *n_bits, uint32_t *n_bytes) {
   KShape s;
   if (!valid_config(cfg, &s)) return KMI_ERR_INVALID;

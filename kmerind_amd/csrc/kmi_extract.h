@@ -110,6 +110,7 @@ struct PackedInput {
   const uint8_t *stream;   // bits [BITS*i, BITS*i+BITS) = complement code of input byte i
   uint64_t n_bytes;        // input length
   uint64_t n_cover;        // bytes covered by the arrays (multiple of the scan tile)
+  uint64_t n_valid;        // FASTA only: windows start at positions below this (valid range of a partition); else unused
 };
 
 template <int C> __device__ __forceinline__ uint32_t read_eol_unit(const uint8_t *__restrict__ pk, uint64_t g) {
@@ -279,15 +280,17 @@ __device__ __forceinline__ uint32_t chunk_valid_mask(const uint32_t *s_eol, uint
 // FASTA (compacted character space, s_eol holds the record-start bits): window r is valid iff no
 // record starts at r+1 .. r+k-1 and r + k <= n_chars
 template <typename Cfg>
-__device__ __forceinline__ uint32_t chunk_valid_mask_fasta(const uint32_t *s_eol, uint32_t k, uint64_t tile0, uint64_t n_chars) {
+__device__ __forceinline__ uint32_t chunk_valid_mask_fasta(const uint32_t *s_eol, uint32_t k, uint64_t tile0, uint64_t n_chars, uint64_t n_valid) {
   uint64_t e[Cfg::NE];
   load_eol_view<Cfg>(s_eol, threadIdx.x, e, 1);
   uint32_t blocked = 0;
   if (k > 1) { smear_right<Cfg::NE>(e, k - 1); blocked = (uint32_t)e[0]; }
   const uint64_t g = tile0 + (uint64_t)threadIdx.x * Cfg::C;
-  uint32_t room = 0;   // positions p with g + p + k <= n_chars
+  uint32_t room = 0;   // positions p with g + p + k <= n_chars and g + p < n_valid
   if (g + k <= n_chars) {
-    const uint64_t lim = n_chars - k - g + 1;
+    uint64_t lim = n_chars - k - g + 1;
+    const uint64_t lim2 = n_valid > g ? n_valid - g : 0ull;
+    lim = lim < lim2 ? lim : lim2;
     room = lim >= (uint64_t)Cfg::C ? Cfg::CMASK : ((1u << (uint32_t)lim) - 1u);
   }
   return ~blocked & room & Cfg::CMASK;

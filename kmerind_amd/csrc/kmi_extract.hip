@@ -312,7 +312,7 @@ __global__ __launch_bounds__((ExCfg<NW, BITS>::NT)) void fasta_extract_kernel(
   uint32_t eol, ls, lbl, ltot;
   tile_front_packed<Cfg>(in, blockIdx.x, s_eol, s_stream, s_scan, eol, ls, lbl, ltot);
   const uint64_t tile0 = (uint64_t)blockIdx.x * Cfg::TILE;
-  const uint32_t total = tile_window_list_from<Cfg>(chunk_valid_mask_fasta<Cfg>(s_eol, shape.k, tile0, in.n_bytes), s_pos, s_scan);
+  const uint32_t total = tile_window_list_from<Cfg>(chunk_valid_mask_fasta<Cfg>(s_eol, shape.k, tile0, in.n_bytes, in.n_valid), s_pos, s_scan);
   const uint64_t base = out_off[blockIdx.x];
   if (base + total > out_capacity) {
     if (threadIdx.x == 0 && total) atomicOr(&flags[1], 1u);
@@ -338,7 +338,7 @@ __global__ __launch_bounds__((ExCfg<NW, BITS>::NT)) void fasta_count_tiles_kerne
   __shared__ uint32_t s_scan[Cfg::NT / 64 + 2];
   uint32_t eol, ls, lbl, ltot;
   tile_front_packed<Cfg>(in, blockIdx.x, s_eol, s_stream, s_scan, eol, ls, lbl, ltot);
-  const uint32_t valid = chunk_valid_mask_fasta<Cfg>(s_eol, k, (uint64_t)blockIdx.x * Cfg::TILE, in.n_bytes);
+  const uint32_t valid = chunk_valid_mask_fasta<Cfg>(s_eol, k, (uint64_t)blockIdx.x * Cfg::TILE, in.n_bytes, in.n_valid);
   uint32_t total;
   (void)block_exclusive_scan<uint32_t>((uint32_t)__builtin_popcount(valid), s_scan, &total);
   if (threadIdx.x == 0) {
@@ -534,7 +534,7 @@ static kmi_status scan_impl(kmi_ctx *ctx, const uint8_t *bytes_dev, size_t n_byt
   KMI_TRY(ws_get(ctx, WS_PK_STREAM, n_cover * BITS / 8 + 64, &p));
   uint8_t *pk_stream = (uint8_t *)p;
   r->n_tiles = n_tiles; r->line_base = base; r->out_off = off; r->hdr_base = hdr;
-  r->packed.eol = pk_eol; r->packed.stream = pk_stream; r->packed.n_bytes = n_bytes; r->packed.n_cover = n_cover;
+  r->packed.eol = pk_eol; r->packed.stream = pk_stream; r->packed.n_bytes = n_bytes; r->packed.n_cover = n_cover; r->packed.n_valid = n_bytes;
   if (reuse) return KMI_OK;   // the scan of these very bytes is still in the workspace
   if (n_tiles > 0) {
     ProfScope ps(ctx, "fastq_scan_tiles", n_bytes);
@@ -657,7 +657,7 @@ static kmi_status fasta_extract_impl(kmi_ctx *ctx, const kmi_config *cfg, const 
   FastaScan fs;
   KMI_HIP(ctx, hipMemsetAsync(ctx->d_flags, 0, sizeof(uint32_t) * 16, ctx->stream));
   KMI_TRY(fasta_scan(ctx, cfg, bytes_dev, n_bytes, file_offset, out_ids_dev != nullptr, &fs));
-  PackedInput in; in.eol = fs.pk_break; in.stream = fs.pk_stream; in.n_bytes = fs.n_chars; in.n_cover = fs.n_cover;
+  PackedInput in; in.eol = fs.pk_break; in.stream = fs.pk_stream; in.n_bytes = fs.n_chars; in.n_cover = fs.n_cover; in.n_valid = fs.n_valid;
   const uint64_t n_tiles = (fs.n_chars + Cfg::TILE - 1) / Cfg::TILE;
   void *p;
   KMI_TRY(ws_get(ctx, WS_TILE_INFO, sizeof(TileInfo) * (n_tiles + 1), &p)); TileInfo *info = (TileInfo *)p;

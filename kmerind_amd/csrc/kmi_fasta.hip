@@ -91,8 +91,8 @@ struct FaTileSum { uint32_t map; uint64_t nseq[3]; uint64_t nev[3]; };
 struct FaTileBase { uint32_t state; uint64_t rank; uint64_t ev; };   // state entering the tile, characters / record starts before it
 
 // bytes -> (eol, newline-derived line starts, header starts) of this thread's chunk
-__device__ __forceinline__ void fa_chunk_masks(const uint8_t *__restrict__ bytes, uint64_t n_bytes, uint64_t tile0, uint32_t *s_nl,
-                                               uint32_t (&dw)[4], uint32_t &eol, uint32_t &ls, uint32_t &hs) {
+__device__ __forceinline__ void fa_chunk_masks(const uint8_t *__restrict__ bytes, uint64_t n_bytes, uint64_t tile0, bool first_ls,
+                                               uint32_t *s_nl, uint32_t (&dw)[4], uint32_t &eol, uint32_t &ls, uint32_t &hs) {
   constexpr int C = FaCfg::C;
   const int j = threadIdx.x;
   const uint64_t g = tile0 + (uint64_t)j * C;
@@ -111,21 +111,21 @@ __device__ __forceinline__ void fa_chunk_masks(const uint8_t *__restrict__ bytes
   lds_barrier();
   bool prev_nl;
   if (j > 0) prev_nl = (reinterpret_cast<uint16_t *>(s_nl)[j - 1] >> (C - 1)) & 1u;
-  else prev_nl = (tile0 == 0) ? true : (bytes[tile0 - 1] == '\n');
+  else prev_nl = (tile0 == 0) ? first_ls : (bytes[tile0 - 1] == '\n');   // first_ls: byte 0 of the buffer opens a line
   const uint32_t inb = (nv >= C) ? FaCfg::CMASK : ((1u << nv) - 1u);
   ls = ((nl << 1) | (prev_nl ? 1u : 0u)) & inb;
   hs = ls & hd;
 }
 
 // ---- pass 1: per-tile summaries
-__global__ __launch_bounds__((FaCfg::NT)) void fasta_scan_tiles_kernel(const uint8_t *__restrict__ bytes, uint64_t n_bytes,
+__global__ __launch_bounds__((FaCfg::NT)) void fasta_scan_tiles_kernel(const uint8_t *__restrict__ bytes, uint64_t n_bytes, bool first_ls,
                                                                       FaTileInfo *__restrict__ info) {
   __shared__ uint32_t s_nl[FaCfg::NT / 2 + 2];
   __shared__ uint32_t s_scan[FaCfg::NT / 64 + 2];
   __shared__ uint32_t s_acc[6];
   if (threadIdx.x < 6) s_acc[threadIdx.x] = 0;
   uint32_t dw[4], eol, ls, hs;
-  fa_chunk_masks(bytes, n_bytes, (uint64_t)blockIdx.x * FaCfg::TILE, s_nl, dw, eol, ls, hs);
+  fa_chunk_masks(bytes, n_bytes, (uint64_t)blockIdx.x * FaCfg::TILE, first_ls, s_nl, dw, eol, ls, hs);
   FaChunk r[3];
 #pragma unroll
   for (uint32_t in = 0; in < 3; ++in) r[in] = fa_chunk_apply(in, eol, ls, hs);
@@ -183,10 +183,11 @@ __global__ __launch_bounds__(1024) void fasta_offsets_reduce_kernel(const FaTile
 
 // in place: sums[b] becomes {state entering block b, characters before it (nseq[0]), record starts before it (nev[0])}
 // totals[0] = sequence characters, totals[2] = records
-__global__ __launch_bounds__(1024) void fasta_offsets_scan_kernel(FaTileSum *__restrict__ sums, uint64_t n_blocks, uint64_t *__restrict__ totals) {
+__global__ __launch_bounds__(1024) void fasta_offsets_scan_kernel(FaTileSum *__restrict__ sums, uint64_t n_blocks, uint32_t init_state,
+                                                                 uint64_t *__restrict__ totals) {
   __shared__ uint32_t s_scanm[1024 / 64 + 2];
   __shared__ uint64_t s_scan[1024 / 64 + 2];
-  uint32_t carry_state = FA_O;
+  uint32_t carry_state = init_state;   // FA_O at the file start; a partition states what its first byte sits on
   uint64_t carry_seq = 0, carry_ev = 0;
   for (uint64_t b0 = 0; b0 < n_blocks; b0 += 1024) {
     const uint64_t b = b0 + threadIdx.x;
@@ -230,9 +231,10 @@ __global__ __launch_bounds__(1024) void fasta_offsets_apply_kernel(const FaTileI
 // ---- pass 3: compaction. pk_stream / pk_break must be zero-filled; ids may be null.
 template <int BITS>
 __global__ __launch_bounds__((FaCfg::NT)) void fasta_compact_kernel(const uint8_t *__restrict__ bytes, uint64_t n_bytes, uint64_t file_offset,
-                                                                   uint64_t index_shift, const FaTileBase *__restrict__ base,
+                                                                   uint64_t index_shift /* + records before the buffer */, bool first_ls,
+                                                                   uint64_t valid_bytes, const FaTileBase *__restrict__ base,
                                                                    uint32_t *__restrict__ pk_stream, uint32_t *__restrict__ pk_break,
-                                                                   uint64_t *__restrict__ ids) {
+                                                                   uint64_t *__restrict__ ids, uint64_t *__restrict__ totals) {
   constexpr int C = FaCfg::C;
   __shared__ uint32_t s_nl[FaCfg::NT / 2 + 2];
   __shared__ uint32_t s_scanm[FaCfg::NT / 64 + 2];
@@ -242,7 +244,7 @@ __global__ __launch_bounds__((FaCfg::NT)) void fasta_compact_kernel(const uint8_
   const uint64_t tile0 = (uint64_t)blockIdx.x * FaCfg::TILE;
   const FaTileBase tb = base[blockIdx.x];
   uint32_t dw[4], eol, ls, hs;
-  fa_chunk_masks(bytes, n_bytes, tile0, s_nl, dw, eol, ls, hs);
+  fa_chunk_masks(bytes, n_bytes, tile0, first_ls, s_nl, dw, eol, ls, hs);
   uint32_t f = 0;
 #pragma unroll
   for (uint32_t in = 0; in < 3; ++in) f |= fa_chunk_apply(in, eol, ls, hs).out << (2 * in);
@@ -252,6 +254,12 @@ __global__ __launch_bounds__((FaCfg::NT)) void fasta_compact_kernel(const uint8_
   const uint32_t lr = block_exclusive_scan<uint32_t>((uint32_t)__builtin_popcount(r.seq), s_scan, &tile_chars);
   const uint32_t le = block_exclusive_scan<uint32_t>((uint32_t)__builtin_popcount(r.ev), s_scan, (uint32_t *)nullptr);
   const uint64_t rank0 = tb.rank + lr;                 // rank of this thread's first sequence character
+  {
+    // characters in the valid range = rank of the first character at or behind byte valid_bytes (partitions only)
+    const uint64_t c0 = tile0 + (uint64_t)threadIdx.x * C;
+    if (valid_bytes >= c0 && valid_bytes < c0 + C && valid_bytes < n_bytes)
+      totals[3] = rank0 + (uint32_t)__builtin_popcount(r.seq & ((1u << (uint32_t)(valid_bytes - c0)) - 1u));
+  }
   const uint32_t shift0 = (uint32_t)((tb.rank * BITS) & 31u);   // bit phase of the tile inside its first global dword
   // record starts: the first character of the record is the next sequence character = rank_before(position)
   {
@@ -330,34 +338,47 @@ kmi_status fasta_scan(kmi_ctx *ctx, const kmi_config *cfg, const uint8_t *bytes_
   KMI_HIP(ctx, hipMemsetAsync(pk_break, 0, break_bytes, ctx->stream));
   uint8_t first = 0;
   KMI_HIP(ctx, hipMemcpyAsync(&first, bytes_dev, 1, hipMemcpyDeviceToHost, ctx->stream));
+  // a partition of a FASTA file (kmi_ctx_set_fasta_partition) brings what init_parser learns from the neighbours
+  const bool part = ctx->fa_part_set;
+  const bool first_ls = part ? ctx->fa_part.at_line_start != 0 : true;
+  const uint32_t init_state = part ? ctx->fa_part.start_state : (uint32_t)FA_O;
+  const uint64_t valid_bytes = (part && ctx->fa_part.valid_bytes < n_bytes) ? ctx->fa_part.valid_bytes : (uint64_t)n_bytes;
   {
     ProfScope ps(ctx, "fasta_scan_tiles", n_bytes);
-    hipLaunchKernelGGL(fasta_scan_tiles_kernel, dim3((unsigned)n_tiles), dim3(FaCfg::NT), 0, ctx->stream, bytes_dev, (uint64_t)n_bytes, info);
+    hipLaunchKernelGGL(fasta_scan_tiles_kernel, dim3((unsigned)n_tiles), dim3(FaCfg::NT), 0, ctx->stream, bytes_dev, (uint64_t)n_bytes, first_ls,
+                       info);
   }
   {
     ProfScope ps(ctx, "fasta_scan_offsets", n_tiles);
     hipLaunchKernelGGL(fasta_offsets_reduce_kernel, dim3((unsigned)n_blocks), dim3(1024), 0, ctx->stream, (const FaTileInfo *)info, n_tiles, sums);
-    hipLaunchKernelGGL(fasta_offsets_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, sums, n_blocks, ctx->d_totals);
+    hipLaunchKernelGGL(fasta_offsets_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, sums, n_blocks, init_state, ctx->d_totals);
     hipLaunchKernelGGL(fasta_offsets_apply_kernel, dim3((unsigned)n_blocks), dim3(1024), 0, ctx->stream, (const FaTileInfo *)info, n_tiles,
                        (const FaTileSum *)sums, base);
   }
   KMI_HIP(ctx, hipGetLastError());
   KMI_HIP(ctx, hipMemcpyAsync(ctx->h_totals, ctx->d_totals, sizeof(uint64_t) * 4, hipMemcpyDeviceToHost, ctx->stream));
   KMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  // init_parser: a leading non-header group shifts the sequence indices by one
-  const uint64_t index_shift = (first == '>' || first == ';') ? 0u : 1u;
+  // init_parser: a leading non-header group shifts the sequence indices by one; a partition adds the records before it
+  const uint64_t index_shift = part ? (uint64_t)ctx->fa_part.index_shift + ctx->fa_part.records_before
+                                    : ((first == '>' || first == ';') ? 0u : 1u);
   {
     ProfScope ps(ctx, "fasta_compact", n_bytes);
     if (shape.bits == 2)
       hipLaunchKernelGGL((fasta_compact_kernel<2>), dim3((unsigned)n_tiles), dim3(FaCfg::NT), 0, ctx->stream, bytes_dev, (uint64_t)n_bytes,
-                         file_offset, index_shift, (const FaTileBase *)base, pk_stream, pk_break, ids);
+                         file_offset, index_shift, first_ls, valid_bytes, (const FaTileBase *)base, pk_stream, pk_break, ids, ctx->d_totals);
     else
       hipLaunchKernelGGL((fasta_compact_kernel<3>), dim3((unsigned)n_tiles), dim3(FaCfg::NT), 0, ctx->stream, bytes_dev, (uint64_t)n_bytes,
-                         file_offset, index_shift, (const FaTileBase *)base, pk_stream, pk_break, ids);
+                         file_offset, index_shift, first_ls, valid_bytes, (const FaTileBase *)base, pk_stream, pk_break, ids, ctx->d_totals);
   }
   KMI_HIP(ctx, hipGetLastError());
   out->n_chars = ctx->h_totals[0];
   out->n_seqs = ctx->h_totals[2];
+  out->n_valid = out->n_chars;
+  if (valid_bytes < (uint64_t)n_bytes) {   // totals[3] was written by the compaction pass
+    KMI_HIP(ctx, hipMemcpyAsync(ctx->h_totals + 3, ctx->d_totals + 3, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+    KMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    out->n_valid = ctx->h_totals[3];
+  }
   out->pk_break = (const uint8_t *)pk_break;
   out->pk_stream = (const uint8_t *)pk_stream;
   out->ids_by_rank = ids;

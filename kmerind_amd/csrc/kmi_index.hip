@@ -1607,7 +1607,7 @@ static kmi_status build_fused_impl(kmi_index *idx, const uint8_t *bytes_dev, siz
   KMI_TRY(fastq_scan(ctx, &idx->cfg, bytes_dev, n_bytes, &sc, false));   // reports malformed FASTQ (the length rule rides on the list pass)
   const uint64_t n = sc.n_tuples, n_tiles = sc.n_tiles;
   if (n == 0) return KMI_OK;
-  PackedInput in; in.eol = sc.pk_eol; in.stream = sc.pk_stream; in.n_bytes = sc.n_bytes; in.n_cover = sc.n_cover;
+  PackedInput in; in.eol = sc.pk_eol; in.stream = sc.pk_stream; in.n_bytes = sc.n_bytes; in.n_cover = sc.n_cover; in.n_valid = sc.n_bytes;
   const uint32_t *line_base = sc.line_base;
   const bool canonical = idx->cfg.strand != KMI_STRAND_SINGLE;
   PartWs w;
@@ -1871,7 +1871,7 @@ static kmi_status extract_route_impl(kmi_ctx *ctx, const kmi_config *cfg, KShape
   const uint64_t n = sc.n_tuples, n_tiles = sc.n_tiles;
   if (n == 0) return KMI_OK;
   if (n > capacity) return set_err(ctx, KMI_ERR_OVERFLOW, "extract_route: output capacity too small");
-  PackedInput in; in.eol = sc.pk_eol; in.stream = sc.pk_stream; in.n_bytes = sc.n_bytes; in.n_cover = sc.n_cover;
+  PackedInput in; in.eol = sc.pk_eol; in.stream = sc.pk_stream; in.n_bytes = sc.n_bytes; in.n_cover = sc.n_cover; in.n_valid = sc.n_bytes;
   const bool canonical = cfg->strand != KMI_STRAND_SINGLE;
   void *p;
   KMI_TRY(ws_get(ctx, WS_WGHIST, sizeof(uint32_t) * kPartGroups * kNumCoarse, &p)); uint32_t *wg_hist = (uint32_t *)p;

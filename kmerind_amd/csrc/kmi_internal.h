@@ -74,6 +74,8 @@ struct kmi_ctx {
   // reaches hipMalloc / hipFree, whose cost on a loaded node is unpredictable)
   struct Spare { void *p; size_t bytes; };
   std::vector<Spare> spare;
+  bool fa_part_set = false;      // kmi_ctx_set_fasta_partition
+  kmi_fasta_partition fa_part{};
 };
 
 namespace kmi {
@@ -189,6 +191,7 @@ kmi_status fastq_length_verdict(kmi_ctx *ctx);
 // FASTA: byte-space passes -> compacted character stream (kmi_fasta.hip)
 struct FastaScan {
   uint64_t n_chars, n_seqs, n_cover;
+  uint64_t n_valid;            // characters whose byte lies in the valid range: k-mer windows start below this rank
   const uint8_t *pk_break;     // bit r: character r is the first of a record
   const uint8_t *pk_stream;    // BITS per character, complement codes
   const uint64_t *ids_by_rank; // or null

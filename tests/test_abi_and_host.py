@@ -100,3 +100,29 @@ def test_partition_fastq_is_record_aligned_and_lossless():
                     got.append(ex["kmers"]); nseq += ex["n_seqs"]
             assert nseq == whole["n_seqs"]
             assert (np.concatenate(got) == whole["kmers"]).all()
+
+
+def test_fasta_partitioner_blocks_tile_the_file_and_carry_the_state():
+    """kmerind_amd.fileio.partition_fasta: valid ranges tile the buffer, overlap holds k - 1 sequence characters (or
+    runs to the end), and the state handed to each rank is the line-kind machine's state at its first byte."""
+    from kmerind_amd import fileio
+    import os
+    path = os.path.join(os.path.dirname(__file__), "golden", "data", "test.fasta")
+    data = open(path, "rb").read()
+    kind, starts, recs = fileio.fasta_line_kinds(data)
+    assert kind[0] == fileio.FA_HEADER and starts[0] == 1 and recs[-1] >= 1
+    for p in (1, 2, 5, 13):
+        parts = fileio.partition_fasta(data, p, 31)
+        pos = 0
+        for part in parts:
+            if part["begin"] == len(data):
+                continue
+            assert part["begin"] == pos
+            pos += part["valid_bytes"]
+            assert part["begin"] + part["valid_bytes"] <= part["end"] <= len(data)
+            b = part["begin"]
+            assert part["at_line_start"] == (1 if (b == 0 or data[b - 1] == 10) else 0)
+            if b and not part["at_line_start"]:
+                assert part["start_state"] == kind[b]
+            assert part["records_before"] == (recs[b - 1] if b else 0)
+        assert pos == len(data)
