@@ -448,21 +448,6 @@ KMI_HD uint32_t fastq_seq_role_mask(uint32_t lines_before, uint32_t ls, uint32_t
   return mask & cmask;
 }
 
-// window of n_bits starting at bit `off` of a normalized dword array -> NW words
-template <int NW, int NR> KMI_HD void window_words(const uint32_t (&r)[NR], int off, const KShape &s, uint64_t (&out)[NW]) {
-  const int d = off >> 5, sh = off & 31;
-#pragma unroll
-  for (int w = 0; w < NW; ++w) {
-    uint32_t a = (d + 2 * w < NR) ? r[d + 2 * w] : 0u;
-    uint32_t b = (d + 2 * w + 1 < NR) ? r[d + 2 * w + 1] : 0u;
-    uint32_t c = (d + 2 * w + 2 < NR) ? r[d + 2 * w + 2] : 0u;
-    uint32_t lo = sh ? ((a >> sh) | (b << (32 - sh))) : a;
-    uint32_t hi = sh ? ((b >> sh) | (c << (32 - sh))) : b;
-    out[w] = ((uint64_t)hi << 32) | lo;
-  }
-  mask_words<NW>(out, s);
-}
-
 // forward k-mer from its reverse complement window (the LDS stream holds complements)
 template <int NW, int BITS> KMI_HD void fwd_from_rc(const uint64_t (&rc)[NW], uint64_t (&fwd)[NW], const KShape &s) {
   revcomp_words<NW, BITS>(rc, fwd, s);

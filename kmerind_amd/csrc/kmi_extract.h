@@ -24,9 +24,6 @@ template <int NW_, int BITS_, int C_, int NT_> struct ExCfgT {
 };
 // default geometry: 16 bytes per thread for one-word k-mers; tile = 8 KB / 4 KB / 2 KB / 2 KB
 template <int NW, int BITS> using ExCfg = ExCfgT<NW, BITS, (NW == 1) ? 16 : 8, (NW <= 2) ? 512 : 256>;
-// same tile with 8 bytes per thread (twice the threads for one-word k-mers): used where LDS
-// allows only one workgroup per CU
-template <int NW, int BITS> using ExCfgWide = ExCfgT<NW, BITS, 8, ExCfg<NW, BITS>::TILE / 8>;
 
 struct TileInfo {
   uint32_t lines;     // line starts in the tile
@@ -88,15 +85,6 @@ template <typename Cfg> __device__ __forceinline__ void load_eol_view(const uint
     uint32_t hi = sh ? ((raw[2 * w + 1] >> sh) | (raw[2 * w + 2] << (32 - sh))) : raw[2 * w + 1];
     e[w] = ((uint64_t)hi << 32) | lo;
   }
-}
-
-template <typename Cfg> __device__ __forceinline__ void load_stream_view(const uint32_t *s_stream, int j, uint32_t (&r)[Cfg::NR]) {
-  const int bit0 = Cfg::C * Cfg::BITS * j, d0 = bit0 >> 5, sh = bit0 & 31;
-  uint32_t raw[Cfg::S_RAW];
-#pragma unroll
-  for (int i = 0; i < Cfg::S_RAW; ++i) raw[i] = s_stream[d0 + i];
-#pragma unroll
-  for (int i = 0; i < Cfg::NR; ++i) r[i] = sh ? ((raw[i] >> sh) | (raw[i + 1] << (32 - sh))) : raw[i];
 }
 
 // ---------------------------------------------------------------------------
@@ -220,63 +208,6 @@ __device__ __forceinline__ void tile_front_packed(const PackedInput &in, uint64_
   lines_before_local = block_exclusive_scan<uint32_t>((uint32_t)__builtin_popcount(ls), s_scan, &lines_total);
 }
 
-// Software-pipelined form of tile_front_packed for workgroups that walk consecutive tiles: the
-// units of tile t+2 are requested while tile t is processed. Loads are unconditional (clamped
-// index) so that no select / phi forces an early s_waitcnt; validity is applied when the
-// registers are published. The halo of tile t is the head of tile t+1, i.e. already in registers.
-template <typename Cfg> struct TileUnits { uint32_t eol; uint64_t st; bool ok; };
-
-template <typename Cfg>
-__device__ __forceinline__ void tile_units_load(const PackedInput &in, uint64_t tile, uint64_t n_tiles, TileUnits<Cfg> &u) {
-  u.ok = tile < n_tiles;
-  const uint64_t g = (u.ok ? tile : 0ull) * Cfg::NT + threadIdx.x;
-  u.eol = read_eol_unit<Cfg::C>(in.eol, g);
-  u.st = read_stream_unit<Cfg::BITS, Cfg::C>(in.stream, g);
-}
-
-// EOL status of the byte just before `tile` (true at the partition start)
-template <typename Cfg>
-__device__ __forceinline__ uint32_t tile_prev_eol(const PackedInput &in, uint64_t tile) {
-  if (tile == 0) return 1u;
-  return (read_eol_unit<Cfg::C>(in.eol, tile * Cfg::NT - 1) >> (Cfg::C - 1)) & 1u;
-}
-
-// publish tile `cur` (+ its halo = head of `nxt`) to LDS, one barrier inside; returns the line
-// starts of this thread's chunk. *s_prev carries the EOL status of the last byte of the previous tile.
-template <typename Cfg>
-__device__ __forceinline__ uint32_t tile_units_publish(const TileUnits<Cfg> &cur, const TileUnits<Cfg> &nxt, uint32_t *s_eol,
-                                                       uint32_t *s_stream, uint32_t *s_prev, uint32_t &eol_out) {
-  constexpr int C = Cfg::C;
-  constexpr int BITS = Cfg::BITS;
-  const int j = threadIdx.x;
-  const uint32_t eol = cur.ok ? cur.eol : Cfg::CMASK;
-  store_eol_bits<C>(s_eol, j, eol);
-  store_stream_bits<BITS, C>(s_stream, j, cur.st);
-  if (j < Cfg::HALO_CHUNKS) {
-    store_eol_bits<C>(s_eol, Cfg::NT + j, nxt.ok ? nxt.eol : Cfg::CMASK);
-    store_stream_bits<BITS, C>(s_stream, Cfg::NT + j, nxt.st);
-  }
-  lds_barrier();
-  bool prev_eol;
-  if (j > 0) {
-    const int pb = C * j - 1;
-    prev_eol = (s_eol[pb >> 5] >> (pb & 31)) & 1u;
-  } else {
-    prev_eol = *s_prev != 0;
-  }
-  eol_out = eol;
-  return line_starts(eol, prev_eol, Cfg::CMASK);
-}
-
-// valid k-mer starts of this thread's chunk
-template <typename Cfg>
-__device__ __forceinline__ uint32_t chunk_valid_mask(const uint32_t *s_eol, uint32_t ls, uint32_t lines_before, uint32_t k) {
-  uint64_t e[Cfg::NE];
-  load_eol_view<Cfg>(s_eol, threadIdx.x, e);
-  smear_right<Cfg::NE>(e, k);
-  return ~(uint32_t)e[0] & fastq_seq_role_mask(lines_before, ls, Cfg::CMASK);
-}
-
 // FASTA (compacted character space, s_eol holds the record-start bits): window r is valid iff no
 // record starts at r+1 .. r+k-1 and r + k <= n_chars
 template <typename Cfg>
@@ -308,22 +239,6 @@ __device__ __forceinline__ uint32_t tile_window_list_from(uint32_t valid, uint16
   }
   lds_barrier();
   return total;
-}
-
-// per-wavefront window list (no workgroup barrier): s_wpos points at this wave's 64*C slots;
-// returns the number of windows of the wave
-template <typename Cfg>
-__device__ __forceinline__ uint32_t wave_window_list(uint32_t valid, uint16_t *s_wpos) {
-  const uint32_t cnt = (uint32_t)__builtin_popcount(valid);
-  const uint32_t inc = wave_inclusive_scan(cnt);
-  uint32_t rank = inc - cnt;
-  const uint32_t base = threadIdx.x * Cfg::C;
-  while (valid) {
-    s_wpos[rank++] = (uint16_t)(base + (uint32_t)__builtin_ctz(valid));
-    valid &= valid - 1u;
-  }
-  __builtin_amdgcn_wave_barrier();   // the list is read by other lanes of this wave next
-  return __shfl(inc, kWave - 1, kWave);
 }
 
 // Compacted list of the tile's k-mer start positions (byte index inside the tile), in file

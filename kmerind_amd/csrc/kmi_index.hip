@@ -168,23 +168,6 @@ __global__ __launch_bounds__(kPartThreads) void hist_rank_kernel(const uint64_t 
   if (threadIdx.x < kNumCoarse) wg_hist[(uint64_t)blockIdx.x * kNumCoarse + threadIdx.x] = s_hist[threadIdx.x];
 }
 
-// wg_off[w][c] = base[c] + sum_{w' < w} wg_hist[w'][c] for c < ncols: one wavefront per column,
-// 64 groups per step, carried wave scan
-__device__ __forceinline__ void column_offsets(const uint32_t *__restrict__ wg_hist, uint32_t groups, uint32_t ncols,
-                                               const uint64_t *base /* LDS or global */, uint64_t *__restrict__ wg_off) {
-  const uint32_t nwaves = blockDim.x >> 6;
-  for (uint32_t c = wave_id(); c < ncols; c += nwaves) {
-    uint64_t carry = base[c];
-    for (uint32_t w0 = 0; w0 < groups; w0 += kWave) {
-      const uint32_t w = w0 + lane_id();
-      const uint64_t v = (w < groups) ? wg_hist[(uint64_t)w * kNumCoarse + c] : 0ull;
-      const uint64_t inc = wave_inclusive_scan(v);
-      if (w < groups) wg_off[(uint64_t)w * kNumCoarse + c] = carry + inc - v;
-      carry += __shfl(inc, kWave - 1, kWave);
-    }
-  }
-}
-
 // ---------------------------------------------------------------------------
 // offsets: fine_off = exclusive scan of fine_hist (u64, kNumFine+1 entries);
 //          wg_off[w][c] = fine_off[c*128] + sum_{w'<w} wg_hist[w'][c]
