@@ -370,6 +370,129 @@ __global__ __launch_bounds__(kPartThreads) void scatter_fine_kernel(const uint64
 }
 
 
+// P2 for one-word keys, whole-line form. The runs a tile-wise bucket sort emits start and end wherever the
+// cursors happen to stand, so every wave store begins and ends inside a 128-byte line, and such partial-line
+// writes cost 1.4-1.6x (tools/microbench6.hip). Here a sub-bucket only ever emits whole lines: after the one
+// unaligned head of its stream, what it has (carry + the tile's new keys) is cut at the last line boundary, the
+// tail of < 16 keys is carried into the next tile in registers (two keys per thread), and the copy-out walks
+// destination lines (16 lanes = one line), not stage slots. The stream ends with one partial line.
+constexpr int kLineKeys = 16;                                          // 128-byte line / 8-byte key
+constexpr int kP2Tile = PartCfg<1>::TILE - (kLineKeys - 1) * 128 - 128;   // new keys per tile: stage holds tile + carry (6144)
+static_assert(kSubPerCoarse == 128 && kP2Tile % kPartThreads == 0, "P2 whole-line geometry");
+__global__ __launch_bounds__(kPartThreads) void scatter_fine_lines_kernel(const uint64_t *__restrict__ in, uint64_t *__restrict__ out,
+                                                                         const uint64_t *__restrict__ fine_off,
+                                                                         const uint64_t *__restrict__ part_off,
+                                                                         const uint64_t *__restrict__ wg_off) {
+  constexpr int NB = kSubPerCoarse, T = kP2Tile, PT = T / kPartThreads, SCAP = PartCfg<1>::TILE;
+  constexpr int MAXG = SCAP / kLineKeys + NB;
+  __shared__ uint64_t s_stage[SCAP];
+  __shared__ uint64_t s_cur0[NB];      // cursor of the bucket before this tile's emission
+  __shared__ uint32_t s_cnt[NB];       // S0: carry + new keys of the tile, by LDS atomic
+  __shared__ uint32_t s_lofs[NB];      // first stage slot of the bucket
+  __shared__ uint32_t s_emit[NB];      // keys that leave this tile (up to the last line boundary)
+  __shared__ uint32_t s_old[NB];       // keys carried into this tile
+  __shared__ uint32_t s_rem[NB];       // keys carried out of this tile
+  __shared__ uint32_t s_lbase[NB];     // first destination-line group of the bucket
+  __shared__ uint32_t s_part[NB / kWave];
+  __shared__ uint32_t s_ng;
+  __shared__ uint8_t s_linebkt[MAXG];  // bucket of every destination-line group
+  const uint32_t c = blockIdx.x / kFineParts, h = blockIdx.x % kFineParts;
+  uint64_t cursor = (threadIdx.x < NB) ? part_off[(uint64_t)h * kNumFine + c * NB + threadIdx.x] : 0ull;
+  const uint64_t begin = wg_off[(uint64_t)(h * kGroupsPerPart) * kNumCoarse + c];
+  const uint64_t end = (h + 1 < (uint32_t)kFineParts) ? wg_off[(uint64_t)((h + 1) * kGroupsPerPart) * kNumCoarse + c] : fine_off[(c + 1) * NB];
+  if (begin >= end) return;
+  if (threadIdx.x < NB) { s_cnt[threadIdx.x] = 0; s_rem[threadIdx.x] = 0; s_emit[threadIdx.x] = 0; s_cur0[threadIdx.x] = cursor; }
+  // carry: thread t keeps slots 2*(t&7), 2*(t&7)+1 of bucket t>>3
+  const uint32_t cb = threadIdx.x >> 3, cj = (threadIdx.x & 7u) * 2u;
+  uint64_t carry0 = 0, carry1 = 0;
+  uint32_t my_carry = 0;   // thread b < NB: keys it carries
+  lds_barrier();
+  uint64_t raw[PT];
+  auto load_tile = [&](uint64_t t0) {   // unconditional (clamped) loads: nothing forces an early wait
+#pragma unroll
+    for (int j = 0; j < PT; ++j) {
+      uint64_t i = t0 + (uint64_t)j * kPartThreads + threadIdx.x;
+      i = (i < end) ? i : end - 1;
+      raw[j] = in[i];
+    }
+  };
+  load_tile(begin);
+  for (uint64_t t0 = begin; t0 < end; t0 += T) {
+    const uint32_t nt = (uint32_t)((end - t0 < (uint64_t)T) ? (end - t0) : (uint64_t)T);
+    uint64_t k[PT];
+    uint32_t bkrk[PT];
+#pragma unroll
+    for (int j = 0; j < PT; ++j) {
+      const uint32_t li = j * kPartThreads + threadIdx.x;
+      k[j] = raw[j];
+      bkrk[j] = 0xffffffffu;
+      if (li < nt) {
+        const uint64_t kk[1] = {k[j]};
+        const uint32_t b = fine_of(place_hash<1>(kk)) & (NB - 1);
+        bkrk[j] = (b << 16) | atomicAdd(&s_cnt[b], 1u);   // rank behind the carried keys: s_cnt starts at the carry count
+      }
+    }
+    if (t0 + T < end) load_tile(t0 + T);   // in flight until the next iteration needs it
+    lds_barrier();
+    uint32_t cnt = 0, emit = 0, ng = 0, inc = 0;
+    if (threadIdx.x < NB) {   // waves 0..1, whole waves
+      cnt = s_cnt[threadIdx.x];
+      const uint64_t aend = (cursor + cnt) & ~(uint64_t)(kLineKeys - 1);
+      emit = aend > cursor ? (uint32_t)(aend - cursor) : 0u;
+      ng = emit ? (uint32_t)((aend - (cursor & ~(uint64_t)(kLineKeys - 1))) / kLineKeys) : 0u;
+      inc = wave_inclusive_scan(cnt | (ng << 16));
+      if (lane_id() == kWave - 1) s_part[wave_id()] = inc;
+    }
+    lds_barrier();
+    if (threadIdx.x < NB) {
+      uint32_t pre = 0;
+#pragma unroll
+      for (uint32_t w = 0; w < NB / kWave; ++w) pre += (w < wave_id()) ? s_part[w] : 0u;
+      const uint32_t ex = pre + inc - (cnt | (ng << 16));
+      const uint32_t lo = ex & 0xffffu, lb = ex >> 16;
+      s_lofs[threadIdx.x] = lo; s_emit[threadIdx.x] = emit; s_old[threadIdx.x] = my_carry; s_cur0[threadIdx.x] = cursor;
+      s_lbase[threadIdx.x] = lb; s_rem[threadIdx.x] = cnt - emit;
+      for (uint32_t i = 0; i < ng; ++i) s_linebkt[lb + i] = (uint8_t)threadIdx.x;
+      if (threadIdx.x == NB - 1) s_ng = lb + ng;
+      s_cnt[threadIdx.x] = cnt - emit;   // the next tile ranks behind these
+      cursor += emit; my_carry = cnt - emit;
+    }
+    lds_barrier();
+    // stage: carried keys first, then the tile's keys, per bucket
+    {
+      const uint32_t oc = s_old[cb], lo = s_lofs[cb];
+      if (cj < oc) s_stage[lo + cj] = carry0;
+      if (cj + 1u < oc) s_stage[lo + cj + 1u] = carry1;
+    }
+#pragma unroll
+    for (int j = 0; j < PT; ++j)
+      if (bkrk[j] != 0xffffffffu) s_stage[s_lofs[bkrk[j] >> 16] + (bkrk[j] & 0xffffu)] = k[j];
+    lds_barrier();
+    // copy-out by destination line: 16 lanes = one 128-byte line of one bucket
+    {
+      const uint32_t groups = s_ng, l16 = threadIdx.x & (kLineKeys - 1);
+      for (uint32_t g = threadIdx.x >> 4; g < groups; g += kPartThreads / kLineKeys) {
+        const uint32_t b = s_linebkt[g];
+        const uint64_t cur0 = s_cur0[b];
+        const uint64_t dpos = (cur0 & ~(uint64_t)(kLineKeys - 1)) + (uint64_t)(g - s_lbase[b]) * kLineKeys + l16;
+        if (dpos >= cur0 && dpos < cur0 + s_emit[b]) out[dpos] = s_stage[s_lofs[b] + (uint32_t)(dpos - cur0)];
+      }
+      // what stays behind the last line boundary travels on in registers
+      const uint32_t rem = s_rem[cb], base = s_lofs[cb] + s_emit[cb];
+      if (cj < rem) carry0 = s_stage[base + cj];
+      if (cj + 1u < rem) carry1 = s_stage[base + cj + 1u];
+    }
+    lds_barrier();   // the next tile rewrites the stage and the per-bucket tables
+  }
+  // the streams end with one partial line each
+  {
+    const uint32_t rem = s_rem[cb];
+    const uint64_t fc = s_cur0[cb] + s_emit[cb];
+    if (cj < rem) out[fc + cj] = carry0;
+    if (cj + 1u < rem) out[fc + cj + 1u] = carry1;
+  }
+}
+
 // ---------------------------------------------------------------------------
 // Fused build (Index::build_* on one rank): the k-mers are generated from the FASTQ tiles
 // inside the histogram pass (E1) and again inside the coarse scatter pass (E2), so the
@@ -1493,8 +1616,12 @@ static kmi_status partition_impl(kmi_ctx *ctx, const kmi_config *cfg, KShape sha
   }
   {
     ProfScope ps(ctx, "scatter_fine", n);
-    hipLaunchKernelGGL((scatter_fine_kernel<NW, BITS, VW>), dim3(kNumCoarse * kFineParts), dim3(kPartThreads), 0, ctx->stream, w.buf_a, w.buf_b, shape,
-                       (const uint64_t *)w.fine_off, (const uint64_t *)w.part_off, (const uint64_t *)w.wg_off);
+    if (NW == 1 && VW == 0)
+      hipLaunchKernelGGL(scatter_fine_lines_kernel, dim3(kNumCoarse * kFineParts), dim3(kPartThreads), 0, ctx->stream, (const uint64_t *)w.buf_a,
+                         w.buf_b, (const uint64_t *)w.fine_off, (const uint64_t *)w.part_off, (const uint64_t *)w.wg_off);
+    else
+      hipLaunchKernelGGL((scatter_fine_kernel<NW, BITS, VW>), dim3(kNumCoarse * kFineParts), dim3(kPartThreads), 0, ctx->stream, w.buf_a, w.buf_b,
+                         shape, (const uint64_t *)w.fine_off, (const uint64_t *)w.part_off, (const uint64_t *)w.wg_off);
   }
   KMI_HIP(ctx, hipGetLastError());
   out->keys = w.buf_b; out->fine_off = w.fine_off;
@@ -1625,8 +1752,12 @@ static kmi_status build_fused_impl(kmi_index *idx, const uint8_t *bytes_dev, siz
   }
   {
     ProfScope ps(ctx, "scatter_fine", n);
-    hipLaunchKernelGGL((scatter_fine_kernel<NW, BITS>), dim3(kNumCoarse * kFineParts), dim3(kPartThreads), 0, ctx->stream, w.buf_a, w.buf_b,
-                       idx->shape, (const uint64_t *)w.fine_off, (const uint64_t *)w.part_off, (const uint64_t *)w.wg_off);
+    if (NW == 1)
+      hipLaunchKernelGGL(scatter_fine_lines_kernel, dim3(kNumCoarse * kFineParts), dim3(kPartThreads), 0, ctx->stream, (const uint64_t *)w.buf_a,
+                         w.buf_b, (const uint64_t *)w.fine_off, (const uint64_t *)w.part_off, (const uint64_t *)w.wg_off);
+    else
+      hipLaunchKernelGGL((scatter_fine_kernel<NW, BITS>), dim3(kNumCoarse * kFineParts), dim3(kPartThreads), 0, ctx->stream, w.buf_a, w.buf_b,
+                         idx->shape, (const uint64_t *)w.fine_off, (const uint64_t *)w.part_off, (const uint64_t *)w.wg_off);
   }
   KMI_HIP(ctx, hipGetLastError());
   Partitioned part; part.keys = w.buf_b; part.fine_off = w.fine_off;
