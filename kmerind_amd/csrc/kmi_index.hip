@@ -43,7 +43,8 @@ constexpr int kSlotBits = 32 - kFineBits;    // low 17 bits pick the LDS slot
 constexpr int kPartThreads = 1024;           // K1/K2/P2 workgroup size
 constexpr int kPartGroups = 512;             // K1/K2 workgroups (two per CU)
 constexpr int kFineParts = 2;                // P2 workgroups per coarse bucket; part h = K2 groups [h*256, (h+1)*256)
-constexpr int kGroupsPerPart = kPartGroups / kFineParts;
+// workgroups of the list-driven histogram and scatter passes (they own the same tiles)
+template <int NW> constexpr int fused_groups() { return kPartGroups; }
 constexpr int kListGroups = 2048;            // workgroups of the window-list pass (small LDS footprint: eight per CU)
 constexpr int kLoadBatch = 8;                // independent key loads kept in flight per thread
 
@@ -136,7 +137,7 @@ __global__ __launch_bounds__(kPartThreads) void hist_fine_kernel(const uint64_t 
     }
   }
   lds_barrier();
-  uint32_t *part_hist = fine_hist + (uint64_t)(blockIdx.x / kGroupsPerPart) * kNumFine;
+  uint32_t *part_hist = fine_hist + (uint64_t)(blockIdx.x / (gridDim.x / kFineParts)) * kNumFine;
   for (int i = threadIdx.x; i < kNumFine; i += kPartThreads) {
     uint32_t v = s_hist[i];
     if (v) atomicAdd(&part_hist[i], v);
@@ -359,12 +360,13 @@ __global__ __launch_bounds__(kPartThreads) void scatter_chunks_kernel(const uint
 template <int NW, int BITS, int VW = 0>
 __global__ __launch_bounds__(kPartThreads) void scatter_fine_kernel(const uint64_t *__restrict__ in, uint64_t *__restrict__ out, KShape shape,
                                                                    const uint64_t *__restrict__ fine_off, const uint64_t *__restrict__ part_off,
-                                                                   const uint64_t *__restrict__ wg_off) {
+                                                                   const uint64_t *__restrict__ wg_off, uint32_t groups) {
   KMI_SCATTER_LDS(NW + VW)
+  const uint32_t gpp = groups / kFineParts;   // K2 / E2 workgroups per part
   const uint32_t c = blockIdx.x / kFineParts, h = blockIdx.x % kFineParts;
   const uint64_t cursor = (threadIdx.x < kSubPerCoarse) ? part_off[(uint64_t)h * kNumFine + c * kSubPerCoarse + threadIdx.x] : 0ull;
-  const uint64_t b = wg_off[(uint64_t)(h * kGroupsPerPart) * kNumCoarse + c];
-  const uint64_t e = (h + 1 < (uint32_t)kFineParts) ? wg_off[(uint64_t)((h + 1) * kGroupsPerPart) * kNumCoarse + c] : fine_off[(c + 1) * kSubPerCoarse];
+  const uint64_t b = wg_off[(uint64_t)(h * gpp) * kNumCoarse + c];
+  const uint64_t e = (h + 1 < (uint32_t)kFineParts) ? wg_off[(uint64_t)((h + 1) * gpp) * kNumCoarse + c] : fine_off[(c + 1) * kSubPerCoarse];
   BucketFn fn; fn.mode = BUCKET_SUB; fn.shape = shape; fn.dist_hash = 0; fn.farm_ndebug = false; fn.nranks = 1; fn.sub = 1;
   if (b < e) scatter_range<NW, BITS, VW>(in, b, e, out, shape, 0u, false, fn, cursor, s_stage, s_bkt, s_cnt, s_lofs, s_gbase, s_part);
 }
@@ -382,7 +384,8 @@ static_assert(kSubPerCoarse == 128 && kP2Tile % kPartThreads == 0, "P2 whole-lin
 __global__ __launch_bounds__(kPartThreads) void scatter_fine_lines_kernel(const uint64_t *__restrict__ in, uint64_t *__restrict__ out,
                                                                          const uint64_t *__restrict__ fine_off,
                                                                          const uint64_t *__restrict__ part_off,
-                                                                         const uint64_t *__restrict__ wg_off) {
+                                                                         const uint64_t *__restrict__ wg_off, uint32_t groups) {
+  const uint32_t gpp = groups / kFineParts;   // K2 / E2 workgroups per part
   constexpr int NB = kSubPerCoarse, T = kP2Tile, PT = T / kPartThreads, SCAP = PartCfg<1>::TILE;
   constexpr int MAXG = SCAP / kLineKeys + NB;
   __shared__ uint64_t s_stage[SCAP];
@@ -398,8 +401,8 @@ __global__ __launch_bounds__(kPartThreads) void scatter_fine_lines_kernel(const 
   __shared__ uint8_t s_linebkt[MAXG];  // bucket of every destination-line group
   const uint32_t c = blockIdx.x / kFineParts, h = blockIdx.x % kFineParts;
   uint64_t cursor = (threadIdx.x < NB) ? part_off[(uint64_t)h * kNumFine + c * NB + threadIdx.x] : 0ull;
-  const uint64_t begin = wg_off[(uint64_t)(h * kGroupsPerPart) * kNumCoarse + c];
-  const uint64_t end = (h + 1 < (uint32_t)kFineParts) ? wg_off[(uint64_t)((h + 1) * kGroupsPerPart) * kNumCoarse + c] : fine_off[(c + 1) * NB];
+  const uint64_t begin = wg_off[(uint64_t)(h * gpp) * kNumCoarse + c];
+  const uint64_t end = (h + 1 < (uint32_t)kFineParts) ? wg_off[(uint64_t)((h + 1) * gpp) * kNumCoarse + c] : fine_off[(c + 1) * NB];
   if (begin >= end) return;
   if (threadIdx.x < NB) { s_cnt[threadIdx.x] = 0; s_rem[threadIdx.x] = 0; s_emit[threadIdx.x] = 0; s_cur0[threadIdx.x] = cursor; }
   // carry: thread t keeps slots 2*(t&7), 2*(t&7)+1 of bucket t>>3
@@ -812,7 +815,7 @@ __global__ __launch_bounds__(kHistThreads) void fastq_hist_list_kernel(PackedInp
     lds_barrier();
     buf ^= 1;
   }
-  uint32_t *part_hist = fine_hist + (uint64_t)(blockIdx.x / kGroupsPerPart) * kNumFine;
+  uint32_t *part_hist = fine_hist + (uint64_t)(blockIdx.x / (gridDim.x / kFineParts)) * kNumFine;
   for (int i = threadIdx.x; i < kNumFine; i += NT) {
     uint32_t v = s_hist[i];
     if (v) atomicAdd(&part_hist[i], v);
@@ -826,14 +829,14 @@ __global__ __launch_bounds__(kHistThreads) void fastq_hist_list_kernel(PackedInp
 
 // Rank counts from the window list (the counting half of imxx::distribute fused with read_file): per-workgroup counts
 // of the rank buckets, same tile ownership as the scatter that follows.
-template <int NW, int BITS>
-__global__ __launch_bounds__(512) void fastq_rank_hist_list_kernel(PackedInput in, uint64_t n_tiles, KShape shape, bool canonical,
+template <int NW, int BITS, int TPB>
+__global__ __launch_bounds__(TPB) void fastq_rank_hist_list_kernel(PackedInput in, uint64_t n_tiles, KShape shape, bool canonical,
                                                                   const uint64_t *__restrict__ tile_off, const uint16_t *__restrict__ win_pos,
                                                                   BucketFn fn, uint32_t *__restrict__ wg_hist,
                                                                   uint32_t *__restrict__ win_pb /* position | bucket << 16 */) {
   using Cfg = ExCfg<NW, BITS>;
   using L = ListCfg<NW, BITS>;
-  constexpr int NT = 512, RMAX = L::RMAX;
+  constexpr int NT = TPB, RMAX = L::RMAX;
   constexpr int UL = (L::UNITS + NT - 1) / NT;
   constexpr int PB = 8;
   __shared__ uint32_t s_hist[kNumCoarse];
@@ -1618,10 +1621,10 @@ static kmi_status partition_impl(kmi_ctx *ctx, const kmi_config *cfg, KShape sha
     ProfScope ps(ctx, "scatter_fine", n);
     if (NW == 1 && VW == 0)
       hipLaunchKernelGGL(scatter_fine_lines_kernel, dim3(kNumCoarse * kFineParts), dim3(kPartThreads), 0, ctx->stream, (const uint64_t *)w.buf_a,
-                         w.buf_b, (const uint64_t *)w.fine_off, (const uint64_t *)w.part_off, (const uint64_t *)w.wg_off);
+                         w.buf_b, (const uint64_t *)w.fine_off, (const uint64_t *)w.part_off, (const uint64_t *)w.wg_off, (uint32_t)kPartGroups);
     else
       hipLaunchKernelGGL((scatter_fine_kernel<NW, BITS, VW>), dim3(kNumCoarse * kFineParts), dim3(kPartThreads), 0, ctx->stream, w.buf_a, w.buf_b,
-                         shape, (const uint64_t *)w.fine_off, (const uint64_t *)w.part_off, (const uint64_t *)w.wg_off);
+                         shape, (const uint64_t *)w.fine_off, (const uint64_t *)w.part_off, (const uint64_t *)w.wg_off, (uint32_t)kPartGroups);
   }
   KMI_HIP(ctx, hipGetLastError());
   out->keys = w.buf_b; out->fine_off = w.fine_off;
@@ -1735,29 +1738,31 @@ static kmi_status build_fused_impl(kmi_index *idx, const uint8_t *bytes_dev, siz
   }
   {
     ProfScope ps(ctx, "fastq_hist", n);
-    hipLaunchKernelGGL((fastq_hist_list_kernel<NW, BITS>), dim3(kPartGroups), dim3(kHistThreads), 0, ctx->stream, in, n_tiles, idx->shape,
+    hipLaunchKernelGGL((fastq_hist_list_kernel<NW, BITS>), dim3(fused_groups<NW>()), dim3(kHistThreads), 0, ctx->stream, in, n_tiles, idx->shape,
                        canonical, sc.tile_off, (const uint16_t *)win_pos, w.fine_hist, w.wg_hist);
   }
   {
     ProfScope ps(ctx, "fine_offsets", kNumFine);
-    hipLaunchKernelGGL(fine_offsets_kernel, dim3(1), dim3(1024), 0, ctx->stream, w.fine_hist, w.wg_hist, (uint32_t)kPartGroups, w.fine_off,
+    hipLaunchKernelGGL(fine_offsets_kernel, dim3(1), dim3(1024), 0, ctx->stream, w.fine_hist, w.wg_hist, (uint32_t)fused_groups<NW>(), w.fine_off,
                        w.part_off, w.coarse_base);
-    hipLaunchKernelGGL(coarse_cursors_kernel, dim3(kNumCoarse / 4), dim3(256), 0, ctx->stream, (const uint32_t *)w.wg_hist, (uint32_t)kPartGroups,
+    hipLaunchKernelGGL(coarse_cursors_kernel, dim3(kNumCoarse / 4), dim3(256), 0, ctx->stream, (const uint32_t *)w.wg_hist, (uint32_t)fused_groups<NW>(),
                        (const uint64_t *)w.coarse_base, w.wg_off);
   }
   {
     ProfScope ps(ctx, "fastq_scatter", n);
-    hipLaunchKernelGGL((fastq_scatter_list_kernel<NW, BITS>), dim3(kPartGroups), dim3(ExCfg<NW, BITS>::NT), 0, ctx->stream, in,
+    hipLaunchKernelGGL((fastq_scatter_list_kernel<NW, BITS>), dim3(fused_groups<NW>()), dim3(ExCfg<NW, BITS>::NT), 0, ctx->stream, in,
                        n_tiles, idx->shape, canonical, sc.tile_off, (const uint16_t *)win_pos, (const uint64_t *)w.wg_off, w.buf_a);
   }
   {
     ProfScope ps(ctx, "scatter_fine", n);
     if (NW == 1)
       hipLaunchKernelGGL(scatter_fine_lines_kernel, dim3(kNumCoarse * kFineParts), dim3(kPartThreads), 0, ctx->stream, (const uint64_t *)w.buf_a,
-                         w.buf_b, (const uint64_t *)w.fine_off, (const uint64_t *)w.part_off, (const uint64_t *)w.wg_off);
+                         w.buf_b, (const uint64_t *)w.fine_off, (const uint64_t *)w.part_off, (const uint64_t *)w.wg_off,
+                         (uint32_t)fused_groups<NW>());
     else
       hipLaunchKernelGGL((scatter_fine_kernel<NW, BITS>), dim3(kNumCoarse * kFineParts), dim3(kPartThreads), 0, ctx->stream, w.buf_a, w.buf_b,
-                         idx->shape, (const uint64_t *)w.fine_off, (const uint64_t *)w.part_off, (const uint64_t *)w.wg_off);
+                         idx->shape, (const uint64_t *)w.fine_off, (const uint64_t *)w.part_off, (const uint64_t *)w.wg_off,
+                         (uint32_t)fused_groups<NW>());
   }
   KMI_HIP(ctx, hipGetLastError());
   Partitioned part; part.keys = w.buf_b; part.fine_off = w.fine_off;
@@ -2005,16 +2010,16 @@ static kmi_status extract_route_impl(kmi_ctx *ctx, const kmi_config *cfg, KShape
   }
   {
     ProfScope ps(ctx, "fastq_rank_hist", n);
-    hipLaunchKernelGGL((fastq_rank_hist_list_kernel<NW, BITS>), dim3(kPartGroups), dim3(512), 0, ctx->stream, in, n_tiles, shape, canonical,
+    hipLaunchKernelGGL((fastq_rank_hist_list_kernel<NW, BITS, 512>), dim3(fused_groups<NW>()), dim3(512), 0, ctx->stream, in, n_tiles, shape, canonical,
                        sc.tile_off, (const uint16_t *)win_pos, fn, wg_hist, win_pb);
   }
   {
     ProfScope ps(ctx, "rank_offsets", nb);
-    launch_rank_offsets(ctx->stream, (const uint32_t *)wg_hist, (uint32_t)kPartGroups, nb, cnt, cnt + kNumCoarse, wg_off);
+    launch_rank_offsets(ctx->stream, (const uint32_t *)wg_hist, (uint32_t)fused_groups<NW>(), nb, cnt, cnt + kNumCoarse, wg_off);
   }
   {
     ProfScope ps(ctx, "fastq_rank_scatter", n);
-    hipLaunchKernelGGL((fastq_scatter_list_kernel<NW, BITS, true>), dim3(kPartGroups), dim3(ExCfg<NW, BITS>::NT), 0, ctx->stream, in, n_tiles,
+    hipLaunchKernelGGL((fastq_scatter_list_kernel<NW, BITS, true>), dim3(fused_groups<NW>()), dim3(ExCfg<NW, BITS>::NT), 0, ctx->stream, in, n_tiles,
                        shape, canonical, sc.tile_off, (const uint32_t *)win_pb, (const uint64_t *)wg_off, out_keys_dev);
   }
   KMI_HIP(ctx, hipGetLastError());
