@@ -372,22 +372,30 @@ __global__ __launch_bounds__(kPartThreads) void scatter_fine_kernel(const uint64
 }
 
 
-// P2 for one-word keys, whole-line form. The runs a tile-wise bucket sort emits start and end wherever the
+// P2 for one-word keys, whole-line form (written over the bucket count NB; with NB = 256, i.e. for K2 / E2, the carry
+// takes half the stage and the form measured no faster than the plain one, so only P2 uses it). The runs a tile-wise bucket sort emits start and end wherever the
 // cursors happen to stand, so every wave store begins and ends inside a 128-byte line, and such partial-line
-// writes cost 1.4-1.6x (tools/microbench6.hip). Here a sub-bucket only ever emits whole lines: after the one
+// writes cost 1.4-1.6x (tools/microbench6.hip). Here a bucket only ever emits whole lines: after the one
 // unaligned head of its stream, what it has (carry + the tile's new keys) is cut at the last line boundary, the
-// tail of < 16 keys is carried into the next tile in registers (two keys per thread), and the copy-out walks
-// destination lines (16 lanes = one line), not stage slots. The stream ends with one partial line.
+// tail of < 16 keys is carried into the next tile in registers (16 slots per bucket spread over the threads), and
+// the copy-out walks destination lines (16 lanes = one line), not stage slots. The stream ends with one partial line.
 constexpr int kLineKeys = 16;                                          // 128-byte line / 8-byte key
-constexpr int kP2Tile = PartCfg<1>::TILE - (kLineKeys - 1) * 128 - 128;   // new keys per tile: stage holds tile + carry (6144)
-static_assert(kSubPerCoarse == 128 && kP2Tile % kPartThreads == 0, "P2 whole-line geometry");
-__global__ __launch_bounds__(kPartThreads) void scatter_fine_lines_kernel(const uint64_t *__restrict__ in, uint64_t *__restrict__ out,
-                                                                         const uint64_t *__restrict__ fine_off,
-                                                                         const uint64_t *__restrict__ part_off,
-                                                                         const uint64_t *__restrict__ wg_off, uint32_t groups) {
-  const uint32_t gpp = groups / kFineParts;   // K2 / E2 workgroups per part
-  constexpr int NB = kSubPerCoarse, T = kP2Tile, PT = T / kPartThreads, SCAP = PartCfg<1>::TILE;
-  constexpr int MAXG = SCAP / kLineKeys + NB;
+template <int NB> struct LinesCfg {
+  static constexpr int SCAP = PartCfg<1>::TILE;                                      // stage slots: tile + carry
+  static constexpr int T = (SCAP - (kLineKeys - 1) * NB) / kPartThreads * kPartThreads;   // new keys per tile (6144 / 4096)
+  static constexpr int PT = T / kPartThreads;
+  static constexpr int MAXG = SCAP / kLineKeys + NB;
+  static constexpr int TPBK = kPartThreads / NB;                                     // threads per bucket for the carry
+  static constexpr int CPT = kLineKeys / TPBK;                                       // carry slots per thread (2 / 4)
+  static_assert(kPartThreads % NB == 0 && kLineKeys % TPBK == 0 && T > 0 && NB <= 256, "whole-line geometry");
+};
+
+// keyfn(raw key) -> key to store; bktfn(key) -> bucket in [0, NB)
+template <int NB, typename KeyFn, typename BktFn>
+__device__ __forceinline__ void scatter_lines_range(const uint64_t *__restrict__ in, uint64_t begin, uint64_t end, uint64_t *__restrict__ out,
+                                                    uint64_t cursor /* of bucket threadIdx.x, threads < NB */, KeyFn keyfn, BktFn bktfn) {
+  using LC = LinesCfg<NB>;
+  constexpr int T = LC::T, PT = LC::PT, SCAP = LC::SCAP, MAXG = LC::MAXG, TPBK = LC::TPBK, CPT = LC::CPT;
   __shared__ uint64_t s_stage[SCAP];
   __shared__ uint64_t s_cur0[NB];      // cursor of the bucket before this tile's emission
   __shared__ uint32_t s_cnt[NB];       // S0: carry + new keys of the tile, by LDS atomic
@@ -399,15 +407,12 @@ __global__ __launch_bounds__(kPartThreads) void scatter_fine_lines_kernel(const 
   __shared__ uint32_t s_part[NB / kWave];
   __shared__ uint32_t s_ng;
   __shared__ uint8_t s_linebkt[MAXG];  // bucket of every destination-line group
-  const uint32_t c = blockIdx.x / kFineParts, h = blockIdx.x % kFineParts;
-  uint64_t cursor = (threadIdx.x < NB) ? part_off[(uint64_t)h * kNumFine + c * NB + threadIdx.x] : 0ull;
-  const uint64_t begin = wg_off[(uint64_t)(h * gpp) * kNumCoarse + c];
-  const uint64_t end = (h + 1 < (uint32_t)kFineParts) ? wg_off[(uint64_t)((h + 1) * gpp) * kNumCoarse + c] : fine_off[(c + 1) * NB];
   if (begin >= end) return;
   if (threadIdx.x < NB) { s_cnt[threadIdx.x] = 0; s_rem[threadIdx.x] = 0; s_emit[threadIdx.x] = 0; s_cur0[threadIdx.x] = cursor; }
-  // carry: thread t keeps slots 2*(t&7), 2*(t&7)+1 of bucket t>>3
-  const uint32_t cb = threadIdx.x >> 3, cj = (threadIdx.x & 7u) * 2u;
-  uint64_t carry0 = 0, carry1 = 0;
+  const uint32_t cb = threadIdx.x / TPBK, cj = (threadIdx.x % TPBK) * CPT;   // carry: slots cj .. cj+CPT-1 of bucket cb
+  uint64_t carry[CPT];
+#pragma unroll
+  for (int i = 0; i < CPT; ++i) carry[i] = 0;
   uint32_t my_carry = 0;   // thread b < NB: keys it carries
   lds_barrier();
   uint64_t raw[PT];
@@ -427,18 +432,17 @@ __global__ __launch_bounds__(kPartThreads) void scatter_fine_lines_kernel(const 
 #pragma unroll
     for (int j = 0; j < PT; ++j) {
       const uint32_t li = j * kPartThreads + threadIdx.x;
-      k[j] = raw[j];
       bkrk[j] = 0xffffffffu;
+      k[j] = keyfn(raw[j]);
       if (li < nt) {
-        const uint64_t kk[1] = {k[j]};
-        const uint32_t b = fine_of(place_hash<1>(kk)) & (NB - 1);
+        const uint32_t b = bktfn(k[j]);
         bkrk[j] = (b << 16) | atomicAdd(&s_cnt[b], 1u);   // rank behind the carried keys: s_cnt starts at the carry count
       }
     }
     if (t0 + T < end) load_tile(t0 + T);   // in flight until the next iteration needs it
     lds_barrier();
     uint32_t cnt = 0, emit = 0, ng = 0, inc = 0;
-    if (threadIdx.x < NB) {   // waves 0..1, whole waves
+    if (threadIdx.x < NB) {   // whole waves
       cnt = s_cnt[threadIdx.x];
       const uint64_t aend = (cursor + cnt) & ~(uint64_t)(kLineKeys - 1);
       emit = aend > cursor ? (uint32_t)(aend - cursor) : 0u;
@@ -464,8 +468,8 @@ __global__ __launch_bounds__(kPartThreads) void scatter_fine_lines_kernel(const 
     // stage: carried keys first, then the tile's keys, per bucket
     {
       const uint32_t oc = s_old[cb], lo = s_lofs[cb];
-      if (cj < oc) s_stage[lo + cj] = carry0;
-      if (cj + 1u < oc) s_stage[lo + cj + 1u] = carry1;
+#pragma unroll
+      for (int i = 0; i < CPT; ++i) if (cj + i < oc) s_stage[lo + cj + i] = carry[i];
     }
 #pragma unroll
     for (int j = 0; j < PT; ++j)
@@ -482,8 +486,8 @@ __global__ __launch_bounds__(kPartThreads) void scatter_fine_lines_kernel(const 
       }
       // what stays behind the last line boundary travels on in registers
       const uint32_t rem = s_rem[cb], base = s_lofs[cb] + s_emit[cb];
-      if (cj < rem) carry0 = s_stage[base + cj];
-      if (cj + 1u < rem) carry1 = s_stage[base + cj + 1u];
+#pragma unroll
+      for (int i = 0; i < CPT; ++i) if (cj + i < rem) carry[i] = s_stage[base + cj + i];
     }
     lds_barrier();   // the next tile rewrites the stage and the per-bucket tables
   }
@@ -491,9 +495,24 @@ __global__ __launch_bounds__(kPartThreads) void scatter_fine_lines_kernel(const 
   {
     const uint32_t rem = s_rem[cb];
     const uint64_t fc = s_cur0[cb] + s_emit[cb];
-    if (cj < rem) out[fc + cj] = carry0;
-    if (cj + 1u < rem) out[fc + cj + 1u] = carry1;
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) if (cj + i < rem) out[fc + cj + i] = carry[i];
   }
+}
+
+// P2, one-word keys: workgroup (c, h) splits its part of coarse bucket c into the 128 sub-buckets
+__global__ __launch_bounds__(kPartThreads) void scatter_fine_lines_kernel(const uint64_t *__restrict__ in, uint64_t *__restrict__ out,
+                                                                         const uint64_t *__restrict__ fine_off,
+                                                                         const uint64_t *__restrict__ part_off,
+                                                                         const uint64_t *__restrict__ wg_off, uint32_t groups) {
+  constexpr int NB = kSubPerCoarse;
+  const uint32_t gpp = groups / kFineParts;   // K2 / E2 workgroups per part
+  const uint32_t c = blockIdx.x / kFineParts, h = blockIdx.x % kFineParts;
+  const uint64_t cursor = (threadIdx.x < NB) ? part_off[(uint64_t)h * kNumFine + c * NB + threadIdx.x] : 0ull;
+  const uint64_t begin = wg_off[(uint64_t)(h * gpp) * kNumCoarse + c];
+  const uint64_t end = (h + 1 < (uint32_t)kFineParts) ? wg_off[(uint64_t)((h + 1) * gpp) * kNumCoarse + c] : fine_off[(c + 1) * NB];
+  scatter_lines_range<NB>(in, begin, end, out, cursor, [](uint64_t r) { return r; },
+                          [](uint64_t k) { const uint64_t kk[1] = {k}; return fine_of(place_hash<1>(kk)) & (uint32_t)(NB - 1); });
 }
 
 // ---------------------------------------------------------------------------
