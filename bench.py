@@ -51,6 +51,8 @@ def main():
     ap.add_argument("--cpu-sample-reads", type=int, default=500_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the extract-only / insert-only / query rates (outside the timed steps)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="run the N > 1 code path (routing + all_to_all_single + insert) even with one rank: exercises the RCCL calls on one GPU")
     ap.add_argument("--chunks", type=int, default=4, help="N > 1: chunks per step (exchange of one overlaps parsing of the next)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = rehearsal of the N>1 flow with ranks sharing one GPU (exchange staged through the host)")
@@ -73,7 +75,8 @@ def main():
         local_rank = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    multi = world > 1 or args.force_dist
+    if multi:
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -83,7 +86,7 @@ def main():
     kmers_per_read = read_len - k + 1
     n_reads = args.reads
     genome_len = args.genome * world
-    seed = 2 if world == 1 else 3
+    seed = 2 if not multi else 3
 
     stream = torch.cuda.current_stream(dev)
     ctx = K.Context(device=local_rank, rank=rank, nranks=world, stream=stream.cuda_stream)
@@ -95,12 +98,16 @@ def main():
     idx = K.CountIndex(ctx, cfg)
     n_kmers = n_reads * kmers_per_read
 
-    if world > 1:
+    if multi:
         # N > 1: the batch goes through in NCH record-aligned chunks. Chunk c is parsed and grouped by destination rank
         # on the device (kmi_extract_route_dev: read_file + the bucketing half of imxx::distribute, fused) while the
         # all-to-all of chunk c-1 is still travelling over xGMI on RCCL's stream; every rank then inserts what it
         # received in one go. Send buffers are double-buffered, the receive buffer takes the chunks back to back.
-        nch = max(1, min(args.chunks, n_reads))
+        # this RCCL build corrupts a peer message above 2^27 eight-byte elements (1 GiB; measured with a self send,
+        # tools/a2a_debug.py), so the chunk count also keeps every per-peer message below that with 10 % headroom
+        MSG_MAX = 1 << 27
+        need = -(-int(n_kmers * 1.1) // (world * MSG_MAX))
+        nch = max(1, min(max(args.chunks, need), n_reads))
         rec_bytes = nbytes // n_reads                      # synthetic records have one size (315 bytes)
         # chunk starts stay 16-byte aligned (the byte kernels load 16 bytes per lane): whole multiples of 16 records
         bounds = [((n_reads * c // nch) // 16 * 16) * rec_bytes for c in range(nch)] + [nbytes]
@@ -114,7 +121,7 @@ def main():
 
     def step():
         idx.clear()
-        if world == 1:
+        if not multi:
             idx.build_device(d_bytes.data_ptr(), nbytes)
             return
         pos, works = 0, []
@@ -130,6 +137,8 @@ def main():
             n_in = int(sum(rc))
             if pos + n_in > recv_cap:
                 raise SystemExit("receive buffer too small: %d > %d" % (pos + n_in, recv_cap))
+            if args.backend == "nccl" and max(max(sc), max(rc)) > MSG_MAX:
+                raise SystemExit("a peer message of %d keys exceeds what this RCCL build moves correctly; raise --chunks" % max(max(sc), max(rc)))
             if args.backend == "nccl":
                 works.append(dist.all_to_all_single(d_recv[pos:pos + n_in], send[: nt.value], output_split_sizes=rc,
                                                     input_split_sizes=sc, async_op=True))
@@ -149,7 +158,7 @@ def main():
 
     def sync():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if multi:
             dist.barrier()
             torch.cuda.synchronize(dev)
 
@@ -167,7 +176,7 @@ def main():
     ctx.profile(False)
 
     local_distinct = idx.local_size()
-    if world > 1:
+    if multi:
         cdev = dev if args.backend == "nccl" else torch.device("cpu")
         t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -203,19 +212,19 @@ def main():
                "config": {"workload": "k=%d DNA CountIndex (canonical), %d synthetic %d-bp reads per GPU as 315-byte "
                                       "FASTQ records, genome %d bp, seed %d" % (k, n_reads, read_len, genome_len, seed),
                           "kmers_per_step": total_kmers, "distinct_kmers": distinct,
-                          "exchange": "none (1 rank)" if world == 1 else
+                          "exchange": "none (1 rank)" if not multi else
                           "%s all_to_all_single (counts + payload), %d chunks per step, overlapped with parsing" %
                           ("RCCL" if args.backend == "nccl" else "gloo (rehearsal)", nch)},
                "roofline": roofline}
-        if world == 1 and not args.no_extra:
+        if not multi and not args.no_extra:
             out["extra"] = extra_rates(ctx, cfg, idx, d_bytes, nbytes, n_kmers, dev, torch)
-        if world == 1 and not args.no_cpu_baseline:
+        if not multi and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(host, args, k, n_reads)
         print(json.dumps(out), flush=True)
 
     idx.close()
     ctx.close()
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 
