@@ -22,12 +22,14 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, data, k, ret):
+def _worker(rank, world, port, data, k, ret, msg_max=None):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from kmerind_amd import dist as kdist
         from kmerind_amd import fileio
+        if msg_max:
+            kdist.MSG_MAX_WORDS = msg_max      # force the piecewise exchange
         s = orc.kspec(k)
         b, e = fileio.partition_fastq(data, world)[rank]
         ex = orc.extract(s, data[b:e], orc.FASTQ, file_offset=b)
@@ -46,14 +48,15 @@ def _worker(rank, world, port, data, k, ret):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_sharded_build_over_gloo_matches_single_rank(world):
+@pytest.mark.parametrize("world,msg_max", [(2, None), (3, None), (2, 5000)])
+def test_sharded_build_over_gloo_matches_single_rank(world, msg_max):
+    """msg_max = 5000: peer messages of ~36 k keys go in 8 pieces (the path that keeps RCCL messages below 1 GiB)"""
     import kmerind_amd as K
     k = 31
     data = bytes(K.synth_fastq(seed=3, genome_len=20_000, n_reads=600))
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_worker, args=(world, _free_port(), data, k, ret), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), data, k, ret, msg_max), nprocs=world, join=True)
     s = orc.kspec(k)
     ex = orc.extract(s, data, orc.FASTQ)
     ref = orc.CountMap(s, orc.CANONICAL)
