@@ -20,10 +20,15 @@ template <int NW_, int BITS_, int C_, int NT_> struct ExCfgT {
   static constexpr int S_RAW = NR + 1;
   static constexpr int EOL_DW = (CHUNKS * C + 31) / 32 + E_RAW + 1;
   static constexpr int STREAM_DW = (CHUNKS * C * BITS + 31) / 32 + S_RAW + 1;
-  static constexpr uint32_t CMASK = (1u << C) - 1u;
+  static constexpr uint32_t CMASK = (C >= 32) ? 0xffffffffu : ((1u << (C & 31)) - 1u);
 };
 // default geometry: 16 bytes per thread for one-word k-mers; tile = 8 KB / 4 KB / 2 KB / 2 KB
 template <int NW, int BITS> using ExCfg = ExCfgT<NW, BITS, (NW == 1) ? 16 : 8, (NW <= 2) ? 512 : 256>;
+
+// scan pass geometry: 32 bytes per lane for 2-bit one-word k-mers (per-lane overheads -- scans, line bookkeeping --
+// amortise over twice the bytes; 64 code bits fill one stream unit), else the default
+template <int NW, int BITS> using ScanCfg = ExCfgT<NW, BITS, (NW == 1 && BITS == 2) ? 32 : ExCfg<NW, BITS>::C,
+                                                    (NW == 1 && BITS == 2) ? ExCfg<NW, BITS>::TILE / 32 : ExCfg<NW, BITS>::NT>;
 
 struct TileInfo {
   uint32_t lines;     // line starts in the tile
@@ -36,7 +41,10 @@ struct TileInfo {
 template <int C> __device__ __forceinline__ int load_chunk(const uint8_t *__restrict__ bytes, uint64_t n_bytes, uint64_t g,
                                                           uint32_t (&dw)[C / 4]) {
   if (g + C <= n_bytes) {
-    if constexpr (C == 16) {
+    if constexpr (C == 32) {
+      const uint4 v = *reinterpret_cast<const uint4 *>(bytes + g), w = *reinterpret_cast<const uint4 *>(bytes + g + 16);
+      dw[0] = v.x; dw[1] = v.y; dw[2] = v.z; dw[3] = v.w; dw[4] = w.x; dw[5] = w.y; dw[6] = w.z; dw[7] = w.w;
+    } else if constexpr (C == 16) {
       uint4 v = *reinterpret_cast<const uint4 *>(bytes + g);
       dw[0] = v.x; dw[1] = v.y; dw[2] = v.z; dw[3] = v.w;
     } else {
@@ -53,7 +61,8 @@ template <int C> __device__ __forceinline__ int load_chunk(const uint8_t *__rest
 }
 
 template <int C> __device__ __forceinline__ void store_eol_bits(uint32_t *s_eol, int chunk, uint32_t eol) {
-  if constexpr (C == 16) reinterpret_cast<uint16_t *>(s_eol)[chunk] = (uint16_t)eol;
+  if constexpr (C == 32) s_eol[chunk] = eol;
+  else if constexpr (C == 16) reinterpret_cast<uint16_t *>(s_eol)[chunk] = (uint16_t)eol;
   else reinterpret_cast<uint8_t *>(s_eol)[chunk] = (uint8_t)eol;
 }
 
@@ -106,7 +115,8 @@ template <int C> __device__ __forceinline__ uint32_t read_eol_unit(const uint8_t
   else return pk[g];
 }
 template <int C> __device__ __forceinline__ void write_eol_unit(uint8_t *__restrict__ pk, uint64_t g, uint32_t e) {
-  if constexpr (C == 16) reinterpret_cast<uint16_t *>(pk)[g] = (uint16_t)e;
+  if constexpr (C == 32) reinterpret_cast<uint32_t *>(pk)[g] = e;
+  else if constexpr (C == 16) reinterpret_cast<uint16_t *>(pk)[g] = (uint16_t)e;
   else pk[g] = (uint8_t)e;
 }
 template <int BITS, int C> __device__ __forceinline__ uint64_t read_stream_unit(const uint8_t *__restrict__ pk, uint64_t g) {
@@ -126,7 +136,8 @@ template <int BITS, int C> __device__ __forceinline__ uint64_t read_stream_unit(
 }
 template <int BITS, int C> __device__ __forceinline__ void write_stream_unit(uint8_t *__restrict__ pk, uint64_t g, uint64_t st) {
   constexpr int NB = BITS * C / 8;
-  if constexpr (NB == 4) reinterpret_cast<uint32_t *>(pk)[g] = (uint32_t)st;
+  if constexpr (NB == 8) reinterpret_cast<uint64_t *>(pk)[g] = st;
+  else if constexpr (NB == 4) reinterpret_cast<uint32_t *>(pk)[g] = (uint32_t)st;
   else if constexpr (NB == 2) reinterpret_cast<uint16_t *>(pk)[g] = (uint16_t)st;
   else if constexpr (NB == 6) {
     uint16_t *p = reinterpret_cast<uint16_t *>(pk) + 3 * g;

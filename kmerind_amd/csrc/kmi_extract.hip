@@ -31,14 +31,14 @@ namespace kmi {
 // ---------------------------------------------------------------------------
 // pass 1
 // ---------------------------------------------------------------------------
-template <int NW, int BITS>
-__global__ __launch_bounds__((ExCfg<NW, BITS>::NT)) void fastq_scan_tiles_kernel(const uint8_t *__restrict__ bytes,
+// Cfg: ExCfg<NW, BITS> or, for 2-bit one-word shapes, the same 8 KB tile with 32 bytes per lane (ScanCfg)
+template <typename Cfg>
+__global__ __launch_bounds__((Cfg::NT)) void fastq_scan_tiles_kernel(const uint8_t *__restrict__ bytes,
                                                                                uint64_t n_bytes, uint32_t k,
                                                                                uint8_t *__restrict__ pk_eol,
                                                                                uint8_t *__restrict__ pk_stream,
                                                                                TileInfo *__restrict__ info,
                                                                                uint32_t *__restrict__ flags) {
-  using Cfg = ExCfg<NW, BITS>;
   __shared__ uint32_t s_eol[Cfg::EOL_DW];
   __shared__ uint32_t s_scan[Cfg::NT / 64 + 2];
   __shared__ uint32_t s_cnt[3];
@@ -59,7 +59,7 @@ __global__ __launch_bounds__((ExCfg<NW, BITS>::NT)) void fastq_scan_tiles_kernel
     uint32_t cur = lbl, start = 0, rest = ls;
     while (true) {
       uint32_t q = rest ? (uint32_t)__builtin_ctz(rest) : (uint32_t)Cfg::C;
-      uint32_t seg = ((1u << q) - 1u) & ~((1u << start) - 1u) & Cfg::CMASK;
+      uint32_t seg = (q >= 32u ? 0xffffffffu : ((1u << q) - 1u)) & ~((1u << start) - 1u) & Cfg::CMASK;
       uint32_t c = (uint32_t)__builtin_popcount(cand & seg);
       uint32_t ph = cur & 3u;
       if (ph < 2) lo += c << (16 * ph); else hi += c << (16 * (ph - 2));
@@ -538,7 +538,9 @@ static kmi_status scan_impl(kmi_ctx *ctx, const uint8_t *bytes_dev, size_t n_byt
   if (reuse) return KMI_OK;   // the scan of these very bytes is still in the workspace
   if (n_tiles > 0) {
     ProfScope ps(ctx, "fastq_scan_tiles", n_bytes);
-    hipLaunchKernelGGL((fastq_scan_tiles_kernel<NW, BITS>), dim3((unsigned)n_tiles), dim3(Cfg::NT), 0, ctx->stream,
+    using SCfg = ScanCfg<NW, BITS>;
+    static_assert(SCfg::TILE == Cfg::TILE, "the scan pass writes the packed arrays of the same tiles");
+    hipLaunchKernelGGL((fastq_scan_tiles_kernel<SCfg>), dim3((unsigned)n_tiles), dim3(SCfg::NT), 0, ctx->stream,
                        bytes_dev, (uint64_t)n_bytes, shape.k, pk_eol, pk_stream, info, ctx->d_flags);
   }
   KMI_TRY(launch_tile_offsets(ctx, info, n_tiles, (uint32_t)Cfg::TILE, hdr, base, off));
