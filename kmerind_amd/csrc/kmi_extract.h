@@ -293,6 +293,32 @@ __device__ __forceinline__ void window_at(const uint32_t *s_stream, uint32_t pos
   fwd_from_rc<NW, BITS>(rc, fw, shape);
 }
 
+// Consecutive windows of one read (an entry of the entry list), one-word 2-bit k-mers: the lane keeps the 128 stream
+// bits it loaded for the first window; the next reverse complement is a 64-bit funnel shift of those registers and the
+// next forward k-mer is the previous one shifted by a base with the new base (complement of the new top code of the
+// reverse complement) appended -- no LDS reads and no group reversal for the up to 7 windows that follow.
+struct RollWin { uint64_t lo, hi, fw; uint32_t sh; };
+template <typename Cfg>
+__device__ __forceinline__ void roll_first(RollWin &w, const uint32_t *s_stream, uint32_t pos, const KShape &shape, uint64_t &rc, uint64_t &fw) {
+  static_assert(Cfg::NW == 1 && Cfg::BITS == 2, "one-word 2-bit k-mers");
+  const uint32_t bit = 2u * pos, d = bit >> 5;
+  w.sh = bit & 31u;
+  w.lo = (uint64_t)s_stream[d] | ((uint64_t)s_stream[d + 1] << 32);
+  w.hi = (uint64_t)s_stream[d + 2] | ((uint64_t)s_stream[d + 3] << 32);
+  uint64_t r1[1], f1[1];
+  r1[0] = (w.sh ? ((w.lo >> w.sh) | (w.hi << (64u - w.sh))) : w.lo) & low_mask64(64 - shape.pad_bits);
+  fwd_from_rc<1, 2>(r1, f1, shape);
+  rc = r1[0]; fw = f1[0]; w.fw = fw;
+}
+// j-th window after the first (1 <= j <= 7)
+__device__ __forceinline__ void roll_next(RollWin &w, uint32_t j, const KShape &shape, uint64_t &rc, uint64_t &fw) {
+  const uint64_t mask = low_mask64(64 - shape.pad_bits);
+  const uint32_t s = w.sh + 2u * j;                 // 2 .. 45
+  rc = ((w.lo >> s) | (w.hi << (64u - s))) & mask;
+  fw = ((w.fw << 2) | ((~rc >> (2u * (shape.k - 1u))) & 3ull)) & mask;
+  w.fw = fw;
+}
+
 // key stored by the map for a parsed k-mer (kmer_index.hpp:436-481): forward strand, or the
 // smaller of forward / reverse complement
 template <int NW>

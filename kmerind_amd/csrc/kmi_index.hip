@@ -521,15 +521,17 @@ __global__ __launch_bounds__(kPartThreads) void scatter_fine_lines_kernel(const 
 // extracted tuple array never exists in HBM: 2 x 2.6 B/k-mer of input reads replace
 // 8 W + 8 R + 8 R of key traffic. Workgroup w owns the same contiguous run of tiles in both.
 // ---------------------------------------------------------------------------
-// L: the window list. The tile position of every k-mer window goes to HBM once (2 bytes per k-mer, file
-// order, windows of scan tile t at tile_off[t]); the histogram and scatter passes start from it and have no
-// per-byte work left. The pass works per LINE, not per byte, and one WAVEFRONT owns a tile, so there is no
+// L: the entry list. Every run of up to 8 consecutive k-mer windows of a read becomes one 16-bit entry
+// (tile position of the first window | (windows - 1) << 13), about 0.27 bytes per k-mer; the entries of scan tile t sit
+// in a slot of ent_stride(k) entries with their number in ent_cnt[t]. The histogram and scatter passes start from it
+// and have no per-byte work left: they read the first k-mer of an entry from the packed stream and roll the others.
+// The pass works per LINE, not per byte, and one WAVEFRONT owns a tile, so there is no
 // workgroup barrier in it. The lanes share the words of the tile's EOL bitmap plus 1 KB of context on either
 // side; line starts (non-EOL after EOL) and line ends (EOL after non-EOL) are ranked with one wave scan and their
 // positions land in two small LDS arrays, so line j of the window is [S[j], E[j + eoff]). A line whose index (from
 // the scan's line bases) says "sequence" becomes a run (first window, number of windows) clipped to the tile; a
-// line that says "quality" is compared with the line two ranks before it (fastq_loader.hpp:454-463); the wavefront
-// then expands the runs into the list. Windows belong to the tile they start in. A window that holds more than
+// line that says "quality" is compared with the line two ranks before it (fastq_loader.hpp:454-463); sixteen lanes
+// then cut each run into entries. Windows belong to the tile they start in. A window that holds more than
 // CAP lines falls back to per-word bit scans.
 constexpr int kListThreads = 256;
 template <int NW, int BITS> struct ListPassCfg {
@@ -543,14 +545,16 @@ template <int NW, int BITS> struct ListPassCfg {
   static_assert(WIN % kWave == 0 && WIN * 32 < 65536 && CTX * 32 >= Cfg::KMAX, "window geometry");
   // a run needs a record of >= k + 7 bytes
   static uint32_t max_runs(uint32_t k) { return (uint32_t)TILE / (k + 7u) + 2u; }
-  static uint32_t wave_lds_bytes(uint32_t k) { return (4u * WIN + 4u * CAP + 6u * max_runs(k) + 15u) & ~15u; }
+  // entry list: one 16-bit entry per run of up to 8 consecutive windows; per-tile slots of this many entries
+  static uint32_t ent_stride(uint32_t k) { return (uint32_t)TILE / 8u + max_runs(k); }
+  static uint32_t wave_lds_bytes(uint32_t k) { return (4u * WIN + 4u * CAP + 4u * max_runs(k) + 15u) & ~15u; }
 };
 
 template <int NW, int BITS>
 __global__ __launch_bounds__(kListThreads) void fastq_list_kernel(PackedInput in, uint64_t n_tiles, uint32_t k, uint32_t max_runs,
                                                                  uint32_t wave_lds_bytes, const uint32_t *__restrict__ line_base,
-                                                                 const uint64_t *__restrict__ tile_off, uint16_t *__restrict__ win_pos,
-                                                                 uint32_t *__restrict__ flags) {
+                                                                 uint32_t *__restrict__ flags, uint16_t *__restrict__ ent,
+                                                                 uint32_t *__restrict__ ent_cnt, uint32_t ent_stride) {
   using P = ListPassCfg<NW, BITS>;
   constexpr int TILE = P::TILE, WORDS = P::WORDS, CTX = P::CTX, WIN = P::WIN, WPL = P::WPL, CAP = P::CAP;
   constexpr uint32_t T0 = CTX * 32u, T1 = T0 + (uint32_t)TILE, NONE = 0xffff0000u;   // tile proper in window positions
@@ -559,7 +563,6 @@ __global__ __launch_bounds__(kListThreads) void fastq_list_kernel(PackedInput in
   uint16_t *S = reinterpret_cast<uint16_t *>(img + WIN);                                      // [CAP] line starts
   uint16_t *E = S + CAP;                                                                      // [CAP] line ends
   uint32_t *s_run = reinterpret_cast<uint32_t *>(E + CAP);                                    // [max_runs] first window | windows << 16
-  uint16_t *s_off = reinterpret_cast<uint16_t *>(s_run + max_runs);                           // [max_runs] rank of the run's first window
   const uint32_t *eolw = reinterpret_cast<const uint32_t *>(in.eol);
   const uint64_t n_words = in.n_cover / 32;
   const uint64_t n_waves = (uint64_t)gridDim.x * (kListThreads / kWave);
@@ -599,7 +602,6 @@ __global__ __launch_bounds__(kListThreads) void fastq_list_kernel(PackedInput in
   for (int i = 0; i < WPL; ++i) w_cur[i] = 0xffffffffu;
   if (tb < te) load_words(tb, w_cur);
   uint32_t lb = (tb < te) ? line_base[tb] : 0u;
-  uint64_t toff = (tb < te) ? tile_off[tb] : 0ull;
   bool bad = false;
   for (uint64_t t = tb; t < te; ++t) {
     const int64_t gw0 = (int64_t)(t * WORDS) - CTX;
@@ -608,7 +610,6 @@ __global__ __launch_bounds__(kListThreads) void fastq_list_kernel(PackedInput in
     const uint32_t prev_win = (gw0 > 0) ? (eolw[gw0 - 1] >> 31) : 1u;   // EOL status of the byte before the window
     load_words(t + 1, w_nxt);   // the next tile's inputs are in flight during this tile
     const uint32_t lb_nxt = line_base[(t + 1 < n_tiles) ? t + 1 : t];
-    const uint64_t toff_nxt = tile_off[t + 1];
     uint32_t prev = __shfl_up(w_cur[WPL - 1] >> 31, 1, kWave);
     if (lane == 0) prev = prev_win;
     uint32_t ls[WPL], le[WPL], ns = 0, ne = 0, nsl = 0, nst = 0;
@@ -650,7 +651,6 @@ __global__ __launch_bounds__(kListThreads) void fastq_list_kernel(PackedInput in
       // candidate lines: c = 0 is the line open at the tile start (the last start before the tile, or the line that
       // was already open at the window start), c >= 1 are the lines that start inside the tile; line index lb + c - 1
       const uint32_t ncand = 1u + (NST - NSL);
-      uint32_t win_base = 0;
       for (uint32_t c0 = 0; c0 < ncand; c0 += kWave) {
         const uint32_t c = c0 + lane;
         const int32_t j = (int32_t)(NSL + c) - 1;            // rank among the window's line starts; -1 = open at window start
@@ -672,11 +672,10 @@ __global__ __launch_bounds__(kListThreads) void fastq_list_kernel(PackedInput in
             }
           }
         }
-        const uint32_t mine = run ? ((1u << 16) | (run >> 16)) : 0u;
+        const uint32_t mine = run ? 1u : 0u;
         const uint32_t sc = wave_inclusive_scan(mine);
-        if (run) { const uint32_t r = n_runs + ((sc - mine) >> 16); s_run[r] = run; s_off[r] = (uint16_t)(win_base + ((sc - mine) & 0xffffu)); }
-        const uint32_t st = __shfl(sc, kWave - 1, kWave);
-        n_runs += st >> 16; win_base += st & 0xffffu;
+        if (run) s_run[n_runs + sc - 1u] = run;
+        n_runs += __shfl(sc, kWave - 1, kWave);
       }
     } else {
       // crowded window: the lanes walk the line starts of their own words (tile proper only) with bit scans
@@ -700,7 +699,7 @@ __global__ __launch_bounds__(kListThreads) void fastq_list_kernel(PackedInput in
         }
       };
       uint32_t mine = 0;
-      walk([&](uint32_t r) { mine += (1u << 16) | (r >> 16); });
+      walk([&](uint32_t) { ++mine; });
       {   // the length rule for the quality lines of the tile
         uint32_t idx = first_idx;
 #pragma unroll
@@ -715,30 +714,40 @@ __global__ __launch_bounds__(kListThreads) void fastq_list_kernel(PackedInput in
         }
       }
       const uint32_t sc = wave_inclusive_scan(mine);
-      n_runs = __shfl(sc, kWave - 1, kWave) >> 16;
+      n_runs = __shfl(sc, kWave - 1, kWave);
       if (mine) {
-        uint32_t r = (sc - mine) >> 16, off = (sc - mine) & 0xffffu;
-        walk([&](uint32_t run) { s_run[r] = run; s_off[r] = (uint16_t)off; ++r; off += run >> 16; });
+        uint32_t r = sc - mine;
+        walk([&](uint32_t run) { s_run[r++] = run; });
       }
     }
     wave_sync();   // run table complete
-    auto expand = [&](uint32_t sc, uint32_t off) {   // wave-uniform arguments; positions go out two per 32-bit store
-      uint32_t s0 = sc & 0xffffu, c = sc >> 16;
-      uint64_t g = toff + off;                        // list index of the run's first window
-      if (g & 1ull) { if (lane == 0) win_pos[g] = (uint16_t)s0; ++g; ++s0; --c; }
-      uint32_t *dst2 = reinterpret_cast<uint32_t *>(win_pos + g);
-      for (uint32_t q = lane; q < (c >> 1); q += kWave) dst2[q] = (s0 + 2u * q) | ((s0 + 2u * q + 1u) << 16);
-      if ((c & 1u) && lane == 0) win_pos[g + c - 1u] = (uint16_t)(s0 + c - 1u);
-    };
+    uint32_t ebase = 0;   // entries of this tile so far
+    uint16_t *etile = ent + (uint64_t)t * ent_stride;
     for (uint32_t r0 = 0; r0 < n_runs; r0 += kWave) {
       const uint32_t nr = (n_runs - r0 < (uint32_t)kWave) ? n_runs - r0 : (uint32_t)kWave;
-      const uint32_t my_sc = (lane < nr) ? s_run[r0 + lane] : 0u, my_off = (lane < nr) ? s_off[r0 + lane] : 0u;
-      for (uint32_t r = 0; r < nr; ++r) expand(__shfl(my_sc, (int)r, kWave), __shfl(my_off, (int)r, kWave));
+      const uint32_t my_sc = (lane < nr) ? s_run[r0 + lane] : 0u;
+      // entry list: a run of c windows = ceil(c / 8) entries (position | (windows - 1) << 13); 16 lanes per run
+      const uint32_t my_ne = ((my_sc >> 16) + 7u) >> 3;
+      const uint32_t einc = wave_inclusive_scan(my_ne);
+      const uint32_t my_eo = ebase + einc - my_ne;
+      for (uint32_t g = 0; g < nr; g += kWave / 16) {
+        const int rr = (int)(g + (lane >> 4));
+        const uint32_t sc = __shfl(my_sc, rr, kWave), eo = __shfl(my_eo, rr, kWave), ne = __shfl(my_ne, rr, kWave);
+        if ((uint32_t)rr < nr) {
+          const uint32_t s0 = sc & 0xffffu, c = sc >> 16;
+          for (uint32_t j = lane & 15u; j < ne; j += 16u) {
+            const uint32_t left = c - 8u * j;
+            etile[eo + j] = (uint16_t)((s0 + 8u * j) | (((left < 8u ? left : 8u) - 1u) << 13));
+          }
+        }
+      }
+      ebase += __shfl(einc, kWave - 1, kWave);
     }
+    if (lane == 0) ent_cnt[t] = ebase;
     wave_sync();   // the next tile overwrites the image, the event arrays and the run table
 #pragma unroll
     for (int i = 0; i < WPL; ++i) w_cur[i] = w_nxt[i];
-    lb = lb_nxt; toff = toff_nxt;
+    lb = lb_nxt;
   }
   if (bad) atomicOr(&flags[0], 4u);
 }
@@ -755,20 +764,50 @@ template <int NW, int BITS> struct ListCfg {
   static constexpr int ULOADS = (UNITS + NT - 1) / NT;     // stream units per thread (scatter)
 };
 
-// E1: fine histogram + per-workgroup coarse counts, driven by the window list. A round = the RMAX scan
-// tiles whose packed stream sits in LDS as one image; the image is double-buffered, so there is one
-// barrier per round and the only per-window work is window -> canonical key -> placement hash -> LDS add.
+// E1: fine histogram + per-workgroup coarse counts, driven by the entry list (one entry = up to 8 consecutive windows
+// of a read: the first k-mer is read from the stream image, the others roll). A round = the RMAX scan tiles whose
+// packed stream sits in LDS as one image; the image is double-buffered, so there is one barrier per round.
 constexpr int kHistThreads = 1024;
+template <int NW, int BITS, typename F>
+__device__ __forceinline__ void for_entry_windows(const uint32_t *img, uint32_t pos, uint32_t len, const KShape &shape, bool canonical, F f) {
+  using Cfg = ExCfg<NW, BITS>;
+  if constexpr (NW == 1 && BITS == 2) {
+    RollWin rw;
+    uint64_t rc[1], fw[1], key[1];
+    roll_first<Cfg>(rw, img, pos, shape, rc[0], fw[0]);
+    select_strand<1>(rc, fw, canonical, key);
+    f(0u, key);
+#pragma unroll
+    for (uint32_t j = 1; j < 8u; ++j) {
+      if (j < len) {
+        roll_next(rw, j, shape, rc[0], fw[0]);
+        select_strand<1>(rc, fw, canonical, key);
+        f(j, key);
+      }
+    }
+  } else {
+#pragma unroll
+    for (uint32_t j = 0; j < 8u; ++j) {
+      if (j < len) {
+        uint64_t rc[NW], fw[NW], key[NW];
+        window_at<Cfg>(img, pos + j, shape, rc, fw);
+        select_strand<NW>(rc, fw, canonical, key);
+        f(j, key);
+      }
+    }
+  }
+}
+
 template <int NW, int BITS>
 __global__ __launch_bounds__(kHistThreads) void fastq_hist_list_kernel(PackedInput in, uint64_t n_tiles, KShape shape, bool canonical,
-                                                                      const uint64_t *__restrict__ tile_off,
-                                                                      const uint16_t *__restrict__ win_pos,
-                                                                      uint32_t *__restrict__ fine_hist, uint32_t *__restrict__ wg_hist) {
+                                                                      const uint16_t *__restrict__ ent, const uint32_t *__restrict__ ent_cnt,
+                                                                      uint32_t ent_stride, uint32_t *__restrict__ fine_hist,
+                                                                      uint32_t *__restrict__ wg_hist) {
   using Cfg = ExCfg<NW, BITS>;
   using L = ListCfg<NW, BITS>;
   constexpr int NT = kHistThreads, RMAX = L::RMAX;
   constexpr int UL = (L::UNITS + NT - 1) / NT;
-  constexpr int PB = 8;   // window positions in flight per thread
+  constexpr int EB = 2;   // entries in flight per thread
   __shared__ uint32_t s_hist[kNumFine];
   __shared__ uint32_t s_stream[2][L::STREAM_DW];
   for (int i = threadIdx.x; i < kNumFine; i += NT) s_hist[i] = 0;
@@ -798,35 +837,32 @@ __global__ __launch_bounds__(kHistThreads) void fastq_hist_list_kernel(PackedInp
   for (uint64_t t = tb; t < te; t += RMAX) {
     const bool more = t + RMAX < te;
     if (more) load_image(t + RMAX, st);   // in flight while this round is processed
-    const uint64_t qa = tile_off[t];
-    uint64_t o[RMAX + 1];
+    uint32_t eo[RMAX + 1];                // entries of the round's tiles, cumulative
+    eo[0] = 0;
 #pragma unroll
-    for (int i = 1; i <= RMAX; ++i) o[i] = tile_off[(t + i < te) ? t + i : te];
-    const uint32_t total = (uint32_t)(o[RMAX] - qa);
-    uint32_t orel[RMAX];
-#pragma unroll
-    for (int i = 1; i < RMAX; ++i) orel[i] = (uint32_t)(o[i] - qa);
+    for (int i = 0; i < RMAX; ++i) eo[i + 1] = eo[i] + ((t + i < te) ? ent_cnt[t + i] : 0u);
+    const uint32_t total = eo[RMAX];
     const uint32_t *img = s_stream[buf];
-    const uint16_t *src = win_pos + qa;
-    for (uint32_t q0 = 0; q0 < total; q0 += NT * PB) {
-      uint32_t p16[PB];
+    for (uint32_t e0 = 0; e0 < total; e0 += NT * EB) {
+      uint32_t ev[EB], er[EB];
 #pragma unroll
-      for (int m = 0; m < PB; ++m) {
-        uint32_t q = q0 + m * NT + threadIdx.x;
-        q = q < total ? q : total - 1;
-        p16[m] = src[q];
+      for (int m = 0; m < EB; ++m) {
+        uint32_t e = e0 + m * NT + threadIdx.x;
+        e = e < total ? e : total - 1;
+        uint32_t r = 0;
+#pragma unroll
+        for (int i = 1; i < RMAX; ++i) r += (e >= eo[i]) ? 1u : 0u;
+        uint32_t base = 0;
+#pragma unroll
+        for (int i = 1; i < RMAX; ++i) base = (r == (uint32_t)i) ? eo[i] : base;
+        er[m] = r;
+        ev[m] = ent[(t + r) * ent_stride + (e - base)];
       }
 #pragma unroll
-      for (int m = 0; m < PB; ++m) {
-        const uint32_t q = q0 + m * NT + threadIdx.x;
-        if (q < total) {
-          uint32_t r = 0;
-#pragma unroll
-          for (int i = 1; i < RMAX; ++i) r += (q >= orel[i]) ? 1u : 0u;
-          uint64_t rc[NW], fw[NW], key[NW];
-          window_at<Cfg>(img, r * Cfg::TILE + p16[m], shape, rc, fw);
-          select_strand<NW>(rc, fw, canonical, key);
-          atomicAdd(&s_hist[fine_of(place_hash<NW>(key))], 1u);
+      for (int m = 0; m < EB; ++m) {
+        if (e0 + m * NT + threadIdx.x < total) {
+          for_entry_windows<NW, BITS>(img, er[m] * Cfg::TILE + (ev[m] & 0x1fffu), (ev[m] >> 13) + 1u, shape, canonical,
+                                      [&](uint32_t, const uint64_t (&key)[NW]) { atomicAdd(&s_hist[fine_of(place_hash<NW>(key))], 1u); });
         }
       }
     }
@@ -846,18 +882,19 @@ __global__ __launch_bounds__(kHistThreads) void fastq_hist_list_kernel(PackedInp
   }
 }
 
-// Rank counts from the window list (the counting half of imxx::distribute fused with read_file): per-workgroup counts
-// of the rank buckets, same tile ownership as the scatter that follows.
+// Rank counts from the entry list (the counting half of imxx::distribute fused with read_file): per-workgroup counts
+// of the rank buckets, same tile ownership as the scatter that follows. The rank bucket of every window is kept (one
+// byte per window, eight per entry) so that the rank hash (Murmur / Farm) is computed once.
 template <int NW, int BITS, int TPB>
 __global__ __launch_bounds__(TPB) void fastq_rank_hist_list_kernel(PackedInput in, uint64_t n_tiles, KShape shape, bool canonical,
-                                                                  const uint64_t *__restrict__ tile_off, const uint16_t *__restrict__ win_pos,
-                                                                  BucketFn fn, uint32_t *__restrict__ wg_hist,
-                                                                  uint32_t *__restrict__ win_pb /* position | bucket << 16 */) {
+                                                                  const uint16_t *__restrict__ ent, const uint32_t *__restrict__ ent_cnt,
+                                                                  uint32_t ent_stride, BucketFn fn, uint32_t *__restrict__ wg_hist,
+                                                                  uint64_t *__restrict__ ent_bkt /* rank bucket of window j in byte j */) {
   using Cfg = ExCfg<NW, BITS>;
   using L = ListCfg<NW, BITS>;
   constexpr int NT = TPB, RMAX = L::RMAX;
   constexpr int UL = (L::UNITS + NT - 1) / NT;
-  constexpr int PB = 8;
+  constexpr int EB = 2;
   __shared__ uint32_t s_hist[kNumCoarse];
   __shared__ uint32_t s_stream[2][L::STREAM_DW];
   if (threadIdx.x < kNumCoarse) s_hist[threadIdx.x] = 0;
@@ -887,37 +924,40 @@ __global__ __launch_bounds__(TPB) void fastq_rank_hist_list_kernel(PackedInput i
   for (uint64_t t = tb; t < te; t += RMAX) {
     const bool more = t + RMAX < te;
     if (more) load_image(t + RMAX, st);
-    const uint64_t qa = tile_off[t];
-    uint64_t o[RMAX + 1];
+    uint32_t eo[RMAX + 1];
+    eo[0] = 0;
 #pragma unroll
-    for (int i = 1; i <= RMAX; ++i) o[i] = tile_off[(t + i < te) ? t + i : te];
-    const uint32_t total = (uint32_t)(o[RMAX] - qa);
-    uint32_t orel[RMAX];
-#pragma unroll
-    for (int i = 1; i < RMAX; ++i) orel[i] = (uint32_t)(o[i] - qa);
+    for (int i = 0; i < RMAX; ++i) eo[i + 1] = eo[i] + ((t + i < te) ? ent_cnt[t + i] : 0u);
+    const uint32_t total = eo[RMAX];
     const uint32_t *img = s_stream[buf];
-    const uint16_t *src = win_pos + qa;
-    for (uint32_t q0 = 0; q0 < total; q0 += NT * PB) {
-      uint32_t p16[PB];
+    for (uint32_t e0 = 0; e0 < total; e0 += NT * EB) {
+      uint32_t ev[EB], er[EB];
+      uint64_t eidx[EB];
 #pragma unroll
-      for (int m = 0; m < PB; ++m) {
-        uint32_t q = q0 + m * NT + threadIdx.x;
-        q = q < total ? q : total - 1;
-        p16[m] = src[q];
+      for (int m = 0; m < EB; ++m) {
+        uint32_t e = e0 + m * NT + threadIdx.x;
+        e = e < total ? e : total - 1;
+        uint32_t r = 0;
+#pragma unroll
+        for (int i = 1; i < RMAX; ++i) r += (e >= eo[i]) ? 1u : 0u;
+        uint32_t base = 0;
+#pragma unroll
+        for (int i = 1; i < RMAX; ++i) base = (r == (uint32_t)i) ? eo[i] : base;
+        er[m] = r;
+        eidx[m] = (t + r) * ent_stride + (e - base);
+        ev[m] = ent[eidx[m]];
       }
 #pragma unroll
-      for (int m = 0; m < PB; ++m) {
-        const uint32_t q = q0 + m * NT + threadIdx.x;
-        if (q < total) {
-          uint32_t r = 0;
-#pragma unroll
-          for (int i = 1; i < RMAX; ++i) r += (q >= orel[i]) ? 1u : 0u;
-          uint64_t rc[NW], fw[NW], key[NW];
-          window_at<Cfg>(img, r * Cfg::TILE + p16[m], shape, rc, fw);
-          select_strand<NW>(rc, fw, canonical, key);
-          const uint32_t b = bucket_of<NW>(key, fn);
-          atomicAdd(&s_hist[b], 1u);
-          win_pb[qa + q] = p16[m] | (b << 16);   // the rank hash (Murmur / Farm) is computed once: the scatter reads it back
+      for (int m = 0; m < EB; ++m) {
+        if (e0 + m * NT + threadIdx.x < total) {
+          uint64_t bk = 0;
+          for_entry_windows<NW, BITS>(img, er[m] * Cfg::TILE + (ev[m] & 0x1fffu), (ev[m] >> 13) + 1u, shape, canonical,
+                                      [&](uint32_t j, const uint64_t (&key)[NW]) {
+                                        const uint32_t b = bucket_of<NW>(key, fn);
+                                        atomicAdd(&s_hist[b], 1u);
+                                        bk |= (uint64_t)b << (8u * j);
+                                      });
+          ent_bkt[eidx[m]] = bk;
         }
       }
     }
@@ -929,21 +969,24 @@ __global__ __launch_bounds__(TPB) void fastq_rank_hist_list_kernel(PackedInput i
   if (threadIdx.x < kNumCoarse) wg_hist[(uint64_t)blockIdx.x * kNumCoarse + threadIdx.x] = s_hist[threadIdx.x];
 }
 
-// E2 from the window list. A round is a run of up to CAPW consecutive windows of this
-// workgroup's tiles (it may start and end inside a tile, and spans at most RMAX scan tiles, whose packed
-// stream is one contiguous LDS image), so the bucket sort always works on a full stage: fewer, longer
-// contiguous runs per coarse bucket and no per-byte work at all.
-// RANK = true: the list entries are 32-bit (position | rank bucket << 16), written by the rank histogram pass.
+// E2 from the entry list. A round is a run of up to EMAX = CAPW / 8 consecutive entries of this workgroup's tiles (it
+// may start and end inside a tile, and spans at most RMAX scan tiles, whose packed stream is one contiguous LDS
+// image), so the bucket sort works on a nearly full stage whatever the tile boundaries; an entry is up to 8 consecutive
+// windows of a read: the first k-mer is read from the image, the others roll. No per-byte work at all.
+// RANK = true: buckets come from the bytes the rank histogram pass left (ent_bkt) instead of the placement hash.
 template <int NW, int BITS, bool RANK = false>
 __global__ __launch_bounds__((ExCfg<NW, BITS>::NT)) void fastq_scatter_list_kernel(PackedInput in, uint64_t n_tiles, KShape shape, bool canonical,
-                                                                                  const uint64_t *__restrict__ tile_off,
-                                                                                  const typename std::conditional<RANK, uint32_t, uint16_t>::type *__restrict__ win_pos,
+                                                                                  const uint16_t *__restrict__ ent,
+                                                                                  const uint32_t *__restrict__ ent_cnt, uint32_t ent_stride,
+                                                                                  const uint64_t *__restrict__ ent_bkt,
                                                                                   const uint64_t *__restrict__ wg_off, uint64_t *__restrict__ out) {
   using Cfg = ExCfg<NW, BITS>;
   using L = ListCfg<NW, BITS>;
-  constexpr int NT = L::NT, MAXQ = L::MAXQ, CAPW = L::CAPW, RMAX = L::RMAX;
+  constexpr int NT = L::NT, CAPW = L::CAPW, RMAX = L::RMAX;
+  constexpr int EMAX = CAPW / 8;                     // entries per round: every entry holds at most 8 windows
+  constexpr int EPT = (EMAX + NT - 1) / NT;          // entries per thread and round
+  constexpr int KPT = EPT * 8;                       // keys per thread and round
   static_assert(NT >= kNumCoarse, "one thread per coarse bucket");
-  static_assert(RMAX * Cfg::TILE < 65536 * 4, "round positions");
   __shared__ uint64_t s_stage[CAPW * NW];
   __shared__ uint8_t s_bkt[CAPW];
   __shared__ uint32_t s_stream[L::STREAM_DW];
@@ -951,33 +994,39 @@ __global__ __launch_bounds__((ExCfg<NW, BITS>::NT)) void fastq_scatter_list_kern
   __shared__ uint32_t s_lofs[kNumCoarse];
   __shared__ uint64_t s_gbase[kNumCoarse];
   __shared__ uint32_t s_part[kNumCoarse / kWave];
+  __shared__ uint32_t s_total;
   uint64_t cursor = (threadIdx.x < kNumCoarse) ? wg_off[(uint64_t)blockIdx.x * kNumCoarse + threadIdx.x] : 0ull;
   if (threadIdx.x < kNumCoarse) s_cnt[threadIdx.x] = 0;
   const uint64_t per = (n_tiles + gridDim.x - 1) / gridDim.x;
   const uint64_t tb = (uint64_t)blockIdx.x * per;
   const uint64_t te = (tb + per < n_tiles) ? tb + per : n_tiles;
   if (tb >= te) return;
-  const uint64_t q_end = tile_off[te];
   const uint64_t last_unit = in.n_cover / Cfg::C - 1;
-  // a round: windows [q0, q0 + total) of tiles t .. t + RMAX - 1; orel[i] = rank of tile t+i's first window
-  struct Round { uint64_t t, q0; uint32_t total; uint32_t orel[RMAX]; };
-  auto plan = [&](uint64_t t, uint64_t q0, Round &r) {
-    while (tile_off[t + 1] <= q0) ++t;                 // tile of window q0 (tiles without windows are skipped)
-    uint64_t o[RMAX + 1];
+  // a round: entries ei .. of tile t, then whole tiles, up to EMAX entries / RMAX tiles; eo[i] = rank of tile t+i's first entry
+  struct Round { uint64_t t; uint32_t ei, total; uint32_t eo[RMAX + 1]; uint64_t nt; uint32_t nei; };
+  auto plan = [&](uint64_t t, uint32_t ei, Round &r) -> bool {
+    while (t < te && ei >= ent_cnt[t]) { ++t; ei = 0; }   // tiles that are used up or hold no window are skipped
+    if (t >= te) return false;
+    r.t = t; r.ei = ei; r.eo[0] = 0;
+    r.nt = t + RMAX; r.nei = 0;                            // where the next round starts if every tile is used up
+    bool cut = false;
 #pragma unroll
-    for (int i = 1; i <= RMAX; ++i) o[i] = (t + i <= te) ? tile_off[t + i] : q_end;   // past the range: does not bind
-    uint64_t q1 = q0 + CAPW;
-    if (q1 > o[RMAX]) q1 = o[RMAX];
-    if (q1 > q_end) q1 = q_end;
-    r.t = t; r.q0 = q0; r.total = (uint32_t)(q1 - q0);
-#pragma unroll
-    for (int i = 1; i < RMAX; ++i) { const uint64_t d = o[i] - q0; r.orel[i] = d > (uint64_t)CAPW ? (uint32_t)CAPW : (uint32_t)d; }
+    for (int i = 0; i < RMAX; ++i) {
+      uint32_t avail = (t + i < te) ? ent_cnt[t + i] : 0u;
+      if (i == 0) avail -= ei;
+      uint32_t take = avail;
+      if (r.eo[i] + take > (uint32_t)EMAX) take = (uint32_t)EMAX - r.eo[i];
+      if (cut) take = 0;
+      if (!cut && take < avail) { cut = true; r.nt = t + i; r.nei = (i == 0 ? ei : 0u) + take; }
+      r.eo[i + 1] = r.eo[i] + take;
+    }
+    r.total = r.eo[RMAX];
+    return true;
   };
   uint64_t st[L::ULOADS];
-  uint32_t p16[MAXQ];
-  // inputs of a round: the packed stream of its tiles (+ halo) and this thread's window positions
-  // (q = tid, tid + NT, ...); clamped loads, not guarded ones, so nothing forces an early wait
-  auto fetch = [&](const Round &r) {
+  uint32_t ev[EPT], er[EPT];
+  uint64_t eb[EPT];
+  auto fetch = [&](const Round &r) {   // clamped loads, not guarded ones, so nothing forces an early wait
 #pragma unroll
     for (int i = 0; i < L::ULOADS; ++i) {
       uint64_t g = r.t * NT + (uint64_t)i * NT + threadIdx.x;
@@ -985,76 +1034,83 @@ __global__ __launch_bounds__((ExCfg<NW, BITS>::NT)) void fastq_scatter_list_kern
       st[i] = read_stream_unit<BITS, Cfg::C>(in.stream, g);
     }
 #pragma unroll
-    for (int m = 0; m < MAXQ; ++m) {
-      uint32_t q = m * NT + threadIdx.x;
-      q = q < r.total ? q : r.total - 1;
-      p16[m] = win_pos[r.q0 + q];
+    for (int m = 0; m < EPT; ++m) {
+      uint32_t e = m * NT + threadIdx.x;
+      e = e < r.total ? e : r.total - 1;
+      uint32_t tr = 0;
+#pragma unroll
+      for (int i = 1; i < RMAX; ++i) tr += (e >= r.eo[i]) ? 1u : 0u;
+      uint32_t base = 0;
+#pragma unroll
+      for (int i = 1; i < RMAX; ++i) base = (tr == (uint32_t)i) ? r.eo[i] : base;
+      const uint64_t idx = (r.t + tr) * ent_stride + (tr == 0u ? r.ei : 0u) + (e - base);
+      er[m] = tr;
+      ev[m] = ent[idx];
+      if (RANK) eb[m] = ent_bkt[idx];
     }
   };
   Round cur, nxt;
-  bool have = tile_off[tb] < q_end;
-  if (have) { plan(tb, tile_off[tb], cur); fetch(cur); }
+  bool have = plan(tb, 0u, cur);
+  if (have) fetch(cur);
   while (have) {
-    const uint32_t total = cur.total;
-    {
 #pragma unroll
-      for (int i = 0; i < L::ULOADS; ++i) {
-        const int u = i * NT + threadIdx.x;
-        if (u < L::UNITS) store_stream_bits<BITS, Cfg::C>(s_stream, u, st[i]);
+    for (int i = 0; i < L::ULOADS; ++i) {
+      const int u = i * NT + threadIdx.x;
+      if (u < L::UNITS) store_stream_bits<BITS, Cfg::C>(s_stream, u, st[i]);
+    }
+    lds_barrier();
+    // S0: keys of this thread's entries, coarse bucket and rank inside (round, bucket)
+    uint64_t key[KPT][NW];
+    uint32_t bkrk[KPT];
+#pragma unroll
+    for (int q = 0; q < KPT; ++q) bkrk[q] = 0xffffffffu;
+#pragma unroll
+    for (int m = 0; m < EPT; ++m) {
+      if ((uint32_t)(m * NT) + threadIdx.x < cur.total) {
+        for_entry_windows<NW, BITS>(s_stream, er[m] * Cfg::TILE + (ev[m] & 0x1fffu), (ev[m] >> 13) + 1u, shape, canonical,
+                                    [&](uint32_t j, const uint64_t (&kk)[NW]) {
+#pragma unroll
+                                      for (int w = 0; w < NW; ++w) key[m * 8 + j][w] = kk[w];
+                                      const uint32_t b = RANK ? (uint32_t)((eb[m] >> (8u * j)) & 0xffu) : coarse_of(place_hash<NW>(kk));
+                                      bkrk[m * 8 + j] = (b << 16) | atomicAdd(&s_cnt[b], 1u);
+                                    });
       }
-      lds_barrier();
-      // S0: keys, coarse bucket and rank inside (round, bucket)
-      uint64_t key[MAXQ][NW];
-      uint32_t bkrk[MAXQ];
+    }
+    // the next round's inputs travel while this one is sorted and written out
+    have = plan(cur.nt, cur.nei, nxt);
+    if (have) fetch(nxt);
+    lds_barrier();
+    uint32_t c = 0, inc = 0;
+    if (threadIdx.x < kNumCoarse) {
+      c = s_cnt[threadIdx.x];
+      s_cnt[threadIdx.x] = 0;
+      inc = wave_inclusive_scan(c);
+      if (lane_id() == kWave - 1) s_part[wave_id()] = inc;
+    }
+    lds_barrier();
+    if (threadIdx.x < kNumCoarse) {
+      uint32_t pre = 0;
 #pragma unroll
-      for (int m = 0; m < MAXQ; ++m) {
-        const uint32_t q = m * NT + threadIdx.x;
-        if (q < total) {
-          uint32_t r = 0;
+      for (uint32_t w = 0; w < kNumCoarse / kWave; ++w) pre += (w < wave_id()) ? s_part[w] : 0u;
+      const uint32_t lo = pre + inc - c;
+      s_lofs[threadIdx.x] = lo;
+      s_gbase[threadIdx.x] = cursor - lo;
+      cursor += c;
+      if (threadIdx.x == kNumCoarse - 1) s_total = pre + inc;   // windows of the round
+    }
+    lds_barrier();
 #pragma unroll
-          for (int i = 1; i < RMAX; ++i) r += (q >= cur.orel[i]) ? 1u : 0u;
-          uint64_t rc[NW], fw[NW];
-          window_at<Cfg>(s_stream, r * Cfg::TILE + (p16[m] & 0xffffu), shape, rc, fw);
-          select_strand<NW>(rc, fw, canonical, key[m]);
-          const uint32_t b = RANK ? (p16[m] >> 16) : coarse_of(place_hash<NW>(key[m]));
-          bkrk[m] = (b << 16) | atomicAdd(&s_cnt[b], 1u);
-        }
-      }
-      // the next round's inputs travel while this one is sorted and written out
-      have = cur.q0 + total < q_end;
-      if (have) { plan(cur.t, cur.q0 + total, nxt); fetch(nxt); }
-      lds_barrier();
-      uint32_t c = 0, inc = 0;
-      if (threadIdx.x < kNumCoarse) {
-        c = s_cnt[threadIdx.x];
-        s_cnt[threadIdx.x] = 0;
-        inc = wave_inclusive_scan(c);
-        if (lane_id() == kWave - 1) s_part[wave_id()] = inc;
-      }
-      lds_barrier();
-      if (threadIdx.x < kNumCoarse) {
-        uint32_t pre = 0;
+    for (int q = 0; q < KPT; ++q) {
+      if (bkrk[q] != 0xffffffffu) {
+        const uint32_t b = bkrk[q] >> 16;
+        const uint32_t pos = s_lofs[b] + (bkrk[q] & 0xffffu);
 #pragma unroll
-        for (uint32_t w = 0; w < kNumCoarse / kWave; ++w) pre += (w < wave_id()) ? s_part[w] : 0u;
-        const uint32_t lo = pre + inc - c;
-        s_lofs[threadIdx.x] = lo;
-        s_gbase[threadIdx.x] = cursor - lo;
-        cursor += c;
-      }
-      lds_barrier();
-#pragma unroll
-      for (int m = 0; m < MAXQ; ++m) {
-        const uint32_t q = m * NT + threadIdx.x;
-        if (q < total) {
-          const uint32_t b = bkrk[m] >> 16;
-          const uint32_t pos = s_lofs[b] + (bkrk[m] & 0xffffu);
-#pragma unroll
-          for (int w = 0; w < NW; ++w) s_stage[(uint64_t)pos * NW + w] = key[m][w];
-          s_bkt[pos] = (uint8_t)b;
-        }
+        for (int w = 0; w < NW; ++w) s_stage[(uint64_t)pos * NW + w] = key[q][w];
+        s_bkt[pos] = (uint8_t)b;
       }
     }
     lds_barrier();
+    const uint32_t total = s_total;
     for (uint32_t s = threadIdx.x; s < total; s += NT) {
       const uint64_t dst = s_gbase[s_bkt[s]] + s;
 #pragma unroll
@@ -1745,20 +1801,24 @@ static kmi_status build_fused_impl(kmi_index *idx, const uint8_t *bytes_dev, siz
   PartWs w;
   KMI_TRY(get_part_ws(ctx, n, NW, WS_KEYS_A, WS_KEYS_B, &w));
   void *pl;
-  KMI_TRY(ws_get(ctx, WS_WIN_LIST, sizeof(uint16_t) * (n + 64), &pl));
-  uint16_t *win_pos = (uint16_t *)pl;
+  using LPC = ListPassCfg<NW, BITS>;
+  KMI_TRY(ws_get(ctx, WS_ENT_LIST, sizeof(uint16_t) * ((size_t)n_tiles * LPC::ent_stride(idx->shape.k) + 64), &pl));
+  uint16_t *ent = (uint16_t *)pl;
+  KMI_TRY(ws_get(ctx, WS_ENT_CNT, sizeof(uint32_t) * (n_tiles + 8), &pl));
+  uint32_t *ent_cnt = (uint32_t *)pl;
   KMI_HIP(ctx, hipMemsetAsync(w.fine_hist, 0, sizeof(uint32_t) * kNumFine * kFineParts, ctx->stream));
   {
     ProfScope ps(ctx, "fastq_list", n);
     using LP = ListPassCfg<NW, BITS>;
     const uint32_t wave_lds = LP::wave_lds_bytes(idx->shape.k);
     hipLaunchKernelGGL((fastq_list_kernel<NW, BITS>), dim3(kListGroups), dim3(kListThreads), wave_lds * (kListThreads / kWave), ctx->stream, in,
-                       n_tiles, idx->shape.k, LP::max_runs(idx->shape.k), wave_lds, line_base, sc.tile_off, win_pos, ctx->d_flags);
+                       n_tiles, idx->shape.k, LP::max_runs(idx->shape.k), wave_lds, line_base, ctx->d_flags, ent, ent_cnt,
+                       LP::ent_stride(idx->shape.k));
   }
   {
     ProfScope ps(ctx, "fastq_hist", n);
     hipLaunchKernelGGL((fastq_hist_list_kernel<NW, BITS>), dim3(fused_groups<NW>()), dim3(kHistThreads), 0, ctx->stream, in, n_tiles, idx->shape,
-                       canonical, sc.tile_off, (const uint16_t *)win_pos, w.fine_hist, w.wg_hist);
+                       canonical, (const uint16_t *)ent, (const uint32_t *)ent_cnt, LPC::ent_stride(idx->shape.k), w.fine_hist, w.wg_hist);
   }
   {
     ProfScope ps(ctx, "fine_offsets", kNumFine);
@@ -1770,7 +1830,8 @@ static kmi_status build_fused_impl(kmi_index *idx, const uint8_t *bytes_dev, siz
   {
     ProfScope ps(ctx, "fastq_scatter", n);
     hipLaunchKernelGGL((fastq_scatter_list_kernel<NW, BITS>), dim3(fused_groups<NW>()), dim3(ExCfg<NW, BITS>::NT), 0, ctx->stream, in,
-                       n_tiles, idx->shape, canonical, sc.tile_off, (const uint16_t *)win_pos, (const uint64_t *)w.wg_off, w.buf_a);
+                       n_tiles, idx->shape, canonical, (const uint16_t *)ent, (const uint32_t *)ent_cnt, LPC::ent_stride(idx->shape.k),
+                       (const uint64_t *)nullptr, (const uint64_t *)w.wg_off, w.buf_a);
   }
   {
     ProfScope ps(ctx, "scatter_fine", n);
@@ -2015,8 +2076,11 @@ static kmi_status extract_route_impl(kmi_ctx *ctx, const kmi_config *cfg, KShape
   KMI_TRY(ws_get(ctx, WS_WGHIST, sizeof(uint32_t) * kPartGroups * kNumCoarse, &p)); uint32_t *wg_hist = (uint32_t *)p;
   KMI_TRY(ws_get(ctx, WS_CURSOR, sizeof(uint64_t) * kPartGroups * kNumCoarse, &p)); uint64_t *wg_off = (uint64_t *)p;
   KMI_TRY(ws_get(ctx, WS_MISC, sizeof(uint64_t) * kNumCoarse * 2, &p)); uint64_t *cnt = (uint64_t *)p;
-  KMI_TRY(ws_get(ctx, WS_WIN_LIST, sizeof(uint16_t) * (n + 64), &p)); uint16_t *win_pos = (uint16_t *)p;
-  KMI_TRY(ws_get(ctx, WS_WIN_LIST2, sizeof(uint32_t) * (n + 64), &p)); uint32_t *win_pb = (uint32_t *)p;
+  using LPC = ListPassCfg<NW, BITS>;
+  KMI_TRY(ws_get(ctx, WS_ENT_LIST, sizeof(uint16_t) * ((size_t)n_tiles * LPC::ent_stride(shape.k) + 64), &p)); uint16_t *ent = (uint16_t *)p;
+  KMI_TRY(ws_get(ctx, WS_ENT_CNT, sizeof(uint32_t) * (n_tiles + 8), &p)); uint32_t *ent_cnt = (uint32_t *)p;
+  KMI_TRY(ws_get(ctx, WS_ENT_BKT, sizeof(uint64_t) * ((size_t)n_tiles * ListPassCfg<NW, BITS>::ent_stride(shape.k) + 64), &p));
+  uint64_t *ent_bkt = (uint64_t *)p;
   BucketFn fn; fn.mode = BUCKET_RANK; fn.shape = shape; fn.dist_hash = cfg->dist_hash; fn.farm_ndebug = cfg->farm_ndebug != 0; fn.nranks = nranks;
   fn.sub = rank_sub_buckets(nranks);
   const uint32_t nb = nranks * fn.sub;
@@ -2025,12 +2089,13 @@ static kmi_status extract_route_impl(kmi_ctx *ctx, const kmi_config *cfg, KShape
     using LP = ListPassCfg<NW, BITS>;
     const uint32_t wave_lds = LP::wave_lds_bytes(shape.k);
     hipLaunchKernelGGL((fastq_list_kernel<NW, BITS>), dim3(kListGroups), dim3(kListThreads), wave_lds * (kListThreads / kWave), ctx->stream, in,
-                       n_tiles, shape.k, LP::max_runs(shape.k), wave_lds, sc.line_base, sc.tile_off, win_pos, ctx->d_flags);
+                       n_tiles, shape.k, LP::max_runs(shape.k), wave_lds, sc.line_base, ctx->d_flags, ent, ent_cnt,
+                       LP::ent_stride(shape.k));
   }
   {
     ProfScope ps(ctx, "fastq_rank_hist", n);
     hipLaunchKernelGGL((fastq_rank_hist_list_kernel<NW, BITS, 512>), dim3(fused_groups<NW>()), dim3(512), 0, ctx->stream, in, n_tiles, shape, canonical,
-                       sc.tile_off, (const uint16_t *)win_pos, fn, wg_hist, win_pb);
+                       (const uint16_t *)ent, (const uint32_t *)ent_cnt, LPC::ent_stride(shape.k), fn, wg_hist, ent_bkt);
   }
   {
     ProfScope ps(ctx, "rank_offsets", nb);
@@ -2039,7 +2104,8 @@ static kmi_status extract_route_impl(kmi_ctx *ctx, const kmi_config *cfg, KShape
   {
     ProfScope ps(ctx, "fastq_rank_scatter", n);
     hipLaunchKernelGGL((fastq_scatter_list_kernel<NW, BITS, true>), dim3(fused_groups<NW>()), dim3(ExCfg<NW, BITS>::NT), 0, ctx->stream, in, n_tiles,
-                       shape, canonical, sc.tile_off, (const uint32_t *)win_pb, (const uint64_t *)wg_off, out_keys_dev);
+                       shape, canonical, (const uint16_t *)ent, (const uint32_t *)ent_cnt, LPC::ent_stride(shape.k), (const uint64_t *)ent_bkt,
+                       (const uint64_t *)wg_off, out_keys_dev);
   }
   KMI_HIP(ctx, hipGetLastError());
   KMI_TRY(read_rank_counts(ctx, cnt, nranks, fn.sub, send_counts_host));

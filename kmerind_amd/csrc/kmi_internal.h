@@ -39,8 +39,9 @@ enum WsSlot {
   WS_FA_IDS,          // LongSequenceKmerId of every compacted FASTA character
   WS_PK_EOL,          // EOL bitmap of the scanned input
   WS_PK_STREAM,       // packed complement-code stream of the scanned input
-  WS_WIN_LIST,        // tile position of every k-mer window, file order (fused build)
-  WS_WIN_LIST2,       // position | rank bucket << 16 of every window (fused extract + route)
+  WS_ENT_BKT,         // rank bucket of the 8 windows of every entry, one byte each (fused extract + route)
+  WS_ENT_LIST,        // entry list: runs of <= 8 consecutive windows, per-tile slots (fused build)
+  WS_ENT_CNT,         // entries per scan tile
   WS_NUM_SLOTS
 };
 
