@@ -26,15 +26,15 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md)
 # total = 1/12). The roofline entry prices the dominant kernel with its own figure.
 KERNEL_ALG_BYTES = {
     "fastq_scan_tiles": 2.625 + 2.625 * (2 + 1) / 8,       # raw bytes in; 2-bit stream + EOL bitmap out
-    "fastq_list": 2.625 / 8 + 2.0,                         # EOL bitmap in; 2-byte window position out
-    "fastq_hist": 2.0 + 2.625 * 2 / 8,                     # window list + packed stream in
-    "fastq_scatter": 2.0 + 2.625 * 2 / 8 + 8.0,            # list + stream in; 8-byte key out
+    "fastq_list": 2.625 / 8 + 0.25,                        # EOL bitmap in; one 2-byte entry per 8 windows out
+    "fastq_hist": 0.25 + 2.625 * 2 / 8,                    # entry list + packed stream in
+    "fastq_scatter": 0.25 + 2.625 * 2 / 8 + 8.0,           # entries + stream in; 8-byte key out
     "scatter_fine": 16.0,                                  # key in, key out
     "bucket_reduce": 8.0 + 12.0 / 12,                      # key in; (key, count) of each distinct key out
     "bucket_compact": 2 * 12.0 / 12,
     # N > 1 and insert-from-keys paths
-    "fastq_rank_hist": 2.0 + 2.625 * 2 / 8,
-    "fastq_rank_scatter": 2.0 + 2.625 * 2 / 8 + 8.0,
+    "fastq_rank_hist": 0.25 + 2.625 * 2 / 8 + 1.0,         # + one rank-bucket byte per window out
+    "fastq_rank_scatter": 1.25 + 2.625 * 2 / 8 + 8.0,
     "hist_fine": 8.0,
     "scatter_coarse": 16.0,
 }

@@ -44,6 +44,7 @@ constexpr int kPartThreads = 1024;           // K1/K2/P2 workgroup size
 constexpr int kPartGroups = 512;             // K1/K2 workgroups (two per CU)
 constexpr int kFineParts = 2;                // P2 workgroups per coarse bucket; part h = K2 groups [h*256, (h+1)*256)
 // workgroups of the list-driven histogram and scatter passes (they own the same tiles)
+// workgroups of the fused passes (E1 and E2 cut the scan tiles the same way)
 template <int NW> constexpr int fused_groups() { return kPartGroups; }
 constexpr int kListGroups = 2048;            // workgroups of the window-list pass (small LDS footprint: eight per CU)
 constexpr int kLoadBatch = 8;                // independent key loads kept in flight per thread
@@ -373,7 +374,9 @@ __global__ __launch_bounds__(kPartThreads) void scatter_fine_kernel(const uint64
 
 
 // P2 for one-word keys, whole-line form (written over the bucket count NB; with NB = 256, i.e. for K2 / E2, the carry
-// takes half the stage and the form measured no faster than the plain one, so only P2 uses it). The runs a tile-wise bucket sort emits start and end wherever the
+// takes half the stage: a whole-line E2 with one 1024-thread workgroup per CU and a 128 KB stage measured 4.4 ms
+// against 4.2 ms for the plain form -- E2 is bound by instruction issue (61 VALU per window, rocprofv3 SQ counters),
+// not by its partial lines -- so only P2 uses it). The runs a tile-wise bucket sort emits start and end wherever the
 // cursors happen to stand, so every wave store begins and ends inside a 128-byte line, and such partial-line
 // writes cost 1.4-1.6x (tools/microbench6.hip). Here a bucket only ever emits whole lines: after the one
 // unaligned head of its stream, what it has (carry + the tile's new keys) is cut at the last line boundary, the
