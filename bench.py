@@ -36,6 +36,8 @@ KERNEL_ALG_BYTES = {
     "fastq_rank_hist": 0.25 + 2.625 * 2 / 8 + 1.0,         # + one rank-bucket byte per window out
     "fastq_rank_scatter": 1.25 + 2.625 * 2 / 8 + 8.0,
     "hist_fine": 8.0,
+    # combine-first exchange (units are index entries, not k-mers)
+    "split_count": 9.0, "split_scatter": 25.0, "bucket_merge": 24.0,
     "scatter_coarse": 16.0,
 }
 
@@ -51,6 +53,9 @@ def main():
     ap.add_argument("--cpu-sample-reads", type=int, default=500_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the extract-only / insert-only / query rates (outside the timed steps)")
+    ap.add_argument("--dist-mode", default="combine", choices=["combine", "raw"],
+                    help="N > 1: 'combine' reduces the rank's own reads first and exchanges (k-mer, count) pairs; 'raw' routes "
+                         "every k-mer occurrence as the reference does (kmi_extract_route_dev + insert)")
     ap.add_argument("--force-dist", action="store_true",
                     help="run the N > 1 code path (routing + all_to_all_single + insert) even with one rank: exercises the RCCL calls on one GPU")
     ap.add_argument("--chunks", type=int, default=4, help="N > 1: chunks per step (exchange of one overlaps parsing of the next)")
@@ -77,6 +82,9 @@ def main():
     dev = torch.device("cuda", local_rank)
     multi = world > 1 or args.force_dist
     if multi:
+        if args.force_dist and "RANK" not in os.environ:      # one-rank rehearsal started without torch.distributed.run
+            for key, val in (("RANK", "0"), ("WORLD_SIZE", "1"), ("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29541")):
+                os.environ.setdefault(key, val)
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -98,7 +106,15 @@ def main():
     idx = K.CountIndex(ctx, cfg)
     n_kmers = n_reads * kmers_per_read
 
-    if multi:
+    combine = multi and args.dist_mode == "combine"
+    nch = 1
+    if combine:
+        # N > 1, combine-first (kmerind_amd.dist.DistributedCountIndex): local count index of the rank's reads (the one-rank
+        # pipeline), split by KeyToRank, all_to_all_single of (k-mer, count) pairs + per-bucket counts, merge.
+        didx = kdist.DistributedCountIndex(ctx, cfg, stage_through_host=(args.backend != "nccl"), device=dev)
+        idx.close()
+        idx = didx.index
+    elif multi:
         # N > 1: the batch goes through in NCH record-aligned chunks. Chunk c is parsed and grouped by destination rank
         # on the device (kmi_extract_route_dev: read_file + the bucketing half of imxx::distribute, fused) while the
         # all-to-all of chunk c-1 is still travelling over xGMI on RCCL's stream; every rank then inserts what it
@@ -123,6 +139,9 @@ def main():
         idx.clear()
         if not multi:
             idx.build_device(d_bytes.data_ptr(), nbytes)
+            return
+        if combine:
+            didx.build_device(d_bytes.data_ptr(), nbytes, dev)
             return
         pos, works = 0, []
         for c in range(nch):
@@ -214,7 +233,9 @@ def main():
                           "kmers_per_step": total_kmers, "distinct_kmers": distinct,
                           "exchange": "none (1 rank)" if not multi else
                           "%s all_to_all_single (counts + payload), %d chunks per step, overlapped with parsing" %
-                          ("RCCL" if args.backend == "nccl" else "gloo (rehearsal)", nch)},
+                          ("RCCL" if args.backend == "nccl" else "gloo (rehearsal)", nch) if not combine else
+                          "%s all_to_all_single of locally reduced (k-mer, count) pairs + per-bucket counts" %
+                          ("RCCL" if args.backend == "nccl" else "gloo (rehearsal)")},
                "roofline": roofline}
         if not multi and not args.no_extra:
             out["extra"] = extra_rates(ctx, cfg, idx, d_bytes, nbytes, n_kmers, dev, torch)
@@ -222,7 +243,10 @@ def main():
             out["cpu_baseline"] = cpu_baseline(host, args, k, n_reads)
         print(json.dumps(out), flush=True)
 
-    idx.close()
+    if combine:
+        didx.close()
+    else:
+        idx.close()
     ctx.close()
     if multi:
         dist.destroy_process_group()

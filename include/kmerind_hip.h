@@ -217,6 +217,28 @@ kmi_status kmi_index_insert_tuples_host(kmi_index *idx, const uint64_t *kmers, c
 kmi_status kmi_index_insert_tuples_dev(kmi_index *idx, const uint64_t *records_dev, size_t n);
 kmi_status kmi_index_export_tuples_host(kmi_index *idx, uint64_t *keys, uint64_t *values, size_t capacity, uint64_t *n);
 
+/* ---- combine-first distributed insert of the count index (N > 1 ranks) ------------------------------------
+ * The reference's counting maps send every k-mer occurrence through imxx::distribute and reduce at the receiver
+ * (distributed_unordered_map.hpp:1715-1745 / distributed_densehash_map.hpp:2584-2610; the local_reduction before
+ * the exchange is there but commented out). Integer counts add up associatively, so a rank may reduce its own
+ * reads first: it builds a local count index of its partition (kmi_index_build_*), splits the entries by
+ * KeyToRank, exchanges (k-mer, count) pairs, and every rank merges what it receives. The resulting distributed
+ * index is the reference's (key on rank DistHash(DistTrans(key)) % p, value = occurrences over all ranks); the
+ * exchanged volume shrinks by the local coverage.
+ *
+ * kmi_index_num_buckets(): the fixed number B of placement buckets every index uses (entries of a bucket are
+ * contiguous; the placement hash is the same on all ranks).
+ * kmi_index_split_by_rank_dev: the entries of `idx` grouped by destination rank (message r starts at the sum of
+ * send_counts_host[0..r)), and inside a message ordered by placement bucket; bucket_counts_dev[r * B + b] = entries
+ * of message r in bucket b. out buffers hold `capacity` >= kmi_index_local_size entries. `idx` is not changed.
+ * kmi_index_merge_parts_dev: kmers_dev / counts_dev = nparts such messages back to back (part s holds
+ * sum_b bucket_counts_dev[s * B + b] pairs); their counts are added into `idx`. */
+uint32_t kmi_index_num_buckets(void);
+kmi_status kmi_index_split_by_rank_dev(kmi_index *idx, uint32_t nranks, uint64_t *out_kmers_dev, uint32_t *out_counts_dev,
+                                       size_t capacity, uint32_t *bucket_counts_dev, uint64_t *send_counts_host);
+kmi_status kmi_index_merge_parts_dev(kmi_index *idx, uint32_t nparts, const uint64_t *kmers_dev, const uint32_t *counts_dev,
+                                     const uint32_t *bucket_counts_dev);
+
 /* ---- measurement support --------------------------------------------------- */
 /* per-kernel HIP-event timing on the context's stream (bench.py roofline leg) */
 kmi_status kmi_profile_enable(kmi_ctx *ctx, int on);

@@ -97,6 +97,9 @@ SIGNATURES = {
     "kmi_index_insert_tuples_host": (C.c_int, [_P, _P, _P, _sz]),
     "kmi_index_insert_tuples_dev": (C.c_int, [_P, _P, _sz]),
     "kmi_index_export_tuples_host": (C.c_int, [_P, _P, _P, _sz, C.POINTER(_u64)]),
+    "kmi_index_num_buckets": (C.c_uint32, []),
+    "kmi_index_split_by_rank_dev": (C.c_int, [_P, _u32, _P, _P, _sz, _P, _P]),
+    "kmi_index_merge_parts_dev": (C.c_int, [_P, _u32, _P, _P, _P]),
     "kmi_profile_enable": (C.c_int, [_P, C.c_int]),
     "kmi_profile_reset": (C.c_int, [_P]),
     "kmi_profile_get": (C.c_int, [_P, C.POINTER(KernelTime), _sz, C.POINTER(_sz)]),

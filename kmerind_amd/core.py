@@ -170,6 +170,10 @@ class Context:
                  "units": arr[i].units} for i in range(min(n.value, 64))]
 
 
+def num_buckets():
+    return int(lib.kmi_index_num_buckets())
+
+
 class CountIndex:
     """bliss::index::kmer::CountIndex<counting map> on one rank (kmer_index.hpp:409-410)."""
 
@@ -215,6 +219,19 @@ class CountIndex:
         return n.value
 
     size = local_size  # single-rank view; kmerind_amd.dist adds the all-reduce
+
+    # combine-first distributed insert (kmerind_hip.h): split the entries by destination rank / merge received parts
+    def split_by_rank_device(self, nranks, keys_dptr, counts_dptr, capacity, bucket_counts_dptr):
+        """-> send counts per rank (numpy uint64). Device buffers: keys [capacity * n_words] u64, counts [capacity] u32,
+        bucket counts [nranks * num_buckets()] u32."""
+        sc = np.zeros(nranks, dtype=np.uint64)
+        self.ctx.check(lib.kmi_index_split_by_rank_dev(self.h, nranks, C.c_void_p(keys_dptr), C.c_void_p(counts_dptr), capacity,
+                                                       C.c_void_p(bucket_counts_dptr), sc.ctypes.data_as(C.c_void_p)))
+        return sc
+
+    def merge_parts_device(self, nparts, keys_dptr, counts_dptr, bucket_counts_dptr):
+        self.ctx.check(lib.kmi_index_merge_parts_dev(self.h, nparts, C.c_void_p(keys_dptr), C.c_void_p(counts_dptr),
+                                                     C.c_void_p(bucket_counts_dptr)))
 
     def to_vector(self):
         n = self.local_size()

@@ -1440,6 +1440,160 @@ __global__ __launch_bounds__((TabCfg<NW>::NT)) void bucket_reduce_kernel(const u
   if (threadIdx.x == 0) out_cnt[b] = *s_out;
 }
 
+// ---------------------------------------------------------------------------
+// Combine-first distributed insert of the count index (N > 1). The reference sends every k-mer occurrence through
+// imxx::distribute and reduces at the receiver (distributed_unordered_map.hpp:1715-1745; its local_reduction before
+// the exchange exists but is commented out). Counts add up associatively, so reducing the rank's own reads first gives
+// the same index and cuts the exchanged volume by the local coverage: the rank builds a local count index of its
+// reads (the one-rank pipeline), SPLITS its entries by KeyToRank keeping fine-bucket order inside every rank's
+// message, exchanges (k-mer, count) pairs plus the per-bucket counts, and MERGES the p bucket-ordered parts it
+// receives into its index without partitioning anything again (all ranks use the same placement hash).
+// ---------------------------------------------------------------------------
+// split 1: destination rank of every entry (kept, one byte) and the (rank, bucket) counts
+template <int NW>
+__global__ __launch_bounds__(256) void split_count_kernel(const uint64_t *__restrict__ keys, const uint64_t *__restrict__ off, BucketFn fn,
+                                                         uint8_t *__restrict__ rank_of, uint32_t *__restrict__ cnt /* [nranks][kNumFine] */) {
+  __shared__ uint32_t s_cnt[kNumCoarse];
+  const uint32_t b = blockIdx.x;
+  if (threadIdx.x < fn.nranks) s_cnt[threadIdx.x] = 0;
+  lds_barrier();
+  const uint64_t e0 = off[b], e1 = off[b + 1];
+  const uint32_t pbits = ceil_log2_u32(fn.nranks);
+  for (uint64_t i = e0 + threadIdx.x; i < e1; i += 256) {
+    uint64_t k[NW];
+#pragma unroll
+    for (int w = 0; w < NW; ++w) k[w] = keys[i * NW + w];
+    const uint32_t r = (uint32_t)(kmer_hash<NW>(k, fn.shape, fn.dist_hash, true, fn.farm_ndebug, pbits) % fn.nranks);
+    rank_of[i] = (uint8_t)r;
+    atomicAdd(&s_cnt[r], 1u);
+  }
+  lds_barrier();
+  if (threadIdx.x < fn.nranks) cnt[(uint64_t)threadIdx.x * kNumFine + b] = s_cnt[threadIdx.x];
+}
+
+// per part (rank): exclusive scan of its bucket counts -> boff[part][kNumFine + 1]; tot[part]
+__global__ __launch_bounds__(1024) void part_offsets_kernel(const uint32_t *__restrict__ cnt, uint64_t *__restrict__ boff, uint64_t *__restrict__ tot) {
+  __shared__ uint64_t s_scan[1024 / 64 + 2];
+  constexpr int PER = kNumFine / 1024;
+  const uint32_t *c = cnt + (uint64_t)blockIdx.x * kNumFine;
+  uint64_t *o = boff + (uint64_t)blockIdx.x * (kNumFine + 1);
+  uint64_t loc[PER], sum = 0;
+#pragma unroll
+  for (int i = 0; i < PER; ++i) { loc[i] = c[threadIdx.x * PER + i]; sum += loc[i]; }
+  uint64_t total;
+  uint64_t x = block_exclusive_scan<uint64_t>(sum, s_scan, &total);
+#pragma unroll
+  for (int i = 0; i < PER; ++i) { o[threadIdx.x * PER + i] = x; x += loc[i]; }
+  if (threadIdx.x == 0) { o[kNumFine] = total; tot[blockIdx.x] = total; }
+}
+
+// base[r] = entries of the parts before r (nparts <= 256); base[nparts] = all
+__global__ __launch_bounds__(256) void part_bases_kernel(const uint64_t *__restrict__ tot, uint32_t nparts, uint64_t *__restrict__ base) {
+  __shared__ uint64_t s_scan[256 / 64 + 2];
+  const uint64_t v = threadIdx.x < nparts ? tot[threadIdx.x] : 0ull;
+  uint64_t total;
+  const uint64_t x = block_exclusive_scan<uint64_t>(v, s_scan, &total);
+  if (threadIdx.x < nparts) base[threadIdx.x] = x;
+  if (threadIdx.x == 0) base[nparts] = total;
+}
+
+// split 2: entries of bucket b to their rank's message, at base[r] + boff[r][b] (order inside is free)
+template <int NW>
+__global__ __launch_bounds__(256) void split_scatter_kernel(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ vals,
+                                                           const uint64_t *__restrict__ off, const uint8_t *__restrict__ rank_of, uint32_t nranks,
+                                                           const uint64_t *__restrict__ boff, const uint64_t *__restrict__ base,
+                                                           uint64_t *__restrict__ out_keys, uint32_t *__restrict__ out_vals) {
+  __shared__ uint32_t s_pos[kNumCoarse];
+  __shared__ uint64_t s_dst[kNumCoarse];
+  const uint32_t b = blockIdx.x;
+  if (threadIdx.x < nranks) {
+    s_pos[threadIdx.x] = 0;
+    s_dst[threadIdx.x] = base[threadIdx.x] + boff[(uint64_t)threadIdx.x * (kNumFine + 1) + b];
+  }
+  lds_barrier();
+  const uint64_t e0 = off[b], e1 = off[b + 1];
+  for (uint64_t i = e0 + threadIdx.x; i < e1; i += 256) {
+    const uint32_t r = rank_of[i];
+    const uint64_t d = s_dst[r] + atomicAdd(&s_pos[r], 1u);
+#pragma unroll
+    for (int w = 0; w < NW; ++w) out_keys[d * NW + w] = keys[i * NW + w];
+    out_vals[d] = vals[i];
+  }
+}
+
+// comb[b] = sum over the parts of boff[part][b]  (b = 0 .. kNumFine)
+__global__ __launch_bounds__(256) void parts_sum_kernel(const uint64_t *__restrict__ boff, uint32_t nparts, uint64_t *__restrict__ comb) {
+  const uint32_t b = blockIdx.x * 256 + threadIdx.x;
+  if (b > (uint32_t)kNumFine) return;
+  uint64_t x = 0;
+  for (uint32_t s = 0; s < nparts; ++s) x += boff[(uint64_t)s * (kNumFine + 1) + b];
+  comb[b] = x;
+}
+
+// merge: bucket b of the index and bucket b of every received part -> one table; same output contract as
+// bucket_reduce_kernel (tmp arrays at comb[b] + old_off[b], out_cnt[b] = distinct)
+template <int NW>
+__global__ __launch_bounds__((TabCfg<NW>::NT)) void bucket_merge_kernel(const uint64_t *__restrict__ part_keys, const uint32_t *__restrict__ part_vals,
+                                                                       uint32_t nparts, const uint64_t *__restrict__ base,
+                                                                       const uint64_t *__restrict__ boff, const uint64_t *__restrict__ comb,
+                                                                       const uint64_t *__restrict__ old_keys, const uint32_t *__restrict__ old_vals,
+                                                                       const uint64_t *__restrict__ old_off, uint64_t *__restrict__ tmp_keys,
+                                                                       uint32_t *__restrict__ tmp_vals, uint32_t *__restrict__ out_cnt,
+                                                                       uint32_t *__restrict__ flags) {
+  KMI_TABLE_LDS(NW)
+  const uint32_t b = blockIdx.x;
+  const uint64_t ob = old_off ? old_off[b] : 0ull, oe = old_off ? old_off[b + 1] : 0ull;
+  if (comb[b] == comb[b + 1] && ob == oe) { if (threadIdx.x == 0) out_cnt[b] = 0; return; }
+  const uint64_t tmp0 = comb[b] + ob;
+  uint32_t *s_out = &s_ctl[4];
+  uint32_t npass = 1;
+  while (true) {
+    if (threadIdx.x == 0) *s_out = 0;
+    bool failed = false;
+    for (uint32_t pass = 0; pass < npass && !failed; ++pass) {
+      table_clear<NW>(tab);
+      lds_barrier();
+      auto add = [&](const uint64_t *keys, const uint32_t *vals, uint64_t kb, uint64_t ke) {
+        for_each_key<NW, BatchOf<NW>::U>(keys, kb, ke, [&](const uint64_t (&k)[NW], uint64_t i) {
+          const uint32_t h = place_hash<NW>(k);
+          if (pass_of(h, npass) != pass) return;
+          int s = table_upsert<NW>(tab, k, h);
+          if (s >= 0) atomicAdd(&tab.vals[s], vals[i]);
+          else if (s == -2) atomicAdd(tab.special, vals[i]);
+        });
+      };
+      add(old_keys, old_vals, ob, oe);
+      for (uint32_t s = 0; s < nparts; ++s) {
+        const uint64_t *bo = boff + (uint64_t)s * (kNumFine + 1);
+        add(part_keys, part_vals, base[s] + bo[b], base[s] + bo[b + 1]);
+      }
+      lds_barrier();
+      if (*tab.overflow) { failed = true; break; }
+      for (int s = threadIdx.x; s < TabCfg<NW>::SLOTS; s += blockDim.x) {
+        const bool used = slot_used<NW>(tab, s);
+        const uint32_t pos = wave_alloc(s_out, used);
+        if (used) {
+#pragma unroll
+          for (int w = 0; w < NW; ++w) tmp_keys[(tmp0 + pos) * NW + w] = tab.keys[(uint64_t)s * NW + w];
+          tmp_vals[tmp0 + pos] = tab.vals[s];
+        }
+      }
+      lds_barrier();
+      if (NW == 1 && threadIdx.x == 0 && *tab.special_set) {
+        const uint32_t pos = atomicAdd(s_out, 1u);
+        tmp_keys[(tmp0 + pos) * NW] = kEmptyKey;
+        tmp_vals[tmp0 + pos] = *tab.special;
+      }
+      lds_barrier();
+    }
+    if (!failed) break;
+    npass *= 2;
+    if (npass > kMaxPasses) { if (threadIdx.x == 0) { atomicOr(&flags[2], 1u); *s_out = 0; } lds_barrier(); break; }
+    lds_barrier();
+  }
+  if (threadIdx.x == 0) out_cnt[b] = *s_out;
+}
+
 // scan of per-bucket counts -> offsets (kNumFine+1) ; totals[slot] = total
 __global__ __launch_bounds__(1024) void bucket_offsets_kernel(const uint32_t *__restrict__ cnt, uint64_t *__restrict__ off,
                                                              uint64_t *__restrict__ totals, int slot) {
@@ -2115,6 +2269,73 @@ static kmi_status extract_route_impl(kmi_ctx *ctx, const kmi_config *cfg, KShape
   return fastq_length_verdict(ctx);   // the length rule rode on the list pass
 }
 
+// split of a count index by destination rank (see "Combine-first distributed insert")
+template <int NW, int BITS>
+static kmi_status split_impl(kmi_index *idx, uint32_t nranks, uint64_t *out_keys_dev, uint32_t *out_counts_dev, size_t capacity,
+                             uint32_t *bucket_cnt_dev, uint64_t *send_counts_host) {
+  kmi_ctx *ctx = idx->ctx;
+  const uint64_t n = idx->n_entries;
+  if (n > capacity) return set_err(ctx, KMI_ERR_OVERFLOW, "output capacity is smaller than the number of index entries");
+  void *p;
+  KMI_TRY(ws_get(ctx, WS_SPLIT_RANK, n + 64, &p)); uint8_t *rank_of = (uint8_t *)p;
+  KMI_TRY(ws_get(ctx, WS_SPLIT_OFF, sizeof(uint64_t) * ((size_t)nranks * (kNumFine + 1) + 2 * (kNumCoarse + 1)), &p));
+  uint64_t *boff = (uint64_t *)p, *tot = boff + (size_t)nranks * (kNumFine + 1), *base = tot + kNumCoarse + 1;
+  BucketFn fn; fn.mode = BUCKET_RANK; fn.shape = idx->shape; fn.dist_hash = idx->cfg.dist_hash; fn.farm_ndebug = idx->cfg.farm_ndebug != 0;
+  fn.nranks = nranks; fn.sub = 1;
+  {
+    ProfScope ps(ctx, "split_count", n);
+    hipLaunchKernelGGL((split_count_kernel<NW>), dim3(kNumFine), dim3(256), 0, ctx->stream, (const uint64_t *)idx->keys,
+                       (const uint64_t *)idx->bucket_off, fn, rank_of, bucket_cnt_dev);
+  }
+  {
+    ProfScope ps(ctx, "split_offsets", (uint64_t)nranks * kNumFine);
+    hipLaunchKernelGGL(part_offsets_kernel, dim3(nranks), dim3(1024), 0, ctx->stream, (const uint32_t *)bucket_cnt_dev, boff, tot);
+    hipLaunchKernelGGL(part_bases_kernel, dim3(1), dim3(256), 0, ctx->stream, (const uint64_t *)tot, nranks, base);
+  }
+  {
+    ProfScope ps(ctx, "split_scatter", n);
+    hipLaunchKernelGGL((split_scatter_kernel<NW>), dim3(kNumFine), dim3(256), 0, ctx->stream, (const uint64_t *)idx->keys, (const uint32_t *)idx->vals,
+                       (const uint64_t *)idx->bucket_off, (const uint8_t *)rank_of, nranks, (const uint64_t *)boff, (const uint64_t *)base,
+                       out_keys_dev, out_counts_dev);
+  }
+  KMI_HIP(ctx, hipGetLastError());
+  KMI_HIP(ctx, hipMemcpyAsync(send_counts_host, tot, sizeof(uint64_t) * nranks, hipMemcpyDeviceToHost, ctx->stream));
+  KMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return KMI_OK;
+}
+
+template <int NW, int BITS>
+static kmi_status merge_impl(kmi_index *idx, uint32_t nparts, const uint64_t *keys_dev, const uint32_t *counts_dev, const uint32_t *bucket_cnt_dev) {
+  kmi_ctx *ctx = idx->ctx;
+  void *p;
+  KMI_TRY(ws_get(ctx, WS_SPLIT_OFF, sizeof(uint64_t) * ((size_t)nparts * (kNumFine + 1) + 2 * (kNumCoarse + 1)), &p));
+  uint64_t *boff = (uint64_t *)p, *tot = boff + (size_t)nparts * (kNumFine + 1), *base = tot + kNumCoarse + 1;
+  KMI_TRY(ws_get(ctx, WS_BUCKET_OFF, sizeof(uint64_t) * (kNumFine + 1), &p)); uint64_t *comb = (uint64_t *)p;
+  {
+    ProfScope ps(ctx, "merge_offsets", (uint64_t)nparts * kNumFine);
+    hipLaunchKernelGGL(part_offsets_kernel, dim3(nparts), dim3(1024), 0, ctx->stream, bucket_cnt_dev, boff, tot);
+    hipLaunchKernelGGL(part_bases_kernel, dim3(1), dim3(256), 0, ctx->stream, (const uint64_t *)tot, nparts, base);
+    hipLaunchKernelGGL(parts_sum_kernel, dim3(kNumFine / 256 + 1), dim3(256), 0, ctx->stream, (const uint64_t *)boff, nparts, comb);
+  }
+  uint64_t n_in = 0;
+  KMI_HIP(ctx, hipMemcpyAsync(&n_in, base + nparts, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+  KMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (n_in == 0) return KMI_OK;
+  const uint64_t cap = n_in + idx->n_entries;
+  KMI_TRY(ws_get(ctx, WS_TMP_KEYS, cap * NW * sizeof(uint64_t), &p)); uint64_t *tmp_keys = (uint64_t *)p;
+  KMI_TRY(ws_get(ctx, WS_TMP_VALS, cap * sizeof(uint32_t), &p)); uint32_t *tmp_vals = (uint32_t *)p;
+  KMI_TRY(ws_get(ctx, WS_BUCKET_CNT, sizeof(uint32_t) * kNumFine, &p)); uint32_t *out_cnt = (uint32_t *)p;
+  {
+    ProfScope ps(ctx, "bucket_merge", n_in);
+    hipLaunchKernelGGL((bucket_merge_kernel<NW>), dim3(kNumFine), dim3(TabCfg<NW>::NT), 0, ctx->stream, keys_dev, counts_dev, nparts,
+                       (const uint64_t *)base, (const uint64_t *)boff, (const uint64_t *)comb, (const uint64_t *)idx->keys,
+                       (const uint32_t *)idx->vals, (const uint64_t *)(idx->has_data ? idx->bucket_off : nullptr), tmp_keys, tmp_vals, out_cnt,
+                       ctx->d_flags);
+  }
+  KMI_HIP(ctx, hipGetLastError());
+  return adopt_tmp<NW>(idx, tmp_keys, tmp_vals, comb, idx->has_data ? idx->bucket_off : nullptr, out_cnt);
+}
+
 }  // namespace kmi
 
 extern "C" {
@@ -2401,6 +2622,36 @@ kmi_status kmi_index_export_tuples_host(kmi_index *idx, uint64_t *keys, uint64_t
   KMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
   *n = idx->n_entries;
   return KMI_OK;
+}
+
+uint32_t kmi_index_num_buckets(void) { return (uint32_t)kmi::kNumFine; }
+
+kmi_status kmi_index_split_by_rank_dev(kmi_index *idx, uint32_t nranks, uint64_t *out_kmers_dev, uint32_t *out_counts_dev, size_t capacity,
+                                       uint32_t *bucket_counts_dev, uint64_t *send_counts_host) {
+  if (!idx) return KMI_ERR_INVALID;
+  kmi_ctx *ctx = idx->ctx;
+  if (idx->val_words) return set_err(ctx, KMI_ERR_INVALID, "only the count index splits into (k-mer, count) pairs");
+  if (nranks == 0 || nranks > (uint32_t)kmi::kNumCoarse || !send_counts_host || !bucket_counts_dev)
+    return set_err(ctx, KMI_ERR_INVALID, "nranks must be in 1..256 and the count buffers non-null");
+  KMI_HIP(ctx, hipSetDevice(ctx->device));
+  if (idx->n_entries == 0) {
+    for (uint32_t r = 0; r < nranks; ++r) send_counts_host[r] = 0;
+    KMI_HIP(ctx, hipMemsetAsync(bucket_counts_dev, 0, sizeof(uint32_t) * (size_t)nranks * kmi::kNumFine, ctx->stream));
+    KMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return KMI_OK;
+  }
+  if (!out_kmers_dev || !out_counts_dev) return set_err(ctx, KMI_ERR_INVALID, "null output buffer");
+  KMI_DISPATCH(idx->shape, kmi::split_impl, idx, nranks, out_kmers_dev, out_counts_dev, capacity, bucket_counts_dev, send_counts_host);
+}
+
+kmi_status kmi_index_merge_parts_dev(kmi_index *idx, uint32_t nparts, const uint64_t *kmers_dev, const uint32_t *counts_dev,
+                                     const uint32_t *bucket_counts_dev) {
+  if (!idx) return KMI_ERR_INVALID;
+  kmi_ctx *ctx = idx->ctx;
+  if (idx->val_words) return set_err(ctx, KMI_ERR_INVALID, "only the count index merges (k-mer, count) pairs");
+  if (nparts == 0 || nparts > (uint32_t)kmi::kNumCoarse || !bucket_counts_dev) return set_err(ctx, KMI_ERR_INVALID, "nparts must be in 1..256");
+  KMI_HIP(ctx, hipSetDevice(ctx->device));
+  KMI_DISPATCH(idx->shape, kmi::merge_impl, idx, nparts, kmers_dev, counts_dev, bucket_counts_dev);
 }
 
 }  // extern "C"

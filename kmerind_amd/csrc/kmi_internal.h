@@ -42,6 +42,8 @@ enum WsSlot {
   WS_ENT_BKT,         // rank bucket of the 8 windows of every entry, one byte each (fused extract + route)
   WS_ENT_LIST,        // entry list: runs of <= 8 consecutive windows, per-tile slots (fused build)
   WS_ENT_CNT,         // entries per scan tile
+  WS_SPLIT_RANK,      // destination rank of every index entry (split by rank)
+  WS_SPLIT_OFF,       // per-part bucket offsets, part totals and bases (split / merge)
   WS_NUM_SLOTS
 };
 

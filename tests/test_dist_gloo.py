@@ -73,3 +73,60 @@ def test_sharded_build_over_gloo_matches_single_rank(world, msg_max):
         assert (orc.key_to_rank(s, orc.MURMUR, orc.CANONICAL, ret[r][0], world) == r).all()
         # all2all(counts): what r receives from src is what src sent to r
         assert ret[r][3] == [ret[src][4][r] for src in range(world)]
+
+
+def _pairs_worker(rank, world, port, data, k, nb, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from kmerind_amd import dist as kdist
+        from kmerind_amd import fileio
+        s = orc.kspec(k)
+        b, e = fileio.partition_fastq(data, world)[rank]
+        m = orc.CountMap(s, orc.CANONICAL)                          # the rank's local reduction
+        m.insert(orc.extract(s, data[b:e], orc.FASTQ, file_offset=b)["kmers"])
+        keys, cnts = m.export()
+        ranks = orc.key_to_rank(s, orc.MURMUR, orc.CANONICAL, keys, world)
+        bucket = (keys[:, 0] % np.uint64(nb)).astype(np.int64)      # stand-in for the device's placement buckets
+        order = np.lexsort([bucket, ranks])                         # by rank, then by bucket: the split's output order
+        bc = np.zeros((world, nb), dtype=np.int32)
+        np.add.at(bc, (ranks.astype(np.int64), bucket), 1)
+        rk, rv, rb = kdist.exchange_pairs(torch.from_numpy(keys[order].view(np.int64)), torch.from_numpy(cnts[order].astype(np.int32)),
+                                          torch.from_numpy(bc))
+        ret[rank] = (rk.numpy().view(np.uint64).copy(), rv.numpy().copy(), rb.numpy().copy(), bc)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_combine_first_exchange_over_gloo(world):
+    """exchange_pairs: the (k-mer, count) messages and the bucket-count matrix of the combine-first count insert. Row s of what
+    rank r receives is row r of what rank s sent; every part is still ordered by bucket; summing the received counts per key
+    gives the single-rank map."""
+    import kmerind_amd as K
+    k, nb = 31, 16
+    data = bytes(K.synth_fastq(seed=5, genome_len=5_000, n_reads=900))
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_pairs_worker, args=(world, _free_port(), data, k, nb, ret), nprocs=world, join=True)
+    s = orc.kspec(k)
+    ref = orc.CountMap(s, orc.CANONICAL)
+    ref.insert(orc.extract(s, data, orc.FASTQ)["kmers"])
+    merged = {}
+    for r in range(world):
+        rk, rv, rb, _ = ret[r]
+        assert rb.tolist() == [ret[src][3][r].tolist() for src in range(world)]
+        off = 0
+        for src in range(world):
+            n = int(rb[src].sum())
+            part = rk[off:off + n, 0]
+            assert (np.diff((part % np.uint64(nb)).astype(np.int64)) >= 0).all()      # bucket order survives the exchange
+            assert ((part % np.uint64(nb)).astype(np.int64) == np.repeat(np.arange(nb), rb[src])).all()
+            off += n
+        assert off == rk.shape[0] == rv.shape[0]
+        assert (orc.key_to_rank(s, orc.MURMUR, orc.CANONICAL, rk, world) == r).all()
+        for key, c in zip(rk[:, 0].tolist(), rv.tolist()):
+            merged[key] = merged.get(key, 0) + c
+    ek, ec = ref.export()
+    assert len(merged) == ek.shape[0]
+    assert all(merged[int(key)] == int(c) for key, c in zip(ek[:, 0], ec))

@@ -247,3 +247,64 @@ def test_extract_route_fused_matches_extract_then_key_to_rank(ctx):
         assert gk.shape == ek.shape
         go, eo = np.lexsort([gk[:, w] for w in range(gk.shape[1])]), np.lexsort([ek[:, w] for w in range(ek.shape[1])])
         assert (gk[go] == ek[eo]).all() and (gc[go] == ec[eo]).all()
+
+
+def test_combine_first_split_and_merge_replayed_on_one_device(ctx):
+    """The N > 1 count build, combine-first (kmi_index_split_by_rank_dev / kmi_index_merge_parts_dev): every rank's local
+    index split by KeyToRank -- message d holds exactly the entries whose key maps to rank d, ordered by placement
+    bucket with the advertised per-bucket counts -- and every destination's merge of the p parts it receives, replayed
+    on one device, equal the oracle's single map restricted to the keys of that rank. A second round merges into the
+    non-empty index (the index grows incrementally, like repeated Index::insert)."""
+    import kmerind_amd as K
+    nb = K.core.num_buckets()
+    for k, alpha, strand, dh, p in ((31, "DNA", "canonical", "murmur", 8), (21, "DNA", "single", "farm", 3),
+                                    (63, "DNA5", "canonical", "murmur", 2), (31, "DNA", "bimolecule", "identity", 5),
+                                    (15, "DNA", "canonical", "murmur", 1)):
+        cfg = K.make_config(k, alpha, strand=strand, dist_hash=dh)
+        s = orc.kspec(k, ALPHA[alpha])
+        hashes = {"murmur": orc.MURMUR, "farm": orc.FARM, "identity": orc.IDENTITY}
+        dest = [K.CountIndex(ctx, cfg) for _ in range(p)]
+        all_kmers = []
+        for rnd in range(2):
+            msgs = [[None] * p for _ in range(p)]                 # msgs[d][src] = (keys, counts, bucket counts)
+            for r in range(p):                                    # rank r reduces its own reads, then splits
+                data = np.asarray(K.synth_fastq(seed=11, genome_len=3000, n_reads=300, first_read=(rnd * p + r) * 300))
+                all_kmers.append(orc.extract(s, data.tobytes(), orc.FASTQ)["kmers"])
+                loc = K.CountIndex(ctx, cfg)
+                loc.build(data)
+                n, nw = loc.local_size(), loc.n_words
+                lk, lc = loc.to_vector()
+                dk, dc, db = ctx.alloc(n * nw * 8 + 64), ctx.alloc(n * 4 + 64), ctx.alloc(p * nb * 4)
+                sc = loc.split_by_rank_device(p, dk, dc, n, db)
+                ok, oc, ob = np.zeros((n, nw), np.uint64), np.zeros(n, np.uint32), np.zeros((p, nb), np.uint32)
+                ctx.to_host(ok, dk); ctx.to_host(oc, dc); ctx.to_host(ob, db)
+                ctx.free(dk); ctx.free(dc); ctx.free(db)
+                assert loc.local_size() == n                      # the split leaves the index as it was
+                loc.close()
+                ranks = orc.key_to_rank(s, hashes[dh], STRAND[strand], lk, p)
+                assert sc.tolist() == np.bincount(ranks, minlength=p).tolist() == ob.sum(axis=1).tolist()
+                off = 0
+                for d in range(p):
+                    seg_k, seg_c = ok[off:off + int(sc[d])], oc[off:off + int(sc[d])]
+                    a, b = orc.sorted_pairs(seg_k, seg_c), orc.sorted_pairs(lk[ranks == d], lc[ranks == d])
+                    assert (a[0] == b[0]).all() and (a[1] == b[1]).all()
+                    msgs[d][r] = (seg_k, seg_c, ob[d])
+                    off += int(sc[d])
+            for d in range(p):                                    # destination d merges the p parts it received
+                mk = np.concatenate([m[0] for m in msgs[d]]); mc = np.concatenate([m[1] for m in msgs[d]])
+                mb = np.stack([m[2] for m in msgs[d]])
+                dk, dc, db = ctx.alloc(mk.nbytes + 64), ctx.alloc(mc.nbytes + 64), ctx.alloc(mb.nbytes)
+                if mk.size:
+                    ctx.to_device(dk, mk); ctx.to_device(dc, mc)
+                ctx.to_device(db, np.ascontiguousarray(mb))
+                dest[d].merge_parts_device(p, dk, dc, db)
+                ctx.free(dk); ctx.free(dc); ctx.free(db)
+        m = orc.CountMap(s, STRAND[strand])
+        m.insert(np.concatenate(all_kmers))
+        ek, ec = m.export()
+        eranks = orc.key_to_rank(s, hashes[dh], STRAND[strand], ek, p)
+        for d in range(p):
+            gk, gc = dest[d].to_vector()
+            a, b = orc.sorted_pairs(gk, gc), orc.sorted_pairs(ek[eranks == d], ec[eranks == d])
+            assert a[0].shape == b[0].shape and (a[0] == b[0]).all() and (a[1] == b[1]).all()
+            dest[d].close()
