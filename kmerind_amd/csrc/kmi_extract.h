@@ -293,30 +293,58 @@ __device__ __forceinline__ void window_at(const uint32_t *s_stream, uint32_t pos
   fwd_from_rc<NW, BITS>(rc, fw, shape);
 }
 
-// Consecutive windows of one read (an entry of the entry list), one-word 2-bit k-mers: the lane keeps the 128 stream
-// bits it loaded for the first window; the next reverse complement is a 64-bit funnel shift of those registers and the
-// next forward k-mer is the previous one shifted by a base with the new base (complement of the new top code of the
-// reverse complement) appended -- no LDS reads and no group reversal for the up to 7 windows that follow.
-struct RollWin { uint64_t lo, hi, fw; uint32_t sh; };
-template <typename Cfg>
-__device__ __forceinline__ void roll_first(RollWin &w, const uint32_t *s_stream, uint32_t pos, const KShape &shape, uint64_t &rc, uint64_t &fw) {
-  static_assert(Cfg::NW == 1 && Cfg::BITS == 2, "one-word 2-bit k-mers");
-  const uint32_t bit = 2u * pos, d = bit >> 5;
-  w.sh = bit & 31u;
-  w.lo = (uint64_t)s_stream[d] | ((uint64_t)s_stream[d + 1] << 32);
-  w.hi = (uint64_t)s_stream[d + 2] | ((uint64_t)s_stream[d + 3] << 32);
+// Consecutive windows of one read (an entry of the entry list), one-word 2-bit k-mers. The lane loads 128 stream bits
+// once: the first reverse complement is a funnel shift of them, the 7 codes that follow the first window are kept in
+// one register, and every further window ROLLS: rc' = rc >> 2 with the new code on top, fw' = fw << 2 with its
+// complement at the bottom -- no LDS reads, no group reversal and no 128-bit shifts after the first window.
+// HI: k >= 17 (the top code sits in the high word; k <= 16 runs on 32-bit registers). CANON: smaller of the two strands.
+// f(j, key) for the windows j < len (1 <= len <= 8) of the entry that starts at tile-image position pos.
+template <bool HI, bool CANON, typename F>
+__device__ __forceinline__ void roll_entry_windows(const uint32_t *s_stream, uint32_t pos, uint32_t len, const KShape &shape, F f) {
+  const uint32_t bit = 2u * pos, d = bit >> 5, sh = bit & 31u;
+  const uint64_t lo = (uint64_t)s_stream[d] | ((uint64_t)s_stream[d + 1] << 32);
+  const uint64_t hi = (uint64_t)s_stream[d + 2] | ((uint64_t)s_stream[d + 3] << 32);
+  const uint32_t kb = 2u * shape.k;                       // bits of a k-mer
+  const uint64_t mask = low_mask64(kb);
   uint64_t r1[1], f1[1];
-  r1[0] = (w.sh ? ((w.lo >> w.sh) | (w.hi << (64u - w.sh))) : w.lo) & low_mask64(64 - shape.pad_bits);
+  r1[0] = (sh ? ((lo >> sh) | (hi << (64u - sh))) : lo) & mask;
   fwd_from_rc<1, 2>(r1, f1, shape);
-  rc = r1[0]; fw = f1[0]; w.fw = fw;
-}
-// j-th window after the first (1 <= j <= 7)
-__device__ __forceinline__ void roll_next(RollWin &w, uint32_t j, const KShape &shape, uint64_t &rc, uint64_t &fw) {
-  const uint64_t mask = low_mask64(64 - shape.pad_bits);
-  const uint32_t s = w.sh + 2u * j;                 // 2 .. 45
-  rc = ((w.lo >> s) | (w.hi << (64u - s))) & mask;
-  fw = ((w.fw << 2) | ((~rc >> (2u * (shape.k - 1u))) & 3ull)) & mask;
-  w.fw = fw;
+  const uint32_t s2 = sh + kb;                            // 2 .. 95: first code behind the first window
+  const uint32_t nb = (uint32_t)(s2 < 64u ? ((lo >> s2) | (hi << (64u - s2))) : (hi >> (s2 - 64u)));
+  if constexpr (HI) {
+    uint64_t rc = r1[0], fw = f1[0];
+    const uint64_t keep = ((uint64_t)(uint32_t)(mask >> 32) << 32) | 0xffffffffull;   // low word all ones: no AND there
+    const uint32_t top = kb - 34u;                                                     // bit of the top code inside the high word
+    uint64_t key[1];
+    key[0] = CANON ? (fw < rc ? fw : rc) : fw;
+    f(0u, key);
+#pragma unroll
+    for (uint32_t j = 1; j < 8u; ++j) {
+      if (j < len) {
+        const uint32_t b = (nb >> (2u * (j - 1u))) & 3u;
+        rc = (rc >> 2) | ((uint64_t)(b << top) << 32);
+        fw = ((fw << 2) | (uint64_t)(b ^ 3u)) & keep;
+        key[0] = CANON ? (fw < rc ? fw : rc) : fw;
+        f(j, key);
+      }
+    }
+  } else {
+    uint32_t rc = (uint32_t)r1[0], fw = (uint32_t)f1[0];
+    const uint32_t m32 = (uint32_t)mask, top = kb - 2u;
+    uint64_t key[1];
+    key[0] = CANON ? (fw < rc ? fw : rc) : fw;
+    f(0u, key);
+#pragma unroll
+    for (uint32_t j = 1; j < 8u; ++j) {
+      if (j < len) {
+        const uint32_t b = (nb >> (2u * (j - 1u))) & 3u;
+        rc = (rc >> 2) | (b << top);
+        fw = ((fw << 2) | (b ^ 3u)) & m32;
+        key[0] = CANON ? (fw < rc ? fw : rc) : fw;
+        f(j, key);
+      }
+    }
+  }
 }
 
 // key stored by the map for a parsed k-mer (kmer_index.hpp:436-481): forward strand, or the

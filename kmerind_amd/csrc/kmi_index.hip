@@ -431,16 +431,14 @@ __device__ __forceinline__ void scatter_lines_range(const uint64_t *__restrict__
   for (uint64_t t0 = begin; t0 < end; t0 += T) {
     const uint32_t nt = (uint32_t)((end - t0 < (uint64_t)T) ? (end - t0) : (uint64_t)T);
     uint64_t k[PT];
-    uint32_t bkrk[PT];
+    uint32_t rnk[PT], bkt[PT];   // the rank stays as the LDS atomic returns it: nothing here waits for the atomic
 #pragma unroll
     for (int j = 0; j < PT; ++j) {
       const uint32_t li = j * kPartThreads + threadIdx.x;
-      bkrk[j] = 0xffffffffu;
+      rnk[j] = 0xffffffffu;
       k[j] = keyfn(raw[j]);
-      if (li < nt) {
-        const uint32_t b = bktfn(k[j]);
-        bkrk[j] = (b << 16) | atomicAdd(&s_cnt[b], 1u);   // rank behind the carried keys: s_cnt starts at the carry count
-      }
+      bkt[j] = bktfn(k[j]);
+      if (li < nt) rnk[j] = atomicAdd(&s_cnt[bkt[j]], 1u);   // rank behind the carried keys: s_cnt starts at the carry count
     }
     if (t0 + T < end) load_tile(t0 + T);   // in flight until the next iteration needs it
     lds_barrier();
@@ -476,7 +474,7 @@ __device__ __forceinline__ void scatter_lines_range(const uint64_t *__restrict__
     }
 #pragma unroll
     for (int j = 0; j < PT; ++j)
-      if (bkrk[j] != 0xffffffffu) s_stage[s_lofs[bkrk[j] >> 16] + (bkrk[j] & 0xffffu)] = k[j];
+      if (rnk[j] != 0xffffffffu) s_stage[s_lofs[bkt[j]] + rnk[j]] = k[j];
     lds_barrier();
     // copy-out by destination line: 16 lanes = one 128-byte line of one bucket
     {
@@ -775,18 +773,13 @@ template <int NW, int BITS, typename F>
 __device__ __forceinline__ void for_entry_windows(const uint32_t *img, uint32_t pos, uint32_t len, const KShape &shape, bool canonical, F f) {
   using Cfg = ExCfg<NW, BITS>;
   if constexpr (NW == 1 && BITS == 2) {
-    RollWin rw;
-    uint64_t rc[1], fw[1], key[1];
-    roll_first<Cfg>(rw, img, pos, shape, rc[0], fw[0]);
-    select_strand<1>(rc, fw, canonical, key);
-    f(0u, key);
-#pragma unroll
-    for (uint32_t j = 1; j < 8u; ++j) {
-      if (j < len) {
-        roll_next(rw, j, shape, rc[0], fw[0]);
-        select_strand<1>(rc, fw, canonical, key);
-        f(j, key);
-      }
+    // uniform dispatch: the rolled loop is specialised on the word the top code lives in and on the strand rule
+    if (shape.k >= 17u) {
+      if (canonical) roll_entry_windows<true, true>(img, pos, len, shape, f);
+      else roll_entry_windows<true, false>(img, pos, len, shape, f);
+    } else {
+      if (canonical) roll_entry_windows<false, true>(img, pos, len, shape, f);
+      else roll_entry_windows<false, false>(img, pos, len, shape, f);
     }
   } else {
 #pragma unroll
@@ -978,7 +971,7 @@ __global__ __launch_bounds__(TPB) void fastq_rank_hist_list_kernel(PackedInput i
 // windows of a read: the first k-mer is read from the image, the others roll. No per-byte work at all.
 // RANK = true: buckets come from the bytes the rank histogram pass left (ent_bkt) instead of the placement hash.
 template <int NW, int BITS, bool RANK = false>
-__global__ __launch_bounds__((ExCfg<NW, BITS>::NT)) void fastq_scatter_list_kernel(PackedInput in, uint64_t n_tiles, KShape shape, bool canonical,
+__global__ __launch_bounds__((ExCfg<NW, BITS>::NT), (NW == 1 ? 4 : 1)) void fastq_scatter_list_kernel(PackedInput in, uint64_t n_tiles, KShape shape, bool canonical,
                                                                                   const uint16_t *__restrict__ ent,
                                                                                   const uint32_t *__restrict__ ent_cnt, uint32_t ent_stride,
                                                                                   const uint64_t *__restrict__ ent_bkt,
@@ -1064,9 +1057,13 @@ __global__ __launch_bounds__((ExCfg<NW, BITS>::NT)) void fastq_scatter_list_kern
     lds_barrier();
     // S0: keys of this thread's entries, coarse bucket and rank inside (round, bucket)
     uint64_t key[KPT][NW];
-    uint32_t bkrk[KPT];
+    // rank inside (round, bucket) as the LDS atomic returns it -- kept raw, so that nothing waits for the atomic here --
+    // and the bucket bytes, four to a register
+    uint32_t rnk[KPT], bpk[KPT / 4];
 #pragma unroll
-    for (int q = 0; q < KPT; ++q) bkrk[q] = 0xffffffffu;
+    for (int q = 0; q < KPT; ++q) rnk[q] = 0xffffffffu;
+#pragma unroll
+    for (int q = 0; q < KPT / 4; ++q) bpk[q] = 0;
 #pragma unroll
     for (int m = 0; m < EPT; ++m) {
       if ((uint32_t)(m * NT) + threadIdx.x < cur.total) {
@@ -1075,7 +1072,8 @@ __global__ __launch_bounds__((ExCfg<NW, BITS>::NT)) void fastq_scatter_list_kern
 #pragma unroll
                                       for (int w = 0; w < NW; ++w) key[m * 8 + j][w] = kk[w];
                                       const uint32_t b = RANK ? (uint32_t)((eb[m] >> (8u * j)) & 0xffu) : coarse_of(place_hash<NW>(kk));
-                                      bkrk[m * 8 + j] = (b << 16) | atomicAdd(&s_cnt[b], 1u);
+                                      rnk[m * 8 + j] = atomicAdd(&s_cnt[b], 1u);
+                                      bpk[(m * 8 + j) / 4] |= b << (8u * ((m * 8 + j) % 4u));
                                     });
       }
     }
@@ -1104,9 +1102,9 @@ __global__ __launch_bounds__((ExCfg<NW, BITS>::NT)) void fastq_scatter_list_kern
     lds_barrier();
 #pragma unroll
     for (int q = 0; q < KPT; ++q) {
-      if (bkrk[q] != 0xffffffffu) {
-        const uint32_t b = bkrk[q] >> 16;
-        const uint32_t pos = s_lofs[b] + (bkrk[q] & 0xffffu);
+      if (rnk[q] != 0xffffffffu) {
+        const uint32_t b = (bpk[q / 4] >> (8u * (q % 4))) & 0xffu;
+        const uint32_t pos = s_lofs[b] + rnk[q];
 #pragma unroll
         for (int w = 0; w < NW; ++w) s_stage[(uint64_t)pos * NW + w] = key[q][w];
         s_bkt[pos] = (uint8_t)b;
