@@ -1126,15 +1126,18 @@ __global__ __launch_bounds__((ExCfg<NW, BITS>::NT), (NW == 1 ? 4 : 1)) void fast
 // LDS table
 // ---------------------------------------------------------------------------
 template <int NW> struct TabCfg {
-  // slots; sized so that two workgroups fit in one CU's 160 KB for one-word keys
-  static constexpr int CAP = (NW == 1) ? 6656 : (NW == 2 ? 4608 : (NW == 3 ? 3584 : 2816));   // home slots
+  // home slots. One-word keys: one 1024-thread workgroup per CU with a table that fills the CU's LDS (154 KB). Two
+  // 512-thread workgroups with half the table each ran at the same speed on config 2 (4.25 ms: the kernel is bound by
+  // the dependent LDS round trips of the probe walk, not by the load factor), and the large table takes twice the
+  // distinct keys per pass (9600 per bucket, 3.1e8 per index) before a bucket needs a second pass.
+  static constexpr int CAP = (NW == 1) ? 12800 : (NW == 2 ? 4608 : (NW == 3 ? 3584 : 2816));   // home slots
   // One-word tables probe linearly WITHOUT wrap-around: a probe sequence that starts near the end runs on
   // into PAD extra slots, so a probe step is "next address, read, compare" and nothing else. The very last
   // slot is never filled (an insert that would need it reports overflow), which ends every probe sequence.
   static constexpr int PAD = (NW == 1) ? 64 : 0;
   static constexpr int SLOTS = CAP + PAD;
   static constexpr int LIMIT = CAP * 3 / 4;      // distinct keys per pass before the bucket is split into more passes
-  static constexpr int NT = 512;
+  static constexpr int NT = (NW == 1) ? 1024 : 512;
 };
 constexpr int kMaxProbe = 192;   // longer probe sequences than this mean the LDS table is overloaded
 constexpr uint32_t kMaxPasses = 1u << 16;

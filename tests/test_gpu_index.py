@@ -308,3 +308,68 @@ def test_combine_first_split_and_merge_replayed_on_one_device(ctx):
             a, b = orc.sorted_pairs(gk, gc), orc.sorted_pairs(ek[eranks == d], ec[eranks == d])
             assert a[0].shape == b[0].shape and (a[0] == b[0]).all() and (a[1] == b[1]).all()
             dest[d].close()
+
+
+def _keys_in_one_placement_bucket(n, bucket, hi_words=(1, 77, 1 << 20)):
+    """white-box helper: one-word keys whose placement hash (kmi_device.h place_hash: three 32-bit multiply / xorshift
+    rounds, a bijection of the low word for a fixed high word) falls into fine bucket `bucket` -- found by inverting it."""
+    M = np.uint64(0xffffffff)
+
+    def inv_mul(c):
+        return np.uint64(pow(c, -1, 1 << 32))
+
+    def unshift(h, s):
+        x = h.copy()
+        for _ in range(4):
+            x = h ^ (x >> np.uint64(s))
+        return x
+
+    per = -(-n // len(hi_words))
+    out = []
+    for hi in hi_words:
+        h = (np.uint64(bucket) << np.uint64(17)) | np.arange(per, dtype=np.uint64)      # final hash values in the bucket
+        h = unshift(h, 16)
+        h = (h * inv_mul(0x27D4EB2F)) & M
+        h = unshift(h, 13)
+        h = ((h * inv_mul(0xC2B2AE35)) & M) ^ np.uint64(hi)
+        h = unshift(h, 15)
+        lo = ((h * inv_mul(0x85EBCA6B)) & M) ^ np.uint64(0x9E3779B9)
+        out.append((np.uint64(hi) << np.uint64(32)) | lo)
+    return np.concatenate(out)[:n]
+
+
+def test_bucket_with_more_distinct_keys_than_the_lds_table_takes_more_passes(ctx):
+    """30 000 distinct keys in ONE placement bucket (the one-word LDS table holds 9600 per pass): the reduce and the query
+    kernels split the bucket into passes over disjoint key subsets; insert twice so the second merge meets the big bucket."""
+    import kmerind_amd as K
+    cfg = K.make_config(31, "DNA", strand="single")
+    rng = np.random.default_rng(8)
+    hot = _keys_in_one_placement_bucket(30_000, bucket=4242)
+    assert np.unique(hot).size == hot.size and int(hot.max()) < (1 << 62)
+    idx = K.CountIndex(ctx, cfg)
+    ref = {}
+    for rnd in range(2):
+        reps = rng.integers(1, 4, size=hot.size)
+        keys = np.concatenate([np.repeat(hot, reps), rng.integers(0, 1 << 62, size=200_000, dtype=np.uint64)])
+        rng.shuffle(keys)
+        idx.insert(keys.reshape(-1, 1))
+        uk, uc = np.unique(keys, return_counts=True)
+        for a, b in zip(uk.tolist(), uc.tolist()):
+            ref[a] = ref.get(a, 0) + b
+    gk, gc = idx.to_vector()
+    assert gk.shape[0] == len(ref)
+    order = np.argsort(gk[:, 0])
+    rk = np.array(sorted(ref), dtype=np.uint64)
+    assert (gk[order, 0] == rk).all() and (gc[order] == np.array([ref[int(a)] for a in rk], dtype=np.uint32)).all()
+    # the hot keys really share a bucket: the per-bucket counts of a one-rank split show it
+    n, nb = idx.local_size(), K.core.num_buckets()
+    dk, dc, db = ctx.alloc(n * 8 + 64), ctx.alloc(n * 4 + 64), ctx.alloc(nb * 4)
+    idx.split_by_rank_device(1, dk, dc, n, db)
+    per_bucket = np.zeros(nb, np.uint32)
+    ctx.to_host(per_bucket, db)
+    ctx.free(dk); ctx.free(dc); ctx.free(db)
+    assert int(per_bucket.sum()) == n and int(per_bucket[4242]) >= hot.size and int(np.delete(per_bucket, 4242).max()) < 200
+    q = np.concatenate([hot[::3], rng.integers(0, 1 << 62, size=1000, dtype=np.uint64)]).reshape(-1, 1)
+    fk, fc = idx.find(q)
+    assert fk.shape[0] == hot[::3].size and all(ref[int(a)] == int(b) for a, b in zip(fk[:, 0], fc))
+    idx.close()
