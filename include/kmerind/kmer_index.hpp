@@ -171,7 +171,10 @@ template <typename K, bool Prefix = false> struct cpp_std { static constexpr uin
 namespace io {
 template <typename Iter> struct FASTQParser { static constexpr uint32_t KMI = KMI_FMT_FASTQ; };
 template <typename Iter> struct FASTAParser { static constexpr uint32_t KMI = KMI_FMT_FASTA; };
-template <typename Iter, template <typename> class Parser> struct SequencesIterator {};
+// the SeqIterType argument of read_file_* / build_* (sequence_iterator.hpp:96-300, filtered_sequence_iterator.hpp:154-165,429-440)
+template <typename Iter, template <typename> class Parser> struct SequencesIterator { static constexpr uint32_t KMI = KMI_SEQ_ALL; };
+template <typename Iter, template <typename> class Parser> struct NFilterSequencesIterator { static constexpr uint32_t KMI = KMI_SEQ_N_FILTER; };
+template <typename Iter, template <typename> class Parser> struct NSplitSequencesIterator { static constexpr uint32_t KMI = KMI_SEQ_N_SPLIT; };
 }  // namespace io
 }  // namespace bliss
 
@@ -251,7 +254,7 @@ template <typename MapType> kmi_config make_config(uint32_t fmt) {
   kmi_config c;
   c.k = Key::size; c.alphabet = Key::KmerAlphabet::KMI; c.strand = MapType::params::strand;
   c.dist_hash = MapType::params::dist_hash; c.store_hash = MapType::params::store_hash;
-  c.index_kind = MapType::index_kind; c.seq_format = fmt; c.farm_ndebug = 0;
+  c.index_kind = MapType::index_kind; c.seq_format = fmt; c.farm_ndebug = 0; c.seq_filter = KMI_SEQ_ALL;
   return c;
 }
 inline std::vector<uint8_t> read_whole_file(const std::string &filename) {
@@ -389,9 +392,11 @@ class Index {
 
   // Index::build_posix / build_mmap (:239-372): read_file + insert; the extension check is the reference's
   template <template <typename> class SeqParser, template <typename, template <typename> class> class SeqIterType>
-  void build_posix(const std::string &filename, void * /*MPI_Comm*/ = nullptr) { build_file<SeqParser>(filename); }
+  void build_posix(const std::string &filename, void * /*MPI_Comm*/ = nullptr) {
+    build_file<SeqParser>(filename, SeqIterType<const unsigned char *, SeqParser>::KMI);
+  }
   template <template <typename> class SeqParser, template <typename, template <typename> class> class SeqIterType>
-  void build_mmap(const std::string &filename, void * = nullptr) { build_file<SeqParser>(filename); }
+  void build_mmap(const std::string &filename, void * = nullptr) { build_file<SeqParser>(filename, SeqIterType<const unsigned char *, SeqParser>::KMI); }
 
   kmi_ctx *context() const { return ctx; }
   const kmi_config &config() const { return cfg; }
@@ -417,12 +422,13 @@ class Index {
     ::kmerind::check(ctx, kmi_index_erase_host(idx, detail::words_of(keys), keys.size(), &n));
     if (!keep.empty()) insert(keep);
   }
-  template <template <typename> class SeqParser> void build_file(const std::string &filename) {
+  template <template <typename> class SeqParser> void build_file(const std::string &filename, uint32_t seq_filter = KMI_SEQ_ALL) {
     uint32_t fmt = detail::format_of(filename);
     if (fmt != SeqParser<const unsigned char *>::KMI) throw std::invalid_argument("Specified File Parser template parameter does not support files with this extension.");
     if (comm.size() > 1) throw std::invalid_argument("build_* with size() > 1: partition the file per rank and use read_file + insert");
     std::vector<uint8_t> bytes = detail::read_whole_file(filename);
     ::kmerind::check(ctx, kmi_index_set_seq_format(idx, fmt));
+    ::kmerind::check(ctx, kmi_index_set_seq_filter(idx, seq_filter));
     ::kmerind::check(ctx, kmi_index_build_host(idx, bytes.data(), bytes.size(), 0));
   }
   void insert_words(const uint64_t *words, size_t n) {
@@ -482,6 +488,7 @@ struct KmerFileHelper {
     kmi_config c; std::memset(&c, 0, sizeof(c));
     c.k = Kmer::size; c.alphabet = Kmer::KmerAlphabet::KMI; c.seq_format = SeqParser<const unsigned char *>::KMI;
     c.index_kind = tuple_kind<typename KmerParser::value_type, Kmer>();
+    c.seq_filter = SeqIterType<const unsigned char *, SeqParser>::KMI;
     if (comm.size() > 1) throw std::invalid_argument("read_file_* with size() > 1: pass each rank its own record-aligned partition");
     std::vector<uint8_t> bytes = ::bliss::index::kmer::detail::read_whole_file(filename);
     kmi_ctx *ctx = nullptr;

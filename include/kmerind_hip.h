@@ -53,6 +53,10 @@ enum { KMI_HASH_MURMUR = 0, KMI_HASH_FARM = 1,                  /* kmer_hash.hpp
        KMI_HASH_IDENTITY = 2, KMI_HASH_STD = 3 };               /* kmer_hash.hpp:205-230, 154-198 (cpp_std, libstdc++) */
 enum { KMI_FMT_FASTQ = 0, KMI_FMT_FASTA = 1 };
 enum { KMI_INDEX_COUNT = 0, KMI_INDEX_POSITION = 1, KMI_INDEX_POSQUAL = 2 }; /* kmer_index.hpp:399-411 */
+/* the SeqIterType argument of read_file_* / build_* (kmer_index.hpp:239-372): SequencesIterator (every record),
+ * NFilterSequencesIterator (records whose sequence holds an 'N' are skipped, filtered_sequence_iterator.hpp:154-165)
+ * or NSplitSequencesIterator (sequences are cut at every 'N' / 'n', so no k-mer spans one, :429-440) */
+enum { KMI_SEQ_ALL = 0, KMI_SEQ_N_FILTER = 1, KMI_SEQ_N_SPLIT = 2 };
 
 /* The compile-time parameters of the reference's Index<Map,Parser> as a runtime struct. */
 typedef struct {
@@ -66,6 +70,9 @@ typedef struct {
   uint32_t seq_format; /* KMI_FMT_* */
   uint32_t farm_ndebug;/* 0: farmhash as the reference's default RelWithDebInfo build computes it
                           (DebugTweak active, CMakeLists.txt:26,200-204); 1: -DNDEBUG behaviour */
+  uint32_t seq_filter; /* KMI_SEQ_*. With a filter, n_seqs counts what the reference's read_block counts: records
+                          that pass (N_FILTER) or non-empty pieces (N_SPLIT; FASTA: records). FASTQ: both filters;
+                          FASTA: N_SPLIT. Quality values (KMI_INDEX_POSQUAL) need KMI_SEQ_ALL. */
 } kmi_config;
 
 typedef struct kmi_ctx kmi_ctx;     /* replaces mxx::comm + per-rank state */
@@ -178,6 +185,8 @@ kmi_status kmi_index_clear(kmi_index *idx);
 /* The SeqParser template argument of Index::build_posix / build_mmap / build_mpiio<SeqParser, SeqIterType>
  * (kmer_index.hpp:239-372): which record grammar the next kmi_index_build_* call parses (KMI_FMT_*). */
 kmi_status kmi_index_set_seq_format(kmi_index *idx, uint32_t seq_format);
+/* the SeqIterType template argument of Index::build_* (kmer_index.hpp:239-372): KMI_SEQ_* for the following builds */
+kmi_status kmi_index_set_seq_filter(kmi_index *idx, uint32_t seq_filter);
 /* MapType::local_size() / size() on one rank (distributed_map_base.hpp:227-245) */
 kmi_status kmi_index_local_size(kmi_index *idx, uint64_t *n);
 /* MapType::to_vector() (distributed_map_base.hpp:202-217): keys n*n_words, counts n; order unspecified */

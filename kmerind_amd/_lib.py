@@ -22,6 +22,7 @@ STRAND_SINGLE, STRAND_CANONICAL, STRAND_BIMOLECULE = 0, 1, 2
 HASH_MURMUR, HASH_FARM, HASH_IDENTITY, HASH_STD = 0, 1, 2, 3
 FMT_FASTQ, FMT_FASTA = 0, 1
 INDEX_COUNT, INDEX_POSITION, INDEX_POSQUAL = 0, 1, 2
+SEQ_ALL, SEQ_N_FILTER, SEQ_N_SPLIT = 0, 1, 2
 
 
 class FastaPartition(C.Structure):
@@ -32,7 +33,7 @@ class FastaPartition(C.Structure):
 class Config(C.Structure):
     _fields_ = [("k", C.c_uint32), ("alphabet", C.c_uint32), ("strand", C.c_uint32),
                 ("dist_hash", C.c_uint32), ("store_hash", C.c_uint32), ("index_kind", C.c_uint32),
-                ("seq_format", C.c_uint32), ("farm_ndebug", C.c_uint32)]
+                ("seq_format", C.c_uint32), ("farm_ndebug", C.c_uint32), ("seq_filter", C.c_uint32)]
 
 
 class Tuples(C.Structure):
@@ -86,6 +87,7 @@ SIGNATURES = {
     "kmi_index_build_dev": (C.c_int, [_P, _P, _sz, _u64]),
     "kmi_index_clear": (C.c_int, [_P]),
     "kmi_index_set_seq_format": (C.c_int, [_P, C.c_uint32]),
+    "kmi_index_set_seq_filter": (C.c_int, [_P, C.c_uint32]),
     "kmi_index_local_size": (C.c_int, [_P, C.POINTER(_u64)]),
     "kmi_index_export_host": (C.c_int, [_P, _P, _P, _sz, C.POINTER(_u64)]),
     "kmi_results_free": (None, [C.POINTER(Results)]),

@@ -14,13 +14,14 @@ lib = L.lib
 
 
 def make_config(k, alphabet="DNA", strand="canonical", dist_hash="murmur", store_hash="murmur",
-                index_kind="count", seq_format="fastq", farm_ndebug=False):
+                index_kind="count", seq_format="fastq", farm_ndebug=False, seq_filter="all"):
     alpha = {"DNA": L.ALPHA_DNA, "DNA5": L.ALPHA_DNA5, "DNA6": L.ALPHA_DNA5}[alphabet]
     st = {"single": L.STRAND_SINGLE, "canonical": L.STRAND_CANONICAL, "bimolecule": L.STRAND_BIMOLECULE}[strand]
     hs = {"murmur": L.HASH_MURMUR, "farm": L.HASH_FARM, "identity": L.HASH_IDENTITY, "std": L.HASH_STD}
     kind = {"count": L.INDEX_COUNT, "position": L.INDEX_POSITION, "posqual": L.INDEX_POSQUAL}[index_kind]
     fmt = {"fastq": L.FMT_FASTQ, "fasta": L.FMT_FASTA}[seq_format]
-    return L.Config(k, alpha, st, hs[dist_hash], hs[store_hash], kind, fmt, int(bool(farm_ndebug)))
+    flt = {"all": L.SEQ_ALL, "n_filter": L.SEQ_N_FILTER, "n_split": L.SEQ_N_SPLIT}[seq_filter]
+    return L.Config(k, alpha, st, hs[dist_hash], hs[store_hash], kind, fmt, int(bool(farm_ndebug)), flt)
 
 
 def _u64(a, n_words=None):

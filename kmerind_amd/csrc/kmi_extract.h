@@ -108,10 +108,13 @@ struct PackedInput {
   uint64_t n_bytes;        // input length
   uint64_t n_cover;        // bytes covered by the arrays (multiple of the scan tile)
   uint64_t n_valid;        // FASTA only: windows start at positions below this (valid range of a partition); else unused
+  const uint8_t *brk = nullptr;   // FASTQ with a sequence filter: bit i <=> no k-mer window may cover byte i (EOL, or an N by the
+                                  // filter's rule); null = the EOL bitmap decides alone
 };
 
 template <int C> __device__ __forceinline__ uint32_t read_eol_unit(const uint8_t *__restrict__ pk, uint64_t g) {
-  if constexpr (C == 16) return reinterpret_cast<const uint16_t *>(pk)[g];
+  if constexpr (C == 32) return reinterpret_cast<const uint32_t *>(pk)[g];
+  else if constexpr (C == 16) return reinterpret_cast<const uint16_t *>(pk)[g];
   else return pk[g];
 }
 template <int C> __device__ __forceinline__ void write_eol_unit(uint8_t *__restrict__ pk, uint64_t g, uint32_t e) {
@@ -147,6 +150,25 @@ template <int BITS, int C> __device__ __forceinline__ void write_stream_unit(uin
 #pragma unroll
     for (int i = 0; i < NB; ++i) p[i] = (uint8_t)(st >> (8 * i));
   }
+}
+
+// LDS image of the window-break bits of a tile + halo (same layout as the EOL image); returns the image the window
+// validity has to be read from
+template <typename Cfg>
+__device__ __forceinline__ const uint32_t *tile_break_image(const uint8_t *__restrict__ brk, uint64_t n_cover, uint64_t tile,
+                                                            const uint32_t *s_eol, uint32_t *s_brk) {
+  if (!brk) return s_eol;   // uniform
+  constexpr int C = Cfg::C;
+  const int j = threadIdx.x;
+  const uint64_t n_units = n_cover / C;
+  const uint64_t g = tile * Cfg::NT + j;
+  store_eol_bits<C>(s_brk, j, g < n_units ? read_eol_unit<C>(brk, g) : Cfg::CMASK);
+  if (j < Cfg::HALO_CHUNKS) {
+    const uint64_t gh = tile * Cfg::NT + Cfg::NT + j;
+    store_eol_bits<C>(s_brk, Cfg::NT + j, gh < n_units ? read_eol_unit<C>(brk, gh) : Cfg::CMASK);
+  }
+  lds_barrier();
+  return s_brk;
 }
 
 // front end of the scan pass: classify the raw bytes of this thread's chunk (+ halo), publish

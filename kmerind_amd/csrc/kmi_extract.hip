@@ -38,8 +38,10 @@ __global__ __launch_bounds__((Cfg::NT)) void fastq_scan_tiles_kernel(const uint8
                                                                                uint8_t *__restrict__ pk_eol,
                                                                                uint8_t *__restrict__ pk_stream,
                                                                                TileInfo *__restrict__ info,
-                                                                               uint32_t *__restrict__ flags) {
+                                                                               uint32_t *__restrict__ flags,
+                                                                               const uint8_t *__restrict__ brk, uint64_t n_cover) {
   __shared__ uint32_t s_eol[Cfg::EOL_DW];
+  __shared__ uint32_t s_brk[Cfg::EOL_DW];
   __shared__ uint32_t s_scan[Cfg::NT / 64 + 2];
   __shared__ uint32_t s_cnt[3];
   __shared__ uint32_t s_last[4];
@@ -48,8 +50,9 @@ __global__ __launch_bounds__((Cfg::NT)) void fastq_scan_tiles_kernel(const uint8
   uint32_t dw[Cfg::C / 4], eol, ls, lbl, ltot;
   tile_front_bytes<Cfg>(bytes, n_bytes, blockIdx.x, pk_eol, pk_stream, s_eol, s_scan, dw, eol, ls, lbl, ltot);
 
+  // k-windows are counted against the break bits: EOLs, plus the N positions of a sequence filter
   uint64_t e[Cfg::NE];
-  load_eol_view<Cfg>(s_eol, threadIdx.x, e);
+  load_eol_view<Cfg>(tile_break_image<Cfg>(brk, n_cover, blockIdx.x, s_eol, s_brk), threadIdx.x, e);
   smear_right<Cfg::NE>(e, k);
   const uint32_t cand = ~(uint32_t)e[0] & Cfg::CMASK;
 
@@ -427,6 +430,7 @@ __global__ __launch_bounds__((ExCfg<NW, BITS>::NT)) void fastq_extract_kernel(
     uint64_t *__restrict__ out_ids, ReadDesc *__restrict__ reads, uint32_t *__restrict__ n_reads, uint32_t *__restrict__ flags) {
   using Cfg = ExCfg<NW, BITS>;
   __shared__ uint32_t s_eol[Cfg::EOL_DW];
+  __shared__ uint32_t s_brk[Cfg::EOL_DW];
   __shared__ uint32_t s_stream[Cfg::STREAM_DW];
   __shared__ uint32_t s_scan[Cfg::NT / 64 + 2];
   __shared__ uint16_t s_pos[Cfg::TILE];
@@ -448,7 +452,8 @@ __global__ __launch_bounds__((ExCfg<NW, BITS>::NT)) void fastq_extract_kernel(
     s_hmask[threadIdx.x] = (uint16_t)hm;
     s_hexcl[threadIdx.x] = (uint16_t)block_exclusive_max<uint32_t>(hlast, s_scan, (uint32_t *)nullptr);
   }
-  const uint32_t total = tile_window_list<Cfg>(s_eol, ls, lines_before, shape.k, s_pos, s_scan);
+  const uint32_t total = tile_window_list<Cfg>(tile_break_image<Cfg>(in.brk, in.n_cover, blockIdx.x, s_eol, s_brk), ls, lines_before,
+                                               shape.k, s_pos, s_scan);
   const uint64_t base = out_off[blockIdx.x];
   if (base + total > out_capacity) {
     if (threadIdx.x == 0 && total) atomicOr(&flags[1], 1u);
@@ -485,6 +490,109 @@ __global__ __launch_bounds__((ExCfg<NW, BITS>::NT)) void fastq_extract_kernel(
 }
 
 // ---------------------------------------------------------------------------
+// Sequence filters (the SeqIterType argument of read_file_* / build_*, filtered_sequence_iterator.hpp): the window-break
+// bitmap. NSplitSequencesIterator cuts a sequence at every 'N' / 'n' (NCharFilter, :429-440), so a k-mer window is
+// kept iff it covers no EOL and no such byte: break = EOL | N | n. NFilterSequencesIterator drops every record whose
+// sequence holds an 'N' (NSequenceFilter, :154-165): break = EOL | every byte of a line that holds an 'N' (lines of the
+// other roles carry no windows, so marking them too changes nothing). Everything downstream reads the break bitmap
+// where it read the EOL bitmap for window validity; line structure stays on the EOL bitmap.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void fastq_nbits_kernel(const uint8_t *__restrict__ bytes, uint64_t n_bytes, uint64_t n_words, bool lower_too,
+                                                         uint32_t *__restrict__ brk, uint32_t *__restrict__ eolw, uint32_t *__restrict__ nbw) {
+  const uint64_t w = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (w >= n_words) return;
+  const uint64_t p0 = w * 32;
+  uint32_t e = 0, n = 0;
+  if (p0 + 32 <= n_bytes) {
+    const uint4 a = *reinterpret_cast<const uint4 *>(bytes + p0), b = *reinterpret_cast<const uint4 *>(bytes + p0 + 16);
+    const uint32_t dw[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+      const uint32_t c = (dw[i >> 2] >> (8 * (i & 3))) & 0xffu;
+      e |= (is_eol(c) ? 1u : 0u) << i;
+      n |= ((c == 'N' || (lower_too && c == 'n')) ? 1u : 0u) << i;
+    }
+  } else {
+    for (int i = 0; i < 32; ++i) {
+      const uint64_t p = p0 + i;
+      const uint32_t c = p < n_bytes ? bytes[p] : (uint32_t)'\n';   // bytes past the end count as EOL
+      e |= (is_eol(c) ? 1u : 0u) << i;
+      n |= ((c == 'N' || (lower_too && c == 'n')) ? 1u : 0u) << i;
+    }
+  }
+  brk[w] = e | n;
+  if (eolw) { eolw[w] = e; nbw[w] = n; }
+}
+
+// N_FILTER: the first 'N' of a line marks the whole line in the break bitmap
+__global__ __launch_bounds__(256) void fastq_poison_lines_kernel(const uint32_t *__restrict__ eolw, const uint32_t *__restrict__ nbw,
+                                                                uint64_t n_words, uint32_t *__restrict__ brk) {
+  const uint64_t w = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (w >= n_words) return;
+  uint32_t rest = nbw[w];
+  while (rest) {
+    const uint32_t b = (uint32_t)__builtin_ctz(rest);
+    rest &= rest - 1u;
+    // line start: one past the last EOL before the N at word w, bit b
+    uint64_t s = 0;
+    {
+      uint64_t wi = w;
+      uint32_t bits = eolw[wi] & ((1u << b) - 1u);
+      while (bits == 0u && wi > 0) bits = eolw[--wi];
+      if (bits) s = wi * 32 + (31u - (uint32_t)__builtin_clz(bits)) + 1u;
+    }
+    // an earlier N of the same line does the marking
+    bool first = true;
+    for (uint64_t wi = s >> 5; wi <= w && first; ++wi) {
+      uint32_t m = nbw[wi];
+      if (wi == (s >> 5)) m &= ~((1u << (s & 31u)) - 1u);
+      if (wi == w) m &= (1u << b) - 1u;
+      if (m) first = false;
+    }
+    if (!first) continue;
+    // line end: the first EOL at or behind p (bytes past the input are EOL)
+    uint64_t e = n_words * 32;
+    {
+      uint64_t wi = w;
+      uint32_t bits = eolw[wi] & ~((1u << b) - 1u);
+      while (bits == 0u && wi + 1 < n_words) bits = eolw[++wi];
+      if (bits) e = wi * 32 + (uint32_t)__builtin_ctz(bits);
+    }
+    for (uint64_t wi = s >> 5; wi <= ((e - 1) >> 5); ++wi) {
+      uint32_t m = 0xffffffffu;
+      if (wi == (s >> 5)) m &= ~((1u << (s & 31u)) - 1u);
+      if (wi == ((e - 1) >> 5) && (e & 31u)) m &= (1u << (e & 31u)) - 1u;
+      atomicOr(&brk[wi], m);
+    }
+  }
+}
+
+// what read_block counts as sequences under a filter (kmer_file_helper.hpp:128-178): N_FILTER -- the records that pass,
+// i.e. the sequence lines whose first byte is not marked; N_SPLIT -- the non-empty pieces, i.e. the bytes of sequence
+// lines that are no break and follow one
+template <int NW, int BITS>
+__global__ __launch_bounds__((ExCfg<NW, BITS>::NT)) void fastq_subseq_count_kernel(PackedInput in, const uint32_t *__restrict__ line_base,
+                                                                                  bool pieces, unsigned long long *__restrict__ total) {
+  using Cfg = ExCfg<NW, BITS>;
+  constexpr int C = Cfg::C;
+  __shared__ uint32_t s_eol[Cfg::EOL_DW];
+  __shared__ uint32_t s_stream[Cfg::STREAM_DW];
+  __shared__ uint32_t s_scan[Cfg::NT / 64 + 2];
+  uint32_t eol, ls, lbl, ltot;
+  tile_front_packed<Cfg>(in, blockIdx.x, s_eol, s_stream, s_scan, eol, ls, lbl, ltot);
+  const uint32_t role = fastq_seq_role_mask(line_base[blockIdx.x] + lbl, ls, Cfg::CMASK);
+  const uint64_t n_units = in.n_cover / C, g = (uint64_t)blockIdx.x * Cfg::NT + threadIdx.x;
+  const uint32_t bk = g < n_units ? read_eol_unit<C>(in.brk, g) : Cfg::CMASK;
+  const uint32_t prevb = g == 0 ? 1u : ((read_eol_unit<C>(in.brk, (g - 1 < n_units ? g - 1 : n_units - 1)) >> (C - 1)) & 1u);
+  uint32_t c;
+  if (pieces) c = (uint32_t)__builtin_popcount(~bk & ((bk << 1) | prevb) & role & Cfg::CMASK);
+  else c = (uint32_t)__builtin_popcount(ls & role & ~bk);
+  uint32_t tot;
+  block_exclusive_scan<uint32_t>(c, s_scan, &tot);
+  if (threadIdx.x == 0 && tot) atomicAdd(total, (unsigned long long)tot);
+}
+
+// ---------------------------------------------------------------------------
 // host drivers
 // ---------------------------------------------------------------------------
 // offsets over the tile records (reduce per 1024 tiles, scan of the block summaries, apply)
@@ -516,7 +624,7 @@ struct ScanResult {
 
 template <int NW, int BITS>
 static kmi_status scan_impl(kmi_ctx *ctx, const uint8_t *bytes_dev, size_t n_bytes, const KShape &shape, ScanResult *r,
-                            bool reuse = false, bool check_lengths = true) {
+                            bool reuse = false, bool check_lengths = true, uint32_t seq_filter = KMI_SEQ_ALL) {
   using Cfg = ExCfg<NW, BITS>;
   const uint64_t n_tiles = (n_bytes + Cfg::TILE - 1) / Cfg::TILE;
   void *p;
@@ -535,15 +643,41 @@ static kmi_status scan_impl(kmi_ctx *ctx, const uint8_t *bytes_dev, size_t n_byt
   uint8_t *pk_stream = (uint8_t *)p;
   r->n_tiles = n_tiles; r->line_base = base; r->out_off = off; r->hdr_base = hdr;
   r->packed.eol = pk_eol; r->packed.stream = pk_stream; r->packed.n_bytes = n_bytes; r->packed.n_cover = n_cover; r->packed.n_valid = n_bytes;
+  uint32_t *brk = nullptr;
+  if (seq_filter != KMI_SEQ_ALL) {
+    KMI_TRY(ws_get(ctx, WS_PK_BRK, n_cover / 8 + 64, &p));
+    brk = (uint32_t *)p;
+    r->packed.brk = (const uint8_t *)brk;
+  }
   if (reuse) return KMI_OK;   // the scan of these very bytes is still in the workspace
+  if (brk && n_tiles > 0) {
+    ProfScope ps(ctx, "fastq_nbits", n_bytes);
+    const uint64_t n_words = n_cover / 32;
+    uint32_t *eolw = nullptr, *nbw = nullptr;
+    if (seq_filter == KMI_SEQ_N_FILTER) {
+      KMI_TRY(ws_get(ctx, WS_PK_NB, 2 * (n_cover / 8) + 64, &p));
+      eolw = (uint32_t *)p; nbw = eolw + n_words;
+    }
+    hipLaunchKernelGGL(fastq_nbits_kernel, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, ctx->stream, bytes_dev, (uint64_t)n_bytes,
+                       n_words, seq_filter == KMI_SEQ_N_SPLIT, brk, eolw, nbw);
+    if (seq_filter == KMI_SEQ_N_FILTER)
+      hipLaunchKernelGGL(fastq_poison_lines_kernel, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, ctx->stream,
+                         (const uint32_t *)eolw, (const uint32_t *)nbw, n_words, brk);
+  }
   if (n_tiles > 0) {
     ProfScope ps(ctx, "fastq_scan_tiles", n_bytes);
     using SCfg = ScanCfg<NW, BITS>;
     static_assert(SCfg::TILE == Cfg::TILE, "the scan pass writes the packed arrays of the same tiles");
     hipLaunchKernelGGL((fastq_scan_tiles_kernel<SCfg>), dim3((unsigned)n_tiles), dim3(SCfg::NT), 0, ctx->stream,
-                       bytes_dev, (uint64_t)n_bytes, shape.k, pk_eol, pk_stream, info, ctx->d_flags);
+                       bytes_dev, (uint64_t)n_bytes, shape.k, pk_eol, pk_stream, info, ctx->d_flags, (const uint8_t *)brk, n_cover);
   }
   KMI_TRY(launch_tile_offsets(ctx, info, n_tiles, (uint32_t)Cfg::TILE, hdr, base, off));
+  if (brk && n_tiles > 0) {
+    // n_seqs under a filter: records that pass / non-empty pieces (totals[2] held lines / 4)
+    KMI_HIP(ctx, hipMemsetAsync(ctx->d_totals + 2, 0, sizeof(uint64_t), ctx->stream));
+    hipLaunchKernelGGL((fastq_subseq_count_kernel<NW, BITS>), dim3((unsigned)n_tiles), dim3(Cfg::NT), 0, ctx->stream, r->packed,
+                       (const uint32_t *)base, seq_filter == KMI_SEQ_N_SPLIT, (unsigned long long *)(ctx->d_totals + 2));
+  }
   if (n_tiles > 0 && check_lengths) {
     ProfScope ps(ctx, "fastq_check", n_bytes);
     hipLaunchKernelGGL((fastq_check_lengths_kernel<Cfg::TILE>), dim3(2048), dim3(256), 0, ctx->stream, (const uint32_t *)pk_eol,
@@ -568,11 +702,11 @@ static kmi_status read_totals(kmi_ctx *ctx, uint64_t *n_tuples, uint64_t *n_seqs
 }
 
 template <int NW, int BITS>
-static kmi_status extract_count_impl(kmi_ctx *ctx, const uint8_t *bytes_dev, size_t n_bytes, KShape shape,
+static kmi_status extract_count_impl(kmi_ctx *ctx, const uint8_t *bytes_dev, size_t n_bytes, KShape shape, uint32_t seq_filter,
                                      uint64_t *n_tuples, uint64_t *n_seqs) {
   ScanResult r;
   KMI_HIP(ctx, hipMemsetAsync(ctx->d_flags, 0, sizeof(uint32_t) * 16, ctx->stream));
-  KMI_TRY((scan_impl<NW, BITS>(ctx, bytes_dev, n_bytes, shape, &r)));
+  KMI_TRY((scan_impl<NW, BITS>(ctx, bytes_dev, n_bytes, shape, &r, false, true, seq_filter)));
   return read_totals(ctx, n_tuples, n_seqs);
 }
 
@@ -584,7 +718,7 @@ static kmi_status extract_run_impl(kmi_ctx *ctx, const kmi_config *cfg, const ui
   using Cfg = ExCfg<NW, BITS>;
   ScanResult r;
   if (!scan_done) KMI_HIP(ctx, hipMemsetAsync(ctx->d_flags, 0, sizeof(uint32_t) * 16, ctx->stream));
-  KMI_TRY((scan_impl<NW, BITS>(ctx, bytes_dev, n_bytes, shape, &r, scan_done)));
+  KMI_TRY((scan_impl<NW, BITS>(ctx, bytes_dev, n_bytes, shape, &r, scan_done, true, cfg->seq_filter)));
   if (r.n_tiles > 0) {
     ProfScope ps(ctx, "fastq_extract", n_bytes);
     const bool canonical = apply_strand && cfg->strand != KMI_STRAND_SINGLE;
@@ -647,6 +781,7 @@ kmi_status fastq_scan(kmi_ctx *ctx, const kmi_config *cfg, const uint8_t *bytes_
   KShape shape;
   if (!valid_config(cfg, &shape)) return set_err(ctx, KMI_ERR_INVALID, "bad kmi_config");
   if (cfg->seq_format != KMI_FMT_FASTQ) return set_err(ctx, KMI_ERR_INVALID, "only FASTQ is implemented on the device yet");
+  if (cfg->seq_filter != KMI_SEQ_ALL) return set_err(ctx, KMI_ERR_INVALID, "the fused FASTQ passes run without a sequence filter (use the extract path)");
   KMI_DISPATCH(shape, fastq_scan_impl, ctx, bytes_dev, n_bytes, shape, out, check_lengths);
 }
 
@@ -725,7 +860,7 @@ kmi_status extract_count(kmi_ctx *ctx, const kmi_config *cfg, const uint8_t *byt
   if (n_bytes == 0) { if (n_tuples) *n_tuples = 0; if (n_seqs) *n_seqs = 0; return KMI_OK; }
   if (cfg->seq_format == KMI_FMT_FASTA)
     return fasta_extract(ctx, cfg, bytes_dev, n_bytes, shape, 0, nullptr, nullptr, 0, false, true, n_tuples, n_seqs);
-  KMI_DISPATCH(shape, extract_count_impl, ctx, bytes_dev, n_bytes, shape, n_tuples, n_seqs);
+  KMI_DISPATCH(shape, extract_count_impl, ctx, bytes_dev, n_bytes, shape, cfg->seq_filter, n_tuples, n_seqs);
 }
 
 kmi_status extract_run(kmi_ctx *ctx, const kmi_config *cfg, const uint8_t *bytes_dev, size_t n_bytes,

@@ -234,7 +234,7 @@ __global__ __launch_bounds__((FaCfg::NT)) void fasta_compact_kernel(const uint8_
                                                                    uint64_t index_shift /* + records before the buffer */, bool first_ls,
                                                                    uint64_t valid_bytes, const FaTileBase *__restrict__ base,
                                                                    uint32_t *__restrict__ pk_stream, uint32_t *__restrict__ pk_break,
-                                                                   uint64_t *__restrict__ ids, uint64_t *__restrict__ totals) {
+                                                                   uint64_t *__restrict__ ids, uint64_t *__restrict__ totals, bool split_n) {
   constexpr int C = FaCfg::C;
   __shared__ uint32_t s_nl[FaCfg::NT / 2 + 2];
   __shared__ uint32_t s_scanm[FaCfg::NT / 64 + 2];
@@ -279,6 +279,13 @@ __global__ __launch_bounds__((FaCfg::NT)) void fasta_compact_kernel(const uint8_
       const uint32_t p = (uint32_t)__builtin_ctz(rest);
       const uint32_t c = (dw[p >> 2] >> (8 * (p & 3))) & 0xffu;
       const uint64_t cc = comp_code<BITS>(code_of<BITS>(c));
+      if (split_n && (c == 'N' || c == 'n')) {
+        // NSplitSequencesIterator (filtered_sequence_iterator.hpp:411-440): no window may hold this character. A break bit
+        // at character x blocks the windows that start in [x - k + 1, x - 1], so bits at x and x + 1 block [x - k + 1, x].
+        const uint64_t rk = rank0 + m;
+        atomicOr(&pk_break[rk >> 5], 1u << (rk & 31u));
+        atomicOr(&pk_break[(rk + 1) >> 5], 1u << ((rk + 1) & 31u));
+      }
       const uint32_t bit = m * BITS;
       if (bit < 64) run_lo |= cc << bit;
       if (bit + BITS > 64) run_hi |= (uint32_t)(cc >> (64 - bit));
@@ -365,10 +372,12 @@ kmi_status fasta_scan(kmi_ctx *ctx, const kmi_config *cfg, const uint8_t *bytes_
     ProfScope ps(ctx, "fasta_compact", n_bytes);
     if (shape.bits == 2)
       hipLaunchKernelGGL((fasta_compact_kernel<2>), dim3((unsigned)n_tiles), dim3(FaCfg::NT), 0, ctx->stream, bytes_dev, (uint64_t)n_bytes,
-                         file_offset, index_shift, first_ls, valid_bytes, (const FaTileBase *)base, pk_stream, pk_break, ids, ctx->d_totals);
+                         file_offset, index_shift, first_ls, valid_bytes, (const FaTileBase *)base, pk_stream, pk_break, ids, ctx->d_totals,
+                         cfg->seq_filter == KMI_SEQ_N_SPLIT);
     else
       hipLaunchKernelGGL((fasta_compact_kernel<3>), dim3((unsigned)n_tiles), dim3(FaCfg::NT), 0, ctx->stream, bytes_dev, (uint64_t)n_bytes,
-                         file_offset, index_shift, first_ls, valid_bytes, (const FaTileBase *)base, pk_stream, pk_break, ids, ctx->d_totals);
+                         file_offset, index_shift, first_ls, valid_bytes, (const FaTileBase *)base, pk_stream, pk_break, ids, ctx->d_totals,
+                         cfg->seq_filter == KMI_SEQ_N_SPLIT);
   }
   KMI_HIP(ctx, hipGetLastError());
   out->n_chars = ctx->h_totals[0];

@@ -2439,14 +2439,24 @@ kmi_status kmi_index_set_seq_format(kmi_index *idx, uint32_t seq_format) {
   return KMI_OK;
 }
 
+kmi_status kmi_index_set_seq_filter(kmi_index *idx, uint32_t seq_filter) {
+  if (!idx) return KMI_ERR_INVALID;
+  kmi_config c = idx->cfg;
+  c.seq_filter = seq_filter;
+  if (!kmi::valid_config(&c, nullptr)) return set_err(idx->ctx, KMI_ERR_INVALID, "sequence filter not available for this index (see kmi_config.seq_filter)");
+  idx->cfg.seq_filter = seq_filter;
+  return KMI_OK;
+}
+
 kmi_status kmi_index_build_dev(kmi_index *idx, const uint8_t *bytes_dev, size_t n_bytes, uint64_t file_offset) {
   if (!idx) return KMI_ERR_INVALID;
   kmi_ctx *ctx = idx->ctx;
   KMI_HIP(ctx, hipSetDevice(ctx->device));
   if (n_bytes == 0) return KMI_OK;
-  if (idx->val_words == 0 && idx->cfg.seq_format == KMI_FMT_FASTQ) return index_build_fused(idx, bytes_dev, n_bytes);
+  if (idx->val_words == 0 && idx->cfg.seq_format == KMI_FMT_FASTQ && idx->cfg.seq_filter == KMI_SEQ_ALL)
+    return index_build_fused(idx, bytes_dev, n_bytes);
   if (idx->val_words == 0) {
-    // FASTA count index: tuples from the compacted-stream extract, then the key insert path
+    // FASTA count index, or FASTQ with a sequence filter: tuples from the extract path, then the key insert path
     uint64_t nt = 0, ns = 0;
     KMI_TRY(extract_count(ctx, &idx->cfg, bytes_dev, n_bytes, &nt, &ns));
     if (nt == 0) return KMI_OK;

@@ -42,6 +42,8 @@ enum WsSlot {
   WS_ENT_BKT,         // rank bucket of the 8 windows of every entry, one byte each (fused extract + route)
   WS_ENT_LIST,        // entry list: runs of <= 8 consecutive windows, per-tile slots (fused build)
   WS_ENT_CNT,         // entries per scan tile
+  WS_PK_BRK,          // window-break bitmap (EOL or N) of the scanned input (N_FILTER / N_SPLIT)
+  WS_PK_NB,           // N bitmap and pure EOL bitmap of the pre-pass (N_FILTER)
   WS_SPLIT_RANK,      // destination rank of every index entry (split by rank)
   WS_SPLIT_OFF,       // per-part bucket offsets, part totals and bases (split / merge)
   WS_NUM_SLOTS
@@ -145,7 +147,9 @@ inline bool valid_config(const kmi_config *cfg, KShape *shape) {
   if (!bits) return false;
   KShape s = make_shape(cfg->k, bits);
   if (s.n_words > (uint32_t)kMaxWords) return false;
-  if (cfg->strand > 2 || cfg->dist_hash > 3 || cfg->store_hash > 3 || cfg->seq_format > 1 || cfg->index_kind > 2) return false;
+  if (cfg->strand > 2 || cfg->dist_hash > 3 || cfg->store_hash > 3 || cfg->seq_format > 1 || cfg->index_kind > 2 || cfg->seq_filter > 2) return false;
+  if (cfg->seq_filter == KMI_SEQ_N_FILTER && cfg->seq_format == KMI_FMT_FASTA) return false;   // not implemented
+  if (cfg->seq_filter && cfg->index_kind == KMI_INDEX_POSQUAL) return false;
   if (shape) *shape = s;
   return true;
 }

@@ -549,9 +549,76 @@ float orc_qual_lut(uint8_t phred_char) {
 /* tuple extraction                                                         */
 /* ------------------------------------------------------------------------ */
 
-long orc_extract(const orc_kspec *s, uint32_t fmt, const uint8_t *bytes, size_t n,
-                 uint64_t file_offset, uint64_t *kmers, uint64_t *ids, float *quals,
-                 size_t out_cap, size_t *n_seqs) {
+/* one (sub)sequence [sb, se) of record rec through the k-mer parser; returns the running tuple count */
+static size_t extract_range(const orc_kspec *s, uint32_t fmt, const uint8_t *bytes, uint64_t file_offset, const orc_record *rec,
+                            size_t sb, size_t se, uint64_t *kmers, uint64_t *ids, float *quals, size_t out_cap, size_t total,
+                            float *qwin) {
+  const uint32_t K = s->k;
+  const float q_lo = orc_qual_lut(33), q_hi = orc_qual_lut(33 + 95);
+  /* KmerGenerationIterator over NotEOL-filtered, ASCII2-mapped chars
+   * (kmer_parser.hpp:198-213, kmer_iterators.hpp:67-116): first K non-EOL chars
+   * fill the window, every further non-EOL char slides it by one. */
+  uint64_t km[ORC_MAX_WORDS];
+  orc_kmer_clear(s, km);
+  uint32_t filled = 0;
+  /* ids of the window's chars: circular buffer of raw offsets */
+  uint64_t *pos_ring = (uint64_t *)malloc(sizeof(uint64_t) * K);
+  uint32_t ring = 0;
+  /* quality window state (quality_score_iterator.hpp:99-173) */
+  float qsum = 0.0f; uint32_t n_bad = 0, qpos = 0;
+  const size_t rsb = (size_t)(rec->seq_begin - file_offset);
+  size_t qb = (size_t)(rec->qual_begin - file_offset);
+  for (size_t i = sb; i < se; ++i) {
+    uint8_t c = bytes[i];
+    if (is_eol(c)) continue;
+    orc_kmer_next_from_char(s, km, orc_from_ascii(s->alphabet, c));
+    pos_ring[ring] = file_offset + i; ring = (ring + 1) % K;
+    if (quals && fmt == ORC_FMT_FASTQ) {
+      float nv = orc_qual_lut(bytes[qb + (i - rsb)]);
+      if (filled >= K) {
+        float ov = qwin[qpos];
+        if (ov > q_lo && ov < q_hi) qsum -= ov; else --n_bad;
+      }
+      qwin[qpos] = nv; qpos = (qpos + 1) % K;
+      if (nv > q_lo && nv < q_hi) qsum += nv; else ++n_bad;
+    }
+    if (filled < K) ++filled;
+    if (filled >= K) {
+      if (total < out_cap) {
+        if (kmers) memcpy(kmers + total * s->n_words, km, s->n_words * sizeof(uint64_t));
+        if (ids) {
+          uint64_t first_pos = pos_ring[ring]; /* oldest entry = first base of window */
+          if (fmt == ORC_FMT_FASTQ) {
+            /* ShortSequenceKmerId: sequence.hpp:156-157 + kmer_parser.hpp:378-386 */
+            ids[total] = ((rec->record_offset & 0xFFFFFFFFFFULL) << 16) |
+                         ((first_pos - rec->record_offset) & 0xFFFF);
+          } else {
+            /* LongSequenceKmerId: sequence.hpp:254-255 */
+            ids[total] = (first_pos & 0xFFFFFFFFFFULL) | ((rec->seq_index & 0xFFFF) << 40);
+          }
+        }
+        if (quals) quals[total] = (fmt == ORC_FMT_FASTQ) ? (n_bad > 0 ? 0.0f : exp2f(qsum)) : 0.0f;
+      }
+      ++total;
+    }
+  }
+  free(pos_ring);
+  return total;
+}
+
+/* seq_filter = the SeqIterType of read_file_* (src/io/filtered_sequence_iterator.hpp):
+ * ORC_SEQ_ALL      SequencesIterator: every record;
+ * ORC_SEQ_N_FILTER NFilterSequencesIterator (:154-165): records whose [seq_begin, seq_end) holds an 'N' are skipped;
+ * ORC_SEQ_N_SPLIT  NSplitSequencesIterator (:166-440): each sequence is cut into the maximal runs of characters that
+ *                  satisfy NCharFilter (x != 'N' && x != 'n', :411-418); a run keeps the record's id, offsets count from the
+ *                  record start (split_seq, :228-249). read_block (kmer_file_helper.hpp:128-178) skips empty pieces
+ *                  and counts every other one as a sequence.
+ * *n_yield (may be NULL): what the reference's parse TESTS count (mpi_test_fastq_seq_parse.cpp:918-921): every
+ * sequence the iterator yields, including the empty one it produces for a run of trailing N (split_seq on a
+ * remainder of only-N characters). */
+long orc_extract_filtered(const orc_kspec *s, uint32_t fmt, uint32_t seq_filter, const uint8_t *bytes, size_t n,
+                          uint64_t file_offset, uint64_t *kmers, uint64_t *ids, float *quals,
+                          size_t out_cap, size_t *n_seqs, size_t *n_yield) {
   long nrec = (fmt == ORC_FMT_FASTQ) ? orc_fastq_records(bytes, n, file_offset, NULL, 0)
                                      : orc_fasta_records(bytes, n, file_offset, NULL, 0);
   if (nrec < 0) return -1;
@@ -559,67 +626,45 @@ long orc_extract(const orc_kspec *s, uint32_t fmt, const uint8_t *bytes, size_t 
   if (fmt == ORC_FMT_FASTQ) orc_fastq_records(bytes, n, file_offset, recs, (size_t)nrec);
   else orc_fasta_records(bytes, n, file_offset, recs, (size_t)nrec);
 
-  size_t total = 0, seqs = 0;
-  const uint32_t K = s->k;
-  float *qwin = (float *)malloc(sizeof(float) * K);
-  const float q_lo = orc_qual_lut(33), q_hi = orc_qual_lut(33 + 95);
+  size_t total = 0, seqs = 0, yields = 0;
+  float *qwin = (float *)malloc(sizeof(float) * s->k);
   for (long r = 0; r < nrec; ++r) {
     const orc_record *rec = &recs[r];
     size_t sb = (size_t)(rec->seq_begin - file_offset), se = (size_t)(rec->seq_end - file_offset);
+    if (seq_filter == ORC_SEQ_N_SPLIT) {
+      if (quals) { free(qwin); free(recs); return -1; }   /* no quality values for pieces */
+      size_t nb = sb;                                      /* `next` = [nb, se) */
+      while (nb < se) {                                    /* get_next skips records whose remainder is empty */
+        size_t b = nb;
+        while (b < se && (bytes[b] == 'N' || bytes[b] == 'n')) ++b;     /* find_if(pred) */
+        size_t e = b;
+        while (e < se && !(bytes[e] == 'N' || bytes[e] == 'n')) ++e;    /* find_if_not(pred) */
+        ++yields;
+        if (e > b) {                                       /* kmer_file_helper.hpp:139 */
+          ++seqs;
+          total = extract_range(s, fmt, bytes, file_offset, rec, b, e, kmers, ids, NULL, out_cap, total, qwin);
+        }
+        nb = e;
+      }
+      continue;
+    }
+    if (seq_filter == ORC_SEQ_N_FILTER && se > sb && memchr(bytes + sb, 'N', se - sb)) continue;
+    ++yields;
     if (se == sb) continue;                               /* kmer_file_helper.hpp:139 */
     ++seqs;                                               /* :176-177 (whole buffer is valid) */
-    /* KmerGenerationIterator over NotEOL-filtered, ASCII2-mapped chars
-     * (kmer_parser.hpp:198-213, kmer_iterators.hpp:67-116): first K non-EOL chars
-     * fill the window, every further non-EOL char slides it by one. */
-    uint64_t km[ORC_MAX_WORDS];
-    orc_kmer_clear(s, km);
-    uint32_t filled = 0;
-    /* ids of the window's chars: circular buffer of raw offsets */
-    uint64_t *pos_ring = (uint64_t *)malloc(sizeof(uint64_t) * K);
-    uint32_t ring = 0;
-    /* quality window state (quality_score_iterator.hpp:99-173) */
-    float qsum = 0.0f; uint32_t n_bad = 0, qpos = 0;
-    size_t qb = (size_t)(rec->qual_begin - file_offset);
-    for (size_t i = sb; i < se; ++i) {
-      uint8_t c = bytes[i];
-      if (is_eol(c)) continue;
-      orc_kmer_next_from_char(s, km, orc_from_ascii(s->alphabet, c));
-      pos_ring[ring] = file_offset + i; ring = (ring + 1) % K;
-      if (quals && fmt == ORC_FMT_FASTQ) {
-        float nv = orc_qual_lut(bytes[qb + (i - sb)]);
-        if (filled >= K) {
-          float ov = qwin[qpos];
-          if (ov > q_lo && ov < q_hi) qsum -= ov; else --n_bad;
-        }
-        qwin[qpos] = nv; qpos = (qpos + 1) % K;
-        if (nv > q_lo && nv < q_hi) qsum += nv; else ++n_bad;
-      }
-      if (filled < K) ++filled;
-      if (filled >= K) {
-        if (total < out_cap) {
-          if (kmers) memcpy(kmers + total * s->n_words, km, s->n_words * sizeof(uint64_t));
-          if (ids) {
-            uint64_t first_pos = pos_ring[ring]; /* oldest entry = first base of window */
-            if (fmt == ORC_FMT_FASTQ) {
-              /* ShortSequenceKmerId: sequence.hpp:156-157 + kmer_parser.hpp:378-386 */
-              ids[total] = ((rec->record_offset & 0xFFFFFFFFFFULL) << 16) |
-                           ((first_pos - rec->record_offset) & 0xFFFF);
-            } else {
-              /* LongSequenceKmerId: sequence.hpp:254-255 */
-              ids[total] = (first_pos & 0xFFFFFFFFFFULL) | ((rec->seq_index & 0xFFFF) << 40);
-            }
-          }
-          if (quals) quals[total] = (fmt == ORC_FMT_FASTQ) ? (n_bad > 0 ? 0.0f : exp2f(qsum)) : 0.0f;
-        }
-        ++total;
-      }
-    }
-    free(pos_ring);
+    total = extract_range(s, fmt, bytes, file_offset, rec, sb, se, kmers, ids, quals, out_cap, total, qwin);
   }
   free(qwin);
   free(recs);
   if (n_seqs) *n_seqs = seqs;
+  if (n_yield) *n_yield = yields;
   return (long)total;
+}
+
+long orc_extract(const orc_kspec *s, uint32_t fmt, const uint8_t *bytes, size_t n,
+                 uint64_t file_offset, uint64_t *kmers, uint64_t *ids, float *quals,
+                 size_t out_cap, size_t *n_seqs) {
+  return orc_extract_filtered(s, fmt, ORC_SEQ_ALL, bytes, n, file_offset, kmers, ids, quals, out_cap, n_seqs, NULL);
 }
 
 /* ------------------------------------------------------------------------ */

@@ -134,6 +134,12 @@ long orc_extract(const orc_kspec *s, uint32_t fmt, const uint8_t *bytes, size_t 
                  uint64_t file_offset, uint64_t *kmers, uint64_t *ids, float *quals,
                  size_t out_cap, size_t *n_seqs);
 
+/* the same behind one of the reference's filtering sequence iterators (filtered_sequence_iterator.hpp:154-165, 166-440) */
+enum { ORC_SEQ_ALL = 0, ORC_SEQ_N_FILTER = 1, ORC_SEQ_N_SPLIT = 2 };
+long orc_extract_filtered(const orc_kspec *s, uint32_t fmt, uint32_t seq_filter, const uint8_t *bytes, size_t n,
+                          uint64_t file_offset, uint64_t *kmers, uint64_t *ids, float *quals,
+                          size_t out_cap, size_t *n_seqs, size_t *n_yield);
+
 /* quality: Illumina18 codec LUT + sliding window,
  * src/index/quality_scores.hpp:88-341, quality_score_iterator.hpp:67-173 */
 float orc_qual_lut(uint8_t phred_char);

@@ -90,6 +90,14 @@ def parse_golden():
     b = _block(fa, "INSTANTIATE_TEST_CASE_P(Bliss, FASTAParseTest", "));")
     for m in re.finditer(r"^\s*TestFileInfo\((\d+),\s*(\d+),\s*(\d+),\s*std::string\(\"/test/data/([^\"]+)\"\)", b, re.M):
         out["fasta"]["files"].append({"file": m.group(4), "records": int(m.group(1)), "kmers": int(m.group(2)), "bytes": int(m.group(3))})
+    # the same tables behind the filtering sequence iterators: NoN*ParseTest (NFilterSequencesIterator) and Split*ParseTest
+    # (NSplitSequencesIterator). "records" is what those tests count: every sequence the iterator yields.
+    pat = r"^\s*TestFileInfo\((\d+),\s*(\d+),\s*(\d+),\s*std::string\(\"/test/data/([^\"]+)\"\)"
+    for fmt, src, stem in (("fastq", fq, "FASTQParseTest"), ("fasta", fa, "FASTAParseTest")):
+        for key, cls in (("n_filter", "NoN" + stem), ("n_split", "Split" + stem)):
+            b = _block(src, "INSTANTIATE_TEST_CASE_P(Bliss, " + cls, "));")
+            out[fmt][key] = [{"file": m.group(4), "yielded": int(m.group(1)), "kmers": int(m.group(2)), "bytes": int(m.group(3))}
+                             for m in re.finditer(pat, b, re.M)]
     return out
 
 

@@ -65,6 +65,9 @@ lib.orc_fasta_records.restype = C.c_long
 lib.orc_extract.argtypes = [_SP, C.c_uint32, _u8p, C.c_size_t, C.c_uint64, C.c_void_p, C.c_void_p,
                             C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
 lib.orc_extract.restype = C.c_long
+lib.orc_extract_filtered.argtypes = [_SP, C.c_uint32, C.c_uint32, _u8p, C.c_size_t, C.c_uint64, C.c_void_p, C.c_void_p,
+                                     C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+lib.orc_extract_filtered.restype = C.c_long
 lib.orc_qual_lut.argtypes = [C.c_uint8]
 lib.orc_qual_lut.restype = C.c_float
 lib.orc_stable_bucket.argtypes = [_u32p, C.c_size_t, C.c_uint32, _u64p, _u64p]
@@ -170,19 +173,22 @@ def records(data, fmt=FASTQ, file_offset=0):
     return [arr[i] for i in range(n)]
 
 
-def extract(s, data, fmt=FASTQ, file_offset=0, want_ids=False, want_quals=False):
-    """reference parser output for a whole buffer: dict(kmers, ids, quals, n_seqs)"""
+SEQ_ALL, SEQ_N_FILTER, SEQ_N_SPLIT = 0, 1, 2
+
+
+def extract(s, data, fmt=FASTQ, file_offset=0, want_ids=False, want_quals=False, seq_filter=SEQ_ALL):
+    """reference parser output for a whole buffer: dict(kmers, ids, quals, n_seqs, n_yield); seq_filter = the SeqIterType"""
     b = _as_bytes(data)
-    nseq = C.c_size_t(0)
-    n = lib.orc_extract(C.byref(s), fmt, b, b.size, file_offset, None, None, None, 0, C.byref(nseq))
+    nseq, nyield = C.c_size_t(0), C.c_size_t(0)
+    n = lib.orc_extract_filtered(C.byref(s), fmt, seq_filter, b, b.size, file_offset, None, None, None, 0, C.byref(nseq), C.byref(nyield))
     if n < 0:
         raise ValueError("parse error")
     kmers = np.zeros((n, s.n_words), dtype=np.uint64)
     ids = np.zeros(n, dtype=np.uint64) if want_ids else None
     quals = np.zeros(n, dtype=np.float32) if want_quals else None
-    lib.orc_extract(C.byref(s), fmt, b, b.size, file_offset, _ptr(kmers), _ptr(ids), _ptr(quals), n,
-                    C.byref(nseq))
-    return {"kmers": kmers, "ids": ids, "quals": quals, "n_seqs": nseq.value}
+    lib.orc_extract_filtered(C.byref(s), fmt, seq_filter, b, b.size, file_offset, _ptr(kmers), _ptr(ids), _ptr(quals), n,
+                             C.byref(nseq), C.byref(nyield))
+    return {"kmers": kmers, "ids": ids, "quals": quals, "n_seqs": nseq.value, "n_yield": nyield.value}
 
 
 class CountMap:

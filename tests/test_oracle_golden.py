@@ -199,6 +199,30 @@ def test_fasta_parse_counts_match_reference_table():
     assert checked >= 4
 
 
+@pytest.mark.parametrize("fmt", ["fastq", "fasta"])
+def test_filtered_parse_counts_match_reference_tables(fmt):
+    """NoN*ParseTest / Split*ParseTest tables (mpi_test_fastq_seq_parse.cpp:834-846,1420-1432;
+    mpi_test_fasta_seq_parse.cpp:764-769,1255-1260): sequences the NFilter / NSplit iterators yield and the k-mers parsed
+    from them."""
+    pg = _load("parse_golden.json")[fmt]
+    s = orc.kspec(pg["k"], orc.DNA5)
+    checked = with_n = 0
+    for key, flt in (("n_filter", orc.SEQ_N_FILTER), ("n_split", orc.SEQ_N_SPLIT)):
+        plain = {e["file"]: e for e in pg["files"]}
+        for e in pg[key]:
+            path = os.path.join(GOLD, "data", e["file"])
+            if not os.path.exists(path):
+                continue
+            data = open(path, "rb").read()
+            assert len(data) == e["bytes"]
+            ex = orc.extract(s, data, orc.FASTQ if fmt == "fastq" else orc.FASTA, seq_filter=flt)
+            assert ex["n_yield"] == e["yielded"], (key, e)
+            assert ex["kmers"].shape[0] == e["kmers"], (key, e)
+            with_n += e["kmers"] != plain[e["file"]]["kmers"]
+            checked += 1
+    assert checked >= 8 and with_n >= 2      # natural.withN.* differs from its unfiltered row under both filters
+
+
 def test_kmer_text_roundtrip_positions():
     """mpi_test_fastq_seq_parse.cpp:235-330: every k-mer equals the file bytes at its id"""
     data = open(os.path.join(GOLD, "data", "test.small.fastq"), "rb").read()
