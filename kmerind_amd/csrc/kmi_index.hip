@@ -1163,11 +1163,13 @@ template <int NW> struct LdsTable {
   uint32_t *overflow;  // flag
   uint32_t *special;   // value of the key that equals the empty sentinel (NW == 1)
   uint32_t *special_set;
+  // geometry in use: TabCfg's by default; the query kernel sizes it to the bucket's query count (a table that is cleared
+  // and swept once per bucket should not be larger than its keys need)
+  uint32_t cap, slots, limit;
 };
 
 template <int NW> __device__ __forceinline__ void table_clear(const LdsTable<NW> &t) {
-  constexpr int SLOTS = TabCfg<NW>::SLOTS;
-  for (int i = threadIdx.x; i < SLOTS; i += blockDim.x) {
+  for (uint32_t i = threadIdx.x; i < t.slots; i += blockDim.x) {
     t.vals[i] = 0;
     if (NW == 1) t.keys[i] = kEmptyKey; else t.tags[i] = kTagEmpty;
   }
@@ -1180,14 +1182,14 @@ __device__ __forceinline__ uint32_t slot_of(uint32_t h, int cap) {
 
 // find-or-insert; returns slot (or -1 when the table overflowed / special key). `inserted` tells a new key.
 template <int NW> __device__ __forceinline__ int table_upsert(const LdsTable<NW> &t, const uint64_t (&key)[NW], uint32_t h) {
-  constexpr int CAP = TabCfg<NW>::CAP;
-  uint32_t slot = slot_of(h, CAP);
+  const uint32_t CAP = t.cap;
+  uint32_t slot = slot_of(h, (int)CAP);
   if (NW == 1) {
     if (key[0] == kEmptyKey) { *t.special_set = 1; return -2; }
-    for (int probes = 0; slot < (uint32_t)TabCfg<1>::SLOTS - 1; ++probes, ++slot) {
+    for (int probes = 0; slot < t.slots - 1u; ++probes, ++slot) {
       unsigned long long old = atomicCAS((unsigned long long *)&t.keys[slot], (unsigned long long)kEmptyKey, (unsigned long long)key[0]);
       if (old == kEmptyKey) {
-        if (atomicAdd(t.distinct, 1u) >= (uint32_t)TabCfg<1>::LIMIT || probes >= kMaxProbe) *t.overflow = 1;   // too loaded: more passes
+        if (atomicAdd(t.distinct, 1u) >= t.limit || probes >= kMaxProbe) *t.overflow = 1;   // too loaded: more passes
         return (int)slot;
       }
       if (old == key[0]) return (int)slot;
@@ -1197,7 +1199,7 @@ template <int NW> __device__ __forceinline__ int table_upsert(const LdsTable<NW>
   } else {
     const uint32_t tagv = h | 0x80000000u;
     int probes = 0;
-    while (probes < CAP) {
+    while (probes < (int)CAP) {
       uint32_t tg = __atomic_load_n(&t.tags[slot], __ATOMIC_RELAXED);
       if (tg == kTagEmpty) {
         uint32_t old = atomicCAS(&t.tags[slot], kTagEmpty, kTagLock);
@@ -1218,7 +1220,7 @@ template <int NW> __device__ __forceinline__ int table_upsert(const LdsTable<NW>
         for (int w = 0; w < NW; ++w) eq &= (t.keys[(uint64_t)slot * NW + w] == key[w]);
         if (eq) { if (probes >= kMaxProbe) *t.overflow = 1; return (int)slot; }
       }
-      slot = (slot + 1 == (uint32_t)CAP) ? 0u : slot + 1;
+      slot = (slot + 1 == CAP) ? 0u : slot + 1;
       ++probes;
     }
     *t.overflow = 1;
@@ -1311,8 +1313,8 @@ __device__ __forceinline__ void table_insert_stream1(const LdsTable<1> &t, const
 
 // lookup only; returns slot or -1
 template <int NW> __device__ __forceinline__ int table_find(const LdsTable<NW> &t, const uint64_t (&key)[NW], uint32_t h) {
-  constexpr int CAP = TabCfg<NW>::CAP;
-  uint32_t slot = slot_of(h, CAP);
+  const uint32_t CAP = t.cap;
+  uint32_t slot = slot_of(h, (int)CAP);
   if (NW == 1) {
     if (key[0] == kEmptyKey) return *t.special_set ? -2 : -1;
     for (;; ++slot) {   // ends at the latest on the never-filled last slot
@@ -1322,7 +1324,7 @@ template <int NW> __device__ __forceinline__ int table_find(const LdsTable<NW> &
     }
   } else {
     const uint32_t tagv = h | 0x80000000u;
-    for (int probes = 0; probes < CAP; ++probes) {
+    for (uint32_t probes = 0; probes < CAP; ++probes) {
       uint32_t tg = t.tags[slot];
       if (tg == kTagEmpty) return -1;
       if (tg == tagv) {
@@ -1331,7 +1333,7 @@ template <int NW> __device__ __forceinline__ int table_find(const LdsTable<NW> &
         for (int w = 0; w < NW; ++w) eq &= (t.keys[(uint64_t)slot * NW + w] == key[w]);
         if (eq) return (int)slot;
       }
-      slot = (slot + 1 == (uint32_t)CAP) ? 0u : slot + 1;
+      slot = (slot + 1 == CAP) ? 0u : slot + 1;
     }
     return -1;
   }
@@ -1363,14 +1365,27 @@ __device__ __forceinline__ void for_each_key(const uint64_t *__restrict__ keys, 
 }
 template <int NW> struct BatchOf { static constexpr int U = (NW == 1) ? kLoadBatch : (NW == 2 ? 4 : 2); };
 
-#define KMI_TABLE_LDS(NW)                                                   \
-  __shared__ uint64_t s_tk[TabCfg<NW>::SLOTS * NW];                         \
-  __shared__ uint32_t s_tv[TabCfg<NW>::SLOTS];                              \
-  __shared__ uint32_t s_tt[(NW == 1) ? 1 : TabCfg<NW>::SLOTS];             \
+// the query kernel's table: it holds a bucket's distinct QUERY keys (a few hundred for the benchmark's 10 M queries), is
+// cleared and swept once per bucket, and 32768 short-lived workgroups are launched, so it keeps the smaller geometry
+// (two 512-thread workgroups per CU) that the reduce table had before it grew
+template <int NW> struct QTabCfg {
+  static constexpr int CAP = (NW == 1) ? 6656 : TabCfg<NW>::CAP;
+  static constexpr int PAD = TabCfg<NW>::PAD;
+  static constexpr int SLOTS = CAP + PAD;
+  static constexpr int LIMIT = CAP * 3 / 4;
+  static constexpr int NT = 512;
+};
+
+#define KMI_TABLE_LDS_CFG(NW, CFG)                                          \
+  __shared__ uint64_t s_tk[CFG::SLOTS * NW];                                \
+  __shared__ uint32_t s_tv[CFG::SLOTS];                                     \
+  __shared__ uint32_t s_tt[(NW == 1) ? 1 : CFG::SLOTS];                    \
   __shared__ uint32_t s_ctl[8];                                             \
   LdsTable<NW> tab;                                                         \
   tab.keys = s_tk; tab.vals = s_tv; tab.tags = s_tt; tab.distinct = &s_ctl[0]; tab.overflow = &s_ctl[1]; \
-  tab.special = &s_ctl[2]; tab.special_set = &s_ctl[3];
+  tab.special = &s_ctl[2]; tab.special_set = &s_ctl[3];                    \
+  tab.cap = CFG::CAP; tab.slots = CFG::SLOTS; tab.limit = CFG::LIMIT;
+#define KMI_TABLE_LDS(NW) KMI_TABLE_LDS_CFG(NW, TabCfg<NW>)
 
 // ---------------------------------------------------------------------------
 // C: per fine bucket reduce  (new keys weight 1, old entries weight = their count)
@@ -1632,13 +1647,13 @@ enum QueryMode { Q_COUNT = 0, Q_FIND = 1, Q_ERASE = 2 };
 // VW = 0: counting map (values are u32 counts in idx_vals32); VW > 0: multimap (every entry carries
 // VW 64-bit value words in idx_mvals, a key may occur many times). Output value stride OW = max(1, VW).
 template <int NW, int VW>
-__global__ __launch_bounds__((TabCfg<NW>::NT)) void bucket_query_kernel(int mode, const uint64_t *__restrict__ q_keys, const uint64_t *__restrict__ q_off,
+__global__ __launch_bounds__((QTabCfg<NW>::NT)) void bucket_query_kernel(int mode, const uint64_t *__restrict__ q_keys, const uint64_t *__restrict__ q_off,
                                                                        const uint64_t *__restrict__ idx_keys, const uint32_t *__restrict__ idx_vals32,
                                                                        const uint64_t *__restrict__ idx_mvals,
                                                                        const uint64_t *__restrict__ idx_off, uint64_t *__restrict__ tmp_keys,
                                                                        uint64_t *__restrict__ tmp_vals64, uint32_t *__restrict__ tmp_vals32,
                                                                        uint32_t *__restrict__ out_cnt, uint32_t *__restrict__ flags) {
-  KMI_TABLE_LDS(NW)
+  KMI_TABLE_LDS_CFG(NW, QTabCfg<NW>)
   constexpr int OW = VW ? VW : 1;
   const uint32_t b = blockIdx.x;
   const uint64_t qb = q_off[b], qe = q_off[b + 1];
@@ -1658,6 +1673,13 @@ __global__ __launch_bounds__((TabCfg<NW>::NT)) void bucket_query_kernel(int mode
       for (int w = 0; w < VW; ++w) tmp_vals64[(tmp0 + pos) * VW + w] = idx_mvals[i * VW + w];
     }
   };
+  {
+    // the table only ever holds this bucket's distinct query keys: twice their number of home slots, at least 512
+    uint32_t want = 2u * (uint32_t)((qe - qb) < (uint64_t)QTabCfg<NW>::CAP ? (qe - qb) : (uint64_t)QTabCfg<NW>::CAP);
+    want = (want + 255u) & ~255u;
+    want = want < 512u ? 512u : want;
+    if (want < (uint32_t)QTabCfg<NW>::CAP) { tab.cap = want; tab.slots = want + QTabCfg<NW>::PAD; tab.limit = want * 3u / 4u; }
+  }
   if (qb == qe) {
     if (mode == Q_ERASE) {
       // nothing to erase here: all entries survive
@@ -1707,8 +1729,8 @@ __global__ __launch_bounds__((TabCfg<NW>::NT)) void bucket_query_kernel(int mode
       }
       lds_barrier();
       if (mode == Q_COUNT) {
-        for (int s = threadIdx.x; s < TabCfg<NW>::SLOTS; s += blockDim.x) {
-          const bool used = slot_used<NW>(tab, s);
+        for (uint32_t s = threadIdx.x; s < ((tab.slots + kWave - 1u) & ~(uint32_t)(kWave - 1)); s += blockDim.x) {   // whole waves: wave_alloc
+          const bool used = s < tab.slots && slot_used<NW>(tab, (int)s);
           const uint32_t pos = wave_alloc(s_out, used);
           if (used) {
 #pragma unroll
@@ -2096,7 +2118,7 @@ static kmi_status query_vw(kmi_index *idx, int mode, const uint64_t *q_dev, size
   KMI_TRY(ws_get(ctx, WS_BUCKET_CNT, sizeof(uint32_t) * kNumFine, &p)); uint32_t *out_cnt = (uint32_t *)p;
   {
     ProfScope ps(ctx, mode == Q_COUNT ? "bucket_query_count" : (mode == Q_FIND ? "bucket_query_find" : "bucket_query_erase"), nq);
-    hipLaunchKernelGGL((bucket_query_kernel<NW, VW>), dim3(kNumFine), dim3(TabCfg<NW>::NT), 0, ctx->stream, mode, (const uint64_t *)part.keys,
+    hipLaunchKernelGGL((bucket_query_kernel<NW, VW>), dim3(kNumFine), dim3(QTabCfg<NW>::NT), 0, ctx->stream, mode, (const uint64_t *)part.keys,
                        (const uint64_t *)part.fine_off, (const uint64_t *)idx->keys, (const uint32_t *)idx->vals, (const uint64_t *)idx->mvals,
                        (const uint64_t *)(idx->has_data ? idx->bucket_off : nullptr), tmp_keys, (uint64_t *)tmp_vals, (uint32_t *)tmp_vals,
                        out_cnt, ctx->d_flags);
