@@ -71,8 +71,8 @@ typedef struct {
   uint32_t farm_ndebug;/* 0: farmhash as the reference's default RelWithDebInfo build computes it
                           (DebugTweak active, CMakeLists.txt:26,200-204); 1: -DNDEBUG behaviour */
   uint32_t seq_filter; /* KMI_SEQ_*. With a filter, n_seqs counts what the reference's read_block counts: records
-                          that pass (N_FILTER) or non-empty pieces (N_SPLIT; FASTA: records). FASTQ: both filters;
-                          FASTA: N_SPLIT. Quality values (KMI_INDEX_POSQUAL) need KMI_SEQ_ALL. */
+                          that pass (N_FILTER) or non-empty pieces (N_SPLIT; FASTA: records). FASTA with a filter
+                          needs k >= 2. Quality values (KMI_INDEX_POSQUAL) need KMI_SEQ_ALL. */
 } kmi_config;
 
 typedef struct kmi_ctx kmi_ctx;     /* replaces mxx::comm + per-rank state */

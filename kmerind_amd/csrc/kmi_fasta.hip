@@ -20,6 +20,8 @@
 // of a record, and optionally the id of every character. After that FASTA is "FASTQ without
 // roles": the k-mer kernels of kmi_extract.hip run on the compacted stream (window r is valid iff
 // no record starts inside (r, r+k) and r + k <= n_chars).
+#include <vector>
+
 #include "kmi_extract.h"
 
 namespace kmi {
@@ -234,7 +236,8 @@ __global__ __launch_bounds__((FaCfg::NT)) void fasta_compact_kernel(const uint8_
                                                                    uint64_t index_shift /* + records before the buffer */, bool first_ls,
                                                                    uint64_t valid_bytes, const FaTileBase *__restrict__ base,
                                                                    uint32_t *__restrict__ pk_stream, uint32_t *__restrict__ pk_break,
-                                                                   uint64_t *__restrict__ ids, uint64_t *__restrict__ totals, bool split_n) {
+                                                                   uint64_t *__restrict__ ids, uint64_t *__restrict__ totals, bool split_n,
+                                                                   uint64_t *__restrict__ rec_start, uint32_t *__restrict__ rec_flag) {
   constexpr int C = FaCfg::C;
   __shared__ uint32_t s_nl[FaCfg::NT / 2 + 2];
   __shared__ uint32_t s_scanm[FaCfg::NT / 64 + 2];
@@ -268,6 +271,8 @@ __global__ __launch_bounds__((FaCfg::NT)) void fasta_compact_kernel(const uint8_
       const uint32_t q = (uint32_t)__builtin_ctz(rest);
       const uint64_t rk = rank0 + (uint32_t)__builtin_popcount(r.seq & ((1u << q) - 1u));
       atomicOr(&pk_break[rk >> 5], 1u << (rk & 31u));
+      // N_FILTER: first character of record e (e-th record start of the buffer; slot 0 = the lines before the first one)
+      if (rec_start) rec_start[tb.ev + le + (uint32_t)__builtin_popcount(r.ev & ((1u << q) - 1u)) + 1u] = rk;
       rest &= rest - 1u;
     }
   }
@@ -279,6 +284,8 @@ __global__ __launch_bounds__((FaCfg::NT)) void fasta_compact_kernel(const uint8_
       const uint32_t p = (uint32_t)__builtin_ctz(rest);
       const uint32_t c = (dw[p >> 2] >> (8 * (p & 3))) & 0xffu;
       const uint64_t cc = comp_code<BITS>(code_of<BITS>(c));
+      if (rec_flag && c == 'N')   // NSequenceFilter (filtered_sequence_iterator.hpp:154-165): this record is dropped
+        atomicOr(&rec_flag[tb.ev + le + (uint32_t)__builtin_popcount(r.ev & ((2u << p) - 1u))], 1u);
       if (split_n && (c == 'N' || c == 'n')) {
         // NSplitSequencesIterator (filtered_sequence_iterator.hpp:411-440): no window may hold this character. A break bit
         // at character x blocks the windows that start in [x - k + 1, x - 1], so bits at x and x + 1 block [x - k + 1, x].
@@ -319,6 +326,35 @@ __global__ __launch_bounds__((FaCfg::NT)) void fasta_compact_kernel(const uint8_
     if (i == 0 || i == ndw - 1) { if (v) atomicOr(&pk_stream[gd0 + i], v); }
     else pk_stream[gd0 + i] = v;
   }
+}
+
+// N_FILTER: every character of a record that holds an 'N' gets a break bit, so no window starts in or reaches into it.
+// One thread per word of the break bitmap; its records are found by binary search over the record starts.
+__global__ __launch_bounds__(256) void fasta_poison_records_kernel(const uint64_t *__restrict__ rec_start, const uint32_t *__restrict__ rec_flag,
+                                                                  uint64_t n_rec /* slots 0 .. n_rec, rec_start[n_rec + 1] = n_chars */,
+                                                                  uint64_t n_words, uint32_t *__restrict__ pk_break) {
+  const uint64_t w = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (w >= n_words) return;
+  const uint64_t lo = w * 32, hi = lo + 32;
+  uint64_t a = 0, b = n_rec;             // last slot e with rec_start[e] <= lo
+  while (a < b) {
+    const uint64_t m = (a + b + 1) >> 1;
+    if (rec_start[m] <= lo) a = m; else b = m - 1;
+  }
+  uint32_t mask = 0;
+  for (uint64_t e = a; e <= n_rec && rec_start[e] < hi; ++e) {
+    if (!rec_flag[e]) continue;
+    const uint64_t s0 = rec_start[e] > lo ? rec_start[e] : lo, s1 = rec_start[e + 1] < hi ? rec_start[e + 1] : hi;
+    if (s1 > s0) mask |= (uint32_t)(((s1 - lo) >= 32 ? 0xffffffffull : ((1ull << (s1 - lo)) - 1ull)) & ~((1ull << (s0 - lo)) - 1ull));
+  }
+  if (mask) pk_break[w] |= mask;
+}
+__global__ __launch_bounds__(256) void fasta_count_dropped_kernel(const uint32_t *__restrict__ rec_flag, uint64_t n_slots,
+                                                                 unsigned long long *__restrict__ total) {
+  uint32_t c = 0;
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n_slots; i += (uint64_t)gridDim.x * 256) c += rec_flag[i] ? 1u : 0u;
+  c = wave_reduce_sum(c);
+  if (lane_id() == 0 && c) atomicAdd(total, (unsigned long long)c);
 }
 
 // ---------------------------------------------------------------------------
@@ -368,20 +404,45 @@ kmi_status fasta_scan(kmi_ctx *ctx, const kmi_config *cfg, const uint8_t *bytes_
   // init_parser: a leading non-header group shifts the sequence indices by one; a partition adds the records before it
   const uint64_t index_shift = part ? (uint64_t)ctx->fa_part.index_shift + ctx->fa_part.records_before
                                     : ((first == '>' || first == ';') ? 0u : 1u);
+  const bool drop_n = cfg->seq_filter == KMI_SEQ_N_FILTER;
+  const uint64_t n_rec = ctx->h_totals[2], n_chars_total = ctx->h_totals[0];
+  uint64_t *rec_start = nullptr; uint32_t *rec_flag = nullptr;
+  if (drop_n) {
+    KMI_TRY(ws_get(ctx, WS_PK_NB, (n_rec + 3) * (sizeof(uint64_t) + sizeof(uint32_t)) + 64, &p));
+    rec_start = (uint64_t *)p; rec_flag = (uint32_t *)(rec_start + n_rec + 3);
+    // every record start writes its slot (characters before it); slot 0 = the lines before the first start, slot
+    // n_rec + 1 = the end
+    std::vector<uint64_t> init(n_rec + 3, n_chars_total);
+    init[0] = 0;
+    KMI_HIP(ctx, hipMemcpyAsync(rec_start, init.data(), sizeof(uint64_t) * (n_rec + 3), hipMemcpyHostToDevice, ctx->stream));
+    KMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    KMI_HIP(ctx, hipMemsetAsync(rec_flag, 0, sizeof(uint32_t) * (n_rec + 3), ctx->stream));
+  }
   {
     ProfScope ps(ctx, "fasta_compact", n_bytes);
     if (shape.bits == 2)
       hipLaunchKernelGGL((fasta_compact_kernel<2>), dim3((unsigned)n_tiles), dim3(FaCfg::NT), 0, ctx->stream, bytes_dev, (uint64_t)n_bytes,
                          file_offset, index_shift, first_ls, valid_bytes, (const FaTileBase *)base, pk_stream, pk_break, ids, ctx->d_totals,
-                         cfg->seq_filter == KMI_SEQ_N_SPLIT);
+                         cfg->seq_filter == KMI_SEQ_N_SPLIT, rec_start, rec_flag);
     else
       hipLaunchKernelGGL((fasta_compact_kernel<3>), dim3((unsigned)n_tiles), dim3(FaCfg::NT), 0, ctx->stream, bytes_dev, (uint64_t)n_bytes,
                          file_offset, index_shift, first_ls, valid_bytes, (const FaTileBase *)base, pk_stream, pk_break, ids, ctx->d_totals,
-                         cfg->seq_filter == KMI_SEQ_N_SPLIT);
+                         cfg->seq_filter == KMI_SEQ_N_SPLIT, rec_start, rec_flag);
+  }
+  uint64_t dropped = 0;
+  if (drop_n && n_chars_total > 0) {
+    const uint64_t n_words = (n_chars_total + 31) / 32;
+    hipLaunchKernelGGL(fasta_poison_records_kernel, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, ctx->stream,
+                       (const uint64_t *)rec_start, (const uint32_t *)rec_flag, n_rec, n_words, pk_break);
+    KMI_HIP(ctx, hipMemsetAsync(ctx->d_totals + 1, 0, sizeof(uint64_t), ctx->stream));
+    hipLaunchKernelGGL(fasta_count_dropped_kernel, dim3(64), dim3(256), 0, ctx->stream, (const uint32_t *)rec_flag, n_rec + 1,
+                       (unsigned long long *)(ctx->d_totals + 1));
+    KMI_HIP(ctx, hipMemcpyAsync(&dropped, ctx->d_totals + 1, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+    KMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
   }
   KMI_HIP(ctx, hipGetLastError());
   out->n_chars = ctx->h_totals[0];
-  out->n_seqs = ctx->h_totals[2];
+  out->n_seqs = ctx->h_totals[2] - dropped;
   out->n_valid = out->n_chars;
   if (valid_bytes < (uint64_t)n_bytes) {   // totals[3] was written by the compaction pass
     KMI_HIP(ctx, hipMemcpyAsync(ctx->h_totals + 3, ctx->d_totals + 3, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));

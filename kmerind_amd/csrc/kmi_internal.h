@@ -148,7 +148,7 @@ inline bool valid_config(const kmi_config *cfg, KShape *shape) {
   KShape s = make_shape(cfg->k, bits);
   if (s.n_words > (uint32_t)kMaxWords) return false;
   if (cfg->strand > 2 || cfg->dist_hash > 3 || cfg->store_hash > 3 || cfg->seq_format > 1 || cfg->index_kind > 2 || cfg->seq_filter > 2) return false;
-  if (cfg->seq_filter == KMI_SEQ_N_FILTER && cfg->seq_format == KMI_FMT_FASTA) return false;   // not implemented
+  if (cfg->seq_filter && cfg->seq_format == KMI_FMT_FASTA && cfg->k == 1) return false;   // break bits need k >= 2 there
   if (cfg->seq_filter && cfg->index_kind == KMI_INDEX_POSQUAL) return false;
   if (shape) *shape = s;
   return true;

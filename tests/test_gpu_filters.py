@@ -94,12 +94,15 @@ def test_count_index_build_with_filter(ctx, flt):
         idx.close()
 
 
-def test_fasta_n_split_matches_oracle_and_reference_table(ctx):
+@pytest.mark.parametrize("flt", ["n_split", "n_filter"])
+def test_fasta_filters_match_oracle_and_reference_table(ctx, flt):
     pg = json.load(open(os.path.join(GOLD, "parse_golden.json")))["fasta"]
     data = open(os.path.join(GOLD, "data", "natural.withN.fasta"), "rb").read()
-    got, ex = _check_extract(ctx, data, "fasta", pg["k"], "DNA5", "n_split")
-    row = [e for e in pg["n_split"] if e["file"] == "natural.withN.fasta"][0]
+    got, ex = _check_extract(ctx, data, "fasta", pg["k"], "DNA5", flt)
+    row = [e for e in pg[flt] if e["file"] == "natural.withN.fasta"][0]
     assert got["kmers"].shape[0] == row["kmers"]
+    if flt == "n_filter":
+        assert got["n_seqs"] == ex["n_seqs"] == row["yielded"]
     # multi-line records with N at line ends, line starts, across EOLs, lower case, and a record of only N
     rng = np.random.default_rng(2)
     recs = []
@@ -114,8 +117,13 @@ def test_fasta_n_split_matches_oracle_and_reference_table(ctx):
         recs.append(b">r%d some text N n\n" % r + b"\n".join(lines) + b"\n")
     data = b"".join(recs)
     for k, alpha in ((21, "DNA"), (33, "DNA5"), (3, "DNA")):
-        _check_extract(ctx, data, "fasta", k, alpha, "n_split")
-        _check_extract(ctx, data, "fasta", k, alpha, "n_split", with_ids=False)
+        got, ex = _check_extract(ctx, data, "fasta", k, alpha, flt)
+        if flt == "n_filter":
+            assert got["n_seqs"] == ex["n_seqs"]
+        _check_extract(ctx, data, "fasta", k, alpha, flt, with_ids=False)
+    # a buffer that begins with sequence lines (no header yet) and holds an N there
+    orphan = b"ACGTNACGTACGTACGTACGTACGTA\nACGT\n" + data
+    _check_extract(ctx, orphan, "fasta", 5, "DNA", flt)
 
 
 def test_unsupported_filter_combinations_are_refused(ctx):
@@ -123,7 +131,7 @@ def test_unsupported_filter_combinations_are_refused(ctx):
     from kmerind_amd import _lib as L
     data = open(os.path.join(GOLD, "data", "natural.withN.fasta"), "rb").read()
     with pytest.raises(L.KmiError):
-        ctx.read_file(K.make_config(21, "DNA", seq_format="fasta", seq_filter="n_filter"), data)      # FASTA + N_FILTER
+        ctx.read_file(K.make_config(1, "DNA", seq_format="fasta", seq_filter="n_filter"), data)       # FASTA filters need k >= 2
     fq = open(os.path.join(GOLD, "data", "natural.withN.fastq"), "rb").read()
     with pytest.raises(L.KmiError):
         ctx.read_file(K.make_config(21, "DNA", index_kind="posqual", seq_filter="n_split"), fq, with_ids=True, with_quals=True)
