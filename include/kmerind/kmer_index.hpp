@@ -77,6 +77,9 @@ using WordType = uint64_t;  // base_types.hpp:36
 struct DNA { static constexpr unsigned SIZE = 4; static constexpr unsigned BITS = 2; static constexpr uint32_t KMI = KMI_ALPHA_DNA; };
 struct DNA6 { static constexpr unsigned SIZE = 8; static constexpr unsigned BITS = 3; static constexpr uint32_t KMI = KMI_ALPHA_DNA5; };
 using DNA5 = DNA6;  // alphabets.hpp:746-747
+struct RNA { static constexpr unsigned SIZE = 4; static constexpr unsigned BITS = 2; static constexpr uint32_t KMI = KMI_ALPHA_RNA; };
+struct RNA6 { static constexpr unsigned SIZE = 8; static constexpr unsigned BITS = 3; static constexpr uint32_t KMI = KMI_ALPHA_RNA5; };
+using RNA5 = RNA6;  // alphabets.hpp:748-750
 
 template <typename A> struct AlphabetTraits {
   static constexpr unsigned getSize() { return A::SIZE; }

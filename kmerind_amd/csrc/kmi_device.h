@@ -381,6 +381,14 @@ template <int BITS> KMI_HD void classify_dword(uint32_t w, uint32_t &eol4, uint3
   }
 }
 
+// RNA_T / RNA6_T (alphabets.hpp:365-445, 448-530) are the DNA / DNA6 tables with 'U','u' in the place of 'T','t', and
+// T an unknown character: swapping T and U in the loaded bytes (they differ in bit 0) lets the DNA classifiers serve.
+KMI_HD uint32_t swap_tu_dword(uint32_t x) {
+  const uint32_t y = (x & 0xDEDEDEDEu) ^ 0x54545454u;                             // zero byte <=> T, U, t or u
+  const uint32_t nz = (((y & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | y) & 0x80808080u;     // 0x80 in every non-zero byte
+  return x ^ ((~nz & 0x80808080u) >> 7);
+}
+
 // `dw` holds the chunk's bytes little-endian, 4 per dword.
 template <int BITS, int C> KMI_HD void classify_chunk(const uint32_t (&dw)[C / 4], int n_valid, uint32_t &eol, uint64_t &stream) {
   uint32_t e = 0; uint64_t s = 0;

@@ -177,13 +177,18 @@ template <typename Cfg>
 __device__ __forceinline__ void tile_front_bytes(const uint8_t *__restrict__ bytes, uint64_t n_bytes, uint64_t tile,
                                                  uint8_t *__restrict__ pk_eol, uint8_t *__restrict__ pk_stream,
                                                  uint32_t *s_eol, uint32_t *s_scan, uint32_t (&dw)[Cfg::C / 4],
-                                                 uint32_t &eol, uint32_t &ls, uint32_t &lines_before_local, uint32_t &lines_total) {
+                                                 uint32_t &eol, uint32_t &ls, uint32_t &lines_before_local, uint32_t &lines_total,
+                                                 bool rna = false) {
   constexpr int C = Cfg::C;
   constexpr int BITS = Cfg::BITS;
   const int j = threadIdx.x;
   const uint64_t tile0 = tile * Cfg::TILE;
   uint64_t st;
   int nv = load_chunk<C>(bytes, n_bytes, tile0 + (uint64_t)j * C, dw);
+  if (rna) {   // uniform
+#pragma unroll
+    for (int i = 0; i < C / 4; ++i) dw[i] = swap_tu_dword(dw[i]);
+  }
   classify_chunk<BITS, C>(dw, nv, eol, st);
   store_eol_bits<C>(s_eol, j, eol);
   write_eol_unit<C>(pk_eol, tile * Cfg::NT + j, eol);
@@ -191,7 +196,7 @@ __device__ __forceinline__ void tile_front_bytes(const uint8_t *__restrict__ byt
   if (j < Cfg::HALO_CHUNKS) {
     uint32_t hdw[C / 4]; uint32_t he; uint64_t hs;
     int hnv = load_chunk<C>(bytes, n_bytes, tile0 + (uint64_t)(Cfg::NT + j) * C, hdw);
-    classify_chunk<BITS, C>(hdw, hnv, he, hs);
+    classify_chunk<BITS, C>(hdw, hnv, he, hs);   // only the EOL bits of the halo are used: no T/U swap needed
     store_eol_bits<C>(s_eol, Cfg::NT + j, he);
   }
   lds_barrier();

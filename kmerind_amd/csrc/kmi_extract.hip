@@ -39,7 +39,7 @@ __global__ __launch_bounds__((Cfg::NT)) void fastq_scan_tiles_kernel(const uint8
                                                                                uint8_t *__restrict__ pk_stream,
                                                                                TileInfo *__restrict__ info,
                                                                                uint32_t *__restrict__ flags,
-                                                                               const uint8_t *__restrict__ brk, uint64_t n_cover) {
+                                                                               const uint8_t *__restrict__ brk, uint64_t n_cover, bool rna) {
   __shared__ uint32_t s_eol[Cfg::EOL_DW];
   __shared__ uint32_t s_brk[Cfg::EOL_DW];
   __shared__ uint32_t s_scan[Cfg::NT / 64 + 2];
@@ -48,7 +48,7 @@ __global__ __launch_bounds__((Cfg::NT)) void fastq_scan_tiles_kernel(const uint8
   if (threadIdx.x < 3) s_cnt[threadIdx.x] = 0;
   if (threadIdx.x < 4) s_last[threadIdx.x] = 0;
   uint32_t dw[Cfg::C / 4], eol, ls, lbl, ltot;
-  tile_front_bytes<Cfg>(bytes, n_bytes, blockIdx.x, pk_eol, pk_stream, s_eol, s_scan, dw, eol, ls, lbl, ltot);
+  tile_front_bytes<Cfg>(bytes, n_bytes, blockIdx.x, pk_eol, pk_stream, s_eol, s_scan, dw, eol, ls, lbl, ltot, rna);
 
   // k-windows are counted against the break bits: EOLs, plus the N positions of a sequence filter
   uint64_t e[Cfg::NE];
@@ -624,7 +624,7 @@ struct ScanResult {
 
 template <int NW, int BITS>
 static kmi_status scan_impl(kmi_ctx *ctx, const uint8_t *bytes_dev, size_t n_bytes, const KShape &shape, ScanResult *r,
-                            bool reuse = false, bool check_lengths = true, uint32_t seq_filter = KMI_SEQ_ALL) {
+                            bool reuse = false, bool check_lengths = true, uint32_t seq_filter = KMI_SEQ_ALL, bool rna = false) {
   using Cfg = ExCfg<NW, BITS>;
   const uint64_t n_tiles = (n_bytes + Cfg::TILE - 1) / Cfg::TILE;
   void *p;
@@ -669,7 +669,7 @@ static kmi_status scan_impl(kmi_ctx *ctx, const uint8_t *bytes_dev, size_t n_byt
     using SCfg = ScanCfg<NW, BITS>;
     static_assert(SCfg::TILE == Cfg::TILE, "the scan pass writes the packed arrays of the same tiles");
     hipLaunchKernelGGL((fastq_scan_tiles_kernel<SCfg>), dim3((unsigned)n_tiles), dim3(SCfg::NT), 0, ctx->stream,
-                       bytes_dev, (uint64_t)n_bytes, shape.k, pk_eol, pk_stream, info, ctx->d_flags, (const uint8_t *)brk, n_cover);
+                       bytes_dev, (uint64_t)n_bytes, shape.k, pk_eol, pk_stream, info, ctx->d_flags, (const uint8_t *)brk, n_cover, rna);
   }
   KMI_TRY(launch_tile_offsets(ctx, info, n_tiles, (uint32_t)Cfg::TILE, hdr, base, off));
   if (brk && n_tiles > 0) {
@@ -702,11 +702,11 @@ static kmi_status read_totals(kmi_ctx *ctx, uint64_t *n_tuples, uint64_t *n_seqs
 }
 
 template <int NW, int BITS>
-static kmi_status extract_count_impl(kmi_ctx *ctx, const uint8_t *bytes_dev, size_t n_bytes, KShape shape, uint32_t seq_filter,
+static kmi_status extract_count_impl(kmi_ctx *ctx, const uint8_t *bytes_dev, size_t n_bytes, KShape shape, uint32_t seq_filter, bool rna,
                                      uint64_t *n_tuples, uint64_t *n_seqs) {
   ScanResult r;
   KMI_HIP(ctx, hipMemsetAsync(ctx->d_flags, 0, sizeof(uint32_t) * 16, ctx->stream));
-  KMI_TRY((scan_impl<NW, BITS>(ctx, bytes_dev, n_bytes, shape, &r, false, true, seq_filter)));
+  KMI_TRY((scan_impl<NW, BITS>(ctx, bytes_dev, n_bytes, shape, &r, false, true, seq_filter, rna)));
   return read_totals(ctx, n_tuples, n_seqs);
 }
 
@@ -718,7 +718,7 @@ static kmi_status extract_run_impl(kmi_ctx *ctx, const kmi_config *cfg, const ui
   using Cfg = ExCfg<NW, BITS>;
   ScanResult r;
   if (!scan_done) KMI_HIP(ctx, hipMemsetAsync(ctx->d_flags, 0, sizeof(uint32_t) * 16, ctx->stream));
-  KMI_TRY((scan_impl<NW, BITS>(ctx, bytes_dev, n_bytes, shape, &r, scan_done, true, cfg->seq_filter)));
+  KMI_TRY((scan_impl<NW, BITS>(ctx, bytes_dev, n_bytes, shape, &r, scan_done, true, cfg->seq_filter, is_rna(cfg))));
   if (r.n_tiles > 0) {
     ProfScope ps(ctx, "fastq_extract", n_bytes);
     const bool canonical = apply_strand && cfg->strand != KMI_STRAND_SINGLE;
@@ -756,10 +756,11 @@ static kmi_status extract_run_impl(kmi_ctx *ctx, const kmi_config *cfg, const ui
 }
 
 template <int NW, int BITS>
-static kmi_status fastq_scan_impl(kmi_ctx *ctx, const uint8_t *bytes_dev, size_t n_bytes, KShape shape, FastqScan *out, bool check_lengths) {
+static kmi_status fastq_scan_impl(kmi_ctx *ctx, const uint8_t *bytes_dev, size_t n_bytes, KShape shape, FastqScan *out, bool check_lengths,
+                                  bool rna) {
   ScanResult r;
   KMI_HIP(ctx, hipMemsetAsync(ctx->d_flags, 0, sizeof(uint32_t) * 16, ctx->stream));
-  KMI_TRY((scan_impl<NW, BITS>(ctx, bytes_dev, n_bytes, shape, &r, false, check_lengths)));
+  KMI_TRY((scan_impl<NW, BITS>(ctx, bytes_dev, n_bytes, shape, &r, false, check_lengths, KMI_SEQ_ALL, rna)));
   out->n_tiles = r.n_tiles; out->line_base = r.line_base; out->tile_off = r.out_off;
   out->pk_eol = r.packed.eol; out->pk_stream = r.packed.stream; out->n_bytes = r.packed.n_bytes; out->n_cover = r.packed.n_cover;
   return read_totals(ctx, &out->n_tuples, &out->n_seqs);
@@ -782,7 +783,7 @@ kmi_status fastq_scan(kmi_ctx *ctx, const kmi_config *cfg, const uint8_t *bytes_
   if (!valid_config(cfg, &shape)) return set_err(ctx, KMI_ERR_INVALID, "bad kmi_config");
   if (cfg->seq_format != KMI_FMT_FASTQ) return set_err(ctx, KMI_ERR_INVALID, "only FASTQ is implemented on the device yet");
   if (cfg->seq_filter != KMI_SEQ_ALL) return set_err(ctx, KMI_ERR_INVALID, "the fused FASTQ passes run without a sequence filter (use the extract path)");
-  KMI_DISPATCH(shape, fastq_scan_impl, ctx, bytes_dev, n_bytes, shape, out, check_lengths);
+  KMI_DISPATCH(shape, fastq_scan_impl, ctx, bytes_dev, n_bytes, shape, out, check_lengths, is_rna(cfg));
 }
 
 // ---- FASTA: byte-space scan + compaction (kmi_fasta.hip), then count / extract over the compacted stream
@@ -860,7 +861,7 @@ kmi_status extract_count(kmi_ctx *ctx, const kmi_config *cfg, const uint8_t *byt
   if (n_bytes == 0) { if (n_tuples) *n_tuples = 0; if (n_seqs) *n_seqs = 0; return KMI_OK; }
   if (cfg->seq_format == KMI_FMT_FASTA)
     return fasta_extract(ctx, cfg, bytes_dev, n_bytes, shape, 0, nullptr, nullptr, 0, false, true, n_tuples, n_seqs);
-  KMI_DISPATCH(shape, extract_count_impl, ctx, bytes_dev, n_bytes, shape, cfg->seq_filter, n_tuples, n_seqs);
+  KMI_DISPATCH(shape, extract_count_impl, ctx, bytes_dev, n_bytes, shape, cfg->seq_filter, is_rna(cfg), n_tuples, n_seqs);
 }
 
 kmi_status extract_run(kmi_ctx *ctx, const kmi_config *cfg, const uint8_t *bytes_dev, size_t n_bytes,

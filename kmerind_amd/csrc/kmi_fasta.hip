@@ -237,7 +237,7 @@ __global__ __launch_bounds__((FaCfg::NT)) void fasta_compact_kernel(const uint8_
                                                                    uint64_t valid_bytes, const FaTileBase *__restrict__ base,
                                                                    uint32_t *__restrict__ pk_stream, uint32_t *__restrict__ pk_break,
                                                                    uint64_t *__restrict__ ids, uint64_t *__restrict__ totals, bool split_n,
-                                                                   uint64_t *__restrict__ rec_start, uint32_t *__restrict__ rec_flag) {
+                                                                   uint64_t *__restrict__ rec_start, uint32_t *__restrict__ rec_flag, bool rna) {
   constexpr int C = FaCfg::C;
   __shared__ uint32_t s_nl[FaCfg::NT / 2 + 2];
   __shared__ uint32_t s_scanm[FaCfg::NT / 64 + 2];
@@ -248,6 +248,10 @@ __global__ __launch_bounds__((FaCfg::NT)) void fasta_compact_kernel(const uint8_
   const FaTileBase tb = base[blockIdx.x];
   uint32_t dw[4], eol, ls, hs;
   fa_chunk_masks(bytes, n_bytes, tile0, first_ls, s_nl, dw, eol, ls, hs);
+  if (rna) {   // uniform: RNA alphabets read U where DNA reads T (kmi_device.h swap_tu_dword)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dw[i] = swap_tu_dword(dw[i]);
+  }
   uint32_t f = 0;
 #pragma unroll
   for (uint32_t in = 0; in < 3; ++in) f |= fa_chunk_apply(in, eol, ls, hs).out << (2 * in);
@@ -423,11 +427,11 @@ kmi_status fasta_scan(kmi_ctx *ctx, const kmi_config *cfg, const uint8_t *bytes_
     if (shape.bits == 2)
       hipLaunchKernelGGL((fasta_compact_kernel<2>), dim3((unsigned)n_tiles), dim3(FaCfg::NT), 0, ctx->stream, bytes_dev, (uint64_t)n_bytes,
                          file_offset, index_shift, first_ls, valid_bytes, (const FaTileBase *)base, pk_stream, pk_break, ids, ctx->d_totals,
-                         cfg->seq_filter == KMI_SEQ_N_SPLIT, rec_start, rec_flag);
+                         cfg->seq_filter == KMI_SEQ_N_SPLIT, rec_start, rec_flag, is_rna(cfg));
     else
       hipLaunchKernelGGL((fasta_compact_kernel<3>), dim3((unsigned)n_tiles), dim3(FaCfg::NT), 0, ctx->stream, bytes_dev, (uint64_t)n_bytes,
                          file_offset, index_shift, first_ls, valid_bytes, (const FaTileBase *)base, pk_stream, pk_break, ids, ctx->d_totals,
-                         cfg->seq_filter == KMI_SEQ_N_SPLIT, rec_start, rec_flag);
+                         cfg->seq_filter == KMI_SEQ_N_SPLIT, rec_start, rec_flag, is_rna(cfg));
   }
   uint64_t dropped = 0;
   if (drop_n && n_chars_total > 0) {

@@ -143,7 +143,8 @@ struct ProfScope {
 
 inline bool valid_config(const kmi_config *cfg, KShape *shape) {
   if (!cfg || cfg->k == 0) return false;
-  uint32_t bits = cfg->alphabet == KMI_ALPHA_DNA ? 2 : (cfg->alphabet == KMI_ALPHA_DNA5 ? 3 : 0);
+  uint32_t bits = (cfg->alphabet == KMI_ALPHA_DNA || cfg->alphabet == KMI_ALPHA_RNA) ? 2 :
+                  ((cfg->alphabet == KMI_ALPHA_DNA5 || cfg->alphabet == KMI_ALPHA_RNA5) ? 3 : 0);
   if (!bits) return false;
   KShape s = make_shape(cfg->k, bits);
   if (s.n_words > (uint32_t)kMaxWords) return false;
@@ -153,6 +154,9 @@ inline bool valid_config(const kmi_config *cfg, KShape *shape) {
   if (shape) *shape = s;
   return true;
 }
+
+// RNA alphabets: the byte classifiers see T and U swapped (kmi_device.h swap_tu_dword)
+inline bool is_rna(const kmi_config *cfg) { return cfg->alphabet == KMI_ALPHA_RNA || cfg->alphabet == KMI_ALPHA_RNA5; }
 
 // dispatch on (n_words, bits)
 #define KMI_DISPATCH(shape, FN, ...)                                                   \

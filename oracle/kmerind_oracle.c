@@ -23,8 +23,8 @@ int orc_kspec_init(orc_kspec *s, uint32_t k, uint32_t alphabet) {
   s->k = k;
   s->alphabet = alphabet;
   /* AlphabetTraits::getBitsPerChar = ceilLog2(SIZE): alphabet_traits.hpp:127-130 */
-  if (alphabet == ORC_DNA) s->bits_per_char = 2;
-  else if (alphabet == ORC_DNA5) s->bits_per_char = 3;
+  if (ORC_IS_2BIT(alphabet)) s->bits_per_char = 2;
+  else if (alphabet == ORC_DNA5 || alphabet == ORC_RNA5) s->bits_per_char = 3;
   else return -1;
   s->n_bits = k * s->bits_per_char;
   s->n_words = (s->n_bits + 63) / 64;   /* padding.hpp:81 */
@@ -41,6 +41,12 @@ int orc_kspec_init(orc_kspec *s, uint32_t k, uint32_t alphabet) {
  * DNA6_T::FROM_ASCII (alphabets.hpp:225-248): A=1 C=3 G=6 T=4 N/X=7 '-','.'=0,
  * everything else 2 (DNA5 is an alias of DNA6, alphabets.hpp:746-747). */
 uint8_t orc_from_ascii(uint32_t alphabet, uint8_t c) {
+  /* RNA_T / RNA6_T::FROM_ASCII (alphabets.hpp:378-400, 459-480): U/u where DNA has T/t; T/t is an unknown character */
+  if (alphabet == ORC_RNA || alphabet == ORC_RNA5) {
+    if (c == 'U' || c == 'u') c = 'T';
+    else if (c == 'T' || c == 't') c = '?';
+    alphabet = (alphabet == ORC_RNA) ? ORC_DNA : ORC_DNA5;
+  }
   if (alphabet == ORC_DNA) {
     switch (c) {
       case 'A': case 'a': return 0;
@@ -63,7 +69,7 @@ uint8_t orc_from_ascii(uint32_t alphabet, uint8_t c) {
 
 /* TO_COMPLEMENT tables: alphabets.hpp:172-178 (DNA), :262-272 (DNA6) */
 uint8_t orc_complement(uint32_t alphabet, uint8_t code) {
-  if (alphabet == ORC_DNA) return (uint8_t)(3 - (code & 3));
+  if (ORC_IS_2BIT(alphabet)) return (uint8_t)(3 - (code & 3));   /* RNA: alphabets.hpp:411-421; RNA6: :497-512, same tables */
   static const uint8_t c6[8] = {0, 4, 2, 6, 1, 5, 3, 7};
   return c6[code & 7];
 }
@@ -188,7 +194,7 @@ static inline uint64_t swar_grouprev2(uint64_t x) {
 }
 
 void orc_kmer_revcomp_fast(const orc_kspec *s, const uint64_t *in, uint64_t *out) {
-  if (s->alphabet != ORC_DNA) { orc_kmer_revcomp(s, in, out); return; }
+  if (!ORC_IS_2BIT(s->alphabet)) { orc_kmer_revcomp(s, in, out); return; }
   uint64_t t[ORC_MAX_WORDS];
   const uint32_t nw = s->n_words, pad = nw * 64 - s->n_bits;
   for (uint32_t w = 0; w < nw; ++w) t[w] = ~swar_grouprev2(in[nw - 1 - w]);

@@ -121,7 +121,25 @@ def quality_lut():
     return {"source": "src/index/quality_scores.hpp:113-211", "codec": "QualityScoreCodec<float,33,126,0>", "decode_lut": vals}
 
 
+def alphabet_tables():
+    """FROM_ASCII of DNA_T, DNA6_T (= DNA5), RNA_T, RNA6_T (= RNA5) (src/common/alphabets.hpp) as data: 256 codes each"""
+    src = open(os.path.join(REF, "src/common/alphabets.hpp")).read()
+    out = {"source": "src/common/alphabets.hpp (FROM_ASCII of DNA_T:139-161, DNA6_T:225-248, RNA_T:378-400, RNA6_T:459-480)"}
+    for name in ("DNA_T", "DNA6_T", "RNA_T", "RNA6_T"):
+        at = src.index("struct " + name + " ")
+        b = _block(src[at:], "FROM_ASCII =", "}};")
+        vals = []
+        for line in b.splitlines()[1:]:
+            line = line.split("//")[0]
+            vals += [int(x) for x in re.findall(r"\d+", line)]
+        assert len(vals) == 256, (name, len(vals))
+        out[name] = vals
+    return out
+
+
 def main():
+    with open(os.path.join(HERE, "alphabet_tables.json"), "w") as f:
+        json.dump(alphabet_tables(), f)
     with open(os.path.join(HERE, "quality_lut.json"), "w") as f:
         json.dump(quality_lut(), f, indent=1)
     with open(os.path.join(HERE, "kmer_golden.json"), "w") as f:

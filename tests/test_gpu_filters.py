@@ -135,3 +135,38 @@ def test_unsupported_filter_combinations_are_refused(ctx):
     fq = open(os.path.join(GOLD, "data", "natural.withN.fastq"), "rb").read()
     with pytest.raises(L.KmiError):
         ctx.read_file(K.make_config(21, "DNA", index_kind="posqual", seq_filter="n_split"), fq, with_ids=True, with_quals=True)
+
+
+@pytest.mark.parametrize("alpha", ["RNA", "RNA5"])
+def test_rna_alphabets_match_oracle(ctx, alpha):
+    """RNA_T / RNA6_T (alphabets.hpp:365-445, 448-530): U where DNA has T, and T an unknown character. FASTQ extract with
+    ids, the fused count build and FASTA, against the oracle's restatement of the two FROM_ASCII tables."""
+    import kmerind_amd as K
+    oa = orc.RNA if alpha == "RNA" else orc.RNA5
+    raw = np.array(K.synth_fastq(seed=21, genome_len=4000, n_reads=600), dtype=np.uint8)
+    rng = np.random.default_rng(21)
+    is_t = raw == ord("T")
+    raw[is_t & (rng.random(raw.size) < 0.8)] = ord("U")              # mostly U, some T left in (unknown characters in RNA)
+    low = rng.random(raw.size) < 0.05
+    seq_rows = (np.arange(raw.size) % 315 >= 11) & (np.arange(raw.size) % 315 < 161)
+    sel = low & seq_rows
+    raw[sel] = np.char.lower(raw[sel].view("S1")).view(np.uint8)     # lower case too
+    data = raw.tobytes()
+    for k in (31, 21) if alpha == "RNA" else (21, 40):
+        s = orc.kspec(k, oa)
+        cfg = K.make_config(k, alpha, strand="single", index_kind="position")
+        ex = orc.extract(s, data, orc.FASTQ, want_ids=True)
+        gk, gi, gn = ctx.read_file(cfg, data, with_ids=True)
+        assert gn == ex["n_seqs"] and (gk == ex["kmers"]).all() and (gi == ex["ids"]).all()
+        idx = K.CountIndex(ctx, K.make_config(k, alpha, strand="canonical"))      # the fused build
+        idx.build(data)
+        m = orc.CountMap(s, orc.CANONICAL)
+        m.insert(ex["kmers"])
+        a, b = orc.sorted_pairs(*idx.to_vector()), orc.sorted_pairs(*m.export())
+        assert a[0].shape == b[0].shape and (a[0] == b[0]).all() and (a[1] == b[1]).all()
+        idx.close()
+    fa = b">r1\nACGUUGCAUGCAUUGGACUUACGuuacgNNACGUAGCUAGCUTTTTACGUACGU\nUUGCA\n>r2\nUGCAUGCAUGCAUGCAUGCAUGCAGGGGG\n"
+    s = orc.kspec(9, oa)
+    ex = orc.extract(s, fa, orc.FASTA, want_ids=True)
+    gk, gi, gn = ctx.read_file(K.make_config(9, alpha, strand="single", seq_format="fasta", index_kind="position"), fa, with_ids=True)
+    assert (gk == ex["kmers"]).all() and (gi == ex["ids"]).all()

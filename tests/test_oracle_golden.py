@@ -223,6 +223,13 @@ def test_filtered_parse_counts_match_reference_tables(fmt):
     assert checked >= 8 and with_n >= 2      # natural.withN.* differs from its unfiltered row under both filters
 
 
+def test_alphabet_tables_match_reference():
+    """orc_from_ascii against the reference's FROM_ASCII arrays of DNA, DNA5/6, RNA, RNA5/6 (all 256 bytes each)"""
+    t = _load("alphabet_tables.json")
+    for name, alpha in (("DNA_T", orc.DNA), ("DNA6_T", orc.DNA5), ("RNA_T", orc.RNA), ("RNA6_T", orc.RNA5)):
+        assert [orc.lib.orc_from_ascii(alpha, c) for c in range(256)] == t[name], name
+
+
 def test_kmer_text_roundtrip_positions():
     """mpi_test_fastq_seq_parse.cpp:235-330: every k-mer equals the file bytes at its id"""
     data = open(os.path.join(GOLD, "data", "test.small.fastq"), "rb").read()
