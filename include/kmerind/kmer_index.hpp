@@ -195,6 +195,10 @@ struct HashMapParams {
   static constexpr uint32_t strand = input_is_lex_less ? KMI_STRAND_CANONICAL : (store_is_lex_less ? KMI_STRAND_BIMOLECULE : KMI_STRAND_SINGLE);
   static constexpr uint32_t dist_hash = DistHash<Key>::KMI;
   static constexpr uint32_t store_hash = StoreHash<Key>::KMI;
+  // DistTrans of the single-strand model ("could be iden, xor, lex_less", kmer_index.hpp:436-450); the other models fix it
+  static constexpr uint32_t dist_trans = strand != KMI_STRAND_SINGLE ? KMI_DIST_MODEL :
+      (std::is_same<DistTrans<Key>, ::bliss::kmer::transform::lex_less<Key>>::value ? KMI_DIST_LEX :
+       (std::is_same<DistTrans<Key>, ::bliss::kmer::transform::xor_rev_comp<Key>>::value ? KMI_DIST_XOR : KMI_DIST_MODEL));
 };
 
 template <typename Key, typename T, template <typename> class MapParams>
@@ -257,7 +261,7 @@ template <typename MapType> kmi_config make_config(uint32_t fmt) {
   kmi_config c;
   c.k = Key::size; c.alphabet = Key::KmerAlphabet::KMI; c.strand = MapType::params::strand;
   c.dist_hash = MapType::params::dist_hash; c.store_hash = MapType::params::store_hash;
-  c.index_kind = MapType::index_kind; c.seq_format = fmt; c.farm_ndebug = 0; c.seq_filter = KMI_SEQ_ALL;
+  c.index_kind = MapType::index_kind; c.seq_format = fmt; c.farm_ndebug = 0; c.seq_filter = KMI_SEQ_ALL; c.dist_trans = MapType::params::dist_trans;
   return c;
 }
 inline std::vector<uint8_t> read_whole_file(const std::string &filename) {

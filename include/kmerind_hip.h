@@ -58,6 +58,11 @@ enum { KMI_INDEX_COUNT = 0, KMI_INDEX_POSITION = 1, KMI_INDEX_POSQUAL = 2 }; /* 
  * NFilterSequencesIterator (records whose sequence holds an 'N' are skipped, filtered_sequence_iterator.hpp:154-165)
  * or NSplitSequencesIterator (sequences are cut at every 'N' / 'n', so no k-mer spans one, :429-440) */
 enum { KMI_SEQ_ALL = 0, KMI_SEQ_N_FILTER = 1, KMI_SEQ_N_SPLIT = 2 };
+/* DistTrans of SingleStrandHashMapParams ("could be iden, xor, lex_less", kmer_index.hpp:436-450; the benchmark's
+ * pDistTrans, BenchmarkKmerIndex.cpp:150-161): what KeyToRank hashes. MODEL = the strand model's own choice (identity for
+ * single strand and canonical, lex_less for bimolecule); LEX / XOR (kmer_transform.hpp:90-116,60-88) need
+ * KMI_STRAND_SINGLE and make both strands of a k-mer land on one rank while they stay separate keys. */
+enum { KMI_DIST_MODEL = 0, KMI_DIST_LEX = 1, KMI_DIST_XOR = 2 };
 
 /* The compile-time parameters of the reference's Index<Map,Parser> as a runtime struct. */
 typedef struct {
@@ -74,6 +79,7 @@ typedef struct {
   uint32_t seq_filter; /* KMI_SEQ_*. With a filter, n_seqs counts what the reference's read_block counts: records
                           that pass (N_FILTER) or non-empty pieces (N_SPLIT; FASTA: records). FASTA with a filter
                           needs k >= 2. Quality values (KMI_INDEX_POSQUAL) need KMI_SEQ_ALL. */
+  uint32_t dist_trans; /* KMI_DIST_* */
 } kmi_config;
 
 typedef struct kmi_ctx kmi_ctx;     /* replaces mxx::comm + per-rank state */

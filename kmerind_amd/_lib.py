@@ -23,6 +23,7 @@ HASH_MURMUR, HASH_FARM, HASH_IDENTITY, HASH_STD = 0, 1, 2, 3
 FMT_FASTQ, FMT_FASTA = 0, 1
 INDEX_COUNT, INDEX_POSITION, INDEX_POSQUAL = 0, 1, 2
 SEQ_ALL, SEQ_N_FILTER, SEQ_N_SPLIT = 0, 1, 2
+DIST_MODEL, DIST_LEX, DIST_XOR = 0, 1, 2
 
 
 class FastaPartition(C.Structure):
@@ -33,7 +34,8 @@ class FastaPartition(C.Structure):
 class Config(C.Structure):
     _fields_ = [("k", C.c_uint32), ("alphabet", C.c_uint32), ("strand", C.c_uint32),
                 ("dist_hash", C.c_uint32), ("store_hash", C.c_uint32), ("index_kind", C.c_uint32),
-                ("seq_format", C.c_uint32), ("farm_ndebug", C.c_uint32), ("seq_filter", C.c_uint32)]
+                ("seq_format", C.c_uint32), ("farm_ndebug", C.c_uint32), ("seq_filter", C.c_uint32),
+                ("dist_trans", C.c_uint32)]
 
 
 class Tuples(C.Structure):

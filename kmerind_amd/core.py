@@ -14,7 +14,7 @@ lib = L.lib
 
 
 def make_config(k, alphabet="DNA", strand="canonical", dist_hash="murmur", store_hash="murmur",
-                index_kind="count", seq_format="fastq", farm_ndebug=False, seq_filter="all"):
+                index_kind="count", seq_format="fastq", farm_ndebug=False, seq_filter="all", dist_trans="model"):
     alpha = {"DNA": L.ALPHA_DNA, "DNA5": L.ALPHA_DNA5, "DNA6": L.ALPHA_DNA5,
              "RNA": L.ALPHA_RNA, "RNA5": L.ALPHA_RNA5, "RNA6": L.ALPHA_RNA5}[alphabet]
     st = {"single": L.STRAND_SINGLE, "canonical": L.STRAND_CANONICAL, "bimolecule": L.STRAND_BIMOLECULE}[strand]
@@ -22,7 +22,8 @@ def make_config(k, alphabet="DNA", strand="canonical", dist_hash="murmur", store
     kind = {"count": L.INDEX_COUNT, "position": L.INDEX_POSITION, "posqual": L.INDEX_POSQUAL}[index_kind]
     fmt = {"fastq": L.FMT_FASTQ, "fasta": L.FMT_FASTA}[seq_format]
     flt = {"all": L.SEQ_ALL, "n_filter": L.SEQ_N_FILTER, "n_split": L.SEQ_N_SPLIT}[seq_filter]
-    return L.Config(k, alpha, st, hs[dist_hash], hs[store_hash], kind, fmt, int(bool(farm_ndebug)), flt)
+    dt = {"model": L.DIST_MODEL, "lex_less": L.DIST_LEX, "xor_rev_comp": L.DIST_XOR}[dist_trans]
+    return L.Config(k, alpha, st, hs[dist_hash], hs[store_hash], kind, fmt, int(bool(farm_ndebug)), flt, dt)
 
 
 def _u64(a, n_words=None):

@@ -66,7 +66,7 @@ enum ArrayOp { OP_REVCOMP = 0, OP_CANONICAL = 1, OP_HASH = 2, OP_RANK = 3 };
 template <int NW, int BITS>
 __global__ __launch_bounds__(256) void kmer_array_op_kernel(const uint64_t *__restrict__ in, uint64_t n, KShape shape, int op,
                                                             uint32_t which, bool prefix, bool farm_ndebug, uint32_t strand,
-                                                            uint32_t nranks, uint64_t *__restrict__ out64,
+                                                            uint32_t dist_trans, uint32_t nranks, uint64_t *__restrict__ out64,
                                                             uint32_t *__restrict__ out32) {
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
     uint64_t k[NW], r[NW];
@@ -83,10 +83,13 @@ __global__ __launch_bounds__(256) void kmer_array_op_kernel(const uint64_t *__re
     } else if (op == OP_HASH) {
       out64[i] = kmer_hash<NW>(k, shape, which, prefix, farm_ndebug);
     } else {
-      // KeyToRank: DistHash(DistTrans(k)) % p ; DistTrans = lex_less only for bimolecule
-      if (strand == KMI_STRAND_BIMOLECULE) { canonical_words<NW, BITS>(k, r, shape);
+      // KeyToRank: DistHash(DistTrans(k)) % p ; DistTrans = lex_less for bimolecule, or the single-strand model's choice
+      if (strand == KMI_STRAND_BIMOLECULE || dist_trans == KMI_DIST_LEX) { canonical_words<NW, BITS>(k, r, shape);
 #pragma unroll
         for (int w = 0; w < NW; ++w) k[w] = r[w]; }
+      else if (dist_trans == KMI_DIST_XOR) { revcomp_words<NW, BITS>(k, r, shape);   // xor_rev_comp (kmer_transform.hpp:60-88)
+#pragma unroll
+        for (int w = 0; w < NW; ++w) k[w] ^= r[w]; }
       out32[i] = (uint32_t)(kmer_hash<NW>(k, shape, which, true, farm_ndebug, ceil_log2_u32(nranks)) % nranks);
     }
   }
@@ -99,7 +102,7 @@ static kmi_status array_op_impl(kmi_ctx *ctx, const kmi_config *cfg, KShape shap
   if (grid == 0) return KMI_OK;
   ProfScope ps(ctx, "kmer_array_op", n);
   hipLaunchKernelGGL((kmer_array_op_kernel<NW, BITS>), dim3(grid), dim3(256), 0, ctx->stream, in_dev, (uint64_t)n, shape, op,
-                     which, prefix, cfg->farm_ndebug != 0, cfg->strand, nranks, out64, out32);
+                     which, prefix, cfg->farm_ndebug != 0, cfg->strand, cfg->dist_trans, nranks, out64, out32);
   KMI_HIP(ctx, hipGetLastError());
   return KMI_OK;
 }

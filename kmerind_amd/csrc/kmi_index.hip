@@ -63,6 +63,7 @@ enum BucketMode { BUCKET_COARSE = 0, BUCKET_SUB = 1, BUCKET_RANK = 2 };
 struct BucketFn {
   int mode; KShape shape; uint32_t dist_hash; bool farm_ndebug; uint32_t nranks;
   uint32_t sub;   // rank mode: sub-buckets per rank (power of two, nranks * sub <= 256)
+  uint32_t dist_trans = 0;   // rank mode: KMI_DIST_* applied to the key before DistHash (single-strand model only)
 };
 // Rank mode spreads every rank over `sub` buckets (bucket = rank * sub + a few high hash bits): the buckets of a rank
 // stay adjacent, so the output is still grouped by rank, but the per-tile LDS counters are 256 distinct addresses
@@ -71,7 +72,17 @@ inline uint32_t rank_sub_buckets(uint32_t nranks) { uint32_t s = 1; while (s * 2
 
 template <int NW> __device__ __forceinline__ uint32_t bucket_of(const uint64_t (&key)[NW], const BucketFn &f) {
   if (f.mode == BUCKET_RANK) {
-    const uint64_t h = kmer_hash<NW>(key, f.shape, f.dist_hash, true, f.farm_ndebug, ceil_log2_u32(f.nranks));
+    uint64_t t[NW];
+#pragma unroll
+    for (int w = 0; w < NW; ++w) t[w] = key[w];
+    if (f.dist_trans) {   // uniform: DistTrans = lex_less / xor_rev_comp (kmer_transform.hpp:90-116, 60-88)
+      uint64_t rc[NW];
+      if (f.shape.bits == 2) revcomp_words<NW, 2>(key, rc, f.shape); else revcomp_words<NW, 3>(key, rc, f.shape);
+      const bool use_rc = f.dist_trans == KMI_DIST_LEX && less_words<NW>(rc, key);
+#pragma unroll
+      for (int w = 0; w < NW; ++w) t[w] = f.dist_trans == KMI_DIST_XOR ? (key[w] ^ rc[w]) : (use_rc ? rc[w] : key[w]);
+    }
+    const uint64_t h = kmer_hash<NW>(t, f.shape, f.dist_hash, true, f.farm_ndebug, ceil_log2_u32(f.nranks));
     const uint32_t spread = (uint32_t)((h >> 40) ^ (h >> 13)) * 0x9E3779B1u;   // identity/std hashes have few high bits
     return (uint32_t)(h % f.nranks) * f.sub + ((spread >> 16) & (f.sub - 1u));
   }
@@ -1474,12 +1485,11 @@ __global__ __launch_bounds__(256) void split_count_kernel(const uint64_t *__rest
   if (threadIdx.x < fn.nranks) s_cnt[threadIdx.x] = 0;
   lds_barrier();
   const uint64_t e0 = off[b], e1 = off[b + 1];
-  const uint32_t pbits = ceil_log2_u32(fn.nranks);
   for (uint64_t i = e0 + threadIdx.x; i < e1; i += 256) {
     uint64_t k[NW];
 #pragma unroll
     for (int w = 0; w < NW; ++w) k[w] = keys[i * NW + w];
-    const uint32_t r = (uint32_t)(kmer_hash<NW>(k, fn.shape, fn.dist_hash, true, fn.farm_ndebug, pbits) % fn.nranks);
+    const uint32_t r = bucket_of<NW>(k, fn);   // fn.sub == 1: the rank itself (DistTrans and DistHash as the routers apply them)
     rank_of[i] = (uint8_t)r;
     atomicAdd(&s_cnt[r], 1u);
   }
@@ -2208,6 +2218,7 @@ static kmi_status route_vw(kmi_ctx *ctx, const kmi_config *cfg, KShape shape, co
   KMI_TRY(ws_get(ctx, WS_CURSOR, sizeof(uint64_t) * kPartGroups * kNumCoarse, &p)); uint64_t *wg_off = (uint64_t *)p;
   KMI_TRY(ws_get(ctx, WS_MISC, sizeof(uint64_t) * kNumCoarse * 2, &p)); uint64_t *cnt = (uint64_t *)p;
   BucketFn fn; fn.mode = BUCKET_RANK; fn.shape = shape; fn.dist_hash = cfg->dist_hash; fn.farm_ndebug = cfg->farm_ndebug != 0; fn.nranks = nranks;
+  fn.dist_trans = cfg->dist_trans;
   fn.sub = rank_sub_buckets(nranks);
   const uint32_t nb = nranks * fn.sub;
   {
@@ -2262,6 +2273,7 @@ static kmi_status extract_route_impl(kmi_ctx *ctx, const kmi_config *cfg, KShape
   KMI_TRY(ws_get(ctx, WS_ENT_BKT, sizeof(uint64_t) * ((size_t)n_tiles * ListPassCfg<NW, BITS>::ent_stride(shape.k) + 64), &p));
   uint64_t *ent_bkt = (uint64_t *)p;
   BucketFn fn; fn.mode = BUCKET_RANK; fn.shape = shape; fn.dist_hash = cfg->dist_hash; fn.farm_ndebug = cfg->farm_ndebug != 0; fn.nranks = nranks;
+  fn.dist_trans = cfg->dist_trans;
   fn.sub = rank_sub_buckets(nranks);
   const uint32_t nb = nranks * fn.sub;
   {
@@ -2304,6 +2316,7 @@ static kmi_status split_impl(kmi_index *idx, uint32_t nranks, uint64_t *out_keys
   KMI_TRY(ws_get(ctx, WS_SPLIT_OFF, sizeof(uint64_t) * ((size_t)nranks * (kNumFine + 1) + 2 * (kNumCoarse + 1)), &p));
   uint64_t *boff = (uint64_t *)p, *tot = boff + (size_t)nranks * (kNumFine + 1), *base = tot + kNumCoarse + 1;
   BucketFn fn; fn.mode = BUCKET_RANK; fn.shape = idx->shape; fn.dist_hash = idx->cfg.dist_hash; fn.farm_ndebug = idx->cfg.farm_ndebug != 0;
+  fn.dist_trans = idx->cfg.dist_trans;
   fn.nranks = nranks; fn.sub = 1;
   {
     ProfScope ps(ctx, "split_count", n);

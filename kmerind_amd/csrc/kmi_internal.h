@@ -151,6 +151,7 @@ inline bool valid_config(const kmi_config *cfg, KShape *shape) {
   if (cfg->strand > 2 || cfg->dist_hash > 3 || cfg->store_hash > 3 || cfg->seq_format > 1 || cfg->index_kind > 2 || cfg->seq_filter > 2) return false;
   if (cfg->seq_filter && cfg->seq_format == KMI_FMT_FASTA && cfg->k == 1) return false;   // break bits need k >= 2 there
   if (cfg->seq_filter && cfg->index_kind == KMI_INDEX_POSQUAL) return false;
+  if (cfg->dist_trans > 2 || (cfg->dist_trans && cfg->strand != KMI_STRAND_SINGLE)) return false;
   if (shape) *shape = s;
   return true;
 }

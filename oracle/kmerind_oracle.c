@@ -428,14 +428,25 @@ void orc_kmers_hash(const orc_kspec *s, uint32_t which, int prefix, const uint64
   for (size_t i = 0; i < n; ++i) out[i] = orc_kmer_hash(s, which, prefix, kmers + i * s->n_words);
 }
 
-void orc_key_to_rank(const orc_kspec *s, uint32_t dist_hash, uint32_t strand,
-                     const uint64_t *kmers, size_t n, uint32_t p, uint32_t *ranks) {
+/* dist_trans: the DistTrans argument of SingleStrandHashMapParams (kmer_index.hpp:436-450): 0 = the model's own
+ * (identity; lex_less for bimolecule), 1 = lex_less (kmer_transform.hpp:90-116), 2 = xor_rev_comp (:60-88, x ^ rc(x)) */
+void orc_key_to_rank_ex(const orc_kspec *s, uint32_t dist_hash, uint32_t strand, uint32_t dist_trans,
+                        const uint64_t *kmers, size_t n, uint32_t p, uint32_t *ranks) {
   uint64_t t[ORC_MAX_WORDS];
   for (size_t i = 0; i < n; ++i) {
     const uint64_t *k = kmers + i * s->n_words;
-    if (strand == ORC_STRAND_BIMOLECULE) { orc_kmer_canonical(s, k, t); k = t; }
+    if (strand == ORC_STRAND_BIMOLECULE || dist_trans == 1) { orc_kmer_canonical(s, k, t); k = t; }
+    else if (dist_trans == 2) {
+      orc_kmer_revcomp(s, k, t);
+      for (uint32_t w = 0; w < s->n_words; ++w) t[w] ^= k[w];
+      k = t;
+    }
     ranks[i] = (uint32_t)(orc_kmer_hash_ex(s, dist_hash, 1, orc_ceil_log2(p), k) % p);
   }
+}
+void orc_key_to_rank(const orc_kspec *s, uint32_t dist_hash, uint32_t strand,
+                     const uint64_t *kmers, size_t n, uint32_t p, uint32_t *ranks) {
+  orc_key_to_rank_ex(s, dist_hash, strand, 0, kmers, n, p, ranks);
 }
 
 /* ------------------------------------------------------------------------ */

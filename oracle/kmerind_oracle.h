@@ -104,6 +104,8 @@ uint64_t orc_kmer_hash_ex(const orc_kspec *s, uint32_t which, int prefix, unsign
 unsigned orc_ceil_log2(unsigned n);
 void orc_key_to_rank(const orc_kspec *s, uint32_t dist_hash, uint32_t strand,
                      const uint64_t *kmers, size_t n, uint32_t p, uint32_t *ranks);
+void orc_key_to_rank_ex(const orc_kspec *s, uint32_t dist_hash, uint32_t strand, uint32_t dist_trans,
+                        const uint64_t *kmers, size_t n, uint32_t p, uint32_t *ranks);
 
 /* ---- sequence records: src/io/fastq_loader.hpp:389-467, fasta_loader.hpp:485-723 */
 typedef struct {

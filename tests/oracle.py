@@ -58,6 +58,7 @@ lib.orc_farm_hash64_with_seed.restype = C.c_uint64
 lib.orc_set_farm_ndebug.argtypes = [C.c_int]
 lib.orc_kmers_hash.argtypes = [_SP, C.c_uint32, C.c_int, _u64p, C.c_size_t, _u64p]
 lib.orc_key_to_rank.argtypes = [_SP, C.c_uint32, C.c_uint32, _u64p, C.c_size_t, C.c_uint32, _u32p]
+lib.orc_key_to_rank_ex.argtypes = [_SP, C.c_uint32, C.c_uint32, C.c_uint32, _u64p, C.c_size_t, C.c_uint32, _u32p]
 lib.orc_fastq_records.argtypes = [_u8p, C.c_size_t, C.c_uint64, C.c_void_p, C.c_size_t]
 lib.orc_fastq_records.restype = C.c_long
 lib.orc_fasta_records.argtypes = [_u8p, C.c_size_t, C.c_uint64, C.c_void_p, C.c_size_t]
@@ -155,10 +156,11 @@ def kmer_hash(s, which, prefix, kmers):
     return out
 
 
-def key_to_rank(s, dist_hash, strand, kmers, p):
+def key_to_rank(s, dist_hash, strand, kmers, p, dist_trans=0):
+    """dist_trans: 0 = the strand model's own DistTrans, 1 = lex_less, 2 = xor_rev_comp (single-strand model)"""
     kmers = np.ascontiguousarray(kmers, dtype=np.uint64).reshape(-1, s.n_words)
     out = np.empty(kmers.shape[0], dtype=np.uint32)
-    lib.orc_key_to_rank(C.byref(s), dist_hash, strand, kmers, kmers.shape[0], p, out)
+    lib.orc_key_to_rank_ex(C.byref(s), dist_hash, strand, dist_trans, kmers, kmers.shape[0], p, out)
     return out
 
 

@@ -373,3 +373,68 @@ def test_bucket_with_more_distinct_keys_than_the_lds_table_takes_more_passes(ctx
     fk, fc = idx.find(q)
     assert fk.shape[0] == hot[::3].size and all(ref[int(a)] == int(b) for a, b in zip(fk[:, 0], fc))
     idx.close()
+
+
+@pytest.mark.parametrize("dist_trans,code", [("lex_less", 1), ("xor_rev_comp", 2)])
+def test_single_strand_dist_transforms(ctx, dist_trans, code):
+    """DistTrans of SingleStrandHashMapParams (kmer_index.hpp:436-450; pDistTrans of BenchmarkKmerIndex.cpp:150-161): the key is
+    stored as parsed but ranked by DistHash(lex_less(key)) or DistHash(key ^ revcomp(key)). KeyToRank on the host-facing op,
+    the key router, the fused extract + route and the index split all follow the oracle; both strands of a k-mer land on
+    one rank; the other strand models refuse the option."""
+    import ctypes as C
+    import kmerind_amd as K
+    from kmerind_amd import _lib as L
+    for k, alpha, dh, p in ((31, "DNA", "murmur", 8), (21, "DNA5", "farm", 3), (40, "DNA", "murmur", 5)):
+        s = orc.kspec(k, ALPHA[alpha])
+        cfg = K.make_config(k, alpha, strand="single", dist_hash=dh, dist_trans=dist_trans)
+        data = np.asarray(K.synth_fastq(seed=13, genome_len=30000, n_reads=700))
+        ex = orc.extract(s, data.tobytes(), orc.FASTQ)["kmers"]
+        n, nw = ex.shape
+        exp = orc.key_to_rank(s, orc.MURMUR if dh == "murmur" else orc.FARM, orc.SINGLE, ex, p, dist_trans=code)
+        assert (ctx.key_to_rank(cfg, ex, p) == exp).all()
+        assert (orc.key_to_rank(s, orc.MURMUR if dh == "murmur" else orc.FARM, orc.SINGLE, orc.revcomp(s, ex), p, dist_trans=code) == exp).all()
+        # router on an existing key array, and the fused extract + route
+        for fused in (False, True):
+            counts = np.zeros(p, dtype=np.uint64)
+            dout = ctx.alloc(ex.nbytes + 64)
+            if fused:
+                dbytes = ctx.alloc(data.nbytes)
+                ctx.to_device(dbytes, data)
+                nt, ns = C.c_uint64(), C.c_uint64()
+                ctx.check(L.lib.kmi_extract_route_dev(ctx.h, C.byref(cfg), C.c_void_p(dbytes), data.nbytes, p, C.c_void_p(dout), n,
+                                                      C.byref(nt), C.byref(ns), counts.ctypes.data_as(C.c_void_p)))
+                ctx.free(dbytes)
+            else:
+                din = ctx.alloc(ex.nbytes)
+                ctx.to_device(din, ex)
+                ctx.check(L.lib.kmi_route_dev(ctx.h, C.byref(cfg), C.c_void_p(din), n, p, C.c_void_p(dout), counts.ctypes.data_as(C.c_void_p)))
+                ctx.free(din)
+            out = np.zeros_like(ex)
+            ctx.to_host(out, dout)
+            ctx.free(dout)
+            assert counts.tolist() == np.bincount(exp, minlength=p).tolist()
+            off = 0
+            for r in range(p):
+                seg, want = out[off:off + int(counts[r])], ex[exp == r]
+                assert (seg[np.lexsort([seg[:, w] for w in range(nw)])] == want[np.lexsort([want[:, w] for w in range(nw)])]).all()
+                off += int(counts[r])
+        # combine-first split of a local index
+        idx = K.CountIndex(ctx, cfg)
+        idx.build(data)
+        m, nb = idx.local_size(), K.core.num_buckets()
+        dk, dc, db = ctx.alloc(m * nw * 8 + 64), ctx.alloc(m * 4 + 64), ctx.alloc(p * nb * 4)
+        sc = idx.split_by_rank_device(p, dk, dc, m, db)
+        ok = np.zeros((m, nw), np.uint64)
+        ctx.to_host(ok, dk)
+        ctx.free(dk); ctx.free(dc); ctx.free(db)
+        lk, _ = idx.to_vector()
+        lr = orc.key_to_rank(s, orc.MURMUR if dh == "murmur" else orc.FARM, orc.SINGLE, lk, p, dist_trans=code)
+        assert sc.tolist() == np.bincount(lr, minlength=p).tolist()
+        off = 0
+        for r in range(p):
+            seg = ok[off:off + int(sc[r])]
+            assert (orc.key_to_rank(s, orc.MURMUR if dh == "murmur" else orc.FARM, orc.SINGLE, seg, p, dist_trans=code) == r).all()
+            off += int(sc[r])
+        idx.close()
+    with pytest.raises((L.KmiError, ValueError)):
+        ctx.key_to_rank(K.make_config(31, "DNA", strand="canonical", dist_trans=dist_trans), np.zeros((4, 1), np.uint64), 4)
