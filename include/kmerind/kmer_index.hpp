@@ -167,6 +167,8 @@ template <typename K, bool Prefix = false> struct murmur { static constexpr uint
 template <typename K, bool Prefix = false> struct farm { static constexpr uint32_t KMI = KMI_HASH_FARM; };
 template <typename K, bool Prefix = false> struct identity { static constexpr uint32_t KMI = KMI_HASH_IDENTITY; };
 template <typename K, bool Prefix = false> struct cpp_std { static constexpr uint32_t KMI = KMI_HASH_STD; };
+// the empty / deleted key pair of the densehash maps (kmer_hash.hpp sparsehash::special_keys): storage detail, a tag here
+namespace sparsehash { template <typename K, bool Canonical = false> struct special_keys {}; }
 }  // namespace hash
 }  // namespace kmer
 
@@ -218,6 +220,23 @@ struct unordered_multimap {
 template <typename Key, typename T, template <typename> class MapParams, typename SpecialKeys = void>
 struct densehash_multimap : unordered_multimap<Key, T, MapParams> {};
 
+// sorted flavours (distributed_sorted_map.hpp; pMAP == SORTED in BenchmarkKmerIndex.cpp:196-218): the reference keeps a
+// sorted vector per rank and splits ranks by sample sort; the map a caller observes -- count / find / erase / size /
+// to_vector as a set -- is the unordered one's, so the tags select the same device index. (With more than one rank the
+// owner of a key follows the hash rule here, not a sort split.)
+template <typename Key, template <typename> class InputTrans, template <typename> class StoreTrans,
+          template <typename> class Less, template <typename> class Equal>
+struct SortedMapParams {
+  static constexpr bool input_is_lex_less = std::is_same<InputTrans<Key>, ::bliss::kmer::transform::lex_less<Key>>::value;
+  static constexpr bool store_is_lex_less = std::is_same<StoreTrans<Key>, ::bliss::kmer::transform::lex_less<Key>>::value;
+  static constexpr uint32_t strand = input_is_lex_less ? KMI_STRAND_CANONICAL : (store_is_lex_less ? KMI_STRAND_BIMOLECULE : KMI_STRAND_SINGLE);
+  static constexpr uint32_t dist_hash = KMI_HASH_MURMUR, store_hash = KMI_HASH_MURMUR, dist_trans = KMI_DIST_MODEL;
+};
+template <typename Key, typename T, template <typename> class MapParams>
+struct counting_sorted_map : counting_unordered_map<Key, T, MapParams> {};
+template <typename Key, typename T, template <typename> class MapParams>
+struct sorted_multimap : unordered_multimap<Key, T, MapParams> {};
+
 }  // namespace dsc
 
 // ---------------------------------------------------------------------------
@@ -231,6 +250,10 @@ template <typename K> using DistHashMurmur = ::bliss::kmer::hash::murmur<K, true
 template <typename K> using DistHashFarm = ::bliss::kmer::hash::farm<K, true>;
 template <typename K> using StoreHashMurmur = ::bliss::kmer::hash::murmur<K, false>;
 template <typename K> using StoreHashFarm = ::bliss::kmer::hash::farm<K, false>;
+template <typename K> using DistHashStd = ::bliss::kmer::hash::cpp_std<K, true>;          // kmer_index.hpp:416-419
+template <typename K> using DistHashIdentity = ::bliss::kmer::hash::identity<K, true>;
+template <typename K> using StoreHashStd = ::bliss::kmer::hash::cpp_std<K, false>;        // :426-429
+template <typename K> using StoreHashIdentity = ::bliss::kmer::hash::identity<K, false>;
 
 template <typename Key, template <typename> class DistHash = DistHashMurmur, template <typename> class StoreHash = StoreHashMurmur,
           template <typename> class DistTrans = ::bliss::transform::identity>
@@ -242,6 +265,14 @@ using CanonicalHashMapParams = ::dsc::HashMapParams<Key, ::bliss::kmer::transfor
 template <typename Key, template <typename> class DistHash = DistHashMurmur, template <typename> class StoreHash = StoreHashMurmur>
 using BimoleculeHashMapParams = ::dsc::HashMapParams<Key, ::bliss::transform::identity, ::bliss::kmer::transform::lex_less, DistHash,
                                                     ::std::equal_to, ::bliss::kmer::transform::lex_less, StoreHash, ::std::equal_to>;
+
+// kmer_index.hpp:530-562
+template <typename Key, template <typename> class Less = ::std::less>
+using SingleStrandSortedMapParams = ::dsc::SortedMapParams<Key, ::bliss::transform::identity, ::bliss::transform::identity, Less, ::std::equal_to>;
+template <typename Key, template <typename> class Less = ::std::less>
+using CanonicalSortedMapParams = ::dsc::SortedMapParams<Key, ::bliss::kmer::transform::lex_less, ::bliss::transform::identity, Less, ::std::equal_to>;
+template <typename Key, template <typename> class Less = ::std::less>
+using BimoleculeSortedMapParams = ::dsc::SortedMapParams<Key, ::bliss::transform::identity, ::bliss::kmer::transform::lex_less, Less, ::std::equal_to>;
 
 // tuple parsers (kmer_parser.hpp:85-294, 909-1083): value_type is what read_file_* produces
 template <typename KmerType> struct KmerParser { using value_type = KmerType; using kmer_type = KmerType; static constexpr size_t window_size = KmerType::size; };

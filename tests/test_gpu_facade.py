@@ -148,3 +148,22 @@ def test_predicate_forms_match_an_independent_computation():
     fm = orc.CountMap(s, orc.CANONICAL)
     fm.insert(fex["kmers"])
     assert grab(r"fasta size (\d+) total (\d+)") == (fm.size(), fex["kmers"].shape[0])
+
+
+def test_reference_type_matrix_through_the_facade(tmp_path):
+    """examples/type_matrix.cpp: the map / parameter combinations BenchmarkKmerIndex.cpp instantiates (unordered, densehash with
+    SpecialKeys, sorted flavours; the three strand models; DistHash / StoreHash / DistTrans choices; count and position
+    indexes; build_posix with NSplitSequencesIterator) compile under the reference's names and agree with one another; the
+    canonical count is the oracle's."""
+    exe = os.path.join(ROOT, "examples", "type_matrix")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "examples")])
+    path = os.path.join(DATA, "natural.withN.fastq")
+    out = subprocess.run([exe, path], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "type matrix ok" in out.stdout
+    m = re.search(r"canonical (\d+)", out.stdout)
+    s = orc.kspec(21)
+    om = orc.CountMap(s, orc.CANONICAL)
+    om.insert(orc.extract(s, open(path, "rb").read(), orc.FASTQ, seq_filter=orc.SEQ_N_SPLIT)["kmers"])
+    assert int(m.group(1)) == om.size()
