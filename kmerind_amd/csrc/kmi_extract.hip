@@ -385,40 +385,116 @@ __device__ __forceinline__ float exp2f_libm(float x) {
   return (float)y;
 }
 
-struct ReadDesc { uint64_t seq_pos, out_off; };
+struct ReadDesc { uint64_t seq_pos, out_off; };   // slot = sequence index of the read; out_off = ~0: the read has no k-mer
 
-__global__ __launch_bounds__(256) void fastq_quality_kernel(const uint8_t *__restrict__ bytes, uint64_t n_bytes, uint32_t k,
-                                                           const ReadDesc *__restrict__ reads, const uint32_t *__restrict__ n_reads,
-                                                           float *__restrict__ out) {
+// One WAVEFRONT per read. Finding the quality line and decoding its characters is done by all lanes (coalesced byte
+// loads, ballots); the running sum is replayed by lane 0 in the reference's order over the decoded values in LDS (two
+// float operations per window, nothing else on that critical path); exp2 and the stores are again all lanes. Windows
+// go through in chunks of QW, so a read of any length needs (QW + k) decoded values at a time.
+constexpr int kQualWin = 192;                         // windows per chunk
+constexpr int kQualThreads = 256;
+__global__ __launch_bounds__(kQualThreads) void fastq_quality_kernel(const uint8_t *__restrict__ bytes, uint64_t n_bytes, uint32_t k,
+                                                                    const ReadDesc *__restrict__ reads, const uint64_t *__restrict__ n_reads,
+                                                                    float *__restrict__ out) {
+  constexpr int QW = kQualWin, VMAX = QW + 128 + 1;   // k <= 128
+  __shared__ float s_v[kQualThreads / kWave][VMAX];
+  __shared__ float s_sum[kQualThreads / kWave][QW];
+  const uint32_t lane = lane_id(), wv = wave_id();
+  float *v = s_v[wv], *sm = s_sum[wv];
   const uint64_t nr = *n_reads;
-  for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < nr; r += (uint64_t)gridDim.x * blockDim.x) {
-    const uint64_t sp = reads[r].seq_pos;
-    uint64_t o = reads[r].out_off;
-    uint64_t len = 0;
-    while (sp + len < n_bytes && !is_eol(bytes[sp + len])) ++len;
-    uint64_t q = sp + len;
-    while (q < n_bytes && is_eol(bytes[q])) ++q;       // to the '+' line
-    while (q < n_bytes && !is_eol(bytes[q])) ++q;      // over it
-    while (q < n_bytes && is_eol(bytes[q])) ++q;       // to the quality line
-    auto decode = [&](uint64_t i) -> float {
-      const uint64_t p = q + i;
-      if (p >= n_bytes) return c_qual_lut[0];
-      const uint32_t c = bytes[p];
-      return (c >= 33u && c < 33u + 96u) ? c_qual_lut[c - 33u] : c_qual_lut[0];
-    };
-    const float lo = c_qual_lut[0], hi = c_qual_lut[95];
-    float sum = 0.0f;
-    uint32_t bad = 0;
-    for (uint32_t i = 0; i < k; ++i) {               // init(): quality_score_iterator.hpp:99-115
-      const float v = decode(i);
-      if (v > lo && v < hi) sum += v; else ++bad;
+  const uint64_t n_waves = (uint64_t)gridDim.x * (kQualThreads / kWave);
+  auto wave_sync = [&]() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); };
+  // first position >= from whose EOL status is `want` (n_bytes if none); 256 bytes per round trip
+  auto scan_to = [&](uint64_t from, bool want) -> uint64_t {
+    for (uint64_t p0 = from;; p0 += 4 * kWave) {
+      uint32_t c[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { const uint64_t p = p0 + (uint64_t)i * kWave + lane; c[i] = bytes[p < n_bytes ? p : n_bytes - 1]; }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const uint64_t p = p0 + (uint64_t)i * kWave + lane;
+        const unsigned long long m = __ballot(p >= n_bytes || (is_eol(c[i]) == want));
+        if (m) { const uint64_t r = p0 + (uint64_t)i * kWave + (uint32_t)(__ffsll((long long)m) - 1); return r < n_bytes ? r : n_bytes; }
+      }
     }
-    out[o++] = bad ? 0.0f : exp2f_libm(sum);  // getValue(): :166-173
-    for (uint64_t j = k; j < len; ++j) {              // next(): :127-159
-      const float ov = decode(j - k), nv = decode(j);
-      if (ov > lo && ov < hi) sum -= ov; else --bad;
-      if (nv > lo && nv < hi) sum += nv; else ++bad;
-      out[o++] = bad ? 0.0f : exp2f_libm(sum);
+  };
+  // the quality line behind the sequence line that ends at e1: "<EOLs> + line <EOLs> quality". One 64-byte look resolves the
+  // usual "\n+\n" (and any '+' line shorter than the look); otherwise three scans.
+  auto quality_start = [&](uint64_t e1) -> uint64_t {
+    if (e1 + kWave <= n_bytes) {
+      const unsigned long long E = __ballot(is_eol(bytes[e1 + lane]));
+      const unsigned long long m1 = ~E;
+      if (m1) {
+        const uint32_t a = (uint32_t)(__ffsll((long long)m1) - 1);
+        const unsigned long long m2 = E & ~((1ull << a) - 1ull);
+        if (m2) {
+          const uint32_t b = (uint32_t)(__ffsll((long long)m2) - 1);
+          const unsigned long long m3 = ~E & ~((1ull << b) - 1ull);
+          if (m3) return e1 + (uint32_t)(__ffsll((long long)m3) - 1);
+        }
+      }
+    }
+    uint64_t q = scan_to(e1, false);                   // the '+' line
+    q = scan_to(q, true);                              // over it
+    return scan_to(q, false);                          // the quality line
+  };
+  const float lo = c_qual_lut[0], hi = c_qual_lut[95];
+  for (uint64_t r = (uint64_t)blockIdx.x * (kQualThreads / kWave) + wv; r < nr; r += n_waves) {
+    const uint64_t sp = reads[r].seq_pos, o = reads[r].out_off;
+    if (o == ~0ull) continue;                          // wave-uniform
+    const uint64_t e1 = scan_to(sp, true);             // end of the sequence line
+    const uint64_t len = e1 - sp;
+    const uint64_t q = quality_start(e1);
+    if (len < k) continue;
+    const uint64_t n_win = len - k + 1;
+    float sum = 0.0f;                                  // lane 0's running state (quality_score_iterator.hpp:99-173)
+    uint32_t bad = 0;
+    for (uint64_t w0 = 0; w0 < n_win; w0 += QW) {
+      const uint32_t nw = (uint32_t)((n_win - w0 < (uint64_t)QW) ? (n_win - w0) : (uint64_t)QW);
+      // decoded values of the characters c0 .. c0 + nv - 1 that this chunk touches: the one leaving window w0 - 1 onward
+      const uint64_t c0 = w0 ? w0 - 1 : 0;
+      const uint32_t nv = (uint32_t)(w0 + nw + k - 1 - c0);
+      for (uint32_t i = lane; i < nv; i += kWave) {
+        const uint64_t p = q + c0 + i;
+        float val = lo;
+        if (p < n_bytes) { const uint32_t c = bytes[p]; val = (c >= 33u && c < 33u + 96u) ? c_qual_lut[c - 33u] : lo; }
+        v[i] = val;
+      }
+      wave_sync();
+      if (lane == 0) {
+        uint32_t w = 0;
+        if (w0 == 0) {                                 // init(): :99-115
+          for (uint32_t i = 0; i < k; ++i) { const float x = v[i]; if (x > lo && x < hi) sum += x; else ++bad; }
+          sm[0] = bad ? INFINITY : sum;
+          w = 1;
+        }
+        // next(): :127-159 -- window w0 + w drops character w0 + w - 1 and takes w0 + w + k - 1. Eight windows' values are
+        // read together so that only the float chain itself is serial.
+        const uint32_t ob = (uint32_t)(w0 - 1 - c0), nb = (uint32_t)(w0 + k - 1 - c0);   // v index of the leaving / entering value of window w0 + 0
+        for (; w + 8 <= nw; w += 8) {
+          float ov[8], nvv[8];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) { ov[i] = v[ob + w + i]; nvv[i] = v[nb + w + i]; }
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            if (ov[i] > lo && ov[i] < hi) sum -= ov[i]; else --bad;
+            if (nvv[i] > lo && nvv[i] < hi) sum += nvv[i]; else ++bad;
+            sm[w + i] = bad ? INFINITY : sum;
+          }
+        }
+        for (; w < nw; ++w) {
+          const float o1 = v[ob + w], n1 = v[nb + w];
+          if (o1 > lo && o1 < hi) sum -= o1; else --bad;
+          if (n1 > lo && n1 < hi) sum += n1; else ++bad;
+          sm[w] = bad ? INFINITY : sum;
+        }
+      }
+      wave_sync();
+      for (uint32_t w = lane; w < nw; w += kWave) {    // getValue(): :166-173
+        const float x = sm[w];
+        out[o + w0 + w] = (x == INFINITY) ? 0.0f : exp2f_libm(x);
+      }
+      wave_sync();
     }
   }
 }
@@ -427,7 +503,7 @@ template <int NW, int BITS, bool WITH_IDS>
 __global__ __launch_bounds__((ExCfg<NW, BITS>::NT)) void fastq_extract_kernel(
     PackedInput in, KShape shape, bool canonical, const uint32_t *__restrict__ line_base, const uint64_t *__restrict__ hdr_base,
     uint64_t file_offset, const uint64_t *__restrict__ out_off, uint64_t out_capacity, uint64_t *__restrict__ out_kmers,
-    uint64_t *__restrict__ out_ids, ReadDesc *__restrict__ reads, uint32_t *__restrict__ n_reads, uint32_t *__restrict__ flags) {
+    uint64_t *__restrict__ out_ids, ReadDesc *__restrict__ reads, uint32_t *__restrict__ flags) {
   using Cfg = ExCfg<NW, BITS>;
   __shared__ uint32_t s_eol[Cfg::EOL_DW];
   __shared__ uint32_t s_brk[Cfg::EOL_DW];
@@ -437,10 +513,11 @@ __global__ __launch_bounds__((ExCfg<NW, BITS>::NT)) void fastq_extract_kernel(
   __shared__ uint16_t s_hmask[WITH_IDS ? Cfg::NT : 1];   // record-start bits of every chunk
   __shared__ uint16_t s_hexcl[WITH_IDS ? Cfg::NT : 1];   // 1 + tile position of the last record start in earlier chunks
   __shared__ uint16_t s_lsmask[WITH_IDS ? Cfg::NT : 1];  // line-start bits of every chunk
+  __shared__ uint16_t s_lcnt[WITH_IDS ? Cfg::NT : 1];    // line starts of the tile before every chunk
   uint32_t eol, ls, lbl, ltot;
   tile_front_packed<Cfg>(in, blockIdx.x, s_eol, s_stream, s_scan, eol, ls, lbl, ltot);
   const uint32_t lines_before = line_base[blockIdx.x] + lbl;
-  if (WITH_IDS) s_lsmask[threadIdx.x] = (uint16_t)ls;
+  if (WITH_IDS) { s_lsmask[threadIdx.x] = (uint16_t)ls; s_lcnt[threadIdx.x] = (uint16_t)lbl; }
   if (WITH_IDS) {
     // record starts = line starts whose line index % 4 == 0 (the '@' line)
     uint32_t cur = lines_before, rest = ls, hm = 0, hlast = 0;
@@ -481,9 +558,10 @@ __global__ __launch_bounds__((ExCfg<NW, BITS>::NT)) void fastq_extract_kernel(
       out_ids[base + q] = ((rec_off & 0xFFFFFFFFFFull) << 16) | (d & 0xFFFFull);
       // first window of its read (the window starts on the line start of the sequence line)
       if (reads && ((s_lsmask[j] >> p) & 1u)) {
-        const uint32_t slot = atomicAdd(n_reads, 1u);
+        // the descriptor slot is the read's sequence index: its sequence line is line 4 * index + 1 of the buffer
+        const uint32_t line = line_base[blockIdx.x] + s_lcnt[j] + (uint32_t)__builtin_popcount((uint32_t)s_lsmask[j] & ((1u << p) - 1u));
         ReadDesc rd; rd.seq_pos = tile0 + pos; rd.out_off = base + q;
-        reads[slot] = rd;
+        reads[(line - 1u) >> 2] = rd;
       }
     }
   }
@@ -723,27 +801,30 @@ static kmi_status extract_run_impl(kmi_ctx *ctx, const kmi_config *cfg, const ui
     ProfScope ps(ctx, "fastq_extract", n_bytes);
     const bool canonical = apply_strand && cfg->strand != KMI_STRAND_SINGLE;
     ReadDesc *reads = nullptr;
-    uint32_t *n_reads = ctx->d_flags + 8;
     if (out_quals_dev) {
-      // one descriptor per read that has at least one window; sequences <= lines / 4 + 1
+      // one descriptor slot per sequence (totals[2] of the scan), empty until the read's first window fills it
+      uint64_t n_seq_now = 0;
+      KMI_HIP(ctx, hipMemcpyAsync(&n_seq_now, ctx->d_totals + 2, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+      KMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
       void *pr;
-      KMI_TRY(ws_get(ctx, WS_READS, sizeof(ReadDesc) * (n_bytes / 4 + 16), &pr));
+      KMI_TRY(ws_get(ctx, WS_READS, sizeof(ReadDesc) * (n_seq_now + 16), &pr));
       reads = (ReadDesc *)pr;
+      KMI_HIP(ctx, hipMemsetAsync(reads, 0xff, sizeof(ReadDesc) * (n_seq_now + 16), ctx->stream));
     }
     if (out_ids_dev) {
       hipLaunchKernelGGL((fastq_extract_kernel<NW, BITS, true>), dim3((unsigned)r.n_tiles), dim3(Cfg::NT), 0, ctx->stream,
                          r.packed, shape, canonical, (const uint32_t *)r.line_base, (const uint64_t *)r.hdr_base, file_offset,
-                         (const uint64_t *)r.out_off, (uint64_t)out_capacity, out_kmers_dev, out_ids_dev, reads, n_reads, ctx->d_flags);
+                         (const uint64_t *)r.out_off, (uint64_t)out_capacity, out_kmers_dev, out_ids_dev, reads, ctx->d_flags);
     } else {
       hipLaunchKernelGGL((fastq_extract_kernel<NW, BITS, false>), dim3((unsigned)r.n_tiles), dim3(Cfg::NT), 0, ctx->stream,
                          r.packed, shape, canonical, (const uint32_t *)r.line_base, (const uint64_t *)r.hdr_base, file_offset,
                          (const uint64_t *)r.out_off, (uint64_t)out_capacity, out_kmers_dev, (uint64_t *)nullptr, (ReadDesc *)nullptr,
-                         (uint32_t *)nullptr, ctx->d_flags);
+                         ctx->d_flags);
     }
     if (out_quals_dev) {
       ProfScope pq(ctx, "fastq_quality", n_bytes);
-      hipLaunchKernelGGL(fastq_quality_kernel, dim3(2048), dim3(256), 0, ctx->stream, bytes_dev, (uint64_t)n_bytes, shape.k,
-                         (const ReadDesc *)reads, (const uint32_t *)n_reads, out_quals_dev);
+      hipLaunchKernelGGL(fastq_quality_kernel, dim3(4096), dim3(kQualThreads), 0, ctx->stream, bytes_dev, (uint64_t)n_bytes, shape.k,
+                         (const ReadDesc *)reads, (const uint64_t *)(ctx->d_totals + 2), out_quals_dev);
     }
   }
   KMI_HIP(ctx, hipGetLastError());
