@@ -387,114 +387,104 @@ __device__ __forceinline__ float exp2f_libm(float x) {
 
 struct ReadDesc { uint64_t seq_pos, out_off; };   // slot = sequence index of the read; out_off = ~0: the read has no k-mer
 
-// One WAVEFRONT per read. Finding the quality line and decoding its characters is done by all lanes (coalesced byte
-// loads, ballots); the running sum is replayed by lane 0 in the reference's order over the decoded values in LDS (two
-// float operations per window, nothing else on that critical path); exp2 and the stores are again all lanes. Windows
-// go through in chunks of QW, so a read of any length needs (QW + k) decoded values at a time.
-constexpr int kQualWin = 192;                         // windows per chunk
+// Sixty-four reads per WAVEFRONT, one per lane, so the sequential float chain of every read (two operations per window, in
+// the reference's order) runs on all lanes at once. Everything around the chain is made wave-friendly:
+//  * the quality line of a read is found by the lane itself with four bit scans over the EOL bitmap of the scan pass;
+//  * the quality characters go through LDS: for every read of the batch the lanes load its characters together
+//    (coalesced), chunk by chunk (kQualChunk windows), into a row per read; the row stride is an odd number of dwords, so
+//    the per-lane walk over "its" row is conflict free;
+//  * the values leave through a 64 x 16 LDS tile: every 16 windows the lanes write each read's 16 floats as one 64-byte line.
+constexpr int kQualChunk = 64;                        // windows per chunk (a multiple of 16)
 constexpr int kQualThreads = 256;
-__global__ __launch_bounds__(kQualThreads) void fastq_quality_kernel(const uint8_t *__restrict__ bytes, uint64_t n_bytes, uint32_t k,
-                                                                    const ReadDesc *__restrict__ reads, const uint64_t *__restrict__ n_reads,
-                                                                    float *__restrict__ out) {
-  constexpr int QW = kQualWin, VMAX = QW + 128 + 1;   // k <= 128
-  __shared__ float s_v[kQualThreads / kWave][VMAX];
-  __shared__ float s_sum[kQualThreads / kWave][QW];
+inline uint32_t qual_row_bytes(uint32_t k) { return (((kQualChunk + k + 3u) / 4u) | 1u) * 4u; }
+inline size_t qual_lds_bytes(uint32_t k) { return (size_t)(kQualThreads / kWave) * (64u * qual_row_bytes(k) + 64u * 17u * 4u) + 96u * 4u; }
+
+__global__ __launch_bounds__(kQualThreads) void fastq_quality_kernel(const uint8_t *__restrict__ bytes, uint64_t n_bytes,
+                                                                    const uint32_t *__restrict__ eolw, uint64_t n_words, uint32_t k,
+                                                                    uint32_t row_bytes, const ReadDesc *__restrict__ reads,
+                                                                    const uint64_t *__restrict__ n_reads, float *__restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t s_q[];
+  constexpr uint32_t W = kQualChunk;
   const uint32_t lane = lane_id(), wv = wave_id();
-  float *v = s_v[wv], *sm = s_sum[wv];
+  float *s_lut = reinterpret_cast<float *>(s_q);                                            // [96]
+  uint8_t *rows = s_q + 96u * 4u + (size_t)wv * (64u * row_bytes + 64u * 17u * 4u);          // [64][row_bytes]
+  float *tile = reinterpret_cast<float *>(rows + 64u * row_bytes);                          // [64][17]
+  if (threadIdx.x < 96) s_lut[threadIdx.x] = c_qual_lut[threadIdx.x];
+  lds_barrier();
+  const float lo = s_lut[0], hi = s_lut[95];
+  auto wave_sync = [&]() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); };
+  // first position >= p whose EOL bit equals `set`; past the bitmap everything is EOL
+  auto next_bit = [&](uint64_t p, bool set) -> uint64_t {
+    uint64_t wi = p >> 5;
+    if (wi >= n_words) return set ? p : n_words * 32;
+    uint32_t bits = (set ? eolw[wi] : ~eolw[wi]) & (0xffffffffu << (p & 31u));
+    while (bits == 0u) { if (++wi >= n_words) return n_words * 32; bits = set ? eolw[wi] : ~eolw[wi]; }
+    return wi * 32 + (uint32_t)__builtin_ctz(bits);
+  };
+  auto decode = [&](uint32_t c) -> float { return (c >= 33u && c < 33u + 96u) ? s_lut[c - 33u] : lo; };
   const uint64_t nr = *n_reads;
   const uint64_t n_waves = (uint64_t)gridDim.x * (kQualThreads / kWave);
-  auto wave_sync = [&]() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); };
-  // first position >= from whose EOL status is `want` (n_bytes if none); 256 bytes per round trip
-  auto scan_to = [&](uint64_t from, bool want) -> uint64_t {
-    for (uint64_t p0 = from;; p0 += 4 * kWave) {
-      uint32_t c[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) { const uint64_t p = p0 + (uint64_t)i * kWave + lane; c[i] = bytes[p < n_bytes ? p : n_bytes - 1]; }
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const uint64_t p = p0 + (uint64_t)i * kWave + lane;
-        const unsigned long long m = __ballot(p >= n_bytes || (is_eol(c[i]) == want));
-        if (m) { const uint64_t r = p0 + (uint64_t)i * kWave + (uint32_t)(__ffsll((long long)m) - 1); return r < n_bytes ? r : n_bytes; }
+  for (uint64_t b0 = ((uint64_t)blockIdx.x * (kQualThreads / kWave) + wv) * kWave; b0 < nr; b0 += n_waves * kWave) {
+    const uint64_t r = b0 + lane;
+    uint64_t q = 0, o = ~0ull;
+    uint32_t n_win = 0, len = 0;
+    if (r < nr) {
+      const ReadDesc rd = reads[r];
+      o = rd.out_off;
+      if (o != ~0ull) {
+        const uint64_t e1 = next_bit(rd.seq_pos, true);             // end of the sequence line
+        len = (uint32_t)(e1 - rd.seq_pos);
+        q = next_bit(next_bit(next_bit(e1, false), true), false);   // '+' line, its end, the quality line
+        n_win = len >= k ? len - k + 1u : 0u;
       }
     }
-  };
-  // the quality line behind the sequence line that ends at e1: "<EOLs> + line <EOLs> quality". One 64-byte look resolves the
-  // usual "\n+\n" (and any '+' line shorter than the look); otherwise three scans.
-  auto quality_start = [&](uint64_t e1) -> uint64_t {
-    if (e1 + kWave <= n_bytes) {
-      const unsigned long long E = __ballot(is_eol(bytes[e1 + lane]));
-      const unsigned long long m1 = ~E;
-      if (m1) {
-        const uint32_t a = (uint32_t)(__ffsll((long long)m1) - 1);
-        const unsigned long long m2 = E & ~((1ull << a) - 1ull);
-        if (m2) {
-          const uint32_t b = (uint32_t)(__ffsll((long long)m2) - 1);
-          const unsigned long long m3 = ~E & ~((1ull << b) - 1ull);
-          if (m3) return e1 + (uint32_t)(__ffsll((long long)m3) - 1);
-        }
-      }
-    }
-    uint64_t q = scan_to(e1, false);                   // the '+' line
-    q = scan_to(q, true);                              // over it
-    return scan_to(q, false);                          // the quality line
-  };
-  const float lo = c_qual_lut[0], hi = c_qual_lut[95];
-  for (uint64_t r = (uint64_t)blockIdx.x * (kQualThreads / kWave) + wv; r < nr; r += n_waves) {
-    const uint64_t sp = reads[r].seq_pos, o = reads[r].out_off;
-    if (o == ~0ull) continue;                          // wave-uniform
-    const uint64_t e1 = scan_to(sp, true);             // end of the sequence line
-    const uint64_t len = e1 - sp;
-    const uint64_t q = quality_start(e1);
-    if (len < k) continue;
-    const uint64_t n_win = len - k + 1;
-    float sum = 0.0f;                                  // lane 0's running state (quality_score_iterator.hpp:99-173)
+    uint32_t max_win = n_win;
+#pragma unroll
+    for (int d = kWave / 2; d > 0; d >>= 1) { const uint32_t t = (uint32_t)__shfl_xor((int)max_win, d, kWave); max_win = t > max_win ? t : max_win; }
+    float sum = 0.0f;
     uint32_t bad = 0;
-    for (uint64_t w0 = 0; w0 < n_win; w0 += QW) {
-      const uint32_t nw = (uint32_t)((n_win - w0 < (uint64_t)QW) ? (n_win - w0) : (uint64_t)QW);
-      // decoded values of the characters c0 .. c0 + nv - 1 that this chunk touches: the one leaving window w0 - 1 onward
-      const uint64_t c0 = w0 ? w0 - 1 : 0;
-      const uint32_t nv = (uint32_t)(w0 + nw + k - 1 - c0);
-      for (uint32_t i = lane; i < nv; i += kWave) {
-        const uint64_t p = q + c0 + i;
-        float val = lo;
-        if (p < n_bytes) { const uint32_t c = bytes[p]; val = (c >= 33u && c < 33u + 96u) ? c_qual_lut[c - 33u] : lo; }
-        v[i] = val;
+    for (uint32_t w0 = 0; w0 < max_win; w0 += W) {
+      // characters cs .. of every read that has windows in this chunk: the one that leaves window w0 - 1 onward
+      const uint32_t cs = w0 ? w0 - 1u : 0u;
+      for (uint32_t i = 0; i < (uint32_t)kWave; ++i) {
+        const uint32_t nwi = (uint32_t)__shfl((int)n_win, (int)i, kWave);
+        if (nwi <= w0) continue;                                      // wave-uniform
+        const uint64_t qi = ((uint64_t)(uint32_t)__shfl((int)(q >> 32), (int)i, kWave) << 32) | (uint32_t)__shfl((int)(uint32_t)q, (int)i, kWave);
+        const uint32_t wend = nwi < w0 + W ? nwi : w0 + W;           // windows [w0, wend) of read i
+        const uint32_t nc = wend + k - 1u - cs;                      // characters cs .. cs + nc - 1
+        for (uint32_t x = lane; x < nc; x += kWave) {
+          const uint64_t p = qi + cs + x;
+          rows[i * row_bytes + x] = p < n_bytes ? bytes[p] : (uint8_t)0;
+        }
       }
       wave_sync();
-      if (lane == 0) {
-        uint32_t w = 0;
-        if (w0 == 0) {                                 // init(): :99-115
-          for (uint32_t i = 0; i < k; ++i) { const float x = v[i]; if (x > lo && x < hi) sum += x; else ++bad; }
-          sm[0] = bad ? INFINITY : sum;
-          w = 1;
-        }
-        // next(): :127-159 -- window w0 + w drops character w0 + w - 1 and takes w0 + w + k - 1. Eight windows' values are
-        // read together so that only the float chain itself is serial.
-        const uint32_t ob = (uint32_t)(w0 - 1 - c0), nb = (uint32_t)(w0 + k - 1 - c0);   // v index of the leaving / entering value of window w0 + 0
-        for (; w + 8 <= nw; w += 8) {
-          float ov[8], nvv[8];
-#pragma unroll
-          for (int i = 0; i < 8; ++i) { ov[i] = v[ob + w + i]; nvv[i] = v[nb + w + i]; }
-#pragma unroll
-          for (int i = 0; i < 8; ++i) {
-            if (ov[i] > lo && ov[i] < hi) sum -= ov[i]; else --bad;
-            if (nvv[i] > lo && nvv[i] < hi) sum += nvv[i]; else ++bad;
-            sm[w + i] = bad ? INFINITY : sum;
+      const uint8_t *my = rows + lane * row_bytes;
+      if (w0 == 0 && n_win) {                                         // init(): quality_score_iterator.hpp:99-115
+        for (uint32_t i = 0; i < k; ++i) { const float x = decode(my[i]); if (x > lo && x < hi) sum += x; else ++bad; }
+      }
+      for (uint32_t t0 = 0; t0 < W && w0 + t0 < max_win; t0 += 16) {
+#pragma unroll 4
+        for (uint32_t t = 0; t < 16; ++t) {
+          const uint32_t w = w0 + t0 + t;
+          if (w < n_win) {
+            if (w) {                                                  // next(): :127-159
+              const float ov = decode(my[w - 1u - cs]), nv = decode(my[w + k - 1u - cs]);
+              if (ov > lo && ov < hi) sum -= ov; else --bad;
+              if (nv > lo && nv < hi) sum += nv; else ++bad;
+            }
+            tile[lane * 17u + t] = bad ? 0.0f : exp2f_libm(sum);      // getValue(): :166-173
           }
         }
-        for (; w < nw; ++w) {
-          const float o1 = v[ob + w], n1 = v[nb + w];
-          if (o1 > lo && o1 < hi) sum -= o1; else --bad;
-          if (n1 > lo && n1 < hi) sum += n1; else ++bad;
-          sm[w] = bad ? INFINITY : sum;
+        wave_sync();
+        // 16 floats of one read = one 64-byte line: four reads per store instruction
+        for (uint32_t g = 0; g < (uint32_t)kWave; g += 4) {
+          const uint32_t row = g + (lane >> 4), col = lane & 15u, w = w0 + t0 + col;
+          const uint32_t nwr = (uint32_t)__shfl((int)n_win, (int)row, kWave);
+          const uint64_t orow = ((uint64_t)(uint32_t)__shfl((int)(o >> 32), (int)row, kWave) << 32) | (uint32_t)__shfl((int)(uint32_t)o, (int)row, kWave);
+          if (w < nwr) out[orow + w] = tile[row * 17u + col];
         }
+        wave_sync();
       }
-      wave_sync();
-      for (uint32_t w = lane; w < nw; w += kWave) {    // getValue(): :166-173
-        const float x = sm[w];
-        out[o + w0 + w] = (x == INFINITY) ? 0.0f : exp2f_libm(x);
-      }
-      wave_sync();
     }
   }
 }
@@ -823,8 +813,9 @@ static kmi_status extract_run_impl(kmi_ctx *ctx, const kmi_config *cfg, const ui
     }
     if (out_quals_dev) {
       ProfScope pq(ctx, "fastq_quality", n_bytes);
-      hipLaunchKernelGGL(fastq_quality_kernel, dim3(4096), dim3(kQualThreads), 0, ctx->stream, bytes_dev, (uint64_t)n_bytes, shape.k,
-                         (const ReadDesc *)reads, (const uint64_t *)(ctx->d_totals + 2), out_quals_dev);
+      hipLaunchKernelGGL(fastq_quality_kernel, dim3(2048), dim3(kQualThreads), qual_lds_bytes(shape.k), ctx->stream, bytes_dev,
+                         (uint64_t)n_bytes, (const uint32_t *)r.packed.eol, (uint64_t)(r.packed.n_cover / 32), shape.k,
+                         qual_row_bytes(shape.k), (const ReadDesc *)reads, (const uint64_t *)(ctx->d_totals + 2), out_quals_dev);
     }
   }
   KMI_HIP(ctx, hipGetLastError());
