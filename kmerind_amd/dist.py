@@ -126,6 +126,56 @@ class DistributedCountIndex:
         rk, rv, rb = exchange_pairs(keys[:n], counts[:n], bcnt, self.group, self.stage)
         self.index.merge_parts_device(self.world, rk.data_ptr(), rv.data_ptr(), rb.data_ptr())
 
+    # ---- queries (distributed_unordered_map.hpp:880-983 count, :564-687 find, :719-779 erase): transform_input, route the
+    # query keys to their owners (imxx::distribute), answer locally per source rank, one return all-to-all
+    def _route_queries(self, q):
+        import numpy as np
+        from . import _lib as L
+        q = np.ascontiguousarray(q, dtype=np.uint64).reshape(-1, self.n_words)
+        if q.shape[0] and self.cfg.strand == L.STRAND_CANONICAL:
+            q = self.ctx.canonical(self.cfg, q)                               # InputTransform of the canonical model
+        ranks = self.ctx.key_to_rank(self.cfg, q, self.world) if q.shape[0] else np.zeros(0, np.uint32)
+        order = np.argsort(ranks, kind="stable")
+        counts = np.bincount(ranks, minlength=self.world).tolist()
+        recv, recv_counts = self._exchange_host(torch.from_numpy(q[order].view(np.int64)), counts)
+        return recv.numpy().view(np.uint64), recv_counts
+
+    def _exchange_host(self, send, counts):
+        """exchange_keys for host tensors: as they are over gloo, through the device over RCCL"""
+        if self.stage or dist.get_backend(self.group) == "gloo":
+            return exchange_keys(send, counts, self.group)
+        recv, rc = exchange_keys(send.to(self.device), counts, self.group)
+        return recv.cpu(), rc
+
+    def _answer(self, fn, q):
+        """fn(keys) -> (keys, values) on the local index; returns this rank's (keys, values) for its own query keys"""
+        import numpy as np
+        mine, recv_counts = self._route_queries(q)
+        out_k, out_v, back = [], [], []
+        off = 0
+        for src in range(self.world):                                         # answers go back to the rank that asked
+            seg = mine[off:off + recv_counts[src]]
+            off += recv_counts[src]
+            k, v = fn(seg) if seg.shape[0] else (np.zeros((0, self.n_words), np.uint64), np.zeros(0, np.uint64))
+            out_k.append(k); out_v.append(np.asarray(v, dtype=np.uint64)); back.append(k.shape[0])
+        sk = torch.from_numpy(np.concatenate(out_k).reshape(-1, self.n_words).view(np.int64))
+        sv = torch.from_numpy(np.concatenate(out_v).reshape(-1, 1).view(np.int64))
+        rk, rc = self._exchange_host(sk, back)
+        rv, _ = self._exchange_host(sv, back)
+        return rk.numpy().view(np.uint64), rv.numpy().view(np.uint64)[:, 0]
+
+    def count(self, q):
+        """one (key, count) per distinct transformed query key of THIS rank's query (0 when absent), as the reference returns"""
+        return self._answer(self.index.count, q)
+
+    def find(self, q):
+        return self._answer(self.index.find, q)
+
+    def erase(self, q):
+        mine, _ = self._route_queries(q)
+        n = self.index.erase(mine) if mine.shape[0] else 0
+        return global_size(n, self.group, None if self.stage else self.device)
+
     def clear(self):
         self.index.clear()
 
@@ -138,6 +188,78 @@ class DistributedCountIndex:
     def close(self):
         self.index.close()
         self.scratch.close()
+
+
+class DistributedPositionIndex(DistributedCountIndex):
+    """PositionIndex / PositionQualityIndex over all ranks (Index<unordered_multimap>::build_* + insert with comm.size() > 1,
+    kmer_index.hpp:148-225, distributed_unordered_map.hpp:1466-1515): every (k-mer, value) tuple is kept, so nothing can be
+    combined before the exchange -- the tuples of this rank's partition are parsed on the device, transformed, routed by
+    KeyToRank, exchanged as records (key words, value words) and inserted by their owners. Host-level orchestration
+    (numpy records); count / find / erase are the routed queries of the base class."""
+
+    def __init__(self, ctx, cfg, group=None, stage_through_host=False, device=None):
+        from .core import PositionIndex
+        self.ctx, self.cfg, self.group, self.stage, self.device = ctx, cfg, group, stage_through_host, device
+        self.world = dist.get_world_size(group)
+        self.index = PositionIndex(ctx, cfg)
+        self.scratch = None
+        self.n_words, self.value_words = self.index.n_words, self.index.value_words
+        self._cap = 0
+
+    def build(self, data, file_offset=0):
+        """adds the tuples of this rank's record-aligned partition (host bytes; file_offset = its offset in the file)"""
+        import numpy as np
+        from . import _lib as L
+        quals = self.value_words == 2
+        out = self.ctx.read_file(self.cfg, data, file_offset=file_offset, with_ids=True, with_quals=quals)
+        kmers, ids = out[0], out[1]
+        vals = ids.reshape(-1, 1)
+        if quals:                                                             # (id, float bits) as two 64-bit words
+            vals = np.concatenate([vals, out[2].view(np.uint32).astype(np.uint64).reshape(-1, 1)], axis=1)
+        if kmers.shape[0] and self.cfg.strand == L.STRAND_CANONICAL:
+            kmers = self.ctx.canonical(self.cfg, kmers)                       # transform_input before distribute
+        ranks = self.ctx.key_to_rank(self.cfg, kmers, self.world) if kmers.shape[0] else np.zeros(0, np.uint32)
+        order = np.argsort(ranks, kind="stable")
+        rec = np.concatenate([kmers, vals], axis=1)[order]
+        recv, _ = self._exchange_host(torch.from_numpy(np.ascontiguousarray(rec).view(np.int64)), np.bincount(ranks, minlength=self.world).tolist())
+        recv = recv.numpy().view(np.uint64)
+        if recv.shape[0]:
+            self.index.insert(np.ascontiguousarray(recv[:, :self.n_words]), np.ascontiguousarray(recv[:, self.n_words:]))
+
+    def build_device(self, *a, **kw):
+        raise NotImplementedError("DistributedPositionIndex.build takes the partition's host bytes")
+
+    def _answer(self, fn, q):
+        """multimap answers carry value_words words per hit"""
+        import numpy as np
+        mine, recv_counts = self._route_queries(q)
+        out, back = [], []
+        off = 0
+        for src in range(self.world):
+            seg = mine[off:off + recv_counts[src]]
+            off += recv_counts[src]
+            if seg.shape[0]:
+                k, v = fn(seg)
+                v = np.asarray(v, dtype=np.uint64).reshape(k.shape[0], -1)
+            else:
+                k, v = np.zeros((0, self.n_words), np.uint64), np.zeros((0, 1), np.uint64)
+            out.append(np.concatenate([k, v], axis=1) if k.shape[0] else np.zeros((0, self.n_words + v.shape[1]), np.uint64))
+            back.append(k.shape[0])
+        width = max(o.shape[1] for o in out)
+        width = int(global_max(width, self.group, None if self.stage else self.device))
+        rec = np.concatenate([np.pad(o, ((0, 0), (0, width - o.shape[1]))) for o in out])
+        r, _ = self._exchange_host(torch.from_numpy(np.ascontiguousarray(rec).view(np.int64)), back)
+        r = r.numpy().view(np.uint64)
+        return r[:, :self.n_words], r[:, self.n_words:]
+
+    def close(self):
+        self.index.close()
+
+
+def global_max(value, group=None, device=None):
+    t = torch.tensor([int(value)], dtype=torch.int64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return int(t.item())
 
 
 def global_size(local_size, group=None, device=None):

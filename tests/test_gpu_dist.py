@@ -41,7 +41,18 @@ def _worker(rank, world, port, data, k, strand, ret):
             d = torch.from_numpy(np.concatenate([buf, np.zeros(pad, np.uint8)])).to(dev)
             didx.build_device(d.data_ptr(), buf.size, dev)
         keys, cnts = didx.index.to_vector()
-        ret[rank] = (keys.copy(), cnts.copy(), didx.size())
+        # distributed queries: every rank asks for its own mix of present / absent keys
+        rng = np.random.default_rng(100 + rank)
+        s = orc.kspec(k)
+        present = orc.extract(s, data, orc.FASTQ)["kmers"][rng.integers(0, 1000, size=300)]
+        absent = rng.integers(0, 1 << (2 * k), size=(200, 1), dtype=np.uint64)
+        q = np.concatenate([present, absent])
+        ck, cv = didx.count(q)
+        fk, fv = didx.find(q)
+        size_before = didx.size()
+        ret[rank] = (keys.copy(), cnts.copy(), size_before, q.copy(), ck.copy(), cv.copy(), fk.copy(), fv.copy())
+        didx.erase(present[:50])
+        ret[rank] = ret[rank] + (didx.size(),)
         didx.close()
         ctx.close()
     finally:
@@ -65,6 +76,79 @@ def test_distributed_count_index_two_ranks_one_gpu(k, strand):
     cnts = np.concatenate([ret[r][1] for r in range(world)])
     a, b = orc.sorted_pairs(keys, cnts), orc.sorted_pairs(rk, rc)
     assert a[0].shape == b[0].shape and (a[0] == b[0]).all() and (a[1] == b[1]).all()
+    erased = set()
     for r in range(world):
         assert ret[r][2] == ref.size()
         assert (orc.key_to_rank(s, orc.MURMUR, st, ret[r][0], world) == r).all()
+        # count / find of rank r's own queries against the single-rank map
+        q = ret[r][3]
+        ek, ec = ref.count(q)
+        a, b = orc.sorted_pairs(ret[r][4], ret[r][5]), orc.sorted_pairs(ek, ec)
+        assert a[0].shape == b[0].shape and (a[0] == b[0]).all() and (a[1] == b[1]).all()
+        ek, ev = ref.find(q)
+        a, b = orc.sorted_pairs(ret[r][6], ret[r][7]), orc.sorted_pairs(ek, ev)
+        assert a[0].shape == b[0].shape and (a[0] == b[0]).all() and (a[1] == b[1]).all()
+        tq = q[:50] if strand == "single" else orc.canonical(s, q[:50])
+        erased |= set(int(x) for x in tq[:, 0])
+    assert all(ret[r][8] == ref.size() - len(erased) for r in range(world))
+
+
+def _pos_worker(rank, world, port, data, k, kind, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import torch
+        import kmerind_amd as K
+        from kmerind_amd import dist as kdist
+        from kmerind_amd import fileio
+        ctx = K.Context(0, rank=rank, nranks=world)
+        cfg = K.make_config(k, "DNA", strand="canonical", index_kind=kind)
+        didx = kdist.DistributedPositionIndex(ctx, cfg, stage_through_host=True, device=torch.device("cuda", 0))
+        b, e = fileio.partition_fastq(data, world)[rank]
+        didx.build(data[b:e], file_offset=b)
+        keys, vals = didx.index.to_vector()
+        s = orc.kspec(k)
+        q = orc.extract(s, data, orc.FASTQ)["kmers"][np.random.default_rng(rank).integers(0, 2000, size=150)]
+        ck, cv = didx.count(q)
+        fk, fv = didx.find(q)
+        ret[rank] = (keys.copy(), vals.copy(), didx.size(), q.copy(), ck.copy(), cv.copy(), fk.copy(), fv.copy())
+        didx.close()
+        ctx.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("kind,vw", [("position", 1), ("posqual", 2)])
+def test_distributed_position_index_two_ranks_one_gpu(kind, vw):
+    """every (k-mer, id[, quality]) tuple of the file lands on the rank KeyToRank names, with the id the single-rank parse
+    gives it (file offsets survive the partitioning); routed count / find agree with the oracle's multimap"""
+    import kmerind_amd as K
+    world, k = 2, 21
+    data = bytes(K.synth_fastq(seed=17, genome_len=20_000, n_reads=1_500))
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_pos_worker, args=(world, _free_port(), data, k, kind, ret), nprocs=world, join=True)
+    s = orc.kspec(k)
+    ex = orc.extract(s, data, orc.FASTQ, want_ids=True, want_quals=(vw == 2))
+    vals = ex["ids"].reshape(-1, 1)
+    if vw == 2:
+        vals = np.concatenate([vals, ex["quals"].view(np.uint32).astype(np.uint64).reshape(-1, 1)], axis=1)
+    ref = orc.MultiMap(s, orc.CANONICAL, vw)
+    ref.insert(ex["kmers"], vals)
+    rk, rv = ref.export()
+
+    def canon(keys, v):
+        rows = np.concatenate([keys, v.reshape(keys.shape[0], -1)], axis=1)
+        return rows[np.lexsort([rows[:, c] for c in range(rows.shape[1] - 1, -1, -1)])]
+
+    got = canon(np.concatenate([ret[r][0] for r in range(world)]), np.concatenate([ret[r][1] for r in range(world)]))
+    assert got.shape == canon(rk, rv).shape and (got == canon(rk, rv)).all()
+    for r in range(world):
+        assert ret[r][2] == ref.size()
+        assert (orc.key_to_rank(s, orc.MURMUR, orc.CANONICAL, ret[r][0], world) == r).all()
+        q = ret[r][3]
+        ek, ec = ref.count(q)
+        a, b = orc.sorted_pairs(ret[r][4], ret[r][5][:, 0]), orc.sorted_pairs(ek, ec)
+        assert a[0].shape == b[0].shape and (a[0] == b[0]).all() and (a[1] == b[1]).all()
+        ek, ev = ref.find(q)
+        assert (canon(ret[r][6], ret[r][7][:, :vw]) == canon(ek, ev)).all()
