@@ -829,10 +829,11 @@ static kmi_status extract_run_impl(kmi_ctx *ctx, const kmi_config *cfg, const ui
 
 template <int NW, int BITS>
 static kmi_status fastq_scan_impl(kmi_ctx *ctx, const uint8_t *bytes_dev, size_t n_bytes, KShape shape, FastqScan *out, bool check_lengths,
-                                  bool rna) {
+                                  bool rna, uint32_t seq_filter) {
   ScanResult r;
   KMI_HIP(ctx, hipMemsetAsync(ctx->d_flags, 0, sizeof(uint32_t) * 16, ctx->stream));
-  KMI_TRY((scan_impl<NW, BITS>(ctx, bytes_dev, n_bytes, shape, &r, false, check_lengths, KMI_SEQ_ALL, rna)));
+  KMI_TRY((scan_impl<NW, BITS>(ctx, bytes_dev, n_bytes, shape, &r, false, check_lengths, seq_filter, rna)));
+  out->pk_brk = r.packed.brk;
   out->n_tiles = r.n_tiles; out->line_base = r.line_base; out->tile_off = r.out_off;
   out->pk_eol = r.packed.eol; out->pk_stream = r.packed.stream; out->n_bytes = r.packed.n_bytes; out->n_cover = r.packed.n_cover;
   return read_totals(ctx, &out->n_tuples, &out->n_seqs);
@@ -854,8 +855,7 @@ kmi_status fastq_scan(kmi_ctx *ctx, const kmi_config *cfg, const uint8_t *bytes_
   KShape shape;
   if (!valid_config(cfg, &shape)) return set_err(ctx, KMI_ERR_INVALID, "bad kmi_config");
   if (cfg->seq_format != KMI_FMT_FASTQ) return set_err(ctx, KMI_ERR_INVALID, "only FASTQ is implemented on the device yet");
-  if (cfg->seq_filter != KMI_SEQ_ALL) return set_err(ctx, KMI_ERR_INVALID, "the fused FASTQ passes run without a sequence filter (use the extract path)");
-  KMI_DISPATCH(shape, fastq_scan_impl, ctx, bytes_dev, n_bytes, shape, out, check_lengths, is_rna(cfg));
+  KMI_DISPATCH(shape, fastq_scan_impl, ctx, bytes_dev, n_bytes, shape, out, check_lengths, is_rna(cfg), cfg->seq_filter);
 }
 
 // ---- FASTA: byte-space scan + compaction (kmi_fasta.hip), then count / extract over the compacted stream

@@ -556,10 +556,13 @@ template <int NW, int BITS> struct ListPassCfg {
   static constexpr int CAP = 512;                              // lines per window on the dense path
   static_assert(WIN % kWave == 0 && WIN * 32 < 65536 && CTX * 32 >= Cfg::KMAX, "window geometry");
   // a run needs a record of >= k + 7 bytes
-  static uint32_t max_runs(uint32_t k) { return (uint32_t)TILE / (k + 7u) + 2u; }
+  // (with a sequence filter the runs are cut at break bytes: a piece needs k bytes and one break)
+  static uint32_t max_runs(uint32_t k, bool split = false) { return (uint32_t)TILE / (k + (split ? 1u : 7u)) + 2u; }
   // entry list: one 16-bit entry per run of up to 8 consecutive windows; per-tile slots of this many entries
-  static uint32_t ent_stride(uint32_t k) { return (uint32_t)TILE / 8u + max_runs(k); }
-  static uint32_t wave_lds_bytes(uint32_t k) { return (4u * WIN + 4u * CAP + 4u * max_runs(k) + 15u) & ~15u; }
+  static uint32_t ent_stride(uint32_t k, bool split = false) { return (uint32_t)TILE / 8u + max_runs(k, split); }
+  static uint32_t wave_lds_bytes(uint32_t k, bool split = false) {   // bitmap window, event arrays, run table (two with a filter)
+    return (4u * WIN + 4u * CAP + 4u * max_runs(k, split) * (split ? 2u : 1u) + 15u) & ~15u;
+  }
 };
 
 template <int NW, int BITS>
@@ -567,6 +570,7 @@ __global__ __launch_bounds__(kListThreads) void fastq_list_kernel(PackedInput in
                                                                  uint32_t wave_lds_bytes, const uint32_t *__restrict__ line_base,
                                                                  uint32_t *__restrict__ flags, uint16_t *__restrict__ ent,
                                                                  uint32_t *__restrict__ ent_cnt, uint32_t ent_stride) {
+  // in.brk (sequence filters): the runs are cut where a break bit (an N by the filter's rule) falls inside them
   using P = ListPassCfg<NW, BITS>;
   constexpr int TILE = P::TILE, WORDS = P::WORDS, CTX = P::CTX, WIN = P::WIN, WPL = P::WPL, CAP = P::CAP;
   constexpr uint32_t T0 = CTX * 32u, T1 = T0 + (uint32_t)TILE, NONE = 0xffff0000u;   // tile proper in window positions
@@ -733,11 +737,49 @@ __global__ __launch_bounds__(kListThreads) void fastq_list_kernel(PackedInput in
       }
     }
     wave_sync();   // run table complete
+    const uint32_t *runs = s_run;
+    if (in.brk) {   // uniform
+      // every lane cuts its runs into the pieces that hold no break byte; counted, ranked with a wave scan, then written
+      const uint32_t *brkw = reinterpret_cast<const uint32_t *>(in.brk);
+      uint32_t *s_run2 = s_run + max_runs;
+      const uint64_t tile0 = t * (uint64_t)TILE;
+      // first position >= p whose break bit equals `set` (past the bitmap everything is a break)
+      auto next_bit = [&](uint64_t p, bool set) -> uint64_t {
+        uint64_t wi = p >> 5;
+        if (wi >= n_words) return set ? p : n_words * 32;
+        uint32_t bits = (set ? brkw[wi] : ~brkw[wi]) & (0xffffffffu << (p & 31u));
+        while (bits == 0u) { if (++wi >= n_words) return n_words * 32; bits = set ? brkw[wi] : ~brkw[wi]; }
+        return wi * 32 + (uint32_t)__builtin_ctz(bits);
+      };
+      auto pieces = [&](uint32_t run, auto f) {   // f(first window (tile position), windows)
+        const uint64_t lo = tile0 + (run & 0xffffu), hi = lo + (run >> 16) + k - 1u;
+        for (uint64_t p = lo; p < hi;) {
+          const uint64_t a = next_bit(p, false);
+          if (a >= hi) break;
+          uint64_t b = next_bit(a, true);
+          b = b < hi ? b : hi;
+          if (b - a >= k) f((uint32_t)(a - tile0), (uint32_t)(b - a - k + 1u));
+          p = b;
+        }
+      };
+      uint32_t n2 = 0;
+      for (uint32_t r0 = 0; r0 < n_runs; r0 += kWave) {
+        const uint32_t run = (r0 + lane < n_runs) ? s_run[r0 + lane] : 0u;
+        uint32_t mine = 0;
+        if (run) pieces(run, [&](uint32_t, uint32_t) { ++mine; });
+        const uint32_t inc = wave_inclusive_scan(mine);
+        uint32_t o = n2 + inc - mine;
+        if (run) pieces(run, [&](uint32_t first, uint32_t c) { s_run2[o++] = first | (c << 16); });
+        n2 += __shfl(inc, kWave - 1, kWave);
+      }
+      wave_sync();
+      runs = s_run2; n_runs = n2;
+    }
     uint32_t ebase = 0;   // entries of this tile so far
     uint16_t *etile = ent + (uint64_t)t * ent_stride;
     for (uint32_t r0 = 0; r0 < n_runs; r0 += kWave) {
       const uint32_t nr = (n_runs - r0 < (uint32_t)kWave) ? n_runs - r0 : (uint32_t)kWave;
-      const uint32_t my_sc = (lane < nr) ? s_run[r0 + lane] : 0u;
+      const uint32_t my_sc = (lane < nr) ? runs[r0 + lane] : 0u;
       // entry list: a run of c windows = ceil(c / 8) entries (position | (windows - 1) << 13); 16 lanes per run
       const uint32_t my_ne = ((my_sc >> 16) + 7u) >> 3;
       const uint32_t einc = wave_inclusive_scan(my_ne);
@@ -1985,14 +2027,15 @@ static kmi_status build_fused_impl(kmi_index *idx, const uint8_t *bytes_dev, siz
   KMI_TRY(fastq_scan(ctx, &idx->cfg, bytes_dev, n_bytes, &sc, false));   // reports malformed FASTQ (the length rule rides on the list pass)
   const uint64_t n = sc.n_tuples, n_tiles = sc.n_tiles;
   if (n == 0) return KMI_OK;
-  PackedInput in; in.eol = sc.pk_eol; in.stream = sc.pk_stream; in.n_bytes = sc.n_bytes; in.n_cover = sc.n_cover; in.n_valid = sc.n_bytes;
+  PackedInput in; in.eol = sc.pk_eol; in.stream = sc.pk_stream; in.n_bytes = sc.n_bytes; in.n_cover = sc.n_cover; in.n_valid = sc.n_bytes; in.brk = sc.pk_brk;
+  const bool split = sc.pk_brk != nullptr;   // a sequence filter cuts the runs: more, shorter runs per tile
   const uint32_t *line_base = sc.line_base;
   const bool canonical = idx->cfg.strand != KMI_STRAND_SINGLE;
   PartWs w;
   KMI_TRY(get_part_ws(ctx, n, NW, WS_KEYS_A, WS_KEYS_B, &w));
   void *pl;
   using LPC = ListPassCfg<NW, BITS>;
-  KMI_TRY(ws_get(ctx, WS_ENT_LIST, sizeof(uint16_t) * ((size_t)n_tiles * LPC::ent_stride(idx->shape.k) + 64), &pl));
+  KMI_TRY(ws_get(ctx, WS_ENT_LIST, sizeof(uint16_t) * ((size_t)n_tiles * LPC::ent_stride(idx->shape.k, split) + 64), &pl));
   uint16_t *ent = (uint16_t *)pl;
   KMI_TRY(ws_get(ctx, WS_ENT_CNT, sizeof(uint32_t) * (n_tiles + 8), &pl));
   uint32_t *ent_cnt = (uint32_t *)pl;
@@ -2000,15 +2043,15 @@ static kmi_status build_fused_impl(kmi_index *idx, const uint8_t *bytes_dev, siz
   {
     ProfScope ps(ctx, "fastq_list", n);
     using LP = ListPassCfg<NW, BITS>;
-    const uint32_t wave_lds = LP::wave_lds_bytes(idx->shape.k);
+    const uint32_t wave_lds = LP::wave_lds_bytes(idx->shape.k, split);
     hipLaunchKernelGGL((fastq_list_kernel<NW, BITS>), dim3(kListGroups), dim3(kListThreads), wave_lds * (kListThreads / kWave), ctx->stream, in,
-                       n_tiles, idx->shape.k, LP::max_runs(idx->shape.k), wave_lds, line_base, ctx->d_flags, ent, ent_cnt,
-                       LP::ent_stride(idx->shape.k));
+                       n_tiles, idx->shape.k, LP::max_runs(idx->shape.k, split), wave_lds, line_base, ctx->d_flags, ent, ent_cnt,
+                       LP::ent_stride(idx->shape.k, split));
   }
   {
     ProfScope ps(ctx, "fastq_hist", n);
     hipLaunchKernelGGL((fastq_hist_list_kernel<NW, BITS>), dim3(fused_groups<NW>()), dim3(kHistThreads), 0, ctx->stream, in, n_tiles, idx->shape,
-                       canonical, (const uint16_t *)ent, (const uint32_t *)ent_cnt, LPC::ent_stride(idx->shape.k), w.fine_hist, w.wg_hist);
+                       canonical, (const uint16_t *)ent, (const uint32_t *)ent_cnt, LPC::ent_stride(idx->shape.k, split), w.fine_hist, w.wg_hist);
   }
   {
     ProfScope ps(ctx, "fine_offsets", kNumFine);
@@ -2020,7 +2063,7 @@ static kmi_status build_fused_impl(kmi_index *idx, const uint8_t *bytes_dev, siz
   {
     ProfScope ps(ctx, "fastq_scatter", n);
     hipLaunchKernelGGL((fastq_scatter_list_kernel<NW, BITS>), dim3(fused_groups<NW>()), dim3(ExCfg<NW, BITS>::NT), 0, ctx->stream, in,
-                       n_tiles, idx->shape, canonical, (const uint16_t *)ent, (const uint32_t *)ent_cnt, LPC::ent_stride(idx->shape.k),
+                       n_tiles, idx->shape, canonical, (const uint16_t *)ent, (const uint32_t *)ent_cnt, LPC::ent_stride(idx->shape.k, split),
                        (const uint64_t *)nullptr, (const uint64_t *)w.wg_off, w.buf_a);
   }
   {
@@ -2261,16 +2304,17 @@ static kmi_status extract_route_impl(kmi_ctx *ctx, const kmi_config *cfg, KShape
   const uint64_t n = sc.n_tuples, n_tiles = sc.n_tiles;
   if (n == 0) return KMI_OK;
   if (n > capacity) return set_err(ctx, KMI_ERR_OVERFLOW, "extract_route: output capacity too small");
-  PackedInput in; in.eol = sc.pk_eol; in.stream = sc.pk_stream; in.n_bytes = sc.n_bytes; in.n_cover = sc.n_cover; in.n_valid = sc.n_bytes;
+  PackedInput in; in.eol = sc.pk_eol; in.stream = sc.pk_stream; in.n_bytes = sc.n_bytes; in.n_cover = sc.n_cover; in.n_valid = sc.n_bytes; in.brk = sc.pk_brk;
+  const bool split = sc.pk_brk != nullptr;
   const bool canonical = cfg->strand != KMI_STRAND_SINGLE;
   void *p;
   KMI_TRY(ws_get(ctx, WS_WGHIST, sizeof(uint32_t) * kPartGroups * kNumCoarse, &p)); uint32_t *wg_hist = (uint32_t *)p;
   KMI_TRY(ws_get(ctx, WS_CURSOR, sizeof(uint64_t) * kPartGroups * kNumCoarse, &p)); uint64_t *wg_off = (uint64_t *)p;
   KMI_TRY(ws_get(ctx, WS_MISC, sizeof(uint64_t) * kNumCoarse * 2, &p)); uint64_t *cnt = (uint64_t *)p;
   using LPC = ListPassCfg<NW, BITS>;
-  KMI_TRY(ws_get(ctx, WS_ENT_LIST, sizeof(uint16_t) * ((size_t)n_tiles * LPC::ent_stride(shape.k) + 64), &p)); uint16_t *ent = (uint16_t *)p;
+  KMI_TRY(ws_get(ctx, WS_ENT_LIST, sizeof(uint16_t) * ((size_t)n_tiles * LPC::ent_stride(shape.k, split) + 64), &p)); uint16_t *ent = (uint16_t *)p;
   KMI_TRY(ws_get(ctx, WS_ENT_CNT, sizeof(uint32_t) * (n_tiles + 8), &p)); uint32_t *ent_cnt = (uint32_t *)p;
-  KMI_TRY(ws_get(ctx, WS_ENT_BKT, sizeof(uint64_t) * ((size_t)n_tiles * ListPassCfg<NW, BITS>::ent_stride(shape.k) + 64), &p));
+  KMI_TRY(ws_get(ctx, WS_ENT_BKT, sizeof(uint64_t) * ((size_t)n_tiles * ListPassCfg<NW, BITS>::ent_stride(shape.k, split) + 64), &p));
   uint64_t *ent_bkt = (uint64_t *)p;
   BucketFn fn; fn.mode = BUCKET_RANK; fn.shape = shape; fn.dist_hash = cfg->dist_hash; fn.farm_ndebug = cfg->farm_ndebug != 0; fn.nranks = nranks;
   fn.dist_trans = cfg->dist_trans;
@@ -2279,15 +2323,15 @@ static kmi_status extract_route_impl(kmi_ctx *ctx, const kmi_config *cfg, KShape
   {
     ProfScope ps(ctx, "fastq_list", n);
     using LP = ListPassCfg<NW, BITS>;
-    const uint32_t wave_lds = LP::wave_lds_bytes(shape.k);
+    const uint32_t wave_lds = LP::wave_lds_bytes(shape.k, split);
     hipLaunchKernelGGL((fastq_list_kernel<NW, BITS>), dim3(kListGroups), dim3(kListThreads), wave_lds * (kListThreads / kWave), ctx->stream, in,
-                       n_tiles, shape.k, LP::max_runs(shape.k), wave_lds, sc.line_base, ctx->d_flags, ent, ent_cnt,
-                       LP::ent_stride(shape.k));
+                       n_tiles, shape.k, LP::max_runs(shape.k, split), wave_lds, sc.line_base, ctx->d_flags, ent, ent_cnt,
+                       LP::ent_stride(shape.k, split));
   }
   {
     ProfScope ps(ctx, "fastq_rank_hist", n);
     hipLaunchKernelGGL((fastq_rank_hist_list_kernel<NW, BITS, 512>), dim3(fused_groups<NW>()), dim3(512), 0, ctx->stream, in, n_tiles, shape, canonical,
-                       (const uint16_t *)ent, (const uint32_t *)ent_cnt, LPC::ent_stride(shape.k), fn, wg_hist, ent_bkt);
+                       (const uint16_t *)ent, (const uint32_t *)ent_cnt, LPC::ent_stride(shape.k, split), fn, wg_hist, ent_bkt);
   }
   {
     ProfScope ps(ctx, "rank_offsets", nb);
@@ -2296,7 +2340,7 @@ static kmi_status extract_route_impl(kmi_ctx *ctx, const kmi_config *cfg, KShape
   {
     ProfScope ps(ctx, "fastq_rank_scatter", n);
     hipLaunchKernelGGL((fastq_scatter_list_kernel<NW, BITS, true>), dim3(fused_groups<NW>()), dim3(ExCfg<NW, BITS>::NT), 0, ctx->stream, in, n_tiles,
-                       shape, canonical, (const uint16_t *)ent, (const uint32_t *)ent_cnt, LPC::ent_stride(shape.k), (const uint64_t *)ent_bkt,
+                       shape, canonical, (const uint16_t *)ent, (const uint32_t *)ent_cnt, LPC::ent_stride(shape.k, split), (const uint64_t *)ent_bkt,
                        (const uint64_t *)wg_off, out_keys_dev);
   }
   KMI_HIP(ctx, hipGetLastError());
@@ -2488,10 +2532,9 @@ kmi_status kmi_index_build_dev(kmi_index *idx, const uint8_t *bytes_dev, size_t 
   kmi_ctx *ctx = idx->ctx;
   KMI_HIP(ctx, hipSetDevice(ctx->device));
   if (n_bytes == 0) return KMI_OK;
-  if (idx->val_words == 0 && idx->cfg.seq_format == KMI_FMT_FASTQ && idx->cfg.seq_filter == KMI_SEQ_ALL)
-    return index_build_fused(idx, bytes_dev, n_bytes);
+  if (idx->val_words == 0 && idx->cfg.seq_format == KMI_FMT_FASTQ) return index_build_fused(idx, bytes_dev, n_bytes);
   if (idx->val_words == 0) {
-    // FASTA count index, or FASTQ with a sequence filter: tuples from the extract path, then the key insert path
+    // FASTA count index: tuples from the compacted-stream extract, then the key insert path
     uint64_t nt = 0, ns = 0;
     KMI_TRY(extract_count(ctx, &idx->cfg, bytes_dev, n_bytes, &nt, &ns));
     if (nt == 0) return KMI_OK;

@@ -194,6 +194,7 @@ struct FastqScan {
   const uint32_t *line_base;
   const uint64_t *tile_off;   // [n_tiles + 1] k-mer windows before each scan tile
   const uint8_t *pk_eol, *pk_stream;
+  const uint8_t *pk_brk;      // window-break bitmap of a sequence filter, or null
 };
 // check_lengths = false: the caller runs fastq_list_kernel, which carries the seq/qual length rule, and asks for
 // fastq_length_verdict afterwards

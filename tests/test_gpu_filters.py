@@ -92,6 +92,24 @@ def test_count_index_build_with_filter(ctx, flt):
         a, b = orc.sorted_pairs(gk, gc), orc.sorted_pairs(ek, ec)
         assert a[0].shape == b[0].shape and (a[0] == b[0]).all() and (a[1] == b[1]).all()
         idx.close()
+        # the fused extract + route of the occurrence-routing N > 1 path honours the filter too
+        import ctypes as C
+        from kmerind_amd import _lib as L
+        ex = orc.extract(s, data, orc.FASTQ, seq_filter=FILTERS[flt])["kmers"]
+        tk = ex if strand == "single" else orc.canonical(s, ex)
+        p = 4
+        buf = np.frombuffer(data, dtype=np.uint8)
+        dbytes, dout = ctx.alloc(buf.size + 64), ctx.alloc(tk.nbytes + 64)
+        ctx.to_device(dbytes, buf)
+        counts = np.zeros(p, dtype=np.uint64)
+        nt, ns = C.c_uint64(), C.c_uint64()
+        ctx.check(L.lib.kmi_extract_route_dev(ctx.h, C.byref(cfg), C.c_void_p(dbytes), buf.size, p, C.c_void_p(dout), tk.shape[0],
+                                              C.byref(nt), C.byref(ns), counts.ctypes.data_as(C.c_void_p)))
+        out = np.zeros_like(tk)
+        ctx.to_host(out, dout)
+        ctx.free(dbytes); ctx.free(dout)
+        assert nt.value == tk.shape[0] and int(counts.sum()) == tk.shape[0]
+        assert (np.sort(out[:, 0]) == np.sort(tk[:, 0])).all()
 
 
 @pytest.mark.parametrize("flt", ["n_split", "n_filter"])
