@@ -53,9 +53,10 @@ def main():
     ap.add_argument("--cpu-sample-reads", type=int, default=500_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the extract-only / insert-only / query rates (outside the timed steps)")
-    ap.add_argument("--dist-mode", default="combine", choices=["combine", "raw"],
+    ap.add_argument("--dist-mode", default="auto", choices=["auto", "combine", "raw"],
                     help="N > 1: 'combine' reduces the rank's own reads first and exchanges (k-mer, count) pairs; 'raw' routes "
-                         "every k-mer occurrence as the reference does (kmi_extract_route_dev + insert)")
+                         "every k-mer occurrence as the reference does (kmi_extract_route_dev + insert); 'auto' combines when the "
+                         "rank's own reads cover the genome at least 4 times (the pairs are then a fraction of the occurrences)")
     ap.add_argument("--force-dist", action="store_true",
                     help="run the N > 1 code path (routing + all_to_all_single + insert) even with one rank: exercises the RCCL calls on one GPU")
     ap.add_argument("--chunks", type=int, default=4, help="N > 1: chunks per step (exchange of one overlaps parsing of the next)")
@@ -106,7 +107,10 @@ def main():
     idx = K.CountIndex(ctx, cfg)
     n_kmers = n_reads * kmers_per_read
 
-    combine = multi and args.dist_mode == "combine"
+    # expected k-mer coverage of the genome by ONE rank's reads: what a local reduction can take out before the exchange
+    local_cov = n_kmers / float(genome_len)
+    dist_mode = args.dist_mode if args.dist_mode != "auto" else ("combine" if local_cov >= 4.0 else "raw")
+    combine = multi and dist_mode == "combine"
     nch = 1
     if combine:
         # N > 1, combine-first (kmerind_amd.dist.DistributedCountIndex): local count index of the rank's reads (the one-rank
@@ -173,7 +177,7 @@ def main():
             pos += n_in
         for w in works[-2:]:
             w.wait()
-        idx.insert_device(d_recv.data_ptr(), pos)
+        idx.insert_device(d_recv.data_ptr(), pos, transformed=True)      # routed keys are already canonical
 
     def sync():
         torch.cuda.synchronize(dev)

@@ -183,6 +183,9 @@ kmi_status kmi_index_destroy(kmi_index *idx);
  * belong to this rank when nranks > 1 (i.e. after the exchange). */
 kmi_status kmi_index_insert_host(kmi_index *idx, const uint64_t *kmers, size_t n);
 kmi_status kmi_index_insert_dev(kmi_index *idx, const uint64_t *kmers_dev, size_t n);
+/* the local_insert half alone (distributed_unordered_map.hpp:1734-1741): keys that already went through the
+ * InputTransform -- what kmi_route_dev / kmi_extract_route_dev produce and the exchange delivers -- are reduced as they are */
+kmi_status kmi_index_insert_transformed_dev(kmi_index *idx, const uint64_t *kmers_dev, size_t n);
 /* Index::build_mmap/build_posix for nranks == 1: read_file + insert fused on the
  * device (kmer_index.hpp:239-372). */
 kmi_status kmi_index_build_host(kmi_index *idx, const uint8_t *bytes, size_t n_bytes, uint64_t file_offset);

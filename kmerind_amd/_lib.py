@@ -85,6 +85,7 @@ SIGNATURES = {
     "kmi_index_destroy": (C.c_int, [_P]),
     "kmi_index_insert_host": (C.c_int, [_P, _P, _sz]),
     "kmi_index_insert_dev": (C.c_int, [_P, _P, _sz]),
+    "kmi_index_insert_transformed_dev": (C.c_int, [_P, _P, _sz]),
     "kmi_index_build_host": (C.c_int, [_P, _P, _sz, _u64]),
     "kmi_index_build_dev": (C.c_int, [_P, _P, _sz, _u64]),
     "kmi_index_clear": (C.c_int, [_P]),

@@ -202,8 +202,10 @@ class CountIndex:
         kmers = _u64(kmers, self.n_words)
         self.ctx.check(lib.kmi_index_insert_host(self.h, kmers.ctypes.data_as(C.c_void_p), kmers.shape[0]))
 
-    def insert_device(self, dptr, n):
-        self.ctx.check(lib.kmi_index_insert_dev(self.h, C.c_void_p(dptr), n))
+    def insert_device(self, dptr, n, transformed=False):
+        """transformed=True: the keys already went through the InputTransform (routed keys after the exchange)"""
+        fn = lib.kmi_index_insert_transformed_dev if transformed else lib.kmi_index_insert_dev
+        self.ctx.check(fn(self.h, C.c_void_p(dptr), n))
 
     def build(self, data, file_offset=0):
         buf = np.frombuffer(bytes(data), dtype=np.uint8) if isinstance(data, (bytes, bytearray)) else \

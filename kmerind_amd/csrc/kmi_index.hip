@@ -2484,6 +2484,13 @@ kmi_status kmi_index_insert_dev(kmi_index *idx, const uint64_t *kmers_dev, size_
   return index_insert(idx, kmers_dev, n, true);
 }
 
+kmi_status kmi_index_insert_transformed_dev(kmi_index *idx, const uint64_t *kmers_dev, size_t n) {
+  if (!idx) return KMI_ERR_INVALID;
+  if (idx->val_words) return set_err(idx->ctx, KMI_ERR_INVALID, "a position index takes (k-mer, value) tuples: kmi_index_insert_tuples_*");
+  KMI_HIP(idx->ctx, hipSetDevice(idx->ctx->device));
+  return index_insert(idx, kmers_dev, n, false);
+}
+
 kmi_status kmi_index_insert_host(kmi_index *idx, const uint64_t *kmers, size_t n) {
   if (!idx) return KMI_ERR_INVALID;
   kmi_ctx *ctx = idx->ctx;
