@@ -80,6 +80,7 @@ using DNA5 = DNA6;  // alphabets.hpp:746-747
 struct RNA { static constexpr unsigned SIZE = 4; static constexpr unsigned BITS = 2; static constexpr uint32_t KMI = KMI_ALPHA_RNA; };
 struct RNA6 { static constexpr unsigned SIZE = 8; static constexpr unsigned BITS = 3; static constexpr uint32_t KMI = KMI_ALPHA_RNA5; };
 using RNA5 = RNA6;  // alphabets.hpp:748-750
+struct DNA16 { static constexpr unsigned SIZE = 16; static constexpr unsigned BITS = 4; static constexpr uint32_t KMI = KMI_ALPHA_DNA16; };
 
 template <typename A> struct AlphabetTraits {
   static constexpr unsigned getSize() { return A::SIZE; }

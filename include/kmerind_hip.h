@@ -48,7 +48,8 @@ typedef enum {
 } kmi_status;
 
 enum { KMI_ALPHA_DNA = 0, KMI_ALPHA_DNA5 = 1,                   /* alphabets.hpp:127-185, 212-285 (DNA5 == DNA6) */
-       KMI_ALPHA_RNA = 2, KMI_ALPHA_RNA5 = 3 };                 /* alphabets.hpp:365-445, 448-530 (RNA5 == RNA6): U for T */
+       KMI_ALPHA_RNA = 2, KMI_ALPHA_RNA5 = 3,                   /* alphabets.hpp:365-445, 448-530 (RNA5 == RNA6): U for T */
+       KMI_ALPHA_DNA16 = 4 };                                   /* alphabets.hpp:648-733: IUPAC, 4 bits, complement = bit reversal */
 enum { KMI_STRAND_SINGLE = 0, KMI_STRAND_CANONICAL = 1, KMI_STRAND_BIMOLECULE = 2 }; /* kmer_index.hpp:436-481 */
 enum { KMI_HASH_MURMUR = 0, KMI_HASH_FARM = 1,                  /* kmer_hash.hpp:242-311 */
        KMI_HASH_IDENTITY = 2, KMI_HASH_STD = 3 };               /* kmer_hash.hpp:205-230, 154-198 (cpp_std, libstdc++) */

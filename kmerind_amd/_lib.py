@@ -17,7 +17,7 @@ if not os.path.exists(LIB_PATH):
 lib = C.CDLL(LIB_PATH)
 
 OK, ERR_INVALID, ERR_DEVICE, ERR_PARSE, ERR_NOMEM, ERR_OVERFLOW = range(6)
-ALPHA_DNA, ALPHA_DNA5, ALPHA_RNA, ALPHA_RNA5 = 0, 1, 2, 3
+ALPHA_DNA, ALPHA_DNA5, ALPHA_RNA, ALPHA_RNA5, ALPHA_DNA16 = 0, 1, 2, 3, 4
 STRAND_SINGLE, STRAND_CANONICAL, STRAND_BIMOLECULE = 0, 1, 2
 HASH_MURMUR, HASH_FARM, HASH_IDENTITY, HASH_STD = 0, 1, 2, 3
 FMT_FASTQ, FMT_FASTA = 0, 1

@@ -16,7 +16,7 @@ lib = L.lib
 def make_config(k, alphabet="DNA", strand="canonical", dist_hash="murmur", store_hash="murmur",
                 index_kind="count", seq_format="fastq", farm_ndebug=False, seq_filter="all", dist_trans="model"):
     alpha = {"DNA": L.ALPHA_DNA, "DNA5": L.ALPHA_DNA5, "DNA6": L.ALPHA_DNA5,
-             "RNA": L.ALPHA_RNA, "RNA5": L.ALPHA_RNA5, "RNA6": L.ALPHA_RNA5}[alphabet]
+             "RNA": L.ALPHA_RNA, "RNA5": L.ALPHA_RNA5, "RNA6": L.ALPHA_RNA5, "DNA16": L.ALPHA_DNA16}[alphabet]
     st = {"single": L.STRAND_SINGLE, "canonical": L.STRAND_CANONICAL, "bimolecule": L.STRAND_BIMOLECULE}[strand]
     hs = {"murmur": L.HASH_MURMUR, "farm": L.HASH_FARM, "identity": L.HASH_IDENTITY, "std": L.HASH_STD}
     kind = {"count": L.INDEX_COUNT, "position": L.INDEX_POSITION, "posqual": L.INDEX_POSQUAL}[index_kind]

@@ -75,11 +75,22 @@ KMI_HD uint32_t code_dna5(uint32_t c) {
   r = ((c == '-') | (c == '.')) ? 0u : r;
   return r;
 }
-template <int BITS> KMI_HD uint32_t code_of(uint32_t c) { return BITS == 2 ? code_dna(c) : code_dna5(c); }
-// complement code: DNA 3-c (alphabets.hpp:172-178); DNA6 = 3-bit reversal (alphabets.hpp:197-210,262-272)
+// DNA16 (alphabets.hpp:648-733): IUPAC letters as presence bits A=1 C=2 G=4 T/U=8 (M=3 R=5 S=6 V=7 W=9 Y=A H=B K=C D=D
+// B=E), '-' and '.' = 0, everything else (N, X, ...) = F. Sixteen letters per 64-bit nibble table.
+KMI_HD uint32_t code_dna16(uint32_t c) {
+  const uint32_t i = (c & 0xDFu) - (uint32_t)'A';               // letter index, case folded
+  const uint64_t t = i < 16u ? 0xfff3fcffb4ffd2e1ull : 0xfaf978865full;
+  uint32_t r = i < 26u ? (uint32_t)(t >> (4u * (i & 15u))) & 15u : 15u;
+  r = ((c == '-') | (c == '.')) ? 0u : r;
+  return r;
+}
+template <int BITS> KMI_HD uint32_t code_of(uint32_t c) { return BITS == 2 ? code_dna(c) : (BITS == 3 ? code_dna5(c) : code_dna16(c)); }
+// complement code: DNA 3-c (alphabets.hpp:172-178); DNA6 = 3-bit reversal (alphabets.hpp:197-210,262-272); DNA16 = 4-bit
+// reversal (alphabets.hpp:706-729)
 template <int BITS> KMI_HD uint32_t comp_code(uint32_t code) {
   if (BITS == 2) return 3u - code;
-  return ((code & 1u) << 2) | (code & 2u) | ((code >> 2) & 1u);
+  if (BITS == 3) return ((code & 1u) << 2) | (code & 2u) | ((code >> 2) & 1u);
+  return ((code & 1u) << 3) | ((code & 2u) << 1) | ((code >> 1) & 2u) | ((code >> 3) & 1u);
 }
 
 // ---------------------------------------------------------------------------
@@ -359,7 +370,12 @@ template <int BITS> KMI_HD void classify_dword(uint32_t w, uint32_t &eol4, uint3
   eol4 = byte_msbs(zero_bytes(w ^ 0x0A0A0A0Au) | zero_bytes(w ^ 0x0D0D0D0Du));
   const uint32_t x = w & 0xDFDFDFDFu;                 // fold case
   const uint32_t idx = (x >> 1) & 0x07070707u;        // A->0 C->1 T->2 G->3 X->4 N->7
-  if (BITS == 2) {
+  if (BITS == 4) {   // DNA16: byte by byte (sixteen IUPAC letters; not a hot path)
+    uint32_t p = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) p |= comp_code<4>(code_dna16((w >> (8 * i)) & 0xffu)) << (4 * i);
+    packed = p;
+  } else if (BITS == 2) {
     // a byte is a base iff it equals the letter its index stands for
     const uint32_t expect = byte_perm(0xFFFFFFFFu, 0x47544341u, idx);            // 'A','C','T','G'
     const uint32_t ok = zero_bytes(x ^ expect);                                  // 0x80 per base byte

@@ -67,8 +67,10 @@ template <int C> __device__ __forceinline__ void store_eol_bits(uint32_t *s_eol,
 }
 
 template <int BITS, int C> __device__ __forceinline__ void store_stream_bits(uint32_t *s_stream, int chunk, uint64_t st) {
-  constexpr int NB = BITS * C / 8;  // bytes per chunk: 4, 6, 2 or 3
-  if constexpr (NB == 4) {
+  constexpr int NB = BITS * C / 8;  // bytes per chunk: 8, 4, 6, 2 or 3
+  if constexpr (NB == 8) {
+    s_stream[2 * chunk] = (uint32_t)st; s_stream[2 * chunk + 1] = (uint32_t)(st >> 32);
+  } else if constexpr (NB == 4) {
     s_stream[chunk] = (uint32_t)st;
   } else if constexpr (NB == 2) {
     reinterpret_cast<uint16_t *>(s_stream)[chunk] = (uint16_t)st;
@@ -124,7 +126,8 @@ template <int C> __device__ __forceinline__ void write_eol_unit(uint8_t *__restr
 }
 template <int BITS, int C> __device__ __forceinline__ uint64_t read_stream_unit(const uint8_t *__restrict__ pk, uint64_t g) {
   constexpr int NB = BITS * C / 8;
-  if constexpr (NB == 4) return reinterpret_cast<const uint32_t *>(pk)[g];
+  if constexpr (NB == 8) return reinterpret_cast<const uint64_t *>(pk)[g];
+  else if constexpr (NB == 4) return reinterpret_cast<const uint32_t *>(pk)[g];
   else if constexpr (NB == 2) return reinterpret_cast<const uint16_t *>(pk)[g];
   else if constexpr (NB == 6) {
     const uint16_t *p = reinterpret_cast<const uint16_t *>(pk) + 3 * g;

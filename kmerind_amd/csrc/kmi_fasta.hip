@@ -428,8 +428,12 @@ kmi_status fasta_scan(kmi_ctx *ctx, const kmi_config *cfg, const uint8_t *bytes_
       hipLaunchKernelGGL((fasta_compact_kernel<2>), dim3((unsigned)n_tiles), dim3(FaCfg::NT), 0, ctx->stream, bytes_dev, (uint64_t)n_bytes,
                          file_offset, index_shift, first_ls, valid_bytes, (const FaTileBase *)base, pk_stream, pk_break, ids, ctx->d_totals,
                          cfg->seq_filter == KMI_SEQ_N_SPLIT, rec_start, rec_flag, is_rna(cfg));
-    else
+    else if (shape.bits == 3)
       hipLaunchKernelGGL((fasta_compact_kernel<3>), dim3((unsigned)n_tiles), dim3(FaCfg::NT), 0, ctx->stream, bytes_dev, (uint64_t)n_bytes,
+                         file_offset, index_shift, first_ls, valid_bytes, (const FaTileBase *)base, pk_stream, pk_break, ids, ctx->d_totals,
+                         cfg->seq_filter == KMI_SEQ_N_SPLIT, rec_start, rec_flag, is_rna(cfg));
+    else
+      hipLaunchKernelGGL((fasta_compact_kernel<4>), dim3((unsigned)n_tiles), dim3(FaCfg::NT), 0, ctx->stream, bytes_dev, (uint64_t)n_bytes,
                          file_offset, index_shift, first_ls, valid_bytes, (const FaTileBase *)base, pk_stream, pk_break, ids, ctx->d_totals,
                          cfg->seq_filter == KMI_SEQ_N_SPLIT, rec_start, rec_flag, is_rna(cfg));
   }

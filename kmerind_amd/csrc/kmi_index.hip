@@ -77,7 +77,7 @@ template <int NW> __device__ __forceinline__ uint32_t bucket_of(const uint64_t (
     for (int w = 0; w < NW; ++w) t[w] = key[w];
     if (f.dist_trans) {   // uniform: DistTrans = lex_less / xor_rev_comp (kmer_transform.hpp:90-116, 60-88)
       uint64_t rc[NW];
-      if (f.shape.bits == 2) revcomp_words<NW, 2>(key, rc, f.shape); else revcomp_words<NW, 3>(key, rc, f.shape);
+      if (f.shape.bits == 2) revcomp_words<NW, 2>(key, rc, f.shape); else revcomp_words<NW, 3>(key, rc, f.shape);   // 3 and 4 bits: plain bit reversal
       const bool use_rc = f.dist_trans == KMI_DIST_LEX && less_words<NW>(rc, key);
 #pragma unroll
       for (int w = 0; w < NW; ++w) t[w] = f.dist_trans == KMI_DIST_XOR ? (key[w] ^ rc[w]) : (use_rc ? rc[w] : key[w]);
@@ -812,7 +812,7 @@ template <int NW, int BITS> struct ListCfg {
   static constexpr int NT = Cfg::NT;
   static constexpr int MAXQ = 61440 / (8 * NW * NT);       // windows per thread and round (scatter)
   static constexpr int CAPW = MAXQ * NT;                   // windows per round (stage capacity)
-  static constexpr int RMAX = (BITS == 3) ? 2 : 4;         // scan tiles per round (LDS image of their packed stream)
+  static constexpr int RMAX = (BITS >= 3) ? 2 : 4;         // scan tiles per round (LDS image of their packed stream)
   static constexpr int UNITS = RMAX * NT + Cfg::HALO_CHUNKS;
   static constexpr int STREAM_DW = (UNITS * Cfg::C * BITS + 31) / 32 + 2 * NW + 2;
   static constexpr int ULOADS = (UNITS + NT - 1) / NT;     // stream units per thread (scatter)

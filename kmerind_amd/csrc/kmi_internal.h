@@ -144,7 +144,7 @@ struct ProfScope {
 inline bool valid_config(const kmi_config *cfg, KShape *shape) {
   if (!cfg || cfg->k == 0) return false;
   uint32_t bits = (cfg->alphabet == KMI_ALPHA_DNA || cfg->alphabet == KMI_ALPHA_RNA) ? 2 :
-                  ((cfg->alphabet == KMI_ALPHA_DNA5 || cfg->alphabet == KMI_ALPHA_RNA5) ? 3 : 0);
+                  ((cfg->alphabet == KMI_ALPHA_DNA5 || cfg->alphabet == KMI_ALPHA_RNA5) ? 3 : (cfg->alphabet == KMI_ALPHA_DNA16 ? 4 : 0));
   if (!bits) return false;
   KShape s = make_shape(cfg->k, bits);
   if (s.n_words > (uint32_t)kMaxWords) return false;
@@ -169,12 +169,19 @@ inline bool is_rna(const kmi_config *cfg) { return cfg->alphabet == KMI_ALPHA_RN
         case 3: return FN<3, 2>(__VA_ARGS__);                                          \
         case 4: return FN<4, 2>(__VA_ARGS__);                                          \
       }                                                                                \
-    } else {                                                                           \
+    } else if ((shape).bits == 3) {                                                    \
       switch ((shape).n_words) {                                                       \
         case 1: return FN<1, 3>(__VA_ARGS__);                                          \
         case 2: return FN<2, 3>(__VA_ARGS__);                                          \
         case 3: return FN<3, 3>(__VA_ARGS__);                                          \
         case 4: return FN<4, 3>(__VA_ARGS__);                                          \
+      }                                                                                \
+    } else {                                                                           \
+      switch ((shape).n_words) {                                                       \
+        case 1: return FN<1, 4>(__VA_ARGS__);                                          \
+        case 2: return FN<2, 4>(__VA_ARGS__);                                          \
+        case 3: return FN<3, 4>(__VA_ARGS__);                                          \
+        case 4: return FN<4, 4>(__VA_ARGS__);                                          \
       }                                                                                \
     }                                                                                  \
     return KMI_ERR_INVALID;                                                            \

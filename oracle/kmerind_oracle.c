@@ -25,6 +25,7 @@ int orc_kspec_init(orc_kspec *s, uint32_t k, uint32_t alphabet) {
   /* AlphabetTraits::getBitsPerChar = ceilLog2(SIZE): alphabet_traits.hpp:127-130 */
   if (ORC_IS_2BIT(alphabet)) s->bits_per_char = 2;
   else if (alphabet == ORC_DNA5 || alphabet == ORC_RNA5) s->bits_per_char = 3;
+  else if (alphabet == ORC_DNA16) s->bits_per_char = 4;
   else return -1;
   s->n_bits = k * s->bits_per_char;
   s->n_words = (s->n_bits + 63) / 64;   /* padding.hpp:81 */
@@ -46,6 +47,18 @@ uint8_t orc_from_ascii(uint32_t alphabet, uint8_t c) {
     if (c == 'U' || c == 'u') c = 'T';
     else if (c == 'T' || c == 't') c = '?';
     alphabet = (alphabet == ORC_RNA) ? ORC_DNA : ORC_DNA5;
+  }
+  if (alphabet == ORC_DNA16) {
+    /* DNA16_T::FROM_ASCII (alphabets.hpp:660-681): presence bits A=1 C=2 G=4 T/U=8, IUPAC unions, '-' '.' = 0, else 0xF */
+    switch (c) {
+      case '-': case '.': return 0x0;
+      case 'A': case 'a': return 0x1; case 'C': case 'c': return 0x2; case 'M': case 'm': return 0x3;
+      case 'G': case 'g': return 0x4; case 'R': case 'r': return 0x5; case 'S': case 's': return 0x6;
+      case 'V': case 'v': return 0x7; case 'T': case 't': case 'U': case 'u': return 0x8;
+      case 'W': case 'w': return 0x9; case 'Y': case 'y': return 0xA; case 'H': case 'h': return 0xB;
+      case 'K': case 'k': return 0xC; case 'D': case 'd': return 0xD; case 'B': case 'b': return 0xE;
+      default: return 0xF;
+    }
   }
   if (alphabet == ORC_DNA) {
     switch (c) {
@@ -70,6 +83,10 @@ uint8_t orc_from_ascii(uint32_t alphabet, uint8_t c) {
 /* TO_COMPLEMENT tables: alphabets.hpp:172-178 (DNA), :262-272 (DNA6) */
 uint8_t orc_complement(uint32_t alphabet, uint8_t code) {
   if (ORC_IS_2BIT(alphabet)) return (uint8_t)(3 - (code & 3));   /* RNA: alphabets.hpp:411-421; RNA6: :497-512, same tables */
+  if (alphabet == ORC_DNA16) {   /* TO_COMPLEMENT (alphabets.hpp:706-729): 4-bit reversal */
+    static const uint8_t c16[16] = {0, 8, 4, 12, 2, 10, 6, 14, 1, 9, 5, 13, 3, 11, 7, 15};
+    return c16[code & 15];
+  }
   static const uint8_t c6[8] = {0, 4, 2, 6, 1, 5, 3, 7};
   return c6[code & 7];
 }

@@ -36,7 +36,7 @@ extern "C" {
 #define ORC_MAX_WORDS 4 /* up to 256-bit k-mers */
 
 /* RNA / RNA5 (= RNA6): alphabets.hpp:365-445, 448-530 -- the DNA / DNA6 tables with U in the place of T */
-enum { ORC_DNA = 0, ORC_DNA5 = 1, ORC_RNA = 2, ORC_RNA5 = 3 };
+enum { ORC_DNA = 0, ORC_DNA5 = 1, ORC_RNA = 2, ORC_RNA5 = 3, ORC_DNA16 = 4 };   /* DNA16: alphabets.hpp:648-733 */
 #define ORC_IS_2BIT(a) ((a) == ORC_DNA || (a) == ORC_RNA)
 enum { ORC_STRAND_SINGLE = 0, ORC_STRAND_CANONICAL = 1, ORC_STRAND_BIMOLECULE = 2 };
 enum { ORC_HASH_MURMUR = 0, ORC_HASH_FARM = 1, ORC_HASH_IDENTITY = 2, ORC_HASH_STD = 3 };

@@ -122,16 +122,16 @@ def quality_lut():
 
 
 def alphabet_tables():
-    """FROM_ASCII of DNA_T, DNA6_T (= DNA5), RNA_T, RNA6_T (= RNA5) (src/common/alphabets.hpp) as data: 256 codes each"""
+    """FROM_ASCII of DNA_T, DNA6_T (= DNA5), RNA_T, RNA6_T (= RNA5), DNA16_T (src/common/alphabets.hpp) as data: 256 codes each"""
     src = open(os.path.join(REF, "src/common/alphabets.hpp")).read()
     out = {"source": "src/common/alphabets.hpp (FROM_ASCII of DNA_T:139-161, DNA6_T:225-248, RNA_T:378-400, RNA6_T:459-480)"}
-    for name in ("DNA_T", "DNA6_T", "RNA_T", "RNA6_T"):
+    for name in ("DNA_T", "DNA6_T", "RNA_T", "RNA6_T", "DNA16_T"):
         at = src.index("struct " + name + " ")
         b = _block(src[at:], "FROM_ASCII =", "}};")
         vals = []
         for line in b.splitlines()[1:]:
             line = line.split("//")[0]
-            vals += [int(x) for x in re.findall(r"\d+", line)]
+            vals += [int(x, 0) for x in re.findall(r"0x[0-9A-Fa-f]+|\d+", line)]
         assert len(vals) == 256, (name, len(vals))
         out[name] = vals
     return out

@@ -13,7 +13,7 @@ ORACLE_DIR = os.path.join(ROOT, "oracle")
 _LIB = os.path.join(ORACLE_DIR, "libkmerind_oracle.so")
 _REF = os.path.join(ORACLE_DIR, "_ref", "libkmerind_refhash.so")
 
-DNA, DNA5, RNA, RNA5 = 0, 1, 2, 3
+DNA, DNA5, RNA, RNA5, DNA16 = 0, 1, 2, 3, 4
 SINGLE, CANONICAL, BIMOLECULE = 0, 1, 2
 MURMUR, FARM, IDENTITY, STD = 0, 1, 2, 3
 FASTQ, FASTA = 0, 1

@@ -188,3 +188,38 @@ def test_rna_alphabets_match_oracle(ctx, alpha):
     ex = orc.extract(s, fa, orc.FASTA, want_ids=True)
     gk, gi, gn = ctx.read_file(K.make_config(9, alpha, strand="single", seq_format="fasta", index_kind="position"), fa, with_ids=True)
     assert (gk == ex["kmers"]).all() and (gi == ex["ids"]).all()
+
+
+def test_dna16_alphabet_matches_oracle(ctx):
+    """DNA16 (alphabets.hpp:648-733): IUPAC presence bits, 4 bits per character, complement = bit reversal. Array ops, FASTQ
+    extract with ids, the fused count build (canonical), FASTA, against the oracle (whose table is pinned on the
+    reference's FROM_ASCII array)."""
+    import kmerind_amd as K
+    raw = np.array(K.synth_fastq(seed=31, genome_len=3000, n_reads=500), dtype=np.uint8)
+    rng = np.random.default_rng(31)
+    seq_rows = (np.arange(raw.size) % 315 >= 11) & (np.arange(raw.size) % 315 < 161)
+    iupac = np.frombuffer(b"RYSWKMBDHVNUrykn-.X", dtype=np.uint8)
+    sel = seq_rows & (rng.random(raw.size) < 0.08)
+    raw[sel] = iupac[rng.integers(0, iupac.size, size=int(sel.sum()))]
+    data = raw.tobytes()
+    for k in (15, 16, 21, 40):                                   # one to three words
+        s = orc.kspec(k, orc.DNA16)
+        cfg = K.make_config(k, "DNA16", strand="single", index_kind="position")
+        ex = orc.extract(s, data, orc.FASTQ, want_ids=True)
+        gk, gi, gn = ctx.read_file(cfg, data, with_ids=True)
+        assert gn == ex["n_seqs"] and gk.shape == ex["kmers"].shape and (gk == ex["kmers"]).all() and (gi == ex["ids"]).all()
+        sub = ex["kmers"][:2000]
+        assert (ctx.revcomp(cfg, sub) == orc.revcomp(s, sub)).all()
+        assert (ctx.canonical(cfg, sub) == orc.canonical(s, sub)).all()
+        idx = K.CountIndex(ctx, K.make_config(k, "DNA16", strand="canonical"))
+        idx.build(data)
+        m = orc.CountMap(s, orc.CANONICAL)
+        m.insert(ex["kmers"])
+        a, b = orc.sorted_pairs(*idx.to_vector()), orc.sorted_pairs(*m.export())
+        assert a[0].shape == b[0].shape and (a[0] == b[0]).all() and (a[1] == b[1]).all()
+        idx.close()
+    fa = b">r1\nACGTRYKMNNACGTUUACGBDHV-.ACGTACGT\nACGTTGCA\n>r2\nTGCATGCARYRYRYTGCATGCAGGGGG\n"
+    s = orc.kspec(9, orc.DNA16)
+    ex = orc.extract(s, fa, orc.FASTA, want_ids=True)
+    gk, gi, gn = ctx.read_file(K.make_config(9, "DNA16", strand="single", seq_format="fasta", index_kind="position"), fa, with_ids=True)
+    assert (gk == ex["kmers"]).all() and (gi == ex["ids"]).all()

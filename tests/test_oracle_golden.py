@@ -226,7 +226,7 @@ def test_filtered_parse_counts_match_reference_tables(fmt):
 def test_alphabet_tables_match_reference():
     """orc_from_ascii against the reference's FROM_ASCII arrays of DNA, DNA5/6, RNA, RNA5/6 (all 256 bytes each)"""
     t = _load("alphabet_tables.json")
-    for name, alpha in (("DNA_T", orc.DNA), ("DNA6_T", orc.DNA5), ("RNA_T", orc.RNA), ("RNA6_T", orc.RNA5)):
+    for name, alpha in (("DNA_T", orc.DNA), ("DNA6_T", orc.DNA5), ("RNA_T", orc.RNA), ("RNA6_T", orc.RNA5), ("DNA16_T", orc.DNA16)):
         assert [orc.lib.orc_from_ascii(alpha, c) for c in range(256)] == t[name], name
 
 
