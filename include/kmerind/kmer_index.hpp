@@ -362,6 +362,28 @@ class Index {
     kmi_results_free(&r);
     return out;
   }
+  // exists() of the densehash maps (distributed_densehash_map.hpp:1465-1560): one byte per INPUT key, in input order
+  // (1 = stored). The device answers per distinct transformed key; the bytes are filled on the host from that answer.
+  std::vector<unsigned char> exists(std::vector<KmerType> &query) const {
+    if (comm.size() > 1) throw std::invalid_argument("exists with size() > 1 is not wired through comm.exchange");
+    std::vector<unsigned char> out(query.size(), 0);
+    if (query.empty()) return out;
+    const size_t nw = KmerType::nWords;
+    std::vector<uint64_t> t(query.size() * nw);
+    const uint64_t *w = detail::words_of(query);
+    if (cfg.strand == KMI_STRAND_SINGLE) std::memcpy(t.data(), w, t.size() * sizeof(uint64_t));
+    else ::kmerind::check(ctx, kmi_canonical_host(ctx, &cfg, w, query.size(), t.data()));   // the key the map stores
+    kmi_results r{};
+    ::kmerind::check(ctx, kmi_index_count_host(idx, w, query.size(), &r));
+    std::map<KmerType, bool> present;
+    for (uint64_t i = 0; i < r.n; ++i) present[KmerType(r.keys + i * nw)] = r.values[i] != 0;
+    kmi_results_free(&r);
+    for (size_t i = 0; i < query.size(); ++i) {
+      auto it = present.find(KmerType(&t[i * nw]));
+      out[i] = (it != present.end() && it->second) ? 1 : 0;
+    }
+    return out;
+  }
   // Index::find (:132-135): (key, stored value) of present query keys
   std::vector<TupleType> find(std::vector<KmerType> &query) const {
     kmi_results r{};

@@ -267,6 +267,14 @@ class CountIndex:
     def find(self, q):
         return self._query(lib.kmi_index_find_host, q)
 
+    def exists(self, q):
+        """densehash exists() (distributed_densehash_map.hpp:1465-1560): one byte per input key, in input order"""
+        q = _u64(q, self.n_words)
+        keys, cnt = self.count(q)
+        tq = q if self.cfg.strand == L.STRAND_SINGLE else self.ctx.canonical(self.cfg, q)
+        have = {tuple(k) for k, c in zip(keys.tolist(), np.asarray(cnt).reshape(len(keys), -1)[:, 0].tolist()) if c}
+        return np.fromiter((tuple(k) in have for k in tq.tolist()), dtype=np.uint8, count=tq.shape[0])
+
     def erase(self, q):
         q = _u64(q, self.n_words)
         n = C.c_uint64()

@@ -438,3 +438,24 @@ def test_single_strand_dist_transforms(ctx, dist_trans, code):
         idx.close()
     with pytest.raises((L.KmiError, ValueError)):
         ctx.key_to_rank(K.make_config(31, "DNA", strand="canonical", dist_trans=dist_trans), np.zeros((4, 1), np.uint64), 4)
+
+
+def test_exists_is_one_byte_per_input_key_in_input_order(ctx):
+    """densehash exists() (distributed_densehash_map.hpp:1465-1560)"""
+    import kmerind_amd as K
+    for strand in ("canonical", "single"):
+        s = orc.kspec(21)
+        cfg = K.make_config(21, "DNA", strand=strand)
+        data = K.synth_fastq(seed=2, genome_len=3000, n_reads=400)
+        ex = orc.extract(s, data, orc.FASTQ)["kmers"]
+        idx = K.CountIndex(ctx, cfg)
+        idx.build(data)
+        rng = np.random.default_rng(3)
+        q = np.concatenate([ex[rng.integers(0, ex.shape[0], size=50)], rng.integers(0, 1 << 42, size=(50, 1), dtype=np.uint64),
+                            orc.revcomp(s, ex[:20])])
+        q = q[rng.permutation(q.shape[0])]
+        stored = set(int(x) for x in (ex[:, 0] if strand == "single" else orc.canonical(s, ex)[:, 0]))
+        tq = q[:, 0] if strand == "single" else orc.canonical(s, q)[:, 0]
+        want = np.array([int(x) in stored for x in tq], dtype=np.uint8)
+        assert (idx.exists(q) == want).all()
+        idx.close()
