@@ -1216,6 +1216,7 @@ template <int NW> struct LdsTable {
   uint32_t *overflow;  // flag
   uint32_t *special;   // value of the key that equals the empty sentinel (NW == 1)
   uint32_t *special_set;
+  uint32_t *progress;  // keys of the stream the insert had scanned when the table overflowed (pass-count estimate)
   // geometry in use: TabCfg's by default; the query kernel sizes it to the bucket's query count (a table that is cleared
   // and swept once per bucket should not be larger than its keys need)
   uint32_t cap, slots, limit;
@@ -1226,7 +1227,7 @@ template <int NW> __device__ __forceinline__ void table_clear(const LdsTable<NW>
     t.vals[i] = 0;
     if (NW == 1) t.keys[i] = kEmptyKey; else t.tags[i] = kTagEmpty;
   }
-  if (threadIdx.x == 0) { *t.distinct = 0; *t.overflow = 0; *t.special = 0; *t.special_set = 0; }
+  if (threadIdx.x == 0) { *t.distinct = 0; *t.overflow = 0; *t.special = 0; *t.special_set = 0; *t.progress = 0; }
 }
 
 __device__ __forceinline__ uint32_t slot_of(uint32_t h, int cap) {
@@ -1353,7 +1354,10 @@ __device__ __forceinline__ void table_insert_stream1(const LdsTable<1> &t, const
   uint64_t ka[U], kb[U];
   load(0u, ka);
   for (uint32_t i0 = 0; i0 < n; i0 += 2 * STEP) {
-    if (__atomic_load_n(t.overflow, __ATOMIC_RELAXED)) break;   // this pass is lost already: stop filling the table
+    if (__atomic_load_n(t.overflow, __ATOMIC_RELAXED)) {        // this pass is lost already: stop filling the table
+      if (lane_id() == 0) atomicMax(t.progress, i0);
+      break;
+    }
     const bool has_b = i0 + STEP < n;
     if (has_b) load(i0 + STEP, kb);
     insert(i0, ka);
@@ -1436,7 +1440,7 @@ template <int NW> struct QTabCfg {
   __shared__ uint32_t s_ctl[8];                                             \
   LdsTable<NW> tab;                                                         \
   tab.keys = s_tk; tab.vals = s_tv; tab.tags = s_tt; tab.distinct = &s_ctl[0]; tab.overflow = &s_ctl[1]; \
-  tab.special = &s_ctl[2]; tab.special_set = &s_ctl[3];                    \
+  tab.special = &s_ctl[2]; tab.special_set = &s_ctl[3]; tab.progress = &s_ctl[5]; \
   tab.cap = CFG::CAP; tab.slots = CFG::SLOTS; tab.limit = CFG::LIMIT;
 #define KMI_TABLE_LDS(NW) KMI_TABLE_LDS_CFG(NW, TabCfg<NW>)
 
@@ -1502,7 +1506,21 @@ __global__ __launch_bounds__((TabCfg<NW>::NT)) void bucket_reduce_kernel(const u
       lds_barrier();
     }
     if (!failed) break;
-    npass *= 2;
+    {
+      // how many passes next: the table held LIMIT distinct keys of this pass after `progress` of the bucket's n stream keys
+      // (known to one load step), so the pass's share of the stream needs about n / progress tables; a third on top for
+      // the spread between passes. Without that knowledge (the old entries alone overflowed) the count doubles.
+      const uint32_t n_new = (uint32_t)(ne - nb), prog = *tab.progress;
+      uint32_t want = npass * 2u;
+      if (NW == 1 && prog > 0u && n_new > 0u) {
+        const uint32_t seen = prog > 12288u ? prog - 8192u : prog / 2u + 2048u;   // the overflow came somewhere inside the last step
+        const uint64_t est = ((uint64_t)npass * n_new * 4u + 3ull * seen - 1ull) / (3ull * seen);
+        want = est > (uint64_t)kMaxPasses ? kMaxPasses : (uint32_t)est;
+        if (want <= npass) want = npass + 1u;
+      }
+      lds_barrier();   // everyone has read the progress word before the next attempt clears it
+      npass = want;
+    }
     if (npass > kMaxPasses) { if (threadIdx.x == 0) { atomicOr(&flags[2], 1u); *s_out = 0; } lds_barrier(); break; }
     lds_barrier();
   }

@@ -338,13 +338,15 @@ def _keys_in_one_placement_bucket(n, bucket, hi_words=(1, 77, 1 << 20)):
     return np.concatenate(out)[:n]
 
 
-def test_bucket_with_more_distinct_keys_than_the_lds_table_takes_more_passes(ctx):
-    """30 000 distinct keys in ONE placement bucket (the one-word LDS table holds 9600 per pass): the reduce and the query
-    kernels split the bucket into passes over disjoint key subsets; insert twice so the second merge meets the big bucket."""
+@pytest.mark.parametrize("n_hot", [30_000, 250_000])
+def test_bucket_with_more_distinct_keys_than_the_lds_table_takes_more_passes(ctx, n_hot):
+    """n_hot distinct keys in ONE placement bucket (the one-word LDS table holds 9600 per pass): the reduce and the query
+    kernels split the bucket into passes over disjoint key subsets (4 and about 35 of them; the pass count is estimated
+    from how far the stream got when the table filled up); insert twice so the second merge meets the big bucket."""
     import kmerind_amd as K
     cfg = K.make_config(31, "DNA", strand="single")
     rng = np.random.default_rng(8)
-    hot = _keys_in_one_placement_bucket(30_000, bucket=4242)
+    hot = _keys_in_one_placement_bucket(n_hot, bucket=4242)
     assert np.unique(hot).size == hot.size and int(hot.max()) < (1 << 62)
     idx = K.CountIndex(ctx, cfg)
     ref = {}
