@@ -306,7 +306,8 @@ __global__ __launch_bounds__(256) void fastq_check_lengths_kernel(const uint32_t
 template <int NW, int BITS, bool WITH_IDS>
 __global__ __launch_bounds__((ExCfg<NW, BITS>::NT)) void fasta_extract_kernel(
     PackedInput in, KShape shape, bool canonical, const uint64_t *__restrict__ ids_by_rank, const uint64_t *__restrict__ out_off,
-    uint64_t out_capacity, uint64_t *__restrict__ out_kmers, uint64_t *__restrict__ out_ids, uint32_t *__restrict__ flags) {
+    uint64_t out_capacity, uint64_t *__restrict__ out_kmers, uint64_t *__restrict__ out_ids, uint32_t *__restrict__ flags,
+    uint32_t kstride /* words between the keys of consecutive tuples */, uint32_t istride /* ... between their ids */) {
   using Cfg = ExCfg<NW, BITS>;
   __shared__ uint32_t s_eol[Cfg::EOL_DW];
   __shared__ uint32_t s_stream[Cfg::STREAM_DW];
@@ -327,8 +328,8 @@ __global__ __launch_bounds__((ExCfg<NW, BITS>::NT)) void fasta_extract_kernel(
     window_at<Cfg>(s_stream, pos, shape, rc, fw);
     select_strand<NW>(rc, fw, canonical, key);
 #pragma unroll
-    for (int w = 0; w < NW; ++w) out_kmers[(base + q) * NW + w] = key[w];
-    if (WITH_IDS) out_ids[base + q] = ids_by_rank[tile0 + pos];
+    for (int w = 0; w < NW; ++w) out_kmers[(base + q) * kstride + w] = key[w];
+    if (WITH_IDS) out_ids[(base + q) * istride] = ids_by_rank[tile0 + pos];
   }
 }
 
@@ -402,7 +403,9 @@ inline size_t qual_lds_bytes(uint32_t k) { return (size_t)(kQualThreads / kWave)
 __global__ __launch_bounds__(kQualThreads) void fastq_quality_kernel(const uint8_t *__restrict__ bytes, uint64_t n_bytes,
                                                                     const uint32_t *__restrict__ eolw, uint64_t n_words, uint32_t k,
                                                                     uint32_t row_bytes, const ReadDesc *__restrict__ reads,
-                                                                    const uint64_t *__restrict__ n_reads, float *__restrict__ out) {
+                                                                    const uint64_t *__restrict__ n_reads, float *__restrict__ out,
+                                                                    uint64_t *__restrict__ out_rec, uint32_t qstride) {
+  // out: one float per tuple; or (records) out_rec[tuple * qstride] = the float's bits in the low half of a 64-bit word
   extern __shared__ __attribute__((aligned(16))) uint8_t s_q[];
   constexpr uint32_t W = kQualChunk;
   const uint32_t lane = lane_id(), wv = wave_id();
@@ -481,7 +484,10 @@ __global__ __launch_bounds__(kQualThreads) void fastq_quality_kernel(const uint8
           const uint32_t row = g + (lane >> 4), col = lane & 15u, w = w0 + t0 + col;
           const uint32_t nwr = (uint32_t)__shfl((int)n_win, (int)row, kWave);
           const uint64_t orow = ((uint64_t)(uint32_t)__shfl((int)(o >> 32), (int)row, kWave) << 32) | (uint32_t)__shfl((int)(uint32_t)o, (int)row, kWave);
-          if (w < nwr) out[orow + w] = tile[row * 17u + col];
+          if (w < nwr) {
+            if (out_rec) out_rec[(orow + w) * qstride] = (uint64_t)__float_as_uint(tile[row * 17u + col]);
+            else out[orow + w] = tile[row * 17u + col];
+          }
         }
         wave_sync();
       }
@@ -493,7 +499,7 @@ template <int NW, int BITS, bool WITH_IDS>
 __global__ __launch_bounds__((ExCfg<NW, BITS>::NT)) void fastq_extract_kernel(
     PackedInput in, KShape shape, bool canonical, const uint32_t *__restrict__ line_base, const uint64_t *__restrict__ hdr_base,
     uint64_t file_offset, const uint64_t *__restrict__ out_off, uint64_t out_capacity, uint64_t *__restrict__ out_kmers,
-    uint64_t *__restrict__ out_ids, ReadDesc *__restrict__ reads, uint32_t *__restrict__ flags) {
+    uint64_t *__restrict__ out_ids, ReadDesc *__restrict__ reads, uint32_t *__restrict__ flags, uint32_t kstride, uint32_t istride) {
   using Cfg = ExCfg<NW, BITS>;
   __shared__ uint32_t s_eol[Cfg::EOL_DW];
   __shared__ uint32_t s_brk[Cfg::EOL_DW];
@@ -533,7 +539,7 @@ __global__ __launch_bounds__((ExCfg<NW, BITS>::NT)) void fastq_extract_kernel(
     window_at<Cfg>(s_stream, pos, shape, rc, fw);
     select_strand<NW>(rc, fw, canonical, key);
 #pragma unroll
-    for (int w = 0; w < NW; ++w) out_kmers[(base + q) * NW + w] = key[w];
+    for (int w = 0; w < NW; ++w) out_kmers[(base + q) * kstride + w] = key[w];
     if (WITH_IDS) {
       // ShortSequenceKmerId (sequence.hpp:156-157): record file offset << 16 | offset of the k-mer's
       // first base from the record start (kmer_parser.hpp:378-386)
@@ -545,7 +551,7 @@ __global__ __launch_bounds__((ExCfg<NW, BITS>::NT)) void fastq_extract_kernel(
       else rec = hdr_base[blockIdx.x];
       const uint64_t rec_off = file_offset + rec - 1u, d = tile0 + pos - (rec - 1u);
       if (rec == 0 || d > 0xFFFFu) atomicOr(&flags[3], 1u);   // ShortSequenceKmerId increment overflow (sequence.hpp:177-183)
-      out_ids[base + q] = ((rec_off & 0xFFFFFFFFFFull) << 16) | (d & 0xFFFFull);
+      out_ids[(base + q) * istride] = ((rec_off & 0xFFFFFFFFFFull) << 16) | (d & 0xFFFFull);
       // first window of its read (the window starts on the line start of the sequence line)
       if (reads && ((s_lsmask[j] >> p) & 1u)) {
         // the descriptor slot is the read's sequence index: its sequence line is line 4 * index + 1 of the buffer
@@ -782,8 +788,12 @@ template <int NW, int BITS>
 static kmi_status extract_run_impl(kmi_ctx *ctx, const kmi_config *cfg, const uint8_t *bytes_dev, size_t n_bytes,
                                    KShape shape, uint64_t file_offset, uint64_t *out_kmers_dev, uint64_t *out_ids_dev,
                                    float *out_quals_dev, size_t out_capacity, bool apply_strand, bool scan_done, uint64_t *n_tuples,
-                                   uint64_t *n_seqs) {
+                                   uint64_t *n_seqs, uint32_t rec_words) {
   using Cfg = ExCfg<NW, BITS>;
+  // rec_words != 0: out_kmers_dev is a record buffer (key words, id[, quality bits]) of rec_words words per tuple
+  const uint32_t kstride = rec_words ? rec_words : (uint32_t)NW, istride = rec_words ? rec_words : 1u;
+  uint64_t *ids_at = rec_words ? out_kmers_dev + NW : out_ids_dev;
+  const bool want_ids = ids_at != nullptr, want_quals = out_quals_dev != nullptr || rec_words == (uint32_t)NW + 2u;
   ScanResult r;
   if (!scan_done) KMI_HIP(ctx, hipMemsetAsync(ctx->d_flags, 0, sizeof(uint32_t) * 16, ctx->stream));
   KMI_TRY((scan_impl<NW, BITS>(ctx, bytes_dev, n_bytes, shape, &r, scan_done, true, cfg->seq_filter, is_rna(cfg))));
@@ -791,7 +801,7 @@ static kmi_status extract_run_impl(kmi_ctx *ctx, const kmi_config *cfg, const ui
     ProfScope ps(ctx, "fastq_extract", n_bytes);
     const bool canonical = apply_strand && cfg->strand != KMI_STRAND_SINGLE;
     ReadDesc *reads = nullptr;
-    if (out_quals_dev) {
+    if (want_quals) {
       // one descriptor slot per sequence (totals[2] of the scan), empty until the read's first window fills it
       uint64_t n_seq_now = 0;
       KMI_HIP(ctx, hipMemcpyAsync(&n_seq_now, ctx->d_totals + 2, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
@@ -801,21 +811,22 @@ static kmi_status extract_run_impl(kmi_ctx *ctx, const kmi_config *cfg, const ui
       reads = (ReadDesc *)pr;
       KMI_HIP(ctx, hipMemsetAsync(reads, 0xff, sizeof(ReadDesc) * (n_seq_now + 16), ctx->stream));
     }
-    if (out_ids_dev) {
+    if (want_ids) {
       hipLaunchKernelGGL((fastq_extract_kernel<NW, BITS, true>), dim3((unsigned)r.n_tiles), dim3(Cfg::NT), 0, ctx->stream,
                          r.packed, shape, canonical, (const uint32_t *)r.line_base, (const uint64_t *)r.hdr_base, file_offset,
-                         (const uint64_t *)r.out_off, (uint64_t)out_capacity, out_kmers_dev, out_ids_dev, reads, ctx->d_flags);
+                         (const uint64_t *)r.out_off, (uint64_t)out_capacity, out_kmers_dev, ids_at, reads, ctx->d_flags, kstride, istride);
     } else {
       hipLaunchKernelGGL((fastq_extract_kernel<NW, BITS, false>), dim3((unsigned)r.n_tiles), dim3(Cfg::NT), 0, ctx->stream,
                          r.packed, shape, canonical, (const uint32_t *)r.line_base, (const uint64_t *)r.hdr_base, file_offset,
                          (const uint64_t *)r.out_off, (uint64_t)out_capacity, out_kmers_dev, (uint64_t *)nullptr, (ReadDesc *)nullptr,
-                         ctx->d_flags);
+                         ctx->d_flags, kstride, istride);
     }
-    if (out_quals_dev) {
+    if (want_quals) {
       ProfScope pq(ctx, "fastq_quality", n_bytes);
       hipLaunchKernelGGL(fastq_quality_kernel, dim3(2048), dim3(kQualThreads), qual_lds_bytes(shape.k), ctx->stream, bytes_dev,
                          (uint64_t)n_bytes, (const uint32_t *)r.packed.eol, (uint64_t)(r.packed.n_cover / 32), shape.k,
-                         qual_row_bytes(shape.k), (const ReadDesc *)reads, (const uint64_t *)(ctx->d_totals + 2), out_quals_dev);
+                         qual_row_bytes(shape.k), (const ReadDesc *)reads, (const uint64_t *)(ctx->d_totals + 2), out_quals_dev,
+                         rec_words ? out_kmers_dev + NW + 1 : (uint64_t *)nullptr, rec_words);
     }
   }
   KMI_HIP(ctx, hipGetLastError());
@@ -862,8 +873,10 @@ kmi_status fastq_scan(kmi_ctx *ctx, const kmi_config *cfg, const uint8_t *bytes_
 template <int NW, int BITS>
 static kmi_status fasta_extract_impl(kmi_ctx *ctx, const kmi_config *cfg, const uint8_t *bytes_dev, size_t n_bytes, KShape shape,
                                      uint64_t file_offset, uint64_t *out_kmers_dev, uint64_t *out_ids_dev, size_t out_capacity,
-                                     bool apply_strand, bool count_only, uint64_t *n_tuples, uint64_t *n_seqs) {
+                                     bool apply_strand, bool count_only, uint64_t *n_tuples, uint64_t *n_seqs, uint32_t rec_words) {
   using Cfg = ExCfg<NW, BITS>;
+  const uint32_t kstride = rec_words ? rec_words : (uint32_t)NW, istride = rec_words ? rec_words : 1u;
+  if (rec_words) out_ids_dev = out_kmers_dev + NW;   // records: the id follows the key words
   FastaScan fs;
   KMI_HIP(ctx, hipMemsetAsync(ctx->d_flags, 0, sizeof(uint32_t) * 16, ctx->stream));
   KMI_TRY(fasta_scan(ctx, cfg, bytes_dev, n_bytes, file_offset, out_ids_dev != nullptr, &fs));
@@ -884,11 +897,12 @@ static kmi_status fasta_extract_impl(kmi_ctx *ctx, const kmi_config *cfg, const 
     const bool canonical = apply_strand && cfg->strand != KMI_STRAND_SINGLE;
     if (out_ids_dev)
       hipLaunchKernelGGL((fasta_extract_kernel<NW, BITS, true>), dim3((unsigned)n_tiles), dim3(Cfg::NT), 0, ctx->stream, in, shape, canonical,
-                         fs.ids_by_rank, (const uint64_t *)off, (uint64_t)out_capacity, out_kmers_dev, out_ids_dev, ctx->d_flags);
+                         fs.ids_by_rank, (const uint64_t *)off, (uint64_t)out_capacity, out_kmers_dev, out_ids_dev, ctx->d_flags, kstride,
+                         istride);
     else
       hipLaunchKernelGGL((fasta_extract_kernel<NW, BITS, false>), dim3((unsigned)n_tiles), dim3(Cfg::NT), 0, ctx->stream, in, shape, canonical,
                          (const uint64_t *)nullptr, (const uint64_t *)off, (uint64_t)out_capacity, out_kmers_dev, (uint64_t *)nullptr,
-                         ctx->d_flags);
+                         ctx->d_flags, kstride, istride);
   }
   KMI_HIP(ctx, hipGetLastError());
   uint32_t fl[4] = {0, 0, 0, 0};
@@ -903,9 +917,9 @@ static kmi_status fasta_extract_impl(kmi_ctx *ctx, const kmi_config *cfg, const 
 
 static kmi_status fasta_extract(kmi_ctx *ctx, const kmi_config *cfg, const uint8_t *bytes_dev, size_t n_bytes, KShape shape,
                                 uint64_t file_offset, uint64_t *out_kmers_dev, uint64_t *out_ids_dev, size_t out_capacity, bool apply_strand,
-                                bool count_only, uint64_t *n_tuples, uint64_t *n_seqs) {
+                                bool count_only, uint64_t *n_tuples, uint64_t *n_seqs, uint32_t rec_words = 0) {
   KMI_DISPATCH(shape, fasta_extract_impl, ctx, cfg, bytes_dev, n_bytes, shape, file_offset, out_kmers_dev, out_ids_dev, out_capacity,
-               apply_strand, count_only, n_tuples, n_seqs);
+               apply_strand, count_only, n_tuples, n_seqs, rec_words);
 }
 
 // Illumina18QualityScoreCodec<float>::DecodeLUT by its generating formula (quality_scores.hpp:111-112):
@@ -938,17 +952,19 @@ kmi_status extract_count(kmi_ctx *ctx, const kmi_config *cfg, const uint8_t *byt
 
 kmi_status extract_run(kmi_ctx *ctx, const kmi_config *cfg, const uint8_t *bytes_dev, size_t n_bytes,
                        uint64_t file_offset, uint64_t *out_kmers_dev, uint64_t *out_ids_dev, size_t out_capacity,
-                       bool apply_strand, bool scan_done, uint64_t *n_tuples, uint64_t *n_seqs, float *out_quals_dev) {
+                       bool apply_strand, bool scan_done, uint64_t *n_tuples, uint64_t *n_seqs, float *out_quals_dev, uint32_t rec_words) {
+  // rec_words != 0: out_kmers_dev takes whole records -- key words, id, and with rec_words == n_words + 2 the quality's float
+  // bits -- rec_words words per tuple, the layout the multimap insert reads (out_ids_dev / out_quals_dev are then unused)
   KShape shape;
   if (!valid_config(cfg, &shape)) return set_err(ctx, KMI_ERR_INVALID, "bad kmi_config");
   if (n_bytes == 0) { if (n_tuples) *n_tuples = 0; if (n_seqs) *n_seqs = 0; return KMI_OK; }
-  if (out_quals_dev && (!out_ids_dev || cfg->seq_format != KMI_FMT_FASTQ))
+  if ((out_quals_dev && !out_ids_dev) || ((out_quals_dev || rec_words == shape.n_words + 2u) && cfg->seq_format != KMI_FMT_FASTQ))
     return set_err(ctx, KMI_ERR_INVALID, "k-mer qualities need FASTQ input and are produced together with the ids");
   if (cfg->seq_format == KMI_FMT_FASTA)
     return fasta_extract(ctx, cfg, bytes_dev, n_bytes, shape, file_offset, out_kmers_dev, out_ids_dev, out_capacity, apply_strand, false,
-                         n_tuples, n_seqs);
+                         n_tuples, n_seqs, rec_words);
   KMI_DISPATCH(shape, extract_run_impl, ctx, cfg, bytes_dev, n_bytes, shape, file_offset, out_kmers_dev, out_ids_dev, out_quals_dev,
-               out_capacity, apply_strand, scan_done, n_tuples, n_seqs);
+               out_capacity, apply_strand, scan_done, n_tuples, n_seqs, rec_words);
 }
 
 }  // namespace kmi

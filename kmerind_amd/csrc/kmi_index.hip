@@ -2573,16 +2573,25 @@ kmi_status kmi_index_build_dev(kmi_index *idx, const uint8_t *bytes_dev, size_t 
   uint64_t nt = 0, ns = 0;
   KMI_TRY(extract_count(ctx, &idx->cfg, bytes_dev, n_bytes, &nt, &ns));
   if (nt == 0) return KMI_OK;
-  void *dk, *di, *dr, *dq = nullptr;
-  KMI_TRY(ws_get(ctx, WS_OUTPUT, (size_t)nt * nw * sizeof(uint64_t), &dk));
-  KMI_TRY(ws_get(ctx, WS_OUTPUT2, (size_t)nt * sizeof(uint64_t), &di));
-  if (vw == 2) KMI_TRY(ws_get(ctx, WS_QUALS, (size_t)nt * sizeof(float) + 16, &dq));
-  KMI_TRY(extract_run(ctx, &idx->cfg, bytes_dev, n_bytes, file_offset, (uint64_t *)dk, (uint64_t *)di, (size_t)nt, false, true, &nt, &ns,
-                      (float *)dq));
+  // the tuples leave the extract pass as records (key words, id[, quality bits]): what the multimap insert reads
+  void *dr;
   KMI_TRY(ws_get(ctx, WS_INPUT2, (size_t)nt * (nw + vw) * sizeof(uint64_t), &dr));
-  hipLaunchKernelGGL(interleave_records_kernel, dim3(2048), dim3(256), 0, ctx->stream, (const uint64_t *)dk, (const uint64_t *)di,
-                     (const float *)dq, nt, nw, vw, (uint64_t *)dr);
-  KMI_HIP(ctx, hipGetLastError());
+  if (vw == 2 && idx->cfg.seq_format != KMI_FMT_FASTQ)   // (id, quality) values without quality lines: the quality word stays zero
+    KMI_HIP(ctx, hipMemsetAsync(dr, 0, (size_t)nt * (nw + vw) * sizeof(uint64_t), ctx->stream));
+  const uint32_t rec_words = nw + ((vw == 2 && idx->cfg.seq_format != KMI_FMT_FASTQ) ? 1u : vw);
+  if (rec_words == nw + vw) {
+    KMI_TRY(extract_run(ctx, &idx->cfg, bytes_dev, n_bytes, file_offset, (uint64_t *)dr, nullptr, (size_t)nt, false, true, &nt, &ns, nullptr,
+                        nw + vw));
+  } else {
+    // FASTA under a position + quality index: separate arrays, then the interleave pass leaves the quality word empty
+    void *dk, *di;
+    KMI_TRY(ws_get(ctx, WS_OUTPUT, (size_t)nt * nw * sizeof(uint64_t), &dk));
+    KMI_TRY(ws_get(ctx, WS_OUTPUT2, (size_t)nt * sizeof(uint64_t), &di));
+    KMI_TRY(extract_run(ctx, &idx->cfg, bytes_dev, n_bytes, file_offset, (uint64_t *)dk, (uint64_t *)di, (size_t)nt, false, true, &nt, &ns));
+    hipLaunchKernelGGL(interleave_records_kernel, dim3(2048), dim3(256), 0, ctx->stream, (const uint64_t *)dk, (const uint64_t *)di,
+                       (const float *)nullptr, nt, nw, vw, (uint64_t *)dr);
+    KMI_HIP(ctx, hipGetLastError());
+  }
   return index_insert_records(idx, (const uint64_t *)dr, (size_t)nt, true);
 }
 
