@@ -292,6 +292,8 @@ def sorted_rows(*cols):
 
 def sorted_pairs(keys, vals):
     """canonical ordering of a (key, value) multiset for comparisons"""
+    if len(vals) == 0:
+        return np.zeros((0, 1), dtype=np.uint64), np.asarray(vals)
     keys = np.asarray(keys, dtype=np.uint64).reshape(len(vals), -1)
     cols = [np.asarray(vals)] + [keys[:, w] for w in range(keys.shape[1])]
     order = np.lexsort(cols)
