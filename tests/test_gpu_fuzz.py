@@ -55,3 +55,49 @@ def test_fused_build_and_extract_follow_the_oracle_on_ragged_fastq(ctx, seed):
     a, b = orc.sorted_pairs(*idx.to_vector()), orc.sorted_pairs(*m.export())
     assert a[0].shape == b[0].shape and (a[0] == b[0]).all() and (a[1] == b[1]).all()
     idx.close()
+
+
+def _random_fasta(seed):
+    rng = np.random.default_rng(seed)
+    eol = b"\r\n" if seed % 3 == 1 else b"\n"
+    alphabet = np.frombuffer(b"ACGTACGTACGTACGTNacgtnRY-", dtype=np.uint8)
+    out = []
+    if seed % 5 == 0:                                   # sequence lines before the first header
+        out.append(alphabet[rng.integers(0, alphabet.size, size=int(rng.integers(1, 90)))].tobytes() + eol)
+    for r in range(int(rng.integers(1, 60))):
+        for h in range(int(rng.integers(1, 3))):       # one or two header / comment lines
+            out.append((b">" if rng.random() < 0.8 else b";") + b"rec%d.%d some text" % (r, h) + eol)
+        total = int(rng.integers(0, 3000)) if rng.random() < 0.9 else int(rng.integers(9000, 30000))
+        width = int(rng.integers(1, 120))
+        seq = alphabet[rng.integers(0, alphabet.size, size=total)].tobytes()
+        for i in range(0, total, width):
+            out.append(seq[i:i + width] + eol)
+    data = b"".join(out)
+    if seed % 4 == 2 and data.endswith(eol):
+        data = data[:-len(eol)]
+    return data
+
+
+@pytest.mark.parametrize("seed", list(range(12)))
+def test_fasta_extract_and_build_follow_the_oracle_on_ragged_fasta(ctx, seed):
+    """multi-line records of any width, records without sequence, '>' and ';' header lines, lines before the first header,
+    CRLF, no final newline (fasta_loader.hpp:485-723), with and without the N filters"""
+    import kmerind_amd as K
+    data = _random_fasta(seed)
+    k, alpha, oa = [(31, "DNA", orc.DNA), (15, "DNA", orc.DNA), (21, "DNA5", orc.DNA5), (64, "DNA", orc.DNA), (12, "DNA16", orc.DNA16)][seed % 5]
+    flt = ["all", "n_split", "n_filter"][seed % 3]
+    fl = {"all": orc.SEQ_ALL, "n_split": orc.SEQ_N_SPLIT, "n_filter": orc.SEQ_N_FILTER}[flt]
+    s = orc.kspec(k, oa)
+    ex = orc.extract(s, data, orc.FASTA, want_ids=True, seq_filter=fl)
+    gk, gi, gn = ctx.read_file(K.make_config(k, alpha, strand="single", index_kind="position", seq_format="fasta", seq_filter=flt), data,
+                               with_ids=True)
+    assert gk.shape == ex["kmers"].shape and (gk == ex["kmers"]).all() and (gi == ex["ids"]).all()
+    if flt != "n_split":                                 # (pieces are not counted for FASTA: kmerind_hip.h, seq_filter)
+        assert gn == ex["n_seqs"]
+    idx = K.CountIndex(ctx, K.make_config(k, alpha, strand="canonical", seq_format="fasta", seq_filter=flt))
+    idx.build(data)
+    m = orc.CountMap(s, orc.CANONICAL)
+    m.insert(ex["kmers"])
+    a, b = orc.sorted_pairs(*idx.to_vector()), orc.sorted_pairs(*m.export())
+    assert a[0].shape == b[0].shape and (a[0] == b[0]).all() and (a[1] == b[1]).all()
+    idx.close()
