@@ -228,7 +228,9 @@ def main():
                         "alg_bytes_per_launch": per_launch * b_kernel,
                         "pipeline_frac": round(n_kmers * B_ALG / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                         "kernels_ms_per_step": {p["name"]: round(p["total_ms"] / args.steps, 4) for p in
-                                                sorted(prof, key=lambda p: -p["total_ms"])}}
+                                                sorted(prof, key=lambda p: -p["total_ms"])},
+                        # what this box's HBM delivers to plain streaming kernels (outside the timed steps), next to the 8 TB/s figure
+                        "measured_stream_gbs": measured_stream(torch, dev)}
         out = {"metric": "kmers_per_sec_indexed", "value": value, "unit": "k-mers/s", "n_gpus": world,
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
                "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
@@ -310,6 +312,25 @@ def extra_rates(ctx, cfg, idx, d_bytes, nbytes, n_kmers, dev, torch):
             "count_queries_per_s": nq / t_count, "find_queries_per_s": nq / t_find, "queries": nq,
             "distinct_query_keys": n_distinct_q, "found": n_out.value,
             "note": "outside the timed steps; 2 runs each after one warm-up; operands resident in HBM"}
+
+
+def measured_stream(torch, dev):
+    """read-only (sum) and copy (read + write) rates of 2 GiB int64 tensors, best of 5, HIP-event timed"""
+    try:
+        n = 1 << 28
+        x = torch.ones(n, dtype=torch.int64, device=dev)
+        y = torch.empty_like(x)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        best = {"read": 0.0, "copy": 0.0}
+        for _ in range(5):
+            ev[0].record(); x.sum(); ev[1].record(); ev[1].synchronize()
+            best["read"] = max(best["read"], n * 8 / (ev[0].elapsed_time(ev[1]) * 1e-3) / 1e9)
+            ev[0].record(); y.copy_(x); ev[1].record(); ev[1].synchronize()
+            best["copy"] = max(best["copy"], 2 * n * 8 / (ev[0].elapsed_time(ev[1]) * 1e-3) / 1e9)
+        del x, y
+        return {k: round(v, 1) for k, v in best.items()}
+    except Exception as e:   # never let the side measurement break the bench line
+        return {"error": str(e)[:80]}
 
 
 def measured_traffic(kernel, n_reads):
