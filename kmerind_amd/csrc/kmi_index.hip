@@ -1293,7 +1293,8 @@ __device__ __forceinline__ uint32_t pass_of(uint32_t h, uint32_t npass) {
 // read, compare), and a compare-and-swap is spent only on an empty slot, i.e. once per distinct key.
 // The walk is the expensive part (every step is a full wave instruction sequence for the few lanes that
 // still probe), hence no wrap-around, no probe counter and no bounds test inside it (see TabCfg).
-template <int U, bool MULTI>
+// SPECIAL: the keys can equal the empty marker (only k-mers that fill all 64 bits can); otherwise that test is left out
+template <int U, bool MULTI, bool SPECIAL = true>
 __device__ __forceinline__ void table_insert_stream1(const LdsTable<1> &t, const uint64_t *__restrict__ keys /* bucket base */, uint32_t n,
                                                      uint32_t npass, uint32_t pass) {
   constexpr int CAP = TabCfg<1>::CAP;
@@ -1321,11 +1322,11 @@ __device__ __forceinline__ void table_insert_stream1(const LdsTable<1> &t, const
       slot[u] = slot_of(h, CAP);
       bool a = i0 + (uint32_t)u * NT + threadIdx.x < n;
       if (MULTI) a = a && (pass_of(h, npass) == pass);
-      const bool sp = k[u] == kEmptyKey;
+      const bool sp = SPECIAL && k[u] == kEmptyKey;
       actm |= (a && !sp) ? (1u << u) : 0u;
       spec += (a && sp) ? 1u : 0u;
     }
-    if (spec) { *t.special_set = 1; atomicAdd(t.special, spec); }   // the key that equals the empty marker (k-mers filling all 64 bits only)
+    if (SPECIAL && spec) { *t.special_set = 1; atomicAdd(t.special, spec); }   // the key that equals the empty marker
     uint64_t cur[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) cur[u] = __atomic_load_n(&t.keys[slot[u]], __ATOMIC_RELAXED);
@@ -1453,7 +1454,7 @@ __global__ __launch_bounds__((TabCfg<NW>::NT)) void bucket_reduce_kernel(const u
                                                                         const uint64_t *__restrict__ old_keys, const uint32_t *__restrict__ old_vals,
                                                                         const uint64_t *__restrict__ old_off, uint64_t *__restrict__ tmp_keys,
                                                                         uint32_t *__restrict__ tmp_vals, uint32_t *__restrict__ out_cnt,
-                                                                        uint32_t *__restrict__ flags) {
+                                                                        uint32_t *__restrict__ flags, bool full_word_keys) {
   KMI_TABLE_LDS(NW)
   const uint32_t b = blockIdx.x;
   const uint64_t nb = new_off[b], ne = new_off[b + 1];
@@ -1476,8 +1477,10 @@ __global__ __launch_bounds__((TabCfg<NW>::NT)) void bucket_reduce_kernel(const u
         else if (s == -2) atomicAdd(tab.special, old_vals[i]);
       });
       if constexpr (NW == 1) {
-        if (npass == 1) table_insert_stream1<kLoadBatch, false>(tab, new_keys + nb, (uint32_t)(ne - nb), 1u, 0u);
-        else table_insert_stream1<kLoadBatch, true>(tab, new_keys + nb, (uint32_t)(ne - nb), npass, pass);
+        if (npass == 1) {
+          if (full_word_keys) table_insert_stream1<kLoadBatch, false, true>(tab, new_keys + nb, (uint32_t)(ne - nb), 1u, 0u);
+          else table_insert_stream1<kLoadBatch, false, false>(tab, new_keys + nb, (uint32_t)(ne - nb), 1u, 0u);
+        } else table_insert_stream1<kLoadBatch, true>(tab, new_keys + nb, (uint32_t)(ne - nb), npass, pass);
       } else {
         for_each_key<NW, BatchOf<NW>::U>(new_keys, nb, ne, [&](const uint64_t (&k)[NW], uint64_t) {
           const uint32_t h = place_hash<NW>(k);
@@ -2022,7 +2025,8 @@ static kmi_status reduce_and_adopt(kmi_index *idx, const Partitioned &part, size
     ProfScope ps(ctx, "bucket_reduce", n);
     hipLaunchKernelGGL((bucket_reduce_kernel<NW>), dim3(kNumFine), dim3(TabCfg<NW>::NT), 0, ctx->stream, (const uint64_t *)part.keys,
                        (const uint64_t *)part.fine_off, (const uint64_t *)idx->keys, (const uint32_t *)idx->vals,
-                       (const uint64_t *)(idx->has_data ? idx->bucket_off : nullptr), tmp_keys, tmp_vals, out_cnt, ctx->d_flags);
+                       (const uint64_t *)(idx->has_data ? idx->bucket_off : nullptr), tmp_keys, tmp_vals, out_cnt, ctx->d_flags,
+                       idx->shape.n_bits == 64u * NW);
   }
   KMI_HIP(ctx, hipGetLastError());
   return adopt_tmp<NW>(idx, tmp_keys, tmp_vals, part.fine_off, idx->has_data ? idx->bucket_off : nullptr, out_cnt, fastq_verdict);
