@@ -1313,14 +1313,15 @@ __device__ __forceinline__ void table_insert_stream1(const LdsTable<1> &t, const
       r[u] = keys[i];
     }
   };
-  auto insert = [&](uint32_t i0, const uint64_t (&k)[U]) {
+  auto insert = [&](uint32_t i0, const uint64_t (&k)[U], auto full_tag) {   // full_tag: every key of the batch lies inside the bucket
+    constexpr bool FULL = decltype(full_tag)::value;
     uint32_t slot[U], actm = 0, spec = 0;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const uint64_t kk[1] = {k[u]};
       const uint32_t h = place_hash<1>(kk);
       slot[u] = slot_of(h, CAP);
-      bool a = i0 + (uint32_t)u * NT + threadIdx.x < n;
+      bool a = FULL || i0 + (uint32_t)u * NT + threadIdx.x < n;
       if (MULTI) a = a && (pass_of(h, npass) == pass);
       const bool sp = SPECIAL && k[u] == kEmptyKey;
       actm |= (a && !sp) ? (1u << u) : 0u;
@@ -1361,10 +1362,10 @@ __device__ __forceinline__ void table_insert_stream1(const LdsTable<1> &t, const
     }
     const bool has_b = i0 + STEP < n;
     if (has_b) load(i0 + STEP, kb);
-    insert(i0, ka);
+    if (i0 + STEP <= n) insert(i0, ka, std::true_type{}); else insert(i0, ka, std::false_type{});
     if (has_b) {
       if (i0 + 2 * STEP < n) load(i0 + 2 * STEP, ka);
-      insert(i0 + STEP, kb);
+      if (i0 + 2 * STEP <= n) insert(i0 + STEP, kb, std::true_type{}); else insert(i0 + STEP, kb, std::false_type{});
     }
   }
 }
