@@ -329,7 +329,9 @@ __device__ __forceinline__ void window_at(const uint32_t *s_stream, uint32_t pos
 // complement at the bottom -- no LDS reads, no group reversal and no 128-bit shifts after the first window.
 // HI: k >= 17 (the top code sits in the high word; k <= 16 runs on 32-bit registers). CANON: smaller of the two strands.
 // f(j, key) for the windows j < len (1 <= len <= 8) of the entry that starts at tile-image position pos.
-template <bool HI, bool CANON, typename F>
+// FULL: every lane's entry holds 8 windows (the rule for whole reads: the caller checks it for the wavefront), so the
+// per-window length tests and their exec-mask bookkeeping are left out.
+template <bool HI, bool CANON, bool FULL, typename F>
 __device__ __forceinline__ void roll_entry_windows(const uint32_t *s_stream, uint32_t pos, uint32_t len, const KShape &shape, F f) {
   const uint32_t bit = 2u * pos, d = bit >> 5, sh = bit & 31u;
   const uint64_t lo = (uint64_t)s_stream[d] | ((uint64_t)s_stream[d + 1] << 32);
@@ -350,7 +352,7 @@ __device__ __forceinline__ void roll_entry_windows(const uint32_t *s_stream, uin
     f(0u, key);
 #pragma unroll
     for (uint32_t j = 1; j < 8u; ++j) {
-      if (j < len) {
+      if (FULL || j < len) {
         const uint32_t b = (nb >> (2u * (j - 1u))) & 3u;
         rc = (rc >> 2) | ((uint64_t)(b << top) << 32);
         fw = ((fw << 2) | (uint64_t)(b ^ 3u)) & keep;
@@ -366,7 +368,7 @@ __device__ __forceinline__ void roll_entry_windows(const uint32_t *s_stream, uin
     f(0u, key);
 #pragma unroll
     for (uint32_t j = 1; j < 8u; ++j) {
-      if (j < len) {
+      if (FULL || j < len) {
         const uint32_t b = (nb >> (2u * (j - 1u))) & 3u;
         rc = (rc >> 2) | (b << top);
         fw = ((fw << 2) | (b ^ 3u)) & m32;

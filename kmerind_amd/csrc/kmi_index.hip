@@ -826,13 +826,15 @@ template <int NW, int BITS, typename F>
 __device__ __forceinline__ void for_entry_windows(const uint32_t *img, uint32_t pos, uint32_t len, const KShape &shape, bool canonical, F f) {
   using Cfg = ExCfg<NW, BITS>;
   if constexpr (NW == 1 && BITS == 2) {
-    // uniform dispatch: the rolled loop is specialised on the word the top code lives in and on the strand rule
+    // uniform dispatch: the rolled loop is specialised on the word the top code lives in, on the strand rule, and on
+    // whether every lane of the wavefront holds a full entry of 8 windows (whole reads: nearly always)
+    const bool full = __all(len == 8u);
     if (shape.k >= 17u) {
-      if (canonical) roll_entry_windows<true, true>(img, pos, len, shape, f);
-      else roll_entry_windows<true, false>(img, pos, len, shape, f);
+      if (canonical) { if (full) roll_entry_windows<true, true, true>(img, pos, len, shape, f); else roll_entry_windows<true, true, false>(img, pos, len, shape, f); }
+      else { if (full) roll_entry_windows<true, false, true>(img, pos, len, shape, f); else roll_entry_windows<true, false, false>(img, pos, len, shape, f); }
     } else {
-      if (canonical) roll_entry_windows<false, true>(img, pos, len, shape, f);
-      else roll_entry_windows<false, false>(img, pos, len, shape, f);
+      if (canonical) roll_entry_windows<false, true, false>(img, pos, len, shape, f);
+      else roll_entry_windows<false, false, false>(img, pos, len, shape, f);
     }
   } else {
 #pragma unroll
