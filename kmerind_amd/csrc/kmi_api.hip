@@ -90,7 +90,8 @@ __global__ __launch_bounds__(256) void kmer_array_op_kernel(const uint64_t *__re
       else if (dist_trans == KMI_DIST_XOR) { revcomp_words<NW, BITS>(k, r, shape);   // xor_rev_comp (kmer_transform.hpp:60-88)
 #pragma unroll
         for (int w = 0; w < NW; ++w) k[w] ^= r[w]; }
-      out32[i] = (uint32_t)(kmer_hash<NW>(k, shape, which, true, farm_ndebug, ceil_log2_u32(nranks)) % nranks);
+      const uint64_t h = kmer_hash<NW>(k, shape, which, true, farm_ndebug, ceil_log2_u32(nranks));
+      out32[i] = (nranks & (nranks - 1u)) == 0u ? (uint32_t)h & (nranks - 1u) : (uint32_t)(h % nranks);
     }
   }
 }

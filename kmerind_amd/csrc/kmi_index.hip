@@ -84,7 +84,9 @@ template <int NW> __device__ __forceinline__ uint32_t bucket_of(const uint64_t (
     }
     const uint64_t h = kmer_hash<NW>(t, f.shape, f.dist_hash, true, f.farm_ndebug, ceil_log2_u32(f.nranks));
     const uint32_t spread = (uint32_t)((h >> 40) ^ (h >> 13)) * 0x9E3779B1u;   // identity/std hashes have few high bits
-    return (uint32_t)(h % f.nranks) * f.sub + ((spread >> 16) & (f.sub - 1u));
+    // h % p: a 64-bit division by a run-time value is a hundred-odd instructions; 2, 4, 8 ... ranks take a mask instead
+    const uint32_t rank = (f.nranks & (f.nranks - 1u)) == 0u ? (uint32_t)h & (f.nranks - 1u) : (uint32_t)(h % f.nranks);   // uniform
+    return rank * f.sub + ((spread >> 16) & (f.sub - 1u));
   }
   uint32_t h = place_hash<NW>(key);
   return f.mode == BUCKET_COARSE ? coarse_of(h) : (fine_of(h) & (kSubPerCoarse - 1));
