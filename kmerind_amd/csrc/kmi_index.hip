@@ -64,7 +64,22 @@ struct BucketFn {
   int mode; KShape shape; uint32_t dist_hash; bool farm_ndebug; uint32_t nranks;
   uint32_t sub;   // rank mode: sub-buckets per rank (power of two, nranks * sub <= 256)
   uint32_t dist_trans = 0;   // rank mode: KMI_DIST_* applied to the key before DistHash (single-strand model only)
+  uint64_t rank_magic = 0;   // rank mode: floor(2^64 / nranks) for rank counts that are no power of two (rank_of_hash)
 };
+inline uint64_t rank_magic_of(uint32_t nranks) { return nranks > 1u ? (uint64_t)(((unsigned __int128)1 << 64) / nranks) : 0ull; }
+// h % p without a division: a mask for 2, 4, 8 ... ranks; else q = mulhi(h, floor(2^64 / p)) is the quotient or one
+// less, so one correction step gives the remainder (a 64-bit division by a run-time value is a hundred-odd instructions)
+__host__ __device__ inline uint32_t rank_of_hash(uint64_t h, uint32_t nranks, uint64_t magic) {
+  if ((nranks & (nranks - 1u)) == 0u) return (uint32_t)h & (nranks - 1u);   // uniform
+#if defined(__HIP_DEVICE_COMPILE__)
+  const uint64_t q = __umul64hi(h, magic);
+#else
+  const uint64_t q = (uint64_t)(((unsigned __int128)h * magic) >> 64);
+#endif
+  uint64_t r = h - q * nranks;
+  r = r >= nranks ? r - nranks : r;
+  return (uint32_t)r;
+}
 // Rank mode spreads every rank over `sub` buckets (bucket = rank * sub + a few high hash bits): the buckets of a rank
 // stay adjacent, so the output is still grouped by rank, but the per-tile LDS counters are 256 distinct addresses
 // instead of p hot ones (with p = 2..8 the same-address LDS atomics were the bottleneck of both rank kernels).
@@ -84,8 +99,7 @@ template <int NW> __device__ __forceinline__ uint32_t bucket_of(const uint64_t (
     }
     const uint64_t h = kmer_hash<NW>(t, f.shape, f.dist_hash, true, f.farm_ndebug, ceil_log2_u32(f.nranks));
     const uint32_t spread = (uint32_t)((h >> 40) ^ (h >> 13)) * 0x9E3779B1u;   // identity/std hashes have few high bits
-    // h % p: a 64-bit division by a run-time value is a hundred-odd instructions; 2, 4, 8 ... ranks take a mask instead
-    const uint32_t rank = (f.nranks & (f.nranks - 1u)) == 0u ? (uint32_t)h & (f.nranks - 1u) : (uint32_t)(h % f.nranks);   // uniform
+    const uint32_t rank = rank_of_hash(h, f.nranks, f.rank_magic);
     return rank * f.sub + ((spread >> 16) & (f.sub - 1u));
   }
   uint32_t h = place_hash<NW>(key);
@@ -2288,7 +2302,7 @@ static kmi_status route_vw(kmi_ctx *ctx, const kmi_config *cfg, KShape shape, co
   KMI_TRY(ws_get(ctx, WS_CURSOR, sizeof(uint64_t) * kPartGroups * kNumCoarse, &p)); uint64_t *wg_off = (uint64_t *)p;
   KMI_TRY(ws_get(ctx, WS_MISC, sizeof(uint64_t) * kNumCoarse * 2, &p)); uint64_t *cnt = (uint64_t *)p;
   BucketFn fn; fn.mode = BUCKET_RANK; fn.shape = shape; fn.dist_hash = cfg->dist_hash; fn.farm_ndebug = cfg->farm_ndebug != 0; fn.nranks = nranks;
-  fn.dist_trans = cfg->dist_trans;
+  fn.dist_trans = cfg->dist_trans; fn.rank_magic = rank_magic_of(nranks);
   fn.sub = rank_sub_buckets(nranks);
   const uint32_t nb = nranks * fn.sub;
   {
@@ -2344,7 +2358,7 @@ static kmi_status extract_route_impl(kmi_ctx *ctx, const kmi_config *cfg, KShape
   KMI_TRY(ws_get(ctx, WS_ENT_BKT, sizeof(uint64_t) * ((size_t)n_tiles * ListPassCfg<NW, BITS>::ent_stride(shape.k, split) + 64), &p));
   uint64_t *ent_bkt = (uint64_t *)p;
   BucketFn fn; fn.mode = BUCKET_RANK; fn.shape = shape; fn.dist_hash = cfg->dist_hash; fn.farm_ndebug = cfg->farm_ndebug != 0; fn.nranks = nranks;
-  fn.dist_trans = cfg->dist_trans;
+  fn.dist_trans = cfg->dist_trans; fn.rank_magic = rank_magic_of(nranks);
   fn.sub = rank_sub_buckets(nranks);
   const uint32_t nb = nranks * fn.sub;
   {
@@ -2387,7 +2401,7 @@ static kmi_status split_impl(kmi_index *idx, uint32_t nranks, uint64_t *out_keys
   KMI_TRY(ws_get(ctx, WS_SPLIT_OFF, sizeof(uint64_t) * ((size_t)nranks * (kNumFine + 1) + 2 * (kNumCoarse + 1)), &p));
   uint64_t *boff = (uint64_t *)p, *tot = boff + (size_t)nranks * (kNumFine + 1), *base = tot + kNumCoarse + 1;
   BucketFn fn; fn.mode = BUCKET_RANK; fn.shape = idx->shape; fn.dist_hash = idx->cfg.dist_hash; fn.farm_ndebug = idx->cfg.farm_ndebug != 0;
-  fn.dist_trans = idx->cfg.dist_trans;
+  fn.dist_trans = idx->cfg.dist_trans; fn.rank_magic = rank_magic_of(nranks);
   fn.nranks = nranks; fn.sub = 1;
   {
     ProfScope ps(ctx, "split_count", n);
