@@ -461,3 +461,21 @@ def test_exists_is_one_byte_per_input_key_in_input_order(ctx):
         want = np.array([int(x) in stored for x in tq], dtype=np.uint8)
         assert (idx.exists(q) == want).all()
         idx.close()
+
+
+def test_insert_of_already_transformed_keys(ctx):
+    """kmi_index_insert_transformed_dev: the local_insert half alone -- routed keys after the exchange are canonical already"""
+    import kmerind_amd as K
+    s = orc.kspec(31)
+    cfg = K.make_config(31, "DNA", strand="canonical")
+    ex = orc.extract(s, K.synth_fastq(seed=4, genome_len=5000, n_reads=800), orc.FASTQ)["kmers"]
+    tk = orc.canonical(s, ex)
+    d = ctx.alloc(tk.nbytes)
+    ctx.to_device(d, tk)
+    a, b = K.CountIndex(ctx, cfg), K.CountIndex(ctx, cfg)
+    a.insert_device(d, tk.shape[0], transformed=True)
+    b.insert(ex)
+    ctx.free(d)
+    pa, pb = orc.sorted_pairs(*a.to_vector()), orc.sorted_pairs(*b.to_vector())
+    assert pa[0].shape == pb[0].shape and (pa[0] == pb[0]).all() and (pa[1] == pb[1]).all()
+    a.close(); b.close()
