@@ -50,6 +50,24 @@ int main(int argc, char **argv) {
   const size_t s2 = build_size<bik::CountIndex<::dsc::counting_sorted_map<KmerType, uint32_t, SingleSorted>>>(file);
   const size_t b1 = build_size<bik::CountIndex<::dsc::counting_unordered_map<KmerType, uint32_t, BimolHash>>>(file);
   const size_t b2 = build_size<bik::CountIndex<::dsc::counting_sorted_map<KmerType, uint32_t, BimolSorted>>>(file);
+  // saturating_counting_densehash_map<..., uint8_t>: counts stop at 255 (a 2-mer index of this file has counts far above)
+  {
+    using K2 = ::bliss::common::Kmer<2, ::bliss::common::DNA, uint64_t>;
+    using Sp2 = ::bliss::kmer::hash::sparsehash::special_keys<K2, true>;
+    bik::CountIndex<::dsc::saturating_counting_densehash_map<K2, uint8_t, CanonHash, Sp2>> sat(::kmerind::comm(0));
+    bik::CountIndex<::dsc::counting_densehash_map<K2, uint32_t, CanonHash, Sp2>> plain(::kmerind::comm(0));
+    sat.template build_posix<::bliss::io::FASTQParser, ::bliss::io::SequencesIterator>(file);
+    plain.template build_posix<::bliss::io::FASTQParser, ::bliss::io::SequencesIterator>(file);
+    auto a = sat.to_vector();
+    auto b = plain.to_vector();
+    bool ok_sat = a.size() == b.size() && !a.empty();
+    size_t big = 0;
+    for (auto &e : b) {
+      for (auto &f : a) if (f.first == e.first) ok_sat = ok_sat && f.second == (e.second > 255u ? 255u : (uint8_t)e.second);
+      big += e.second > 255u;
+    }
+    if (!ok_sat || big == 0) { std::printf("saturating counts MISMATCH\n"); return 1; }
+  }
   const size_t p1 = build_size<bik::PositionIndex<::dsc::unordered_multimap<KmerType, IdType, CanonHash>>>(file);
   const size_t p2 = build_size<bik::PositionIndex<::dsc::densehash_multimap<KmerType, IdType, CanonHash, Special>>>(file);
   const size_t p3 = build_size<bik::PositionIndex<::dsc::sorted_multimap<KmerType, IdType, CanonSorted>>>(file);

@@ -24,6 +24,7 @@
 #include <cstdio>
 #include <cstring>
 #include <functional>
+#include <limits>
 #include <stdexcept>
 #include <string>
 #include <type_traits>
@@ -208,6 +209,13 @@ template <typename Key, typename T, template <typename> class MapParams>
 struct counting_unordered_map {
   using key_type = Key; using mapped_type = T; using params = MapParams<Key>;
   static constexpr uint32_t index_kind = KMI_INDEX_COUNT;
+  static constexpr bool saturating = false;   // std::plus<T>: a count type narrower than the device's 32 bits wraps
+};
+// saturating_counting_densehash_map (distributed_densehash_map.hpp:2903-2953, sat_plus<T>): counts stop at the largest T.
+// The device counts in 32 bits; what a caller reads is min(count, max(T)), which is what a chain of sat_plus(+1) gives.
+template <typename Key, typename T, template <typename> class MapParams, typename SpecialKeys = void>
+struct saturating_counting_densehash_map : counting_unordered_map<Key, T, MapParams> {
+  static constexpr bool saturating = true;
 };
 template <typename Key, typename T, template <typename> class MapParams, typename SpecialKeys = void>
 struct counting_densehash_map : counting_unordered_map<Key, T, MapParams> {};
@@ -216,6 +224,7 @@ template <typename Key, typename T, template <typename> class MapParams>
 struct unordered_multimap {
   using key_type = Key; using mapped_type = T; using params = MapParams<Key>;
   static constexpr uint32_t index_kind = KMI_INDEX_POSITION;
+  static constexpr bool saturating = false;
   static_assert(sizeof(T) == sizeof(uint64_t), "position ids are one 64-bit word");
 };
 template <typename Key, typename T, template <typename> class MapParams, typename SpecialKeys = void>
@@ -312,6 +321,12 @@ inline uint32_t format_of(const std::string &filename) {  // kmer_index.hpp:243-
   throw std::invalid_argument("input filename extension is not supported.");
 }
 template <typename V> typename std::enable_if<std::is_arithmetic<V>::value, V>::type value_of(uint64_t w) { return (V)w; }
+// the stored count as the map's mapped_type: wrapped (std::plus) or stopped at the type's maximum (sat_plus)
+template <typename MapType, typename V> typename std::enable_if<std::is_arithmetic<V>::value, V>::type count_of(uint64_t w) {
+  if (MapType::saturating && w > (uint64_t)std::numeric_limits<V>::max()) return std::numeric_limits<V>::max();
+  return (V)w;
+}
+template <typename MapType, typename V> typename std::enable_if<!std::is_arithmetic<V>::value, V>::type count_of(uint64_t w) { return V((size_t)w); }
 template <typename V> typename std::enable_if<!std::is_arithmetic<V>::value, V>::type value_of(uint64_t w) { return V((size_t)w); }
 template <typename Kmer> const uint64_t *words_of(const std::vector<Kmer> &v) { return reinterpret_cast<const uint64_t *>(v.data()); }
 template <typename Kmer, typename T> std::vector<uint64_t> words_of_pairs(const std::vector<std::pair<Kmer, T>> &v) {
@@ -390,7 +405,7 @@ class Index {
     std::vector<uint64_t> q = route_queries(query);
     ::kmerind::check(ctx, kmi_index_find_host(idx, q.data(), q.size() / KmerType::nWords, &r));
     std::vector<TupleType> out(r.n);
-    for (uint64_t i = 0; i < r.n; ++i) out[i] = std::make_pair(KmerType(r.keys + i * KmerType::nWords), detail::value_of<ValueType>(r.values[i]));
+    for (uint64_t i = 0; i < r.n; ++i) out[i] = std::make_pair(KmerType(r.keys + i * KmerType::nWords), detail::count_of<MapType, ValueType>(r.values[i]));
     kmi_results_free(&r);
     return out;
   }
@@ -447,7 +462,7 @@ class Index {
     std::vector<uint32_t> cnt(n + 1);
     ::kmerind::check(ctx, kmi_index_export_host(idx, keys.data(), cnt.data(), n, &got));
     std::vector<TupleType> out(got);
-    for (uint64_t i = 0; i < got; ++i) out[i] = std::make_pair(KmerType(&keys[i * KmerType::nWords]), detail::value_of<ValueType>(cnt[i]));
+    for (uint64_t i = 0; i < got; ++i) out[i] = std::make_pair(KmerType(&keys[i * KmerType::nWords]), detail::count_of<MapType, ValueType>(cnt[i]));
     return out;
   }
 
