@@ -57,6 +57,36 @@ def exchange_keys(send, send_counts, group=None):
     return recv, recv_counts
 
 
+def _a2a_rows_in_order(a2a, send, sc, rc, pieces):
+    """all-to-all of row blocks (send grouped by destination, sc / rc rows per peer) that keeps every source's rows
+    contiguous and in order in the result even when the peer messages travel in `pieces` pieces (the same number on every
+    rank; the RCCL build of this image moves at most 2^27 elements per message correctly)"""
+    world = len(sc)
+    out = torch.empty((int(sum(rc)),) + tuple(send.shape[1:]), dtype=send.dtype, device=send.device)
+    if pieces <= 1:
+        a2a(out, send, output_split_sizes=rc, input_split_sizes=sc)
+        return out
+    s_off, r_off = [0], [0]
+    for c in sc:
+        s_off.append(s_off[-1] + c)
+    for c in rc:
+        r_off.append(r_off[-1] + c)
+    for p in range(pieces):
+        lo = [(c * p) // pieces for c in sc]
+        hi = [(c * (p + 1)) // pieces for c in sc]
+        rlo = [(c * p) // pieces for c in rc]
+        rhi = [(c * (p + 1)) // pieces for c in rc]
+        chunk = torch.cat([send[s_off[r] + lo[r]: s_off[r] + hi[r]] for r in range(world)])
+        out_split = [rhi[r] - rlo[r] for r in range(world)]
+        tmp = torch.empty((int(sum(out_split)),) + tuple(send.shape[1:]), dtype=send.dtype, device=send.device)
+        a2a(tmp, chunk, output_split_sizes=out_split, input_split_sizes=[hi[r] - lo[r] for r in range(world)])
+        pos = 0
+        for src in range(world):                                # piece p of source src goes behind its earlier pieces
+            out[r_off[src] + rlo[src]: r_off[src] + rhi[src]] = tmp[pos:pos + out_split[src]]
+            pos += out_split[src]
+    return out
+
+
 def exchange_pairs(keys, counts, bucket_counts, group=None, stage_through_host=False):
     """The exchange of the combine-first count insert (kmerind_hip.h, kmi_index_split_by_rank_dev): keys int64 [n, n_words]
     and counts int32 [n] grouped by destination rank, bucket_counts int32 [world, B] (row r describes the message to
@@ -80,22 +110,19 @@ def exchange_pairs(keys, counts, bucket_counts, group=None, stage_through_host=F
     sc = [int(x) for x in bucket_counts.to(torch.int64).sum(dim=1).tolist()]
     rc = [int(x) for x in rb.to(torch.int64).sum(dim=1).tolist()]
     assert sum(sc) == keys.shape[0]
-    if max(sc + rc) * keys.shape[1] > MSG_MAX_WORDS:
-        raise RuntimeError("a peer message of %d pairs exceeds what this RCCL build moves correctly" % max(sc + rc))
-    n_in = sum(rc)
-    rk = torch.empty((n_in, keys.shape[1]), dtype=keys.dtype, device=dev)
-    a2a(rk, keys, output_split_sizes=rc, input_split_sizes=sc)
+    # messages above the RCCL limit travel in pieces; the piece count must agree on all ranks
+    biggest = torch.tensor([max(sc + rc + [0])], dtype=torch.int64, device=cdev)
+    dist.all_reduce(biggest, op=dist.ReduceOp.MAX, group=group)
+    pieces = max(1, -(-int(biggest.item()) * keys.shape[1] // MSG_MAX_WORDS))
+    rk = _a2a_rows_in_order(a2a, keys, sc, rc, pieces)
     # counts of one rank's own reads are small: when every rank's fit a byte they travel as bytes (9 instead of 12 bytes
     # per pair on the link)
     big = torch.tensor([int(counts.max().item()) if counts.numel() else 0], dtype=torch.int64, device=cdev)
     dist.all_reduce(big, op=dist.ReduceOp.MAX, group=group)
     if int(big.item()) <= 255:
-        rv8 = torch.empty((n_in,), dtype=torch.uint8, device=dev)
-        a2a(rv8, counts.to(torch.uint8), output_split_sizes=rc, input_split_sizes=sc)
-        rv = rv8.to(counts.dtype)
+        rv = _a2a_rows_in_order(a2a, counts.to(torch.uint8), sc, rc, pieces).to(counts.dtype)
     else:
-        rv = torch.empty((n_in,), dtype=counts.dtype, device=dev)
-        a2a(rv, counts, output_split_sizes=rc, input_split_sizes=sc)
+        rv = _a2a_rows_in_order(a2a, counts, sc, rc, pieces)
     return rk, rv, rb
 
 

@@ -75,12 +75,14 @@ def test_sharded_build_over_gloo_matches_single_rank(world, msg_max):
         assert ret[r][3] == [ret[src][4][r] for src in range(world)]
 
 
-def _pairs_worker(rank, world, port, data, k, nb, ret):
+def _pairs_worker(rank, world, port, data, k, nb, ret, msg_max=None):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from kmerind_amd import dist as kdist
         from kmerind_amd import fileio
+        if msg_max:
+            kdist.MSG_MAX_WORDS = msg_max      # force the piecewise exchange
         s = orc.kspec(k)
         b, e = fileio.partition_fastq(data, world)[rank]
         m = orc.CountMap(s, orc.CANONICAL)                          # the rank's local reduction
@@ -98,8 +100,8 @@ def _pairs_worker(rank, world, port, data, k, nb, ret):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_combine_first_exchange_over_gloo(world):
+@pytest.mark.parametrize("world,msg_max", [(2, None), (3, None), (2, 700)])
+def test_combine_first_exchange_over_gloo(world, msg_max):
     """exchange_pairs: the (k-mer, count) messages and the bucket-count matrix of the combine-first count insert. Row s of what
     rank r receives is row r of what rank s sent; every part is still ordered by bucket; summing the received counts per key
     gives the single-rank map."""
@@ -108,7 +110,7 @@ def test_combine_first_exchange_over_gloo(world):
     data = bytes(K.synth_fastq(seed=5, genome_len=5_000, n_reads=900))
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_pairs_worker, args=(world, _free_port(), data, k, nb, ret), nprocs=world, join=True)
+    mp.spawn(_pairs_worker, args=(world, _free_port(), data, k, nb, ret, msg_max), nprocs=world, join=True)   # msg_max: several pieces per message
     s = orc.kspec(k)
     ref = orc.CountMap(s, orc.CANONICAL)
     ref.insert(orc.extract(s, data, orc.FASTQ)["kmers"])
