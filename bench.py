@@ -56,7 +56,7 @@ def main():
     ap.add_argument("--dist-mode", default="auto", choices=["auto", "combine", "raw"],
                     help="N > 1: 'combine' reduces the rank's own reads first and exchanges (k-mer, count) pairs; 'raw' routes "
                          "every k-mer occurrence as the reference does (kmi_extract_route_dev + insert); 'auto' combines when the "
-                         "rank's own reads cover the genome at least 4 times (the pairs are then a fraction of the occurrences)")
+                         "rank's own reads cover the genome at least 2.5 times (the pairs are then a fraction of the occurrences)")
     ap.add_argument("--force-dist", action="store_true",
                     help="run the N > 1 code path (routing + all_to_all_single + insert) even with one rank: exercises the RCCL calls on one GPU")
     ap.add_argument("--chunks", type=int, default=4, help="N > 1: chunks per step (exchange of one overlaps parsing of the next)")
@@ -109,7 +109,7 @@ def main():
 
     # expected k-mer coverage of the genome by ONE rank's reads: what a local reduction can take out before the exchange
     local_cov = n_kmers / float(genome_len)
-    dist_mode = args.dist_mode if args.dist_mode != "auto" else ("combine" if local_cov >= 4.0 else "raw")
+    dist_mode = args.dist_mode if args.dist_mode != "auto" else ("combine" if local_cov >= 2.5 else "raw")
     combine = multi and dist_mode == "combine"
     nch = 1
     if combine:
