@@ -1312,9 +1312,12 @@ __device__ __forceinline__ uint32_t pass_of(uint32_t h, uint32_t npass) {
 // The walk is the expensive part (every step is a full wave instruction sequence for the few lanes that
 // still probe), hence no wrap-around, no probe counter and no bounds test inside it (see TabCfg).
 // SPECIAL: the keys can equal the empty marker (only k-mers that fill all 64 bits can); otherwise that test is left out
-template <int U, bool MULTI, bool SPECIAL = true>
+// SPILL (with MULTI): the keys of later passes are written, compacted, to `spill` (spill[0], spill[dir], spill[2 dir] ...;
+// *spill_cnt counts them), so the next pass reads only what is left instead of filtering the whole stream again
+template <int U, bool MULTI, bool SPECIAL = true, bool SPILL = false>
 __device__ __forceinline__ void table_insert_stream1(const LdsTable<1> &t, const uint64_t *__restrict__ keys /* bucket base */, uint32_t n,
-                                                     uint32_t npass, uint32_t pass) {
+                                                     uint32_t npass, uint32_t pass, uint64_t *spill = nullptr, int spill_dir = 1,
+                                                     uint32_t *spill_cnt = nullptr) {
   constexpr int CAP = TabCfg<1>::CAP;
   constexpr uint32_t LAST = TabCfg<1>::SLOTS - 1;
   constexpr uint32_t NT = TabCfg<1>::NT;
@@ -1340,7 +1343,15 @@ __device__ __forceinline__ void table_insert_stream1(const LdsTable<1> &t, const
       const uint32_t h = place_hash<1>(kk);
       slot[u] = slot_of(h, CAP);
       bool a = FULL || i0 + (uint32_t)u * NT + threadIdx.x < n;
-      if (MULTI) a = a && (pass_of(h, npass) == pass);
+      if (MULTI) {
+        const bool mine = pass_of(h, npass) == pass;
+        if (SPILL) {   // wave-uniform call: one LDS add per wavefront
+          const bool later = a && !mine;
+          const uint32_t pos = wave_alloc(spill_cnt, later);
+          if (later) spill[(long long)pos * spill_dir] = k[u];
+        }
+        a = a && mine;
+      }
       const bool sp = SPECIAL && k[u] == kEmptyKey;
       actm |= (a && !sp) ? (1u << u) : 0u;
       spec += (a && sp) ? 1u : 0u;
@@ -1473,7 +1484,8 @@ __global__ __launch_bounds__((TabCfg<NW>::NT)) void bucket_reduce_kernel(const u
                                                                         const uint64_t *__restrict__ old_keys, const uint32_t *__restrict__ old_vals,
                                                                         const uint64_t *__restrict__ old_off, uint64_t *__restrict__ tmp_keys,
                                                                         uint32_t *__restrict__ tmp_vals, uint32_t *__restrict__ out_cnt,
-                                                                        uint32_t *__restrict__ flags, bool full_word_keys) {
+                                                                        uint32_t *__restrict__ flags, bool full_word_keys,
+                                                                        uint64_t *scratch /* as large as new_keys and free, or null */) {
   KMI_TABLE_LDS(NW)
   const uint32_t b = blockIdx.x;
   const uint64_t nb = new_off[b], ne = new_off[b + 1];
@@ -1481,12 +1493,21 @@ __global__ __launch_bounds__((TabCfg<NW>::NT)) void bucket_reduce_kernel(const u
   if (nb == ne && ob == oe) { if (threadIdx.x == 0) out_cnt[b] = 0; return; }
   const uint64_t tmp0 = nb + ob;
   uint32_t *s_out = &s_ctl[4];
+  uint32_t *s_spill = &s_ctl[6];
   uint32_t npass = 1;
   while (true) {
     if (threadIdx.x == 0) *s_out = 0;
     bool failed = false;
+    // several passes (NW == 1): every pass but the last writes the keys of the later passes, compacted, to a list the next
+    // pass reads instead of the whole bucket. The lists alternate between the bucket's range of `scratch` (upwards) and the
+    // top of its range of tmp_keys (downwards: entries emitted plus keys still to do never exceed the bucket's keys, and a
+    // pass emits only after it has read its stream). new_keys stays intact for a restart with more passes.
+    const uint64_t *src = new_keys + nb * NW;
+    uint32_t n_src = (uint32_t)(ne - nb);
+    uint32_t pass_len = n_src;   // keys the pass in work was given (for the pass-count estimate when it overflows)
     for (uint32_t pass = 0; pass < npass && !failed; ++pass) {
       table_clear<NW>(tab);
+      if (threadIdx.x == 0) *s_spill = 0;
       lds_barrier();
       for_each_key<NW, BatchOf<NW>::U>(old_keys, ob, oe, [&](const uint64_t (&k)[NW], uint64_t i) {
         const uint32_t h = place_hash<NW>(k);
@@ -1499,7 +1520,21 @@ __global__ __launch_bounds__((TabCfg<NW>::NT)) void bucket_reduce_kernel(const u
         if (npass == 1) {
           if (full_word_keys) table_insert_stream1<kLoadBatch, false, true>(tab, new_keys + nb, (uint32_t)(ne - nb), 1u, 0u);
           else table_insert_stream1<kLoadBatch, false, false>(tab, new_keys + nb, (uint32_t)(ne - nb), 1u, 0u);
-        } else table_insert_stream1<kLoadBatch, true>(tab, new_keys + nb, (uint32_t)(ne - nb), npass, pass);
+        } else if (scratch == nullptr) {
+          table_insert_stream1<kLoadBatch, true>(tab, new_keys + nb, (uint32_t)(ne - nb), npass, pass);
+        } else if (pass + 1u < npass) {
+          const bool up = (pass & 1u) == 0u;
+          uint64_t *spill = up ? scratch + nb : tmp_keys + tmp0 + (ne - nb) + (oe - ob) - 1u;
+          pass_len = n_src;
+          table_insert_stream1<kLoadBatch, true, true, true>(tab, src, n_src, npass, pass, spill, up ? 1 : -1, s_spill);
+          __syncthreads();   // workgroup-scope release / acquire: the list is read by other lanes of this workgroup in the next
+                             // pass (a device-scope fence here would write the XCD's L2 back once per bucket and pass)
+          n_src = *s_spill;
+          src = up ? spill : spill - (n_src ? n_src - 1u : 0u);
+        } else {
+          pass_len = n_src;
+          table_insert_stream1<kLoadBatch, false, true>(tab, src, n_src, 1u, 0u);   // what is left belongs to the last pass
+        }
       } else {
         for_each_key<NW, BatchOf<NW>::U>(new_keys, nb, ne, [&](const uint64_t (&k)[NW], uint64_t) {
           const uint32_t h = place_hash<NW>(k);
@@ -1532,7 +1567,9 @@ __global__ __launch_bounds__((TabCfg<NW>::NT)) void bucket_reduce_kernel(const u
       // how many passes next: the table held LIMIT distinct keys of this pass after `progress` of the bucket's n stream keys
       // (known to one load step), so the pass's share of the stream needs about n / progress tables; a third on top for
       // the spread between passes. Without that knowledge (the old entries alone overflowed) the count doubles.
-      const uint32_t n_new = (uint32_t)(ne - nb), prog = *tab.progress;
+      // (a later pass reads a list of the keys of the passes from it on: its share of that list fills the table after
+      // `progress` of pass_len keys just as a share of the whole bucket would, so the same ratio scales the pass count)
+      const uint32_t n_new = pass_len, prog = *tab.progress;
       uint32_t want = npass * 2u;
       if (NW == 1 && prog > 0u && n_new > 0u) {
         const uint32_t seen = prog > 12288u ? prog - 8192u : prog / 2u + 2048u;   // the overflow came somewhere inside the last step
@@ -1910,6 +1947,7 @@ namespace kmi {
 struct Partitioned {
   uint64_t *keys;      // fine-partitioned keys (WS_KEYS_B or WS_QUERY_B)
   uint64_t *fine_off;  // [kNumFine+1]
+  uint64_t *scratch = nullptr;   // the other partition buffer (free once the keys sit in `keys`): pass lists of bucket_reduce
 };
 
 struct PartWs {
@@ -1975,6 +2013,7 @@ static kmi_status partition_impl(kmi_ctx *ctx, const kmi_config *cfg, KShape sha
   }
   KMI_HIP(ctx, hipGetLastError());
   out->keys = w.buf_b; out->fine_off = w.fine_off;
+  out->scratch = (NW == 1 && VW == 0) ? w.buf_a : nullptr;
   return KMI_OK;
 }
 
@@ -2045,7 +2084,7 @@ static kmi_status reduce_and_adopt(kmi_index *idx, const Partitioned &part, size
     hipLaunchKernelGGL((bucket_reduce_kernel<NW>), dim3(kNumFine), dim3(TabCfg<NW>::NT), 0, ctx->stream, (const uint64_t *)part.keys,
                        (const uint64_t *)part.fine_off, (const uint64_t *)idx->keys, (const uint32_t *)idx->vals,
                        (const uint64_t *)(idx->has_data ? idx->bucket_off : nullptr), tmp_keys, tmp_vals, out_cnt, ctx->d_flags,
-                       idx->shape.n_bits == 64u * NW);
+                       idx->shape.n_bits == 64u * NW, part.scratch);
   }
   KMI_HIP(ctx, hipGetLastError());
   return adopt_tmp<NW>(idx, tmp_keys, tmp_vals, part.fine_off, idx->has_data ? idx->bucket_off : nullptr, out_cnt, fastq_verdict);
@@ -2119,7 +2158,7 @@ static kmi_status build_fused_impl(kmi_index *idx, const uint8_t *bytes_dev, siz
                          (uint32_t)fused_groups<NW>());
   }
   KMI_HIP(ctx, hipGetLastError());
-  Partitioned part; part.keys = w.buf_b; part.fine_off = w.fine_off;
+  Partitioned part; part.keys = w.buf_b; part.fine_off = w.fine_off; part.scratch = (NW == 1) ? w.buf_a : nullptr;
   return reduce_and_adopt<NW>(idx, part, (size_t)n, true);
 }
 
