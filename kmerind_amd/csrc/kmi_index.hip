@@ -1314,10 +1314,13 @@ __device__ __forceinline__ uint32_t pass_of(uint32_t h, uint32_t npass) {
 // SPECIAL: the keys can equal the empty marker (only k-mers that fill all 64 bits can); otherwise that test is left out
 // SPILL (with MULTI): the keys of later passes are written, compacted, to `spill` (spill[0], spill[dir], spill[2 dir] ...;
 // *spill_cnt counts them), so the next pass reads only what is left instead of filtering the whole stream again
-template <int U, bool MULTI, bool SPECIAL = true, bool SPILL = false>
+// CHECK (first attempt at a bucket with nothing to merge): after the first load step the workgroup meets once, and if the
+// distinct keys seen so far say the bucket will not fit one table (occupancy: d of D keys after n draws = D (1 - e^(-n/D))),
+// the attempt ends there with the pass count to use in *hint, instead of filling the table before it fails.
+template <int U, bool MULTI, bool SPECIAL = true, bool SPILL = false, bool CHECK = false>
 __device__ __forceinline__ void table_insert_stream1(const LdsTable<1> &t, const uint64_t *__restrict__ keys /* bucket base */, uint32_t n,
                                                      uint32_t npass, uint32_t pass, uint64_t *spill = nullptr, int spill_dir = 1,
-                                                     uint32_t *spill_cnt = nullptr) {
+                                                     uint32_t *spill_cnt = nullptr, uint32_t *hint = nullptr) {
   constexpr int CAP = TabCfg<1>::CAP;
   constexpr uint32_t LAST = TabCfg<1>::SLOTS - 1;
   constexpr uint32_t NT = TabCfg<1>::NT;
@@ -1385,13 +1388,36 @@ __device__ __forceinline__ void table_insert_stream1(const LdsTable<1> &t, const
   uint64_t ka[U], kb[U];
   load(0u, ka);
   for (uint32_t i0 = 0; i0 < n; i0 += 2 * STEP) {
-    if (__atomic_load_n(t.overflow, __ATOMIC_RELAXED)) {        // this pass is lost already: stop filling the table
+    // (with CHECK every wave must reach the two barriers of the first step, whatever another wave has flagged by then)
+    if (!(CHECK && i0 == 0u) && __atomic_load_n(t.overflow, __ATOMIC_RELAXED)) {   // this pass is lost already: stop filling the table
       if (lane_id() == 0) atomicMax(t.progress, i0);
       break;
     }
     const bool has_b = i0 + STEP < n;
     if (has_b) load(i0 + STEP, kb);
     if (i0 + STEP <= n) insert(i0, ka, std::true_type{}); else insert(i0, ka, std::false_type{});
+    if (CHECK && i0 == 0u && n > 2u * STEP) {   // uniform; every wave is here (nothing sets the overflow flag before the first step is in)
+      // a bucket of exactly LIMIT keys shows 5510 +- 29 distinct ones after the first 8192 draws
+      constexpr uint32_t kFits = 5580u;
+      static_assert(STEP == 8192u && TabCfg<1>::LIMIT == 9600, "kFits belongs to this step and limit");
+      lds_barrier();
+      if (threadIdx.x == 0) {
+        const uint32_t d1 = *t.distinct;
+        if (d1 >= kFits) {
+          const float r = (float)d1 / (float)STEP;           // (1 - e^-x) / x with x = STEP / D
+          float x = fmaxf(2.f * (1.f - r), 1e-4f);
+          for (int it = 0; it < 4; ++it) {
+            const float e = __expf(-x), g = (1.f - e) / x - r, dg = (e * (x + 1.f) - 1.f) / (x * x);
+            x = fmaxf(x - g / dg, 1e-4f);
+          }
+          const float D = (float)STEP / x, dn = D * (1.f - __expf(-(float)n / D));   // distinct keys among all n
+          const float want = ceilf(dn * 1.15f / (float)TabCfg<1>::LIMIT);
+          *hint = want < 2.f ? 2u : (want > 65536.f ? 65536u : (uint32_t)want);
+        }
+      }
+      lds_barrier();
+      if (*hint) return;   // written only between the two barriers: the same for every lane
+    }
     if (has_b) {
       if (i0 + 2 * STEP < n) load(i0 + 2 * STEP, ka);
       if (i0 + 2 * STEP <= n) insert(i0 + STEP, kb, std::true_type{}); else insert(i0 + STEP, kb, std::false_type{});
@@ -1494,7 +1520,13 @@ __global__ __launch_bounds__((TabCfg<NW>::NT)) void bucket_reduce_kernel(const u
   const uint64_t tmp0 = nb + ob;
   uint32_t *s_out = &s_ctl[4];
   uint32_t *s_spill = &s_ctl[6];
+  uint32_t *s_hint = &s_ctl[7];
   uint32_t npass = 1;
+  // The fit check of the first attempt (CHECK) costs two workgroup barriers per bucket, 7 % of this kernel on input
+  // that never needs it, so it is switched on by the first bucket of the launch that overflows (flags[8], cleared by
+  // the host before the launch): sequencing data at coverage never pays it, a genome or a thin sample pays one lost
+  // attempt per CU and then checks.
+  const bool check_on = (NW == 1) && __hip_atomic_load(&flags[8], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
   while (true) {
     if (threadIdx.x == 0) *s_out = 0;
     bool failed = false;
@@ -1507,7 +1539,7 @@ __global__ __launch_bounds__((TabCfg<NW>::NT)) void bucket_reduce_kernel(const u
     uint32_t pass_len = n_src;   // keys the pass in work was given (for the pass-count estimate when it overflows)
     for (uint32_t pass = 0; pass < npass && !failed; ++pass) {
       table_clear<NW>(tab);
-      if (threadIdx.x == 0) *s_spill = 0;
+      if (threadIdx.x == 0) { *s_spill = 0; *s_hint = 0; }
       lds_barrier();
       for_each_key<NW, BatchOf<NW>::U>(old_keys, ob, oe, [&](const uint64_t (&k)[NW], uint64_t i) {
         const uint32_t h = place_hash<NW>(k);
@@ -1517,7 +1549,10 @@ __global__ __launch_bounds__((TabCfg<NW>::NT)) void bucket_reduce_kernel(const u
         else if (s == -2) atomicAdd(tab.special, old_vals[i]);
       });
       if constexpr (NW == 1) {
-        if (npass == 1) {
+        if (npass == 1 && ob == oe && check_on) {   // nothing to merge: the first load step tells whether the bucket fits (CHECK)
+          if (full_word_keys) table_insert_stream1<kLoadBatch, false, true, false, true>(tab, new_keys + nb, (uint32_t)(ne - nb), 1u, 0u, nullptr, 1, nullptr, s_hint);
+          else table_insert_stream1<kLoadBatch, false, false, false, true>(tab, new_keys + nb, (uint32_t)(ne - nb), 1u, 0u, nullptr, 1, nullptr, s_hint);
+        } else if (npass == 1) {
           if (full_word_keys) table_insert_stream1<kLoadBatch, false, true>(tab, new_keys + nb, (uint32_t)(ne - nb), 1u, 0u);
           else table_insert_stream1<kLoadBatch, false, false>(tab, new_keys + nb, (uint32_t)(ne - nb), 1u, 0u);
         } else if (scratch == nullptr) {
@@ -1544,7 +1579,7 @@ __global__ __launch_bounds__((TabCfg<NW>::NT)) void bucket_reduce_kernel(const u
         });
       }
       lds_barrier();
-      if (*tab.overflow) { failed = true; break; }
+      if (*tab.overflow || (NW == 1 && *s_hint)) { failed = true; break; }
       for (int s = threadIdx.x; s < TabCfg<NW>::SLOTS; s += blockDim.x) {
         const bool used = slot_used<NW>(tab, s);
         const uint32_t pos = wave_alloc(s_out, used);
@@ -1569,9 +1604,11 @@ __global__ __launch_bounds__((TabCfg<NW>::NT)) void bucket_reduce_kernel(const u
       // the spread between passes. Without that knowledge (the old entries alone overflowed) the count doubles.
       // (a later pass reads a list of the keys of the passes from it on: its share of that list fills the table after
       // `progress` of pass_len keys just as a share of the whole bucket would, so the same ratio scales the pass count)
-      const uint32_t n_new = pass_len, prog = *tab.progress;
+      const uint32_t n_new = pass_len, prog = *tab.progress, hinted = (NW == 1) ? *s_hint : 0u;
       uint32_t want = npass * 2u;
-      if (NW == 1 && prog > 0u && n_new > 0u) {
+      if (NW == 1 && npass == 1u && !check_on && threadIdx.x == 0) atomicOr(&flags[8], 1u);   // later buckets of this launch check
+      if (hinted) want = hinted;   // the first load step already told (CHECK)
+      else if (NW == 1 && prog > 0u && n_new > 0u) {
         const uint32_t seen = prog > 12288u ? prog - 8192u : prog / 2u + 2048u;   // the overflow came somewhere inside the last step
         const uint64_t est = ((uint64_t)npass * n_new * 4u + 3ull * seen - 1ull) / (3ull * seen);
         want = est > (uint64_t)kMaxPasses ? kMaxPasses : (uint32_t)est;
@@ -2079,6 +2116,7 @@ static kmi_status reduce_and_adopt(kmi_index *idx, const Partitioned &part, size
   KMI_TRY(ws_get(ctx, WS_TMP_KEYS, cap * NW * sizeof(uint64_t), &p)); uint64_t *tmp_keys = (uint64_t *)p;
   KMI_TRY(ws_get(ctx, WS_TMP_VALS, cap * sizeof(uint32_t), &p)); uint32_t *tmp_vals = (uint32_t *)p;
   KMI_TRY(ws_get(ctx, WS_BUCKET_CNT, sizeof(uint32_t) * kNumFine, &p)); uint32_t *out_cnt = (uint32_t *)p;
+  KMI_HIP(ctx, hipMemsetAsync(ctx->d_flags + 8, 0, sizeof(uint32_t), ctx->stream));   // "a bucket overflowed" (bucket_reduce_kernel)
   {
     ProfScope ps(ctx, "bucket_reduce", n);
     hipLaunchKernelGGL((bucket_reduce_kernel<NW>), dim3(kNumFine), dim3(TabCfg<NW>::NT), 0, ctx->stream, (const uint64_t *)part.keys,
