@@ -377,6 +377,58 @@ def test_bucket_with_more_distinct_keys_than_the_lds_table_takes_more_passes(ctx
     idx.close()
 
 
+@pytest.mark.parametrize("n_hot,p", [(30_000, 1), (30_000, 3)])
+def test_merge_of_parts_with_more_distinct_keys_per_bucket_than_the_lds_table(ctx, n_hot, p):
+    """combine-first at low coverage: a placement bucket of the parts holds more distinct keys than one LDS table takes, so
+    bucket_merge runs in passes. Two source ranks' indexes (overlapping hot keys) are split for p destinations and every
+    destination merges what it is sent, twice (the second merge meets the big bucket in the index)."""
+    import kmerind_amd as K
+    cfg = K.make_config(31, "DNA", strand="single")
+    s = orc.kspec(31, ALPHA["DNA"])
+    nb = K.core.num_buckets()
+    rng = np.random.default_rng(21)
+    hot = _keys_in_one_placement_bucket(n_hot, bucket=777)
+    dest = [K.CountIndex(ctx, cfg) for _ in range(p)]
+    ref = {}
+    for rnd in range(2):
+        msgs = [[None, None] for _ in range(p)]
+        for src in range(2):
+            mine = hot[rng.random(hot.size) < 0.8]
+            keys = np.concatenate([np.repeat(mine, rng.integers(1, 4, size=mine.size)), rng.integers(0, 1 << 62, size=50_000, dtype=np.uint64)])
+            uk, uc = np.unique(keys, return_counts=True)
+            for a, b in zip(uk.tolist(), uc.tolist()):
+                ref[a] = ref.get(a, 0) + b
+            loc = K.CountIndex(ctx, cfg)
+            loc.insert(keys.reshape(-1, 1))
+            n = loc.local_size()
+            dk, dc, db = ctx.alloc(n * 8 + 64), ctx.alloc(n * 4 + 64), ctx.alloc(p * nb * 4)
+            sc = loc.split_by_rank_device(p, dk, dc, n, db)
+            ok, oc, ob = np.zeros((n, 1), np.uint64), np.zeros(n, np.uint32), np.zeros((p, nb), np.uint32)
+            ctx.to_host(ok, dk); ctx.to_host(oc, dc); ctx.to_host(ob, db)
+            ctx.free(dk); ctx.free(dc); ctx.free(db)
+            loc.close()
+            off = 0
+            for d in range(p):
+                msgs[d][src] = (ok[off:off + int(sc[d])], oc[off:off + int(sc[d])], ob[d])
+                off += int(sc[d])
+        for d in range(p):
+            mk = np.concatenate([m[0] for m in msgs[d]]); mc = np.concatenate([m[1] for m in msgs[d]])
+            mb = np.ascontiguousarray(np.stack([m[2] for m in msgs[d]]))
+            dk, dc, db = ctx.alloc(mk.nbytes + 64), ctx.alloc(mc.nbytes + 64), ctx.alloc(mb.nbytes)
+            ctx.to_device(dk, mk); ctx.to_device(dc, mc); ctx.to_device(db, mb)
+            dest[d].merge_parts_device(2, dk, dc, db)
+            ctx.free(dk); ctx.free(dc); ctx.free(db)
+    rk = np.array(sorted(ref), dtype=np.uint64)
+    rc = np.array([ref[int(a)] for a in rk], dtype=np.uint32)
+    ranks = orc.key_to_rank(s, orc.MURMUR, STRAND["single"], rk.reshape(-1, 1), p)
+    for d in range(p):
+        gk, gc = dest[d].to_vector()
+        order = np.argsort(gk[:, 0])
+        assert gk.shape[0] == int((ranks == d).sum())
+        assert (gk[order, 0] == rk[ranks == d]).all() and (gc[order] == rc[ranks == d]).all()
+        dest[d].close()
+
+
 @pytest.mark.parametrize("dist_trans,code", [("lex_less", 1), ("xor_rev_comp", 2)])
 def test_single_strand_dist_transforms(ctx, dist_trans, code):
     """DistTrans of SingleStrandHashMapParams (kmer_index.hpp:436-450; pDistTrans of BenchmarkKmerIndex.cpp:150-161): the key is
