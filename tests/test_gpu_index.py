@@ -377,6 +377,32 @@ def test_bucket_with_more_distinct_keys_than_the_lds_table_takes_more_passes(ctx
     idx.close()
 
 
+def test_fit_check_of_the_first_reduce_attempt(ctx):
+    """bucket_reduce, once a bucket of the launch has overflowed, lets later buckets decide after their first 8192 keys
+    whether they fit one LDS table. Four large buckets in launch order: 30 k distinct keys (overflows, switches the
+    check on), 12 k distinct keys twice over (the check ends the first attempt early), 5 k distinct keys four times
+    over (passes the check), and 9 k distinct keys whose first 9 k stream positions are all different (the check
+    errs on the safe side and takes passes where one table would have done). Counts stay exact in every case."""
+    import kmerind_amd as K
+    cfg = K.make_config(31, "DNA", strand="single")
+    rng = np.random.default_rng(33)
+    a = _keys_in_one_placement_bucket(30_000, bucket=64)
+    b = _keys_in_one_placement_bucket(12_000, bucket=20_000)
+    c = _keys_in_one_placement_bucket(5_000, bucket=26_000)
+    d = _keys_in_one_placement_bucket(9_000, bucket=31_000)
+    parts = [np.repeat(a, rng.integers(1, 3, size=a.size)), rng.permutation(np.tile(b, 2)), rng.permutation(np.tile(c, 4)),
+             np.concatenate([d, rng.permutation(np.tile(d, 2))]), rng.integers(0, 1 << 62, size=100_000, dtype=np.uint64)]
+    keys = np.concatenate(parts)                       # not shuffled: the stream order inside a bucket follows the input
+    uk, uc = np.unique(keys, return_counts=True)
+    for rnd in range(2):                               # the second insert merges into the filled buckets (no check there)
+        idx = K.CountIndex(ctx, cfg) if rnd == 0 else idx
+        idx.insert(keys.reshape(-1, 1))
+        gk, gc = idx.to_vector()
+        order = np.argsort(gk[:, 0])
+        assert gk.shape[0] == uk.size and (gk[order, 0] == uk).all() and (gc[order] == uc * (rnd + 1)).all()
+    idx.close()
+
+
 @pytest.mark.parametrize("n_hot,p", [(30_000, 1), (30_000, 3)])
 def test_merge_of_parts_with_more_distinct_keys_per_bucket_than_the_lds_table(ctx, n_hot, p):
     """combine-first at low coverage: a placement bucket of the parts holds more distinct keys than one LDS table takes, so
