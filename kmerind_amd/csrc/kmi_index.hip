@@ -1410,7 +1410,9 @@ __device__ __forceinline__ void table_insert_stream1(const LdsTable<1> &t, const
             const float e = __expf(-x), g = (1.f - e) / x - r, dg = (e * (x + 1.f) - 1.f) / (x * x);
             x = fmaxf(x - g / dg, 1e-4f);
           }
-          const float D = (float)STEP / x, dn = D * (1.f - __expf(-(float)n / D));   // distinct keys among all n
+          const float D = (float)STEP / x;
+          // distinct keys among all n (nearly every key of the step new: the inversion loses its footing, and all n are)
+          const float dn = r > 0.99f ? (float)n : D * (1.f - __expf(-(float)n / D));
           const float want = ceilf(dn * 1.15f / (float)TabCfg<1>::LIMIT);
           *hint = want < 2.f ? 2u : (want > 65536.f ? 65536u : (uint32_t)want);
         }
