@@ -3,8 +3,14 @@
 
 One step = one pass of the hot path over one batch: FASTQ bytes resident in HBM ->
 k-mer extraction -> canonical strand -> (N>1: KeyToRank routing + RCCL all-to-all) ->
-count-index build. N=1 workload = BASELINE.json configs[1]: 10 M reads / 1.2e9 k-mers.
-N>1 is weak scaling: every rank gets its own 10 M reads of a genome N times as long.
+count-index build. N=1 workload = BASELINE.json configs[1] (config 2 of SURVEY.md 8d): 10 M reads
+of a 100 Mbp genome, seed 2, 1.2e9 k-mers. N>1 is the weak-scaling family of configs[2] (config 3:
+100 M reads of a 1 Gbp genome over 8 GPUs, seed 3): every rank gets 12.5 M reads, the genome is
+N x 125 Mbp, so N=8 IS config 3 and the genome coverage (12x) is the same at every N.
+
+`python bench.py --gpus N` without RANK/WORLD_SIZE in the environment starts the N ranks itself (fresh
+child processes, one per GPU, before anything touches the GPU) and relays rank 0's line; under
+torch.distributed.run it reads RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* as usual.
 
 Prints ONE JSON line (rank 0) with `roofline` (dominant kernel, HIP-event timed on the
 launch stream inside the timed region) and `cpu_baseline` (the oracle's restatement of
@@ -47,8 +53,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--reads", type=int, default=10_000_000, help="reads per GPU (config 2: 10 M)")
-    ap.add_argument("--genome", type=int, default=100_000_000, help="genome bases per GPU")
+    ap.add_argument("--reads", type=int, default=None, help="reads per GPU (default: 10 M at N=1 = config 2; 12.5 M at N>1 = config 3 / 8)")
+    ap.add_argument("--genome", type=int, default=None, help="genome bases per GPU (default: 100 Mbp at N=1; 125 Mbp at N>1)")
     ap.add_argument("--k", type=int, default=31)
     ap.add_argument("--cpu-sample-reads", type=int, default=500_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -63,6 +69,17 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = rehearsal of the N>1 flow with ranks sharing one GPU (exchange staged through the host)")
     args = ap.parse_args()
+    multi_default = args.gpus > 1 or args.force_dist
+    if args.reads is None:
+        args.reads = 12_500_000 if args.gpus > 1 else 10_000_000
+    if args.genome is None:
+        args.genome = 125_000_000 if args.gpus > 1 else 100_000_000
+    del multi_default
+
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # the driver's form: no launcher around us. Start the ranks as fresh children BEFORE this process touches the GPU
+        # (it never does) and relay rank 0's line.
+        sys.exit(launch_ranks(args.gpus))
 
     import numpy as np
     import torch
@@ -75,8 +92,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+        raise SystemExit("WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
     if args.backend == "gloo":
         local_rank = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
@@ -96,6 +112,13 @@ def main():
     n_reads = args.reads
     genome_len = args.genome * world
     seed = 2 if not multi else 3
+    workload_tag = ""
+    if world == 1 and (n_reads, genome_len) == (10_000_000, 100_000_000):
+        workload_tag = " [BASELINE configs[1] = SURVEY config 2]"
+    elif world > 1 and (n_reads, args.genome) == (12_500_000, 125_000_000):
+        workload_tag = " [weak-scaling family of config 3: %d M reads, %d Mbp genome in all%s]" % (
+            n_reads * world // 1_000_000, genome_len // 1_000_000, "; N=8 is config 3 verbatim" if world != 8 else " = config 3 verbatim")
+    peer_counts, verified = None, False
 
     stream = torch.cuda.current_stream(dev)
     ctx = K.Context(device=local_rank, rank=rank, nranks=world, stream=stream.cuda_stream)
@@ -140,14 +163,17 @@ def main():
         cdev = dev if args.backend == "nccl" else torch.device("cpu")
 
     def step():
+        nonlocal peer_counts, verified
         idx.clear()
         if not multi:
             idx.build_device(d_bytes.data_ptr(), nbytes)
             return
         if combine:
-            didx.build_device(d_bytes.data_ptr(), nbytes, dev)
+            didx.build_device(d_bytes.data_ptr(), nbytes, dev)     # (its first exchange carries checksums)
+            verified = True
             return
         pos, works = 0, []
+        peer_counts = [0] * world
         for c in range(nch):
             if c >= 2:
                 works[c - 2].wait()                        # the send buffer about to be rewritten has left
@@ -156,6 +182,7 @@ def main():
                                                   bounds[c + 1] - bounds[c], world, C.c_void_p(send.data_ptr()), send.shape[0],
                                                   C.byref(nt), C.byref(ns), counts.ctypes.data_as(C.c_void_p)))
             sc = [int(x) for x in counts]
+            peer_counts = [a + b for a, b in zip(peer_counts, sc)]
             rc = kdist.exchange_counts(sc, device=cdev)
             n_in = int(sum(rc))
             if pos + n_in > recv_cap:
@@ -174,6 +201,10 @@ def main():
                     def wait(self):
                         return True
                 works.append(_Done())
+            if not verified:                               # first exchange of the process: checksums travel with the payload
+                works[-1].wait()
+                kdist.verify_exchange(send[: nt.value], sc, d_recv[pos:pos + n_in], rc, stage_through_host=(args.backend != "nccl"))
+                verified = True
             pos += n_in
         for w in works[-2:]:
             w.wait()
@@ -208,34 +239,50 @@ def main():
     else:
         distinct = local_distinct
 
+    # peer balance of the exchange (max / mean message of this rank's last step; worst rank reported)
+    peer_ratio = None
+    if multi:
+        sc_last = (didx.last_send_counts if combine else peer_counts) or [0]
+        mean = float(sum(sc_last)) / max(1, len(sc_last))
+        t = torch.tensor([max(sc_last) / mean if mean > 0 else 1.0], dtype=torch.float64, device=cdev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        peer_ratio = round(float(t.item()), 4)
+        group_ranks = dist.get_world_size()
+        backend_name = dist.get_backend()
+
     if rank == 0:
         total_kmers = n_kmers * world
         ms_per_step = elapsed * 1e3 / args.steps
         value = total_kmers * args.steps / elapsed
         prof = [p for p in prof if p["launches"] > 0]
         dom = max(prof, key=lambda p: p["total_ms"]) if prof else None
-        roofline = None
+        # roofline: the WHOLE step against the contract figure (B_alg = 10.625 B per k-mer, input bytes once + the
+        # materialised tuple once) per GPU; the dominant kernel priced with its OWN algorithmic bytes sits under "dominant_kernel"
+        step_gbs = n_kmers * B_ALG / (ms_per_step * 1e-3) / 1e9
+        traffic, traffic_src = measured_traffic(None, n_reads) if not multi else (None, None)
+        roofline = {"bound": "hbm", "achieved": round(step_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(step_gbs / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                    "scope": "whole step per GPU: k-mers x 10.625 B / step time",
+                    "alg_bytes_per_kmer": B_ALG, "alg_bytes_per_step": n_kmers * B_ALG}
         if dom:
             avg_ms = dom["total_ms"] / dom["launches"]
             b_kernel = KERNEL_ALG_BYTES.get(dom["name"], B_ALG)
             per_launch = n_kmers * args.steps / dom["launches"]      # k-mers one launch processes (N > 1 runs in chunks)
             achieved = per_launch * b_kernel / (avg_ms * 1e-3) / 1e9
-            roofline = {"bound": "hbm", "kernel": dom["name"], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                        "traffic": measured_traffic(dom["name"], n_reads),
-                        "avg_kernel_ms": round(avg_ms, 4),
-                        "alg_bytes_per_kmer": b_kernel,
-                        "alg_bytes_per_launch": per_launch * b_kernel,
-                        "pipeline_frac": round(n_kmers * B_ALG / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                        "kernels_ms_per_step": {p["name"]: round(p["total_ms"] / args.steps, 4) for p in
-                                                sorted(prof, key=lambda p: -p["total_ms"])},
-                        # what this box's HBM delivers to plain streaming kernels (outside the timed steps), next to the 8 TB/s figure
-                        "measured_stream_gbs": measured_stream(torch, dev)}
+            ktraffic, ksrc = measured_traffic(dom["name"], n_reads) if not multi else (None, None)
+            roofline["dominant_kernel"] = {"kernel": dom["name"], "avg_kernel_ms": round(avg_ms, 4), "alg_bytes_per_kmer": b_kernel,
+                                           "alg_bytes_per_launch": per_launch * b_kernel, "achieved": round(achieved, 1),
+                                           "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": ktraffic, "traffic_source": ksrc,
+                                           "timing": "HIP events on the launch stream inside the timed region"}
+        roofline["kernels_ms_per_step"] = {p["name"]: round(p["total_ms"] / args.steps, 4) for p in
+                                           sorted(prof, key=lambda p: -p["total_ms"])}
+        # what this box's HBM delivers to plain streaming kernels (outside the timed steps), next to the 8 TB/s figure
+        roofline["measured_stream_gbs"] = measured_stream(torch, dev)
         out = {"metric": "kmers_per_sec_indexed", "value": value, "unit": "k-mers/s", "n_gpus": world,
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-               "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+               "scaling": "weak" if world > 1 else None, "vs_baseline": None, "dtype": "u64", "data": "synthetic",
                "config": {"workload": "k=%d DNA CountIndex (canonical), %d synthetic %d-bp reads per GPU as 315-byte "
-                                      "FASTQ records, genome %d bp, seed %d" % (k, n_reads, read_len, genome_len, seed),
+                                      "FASTQ records, genome %d bp, seed %d%s" % (k, n_reads, read_len, genome_len, seed, workload_tag),
                           "kmers_per_step": total_kmers, "distinct_kmers": distinct,
                           "exchange": "none (1 rank)" if not multi else
                           "%s all_to_all_single (counts + payload), %d chunks per step, overlapped with parsing" %
@@ -243,8 +290,12 @@ def main():
                           "%s all_to_all_single of locally reduced (k-mer, count) pairs + per-bucket counts" %
                           ("RCCL" if args.backend == "nccl" else "gloo (rehearsal)")},
                "roofline": roofline}
+        if multi:
+            out["config"].update({"dist_mode": dist_mode, "backend": backend_name, "rccl_ranks": group_ranks if args.backend == "nccl" else 0,
+                                  "group_ranks": group_ranks, "peer_bucket_max_over_mean": peer_ratio,
+                                  "exchange_checksum": "verified on the first exchange" if verified else "not run"})
         if not multi and not args.no_extra:
-            out["extra"] = extra_rates(ctx, cfg, idx, d_bytes, nbytes, n_kmers, dev, torch)
+            out["extra"] = extra_rates(ctx, cfg, idx, d_bytes, nbytes, n_kmers, dev, torch, host)
         if not multi and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(host, args, k, n_reads)
         print(json.dumps(out), flush=True)
@@ -258,7 +309,52 @@ def main():
         dist.destroy_process_group()
 
 
-def extra_rates(ctx, cfg, idx, d_bytes, nbytes, n_kmers, dev, torch):
+def launch_ranks(n):
+    """`python bench.py --gpus N` as the driver runs it: N child ranks of this same script (one per GPU, RCCL over xGMI between
+    them), rank 0's stdout relayed, non-zero exit if any rank fails. The parent never initialises the GPU."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: what RCCL needs on this pool
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=(r == 0)))
+    import threading
+    chunks = []
+    rd = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    rd.start()
+    deadline = time.time() + 1800
+    rcs = [None] * n
+    while any(rc is None for rc in rcs):
+        for r, pr in enumerate(procs):
+            if rcs[r] is None:
+                rcs[r] = pr.poll()
+        failed = any(rc not in (None, 0) for rc in rcs)
+        if failed or time.time() > deadline:                    # a dead rank leaves the others waiting in a collective
+            for r, pr in enumerate(procs):
+                if rcs[r] is None:
+                    pr.kill()
+                    rcs[r] = pr.wait()
+            break
+        time.sleep(0.2)
+    rd.join(timeout=10)
+    out0 = "".join(chunks)
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
+    if bad:
+        sys.stderr.write("bench.py: ranks failed: %s\n" % bad)
+        return 1
+    return 0
+
+
+def extra_rates(ctx, cfg, idx, d_bytes, nbytes, n_kmers, dev, torch, host=None):
     """The other sections the reference's benchmark times (BenchmarkKmerIndex.cpp:526-581), outside the timed steps, two
     runs each, HBM-resident operands: read (extract only), insert (from an extracted tuple array), count and find of
     10 M query k-mers (5 M present, 5 M random 62-bit values)."""
@@ -308,7 +404,27 @@ def extra_rates(ctx, cfg, idx, d_bytes, nbytes, n_kmers, dev, torch):
         ctx.check(L.lib.kmi_index_find_dev(idx.h, C.c_void_p(q.data_ptr()), nq, C.c_void_p(ok.data_ptr()), C.c_void_p(ov.data_ptr()),
                                            C.byref(n_out)))
     t_find = timed(find)
-    return {"extract_only_kmers_per_s": n_kmers / t_extract, "insert_only_kmers_per_s": n_kmers / t_insert,
+    # the same build from bytes resident in HOST memory (SURVEY 8d defines the wall from there): pinned host buffer ->
+    # H2D copy on the build's stream -> build. PCIe-bound; reported next to `value`, never as `value`.
+    host_rate, host_note = None, "not measured"
+    if host is not None:
+        try:
+            h_pinned = torch.from_numpy(host).pin_memory()
+            idx3 = K.CountIndex(ctx, cfg)
+
+            def host_build():
+                idx3.clear()
+                d_bytes.copy_(h_pinned, non_blocking=True)
+                idx3.build_device(d_bytes.data_ptr(), nbytes)
+            t_host = timed(host_build)
+            idx3.close()
+            del h_pinned
+            host_rate = n_kmers / t_host
+            host_note = "pinned host buffer, one H2D copy (%.1f GB/s incl. the build) + the build, %.1f ms" % (nbytes / t_host / 1e9, t_host * 1e3)
+        except Exception as e:   # pinning 3 GB can fail on a small box: the side measurement must not break the bench line
+            host_note = "failed: " + str(e)[:80]
+    return {"host_resident_kmers_per_s": host_rate, "host_resident_note": host_note,
+            "extract_only_kmers_per_s": n_kmers / t_extract, "insert_only_kmers_per_s": n_kmers / t_insert,
             "count_queries_per_s": nq / t_count, "find_queries_per_s": nq / t_find, "queries": nq,
             "distinct_query_keys": n_distinct_q, "found": n_out.value,
             "note": "outside the timed steps; 2 runs each after one warm-up; operands resident in HBM"}
@@ -334,20 +450,25 @@ def measured_stream(torch, dev):
 
 
 def measured_traffic(kernel, n_reads):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE,
-    profiles/*_hbm_traffic.json, collected on config 2); None for other workloads or kernels."""
+    """(HBM bytes, source file) from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE per launch,
+    profiles/*_hbm_traffic.json, collected on config 2 by tools/profile_round.sh): of one launch of `kernel`, or of the whole
+    step (all kernels) for kernel=None. These are NOT counters of this run; (None, None) for other workloads."""
     import glob
     if n_reads != 10_000_000:
-        return None
+        return None, None
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.json")))
     if not files:
-        return None
+        return None, None
+    src = "profiles/" + os.path.basename(files[-1])
     try:
         with open(files[-1]) as f:
-            rec = json.load(f)["kernels"].get(kernel)
-        return rec["hbm_bytes"] if rec else None
+            kernels = json.load(f)["kernels"]
+        if kernel is None:
+            return sum(r["hbm_bytes"] for r in kernels.values()), src
+        rec = kernels.get(kernel)
+        return (rec["hbm_bytes"], src) if rec else (None, None)
     except (OSError, ValueError, KeyError):
-        return None
+        return None, None
 
 
 def cpu_baseline(host, args, k, n_reads):

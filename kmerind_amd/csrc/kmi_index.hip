@@ -1528,7 +1528,13 @@ __global__ __launch_bounds__((TabCfg<NW>::NT)) void bucket_reduce_kernel(const u
   // that never needs it, so it is switched on by the first bucket of the launch that overflows (flags[8], cleared by
   // the host before the launch): sequencing data at coverage never pays it, a genome or a thin sample pays one lost
   // attempt per CU and then checks.
-  const bool check_on = (NW == 1) && __hip_atomic_load(&flags[8], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+  // Other workgroups flip flags[8] while this one runs, and the waves of a workgroup start at different times: the flag is
+  // read ONCE, by one lane, and handed to the others through LDS behind a barrier, because it selects between code paths
+  // that hold different numbers of workgroup barriers (a per-wave read could send waves of one workgroup down both).
+  if (threadIdx.x == 0) s_ctl[5] = (NW == 1) ? __hip_atomic_load(&flags[8], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+  lds_barrier();
+  const bool check_on = s_ctl[5] != 0u;   // (s_ctl[5] is the progress word: table_clear resets it behind the next barrier)
+  lds_barrier();
   while (true) {
     if (threadIdx.x == 0) *s_out = 0;
     bool failed = false;

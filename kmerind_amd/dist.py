@@ -23,38 +23,51 @@ MSG_MAX_WORDS = 1 << 27
 
 def exchange_keys(send, send_counts, group=None):
     """send: int64 tensor [n, n_words] grouped by destination rank; returns (recv, recv_counts).
-    recv is the concatenation by source rank ascending (the reference's receive buffer) when every peer message fits one
-    transfer; otherwise the exchange runs in pieces and recv is ordered by piece, then by source rank (same multiset)."""
+    recv is the concatenation by source rank ascending (the reference's receive buffer), also when the peer messages are
+    too large for one transfer and travel in pieces (every source's rows stay contiguous and in order)."""
     world = dist.get_world_size(group)
     assert len(send_counts) == world and send.dim() == 2
     assert int(sum(send_counts)) == send.shape[0]
     nw = send.shape[1]
     send_counts = [int(c) for c in send_counts]
     recv_counts = exchange_counts(send_counts, group, send.device)
-    recv = torch.empty((int(sum(recv_counts)), nw), dtype=send.dtype, device=send.device)
     rows_max = max(1, MSG_MAX_WORDS // max(1, nw))
     # the number of pieces must be the same on every rank: it follows from the largest message anywhere
     biggest = torch.tensor([max(send_counts + recv_counts)], dtype=torch.int64, device=send.device)
     dist.all_reduce(biggest, op=dist.ReduceOp.MAX, group=group)
     pieces = max(1, -(-int(biggest.item()) // rows_max))
-    if pieces == 1:
-        dist.all_to_all_single(recv, send.contiguous(), output_split_sizes=recv_counts, input_split_sizes=send_counts, group=group)
-        return recv, recv_counts
-    s_off = [0]
-    for c in send_counts:
-        s_off.append(s_off[-1] + c)
-    pos = 0
-    for p in range(pieces):
-        def part(c):                      # rows of a message that travel in piece p
-            lo, hi = (c * p) // pieces, (c * (p + 1)) // pieces
-            return lo, hi
-        in_split = [part(c)[1] - part(c)[0] for c in send_counts]
-        out_split = [part(c)[1] - part(c)[0] for c in recv_counts]
-        chunk = torch.cat([send[s_off[r] + part(send_counts[r])[0]: s_off[r] + part(send_counts[r])[1]] for r in range(world)])
-        n_out = int(sum(out_split))
-        dist.all_to_all_single(recv[pos:pos + n_out], chunk, output_split_sizes=out_split, input_split_sizes=in_split, group=group)
-        pos += n_out
-    return recv, recv_counts
+
+    def a2a(out, inp, **kw):
+        dist.all_to_all_single(out, inp.contiguous(), group=group, **kw)
+    return _a2a_rows_in_order(a2a, send, send_counts, recv_counts, pieces), recv_counts
+
+
+def verify_exchange(send, sc, recv, rc, group=None, stage_through_host=False):
+    """End-to-end check of one all-to-all: the wrap-around 64-bit sum of every peer message, computed by the sender, travels
+    next to it and is compared with the sum of what arrived. bench.py and DistributedCountIndex run it on the FIRST exchange
+    of a process: the RCCL build of this image was seen to corrupt peer messages above 1 GiB (tools/a2a_debug.py), and that
+    limit is a property of one library build, not a constant -- so it is asserted at run time rather than trusted.
+    send / recv: integer tensors whose rows are grouped by destination / source; sc / rc rows per peer."""
+    world = dist.get_world_size(group)
+
+    def sums(t, counts):
+        flat = t.reshape(t.shape[0], -1).to(torch.int64) if t.dim() > 1 else t.to(torch.int64).reshape(-1, 1)
+        out, off = [], 0
+        for c in counts:
+            out.append(flat[off:off + c].sum() if c else torch.zeros((), dtype=torch.int64, device=t.device))
+            off += c
+        return torch.stack(out)
+    mine = sums(send, sc)
+    got = sums(recv, rc)
+    if stage_through_host:
+        mine, got = mine.cpu(), got.cpu()
+    theirs = torch.empty_like(mine)
+    dist.all_to_all_single(theirs, mine, group=group)
+    bad = (theirs != got).nonzero().flatten().tolist()
+    if bad:
+        raise RuntimeError("all-to-all payload corrupted: messages from ranks %s to rank %d do not match their senders' checksums "
+                           "(%d ranks)" % (bad, dist.get_rank(group), world))
+    return True
 
 
 def _a2a_rows_in_order(a2a, send, sc, rc, pieces):
@@ -87,7 +100,7 @@ def _a2a_rows_in_order(a2a, send, sc, rc, pieces):
     return out
 
 
-def exchange_pairs(keys, counts, bucket_counts, group=None, stage_through_host=False):
+def exchange_pairs(keys, counts, bucket_counts, group=None, stage_through_host=False, verify=False):
     """The exchange of the combine-first count insert (kmerind_hip.h, kmi_index_split_by_rank_dev): keys int64 [n, n_words]
     and counts int32 [n] grouped by destination rank, bucket_counts int32 [world, B] (row r describes the message to
     rank r). Returns (recv_keys, recv_counts, recv_bucket_counts [world, B] with row s = the message from rank s).
@@ -115,6 +128,8 @@ def exchange_pairs(keys, counts, bucket_counts, group=None, stage_through_host=F
     dist.all_reduce(biggest, op=dist.ReduceOp.MAX, group=group)
     pieces = max(1, -(-int(biggest.item()) * keys.shape[1] // MSG_MAX_WORDS))
     rk = _a2a_rows_in_order(a2a, keys, sc, rc, pieces)
+    if verify:
+        verify_exchange(keys, sc, rk, rc, group, stage_through_host)
     # counts of one rank's own reads are small: when every rank's fit a byte they travel as bytes (9 instead of 12 bytes
     # per pair on the link)
     big = torch.tensor([int(counts.max().item()) if counts.numel() else 0], dtype=torch.int64, device=cdev)
@@ -142,9 +157,11 @@ class DistributedCountIndex:
         self.nb = num_buckets()
         self.n_words = self.index.n_words
         self._cap = 0
+        self._verified = False                     # the first exchange of this object carries checksums (verify_exchange)
+        self.last_send_counts = None               # pairs sent to every rank by the last build (peer balance)
 
     def _buffers(self, n, dev):
-        if n > self._cap:
+        if n > self._cap or not hasattr(self, "_keys"):     # (a first build that yields no k-mer still needs the buffers)
             self._cap = int(n * 1.1) + 1024
             self._keys = torch.empty((self._cap, self.n_words), dtype=torch.int64, device=dev)
             self._counts = torch.empty((self._cap,), dtype=torch.int32, device=dev)
@@ -158,8 +175,10 @@ class DistributedCountIndex:
         self.scratch.build_device(dptr, nbytes)
         n = self.scratch.local_size()
         keys, counts, bcnt = self._buffers(n, device)
-        self.scratch.split_by_rank_device(self.world, keys.data_ptr(), counts.data_ptr(), self._cap, bcnt.data_ptr())
-        rk, rv, rb = exchange_pairs(keys[:n], counts[:n], bcnt, self.group, self.stage)
+        sc = self.scratch.split_by_rank_device(self.world, keys.data_ptr(), counts.data_ptr(), self._cap, bcnt.data_ptr())
+        self.last_send_counts = [int(x) for x in sc]
+        rk, rv, rb = exchange_pairs(keys[:n], counts[:n], bcnt, self.group, self.stage, verify=not self._verified)
+        self._verified = True
         self.index.merge_parts_device(self.world, rk.data_ptr(), rv.data_ptr(), rb.data_ptr())
 
     # ---- queries (distributed_unordered_map.hpp:880-983 count, :564-687 find, :719-779 erase): transform_input, route the
@@ -276,7 +295,9 @@ class DistributedPositionIndex(DistributedCountIndex):
             off += recv_counts[src]
             if seg.shape[0]:
                 k, v = fn(seg)
-                v = np.asarray(v, dtype=np.uint64).reshape(k.shape[0], -1)
+                # explicit width: a segment whose keys are all absent gives zero rows, which reshape(0, -1) cannot size
+                vw = self.value_words if fn == self.index.find else 1
+                v = np.asarray(v, dtype=np.uint64).reshape(k.shape[0], vw)
             else:
                 k, v = np.zeros((0, self.n_words), np.uint64), np.zeros((0, 1), np.uint64)
             out.append(np.concatenate([k, v], axis=1) if k.shape[0] else np.zeros((0, self.n_words + v.shape[1]), np.uint64))

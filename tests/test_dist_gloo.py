@@ -132,3 +132,63 @@ def test_combine_first_exchange_over_gloo(world, msg_max):
     ek, ec = ref.export()
     assert len(merged) == ek.shape[0]
     assert all(merged[int(key)] == int(c) for key, c in zip(ek[:, 0], ec))
+
+
+def _order_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from kmerind_amd import dist as kdist
+        kdist.MSG_MAX_WORDS = 64                      # every peer message of a few hundred rows goes in several pieces
+        counts = [100 + 37 * ((rank + d) % world) for d in range(world)]
+        rows = []
+        for d, c in enumerate(counts):                # row value = (source, destination, position inside the message)
+            rows.append(np.stack([np.full(c, rank), np.full(c, d), np.arange(c)], axis=1))
+        send = torch.from_numpy(np.concatenate(rows).astype(np.int64))
+        recv, rc = kdist.exchange_keys(send, counts)
+        assert kdist.verify_exchange(send, counts, recv, rc)
+        bad = recv.clone()
+        bad[0, 2] += 1                                # a corrupted payload must be noticed
+        try:
+            kdist.verify_exchange(send, counts, bad, rc)
+            noticed = False
+        except RuntimeError:
+            noticed = True
+        ret[rank] = (recv.numpy().copy(), rc, noticed)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_exchange_keys_keeps_source_order_when_messages_travel_in_pieces():
+    """imxx::distribute's receive buffer is the concatenation by source rank ascending (incremental_mxx.hpp:1098); the routed
+    query / answer exchanges slice it per source, so the order must hold for any number of pieces"""
+    world = 3
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_order_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    for r in range(world):
+        recv, rc, noticed = ret[r]
+        assert noticed
+        off = 0
+        for src in range(world):
+            c = 100 + 37 * ((src + r) % world)
+            assert rc[src] == c
+            seg = recv[off:off + c]
+            assert (seg[:, 0] == src).all() and (seg[:, 1] == r).all() and (seg[:, 2] == np.arange(c)).all()
+            off += c
+        assert off == recv.shape[0]
+
+
+def test_bench_launcher_reports_a_failed_rank():
+    """python bench.py --gpus 2 without a GPU: both children fail at context creation; the launcher must come back non-zero
+    (not hang, not exit 0)"""
+    import subprocess
+    import sys
+    if torch.cuda.is_available():
+        pytest.skip("needs a box without a GPU")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--reads", "1000", "--genome",
+                          "100000", "--steps", "1", "--warmup", "0"], capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode != 0
+    assert not [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
