@@ -1200,8 +1200,9 @@ template <int NW> struct TabCfg {
   // home slots. One-word keys: one 1024-thread workgroup per CU with a table that fills the CU's LDS (154 KB). Two
   // 512-thread workgroups with half the table each ran at the same speed on config 2 (4.25 ms: the kernel is bound by
   // the dependent LDS round trips of the probe walk, not by the load factor), and the large table takes twice the
-  // distinct keys per pass (9600 per bucket, 3.1e8 per index) before a bucket needs a second pass.
-  static constexpr int CAP = (NW == 1) ? 12800 : (NW == 2 ? 4608 : (NW == 3 ? 3584 : 2816));   // home slots
+  // distinct keys per pass (9120 per bucket, 3.0e8 per index) before a bucket needs a second pass.
+  // (12160 + 64 slots x 12 B + 16 KB of per-wave miss queues = 160 KB)
+  static constexpr int CAP = (NW == 1) ? 12160 : (NW == 2 ? 4608 : (NW == 3 ? 3584 : 2816));   // home slots
   // One-word tables probe linearly WITHOUT wrap-around: a probe sequence that starts near the end runs on
   // into PAD extra slots, so a probe step is "next address, read, compare" and nothing else. The very last
   // slot is never filled (an insert that would need it reports overflow), which ends every probe sequence.
@@ -1300,6 +1301,11 @@ template <int NW> __device__ __forceinline__ int table_upsert(const LdsTable<NW>
   }
 }
 
+// fit check of a first attempt (CHECK): a bucket of exactly LIMIT = 9120 distinct keys shows 5406 +- 29 distinct ones after
+// its first 8192 draws (D (1 - e^(-n/D))); more than that (+ 2.4 sigma) and the bucket will not fit one table
+constexpr uint32_t kFitsStep8192 = 5475u;
+static_assert(TabCfg<1>::LIMIT == 9120, "kFitsStep8192 belongs to this limit");
+
 // which reduction pass a key belongs to when a bucket needs several
 __device__ __forceinline__ uint32_t pass_of(uint32_t h, uint32_t npass) {
   return npass == 1 ? 0u : (uint32_t)(((uint64_t)(h * 0x9E3779B1u) * npass) >> 32);
@@ -1397,9 +1403,8 @@ __device__ __forceinline__ void table_insert_stream1(const LdsTable<1> &t, const
     if (has_b) load(i0 + STEP, kb);
     if (i0 + STEP <= n) insert(i0, ka, std::true_type{}); else insert(i0, ka, std::false_type{});
     if (CHECK && i0 == 0u && n > 2u * STEP) {   // uniform; every wave is here (nothing sets the overflow flag before the first step is in)
-      // a bucket of exactly LIMIT keys shows 5510 +- 29 distinct ones after the first 8192 draws
-      constexpr uint32_t kFits = 5580u;
-      static_assert(STEP == 8192u && TabCfg<1>::LIMIT == 9600, "kFits belongs to this step and limit");
+      constexpr uint32_t kFits = kFitsStep8192;
+      static_assert(STEP == 8192u, "kFits belongs to this step and limit");
       lds_barrier();
       if (threadIdx.x == 0) {
         const uint32_t d1 = *t.distinct;
@@ -1425,6 +1430,162 @@ __device__ __forceinline__ void table_insert_stream1(const LdsTable<1> &t, const
       if (i0 + 2 * STEP <= n) insert(i0 + STEP, kb, std::true_type{}); else insert(i0 + STEP, kb, std::false_type{});
     }
   }
+}
+
+// ---------------------------------------------------------------------------
+// Flat insert of one-word keys (weight 1), the common case of bucket_reduce. table_insert_stream1 above walks, claims and
+// counts inside one divergent per-key loop, so every wavefront runs the whole slow path for each of its U keys as soon as
+// ONE lane needs it -- and one nearly always does: its exec-mask bookkeeping (67 scalar instructions per key against 59
+// vector ones, rocprofv3 SQ_INSTS_*) was what bound the kernel, not the table. Here the per-key code is straight-line:
+//   fast path  hash, home slot, ONE 64-bit read, compare; a hit (the key was seen before and sits in its home slot: the
+//              rule at sequencing coverage) costs one predicated 32-bit LDS add;
+//   misses     (first sighting, or the home slot holds another key) go to a 128-entry queue of the WAVEFRONT in LDS
+//              (ballot + mbcnt: no atomics), and whenever 64 are waiting the wavefront pops them, one per lane, and runs
+//              the probe walk / claim loop with every lane busy.
+// MULTI: only the keys of `pass` (pass_of) are taken. SPECIAL: the keys may equal the empty marker (k-mers of 64 bits).
+// CHECK: the fit check of a first attempt (see table_insert_stream1); the queue is emptied before the distinct count is read.
+// ---------------------------------------------------------------------------
+constexpr int kMissQ = 2 * kWave;   // queue entries per wavefront: fewer than 64 wait, at most 64 join per step
+
+// pass count from the distinct keys d1 among the first `step` of a bucket's n keys (occupancy: d of D after s draws = D (1 - e^(-s/D)))
+__device__ __forceinline__ uint32_t passes_from_first_step(uint32_t d1, uint32_t step, uint32_t n) {
+  const float r = (float)d1 / (float)step;           // (1 - e^-x) / x with x = step / D
+  float x = fmaxf(2.f * (1.f - r), 1e-4f);
+  for (int it = 0; it < 4; ++it) {
+    const float e = __expf(-x), g = (1.f - e) / x - r, dg = (e * (x + 1.f) - 1.f) / (x * x);
+    x = fmaxf(x - g / dg, 1e-4f);
+  }
+  const float D = (float)step / x;
+  // distinct keys among all n (nearly every key of the step new: the inversion loses its footing, and all n are)
+  const float dn = r > 0.99f ? (float)n : D * (1.f - __expf(-(float)n / D));
+  const float want = ceilf(dn * 1.15f / (float)TabCfg<1>::LIMIT);
+  return want < 2.f ? 2u : (want > 65536.f ? 65536u : (uint32_t)want);
+}
+
+// The slow path as ONE out-of-line function (LDS address-space pointers, so the table accesses stay ds_ instructions):
+// table_insert_flat reaches it from 2 x U places, once per 64 misses -- inlined, those copies made the kernel 50 k lines of ISA.
+// Pops queue entries [first, first + cnt), cnt <= 64, one per lane: walk from the home slot, claim an empty slot, count.
+typedef __attribute__((address_space(3))) uint64_t lds_u64_t;
+typedef __attribute__((address_space(3))) uint32_t lds_u32_t;
+__device__ __attribute__((noinline)) void probe_insert_lds(lds_u64_t *tkeys, lds_u32_t *tvals, lds_u32_t *distinct, lds_u32_t *overflow,
+                                                          const lds_u64_t *wq, uint32_t first, uint32_t cnt) {
+  constexpr int CAP = TabCfg<1>::CAP;
+  constexpr uint32_t LAST = TabCfg<1>::SLOTS - 1;
+  const uint32_t lane = lane_id();
+  if (lane < cnt) {
+    const uint64_t key = wq[first + lane];
+    const uint64_t kk[1] = {key};
+    uint32_t s = slot_of(place_hash<1>(kk), CAP);
+    uint64_t c = __atomic_load_n(&tkeys[s], __ATOMIC_RELAXED);
+    for (;;) {
+      while (c != key && c != kEmptyKey) { ++s; c = __atomic_load_n(&tkeys[s], __ATOMIC_RELAXED); }   // the walk
+      if (c == key) break;
+      // empty slot: first sighting of this key (or the table is overloaded)
+      if (s >= LAST || __atomic_load_n(distinct, __ATOMIC_RELAXED) >= (uint32_t)TabCfg<1>::LIMIT) { *overflow = 1; s = LAST; break; }
+      uint64_t expected = kEmptyKey;
+      if (__atomic_compare_exchange_n(&tkeys[s], &expected, key, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {
+        // count the new key, one LDS add per wavefront
+        const unsigned long long m = __ballot(1);
+        if ((int)lane == __ffsll((long long)m) - 1) __atomic_fetch_add(distinct, (uint32_t)__popcll(m), __ATOMIC_RELAXED);
+        break;
+      }
+      c = expected;   // lost the slot to another lane: its key is ours (done) or the walk goes on
+    }
+    __atomic_fetch_add(&tvals[s], 1u, __ATOMIC_RELAXED);   // (slot LAST never holds a key: counts parked there on overflow are never read)
+  }
+}
+
+template <int U, bool MULTI, bool SPECIAL, bool CHECK>
+__device__ __forceinline__ void table_insert_flat(const LdsTable<1> &t, uint64_t *wq /* this wavefront's queue [kMissQ] */,
+                                                  const uint64_t *__restrict__ keys /* bucket base */, uint32_t n, uint32_t npass,
+                                                  uint32_t pass, uint32_t *hint = nullptr) {
+  constexpr int CAP = TabCfg<1>::CAP;
+  constexpr uint32_t LAST = TabCfg<1>::SLOTS - 1;
+  constexpr uint32_t NT = TabCfg<1>::NT;
+  constexpr uint32_t STEP = NT * U;
+  if (n == 0) return;
+  const uint32_t last = n - 1;
+  const uint32_t lane = lane_id();
+  uint32_t qn = 0;   // keys waiting in the queue (the same in every lane)
+  lds_u64_t *const tkeys = (lds_u64_t *)t.keys;
+  lds_u32_t *const tvals = (lds_u32_t *)t.vals;
+  lds_u32_t *const tdist = (lds_u32_t *)t.distinct;
+  lds_u32_t *const tovf = (lds_u32_t *)t.overflow;
+  const lds_u64_t *const wql = (const lds_u64_t *)wq;
+  auto drain = [&](uint32_t cnt) {   // the top cnt <= 64 entries of the queue, one per lane
+    probe_insert_lds(tkeys, tvals, tdist, tovf, wql, qn - cnt, cnt);
+    qn -= cnt;
+  };
+  auto load = [&](uint32_t i0, uint64_t (&r)[U]) {   // clamped (not guarded) loads, indices relative to the bucket
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      uint32_t i = i0 + (uint32_t)u * NT + threadIdx.x;
+      i = i < last ? i : last;
+      r[u] = keys[i];
+    }
+  };
+  auto insert = [&](uint32_t i0, const uint64_t (&k)[U], auto full_tag) {   // full_tag: every key of the batch lies inside the bucket
+    constexpr bool FULL = decltype(full_tag)::value;
+    uint32_t slot[U], valid = 0, spec = 0;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint64_t kk[1] = {k[u]};
+      const uint32_t h = place_hash<1>(kk);
+      slot[u] = slot_of(h, CAP);
+      bool a = FULL || i0 + (uint32_t)u * NT + threadIdx.x < n;
+      if (MULTI) a = a && pass_of(h, npass) == pass;
+      const bool sp = SPECIAL && k[u] == kEmptyKey;
+      valid |= (a && !sp) ? (1u << u) : 0u;
+      spec += (a && sp) ? 1u : 0u;
+    }
+    if (SPECIAL && spec) { *t.special_set = 1; atomicAdd(t.special, spec); }   // the key that equals the empty marker
+    uint64_t cur[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) cur[u] = __atomic_load_n(&t.keys[slot[u]], __ATOMIC_RELAXED);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const bool v = (valid >> u) & 1u;
+      const bool hit = v && cur[u] == k[u];
+      if (hit) atomicAdd(&t.vals[slot[u]], 1u);
+      const bool miss = v && !hit;
+      const unsigned long long m = __ballot(miss);
+      if (m) {   // uniform
+        const uint32_t pos = qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        if (miss) wq[pos] = k[u];
+        qn += (uint32_t)__popcll(m);
+        if (qn >= (uint32_t)kWave) drain((uint32_t)kWave);
+      }
+    }
+  };
+  uint64_t ka[U], kb[U];
+  load(0u, ka);
+  for (uint32_t i0 = 0; i0 < n; i0 += 2 * STEP) {
+    // (with CHECK every wave must reach the two barriers of the first step, whatever another wave has flagged by then)
+    if (!(CHECK && i0 == 0u) && __atomic_load_n(t.overflow, __ATOMIC_RELAXED)) {   // this pass is lost already: stop filling the table
+      if (lane == 0) atomicMax(t.progress, i0);
+      qn = 0;
+      break;
+    }
+    const bool has_b = i0 + STEP < n;
+    if (has_b) load(i0 + STEP, kb);
+    if (i0 + STEP <= n) insert(i0, ka, std::true_type{}); else insert(i0, ka, std::false_type{});
+    if (CHECK && i0 == 0u && n > 2u * STEP) {   // uniform; every wave is here (only this step's keys can have set the overflow flag)
+      static_assert(!CHECK || STEP == 8192u, "kFitsStep8192 belongs to this step");
+      if (qn) drain(qn);                        // the distinct count has to cover the whole step
+      lds_barrier();
+      if (threadIdx.x == 0) {
+        const uint32_t d1 = *t.distinct;
+        if (d1 >= kFitsStep8192) *hint = passes_from_first_step(d1, STEP, n);
+      }
+      lds_barrier();
+      if (*hint) return;   // written only between the two barriers: the same for every lane
+    }
+    if (has_b) {
+      if (i0 + 2 * STEP < n) load(i0 + 2 * STEP, ka);
+      if (i0 + 2 * STEP <= n) insert(i0 + STEP, kb, std::true_type{}); else insert(i0 + STEP, kb, std::false_type{});
+    }
+  }
+  if (qn) drain(qn);
 }
 
 // lookup only; returns slot or -1
@@ -1515,6 +1676,8 @@ __global__ __launch_bounds__((TabCfg<NW>::NT)) void bucket_reduce_kernel(const u
                                                                         uint32_t *__restrict__ flags, bool full_word_keys,
                                                                         uint64_t *scratch /* as large as new_keys and free, or null */) {
   KMI_TABLE_LDS(NW)
+  __shared__ uint64_t s_missq[(NW == 1) ? (TabCfg<NW>::NT / kWave) * kMissQ : 1];   // per-wavefront miss queues (table_insert_flat)
+  uint64_t *wq = s_missq + ((NW == 1) ? wave_id() * kMissQ : 0);
   const uint32_t b = blockIdx.x;
   const uint64_t nb = new_off[b], ne = new_off[b + 1];
   const uint64_t ob = old_off ? old_off[b] : 0ull, oe = old_off ? old_off[b + 1] : 0ull;
@@ -1558,13 +1721,13 @@ __global__ __launch_bounds__((TabCfg<NW>::NT)) void bucket_reduce_kernel(const u
       });
       if constexpr (NW == 1) {
         if (npass == 1 && ob == oe && check_on) {   // nothing to merge: the first load step tells whether the bucket fits (CHECK)
-          if (full_word_keys) table_insert_stream1<kLoadBatch, false, true, false, true>(tab, new_keys + nb, (uint32_t)(ne - nb), 1u, 0u, nullptr, 1, nullptr, s_hint);
-          else table_insert_stream1<kLoadBatch, false, false, false, true>(tab, new_keys + nb, (uint32_t)(ne - nb), 1u, 0u, nullptr, 1, nullptr, s_hint);
+          if (full_word_keys) table_insert_flat<kLoadBatch, false, true, true>(tab, wq, new_keys + nb, (uint32_t)(ne - nb), 1u, 0u, s_hint);
+          else table_insert_flat<kLoadBatch, false, false, true>(tab, wq, new_keys + nb, (uint32_t)(ne - nb), 1u, 0u, s_hint);
         } else if (npass == 1) {
-          if (full_word_keys) table_insert_stream1<kLoadBatch, false, true>(tab, new_keys + nb, (uint32_t)(ne - nb), 1u, 0u);
-          else table_insert_stream1<kLoadBatch, false, false>(tab, new_keys + nb, (uint32_t)(ne - nb), 1u, 0u);
+          if (full_word_keys) table_insert_flat<kLoadBatch, false, true, false>(tab, wq, new_keys + nb, (uint32_t)(ne - nb), 1u, 0u);
+          else table_insert_flat<kLoadBatch, false, false, false>(tab, wq, new_keys + nb, (uint32_t)(ne - nb), 1u, 0u);
         } else if (scratch == nullptr) {
-          table_insert_stream1<kLoadBatch, true>(tab, new_keys + nb, (uint32_t)(ne - nb), npass, pass);
+          table_insert_flat<kLoadBatch, true, true, false>(tab, wq, new_keys + nb, (uint32_t)(ne - nb), npass, pass);
         } else if (pass + 1u < npass) {
           const bool up = (pass & 1u) == 0u;
           uint64_t *spill = up ? scratch + nb : tmp_keys + tmp0 + (ne - nb) + (oe - ob) - 1u;
@@ -1576,7 +1739,7 @@ __global__ __launch_bounds__((TabCfg<NW>::NT)) void bucket_reduce_kernel(const u
           src = up ? spill : spill - (n_src ? n_src - 1u : 0u);
         } else {
           pass_len = n_src;
-          table_insert_stream1<kLoadBatch, false, true>(tab, src, n_src, 1u, 0u);   // what is left belongs to the last pass
+          table_insert_flat<kLoadBatch, false, true, false>(tab, wq, src, n_src, 1u, 0u);   // what is left belongs to the last pass
         }
       } else {
         for_each_key<NW, BatchOf<NW>::U>(new_keys, nb, ne, [&](const uint64_t (&k)[NW], uint64_t) {
