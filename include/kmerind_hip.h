@@ -187,6 +187,12 @@ kmi_status kmi_index_insert_dev(kmi_index *idx, const uint64_t *kmers_dev, size_
 /* the local_insert half alone (distributed_unordered_map.hpp:1734-1741): keys that already went through the
  * InputTransform -- what kmi_route_dev / kmi_extract_route_dev produce and the exchange delivers -- are reduced as they are */
 kmi_status kmi_index_insert_transformed_dev(kmi_index *idx, const uint64_t *kmers_dev, size_t n);
+/* Index::insert(std::vector<std::pair<Kmer, T>>&) of the counting / reduction maps (kmer_index.hpp:200-225 ->
+ * reduction_unordered_map::local_insert, distributed_unordered_map.hpp:1603-1618: `at() = r(at(), v)` with r = std::plus):
+ * every pair's value is ADDED to the key's count. records = n objects of (n_words key words, one value word whose low
+ * 32 bits are the count) -- the object bytes of std::pair<Kmer, uint32_t>; the keys go through the InputTransform. */
+kmi_status kmi_index_insert_pairs_host(kmi_index *idx, const uint64_t *records, size_t n);
+kmi_status kmi_index_insert_pairs_dev(kmi_index *idx, const uint64_t *records_dev, size_t n);
 /* Index::build_mmap/build_posix for nranks == 1: read_file + insert fused on the
  * device (kmer_index.hpp:239-372). */
 kmi_status kmi_index_build_host(kmi_index *idx, const uint8_t *bytes, size_t n_bytes, uint64_t file_offset);

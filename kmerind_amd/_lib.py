@@ -86,6 +86,8 @@ SIGNATURES = {
     "kmi_index_insert_host": (C.c_int, [_P, _P, _sz]),
     "kmi_index_insert_dev": (C.c_int, [_P, _P, _sz]),
     "kmi_index_insert_transformed_dev": (C.c_int, [_P, _P, _sz]),
+    "kmi_index_insert_pairs_host": (C.c_int, [_P, _P, _sz]),
+    "kmi_index_insert_pairs_dev": (C.c_int, [_P, _P, _sz]),
     "kmi_index_build_host": (C.c_int, [_P, _P, _sz, _u64]),
     "kmi_index_build_dev": (C.c_int, [_P, _P, _sz, _u64]),
     "kmi_index_clear": (C.c_int, [_P]),

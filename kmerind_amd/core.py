@@ -202,6 +202,14 @@ class CountIndex:
         kmers = _u64(kmers, self.n_words)
         self.ctx.check(lib.kmi_index_insert_host(self.h, kmers.ctypes.data_as(C.c_void_p), kmers.shape[0]))
 
+    def insert_pairs(self, kmers, counts):
+        """Index::insert(vector<pair<Kmer, count>>): every pair's count is added (distributed_unordered_map.hpp:1603-1618)"""
+        kmers = _u64(kmers, self.n_words)
+        rec = np.zeros((kmers.shape[0], self.n_words + 1), dtype=np.uint64)
+        rec[:, :self.n_words] = kmers
+        rec[:, self.n_words] = np.asarray(counts, dtype=np.uint64) & np.uint64(0xFFFFFFFF)
+        self.ctx.check(lib.kmi_index_insert_pairs_host(self.h, rec.ctypes.data_as(C.c_void_p), rec.shape[0]))
+
     def insert_device(self, dptr, n, transformed=False):
         """transformed=True: the keys already went through the InputTransform (routed keys after the exchange)"""
         fn = lib.kmi_index_insert_transformed_dev if transformed else lib.kmi_index_insert_dev

@@ -58,7 +58,8 @@ template <int RW> struct PartCfg {
   static constexpr int PER_THREAD = TILE / kPartThreads;                                         // 8, 4, 2, 1
 };
 
-enum BucketMode { BUCKET_COARSE = 0, BUCKET_SUB = 1, BUCKET_RANK = 2 };
+// BUCKET_REC: super-k-mer records (kmi_superkmer.h): the fine bucket sits in bits 46..52 of the record's second word
+enum BucketMode { BUCKET_COARSE = 0, BUCKET_SUB = 1, BUCKET_RANK = 2, BUCKET_REC = 3 };
 
 struct BucketFn {
   int mode; KShape shape; uint32_t dist_hash; bool farm_ndebug; uint32_t nranks;
@@ -317,7 +318,8 @@ __device__ __forceinline__ void scatter_range(const uint64_t *__restrict__ in, u
 #pragma unroll
           for (int w = 0; w < NW; ++w) k[j][w] = kr[w];
         }
-        bk[j] = bucket_of<NW>(k[j], fn);
+        if (VW > 0 && fn.mode == BUCKET_REC) bk[j] = (uint32_t)(v[j][0] >> 46) & (uint32_t)(kSubPerCoarse - 1);
+        else bk[j] = bucket_of<NW>(k[j], fn);
         rk[j] = atomicAdd(&s_cnt[bk[j]], 1u);
       }
     }
@@ -388,14 +390,14 @@ __global__ __launch_bounds__(kPartThreads) void scatter_chunks_kernel(const uint
 template <int NW, int BITS, int VW = 0>
 __global__ __launch_bounds__(kPartThreads) void scatter_fine_kernel(const uint64_t *__restrict__ in, uint64_t *__restrict__ out, KShape shape,
                                                                    const uint64_t *__restrict__ fine_off, const uint64_t *__restrict__ part_off,
-                                                                   const uint64_t *__restrict__ wg_off, uint32_t groups) {
+                                                                   const uint64_t *__restrict__ wg_off, uint32_t groups, int mode = BUCKET_SUB) {
   KMI_SCATTER_LDS(NW + VW)
   const uint32_t gpp = groups / kFineParts;   // K2 / E2 workgroups per part
   const uint32_t c = blockIdx.x / kFineParts, h = blockIdx.x % kFineParts;
   const uint64_t cursor = (threadIdx.x < kSubPerCoarse) ? part_off[(uint64_t)h * kNumFine + c * kSubPerCoarse + threadIdx.x] : 0ull;
   const uint64_t b = wg_off[(uint64_t)(h * gpp) * kNumCoarse + c];
   const uint64_t e = (h + 1 < (uint32_t)kFineParts) ? wg_off[(uint64_t)((h + 1) * gpp) * kNumCoarse + c] : fine_off[(c + 1) * kSubPerCoarse];
-  BucketFn fn; fn.mode = BUCKET_SUB; fn.shape = shape; fn.dist_hash = 0; fn.farm_ndebug = false; fn.nranks = 1; fn.sub = 1;
+  BucketFn fn; fn.mode = mode; fn.shape = shape; fn.dist_hash = 0; fn.farm_ndebug = false; fn.nranks = 1; fn.sub = 1;
   if (b < e) scatter_range<NW, BITS, VW>(in, b, e, out, shape, 0u, false, fn, cursor, s_stage, s_bkt, s_cnt, s_lofs, s_gbase, s_part);
 }
 
@@ -576,16 +578,23 @@ template <int NW, int BITS> struct ListPassCfg {
   static uint32_t max_runs(uint32_t k, bool split = false) { return (uint32_t)TILE / (k + (split ? 1u : 7u)) + 2u; }
   // entry list: one 16-bit entry per run of up to 8 consecutive windows; per-tile slots of this many entries
   static uint32_t ent_stride(uint32_t k, bool split = false) { return (uint32_t)TILE / 8u + max_runs(k, split); }
+  // run list (RUNS): one 32-bit entry per run of up to `seg` windows
+  static uint32_t run_stride(uint32_t k, uint32_t seg, bool split = false) { return (uint32_t)TILE / seg + max_runs(k, split); }
   static uint32_t wave_lds_bytes(uint32_t k, bool split = false) {   // bitmap window, event arrays, run table (two with a filter)
     return (4u * WIN + 4u * CAP + 4u * max_runs(k, split) * (split ? 2u : 1u) + 15u) & ~15u;
   }
 };
 
-template <int NW, int BITS>
+// RUNS = true: the list holds the runs themselves, cut only every kSegWindows windows, as 32-bit entries (tile position of the
+// first window | (windows - 1) << 13): what the super-k-mer passes start from (one lane walks one run).
+template <int NW, int BITS, bool RUNS = false>
 __global__ __launch_bounds__(kListThreads) void fastq_list_kernel(PackedInput in, uint64_t n_tiles, uint32_t k, uint32_t max_runs,
                                                                  uint32_t wave_lds_bytes, const uint32_t *__restrict__ line_base,
-                                                                 uint32_t *__restrict__ flags, uint16_t *__restrict__ ent,
-                                                                 uint32_t *__restrict__ ent_cnt, uint32_t ent_stride) {
+                                                                 uint32_t *__restrict__ flags, void *__restrict__ ent_out,
+                                                                 uint32_t *__restrict__ ent_cnt, uint32_t ent_stride,
+                                                                 uint32_t kSegWindows = 128u /* RUNS: windows per entry at most */) {
+  uint16_t *const ent = reinterpret_cast<uint16_t *>(ent_out);
+  uint32_t *const ent32 = reinterpret_cast<uint32_t *>(ent_out);
   // in.brk (sequence filters): the runs are cut where a break bit (an N by the filter's rule) falls inside them
   using P = ListPassCfg<NW, BITS>;
   constexpr int TILE = P::TILE, WORDS = P::WORDS, CTX = P::CTX, WIN = P::WIN, WPL = P::WPL, CAP = P::CAP;
@@ -793,6 +802,21 @@ __global__ __launch_bounds__(kListThreads) void fastq_list_kernel(PackedInput in
     }
     uint32_t ebase = 0;   // entries of this tile so far
     uint16_t *etile = ent + (uint64_t)t * ent_stride;
+    if constexpr (RUNS) {
+      uint32_t *etile32 = ent32 + (uint64_t)t * ent_stride;
+      for (uint32_t r0 = 0; r0 < n_runs; r0 += kWave) {
+        const uint32_t my_sc = (r0 + lane < n_runs) ? runs[r0 + lane] : 0u;
+        const uint32_t s0 = my_sc & 0xffffu, c = my_sc >> 16;
+        const uint32_t my_ne = (c + kSegWindows - 1u) / kSegWindows;
+        const uint32_t einc = wave_inclusive_scan(my_ne);
+        const uint32_t my_eo = ebase + einc - my_ne;
+        for (uint32_t j = 0; j < my_ne; ++j) {
+          const uint32_t left = c - kSegWindows * j;
+          etile32[my_eo + j] = (s0 + kSegWindows * j) | (((left < kSegWindows ? left : kSegWindows) - 1u) << 13);
+        }
+        ebase += __shfl(einc, kWave - 1, kWave);
+      }
+    } else
     for (uint32_t r0 = 0; r0 < n_runs; r0 += kWave) {
       const uint32_t nr = (n_runs - r0 < (uint32_t)kWave) ? n_runs - r0 : (uint32_t)kWave;
       const uint32_t my_sc = (lane < nr) ? runs[r0 + lane] : 0u;
@@ -1467,10 +1491,10 @@ __device__ __forceinline__ uint32_t passes_from_first_step(uint32_t d1, uint32_t
 // Pops queue entries [first, first + cnt), cnt <= 64, one per lane: walk from the home slot, claim an empty slot, count.
 typedef __attribute__((address_space(3))) uint64_t lds_u64_t;
 typedef __attribute__((address_space(3))) uint32_t lds_u32_t;
-__device__ __attribute__((noinline)) void probe_insert_lds(lds_u64_t *tkeys, lds_u32_t *tvals, lds_u32_t *distinct, lds_u32_t *overflow,
-                                                          const lds_u64_t *wq, uint32_t first, uint32_t cnt) {
-  constexpr int CAP = TabCfg<1>::CAP;
-  constexpr uint32_t LAST = TabCfg<1>::SLOTS - 1;
+template <int CAP, int SLOTS, int LIMIT>
+__device__ __attribute__((noinline)) void probe_insert_lds_cap(lds_u64_t *tkeys, lds_u32_t *tvals, lds_u32_t *distinct, lds_u32_t *overflow,
+                                                              const lds_u64_t *wq, uint32_t first, uint32_t cnt) {
+  constexpr uint32_t LAST = SLOTS - 1;
   const uint32_t lane = lane_id();
   if (lane < cnt) {
     const uint64_t key = wq[first + lane];
@@ -1481,7 +1505,7 @@ __device__ __attribute__((noinline)) void probe_insert_lds(lds_u64_t *tkeys, lds
       while (c != key && c != kEmptyKey) { ++s; c = __atomic_load_n(&tkeys[s], __ATOMIC_RELAXED); }   // the walk
       if (c == key) break;
       // empty slot: first sighting of this key (or the table is overloaded)
-      if (s >= LAST || __atomic_load_n(distinct, __ATOMIC_RELAXED) >= (uint32_t)TabCfg<1>::LIMIT) { *overflow = 1; s = LAST; break; }
+      if (s >= LAST || __atomic_load_n(distinct, __ATOMIC_RELAXED) >= (uint32_t)LIMIT) { *overflow = 1; s = LAST; break; }
       uint64_t expected = kEmptyKey;
       if (__atomic_compare_exchange_n(&tkeys[s], &expected, key, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {
         // count the new key, one LDS add per wavefront
@@ -1493,6 +1517,11 @@ __device__ __attribute__((noinline)) void probe_insert_lds(lds_u64_t *tkeys, lds
     }
     __atomic_fetch_add(&tvals[s], 1u, __ATOMIC_RELAXED);   // (slot LAST never holds a key: counts parked there on overflow are never read)
   }
+}
+
+__device__ __forceinline__ void probe_insert_lds(lds_u64_t *tkeys, lds_u32_t *tvals, lds_u32_t *distinct, lds_u32_t *overflow,
+                                                 const lds_u64_t *wq, uint32_t first, uint32_t cnt) {
+  probe_insert_lds_cap<TabCfg<1>::CAP, TabCfg<1>::SLOTS, TabCfg<1>::LIMIT>(tkeys, tvals, distinct, overflow, wq, first, cnt);
 }
 
 template <int U, bool MULTI, bool SPECIAL, bool CHECK>
@@ -1947,6 +1976,88 @@ __global__ __launch_bounds__((TabCfg<NW>::NT)) void bucket_merge_kernel(const ui
   if (threadIdx.x == 0) out_cnt[b] = *s_out;
 }
 
+// Weighted insert: reduction_unordered_map::local_insert with the caller's value (distributed_unordered_map.hpp:1603-1618,
+// `at() = r(at(), v)` with r = std::plus): records = key words followed by ONE value word whose low 32 bits are the count
+// (the object bytes of std::pair<Kmer, uint32_t>). Bucket b of the index and the records of bucket b go through one table.
+// Same output contract as bucket_reduce_kernel.
+template <int NW>
+__global__ __launch_bounds__((TabCfg<NW>::NT)) void bucket_reduce_pairs_kernel(const uint64_t *__restrict__ recs, const uint64_t *__restrict__ new_off,
+                                                                              const uint64_t *__restrict__ old_keys, const uint32_t *__restrict__ old_vals,
+                                                                              const uint64_t *__restrict__ old_off, uint64_t *__restrict__ tmp_keys,
+                                                                              uint32_t *__restrict__ tmp_vals, uint32_t *__restrict__ out_cnt,
+                                                                              uint32_t *__restrict__ flags) {
+  KMI_TABLE_LDS(NW)
+  constexpr int RW = NW + 1;
+  const uint32_t b = blockIdx.x;
+  const uint64_t nb = new_off[b], ne = new_off[b + 1];
+  const uint64_t ob = old_off ? old_off[b] : 0ull, oe = old_off ? old_off[b + 1] : 0ull;
+  if (nb == ne && ob == oe) { if (threadIdx.x == 0) out_cnt[b] = 0; return; }
+  const uint64_t tmp0 = nb + ob;
+  uint32_t *s_out = &s_ctl[4];
+  uint32_t npass = 1;
+  while (true) {
+    if (threadIdx.x == 0) *s_out = 0;
+    bool failed = false;
+    for (uint32_t pass = 0; pass < npass && !failed; ++pass) {
+      table_clear<NW>(tab);
+      lds_barrier();
+      for_each_key<NW, BatchOf<NW>::U>(old_keys, ob, oe, [&](const uint64_t (&k)[NW], uint64_t i) {
+        const uint32_t h = place_hash<NW>(k);
+        if (pass_of(h, npass) != pass) return;
+        int s = table_upsert<NW>(tab, k, h);
+        if (s >= 0) atomicAdd(&tab.vals[s], old_vals[i]);
+        else if (s == -2) atomicAdd(tab.special, old_vals[i]);
+      });
+      for (uint64_t i = nb + threadIdx.x; i < ne; i += blockDim.x) {
+        uint64_t k[NW];
+#pragma unroll
+        for (int w = 0; w < NW; ++w) k[w] = recs[i * RW + w];
+        const uint32_t v = (uint32_t)recs[i * RW + NW];
+        const uint32_t h = place_hash<NW>(k);
+        if (pass_of(h, npass) != pass) continue;
+        int s = table_upsert<NW>(tab, k, h);
+        if (s >= 0) atomicAdd(&tab.vals[s], v);
+        else if (s == -2) atomicAdd(tab.special, v);
+      }
+      lds_barrier();
+      if (*tab.overflow) { failed = true; break; }
+      for (int s = threadIdx.x; s < TabCfg<NW>::SLOTS; s += blockDim.x) {
+        const bool used = slot_used<NW>(tab, s);
+        const uint32_t pos = wave_alloc(s_out, used);
+        if (used) {
+#pragma unroll
+          for (int w = 0; w < NW; ++w) tmp_keys[(tmp0 + pos) * NW + w] = tab.keys[(uint64_t)s * NW + w];
+          tmp_vals[tmp0 + pos] = tab.vals[s];
+        }
+      }
+      lds_barrier();
+      if (NW == 1 && threadIdx.x == 0 && *tab.special_set) {
+        const uint32_t pos = atomicAdd(s_out, 1u);
+        tmp_keys[(tmp0 + pos) * NW] = kEmptyKey;
+        tmp_vals[tmp0 + pos] = *tab.special;
+      }
+      lds_barrier();
+    }
+    if (!failed) break;
+    npass *= 2;
+    if (npass > kMaxPasses) { if (threadIdx.x == 0) { atomicOr(&flags[2], 1u); *s_out = 0; } lds_barrier(); break; }
+    lds_barrier();
+  }
+  if (threadIdx.x == 0) out_cnt[b] = *s_out;
+}
+
+// records (key words, count word) of an index whose keys are already distinct and fine-partitioned -> the index arrays
+template <int NW>
+__global__ __launch_bounds__(256) void unzip_pairs_kernel(const uint64_t *__restrict__ recs, uint64_t n, uint64_t *__restrict__ keys,
+                                                         uint32_t *__restrict__ vals) {
+  constexpr int RW = NW + 1;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+#pragma unroll
+    for (int w = 0; w < NW; ++w) keys[i * NW + w] = recs[i * RW + w];
+    vals[i] = (uint32_t)recs[i * RW + NW];
+  }
+}
+
 // scan of per-bucket counts -> offsets (kNumFine+1) ; totals[slot] = total
 __global__ __launch_bounds__(1024) void bucket_offsets_kernel(const uint32_t *__restrict__ cnt, uint64_t *__restrict__ off,
                                                              uint64_t *__restrict__ totals, int slot) {
@@ -2129,6 +2240,8 @@ __global__ __launch_bounds__(256) void bucket_compact_words_kernel(const uint64_
 }
 
 }  // namespace kmi
+
+#include "kmi_superkmer.h"
 
 // ===========================================================================
 // host side
@@ -2371,7 +2484,116 @@ static kmi_status build_fused_impl(kmi_index *idx, const uint8_t *bytes_dev, siz
   return reduce_and_adopt<NW>(idx, part, (size_t)n, true);
 }
 
+static kmi_status index_insert_pairs(kmi_index *idx, const uint64_t *recs_dev, size_t n, bool transform, bool distinct_in);
+
+// Index::build_* on one rank through super-k-mers (kmi_superkmer.h): FASTQ, one-word 2-bit k-mers, k >= 17.
+// returns KMI_OK with *done = false when the input does not fit the item capacities (the k-mer pipeline takes over)
+template <int W>
+static kmi_status build_superkmer_w(kmi_index *idx, const FastqScan &sc, bool *done) {
+  constexpr int NW = 1, BITS = 2;
+  kmi_ctx *ctx = idx->ctx;
+  *done = false;
+  const uint64_t n = sc.n_tuples, n_tiles = sc.n_tiles;
+  const uint32_t k = idx->shape.k;
+  PackedInput in; in.eol = sc.pk_eol; in.stream = sc.pk_stream; in.n_bytes = sc.n_bytes; in.n_cover = sc.n_cover; in.n_valid = sc.n_bytes; in.brk = sc.pk_brk;
+  const bool split = sc.pk_brk != nullptr;
+  const bool canonical = idx->cfg.strand != KMI_STRAND_SINGLE;
+  using LP = ListPassCfg<NW, BITS>;
+  const uint32_t seg = sk_segment_of((uint32_t)W), ipt = sk_items_per_tile((uint32_t)W);
+  const uint32_t stride = LP::run_stride(k, seg, split);
+  void *p;
+  KMI_TRY(ws_get(ctx, WS_ENT_LIST, sizeof(uint32_t) * ((size_t)n_tiles * stride + 64), &p)); uint32_t *ent = (uint32_t *)p;
+  KMI_TRY(ws_get(ctx, WS_ENT_CNT, sizeof(uint32_t) * (n_tiles + 8), &p)); uint32_t *ent_cnt = (uint32_t *)p;
+  KMI_TRY(ws_get(ctx, WS_ENT_BKT, sizeof(uint32_t) * ((size_t)n_tiles * stride + 64), &p)); uint32_t *run_items = (uint32_t *)p;
+  KMI_TRY(ws_get(ctx, WS_SK_ITEMS, sizeof(uint32_t) * ((size_t)n_tiles * ipt + 64), &p)); uint32_t *items = (uint32_t *)p;
+  KMI_TRY(ws_get(ctx, WS_WGHIST, sizeof(uint32_t) * kPartGroups * kNumCoarse, &p)); uint32_t *wg_hist = (uint32_t *)p;
+  KMI_TRY(ws_get(ctx, WS_CURSOR, sizeof(uint64_t) * kPartGroups * kNumCoarse, &p)); uint64_t *wg_off = (uint64_t *)p;
+  KMI_TRY(ws_get(ctx, WS_MISC, sizeof(uint64_t) * kNumCoarse * 3, &p)); uint64_t *cnt = (uint64_t *)p, *base = cnt + kNumCoarse, *cend = base + kNumCoarse;
+  KMI_TRY(ws_get(ctx, WS_HIST, sizeof(uint32_t) * kNumFine * kFineParts + sizeof(uint64_t) * ((kNumFine + 1) * 2 + kNumFine * kFineParts + kNumCoarse) + 256, &p));
+  uint32_t *fine_hist = (uint32_t *)p;
+  uint64_t *fine_off = (uint64_t *)((char *)p + sizeof(uint32_t) * kNumFine * kFineParts);
+  uint64_t *part_off = fine_off + 2 * (kNumFine + 1);
+  uint64_t *coarse_base = part_off + (uint64_t)kNumFine * kFineParts;
+  KMI_HIP(ctx, hipMemsetAsync(ctx->d_flags + 9, 0, sizeof(uint32_t), ctx->stream));
+  {
+    ProfScope ps(ctx, "fastq_list", n);
+    const uint32_t wave_lds = LP::wave_lds_bytes(k, split);
+    hipLaunchKernelGGL((fastq_list_kernel<NW, BITS, true>), dim3(kListGroups), dim3(kListThreads), wave_lds * (kListThreads / kWave), ctx->stream, in,
+                       n_tiles, k, LP::max_runs(k, split), wave_lds, sc.line_base, ctx->d_flags, (void *)ent, ent_cnt, stride, seg);
+  }
+  {
+    ProfScope ps(ctx, "sk_minimizer", n);
+    hipLaunchKernelGGL((sk_minimizer_kernel<W>), dim3(kPartGroups), dim3(kSkThreads), 0, ctx->stream, in, n_tiles, k, (const uint32_t *)ent,
+                       (const uint32_t *)ent_cnt, stride, ipt, items, run_items, wg_hist, ctx->d_flags);
+  }
+  {
+    ProfScope ps(ctx, "sk_offsets", kNumCoarse);
+    launch_rank_offsets(ctx->stream, (const uint32_t *)wg_hist, (uint32_t)kPartGroups, (uint32_t)kNumCoarse, cnt, base, wg_off);
+  }
+  KMI_HIP(ctx, hipGetLastError());
+  uint64_t h_cnt[2 * kNumCoarse];
+  uint32_t h_flag = 0;
+  KMI_HIP(ctx, hipMemcpyAsync(h_cnt, cnt, sizeof(uint64_t) * 2 * kNumCoarse, hipMemcpyDeviceToHost, ctx->stream));
+  KMI_HIP(ctx, hipMemcpyAsync(&h_flag, ctx->d_flags + 9, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+  KMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  KMI_TRY(fastq_length_verdict(ctx));     // the seq / qual length rule rode on the list pass: the index stays as it was on a parse error
+  if (h_flag) return KMI_OK;              // a run with more items than a lane's list holds, or a tile with more than its share
+  uint64_t R = 0, h_end[kNumCoarse];
+  for (int c = 0; c < kNumCoarse; ++c) { R += h_cnt[c]; h_end[c] = h_cnt[kNumCoarse + c] + h_cnt[c]; }
+  KMI_HIP(ctx, hipMemcpyAsync(cend, h_end, sizeof(h_end), hipMemcpyHostToDevice, ctx->stream));
+  KMI_TRY(ws_get(ctx, WS_KEYS_A, (R + 64) * 16, &p)); uint64_t *rec_a = (uint64_t *)p;
+  KMI_TRY(ws_get(ctx, WS_KEYS_B, (R + 64) * 16, &p)); uint64_t *rec_b = (uint64_t *)p;
+  {
+    ProfScope ps(ctx, "sk_scatter", n);
+    hipLaunchKernelGGL(sk_scatter_kernel, dim3(kPartGroups), dim3(kSkThreads), 0, ctx->stream, in, n_tiles, k, (const uint32_t *)ent,
+                       (const uint32_t *)ent_cnt, stride, ipt, (const uint32_t *)items, (const uint32_t *)run_items, (const uint64_t *)wg_off, rec_a);
+  }
+  {
+    ProfScope ps(ctx, "sk_fine_count", R);
+    hipLaunchKernelGGL(sk_fine_count_kernel, dim3(kNumCoarse * kFineParts), dim3(1024), 0, ctx->stream, (const uint64_t *)rec_a,
+                       (const uint64_t *)wg_off, (const uint64_t *)cend, (uint32_t)kPartGroups, fine_hist);
+  }
+  {
+    ProfScope ps(ctx, "fine_offsets", kNumFine);
+    hipLaunchKernelGGL(fine_offsets_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const uint32_t *)fine_hist, (const uint32_t *)wg_hist,
+                       (uint32_t)kPartGroups, fine_off, part_off, coarse_base);
+  }
+  {
+    ProfScope ps(ctx, "sk_scatter_fine", R);
+    hipLaunchKernelGGL((scatter_fine_kernel<1, 2, 1>), dim3(kNumCoarse * kFineParts), dim3(kPartThreads), 0, ctx->stream, (const uint64_t *)rec_a,
+                       rec_b, idx->shape, (const uint64_t *)fine_off, (const uint64_t *)part_off, (const uint64_t *)wg_off,
+                       (uint32_t)kPartGroups, (int)BUCKET_REC);
+  }
+  KMI_TRY(ws_get(ctx, WS_TMP_KEYS, (n + 64) * 16, &p)); uint64_t *pairs = (uint64_t *)p;
+  unsigned long long *cursor = (unsigned long long *)(ctx->d_totals + 6);
+  KMI_HIP(ctx, hipMemsetAsync(cursor, 0, sizeof(uint64_t), ctx->stream));
+  {
+    ProfScope ps(ctx, "sk_reduce", n);
+    if (canonical)
+      hipLaunchKernelGGL((sk_reduce_kernel<true>), dim3(kNumFine), dim3(SkTabCfg::NT), 0, ctx->stream, (const uint64_t *)rec_b,
+                         (const uint64_t *)fine_off, k, pairs, (uint64_t)n, cursor, ctx->d_flags);
+    else
+      hipLaunchKernelGGL((sk_reduce_kernel<false>), dim3(kNumFine), dim3(SkTabCfg::NT), 0, ctx->stream, (const uint64_t *)rec_b,
+                         (const uint64_t *)fine_off, k, pairs, (uint64_t)n, cursor, ctx->d_flags);
+  }
+  KMI_HIP(ctx, hipGetLastError());
+  uint64_t distinct = 0;
+  KMI_TRY(read_total(ctx, 6, &distinct));
+  *done = true;
+  return index_insert_pairs(idx, pairs, (size_t)distinct, false, true);
+}
+
 static kmi_status index_build_fused(kmi_index *idx, const uint8_t *bytes_dev, size_t n_bytes) {
+  const uint32_t w = (idx->shape.n_words == 1 && idx->shape.bits == 2 && idx->ctx->fused_superkmer) ? sk_window_of(idx->shape.k) : 0u;
+  if (w) {
+    kmi_ctx *ctx = idx->ctx;
+    FastqScan sc;
+    KMI_TRY(fastq_scan(ctx, &idx->cfg, bytes_dev, n_bytes, &sc, false));
+    if (sc.n_tuples == 0) return KMI_OK;
+    bool done = false;
+    kmi_status st = w == 19u ? build_superkmer_w<19>(idx, sc, &done) : (w == 13u ? build_superkmer_w<13>(idx, sc, &done) : build_superkmer_w<7>(idx, sc, &done));
+    if (st != KMI_OK || done) return st;
+  }
   KMI_DISPATCH(idx->shape, build_fused_impl, idx, bytes_dev, n_bytes);
 }
 
@@ -2439,6 +2661,56 @@ static kmi_status mm_insert_impl(kmi_index *idx, const uint64_t *recs_dev, size_
 
 static kmi_status index_insert_records(kmi_index *idx, const uint64_t *recs_dev, size_t n, bool transform) {
   KMI_DISPATCH(idx->shape, mm_insert_impl, idx, recs_dev, n, transform);
+}
+
+// Index::insert(std::vector<std::pair<Kmer, T>>&) of the counting maps: the value of every pair is ADDED
+// (distributed_unordered_map.hpp:1603-1618). distinct_in = true: the keys are known to be distinct (a reduced map handed
+// over), so into an empty index they need no table at all.
+template <int NW, int BITS>
+static kmi_status insert_pairs_impl(kmi_index *idx, const uint64_t *recs_dev, size_t n, bool transform, bool distinct_in) {
+  kmi_ctx *ctx = idx->ctx;
+  if (n == 0) return KMI_OK;
+  Partitioned part;
+  KMI_TRY((partition_impl<NW, BITS, 1>(ctx, &idx->cfg, idx->shape, recs_dev, n, transform, WS_KEYS_A, WS_KEYS_B, &part)));
+  if (distinct_in && !idx->has_data) {
+    uint64_t *nk = nullptr, *noff = nullptr; uint32_t *nv = nullptr;
+    const size_t kb = n * NW * sizeof(uint64_t), vb = n * sizeof(uint32_t);
+    hipError_t e0 = pool_alloc(ctx, (void **)&noff, kOffBytes), e1 = pool_alloc(ctx, (void **)&nk, kb), e2 = pool_alloc(ctx, (void **)&nv, vb);
+    if (e0 != hipSuccess || e1 != hipSuccess || e2 != hipSuccess) {
+      if (nk) pool_free(ctx, nk, kb);
+      if (nv) pool_free(ctx, nv, vb);
+      if (noff) pool_free(ctx, noff, kOffBytes);
+      return set_err(ctx, KMI_ERR_NOMEM, "hipMalloc failed for the index arrays");
+    }
+    {
+      ProfScope ps(ctx, "unzip_pairs", n);
+      hipLaunchKernelGGL((unzip_pairs_kernel<NW>), dim3(2048), dim3(256), 0, ctx->stream, (const uint64_t *)part.keys, (uint64_t)n, nk, nv);
+    }
+    KMI_HIP(ctx, hipMemcpyAsync(noff, part.fine_off, kOffBytes, hipMemcpyDeviceToDevice, ctx->stream));
+    KMI_HIP(ctx, hipGetLastError());
+    KMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    free_index_arrays(idx);
+    idx->keys = nk; idx->vals = nv; idx->bucket_off = noff; idx->n_entries = n; idx->has_data = true;
+    idx->keys_bytes = kb; idx->vals_bytes = vb;
+    return KMI_OK;
+  }
+  void *p;
+  const uint64_t cap = n + idx->n_entries;
+  KMI_TRY(ws_get(ctx, WS_TMP_KEYS, cap * NW * sizeof(uint64_t), &p)); uint64_t *tmp_keys = (uint64_t *)p;
+  KMI_TRY(ws_get(ctx, WS_TMP_VALS, cap * sizeof(uint32_t), &p)); uint32_t *tmp_vals = (uint32_t *)p;
+  KMI_TRY(ws_get(ctx, WS_BUCKET_CNT, sizeof(uint32_t) * kNumFine, &p)); uint32_t *out_cnt = (uint32_t *)p;
+  {
+    ProfScope ps(ctx, "bucket_reduce_pairs", n);
+    hipLaunchKernelGGL((bucket_reduce_pairs_kernel<NW>), dim3(kNumFine), dim3(TabCfg<NW>::NT), 0, ctx->stream, (const uint64_t *)part.keys,
+                       (const uint64_t *)part.fine_off, (const uint64_t *)idx->keys, (const uint32_t *)idx->vals,
+                       (const uint64_t *)(idx->has_data ? idx->bucket_off : nullptr), tmp_keys, tmp_vals, out_cnt, ctx->d_flags);
+  }
+  KMI_HIP(ctx, hipGetLastError());
+  return adopt_tmp<NW>(idx, tmp_keys, tmp_vals, part.fine_off, idx->has_data ? idx->bucket_off : nullptr, out_cnt);
+}
+
+static kmi_status index_insert_pairs(kmi_index *idx, const uint64_t *recs_dev, size_t n, bool transform, bool distinct_in) {
+  KMI_DISPATCH(idx->shape, insert_pairs_impl, idx, recs_dev, n, transform, distinct_in);
 }
 
 // queries: results compacted into out_keys_dev / out_vals_dev (max(1, val_words) u64 per result)
@@ -2778,6 +3050,27 @@ kmi_status kmi_index_insert_transformed_dev(kmi_index *idx, const uint64_t *kmer
   if (idx->val_words) return set_err(idx->ctx, KMI_ERR_INVALID, "a position index takes (k-mer, value) tuples: kmi_index_insert_tuples_*");
   KMI_HIP(idx->ctx, hipSetDevice(idx->ctx->device));
   return index_insert(idx, kmers_dev, n, false);
+}
+
+kmi_status kmi_index_insert_pairs_dev(kmi_index *idx, const uint64_t *records_dev, size_t n) {
+  if (!idx) return KMI_ERR_INVALID;
+  if (idx->val_words) return set_err(idx->ctx, KMI_ERR_INVALID, "(k-mer, count) pairs go into a count index");
+  KMI_HIP(idx->ctx, hipSetDevice(idx->ctx->device));
+  return index_insert_pairs(idx, records_dev, n, true, false);
+}
+
+kmi_status kmi_index_insert_pairs_host(kmi_index *idx, const uint64_t *records, size_t n) {
+  if (!idx) return KMI_ERR_INVALID;
+  kmi_ctx *ctx = idx->ctx;
+  if (idx->val_words) return set_err(ctx, KMI_ERR_INVALID, "(k-mer, count) pairs go into a count index");
+  if (n == 0) return KMI_OK;
+  if (!records) return set_err(ctx, KMI_ERR_INVALID, "null buffer");
+  KMI_HIP(ctx, hipSetDevice(ctx->device));
+  void *din;
+  const size_t bytes = n * (idx->shape.n_words + 1) * sizeof(uint64_t);
+  KMI_TRY(ws_get(ctx, WS_INPUT, bytes, &din));
+  KMI_HIP(ctx, hipMemcpyAsync(din, records, bytes, hipMemcpyHostToDevice, ctx->stream));
+  return index_insert_pairs(idx, (const uint64_t *)din, n, true, false);
 }
 
 kmi_status kmi_index_insert_host(kmi_index *idx, const uint64_t *kmers, size_t n) {

@@ -46,6 +46,7 @@ enum WsSlot {
   WS_PK_NB,           // N bitmap and pure EOL bitmap of the pre-pass (N_FILTER)
   WS_SPLIT_RANK,      // destination rank of every index entry (split by rank)
   WS_SPLIT_OFF,       // per-part bucket offsets, part totals and bases (split / merge)
+  WS_SK_ITEMS,        // super-k-mer items of the minimizer pass (fused build through super-k-mers)
   WS_NUM_SLOTS
 };
 
@@ -79,6 +80,7 @@ struct kmi_ctx {
   // reaches hipMalloc / hipFree, whose cost on a loaded node is unpredictable)
   struct Spare { void *p; size_t bytes; };
   std::vector<Spare> spare;
+  bool fused_superkmer = true;   // fused count-index build through super-k-mers (KMI_FUSED_PATH=kmer in the environment: the k-mer pipeline)
   bool fa_part_set = false;      // kmi_ctx_set_fasta_partition
   kmi_fasta_partition fa_part{};
 };

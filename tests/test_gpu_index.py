@@ -557,3 +557,93 @@ def test_insert_of_already_transformed_keys(ctx):
     pa, pb = orc.sorted_pairs(*a.to_vector()), orc.sorted_pairs(*b.to_vector())
     assert pa[0].shape == pb[0].shape and (pa[0] == pb[0]).all() and (pa[1] == pb[1]).all()
     a.close(); b.close()
+
+
+@pytest.mark.parametrize("k,alpha", [(31, "DNA"), (21, "DNA"), (63, "DNA"), (21, "DNA5")])
+@pytest.mark.parametrize("strand", ["single", "canonical"])
+def test_weighted_pairs_insert_adds_the_values(ctx, k, alpha, strand):
+    """Index::insert(vector<pair<Kmer, count>>): reduction_unordered_map::local_insert adds .second to the stored count
+    (distributed_unordered_map.hpp:1603-1618, std::plus<uint32_t>, wrapping). Weights != 1, keys repeated inside the batch,
+    keys already in the index, both strands of a k-mer in one batch (canonical model: one entry)."""
+    import kmerind_amd as K
+    s = orc.kspec(k, ALPHA[alpha])
+    data = K.synth_fastq(seed=100 + k, genome_len=3000, n_reads=400)
+    ex = orc.extract(s, data, orc.FASTQ)["kmers"]
+    rng = np.random.default_rng(k)
+    first = ex[: ex.shape[0] // 2]
+    idx = K.CountIndex(ctx, K.make_config(k, alpha, strand=strand))
+    idx.insert(first)                                               # weight 1 each
+    pick = rng.integers(0, ex.shape[0], 5000)
+    pk = np.concatenate([ex[pick], orc.revcomp(s, ex[pick[:500]])])
+    pw = rng.integers(0, 1000, pk.shape[0]).astype(np.uint64)
+    pw[:3] = np.uint64(0xFFFFFFFF)                                  # wraps like uint32_t addition
+    idx.insert_pairs(pk, pw)
+    # expectation: the oracle's map for the weight-1 part, plus the weights summed per transformed key (mod 2^32)
+    om = orc.CountMap(s, STRAND[strand])
+    om.insert(first)
+    ok, oc = om.export()
+    tk = pk if strand == "single" else orc.canonical(s, pk)
+    exp = {tuple(kk): int(c) for kk, c in zip(ok.tolist(), oc.tolist())}
+    for kk, w in zip(tk.tolist(), pw.tolist()):
+        exp[tuple(kk)] = (exp.get(tuple(kk), 0) + int(w)) & 0xFFFFFFFF
+    keys, counts = idx.to_vector()
+    got = {tuple(kk): int(c) for kk, c in zip(keys.tolist(), counts.tolist())}
+    assert len(got) == keys.shape[0]                                # distinct entries
+    assert got == exp
+    # pairs into an EMPTY index
+    idx2 = K.CountIndex(ctx, K.make_config(k, alpha, strand=strand))
+    idx2.insert_pairs(pk, pw)
+    exp2 = {}
+    for kk, w in zip(tk.tolist(), pw.tolist()):
+        exp2[tuple(kk)] = (exp2.get(tuple(kk), 0) + int(w)) & 0xFFFFFFFF
+    keys, counts = idx2.to_vector()
+    assert {tuple(kk): int(c) for kk, c in zip(keys.tolist(), counts.tolist())} == exp2
+    idx.close()
+    idx2.close()
+
+
+@pytest.mark.parametrize("k,strand", [(31, "canonical"), (32, "single"), (29, "canonical"), (28, "canonical"), (23, "single"), (21, "canonical"), (17, "canonical")])
+def test_superkmer_build_ran_and_matches_oracle(ctx, k, strand):
+    """The fused FASTQ build of one-word DNA k-mers (k >= 17) goes through super-k-mers (kmi_superkmer.h): the kernels must
+    actually have run (no silent fall-back to the k-mer pipeline) and the index must be the oracle's, also when the build
+    lands in an index that already holds entries."""
+    import kmerind_amd as K
+    s = orc.kspec(k, orc.DNA)
+    data = K.synth_fastq(seed=7 * k, genome_len=60_000, n_reads=6_000)
+    half = (data.shape[0] // 315 // 2) * 315
+    idx = K.CountIndex(ctx, K.make_config(k, "DNA", strand=strand))
+    ctx.profile(True)
+    ctx.profile_reset()
+    idx.build(data[:half])
+    names = {p["name"] for p in ctx.profile_get() if p["launches"]}
+    ctx.profile(False)
+    assert {"sk_minimizer", "sk_scatter", "sk_reduce"} <= names and "fastq_scatter" not in names, names
+    om = orc.CountMap(s, STRAND[strand])
+    om.insert(orc.extract(s, data[:half], orc.FASTQ)["kmers"])
+    _same_map(idx, om)
+    idx.build(data[half:])                                          # second build: merges into the existing entries
+    om.insert(orc.extract(s, data[half:], orc.FASTQ)["kmers"])
+    _same_map(idx, om)
+    idx.close()
+
+
+def test_kmer_pipeline_still_selectable(monkeypatch):
+    """KMI_FUSED_PATH=kmer at context creation keeps the fused build on the k-mer pipeline (the fall-back of the super-k-mer
+    path when a run or a tile exceeds its item capacity): same index."""
+    import kmerind_amd as K
+    monkeypatch.setenv("KMI_FUSED_PATH", "kmer")
+    c2 = K.Context(0)
+    k = 31
+    s = orc.kspec(k, orc.DNA)
+    data = K.synth_fastq(seed=11, genome_len=30_000, n_reads=3_000)
+    idx = K.CountIndex(c2, K.make_config(k, "DNA", strand="canonical"))
+    c2.profile(True)
+    c2.profile_reset()
+    idx.build(data)
+    names = {p["name"] for p in c2.profile_get() if p["launches"]}
+    assert "fastq_scatter" in names and "sk_reduce" not in names
+    om = orc.CountMap(s, orc.CANONICAL)
+    om.insert(orc.extract(s, data, orc.FASTQ)["kmers"])
+    _same_map(idx, om)
+    idx.close()
+    c2.close()
