@@ -30,6 +30,7 @@
 #include <algorithm>
 
 #include "kmi_extract.h"
+#include "kmi_minimizer.h"
 #include <type_traits>
 
 namespace kmi {
@@ -65,6 +66,7 @@ struct BucketFn {
   int mode; KShape shape; uint32_t dist_hash; bool farm_ndebug; uint32_t nranks;
   uint32_t sub;   // rank mode: sub-buckets per rank (power of two, nranks * sub <= 256)
   uint32_t dist_trans = 0;   // rank mode: KMI_DIST_* applied to the key before DistHash (single-strand model only)
+  uint32_t layout_w = 0;     // coarse / sub modes: 0 = the index is laid out by placement hash; W = by minimizer bucket (fine15_of_key)
   uint64_t rank_magic = 0;   // rank mode: floor(2^64 / nranks) for rank counts that are no power of two (rank_of_hash)
 };
 inline uint64_t rank_magic_of(uint32_t nranks) { return nranks > 1u ? (uint64_t)(((unsigned __int128)1 << 64) / nranks) : 0ull; }
@@ -86,6 +88,16 @@ __host__ __device__ inline uint32_t rank_of_hash(uint64_t h, uint32_t nranks, ui
 // instead of p hot ones (with p = 2..8 the same-address LDS atomics were the bottleneck of both rank kernels).
 inline uint32_t rank_sub_buckets(uint32_t nranks) { uint32_t s = 1; while (s * 2u * nranks <= (uint32_t)kNumCoarse) s *= 2u; return s; }
 
+// The 15-bit fine bucket of a stored key. An index is laid out either by the placement hash (layout_w = 0: everything that
+// arrives as k-mers) or by minimizer bucket (layout_w = W: what the super-k-mer build leaves, one-word 2-bit k-mers only);
+// kmi_index::layout_w says which, and every partition of keys for that index uses the same function.
+template <int NW> __device__ __forceinline__ uint32_t fine15_of_key(const uint64_t (&key)[NW], uint32_t layout_w, uint32_t k) {
+  if constexpr (NW == 1) {
+    if (layout_w) return sk_key_bucket18(key[0], k, layout_w) >> 3;   // uniform
+  }
+  return fine_of(place_hash<NW>(key));
+}
+
 template <int NW> __device__ __forceinline__ uint32_t bucket_of(const uint64_t (&key)[NW], const BucketFn &f) {
   if (f.mode == BUCKET_RANK) {
     uint64_t t[NW];
@@ -103,8 +115,8 @@ template <int NW> __device__ __forceinline__ uint32_t bucket_of(const uint64_t (
     const uint32_t rank = rank_of_hash(h, f.nranks, f.rank_magic);
     return rank * f.sub + ((spread >> 16) & (f.sub - 1u));
   }
-  uint32_t h = place_hash<NW>(key);
-  return f.mode == BUCKET_COARSE ? coarse_of(h) : (fine_of(h) & (kSubPerCoarse - 1));
+  const uint32_t fb = fine15_of_key<NW>(key, f.layout_w, f.shape.k);
+  return f.mode == BUCKET_COARSE ? (fb >> (kFineBits - kCoarseBits)) : (fb & (kSubPerCoarse - 1));
 }
 
 template <int NW, int BITS> __device__ __forceinline__ void load_key(const uint64_t *__restrict__ keys, uint64_t i, const KShape &s,
@@ -132,7 +144,8 @@ template <int NW, int BITS, int VW = 0>
 __global__ __launch_bounds__(kPartThreads) void hist_fine_kernel(const uint64_t *__restrict__ keys, uint64_t n, KShape shape,
                                                                 uint32_t strand, bool transform,
                                                                 uint32_t *__restrict__ fine_hist,     // [kFineParts][kNumFine] global
-                                                                uint32_t *__restrict__ wg_hist) {     // [groups][256]
+                                                                uint32_t *__restrict__ wg_hist,       // [groups][256]
+                                                                uint32_t layout_w = 0) {
   __shared__ uint32_t s_hist[kNumFine];
   for (int i = threadIdx.x; i < kNumFine; i += kPartThreads) s_hist[i] = 0;
   lds_barrier();
@@ -161,7 +174,7 @@ __global__ __launch_bounds__(kPartThreads) void hist_fine_kernel(const uint64_t 
 #pragma unroll
           for (int w = 0; w < NW; ++w) k[w] = raw[u][w];
         }
-        atomicAdd(&s_hist[fine_of(place_hash<NW>(k))], 1u);
+        atomicAdd(&s_hist[fine15_of_key<NW>(k, layout_w, shape.k)], 1u);
       }
     }
   }
@@ -390,14 +403,15 @@ __global__ __launch_bounds__(kPartThreads) void scatter_chunks_kernel(const uint
 template <int NW, int BITS, int VW = 0>
 __global__ __launch_bounds__(kPartThreads) void scatter_fine_kernel(const uint64_t *__restrict__ in, uint64_t *__restrict__ out, KShape shape,
                                                                    const uint64_t *__restrict__ fine_off, const uint64_t *__restrict__ part_off,
-                                                                   const uint64_t *__restrict__ wg_off, uint32_t groups, int mode = BUCKET_SUB) {
+                                                                   const uint64_t *__restrict__ wg_off, uint32_t groups, int mode = BUCKET_SUB,
+                                                                   uint32_t layout_w = 0) {
   KMI_SCATTER_LDS(NW + VW)
   const uint32_t gpp = groups / kFineParts;   // K2 / E2 workgroups per part
   const uint32_t c = blockIdx.x / kFineParts, h = blockIdx.x % kFineParts;
   const uint64_t cursor = (threadIdx.x < kSubPerCoarse) ? part_off[(uint64_t)h * kNumFine + c * kSubPerCoarse + threadIdx.x] : 0ull;
   const uint64_t b = wg_off[(uint64_t)(h * gpp) * kNumCoarse + c];
   const uint64_t e = (h + 1 < (uint32_t)kFineParts) ? wg_off[(uint64_t)((h + 1) * gpp) * kNumCoarse + c] : fine_off[(c + 1) * kSubPerCoarse];
-  BucketFn fn; fn.mode = mode; fn.shape = shape; fn.dist_hash = 0; fn.farm_ndebug = false; fn.nranks = 1; fn.sub = 1;
+  BucketFn fn; fn.mode = mode; fn.shape = shape; fn.dist_hash = 0; fn.farm_ndebug = false; fn.nranks = 1; fn.sub = 1; fn.layout_w = layout_w;
   if (b < e) scatter_range<NW, BITS, VW>(in, b, e, out, shape, 0u, false, fn, cursor, s_stage, s_bkt, s_cnt, s_lofs, s_gbase, s_part);
 }
 
@@ -534,7 +548,8 @@ __device__ __forceinline__ void scatter_lines_range(const uint64_t *__restrict__
 __global__ __launch_bounds__(kPartThreads) void scatter_fine_lines_kernel(const uint64_t *__restrict__ in, uint64_t *__restrict__ out,
                                                                          const uint64_t *__restrict__ fine_off,
                                                                          const uint64_t *__restrict__ part_off,
-                                                                         const uint64_t *__restrict__ wg_off, uint32_t groups) {
+                                                                         const uint64_t *__restrict__ wg_off, uint32_t groups,
+                                                                         uint32_t layout_w = 0, uint32_t k = 0) {
   constexpr int NB = kSubPerCoarse;
   const uint32_t gpp = groups / kFineParts;   // K2 / E2 workgroups per part
   const uint32_t c = blockIdx.x / kFineParts, h = blockIdx.x % kFineParts;
@@ -542,7 +557,7 @@ __global__ __launch_bounds__(kPartThreads) void scatter_fine_lines_kernel(const 
   const uint64_t begin = wg_off[(uint64_t)(h * gpp) * kNumCoarse + c];
   const uint64_t end = (h + 1 < (uint32_t)kFineParts) ? wg_off[(uint64_t)((h + 1) * gpp) * kNumCoarse + c] : fine_off[(c + 1) * NB];
   scatter_lines_range<NB>(in, begin, end, out, cursor, [](uint64_t r) { return r; },
-                          [](uint64_t k) { const uint64_t kk[1] = {k}; return fine_of(place_hash<1>(kk)) & (uint32_t)(NB - 1); });
+                          [=](uint64_t key) { const uint64_t kk[1] = {key}; return fine15_of_key<1>(kk, layout_w, k) & (uint32_t)(NB - 1); });
 }
 
 // ---------------------------------------------------------------------------
@@ -2259,11 +2274,23 @@ struct kmi_index {
   uint64_t *bucket_off = nullptr; // [kNumFine + 1]
   uint64_t n_entries = 0;
   bool has_data = false;
+  uint32_t layout_w = 0;          // what the fine buckets mean: 0 = top bits of the placement hash; W = minimizer bucket (fine15_of_key)
   size_t keys_bytes = 0, vals_bytes = 0, mvals_bytes = 0;   // sizes of the blocks above (for the context's spare list)
 };
 constexpr size_t kOffBytes = sizeof(uint64_t) * ((size_t)1 << 15) + sizeof(uint64_t);
 
 namespace kmi {
+
+static kmi_status index_insert_pairs(kmi_index *idx, const uint64_t *recs_dev, size_t n, bool transform, bool distinct_in);
+static kmi_status ensure_layout(kmi_index *idx, uint32_t target_w);
+static void free_index_arrays(kmi_index *idx);
+template <int NW>
+__global__ void zip_pairs_kernel(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ vals, uint64_t n, uint64_t *__restrict__ recs);
+// the layout a count index of this configuration is kept in when it has the choice (split / merge between ranks agree on it)
+static uint32_t preferred_layout(const kmi_index *idx) {
+  return (idx->val_words == 0 && idx->shape.n_words == 1 && idx->shape.bits == 2 && idx->ctx->fused_superkmer) ? sk_window_of(idx->shape.k) : 0u;
+}
+
 
 struct Partitioned {
   uint64_t *keys;      // fine-partitioned keys (WS_KEYS_B or WS_QUERY_B)
@@ -2301,14 +2328,14 @@ static kmi_status get_part_ws(kmi_ctx *ctx, size_t n, int nw, WsSlot slot_a, WsS
 // K1 + offsets + K2 + P2 on `n` keys; result in slot `slot_b`, scratch in `slot_a`
 template <int NW, int BITS, int VW = 0>
 static kmi_status partition_impl(kmi_ctx *ctx, const kmi_config *cfg, KShape shape, const uint64_t *keys_dev, size_t n, bool transform,
-                                 WsSlot slot_a, WsSlot slot_b, Partitioned *out) {
+                                 WsSlot slot_a, WsSlot slot_b, Partitioned *out, uint32_t layout_w = 0) {
   PartWs w;
   KMI_TRY(get_part_ws(ctx, n, NW + VW, slot_a, slot_b, &w));
   KMI_HIP(ctx, hipMemsetAsync(w.fine_hist, 0, sizeof(uint32_t) * kNumFine * kFineParts, ctx->stream));
   {
     ProfScope ps(ctx, "hist_fine", n);
     hipLaunchKernelGGL((hist_fine_kernel<NW, BITS, VW>), dim3(kPartGroups), dim3(kPartThreads), 0, ctx->stream, keys_dev, (uint64_t)n, shape,
-                       cfg->strand, transform, w.fine_hist, w.wg_hist);
+                       cfg->strand, transform, w.fine_hist, w.wg_hist, layout_w);
   }
   {
     ProfScope ps(ctx, "fine_offsets", kNumFine);
@@ -2317,7 +2344,7 @@ static kmi_status partition_impl(kmi_ctx *ctx, const kmi_config *cfg, KShape sha
     hipLaunchKernelGGL(coarse_cursors_kernel, dim3(kNumCoarse / 4), dim3(256), 0, ctx->stream, (const uint32_t *)w.wg_hist, (uint32_t)kPartGroups,
                        (const uint64_t *)w.coarse_base, w.wg_off);
   }
-  BucketFn fn; fn.mode = BUCKET_COARSE; fn.shape = shape; fn.dist_hash = 0; fn.farm_ndebug = false; fn.nranks = 1; fn.sub = 1;
+  BucketFn fn; fn.mode = BUCKET_COARSE; fn.shape = shape; fn.dist_hash = 0; fn.farm_ndebug = false; fn.nranks = 1; fn.sub = 1; fn.layout_w = layout_w;
   {
     ProfScope ps(ctx, "scatter_coarse", n);
     hipLaunchKernelGGL((scatter_chunks_kernel<NW, BITS, VW>), dim3(kPartGroups), dim3(kPartThreads), 0, ctx->stream, keys_dev, (uint64_t)n, w.buf_a,
@@ -2327,10 +2354,12 @@ static kmi_status partition_impl(kmi_ctx *ctx, const kmi_config *cfg, KShape sha
     ProfScope ps(ctx, "scatter_fine", n);
     if (NW == 1 && VW == 0)
       hipLaunchKernelGGL(scatter_fine_lines_kernel, dim3(kNumCoarse * kFineParts), dim3(kPartThreads), 0, ctx->stream, (const uint64_t *)w.buf_a,
-                         w.buf_b, (const uint64_t *)w.fine_off, (const uint64_t *)w.part_off, (const uint64_t *)w.wg_off, (uint32_t)kPartGroups);
+                         w.buf_b, (const uint64_t *)w.fine_off, (const uint64_t *)w.part_off, (const uint64_t *)w.wg_off, (uint32_t)kPartGroups,
+                         layout_w, shape.k);
     else
       hipLaunchKernelGGL((scatter_fine_kernel<NW, BITS, VW>), dim3(kNumCoarse * kFineParts), dim3(kPartThreads), 0, ctx->stream, w.buf_a, w.buf_b,
-                         shape, (const uint64_t *)w.fine_off, (const uint64_t *)w.part_off, (const uint64_t *)w.wg_off, (uint32_t)kPartGroups);
+                         shape, (const uint64_t *)w.fine_off, (const uint64_t *)w.part_off, (const uint64_t *)w.wg_off, (uint32_t)kPartGroups,
+                         (int)BUCKET_SUB, layout_w);
   }
   KMI_HIP(ctx, hipGetLastError());
   out->keys = w.buf_b; out->fine_off = w.fine_off;
@@ -2416,6 +2445,7 @@ template <int NW, int BITS>
 static kmi_status insert_impl(kmi_index *idx, const uint64_t *keys_dev, size_t n, bool transform) {
   kmi_ctx *ctx = idx->ctx;
   if (n == 0) return KMI_OK;
+  KMI_TRY(ensure_layout(idx, 0u));   // k-mers are partitioned by the placement hash
   Partitioned part;
   KMI_TRY((partition_impl<NW, BITS>(ctx, &idx->cfg, idx->shape, keys_dev, n, transform, WS_KEYS_A, WS_KEYS_B, &part)));
   return reduce_and_adopt<NW>(idx, part, n);
@@ -2425,6 +2455,7 @@ static kmi_status insert_impl(kmi_index *idx, const uint64_t *keys_dev, size_t n
 template <int NW, int BITS>
 static kmi_status build_fused_impl(kmi_index *idx, const uint8_t *bytes_dev, size_t n_bytes) {
   kmi_ctx *ctx = idx->ctx;
+  KMI_TRY(ensure_layout(idx, 0u));
   FastqScan sc;
   KMI_TRY(fastq_scan(ctx, &idx->cfg, bytes_dev, n_bytes, &sc, false));   // reports malformed FASTQ (the length rule rides on the list pass)
   const uint64_t n = sc.n_tuples, n_tiles = sc.n_tiles;
@@ -2483,8 +2514,6 @@ static kmi_status build_fused_impl(kmi_index *idx, const uint8_t *bytes_dev, siz
   Partitioned part; part.keys = w.buf_b; part.fine_off = w.fine_off; part.scratch = (NW == 1) ? w.buf_a : nullptr;
   return reduce_and_adopt<NW>(idx, part, (size_t)n, true);
 }
-
-static kmi_status index_insert_pairs(kmi_index *idx, const uint64_t *recs_dev, size_t n, bool transform, bool distinct_in);
 
 // Index::build_* on one rank through super-k-mers (kmi_superkmer.h): FASTQ, one-word 2-bit k-mers, k >= 17.
 // returns KMI_OK with *done = false when the input does not fit the item capacities (the k-mer pipeline takes over)
@@ -2548,39 +2577,65 @@ static kmi_status build_superkmer_w(kmi_index *idx, const FastqScan &sc, bool *d
     hipLaunchKernelGGL(sk_scatter_kernel, dim3(kPartGroups), dim3(kSkThreads), 0, ctx->stream, in, n_tiles, k, (const uint32_t *)ent,
                        (const uint32_t *)ent_cnt, stride, ipt, (const uint32_t *)items, (const uint32_t *)run_items, (const uint64_t *)wg_off, rec_a);
   }
+  KMI_TRY(ws_get(ctx, WS_SPLIT_OFF, sizeof(uint32_t) * kNumFine * kFineParts + sizeof(uint64_t) * ((kNumFine + 1) + kNumFine * kFineParts + kNumCoarse) + 256, &p));
+  uint32_t *fine_kmers = (uint32_t *)p;
+  uint64_t *kmer_off = (uint64_t *)((char *)p + sizeof(uint32_t) * kNumFine * kFineParts);
+  uint64_t *k_part = kmer_off + (kNumFine + 1), *k_base = k_part + (uint64_t)kNumFine * kFineParts;
   {
     ProfScope ps(ctx, "sk_fine_count", R);
     hipLaunchKernelGGL(sk_fine_count_kernel, dim3(kNumCoarse * kFineParts), dim3(1024), 0, ctx->stream, (const uint64_t *)rec_a,
-                       (const uint64_t *)wg_off, (const uint64_t *)cend, (uint32_t)kPartGroups, fine_hist);
+                       (const uint64_t *)wg_off, (const uint64_t *)cend, (uint32_t)kPartGroups, fine_hist, fine_kmers);
   }
   {
     ProfScope ps(ctx, "fine_offsets", kNumFine);
     hipLaunchKernelGGL(fine_offsets_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const uint32_t *)fine_hist, (const uint32_t *)wg_hist,
                        (uint32_t)kPartGroups, fine_off, part_off, coarse_base);
+    hipLaunchKernelGGL(fine_offsets_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const uint32_t *)fine_kmers, (const uint32_t *)wg_hist,
+                       (uint32_t)kPartGroups, kmer_off, k_part, k_base);
   }
   {
     ProfScope ps(ctx, "sk_scatter_fine", R);
     hipLaunchKernelGGL((scatter_fine_kernel<1, 2, 1>), dim3(kNumCoarse * kFineParts), dim3(kPartThreads), 0, ctx->stream, (const uint64_t *)rec_a,
                        rec_b, idx->shape, (const uint64_t *)fine_off, (const uint64_t *)part_off, (const uint64_t *)wg_off,
-                       (uint32_t)kPartGroups, (int)BUCKET_REC);
+                       (uint32_t)kPartGroups, (int)BUCKET_REC, 0u);
   }
-  KMI_TRY(ws_get(ctx, WS_TMP_KEYS, (n + 64) * 16, &p)); uint64_t *pairs = (uint64_t *)p;
-  unsigned long long *cursor = (unsigned long long *)(ctx->d_totals + 6);
-  KMI_HIP(ctx, hipMemsetAsync(cursor, 0, sizeof(uint64_t), ctx->stream));
+  // per bucket: as many output slots as it has k-mers (bucket_reduce_kernel's contract), compacted by adopt_tmp
+  KMI_TRY(ws_get(ctx, WS_TMP_KEYS, (n + 64) * sizeof(uint64_t), &p)); uint64_t *tmp_keys = (uint64_t *)p;
+  KMI_TRY(ws_get(ctx, WS_TMP_VALS, (n + 64) * sizeof(uint32_t), &p)); uint32_t *tmp_vals = (uint32_t *)p;
+  KMI_TRY(ws_get(ctx, WS_BUCKET_CNT, sizeof(uint32_t) * kNumFine, &p)); uint32_t *out_cnt = (uint32_t *)p;
   {
     ProfScope ps(ctx, "sk_reduce", n);
     if (canonical)
       hipLaunchKernelGGL((sk_reduce_kernel<true>), dim3(kNumFine), dim3(SkTabCfg::NT), 0, ctx->stream, (const uint64_t *)rec_b,
-                         (const uint64_t *)fine_off, k, pairs, (uint64_t)n, cursor, ctx->d_flags);
+                         (const uint64_t *)fine_off, k, (const uint64_t *)kmer_off, tmp_keys, tmp_vals, out_cnt, ctx->d_flags, ctx->sk_dbg);
     else
       hipLaunchKernelGGL((sk_reduce_kernel<false>), dim3(kNumFine), dim3(SkTabCfg::NT), 0, ctx->stream, (const uint64_t *)rec_b,
-                         (const uint64_t *)fine_off, k, pairs, (uint64_t)n, cursor, ctx->d_flags);
+                         (const uint64_t *)fine_off, k, (const uint64_t *)kmer_off, tmp_keys, tmp_vals, out_cnt, ctx->d_flags, ctx->sk_dbg);
   }
   KMI_HIP(ctx, hipGetLastError());
-  uint64_t distinct = 0;
-  KMI_TRY(read_total(ctx, 6, &distinct));
   *done = true;
-  return index_insert_pairs(idx, pairs, (size_t)distinct, false, true);
+  if (!idx->has_data || idx->n_entries == 0) {
+    // the index IS the reduce output: entries grouped by minimizer bucket. Queries partition their keys by the same function
+    // (fine15_of_key); whatever needs the placement-hash layout converts the entries once (ensure_layout).
+    KMI_TRY((adopt_tmp<NW>(idx, tmp_keys, tmp_vals, kmer_off, nullptr, out_cnt)));
+    idx->layout_w = (uint32_t)W;
+    return KMI_OK;
+  }
+  // the index holds entries already: the new ones become a scratch index, whose pairs are added to the old
+  kmi_index scratch;
+  scratch.ctx = ctx; scratch.cfg = idx->cfg; scratch.shape = idx->shape; scratch.val_words = 0;
+  kmi_status st = adopt_tmp<NW>(&scratch, tmp_keys, tmp_vals, kmer_off, nullptr, out_cnt);
+  if (st == KMI_OK && scratch.n_entries) {
+    st = ws_get(ctx, WS_OUTPUT, (scratch.n_entries + 64) * 2 * sizeof(uint64_t), &p);   // (WS_INPUT2 is the re-layout's)
+    if (st == KMI_OK) {
+      hipLaunchKernelGGL((zip_pairs_kernel<NW>), dim3(2048), dim3(256), 0, ctx->stream, (const uint64_t *)scratch.keys, (const uint32_t *)scratch.vals,
+                         scratch.n_entries, (uint64_t *)p);
+      st = index_insert_pairs(idx, (const uint64_t *)p, (size_t)scratch.n_entries, false, true);
+    }
+  }
+  (void)hipStreamSynchronize(ctx->stream);
+  free_index_arrays(&scratch);
+  return st;
 }
 
 static kmi_status index_build_fused(kmi_index *idx, const uint8_t *bytes_dev, size_t n_bytes) {
@@ -2609,6 +2664,51 @@ static void free_index_arrays(kmi_index *idx) {
   pool_free(ctx, idx->bucket_off, kOffBytes);
   idx->keys = nullptr; idx->vals = nullptr; idx->mvals = nullptr; idx->bucket_off = nullptr;
   idx->keys_bytes = idx->vals_bytes = idx->mvals_bytes = 0;
+}
+
+// pairs (key words, count word) out of the index arrays
+template <int NW>
+__global__ __launch_bounds__(256) void zip_pairs_kernel(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ vals, uint64_t n,
+                                                       uint64_t *__restrict__ recs) {
+  constexpr int RW = NW + 1;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+#pragma unroll
+    for (int w = 0; w < NW; ++w) recs[i * RW + w] = keys[i * NW + w];
+    recs[i * RW + NW] = vals[i];
+  }
+}
+
+// A count index of one-word 2-bit k-mers is laid out by placement hash or by minimizer bucket (kmi_index::layout_w). The
+// super-k-mer build leaves the second, everything that arrives as k-mers or pairs is partitioned by the first; an entry
+// point that needs the other layout re-partitions the (distinct) entries once: zip -> partition by the target's bucket
+// function -> unzip.
+template <int NW, int BITS>
+static kmi_status relayout_impl(kmi_index *idx, uint32_t target_w) {
+  kmi_ctx *ctx = idx->ctx;
+  const uint64_t n = idx->n_entries;
+  void *p;
+  KMI_TRY(ws_get(ctx, WS_INPUT2, (n + 64) * (NW + 1) * sizeof(uint64_t), &p)); uint64_t *recs = (uint64_t *)p;
+  {
+    ProfScope ps(ctx, "zip_pairs", n);
+    hipLaunchKernelGGL((zip_pairs_kernel<NW>), dim3(2048), dim3(256), 0, ctx->stream, (const uint64_t *)idx->keys, (const uint32_t *)idx->vals, n, recs);
+  }
+  Partitioned part;
+  KMI_TRY((partition_impl<NW, BITS, 1>(ctx, &idx->cfg, idx->shape, recs, (size_t)n, false, WS_KEYS_A, WS_KEYS_B, &part, target_w)));
+  {   // same number of entries: the arrays are rewritten in place
+    ProfScope ps(ctx, "unzip_pairs", n);
+    hipLaunchKernelGGL((unzip_pairs_kernel<NW>), dim3(2048), dim3(256), 0, ctx->stream, (const uint64_t *)part.keys, n, idx->keys, idx->vals);
+  }
+  KMI_HIP(ctx, hipMemcpyAsync(idx->bucket_off, part.fine_off, kOffBytes, hipMemcpyDeviceToDevice, ctx->stream));
+  KMI_HIP(ctx, hipGetLastError());
+  KMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  idx->layout_w = target_w;
+  return KMI_OK;
+}
+static kmi_status relayout_dispatch(kmi_index *idx, uint32_t target_w) { KMI_DISPATCH(idx->shape, relayout_impl, idx, target_w); }
+static kmi_status ensure_layout(kmi_index *idx, uint32_t target_w) {
+  if (idx->layout_w == target_w) return KMI_OK;
+  if (!idx->has_data || idx->n_entries == 0 || idx->val_words) { idx->layout_w = idx->val_words ? 0u : target_w; return KMI_OK; }
+  return relayout_dispatch(idx, target_w);
 }
 
 static kmi_status alloc_mm_arrays(kmi_ctx *ctx, uint64_t total, int nw, int vw, uint64_t **nk, uint64_t **nv, uint64_t **noff, size_t *kb,
@@ -2670,6 +2770,7 @@ template <int NW, int BITS>
 static kmi_status insert_pairs_impl(kmi_index *idx, const uint64_t *recs_dev, size_t n, bool transform, bool distinct_in) {
   kmi_ctx *ctx = idx->ctx;
   if (n == 0) return KMI_OK;
+  KMI_TRY(ensure_layout(idx, 0u));
   Partitioned part;
   KMI_TRY((partition_impl<NW, BITS, 1>(ctx, &idx->cfg, idx->shape, recs_dev, n, transform, WS_KEYS_A, WS_KEYS_B, &part)));
   if (distinct_in && !idx->has_data) {
@@ -2723,7 +2824,7 @@ static kmi_status query_vw(kmi_index *idx, int mode, const uint64_t *q_dev, size
   if (nq == 0) return KMI_OK;
   if (mode == Q_ERASE && !idx->has_data) return KMI_OK;
   Partitioned part;
-  KMI_TRY((partition_impl<NW, BITS>(ctx, &idx->cfg, idx->shape, q_dev, nq, true, WS_QUERY_A, WS_QUERY_B, &part)));
+  KMI_TRY((partition_impl<NW, BITS>(ctx, &idx->cfg, idx->shape, q_dev, nq, true, WS_QUERY_A, WS_QUERY_B, &part, idx->has_data ? idx->layout_w : 0u)));
   void *p;
   const bool by_entries = (mode == Q_ERASE) || (VW > 0 && mode == Q_FIND);
   const uint64_t cap = by_entries ? std::max<uint64_t>(idx->n_entries, 1) : nq;
@@ -2916,6 +3017,7 @@ static kmi_status split_impl(kmi_index *idx, uint32_t nranks, uint64_t *out_keys
   kmi_ctx *ctx = idx->ctx;
   const uint64_t n = idx->n_entries;
   if (n > capacity) return set_err(ctx, KMI_ERR_OVERFLOW, "output capacity is smaller than the number of index entries");
+  KMI_TRY(ensure_layout(idx, preferred_layout(idx)));   // sender and receiver agree on what "bucket b" means
   void *p;
   KMI_TRY(ws_get(ctx, WS_SPLIT_RANK, n + 64, &p)); uint8_t *rank_of = (uint8_t *)p;
   KMI_TRY(ws_get(ctx, WS_SPLIT_OFF, sizeof(uint64_t) * ((size_t)nranks * (kNumFine + 1) + 2 * (kNumCoarse + 1)), &p));
@@ -2948,6 +3050,7 @@ static kmi_status split_impl(kmi_index *idx, uint32_t nranks, uint64_t *out_keys
 template <int NW, int BITS>
 static kmi_status merge_impl(kmi_index *idx, uint32_t nparts, const uint64_t *keys_dev, const uint32_t *counts_dev, const uint32_t *bucket_cnt_dev) {
   kmi_ctx *ctx = idx->ctx;
+  KMI_TRY(ensure_layout(idx, preferred_layout(idx)));
   void *p;
   KMI_TRY(ws_get(ctx, WS_SPLIT_OFF, sizeof(uint64_t) * ((size_t)nparts * (kNumFine + 1) + 2 * (kNumCoarse + 1)), &p));
   uint64_t *boff = (uint64_t *)p, *tot = boff + (size_t)nparts * (kNumFine + 1), *base = tot + kNumCoarse + 1;

@@ -81,6 +81,7 @@ struct kmi_ctx {
   struct Spare { void *p; size_t bytes; };
   std::vector<Spare> spare;
   bool fused_superkmer = true;   // fused count-index build through super-k-mers (KMI_FUSED_PATH=kmer in the environment: the k-mer pipeline)
+  int sk_dbg = 0;                // KMI_SK_DBG: timing experiments of sk_reduce (results are wrong when set)
   bool fa_part_set = false;      // kmi_ctx_set_fasta_partition
   kmi_fasta_partition fa_part{};
 };

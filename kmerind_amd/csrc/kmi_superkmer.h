@@ -26,17 +26,6 @@
 
 namespace kmi {
 
-// (W, m) by k: W = 19 for k 29..32 (m = 11..14), 13 for k 23..28 (m = 11..16), 7 for k 17..22 (m = 11..16); an m-mer
-// always fits 32 bits and has at least 2 M canonical values (bucket balance). Smaller k keep the k-mer pipeline.
-__host__ __device__ inline uint32_t sk_window_of(uint32_t k) { return k >= 29u ? 19u : (k >= 23u ? 13u : (k >= 17u ? 7u : 0u)); }
-// A run entry is one lane's work and its items one lane's list: entries are cut every so many windows that they hold about
-// 12 items whatever W is (a super-k-mer averages (W + 1) / 2 windows)
-__host__ __device__ inline uint32_t sk_segment_of(uint32_t w) { return w >= 19u ? 128u : (w >= 13u ? 80u : 44u); }
-// capacity of the item stream per 8 KB scan tile (26 reads of 150 bases: about 330 / 500 / 850 items are used)
-__host__ __device__ inline uint32_t sk_items_per_tile(uint32_t w) { return w >= 19u ? 1024u : (w >= 13u ? 1536u : 2560u); }
-// longest super-k-mer kept in one record: k + n - 1 <= 51 bases (102 bits) and n - 1 in 5 bits
-__host__ __device__ inline uint32_t sk_nmax_of(uint32_t k) { return (52u - k) < 32u ? (52u - k) : 32u; }
-
 // record (16 bytes): word 0 = bases 0..31 of the complement-stream slice, word 1 = bases 32..50 (38 bits) | (n - 1) << 38 |
 // bucket bits << 43 (18 bits: coarse 8 | fine 7 | sub 3, most significant first)
 constexpr int kRecNShift = 38, kRecHashShift = 43;
@@ -46,28 +35,6 @@ __device__ __forceinline__ uint32_t rec_fine_sub(uint64_t w1) { return (rec_hash
 constexpr int kSkThreads = 512;      // workgroup of the minimizer and scatter passes: one lane per run
 constexpr int kSkRoundTiles = 24;    // scan tiles a round may span (512 reads of 150 bases are 20 tiles)
 constexpr int kSkListCap = 32;       // items per run entry (about 13: 25 come up once in 1e5 entries; see sk_segment_of)
-
-// order hash of a canonical m-mer: a bijection on 32 bits, so distinct m-mers never tie (a tie would be broken by
-// position, and position order flips with the strand)
-__device__ __forceinline__ uint32_t sk_order_hash(uint32_t c) {
-  uint32_t h = c * 0x9E3779B1u;
-  h ^= h >> 15;
-  return h;
-}
-// bucket bits of a minimizer (from the low 27 bits of its order hash: the high bits of a MINIMUM are nearly always zero)
-__device__ __forceinline__ uint32_t sk_bucket_bits(uint32_t hv27) {
-  uint32_t h = (hv27 ^ 0x5bd1e995u) * 0x85EBCA6Bu;
-  h ^= h >> 13;
-  h *= 0xC2B2AE35u;
-  h ^= h >> 16;
-  return h >> 14;   // 18 bits
-}
-// forward strand of an m-mer from its complement-stream window (m <= 16: 32 bits)
-__device__ __forceinline__ uint32_t sk_fwd_of(uint32_t r, uint32_t m) {
-  uint32_t x = __builtin_bitreverse32(~r);                    // complement codes -> forward codes, first base to the top
-  x = ((x >> 1) & 0x55555555u) | ((x & 0x55555555u) << 1);   // bit reversal swapped the two bits of every base
-  return x >> (32u - 2u * m);
-}
 
 // a round of the minimizer / scatter passes: up to kSkThreads consecutive runs of the workgroup's tiles (at most
 // kSkRoundTiles scan tiles: the tile of a lane's run is found by comparing against that many prefix counts)
@@ -355,57 +322,105 @@ __global__ __launch_bounds__(kSkThreads) void sk_scatter_kernel(PackedInput in, 
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void sk_fine_count_kernel(const uint64_t *__restrict__ recs, const uint64_t *__restrict__ wg_off,
                                                             const uint64_t *__restrict__ coarse_end /* [kNumCoarse]: end of every coarse bucket */,
-                                                            uint32_t groups, uint32_t *__restrict__ fine_hist /* [kFineParts][kNumFine] */) {
-  __shared__ uint32_t s_h[kSubPerCoarse];
+                                                            uint32_t groups, uint32_t *__restrict__ fine_hist /* [kFineParts][kNumFine] */,
+                                                            uint32_t *__restrict__ fine_kmers /* [kFineParts][kNumFine]: k-mers */) {
+  __shared__ uint32_t s_h[kSubPerCoarse], s_k[kSubPerCoarse];
   const uint32_t gpp = groups / kFineParts;
   const uint32_t c = blockIdx.x / kFineParts, h = blockIdx.x % kFineParts;
-  if (threadIdx.x < kSubPerCoarse) s_h[threadIdx.x] = 0;
+  if (threadIdx.x < kSubPerCoarse) { s_h[threadIdx.x] = 0; s_k[threadIdx.x] = 0; }
   lds_barrier();
   const uint64_t b = wg_off[(uint64_t)(h * gpp) * kNumCoarse + c];
   const uint64_t e = (h + 1 < (uint32_t)kFineParts) ? wg_off[(uint64_t)((h + 1) * gpp) * kNumCoarse + c] : coarse_end[c];
-  for (uint64_t i = b + threadIdx.x; i < e; i += blockDim.x) atomicAdd(&s_h[rec_fine_sub(recs[2 * i + 1])], 1u);
+  for (uint64_t i = b + threadIdx.x; i < e; i += blockDim.x) {
+    const uint64_t w1 = recs[2 * i + 1];
+    atomicAdd(&s_h[rec_fine_sub(w1)], 1u);
+    atomicAdd(&s_k[rec_fine_sub(w1)], ((uint32_t)(w1 >> kRecNShift) & 31u) + 1u);
+  }
   lds_barrier();
-  if (threadIdx.x < kSubPerCoarse) fine_hist[(uint64_t)h * kNumFine + c * kSubPerCoarse + threadIdx.x] = s_h[threadIdx.x];
+  if (threadIdx.x < kSubPerCoarse) {
+    fine_hist[(uint64_t)h * kNumFine + c * kSubPerCoarse + threadIdx.x] = s_h[threadIdx.x];
+    fine_kmers[(uint64_t)h * kNumFine + c * kSubPerCoarse + threadIdx.x] = s_k[threadIdx.x];
+  }
 }
 
 // ---------------------------------------------------------------------------
 // C: per fine bucket, records -> distinct (k-mer, count) pairs
 // ---------------------------------------------------------------------------
-constexpr int kSkKeyQ = 2 * kWave;   // expanded keys waiting per wavefront (fewer than 64 wait, at most 64 join per step)
+// inclusive scans across the 64 lanes on the DPP path (row_shr 1, 2, 4, 8 inside the rows of 16, row_bcast 15 / 31 across
+// them): six VALU instructions, no LDS crossbar
+__device__ __forceinline__ uint32_t wave_inclusive_max_dpp(uint32_t v) {   // identity 0
+  uint32_t t;
+  t = __builtin_amdgcn_update_dpp(0u, v, 0x111, 0xf, 0xf, false); v = v > t ? v : t;
+  t = __builtin_amdgcn_update_dpp(0u, v, 0x112, 0xf, 0xf, false); v = v > t ? v : t;
+  t = __builtin_amdgcn_update_dpp(0u, v, 0x114, 0xf, 0xf, false); v = v > t ? v : t;
+  t = __builtin_amdgcn_update_dpp(0u, v, 0x118, 0xf, 0xf, false); v = v > t ? v : t;
+  t = __builtin_amdgcn_update_dpp(0u, v, 0x142, 0xa, 0xf, false); v = v > t ? v : t;
+  t = __builtin_amdgcn_update_dpp(0u, v, 0x143, 0xc, 0xf, false); v = v > t ? v : t;
+  return v;
+}
+__device__ __forceinline__ uint32_t wave_inclusive_sum_dpp(uint32_t v) {
+  v += __builtin_amdgcn_update_dpp(0u, v, 0x111, 0xf, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(0u, v, 0x112, 0xf, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(0u, v, 0x114, 0xf, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(0u, v, 0x118, 0xf, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(0u, v, 0x142, 0xa, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(0u, v, 0x143, 0xc, 0xf, false);
+  return v;
+}
 
-// table + the two queues of every wavefront fill the CU's LDS: (10752 + 64) x 12 B + 16 x (1 KB + 1 KB)
+// table + per-wavefront scratch fill the CU's LDS: (7680 + 64) x 12 B + 16 x 4352 B
 struct SkTabCfg {
-  static constexpr int CAP = 10752, PAD = 64, SLOTS = CAP + PAD, LIMIT = CAP * 3 / 4, NT = 1024;
+  static constexpr int CAP = 7680, PAD = 64, SLOTS = CAP + PAD, LIMIT = CAP * 3 / 4, NT = 1024;
+  static constexpr int OWN = kWave * 32;   // k-mers of a batch of 64 records at most
 };
 
+// The k-mers of a batch of 64 records (one per lane) are numbered 0 .. T - 1 through the records' prefix sums, and lane l
+// of step t takes k-mer g = 64 t + l WHATEVER record it belongs to, so every lane works in every step although the records
+// hold 1 to 20 k-mers: the record of g is the last one that starts at or before g -- the records mark their first k-mer in
+// a byte array (own[P_r] = r + 1), the step reads own[g] and takes a running maximum over the lanes (DPP scan) -- and its
+// k-mer j = g - P_r is cut out of the record's 128 bits; the forward strand comes from one reverse complement.
 template <bool CANON>
 __global__ __launch_bounds__(SkTabCfg::NT) void sk_reduce_kernel(const uint64_t *__restrict__ recs, const uint64_t *__restrict__ rec_off, uint32_t k,
-                                                                uint64_t *__restrict__ out_pairs, uint64_t out_cap,
-                                                                unsigned long long *__restrict__ out_cursor, uint32_t *__restrict__ flags) {
+                                                                const uint64_t *__restrict__ kmer_off /* k-mers before every bucket */,
+                                                                uint64_t *__restrict__ tmp_keys, uint32_t *__restrict__ tmp_vals,
+                                                                uint32_t *__restrict__ out_cnt, uint32_t *__restrict__ flags, int dbg) {
   using T = SkTabCfg;
+  constexpr int NWAVES = T::NT / kWave;
   __shared__ uint64_t s_tk[T::SLOTS];
   __shared__ uint32_t s_tv[T::SLOTS];
-  __shared__ uint64_t s_keyq[(T::NT / kWave) * kSkKeyQ];
-  __shared__ uint64_t s_missq[(T::NT / kWave) * kMissQ];
-  __shared__ uint32_t s_ctl[8];        // 0 distinct, 1 overflow, 2 special count, 3 special set, 4 output base, 5 stack size
+  __shared__ uint64_t s_missq[NWAVES * kMissQ];
+  __shared__ ulonglong2 s_recs[NWAVES * kWave];
+  __shared__ uint32_t s_pre[NWAVES * kWave];
+  __shared__ uint8_t s_own[NWAVES * T::OWN];
+  __shared__ uint32_t s_ctl[8];        // 0 distinct, 1 overflow, 2 special count, 3 special set, 4 emit counter, 5 stack size, 6/7 output base
   __shared__ uint32_t s_stack[64];     // pending passes: filter bits | value << 8
   const uint32_t b = blockIdx.x;
   const uint64_t rb = rec_off[b], re = rec_off[b + 1];
-  if (rb == re) return;
-  const uint32_t lane = lane_id();
+  if (rb == re) { if (threadIdx.x == 0) out_cnt[b] = 0; return; }
+  const uint64_t tmp0 = kmer_off[b];   // the bucket's output range: as many slots as it has k-mers (same contract as bucket_reduce_kernel)
+  const uint32_t lane = lane_id(), wv = wave_id();
   lds_u64_t *const tkeys = (lds_u64_t *)s_tk;
   lds_u32_t *const tvals = (lds_u32_t *)s_tv;
   lds_u32_t *const tdist = (lds_u32_t *)&s_ctl[0];
   lds_u32_t *const tovf = (lds_u32_t *)&s_ctl[1];
-  uint64_t *const kq = s_keyq + wave_id() * kSkKeyQ;
-  uint64_t *const mq = s_missq + wave_id() * kMissQ;
+  uint64_t *const mq = s_missq + wv * kMissQ;
   const lds_u64_t *const mql = (const lds_u64_t *)mq;
+  ulonglong2 *const wrec = s_recs + wv * kWave;
+  uint32_t *const wpre = s_pre + wv * kWave;
+  uint8_t *const wown = s_own + wv * T::OWN;
   const uint32_t kb = 2u * k;
   const uint64_t kmask = low_mask64(kb);
   const bool full64 = kb == 64u;   // only then can a key equal the empty marker
-  KShape shape = make_shape(k, 2);
-  if (threadIdx.x == 0) { s_ctl[5] = 1; s_stack[0] = 0; }
+  const KShape shape = make_shape(k, 2);
+  for (uint32_t i = threadIdx.x; i < (uint32_t)(NWAVES * T::OWN / 4); i += T::NT) reinterpret_cast<uint32_t *>(s_own)[i] = 0;
+  if (threadIdx.x == 0) { s_ctl[5] = 1; s_stack[0] = 0; s_ctl[4] = 0; }
   lds_barrier();
+  // this wavefront's share of the bucket's records: a contiguous range
+  const uint32_t n_rec = (uint32_t)(re - rb);
+  const uint32_t share = (n_rec + NWAVES - 1) / NWAVES;
+  const uint32_t r_lo = wv * share < n_rec ? wv * share : n_rec;
+  const uint32_t r_hi = r_lo + share < n_rec ? r_lo + share : n_rec;
+  const ulonglong2 *const src = reinterpret_cast<const ulonglong2 *>(recs) + rb;
   while (true) {
     const uint32_t sp = s_ctl[5];
     if (sp == 0) break;                       // uniform
@@ -418,62 +433,67 @@ __global__ __launch_bounds__(SkTabCfg::NT) void sk_reduce_kernel(const uint64_t 
     // the first three filter bits are the records' sub-bucket bits (whole records are skipped), the others come from the key's hash
     const uint32_t rbits = fbits < 3u ? fbits : 3u, rmask = (1u << rbits) - 1u, rval = fval & rmask;
     const uint32_t hbits = fbits - rbits, hmask = (1u << hbits) - 1u, hval = fval >> rbits;
-    uint32_t qn = 0, mn = 0;   // keys waiting in the key queue / the miss queue (uniform)
-    auto fast = [&](uint32_t cnt) {   // the top cnt <= 64 keys of the key queue through the table's fast path
-      const bool act = lane < cnt;
-      const uint64_t key = kq[act ? qn - cnt + lane : 0u];
-      qn -= cnt;
-      const uint64_t kk[1] = {key};
-      const uint32_t h = place_hash<1>(kk);
-      const uint32_t slot = slot_of(h, T::CAP);
-      bool v = act;
-      if (hbits) v = v && ((h >> 17) & hmask) == hval;   // (the slot uses the low 17 bits)
-      if (full64 && v && key == kEmptyKey) { s_ctl[3] = 1; atomicAdd(&s_ctl[2], 1u); v = false; }
-      const uint64_t cur = __atomic_load_n(&s_tk[slot], __ATOMIC_RELAXED);
-      const bool hit = v && cur == key;
-      if (hit) atomicAdd(&s_tv[slot], 1u);
-      const bool miss = v && !hit;
-      const unsigned long long mm = __ballot(miss);
-      if (mm) {
-        const uint32_t pos = mn + __builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0u));
-        if (miss) mq[pos] = key;
-        mn += (uint32_t)__popcll(mm);
-        if (mn >= (uint32_t)kWave) { probe_insert_lds_cap<T::CAP, T::SLOTS, T::LIMIT>(tkeys, tvals, tdist, tovf, mql, mn - kWave, kWave); mn -= kWave; }
-      }
-    };
-    const uint64_t n_rec = re - rb;
-    for (uint64_t r0 = (uint64_t)wave_id() * kWave; r0 < n_rec; r0 += T::NT) {
-      if (__atomic_load_n(&s_ctl[1], __ATOMIC_RELAXED)) break;   // this pass is lost already (uniform enough: every wave leaves at its next step)
-      const uint64_t ri = r0 + lane;
-      uint64_t w0 = 0, w1 = 0;
-      if (ri < n_rec) { const ulonglong2 v = reinterpret_cast<const ulonglong2 *>(recs)[rb + ri]; w0 = v.x; w1 = v.y; }
-      uint32_t n = (ri < n_rec) ? ((uint32_t)(w1 >> kRecNShift) & 31u) + 1u : 0u;
-      if ((rec_hash18(w1) & rmask) != rval) n = 0;
-      // rolling: rc = complement-stream window (the reverse complement), fw = forward strand
-      uint64_t rc = w0 & kmask;
-      uint64_t f1[1], r1[1] = {rc};
-      fwd_from_rc<1, 2>(r1, f1, shape);
-      uint64_t fw = f1[0];
-      // the bases behind the first window: base k + j - 1 completes window j
-      uint64_t nxt = (kb < 64u) ? ((w0 >> kb) | (w1 << (64u - kb))) : w1;
-      for (uint32_t j = 0;; ++j) {
-        const unsigned long long am = __ballot(j < n);
-        if (am == 0ull) break;   // uniform
-        if (j > 0) {
-          const uint64_t c = nxt & 3ull;
-          nxt >>= 2;
-          rc = (rc >> 2) | (c << (kb - 2u));
-          fw = ((fw << 2) | (c ^ 3ull)) & kmask;
+    uint32_t mn = 0;   // keys waiting in the miss queue (uniform)
+    ulonglong2 nxt = make_ulonglong2(0, 0);
+    if (r_lo + lane < r_hi) nxt = src[r_lo + lane];
+    for (uint32_t r0 = r_lo; r0 < r_hi; r0 += kWave) {
+      if (__atomic_load_n(&s_ctl[1], __ATOMIC_RELAXED)) break;   // this pass is lost already
+      if (dbg == 3) { if (nxt.x == 12345ull) s_ctl[2] = 1; if (r0 + kWave + lane < r_hi) nxt = src[r0 + kWave + lane]; continue; }   // experiment: records read only
+      const ulonglong2 rec = nxt;
+      const bool have = r0 + lane < r_hi;
+      if (r0 + kWave + lane < r_hi) nxt = src[r0 + kWave + lane];   // in flight while this batch is expanded
+      uint32_t n = have ? ((uint32_t)(rec.y >> kRecNShift) & 31u) + 1u : 0u;
+      if ((rec_hash18(rec.y) & rmask) != rval) n = 0;
+      const uint32_t inc = wave_inclusive_sum_dpp(n);
+      const uint32_t pre = inc - n;
+      const uint32_t total = __builtin_amdgcn_readlane(inc, kWave - 1);
+      wrec[lane] = rec;
+      wpre[lane] = pre;
+      if (n) wown[pre] = (uint8_t)(lane + 1u);
+      uint32_t carry = 0;   // record (+ 1) the previous step ended in
+      for (uint32_t g0 = 0; g0 < total; g0 += kWave) {
+        const uint32_t g = g0 + lane;
+        const bool act = g < total;
+        uint32_t o = act ? (uint32_t)wown[g] : 0u;
+        o = wave_inclusive_max_dpp(o);
+        o = o > carry ? o : carry;
+        carry = __builtin_amdgcn_readlane(o, kWave - 1);
+        const uint32_t rid = o ? o - 1u : 0u;
+        const uint32_t j = g - wpre[rid];
+        const ulonglong2 rr = wrec[rid];
+        // k-mer j of the record: 2 k bits from bit 2 j of its 128
+        const uint32_t sh = 2u * j;   // 0 .. 62
+        uint64_t rc = sh ? ((rr.x >> sh) | (rr.y << (64u - sh))) : rr.x;
+        rc &= kmask;
+        uint64_t key = rc;
+        {
+          const uint64_t r1[1] = {rc};
+          uint64_t f1[1];
+          fwd_from_rc<1, 2>(r1, f1, shape);
+          key = CANON ? (f1[0] < rc ? f1[0] : rc) : f1[0];
         }
-        const bool a = j < n;
-        const uint64_t key = CANON ? (fw < rc ? fw : rc) : fw;
-        const uint32_t pos = qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(am >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)am, 0u));
-        if (a) kq[pos] = key;
-        qn += (uint32_t)__popcll(am);
-        if (qn >= (uint32_t)kWave) fast(kWave);
+        if (dbg == 1) { if (key == 12345ull) s_ctl[2] = 1; continue; }   // experiment: expansion only
+        // table fast path
+        const uint64_t kk[1] = {key};
+        const uint32_t h = place_hash<1>(kk);
+        const uint32_t slot = slot_of(h, T::CAP);
+        bool v = act;
+        if (hbits) v = v && ((h >> 17) & hmask) == hval;   // (the slot uses the low 17 bits)
+        if (full64 && v && key == kEmptyKey) { s_ctl[3] = 1; atomicAdd(&s_ctl[2], 1u); v = false; }
+        const uint64_t cur = __atomic_load_n(&s_tk[slot], __ATOMIC_RELAXED);
+        const bool hit = v && cur == key;
+        if (hit) atomicAdd(&s_tv[slot], 1u);
+        const bool miss = v && !hit && dbg != 2;   // (experiment 2: no slow path)
+        const unsigned long long mm = __ballot(miss);
+        if (mm) {
+          const uint32_t pos = mn + __builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0u));
+          if (miss) mq[pos] = key;
+          mn += (uint32_t)__popcll(mm);
+          if (mn >= (uint32_t)kWave) { probe_insert_lds_cap<T::CAP, T::SLOTS, T::LIMIT>(tkeys, tvals, tdist, tovf, mql, mn - kWave, kWave); mn -= kWave; }
+        }
       }
+      if (n) wown[pre] = 0;   // the marks go back to zero for the next batch
     }
-    while (qn) fast(qn < (uint32_t)kWave ? qn : (uint32_t)kWave);
     if (mn) { probe_insert_lds_cap<T::CAP, T::SLOTS, T::LIMIT>(tkeys, tvals, tdist, tovf, mql, 0u, mn); mn = 0; }
     lds_barrier();
     if (s_ctl[1]) {   // overflow: this pass splits in two (one more filter bit)
@@ -489,30 +509,24 @@ __global__ __launch_bounds__(SkTabCfg::NT) void sk_reduce_kernel(const uint64_t 
       lds_barrier();
       continue;
     }
-    // emit: one cursor add per pass
-    if (threadIdx.x == 0) {
-      const uint32_t d = s_ctl[0] + (s_ctl[3] ? 1u : 0u);
-      const unsigned long long base = atomicAdd(out_cursor, (unsigned long long)d);
-      if (base + d > out_cap) { atomicOr(&flags[2], 2u); s_ctl[4] = 0xffffffffu; s_ctl[6] = 0; s_ctl[7] = 0; }
-      else { s_ctl[4] = 0; s_ctl[6] = (uint32_t)base; s_ctl[7] = (uint32_t)(base >> 32); }
-    }
-    lds_barrier();
-    if (s_ctl[4] != 0xffffffffu) {
-      const uint64_t base = (uint64_t)s_ctl[6] | ((uint64_t)s_ctl[7] << 32);
+    // emit behind what the earlier passes left (disjoint key sets)
+    {
       uint32_t *s_out = &s_ctl[4];
       for (uint32_t s = threadIdx.x; s < (uint32_t)((T::SLOTS + kWave - 1) / kWave * kWave); s += T::NT) {
         const bool used = s < (uint32_t)T::SLOTS && s_tk[s] != kEmptyKey;
         const uint32_t pos = wave_alloc(s_out, used);
-        if (used) reinterpret_cast<ulonglong2 *>(out_pairs)[base + pos] = make_ulonglong2(s_tk[s], (uint64_t)s_tv[s]);
+        if (used) { tmp_keys[tmp0 + pos] = s_tk[s]; tmp_vals[tmp0 + pos] = s_tv[s]; }
       }
       lds_barrier();
       if (threadIdx.x == 0 && s_ctl[3]) {
         const uint32_t pos = atomicAdd(s_out, 1u);
-        reinterpret_cast<ulonglong2 *>(out_pairs)[base + pos] = make_ulonglong2(kEmptyKey, (uint64_t)s_ctl[2]);
+        tmp_keys[tmp0 + pos] = kEmptyKey;
+        tmp_vals[tmp0 + pos] = s_ctl[2];
       }
     }
     lds_barrier();
   }
+  if (threadIdx.x == 0) out_cnt[b] = s_ctl[4];
 }
 
 }  // namespace kmi
