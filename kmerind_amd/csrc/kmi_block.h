@@ -26,6 +26,28 @@ template <typename T> __device__ __forceinline__ T wave_inclusive_scan(T v) {
   return v;
 }
 
+// inclusive scans across the 64 lanes on the DPP path (row_shr 1, 2, 4, 8 inside the rows of 16, row_bcast 15 / 31 across
+// them): six VALU instructions, no LDS crossbar
+__device__ __forceinline__ uint32_t wave_inclusive_max_dpp(uint32_t v) {   // identity 0
+  uint32_t t;
+  t = __builtin_amdgcn_update_dpp(0u, v, 0x111, 0xf, 0xf, false); v = v > t ? v : t;
+  t = __builtin_amdgcn_update_dpp(0u, v, 0x112, 0xf, 0xf, false); v = v > t ? v : t;
+  t = __builtin_amdgcn_update_dpp(0u, v, 0x114, 0xf, 0xf, false); v = v > t ? v : t;
+  t = __builtin_amdgcn_update_dpp(0u, v, 0x118, 0xf, 0xf, false); v = v > t ? v : t;
+  t = __builtin_amdgcn_update_dpp(0u, v, 0x142, 0xa, 0xf, false); v = v > t ? v : t;
+  t = __builtin_amdgcn_update_dpp(0u, v, 0x143, 0xc, 0xf, false); v = v > t ? v : t;
+  return v;
+}
+__device__ __forceinline__ uint32_t wave_inclusive_sum_dpp(uint32_t v) {
+  v += __builtin_amdgcn_update_dpp(0u, v, 0x111, 0xf, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(0u, v, 0x112, 0xf, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(0u, v, 0x114, 0xf, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(0u, v, 0x118, 0xf, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(0u, v, 0x142, 0xa, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(0u, v, 0x143, 0xc, 0xf, false);
+  return v;
+}
+
 template <typename T> __device__ __forceinline__ T wave_reduce_sum(T v) {
 #pragma unroll
   for (int d = kWave / 2; d > 0; d >>= 1) v += __shfl_xor(v, d, kWave);

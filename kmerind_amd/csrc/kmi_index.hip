@@ -2605,14 +2605,22 @@ static kmi_status build_superkmer_w(kmi_index *idx, const FastqScan &sc, bool *d
   KMI_TRY(ws_get(ctx, WS_BUCKET_CNT, sizeof(uint32_t) * kNumFine, &p)); uint32_t *out_cnt = (uint32_t *)p;
   {
     ProfScope ps(ctx, "sk_reduce", n);
-    if (canonical)
-      hipLaunchKernelGGL((sk_reduce_kernel<true>), dim3(kNumFine), dim3(SkTabCfg::NT), 0, ctx->stream, (const uint64_t *)rec_b,
-                         (const uint64_t *)fine_off, k, (const uint64_t *)kmer_off, tmp_keys, tmp_vals, out_cnt, ctx->d_flags, ctx->sk_dbg);
-    else
-      hipLaunchKernelGGL((sk_reduce_kernel<false>), dim3(kNumFine), dim3(SkTabCfg::NT), 0, ctx->stream, (const uint64_t *)rec_b,
-                         (const uint64_t *)fine_off, k, (const uint64_t *)kmer_off, tmp_keys, tmp_vals, out_cnt, ctx->d_flags, ctx->sk_dbg);
+    const uint32_t nmax = sk_nmax_of(k);
+#define KMI_SK_REDUCE(CANON, OWN)                                                                                                        \
+    hipLaunchKernelGGL((sk_reduce_kernel<CANON, OWN>), dim3(kNumFine), dim3(1024), 0, ctx->stream, (const uint64_t *)rec_b,              \
+                       (const uint64_t *)fine_off, k, (const uint64_t *)kmer_off, tmp_keys, tmp_vals, out_cnt, ctx->d_flags, ctx->sk_dbg)
+    if (nmax <= 21u) { if (canonical) KMI_SK_REDUCE(true, 64 * 21); else KMI_SK_REDUCE(false, 64 * 21); }
+    else if (nmax <= 24u) { if (canonical) KMI_SK_REDUCE(true, 64 * 24); else KMI_SK_REDUCE(false, 64 * 24); }
+    else { if (canonical) KMI_SK_REDUCE(true, 64 * 32); else KMI_SK_REDUCE(false, 64 * 32); }
+#undef KMI_SK_REDUCE
   }
   KMI_HIP(ctx, hipGetLastError());
+  if (ctx->sk_dbg == 6) {
+    uint32_t hf[16];
+    (void)hipMemcpy(hf, ctx->d_flags, sizeof(hf), hipMemcpyDeviceToHost);
+    fprintf(stderr, "sk_reduce: records %u, direct %u, T1 entries %u\n", hf[10], hf[11], hf[12]);
+    (void)hipMemset(ctx->d_flags + 10, 0, 3 * sizeof(uint32_t));
+  }
   *done = true;
   if (!idx->has_data || idx->n_entries == 0) {
     // the index IS the reduce output: entries grouped by minimizer bucket. Queries partition their keys by the same function

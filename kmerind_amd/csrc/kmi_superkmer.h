@@ -229,14 +229,38 @@ __device__ __forceinline__ void sk_assemble(const uint32_t *__restrict__ st, uin
   w1 = hi | ((uint64_t)n1 << kRecNShift) | ((uint64_t)h18 << kRecHashShift);
 }
 
-__global__ __launch_bounds__(kSkThreads) void sk_scatter_kernel(PackedInput in, uint64_t n_tiles, uint32_t k, const uint32_t *__restrict__ ent,
-                                                               const uint32_t *__restrict__ ent_cnt, uint32_t ent_stride, uint32_t items_per_tile,
-                                                               const uint32_t *__restrict__ items, const uint32_t *__restrict__ run_items,
-                                                               const uint64_t *__restrict__ wg_off, uint64_t *__restrict__ out) {
+// the same from a run's row of stream words in LDS: bit position `bit` of the row
+__device__ __forceinline__ void sk_assemble_row(const uint32_t *row, uint32_t bit, uint32_t nb, uint32_t n1, uint32_t h18, uint64_t &w0, uint64_t &w1) {
+  const uint32_t d = bit >> 5, sh = bit & 31u;
+  const uint32_t r0 = row[d], r1 = row[d + 1], r2 = row[d + 2], r3 = row[d + 3], r4 = row[d + 4];
+  const uint32_t a0 = __builtin_amdgcn_alignbit(r1, r0, sh), a1 = __builtin_amdgcn_alignbit(r2, r1, sh);
+  const uint32_t a2 = __builtin_amdgcn_alignbit(r3, r2, sh), a3 = __builtin_amdgcn_alignbit(r4, r3, sh);
+  w0 = (uint64_t)a0 | ((uint64_t)a1 << 32);
+  uint64_t hi = (uint64_t)a2 | ((uint64_t)a3 << 32);
+  const uint32_t bits = 2u * nb;   // 34 .. 102
+  if (bits < 64u) { w0 &= (1ull << bits) - 1ull; hi = 0; }
+  else hi &= (1ull << (bits - 64u)) - 1ull;
+  w1 = hi | ((uint64_t)n1 << kRecNShift) | ((uint64_t)h18 << kRecHashShift);
+}
+
+constexpr int kSkRowDw = 17;   // stream words of a run kept in LDS: up to 63 bases of alignment + 128 + 31 bases = 444 bits in 16 words (odd stride: rows on different banks)
+
+__global__ __launch_bounds__(kSkThreads, 2) void sk_scatter_kernel(PackedInput in, uint64_t n_tiles, uint32_t k, const uint32_t *__restrict__ ent,
+                                                                  const uint32_t *__restrict__ ent_cnt, uint32_t ent_stride, uint32_t items_per_tile,
+                                                                  const uint32_t *__restrict__ items, const uint32_t *__restrict__ run_items,
+                                                                  const uint64_t *__restrict__ wg_off, uint64_t *__restrict__ out) {
+  // A round = the runs of up to 512 lanes. Every lane brings the stream words of its run into LDS (three 16-byte loads of
+  // consecutive memory: gathering them per RECORD on the way out cost five loads of 64 different lines each). The items are
+  // bucket-sorted as 16-bit references (lane of the run << 5 | item number): count per coarse bucket, scan, place. The
+  // copy-out walks the sorted references, so consecutive threads write consecutive 16-byte records of one bucket, each cut
+  // from its run's row.
   constexpr int NT = kSkThreads, CAP = kSkListCap;
-  __shared__ uint64_t s_stage[CAP * NT];   // descriptors: stream position (41 bits) | (n - 1) << 41 | bucket bits << 46
+  __shared__ uint16_t s_stage[CAP * NT];
+  __shared__ uint32_t s_row[NT * kSkRowDw + 4];   // (a record's five-word read window may reach past the last row)
+  __shared__ uint32_t s_bit0[NT];       // bit of the run's first base inside its row
+  __shared__ uint32_t s_ioff[NT];       // first item of every run in the workgroup's item stream
   __shared__ uint32_t s_cnt[kNumCoarse];
-  __shared__ uint32_t s_lofs[kNumCoarse];
+  __shared__ uint32_t s_cur[kNumCoarse];
   __shared__ uint64_t s_gbase[kNumCoarse];
   __shared__ uint32_t s_part[kNumCoarse / kWave];
   __shared__ uint32_t s_total;
@@ -247,34 +271,42 @@ __global__ __launch_bounds__(kSkThreads) void sk_scatter_kernel(PackedInput in, 
   const uint64_t per = (n_tiles + gridDim.x - 1) / gridDim.x;
   const uint64_t tb = (uint64_t)blockIdx.x * per;
   const uint64_t te = (tb + per < n_tiles) ? tb + per : n_tiles;
-  const uint64_t item_base = tb * (uint64_t)items_per_tile;
+  const uint32_t *const wg_items = items + tb * (uint64_t)items_per_tile;
   SkRound cur;
   bool have = tb < te && sk_plan(ent_cnt, te, tb, 0u, cur);
   while (have) {
-    lds_barrier();   // the previous round's stage is done with; the counters are clear
-    uint32_t tr = 0, ev = 0, cnt = 0;
-    uint32_t it[CAP], rk[CAP];
+    lds_barrier();   // the previous round's stage and run tables are done with; the counters are clear
+    uint32_t cnt = 0;
+    uint32_t it[CAP];
     {
+      uint32_t tr = 0, ev = 0, ri = 0;
       uint64_t eidx = 0;
-      uint32_t ri = 0;
       if (threadIdx.x < cur.total) { sk_locate(cur, threadIdx.x, ent_stride, tr, eidx); ev = ent[eidx]; ri = run_items[eidx]; }
       cnt = ri >> 26;
-      const uint32_t *src = items + item_base + (ri & 0x3ffffffu);
+      const uint32_t *src = wg_items + (ri & 0x3ffffffu);
 #pragma unroll
       for (int j = 0; j < CAP; ++j) it[j] = ((uint32_t)j < cnt) ? src[j] : 0u;
+      const uint64_t ip0 = (cur.t + tr) * 8192ull + (ev & 0x1fffu);
+      uint64_t d0 = (ip0 >> 4) & ~3ull;               // 16-byte aligned: dword index, multiple of four
+      d0 = d0 + 16 <= last_dw + 16 ? d0 : 0;          // (16 words from here stay inside the buffer and its 64 bytes of slack)
+      const uint4 q0 = *reinterpret_cast<const uint4 *>(st + d0), q1 = *reinterpret_cast<const uint4 *>(st + d0 + 4),
+                  q2 = *reinterpret_cast<const uint4 *>(st + d0 + 8), q3 = *reinterpret_cast<const uint4 *>(st + d0 + 12);
+      uint32_t *row = s_row + threadIdx.x * kSkRowDw;
+      row[0] = q0.x; row[1] = q0.y; row[2] = q0.z; row[3] = q0.w; row[4] = q1.x; row[5] = q1.y; row[6] = q1.z; row[7] = q1.w;
+      row[8] = q2.x; row[9] = q2.y; row[10] = q2.z; row[11] = q2.w; row[12] = q3.x; row[13] = q3.y; row[14] = q3.z; row[15] = q3.w;
+      row[16] = 0;
+      s_bit0[threadIdx.x] = (uint32_t)(ip0 - d0 * 16) * 2u;   // 0 .. 126
+      s_ioff[threadIdx.x] = ri & 0x3ffffffu;
     }
-    // rank inside (round, coarse bucket), kept as the LDS atomic returns it
 #pragma unroll
-    for (int j = 0; j < CAP; ++j) {
-      rk[j] = 0;
-      if ((uint32_t)j < cnt) rk[j] = atomicAdd(&s_cnt[it[j] >> 22], 1u);
-    }
+    for (int j = 0; j < CAP; ++j)
+      if ((uint32_t)j < cnt) atomicAdd(&s_cnt[it[j] >> 22], 1u);
     lds_barrier();
     uint32_t c = 0, inc = 0;
     if (threadIdx.x < kNumCoarse) {
       c = s_cnt[threadIdx.x];
       s_cnt[threadIdx.x] = 0;
-      inc = wave_inclusive_scan(c);
+      inc = wave_inclusive_sum_dpp(c);
       if (lane_id() == kWave - 1) s_part[wave_id()] = inc;
     }
     lds_barrier();
@@ -283,32 +315,24 @@ __global__ __launch_bounds__(kSkThreads) void sk_scatter_kernel(PackedInput in, 
 #pragma unroll
       for (uint32_t w = 0; w < kNumCoarse / kWave; ++w) pre += (w < wave_id()) ? s_part[w] : 0u;
       const uint32_t lo = pre + inc - c;
-      s_lofs[threadIdx.x] = lo;
+      s_cur[threadIdx.x] = lo;
       s_gbase[threadIdx.x] = cursor - lo;
       cursor += c;
       if (threadIdx.x == kNumCoarse - 1) s_total = pre + inc;
     }
     lds_barrier();
-    {
-      const uint64_t ip0 = (cur.t + tr) * 8192ull + (ev & 0x1fffu);
 #pragma unroll
-      for (int j = 0; j < CAP; ++j) {
-        if ((uint32_t)j < cnt) {
-          const uint32_t h18 = it[j] >> 12, n1 = (it[j] >> 7) & 31u, woff = it[j] & 127u;
-          s_stage[s_lofs[h18 >> 10] + rk[j]] = (ip0 + woff) | ((uint64_t)n1 << 41) | ((uint64_t)h18 << 46);
-        }
-      }
-    }
+    for (int j = 0; j < CAP; ++j)
+      if ((uint32_t)j < cnt) s_stage[atomicAdd(&s_cur[it[j] >> 22], 1u)] = (uint16_t)((threadIdx.x << 5) | (uint32_t)j);
     lds_barrier();
     const uint32_t total = s_total;
     for (uint32_t s = threadIdx.x; s < total; s += NT) {
-      const uint64_t d = s_stage[s];
-      const uint64_t ip = d & ((1ull << 41) - 1ull);
-      const uint32_t n1 = (uint32_t)(d >> 41) & 31u, h18 = (uint32_t)(d >> 46);
+      const uint32_t e = s_stage[s], rl = e >> 5, j = e & 31u;
+      const uint32_t item = wg_items[s_ioff[rl] + j];
+      const uint32_t h18 = item >> 12, n1 = (item >> 7) & 31u;
       uint64_t w0, w1;
-      sk_assemble(st, last_dw, ip, k + n1, n1, h18, w0, w1);
-      const uint64_t dst = s_gbase[h18 >> 10] + s;
-      reinterpret_cast<ulonglong2 *>(out)[dst] = make_ulonglong2(w0, w1);
+      sk_assemble_row(s_row + rl * kSkRowDw, s_bit0[rl] + 2u * (item & 127u), k + n1, n1, h18, w0, w1);
+      reinterpret_cast<ulonglong2 *>(out)[s_gbase[h18 >> 10] + s] = make_ulonglong2(w0, w1);
     }
     SkRound nxt;
     have = sk_plan(ent_cnt, te, cur.nt, cur.nei, nxt);
@@ -346,53 +370,81 @@ __global__ __launch_bounds__(1024) void sk_fine_count_kernel(const uint64_t *__r
 // ---------------------------------------------------------------------------
 // C: per fine bucket, records -> distinct (k-mer, count) pairs
 // ---------------------------------------------------------------------------
-// inclusive scans across the 64 lanes on the DPP path (row_shr 1, 2, 4, 8 inside the rows of 16, row_bcast 15 / 31 across
-// them): six VALU instructions, no LDS crossbar
-__device__ __forceinline__ uint32_t wave_inclusive_max_dpp(uint32_t v) {   // identity 0
-  uint32_t t;
-  t = __builtin_amdgcn_update_dpp(0u, v, 0x111, 0xf, 0xf, false); v = v > t ? v : t;
-  t = __builtin_amdgcn_update_dpp(0u, v, 0x112, 0xf, 0xf, false); v = v > t ? v : t;
-  t = __builtin_amdgcn_update_dpp(0u, v, 0x114, 0xf, 0xf, false); v = v > t ? v : t;
-  t = __builtin_amdgcn_update_dpp(0u, v, 0x118, 0xf, 0xf, false); v = v > t ? v : t;
-  t = __builtin_amdgcn_update_dpp(0u, v, 0x142, 0xa, 0xf, false); v = v > t ? v : t;
-  t = __builtin_amdgcn_update_dpp(0u, v, 0x143, 0xc, 0xf, false); v = v > t ? v : t;
-  return v;
-}
-__device__ __forceinline__ uint32_t wave_inclusive_sum_dpp(uint32_t v) {
-  v += __builtin_amdgcn_update_dpp(0u, v, 0x111, 0xf, 0xf, false);
-  v += __builtin_amdgcn_update_dpp(0u, v, 0x112, 0xf, 0xf, false);
-  v += __builtin_amdgcn_update_dpp(0u, v, 0x114, 0xf, 0xf, false);
-  v += __builtin_amdgcn_update_dpp(0u, v, 0x118, 0xf, 0xf, false);
-  v += __builtin_amdgcn_update_dpp(0u, v, 0x142, 0xa, 0xf, false);
-  v += __builtin_amdgcn_update_dpp(0u, v, 0x143, 0xc, 0xf, false);
-  return v;
-}
-
-// table + per-wavefront scratch fill the CU's LDS: (7680 + 64) x 12 B + 16 x 4352 B
+// ---- sk_reduce -----------------------------------------------------------------------------------------------------
+// Two tables per workgroup. Reads that cover the same stretch of the genome cut it into the SAME super-k-mers (the
+// boundaries depend on the bases alone), so at sequencing coverage most records of a bucket are copies of one another --
+// all but the ones a read's end cut short. T1 counts identical records first (phase A: 128-bit keys); only its distinct
+// records are expanded (phase B), and each of their k-mers enters the k-mer table T2 once, with the record's multiplicity
+// as its weight: for 12x coverage about a quarter of the expansions and table operations. T1 is an accelerator, not a
+// set: a record that finds no room in it (table full, long probe walk, an unlucky race between a claim and its second
+// word) is expanded directly with weight 1, so nothing depends on T1 holding every distinct record exactly once.
+//
+// Expansion (both for T1's slots and for direct records): the k-mers of a batch of 64 records (one per lane) are numbered
+// 0 .. T - 1 through the records' prefix sums, and lane l of step t takes k-mer g = 64 t + l WHATEVER record it belongs
+// to, so every lane works in every step although the records hold 1 to 20 k-mers: the record of g is the last one that
+// starts at or before g -- the records mark their first k-mer in a byte array (own[P_r] = r + 1), the step reads own[g]
+// and takes a running maximum over the lanes (DPP scan) -- its words come over the lane crossbar (ds_bpermute), and its
+// k-mer j = g - P_r is cut out of the record's 128 bits; the forward strand comes from one reverse complement.
+template <int OWN_>
 struct SkTabCfg {
-  static constexpr int CAP = 7680, PAD = 64, SLOTS = CAP + PAD, LIMIT = CAP * 3 / 4, NT = 1024;
-  static constexpr int OWN = kWave * 32;   // k-mers of a batch of 64 records at most
+  static constexpr int NT = 1024, NWAVES = NT / kWave;
+  static constexpr int OWN = OWN_;                       // k-mers of a batch of 64 records at most (64 x nmax)
+  static constexpr int S1 = 2048 + 64;                   // record table slots (20 bytes each)
+  static constexpr int L1 = 1536;                        // records it takes before the rest goes direct
+  static constexpr int FIXED = NWAVES * (OWN + kMissQ * 12) + S1 * 20 + 1024;
+  static constexpr int S2 = ((160 * 1024 - FIXED) / 12) / 64 * 64;   // k-mer table slots (12 bytes each)
+  static constexpr int CAP2 = S2 - 64, LIMIT2 = 48;      // LIMIT2: longest probe walk before the table counts as full
 };
 
-// The k-mers of a batch of 64 records (one per lane) are numbered 0 .. T - 1 through the records' prefix sums, and lane l
-// of step t takes k-mer g = 64 t + l WHATEVER record it belongs to, so every lane works in every step although the records
-// hold 1 to 20 k-mers: the record of g is the last one that starts at or before g -- the records mark their first k-mer in
-// a byte array (own[P_r] = r + 1), the step reads own[g] and takes a running maximum over the lanes (DPP scan) -- and its
-// k-mer j = g - P_r is cut out of the record's 128 bits; the forward strand comes from one reverse complement.
-template <bool CANON>
-__global__ __launch_bounds__(SkTabCfg::NT) void sk_reduce_kernel(const uint64_t *__restrict__ recs, const uint64_t *__restrict__ rec_off, uint32_t k,
-                                                                const uint64_t *__restrict__ kmer_off /* k-mers before every bucket */,
-                                                                uint64_t *__restrict__ tmp_keys, uint32_t *__restrict__ tmp_vals,
-                                                                uint32_t *__restrict__ out_cnt, uint32_t *__restrict__ flags, int dbg) {
-  using T = SkTabCfg;
-  constexpr int NWAVES = T::NT / kWave;
-  __shared__ uint64_t s_tk[T::SLOTS];
-  __shared__ uint32_t s_tv[T::SLOTS];
+// slot hash of the k-mer table (private to this kernel: two multiplies instead of the placement hash's three)
+__device__ __forceinline__ uint32_t sk_slot_hash(uint64_t key) {
+  uint32_t h = ((uint32_t)key ^ ((uint32_t)(key >> 32) * 0x85EBCA6Bu)) * 0x9E3779B1u;
+  h ^= h >> 15;
+  return h;
+}
+__device__ __forceinline__ uint32_t sk_slot_of(uint32_t h, uint32_t cap) { return ((h >> 16) * cap) >> 16; }   // (cap < 2^16: a 24-bit multiply)
+
+// the slow path of the k-mer table, out of line: queue entries [first, first + cnt) (key, weight), one per lane
+__device__ __attribute__((noinline)) void sk_probe_insert(lds_u64_t *tkeys, lds_u32_t *tvals, lds_u32_t *distinct, lds_u32_t *overflow,
+                                                         const lds_u64_t *q, const lds_u32_t *qw, uint32_t first, uint32_t cnt,
+                                                         uint32_t cap, uint32_t last, uint32_t limit) {
+  const uint32_t lane = lane_id();
+  if (lane < cnt) {
+    const uint64_t key = q[first + lane];
+    const uint32_t wt = qw[first + lane];
+    const uint32_t s0 = sk_slot_of(sk_slot_hash(key), cap);
+    uint32_t s = s0;
+    uint64_t c = __atomic_load_n(&tkeys[s], __ATOMIC_RELAXED);
+    for (;;) {
+      while (c != key && c != kEmptyKey) { ++s; c = __atomic_load_n(&tkeys[s], __ATOMIC_RELAXED); }   // the walk (no wrap: padded table)
+      if (c == key) break;
+      // an empty slot. The table counts as full when a walk gets longer than `limit` slots or reaches the end of the padding
+      // (no shared counter of distinct keys on this path: every read of it was a full LDS round trip for a few lanes)
+      if (s >= last || s - s0 > limit) { *overflow = 1; s = last; break; }
+      uint64_t expected = kEmptyKey;
+      if (__atomic_compare_exchange_n(&tkeys[s], &expected, key, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) break;
+      c = expected;
+    }
+    __atomic_fetch_add(&tvals[s], wt, __ATOMIC_RELAXED);   // (slot `last` never holds a key: counts parked there are never read)
+  }
+}
+
+template <bool CANON, int OWN_>
+__global__ __launch_bounds__(1024) void sk_reduce_kernel(const uint64_t *__restrict__ recs, const uint64_t *__restrict__ rec_off, uint32_t k,
+                                                        const uint64_t *__restrict__ kmer_off /* k-mers before every bucket */,
+                                                        uint64_t *__restrict__ tmp_keys, uint32_t *__restrict__ tmp_vals,
+                                                        uint32_t *__restrict__ out_cnt, uint32_t *__restrict__ flags, int dbg) {
+  using T = SkTabCfg<OWN_>;
+  constexpr int NWAVES = T::NWAVES;
+  constexpr uint64_t W1_INIT = ~0ull;   // never a record's second word (its top three bits are zero)
+  __shared__ uint64_t s_tk[T::S2];
+  __shared__ uint32_t s_tv[T::S2];
+  __shared__ ulonglong2 s_r[T::S1];    // T1: the record (x claimed by compare-and-swap, y stored behind it) and its multiplicity
+  __shared__ uint32_t s_rc[T::S1];
   __shared__ uint64_t s_missq[NWAVES * kMissQ];
-  __shared__ ulonglong2 s_recs[NWAVES * kWave];
-  __shared__ uint32_t s_pre[NWAVES * kWave];
+  __shared__ uint32_t s_missw[NWAVES * kMissQ];
   __shared__ uint8_t s_own[NWAVES * T::OWN];
-  __shared__ uint32_t s_ctl[8];        // 0 distinct, 1 overflow, 2 special count, 3 special set, 4 emit counter, 5 stack size, 6/7 output base
+  __shared__ uint32_t s_ctl[12];       // 0 distinct, 1 overflow, 2 special count, 3 special set, 4 emit counter, 5 stack size, 8 records in T1
   __shared__ uint32_t s_stack[64];     // pending passes: filter bits | value << 8
   const uint32_t b = blockIdx.x;
   const uint64_t rb = rec_off[b], re = rec_off[b + 1];
@@ -404,9 +456,7 @@ __global__ __launch_bounds__(SkTabCfg::NT) void sk_reduce_kernel(const uint64_t 
   lds_u32_t *const tdist = (lds_u32_t *)&s_ctl[0];
   lds_u32_t *const tovf = (lds_u32_t *)&s_ctl[1];
   uint64_t *const mq = s_missq + wv * kMissQ;
-  const lds_u64_t *const mql = (const lds_u64_t *)mq;
-  ulonglong2 *const wrec = s_recs + wv * kWave;
-  uint32_t *const wpre = s_pre + wv * kWave;
+  uint32_t *const mw = s_missw + wv * kMissQ;
   uint8_t *const wown = s_own + wv * T::OWN;
   const uint32_t kb = 2u * k;
   const uint64_t kmask = low_mask64(kb);
@@ -415,11 +465,7 @@ __global__ __launch_bounds__(SkTabCfg::NT) void sk_reduce_kernel(const uint64_t 
   for (uint32_t i = threadIdx.x; i < (uint32_t)(NWAVES * T::OWN / 4); i += T::NT) reinterpret_cast<uint32_t *>(s_own)[i] = 0;
   if (threadIdx.x == 0) { s_ctl[5] = 1; s_stack[0] = 0; s_ctl[4] = 0; }
   lds_barrier();
-  // this wavefront's share of the bucket's records: a contiguous range
   const uint32_t n_rec = (uint32_t)(re - rb);
-  const uint32_t share = (n_rec + NWAVES - 1) / NWAVES;
-  const uint32_t r_lo = wv * share < n_rec ? wv * share : n_rec;
-  const uint32_t r_hi = r_lo + share < n_rec ? r_lo + share : n_rec;
   const ulonglong2 *const src = reinterpret_cast<const ulonglong2 *>(recs) + rb;
   while (true) {
     const uint32_t sp = s_ctl[5];
@@ -427,28 +473,20 @@ __global__ __launch_bounds__(SkTabCfg::NT) void sk_reduce_kernel(const uint64_t 
     const uint32_t pass = s_stack[sp - 1];
     const uint32_t fbits = pass & 0xffu, fval = pass >> 8;
     lds_barrier();                            // everyone has read the stack
-    for (uint32_t i = threadIdx.x; i < (uint32_t)T::SLOTS; i += T::NT) { s_tk[i] = kEmptyKey; s_tv[i] = 0; }
-    if (threadIdx.x == 0) { s_ctl[0] = 0; s_ctl[1] = 0; s_ctl[2] = 0; s_ctl[3] = 0; s_ctl[5] = sp - 1; }
+    for (uint32_t i = threadIdx.x; i < (uint32_t)T::S2; i += T::NT) { s_tk[i] = kEmptyKey; s_tv[i] = 0; }
+    for (uint32_t i = threadIdx.x; i < (uint32_t)T::S1; i += T::NT) { s_r[i] = make_ulonglong2(kEmptyKey, W1_INIT); s_rc[i] = 0; }
+    if (threadIdx.x == 0) { s_ctl[0] = 0; s_ctl[1] = 0; s_ctl[2] = 0; s_ctl[3] = 0; s_ctl[5] = sp - 1; s_ctl[8] = 0; }
     lds_barrier();
     // the first three filter bits are the records' sub-bucket bits (whole records are skipped), the others come from the key's hash
     const uint32_t rbits = fbits < 3u ? fbits : 3u, rmask = (1u << rbits) - 1u, rval = fval & rmask;
     const uint32_t hbits = fbits - rbits, hmask = (1u << hbits) - 1u, hval = fval >> rbits;
-    uint32_t mn = 0;   // keys waiting in the miss queue (uniform)
-    ulonglong2 nxt = make_ulonglong2(0, 0);
-    if (r_lo + lane < r_hi) nxt = src[r_lo + lane];
-    for (uint32_t r0 = r_lo; r0 < r_hi; r0 += kWave) {
-      if (__atomic_load_n(&s_ctl[1], __ATOMIC_RELAXED)) break;   // this pass is lost already
-      if (dbg == 3) { if (nxt.x == 12345ull) s_ctl[2] = 1; if (r0 + kWave + lane < r_hi) nxt = src[r0 + kWave + lane]; continue; }   // experiment: records read only
-      const ulonglong2 rec = nxt;
-      const bool have = r0 + lane < r_hi;
-      if (r0 + kWave + lane < r_hi) nxt = src[r0 + kWave + lane];   // in flight while this batch is expanded
-      uint32_t n = have ? ((uint32_t)(rec.y >> kRecNShift) & 31u) + 1u : 0u;
-      if ((rec_hash18(rec.y) & rmask) != rval) n = 0;
+    uint32_t mn = 0;   // (key, weight) pairs waiting in the miss queue (uniform)
+    // all k-mers of the batch's records (w0, w1, weight wt; n = 0: none) into the k-mer table
+    auto expand = [&](uint64_t w0, uint64_t w1, uint32_t wt, uint32_t n) {
       const uint32_t inc = wave_inclusive_sum_dpp(n);
       const uint32_t pre = inc - n;
       const uint32_t total = __builtin_amdgcn_readlane(inc, kWave - 1);
-      wrec[lane] = rec;
-      wpre[lane] = pre;
+      if (total == 0u) return;   // uniform
       if (n) wown[pre] = (uint8_t)(lane + 1u);
       uint32_t carry = 0;   // record (+ 1) the previous step ended in
       for (uint32_t g0 = 0; g0 < total; g0 += kWave) {
@@ -458,14 +496,17 @@ __global__ __launch_bounds__(SkTabCfg::NT) void sk_reduce_kernel(const uint64_t 
         o = wave_inclusive_max_dpp(o);
         o = o > carry ? o : carry;
         carry = __builtin_amdgcn_readlane(o, kWave - 1);
-        const uint32_t rid = o ? o - 1u : 0u;
-        const uint32_t j = g - wpre[rid];
-        const ulonglong2 rr = wrec[rid];
+        const int rl = (int)((o ? o - 1u : 0u) << 2);   // byte address of the lane that holds the record
+        const uint32_t j = g - (uint32_t)__builtin_amdgcn_ds_bpermute(rl, (int)pre);
+        const uint32_t a0 = (uint32_t)__builtin_amdgcn_ds_bpermute(rl, (int)(uint32_t)w0), a1 = (uint32_t)__builtin_amdgcn_ds_bpermute(rl, (int)(uint32_t)(w0 >> 32));
+        const uint32_t a2 = (uint32_t)__builtin_amdgcn_ds_bpermute(rl, (int)(uint32_t)w1), a3 = (uint32_t)__builtin_amdgcn_ds_bpermute(rl, (int)(uint32_t)(w1 >> 32));
+        const uint32_t kw = (uint32_t)__builtin_amdgcn_ds_bpermute(rl, (int)wt);
+        const uint64_t x = (uint64_t)a0 | ((uint64_t)a1 << 32), y = (uint64_t)a2 | ((uint64_t)a3 << 32);
         // k-mer j of the record: 2 k bits from bit 2 j of its 128
         const uint32_t sh = 2u * j;   // 0 .. 62
-        uint64_t rc = sh ? ((rr.x >> sh) | (rr.y << (64u - sh))) : rr.x;
+        uint64_t rc = sh ? ((x >> sh) | (y << (64u - sh))) : x;
         rc &= kmask;
-        uint64_t key = rc;
+        uint64_t key;
         {
           const uint64_t r1[1] = {rc};
           uint64_t f1[1];
@@ -473,28 +514,101 @@ __global__ __launch_bounds__(SkTabCfg::NT) void sk_reduce_kernel(const uint64_t 
           key = CANON ? (f1[0] < rc ? f1[0] : rc) : f1[0];
         }
         if (dbg == 1) { if (key == 12345ull) s_ctl[2] = 1; continue; }   // experiment: expansion only
-        // table fast path
-        const uint64_t kk[1] = {key};
-        const uint32_t h = place_hash<1>(kk);
-        const uint32_t slot = slot_of(h, T::CAP);
+        // table fast path: the home slot and the one behind it in one read
+        const uint32_t h = sk_slot_hash(key);
+        const uint32_t slot = sk_slot_of(h, (uint32_t)T::CAP2);
         bool v = act;
-        if (hbits) v = v && ((h >> 17) & hmask) == hval;   // (the slot uses the low 17 bits)
-        if (full64 && v && key == kEmptyKey) { s_ctl[3] = 1; atomicAdd(&s_ctl[2], 1u); v = false; }
-        const uint64_t cur = __atomic_load_n(&s_tk[slot], __ATOMIC_RELAXED);
-        const bool hit = v && cur == key;
-        if (hit) atomicAdd(&s_tv[slot], 1u);
-        const bool miss = v && !hit && dbg != 2;   // (experiment 2: no slow path)
+        if (hbits) v = v && (h & hmask) == hval;   // (the slot comes from the high bits)
+        if (full64 && v && key == kEmptyKey) { s_ctl[3] = 1; atomicAdd(&s_ctl[2], kw); v = false; }
+        const uint64_t c0 = __atomic_load_n(&s_tk[slot], __ATOMIC_RELAXED), c1 = __atomic_load_n(&s_tk[slot + 1u], __ATOMIC_RELAXED);
+        bool hit0 = v && c0 == key;
+        const bool hit1 = v && c1 == key;
+        if (v && c0 == kEmptyKey) {   // first sighting with a free home slot: claimed here, in line (most first sightings are)
+          const unsigned long long old = atomicCAS((unsigned long long *)&s_tk[slot], (unsigned long long)kEmptyKey, (unsigned long long)key);
+          hit0 = old == kEmptyKey || old == key;
+        }
+        if (hit0 || hit1) atomicAdd(&s_tv[slot + (hit0 ? 0u : 1u)], kw);
+        const bool miss = v && !hit0 && !hit1 && dbg != 2;
         const unsigned long long mm = __ballot(miss);
         if (mm) {
           const uint32_t pos = mn + __builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0u));
-          if (miss) mq[pos] = key;
+          if (miss) { mq[pos] = key; mw[pos] = kw; }
           mn += (uint32_t)__popcll(mm);
-          if (mn >= (uint32_t)kWave) { probe_insert_lds_cap<T::CAP, T::SLOTS, T::LIMIT>(tkeys, tvals, tdist, tovf, mql, mn - kWave, kWave); mn -= kWave; }
+          if (mn >= (uint32_t)kWave) {
+            sk_probe_insert(tkeys, tvals, tdist, tovf, (const lds_u64_t *)mq, (const lds_u32_t *)mw, mn - kWave, kWave, (uint32_t)T::CAP2,
+                            (uint32_t)T::S2 - 1u, (uint32_t)T::LIMIT2);
+            mn -= kWave;
+          }
         }
       }
       if (n) wown[pre] = 0;   // the marks go back to zero for the next batch
+    };
+    // ---- phase A: identical records are counted, what T1 does not take is expanded directly
+    {
+      const uint32_t share = (n_rec + NWAVES - 1) / NWAVES;
+      const uint32_t r_lo = wv * share < n_rec ? wv * share : n_rec;
+      const uint32_t r_hi = r_lo + share < n_rec ? r_lo + share : n_rec;
+      ulonglong2 nxt = make_ulonglong2(0, 0);
+      if (r_lo + lane < r_hi) nxt = src[r_lo + lane];
+      for (uint32_t r0 = r_lo; r0 < r_hi; r0 += kWave) {
+        if (__atomic_load_n(&s_ctl[1], __ATOMIC_RELAXED)) break;   // this pass is lost already
+        const ulonglong2 rec = nxt;
+        const bool have = r0 + lane < r_hi;
+        if (r0 + kWave + lane < r_hi) nxt = src[r0 + kWave + lane];   // in flight while this batch is worked on
+        uint32_t n = have ? ((uint32_t)(rec.y >> kRecNShift) & 31u) + 1u : 0u;
+        if ((rec_hash18(rec.y) & rmask) != rval) n = 0;
+        if (dbg == 3) { if (rec.x == 12345ull) s_ctl[2] = 1; continue; }
+        bool direct = n != 0u;   // still to be placed
+        if (direct && rec.x != kEmptyKey && dbg != 4) {
+          // four consecutive slots in one go (independent reads): the first that holds this record takes the count, else the
+          // first empty one is claimed; no loop -- a record that finds neither is expanded directly
+          uint32_t h = ((uint32_t)rec.x ^ (uint32_t)(rec.x >> 32)) * 0x9E3779B1u ^ ((uint32_t)rec.y ^ (uint32_t)(rec.y >> 32)) * 0x85EBCA6Bu;
+          h ^= h >> 15;
+          const uint32_t s = h >> 21;   // 2048 home slots (+ 64 of padding)
+          ulonglong2 e[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) e[i] = s_r[s + i];
+          int hit = -1, free_ = -1;
+#pragma unroll
+          for (int i = 3; i >= 0; --i) {
+            const bool same = e[i].x == rec.x && e[i].y == rec.y, empty = e[i].x == kEmptyKey;
+            if (same) { hit = i; free_ = -1; } else if (empty) { free_ = i; hit = -1; }   // (the earliest of either kind wins)
+          }
+          if (hit >= 0) { atomicAdd(&s_rc[s + hit], 1u); direct = false; }
+          else if (free_ >= 0 && __atomic_load_n(&s_ctl[8], __ATOMIC_RELAXED) < (uint32_t)T::L1) {
+            const unsigned long long old = atomicCAS((unsigned long long *)&s_r[s + free_].x, (unsigned long long)kEmptyKey, (unsigned long long)rec.x);
+            if (old == kEmptyKey) {   // claimed
+              __atomic_store_n(&s_r[s + free_].y, rec.y, __ATOMIC_RELAXED);
+              atomicAdd(&s_rc[s + free_], 1u);
+              atomicAdd(&s_ctl[8], 1u);
+              direct = false;
+            }
+          }
+        }
+        if (dbg == 6) {   // experiment: how many records go direct
+          const unsigned long long dm = __ballot(direct), nm = __ballot(n != 0u);
+          if (lane == 0) { atomicAdd(&flags[10], (uint32_t)__popcll(nm)); atomicAdd(&flags[11], (uint32_t)__popcll(dm)); }
+        }
+        if (__any(direct)) expand(rec.x, rec.y, 1u, direct ? n : 0u);
+      }
     }
-    if (mn) { probe_insert_lds_cap<T::CAP, T::SLOTS, T::LIMIT>(tkeys, tvals, tdist, tovf, mql, 0u, mn); mn = 0; }
+    lds_barrier();   // T1 complete
+    if (dbg == 6 && threadIdx.x == 0) atomicAdd(&flags[12], s_ctl[8]);
+    // ---- phase B: every distinct record once, with its multiplicity
+    for (uint32_t s0 = wv * kWave; s0 < (uint32_t)T::S1; s0 += T::NT) {
+      if (__atomic_load_n(&s_ctl[1], __ATOMIC_RELAXED)) break;
+      const uint32_t s = s0 + lane;
+      const ulonglong2 ent = s_r[s];
+      const uint64_t w0 = ent.x, w1 = ent.y;
+      const uint32_t wt = s_rc[s];
+      const uint32_t n = (w0 != kEmptyKey && wt) ? ((uint32_t)(w1 >> kRecNShift) & 31u) + 1u : 0u;
+      if (__any(n != 0u)) expand(w0, w1, wt, n);
+    }
+    if (mn) {
+      sk_probe_insert(tkeys, tvals, tdist, tovf, (const lds_u64_t *)mq, (const lds_u32_t *)mw, 0u, mn, (uint32_t)T::CAP2, (uint32_t)T::S2 - 1u,
+                      (uint32_t)T::LIMIT2);
+      mn = 0;
+    }
     lds_barrier();
     if (s_ctl[1]) {   // overflow: this pass splits in two (one more filter bit)
       if (threadIdx.x == 0) {
@@ -512,8 +626,8 @@ __global__ __launch_bounds__(SkTabCfg::NT) void sk_reduce_kernel(const uint64_t 
     // emit behind what the earlier passes left (disjoint key sets)
     {
       uint32_t *s_out = &s_ctl[4];
-      for (uint32_t s = threadIdx.x; s < (uint32_t)((T::SLOTS + kWave - 1) / kWave * kWave); s += T::NT) {
-        const bool used = s < (uint32_t)T::SLOTS && s_tk[s] != kEmptyKey;
+      for (uint32_t s = threadIdx.x; s < (uint32_t)((T::S2 + kWave - 1) / kWave * kWave); s += T::NT) {
+        const bool used = s < (uint32_t)T::S2 && s_tk[s] != kEmptyKey;
         const uint32_t pos = wave_alloc(s_out, used);
         if (used) { tmp_keys[tmp0 + pos] = s_tk[s]; tmp_vals[tmp0 + pos] = s_tv[s]; }
       }
