@@ -38,6 +38,13 @@ KERNEL_ALG_BYTES = {
     "scatter_fine": 16.0,                                  # key in, key out
     "bucket_reduce": 8.0 + 12.0 / 12,                      # key in; (key, count) of each distinct key out
     "bucket_compact": 2 * 12.0 / 12,
+    # fused build through super-k-mers (kmi_superkmer.h): a record is 16 bytes for about 9.3 k-mers (0.108 records per k-mer,
+    # 1.73 B per k-mer), an item 4 bytes per record, a run entry 4 bytes per read
+    "sk_minimizer": 2.625 * 2 / 8 + 0.03 + 0.43 + 0.03,    # packed stream + run list in; items + per-run item index out
+    "sk_scatter": 2.625 * 2 / 8 + 0.43 + 0.06 + 1.73,      # stream + items + run tables in; records out
+    "sk_fine_count": 1.73,                                 # records in
+    "sk_scatter_fine": 2 * 1.73,                           # records in, records out
+    "sk_reduce": 1.73 + 12.0 / 12,                         # records in; (key, count) of each distinct key out
     # N > 1 and insert-from-keys paths
     "fastq_rank_hist": 0.25 + 2.625 * 2 / 8 + 1.0,         # + one rank-bucket byte per window out
     "fastq_rank_scatter": 1.25 + 2.625 * 2 / 8 + 8.0,

@@ -121,10 +121,47 @@ __global__ __launch_bounds__(kSkThreads, 2) void sk_minimizer_kernel(PackedInput
       const uint32_t L = mine ? (ev >> 13) + 1u : 0u;                      // windows of the run
       const uint64_t ip0 = (cur.t + tr) * 8192ull + (ev & 0x1fffu);        // stream position of its first base
       const uint32_t nblk = mine ? (L + (uint32_t)W - 2u) / (uint32_t)W + 1u : 0u;   // m-mer positions 0 .. L + W - 2
+      // the run's stream words, once, into registers: 16 words from the word that holds its first base (a read of 150 bases is
+      // 10 of them). A block's window of codes starts at base a + c of these (a = ip0 mod 16 differs per lane, c = b W + m - 1
+      // does not), i.e. in word (c >> 4) or the one after it: the four candidate words are picked by a uniform switch, the
+      // lane's own carry and shift finish the job -- no memory access inside the walk.
+      uint32_t r[16];
+      {
+        uint64_t d0 = ip0 >> 4;
+        d0 = d0 < last_dw ? d0 : last_dw;   // (16 words from here stay inside the buffer and its 64 bytes of slack)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) r[i] = st[d0 + i];
+      }
+      const uint32_t a = (uint32_t)ip0 & 15u;
+      auto window = [&](uint32_t c, uint32_t &lo, uint32_t &hi) {   // 64 stream bits from base a + c of the run's words
+        uint32_t x0, x1, x2, x3;
+        switch (c >> 4) {   // uniform
+          case 0: x0 = r[0]; x1 = r[1]; x2 = r[2]; x3 = r[3]; break;
+          case 1: x0 = r[1]; x1 = r[2]; x2 = r[3]; x3 = r[4]; break;
+          case 2: x0 = r[2]; x1 = r[3]; x2 = r[4]; x3 = r[5]; break;
+          case 3: x0 = r[3]; x1 = r[4]; x2 = r[5]; x3 = r[6]; break;
+          case 4: x0 = r[4]; x1 = r[5]; x2 = r[6]; x3 = r[7]; break;
+          case 5: x0 = r[5]; x1 = r[6]; x2 = r[7]; x3 = r[8]; break;
+          case 6: x0 = r[6]; x1 = r[7]; x2 = r[8]; x3 = r[9]; break;
+          case 7: x0 = r[7]; x1 = r[8]; x2 = r[9]; x3 = r[10]; break;
+          case 8: x0 = r[8]; x1 = r[9]; x2 = r[10]; x3 = r[11]; break;
+          case 9: x0 = r[9]; x1 = r[10]; x2 = r[11]; x3 = r[12]; break;
+          case 10: x0 = r[10]; x1 = r[11]; x2 = r[12]; x3 = r[13]; break;
+          case 11: x0 = r[11]; x1 = r[12]; x2 = r[13]; x3 = r[14]; break;
+          default: x0 = r[12]; x1 = r[13]; x2 = r[14]; x3 = r[15]; break;   // (only blocks past the longest run get here)
+        }
+        const uint32_t o = a + (c & 15u);          // 0 .. 30
+        const bool carry = o >= 16u;
+        const uint32_t sh = (o & 15u) * 2u;
+        const uint32_t y0 = carry ? x1 : x0, y1 = carry ? x2 : x1, y2 = carry ? x3 : x2;
+        lo = __builtin_amdgcn_alignbit(y1, y0, sh);
+        hi = __builtin_amdgcn_alignbit(y2, y1, sh);
+      };
       uint32_t R, F;
       {
-        const SkWin w0 = sk_fetch(st, last_dw, ip0);
-        R = sk_lo(w0) & mmask;
+        uint32_t lo, hi;
+        window(0u, lo, hi);
+        R = lo & mmask;
         F = sk_fwd_of(R, m);
       }
       uint32_t sprev[W + 1];
@@ -133,12 +170,10 @@ __global__ __launch_bounds__(kSkThreads, 2) void sk_minimizer_kernel(PackedInput
       // The first window opens a super-k-mer like any other boundary: len starts at nmax ("the one before is full"), and
       // the dummy this closes lands in list slot 0.
       uint32_t prev = 0, len = nmax;
-      // codes of the bases b W + m - 1 .. b W + m + W - 2 (the base that completes m-mer position q = b W + j is q + m - 1);
-      // the next block's are in flight while this one is walked
-      SkWin wn = sk_fetch(st, last_dw, ip0 + m - 1u);
       for (uint32_t b = 0; __any(b < nblk); ++b) {
-        const uint32_t clo = sk_lo(wn), chi = sk_hi(wn);
-        wn = sk_fetch(st, last_dw, ip0 + (uint64_t)(b + 1u) * (uint32_t)W + m - 1u);
+        // codes of the bases b W + m - 1 .. b W + m + W - 2 (the base that completes m-mer position q = b W + j is q + m - 1)
+        uint32_t clo, chi;
+        window(b * (uint32_t)W + m - 1u, clo, chi);
         uint32_t hh[W];
         uint32_t p = INF;
 #pragma unroll
