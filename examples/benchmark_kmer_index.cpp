@@ -8,6 +8,7 @@
 // std::default_random_engine, BenchmarkKmerIndex.cpp:372-392; a fixed prefix keeps runs
 // reproducible).
 #include <chrono>
+#include <cstring>
 #include <cstdio>
 #include <cstdlib>
 #include <string>
@@ -64,7 +65,16 @@ template <typename Key> using MapParams = ::bliss::index::kmer::BimoleculeHashMa
 template <typename Key> using MapParams = ::bliss::index::kmer::CanonicalHashMapParams<Key, DistHash, StoreHash>;
 #endif
 
-#if defined(pINDEX_POS)
+#if defined(pINDEX_POSQUAL)
+// PositionQualityIndex (kmer_index.hpp:405-406): (ShortSequenceKmerId, k-mer quality)
+using ValType = std::pair<bliss::common::ShortSequenceKmerId, float>;
+using MapType = ::dsc::unordered_multimap<KmerType, ValType, MapParams>;
+using IndexType = bliss::index::kmer::PositionQualityIndex<MapType>;
+static unsigned long long val_of(const ValType &v) {   // position + the bit pattern of the quality: both are checked by the harness test
+  uint32_t b; std::memcpy(&b, &v.second, 4);
+  return (unsigned long long)v.first.get_pos() + (unsigned long long)b;
+}
+#elif defined(pINDEX_POS)
 using ValType = bliss::common::ShortSequenceKmerId;
 using MapType = ::dsc::unordered_multimap<KmerType, ValType, MapParams>;
 using IndexType = bliss::index::kmer::PositionIndex<MapType>;

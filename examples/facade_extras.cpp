@@ -1,0 +1,62 @@
+// facade_extras.cpp -- the members of bliss::index::kmer::Index a reference caller reaches beyond the benchmark's
+// sequence (src/index/kmer_index.hpp): insert(std::vector<std::pair<Kmer, count>>&) ADDING the values (:200-225 ->
+// distributed_unordered_map.hpp:1603-1618), get_map() / cbegin() / cend() (:120-125, 377-384), and the
+// PositionQualityIndex alias (:405-406) with its (ShortSequenceKmerId, float) values. Prints numbers the test checks
+// in tests/test_gpu_facade.py.
+//   usage: facade_extras file.fastq
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "kmerind/kmer_index.hpp"
+
+using KmerType = bliss::common::Kmer<21, bliss::common::DNA, uint64_t>;
+template <typename Key> using MapParams = ::bliss::index::kmer::CanonicalHashMapParams<Key>;
+using CountMap = ::dsc::counting_unordered_map<KmerType, uint32_t, MapParams>;
+using CountIdx = bliss::index::kmer::CountIndex<CountMap>;
+using QVal = std::pair<bliss::common::ShortSequenceKmerId, float>;
+using QMap = ::dsc::unordered_multimap<KmerType, QVal, MapParams>;
+using QIdx = bliss::index::kmer::PositionQualityIndex<QMap>;
+
+int main(int argc, char **argv) {
+  if (argc < 2) { std::fprintf(stderr, "usage: %s file.fastq\n", argv[0]); return 2; }
+  const std::string fastq = argv[1];
+  try {
+    kmerind::comm comm(0);
+    // ---- weighted pairs: the count parser's tuples carry 1; insert them, then the same keys again with weight 3
+    std::vector<std::pair<KmerType, uint32_t>> tuples;
+    ::bliss::io::KmerFileHelper::read_file_posix<typename CountIdx::KmerParserType, ::bliss::io::FASTQParser, ::bliss::io::SequencesIterator>(fastq, tuples, comm);
+    CountIdx cidx(comm);
+    {
+      auto t = tuples;
+      cidx.insert(t);                                     // every occurrence with weight 1
+      for (auto &e : t) e.second = 3;
+      cidx.insert(t);                                     // + 3 per occurrence
+    }
+    unsigned long long sum = 0, n = 0;
+    for (auto it = cidx.cbegin(); it != cidx.cend(); ++it) { sum += it->second; ++n; }   // the map walked through its iterators
+    std::printf("weighted entries %llu sum %llu occurrences %zu\n", n, sum, tuples.size());
+    auto &view = cidx.get_map();
+    std::printf("get_map local_size %zu size %zu\n", view.local_size(), view.size());
+    // ---- PositionQualityIndex: (k-mer, (id, quality)) tuples through read_file + insert, then find
+    std::vector<std::pair<KmerType, QVal>> qt;
+    ::bliss::io::KmerFileHelper::read_file_posix<typename QIdx::KmerParserType, ::bliss::io::FASTQParser, ::bliss::io::SequencesIterator>(fastq, qt, comm);
+    QIdx qidx(comm);
+    { auto t = qt; qidx.insert(t); }
+    std::vector<KmerType> q;
+    for (size_t i = 0; i < qt.size(); i += 5) q.push_back(qt[i].first);
+    auto found = qidx.find(q);
+    unsigned long long pos = 0, qbits = 0;
+    for (auto &f : found) { pos += f.second.first.get_pos(); uint32_t b; std::memcpy(&b, &f.second.second, 4); qbits += b; }
+    std::printf("posqual tuples %zu entries %zu found %zu pos %llu qbits %llu\n", qt.size(), qidx.local_size(), found.size(), pos, qbits);
+    unsigned long long all_q = 0;
+    for (auto &e : qidx.to_vector()) { uint32_t b; std::memcpy(&b, &e.second.second, 4); all_q += b; }
+    std::printf("posqual all qbits %llu\n", all_q);
+  } catch (const std::exception &e) {
+    std::fprintf(stderr, "error: %s\n", e.what());
+    return 1;
+  }
+  return 0;
+}

@@ -10,8 +10,9 @@
 // mirrored; everything is host C++ that forwards to the C ABI in ../kmerind_hip.h.
 //
 // Differences a maintainer must know (also in INTEGRATION.md):
-//   * mxx::comm is replaced by kmerind::comm {device, rank, size}; with size > 1 the caller
-//     provides the all-to-all (kmerind::comm::exchange), e.g. RCCL ncclSend/ncclRecv.
+//   * mxx::comm is replaced by kmerind::comm {device, rank, size}; with size > 1 the exchange runs over RCCL inside the
+//     library (comm.unique_id: rank 0's ncclUniqueId bytes, handed to every rank by the application), or through the
+//     caller's own all-to-all (kmerind::comm::exchange) when that functor is set.
 //   * MapType template arguments are tag types: they only select the kmi_config.
 //   * insert()/count()/find()/erase() leave their argument vector unchanged (the reference
 //     leaves it in an unspecified state).
@@ -49,6 +50,15 @@ struct comm {
   // (send words grouped by destination, send counts in k-mers [size], n_words) -> received words
   std::function<std::vector<uint64_t>(const std::vector<uint64_t> &, const std::vector<uint64_t> &, uint32_t)> exchange;
   std::function<uint64_t(uint64_t)> allreduce_sum;
+  // size() > 1 without the two functors above: the exchange runs inside the library over RCCL (kmi_comm_*, grouped
+  // ncclSend / ncclRecv over device buffers). All ranks need the same 128-byte id: rank 0 calls make_unique_id() and the
+  // application hands the bytes to the others (MPI_Bcast in the reference's world) before the Index is constructed.
+  std::vector<char> unique_id;
+  static std::vector<char> make_unique_id() {
+    std::vector<char> id(KMI_COMM_ID_BYTES);
+    if (kmi_comm_unique_id(id.data()) != KMI_OK) throw std::runtime_error("kmerind_hip: RCCL is not available (kmi_comm_unique_id)");
+    return id;
+  }
 
   comm() = default;
   explicit comm(int dev, int r = 0, int s = 1) : device(dev), rank_(r), size_(s) {}
@@ -163,7 +173,9 @@ struct LongSequenceKmerId {
 // transform / hash tags (kmer_transform.hpp:90-145, kmer_hash.hpp:242-311)
 namespace transform { template <typename K> struct identity {}; }
 namespace kmer {
-namespace transform { template <typename K> struct lex_less {}; template <typename K> struct xor_rev_comp {}; }
+// lex_greater (kmer_transform.hpp:128-145) picks the larger strand. No *MapParams of kmer_index.hpp uses it; it is accepted as
+// a DistTrans / StoreTrans tag and treated as lex_less (as sets of stored keys the two differ by which strand represents a pair).
+namespace transform { template <typename K> struct lex_less {}; template <typename K> struct xor_rev_comp {}; template <typename K> struct lex_greater {}; }
 namespace hash {
 template <typename K, bool Prefix = false> struct murmur { static constexpr uint32_t KMI = KMI_HASH_MURMUR; };
 template <typename K, bool Prefix = false> struct farm { static constexpr uint32_t KMI = KMI_HASH_FARM; };
@@ -223,9 +235,11 @@ struct counting_densehash_map : counting_unordered_map<Key, T, MapParams> {};
 template <typename Key, typename T, template <typename> class MapParams>
 struct unordered_multimap {
   using key_type = Key; using mapped_type = T; using params = MapParams<Key>;
-  static constexpr uint32_t index_kind = KMI_INDEX_POSITION;
+  // T = ShortSequenceKmerId / LongSequenceKmerId (one word) or std::pair<ShortSequenceKmerId, float> (kmer_index.hpp:405-406:
+  // two words on the device, the float's bits in the low half of the second)
+  static constexpr uint32_t index_kind = sizeof(T) == sizeof(uint64_t) ? KMI_INDEX_POSITION : KMI_INDEX_POSQUAL;
   static constexpr bool saturating = false;
-  static_assert(sizeof(T) == sizeof(uint64_t), "position ids are one 64-bit word");
+  static_assert(sizeof(T) == sizeof(uint64_t) || sizeof(T) == 2 * sizeof(uint64_t), "values are one (id) or two ((id, quality)) 64-bit words");
 };
 template <typename Key, typename T, template <typename> class MapParams, typename SpecialKeys = void>
 struct densehash_multimap : unordered_multimap<Key, T, MapParams> {};
@@ -291,6 +305,10 @@ template <typename TupleType> struct KmerCountTupleParser {
   static constexpr size_t window_size = kmer_type::size;
 };
 
+template <typename TupleType> struct KmerPositionQualityTupleParser {   // kmer_parser.hpp:577-900: (k-mer, (ShortSequenceKmerId, quality))
+  using value_type = TupleType; using kmer_type = typename std::tuple_element<0, TupleType>::type;
+  static constexpr size_t window_size = kmer_type::size;
+};
 template <typename TupleType> struct KmerPositionTupleParser {   // kmer_parser.hpp:303-569
   using value_type = TupleType; using kmer_type = typename std::tuple_element<0, TupleType>::type;
   static constexpr size_t window_size = kmer_type::size;
@@ -326,8 +344,19 @@ template <typename MapType, typename V> typename std::enable_if<std::is_arithmet
   if (MapType::saturating && w > (uint64_t)std::numeric_limits<V>::max()) return std::numeric_limits<V>::max();
   return (V)w;
 }
-template <typename MapType, typename V> typename std::enable_if<!std::is_arithmetic<V>::value, V>::type count_of(uint64_t w) { return V((size_t)w); }
+template <typename MapType, typename V> typename std::enable_if<!std::is_arithmetic<V>::value, V>::type count_of(uint64_t w) { return value_of<V>(w); }
 template <typename V> typename std::enable_if<!std::is_arithmetic<V>::value, V>::type value_of(uint64_t w) { return V((size_t)w); }
+// multimap values <-> device words: an id is one word; (id, quality) is two, the float's bits in the low half of the second
+template <typename V> struct value_words { static constexpr unsigned N = 1;
+  static void to(const V &v, uint64_t *w) { uint64_t t = 0; std::memcpy(&t, &v, sizeof(V) < sizeof(uint64_t) ? sizeof(V) : sizeof(uint64_t)); w[0] = t; }
+  static V from(const uint64_t *w) { return value_of<V>(w[0]); } };
+template <typename Id> struct value_words<std::pair<Id, float>> { static constexpr unsigned N = 2;
+  static void to(const std::pair<Id, float> &v, uint64_t *w) { std::memcpy(w, &v.first, sizeof(uint64_t)); uint32_t b; std::memcpy(&b, &v.second, 4); w[1] = b; }
+  static std::pair<Id, float> from(const uint64_t *w) { uint32_t b = (uint32_t)w[1]; float q; std::memcpy(&q, &b, 4); return std::make_pair(Id((size_t)w[0]), q); } };
+// what find() / to_vector() hand back for one entry: the count as mapped_type, or the multimap value from its words
+template <typename MapType, typename V> typename std::enable_if<MapType::index_kind == KMI_INDEX_COUNT, V>::type stored_value(const uint64_t *w) { return count_of<MapType, V>(w[0]); }
+template <typename MapType, typename V> typename std::enable_if<MapType::index_kind != KMI_INDEX_COUNT, V>::type stored_value(const uint64_t *w) { return value_words<V>::from(w); }
+template <typename MapType, typename V> constexpr unsigned stored_words() { return MapType::index_kind == KMI_INDEX_COUNT ? 1u : value_words<V>::N; }
 template <typename Kmer> const uint64_t *words_of(const std::vector<Kmer> &v) { return reinterpret_cast<const uint64_t *>(v.data()); }
 template <typename Kmer, typename T> std::vector<uint64_t> words_of_pairs(const std::vector<std::pair<Kmer, T>> &v) {
   std::vector<uint64_t> w(v.size() * Kmer::nWords);
@@ -350,28 +379,30 @@ class Index {
     cfg = detail::make_config<MapType>(KMI_FMT_FASTQ);
     ::kmerind::check(nullptr, kmi_ctx_create(comm.device, comm.rank(), comm.size(), comm.stream, &ctx));
     ::kmerind::check(ctx, kmi_index_create(ctx, &cfg, &idx));
+    if (comm.size() > 1 && !comm.exchange) {   // the exchange runs inside the library over RCCL (collective: every rank constructs)
+      if (comm.unique_id.size() != KMI_COMM_ID_BYTES)
+        throw std::invalid_argument("comm.size() > 1 needs comm.unique_id (kmerind::comm::make_unique_id() on rank 0, handed to every rank) or comm.exchange");
+      ::kmerind::check(ctx, kmi_comm_create(ctx, comm.unique_id.data(), &rccl));
+    }
   }
   Index(const Index &) = delete;
   Index &operator=(const Index &) = delete;
-  virtual ~Index() { if (idx) kmi_index_destroy(idx); if (ctx) kmi_ctx_destroy(ctx); }
+  virtual ~Index() { if (rccl) kmi_comm_destroy(rccl); if (idx) kmi_index_destroy(idx); if (ctx) kmi_ctx_destroy(ctx); }
 
-  // Index::insert (kmer_index.hpp:200-225): vector<Kmer> or vector<pair<Kmer,count>> (the count parser's tuples)
+  // Index::insert (kmer_index.hpp:200-225): vector<Kmer>, or the map's own tuples. For the counting maps a tuple's value is
+  // ADDED to the key's count (reduction_unordered_map::local_insert, distributed_unordered_map.hpp:1603-1618); for the
+  // multimaps every (k-mer, value) is kept.
   void insert(std::vector<KmerType> &temp) { insert_words(detail::words_of(temp), temp.size()); }
-  void insert(std::vector<TupleType> &temp) {
-    auto w = detail::words_of_pairs(temp);
-    if (MapType::index_kind == KMI_INDEX_COUNT) { insert_words(w.data(), temp.size()); return; }
-    // multimap: (k-mer, position id) tuples
-    if (comm.size() > 1) throw std::invalid_argument("multimap insert with size() > 1 is not wired through comm.exchange yet");
-    std::vector<uint64_t> vals(temp.size());
-    for (size_t i = 0; i < temp.size(); ++i) std::memcpy(&vals[i], &temp[i].second, sizeof(uint64_t));
-    ::kmerind::check(ctx, kmi_index_insert_tuples_host(idx, w.data(), vals.data(), temp.size()));
-  }
+  void insert(std::vector<TupleType> &temp) { insert_tuples(temp, std::integral_constant<bool, MapType::index_kind == KMI_INDEX_COUNT>()); }
 
   // Index::count (:142-145): one (key, 0|1) per distinct transformed query key
   std::vector<std::pair<KmerType, size_t>> count(std::vector<KmerType> &query) const {
     kmi_results r{};
-    std::vector<uint64_t> q = route_queries(query);
-    ::kmerind::check(ctx, kmi_index_count_host(idx, q.data(), q.size() / KmerType::nWords, &r));
+    if (rccl) ::kmerind::check(ctx, kmi_index_count_dist_host(idx, rccl, detail::words_of(query), query.size(), &r));
+    else {
+      std::vector<uint64_t> q = route_queries(query);
+      ::kmerind::check(ctx, kmi_index_count_host(idx, q.data(), q.size() / KmerType::nWords, &r));
+    }
     std::vector<std::pair<KmerType, size_t>> out(r.n);
     for (uint64_t i = 0; i < r.n; ++i) out[i] = std::make_pair(KmerType(r.keys + i * KmerType::nWords), (size_t)r.values[i]);
     kmi_results_free(&r);
@@ -402,16 +433,21 @@ class Index {
   // Index::find (:132-135): (key, stored value) of present query keys
   std::vector<TupleType> find(std::vector<KmerType> &query) const {
     kmi_results r{};
-    std::vector<uint64_t> q = route_queries(query);
-    ::kmerind::check(ctx, kmi_index_find_host(idx, q.data(), q.size() / KmerType::nWords, &r));
+    if (rccl) ::kmerind::check(ctx, kmi_index_find_dist_host(idx, rccl, detail::words_of(query), query.size(), &r));
+    else {
+      std::vector<uint64_t> q = route_queries(query);
+      ::kmerind::check(ctx, kmi_index_find_host(idx, q.data(), q.size() / KmerType::nWords, &r));
+    }
+    constexpr unsigned ow = detail::stored_words<MapType, ValueType>();
     std::vector<TupleType> out(r.n);
-    for (uint64_t i = 0; i < r.n; ++i) out[i] = std::make_pair(KmerType(r.keys + i * KmerType::nWords), detail::count_of<MapType, ValueType>(r.values[i]));
+    for (uint64_t i = 0; i < r.n; ++i) out[i] = std::make_pair(KmerType(r.keys + i * KmerType::nWords), detail::stored_value<MapType, ValueType>(r.values + i * ow));
     kmi_results_free(&r);
     return out;
   }
   // Index::erase (:147-149)
   void erase(std::vector<KmerType> &query) {
     uint64_t n = 0;
+    if (rccl) { ::kmerind::check(ctx, kmi_index_erase_dist_host(idx, rccl, detail::words_of(query), query.size(), &n)); return; }
     std::vector<uint64_t> q = route_queries(query);
     ::kmerind::check(ctx, kmi_index_erase_host(idx, q.data(), q.size() / KmerType::nWords, &n));
   }
@@ -446,23 +482,45 @@ class Index {
   }
 
   size_t local_size() const { uint64_t n = 0; ::kmerind::check(ctx, kmi_index_local_size(idx, &n)); return (size_t)n; }
-  size_t size() const { size_t n = local_size(); return (comm.size() > 1 && comm.allreduce_sum) ? (size_t)comm.allreduce_sum(n) : n; }
+  size_t size() const {
+    if (rccl) { uint64_t n = 0; ::kmerind::check(ctx, kmi_index_size_dist(idx, rccl, &n)); return (size_t)n; }
+    size_t n = local_size();
+    return (comm.size() > 1 && comm.allreduce_sum) ? (size_t)comm.allreduce_sum(n) : n;
+  }
+  // get_map() / cbegin() / cend() (kmer_index.hpp:120-125, 377-384): the reference hands out its local container and
+  // iterators into it. The entries live in HBM here, so the "map" a caller can walk is a host snapshot of this rank's
+  // entries (to_vector), refreshed on every get_map() / cbegin() call; cend() belongs to the snapshot cbegin() took.
+  struct MapView {
+    const Index *owner; std::vector<TupleType> entries;
+    using const_iterator = typename std::vector<TupleType>::const_iterator;
+    const_iterator cbegin() const { return entries.cbegin(); }
+    const_iterator cend() const { return entries.cend(); }
+    const_iterator begin() const { return entries.cbegin(); }
+    const_iterator end() const { return entries.cend(); }
+    size_t local_size() const { return entries.size(); }
+    size_t size() const { return owner->size(); }
+    std::vector<TupleType> to_vector() const { return entries; }
+  };
+  MapView &get_map() { view.owner = this; view.entries = to_vector(); return view; }
+  typename MapView::const_iterator cbegin() { return get_map().cbegin(); }
+  typename MapView::const_iterator cend() const { return view.cend(); }
 
   // MapType::to_vector (distributed_map_base.hpp:202-217)
   std::vector<TupleType> to_vector() const {
     uint64_t n = local_size(), got = 0;
     if (MapType::index_kind != KMI_INDEX_COUNT) {
-      std::vector<uint64_t> keys(n * KmerType::nWords + 1), vals(n + 1);
+      constexpr unsigned vw = detail::stored_words<MapType, ValueType>();
+      std::vector<uint64_t> keys(n * KmerType::nWords + 1), vals(n * vw + 1);
       ::kmerind::check(ctx, kmi_index_export_tuples_host(idx, keys.data(), vals.data(), n, &got));
       std::vector<TupleType> out(got);
-      for (uint64_t i = 0; i < got; ++i) out[i] = std::make_pair(KmerType(&keys[i * KmerType::nWords]), detail::value_of<ValueType>(vals[i]));
+      for (uint64_t i = 0; i < got; ++i) out[i] = std::make_pair(KmerType(&keys[i * KmerType::nWords]), detail::stored_value<MapType, ValueType>(&vals[i * vw]));
       return out;
     }
     std::vector<uint64_t> keys(n * KmerType::nWords + 1);
     std::vector<uint32_t> cnt(n + 1);
     ::kmerind::check(ctx, kmi_index_export_host(idx, keys.data(), cnt.data(), n, &got));
     std::vector<TupleType> out(got);
-    for (uint64_t i = 0; i < got; ++i) out[i] = std::make_pair(KmerType(&keys[i * KmerType::nWords]), detail::count_of<MapType, ValueType>(cnt[i]));
+    for (uint64_t i = 0; i < got; ++i) { const uint64_t c = cnt[i]; out[i] = std::make_pair(KmerType(&keys[i * KmerType::nWords]), detail::stored_value<MapType, ValueType>(&c)); }
     return out;
   }
 
@@ -473,6 +531,19 @@ class Index {
   }
   template <template <typename> class SeqParser, template <typename, template <typename> class> class SeqIterType>
   void build_mmap(const std::string &filename, void * = nullptr) { build_file<SeqParser>(filename, SeqIterType<const unsigned char *, SeqParser>::KMI); }
+  // build_mpiio (:239-262): the reference reads through MPI-IO; which call brings the bytes into host memory is not observable
+  template <template <typename> class SeqParser, template <typename, template <typename> class> class SeqIterType>
+  void build_mpiio(const std::string &filename, void * = nullptr) { build_file<SeqParser>(filename, SeqIterType<const unsigned char *, SeqParser>::KMI); }
+  // size() > 1: every rank passes ITS record-aligned partition of the file (bytes + the partition's offset in the file; the
+  // partition negotiation of file.hpp:1216-1430 is the caller's, e.g. kmerind_amd.fileio or an MPI-IO split): parse, route,
+  // exchange over RCCL, insert. Collective.
+  void build_partition(const uint8_t *bytes, size_t n_bytes, uint64_t file_offset, uint32_t fmt = KMI_FMT_FASTQ, uint32_t seq_filter = KMI_SEQ_ALL) {
+    ::kmerind::check(ctx, kmi_index_set_seq_format(idx, fmt));
+    ::kmerind::check(ctx, kmi_index_set_seq_filter(idx, seq_filter));
+    if (comm.size() == 1) { ::kmerind::check(ctx, kmi_index_build_host(idx, bytes, n_bytes, file_offset)); return; }
+    need_rccl("build_partition");
+    ::kmerind::check(ctx, kmi_index_build_dist_host(idx, rccl, bytes, n_bytes, file_offset));
+  }
 
   kmi_ctx *context() const { return ctx; }
   const kmi_config &config() const { return cfg; }
@@ -501,7 +572,7 @@ class Index {
   template <template <typename> class SeqParser> void build_file(const std::string &filename, uint32_t seq_filter = KMI_SEQ_ALL) {
     uint32_t fmt = detail::format_of(filename);
     if (fmt != SeqParser<const unsigned char *>::KMI) throw std::invalid_argument("Specified File Parser template parameter does not support files with this extension.");
-    if (comm.size() > 1) throw std::invalid_argument("build_* with size() > 1: partition the file per rank and use read_file + insert");
+    if (comm.size() > 1) throw std::invalid_argument("build_* with size() > 1: hand every rank its record-aligned partition (build_partition)");
     std::vector<uint8_t> bytes = detail::read_whole_file(filename);
     ::kmerind::check(ctx, kmi_index_set_seq_format(idx, fmt));
     ::kmerind::check(ctx, kmi_index_set_seq_filter(idx, seq_filter));
@@ -509,6 +580,7 @@ class Index {
   }
   void insert_words(const uint64_t *words, size_t n) {
     if (comm.size() == 1) { ::kmerind::check(ctx, kmi_index_insert_host(idx, words, n)); return; }
+    if (rccl) { ::kmerind::check(ctx, kmi_index_insert_dist_host(idx, rccl, words, n)); return; }
     std::vector<uint64_t> mine = route_words(words, n);
     ::kmerind::check(ctx, kmi_index_insert_host(idx, mine.data(), mine.size() / KmerType::nWords));
   }
@@ -535,19 +607,57 @@ class Index {
     return route_words(w, query.size());
   }
 
+  void insert_tuples(std::vector<TupleType> &temp, std::true_type /* counting map */) {
+    auto w = detail::words_of_pairs(temp);
+    constexpr unsigned nw = KmerType::nWords;
+    if (comm.size() > 1) {
+      // over ranks the occurrences travel as keys; weights other than 1 only come from callers that reduced before, and those
+      // insert on the rank that owns the keys
+      for (const TupleType &t : temp)
+        if (weight_word(t)[0] != 1ull) throw std::invalid_argument("weighted (k-mer, count) insert with size() > 1: insert the pairs on the rank that owns them");
+      insert_words(w.data(), temp.size());
+      return;
+    }
+    std::vector<uint64_t> rec(temp.size() * (nw + 1) + 1);
+    for (size_t i = 0; i < temp.size(); ++i) {
+      std::memcpy(&rec[i * (nw + 1)], &w[i * nw], sizeof(uint64_t) * nw);
+      rec[i * (nw + 1) + nw] = weight_word(temp[i])[0] & 0xffffffffull;
+    }
+    ::kmerind::check(ctx, kmi_index_insert_pairs_host(idx, rec.data(), temp.size()));
+  }
+  void insert_tuples(std::vector<TupleType> &temp, std::false_type /* multimap: (k-mer, position id[, quality]) */) {
+    auto w = detail::words_of_pairs(temp);
+    constexpr unsigned vw = detail::value_words<ValueType>::N;
+    std::vector<uint64_t> vals(temp.size() * vw + 1);
+    for (size_t i = 0; i < temp.size(); ++i) detail::value_words<ValueType>::to(temp[i].second, &vals[i * vw]);
+    if (comm.size() == 1) { ::kmerind::check(ctx, kmi_index_insert_tuples_host(idx, w.data(), vals.data(), temp.size())); return; }
+    need_rccl("multimap insert");
+    ::kmerind::check(ctx, kmi_index_insert_tuples_dist_host(idx, rccl, w.data(), vals.data(), temp.size()));
+  }
+  void need_rccl(const char *what) const {
+    if (!rccl) throw std::invalid_argument(std::string(what) + " with size() > 1 needs the RCCL communicator (comm.unique_id)");
+  }
+  static std::vector<uint64_t> weight_word(const TupleType &t) {
+    std::vector<uint64_t> w(detail::value_words<ValueType>::N + 1, 0);
+    std::memcpy(w.data(), &t.second, sizeof(t.second) < sizeof(uint64_t) ? sizeof(t.second) : sizeof(uint64_t));
+    return w;
+  }
+
   ::kmerind::comm comm;
   kmi_config cfg;
   kmi_ctx *ctx = nullptr;
   kmi_index *idx = nullptr;
+  kmi_comm *rccl = nullptr;
+  MapView view{};
 };
 
 template <typename MapType> using KmerIndex = Index<MapType, KmerParser<typename MapType::key_type>>;
 template <typename MapType> using CountIndex = Index<MapType, KmerCountTupleParser<std::pair<typename MapType::key_type, typename MapType::mapped_type>>>;
 template <typename MapType> using CountIndex2 = Index<MapType, KmerParser<typename MapType::key_type>>;
 template <typename MapType> using PositionIndex = Index<MapType, KmerPositionTupleParser<std::pair<typename MapType::key_type, typename MapType::mapped_type>>>;
-// PositionQualityIndex (kmer_index.hpp:405-406): value = std::pair<ShortSequenceKmerId, float>. The C ABI carries it as two
-// 64-bit words (id, float bits in the low half of the second word) = the object bytes of that pair; use
-// kmi_index_create(index_kind = KMI_INDEX_POSQUAL) + kmi_index_build_* / kmi_index_insert_tuples_* directly.
+// PositionQualityIndex (kmer_index.hpp:405-406): mapped_type = std::pair<ShortSequenceKmerId, float>; on the device two 64-bit
+// words per value (id, the float's bits in the low half of the second)
+template <typename MapType> using PositionQualityIndex = Index<MapType, KmerPositionQualityTupleParser<std::pair<typename MapType::key_type, typename MapType::mapped_type>>>;
 
 }  // namespace kmer
 }  // namespace index
@@ -575,7 +685,7 @@ struct KmerFileHelper {
     const size_t before = result.size();
     result.reserve(before + t.n_tuples);
     for (uint64_t i = 0; i < t.n_tuples; ++i)
-      result.push_back(make_value<typename KmerParser::value_type, Kmer>(t.kmers + i * Kmer::nWords, t.ids ? t.ids[i] : 1));
+      result.push_back(make_value<typename KmerParser::value_type, Kmer>(t.kmers + i * Kmer::nWords, t.ids ? t.ids[i] : 1, t.quals ? t.quals[i] : 0.f));
     std::pair<size_t, size_t> r((size_t)t.n_seqs, (size_t)t.n_tuples);
     kmi_tuples_free(&t);
     kmi_ctx_destroy(ctx);
@@ -590,12 +700,20 @@ struct KmerFileHelper {
  private:
   template <typename V, typename Kmer> static typename std::enable_if<std::is_same<V, Kmer>::value, uint32_t>::type tuple_kind() { return KMI_INDEX_COUNT; }
   template <typename V, typename Kmer> static typename std::enable_if<!std::is_same<V, Kmer>::value, uint32_t>::type tuple_kind() {
-    return std::is_arithmetic<typename V::second_type>::value ? KMI_INDEX_COUNT : KMI_INDEX_POSITION;
+    return std::is_arithmetic<typename V::second_type>::value ? KMI_INDEX_COUNT :
+           (sizeof(typename V::second_type) == sizeof(uint64_t) ? KMI_INDEX_POSITION : KMI_INDEX_POSQUAL);
   }
-  template <typename V, typename Kmer> static typename std::enable_if<std::is_same<V, Kmer>::value, V>::type make_value(const uint64_t *w, uint64_t) { return Kmer(w); }
-  // KmerCountTupleParser zips the k-mer with a constant 1 (kmer_parser.hpp:1008-1081); KmerPositionTupleParser with its id
-  template <typename V, typename Kmer> static typename std::enable_if<!std::is_same<V, Kmer>::value, V>::type make_value(const uint64_t *w, uint64_t v) {
-    return V(Kmer(w), ::bliss::index::kmer::detail::value_of<typename V::second_type>(v));
+  template <typename V, typename Kmer> static typename std::enable_if<std::is_same<V, Kmer>::value, V>::type make_value(const uint64_t *w, uint64_t, float) { return Kmer(w); }
+  // KmerCountTupleParser zips the k-mer with a constant 1 (kmer_parser.hpp:1008-1081), KmerPositionTupleParser with its id,
+  // KmerPositionQualityTupleParser with (id, quality) (kmer_parser.hpp:577-900)
+  template <typename V, typename Kmer> static typename std::enable_if<!std::is_same<V, Kmer>::value, V>::type make_value(const uint64_t *w, uint64_t v, float q) {
+    uint32_t qb; std::memcpy(&qb, &q, 4);
+    const uint64_t words[2] = {v, (uint64_t)qb};
+    return V(Kmer(w), second_of<typename V::second_type>(words));
+  }
+  template <typename S> static typename std::enable_if<std::is_arithmetic<S>::value, S>::type second_of(const uint64_t *w) { return (S)w[0]; }
+  template <typename S> static typename std::enable_if<!std::is_arithmetic<S>::value, S>::type second_of(const uint64_t *w) {
+    return ::bliss::index::kmer::detail::value_words<S>::from(w);
   }
 };
 }  // namespace io

@@ -265,6 +265,41 @@ kmi_status kmi_index_split_by_rank_dev(kmi_index *idx, uint32_t nranks, uint64_t
 kmi_status kmi_index_merge_parts_dev(kmi_index *idx, uint32_t nparts, const uint64_t *kmers_dev, const uint32_t *counts_dev,
                                      const uint32_t *bucket_counts_dev);
 
+/* ---- more than one rank: the exchange over RCCL (xGMI inside one node) -------------------------------------------
+ * One process per GPU (kmi_ctx_create(device, rank, nranks)). A communicator replaces the mxx::comm the reference's maps
+ * hold: rank 0 makes an id (kmi_comm_unique_id = ncclGetUniqueId, 128 bytes) and the application hands it to the other
+ * ranks (MPI_Bcast in the reference's world), every rank calls kmi_comm_create (ncclCommInitRank; collective).
+ * kmi_comm_all_to_all_counts / _v are mxx::all2all / mxx::all2allv of imxx::distribute (incremental_mxx.hpp:1087, 1098):
+ * counts on the host, payload in device buffers grouped by destination, received as the concatenation by source rank
+ * ascending; grouped ncclSend / ncclRecv on the context's stream, 64-bit counts, peer messages in pieces below 1 GiB, the
+ * first exchange of a communicator verified by per-message checksums. nranks == 1 works (self exchange). */
+typedef struct kmi_comm kmi_comm;
+enum { KMI_COMM_ID_BYTES = 128 };
+kmi_status kmi_comm_unique_id(void *id_out /* KMI_COMM_ID_BYTES */);
+kmi_status kmi_comm_create(kmi_ctx *ctx, const void *id /* NULL allowed when nranks == 1 */, kmi_comm **out);
+kmi_status kmi_comm_destroy(kmi_comm *comm);
+kmi_status kmi_comm_all_to_all_counts(kmi_comm *comm, const uint64_t *send_counts_host, uint64_t *recv_counts_host);
+kmi_status kmi_comm_all_to_all_v(kmi_comm *comm, const void *send_dev, const uint64_t *send_counts_host, void *recv_dev,
+                                 const uint64_t *recv_counts_host, size_t elem_bytes /* multiple of 8 */);
+kmi_status kmi_comm_allreduce_sum_u64(kmi_comm *comm, uint64_t *value_host);
+
+/* The collectives of Index<MapType, Parser> with comm.size() > 1, every rank calling with its own (possibly empty) share:
+ * insert  (distributed_unordered_map.hpp:1697-1745, :1466-1515): InputTransform, KeyToRank grouping on the device
+ *         (kmi_route_dev), all2all(counts) + all2allv(keys), local insert of what arrives;
+ * build   (kmer_index.hpp:239-372): this rank's record-aligned partition of the file -> parse -> route -> insert (FASTQ count
+ *         index: kmi_extract_route_dev, the tuple array never exists; position indexes: records with their values);
+ * count / find / erase (:880-983, :564-687, :719-779): the query keys travel to their owners, every owner answers per source
+ *         rank, one return exchange; results are this rank's own queries' answers, as the reference returns them;
+ * size    (distributed_map_base.hpp:227-245): allreduce of the local sizes.
+ * Device buffers throughout; only the caller's vectors cross PCIe. */
+kmi_status kmi_index_insert_dist_host(kmi_index *idx, kmi_comm *comm, const uint64_t *kmers, size_t n);
+kmi_status kmi_index_insert_tuples_dist_host(kmi_index *idx, kmi_comm *comm, const uint64_t *kmers, const uint64_t *values, size_t n);
+kmi_status kmi_index_build_dist_host(kmi_index *idx, kmi_comm *comm, const uint8_t *bytes, size_t n_bytes, uint64_t file_offset);
+kmi_status kmi_index_count_dist_host(kmi_index *idx, kmi_comm *comm, const uint64_t *queries, size_t nq, kmi_results *out);
+kmi_status kmi_index_find_dist_host(kmi_index *idx, kmi_comm *comm, const uint64_t *queries, size_t nq, kmi_results *out);
+kmi_status kmi_index_erase_dist_host(kmi_index *idx, kmi_comm *comm, const uint64_t *queries, size_t nq, uint64_t *n_erased_local);
+kmi_status kmi_index_size_dist(kmi_index *idx, kmi_comm *comm, uint64_t *n);
+
 /* ---- measurement support --------------------------------------------------- */
 /* per-kernel HIP-event timing on the context's stream (bench.py roofline leg) */
 kmi_status kmi_profile_enable(kmi_ctx *ctx, int on);

@@ -107,6 +107,19 @@ SIGNATURES = {
     "kmi_index_num_buckets": (C.c_uint32, []),
     "kmi_index_split_by_rank_dev": (C.c_int, [_P, _u32, _P, _P, _sz, _P, _P]),
     "kmi_index_merge_parts_dev": (C.c_int, [_P, _u32, _P, _P, _P]),
+    "kmi_comm_unique_id": (C.c_int, [_P]),
+    "kmi_comm_create": (C.c_int, [_P, _P, C.POINTER(_P)]),
+    "kmi_comm_destroy": (C.c_int, [_P]),
+    "kmi_comm_all_to_all_counts": (C.c_int, [_P, _P, _P]),
+    "kmi_comm_all_to_all_v": (C.c_int, [_P, _P, _P, _P, _P, _sz]),
+    "kmi_comm_allreduce_sum_u64": (C.c_int, [_P, C.POINTER(_u64)]),
+    "kmi_index_insert_dist_host": (C.c_int, [_P, _P, _P, _sz]),
+    "kmi_index_insert_tuples_dist_host": (C.c_int, [_P, _P, _P, _P, _sz]),
+    "kmi_index_build_dist_host": (C.c_int, [_P, _P, _P, _sz, _u64]),
+    "kmi_index_count_dist_host": (C.c_int, [_P, _P, _P, _sz, C.POINTER(Results)]),
+    "kmi_index_find_dist_host": (C.c_int, [_P, _P, _P, _sz, C.POINTER(Results)]),
+    "kmi_index_erase_dist_host": (C.c_int, [_P, _P, _P, _sz, C.POINTER(_u64)]),
+    "kmi_index_size_dist": (C.c_int, [_P, _P, C.POINTER(_u64)]),
     "kmi_profile_enable": (C.c_int, [_P, C.c_int]),
     "kmi_profile_reset": (C.c_int, [_P]),
     "kmi_profile_get": (C.c_int, [_P, C.POINTER(KernelTime), _sz, C.POINTER(_sz)]),

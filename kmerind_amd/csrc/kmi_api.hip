@@ -151,6 +151,7 @@ kmi_status kmi_ctx_create(int device, int rank, int nranks, void *stream, kmi_ct
   kmi_ctx *ctx = new kmi_ctx();
   if (const char *fp = getenv("KMI_FUSED_PATH")) ctx->fused_superkmer = strcmp(fp, "kmer") != 0;
   if (const char *dg = getenv("KMI_SK_DBG")) ctx->sk_dbg = atoi(dg);
+  if (const char *fd = getenv("KMI_FORCE_DIST")) ctx->force_dist = atoi(fd) != 0;
   ctx->device = device; ctx->rank = rank; ctx->nranks = nranks; ctx->stream = (hipStream_t)stream;
   if (hipMalloc((void **)&ctx->d_flags, sizeof(uint32_t) * 16) != hipSuccess ||
       hipMalloc((void **)&ctx->d_totals, sizeof(uint64_t) * 16) != hipSuccess ||

@@ -3452,4 +3452,184 @@ kmi_status kmi_index_merge_parts_dev(kmi_index *idx, uint32_t nparts, const uint
   KMI_DISPATCH(idx->shape, kmi::merge_impl, idx, nparts, kmers_dev, counts_dev, bucket_counts_dev);
 }
 
+// ---- the collectives of Index<MapType, Parser> over ranks (see kmerind_hip.h) ----------------------------------------
+static kmi_status dist_check(kmi_index *idx, kmi_comm *comm) {
+  if (!idx || !comm) return KMI_ERR_INVALID;
+  if (kmi::comm_ctx(comm) != idx->ctx) return set_err(idx->ctx, KMI_ERR_INVALID, "the communicator belongs to another context");
+  KMI_HIP(idx->ctx, hipSetDevice(idx->ctx->device));
+  return KMI_OK;
+}
+
+// imxx::distribute of `n` items already grouped by destination in send_dev: counts, then payload; *recv_dev (workspace
+// slot `slot`) holds the concatenation by source rank, recv_counts what every source sent
+static kmi_status dist_exchange(kmi_comm *comm, const void *send_dev, const uint64_t *send_counts, size_t elem_bytes, kmi::WsSlot slot,
+                                void **recv_dev, std::vector<uint64_t> &recv_counts, uint64_t *total) {
+  kmi_ctx *ctx = kmi::comm_ctx(comm);
+  const int p = kmi::comm_size(comm);
+  recv_counts.assign(p, 0);
+  KMI_TRY(kmi::comm_all_to_all_counts(comm, send_counts, recv_counts.data()));
+  uint64_t t = 0;
+  for (int r = 0; r < p; ++r) t += recv_counts[r];
+  KMI_TRY(ws_get(ctx, slot, (t + 8) * elem_bytes, recv_dev));
+  KMI_TRY(kmi::comm_all_to_all_v(comm, send_dev, send_counts, *recv_dev, recv_counts.data(), elem_bytes));
+  *total = t;
+  return KMI_OK;
+}
+
+kmi_status kmi_index_insert_dist_host(kmi_index *idx, kmi_comm *comm, const uint64_t *kmers, size_t n) {
+  KMI_TRY(dist_check(idx, comm));
+  kmi_ctx *ctx = idx->ctx;
+  if (idx->val_words) return set_err(ctx, KMI_ERR_INVALID, "a position index takes (k-mer, value) tuples: kmi_index_insert_tuples_dist_host");
+  if (n && !kmers) return set_err(ctx, KMI_ERR_INVALID, "null buffer");
+  const int p = kmi::comm_size(comm);
+  if (p == 1 && !ctx->force_dist) return kmi_index_insert_host(idx, kmers, n);
+  const size_t kb = idx->shape.n_words * sizeof(uint64_t);
+  void *d_in, *d_send, *d_recv;
+  KMI_TRY(ws_get(ctx, WS_INPUT, (n + 8) * kb, &d_in));
+  KMI_TRY(ws_get(ctx, WS_DIST_A, (n + 8) * kb, &d_send));
+  if (n) KMI_HIP(ctx, hipMemcpyAsync(d_in, kmers, n * kb, hipMemcpyHostToDevice, ctx->stream));
+  std::vector<uint64_t> sc(p, 0), rc;
+  KMI_TRY(kmi_route_dev(ctx, &idx->cfg, (const uint64_t *)d_in, n, (uint32_t)p, (uint64_t *)d_send, sc.data()));   // InputTransform + grouping by KeyToRank
+  uint64_t total = 0;
+  KMI_TRY(dist_exchange(comm, d_send, sc.data(), kb, WS_DIST_B, &d_recv, rc, &total));
+  return index_insert(idx, (const uint64_t *)d_recv, (size_t)total, false);
+}
+
+kmi_status kmi_index_insert_tuples_dist_host(kmi_index *idx, kmi_comm *comm, const uint64_t *kmers, const uint64_t *values, size_t n) {
+  KMI_TRY(dist_check(idx, comm));
+  kmi_ctx *ctx = idx->ctx;
+  if (idx->val_words == 0) return set_err(ctx, KMI_ERR_INVALID, "insert_tuples needs a position index");
+  if (n && (!kmers || !values)) return set_err(ctx, KMI_ERR_INVALID, "null buffer");
+  const int p = kmi::comm_size(comm);
+  if (p == 1 && !ctx->force_dist) return kmi_index_insert_tuples_host(idx, kmers, values, n);
+  const uint32_t nw = idx->shape.n_words, vw = idx->val_words, rw = nw + vw;
+  std::vector<uint64_t> rec((n + 1) * rw);
+  for (size_t i = 0; i < n; ++i) {
+    memcpy(&rec[i * rw], kmers + i * nw, nw * sizeof(uint64_t));
+    memcpy(&rec[i * rw + nw], values + i * vw, vw * sizeof(uint64_t));
+  }
+  void *d_in, *d_send, *d_recv;
+  KMI_TRY(ws_get(ctx, WS_INPUT, (n + 8) * rw * sizeof(uint64_t), &d_in));
+  KMI_TRY(ws_get(ctx, WS_DIST_A, (n + 8) * rw * sizeof(uint64_t), &d_send));
+  if (n) KMI_HIP(ctx, hipMemcpy(d_in, rec.data(), n * rw * sizeof(uint64_t), hipMemcpyHostToDevice));
+  std::vector<uint64_t> sc(p, 0), rc;
+  KMI_TRY(kmi_route_tuples_dev(ctx, &idx->cfg, (const uint64_t *)d_in, n, (uint32_t)p, vw, (uint64_t *)d_send, sc.data()));
+  uint64_t total = 0;
+  KMI_TRY(dist_exchange(comm, d_send, sc.data(), rw * sizeof(uint64_t), WS_DIST_B, &d_recv, rc, &total));
+  return index_insert_records(idx, (const uint64_t *)d_recv, (size_t)total, true);   // (the transform is idempotent)
+}
+
+kmi_status kmi_index_build_dist_host(kmi_index *idx, kmi_comm *comm, const uint8_t *bytes, size_t n_bytes, uint64_t file_offset) {
+  KMI_TRY(dist_check(idx, comm));
+  kmi_ctx *ctx = idx->ctx;
+  const int p = kmi::comm_size(comm);
+  if (p == 1 && !ctx->force_dist) return kmi_index_build_host(idx, bytes, n_bytes, file_offset);
+  if (n_bytes && !bytes) return set_err(ctx, KMI_ERR_INVALID, "null buffer");
+  const uint32_t nw = idx->shape.n_words, vw = idx->val_words, rw = nw + vw;
+  void *d_bytes, *d_send = nullptr, *d_recv;
+  KMI_TRY(ws_get(ctx, WS_INPUT, n_bytes + 64, &d_bytes));
+  if (n_bytes) KMI_HIP(ctx, hipMemcpyAsync(d_bytes, bytes, n_bytes, hipMemcpyHostToDevice, ctx->stream));
+  std::vector<uint64_t> sc(p, 0), rc;
+  uint64_t nt = 0, ns = 0, total = 0;
+  if (n_bytes) KMI_TRY(extract_count(ctx, &idx->cfg, (const uint8_t *)d_bytes, n_bytes, &nt, &ns));   // (an empty share still enters the collectives)
+  if (vw == 0) {
+    KMI_TRY(ws_get(ctx, WS_DIST_A, (nt + 64) * nw * sizeof(uint64_t), &d_send));
+    if (nt && idx->cfg.seq_format == KMI_FMT_FASTQ) {
+      // read_file + the bucketing half of imxx::distribute, fused: the tuple array in file order never exists
+      KMI_TRY(kmi_extract_route_dev(ctx, &idx->cfg, (const uint8_t *)d_bytes, n_bytes, (uint32_t)p, (uint64_t *)d_send, (size_t)nt, &nt, &ns, sc.data()));
+    } else if (nt) {
+      void *d_keys;
+      KMI_TRY(ws_get(ctx, WS_OUTPUT, (nt + 64) * nw * sizeof(uint64_t), &d_keys));
+      KMI_TRY(extract_run(ctx, &idx->cfg, (const uint8_t *)d_bytes, n_bytes, file_offset, (uint64_t *)d_keys, nullptr, (size_t)nt, true, true, &nt, &ns));
+      KMI_TRY(kmi_route_dev(ctx, &idx->cfg, (const uint64_t *)d_keys, (size_t)nt, (uint32_t)p, (uint64_t *)d_send, sc.data()));
+    }
+    KMI_TRY(dist_exchange(comm, d_send, sc.data(), nw * sizeof(uint64_t), WS_DIST_B, &d_recv, rc, &total));
+    return index_insert(idx, (const uint64_t *)d_recv, (size_t)total, false);
+  }
+  if (vw == 2 && idx->cfg.seq_format != KMI_FMT_FASTQ)
+    return set_err(ctx, KMI_ERR_INVALID, "a position + quality index over ranks is built from FASTQ partitions");
+  void *d_rec;
+  KMI_TRY(ws_get(ctx, WS_INPUT2, (nt + 64) * rw * sizeof(uint64_t), &d_rec));
+  KMI_TRY(ws_get(ctx, WS_DIST_A, (nt + 64) * rw * sizeof(uint64_t), &d_send));
+  if (nt) {
+    KMI_TRY(extract_run(ctx, &idx->cfg, (const uint8_t *)d_bytes, n_bytes, file_offset, (uint64_t *)d_rec, nullptr, (size_t)nt, false, true, &nt, &ns, nullptr, rw));
+    KMI_TRY(kmi_route_tuples_dev(ctx, &idx->cfg, (const uint64_t *)d_rec, (size_t)nt, (uint32_t)p, vw, (uint64_t *)d_send, sc.data()));
+  }
+  KMI_TRY(dist_exchange(comm, d_send, sc.data(), rw * sizeof(uint64_t), WS_DIST_B, &d_recv, rc, &total));
+  return index_insert_records(idx, (const uint64_t *)d_recv, (size_t)total, true);
+}
+
+static kmi_status query_dist_host(kmi_index *idx, kmi_comm *comm, int mode, const uint64_t *queries, size_t nq, kmi_results *out, uint64_t *n_erased) {
+  KMI_TRY(dist_check(idx, comm));
+  kmi_ctx *ctx = idx->ctx;
+  const int p = kmi::comm_size(comm);
+  if (p == 1 && !ctx->force_dist) return query_host(idx, mode, queries, nq, out, n_erased);
+  if (out) memset(out, 0, sizeof(*out));
+  if (n_erased) *n_erased = 0;
+  if (nq && !queries) return set_err(ctx, KMI_ERR_INVALID, "null buffer");
+  const uint32_t nw = idx->shape.n_words, ow = idx->val_words ? idx->val_words : 1u;
+  const size_t kb = nw * sizeof(uint64_t), vb = ow * sizeof(uint64_t);
+  void *d_in, *d_send, *d_q;
+  KMI_TRY(ws_get(ctx, WS_INPUT, (nq + 8) * kb, &d_in));
+  KMI_TRY(ws_get(ctx, WS_DIST_A, (nq + 8) * kb, &d_send));
+  if (nq) KMI_HIP(ctx, hipMemcpyAsync(d_in, queries, nq * kb, hipMemcpyHostToDevice, ctx->stream));
+  std::vector<uint64_t> sc(p, 0), rc;
+  KMI_TRY(kmi_route_dev(ctx, &idx->cfg, (const uint64_t *)d_in, nq, (uint32_t)p, (uint64_t *)d_send, sc.data()));
+  uint64_t total = 0;
+  KMI_TRY(dist_exchange(comm, d_send, sc.data(), kb, WS_DIST_B, &d_q, rc, &total));
+  if (mode == Q_ERASE) {
+    uint64_t n = 0;
+    if (total) KMI_TRY(index_query(idx, Q_ERASE, (const uint64_t *)d_q, (size_t)total, nullptr, nullptr, 0, &n));
+    if (n_erased) *n_erased = n;
+    return KMI_OK;
+  }
+  // every source rank's keys are answered on their own (a key two ranks ask about is answered to both)
+  uint64_t bound = 0;
+  for (int s = 0; s < p; ++s) bound += query_result_bound(idx, mode, (size_t)rc[s]);
+  void *d_rk, *d_rv;
+  KMI_TRY(ws_get(ctx, WS_DIST_C, (bound + 8) * kb, &d_rk));
+  KMI_TRY(ws_get(ctx, WS_DIST_D, (bound + 8) * vb, &d_rv));
+  std::vector<uint64_t> back(p, 0), got;
+  uint64_t off = 0, pos = 0;
+  for (int s = 0; s < p; ++s) {
+    uint64_t n = 0;
+    if (rc[s])
+      KMI_TRY(index_query(idx, mode, (const uint64_t *)d_q + off * nw, (size_t)rc[s], (uint64_t *)d_rk + pos * nw, (uint64_t *)d_rv + pos * ow,
+                          query_result_bound(idx, mode, (size_t)rc[s]), &n));
+    back[s] = n; off += rc[s]; pos += n;
+  }
+  void *d_ak, *d_av;
+  uint64_t n_mine = 0, n_mine2 = 0;
+  KMI_TRY(dist_exchange(comm, d_rk, back.data(), kb, WS_DIST_A, &d_ak, got, &n_mine));
+  KMI_TRY(dist_exchange(comm, d_rv, back.data(), vb, WS_DIST_B, &d_av, got, &n_mine2));
+  out->n = n_mine;
+  out->keys = (uint64_t *)malloc((n_mine ? n_mine : 1) * kb);
+  out->values = (uint64_t *)malloc((n_mine ? n_mine : 1) * vb);
+  if (!out->keys || !out->values) return set_err(ctx, KMI_ERR_NOMEM, "host malloc failed");
+  if (n_mine) {
+    KMI_HIP(ctx, hipMemcpyAsync(out->keys, d_ak, n_mine * kb, hipMemcpyDeviceToHost, ctx->stream));
+    KMI_HIP(ctx, hipMemcpyAsync(out->values, d_av, n_mine * vb, hipMemcpyDeviceToHost, ctx->stream));
+  }
+  KMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return KMI_OK;
+}
+
+kmi_status kmi_index_count_dist_host(kmi_index *idx, kmi_comm *comm, const uint64_t *queries, size_t nq, kmi_results *out) {
+  if (!out) return KMI_ERR_INVALID;
+  return query_dist_host(idx, comm, Q_COUNT, queries, nq, out, nullptr);
+}
+kmi_status kmi_index_find_dist_host(kmi_index *idx, kmi_comm *comm, const uint64_t *queries, size_t nq, kmi_results *out) {
+  if (!out) return KMI_ERR_INVALID;
+  return query_dist_host(idx, comm, Q_FIND, queries, nq, out, nullptr);
+}
+kmi_status kmi_index_erase_dist_host(kmi_index *idx, kmi_comm *comm, const uint64_t *queries, size_t nq, uint64_t *n_erased_local) {
+  return query_dist_host(idx, comm, Q_ERASE, queries, nq, nullptr, n_erased_local);
+}
+kmi_status kmi_index_size_dist(kmi_index *idx, kmi_comm *comm, uint64_t *n) {
+  if (!n) return KMI_ERR_INVALID;
+  KMI_TRY(dist_check(idx, comm));
+  *n = idx->n_entries;
+  return kmi::comm_allreduce_sum(comm, n);
+}
+
 }  // extern "C"

@@ -47,6 +47,10 @@ enum WsSlot {
   WS_SPLIT_RANK,      // destination rank of every index entry (split by rank)
   WS_SPLIT_OFF,       // per-part bucket offsets, part totals and bases (split / merge)
   WS_SK_ITEMS,        // super-k-mer items of the minimizer pass (fused build through super-k-mers)
+  WS_DIST_A,          // the collectives over ranks (kmi_index_*_dist_*): send / receive / result buffers
+  WS_DIST_B,
+  WS_DIST_C,
+  WS_DIST_D,
   WS_NUM_SLOTS
 };
 
@@ -81,6 +85,7 @@ struct kmi_ctx {
   struct Spare { void *p; size_t bytes; };
   std::vector<Spare> spare;
   bool fused_superkmer = true;   // fused count-index build through super-k-mers (KMI_FUSED_PATH=kmer in the environment: the k-mer pipeline)
+  bool force_dist = false;       // KMI_FORCE_DIST=1: the *_dist_* entry points run their exchange even with one rank (RCCL self exchange: tests)
   int sk_dbg = 0;                // KMI_SK_DBG: timing experiments of sk_reduce (results are wrong when set)
   bool fa_part_set = false;      // kmi_ctx_set_fasta_partition
   kmi_fasta_partition fa_part{};
@@ -189,6 +194,15 @@ inline bool is_rna(const kmi_config *cfg) { return cfg->alphabet == KMI_ALPHA_RN
     }                                                                                  \
     return KMI_ERR_INVALID;                                                            \
   } while (0)
+
+// ---- the RCCL exchange (kmi_comm.hip)
+kmi_status comm_all_to_all_counts(kmi_comm *c, const uint64_t *send_counts, uint64_t *recv_counts);
+kmi_status comm_all_to_all_v(kmi_comm *c, const void *send_dev, const uint64_t *send_counts, void *recv_dev, const uint64_t *recv_counts,
+                             size_t elem_bytes);
+kmi_status comm_allreduce_sum(kmi_comm *c, uint64_t *value);
+kmi_ctx *comm_ctx(kmi_comm *c);
+int comm_size(kmi_comm *c);
+int comm_rank(kmi_comm *c);
 
 // ---- entry points implemented across the .hip files
 kmi_status extract_count(kmi_ctx *ctx, const kmi_config *cfg, const uint8_t *bytes_dev, size_t n_bytes,

@@ -167,3 +167,63 @@ def test_reference_type_matrix_through_the_facade(tmp_path):
     om = orc.CountMap(s, orc.CANONICAL)
     om.insert(orc.extract(s, open(path, "rb").read(), orc.FASTQ, seq_filter=orc.SEQ_N_SPLIT)["kmers"])
     assert int(m.group(1)) == om.size()
+
+
+def test_position_quality_index_harness_matches_oracle():
+    """PositionQualityIndex<unordered_multimap<Kmer<31,DNA>, pair<ShortSequenceKmerId, float>>> (kmer_index.hpp:405-406) through
+    the facade: read_file with KmerPositionQualityTupleParser tuples, insert, count, find (positions and the quality floats'
+    bit patterns), erase -- BASELINE config 5's index type on one rank."""
+    path = os.path.join(DATA, "natural.fastq")
+    ratio = 4
+    exe = os.path.join(ROOT, "examples", "bench_posqual_k31_dna")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "examples")])
+    got = _run("bench_posqual_k31_dna", path, ratio)
+    s = orc.kspec(31)
+    data = open(path, "rb").read()
+    ex = orc.extract(s, data, orc.FASTQ, want_ids=True, want_quals=True)
+    vals = np.stack([ex["ids"], ex["quals"].view(np.uint32).astype(np.uint64)], axis=1)
+    m = orc.MultiMap(s, orc.CANONICAL, vw=2)
+    m.insert(ex["kmers"], vals)
+    q = ex["kmers"][: ex["kmers"].shape[0] // ratio]
+    ck, cv = m.count(q)
+    fk, fv = m.find(q)
+    pos = ((fv[:, 0] >> np.uint64(16)) & np.uint64(0xFFFFFFFFFF)) + (fv[:, 0] & np.uint64(0xFFFF))
+    assert got["total"] == (ex["kmers"].shape[0],)
+    assert got["distinct"] == (m.size(),)
+    assert got["count"] == (ck.shape[0], int(cv.sum()))
+    assert got["find"] == (fk.shape[0], int(pos.sum()) + int(fv[:, 1].sum()))
+    m.erase(q)
+    assert got["after_erase"] == (m.size(),)
+
+
+def test_weighted_insert_iterators_and_posqual_through_the_facade():
+    """examples/facade_extras.cpp: insert(vector<pair<Kmer, count>>) adds the values (weights 1 then 3 per occurrence ->
+    4 x occurrences), cbegin()/cend()/get_map() walk this rank's entries, PositionQualityIndex tuples round-trip."""
+    exe = os.path.join(ROOT, "examples", "facade_extras")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "examples")])
+    path = os.path.join(DATA, "natural.fastq")
+    out = subprocess.run([exe, path], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+
+    def grab(pat):
+        m = re.search(pat, out.stdout)
+        assert m, out.stdout
+        return tuple(int(x) for x in m.groups())
+
+    s = orc.kspec(21)
+    data = open(path, "rb").read()
+    ex = orc.extract(s, data, orc.FASTQ, want_ids=True, want_quals=True)
+    cm = orc.CountMap(s, orc.CANONICAL)
+    cm.insert(ex["kmers"])
+    n = ex["kmers"].shape[0]
+    assert grab(r"weighted entries (\d+) sum (\d+) occurrences (\d+)") == (cm.size(), 4 * n, n)
+    assert grab(r"get_map local_size (\d+) size (\d+)") == (cm.size(), cm.size())
+    vals = np.stack([ex["ids"], ex["quals"].view(np.uint32).astype(np.uint64)], axis=1)
+    mm = orc.MultiMap(s, orc.CANONICAL, vw=2)
+    mm.insert(ex["kmers"], vals)
+    fk, fv = mm.find(ex["kmers"][::5])
+    pos = ((fv[:, 0] >> np.uint64(16)) & np.uint64(0xFFFFFFFFFF)) + (fv[:, 0] & np.uint64(0xFFFF))
+    assert grab(r"posqual tuples (\d+) entries (\d+) found (\d+) pos (\d+) qbits (\d+)") == (n, mm.size(), fk.shape[0], int(pos.sum()), int(fv[:, 1].sum()))
+    assert grab(r"posqual all qbits (\d+)") == (int(vals[:, 1].sum()),)
