@@ -403,8 +403,10 @@ class Index {
       std::vector<uint64_t> q = route_queries(query);
       ::kmerind::check(ctx, kmi_index_count_host(idx, q.data(), q.size() / KmerType::nWords, &r));
     }
+    // (the device hands count results back at the stride of the map's values: one word, two for (id, quality))
+    constexpr unsigned ow = detail::stored_words<MapType, ValueType>();
     std::vector<std::pair<KmerType, size_t>> out(r.n);
-    for (uint64_t i = 0; i < r.n; ++i) out[i] = std::make_pair(KmerType(r.keys + i * KmerType::nWords), (size_t)r.values[i]);
+    for (uint64_t i = 0; i < r.n; ++i) out[i] = std::make_pair(KmerType(r.keys + i * KmerType::nWords), (size_t)r.values[i * ow]);
     kmi_results_free(&r);
     return out;
   }
@@ -422,7 +424,8 @@ class Index {
     kmi_results r{};
     ::kmerind::check(ctx, kmi_index_count_host(idx, w, query.size(), &r));
     std::map<KmerType, bool> present;
-    for (uint64_t i = 0; i < r.n; ++i) present[KmerType(r.keys + i * nw)] = r.values[i] != 0;
+    constexpr unsigned ow = detail::stored_words<MapType, ValueType>();
+    for (uint64_t i = 0; i < r.n; ++i) present[KmerType(r.keys + i * nw)] = r.values[i * ow] != 0;
     kmi_results_free(&r);
     for (size_t i = 0; i < query.size(); ++i) {
       auto it = present.find(KmerType(&t[i * nw]));
