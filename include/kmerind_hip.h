@@ -156,10 +156,24 @@ kmi_status kmi_extract_dev(kmi_ctx *ctx, const kmi_config *cfg, const uint8_t *b
                            uint64_t file_offset, uint64_t *out_kmers_dev, uint64_t *out_ids_dev,
                            size_t out_capacity, uint64_t *n_tuples, uint64_t *n_seqs);
 
+/* the tuples of the position parsers as records, device to device: n_words key words followed by the value words (id, or
+ * id and the quality's float bits in the low half of a second word) -- the object bytes of std::pair<Kmer, ShortSequenceKmerId>
+ * / std::pair<Kmer, std::pair<ShortSequenceKmerId, float>> (kmer_parser.hpp:303-569, 577-900): what kmi_route_tuples_dev
+ * and kmi_index_insert_tuples_dev take. out_capacity in records (kmi_extract_count_dev gives the number). */
+kmi_status kmi_extract_records_dev(kmi_ctx *ctx, const kmi_config *cfg, const uint8_t *bytes_dev, size_t n_bytes, uint64_t file_offset,
+                                   uint64_t *out_records_dev, size_t out_capacity, uint64_t *n_tuples, uint64_t *n_seqs);
+
+/* record-aligned partition of a FASTQ buffer that already sits in HBM: cuts[r] = first record start at or after byte
+ * floor(n_bytes * r / n_parts) by the four-line rule of FASTQParser::find_first_record (fastq_loader.hpp:269-364, as
+ * partitioned_file applies it, file.hpp:1216-1430); cuts[n_parts] = n_bytes; the ranges [cuts[r], cuts[r + 1]) tile the
+ * buffer. What every rank hands to kmi_index_build_* / kmi_extract_* when one buffer is split between ranks or batches. */
+kmi_status kmi_fastq_partition_dev(kmi_ctx *ctx, const uint8_t *bytes_dev, size_t n_bytes, uint32_t n_parts, uint64_t *cuts_host /* n_parts + 1 */);
+
 /* ---- L4: the exchange step of imxx::distribute (incremental_mxx.hpp:1039-1109):
  * assign_to_buckets + bucket_to_permutation + permute on the device. Output is the
- * send buffer grouped by destination rank (stable inside a rank), counts[nranks] on
- * the host. The all-to-all itself is done by the caller (RCCL through
+ * send buffer grouped by destination rank, counts[nranks] on the host. The order INSIDE a rank's message is unspecified (the
+ * reference's permutation is stable, incremental_mxx.hpp:324-364, but nothing it feeds -- hash map inserts, query dedup --
+ * observes that order). The all-to-all itself is done by the caller (RCCL through
  * torch.distributed in kmerind_amd.dist, or ncclSend/ncclRecv from C++). */
 kmi_status kmi_route_dev(kmi_ctx *ctx, const kmi_config *cfg, const uint64_t *keys_dev, size_t n,
                          uint32_t nranks, uint64_t *out_keys_dev, uint64_t *send_counts_host);

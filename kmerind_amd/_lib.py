@@ -78,6 +78,8 @@ SIGNATURES = {
     "kmi_tuples_free": (None, [C.POINTER(Tuples)]),
     "kmi_extract_count_dev": (C.c_int, [_P, _CFG, _P, _sz, C.POINTER(_u64), C.POINTER(_u64)]),
     "kmi_extract_dev": (C.c_int, [_P, _CFG, _P, _sz, _u64, _P, _P, _sz, C.POINTER(_u64), C.POINTER(_u64)]),
+    "kmi_extract_records_dev": (C.c_int, [_P, _CFG, _P, _sz, _u64, _P, _sz, C.POINTER(_u64), C.POINTER(_u64)]),
+    "kmi_fastq_partition_dev": (C.c_int, [_P, _P, _sz, _u32, _P]),
     "kmi_route_dev": (C.c_int, [_P, _CFG, _P, _sz, _u32, _P, _P]),
     "kmi_route_tuples_dev": (C.c_int, [_P, _CFG, _P, _sz, _u32, _u32, _P, _P]),
     "kmi_extract_route_dev": (C.c_int, [_P, _P, _P, _sz, C.c_uint32, _P, _sz, C.POINTER(_u64), C.POINTER(_u64), _P]),

@@ -272,6 +272,21 @@ kmi_status kmi_extract_dev(kmi_ctx *ctx, const kmi_config *cfg, const uint8_t *b
                      n_seqs);
 }
 
+kmi_status kmi_extract_records_dev(kmi_ctx *ctx, const kmi_config *cfg, const uint8_t *bytes_dev, size_t n_bytes, uint64_t file_offset,
+                                   uint64_t *out_records_dev, size_t out_capacity, uint64_t *n_tuples, uint64_t *n_seqs) {
+  if (!ctx) return KMI_ERR_INVALID;
+  KShape shape;
+  if (!valid_config(cfg, &shape)) return set_err(ctx, KMI_ERR_INVALID, "bad kmi_config");
+  if (cfg->index_kind == KMI_INDEX_COUNT) return set_err(ctx, KMI_ERR_INVALID, "records are the tuples of the position indexes (index_kind POSITION / POSQUAL)");
+  if (cfg->index_kind == KMI_INDEX_POSQUAL && cfg->seq_format != KMI_FMT_FASTQ) return set_err(ctx, KMI_ERR_INVALID, "quality values need FASTQ input");
+  KMI_HIP(ctx, hipSetDevice(ctx->device));
+  if (n_tuples) *n_tuples = 0;
+  if (n_seqs) *n_seqs = 0;
+  if (n_bytes == 0) return KMI_OK;
+  const uint32_t rw = shape.n_words + (cfg->index_kind == KMI_INDEX_POSITION ? 1u : 2u);
+  return extract_run(ctx, cfg, bytes_dev, n_bytes, file_offset, out_records_dev, nullptr, out_capacity, false, false, n_tuples, n_seqs, nullptr, rw);
+}
+
 kmi_status kmi_extract_host(kmi_ctx *ctx, const kmi_config *cfg, const uint8_t *bytes, size_t n_bytes, uint64_t file_offset,
                             kmi_tuples *out) {
   if (!ctx || !out) return KMI_ERR_INVALID;

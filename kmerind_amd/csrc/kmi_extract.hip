@@ -967,4 +967,54 @@ kmi_status extract_run(kmi_ctx *ctx, const kmi_config *cfg, const uint8_t *bytes
                out_capacity, apply_strand, scan_done, n_tuples, n_seqs, rec_words);
 }
 
+// ---------------------------------------------------------------------------
+// Record-aligned partition of a FASTQ buffer on the device: FASTQParser::find_first_record (fastq_loader.hpp:269-364) as
+// partitioned_file<..., FASTQParser> applies it (file.hpp:1216-1430). One thread per nominal split point: skip the rest
+// of the line the split falls in, look at the first characters of the next four lines; a record starts at the line
+// where '@' is followed two lines later by '+' (a quality line may itself begin with '@').
+// ---------------------------------------------------------------------------
+__global__ void fastq_find_first_records_kernel(const uint8_t *__restrict__ bytes, uint64_t n, uint32_t n_parts, uint64_t *__restrict__ cuts) {
+  const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r > n_parts) return;
+  if (r == n_parts) { cuts[r] = n; return; }
+  const uint64_t pos = n / n_parts * r + (n % n_parts) * r / n_parts;   // = floor(n r / n_parts) without overflow
+  if (pos == 0) { cuts[r] = 0; return; }
+  auto eol = [&](uint64_t i) { return bytes[i] == '\n' || bytes[i] == '\r'; };
+  uint64_t i = pos;
+  while (i < n && !eol(i)) ++i;          // the rest of this (partial) line
+  uint64_t starts[4];
+  uint8_t firsts[4];
+  for (int l = 0; l < 4; ++l) {
+    while (i < n && eol(i)) ++i;
+    if (i >= n) { cuts[r] = n; return; }
+    starts[l] = i; firsts[l] = bytes[i];
+    while (i < n && !eol(i)) ++i;
+  }
+  uint64_t c = n;
+  if (firsts[0] == '@' && firsts[2] == '+') c = starts[0];
+  else if (firsts[1] == '@' && firsts[3] == '+') c = starts[1];
+  else if (firsts[0] == '+' && firsts[2] == '@') c = starts[2];
+  else if (firsts[1] == '+' && firsts[3] == '@') c = starts[3];
+  cuts[r] = c;
+}
+
+}  // namespace kmi
+
+extern "C" kmi_status kmi_fastq_partition_dev(kmi_ctx *ctx, const uint8_t *bytes_dev, size_t n_bytes, uint32_t n_parts, uint64_t *cuts_host) {
+  using namespace kmi;
+  if (!ctx || !cuts_host || n_parts == 0) return KMI_ERR_INVALID;
+  KMI_HIP(ctx, hipSetDevice(ctx->device));
+  if (n_bytes == 0) { for (uint32_t r = 0; r <= n_parts; ++r) cuts_host[r] = 0; return KMI_OK; }
+  void *p;
+  KMI_TRY(ws_get(ctx, WS_MISC, sizeof(uint64_t) * ((size_t)n_parts + 1), &p));
+  hipLaunchKernelGGL(fastq_find_first_records_kernel, dim3((n_parts + 1 + 63) / 64), dim3(64), 0, ctx->stream, bytes_dev, (uint64_t)n_bytes, n_parts,
+                     (uint64_t *)p);
+  KMI_HIP(ctx, hipGetLastError());
+  KMI_HIP(ctx, hipMemcpyAsync(cuts_host, p, sizeof(uint64_t) * ((size_t)n_parts + 1), hipMemcpyDeviceToHost, ctx->stream));
+  KMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  for (uint32_t r = 1; r <= n_parts; ++r) cuts_host[r] = std::max(cuts_host[r], cuts_host[r - 1]);   // ranges tile the buffer
+  return KMI_OK;
+}
+
+namespace kmi {
 }  // namespace kmi

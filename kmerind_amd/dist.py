@@ -182,53 +182,78 @@ class DistributedCountIndex:
         self.index.merge_parts_device(self.world, rk.data_ptr(), rv.data_ptr(), rb.data_ptr())
 
     # ---- queries (distributed_unordered_map.hpp:880-983 count, :564-687 find, :719-779 erase): transform_input, route the
-    # query keys to their owners (imxx::distribute), answer locally per source rank, one return all-to-all
+    # query keys to their owners (imxx::distribute), answer locally per source rank, one return all-to-all. Device buffers
+    # throughout: the keys are transformed and grouped by KeyToRank on the device (kmi_route_dev), every source's segment is
+    # answered by kmi_index_count_dev / kmi_index_find_dev into device buffers, and only the caller's arrays cross PCIe
+    # (over gloo -- the CPU rehearsal -- the exchanged tensors are staged through the host, as everywhere).
+    value_words = 0
+
+    def _dev(self):
+        return self.device if self.device is not None else torch.device("cuda", self.ctx.device)
+
+    def _exchange_dev(self, send, counts):
+        """exchange_keys for device tensors: over RCCL as they are, over gloo through the host"""
+        if self.stage or dist.get_backend(self.group) == "gloo":
+            recv, rc = exchange_keys(send.cpu(), counts, self.group)
+            return recv.to(send.device), rc
+        return exchange_keys(send, counts, self.group)
+
     def _route_queries(self, q):
+        """-> (query keys this rank owns, grouped by source rank, as a device tensor [n, n_words]; counts per source)"""
+        import ctypes as C
         import numpy as np
         from . import _lib as L
         q = np.ascontiguousarray(q, dtype=np.uint64).reshape(-1, self.n_words)
-        if q.shape[0] and self.cfg.strand == L.STRAND_CANONICAL:
-            q = self.ctx.canonical(self.cfg, q)                               # InputTransform of the canonical model
-        ranks = self.ctx.key_to_rank(self.cfg, q, self.world) if q.shape[0] else np.zeros(0, np.uint32)
-        order = np.argsort(ranks, kind="stable")
-        counts = np.bincount(ranks, minlength=self.world).tolist()
-        recv, recv_counts = self._exchange_host(torch.from_numpy(q[order].view(np.int64)), counts)
-        return recv.numpy().view(np.uint64), recv_counts
+        dev = self._dev()
+        d_q = torch.from_numpy(q.view(np.int64)).to(dev)
+        d_s = torch.empty_like(d_q)
+        counts = np.zeros(self.world, dtype=np.uint64)
+        self.ctx.check(L.lib.kmi_route_dev(self.ctx.h, C.byref(self.cfg), C.c_void_p(d_q.data_ptr()), q.shape[0], self.world,
+                                           C.c_void_p(d_s.data_ptr()), counts.ctypes.data_as(C.c_void_p)))
+        return self._exchange_dev(d_s, [int(c) for c in counts])
 
-    def _exchange_host(self, send, counts):
-        """exchange_keys for host tensors: as they are over gloo, through the device over RCCL"""
-        if self.stage or dist.get_backend(self.group) == "gloo":
-            return exchange_keys(send, counts, self.group)
-        recv, rc = exchange_keys(send.to(self.device), counts, self.group)
-        return recv.cpu(), rc
-
-    def _answer(self, fn, q):
-        """fn(keys) -> (keys, values) on the local index; returns this rank's (keys, values) for its own query keys"""
+    def _answer(self, mode, q):
+        """mode "count" / "find" on the local index per source rank; returns this rank's (keys, values) for its own query keys"""
+        import ctypes as C
         import numpy as np
+        from . import _lib as L
         mine, recv_counts = self._route_queries(q)
+        dev = mine.device
+        vw = max(1, self.value_words)
+        fn = L.lib.kmi_index_count_dev if mode == "count" else L.lib.kmi_index_find_dev
         out_k, out_v, back = [], [], []
         off = 0
         for src in range(self.world):                                         # answers go back to the rank that asked
-            seg = mine[off:off + recv_counts[src]]
-            off += recv_counts[src]
-            k, v = fn(seg) if seg.shape[0] else (np.zeros((0, self.n_words), np.uint64), np.zeros(0, np.uint64))
-            out_k.append(k); out_v.append(np.asarray(v, dtype=np.uint64)); back.append(k.shape[0])
-        sk = torch.from_numpy(np.concatenate(out_k).reshape(-1, self.n_words).view(np.int64))
-        sv = torch.from_numpy(np.concatenate(out_v).reshape(-1, 1).view(np.int64))
-        rk, rc = self._exchange_host(sk, back)
-        rv, _ = self._exchange_host(sv, back)
-        return rk.numpy().view(np.uint64), rv.numpy().view(np.uint64)[:, 0]
+            n = recv_counts[src]
+            seg = mine[off:off + n]
+            off += n
+            cap = n if not (self.value_words and mode == "find") else max(1, self.index.local_size())
+            k = torch.empty((max(cap, 1), self.n_words), dtype=torch.int64, device=dev)
+            v = torch.empty((max(cap, 1), vw), dtype=torch.int64, device=dev)
+            n_out = C.c_uint64(0)
+            if n:
+                self.ctx.check(fn(self.index.h, C.c_void_p(seg.data_ptr()), n, C.c_void_p(k.data_ptr()), C.c_void_p(v.data_ptr()), C.byref(n_out)))
+            out_k.append(k[:n_out.value]); out_v.append(v[:n_out.value]); back.append(int(n_out.value))
+        rk, _ = self._exchange_dev(torch.cat(out_k), back)
+        rv, _ = self._exchange_dev(torch.cat(out_v), back)
+        keys = rk.cpu().numpy().view(np.uint64)
+        vals = rv.cpu().numpy().view(np.uint64)
+        if not self.value_words:
+            vals = vals[:, 0]
+        return keys, vals                                                       # multimaps: [n, value_words]; count() has the multiplicity in column 0
 
     def count(self, q):
         """one (key, count) per distinct transformed query key of THIS rank's query (0 when absent), as the reference returns"""
-        return self._answer(self.index.count, q)
+        return self._answer("count", q)
 
     def find(self, q):
-        return self._answer(self.index.find, q)
+        return self._answer("find", q)
 
     def erase(self, q):
+        import numpy as np
         mine, _ = self._route_queries(q)
-        n = self.index.erase(mine) if mine.shape[0] else 0
+        host = mine.cpu().numpy().view(np.uint64)                             # (erase takes host keys; they are already transformed)
+        n = self.index.erase(host) if host.shape[0] else 0
         return global_size(n, self.group, None if self.stage else self.device)
 
     def clear(self):
@@ -248,9 +273,11 @@ class DistributedCountIndex:
 class DistributedPositionIndex(DistributedCountIndex):
     """PositionIndex / PositionQualityIndex over all ranks (Index<unordered_multimap>::build_* + insert with comm.size() > 1,
     kmer_index.hpp:148-225, distributed_unordered_map.hpp:1466-1515): every (k-mer, value) tuple is kept, so nothing can be
-    combined before the exchange -- the tuples of this rank's partition are parsed on the device, transformed, routed by
-    KeyToRank, exchanged as records (key words, value words) and inserted by their owners. Host-level orchestration
-    (numpy records); count / find / erase are the routed queries of the base class."""
+    combined before the exchange. Per batch of this rank's partition, all on the device: parse the tuples as records
+    (kmi_extract_records_dev: key words, id[, quality bits]), transform and group them by KeyToRank (kmi_route_tuples_dev),
+    exchange the records, insert what arrives (kmi_index_insert_tuples_dev). The partition goes through in record-aligned
+    batches (kmi_fastq_partition_dev), so the tuple array of a whole partition -- 72 GB per GPU for 200 M reads on 8 --
+    never has to exist at once; count / find / erase are the routed queries of the base class."""
 
     def __init__(self, ctx, cfg, group=None, stage_through_host=False, device=None):
         from .core import PositionIndex
@@ -261,53 +288,45 @@ class DistributedPositionIndex(DistributedCountIndex):
         self.n_words, self.value_words = self.index.n_words, self.index.value_words
         self._cap = 0
 
-    def build(self, data, file_offset=0):
+    def build(self, data, file_offset=0, batch_bytes=None):
         """adds the tuples of this rank's record-aligned partition (host bytes; file_offset = its offset in the file)"""
         import numpy as np
-        from . import _lib as L
-        quals = self.value_words == 2
-        out = self.ctx.read_file(self.cfg, data, file_offset=file_offset, with_ids=True, with_quals=quals)
-        kmers, ids = out[0], out[1]
-        vals = ids.reshape(-1, 1)
-        if quals:                                                             # (id, float bits) as two 64-bit words
-            vals = np.concatenate([vals, out[2].view(np.uint32).astype(np.uint64).reshape(-1, 1)], axis=1)
-        if kmers.shape[0] and self.cfg.strand == L.STRAND_CANONICAL:
-            kmers = self.ctx.canonical(self.cfg, kmers)                       # transform_input before distribute
-        ranks = self.ctx.key_to_rank(self.cfg, kmers, self.world) if kmers.shape[0] else np.zeros(0, np.uint32)
-        order = np.argsort(ranks, kind="stable")
-        rec = np.concatenate([kmers, vals], axis=1)[order]
-        recv, _ = self._exchange_host(torch.from_numpy(np.ascontiguousarray(rec).view(np.int64)), np.bincount(ranks, minlength=self.world).tolist())
-        recv = recv.numpy().view(np.uint64)
-        if recv.shape[0]:
-            self.index.insert(np.ascontiguousarray(recv[:, :self.n_words]), np.ascontiguousarray(recv[:, self.n_words:]))
+        buf = np.frombuffer(bytes(data), dtype=np.uint8) if isinstance(data, (bytes, bytearray)) else np.ascontiguousarray(data, dtype=np.uint8)
+        d = torch.from_numpy(buf.copy()).to(self._dev()) if buf.size else torch.empty(0, dtype=torch.uint8, device=self._dev())
+        self.build_device(d.data_ptr(), int(buf.size), file_offset, batch_bytes)
 
-    def build_device(self, *a, **kw):
-        raise NotImplementedError("DistributedPositionIndex.build takes the partition's host bytes")
-
-    def _answer(self, fn, q):
-        """multimap answers carry value_words words per hit"""
+    def build_device(self, dptr, nbytes, file_offset=0, batch_bytes=None):
+        """the same for a partition resident in HBM; batch_bytes = upper bound of the bytes parsed per exchange (FASTQ only)"""
+        import ctypes as C
         import numpy as np
-        mine, recv_counts = self._route_queries(q)
-        out, back = [], []
-        off = 0
-        for src in range(self.world):
-            seg = mine[off:off + recv_counts[src]]
-            off += recv_counts[src]
-            if seg.shape[0]:
-                k, v = fn(seg)
-                # explicit width: a segment whose keys are all absent gives zero rows, which reshape(0, -1) cannot size
-                vw = self.value_words if fn == self.index.find else 1
-                v = np.asarray(v, dtype=np.uint64).reshape(k.shape[0], vw)
-            else:
-                k, v = np.zeros((0, self.n_words), np.uint64), np.zeros((0, 1), np.uint64)
-            out.append(np.concatenate([k, v], axis=1) if k.shape[0] else np.zeros((0, self.n_words + v.shape[1]), np.uint64))
-            back.append(k.shape[0])
-        width = max(o.shape[1] for o in out)
-        width = int(global_max(width, self.group, None if self.stage else self.device))
-        rec = np.concatenate([np.pad(o, ((0, 0), (0, width - o.shape[1]))) for o in out])
-        r, _ = self._exchange_host(torch.from_numpy(np.ascontiguousarray(rec).view(np.int64)), back)
-        r = r.numpy().view(np.uint64)
-        return r[:, :self.n_words], r[:, self.n_words:]
+        from . import _lib as L
+        from . import fileio
+        dev = self._dev()
+        rw = self.n_words + self.value_words
+        nb = 1
+        if batch_bytes and nbytes > batch_bytes and self.cfg.seq_format == L.FMT_FASTQ:
+            nb = -(-nbytes // batch_bytes)
+        nb = int(global_max(nb, self.group, None if self.stage else self.device))     # every rank enters every exchange
+        cuts = fileio.partition_fastq_device(self.ctx, dptr, nbytes, nb) if nb > 1 else [(0, nbytes)]
+        cdev = None if self.stage else self.device
+        for b, e in cuts:
+            nt, ns = C.c_uint64(0), C.c_uint64(0)
+            if e > b:
+                self.ctx.check(L.lib.kmi_extract_count_dev(self.ctx.h, C.byref(self.cfg), C.c_void_p(dptr + b), e - b, C.byref(nt), C.byref(ns)))
+            n = int(nt.value)
+            rec = torch.empty((n + 8, rw), dtype=torch.int64, device=dev)
+            send = torch.empty((n + 8, rw), dtype=torch.int64, device=dev)
+            counts = np.zeros(self.world, dtype=np.uint64)
+            if n:
+                self.ctx.check(L.lib.kmi_extract_records_dev(self.ctx.h, C.byref(self.cfg), C.c_void_p(dptr + b), e - b, file_offset + b,
+                                                              C.c_void_p(rec.data_ptr()), n, C.byref(nt), C.byref(ns)))
+                self.ctx.check(L.lib.kmi_route_tuples_dev(self.ctx.h, C.byref(self.cfg), C.c_void_p(rec.data_ptr()), n, self.world,
+                                                          self.value_words, C.c_void_p(send.data_ptr()), counts.ctypes.data_as(C.c_void_p)))
+            recv, _ = self._exchange_dev(send[:n], [int(c) for c in counts])
+            if recv.shape[0]:
+                self.ctx.check(L.lib.kmi_index_insert_tuples_dev(self.index.h, C.c_void_p(recv.data_ptr()), recv.shape[0]))
+            del rec, send, recv
+        del cdev
 
     def close(self):
         self.index.close()

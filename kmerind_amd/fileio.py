@@ -54,6 +54,16 @@ def partition_fastq(data, n_parts):
     return [(cuts[r], cuts[r + 1]) for r in range(n_parts)]
 
 
+def partition_fastq_device(ctx, dptr, nbytes, n_parts):
+    """partition_fastq for a buffer resident in HBM: the four-line rule runs on the device (kmi_fastq_partition_dev),
+    one thread per split point; same ranges as the host version"""
+    import ctypes as C
+    from . import _lib as L
+    cuts = np.zeros(n_parts + 1, dtype=np.uint64)
+    ctx.check(L.lib.kmi_fastq_partition_dev(ctx.h, C.c_void_p(dptr), nbytes, n_parts, cuts.ctypes.data_as(C.c_void_p)))
+    return [(int(cuts[r]), int(cuts[r + 1])) for r in range(n_parts)]
+
+
 # ---------------------------------------------------------------------------
 # FASTA: fixed byte blocks with k - 1 characters of overlap and the header bookkeeping that
 # FASTAParser::init_parser obtains from the neighbouring ranks (src/io/fasta_loader.hpp:232-456, 485-604;

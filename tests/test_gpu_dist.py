@@ -152,3 +152,47 @@ def test_distributed_position_index_two_ranks_one_gpu(kind, vw):
         assert a[0].shape == b[0].shape and (a[0] == b[0]).all() and (a[1] == b[1]).all()
         ek, ev = ref.find(q)
         assert (canon(ret[r][6], ret[r][7][:, :vw]) == canon(ek, ev)).all()
+
+
+def _batch_worker(rank, world, port, data, k, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import torch
+        import kmerind_amd as K
+        from kmerind_amd import dist as kdist
+        from kmerind_amd import fileio
+        ctx = K.Context(0, rank=rank, nranks=world)
+        cfg = K.make_config(k, "DNA", strand="canonical", index_kind="posqual")
+        didx = kdist.DistributedPositionIndex(ctx, cfg, stage_through_host=True, device=torch.device("cuda", 0))
+        # rank 0 gets a third of the file, rank 1 the rest: different batch counts per rank, every rank still enters every exchange
+        cut = fileio.find_first_record(data, len(data) // 3)
+        b, e = (0, cut) if rank == 0 else (cut, len(data))
+        didx.build(data[b:e], file_offset=b, batch_bytes=50_000)
+        keys, vals = didx.index.to_vector()
+        ret[rank] = (keys.copy(), vals.copy(), didx.size())
+        didx.close()
+        ctx.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_distributed_position_quality_index_in_batches():
+    """config 5's build streams a rank's partition through in record-aligned batches (kmi_fastq_partition_dev), one
+    exchange per batch: same multimap as the single-rank parse, ids and qualities included"""
+    import kmerind_amd as K
+    world, k = 2, 31
+    data = bytes(K.synth_fastq(seed=23, genome_len=15_000, n_reads=1_200))
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_batch_worker, args=(world, _free_port(), data, k, ret), nprocs=world, join=True)
+    s = orc.kspec(k)
+    ex = orc.extract(s, data, orc.FASTQ, want_ids=True, want_quals=True)
+    vals = np.concatenate([ex["ids"].reshape(-1, 1), ex["quals"].view(np.uint32).astype(np.uint64).reshape(-1, 1)], axis=1)
+    ref = orc.MultiMap(s, orc.CANONICAL, 2)
+    ref.insert(ex["kmers"], vals)
+    rk, rv = ref.export()
+    got_k = np.concatenate([ret[r][0] for r in range(world)])
+    got_v = np.concatenate([ret[r][1] for r in range(world)])
+    assert (orc.sorted_rows(got_k, got_v) == orc.sorted_rows(rk, rv)).all()
+    assert all(ret[r][2] == ref.size() for r in range(world))

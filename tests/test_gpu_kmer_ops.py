@@ -263,3 +263,21 @@ def test_position_id_overflow_is_reported(ctx):
     with pytest.raises(L.KmiError) as ei:
         ctx.read_file(cfg, long_read, with_ids=True)
     assert ei.value.status == L.ERR_OVERFLOW
+
+
+def test_fastq_partition_on_the_device_matches_the_host_rule(ctx):
+    """kmi_fastq_partition_dev = FASTQParser::find_first_record per split point (fastq_loader.hpp:269-364): same record-aligned
+    ranges as kmerind_amd.fileio.partition_fastq, also when quality lines begin with '@' or '+' and for more parts than records"""
+    import kmerind_amd as K
+    from kmerind_amd import fileio
+    files = [open(os.path.join(GOLD, "data", n), "rb").read() for n in ("natural.fastq", "test.small.fastq", "test.medium.fastq")]
+    tricky = b"".join(b"@r%d\nACGTACGTAC\n+\n%s\n" % (i, q) for i, q in enumerate([b"@@@@@@@@@@", b"+IIIIIIIII", b"@+@+@+@+@+", b"IIIIIIIIII"] * 40))
+    files.append(tricky)
+    files.append(bytes(K.synth_fastq(seed=3, genome_len=5000, n_reads=300)))
+    for data in files:
+        buf = np.frombuffer(data, dtype=np.uint8)
+        d = ctx.alloc(buf.size + 64)
+        ctx.to_device(d, buf)
+        for parts in (1, 2, 3, 5, 8, 16, 257):
+            assert fileio.partition_fastq_device(ctx, d, buf.size, parts) == fileio.partition_fastq(data, parts), parts
+        ctx.free(d)
