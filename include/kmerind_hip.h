@@ -148,8 +148,9 @@ typedef struct {
 kmi_status kmi_extract_host(kmi_ctx *ctx, const kmi_config *cfg, const uint8_t *bytes, size_t n_bytes,
                             uint64_t file_offset, kmi_tuples *out /* buffers malloc'd; kmi_tuples_free */);
 void kmi_tuples_free(kmi_tuples *t);
-/* device form: bytes_dev 16-byte aligned, out_kmers_dev capacity in tuples (use
- * kmi_extract_count_dev first, or pass an upper bound n_bytes). */
+/* device form: out_kmers_dev capacity in tuples (use kmi_extract_count_dev first, or pass an upper bound n_bytes). bytes_dev
+ * may point anywhere (a record-aligned batch inside a larger buffer): an input that is not 16-byte aligned is copied once,
+ * device to device, to an aligned workspace buffer. */
 kmi_status kmi_extract_count_dev(kmi_ctx *ctx, const kmi_config *cfg, const uint8_t *bytes_dev, size_t n_bytes,
                                  uint64_t *n_tuples, uint64_t *n_seqs);
 kmi_status kmi_extract_dev(kmi_ctx *ctx, const kmi_config *cfg, const uint8_t *bytes_dev, size_t n_bytes,

@@ -260,6 +260,7 @@ kmi_status kmi_extract_count_dev(kmi_ctx *ctx, const kmi_config *cfg, const uint
                                  uint64_t *n_tuples, uint64_t *n_seqs) {
   if (!ctx) return KMI_ERR_INVALID;
   KMI_HIP(ctx, hipSetDevice(ctx->device));
+  KMI_TRY(align_input(ctx, &bytes_dev, n_bytes));
   return extract_count(ctx, cfg, bytes_dev, n_bytes, n_tuples, n_seqs);
 }
 
@@ -268,6 +269,7 @@ kmi_status kmi_extract_dev(kmi_ctx *ctx, const kmi_config *cfg, const uint8_t *b
                            uint64_t *n_tuples, uint64_t *n_seqs) {
   if (!ctx) return KMI_ERR_INVALID;
   KMI_HIP(ctx, hipSetDevice(ctx->device));
+  KMI_TRY(align_input(ctx, &bytes_dev, n_bytes));
   return extract_run(ctx, cfg, bytes_dev, n_bytes, file_offset, out_kmers_dev, out_ids_dev, out_capacity, false, false, n_tuples,
                      n_seqs);
 }
@@ -284,6 +286,7 @@ kmi_status kmi_extract_records_dev(kmi_ctx *ctx, const kmi_config *cfg, const ui
   if (n_seqs) *n_seqs = 0;
   if (n_bytes == 0) return KMI_OK;
   const uint32_t rw = shape.n_words + (cfg->index_kind == KMI_INDEX_POSITION ? 1u : 2u);
+  KMI_TRY(align_input(ctx, &bytes_dev, n_bytes));
   return extract_run(ctx, cfg, bytes_dev, n_bytes, file_offset, out_records_dev, nullptr, out_capacity, false, false, n_tuples, n_seqs, nullptr, rw);
 }
 

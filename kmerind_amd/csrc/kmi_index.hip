@@ -3126,6 +3126,7 @@ kmi_status kmi_extract_route_dev(kmi_ctx *ctx, const kmi_config *cfg, const uint
   if (n_tuples) *n_tuples = 0;
   if (n_seqs) *n_seqs = 0;
   if (n_bytes == 0) { for (uint32_t r = 0; r < nranks; ++r) send_counts_host[r] = 0; return KMI_OK; }
+  KMI_TRY(align_input(ctx, &bytes_dev, n_bytes));
   KMI_DISPATCH(shape, extract_route_impl, ctx, cfg, shape, bytes_dev, n_bytes, nranks, out_keys_dev, out_capacity, n_tuples, n_seqs, send_counts_host);
 }
 
@@ -3232,6 +3233,7 @@ kmi_status kmi_index_build_dev(kmi_index *idx, const uint8_t *bytes_dev, size_t 
   kmi_ctx *ctx = idx->ctx;
   KMI_HIP(ctx, hipSetDevice(ctx->device));
   if (n_bytes == 0) return KMI_OK;
+  KMI_TRY(align_input(ctx, &bytes_dev, n_bytes));
   if (idx->val_words == 0 && idx->cfg.seq_format == KMI_FMT_FASTQ) return index_build_fused(idx, bytes_dev, n_bytes);
   if (idx->val_words == 0) {
     // FASTA count index: tuples from the compacted-stream extract, then the key insert path

@@ -51,6 +51,7 @@ enum WsSlot {
   WS_DIST_B,
   WS_DIST_C,
   WS_DIST_D,
+  WS_ALIGNED,         // 16-byte aligned copy of an input buffer that arrived at an odd address (a batch inside a larger buffer)
   WS_NUM_SLOTS
 };
 
@@ -194,6 +195,17 @@ inline bool is_rna(const kmi_config *cfg) { return cfg->alphabet == KMI_ALPHA_RN
     }                                                                                  \
     return KMI_ERR_INVALID;                                                            \
   } while (0)
+
+// The byte kernels load 16 bytes per lane: an input that does not start on a 16-byte boundary (a record-aligned batch or
+// partition inside a larger device buffer) is copied once to an aligned workspace buffer, device to device.
+inline kmi_status align_input(kmi_ctx *ctx, const uint8_t **bytes_dev, size_t n_bytes) {
+  if (n_bytes == 0 || (reinterpret_cast<uintptr_t>(*bytes_dev) & 15u) == 0) return KMI_OK;
+  void *p;
+  KMI_TRY(ws_get(ctx, WS_ALIGNED, n_bytes + 64, &p));
+  KMI_HIP(ctx, hipMemcpyAsync(p, *bytes_dev, n_bytes, hipMemcpyDeviceToDevice, ctx->stream));
+  *bytes_dev = (const uint8_t *)p;
+  return KMI_OK;
+}
 
 // ---- the RCCL exchange (kmi_comm.hip)
 kmi_status comm_all_to_all_counts(kmi_comm *c, const uint64_t *send_counts, uint64_t *recv_counts);

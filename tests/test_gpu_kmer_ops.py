@@ -281,3 +281,33 @@ def test_fastq_partition_on_the_device_matches_the_host_rule(ctx):
         for parts in (1, 2, 3, 5, 8, 16, 257):
             assert fileio.partition_fastq_device(ctx, d, buf.size, parts) == fileio.partition_fastq(data, parts), parts
         ctx.free(d)
+
+
+def test_parts_of_a_device_buffer_parse_like_the_whole(ctx):
+    """a record-aligned part of a larger device buffer starts at an arbitrary address (the byte kernels load 16 bytes per
+    lane: the library aligns such an input itself): the parts' tuples add up to the whole buffer's, ids included"""
+    import ctypes as C
+    import kmerind_amd as K
+    from kmerind_amd import _lib as L
+    from kmerind_amd import fileio
+    k = 31
+    s = orc.kspec(k, orc.DNA)
+    data = K.synth_fastq(seed=8, genome_len=4000, n_reads=1000)          # 315-byte records: odd part offsets
+    cfg = K.make_config(k, "DNA", strand="canonical", index_kind="position")
+    d = ctx.alloc(data.size + 64)
+    ctx.to_device(d, data)
+    ex = orc.extract(s, bytes(data), orc.FASTQ, want_ids=True)
+    got_k, got_i = [], []
+    for b, e in fileio.partition_fastq_device(ctx, d, data.size, 7):
+        assert b % 315 == 0
+        nt, ns = C.c_uint64(), C.c_uint64()
+        ctx.check(L.lib.kmi_extract_count_dev(ctx.h, C.byref(cfg), C.c_void_p(d + b), e - b, C.byref(nt), C.byref(ns)))
+        assert nt.value == (e - b) // 315 * (150 - k + 1) and ns.value == (e - b) // 315
+        dk, di = ctx.alloc(nt.value * 8 + 64), ctx.alloc(nt.value * 8 + 64)
+        ctx.check(L.lib.kmi_extract_dev(ctx.h, C.byref(cfg), C.c_void_p(d + b), e - b, b, C.c_void_p(dk), C.c_void_p(di), nt.value, C.byref(nt), C.byref(ns)))
+        hk, hi = np.zeros((nt.value, 1), np.uint64), np.zeros(nt.value, np.uint64)
+        ctx.to_host(hk, dk); ctx.to_host(hi, di)
+        ctx.free(dk); ctx.free(di)
+        got_k.append(hk); got_i.append(hi)
+    ctx.free(d)
+    assert (np.concatenate(got_k) == ex["kmers"]).all() and (np.concatenate(got_i) == ex["ids"]).all()
