@@ -1589,7 +1589,15 @@ __device__ __forceinline__ void table_insert_flat(const LdsTable<1> &t, uint64_t
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const bool v = (valid >> u) & 1u;
-      const bool hit = v && cur[u] == k[u];
+      bool hit = v && cur[u] == k[u];
+      if (v && cur[u] == kEmptyKey) {   // first sighting with a free home slot: claimed here, in line (with little duplication most keys are)
+        const unsigned long long old = atomicCAS((unsigned long long *)&t.keys[slot[u]], (unsigned long long)kEmptyKey, (unsigned long long)k[u]);
+        if (old == kEmptyKey) {
+          hit = true;
+          const unsigned long long cm = __ballot(1);
+          if ((int)lane == __ffsll((long long)cm) - 1) atomicAdd(t.distinct, (uint32_t)__popcll(cm));
+        } else hit = old == k[u];
+      }
       if (hit) atomicAdd(&t.vals[slot[u]], 1u);
       const bool miss = v && !hit;
       const unsigned long long m = __ballot(miss);
@@ -2603,22 +2611,35 @@ static kmi_status build_superkmer_w(kmi_index *idx, const FastqScan &sc, bool *d
   KMI_TRY(ws_get(ctx, WS_TMP_KEYS, (n + 64) * sizeof(uint64_t), &p)); uint64_t *tmp_keys = (uint64_t *)p;
   KMI_TRY(ws_get(ctx, WS_TMP_VALS, (n + 64) * sizeof(uint32_t), &p)); uint32_t *tmp_vals = (uint32_t *)p;
   KMI_TRY(ws_get(ctx, WS_BUCKET_CNT, sizeof(uint32_t) * kNumFine, &p)); uint32_t *out_cnt = (uint32_t *)p;
+  KMI_HIP(ctx, hipMemsetAsync(ctx->d_flags + 16, 0, sizeof(uint32_t) * 18, ctx->stream));   // the pass-structure votes of sk_reduce
   {
     ProfScope ps(ctx, "sk_reduce", n);
     const uint32_t nmax = sk_nmax_of(k);
 #define KMI_SK_REDUCE(CANON, OWN)                                                                                                        \
     hipLaunchKernelGGL((sk_reduce_kernel<CANON, OWN>), dim3(kNumFine), dim3(1024), 0, ctx->stream, (const uint64_t *)rec_b,              \
-                       (const uint64_t *)fine_off, k, (const uint64_t *)kmer_off, tmp_keys, tmp_vals, out_cnt, ctx->d_flags, ctx->sk_dbg)
+                       (const uint64_t *)fine_off, k, (const uint64_t *)kmer_off, tmp_keys, tmp_vals, out_cnt, ctx->d_flags, ctx->sk_dbg, ctx->sk_level_hint)
     if (nmax <= 21u) { if (canonical) KMI_SK_REDUCE(true, 64 * 21); else KMI_SK_REDUCE(false, 64 * 21); }
     else if (nmax <= 24u) { if (canonical) KMI_SK_REDUCE(true, 64 * 24); else KMI_SK_REDUCE(false, 64 * 24); }
     else { if (canonical) KMI_SK_REDUCE(true, 64 * 32); else KMI_SK_REDUCE(false, 64 * 32); }
 #undef KMI_SK_REDUCE
   }
   KMI_HIP(ctx, hipGetLastError());
+  {   // the level most buckets ended at: where the buckets of the NEXT build (batch, step) of this context start
+    uint32_t lv[9] = {0};
+    KMI_HIP(ctx, hipMemcpyAsync(lv, ctx->d_flags + 16, sizeof(lv), hipMemcpyDeviceToHost, ctx->stream));
+    KMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    uint64_t seen = 0; uint32_t best = 0;
+    for (uint32_t l = 0; l < 9; ++l) { seen += lv[l]; if (lv[l] > lv[best]) best = l; }
+    // (level 0 finishes are only recorded once the hint is non-zero: no record at all means "everything fit at level 0")
+    if (seen == 0) ctx->sk_level_hint = 0;
+    else if (ctx->sk_level_hint == 0) { uint64_t up = seen; ctx->sk_level_hint = (up * 2 > (uint64_t)kNumFine) ? best : 0u; }
+    else ctx->sk_level_hint = best;
+  }
   if (ctx->sk_dbg == 6) {
-    uint32_t hf[16];
+    uint32_t hf[40];
     (void)hipMemcpy(hf, ctx->d_flags, sizeof(hf), hipMemcpyDeviceToHost);
-    fprintf(stderr, "sk_reduce: records %u, direct %u, T1 entries %u\n", hf[10], hf[11], hf[12]);
+    fprintf(stderr, "sk_reduce: records %u, direct %u, T1 entries %u; buckets without / with a split at level 0: %u / %u, level 1: %u / %u\n", hf[10], hf[11],
+            hf[12], hf[16], hf[17], hf[18], hf[19]);
     (void)hipMemset(ctx->d_flags + 10, 0, 3 * sizeof(uint32_t));
   }
   *done = true;

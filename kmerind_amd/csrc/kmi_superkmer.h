@@ -426,9 +426,9 @@ struct SkTabCfg {
   static constexpr int OWN = OWN_;                       // k-mers of a batch of 64 records at most (64 x nmax)
   static constexpr int S1 = 2048 + 64;                   // record table slots (20 bytes each)
   static constexpr int L1 = 1536;                        // records it takes before the rest goes direct
-  static constexpr int FIXED = NWAVES * (OWN + kMissQ * 12) + S1 * 20 + 1024;
+  static constexpr int FIXED = NWAVES * (OWN + kMissQ * 12) + S1 * 20 + 2560;   // + control words and the pass stack
   static constexpr int S2 = ((160 * 1024 - FIXED) / 12) / 64 * 64;   // k-mer table slots (12 bytes each)
-  static constexpr int CAP2 = S2 - 64, LIMIT2 = 48;      // LIMIT2: longest probe walk before the table counts as full
+  static constexpr int CAP2 = S2 - 64, LIMIT2 = CAP2 * 4 / 5;   // LIMIT2: distinct keys of a pass before the bucket is split
 };
 
 // slot hash of the k-mer table (private to this kernel: two multiplies instead of the placement hash's three)
@@ -440,10 +440,11 @@ __device__ __forceinline__ uint32_t sk_slot_hash(uint64_t key) {
 __device__ __forceinline__ uint32_t sk_slot_of(uint32_t h, uint32_t cap) { return ((h >> 16) * cap) >> 16; }   // (cap < 2^16: a 24-bit multiply)
 
 // the slow path of the k-mer table, out of line: queue entries [first, first + cnt) (key, weight), one per lane
-__device__ __attribute__((noinline)) void sk_probe_insert(lds_u64_t *tkeys, lds_u32_t *tvals, lds_u32_t *distinct, lds_u32_t *overflow,
+__device__ __attribute__((noinline)) uint32_t sk_probe_insert(lds_u64_t *tkeys, lds_u32_t *tvals, lds_u32_t *distinct, lds_u32_t *overflow,
                                                          const lds_u64_t *q, const lds_u32_t *qw, uint32_t first, uint32_t cnt,
-                                                         uint32_t cap, uint32_t last, uint32_t limit) {
+                                                         uint32_t cap, uint32_t last, uint32_t limit, uint32_t pending) {
   const uint32_t lane = lane_id();
+  bool claimed = false;
   if (lane < cnt) {
     const uint64_t key = q[first + lane];
     const uint32_t wt = qw[first + lane];
@@ -451,24 +452,36 @@ __device__ __attribute__((noinline)) void sk_probe_insert(lds_u64_t *tkeys, lds_
     uint32_t s = s0;
     uint64_t c = __atomic_load_n(&tkeys[s], __ATOMIC_RELAXED);
     for (;;) {
-      while (c != key && c != kEmptyKey) { ++s; c = __atomic_load_n(&tkeys[s], __ATOMIC_RELAXED); }   // the walk (no wrap: padded table)
+      while (c != key && c != kEmptyKey && s - s0 < 64u) { ++s; c = __atomic_load_n(&tkeys[s], __ATOMIC_RELAXED); }   // the walk (no wrap: padded table)
       if (c == key) break;
-      // an empty slot. The table counts as full when a walk gets longer than `limit` slots or reaches the end of the padding
-      // (no shared counter of distinct keys on this path: every read of it was a full LDS round trip for a few lanes)
-      if (s >= last || s - s0 > limit) { *overflow = 1; s = last; break; }
+      // an empty slot, or the walk got too long: a walk of 64 slots or one that reaches the end of the padding ends the pass
+      // (the other wavefronts keep filling the table until they see the flag: without the bound a full table turns every
+      // walk into a scan of all of it)
+      if (c != kEmptyKey || s >= last) { *overflow = 1; s = last; break; }
       uint64_t expected = kEmptyKey;
-      if (__atomic_compare_exchange_n(&tkeys[s], &expected, key, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) break;
+      if (__atomic_compare_exchange_n(&tkeys[s], &expected, key, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) { claimed = true; break; }
       c = expected;
     }
     __atomic_fetch_add(&tvals[s], wt, __ATOMIC_RELAXED);   // (slot `last` never holds a key: counts parked there are never read)
   }
+  // fill level: the claims of this call (and the `pending` ones the caller made in line since its last call) go to the shared
+  // counter in ONE add per wavefront; its return value is the level -- past `limit` the pass is over (a linear-probing
+  // table near full turns every insert into a long walk)
+  const unsigned long long cm = __ballot(claimed);
+  const uint32_t add = (uint32_t)__popcll(cm) + pending;
+  if (add >= 16u || (add && cnt < 64u)) {   // (small amounts ride along with the next call; the last call of a pass flushes)
+    if (lane == 0 && __atomic_fetch_add(distinct, add, __ATOMIC_RELAXED) + add >= limit) *overflow = 1;
+    return 0u;
+  }
+  return add;
 }
 
 template <bool CANON, int OWN_>
 __global__ __launch_bounds__(1024) void sk_reduce_kernel(const uint64_t *__restrict__ recs, const uint64_t *__restrict__ rec_off, uint32_t k,
                                                         const uint64_t *__restrict__ kmer_off /* k-mers before every bucket */,
                                                         uint64_t *__restrict__ tmp_keys, uint32_t *__restrict__ tmp_vals,
-                                                        uint32_t *__restrict__ out_cnt, uint32_t *__restrict__ flags, int dbg) {
+                                                        uint32_t *__restrict__ out_cnt, uint32_t *__restrict__ flags, int dbg,
+                                                        uint32_t start_bits /* filter bits every bucket starts with (the level most buckets of the last build ended at) */) {
   using T = SkTabCfg<OWN_>;
   constexpr int NWAVES = T::NWAVES;
   constexpr uint64_t W1_INIT = ~0ull;   // never a record's second word (its top three bits are zero)
@@ -480,7 +493,7 @@ __global__ __launch_bounds__(1024) void sk_reduce_kernel(const uint64_t *__restr
   __shared__ uint32_t s_missw[NWAVES * kMissQ];
   __shared__ uint8_t s_own[NWAVES * T::OWN];
   __shared__ uint32_t s_ctl[12];       // 0 distinct, 1 overflow, 2 special count, 3 special set, 4 emit counter, 5 stack size, 8 records in T1
-  __shared__ uint32_t s_stack[64];     // pending passes: filter bits | value << 8
+  __shared__ uint32_t s_stack[320];    // pending passes: filter bits | value << 8 (up to 256 to start with + the splits)
   const uint32_t b = blockIdx.x;
   const uint64_t rb = rec_off[b], re = rec_off[b + 1];
   if (rb == re) { if (threadIdx.x == 0) out_cnt[b] = 0; return; }
@@ -498,7 +511,11 @@ __global__ __launch_bounds__(1024) void sk_reduce_kernel(const uint64_t *__restr
   const bool full64 = kb == 64u;   // only then can a key equal the empty marker
   const KShape shape = make_shape(k, 2);
   for (uint32_t i = threadIdx.x; i < (uint32_t)(NWAVES * T::OWN / 4); i += T::NT) reinterpret_cast<uint32_t *>(s_own)[i] = 0;
-  if (threadIdx.x == 0) { s_ctl[5] = 1; s_stack[0] = 0; s_ctl[4] = 0; }
+  if (threadIdx.x == 0) {
+    const uint32_t hb = start_bits > 8u ? 8u : start_bits;
+    for (uint32_t v = 0; v < (1u << hb); ++v) s_stack[v] = hb | (v << 8);
+    s_ctl[5] = 1u << hb; s_ctl[4] = 0; s_ctl[9] = hb;
+  }
   lds_barrier();
   const uint32_t n_rec = (uint32_t)(re - rb);
   const ulonglong2 *const src = reinterpret_cast<const ulonglong2 *>(recs) + rb;
@@ -508,14 +525,18 @@ __global__ __launch_bounds__(1024) void sk_reduce_kernel(const uint64_t *__restr
     const uint32_t pass = s_stack[sp - 1];
     const uint32_t fbits = pass & 0xffu, fval = pass >> 8;
     lds_barrier();                            // everyone has read the stack
+    // a bucket that needs four passes or more holds little duplication: counting identical records first would only cost
+    const bool use_t1 = fbits < 2u;
     for (uint32_t i = threadIdx.x; i < (uint32_t)T::S2; i += T::NT) { s_tk[i] = kEmptyKey; s_tv[i] = 0; }
-    for (uint32_t i = threadIdx.x; i < (uint32_t)T::S1; i += T::NT) { s_r[i] = make_ulonglong2(kEmptyKey, W1_INIT); s_rc[i] = 0; }
+    if (use_t1) for (uint32_t i = threadIdx.x; i < (uint32_t)T::S1; i += T::NT) { s_r[i] = make_ulonglong2(kEmptyKey, W1_INIT); s_rc[i] = 0; }
     if (threadIdx.x == 0) { s_ctl[0] = 0; s_ctl[1] = 0; s_ctl[2] = 0; s_ctl[3] = 0; s_ctl[5] = sp - 1; s_ctl[8] = 0; }
     lds_barrier();
     // the first three filter bits are the records' sub-bucket bits (whole records are skipped), the others come from the key's hash
     const uint32_t rbits = fbits < 3u ? fbits : 3u, rmask = (1u << rbits) - 1u, rval = fval & rmask;
     const uint32_t hbits = fbits - rbits, hmask = (1u << hbits) - 1u, hval = fval >> rbits;
     uint32_t mn = 0;   // (key, weight) pairs waiting in the miss queue (uniform)
+    uint32_t pending = 0;   // slots this wavefront claimed in line since it last reported to the shared fill counter (uniform)
+    uint32_t my_claims = 0; // ... and this lane in the batch being expanded
     // all k-mers of the batch's records (w0, w1, weight wt; n = 0: none) into the k-mer table
     auto expand = [&](uint64_t w0, uint64_t w1, uint32_t wt, uint32_t n) {
       const uint32_t inc = wave_inclusive_sum_dpp(n);
@@ -558,10 +579,13 @@ __global__ __launch_bounds__(1024) void sk_reduce_kernel(const uint64_t *__restr
         const uint64_t c0 = __atomic_load_n(&s_tk[slot], __ATOMIC_RELAXED), c1 = __atomic_load_n(&s_tk[slot + 1u], __ATOMIC_RELAXED);
         bool hit0 = v && c0 == key;
         const bool hit1 = v && c1 == key;
+        bool won = false;
         if (v && c0 == kEmptyKey) {   // first sighting with a free home slot: claimed here, in line (most first sightings are)
           const unsigned long long old = atomicCAS((unsigned long long *)&s_tk[slot], (unsigned long long)kEmptyKey, (unsigned long long)key);
-          hit0 = old == kEmptyKey || old == key;
+          won = old == kEmptyKey;
+          hit0 = won || old == key;
         }
+        my_claims += won ? 1u : 0u;   // (per lane; the wavefront adds them up once per batch)
         if (hit0 || hit1) atomicAdd(&s_tv[slot + (hit0 ? 0u : 1u)], kw);
         const bool miss = v && !hit0 && !hit1 && dbg != 2;
         const unsigned long long mm = __ballot(miss);
@@ -570,13 +594,21 @@ __global__ __launch_bounds__(1024) void sk_reduce_kernel(const uint64_t *__restr
           if (miss) { mq[pos] = key; mw[pos] = kw; }
           mn += (uint32_t)__popcll(mm);
           if (mn >= (uint32_t)kWave) {
-            sk_probe_insert(tkeys, tvals, tdist, tovf, (const lds_u64_t *)mq, (const lds_u32_t *)mw, mn - kWave, kWave, (uint32_t)T::CAP2,
-                            (uint32_t)T::S2 - 1u, (uint32_t)T::LIMIT2);
+            pending = sk_probe_insert(tkeys, tvals, tdist, tovf, (const lds_u64_t *)mq, (const lds_u32_t *)mw, mn - kWave, kWave, (uint32_t)T::CAP2,
+                                      (uint32_t)T::S2 - 1u, (uint32_t)T::LIMIT2, pending);
             mn -= kWave;
           }
         }
       }
       if (n) wown[pre] = 0;   // the marks go back to zero for the next batch
+      // fill level: this batch's in-line claims go to the shared counter (one scan + one LDS add per batch of records)
+      const uint32_t batch_claims = __builtin_amdgcn_readlane(wave_inclusive_sum_dpp(my_claims), kWave - 1);
+      my_claims = 0;
+      pending += batch_claims;
+      if (pending >= 32u) {   // uniform
+        if (lane == 0 && atomicAdd(&s_ctl[0], pending) + pending >= (uint32_t)T::LIMIT2) s_ctl[1] = 1;
+        pending = 0;
+      }
     };
     // ---- phase A: identical records are counted, what T1 does not take is expanded directly
     {
@@ -594,7 +626,7 @@ __global__ __launch_bounds__(1024) void sk_reduce_kernel(const uint64_t *__restr
         if ((rec_hash18(rec.y) & rmask) != rval) n = 0;
         if (dbg == 3) { if (rec.x == 12345ull) s_ctl[2] = 1; continue; }
         bool direct = n != 0u;   // still to be placed
-        if (direct && rec.x != kEmptyKey && dbg != 4) {
+        if (direct && use_t1 && rec.x != kEmptyKey && dbg != 4) {
           // four consecutive slots in one go (independent reads): the first that holds this record takes the count, else the
           // first empty one is claimed; no loop -- a record that finds neither is expanded directly
           uint32_t h = ((uint32_t)rec.x ^ (uint32_t)(rec.x >> 32)) * 0x9E3779B1u ^ ((uint32_t)rec.y ^ (uint32_t)(rec.y >> 32)) * 0x85EBCA6Bu;
@@ -630,7 +662,7 @@ __global__ __launch_bounds__(1024) void sk_reduce_kernel(const uint64_t *__restr
     lds_barrier();   // T1 complete
     if (dbg == 6 && threadIdx.x == 0) atomicAdd(&flags[12], s_ctl[8]);
     // ---- phase B: every distinct record once, with its multiplicity
-    for (uint32_t s0 = wv * kWave; s0 < (uint32_t)T::S1; s0 += T::NT) {
+    for (uint32_t s0 = wv * kWave; use_t1 && s0 < (uint32_t)T::S1; s0 += T::NT) {
       if (__atomic_load_n(&s_ctl[1], __ATOMIC_RELAXED)) break;
       const uint32_t s = s0 + lane;
       const ulonglong2 ent = s_r[s];
@@ -640,19 +672,31 @@ __global__ __launch_bounds__(1024) void sk_reduce_kernel(const uint64_t *__restr
       if (__any(n != 0u)) expand(w0, w1, wt, n);
     }
     if (mn) {
-      sk_probe_insert(tkeys, tvals, tdist, tovf, (const lds_u64_t *)mq, (const lds_u32_t *)mw, 0u, mn, (uint32_t)T::CAP2, (uint32_t)T::S2 - 1u,
-                      (uint32_t)T::LIMIT2);
+      pending = sk_probe_insert(tkeys, tvals, tdist, tovf, (const lds_u64_t *)mq, (const lds_u32_t *)mw, 0u, mn, (uint32_t)T::CAP2, (uint32_t)T::S2 - 1u,
+                                (uint32_t)T::LIMIT2, pending);
       mn = 0;
     }
+    if (pending && lane == 0 && atomicAdd(&s_ctl[0], pending) + pending >= (uint32_t)T::LIMIT2) s_ctl[1] = 1;
     lds_barrier();
-    if (s_ctl[1]) {   // overflow: this pass splits in two (one more filter bit)
+    if (s_ctl[1]) {
+      // Overflow: this pass is split. How far is a property of the input (distinct k-mers per bucket), about the same for most
+      // buckets: flags[16 + L] counts the buckets that finished with L filter bits, and the split goes straight to the level
+      // most of them ended at (2^L passes, no further lost ones) instead of one bit at a time. Buckets that never overflow --
+      // all of them at sequencing coverage -- never look at these words; only the pass structure depends on them.
       if (threadIdx.x == 0) {
         if (fbits >= 18u) atomicOr(&flags[2], 1u);   // 3 record bits + 15 hash bits: 2^18 tables did not hold the bucket
         else {
-          const uint32_t spn = s_ctl[5];
-          s_stack[spn] = (fbits + 1u) | (fval << 8);
-          s_stack[spn + 1] = (fbits + 1u) | ((fval | (1u << fbits)) << 8);
-          s_ctl[5] = spn + 2u;
+          uint32_t best = 0, best_n = 0;
+          for (uint32_t l = 0; l <= 8u; ++l) {
+            const uint32_t c = __hip_atomic_load(&flags[16 + l], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (c > best_n) { best_n = c; best = l; }
+          }
+          uint32_t target = best > fbits ? best : fbits + 1u;
+          if (target > fbits + 6u) target = fbits + 6u;     // (64 children at most at a time: the stack holds 320)
+          uint32_t spn = s_ctl[5];
+          for (uint32_t v = 0; v < (1u << (target - fbits)); ++v) s_stack[spn++] = target | ((fval | (v << fbits)) << 8);
+          s_ctl[5] = spn;
+          if (target > s_ctl[9]) s_ctl[9] = target;
         }
       }
       lds_barrier();
@@ -675,7 +719,10 @@ __global__ __launch_bounds__(1024) void sk_reduce_kernel(const uint64_t *__restr
     }
     lds_barrier();
   }
-  if (threadIdx.x == 0) out_cnt[b] = s_ctl[4];
+  if (threadIdx.x == 0) {
+    out_cnt[b] = s_ctl[4];
+    if (s_ctl[9] || start_bits) atomicAdd(&flags[16 + (s_ctl[9] > 8u ? 8u : s_ctl[9])], 1u);   // (level 0 is only recorded when someone could be misled)
+  }
 }
 
 }  // namespace kmi
