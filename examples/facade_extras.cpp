@@ -38,6 +38,18 @@ int main(int argc, char **argv) {
     unsigned long long sum = 0, n = 0;
     for (auto it = cidx.cbegin(); it != cidx.cend(); ++it) { sum += it->second; ++n; }   // the map walked through its iterators
     std::printf("weighted entries %llu sum %llu occurrences %zu\n", n, sum, tuples.size());
+    {
+      // update (distributed_densehash_map.hpp:1975-2030): pairs of stored keys add their value and report 1, unknown keys are skipped
+      std::vector<std::pair<KmerType, uint32_t>> upd;
+      for (size_t i = 0; i < tuples.size(); i += 11) upd.push_back(std::make_pair(tuples[i].first, 5u));
+      upd.push_back(std::make_pair(KmerType(), 7u));   // AAAA...A: not in these reads
+      const size_t hit = cidx.update(upd, false, [](uint32_t &stored, uint32_t const &v) { stored += v; return 1; });
+      // filter form: every entry with a count of at least 20 is halved
+      const size_t halved = cidx.update([](const std::pair<KmerType, uint32_t> &e) { return e.second >= 20; }, [](uint32_t &stored) { stored /= 2; return 1; });
+      unsigned long long s2 = 0;
+      for (auto &e : cidx.to_vector()) s2 += e.second;
+      std::printf("update hit %zu halved %zu sum %llu entries %zu\n", hit, halved, s2, cidx.local_size());
+    }
     auto &view = cidx.get_map();
     std::printf("get_map local_size %zu size %zu\n", view.local_size(), view.size());
     // ---- PositionQualityIndex: (k-mer, (id, quality)) tuples through read_file + insert, then find

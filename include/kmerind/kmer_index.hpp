@@ -484,6 +484,49 @@ class Index {
     erase_entries(all, pred);
   }
 
+  // update() of the densehash maps (distributed_densehash_map.hpp:1975-2030 -> densehash_map.hpp:663-736): for every input
+  // pair whose (transformed) key is stored, `count += op(stored_value, input_value)`, op changing the stored value in
+  // place; keys that are not stored are skipped. The filter form visits every stored entry fop accepts with
+  // `count += op(stored_value)`. Updater and Filter are host functors, so -- like the predicate forms -- they run on
+  // the host over the entries the device returns; the changed values go back as (key, value) pairs. Counting maps, one rank.
+  template <typename Updater> size_t update(std::vector<TupleType> &input, bool /*sorted_input*/, Updater const &op) {
+    static_assert(MapType::index_kind == KMI_INDEX_COUNT, "update() is a member of the counting / reduction maps");
+    if (comm.size() > 1) throw std::invalid_argument("update with size() > 1 is not wired through the exchange");
+    if (input.empty() || local_size() == 0) return 0;
+    constexpr unsigned nw = KmerType::nWords;
+    std::vector<KmerType> keys(input.size());
+    for (size_t i = 0; i < input.size(); ++i) keys[i] = input[i].first;
+    std::vector<TupleType> found = find(keys);
+    std::map<KmerType, ValueType> cur;
+    for (const TupleType &e : found) cur[e.first] = e.second;
+    std::vector<uint64_t> t(input.size() * nw);   // the keys as the map stores them
+    if (cfg.strand == KMI_STRAND_SINGLE) std::memcpy(t.data(), detail::words_of(keys), t.size() * sizeof(uint64_t));
+    else ::kmerind::check(ctx, kmi_canonical_host(ctx, &cfg, detail::words_of(keys), keys.size(), t.data()));
+    size_t count = 0;
+    std::map<KmerType, bool> touched;
+    for (size_t i = 0; i < input.size(); ++i) {
+      auto it = cur.find(KmerType(&t[i * nw]));
+      if (it == cur.end()) continue;
+      count += (size_t)op(it->second, input[i].second);
+      touched[it->first] = true;
+    }
+    write_back(cur, touched);
+    return count;
+  }
+  template <typename Filter, typename Updater> size_t update(Filter const &fop, Updater const &op) {
+    static_assert(MapType::index_kind == KMI_INDEX_COUNT, "update() is a member of the counting / reduction maps");
+    std::map<KmerType, ValueType> cur;
+    std::map<KmerType, bool> touched;
+    size_t count = 0;
+    for (TupleType &e : to_vector()) {
+      if (!fop(e)) continue;
+      count += (size_t)op(e.second);
+      cur[e.first] = e.second; touched[e.first] = true;
+    }
+    write_back(cur, touched);
+    return count;
+  }
+
   size_t local_size() const { uint64_t n = 0; ::kmerind::check(ctx, kmi_index_local_size(idx, &n)); return (size_t)n; }
   size_t size() const {
     if (rccl) { uint64_t n = 0; ::kmerind::check(ctx, kmi_index_size_dist(idx, rccl, &n)); return (size_t)n; }
@@ -636,6 +679,22 @@ class Index {
     if (comm.size() == 1) { ::kmerind::check(ctx, kmi_index_insert_tuples_host(idx, w.data(), vals.data(), temp.size())); return; }
     need_rccl("multimap insert");
     ::kmerind::check(ctx, kmi_index_insert_tuples_dist_host(idx, rccl, w.data(), vals.data(), temp.size()));
+  }
+  // the touched entries leave the map and come back with their new values (stored keys: no second transform needed)
+  void write_back(const std::map<KmerType, ValueType> &cur, const std::map<KmerType, bool> &touched) {
+    if (touched.empty()) return;
+    constexpr unsigned nw = KmerType::nWords;
+    std::vector<KmerType> keys;
+    std::vector<uint64_t> rec;
+    for (auto &kv : touched) {
+      keys.push_back(kv.first);
+      const uint64_t *w = kv.first.getData();
+      rec.insert(rec.end(), w, w + nw);
+      rec.push_back((uint64_t)cur.at(kv.first) & 0xffffffffull);
+    }
+    uint64_t n = 0;
+    ::kmerind::check(ctx, kmi_index_erase_host(idx, detail::words_of(keys), keys.size(), &n));
+    ::kmerind::check(ctx, kmi_index_insert_pairs_host(idx, rec.data(), keys.size()));
   }
   void need_rccl(const char *what) const {
     if (!rccl) throw std::invalid_argument(std::string(what) + " with size() > 1 needs the RCCL communicator (comm.unique_id)");

@@ -219,6 +219,16 @@ def test_weighted_insert_iterators_and_posqual_through_the_facade():
     cm.insert(ex["kmers"])
     n = ex["kmers"].shape[0]
     assert grab(r"weighted entries (\d+) sum (\d+) occurrences (\d+)") == (cm.size(), 4 * n, n)
+    # update(): every 11th occurrence adds 5 to its key's count (one hit per such pair, the all-A k-mer is not stored and is
+    # skipped), then entries with a count >= 20 are halved
+    keys, cnt = cm.export()
+    val = {tuple(kk): 4 * int(c) for kk, c in zip(keys.tolist(), cnt.tolist())}
+    canon = orc.canonical(s, ex["kmers"])
+    for kk in canon[::11].tolist():
+        val[tuple(kk)] += 5
+    halved = sum(1 for v in val.values() if v >= 20)
+    val = {kk: (v // 2 if v >= 20 else v) for kk, v in val.items()}
+    assert grab(r"update hit (\d+) halved (\d+) sum (\d+) entries (\d+)") == (len(canon[::11]), halved, sum(val.values()), cm.size())
     assert grab(r"get_map local_size (\d+) size (\d+)") == (cm.size(), cm.size())
     vals = np.stack([ex["ids"], ex["quals"].view(np.uint32).astype(np.uint64)], axis=1)
     mm = orc.MultiMap(s, orc.CANONICAL, vw=2)
