@@ -2582,8 +2582,12 @@ static kmi_status build_superkmer_w(kmi_index *idx, const FastqScan &sc, bool *d
   KMI_TRY(ws_get(ctx, WS_KEYS_B, (R + 64) * 16, &p)); uint64_t *rec_b = (uint64_t *)p;
   {
     ProfScope ps(ctx, "sk_scatter", n);
-    hipLaunchKernelGGL(sk_scatter_kernel, dim3(kPartGroups), dim3(kSkThreads), 0, ctx->stream, in, n_tiles, k, (const uint32_t *)ent,
-                       (const uint32_t *)ent_cnt, stride, ipt, (const uint32_t *)items, (const uint32_t *)run_items, (const uint64_t *)wg_off, rec_a);
+    if (canonical)
+      hipLaunchKernelGGL(sk_scatter_kernel<true>, dim3(kPartGroups), dim3(kSkThreads), 0, ctx->stream, in, n_tiles, k, (const uint32_t *)ent,
+                         (const uint32_t *)ent_cnt, stride, ipt, (const uint32_t *)items, (const uint32_t *)run_items, (const uint64_t *)wg_off, rec_a);
+    else
+      hipLaunchKernelGGL(sk_scatter_kernel<false>, dim3(kPartGroups), dim3(kSkThreads), 0, ctx->stream, in, n_tiles, k, (const uint32_t *)ent,
+                         (const uint32_t *)ent_cnt, stride, ipt, (const uint32_t *)items, (const uint32_t *)run_items, (const uint64_t *)wg_off, rec_a);
   }
   KMI_TRY(ws_get(ctx, WS_SPLIT_OFF, sizeof(uint32_t) * kNumFine * kFineParts + sizeof(uint64_t) * ((kNumFine + 1) + kNumFine * kFineParts + kNumCoarse) + 256, &p));
   uint32_t *fine_kmers = (uint32_t *)p;

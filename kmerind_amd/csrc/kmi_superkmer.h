@@ -265,6 +265,11 @@ __device__ __forceinline__ void sk_assemble(const uint32_t *__restrict__ st, uin
 }
 
 // the same from a run's row of stream words in LDS: bit position `bit` of the row
+// CANON (canonical strand model): of the super-k-mer and its reverse complement the smaller bit pattern is kept. The two
+// strands' reads of a stretch of genome cut it into mirror-image super-k-mers (same minimizers, same boundaries); their
+// k-mers are the same canonical k-mers, so which mirror image travels does not matter to the count -- but with ONE form the
+// reduce finds the copies of both strands identical and expands them once (sk_reduce, T1).
+template <bool CANON>
 __device__ __forceinline__ void sk_assemble_row(const uint32_t *row, uint32_t bit, uint32_t nb, uint32_t n1, uint32_t h18, uint64_t &w0, uint64_t &w1) {
   const uint32_t d = bit >> 5, sh = bit & 31u;
   const uint32_t r0 = row[d], r1 = row[d + 1], r2 = row[d + 2], r3 = row[d + 3], r4 = row[d + 4];
@@ -275,11 +280,26 @@ __device__ __forceinline__ void sk_assemble_row(const uint32_t *row, uint32_t bi
   const uint32_t bits = 2u * nb;   // 34 .. 102
   if (bits < 64u) { w0 &= (1ull << bits) - 1ull; hi = 0; }
   else hi &= (1ull << (bits - 64u)) - 1ull;
+  if (CANON) {
+    // reverse complement of nb bases held as complement codes, base i at bits 2 i: reverse all 128 bits (the two bits of a
+    // base change places: swap them back), complement, and bring the nb bases down from the top
+    uint64_t r_hi = __builtin_bitreverse64(w0), r_lo = __builtin_bitreverse64(hi);
+    r_hi = ~(((r_hi >> 1) & 0x5555555555555555ull) | ((r_hi & 0x5555555555555555ull) << 1));
+    r_lo = ~(((r_lo >> 1) & 0x5555555555555555ull) | ((r_lo & 0x5555555555555555ull) << 1));
+    const uint32_t sh = 128u - bits;   // 26 .. 94
+    uint64_t c_lo, c_hi;
+    if (sh < 64u) { c_lo = (r_lo >> sh) | (r_hi << (64u - sh)); c_hi = r_hi >> sh; }
+    else { c_lo = r_hi >> (sh - 64u); c_hi = 0; }
+    const bool take = c_hi < hi || (c_hi == hi && c_lo < w0);
+    w0 = take ? c_lo : w0;
+    hi = take ? c_hi : hi;
+  }
   w1 = hi | ((uint64_t)n1 << kRecNShift) | ((uint64_t)h18 << kRecHashShift);
 }
 
 constexpr int kSkRowDw = 17;   // stream words of a run kept in LDS: up to 63 bases of alignment + 128 + 31 bases = 444 bits in 16 words (odd stride: rows on different banks)
 
+template <bool CANON>
 __global__ __launch_bounds__(kSkThreads, 2) void sk_scatter_kernel(PackedInput in, uint64_t n_tiles, uint32_t k, const uint32_t *__restrict__ ent,
                                                                   const uint32_t *__restrict__ ent_cnt, uint32_t ent_stride, uint32_t items_per_tile,
                                                                   const uint32_t *__restrict__ items, const uint32_t *__restrict__ run_items,
@@ -366,7 +386,7 @@ __global__ __launch_bounds__(kSkThreads, 2) void sk_scatter_kernel(PackedInput i
       const uint32_t item = wg_items[s_ioff[rl] + j];
       const uint32_t h18 = item >> 12, n1 = (item >> 7) & 31u;
       uint64_t w0, w1;
-      sk_assemble_row(s_row + rl * kSkRowDw, s_bit0[rl] + 2u * (item & 127u), k + n1, n1, h18, w0, w1);
+      sk_assemble_row<CANON>(s_row + rl * kSkRowDw, s_bit0[rl] + 2u * (item & 127u), k + n1, n1, h18, w0, w1);
       reinterpret_cast<ulonglong2 *>(out)[s_gbase[h18 >> 10] + s] = make_ulonglong2(w0, w1);
     }
     SkRound nxt;
@@ -628,27 +648,35 @@ __global__ __launch_bounds__(1024) void sk_reduce_kernel(const uint64_t *__restr
         bool direct = n != 0u;   // still to be placed
         if (direct && use_t1 && rec.x != kEmptyKey && dbg != 4) {
           // four consecutive slots in one go (independent reads): the first that holds this record takes the count, else the
-          // first empty one is claimed; no loop -- a record that finds neither is expanded directly
+          // first empty one is claimed; a record that finds neither in two such windows is expanded directly
           uint32_t h = ((uint32_t)rec.x ^ (uint32_t)(rec.x >> 32)) * 0x9E3779B1u ^ ((uint32_t)rec.y ^ (uint32_t)(rec.y >> 32)) * 0x85EBCA6Bu;
           h ^= h >> 15;
-          const uint32_t s = h >> 21;   // 2048 home slots (+ 64 of padding)
-          ulonglong2 e[4];
+          const uint32_t s0 = h >> 21;   // 2048 home slots (+ 64 of padding)
+          for (uint32_t s = s0; direct && s < s0 + 8u; s += 4u) {   // (a second window of four for the few that find the first one taken)
+            ulonglong2 e[4];
 #pragma unroll
-          for (int i = 0; i < 4; ++i) e[i] = s_r[s + i];
-          int hit = -1, free_ = -1;
+            for (int i = 0; i < 4; ++i) e[i] = s_r[s + i];
+            int hit = -1, free_ = -1;
 #pragma unroll
-          for (int i = 3; i >= 0; --i) {
-            const bool same = e[i].x == rec.x && e[i].y == rec.y, empty = e[i].x == kEmptyKey;
-            if (same) { hit = i; free_ = -1; } else if (empty) { free_ = i; hit = -1; }   // (the earliest of either kind wins)
-          }
-          if (hit >= 0) { atomicAdd(&s_rc[s + hit], 1u); direct = false; }
-          else if (free_ >= 0 && __atomic_load_n(&s_ctl[8], __ATOMIC_RELAXED) < (uint32_t)T::L1) {
-            const unsigned long long old = atomicCAS((unsigned long long *)&s_r[s + free_].x, (unsigned long long)kEmptyKey, (unsigned long long)rec.x);
-            if (old == kEmptyKey) {   // claimed
-              __atomic_store_n(&s_r[s + free_].y, rec.y, __ATOMIC_RELAXED);
-              atomicAdd(&s_rc[s + free_], 1u);
-              atomicAdd(&s_ctl[8], 1u);
-              direct = false;
+            for (int i = 3; i >= 0; --i) {
+              const bool same = e[i].x == rec.x && e[i].y == rec.y, empty = e[i].x == kEmptyKey;
+              if (same) { hit = i; free_ = -1; } else if (empty) { free_ = i; hit = -1; }   // (the earliest of either kind wins)
+            }
+            if (hit >= 0) { atomicAdd(&s_rc[s + hit], 1u); direct = false; }
+            else if (free_ >= 0) {
+              if (__atomic_load_n(&s_ctl[8], __ATOMIC_RELAXED) >= (uint32_t)T::L1) break;   // full enough: the rest goes direct
+              const unsigned long long old = atomicCAS((unsigned long long *)&s_r[s + free_].x, (unsigned long long)kEmptyKey, (unsigned long long)rec.x);
+              if (old == kEmptyKey) {   // claimed
+                __atomic_store_n(&s_r[s + free_].y, rec.y, __ATOMIC_RELAXED);
+                atomicAdd(&s_rc[s + free_], 1u);
+                atomicAdd(&s_ctl[8], 1u);
+                direct = false;
+              } else if (old == rec.x && __atomic_load_n(&s_r[s + free_].y, __ATOMIC_RELAXED) == rec.y) {
+                // lost the slot to a copy of the same record that arrived in the same step (copies travel together: the usual
+                // way to lose): its second word is there by now, so this copy is counted with it
+                atomicAdd(&s_rc[s + free_], 1u);
+                direct = false;
+              } else break;   // lost it to another record: direct
             }
           }
         }
