@@ -315,6 +315,53 @@ kmi_status kmi_index_find_dist_host(kmi_index *idx, kmi_comm *comm, const uint64
 kmi_status kmi_index_erase_dist_host(kmi_index *idx, kmi_comm *comm, const uint64_t *queries, size_t nq, uint64_t *n_erased_local);
 kmi_status kmi_index_size_dist(kmi_index *idx, kmi_comm *comm, uint64_t *n);
 
+/* ---- de Bruijn graph nodes ------------------------------------------------------
+ * The reference's in-tree consumer of Index: de_bruijn_engine<NodeMap> = Index<NodeMap, de_bruijn_parser>
+ * (test/test/debruijn/de_bruijn_construct_engine.hpp:241-245) with NodeMap = de_bruijn_nodes_distributed<Kmer,
+ * node::edge_counts<DNA16, int32_t> | node::edge_exists<DNA16>, BimoleculeHashMapParams>
+ * (de_bruijn_nodes_distributed.hpp:57-265, de_bruijn_node_trait.hpp:139-336), as
+ * test/test/test_de_bruijn_graph_construction.cpp:124-137,195-206 instantiates it.
+ * A node = (k-mer, counts[9]): counts[0..3] = out edges A C G T (the base right of the k-mer in a read),
+ * counts[4..7] = in edges A C G T (the base left of it), counts[8] = occurrences of the k-mer. Edge bytes are DNA16
+ * presence bits (in << 4 | out), so an 'N' neighbour counts for all four. EDGE_EXISTS keeps 0 / 1 per edge and no
+ * occurrence count (counts[8] = 0).
+ * Orientation: the reference keeps a node under whichever strand reached the map first (an order MPI decides); this
+ * library keeps the lexicographically smaller strand and turns the edges with it (reverse_complement_edges,
+ * de_bruijn_node_trait.hpp:122-124). The node set is the same, and so is every node up to that flip.
+ * Input is FASTQ without a sequence filter (what the engine is instantiated with, :96,195); kmi_config.strand,
+ * index_kind and dist_trans are not consulted. erase is not provided. */
+typedef struct kmi_dbg kmi_dbg;
+enum { KMI_DBG_EDGE_COUNTS = 0, KMI_DBG_EDGE_EXISTS = 1 };
+#define KMI_DBG_VALUE_WORDS 5 /* a node value in kmi_results.values: uint32_t counts[9] + one uint32_t of padding */
+kmi_status kmi_dbg_create(kmi_ctx *ctx, const kmi_config *cfg, uint32_t node_kind, kmi_dbg **out);   /* NodeMap(comm) */
+kmi_status kmi_dbg_destroy(kmi_dbg *g);
+kmi_status kmi_dbg_clear(kmi_dbg *g);
+kmi_status kmi_dbg_local_size(kmi_dbg *g, uint64_t *n);                                               /* local_size() */
+/* de_bruijn_parser::operator() over every record of a FASTQ buffer (de_bruijn_construct_engine.hpp:109-157):
+ * records of n_words + 1 words, the k-mer as parsed and the edge byte (edge_iterator.hpp:163-177) in the low
+ * byte of the last word. out_records_dev == NULL: count only. */
+kmi_status kmi_dbg_parse_dev(kmi_ctx *ctx, const kmi_config *cfg, const uint8_t *bytes_dev, size_t n_bytes,
+                             uint64_t *out_records_dev, size_t out_capacity, uint64_t *n_tuples);
+/* build_posix / build_mmap<FASTQParser> on one rank (kmer_index.hpp:239-372 with the parser above): parse + insert */
+kmi_status kmi_dbg_build_dev(kmi_dbg *g, const uint8_t *bytes_dev, size_t n_bytes);
+kmi_status kmi_dbg_build_host(kmi_dbg *g, const uint8_t *bytes, size_t n_bytes);
+/* insert(std::vector<std::pair<Kmer, uint8_t>>&) (de_bruijn_nodes_distributed.hpp:230-264, local_insert :91-159):
+ * records as kmi_dbg_parse_dev emits them, either strand */
+kmi_status kmi_dbg_insert_dev(kmi_dbg *g, const uint64_t *records_dev, size_t n);
+kmi_status kmi_dbg_insert_host(kmi_dbg *g, const uint64_t *records, size_t n);
+/* find(): one (stored k-mer, node) per distinct query key that is a node, KMI_DBG_VALUE_WORDS words per value;
+ * a query matches under either strand. count(): 0 / 1 per distinct query key (values: one word each). */
+kmi_status kmi_dbg_find_host(kmi_dbg *g, const uint64_t *queries, size_t nq, kmi_results *out);
+kmi_status kmi_dbg_find_dev(kmi_dbg *g, const uint64_t *queries_dev, size_t nq, uint64_t *out_keys_dev, uint64_t *out_values_dev,
+                            uint64_t *n_out);
+kmi_status kmi_dbg_count_host(kmi_dbg *g, const uint64_t *queries, size_t nq, kmi_results *out);
+/* the local nodes: keys[n * n_words], counts9[n * 9] (either may be NULL) */
+kmi_status kmi_dbg_export_host(kmi_dbg *g, uint64_t *keys, uint32_t *counts9, size_t capacity, uint64_t *n);
+/* over the ranks of a communicator: every rank parses its record-aligned share, the tuples travel to the rank
+ * KeyToRank gives their canonical k-mer (the distribute step of insert, de_bruijn_nodes_distributed.hpp:243-250) */
+kmi_status kmi_dbg_build_dist_host(kmi_dbg *g, kmi_comm *comm, const uint8_t *bytes, size_t n_bytes);
+kmi_status kmi_dbg_size_dist(kmi_dbg *g, kmi_comm *comm, uint64_t *n);                                /* size() */
+
 /* ---- measurement support --------------------------------------------------- */
 /* per-kernel HIP-event timing on the context's stream (bench.py roofline leg) */
 kmi_status kmi_profile_enable(kmi_ctx *ctx, int on);

@@ -122,6 +122,21 @@ SIGNATURES = {
     "kmi_index_find_dist_host": (C.c_int, [_P, _P, _P, _sz, C.POINTER(Results)]),
     "kmi_index_erase_dist_host": (C.c_int, [_P, _P, _P, _sz, C.POINTER(_u64)]),
     "kmi_index_size_dist": (C.c_int, [_P, _P, C.POINTER(_u64)]),
+    "kmi_dbg_create": (C.c_int, [_P, _CFG, _u32, C.POINTER(_P)]),
+    "kmi_dbg_destroy": (C.c_int, [_P]),
+    "kmi_dbg_clear": (C.c_int, [_P]),
+    "kmi_dbg_local_size": (C.c_int, [_P, C.POINTER(_u64)]),
+    "kmi_dbg_parse_dev": (C.c_int, [_P, _CFG, _P, _sz, _P, _sz, C.POINTER(_u64)]),
+    "kmi_dbg_build_dev": (C.c_int, [_P, _P, _sz]),
+    "kmi_dbg_build_host": (C.c_int, [_P, _P, _sz]),
+    "kmi_dbg_insert_dev": (C.c_int, [_P, _P, _sz]),
+    "kmi_dbg_insert_host": (C.c_int, [_P, _P, _sz]),
+    "kmi_dbg_find_host": (C.c_int, [_P, _P, _sz, C.POINTER(Results)]),
+    "kmi_dbg_find_dev": (C.c_int, [_P, _P, _sz, _P, _P, C.POINTER(_u64)]),
+    "kmi_dbg_count_host": (C.c_int, [_P, _P, _sz, C.POINTER(Results)]),
+    "kmi_dbg_export_host": (C.c_int, [_P, _P, _P, _sz, C.POINTER(_u64)]),
+    "kmi_dbg_build_dist_host": (C.c_int, [_P, _P, _P, _sz]),
+    "kmi_dbg_size_dist": (C.c_int, [_P, _P, C.POINTER(_u64)]),
     "kmi_profile_enable": (C.c_int, [_P, C.c_int]),
     "kmi_profile_reset": (C.c_int, [_P]),
     "kmi_profile_get": (C.c_int, [_P, C.POINTER(KernelTime), _sz, C.POINTER(_sz)]),

@@ -334,6 +334,107 @@ class PositionIndex(CountIndex):
         return keys, vals[:, 0]
 
 
+class DeBruijnNodes:
+    """de_bruijn_engine<NodeMap> on one rank (test/test/debruijn/de_bruijn_construct_engine.hpp:241-245): nodes =
+    (k-mer, [out A C G T, in A C G T, occurrences]); exists_only = node::edge_exists (0 / 1 per edge, no occurrence count).
+    Every node is kept under its lexicographically smaller strand (include/kmerind_hip.h)."""
+
+    def __init__(self, ctx, cfg, exists_only=False):
+        self.ctx, self.cfg = ctx, cfg
+        self.n_words = ctx.shape(cfg)[0]
+        h = C.c_void_p()
+        ctx.check(lib.kmi_dbg_create(ctx.h, C.byref(cfg), 1 if exists_only else 0, C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib.kmi_dbg_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def parse(self, data):
+        """de_bruijn_parser over a FASTQ buffer -> (k-mers as parsed, edge bytes)"""
+        buf = np.frombuffer(bytes(data), dtype=np.uint8) if isinstance(data, (bytes, bytearray)) else np.ascontiguousarray(data, dtype=np.uint8)
+        d = self.ctx.alloc(buf.size + 64)
+        try:
+            self.ctx.to_device(d, buf)
+            n = C.c_uint64()
+            self.ctx.check(lib.kmi_dbg_parse_dev(self.ctx.h, C.byref(self.cfg), C.c_void_p(d), buf.size, None, 0, C.byref(n)))
+            rec = np.zeros((n.value, self.n_words + 1), dtype=np.uint64)
+            if n.value:
+                dr = self.ctx.alloc(rec.nbytes)
+                try:
+                    self.ctx.check(lib.kmi_dbg_parse_dev(self.ctx.h, C.byref(self.cfg), C.c_void_p(d), buf.size, C.c_void_p(dr), n.value, C.byref(n)))
+                    self.ctx.to_host(rec, dr)
+                finally:
+                    self.ctx.free(dr)
+        finally:
+            self.ctx.free(d)
+        return rec[:, :self.n_words].copy(), rec[:, self.n_words].astype(np.uint8)
+
+    def build(self, data):
+        buf = np.frombuffer(bytes(data), dtype=np.uint8) if isinstance(data, (bytes, bytearray)) else np.ascontiguousarray(data, dtype=np.uint8)
+        self.ctx.check(lib.kmi_dbg_build_host(self.h, buf.ctypes.data_as(C.c_void_p), buf.size))
+
+    def build_device(self, dptr, nbytes):
+        self.ctx.check(lib.kmi_dbg_build_dev(self.h, C.c_void_p(dptr), nbytes))
+
+    def insert(self, kmers, edges):
+        """insert(vector<pair<Kmer, uint8_t>>): tuples as the parser emits them, either strand"""
+        kmers = _u64(kmers, self.n_words)
+        rec = np.zeros((kmers.shape[0], self.n_words + 1), dtype=np.uint64)
+        rec[:, :self.n_words] = kmers
+        rec[:, self.n_words] = np.asarray(edges, dtype=np.uint64) & np.uint64(0xFF)
+        self.ctx.check(lib.kmi_dbg_insert_host(self.h, rec.ctypes.data_as(C.c_void_p), rec.shape[0]))
+
+    def clear(self):
+        self.ctx.check(lib.kmi_dbg_clear(self.h))
+
+    def local_size(self):
+        n = C.c_uint64()
+        self.ctx.check(lib.kmi_dbg_local_size(self.h, C.byref(n)))
+        return n.value
+
+    size = local_size
+
+    def to_vector(self):
+        n = self.local_size()
+        keys = np.zeros((n, self.n_words), dtype=np.uint64)
+        counts = np.zeros((n, 9), dtype=np.uint32)
+        got = C.c_uint64()
+        self.ctx.check(lib.kmi_dbg_export_host(self.h, keys.ctypes.data_as(C.c_void_p), counts.ctypes.data_as(C.c_void_p), n, C.byref(got)))
+        return keys[:got.value], counts[:got.value]
+
+    def find(self, q):
+        q = _u64(q, self.n_words)
+        r = L.Results()
+        self.ctx.check(lib.kmi_dbg_find_host(self.h, q.ctypes.data_as(C.c_void_p), q.shape[0], C.byref(r)))
+        n = r.n
+        if n:
+            keys = np.ctypeslib.as_array(r.keys, shape=(n * self.n_words,)).copy().reshape(n, self.n_words)
+            vals = np.ctypeslib.as_array(r.values, shape=(n * 5,)).copy().view(np.uint32).reshape(n, 10)[:, :9].copy()
+        else:
+            keys = np.zeros((0, self.n_words), dtype=np.uint64)
+            vals = np.zeros((0, 9), dtype=np.uint32)
+        lib.kmi_results_free(C.byref(r))
+        return keys, vals
+
+    def count(self, q):
+        q = _u64(q, self.n_words)
+        r = L.Results()
+        self.ctx.check(lib.kmi_dbg_count_host(self.h, q.ctypes.data_as(C.c_void_p), q.shape[0], C.byref(r)))
+        n = r.n
+        keys = np.ctypeslib.as_array(r.keys, shape=(n * self.n_words,)).copy().reshape(n, self.n_words) if n else np.zeros((0, self.n_words), np.uint64)
+        vals = np.ctypeslib.as_array(r.values, shape=(n,)).copy() if n else np.zeros(0, np.uint64)
+        lib.kmi_results_free(C.byref(r))
+        return keys, vals
+
+
 def synth_fastq(seed, genome_len, n_reads, read_len=150, first_read=0, threads=None):
     """SURVEY.md 8(d) synthetic FASTQ as a numpy uint8 array (host)."""
     nbytes = lib.kmi_synth_fastq_bytes(n_reads, read_len)

@@ -1,0 +1,275 @@
+// De Bruijn graph nodes: the reference's in-tree consumer of Index (test/test/debruijn/, driven by
+// test/test/test_de_bruijn_graph_construction.cpp:96-133) on the same extract -> partition -> reduce kernels.
+//
+//   de_bruijn_parser (de_bruijn_construct_engine.hpp:90-158)     -> dbg_edges_kernel over the position tuples of the extract pass
+//   de_bruijn_nodes_distributed::local_insert (..._distributed.hpp:91-159) with
+//   node::edge_counts<DNA16, int32_t> / node::edge_exists<DNA16> (de_bruijn_node_trait.hpp:139-336)
+//                                                                -> weighted count insert of (k-mer, 1 | edge << 32) records
+//                                                                   + dbg_accumulate_kernel per fine bucket
+//
+// A node is (k-mer, [out A C G T, in A C G T, occurrences]). The reference finds a node under either strand and keeps the
+// strand that reached the map first (BimoleculeHashMapParams, kmer_index.hpp:468-481) -- an order that depends on how
+// MPI delivered the tuples; here every node is kept in the orientation of its lexicographically smaller strand (the edge byte
+// of a k-mer that is stored reverse-complemented goes through reverse_complement_edges, de_bruijn_node_trait.hpp:122-124, as
+// the reference does for an ANTI_SENSE insert). The node SET and, per node up to that orientation, the counts are the same.
+//
+// Included by kmi_index.hip (it uses the table, partition and insert machinery of that translation unit).
+#pragma once
+
+namespace kmi {
+
+constexpr uint32_t kDbgValueWords = 5;   // a node's value as 64-bit words: uint32_t counts[9] + one word of padding
+
+// The value word of a parsed tuple -> the edge byte of its k-mer.
+//   from_ids: the word holds the ShortSequenceKmerId of the extract pass (record offset << 16 | offset of the k-mer's first
+//             base, file_offset 0): the bases around the k-mer are bytes[pos - 1] and bytes[pos + k] of the FASTQ sequence line
+//             (edge_iterator.hpp:163-177: DNA16 code of the left base << 4 | code of the right base, 0 where the read ends).
+//             Otherwise the word already holds the edge byte (insert of caller-made tuples).
+//   node_form: the key becomes the smaller of the k-mer and its reverse complement (the edge byte follows it) and the value word
+//             1 | edge << 32: weight 1 for the count insert, the edge byte above it for the accumulate pass.
+//             Otherwise the tuple stays as parsed and the word is the edge byte (what de_bruijn_parser emits).
+template <int NW, int BITS>
+__global__ __launch_bounds__(256) void dbg_edges_kernel(uint64_t *__restrict__ recs, uint64_t n, const uint8_t *__restrict__ bytes,
+                                                       uint64_t n_bytes, KShape shape, bool from_ids, bool node_form) {
+  constexpr int RW = NW + 1;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    uint64_t key[NW];
+#pragma unroll
+    for (int w = 0; w < NW; ++w) key[w] = recs[i * RW + w];
+    const uint64_t v = recs[i * RW + NW];
+    uint32_t e;
+    if (from_ids) {
+      const uint64_t pos = (v >> 16) + (v & 0xFFFFull);
+      const uint32_t lc = pos > 0 ? bytes[pos - 1] : (uint32_t)'\n';
+      const uint32_t rc = pos + shape.k < n_bytes ? bytes[pos + shape.k] : (uint32_t)'\n';
+      e = ((is_eol(lc) ? 0u : code_dna16(lc)) << 4) | (is_eol(rc) ? 0u : code_dna16(rc));
+    } else {
+      e = (uint32_t)v & 0xFFu;
+    }
+    if (node_form) {
+      uint64_t rck[NW];
+      revcomp_words<NW, BITS>(key, rck, shape);
+      if (less_words<NW>(rck, key)) {
+#pragma unroll
+        for (int w = 0; w < NW; ++w) recs[i * RW + w] = rck[w];
+        e = (comp_code<4>(e & 0xFu) << 4) | comp_code<4>(e >> 4);   // reverse_complement_edges<DNA16>
+      }
+      recs[i * RW + NW] = 1ull | ((uint64_t)e << 32);
+    } else {
+      recs[i * RW + NW] = e;
+    }
+  }
+}
+
+// The accumulate pass keeps, per workgroup, a table of one chunk of a bucket's nodes (key -> row) and eight counters per row.
+template <int NW> struct DbgCfg {
+  static constexpr int CAP = (NW == 1) ? 4096 : 2048;    // home slots
+  static constexpr int PAD = TabCfg<NW>::PAD;
+  static constexpr int SLOTS = CAP + PAD;
+  static constexpr int ROWS = CAP * 3 / 4;               // nodes per chunk
+  static constexpr int NT = 512;
+};
+
+// Fine bucket b: edges[node][0..7] += the edge bits of the bucket's records (+ the counts of the nodes that were there before
+// the insert, whose positions have changed). The nodes of the bucket are distinct keys at known positions, so the table is
+// filled once per chunk of ROWS nodes and only read afterwards; the counters live in LDS and leave as whole rows.
+template <int NW>
+__global__ __launch_bounds__((DbgCfg<NW>::NT)) void dbg_accumulate_kernel(const uint64_t *__restrict__ idx_keys, const uint64_t *__restrict__ idx_off,
+                                                                         const uint64_t *__restrict__ recs, const uint64_t *__restrict__ rec_off,
+                                                                         const uint64_t *__restrict__ old_keys, const uint32_t *__restrict__ old_edges,
+                                                                         const uint64_t *__restrict__ old_off, uint32_t *__restrict__ edges) {
+  using Cfg = DbgCfg<NW>;
+  constexpr int RW = NW + 1;
+  __shared__ uint64_t s_tk[Cfg::SLOTS * NW];
+  __shared__ uint32_t s_tv[Cfg::SLOTS];
+  __shared__ uint32_t s_tt[(NW == 1) ? 1 : Cfg::SLOTS];
+  __shared__ uint32_t s_cnt[Cfg::ROWS * 8];
+  __shared__ uint32_t s_ctl[8];
+  LdsTable<NW> tab;
+  tab.keys = s_tk; tab.vals = s_tv; tab.tags = s_tt; tab.distinct = &s_ctl[0]; tab.overflow = &s_ctl[1];
+  tab.special = &s_ctl[2]; tab.special_set = &s_ctl[3]; tab.progress = &s_ctl[5];
+  tab.cap = Cfg::CAP; tab.slots = Cfg::SLOTS; tab.limit = 2u * Cfg::CAP;   // (never "too loaded": the chunk size bounds the load)
+  uint32_t *s_fail = &s_ctl[6], *s_special_row = &s_ctl[7];
+  const uint32_t b = blockIdx.x;
+  const uint64_t ib = idx_off[b], ie = idx_off[b + 1];
+  if (ib == ie) return;
+  const uint64_t rb = recs ? rec_off[b] : 0ull, re = recs ? rec_off[b + 1] : 0ull;
+  const uint64_t ob = old_keys ? old_off[b] : 0ull, oe = old_keys ? old_off[b + 1] : 0ull;
+  if (rb == re && ob == oe) return;
+  auto row_of = [&](const uint64_t (&k)[NW]) -> uint32_t {
+    const int s = table_find<NW>(tab, k, place_hash<NW>(k));
+    return s >= 0 ? tab.vals[s] : (s == -2 ? *s_special_row : ~0u);
+  };
+  uint32_t chunk = Cfg::ROWS;
+  uint64_t i0 = ib;
+  while (i0 < ie) {
+    const uint32_t nc = (uint32_t)((ie - i0) < (uint64_t)chunk ? (ie - i0) : (uint64_t)chunk);
+    table_clear<NW>(tab);
+    for (uint32_t x = threadIdx.x; x < nc * 8u; x += blockDim.x) s_cnt[x] = 0;
+    if (threadIdx.x == 0) { *s_fail = 0; *s_special_row = ~0u; }
+    lds_barrier();
+    for (uint32_t j = threadIdx.x; j < nc; j += blockDim.x) {
+      uint64_t k[NW];
+#pragma unroll
+      for (int w = 0; w < NW; ++w) k[w] = idx_keys[(i0 + j) * NW + w];
+      const int s = table_upsert<NW>(tab, k, place_hash<NW>(k));
+      if (s >= 0) tab.vals[s] = j; else if (s == -2) *s_special_row = j; else *s_fail = 1;
+    }
+    lds_barrier();
+    if (*s_fail) {   // a probe sequence ran off the end of the table (one-word keys do not wrap around): fewer nodes per chunk
+      lds_barrier();
+      chunk = chunk > 64u ? chunk / 2u : 32u;   // 32 nodes always fit the 64 slots of padding
+      continue;
+    }
+    for (uint64_t i = rb + threadIdx.x; i < re; i += blockDim.x) {
+      uint32_t e = (uint32_t)(recs[i * RW + NW] >> 32) & 0xFFu;
+      if (e == 0u) continue;
+      uint64_t k[NW];
+#pragma unroll
+      for (int w = 0; w < NW; ++w) k[w] = recs[i * RW + w];
+      const uint32_t row = row_of(k);
+      if (row == ~0u) continue;   // a node of another chunk
+      while (e) { atomicAdd(&s_cnt[row * 8u + (uint32_t)__builtin_ctz(e)], 1u); e &= e - 1u; }
+    }
+    for (uint64_t i = ob + threadIdx.x; i < oe; i += blockDim.x) {
+      uint64_t k[NW];
+#pragma unroll
+      for (int w = 0; w < NW; ++w) k[w] = old_keys[i * NW + w];
+      const uint32_t row = row_of(k);
+      if (row == ~0u) continue;
+#pragma unroll
+      for (int t = 0; t < 8; ++t) { const uint32_t c = old_edges[i * 8u + t]; if (c) atomicAdd(&s_cnt[row * 8u + t], c); }
+    }
+    lds_barrier();
+    for (uint32_t x = threadIdx.x; x < nc * 8u; x += blockDim.x) { const uint32_t c = s_cnt[x]; if (c) edges[i0 * 8u + x] += c; }
+    lds_barrier();
+    i0 += nc;
+  }
+}
+
+// find(): the node values of the hits. pos = entry positions (what the count index's find reports with find_emits_index);
+// out = kDbgValueWords words per node: counts[0..7] (exists_only: 0 / 1), counts[8] = occurrences (exists_only: 0), padding
+__global__ __launch_bounds__(256) void dbg_gather_kernel(const uint64_t *__restrict__ pos, uint64_t n, const uint32_t *__restrict__ edges,
+                                                        const uint32_t *__restrict__ self, bool exists_only, uint64_t *__restrict__ out) {
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t p = pos[i];
+    uint32_t c[10];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) { const uint32_t v = edges[p * 8u + t]; c[t] = exists_only ? (v ? 1u : 0u) : v; }
+    c[8] = exists_only ? 0u : self[p];
+    c[9] = 0u;
+#pragma unroll
+    for (int w = 0; w < 5; ++w) out[i * kDbgValueWords + w] = (uint64_t)c[2 * w] | ((uint64_t)c[2 * w + 1] << 32);
+  }
+}
+
+}  // namespace kmi
+
+struct kmi_dbg {
+  kmi_ctx *ctx = nullptr;
+  kmi_config cfg{};          // as given (alphabet, k, hashes); the strand model of the node map is fixed (see the header comment)
+  KShape shape{};
+  uint32_t node_kind = 0;    // KMI_DBG_EDGE_COUNTS / KMI_DBG_EDGE_EXISTS
+  kmi_index *nodes = nullptr;   // canonical k-mer -> occurrences (a count index, laid out by the placement hash)
+  uint32_t *edges = nullptr;    // [n_entries][8]: out A C G T, in A C G T, in the order of nodes->keys
+  size_t edges_bytes = 0;
+};
+
+namespace kmi {
+
+template <int NW, int BITS>
+static kmi_status dbg_edges_impl(kmi_ctx *ctx, uint64_t *recs, size_t n, const uint8_t *bytes_dev, size_t n_bytes, KShape shape, bool from_ids,
+                                 bool node_form) {
+  if (n == 0) return KMI_OK;
+  ProfScope ps(ctx, "dbg_edges", n);
+  hipLaunchKernelGGL((dbg_edges_kernel<NW, BITS>), dim3(4096), dim3(256), 0, ctx->stream, recs, (uint64_t)n, bytes_dev, (uint64_t)n_bytes, shape,
+                     from_ids, node_form);
+  KMI_HIP(ctx, hipGetLastError());
+  return KMI_OK;
+}
+static kmi_status dbg_edges(kmi_ctx *ctx, uint64_t *recs, size_t n, const uint8_t *bytes_dev, size_t n_bytes, KShape shape, bool from_ids,
+                            bool node_form) {
+  KMI_DISPATCH(shape, dbg_edges_impl, ctx, recs, n, bytes_dev, n_bytes, shape, from_ids, node_form);
+}
+
+// the tuples of a FASTQ buffer as records (key words, value word) in WS_DBG_RECS; the value word is what dbg_edges_kernel leaves
+static kmi_status dbg_parse(kmi_ctx *ctx, const kmi_config *cfg, const uint8_t *bytes_dev, size_t n_bytes, bool node_form, uint64_t **recs_out,
+                            uint64_t *n_out) {
+  *recs_out = nullptr; *n_out = 0;
+  if (n_bytes == 0) return KMI_OK;
+  kmi_config c = *cfg;
+  c.index_kind = KMI_INDEX_POSITION; c.strand = KMI_STRAND_SINGLE; c.seq_format = KMI_FMT_FASTQ; c.seq_filter = KMI_SEQ_ALL; c.dist_trans = KMI_DIST_MODEL;
+  KShape shape;
+  if (!valid_config(&c, &shape)) return set_err(ctx, KMI_ERR_INVALID, "bad kmi_config");
+  KMI_TRY(align_input(ctx, &bytes_dev, n_bytes));
+  uint64_t nt = 0, ns = 0;
+  KMI_TRY(extract_count(ctx, &c, bytes_dev, n_bytes, &nt, &ns));
+  if (nt == 0) return KMI_OK;
+  void *dr;
+  const uint32_t rw = shape.n_words + 1u;
+  KMI_TRY(ws_get(ctx, WS_DBG_RECS, ((size_t)nt + 8) * rw * sizeof(uint64_t), &dr));
+  KMI_TRY(extract_run(ctx, &c, bytes_dev, n_bytes, 0, (uint64_t *)dr, nullptr, (size_t)nt, false, true, &nt, &ns, nullptr, rw));
+  KMI_TRY(dbg_edges(ctx, (uint64_t *)dr, (size_t)nt, bytes_dev, n_bytes, shape, true, node_form));
+  *recs_out = (uint64_t *)dr; *n_out = nt;
+  return KMI_OK;
+}
+
+// nodes.insert(tuples): records in node form (canonical key, 1 | edge << 32)
+template <int NW, int BITS>
+static kmi_status dbg_insert_impl(kmi_dbg *g, const uint64_t *recs_dev, size_t n) {
+  kmi_ctx *ctx = g->ctx;
+  kmi_index *idx = g->nodes;
+  if (n == 0) return KMI_OK;
+  // the nodes that are there keep their edge counts but not their positions: their keys and bucket offsets are set aside
+  const uint64_t n_old = idx->has_data ? idx->n_entries : 0;
+  uint64_t *old_keys = nullptr, *old_off = nullptr;
+  if (n_old) {
+    void *p;
+    const size_t kb = (size_t)n_old * NW * sizeof(uint64_t);
+    KMI_TRY(ws_get(ctx, WS_DBG_OLD, kb + kOffBytes + 64, &p));
+    old_keys = (uint64_t *)p; old_off = (uint64_t *)((uint8_t *)p + ((kb + 15) & ~(size_t)15));
+    KMI_HIP(ctx, hipMemcpyAsync(old_keys, idx->keys, kb, hipMemcpyDeviceToDevice, ctx->stream));
+    KMI_HIP(ctx, hipMemcpyAsync(old_off, idx->bucket_off, kOffBytes, hipMemcpyDeviceToDevice, ctx->stream));
+  }
+  Partitioned part;
+  KMI_TRY(index_insert_pairs(idx, recs_dev, n, false, false, &part));   // occurrences: the low half of the value word is the weight 1
+  const size_t eb = (size_t)(idx->n_entries ? idx->n_entries : 1) * 8 * sizeof(uint32_t);
+  uint32_t *ne = nullptr;
+  if (pool_alloc(ctx, (void **)&ne, eb) != hipSuccess) return set_err(ctx, KMI_ERR_NOMEM, "hipMalloc failed for the edge counts");
+  KMI_HIP(ctx, hipMemsetAsync(ne, 0, eb, ctx->stream));
+  {
+    ProfScope ps(ctx, "dbg_accumulate", n);
+    hipLaunchKernelGGL((dbg_accumulate_kernel<NW>), dim3(kNumFine), dim3(DbgCfg<NW>::NT), 0, ctx->stream, (const uint64_t *)idx->keys,
+                       (const uint64_t *)idx->bucket_off, (const uint64_t *)part.keys, (const uint64_t *)part.fine_off, (const uint64_t *)old_keys,
+                       (const uint32_t *)g->edges, (const uint64_t *)old_off, ne);
+  }
+  KMI_HIP(ctx, hipGetLastError());
+  KMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (g->edges) pool_free(ctx, g->edges, g->edges_bytes);
+  g->edges = ne; g->edges_bytes = eb;
+  return KMI_OK;
+}
+static kmi_status dbg_insert(kmi_dbg *g, const uint64_t *recs_dev, size_t n) { KMI_DISPATCH(g->shape, dbg_insert_impl, g, recs_dev, n); }
+
+// find(): keys of the hits + kDbgValueWords value words each
+static kmi_status dbg_find(kmi_dbg *g, const uint64_t *q_dev, size_t nq, uint64_t *out_keys_dev, uint64_t *out_vals_dev, uint64_t *n_out) {
+  kmi_ctx *ctx = g->ctx;
+  *n_out = 0;
+  if (nq == 0 || !g->nodes->has_data || g->nodes->n_entries == 0) return KMI_OK;
+  void *dp;
+  KMI_TRY(ws_get(ctx, WS_DBG_POS, (nq + 8) * sizeof(uint64_t), &dp));
+  g->nodes->find_emits_index = true;
+  const kmi_status st = index_query(g->nodes, Q_FIND, q_dev, nq, out_keys_dev, (uint64_t *)dp, nq, n_out);
+  g->nodes->find_emits_index = false;
+  KMI_TRY(st);
+  if (*n_out) {
+    ProfScope ps(ctx, "dbg_gather", *n_out);
+    hipLaunchKernelGGL(dbg_gather_kernel, dim3(1024), dim3(256), 0, ctx->stream, (const uint64_t *)dp, *n_out, (const uint32_t *)g->edges,
+                       (const uint32_t *)g->nodes->vals, g->node_kind == KMI_DBG_EDGE_EXISTS, out_vals_dev);
+    KMI_HIP(ctx, hipGetLastError());
+    KMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  return KMI_OK;
+}
+
+}  // namespace kmi

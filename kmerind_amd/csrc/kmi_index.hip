@@ -2123,7 +2123,10 @@ __global__ __launch_bounds__((QTabCfg<NW>::NT)) void bucket_query_kernel(int mod
                                                                        const uint64_t *__restrict__ idx_mvals,
                                                                        const uint64_t *__restrict__ idx_off, uint64_t *__restrict__ tmp_keys,
                                                                        uint64_t *__restrict__ tmp_vals64, uint32_t *__restrict__ tmp_vals32,
-                                                                       uint32_t *__restrict__ out_cnt, uint32_t *__restrict__ flags) {
+                                                                       uint32_t *__restrict__ out_cnt, uint32_t *__restrict__ flags,
+                                                                       bool emit_index) {
+  // emit_index (find on a counting map): the value of a hit is the entry's position in the index arrays instead of its count
+  // (the de Bruijn node map gathers the node's edge counts from there)
   KMI_TABLE_LDS_CFG(NW, QTabCfg<NW>)
   constexpr int OW = VW ? VW : 1;
   const uint32_t b = blockIdx.x;
@@ -2138,7 +2141,7 @@ __global__ __launch_bounds__((QTabCfg<NW>::NT)) void bucket_query_kernel(int mod
 #pragma unroll
     for (int w = 0; w < NW; ++w) tmp_keys[(tmp0 + pos) * NW + w] = k[w];
     if constexpr (VW == 0) {
-      if (mode == Q_ERASE) tmp_vals32[tmp0 + pos] = idx_vals32[i]; else tmp_vals64[tmp0 + pos] = idx_vals32[i];
+      if (mode == Q_ERASE) tmp_vals32[tmp0 + pos] = idx_vals32[i]; else tmp_vals64[tmp0 + pos] = emit_index ? i : (uint64_t)idx_vals32[i];
     } else {
 #pragma unroll
       for (int w = 0; w < VW; ++w) tmp_vals64[(tmp0 + pos) * VW + w] = idx_mvals[i * VW + w];
@@ -2282,6 +2285,7 @@ struct kmi_index {
   uint64_t *bucket_off = nullptr; // [kNumFine + 1]
   uint64_t n_entries = 0;
   bool has_data = false;
+  bool find_emits_index = false;  // find() of a counting map reports entry positions instead of counts (kmi_debruijn.h)
   uint32_t layout_w = 0;          // what the fine buckets mean: 0 = top bits of the placement hash; W = minimizer bucket (fine15_of_key)
   size_t keys_bytes = 0, vals_bytes = 0, mvals_bytes = 0;   // sizes of the blocks above (for the context's spare list)
 };
@@ -2289,7 +2293,9 @@ constexpr size_t kOffBytes = sizeof(uint64_t) * ((size_t)1 << 15) + sizeof(uint6
 
 namespace kmi {
 
-static kmi_status index_insert_pairs(kmi_index *idx, const uint64_t *recs_dev, size_t n, bool transform, bool distinct_in);
+struct Partitioned;
+static kmi_status index_insert_pairs(kmi_index *idx, const uint64_t *recs_dev, size_t n, bool transform, bool distinct_in,
+                                     Partitioned *part_out = nullptr);
 static kmi_status ensure_layout(kmi_index *idx, uint32_t target_w);
 static void free_index_arrays(kmi_index *idx);
 template <int NW>
@@ -2800,12 +2806,14 @@ static kmi_status index_insert_records(kmi_index *idx, const uint64_t *recs_dev,
 // (distributed_unordered_map.hpp:1603-1618). distinct_in = true: the keys are known to be distinct (a reduced map handed
 // over), so into an empty index they need no table at all.
 template <int NW, int BITS>
-static kmi_status insert_pairs_impl(kmi_index *idx, const uint64_t *recs_dev, size_t n, bool transform, bool distinct_in) {
+static kmi_status insert_pairs_impl(kmi_index *idx, const uint64_t *recs_dev, size_t n, bool transform, bool distinct_in, Partitioned *part_out) {
+  // part_out: where the fine-partitioned records are left (workspace, valid until the next partition)
   kmi_ctx *ctx = idx->ctx;
   if (n == 0) return KMI_OK;
   KMI_TRY(ensure_layout(idx, 0u));
   Partitioned part;
   KMI_TRY((partition_impl<NW, BITS, 1>(ctx, &idx->cfg, idx->shape, recs_dev, n, transform, WS_KEYS_A, WS_KEYS_B, &part)));
+  if (part_out) *part_out = part;
   if (distinct_in && !idx->has_data) {
     uint64_t *nk = nullptr, *noff = nullptr; uint32_t *nv = nullptr;
     const size_t kb = n * NW * sizeof(uint64_t), vb = n * sizeof(uint32_t);
@@ -2843,8 +2851,8 @@ static kmi_status insert_pairs_impl(kmi_index *idx, const uint64_t *recs_dev, si
   return adopt_tmp<NW>(idx, tmp_keys, tmp_vals, part.fine_off, idx->has_data ? idx->bucket_off : nullptr, out_cnt);
 }
 
-static kmi_status index_insert_pairs(kmi_index *idx, const uint64_t *recs_dev, size_t n, bool transform, bool distinct_in) {
-  KMI_DISPATCH(idx->shape, insert_pairs_impl, idx, recs_dev, n, transform, distinct_in);
+static kmi_status index_insert_pairs(kmi_index *idx, const uint64_t *recs_dev, size_t n, bool transform, bool distinct_in, Partitioned *part_out) {
+  KMI_DISPATCH(idx->shape, insert_pairs_impl, idx, recs_dev, n, transform, distinct_in, part_out);
 }
 
 // queries: results compacted into out_keys_dev / out_vals_dev (max(1, val_words) u64 per result)
@@ -2869,7 +2877,7 @@ static kmi_status query_vw(kmi_index *idx, int mode, const uint64_t *q_dev, size
     hipLaunchKernelGGL((bucket_query_kernel<NW, VW>), dim3(kNumFine), dim3(QTabCfg<NW>::NT), 0, ctx->stream, mode, (const uint64_t *)part.keys,
                        (const uint64_t *)part.fine_off, (const uint64_t *)idx->keys, (const uint32_t *)idx->vals, (const uint64_t *)idx->mvals,
                        (const uint64_t *)(idx->has_data ? idx->bucket_off : nullptr), tmp_keys, (uint64_t *)tmp_vals, (uint32_t *)tmp_vals,
-                       out_cnt, ctx->d_flags);
+                       out_cnt, ctx->d_flags, idx->find_emits_index && mode == Q_FIND && VW == 0);
   }
   KMI_HIP(ctx, hipGetLastError());
   const uint64_t *src_off = (by_entries && idx->has_data) ? idx->bucket_off : part.fine_off;
@@ -3114,6 +3122,8 @@ static kmi_status merge_impl(kmi_index *idx, uint32_t nparts, const uint64_t *ke
 }
 
 }  // namespace kmi
+
+#include "kmi_debruijn.h"
 
 extern "C" {
 
@@ -3657,6 +3667,206 @@ kmi_status kmi_index_size_dist(kmi_index *idx, kmi_comm *comm, uint64_t *n) {
   KMI_TRY(dist_check(idx, comm));
   *n = idx->n_entries;
   return kmi::comm_allreduce_sum(comm, n);
+}
+
+// ---- de Bruijn graph nodes (kmi_debruijn.h)
+kmi_status kmi_dbg_create(kmi_ctx *ctx, const kmi_config *cfg, uint32_t node_kind, kmi_dbg **out) {
+  if (!ctx || !out) return KMI_ERR_INVALID;
+  KShape shape;
+  if (!valid_config(cfg, &shape)) return set_err(ctx, KMI_ERR_INVALID, "bad kmi_config");
+  if (node_kind > KMI_DBG_EDGE_EXISTS) return set_err(ctx, KMI_ERR_INVALID, "unknown node kind");
+  if (cfg->seq_format != KMI_FMT_FASTQ || cfg->seq_filter != KMI_SEQ_ALL)
+    return set_err(ctx, KMI_ERR_INVALID, "de Bruijn nodes are built from FASTQ records without a sequence filter (as the reference's engine is)");
+  kmi_dbg *g = new kmi_dbg();
+  g->ctx = ctx; g->cfg = *cfg; g->shape = shape; g->node_kind = node_kind;
+  kmi_config c = *cfg;   // the node map proper: both strands of a k-mer are one node, kept under the smaller one
+  c.index_kind = KMI_INDEX_COUNT; c.strand = KMI_STRAND_CANONICAL; c.dist_trans = KMI_DIST_MODEL;
+  const kmi_status st = kmi_index_create(ctx, &c, &g->nodes);
+  if (st != KMI_OK) { delete g; return st; }
+  *out = g;
+  return KMI_OK;
+}
+
+kmi_status kmi_dbg_destroy(kmi_dbg *g) {
+  if (!g) return KMI_OK;
+  (void)hipSetDevice(g->ctx->device);
+  (void)hipStreamSynchronize(g->ctx->stream);
+  if (g->edges) pool_free(g->ctx, g->edges, g->edges_bytes);
+  (void)kmi_index_destroy(g->nodes);
+  delete g;
+  return KMI_OK;
+}
+
+kmi_status kmi_dbg_clear(kmi_dbg *g) {
+  if (!g) return KMI_ERR_INVALID;
+  KMI_TRY(kmi_index_clear(g->nodes));
+  if (g->edges) pool_free(g->ctx, g->edges, g->edges_bytes);
+  g->edges = nullptr; g->edges_bytes = 0;
+  return KMI_OK;
+}
+
+kmi_status kmi_dbg_local_size(kmi_dbg *g, uint64_t *n) {
+  if (!g || !n) return KMI_ERR_INVALID;
+  *n = g->nodes->n_entries;
+  return KMI_OK;
+}
+
+kmi_status kmi_dbg_parse_dev(kmi_ctx *ctx, const kmi_config *cfg, const uint8_t *bytes_dev, size_t n_bytes, uint64_t *out_records_dev,
+                             size_t out_capacity, uint64_t *n_tuples) {
+  if (!ctx || !n_tuples) return KMI_ERR_INVALID;
+  KShape shape;
+  if (!valid_config(cfg, &shape)) return set_err(ctx, KMI_ERR_INVALID, "bad kmi_config");
+  KMI_HIP(ctx, hipSetDevice(ctx->device));
+  uint64_t *recs = nullptr;
+  KMI_TRY(dbg_parse(ctx, cfg, bytes_dev, n_bytes, false, &recs, n_tuples));
+  if (!out_records_dev) return KMI_OK;   // count only
+  if (*n_tuples > out_capacity) return set_err(ctx, KMI_ERR_OVERFLOW, "parse: output capacity too small");
+  if (*n_tuples) KMI_HIP(ctx, hipMemcpyAsync(out_records_dev, recs, (size_t)*n_tuples * (shape.n_words + 1) * sizeof(uint64_t), hipMemcpyDeviceToDevice, ctx->stream));
+  KMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return KMI_OK;
+}
+
+kmi_status kmi_dbg_build_dev(kmi_dbg *g, const uint8_t *bytes_dev, size_t n_bytes) {
+  if (!g) return KMI_ERR_INVALID;
+  kmi_ctx *ctx = g->ctx;
+  KMI_HIP(ctx, hipSetDevice(ctx->device));
+  if (n_bytes == 0) return KMI_OK;
+  uint64_t *recs = nullptr, nt = 0;
+  KMI_TRY(dbg_parse(ctx, &g->cfg, bytes_dev, n_bytes, true, &recs, &nt));
+  return dbg_insert(g, recs, (size_t)nt);
+}
+
+kmi_status kmi_dbg_build_host(kmi_dbg *g, const uint8_t *bytes, size_t n_bytes) {
+  if (!g) return KMI_ERR_INVALID;
+  kmi_ctx *ctx = g->ctx;
+  if (n_bytes == 0) return KMI_OK;
+  if (!bytes) return set_err(ctx, KMI_ERR_INVALID, "null buffer");
+  KMI_HIP(ctx, hipSetDevice(ctx->device));
+  void *din;
+  KMI_TRY(ws_get(ctx, WS_INPUT, n_bytes + 64, &din));
+  KMI_HIP(ctx, hipMemcpyAsync(din, bytes, n_bytes, hipMemcpyHostToDevice, ctx->stream));
+  return kmi_dbg_build_dev(g, (const uint8_t *)din, n_bytes);
+}
+
+// tuples as the parser emits them (any strand; value word = edge byte); they are rewritten in place into node form
+static kmi_status dbg_insert_tuples(kmi_dbg *g, uint64_t *recs_dev, size_t n) {
+  KMI_TRY(dbg_edges(g->ctx, recs_dev, n, nullptr, 0, g->shape, false, true));
+  return dbg_insert(g, recs_dev, n);
+}
+
+kmi_status kmi_dbg_insert_dev(kmi_dbg *g, const uint64_t *records_dev, size_t n) {
+  if (!g) return KMI_ERR_INVALID;
+  kmi_ctx *ctx = g->ctx;
+  KMI_HIP(ctx, hipSetDevice(ctx->device));
+  if (n == 0) return KMI_OK;
+  void *dr;   // (the caller's buffer stays as it is)
+  const size_t bytes = n * (g->shape.n_words + 1) * sizeof(uint64_t);
+  KMI_TRY(ws_get(ctx, WS_DBG_RECS, bytes + 64, &dr));
+  KMI_HIP(ctx, hipMemcpyAsync(dr, records_dev, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+  return dbg_insert_tuples(g, (uint64_t *)dr, n);
+}
+
+kmi_status kmi_dbg_insert_host(kmi_dbg *g, const uint64_t *records, size_t n) {
+  if (!g) return KMI_ERR_INVALID;
+  kmi_ctx *ctx = g->ctx;
+  if (n == 0) return KMI_OK;
+  if (!records) return set_err(ctx, KMI_ERR_INVALID, "null buffer");
+  KMI_HIP(ctx, hipSetDevice(ctx->device));
+  void *dr;
+  const size_t bytes = n * (g->shape.n_words + 1) * sizeof(uint64_t);
+  KMI_TRY(ws_get(ctx, WS_DBG_RECS, bytes + 64, &dr));
+  KMI_HIP(ctx, hipMemcpyAsync(dr, records, bytes, hipMemcpyHostToDevice, ctx->stream));
+  return dbg_insert_tuples(g, (uint64_t *)dr, n);
+}
+
+kmi_status kmi_dbg_find_dev(kmi_dbg *g, const uint64_t *queries_dev, size_t nq, uint64_t *out_keys_dev, uint64_t *out_values_dev, uint64_t *n_out) {
+  if (!g || !n_out) return KMI_ERR_INVALID;
+  KMI_HIP(g->ctx, hipSetDevice(g->ctx->device));
+  return dbg_find(g, queries_dev, nq, out_keys_dev, out_values_dev, n_out);
+}
+
+kmi_status kmi_dbg_find_host(kmi_dbg *g, const uint64_t *queries, size_t nq, kmi_results *out) {
+  if (!g || !out) return KMI_ERR_INVALID;
+  kmi_ctx *ctx = g->ctx;
+  memset(out, 0, sizeof(*out));
+  if (nq == 0) return KMI_OK;
+  if (!queries) return set_err(ctx, KMI_ERR_INVALID, "null buffer");
+  KMI_HIP(ctx, hipSetDevice(ctx->device));
+  const uint32_t nw = g->shape.n_words;
+  void *dq, *dk, *dv;
+  KMI_TRY(ws_get(ctx, WS_INPUT, nq * nw * sizeof(uint64_t), &dq));
+  KMI_TRY(ws_get(ctx, WS_OUTPUT, nq * nw * sizeof(uint64_t), &dk));
+  KMI_TRY(ws_get(ctx, WS_OUTPUT2, nq * kDbgValueWords * sizeof(uint64_t), &dv));
+  KMI_HIP(ctx, hipMemcpyAsync(dq, queries, nq * nw * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+  uint64_t n = 0;
+  KMI_TRY(dbg_find(g, (const uint64_t *)dq, nq, (uint64_t *)dk, (uint64_t *)dv, &n));
+  out->n = n;
+  out->keys = (uint64_t *)malloc((n ? n : 1) * nw * sizeof(uint64_t));
+  out->values = (uint64_t *)malloc((n ? n : 1) * kDbgValueWords * sizeof(uint64_t));
+  if (!out->keys || !out->values) return set_err(ctx, KMI_ERR_NOMEM, "host malloc failed");
+  if (n) {
+    KMI_HIP(ctx, hipMemcpyAsync(out->keys, dk, n * nw * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+    KMI_HIP(ctx, hipMemcpyAsync(out->values, dv, n * kDbgValueWords * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+    KMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  return KMI_OK;
+}
+
+kmi_status kmi_dbg_count_host(kmi_dbg *g, const uint64_t *queries, size_t nq, kmi_results *out) {
+  if (!g) return KMI_ERR_INVALID;
+  return kmi_index_count_host(g->nodes, queries, nq, out);
+}
+
+kmi_status kmi_dbg_export_host(kmi_dbg *g, uint64_t *keys, uint32_t *counts9, size_t capacity, uint64_t *n) {
+  if (!g || !n) return KMI_ERR_INVALID;
+  kmi_ctx *ctx = g->ctx;
+  *n = 0;
+  const uint64_t ne = g->nodes->n_entries;
+  if (ne == 0) return KMI_OK;
+  if (capacity < ne) return set_err(ctx, KMI_ERR_OVERFLOW, "export: capacity too small");
+  KMI_HIP(ctx, hipSetDevice(ctx->device));
+  if (keys) KMI_HIP(ctx, hipMemcpyAsync(keys, g->nodes->keys, ne * g->shape.n_words * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+  if (counts9) {
+    std::vector<uint32_t> e(ne * 8), s(ne);
+    KMI_HIP(ctx, hipMemcpyAsync(e.data(), g->edges, ne * 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    KMI_HIP(ctx, hipMemcpyAsync(s.data(), g->nodes->vals, ne * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    KMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const bool ex = g->node_kind == KMI_DBG_EDGE_EXISTS;
+    for (uint64_t i = 0; i < ne; ++i) {
+      for (int t = 0; t < 8; ++t) counts9[i * 9 + t] = ex ? (e[i * 8 + t] ? 1u : 0u) : e[i * 8 + t];
+      counts9[i * 9 + 8] = ex ? 0u : s[i];
+    }
+  }
+  KMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  *n = ne;
+  return KMI_OK;
+}
+
+// build over ranks: parse the rank's share, group the node-form tuples by KeyToRank of the canonical k-mer, one all-to-all
+// (imxx::distribute inside de_bruijn_nodes_distributed::insert, de_bruijn_nodes_distributed.hpp:243-250), insert what arrives
+kmi_status kmi_dbg_build_dist_host(kmi_dbg *g, kmi_comm *comm, const uint8_t *bytes, size_t n_bytes) {
+  if (!g) return KMI_ERR_INVALID;
+  KMI_TRY(dist_check(g->nodes, comm));
+  kmi_ctx *ctx = g->ctx;
+  const int p = kmi::comm_size(comm);
+  if (p == 1 && !ctx->force_dist) return kmi_dbg_build_host(g, bytes, n_bytes);
+  if (n_bytes && !bytes) return set_err(ctx, KMI_ERR_INVALID, "null buffer");
+  const uint32_t rw = g->shape.n_words + 1u;
+  void *d_bytes, *d_send, *d_recv;
+  KMI_TRY(ws_get(ctx, WS_INPUT, n_bytes + 64, &d_bytes));
+  if (n_bytes) KMI_HIP(ctx, hipMemcpyAsync(d_bytes, bytes, n_bytes, hipMemcpyHostToDevice, ctx->stream));
+  uint64_t *recs = nullptr, nt = 0, total = 0;
+  KMI_TRY(dbg_parse(ctx, &g->cfg, (const uint8_t *)d_bytes, n_bytes, true, &recs, &nt));   // (an empty share still enters the collectives)
+  KMI_TRY(ws_get(ctx, WS_DIST_A, ((size_t)nt + 64) * rw * sizeof(uint64_t), &d_send));
+  std::vector<uint64_t> sc(p, 0), rc;
+  if (nt) KMI_TRY(kmi_route_tuples_dev(ctx, &g->nodes->cfg, recs, (size_t)nt, (uint32_t)p, 1, (uint64_t *)d_send, sc.data()));
+  KMI_TRY(dist_exchange(comm, d_send, sc.data(), rw * sizeof(uint64_t), WS_DIST_B, &d_recv, rc, &total));
+  return dbg_insert(g, (const uint64_t *)d_recv, (size_t)total);
+}
+
+kmi_status kmi_dbg_size_dist(kmi_dbg *g, kmi_comm *comm, uint64_t *n) {
+  if (!g) return KMI_ERR_INVALID;
+  return kmi_index_size_dist(g->nodes, comm, n);
 }
 
 }  // extern "C"

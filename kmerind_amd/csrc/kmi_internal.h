@@ -51,6 +51,9 @@ enum WsSlot {
   WS_DIST_B,
   WS_DIST_C,
   WS_DIST_D,
+  WS_DBG_RECS,        // de Bruijn node build: (k-mer, edge) records of the parsed input
+  WS_DBG_OLD,         // ... keys and bucket offsets of the nodes before an insert (their edge counts move to the new order)
+  WS_DBG_POS,         // ... entry positions of the nodes a find() hit
   WS_ALIGNED,         // 16-byte aligned copy of an input buffer that arrived at an odd address (a batch inside a larger buffer)
   WS_NUM_SLOTS
 };

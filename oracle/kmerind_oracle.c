@@ -1083,6 +1083,195 @@ static size_t fastq_align(const uint8_t *b, size_t n, size_t pos) {
   return n;
 }
 
+/* ------------------------------------------------------------------------ */
+/* de Bruijn graph nodes (test/test/debruijn/)                              */
+/* ------------------------------------------------------------------------ */
+
+/* edge_iterator<IT, DNA16> (edge_iterator.hpp:84-177) zipped with the k-mer iterator (de_bruijn_construct_engine.hpp:
+ * 140-155). chars = the NotEOL-filtered characters of one sequence. _curr starts k-1 characters in, _right one further,
+ * _left at "none"; every step moves all three (operator++, :119-138); operator* (:163-177) packs
+ * FROM_ASCII[*_left] << 4 | FROM_ASCII[*_right], leaving out the side that has run off the sequence. */
+static size_t dbg_parse_seq(const orc_kspec *s, const uint8_t *chars, size_t len, uint64_t *kmers, uint8_t *edges,
+                            size_t out_cap, size_t total) {
+  const uint32_t K = s->k;
+  if (len < K) return total;
+  uint64_t km[ORC_MAX_WORDS];
+  orc_kmer_clear(s, km);
+  for (uint32_t i = 0; i + 1 < K; ++i) orc_kmer_next_from_char(s, km, orc_from_ascii(s->alphabet, chars[i]));
+  size_t left = len /* = _data_end: none yet */, right = K;
+  for (size_t curr = K - 1; curr < len; ++curr) {
+    orc_kmer_next_from_char(s, km, orc_from_ascii(s->alphabet, chars[curr]));
+    uint8_t e = 0;
+    if (left != len && right != len) e = (uint8_t)((orc_from_ascii(ORC_DNA16, chars[left]) << 4) | orc_from_ascii(ORC_DNA16, chars[right]));
+    else if (left == len && right != len) e = orc_from_ascii(ORC_DNA16, chars[right]);
+    else if (left != len && right == len) e = (uint8_t)(orc_from_ascii(ORC_DNA16, chars[left]) << 4);
+    if (total < out_cap) {
+      if (kmers) memcpy(kmers + total * s->n_words, km, s->n_words * sizeof(uint64_t));
+      if (edges) edges[total] = e;
+    }
+    ++total;
+    /* operator++ */
+    if (left == len) left = 0; else ++left;
+    if (right != len) ++right;
+  }
+  return total;
+}
+
+long orc_dbg_parse(const orc_kspec *s, const uint8_t *bytes, size_t n, uint64_t *kmers, uint8_t *edges, size_t out_cap) {
+  long nrec = orc_fastq_records(bytes, n, 0, NULL, 0);
+  if (nrec < 0) return -1;
+  orc_record *recs = (orc_record *)malloc(sizeof(orc_record) * (size_t)(nrec ? nrec : 1));
+  orc_fastq_records(bytes, n, 0, recs, (size_t)nrec);
+  size_t total = 0;
+  uint8_t *chars = (uint8_t *)malloc(n ? n : 1);
+  for (long r = 0; r < nrec; ++r) {
+    size_t len = 0;
+    for (size_t i = (size_t)recs[r].seq_begin; i < (size_t)recs[r].seq_end; ++i)
+      if (!is_eol(bytes[i])) chars[len++] = bytes[i];     /* NonEOLIter */
+    if (len == 0) continue;                                /* :138 */
+    total = dbg_parse_seq(s, chars, len, kmers, edges, out_cap, total);
+  }
+  free(chars); free(recs);
+  return (long)total;
+}
+
+uint8_t orc_dbg_edges_revcomp(uint8_t exts) {
+  return (uint8_t)((orc_complement(ORC_DNA16, exts & 0xF) << 4) | orc_complement(ORC_DNA16, exts >> 4));
+}
+
+typedef struct dbg_node {
+  struct dbg_node *next;
+  uint64_t hash;
+  uint32_t counts[9];
+  uint64_t stamp;          /* last find() call that reported the node */
+  uint64_t key[];          /* the strand the node was created with */
+} dbg_node;
+
+struct orc_dbg_map {
+  orc_kspec spec;
+  uint32_t store_hash;
+  int exists_only;
+  dbg_node **buckets;
+  size_t n_buckets, size;
+  uint64_t stamp;
+};
+
+orc_dbg_map *orc_dbg_map_create(const orc_kspec *s, uint32_t store_hash, int exists_only) {
+  orc_dbg_map *m = (orc_dbg_map *)calloc(1, sizeof(orc_dbg_map));
+  m->spec = *s; m->store_hash = store_hash; m->exists_only = exists_only;
+  m->n_buckets = 1024;
+  m->buckets = (dbg_node **)calloc(m->n_buckets, sizeof(dbg_node *));
+  return m;
+}
+
+void orc_dbg_map_destroy(orc_dbg_map *m) {
+  if (!m) return;
+  for (size_t b = 0; b < m->n_buckets; ++b) {
+    dbg_node *nd = m->buckets[b];
+    while (nd) { dbg_node *nx = nd->next; free(nd); nd = nx; }
+  }
+  free(m->buckets); free(m);
+}
+
+/* BimoleculeHashMapParams (kmer_index.hpp:468-481): hash and equality on lex_less(key), the key itself is stored as given */
+static dbg_node *dbg_find(const orc_dbg_map *m, const uint64_t *key, uint64_t *hash_out, int *same_strand) {
+  uint64_t canon[ORC_MAX_WORDS], other[ORC_MAX_WORDS];
+  orc_kmer_canonical(&m->spec, key, canon);
+  const uint64_t h = orc_kmer_hash(&m->spec, m->store_hash, 0, canon);
+  if (hash_out) *hash_out = h;
+  for (dbg_node *nd = m->buckets[h & (m->n_buckets - 1)]; nd; nd = nd->next) {
+    if (nd->hash != h) continue;
+    orc_kmer_canonical(&m->spec, nd->key, other);
+    if (orc_kmer_equal(&m->spec, other, canon)) {
+      if (same_strand) *same_strand = orc_kmer_equal(&m->spec, nd->key, key);
+      return nd;
+    }
+  }
+  return NULL;
+}
+
+static void dbg_update(const orc_dbg_map *m, dbg_node *nd, uint8_t exts) {
+  if (m->exists_only) {            /* edge_exists::update (:302-311): counts |= exts */
+    for (int i = 0; i < 8; ++i) nd->counts[i] |= (exts >> i) & 1u;
+    return;
+  }
+  nd->counts[8] += 1;              /* edge_counts<DNA16, int32_t>::update (:200-239): no clamping at 32 bits */
+  for (int i = 0; i < 8; ++i) nd->counts[i] += (exts >> i) & 1u;
+}
+
+void orc_dbg_map_insert(orc_dbg_map *m, const uint64_t *kmers, const uint8_t *edges, size_t n) {
+  const uint32_t nw = m->spec.n_words;
+  for (size_t i = 0; i < n; ++i) {
+    const uint64_t *key = kmers + i * nw;
+    uint64_t h; int same = 1;
+    dbg_node *nd = dbg_find(m, key, &h, &same);
+    if (!nd) {                       /* de_bruijn_nodes_distributed.hpp:116-133: new node, SENSE */
+      if (m->size + 1 > m->n_buckets) {
+        size_t nb = m->n_buckets * 2;
+        dbg_node **nbk = (dbg_node **)calloc(nb, sizeof(dbg_node *));
+        for (size_t b = 0; b < m->n_buckets; ++b) {
+          dbg_node *x = m->buckets[b];
+          while (x) { dbg_node *nx = x->next; size_t j = x->hash & (nb - 1); x->next = nbk[j]; nbk[j] = x; x = nx; }
+        }
+        free(m->buckets); m->buckets = nbk; m->n_buckets = nb;
+      }
+      nd = (dbg_node *)calloc(1, sizeof(dbg_node) + nw * sizeof(uint64_t));
+      nd->hash = h; memcpy(nd->key, key, nw * sizeof(uint64_t));
+      size_t b = h & (m->n_buckets - 1);
+      nd->next = m->buckets[b]; m->buckets[b] = nd; m->size++;
+      same = 1;
+    }
+    /* :149-155: ANTI_SENSE -> reverse-complemented edges */
+    dbg_update(m, nd, same ? edges[i] : orc_dbg_edges_revcomp(edges[i]));
+  }
+}
+
+size_t orc_dbg_map_size(const orc_dbg_map *m) { return m->size; }
+
+static void dbg_emit(const orc_dbg_map *m, const dbg_node *nd, uint64_t *key, uint32_t *c9, int canonical_orientation) {
+  uint64_t rc[ORC_MAX_WORDS];
+  orc_kmer_revcomp(&m->spec, nd->key, rc);
+  if (canonical_orientation && orc_kmer_less(&m->spec, rc, nd->key)) {
+    memcpy(key, rc, m->spec.n_words * sizeof(uint64_t));
+    /* out X of the other strand = in complement(X) of this one: bit i of the edge byte moves to where
+     * reverse_complement_edges would put it */
+    for (int i = 0; i < 8; ++i) {
+      uint8_t bit = (uint8_t)(1u << i), to = orc_dbg_edges_revcomp(bit);
+      int j = 0; while (!((to >> j) & 1)) ++j;
+      c9[j] = nd->counts[i];
+    }
+    c9[8] = nd->counts[8];
+  } else {
+    memcpy(key, nd->key, m->spec.n_words * sizeof(uint64_t));
+    memcpy(c9, nd->counts, sizeof(uint32_t) * 9);
+  }
+}
+
+size_t orc_dbg_map_export(const orc_dbg_map *m, uint64_t *keys, uint32_t *counts9, int canonical_orientation) {
+  size_t j = 0;
+  for (size_t b = 0; b < m->n_buckets; ++b)
+    for (dbg_node *nd = m->buckets[b]; nd; nd = nd->next) {
+      dbg_emit(m, nd, keys + j * m->spec.n_words, counts9 + j * 9, canonical_orientation);
+      ++j;
+    }
+  return j;
+}
+
+/* find(): unique queries (under the map's equality) that hit, as (stored key, node) -- distributed_unordered_map.hpp:1100-1131 */
+size_t orc_dbg_map_find(orc_dbg_map *m, const uint64_t *queries, size_t nq, uint64_t *out_keys, uint32_t *out_counts9,
+                        int canonical_orientation) {
+  size_t j = 0;
+  const uint64_t stamp = ++m->stamp;
+  for (size_t i = 0; i < nq; ++i) {
+    dbg_node *nd = dbg_find(m, queries + i * m->spec.n_words, NULL, NULL);
+    if (!nd || nd->stamp == stamp) continue;
+    nd->stamp = stamp;
+    dbg_emit(m, nd, out_keys + j * m->spec.n_words, out_counts9 + j * 9, canonical_orientation);
+    ++j;
+  }
+  return j;
+}
+
 double orc_bench_count_index(const uint8_t *bytes, size_t n, uint32_t k, uint32_t strand,
                              uint32_t threads, uint64_t *n_kmers, uint64_t *n_distinct) {
   orc_kspec spec;

@@ -185,6 +185,31 @@ size_t orc_multi_map_count(const orc_multi_map *m, const uint64_t *queries, size
 size_t orc_multi_map_find(const orc_multi_map *m, const uint64_t *queries, size_t nq, uint64_t *out_keys, uint64_t *out_values, size_t cap);
 size_t orc_multi_map_erase(orc_multi_map *m, const uint64_t *queries, size_t nq);
 
+/* ---- de Bruijn graph nodes: test/test/debruijn/ (the reference's only in-tree consumer of Index).
+ * No expected values are held by the reference for this path (its test prints sizes only): the functions below restate
+ * edge_iterator.hpp:84-177, de_bruijn_node_trait.hpp:119-131,139-336 and de_bruijn_nodes_distributed.hpp:91-159 literally,
+ * and tests/ pins them on hand-worked vectors. */
+/* de_bruijn_parser::operator() (de_bruijn_construct_engine.hpp:109-157) over every FASTQ record: k-mers as parsed
+ * (no strand transform) zipped with edge_iterator<CharIter, DNA16>: high nibble = DNA16 code of the base left of the k-mer
+ * in the read, low nibble = base right of it, 0 where the read ends. Returns the tuple count, -1 on a parse error. */
+long orc_dbg_parse(const orc_kspec *s, const uint8_t *bytes, size_t n, uint64_t *kmers, uint8_t *edges, size_t out_cap);
+/* input_edge_utils::reverse_complement_edges<DNA16> (de_bruijn_node_trait.hpp:122-124) */
+uint8_t orc_dbg_edges_revcomp(uint8_t exts);
+/* de_bruijn_nodes_distributed<Kmer, edge_counts<DNA16, int32_t> | edge_exists<DNA16>, BimoleculeHashMapParams>:
+ * a node is found under either strand and keeps the strand it was created with (the first one inserted);
+ * counts[0..3] = out A C G T, [4..7] = in A C G T, [8] = occurrences of the k-mer (edge_counts::update, :200-239).
+ * edge_exists keeps the OR of the edge bytes: export gives it as counts[i] = bit i, counts[8] = 0. */
+typedef struct orc_dbg_map orc_dbg_map;
+orc_dbg_map *orc_dbg_map_create(const orc_kspec *s, uint32_t store_hash, int exists_only);
+void orc_dbg_map_destroy(orc_dbg_map *m);
+void orc_dbg_map_insert(orc_dbg_map *m, const uint64_t *kmers, const uint8_t *edges, size_t n);
+size_t orc_dbg_map_size(const orc_dbg_map *m);
+/* canonical_orientation != 0: every node is given in the orientation of the lexicographically smaller strand (key
+ * reverse-complemented, in/out counts swapped and complemented) -- the form the device library stores */
+size_t orc_dbg_map_export(const orc_dbg_map *m, uint64_t *keys, uint32_t *counts9, int canonical_orientation);
+size_t orc_dbg_map_find(orc_dbg_map *m, const uint64_t *queries, size_t nq, uint64_t *out_keys, uint32_t *out_counts9,
+                        int canonical_orientation);
+
 /* ---- CPU baseline driver ("port" of the reference MPI path with T thread-ranks):
  * per rank parse (record-aligned byte range) -> KeyToRank (murmur h[1] % T) ->
  * stable bucket -> in-memory exchange -> per-rank counting map insert.

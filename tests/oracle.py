@@ -100,6 +100,20 @@ lib.orc_multi_map_find.argtypes = [C.c_void_p, _u64p, C.c_size_t, C.c_void_p, C.
 lib.orc_multi_map_find.restype = C.c_size_t
 lib.orc_multi_map_erase.argtypes = [C.c_void_p, _u64p, C.c_size_t]
 lib.orc_multi_map_erase.restype = C.c_size_t
+lib.orc_dbg_parse.argtypes = [_SP, _u8p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t]
+lib.orc_dbg_parse.restype = C.c_long
+lib.orc_dbg_edges_revcomp.argtypes = [C.c_uint8]
+lib.orc_dbg_edges_revcomp.restype = C.c_uint8
+lib.orc_dbg_map_create.argtypes = [_SP, C.c_uint32, C.c_int]
+lib.orc_dbg_map_create.restype = C.c_void_p
+lib.orc_dbg_map_destroy.argtypes = [C.c_void_p]
+lib.orc_dbg_map_insert.argtypes = [C.c_void_p, _u64p, _u8p, C.c_size_t]
+lib.orc_dbg_map_size.argtypes = [C.c_void_p]
+lib.orc_dbg_map_size.restype = C.c_size_t
+lib.orc_dbg_map_export.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+lib.orc_dbg_map_export.restype = C.c_size_t
+lib.orc_dbg_map_find.argtypes = [C.c_void_p, _u64p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int]
+lib.orc_dbg_map_find.restype = C.c_size_t
 lib.orc_bench_count_index.argtypes = [_u8p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32,
                                       C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
 lib.orc_bench_count_index.restype = C.c_double
@@ -234,6 +248,55 @@ class CountMap:
     def erase(self, q):
         q = np.ascontiguousarray(q, dtype=np.uint64).reshape(-1, self.s.n_words)
         return lib.orc_count_map_erase(self.h, q, q.shape[0])
+
+
+def dbg_parse(s, data):
+    """de_bruijn_parser over a FASTQ buffer: (k-mers as parsed, DNA16 edge bytes: left << 4 | right)"""
+    b = _as_bytes(data)
+    n = lib.orc_dbg_parse(C.byref(s), b, b.size, None, None, 0)
+    if n < 0:
+        raise ValueError("parse error")
+    kmers = np.zeros((n, s.n_words), dtype=np.uint64)
+    edges = np.zeros(n, dtype=np.uint8)
+    lib.orc_dbg_parse(C.byref(s), b, b.size, _ptr(kmers), _ptr(edges), n)
+    return kmers, edges
+
+
+class DbgMap:
+    """de_bruijn_nodes_distributed restatement: nodes = (k-mer, [out ACGT, in ACGT, self]); canonical=True gives every node
+    in the orientation of its lexicographically smaller strand"""
+
+    def __init__(self, s, exists_only=False, store_hash=MURMUR):
+        self.s = s
+        self.h = lib.orc_dbg_map_create(C.byref(s), store_hash, int(exists_only))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib.orc_dbg_map_destroy(self.h)
+            self.h = None
+
+    def insert(self, kmers, edges):
+        kmers = np.ascontiguousarray(kmers, dtype=np.uint64).reshape(-1, self.s.n_words)
+        edges = np.ascontiguousarray(edges, dtype=np.uint8)
+        assert edges.shape[0] == kmers.shape[0]
+        lib.orc_dbg_map_insert(self.h, kmers, edges, kmers.shape[0])
+
+    def size(self):
+        return lib.orc_dbg_map_size(self.h)
+
+    def export(self, canonical=True):
+        n = self.size()
+        keys = np.zeros((n, self.s.n_words), dtype=np.uint64)
+        counts = np.zeros((n, 9), dtype=np.uint32)
+        lib.orc_dbg_map_export(self.h, _ptr(keys), _ptr(counts), int(canonical))
+        return keys, counts
+
+    def find(self, q, canonical=True):
+        q = np.ascontiguousarray(q, dtype=np.uint64).reshape(-1, self.s.n_words)
+        keys = np.zeros((q.shape[0], self.s.n_words), dtype=np.uint64)
+        counts = np.zeros((q.shape[0], 9), dtype=np.uint32)
+        n = lib.orc_dbg_map_find(self.h, q, q.shape[0], _ptr(keys), _ptr(counts), int(canonical))
+        return keys[:n], counts[:n]
 
 
 class MultiMap:
