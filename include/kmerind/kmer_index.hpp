@@ -126,6 +126,15 @@ class Kmer {
     data[0] = (data[0] << bitsPerChar) | (static_cast<WORD_TYPE>(c) & ((WORD_TYPE(1) << bitsPerChar) - 1));
     sanitize();
   }
+  // Kmer::nextReverseFromChar (kmer.hpp:758-768): the window moves one base to the left, c becomes the oldest base
+  void nextReverseFromChar(unsigned char c) {
+    for (unsigned w = 0; w + 1 < nWords; ++w) data[w] = (data[w] >> bitsPerChar) | (data[w + 1] << (64 - bitsPerChar));
+    data[nWords - 1] >>= bitsPerChar;
+    constexpr unsigned top = (size - 1) * bitsPerChar;
+    data[top / 64] |= (static_cast<WORD_TYPE>(c) & ((WORD_TYPE(1) << bitsPerChar) - 1)) << (top % 64);
+    if ((top % 64) + bitsPerChar > 64) data[top / 64 + 1] |= (static_cast<WORD_TYPE>(c) & ((WORD_TYPE(1) << bitsPerChar) - 1)) >> (64 - top % 64);
+    sanitize();
+  }
   void sanitize() {
     constexpr unsigned inv_pad = 64 - (nWords * 64 - nBits);
     if (inv_pad < 64) data[nWords - 1] &= ((WORD_TYPE(1) << inv_pad) - 1);

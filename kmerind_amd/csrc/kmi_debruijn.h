@@ -63,16 +63,23 @@ __global__ __launch_bounds__(256) void dbg_edges_kernel(uint64_t *__restrict__ r
 
 // The accumulate pass keeps, per workgroup, a table of one chunk of a bucket's nodes (key -> row) and eight counters per row.
 template <int NW> struct DbgCfg {
-  static constexpr int CAP = (NW == 1) ? 4096 : 2048;    // home slots
+  static constexpr int CAP = (NW == 1) ? 6144 : 2048;    // home slots
   static constexpr int PAD = TabCfg<NW>::PAD;
   static constexpr int SLOTS = CAP + PAD;
-  static constexpr int ROWS = CAP * 3 / 4;               // nodes per chunk
-  static constexpr int NT = 512;
+  static constexpr int ROWS = CAP * 3 / 4;               // nodes per chunk (one-word keys: 4608, i.e. 1.5e8 nodes per index before a
+                                                         // bucket of average size needs a second chunk)
+  static constexpr int NT = 1024;
 };
 
-// Fine bucket b: edges[node][0..7] += the edge bits of the bucket's records (+ the counts of the nodes that were there before
-// the insert, whose positions have changed). The nodes of the bucket are distinct keys at known positions, so the table is
-// filled once per chunk of ROWS nodes and only read afterwards; the counters live in LDS and leave as whole rows.
+// Fine bucket b: edges[node][0..7] = the edge bits of the bucket's records added up (+ the counts of the nodes that were there
+// before the insert, whose positions have changed). The nodes of the bucket are distinct keys at known positions, so the table
+// is filled once per chunk of ROWS nodes and only read afterwards.
+//
+// Counters: 16 bits each in LDS, two to a word, exact beyond that: an add returns the word as it was, so exactly one add sees
+// each carry out of a low half (n1 of them) and each wrap of the whole word (n2); with the halves lo, hi that are left,
+//   sum of the low counter  = lo + 65536 n1          sum of the high counter = hi + 65536 n2 - n1     (mod 2^32, as int32 wraps)
+// The adds that see one send the correction to `edges` with a global atomic and mark the row; a marked row leaves with atomic
+// adds too, every other row (all of them, outside homopolymer-like repeats) as plain stores into the zero-filled array.
 template <int NW>
 __global__ __launch_bounds__((DbgCfg<NW>::NT)) void dbg_accumulate_kernel(const uint64_t *__restrict__ idx_keys, const uint64_t *__restrict__ idx_off,
                                                                          const uint64_t *__restrict__ recs, const uint64_t *__restrict__ rec_off,
@@ -81,12 +88,13 @@ __global__ __launch_bounds__((DbgCfg<NW>::NT)) void dbg_accumulate_kernel(const 
   using Cfg = DbgCfg<NW>;
   constexpr int RW = NW + 1;
   __shared__ uint64_t s_tk[Cfg::SLOTS * NW];
-  __shared__ uint32_t s_tv[Cfg::SLOTS];
   __shared__ uint32_t s_tt[(NW == 1) ? 1 : Cfg::SLOTS];
-  __shared__ uint32_t s_cnt[Cfg::ROWS * 8];
+  __shared__ uint16_t s_row[Cfg::SLOTS];
+  __shared__ uint32_t s_cnt[Cfg::ROWS * 4];
+  __shared__ uint32_t s_mark[(Cfg::ROWS + 31) / 32];
   __shared__ uint32_t s_ctl[8];
   LdsTable<NW> tab;
-  tab.keys = s_tk; tab.vals = s_tv; tab.tags = s_tt; tab.distinct = &s_ctl[0]; tab.overflow = &s_ctl[1];
+  tab.keys = s_tk; tab.vals = nullptr; tab.tags = s_tt; tab.distinct = &s_ctl[0]; tab.overflow = &s_ctl[1];
   tab.special = &s_ctl[2]; tab.special_set = &s_ctl[3]; tab.progress = &s_ctl[5];
   tab.cap = Cfg::CAP; tab.slots = Cfg::SLOTS; tab.limit = 2u * Cfg::CAP;   // (never "too loaded": the chunk size bounds the load)
   uint32_t *s_fail = &s_ctl[6], *s_special_row = &s_ctl[7];
@@ -96,24 +104,41 @@ __global__ __launch_bounds__((DbgCfg<NW>::NT)) void dbg_accumulate_kernel(const 
   const uint64_t rb = recs ? rec_off[b] : 0ull, re = recs ? rec_off[b + 1] : 0ull;
   const uint64_t ob = old_keys ? old_off[b] : 0ull, oe = old_keys ? old_off[b + 1] : 0ull;
   if (rb == re && ob == oe) return;
+  uint64_t i0 = ib;
   auto row_of = [&](const uint64_t (&k)[NW]) -> uint32_t {
     const int s = table_find<NW>(tab, k, place_hash<NW>(k));
-    return s >= 0 ? tab.vals[s] : (s == -2 ? *s_special_row : ~0u);
+    return s >= 0 ? (uint32_t)s_row[s] : (s == -2 ? *s_special_row : ~0u);
+  };
+  // counter t of `row` += a (a < 65536)
+  auto add = [&](uint32_t row, uint32_t t, uint32_t a) {
+    uint32_t *g = edges + (i0 + row) * 8u;
+    if (t & 1u) {
+      const uint32_t old = atomicAdd(&s_cnt[row * 4u + (t >> 1)], a << 16);
+      if ((old >> 16) + a > 0xFFFFu) { atomicOr(&s_mark[row >> 5], 1u << (row & 31u)); atomicAdd(&g[t], 65536u); }
+    } else {
+      const uint32_t old = atomicAdd(&s_cnt[row * 4u + (t >> 1)], a);
+      if ((old & 0xFFFFu) + a > 0xFFFFu) {
+        atomicOr(&s_mark[row >> 5], 1u << (row & 31u));
+        atomicAdd(&g[t], 65536u);
+        atomicAdd(&g[t + 1u], 0xFFFFFFFFu);                                   // the carry sits in the neighbour
+        if ((uint64_t)old + a > 0xFFFFFFFFull) atomicAdd(&g[t + 1u], 65536u);   // ... and made the word wrap
+      }
+    }
   };
   uint32_t chunk = Cfg::ROWS;
-  uint64_t i0 = ib;
   while (i0 < ie) {
     const uint32_t nc = (uint32_t)((ie - i0) < (uint64_t)chunk ? (ie - i0) : (uint64_t)chunk);
-    table_clear<NW>(tab);
-    for (uint32_t x = threadIdx.x; x < nc * 8u; x += blockDim.x) s_cnt[x] = 0;
-    if (threadIdx.x == 0) { *s_fail = 0; *s_special_row = ~0u; }
+    for (uint32_t x = threadIdx.x; x < (uint32_t)Cfg::SLOTS; x += blockDim.x) { if (NW == 1) s_tk[x] = kEmptyKey; else s_tt[x] = kTagEmpty; }
+    for (uint32_t x = threadIdx.x; x < nc * 4u; x += blockDim.x) s_cnt[x] = 0;
+    for (uint32_t x = threadIdx.x; x < (nc + 31u) / 32u; x += blockDim.x) s_mark[x] = 0;
+    if (threadIdx.x == 0) { s_ctl[0] = s_ctl[1] = s_ctl[2] = s_ctl[3] = s_ctl[5] = 0; *s_fail = 0; *s_special_row = ~0u; }
     lds_barrier();
     for (uint32_t j = threadIdx.x; j < nc; j += blockDim.x) {
       uint64_t k[NW];
 #pragma unroll
       for (int w = 0; w < NW; ++w) k[w] = idx_keys[(i0 + j) * NW + w];
       const int s = table_upsert<NW>(tab, k, place_hash<NW>(k));
-      if (s >= 0) tab.vals[s] = j; else if (s == -2) *s_special_row = j; else *s_fail = 1;
+      if (s >= 0) s_row[s] = (uint16_t)j; else if (s == -2) *s_special_row = j; else *s_fail = 1;
     }
     lds_barrier();
     if (*s_fail) {   // a probe sequence ran off the end of the table (one-word keys do not wrap around): fewer nodes per chunk
@@ -129,7 +154,7 @@ __global__ __launch_bounds__((DbgCfg<NW>::NT)) void dbg_accumulate_kernel(const 
       for (int w = 0; w < NW; ++w) k[w] = recs[i * RW + w];
       const uint32_t row = row_of(k);
       if (row == ~0u) continue;   // a node of another chunk
-      while (e) { atomicAdd(&s_cnt[row * 8u + (uint32_t)__builtin_ctz(e)], 1u); e &= e - 1u; }
+      while (e) { add(row, (uint32_t)__builtin_ctz(e), 1u); e &= e - 1u; }
     }
     for (uint64_t i = ob + threadIdx.x; i < oe; i += blockDim.x) {
       uint64_t k[NW];
@@ -138,10 +163,19 @@ __global__ __launch_bounds__((DbgCfg<NW>::NT)) void dbg_accumulate_kernel(const 
       const uint32_t row = row_of(k);
       if (row == ~0u) continue;
 #pragma unroll
-      for (int t = 0; t < 8; ++t) { const uint32_t c = old_edges[i * 8u + t]; if (c) atomicAdd(&s_cnt[row * 8u + t], c); }
+      for (uint32_t t = 0; t < 8u; ++t) {
+        const uint32_t c = old_edges[i * 8u + t];
+        if (c & 0xFFFFu) add(row, t, c & 0xFFFFu);
+        if (c >> 16) { atomicOr(&s_mark[row >> 5], 1u << (row & 31u)); atomicAdd(&edges[(i0 + row) * 8u + t], c & 0xFFFF0000u); }
+      }
     }
     lds_barrier();
-    for (uint32_t x = threadIdx.x; x < nc * 8u; x += blockDim.x) { const uint32_t c = s_cnt[x]; if (c) edges[i0 * 8u + x] += c; }
+    for (uint32_t x = threadIdx.x; x < nc * 8u; x += blockDim.x) {
+      const uint32_t row = x >> 3, t = x & 7u;
+      const uint32_t c = (s_cnt[row * 4u + (t >> 1)] >> ((t & 1u) * 16u)) & 0xFFFFu;
+      if ((s_mark[row >> 5] >> (row & 31u)) & 1u) { if (c) atomicAdd(&edges[i0 * 8u + x], c); }
+      else edges[i0 * 8u + x] = c;
+    }
     lds_barrier();
     i0 += nc;
   }

@@ -132,6 +132,30 @@ def test_bucket_with_more_nodes_than_one_table_chunk(ctx):
     assert fk.shape[0] == hot[::5].shape[0] and (_nodes(fk, fc) == _nodes(*om.find(hot[::5], canonical=True))).all()
 
 
+def test_edge_counts_beyond_16_bits(ctx):
+    """the accumulate pass counts in 16-bit halves and sends carries on separately: one k-mer 150 000 times with every edge
+    bit set, another 70 000 times with alternating edges, twice (the second insert also carries the earlier counts over)"""
+    import kmerind_amd as K
+    k = 31
+    s = orc.kspec(k)
+    rng = np.random.default_rng(11)
+    hot = np.array([[0x0123456789ABCDE], [0x0FEDCBA98765432]], dtype=np.uint64)
+    om = orc.DbgMap(s)
+    g = K.DeBruijnNodes(ctx, K.make_config(k))
+    for rnd in range(2):
+        keys = np.concatenate([np.repeat(hot[:1], 150_000, axis=0), np.repeat(hot[1:], 70_000, axis=0),
+                               rng.integers(0, 1 << 62, size=(30_000, 1), dtype=np.uint64)])
+        edges = np.concatenate([np.full(150_000, 0xFF, np.uint8), np.tile(np.array([0x21, 0x12], np.uint8), 35_000),
+                                rng.integers(0, 256, size=30_000).astype(np.uint8)])
+        perm = rng.permutation(keys.shape[0])
+        keys, edges = keys[perm], edges[perm]
+        om.insert(keys, edges)
+        g.insert(keys, edges)
+        assert (_nodes(*g.to_vector()) == _nodes(*om.export(canonical=True))).all()
+    fk, fc = g.find(hot)
+    assert sorted(int(c.max()) for c in fc) == [140_000, 300_000]
+
+
 def test_full_size_properties(ctx):
     """1 M reads (120 M k-mers): occurrences sum to the k-mer count, edge totals miss one per read end, the node keys are the
     count index's keys; a sampled set of nodes agrees with the oracle"""
@@ -161,3 +185,70 @@ def test_full_size_properties(ctx):
     g2 = K.DeBruijnNodes(ctx, cfg)
     g2.build(head)
     assert (_nodes(*g2.to_vector()) == _nodes(*om.export(canonical=True))).all()
+
+
+def test_build_over_rccl_one_rank_self_exchange(monkeypatch):
+    """kmi_dbg_build_dist_host with KMI_FORCE_DIST=1 (one GPU, one-rank communicator): parse -> tuples grouped by KeyToRank of
+    the canonical k-mer -> grouped ncclSend / ncclRecv -> insert; twice, so the second build meets the nodes of the first"""
+    import ctypes as C
+    import kmerind_amd as K
+    from kmerind_amd import _lib as L
+    monkeypatch.setenv("KMI_FORCE_DIST", "1")
+    ctx = K.Context(0, rank=0, nranks=1)
+    comm = C.c_void_p()
+    ctx.check(L.lib.kmi_comm_create(ctx.h, None, C.byref(comm)))
+    try:
+        k = 31
+        s = orc.kspec(k)
+        om = orc.DbgMap(s)
+        g = K.DeBruijnNodes(ctx, K.make_config(k))
+        for seed in (4, 5):
+            data = np.frombuffer(_with_n(bytes(K.synth_fastq(seed=seed, genome_len=8000, n_reads=2000)), seed), dtype=np.uint8).copy()
+            ctx.check(L.lib.kmi_dbg_build_dist_host(g.h, comm, data.ctypes.data_as(C.c_void_p), data.size))
+            om.insert(*orc.dbg_parse(s, data))
+            n = C.c_uint64()
+            ctx.check(L.lib.kmi_dbg_size_dist(g.h, comm, C.byref(n)))
+            assert n.value == om.size()
+            assert (_nodes(*g.to_vector()) == _nodes(*om.export(canonical=True))).all()
+        g.close()
+    finally:
+        L.lib.kmi_comm_destroy(comm)
+        ctx.close()
+
+
+def test_reference_sample_program_through_the_facade():
+    """examples/de_bruijn_graph_construction.cpp (the reference's sample with kmerind/de_bruijn.hpp): node counts and checksums
+    of find(), the neighbours node_utils derives, and the whole map"""
+    import re
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "examples", "de_bruijn_graph_construction")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.join(root, "examples"), "de_bruijn_graph_construction"])
+    path = os.path.join(GOLD, "test.debruijn.small.fastq")
+    out = subprocess.run([exe, path], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    k = 21
+    s = orc.kspec(k)
+    data = open(path, "rb").read()
+    kmers, edges = orc.dbg_parse(s, data)
+    q = kmers[: kmers.shape[0] // 2] if kmers.shape[0] > 50 else kmers
+    mask = np.uint64((1 << (2 * k)) - 1)
+    for tag, exists in (("count", False), ("exist", True)):
+        m = re.search(tag + r" nodes (\d+) size (\d+) found (\d+) keysum (\d+) edgesum (\d+) nbrsum (\d+) a_out_t_in (\d+)", out.stdout)
+        assert m, out.stdout
+        got = tuple(int(x) for x in m.groups())
+        om = orc.DbgMap(s, exists_only=exists)
+        om.insert(kmers, edges)
+        fk, fc = om.find(q, canonical=True)
+        w = np.arange(1, 9, dtype=np.uint64)
+        nbr = 0
+        for key, c in zip(fk[:, 0].tolist(), fc.tolist()):
+            for i in range(4):
+                if c[i]:
+                    nbr += (((key << 2) | i) & int(mask)) % 1000003          # nextFromChar
+                if c[4 + i]:
+                    nbr += ((key >> 2) | (i << (2 * (k - 1)))) % 1000003     # nextReverseFromChar
+        ak, ac = om.export(canonical=True)
+        assert got == (om.size(), om.size(), fk.shape[0], int(fk[:, 0].sum()), int((fc[:, :8].astype(np.uint64) * w).sum()), nbr,
+                       int(ac[:, 0].astype(np.uint64).sum() + ac[:, 7].astype(np.uint64).sum()))
