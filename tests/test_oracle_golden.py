@@ -330,3 +330,32 @@ def test_identity_and_std_hashers_follow_the_cited_formulas():
     h = ((w[0] << 1) ^ (w[1] << 1) ^ (w[2] << 1)) & M
     assert int(orc.kmer_hash(s3, orc.STD, False, km3)[0]) == h
     assert int(orc.kmer_hash(s3, orc.STD, True, km3)[0]) == h >> (64 - 32)
+
+
+def test_std_hasher_against_the_standard_library_the_reference_calls():
+    """cpp_std (kmer_hash.hpp:154-198) = xor of ::std::hash<size_t> of the words, shifted left by one: evaluated here with the
+    toolchain's own std::hash<size_t> (oracle/std_hash_probe.cpp), for one-, two- and three-word k-mers; this pins the
+    third-party half of the hasher (the Kmer word layout is row a1's)"""
+    import ctypes as C
+    import subprocess
+    so = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "libkmerind_stdprobe.so")
+    if not os.path.exists(so):
+        subprocess.check_call(["make", "-C", os.path.dirname(so), "libkmerind_stdprobe.so"], stdout=subprocess.DEVNULL)
+    probe = C.CDLL(so).orc_probe_std_hash_size_t
+    probe.argtypes, probe.restype = [C.c_size_t], C.c_size_t
+    M = (1 << 64) - 1
+    rng = np.random.default_rng(4)
+    for k, alpha in ((31, orc.DNA), (21, orc.DNA), (33, orc.DNA), (63, orc.DNA5), (96, orc.DNA), (16, orc.DNA16)):
+        s = orc.kspec(k, alpha)
+        km = rng.integers(0, 1 << 63, size=(64, s.n_words), dtype=np.uint64)
+        km[:, -1] &= np.uint64((1 << (64 - (s.n_words * 64 - s.n_bits))) - 1)           # pad bits are zero in a Kmer
+        want = []
+        for row in km.tolist():
+            h = 0                                   # leftover == 0: the word array is a whole number of size_t
+            for w in row:
+                h ^= (probe(w) << 1) & M
+            want.append(h)
+        got = orc.kmer_hash(s, orc.STD, False, km)
+        assert [int(x) for x in got] == want
+        shift = min(s.n_bits, 64) - min(32, s.n_bits)
+        assert [int(x) for x in orc.kmer_hash(s, orc.STD, True, km)] == [h >> shift for h in want]
