@@ -66,10 +66,12 @@ def main():
     ap.add_argument("--cpu-sample-reads", type=int, default=500_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the extract-only / insert-only / query rates (outside the timed steps)")
-    ap.add_argument("--dist-mode", default="auto", choices=["auto", "combine", "raw"],
-                    help="N > 1: 'combine' reduces the rank's own reads first and exchanges (k-mer, count) pairs; 'raw' routes "
-                         "every k-mer occurrence as the reference does (kmi_extract_route_dev + insert); 'auto' combines when the "
-                         "rank's own reads cover the genome at least 2.5 times (the pairs are then a fraction of the occurrences)")
+    ap.add_argument("--dist-mode", default="auto", choices=["auto", "superkmer", "combine", "raw"],
+                    help="N > 1: 'superkmer' exchanges 16-byte super-k-mer records (about nine k-mers each) and keeps a k-mer on the "
+                         "owner of its minimizer's bucket; 'combine' reduces the rank's own reads first and exchanges (k-mer, count) "
+                         "pairs; 'raw' routes every k-mer occurrence as the reference does (kmi_extract_route_dev + insert); 'auto': "
+                         "super-k-mers over 2 / 4 / 8 ranks, else combine when the rank's own reads cover the genome at least 2.5 "
+                         "times (the pairs are then a fraction of the occurrences), else raw")
     ap.add_argument("--force-dist", action="store_true",
                     help="run the N > 1 code path (routing + all_to_all_single + insert) even with one rank: exercises the RCCL calls on one GPU")
     ap.add_argument("--chunks", type=int, default=4, help="N > 1: chunks per step (exchange of one overlaps parsing of the next)")
@@ -139,8 +141,9 @@ def main():
 
     # expected k-mer coverage of the genome by ONE rank's reads: what a local reduction can take out before the exchange
     local_cov = n_kmers / float(genome_len)
-    dist_mode = args.dist_mode if args.dist_mode != "auto" else ("combine" if local_cov >= 2.5 else "raw")
-    combine = multi and dist_mode == "combine"
+    dist_mode = args.dist_mode if args.dist_mode != "auto" else \
+        ("superkmer" if world in (2, 4, 8) else ("combine" if local_cov >= 2.5 else "raw"))
+    combine = multi and dist_mode in ("combine", "superkmer")     # both run through kmerind_amd.dist.DistributedCountIndex
     nch = 1
     if combine:
         # N > 1, combine-first (kmerind_amd.dist.DistributedCountIndex): local count index of the rank's reads (the one-rank
@@ -148,6 +151,13 @@ def main():
         didx = kdist.DistributedCountIndex(ctx, cfg, stage_through_host=(args.backend != "nccl"), device=dev)
         idx.close()
         idx = didx.index
+        sk_bounds = None
+        if dist_mode == "superkmer":
+            # the step goes through in record-aligned chunks: the records of chunk c travel over xGMI while chunk c + 1 is cut
+            # into super-k-mers (chunk starts on multiples of 16 records = 16-byte aligned addresses)
+            nch = max(1, min(args.chunks, n_reads // 16))
+            rec_bytes = nbytes // n_reads
+            sk_bounds = [((n_reads * c // nch) // 16 * 16) * rec_bytes for c in range(nch)] + [nbytes]
     elif multi:
         # N > 1: the batch goes through in NCH record-aligned chunks. Chunk c is parsed and grouped by destination rank
         # on the device (kmi_extract_route_dev: read_file + the bucketing half of imxx::distribute, fused) while the
@@ -176,7 +186,7 @@ def main():
             idx.build_device(d_bytes.data_ptr(), nbytes)
             return
         if combine:
-            didx.build_device(d_bytes.data_ptr(), nbytes, dev)     # (its first exchange carries checksums)
+            didx.build_device(d_bytes.data_ptr(), nbytes, dev, mode=dist_mode, bounds=sk_bounds)     # (its first exchange carries checksums)
             verified = True
             return
         pos, works = 0, []
@@ -294,7 +304,9 @@ def main():
                           "exchange": "none (1 rank)" if not multi else
                           "%s all_to_all_single (counts + payload), %d chunks per step, overlapped with parsing" %
                           ("RCCL" if args.backend == "nccl" else "gloo (rehearsal)", nch) if not combine else
-                          "%s all_to_all_single of locally reduced (k-mer, count) pairs + per-bucket counts" %
+                          ("%%s all_to_all_single of 16-byte super-k-mer records (owner = the minimizer bucket's rank), %d chunks per step, "
+                           "overlapped with the next chunk's front end" % nch if dist_mode == "superkmer"
+                           else "%s all_to_all_single of locally reduced (k-mer, count) pairs + per-bucket counts") %
                           ("RCCL" if args.backend == "nccl" else "gloo (rehearsal)")},
                "roofline": roofline}
         if multi:

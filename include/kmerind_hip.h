@@ -98,6 +98,7 @@ void kmi_free_host(void *p);
 kmi_status kmi_device_alloc(kmi_ctx *ctx, size_t bytes, void **dptr);
 kmi_status kmi_device_free(kmi_ctx *ctx, void *dptr);
 kmi_status kmi_copy_to_device(kmi_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
+kmi_status kmi_copy_on_device(kmi_ctx *ctx, void *dst_dev, const void *src_dev, size_t bytes); /* on the context's stream, completed on return */
 kmi_status kmi_copy_to_host(kmi_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
 kmi_status kmi_synchronize(kmi_ctx *ctx);
 
@@ -314,6 +315,32 @@ kmi_status kmi_index_count_dist_host(kmi_index *idx, kmi_comm *comm, const uint6
 kmi_status kmi_index_find_dist_host(kmi_index *idx, kmi_comm *comm, const uint64_t *queries, size_t nq, kmi_results *out);
 kmi_status kmi_index_erase_dist_host(kmi_index *idx, kmi_comm *comm, const uint64_t *queries, size_t nq, uint64_t *n_erased_local);
 kmi_status kmi_index_size_dist(kmi_index *idx, kmi_comm *comm, uint64_t *n);
+
+/* ---- a count index over 2, 4 or 8 ranks through exchanged super-k-mers ---------------
+ * The reference's distributed insert sends every k-mer to KeyToRank(k-mer) (8 bytes per k-mer over the wire,
+ * distributed_unordered_map.hpp:1697-1745). For FASTQ input and one-word DNA k-mers (17 <= k <= 32) the fused build cuts
+ * the reads into super-k-mers first (runs of k-mers that share a minimizer: 16 bytes for about nine k-mers), so the
+ * exchange can move those instead: the owner of a k-mer is then the rank that owns its MINIMIZER's bucket (the top
+ * log2(nranks) bits of the 18 bucket bits), not hash(k-mer) % nranks. Which rank holds a k-mer is not observable through
+ * Index (count / find / erase / size are collectives); the union of the ranks' maps is the reference's map, bit for bit.
+ *   produce: this rank's FASTQ share -> records grouped by owner rank in library workspace (*records_dev, valid until the
+ *            next call on the context; 2 words per record), send_counts_host[nranks] in records. *produced = 0: this
+ *            path does not apply (shape, rank count) or an input exceeded a capacity of the fused front end -- EVERY
+ *            rank must then take the k-mer route for this input (agree on min(*produced) over ranks first);
+ *   (caller: all-to-all of the records, 16-byte elements)
+ *   consume: the records that arrived (flat array, any order of sources) -> this rank's part of the index;
+ *   kmi_route_owner_dev: query keys (transformed as the index's strand model says) grouped by owner rank, the
+ *            counterpart of kmi_route_dev for an index built this way; kmi_index_owner_ranks tells how an index was built
+ *            (1 = by kmi_index_build / insert: route with kmi_route_dev); kmi_index_set_owner_ranks declares it for an
+ *            index that is filled with k-mers routed by kmi_route_owner_dev only (an input none of whose parts could
+ *            be produced as records). */
+kmi_status kmi_index_sk_produce_dev(kmi_index *idx, const uint8_t *bytes_dev, size_t n_bytes, uint32_t nranks,
+                                    const uint64_t **records_dev, uint64_t *n_records, uint64_t *send_counts_host, int *produced);
+kmi_status kmi_index_sk_consume_dev(kmi_index *idx, const uint64_t *records_dev, size_t n_records, uint32_t nranks);
+kmi_status kmi_route_owner_dev(kmi_ctx *ctx, const kmi_config *cfg, const uint64_t *keys_dev, size_t n, uint32_t nranks,
+                               uint64_t *out_keys_dev, uint64_t *send_counts_host);
+kmi_status kmi_index_owner_ranks(kmi_index *idx, uint32_t *nranks);
+kmi_status kmi_index_set_owner_ranks(kmi_index *idx, uint32_t nranks);
 
 /* ---- de Bruijn graph nodes ------------------------------------------------------
  * The reference's in-tree consumer of Index: de_bruijn_engine<NodeMap> = Index<NodeMap, de_bruijn_parser>

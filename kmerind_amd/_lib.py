@@ -69,6 +69,7 @@ SIGNATURES = {
     "kmi_device_free": (C.c_int, [_P, _P]),
     "kmi_copy_to_device": (C.c_int, [_P, _P, _P, _sz]),
     "kmi_copy_to_host": (C.c_int, [_P, _P, _P, _sz]),
+    "kmi_copy_on_device": (C.c_int, [_P, _P, _P, _sz]),
     "kmi_synchronize": (C.c_int, [_P]),
     "kmi_revcomp_host": (C.c_int, [_P, _CFG, _P, _sz, _P]),
     "kmi_canonical_host": (C.c_int, [_P, _CFG, _P, _sz, _P]),
@@ -122,6 +123,11 @@ SIGNATURES = {
     "kmi_index_find_dist_host": (C.c_int, [_P, _P, _P, _sz, C.POINTER(Results)]),
     "kmi_index_erase_dist_host": (C.c_int, [_P, _P, _P, _sz, C.POINTER(_u64)]),
     "kmi_index_size_dist": (C.c_int, [_P, _P, C.POINTER(_u64)]),
+    "kmi_index_sk_produce_dev": (C.c_int, [_P, _P, _sz, _u32, C.POINTER(_P), C.POINTER(_u64), _P, C.POINTER(C.c_int)]),
+    "kmi_index_sk_consume_dev": (C.c_int, [_P, _P, _sz, _u32]),
+    "kmi_route_owner_dev": (C.c_int, [_P, _CFG, _P, _sz, _u32, _P, _P]),
+    "kmi_index_owner_ranks": (C.c_int, [_P, C.POINTER(_u32)]),
+    "kmi_index_set_owner_ranks": (C.c_int, [_P, _u32]),
     "kmi_dbg_create": (C.c_int, [_P, _CFG, _u32, C.POINTER(_P)]),
     "kmi_dbg_destroy": (C.c_int, [_P]),
     "kmi_dbg_clear": (C.c_int, [_P]),

@@ -233,6 +233,12 @@ class CountIndex:
 
     size = local_size  # single-rank view; kmerind_amd.dist adds the all-reduce
 
+    def owner_ranks(self):
+        """1, or the rank count of the build through exchanged super-k-mers that filled this index (kmi_index_sk_consume_dev)"""
+        n = C.c_uint32()
+        self.ctx.check(lib.kmi_index_owner_ranks(self.h, C.byref(n)))
+        return n.value
+
     # combine-first distributed insert (kmerind_hip.h): split the entries by destination rank / merge received parts
     def split_by_rank_device(self, nranks, keys_dptr, counts_dptr, capacity, bucket_counts_dptr):
         """-> send counts per rank (numpy uint64). Device buffers: keys [capacity * n_words] u64, counts [capacity] u32,

@@ -232,6 +232,13 @@ kmi_status kmi_copy_to_host(kmi_ctx *ctx, void *dst_host, const void *src_dev, s
   return KMI_OK;
 }
 
+kmi_status kmi_copy_on_device(kmi_ctx *ctx, void *dst_dev, const void *src_dev, size_t bytes) {
+  if (!ctx) return KMI_ERR_INVALID;
+  if (bytes) KMI_HIP(ctx, hipMemcpyAsync(dst_dev, src_dev, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+  KMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return KMI_OK;
+}
+
 kmi_status kmi_synchronize(kmi_ctx *ctx) {
   if (!ctx) return KMI_ERR_INVALID;
   KMI_HIP(ctx, hipStreamSynchronize(ctx->stream));

@@ -60,7 +60,8 @@ template <int RW> struct PartCfg {
 };
 
 // BUCKET_REC: super-k-mer records (kmi_superkmer.h): the fine bucket sits in bits 46..52 of the record's second word
-enum BucketMode { BUCKET_COARSE = 0, BUCKET_SUB = 1, BUCKET_RANK = 2, BUCKET_REC = 3 };
+// BUCKET_REC_COARSE: its coarse bucket, bits 53..60 (records that arrived from other ranks are sorted by it first)
+enum BucketMode { BUCKET_COARSE = 0, BUCKET_SUB = 1, BUCKET_RANK = 2, BUCKET_REC = 3, BUCKET_REC_COARSE = 4 };
 
 struct BucketFn {
   int mode; KShape shape; uint32_t dist_hash; bool farm_ndebug; uint32_t nranks;
@@ -68,6 +69,8 @@ struct BucketFn {
   uint32_t dist_trans = 0;   // rank mode: KMI_DIST_* applied to the key before DistHash (single-strand model only)
   uint32_t layout_w = 0;     // coarse / sub modes: 0 = the index is laid out by placement hash; W = by minimizer bucket (fine15_of_key)
   uint64_t rank_magic = 0;   // rank mode: floor(2^64 / nranks) for rank counts that are no power of two (rank_of_hash)
+  uint32_t owner_w = 0;      // rank mode: W = the rank is the owner of the key's minimizer bucket (the top log2(nranks) bucket bits:
+                             // where a build through exchanged super-k-mers put it), not KeyToRank's hash
 };
 inline uint64_t rank_magic_of(uint32_t nranks) { return nranks > 1u ? (uint64_t)(((unsigned __int128)1 << 64) / nranks) : 0ull; }
 // h % p without a division: a mask for 2, 4, 8 ... ranks; else q = mulhi(h, floor(2^64 / p)) is the quotient or one
@@ -93,13 +96,23 @@ inline uint32_t rank_sub_buckets(uint32_t nranks) { uint32_t s = 1; while (s * 2
 // kmi_index::layout_w says which, and every partition of keys for that index uses the same function.
 template <int NW> __device__ __forceinline__ uint32_t fine15_of_key(const uint64_t (&key)[NW], uint32_t layout_w, uint32_t k) {
   if constexpr (NW == 1) {
-    if (layout_w) return sk_key_bucket18(key[0], k, layout_w) >> 3;   // uniform
+    if (layout_w) {   // uniform. layout_w = W | lp << 8: an index built over 2^lp ranks dropped the lp top bucket bits (its rank)
+      const uint32_t lp = layout_w >> 8;
+      return ((sk_key_bucket18(key[0], k, layout_w & 0xffu) << lp) & 0x3ffffu) >> 3;
+    }
   }
   return fine_of(place_hash<NW>(key));
 }
 
 template <int NW> __device__ __forceinline__ uint32_t bucket_of(const uint64_t (&key)[NW], const BucketFn &f) {
   if (f.mode == BUCKET_RANK) {
+    if constexpr (NW == 1) {
+      if (f.owner_w) {   // uniform (nranks is a power of two here)
+        const uint32_t h18 = sk_key_bucket18(key[0], f.shape.k, f.owner_w);
+        const uint32_t lp = 31u - (uint32_t)__builtin_clz(f.nranks);
+        return (h18 >> (18u - lp)) * f.sub + ((h18 >> 3) & (f.sub - 1u));
+      }
+    }
     uint64_t t[NW];
 #pragma unroll
     for (int w = 0; w < NW; ++w) t[w] = key[w];
@@ -332,6 +345,7 @@ __device__ __forceinline__ void scatter_range(const uint64_t *__restrict__ in, u
           for (int w = 0; w < NW; ++w) k[j][w] = kr[w];
         }
         if (VW > 0 && fn.mode == BUCKET_REC) bk[j] = (uint32_t)(v[j][0] >> 46) & (uint32_t)(kSubPerCoarse - 1);
+        else if (VW > 0 && fn.mode == BUCKET_REC_COARSE) bk[j] = (uint32_t)(v[j][0] >> 53) & (uint32_t)(kNumCoarse - 1);
         else bk[j] = bucket_of<NW>(k[j], fn);
         rk[j] = atomicAdd(&s_cnt[bk[j]], 1u);
       }
@@ -2285,6 +2299,7 @@ struct kmi_index {
   uint64_t *bucket_off = nullptr; // [kNumFine + 1]
   uint64_t n_entries = 0;
   bool has_data = false;
+  uint32_t owner_lp = 0;          // the entries are this rank's share of a build over 2^owner_lp ranks by minimizer-bucket owner (sk_consume)
   bool find_emits_index = false;  // find() of a counting map reports entry positions instead of counts (kmi_debruijn.h)
   uint32_t layout_w = 0;          // what the fine buckets mean: 0 = top bits of the placement hash; W = minimizer bucket (fine15_of_key)
   size_t keys_bytes = 0, vals_bytes = 0, mvals_bytes = 0;   // sizes of the blocks above (for the context's spare list)
@@ -2531,16 +2546,26 @@ static kmi_status build_fused_impl(kmi_index *idx, const uint8_t *bytes_dev, siz
 
 // Index::build_* on one rank through super-k-mers (kmi_superkmer.h): FASTQ, one-word 2-bit k-mers, k >= 17.
 // returns KMI_OK with *done = false when the input does not fit the item capacities (the k-mer pipeline takes over)
+// The super-k-mer build in two halves, so that a build over several ranks can put its exchange between them.
+// Front end: FASTQ scan -> window runs -> minimizer items -> 16-byte records grouped by the top 8 bucket bits (WS_KEYS_A),
+// the groups of workgroup g at wg_off[g][c]. h_cnt / h_base: records and start of every group.
+struct SkFront {
+  bool ok = false;                 // false: a run or a tile exceeded its item capacity (the caller takes the k-mer path)
+  uint64_t *recs = nullptr;        // WS_KEYS_A
+  uint64_t n_records = 0, n_kmers = 0;
+  uint64_t h_cnt[kNumCoarse], h_base[kNumCoarse];
+  uint64_t *wg_off = nullptr;      // [kPartGroups][kNumCoarse] (WS_CURSOR)
+};
+
 template <int W>
-static kmi_status build_superkmer_w(kmi_index *idx, const FastqScan &sc, bool *done) {
+static kmi_status sk_front_end(kmi_ctx *ctx, const kmi_config *cfg, const KShape &shape, const FastqScan &sc, uint32_t lp, SkFront *f) {
   constexpr int NW = 1, BITS = 2;
-  kmi_ctx *ctx = idx->ctx;
-  *done = false;
+  f->ok = false;
   const uint64_t n = sc.n_tuples, n_tiles = sc.n_tiles;
-  const uint32_t k = idx->shape.k;
+  const uint32_t k = shape.k;
   PackedInput in; in.eol = sc.pk_eol; in.stream = sc.pk_stream; in.n_bytes = sc.n_bytes; in.n_cover = sc.n_cover; in.n_valid = sc.n_bytes; in.brk = sc.pk_brk;
   const bool split = sc.pk_brk != nullptr;
-  const bool canonical = idx->cfg.strand != KMI_STRAND_SINGLE;
+  const bool canonical = cfg->strand != KMI_STRAND_SINGLE;
   using LP = ListPassCfg<NW, BITS>;
   const uint32_t seg = sk_segment_of((uint32_t)W), ipt = sk_items_per_tile((uint32_t)W);
   const uint32_t stride = LP::run_stride(k, seg, split);
@@ -2551,12 +2576,7 @@ static kmi_status build_superkmer_w(kmi_index *idx, const FastqScan &sc, bool *d
   KMI_TRY(ws_get(ctx, WS_SK_ITEMS, sizeof(uint32_t) * ((size_t)n_tiles * ipt + 64), &p)); uint32_t *items = (uint32_t *)p;
   KMI_TRY(ws_get(ctx, WS_WGHIST, sizeof(uint32_t) * kPartGroups * kNumCoarse, &p)); uint32_t *wg_hist = (uint32_t *)p;
   KMI_TRY(ws_get(ctx, WS_CURSOR, sizeof(uint64_t) * kPartGroups * kNumCoarse, &p)); uint64_t *wg_off = (uint64_t *)p;
-  KMI_TRY(ws_get(ctx, WS_MISC, sizeof(uint64_t) * kNumCoarse * 3, &p)); uint64_t *cnt = (uint64_t *)p, *base = cnt + kNumCoarse, *cend = base + kNumCoarse;
-  KMI_TRY(ws_get(ctx, WS_HIST, sizeof(uint32_t) * kNumFine * kFineParts + sizeof(uint64_t) * ((kNumFine + 1) * 2 + kNumFine * kFineParts + kNumCoarse) + 256, &p));
-  uint32_t *fine_hist = (uint32_t *)p;
-  uint64_t *fine_off = (uint64_t *)((char *)p + sizeof(uint32_t) * kNumFine * kFineParts);
-  uint64_t *part_off = fine_off + 2 * (kNumFine + 1);
-  uint64_t *coarse_base = part_off + (uint64_t)kNumFine * kFineParts;
+  KMI_TRY(ws_get(ctx, WS_MISC, sizeof(uint64_t) * kNumCoarse * 3, &p)); uint64_t *cnt = (uint64_t *)p, *base = cnt + kNumCoarse;
   KMI_HIP(ctx, hipMemsetAsync(ctx->d_flags + 9, 0, sizeof(uint32_t), ctx->stream));
   {
     ProfScope ps(ctx, "fastq_list", n);
@@ -2581,20 +2601,45 @@ static kmi_status build_superkmer_w(kmi_index *idx, const FastqScan &sc, bool *d
   KMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
   KMI_TRY(fastq_length_verdict(ctx));     // the seq / qual length rule rode on the list pass: the index stays as it was on a parse error
   if (h_flag) return KMI_OK;              // a run with more items than a lane's list holds, or a tile with more than its share
-  uint64_t R = 0, h_end[kNumCoarse];
-  for (int c = 0; c < kNumCoarse; ++c) { R += h_cnt[c]; h_end[c] = h_cnt[kNumCoarse + c] + h_cnt[c]; }
-  KMI_HIP(ctx, hipMemcpyAsync(cend, h_end, sizeof(h_end), hipMemcpyHostToDevice, ctx->stream));
+  uint64_t R = 0;
+  for (int c = 0; c < kNumCoarse; ++c) { R += h_cnt[c]; f->h_cnt[c] = h_cnt[c]; f->h_base[c] = h_cnt[kNumCoarse + c]; }
   KMI_TRY(ws_get(ctx, WS_KEYS_A, (R + 64) * 16, &p)); uint64_t *rec_a = (uint64_t *)p;
-  KMI_TRY(ws_get(ctx, WS_KEYS_B, (R + 64) * 16, &p)); uint64_t *rec_b = (uint64_t *)p;
   {
     ProfScope ps(ctx, "sk_scatter", n);
     if (canonical)
       hipLaunchKernelGGL(sk_scatter_kernel<true>, dim3(kPartGroups), dim3(kSkThreads), 0, ctx->stream, in, n_tiles, k, (const uint32_t *)ent,
-                         (const uint32_t *)ent_cnt, stride, ipt, (const uint32_t *)items, (const uint32_t *)run_items, (const uint64_t *)wg_off, rec_a);
+                         (const uint32_t *)ent_cnt, stride, ipt, (const uint32_t *)items, (const uint32_t *)run_items, (const uint64_t *)wg_off, rec_a, lp);
     else
       hipLaunchKernelGGL(sk_scatter_kernel<false>, dim3(kPartGroups), dim3(kSkThreads), 0, ctx->stream, in, n_tiles, k, (const uint32_t *)ent,
-                         (const uint32_t *)ent_cnt, stride, ipt, (const uint32_t *)items, (const uint32_t *)run_items, (const uint64_t *)wg_off, rec_a);
+                         (const uint32_t *)ent_cnt, stride, ipt, (const uint32_t *)items, (const uint32_t *)run_items, (const uint64_t *)wg_off, rec_a, lp);
   }
+  KMI_HIP(ctx, hipGetLastError());
+  f->ok = true; f->recs = rec_a; f->n_records = R; f->n_kmers = n; f->wg_off = wg_off;
+  return KMI_OK;
+}
+
+// Back end: records grouped by coarse bucket (rec_a; group c = [h_base[c], h_base[c] + h_cnt[c]), written by kPartGroups
+// workgroups at wg_off[g][c]) -> fine buckets -> sk_reduce -> the index (layout W | lp << 8), or added to what it holds.
+template <int W>
+static kmi_status sk_back_end(kmi_index *idx, const uint64_t *rec_a, uint64_t R, const uint64_t *h_cnt, const uint64_t *h_base, const uint64_t *wg_off,
+                              uint64_t n, uint32_t lp) {
+  constexpr int NW = 1;
+  kmi_ctx *ctx = idx->ctx;
+  const uint32_t k = idx->shape.k;
+  const bool canonical = idx->cfg.strand != KMI_STRAND_SINGLE;
+  void *p;
+  KMI_TRY(ws_get(ctx, WS_WGHIST, sizeof(uint32_t) * kPartGroups * kNumCoarse, &p)); uint32_t *wg_hist = (uint32_t *)p;   // (not read by fine_offsets)
+  KMI_TRY(ws_get(ctx, WS_MISC, sizeof(uint64_t) * kNumCoarse * 3, &p)); uint64_t *cend = (uint64_t *)p + 2 * kNumCoarse;
+  KMI_TRY(ws_get(ctx, WS_HIST, sizeof(uint32_t) * kNumFine * kFineParts + sizeof(uint64_t) * ((kNumFine + 1) * 2 + kNumFine * kFineParts + kNumCoarse) + 256, &p));
+  uint32_t *fine_hist = (uint32_t *)p;
+  uint64_t *fine_off = (uint64_t *)((char *)p + sizeof(uint32_t) * kNumFine * kFineParts);
+  uint64_t *part_off = fine_off + 2 * (kNumFine + 1);
+  uint64_t *coarse_base = part_off + (uint64_t)kNumFine * kFineParts;
+  uint64_t h_end[kNumCoarse];
+  for (int c = 0; c < kNumCoarse; ++c) h_end[c] = h_base[c] + h_cnt[c];
+  KMI_HIP(ctx, hipMemcpyAsync(cend, h_end, sizeof(h_end), hipMemcpyHostToDevice, ctx->stream));
+  KMI_HIP(ctx, hipStreamSynchronize(ctx->stream));   // (h_end is a stack array)
+  KMI_TRY(ws_get(ctx, WS_KEYS_B, (R + 64) * 16, &p)); uint64_t *rec_b = (uint64_t *)p;
   KMI_TRY(ws_get(ctx, WS_SPLIT_OFF, sizeof(uint32_t) * kNumFine * kFineParts + sizeof(uint64_t) * ((kNumFine + 1) + kNumFine * kFineParts + kNumCoarse) + 256, &p));
   uint32_t *fine_kmers = (uint32_t *)p;
   uint64_t *kmer_off = (uint64_t *)((char *)p + sizeof(uint32_t) * kNumFine * kFineParts);
@@ -2652,12 +2697,12 @@ static kmi_status build_superkmer_w(kmi_index *idx, const FastqScan &sc, bool *d
             hf[12], hf[16], hf[17], hf[18], hf[19]);
     (void)hipMemset(ctx->d_flags + 10, 0, 3 * sizeof(uint32_t));
   }
-  *done = true;
+  const uint32_t layout = (uint32_t)W | (lp << 8);
   if (!idx->has_data || idx->n_entries == 0) {
     // the index IS the reduce output: entries grouped by minimizer bucket. Queries partition their keys by the same function
     // (fine15_of_key); whatever needs the placement-hash layout converts the entries once (ensure_layout).
     KMI_TRY((adopt_tmp<NW>(idx, tmp_keys, tmp_vals, kmer_off, nullptr, out_cnt)));
-    idx->layout_w = (uint32_t)W;
+    idx->layout_w = layout;
     return KMI_OK;
   }
   // the index holds entries already: the new ones become a scratch index, whose pairs are added to the old
@@ -2675,6 +2720,83 @@ static kmi_status build_superkmer_w(kmi_index *idx, const FastqScan &sc, bool *d
   (void)hipStreamSynchronize(ctx->stream);
   free_index_arrays(&scratch);
   return st;
+}
+
+template <int W>
+static kmi_status build_superkmer_w(kmi_index *idx, const FastqScan &sc, bool *done) {
+  *done = false;
+  SkFront f;
+  KMI_TRY((sk_front_end<W>(idx->ctx, &idx->cfg, idx->shape, sc, 0u, &f)));
+  if (!f.ok) return KMI_OK;
+  *done = true;
+  return sk_back_end<W>(idx, f.recs, f.n_records, f.h_cnt, f.h_base, f.wg_off, f.n_kmers, 0u);
+}
+
+// ---- a build over 2^lp ranks through exchanged super-k-mer records ------------------------------------------------------
+// produce: the front end; the records leave grouped by owner rank (the owner of a record = the top lp bits of its bucket bits;
+// groups of 256 / nranks consecutive coarse buckets), send_counts = records per rank.
+template <int W>
+static kmi_status sk_produce_w(kmi_index *idx, const uint8_t *bytes_dev, size_t n_bytes, uint32_t nranks, const uint64_t **recs_out, uint64_t *n_records,
+                               uint64_t *send_counts, int *produced) {
+  kmi_ctx *ctx = idx->ctx;
+  *produced = 0; *recs_out = nullptr; *n_records = 0;
+  for (uint32_t r = 0; r < nranks; ++r) send_counts[r] = 0;
+  if (n_bytes == 0) { *produced = 1; return KMI_OK; }
+  FastqScan sc;
+  KMI_TRY(fastq_scan(ctx, &idx->cfg, bytes_dev, n_bytes, &sc, false));
+  if (sc.n_tuples == 0) { KMI_TRY(fastq_length_verdict(ctx)); *produced = 1; return KMI_OK; }
+  const uint32_t lp = 31u - (uint32_t)__builtin_clz(nranks);
+  SkFront f;
+  KMI_TRY((sk_front_end<W>(ctx, &idx->cfg, idx->shape, sc, lp, &f)));
+  if (!f.ok) return KMI_OK;
+  const uint32_t per = (uint32_t)kNumCoarse / nranks;
+  for (uint32_t c = 0; c < (uint32_t)kNumCoarse; ++c) send_counts[c / per] += f.h_cnt[c];
+  *recs_out = f.recs; *n_records = f.n_records; *produced = 1;
+  KMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return KMI_OK;
+}
+
+// consume: what arrived (a flat record array; inside every source's part the records are grouped by the sender's buckets, whose
+// low lp bits are not the receiver's coarse bucket bits) is sorted by coarse bucket once, then takes the back end
+template <int W>
+static kmi_status sk_consume_w(kmi_index *idx, const uint64_t *recs_dev, uint64_t R, uint32_t nranks) {
+  kmi_ctx *ctx = idx->ctx;
+  if (R == 0) return KMI_OK;
+  const uint32_t lp = 31u - (uint32_t)__builtin_clz(nranks);
+  void *p;
+  KMI_TRY(ws_get(ctx, WS_WGHIST, sizeof(uint32_t) * kPartGroups * kNumCoarse, &p)); uint32_t *wg_hist = (uint32_t *)p;
+  KMI_TRY(ws_get(ctx, WS_CURSOR, sizeof(uint64_t) * kPartGroups * kNumCoarse, &p)); uint64_t *wg_off = (uint64_t *)p;
+  KMI_TRY(ws_get(ctx, WS_MISC, sizeof(uint64_t) * kNumCoarse * 3, &p)); uint64_t *cnt = (uint64_t *)p, *base = cnt + kNumCoarse;
+  KMI_TRY(ws_get(ctx, WS_KEYS_A, (R + 64) * 16, &p)); uint64_t *rec_a = (uint64_t *)p;
+  KMI_HIP(ctx, hipMemsetAsync(ctx->d_totals + 6, 0, sizeof(uint64_t), ctx->stream));
+  {
+    ProfScope ps(ctx, "sk_recv_hist", R);
+    hipLaunchKernelGGL(sk_recv_hist_kernel, dim3(kPartGroups), dim3(kPartThreads), 0, ctx->stream, recs_dev, R, wg_hist, (unsigned long long *)(ctx->d_totals + 6));
+  }
+  {
+    ProfScope ps(ctx, "sk_offsets", kNumCoarse);
+    launch_rank_offsets(ctx->stream, (const uint32_t *)wg_hist, (uint32_t)kPartGroups, (uint32_t)kNumCoarse, cnt, base, wg_off);
+  }
+  BucketFn fn; fn.mode = BUCKET_REC_COARSE; fn.shape = idx->shape; fn.dist_hash = 0; fn.farm_ndebug = false; fn.nranks = 1; fn.sub = 1;
+  {
+    ProfScope ps(ctx, "sk_recv_scatter", R);
+    hipLaunchKernelGGL((scatter_chunks_kernel<1, 2, 1>), dim3(kPartGroups), dim3(kPartThreads), 0, ctx->stream, recs_dev, R, rec_a, idx->shape, 0u, false, fn,
+                       (const uint64_t *)wg_off);
+  }
+  KMI_HIP(ctx, hipGetLastError());
+  uint64_t h[2 * kNumCoarse], n_kmers = 0;
+  KMI_HIP(ctx, hipMemcpyAsync(h, cnt, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+  KMI_HIP(ctx, hipMemcpyAsync(&n_kmers, ctx->d_totals + 6, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+  KMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  KMI_TRY((sk_back_end<W>(idx, rec_a, R, h, h + kNumCoarse, wg_off, n_kmers, lp)));
+  idx->owner_lp = lp;
+  return KMI_OK;
+}
+
+// which W the super-k-mer paths take for this index (0: they do not apply)
+static uint32_t sk_width_of(const kmi_index *idx) {
+  return (idx->val_words == 0 && idx->shape.n_words == 1 && idx->shape.bits == 2 && idx->ctx->fused_superkmer && idx->cfg.seq_format == KMI_FMT_FASTQ)
+             ? sk_window_of(idx->shape.k) : 0u;
 }
 
 static kmi_status index_build_fused(kmi_index *idx, const uint8_t *bytes_dev, size_t n_bytes) {
@@ -2980,6 +3102,35 @@ static kmi_status route_vw(kmi_ctx *ctx, const kmi_config *cfg, KShape shape, co
     ProfScope ps(ctx, "scatter_rank", n);
     hipLaunchKernelGGL((scatter_chunks_kernel<NW, BITS, VW>), dim3(kPartGroups), dim3(kPartThreads), 0, ctx->stream, keys_dev, (uint64_t)n,
                        out_keys_dev, shape, cfg->strand, true, fn, (const uint64_t *)wg_off);
+  }
+  KMI_HIP(ctx, hipGetLastError());
+  return read_rank_counts(ctx, cnt, nranks, fn.sub, send_counts_host);
+}
+
+// queries (and anything else keyed by k-mer) to the rank that owns the key's minimizer bucket
+static kmi_status route_owner(kmi_ctx *ctx, const kmi_config *cfg, KShape shape, const uint64_t *keys_dev, size_t n, uint32_t nranks,
+                              uint64_t *out_keys_dev, uint64_t *send_counts_host) {
+  void *p;
+  KMI_TRY(ws_get(ctx, WS_WGHIST, sizeof(uint32_t) * kPartGroups * kNumCoarse, &p)); uint32_t *wg_hist = (uint32_t *)p;
+  KMI_TRY(ws_get(ctx, WS_CURSOR, sizeof(uint64_t) * kPartGroups * kNumCoarse, &p)); uint64_t *wg_off = (uint64_t *)p;
+  KMI_TRY(ws_get(ctx, WS_MISC, sizeof(uint64_t) * kNumCoarse * 2, &p)); uint64_t *cnt = (uint64_t *)p;
+  BucketFn fn; fn.mode = BUCKET_RANK; fn.shape = shape; fn.dist_hash = cfg->dist_hash; fn.farm_ndebug = cfg->farm_ndebug != 0; fn.nranks = nranks;
+  fn.dist_trans = 0; fn.rank_magic = rank_magic_of(nranks);
+  fn.sub = rank_sub_buckets(nranks);
+  fn.owner_w = sk_window_of(shape.k);
+  const uint32_t nb = nranks * fn.sub;
+  {
+    ProfScope ps(ctx, "hist_rank", n);
+    hipLaunchKernelGGL((hist_rank_kernel<1, 2, 0>), dim3(kPartGroups), dim3(kPartThreads), 0, ctx->stream, keys_dev, (uint64_t)n, shape, cfg->strand, fn, wg_hist);
+  }
+  {
+    ProfScope ps(ctx, "rank_offsets", nb);
+    launch_rank_offsets(ctx->stream, (const uint32_t *)wg_hist, (uint32_t)kPartGroups, nb, cnt, cnt + kNumCoarse, wg_off);
+  }
+  {
+    ProfScope ps(ctx, "scatter_rank", n);
+    hipLaunchKernelGGL((scatter_chunks_kernel<1, 2, 0>), dim3(kPartGroups), dim3(kPartThreads), 0, ctx->stream, keys_dev, (uint64_t)n, out_keys_dev, shape,
+                       cfg->strand, true, fn, (const uint64_t *)wg_off);
   }
   KMI_HIP(ctx, hipGetLastError());
   return read_rank_counts(ctx, cnt, nranks, fn.sub, send_counts_host);
@@ -3325,7 +3476,7 @@ kmi_status kmi_index_clear(kmi_index *idx) {
   KMI_HIP(ctx, hipSetDevice(ctx->device));
   KMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
   free_index_arrays(idx);
-  idx->n_entries = 0; idx->has_data = false;
+  idx->n_entries = 0; idx->has_data = false; idx->owner_lp = 0;
   return KMI_OK;
 }
 
@@ -3867,6 +4018,61 @@ kmi_status kmi_dbg_build_dist_host(kmi_dbg *g, kmi_comm *comm, const uint8_t *by
 kmi_status kmi_dbg_size_dist(kmi_dbg *g, kmi_comm *comm, uint64_t *n) {
   if (!g) return KMI_ERR_INVALID;
   return kmi_index_size_dist(g->nodes, comm, n);
+}
+
+// ---- builds over ranks through exchanged super-k-mer records
+kmi_status kmi_index_sk_produce_dev(kmi_index *idx, const uint8_t *bytes_dev, size_t n_bytes, uint32_t nranks, const uint64_t **records_dev,
+                                    uint64_t *n_records, uint64_t *send_counts_host, int *produced) {
+  if (!idx || !records_dev || !n_records || !send_counts_host || !produced) return KMI_ERR_INVALID;
+  kmi_ctx *ctx = idx->ctx;
+  KMI_HIP(ctx, hipSetDevice(ctx->device));
+  *produced = 0; *records_dev = nullptr; *n_records = 0;
+  const uint32_t w = sk_width_of(idx);
+  if (!w || nranks < 2 || nranks > 8 || (nranks & (nranks - 1u))) return KMI_OK;   // not a case of this path: the caller routes k-mers
+  if (ctx->sk_dbg == 7) return KMI_OK;   // (test knob: as if the input had exceeded a capacity of the front end)
+  if (n_bytes) KMI_TRY(align_input(ctx, &bytes_dev, n_bytes));
+  return w == 19u ? sk_produce_w<19>(idx, bytes_dev, n_bytes, nranks, records_dev, n_records, send_counts_host, produced)
+       : (w == 13u ? sk_produce_w<13>(idx, bytes_dev, n_bytes, nranks, records_dev, n_records, send_counts_host, produced)
+                   : sk_produce_w<7>(idx, bytes_dev, n_bytes, nranks, records_dev, n_records, send_counts_host, produced));
+}
+
+kmi_status kmi_index_sk_consume_dev(kmi_index *idx, const uint64_t *records_dev, size_t n_records, uint32_t nranks) {
+  if (!idx) return KMI_ERR_INVALID;
+  kmi_ctx *ctx = idx->ctx;
+  KMI_HIP(ctx, hipSetDevice(ctx->device));
+  const uint32_t w = sk_width_of(idx);
+  if (!w || nranks < 2 || nranks > 8 || (nranks & (nranks - 1u))) return set_err(ctx, KMI_ERR_INVALID, "no super-k-mer build for this index / rank count");
+  if (n_records && !records_dev) return set_err(ctx, KMI_ERR_INVALID, "null buffer");
+  return w == 19u ? sk_consume_w<19>(idx, records_dev, n_records, nranks) : (w == 13u ? sk_consume_w<13>(idx, records_dev, n_records, nranks)
+                                                                                       : sk_consume_w<7>(idx, records_dev, n_records, nranks));
+}
+
+kmi_status kmi_index_set_owner_ranks(kmi_index *idx, uint32_t nranks) {
+  if (!idx) return KMI_ERR_INVALID;
+  if (nranks == 0 || nranks > 8 || (nranks & (nranks - 1u))) return set_err(idx->ctx, KMI_ERR_INVALID, "owner ranks: 1, 2, 4 or 8");
+  if (idx->has_data && idx->n_entries && (1u << idx->owner_lp) != nranks)
+    return set_err(idx->ctx, KMI_ERR_INVALID, "the index holds entries distributed another way");
+  idx->owner_lp = 31u - (uint32_t)__builtin_clz(nranks);
+  return KMI_OK;
+}
+
+kmi_status kmi_index_owner_ranks(kmi_index *idx, uint32_t *nranks) {
+  if (!idx || !nranks) return KMI_ERR_INVALID;
+  *nranks = 1u << idx->owner_lp;
+  return KMI_OK;
+}
+
+kmi_status kmi_route_owner_dev(kmi_ctx *ctx, const kmi_config *cfg, const uint64_t *keys_dev, size_t n, uint32_t nranks, uint64_t *out_keys_dev,
+                               uint64_t *send_counts_host) {
+  if (!ctx) return KMI_ERR_INVALID;
+  KShape shape;
+  if (!valid_config(cfg, &shape)) return set_err(ctx, KMI_ERR_INVALID, "bad kmi_config");
+  if (shape.n_words != 1 || shape.bits != 2 || sk_window_of(shape.k) == 0 || nranks < 2 || nranks > 8 || (nranks & (nranks - 1u)) || !send_counts_host)
+    return set_err(ctx, KMI_ERR_INVALID, "owner routing is for one-word DNA k-mers over 2, 4 or 8 ranks");
+  KMI_HIP(ctx, hipSetDevice(ctx->device));
+  for (uint32_t r = 0; r < nranks; ++r) send_counts_host[r] = 0;
+  if (n == 0) return KMI_OK;
+  return route_owner(ctx, cfg, shape, keys_dev, n, nranks, out_keys_dev, send_counts_host);
 }
 
 }  // extern "C"

@@ -303,7 +303,10 @@ template <bool CANON>
 __global__ __launch_bounds__(kSkThreads, 2) void sk_scatter_kernel(PackedInput in, uint64_t n_tiles, uint32_t k, const uint32_t *__restrict__ ent,
                                                                   const uint32_t *__restrict__ ent_cnt, uint32_t ent_stride, uint32_t items_per_tile,
                                                                   const uint32_t *__restrict__ items, const uint32_t *__restrict__ run_items,
-                                                                  const uint64_t *__restrict__ wg_off, uint64_t *__restrict__ out) {
+                                                                  const uint64_t *__restrict__ wg_off, uint64_t *__restrict__ out, uint32_t lp) {
+  // lp (a build over 2^lp ranks): the records are grouped by the top 8 bucket bits as always -- the top lp of them name the
+  // rank that will own the record -- but carry the bucket bits shifted left by lp: what is left of them is the bucket inside
+  // the owner's index (kmi_index::layout_w holds lp next to W)
   // A round = the runs of up to 512 lanes. Every lane brings the stream words of its run into LDS (three 16-byte loads of
   // consecutive memory: gathering them per RECORD on the way out cost five loads of 64 different lines each). The items are
   // bucket-sorted as 16-bit references (lane of the run << 5 | item number): count per coarse bucket, scan, place. The
@@ -386,7 +389,7 @@ __global__ __launch_bounds__(kSkThreads, 2) void sk_scatter_kernel(PackedInput i
       const uint32_t item = wg_items[s_ioff[rl] + j];
       const uint32_t h18 = item >> 12, n1 = (item >> 7) & 31u;
       uint64_t w0, w1;
-      sk_assemble_row<CANON>(s_row + rl * kSkRowDw, s_bit0[rl] + 2u * (item & 127u), k + n1, n1, h18, w0, w1);
+      sk_assemble_row<CANON>(s_row + rl * kSkRowDw, s_bit0[rl] + 2u * (item & 127u), k + n1, n1, (h18 << lp) & 0x3ffffu, w0, w1);
       reinterpret_cast<ulonglong2 *>(out)[s_gbase[h18 >> 10] + s] = make_ulonglong2(w0, w1);
     }
     SkRound nxt;
@@ -420,6 +423,30 @@ __global__ __launch_bounds__(1024) void sk_fine_count_kernel(const uint64_t *__r
     fine_hist[(uint64_t)h * kNumFine + c * kSubPerCoarse + threadIdx.x] = s_h[threadIdx.x];
     fine_kmers[(uint64_t)h * kNumFine + c * kSubPerCoarse + threadIdx.x] = s_k[threadIdx.x];
   }
+}
+
+// Records that arrived from the other ranks of a build (a flat array, every source's part grouped by the sender's buckets):
+// coarse-bucket counts of every workgroup's chunk (the chunks scatter_chunks_kernel will take) and the k-mers they hold
+__global__ __launch_bounds__(kPartThreads) void sk_recv_hist_kernel(const uint64_t *__restrict__ recs, uint64_t n, uint32_t *__restrict__ wg_hist,
+                                                                   unsigned long long *__restrict__ n_kmers) {
+  __shared__ uint32_t s_h[kNumCoarse];
+  __shared__ unsigned long long s_k;
+  if (threadIdx.x < kNumCoarse) s_h[threadIdx.x] = 0;
+  if (threadIdx.x == 0) s_k = 0ull;
+  lds_barrier();
+  const uint64_t chunk = part_chunk(n, gridDim.x, PartCfg<2>::TILE);
+  const uint64_t b = (uint64_t)blockIdx.x * chunk, e = (b + chunk < n) ? b + chunk : n;
+  unsigned long long km = 0;
+  for (uint64_t i = b + threadIdx.x; i < e; i += blockDim.x) {
+    const uint64_t w1 = recs[2 * i + 1];
+    atomicAdd(&s_h[rec_hash18(w1) >> 10], 1u);
+    km += ((uint32_t)(w1 >> kRecNShift) & 31u) + 1u;
+  }
+  km = wave_reduce_sum(km);
+  if (lane_id() == 0 && km) atomicAdd(&s_k, km);
+  lds_barrier();
+  if (threadIdx.x < kNumCoarse) wg_hist[(uint64_t)blockIdx.x * kNumCoarse + threadIdx.x] = s_h[threadIdx.x];
+  if (threadIdx.x == 0 && s_k) atomicAdd(n_kmers, s_k);
 }
 
 // ---------------------------------------------------------------------------

@@ -168,9 +168,23 @@ class DistributedCountIndex:
             self._bcnt = torch.empty((self.world, self.nb), dtype=torch.int32, device=dev)
         return self._keys, self._counts, self._bcnt
 
-    def build_device(self, dptr, nbytes, device=None):
-        """adds the k-mers of this rank's FASTQ/FASTA partition (device bytes) to the distributed index"""
+    def build_device(self, dptr, nbytes, device=None, mode="auto", bounds=None):
+        """adds the k-mers of this rank's FASTQ/FASTA partition (device bytes) to the distributed index.
+        mode "superkmer": the ranks exchange super-k-mer records (16 bytes for about nine k-mers) and a k-mer lives on the
+        rank that owns its minimizer's bucket (include/kmerind_hip.h, kmi_index_sk_produce_dev); "combine": every rank
+        reduces its own reads first and (k-mer, count) pairs travel to KeyToRank(k-mer); "auto": super-k-mers where they
+        apply (FASTQ, one-word DNA k-mers, 2 / 4 / 8 ranks, an index that is empty or was built that way), else combine.
+        bounds (super-k-mers): byte offsets [0, ..., nbytes] of record-aligned chunks, the same number on every rank -- the
+        exchange of one chunk then travels while the next one is cut into records. self.last_mode says which mode ran."""
         device = device or self.device
+        if mode in ("auto", "superkmer") and self._build_superkmer(dptr, nbytes, device, bounds):
+            self.last_mode = "superkmer"
+            return
+        if mode == "superkmer":
+            raise RuntimeError("the super-k-mer exchange does not apply to this index / rank count")
+        if self.index.owner_ranks() > 1:
+            raise RuntimeError("this index holds entries distributed by minimizer owner: a KeyToRank-routed insert would split keys over two ranks")
+        self.last_mode = "combine"
         self.scratch.clear()
         self.scratch.build_device(dptr, nbytes)
         n = self.scratch.local_size()
@@ -180,6 +194,108 @@ class DistributedCountIndex:
         rk, rv, rb = exchange_pairs(keys[:n], counts[:n], bcnt, self.group, self.stage, verify=not self._verified)
         self._verified = True
         self.index.merge_parts_device(self.world, rk.data_ptr(), rv.data_ptr(), rb.data_ptr())
+
+    def _staged(self):
+        return self.stage or dist.get_backend(self.group) == "gloo"
+
+    def _build_superkmer(self, dptr, nbytes, device, bounds=None):
+        """-> False when the path does not apply (nothing was exchanged; the caller takes another route). Per chunk: records of
+        the chunk grouped by owner rank (kmi_index_sk_produce_dev) -> all-to-all, asynchronous over RCCL, so it overlaps the
+        next chunk's front end; a chunk the front end cannot take (an item capacity exceeded on some rank) travels as k-mers
+        routed to the same owners. What arrived is consumed in one go (kmi_index_sk_consume_dev)."""
+        import ctypes as C
+        import numpy as np
+        from . import _lib as L
+        staged = self._staged()
+        cdev = torch.device("cpu") if staged else device
+        ok = self.world in (2, 4, 8) and (self.index.local_size() == 0 or self.index.owner_ranks() == self.world)
+        bounds = [0, nbytes] if not bounds else [int(b) for b in bounds]
+        assert bounds[0] == 0 and bounds[-1] == nbytes and all(a <= b for a, b in zip(bounds, bounds[1:]))
+        nch = len(bounds) - 1
+        # every rank or none, and the same number of chunks everywhere (the exchanges are collectives)
+        flag = torch.tensor([int(ok), nch, -nch], dtype=torch.int64, device=cdev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+        if int(flag[0].item()) == 0:
+            return False
+        if int(flag[1].item()) != nch or -int(flag[2].item()) != nch:
+            raise RuntimeError("build_device(bounds=...): the ranks disagree on the number of chunks")
+        self.ctx.check(L.lib.kmi_index_set_owner_ranks(self.index.h, self.world))
+        recv_parts, works, sends, kmer_chunks = [], [], [], []
+        total_sc = [0] * self.world
+        pool, pool_pos = None, 0          # one receive buffer for all chunks (sized after the first one), so nothing is concatenated
+        for c in range(nch):
+            recs_p, n, produced = C.c_void_p(), C.c_uint64(), C.c_int(0)
+            sc = np.zeros(self.world, dtype=np.uint64)
+            self.ctx.check(L.lib.kmi_index_sk_produce_dev(self.index.h, C.c_void_p(dptr + bounds[c]), bounds[c + 1] - bounds[c], self.world,
+                                                          C.byref(recs_p), C.byref(n), sc.ctypes.data_as(C.c_void_p), C.byref(produced)))
+            counts = [int(x) for x in sc]
+            # the send counts go round with the verdict: a rank that could not produce this chunk says so with -1
+            t = torch.tensor(counts if produced.value else [-1] * self.world, dtype=torch.int64, device=cdev)
+            r = torch.empty_like(t)
+            dist.all_to_all_single(r, t, group=self.group)
+            rc = [int(x) for x in r.tolist()]
+            if not produced.value or min(rc) < 0:                      # (every rank hears from every rank: all see the same verdict)
+                kmer_chunks.append(c)
+                continue
+            send = torch.empty((n.value, 2), dtype=torch.int64, device=device)
+            if n.value:
+                self.ctx.check(L.lib.kmi_copy_on_device(self.ctx.h, C.c_void_p(send.data_ptr()), recs_p, n.value * 16))
+            total_sc = [a + b for a, b in zip(total_sc, counts)]
+            n_in = sum(rc)
+            first = not self._verified
+            if staged or first or max(counts + rc + [0]) * 2 > MSG_MAX_WORDS:
+                recv, rc2 = self._exchange_dev(send, counts)          # (synchronous; pieces where a message is too large)
+                assert rc2 == rc
+                if first:
+                    verify_exchange(send, counts, recv, rc, self.group, staged)
+                    self._verified = True
+            else:
+                if pool is None:
+                    pool = torch.empty((int(n_in * (nch - c) * 1.15) + 4096, 2), dtype=torch.int64, device=device)
+                if pool_pos + n_in <= pool.shape[0]:
+                    recv, in_pool = pool[pool_pos:pool_pos + n_in], True
+                    pool_pos += n_in
+                else:
+                    recv, in_pool = torch.empty((n_in, 2), dtype=torch.int64, device=device), False
+                works.append(dist.all_to_all_single(recv, send, output_split_sizes=rc, input_split_sizes=counts, group=self.group, async_op=True))
+                sends.append(send)                                      # stays alive until the transfer has left
+                if in_pool:
+                    continue                                            # (the pool is consumed as one piece)
+            recv_parts.append(recv)
+        for w in works:
+            w.wait()
+        sends.clear()
+        self.last_send_counts = total_sc
+        if pool is not None and pool_pos:
+            recv_parts.append(pool[:pool_pos])
+        if recv_parts:
+            allrecv = recv_parts[0] if len(recv_parts) == 1 else torch.cat(recv_parts)
+            recv_parts.clear()
+            self.ctx.check(L.lib.kmi_index_sk_consume_dev(self.index.h, C.c_void_p(allrecv.data_ptr()), allrecv.shape[0], self.world))
+            del allrecv
+        for c in kmer_chunks:
+            self._owner_routed_kmers(dptr + bounds[c], bounds[c + 1] - bounds[c], device)
+        return True
+
+    def _owner_routed_kmers(self, dptr, nbytes, device):
+        """a chunk as k-mers: parse, group by the owner of the minimizer's bucket, exchange, insert"""
+        import ctypes as C
+        import numpy as np
+        from . import _lib as L
+        nt, ns = C.c_uint64(), C.c_uint64()
+        if nbytes:
+            self.ctx.check(L.lib.kmi_extract_count_dev(self.ctx.h, C.byref(self.cfg), C.c_void_p(dptr), nbytes, C.byref(nt), C.byref(ns)))
+        keys = torch.empty((nt.value + 8, self.n_words), dtype=torch.int64, device=device)
+        send = torch.empty_like(keys)
+        counts = np.zeros(self.world, dtype=np.uint64)
+        if nt.value:
+            self.ctx.check(L.lib.kmi_extract_dev(self.ctx.h, C.byref(self.cfg), C.c_void_p(dptr), nbytes, 0, C.c_void_p(keys.data_ptr()), None,
+                                                 nt.value, C.byref(nt), C.byref(ns)))
+            self.ctx.check(L.lib.kmi_route_owner_dev(self.ctx.h, C.byref(self.cfg), C.c_void_p(keys.data_ptr()), nt.value, self.world,
+                                                     C.c_void_p(send.data_ptr()), counts.ctypes.data_as(C.c_void_p)))
+        recv, _ = self._exchange_dev(send[: nt.value], [int(x) for x in counts])
+        if recv.shape[0]:
+            self.index.insert_device(recv.data_ptr(), recv.shape[0], transformed=True)
 
     # ---- queries (distributed_unordered_map.hpp:880-983 count, :564-687 find, :719-779 erase): transform_input, route the
     # query keys to their owners (imxx::distribute), answer locally per source rank, one return all-to-all. Device buffers
@@ -208,8 +324,10 @@ class DistributedCountIndex:
         d_q = torch.from_numpy(q.view(np.int64)).to(dev)
         d_s = torch.empty_like(d_q)
         counts = np.zeros(self.world, dtype=np.uint64)
-        self.ctx.check(L.lib.kmi_route_dev(self.ctx.h, C.byref(self.cfg), C.c_void_p(d_q.data_ptr()), q.shape[0], self.world,
-                                           C.c_void_p(d_s.data_ptr()), counts.ctypes.data_as(C.c_void_p)))
+        # an index built through exchanged super-k-mers keeps a k-mer on the owner of its minimizer's bucket
+        route = L.lib.kmi_route_owner_dev if self.index.owner_ranks() > 1 else L.lib.kmi_route_dev
+        self.ctx.check(route(self.ctx.h, C.byref(self.cfg), C.c_void_p(d_q.data_ptr()), q.shape[0], self.world,
+                             C.c_void_p(d_s.data_ptr()), counts.ctypes.data_as(C.c_void_p)))
         return self._exchange_dev(d_s, [int(c) for c in counts])
 
     def _answer(self, mode, q):

@@ -46,7 +46,7 @@ def test_bench_starts_its_own_ranks():
     """`python bench.py --gpus 2` with no launcher around it (the driver's form): the script starts two ranks itself and relays
     rank 0's single line. Rehearsal on one GPU: gloo group, both ranks share the card, payload staged through the host."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
-    for mode in ("combine", "raw"):
+    for mode in ("superkmer", "combine", "raw"):
         out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "2", "--warmup", "1",
                               "--reads", "100000", "--genome", "1000000", "--dist-mode", mode], capture_output=True, text=True, timeout=900,
                              cwd=ROOT, env=env)

@@ -1,5 +1,5 @@
-"""Two ranks on one GPU (gloo, payload staged through the host): kmerind_amd.dist.DistributedCountIndex, the combine-first
-N > 1 count build, end to end through the C ABI, against the oracle's single map."""
+"""Two ranks on one GPU (gloo, payload staged through the host): kmerind_amd.dist.DistributedCountIndex -- the N > 1 count build
+through exchanged super-k-mers and the combine-first one -- end to end through the C ABI, against the oracle's single map."""
 import os
 import socket
 
@@ -21,7 +21,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, data, k, strand, ret):
+def _worker(rank, world, port, data, k, strand, mode, ret):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -30,6 +30,9 @@ def _worker(rank, world, port, data, k, strand, ret):
         from kmerind_amd import dist as kdist
         from kmerind_amd import fileio
         dev = torch.device("cuda", 0)
+        if mode == "superkmer-fallback":          # the front end reports "cannot take this input": every chunk goes as k-mers
+            os.environ["KMI_SK_DBG"] = "7"
+            mode = "superkmer"
         ctx = K.Context(0, rank=rank, nranks=world)
         cfg = K.make_config(k, "DNA", strand=strand)
         didx = kdist.DistributedCountIndex(ctx, cfg, stage_through_host=True, device=dev)
@@ -39,7 +42,9 @@ def _worker(rank, world, port, data, k, strand, ret):
             buf = np.frombuffer(data[b:e], dtype=np.uint8)
             pad = (-buf.size) % 16
             d = torch.from_numpy(np.concatenate([buf, np.zeros(pad, np.uint8)])).to(dev)
-            didx.build_device(d.data_ptr(), buf.size, dev)
+            # three record-aligned chunks per call on the super-k-mer route (chunk starts at odd addresses: the library aligns)
+            bounds = None if mode == "combine" else [x[0] for x in fileio.partition_fastq(bytes(buf), 3)] + [buf.size]
+            didx.build_device(d.data_ptr(), buf.size, dev, mode=mode, bounds=bounds)
         keys, cnts = didx.index.to_vector()
         # distributed queries: every rank asks for its own mix of present / absent keys
         rng = np.random.default_rng(100 + rank)
@@ -52,21 +57,25 @@ def _worker(rank, world, port, data, k, strand, ret):
         size_before = didx.size()
         ret[rank] = (keys.copy(), cnts.copy(), size_before, q.copy(), ck.copy(), cv.copy(), fk.copy(), fv.copy())
         didx.erase(present[:50])
-        ret[rank] = ret[rank] + (didx.size(),)
+        ret[rank] = ret[rank] + (didx.size(), didx.last_mode)
         didx.close()
         ctx.close()
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("k,strand", [(31, "canonical"), (21, "single")])
-def test_distributed_count_index_two_ranks_one_gpu(k, strand):
+@pytest.mark.parametrize("k,strand,mode", [(31, "canonical", "combine"), (21, "single", "combine"), (31, "canonical", "superkmer"),
+                                           (21, "single", "superkmer"), (25, "canonical", "auto"), (31, "canonical", "superkmer-fallback")])
+def test_distributed_count_index_two_ranks_one_gpu(k, strand, mode):
+    """combine: (k-mer, count) pairs to KeyToRank(k-mer); superkmer: 16-byte super-k-mer records to the owner of the
+    minimizer's bucket (what "auto" picks for FASTQ and one-word DNA k-mers). Two build calls per rank, so the second one meets
+    the entries of the first; the union of the ranks' maps is the single-rank map either way."""
     import kmerind_amd as K
     world = 2
     data = bytes(K.synth_fastq(seed=9, genome_len=30_000, n_reads=2_000))
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_worker, args=(world, _free_port(), data, k, strand, ret), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), data, k, strand, mode, ret), nprocs=world, join=True)
     s = orc.kspec(k)
     st = orc.CANONICAL if strand == "canonical" else orc.SINGLE
     ref = orc.CountMap(s, st)
@@ -79,7 +88,11 @@ def test_distributed_count_index_two_ranks_one_gpu(k, strand):
     erased = set()
     for r in range(world):
         assert ret[r][2] == ref.size()
-        assert (orc.key_to_rank(s, orc.MURMUR, st, ret[r][0], world) == r).all()
+        assert ret[r][9] == ("combine" if mode == "combine" else "superkmer")
+        if mode == "combine":
+            assert (orc.key_to_rank(s, orc.MURMUR, st, ret[r][0], world) == r).all()
+        else:        # owner = the minimizer bucket's rank: every key on exactly one rank (the union was compared above)
+            assert ret[r][0].shape[0] > 0 and np.unique(keys, axis=0).shape[0] == keys.shape[0]
         # count / find of rank r's own queries against the single-rank map
         q = ret[r][3]
         ek, ec = ref.count(q)
