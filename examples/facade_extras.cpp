@@ -49,6 +49,19 @@ int main(int argc, char **argv) {
       unsigned long long s2 = 0;
       for (auto &e : cidx.to_vector()) s2 += e.second;
       std::printf("update hit %zu halved %zu sum %llu entries %zu\n", hit, halved, s2, cidx.local_size());
+      // the same call with device-side updaters (kmerind::updater): max with 9 on every 7th occurrence, then assign -- the
+      // pairs of one key are applied in input order, so its LAST pair stays (value = input position mod 1000)
+      std::vector<std::pair<KmerType, uint32_t>> up2, up3;
+      for (size_t i = 0; i < tuples.size(); i += 7) up2.push_back(std::make_pair(tuples[i].first, 9u));
+      for (size_t i = 0; i < tuples.size(); i += 3) up3.push_back(std::make_pair(tuples[i].first, (uint32_t)(up3.size() % 1000)));
+      up3.push_back(std::make_pair(KmerType(), 1u));
+      const size_t h2 = cidx.update(up2, false, kmerind::updater::max());
+      unsigned long long s3 = 0;
+      for (auto &e : cidx.to_vector()) s3 += e.second;
+      const size_t h3 = cidx.update(up3, false, kmerind::updater::assign());
+      unsigned long long s4 = 0;
+      for (auto &e : cidx.to_vector()) s4 += e.second;
+      std::printf("device max hit %zu sum %llu assign hit %zu sum %llu\n", h2, s3, h3, s4);
     }
     auto &view = cidx.get_map();
     std::printf("get_map local_size %zu size %zu\n", view.local_size(), view.size());

@@ -67,6 +67,15 @@ struct comm {
   void barrier() const {}
 };
 
+// updaters of Index::update that run on the device (kmi_index_update_pairs_*): op(stored, v) = stored + v, max(stored, v),
+// min(stored, v), v -- each returning 1, so update() returns the number of input pairs whose key is stored
+namespace updater {
+struct add { static constexpr uint32_t KMI = KMI_UPDATE_ADD; };
+struct max { static constexpr uint32_t KMI = KMI_UPDATE_MAX; };
+struct min { static constexpr uint32_t KMI = KMI_UPDATE_MIN; };
+struct assign { static constexpr uint32_t KMI = KMI_UPDATE_ASSIGN; };
+}  // namespace updater
+
 inline void check(kmi_ctx *ctx, kmi_status st) {
   if (st == KMI_OK) return;
   std::string msg = std::string("kmerind_hip: ") + (ctx ? kmi_last_error(ctx) : "error");
@@ -522,6 +531,12 @@ class Index {
     write_back(cur, touched);
     return count;
   }
+  // ... with one of the arithmetic updaters of kmerind::updater the whole call runs on the device: the pairs are partitioned
+  // like queries, every bucket's entries sit in an LDS table and the counts are updated in place (kmi_update.h)
+  size_t update(std::vector<TupleType> &input, bool, ::kmerind::updater::add const &) { return update_on_device(input, KMI_UPDATE_ADD); }
+  size_t update(std::vector<TupleType> &input, bool, ::kmerind::updater::max const &) { return update_on_device(input, KMI_UPDATE_MAX); }
+  size_t update(std::vector<TupleType> &input, bool, ::kmerind::updater::min const &) { return update_on_device(input, KMI_UPDATE_MIN); }
+  size_t update(std::vector<TupleType> &input, bool, ::kmerind::updater::assign const &) { return update_on_device(input, KMI_UPDATE_ASSIGN); }
   template <typename Filter, typename Updater> size_t update(Filter const &fop, Updater const &op) {
     static_assert(MapType::index_kind == KMI_INDEX_COUNT, "update() is a member of the counting / reduction maps");
     std::map<KmerType, ValueType> cur;
@@ -604,6 +619,20 @@ class Index {
   const kmi_config &config() const { return cfg; }
 
  protected:
+  size_t update_on_device(std::vector<TupleType> &input, uint32_t op) {
+    static_assert(MapType::index_kind == KMI_INDEX_COUNT, "update() is a member of the counting / reduction maps");
+    if (comm.size() > 1) throw std::invalid_argument("update with size() > 1 is not wired through the exchange");
+    if (input.empty()) return 0;
+    constexpr unsigned nw = KmerType::nWords;
+    std::vector<uint64_t> rec(input.size() * (nw + 1) + 1);
+    for (size_t i = 0; i < input.size(); ++i) {
+      std::memcpy(&rec[i * (nw + 1)], input[i].first.getData(), sizeof(uint64_t) * nw);
+      rec[i * (nw + 1) + nw] = (uint64_t)input[i].second & 0xffffffffull;
+    }
+    uint64_t n = 0;
+    ::kmerind::check(ctx, kmi_index_update_pairs_host(idx, rec.data(), input.size(), op, &n));
+    return (size_t)n;
+  }
   template <typename Predicate> static std::vector<TupleType> filtered(std::vector<TupleType> v, Predicate const &pred) {
     v.erase(std::remove_if(v.begin(), v.end(), [&](const TupleType &e) { return !pred(e); }), v.end());
     return v;

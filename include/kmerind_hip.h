@@ -316,6 +316,17 @@ kmi_status kmi_index_find_dist_host(kmi_index *idx, kmi_comm *comm, const uint64
 kmi_status kmi_index_erase_dist_host(kmi_index *idx, kmi_comm *comm, const uint64_t *queries, size_t nq, uint64_t *n_erased_local);
 kmi_status kmi_index_size_dist(kmi_index *idx, kmi_comm *comm, uint64_t *n);
 
+/* ---- update() of the counting maps with a device-side updater ------------------------
+ * distributed_densehash_map.hpp:1975-2003 -> densehash_map.hpp:663-714: for every input pair whose transformed key is
+ * stored, op(stored value, pair value); pairs of absent keys are skipped; returns the number of calls. The reference
+ * takes any functor (the facade runs those on the host); the arithmetic updaters have a device form: records as for
+ * kmi_index_insert_pairs_* (key words + one word whose low 32 bits are the value). Pairs with the same key are applied
+ * in input order there: ADD / MAX / MIN do not depend on it, ASSIGN keeps the value of the LAST such pair, as there.
+ * One rank's entries only (the caller routes the pairs with kmi_route_tuples_dev first when size() > 1). */
+enum { KMI_UPDATE_ADD = 0, KMI_UPDATE_MAX = 1, KMI_UPDATE_MIN = 2, KMI_UPDATE_ASSIGN = 3 };
+kmi_status kmi_index_update_pairs_host(kmi_index *idx, const uint64_t *records, size_t n, uint32_t op, uint64_t *n_updated);
+kmi_status kmi_index_update_pairs_dev(kmi_index *idx, const uint64_t *records_dev, size_t n, uint32_t op, uint64_t *n_updated);
+
 /* ---- a count index over 2, 4 or 8 ranks through exchanged super-k-mers ---------------
  * The reference's distributed insert sends every k-mer to KeyToRank(k-mer) (8 bytes per k-mer over the wire,
  * distributed_unordered_map.hpp:1697-1745). For FASTQ input and one-word DNA k-mers (17 <= k <= 32) the fused build cuts

@@ -210,6 +210,17 @@ class CountIndex:
         rec[:, self.n_words] = np.asarray(counts, dtype=np.uint64) & np.uint64(0xFFFFFFFF)
         self.ctx.check(lib.kmi_index_insert_pairs_host(self.h, rec.ctypes.data_as(C.c_void_p), rec.shape[0]))
 
+    def update_pairs(self, kmers, values, op="add"):
+        """update(pairs, op) with a device-side updater (add / max / min / assign): stored keys only -> number of pairs applied"""
+        kmers = _u64(kmers, self.n_words)
+        rec = np.zeros((kmers.shape[0], self.n_words + 1), dtype=np.uint64)
+        rec[:, :self.n_words] = kmers
+        rec[:, self.n_words] = np.asarray(values, dtype=np.uint64) & np.uint64(0xFFFFFFFF)
+        n = C.c_uint64()
+        code = {"add": 0, "max": 1, "min": 2, "assign": 3}[op]
+        self.ctx.check(lib.kmi_index_update_pairs_host(self.h, rec.ctypes.data_as(C.c_void_p), rec.shape[0], code, C.byref(n)))
+        return n.value
+
     def insert_device(self, dptr, n, transformed=False):
         """transformed=True: the keys already went through the InputTransform (routed keys after the exchange)"""
         fn = lib.kmi_index_insert_transformed_dev if transformed else lib.kmi_index_insert_dev

@@ -3275,6 +3275,7 @@ static kmi_status merge_impl(kmi_index *idx, uint32_t nparts, const uint64_t *ke
 }  // namespace kmi
 
 #include "kmi_debruijn.h"
+#include "kmi_update.h"
 
 extern "C" {
 
@@ -4073,6 +4074,38 @@ kmi_status kmi_route_owner_dev(kmi_ctx *ctx, const kmi_config *cfg, const uint64
   for (uint32_t r = 0; r < nranks; ++r) send_counts_host[r] = 0;
   if (n == 0) return KMI_OK;
   return route_owner(ctx, cfg, shape, keys_dev, n, nranks, out_keys_dev, send_counts_host);
+}
+
+// ---- update() with a device-side updater (kmi_update.h)
+kmi_status kmi_index_update_pairs_dev(kmi_index *idx, const uint64_t *records_dev, size_t n, uint32_t op, uint64_t *n_updated) {
+  if (!idx || !n_updated) return KMI_ERR_INVALID;
+  kmi_ctx *ctx = idx->ctx;
+  *n_updated = 0;
+  if (idx->val_words) return set_err(ctx, KMI_ERR_INVALID, "update() is a member of the counting maps");
+  if (op > KMI_UPDATE_ASSIGN) return set_err(ctx, KMI_ERR_INVALID, "unknown updater");
+  KMI_HIP(ctx, hipSetDevice(ctx->device));
+  if (n == 0) return KMI_OK;
+  void *dr;   // (the caller's buffer stays as it is)
+  const size_t bytes = n * (idx->shape.n_words + 1) * sizeof(uint64_t);
+  KMI_TRY(ws_get(ctx, WS_INPUT2, bytes + 64, &dr));
+  KMI_HIP(ctx, hipMemcpyAsync(dr, records_dev, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+  return index_update_pairs(idx, (uint64_t *)dr, n, (int)op, n_updated);
+}
+
+kmi_status kmi_index_update_pairs_host(kmi_index *idx, const uint64_t *records, size_t n, uint32_t op, uint64_t *n_updated) {
+  if (!idx || !n_updated) return KMI_ERR_INVALID;
+  kmi_ctx *ctx = idx->ctx;
+  *n_updated = 0;
+  if (idx->val_words) return set_err(ctx, KMI_ERR_INVALID, "update() is a member of the counting maps");
+  if (op > KMI_UPDATE_ASSIGN) return set_err(ctx, KMI_ERR_INVALID, "unknown updater");
+  if (n == 0) return KMI_OK;
+  if (!records) return set_err(ctx, KMI_ERR_INVALID, "null buffer");
+  KMI_HIP(ctx, hipSetDevice(ctx->device));
+  void *dr;
+  const size_t bytes = n * (idx->shape.n_words + 1) * sizeof(uint64_t);
+  KMI_TRY(ws_get(ctx, WS_INPUT2, bytes + 64, &dr));
+  KMI_HIP(ctx, hipMemcpyAsync(dr, records, bytes, hipMemcpyHostToDevice, ctx->stream));
+  return index_update_pairs(idx, (uint64_t *)dr, n, (int)op, n_updated);
 }
 
 }  // extern "C"

@@ -229,6 +229,13 @@ def test_weighted_insert_iterators_and_posqual_through_the_facade():
     halved = sum(1 for v in val.values() if v >= 20)
     val = {kk: (v // 2 if v >= 20 else v) for kk, v in val.items()}
     assert grab(r"update hit (\d+) halved (\d+) sum (\d+) entries (\d+)") == (len(canon[::11]), halved, sum(val.values()), cm.size())
+    # device-side updaters: max with 9 on every 7th occurrence; assign (the last pair of a key in input order stays)
+    for kk in canon[::7].tolist():
+        val[tuple(kk)] = max(val[tuple(kk)], 9)
+    s3 = sum(val.values())
+    for j, kk in enumerate(canon[::3].tolist()):
+        val[tuple(kk)] = j % 1000
+    assert grab(r"device max hit (\d+) sum (\d+) assign hit (\d+) sum (\d+)") == (len(canon[::7]), s3, len(canon[::3]), sum(val.values()))
     assert grab(r"get_map local_size (\d+) size (\d+)") == (cm.size(), cm.size())
     vals = np.stack([ex["ids"], ex["quals"].view(np.uint32).astype(np.uint64)], axis=1)
     mm = orc.MultiMap(s, orc.CANONICAL, vw=2)

@@ -11,7 +11,7 @@ from tests import oracle as orc
 pytestmark = pytest.mark.gpu
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
-ALPHA = {"DNA": orc.DNA, "DNA5": orc.DNA5}
+ALPHA = {"DNA": orc.DNA, "DNA5": orc.DNA5, "DNA16": orc.DNA16}
 STRAND = {"single": orc.SINGLE, "canonical": orc.CANONICAL, "bimolecule": orc.BIMOLECULE}
 
 
@@ -652,3 +652,42 @@ def test_kmer_pipeline_still_selectable(monkeypatch):
     _same_map(idx, om)
     idx.close()
     c2.close()
+
+
+@pytest.mark.parametrize("k,alpha,strand", [(31, "DNA", "canonical"), (21, "DNA", "single"), (40, "DNA", "canonical"), (16, "DNA16", "single")])
+def test_update_with_device_updaters(k, alpha, strand):
+    """update(pairs, op) (distributed_densehash_map.hpp:1975-2003 -> densehash_map.hpp:663-714) with the device-side updaters:
+    stored keys only, pairs of one key in input order (assign keeps the last), the return value counts the pairs applied"""
+    import kmerind_amd as K
+    ctx = K.Context(0)
+    s = orc.kspec(k, ALPHA[alpha])
+    st = STRAND[strand]
+    data = bytes(K.synth_fastq(seed=k, genome_len=5000, n_reads=1500))
+    kmers = orc.extract(s, data, orc.FASTQ)["kmers"]
+    idx = K.CountIndex(ctx, K.make_config(k, alpha, strand=strand))
+    idx.build(data)
+    om = orc.CountMap(s, st)
+    om.insert(kmers)
+    keys, cnt = om.export()
+    ref = {tuple(a): int(b) for a, b in zip(keys.tolist(), cnt.tolist())}
+    rng = np.random.default_rng(k)
+    absent = orc.extract(s, bytes(K.synth_fastq(seed=91, genome_len=40000, n_reads=20)), orc.FASTQ)["kmers"]
+
+    def canon(q):
+        return q if strand == "single" else orc.canonical(s, q)
+
+    for op in ("add", "max", "min", "assign", "add"):
+        q = np.concatenate([kmers[rng.integers(0, kmers.shape[0], size=6000)], absent, orc.revcomp(s, kmers[:500])])
+        v = rng.integers(0, 50, size=q.shape[0]).astype(np.uint32)
+        hit = 0
+        for kk, x in zip(canon(q).tolist(), v.tolist()):
+            t = tuple(kk)
+            if t not in ref:
+                continue
+            hit += 1
+            ref[t] = {"add": (ref[t] + x) & 0xFFFFFFFF, "max": max(ref[t], x), "min": min(ref[t], x), "assign": x}[op]
+        assert idx.update_pairs(q, v, op) == hit
+        gk, gc = idx.to_vector()
+        assert gk.shape[0] == len(ref) and all(ref[tuple(a)] == int(b) for a, b in zip(gk.tolist(), gc.tolist()))
+    idx.close()
+    ctx.close()
