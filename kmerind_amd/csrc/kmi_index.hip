@@ -2672,7 +2672,7 @@ static kmi_status sk_back_end(kmi_index *idx, const uint64_t *rec_a, uint64_t R,
     const uint32_t nmax = sk_nmax_of(k);
 #define KMI_SK_REDUCE(CANON, OWN)                                                                                                        \
     hipLaunchKernelGGL((sk_reduce_kernel<CANON, OWN>), dim3(kNumFine), dim3(1024), 0, ctx->stream, (const uint64_t *)rec_b,              \
-                       (const uint64_t *)fine_off, k, (const uint64_t *)kmer_off, tmp_keys, tmp_vals, out_cnt, ctx->d_flags, ctx->sk_dbg, ctx->sk_level_hint)
+                       (const uint64_t *)fine_off, k, (const uint64_t *)kmer_off, tmp_keys, tmp_vals, out_cnt, ctx->d_flags, ctx->sk_dbg, ctx->sk_level_hint, lp, ctx->sk_inv_dup)
     if (nmax <= 21u) { if (canonical) KMI_SK_REDUCE(true, 64 * 21); else KMI_SK_REDUCE(false, 64 * 21); }
     else if (nmax <= 24u) { if (canonical) KMI_SK_REDUCE(true, 64 * 24); else KMI_SK_REDUCE(false, 64 * 24); }
     else { if (canonical) KMI_SK_REDUCE(true, 64 * 32); else KMI_SK_REDUCE(false, 64 * 32); }
@@ -2703,12 +2703,14 @@ static kmi_status sk_back_end(kmi_index *idx, const uint64_t *rec_a, uint64_t R,
     // (fine15_of_key); whatever needs the placement-hash layout converts the entries once (ensure_layout).
     KMI_TRY((adopt_tmp<NW>(idx, tmp_keys, tmp_vals, kmer_off, nullptr, out_cnt)));
     idx->layout_w = layout;
+    if (n) ctx->sk_inv_dup = (float)((double)idx->n_entries / (double)n);   // where the buckets of the next build start (sk_reduce_kernel)
     return KMI_OK;
   }
   // the index holds entries already: the new ones become a scratch index, whose pairs are added to the old
   kmi_index scratch;
   scratch.ctx = ctx; scratch.cfg = idx->cfg; scratch.shape = idx->shape; scratch.val_words = 0;
   kmi_status st = adopt_tmp<NW>(&scratch, tmp_keys, tmp_vals, kmer_off, nullptr, out_cnt);
+  if (st == KMI_OK && n) ctx->sk_inv_dup = (float)((double)scratch.n_entries / (double)n);
   if (st == KMI_OK && scratch.n_entries) {
     st = ws_get(ctx, WS_OUTPUT, (scratch.n_entries + 64) * 2 * sizeof(uint64_t), &p);   // (WS_INPUT2 is the re-layout's)
     if (st == KMI_OK) {

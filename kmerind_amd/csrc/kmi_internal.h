@@ -91,6 +91,7 @@ struct kmi_ctx {
   bool fused_superkmer = true;   // fused count-index build through super-k-mers (KMI_FUSED_PATH=kmer in the environment: the k-mer pipeline)
   bool force_dist = false;       // KMI_FORCE_DIST=1: the *_dist_* entry points run their exchange even with one rank (RCCL self exchange: tests)
   uint32_t sk_level_hint = 0;    // sk_reduce: filter bits the buckets of the next build start with (majority of the last build)
+  float sk_inv_dup = 0.f;        // sk_reduce: distinct k-mers per k-mer occurrence of the last build (a bucket's expected fill; 0: unknown)
   int sk_dbg = 0;                // KMI_SK_DBG: timing experiments of sk_reduce (results are wrong when set)
   bool fa_part_set = false;      // kmi_ctx_set_fasta_partition
   kmi_fasta_partition fa_part{};

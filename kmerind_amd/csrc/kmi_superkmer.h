@@ -528,7 +528,9 @@ __global__ __launch_bounds__(1024) void sk_reduce_kernel(const uint64_t *__restr
                                                         const uint64_t *__restrict__ kmer_off /* k-mers before every bucket */,
                                                         uint64_t *__restrict__ tmp_keys, uint32_t *__restrict__ tmp_vals,
                                                         uint32_t *__restrict__ out_cnt, uint32_t *__restrict__ flags, int dbg,
-                                                        uint32_t start_bits /* filter bits every bucket starts with (the level most buckets of the last build ended at) */) {
+                                                        uint32_t start_bits /* filter bits every bucket starts with (the level most buckets of the last build ended at) */,
+                                                        uint32_t lp /* the low lp sub-bucket bits of the records are zero (records received in a build over 2^lp ranks) */,
+                                                        float inv_dup /* distinct k-mers per k-mer occurrence of the context's last build (0: none yet) */) {
   using T = SkTabCfg<OWN_>;
   constexpr int NWAVES = T::NWAVES;
   constexpr uint64_t W1_INIT = ~0ull;   // never a record's second word (its top three bits are zero)
@@ -559,7 +561,16 @@ __global__ __launch_bounds__(1024) void sk_reduce_kernel(const uint64_t *__restr
   const KShape shape = make_shape(k, 2);
   for (uint32_t i = threadIdx.x; i < (uint32_t)(NWAVES * T::OWN / 4); i += T::NT) reinterpret_cast<uint32_t *>(s_own)[i] = 0;
   if (threadIdx.x == 0) {
-    const uint32_t hb = start_bits > 8u ? 8u : start_bits;
+    uint32_t hb = start_bits > 8u ? 8u : start_bits;
+    if (inv_dup > 0.f) {
+      // A bucket that will not fit fails late (the table fills up near the end of the attempt), so a lost attempt costs a whole
+      // pass -- and the buckets that overflow are the large ones. The bucket's k-mer count is known; with the duplication of the
+      // last build it says how many distinct k-mers to expect, and a bucket expected above 88 % of what a pass takes starts one
+      // level down (two passes over half the records each cost about as much as one that fits).
+      const float pred = (float)(kmer_off[b + 1] - tmp0) * inv_dup;
+      float room = 0.88f * (float)T::LIMIT2 * (float)(1u << hb);
+      while (hb < 8u && pred > room) { ++hb; room *= 2.f; }
+    }
     for (uint32_t v = 0; v < (1u << hb); ++v) s_stack[v] = hb | (v << 8);
     s_ctl[5] = 1u << hb; s_ctl[4] = 0; s_ctl[9] = hb;
   }
@@ -578,8 +589,10 @@ __global__ __launch_bounds__(1024) void sk_reduce_kernel(const uint64_t *__restr
     if (use_t1) for (uint32_t i = threadIdx.x; i < (uint32_t)T::S1; i += T::NT) { s_r[i] = make_ulonglong2(kEmptyKey, W1_INIT); s_rc[i] = 0; }
     if (threadIdx.x == 0) { s_ctl[0] = 0; s_ctl[1] = 0; s_ctl[2] = 0; s_ctl[3] = 0; s_ctl[5] = sp - 1; s_ctl[8] = 0; }
     lds_barrier();
-    // the first three filter bits are the records' sub-bucket bits (whole records are skipped), the others come from the key's hash
-    const uint32_t rbits = fbits < 3u ? fbits : 3u, rmask = (1u << rbits) - 1u, rval = fval & rmask;
+    // the first three filter bits (3 - lp in a build over ranks) are the records' sub-bucket bits (whole records are skipped), the
+    // others come from the key's hash
+    const uint32_t rmax = 3u - lp;   // (the sub-bucket bits that carry information)
+    const uint32_t rbits = fbits < rmax ? fbits : rmax, rmask = ((1u << rbits) - 1u) << lp, rval = (fval & ((1u << rbits) - 1u)) << lp;
     const uint32_t hbits = fbits - rbits, hmask = (1u << hbits) - 1u, hval = fval >> rbits;
     uint32_t mn = 0;   // (key, weight) pairs waiting in the miss queue (uniform)
     uint32_t pending = 0;   // slots this wavefront claimed in line since it last reported to the shared fill counter (uniform)
