@@ -154,14 +154,14 @@ kmi_status kmi_ctx_create(int device, int rank, int nranks, void *stream, kmi_ct
   if (const char *fd = getenv("KMI_FORCE_DIST")) ctx->force_dist = atoi(fd) != 0;
   ctx->device = device; ctx->rank = rank; ctx->nranks = nranks; ctx->stream = (hipStream_t)stream;
   if (hipMalloc((void **)&ctx->d_flags, sizeof(uint32_t) * 40) != hipSuccess ||
-      hipMalloc((void **)&ctx->d_totals, sizeof(uint64_t) * 16) != hipSuccess ||
+      hipMalloc((void **)&ctx->d_totals, sizeof(uint64_t) * (16 + 256)) != hipSuccess ||
       hipHostMalloc((void **)&ctx->h_totals, sizeof(uint64_t) * 16, hipHostMallocDefault) != hipSuccess) {
     delete ctx;
     return KMI_ERR_DEVICE;
   }
   (void)hipMemset(ctx->d_flags, 0, sizeof(uint32_t) * 40);
   if (upload_quality_lut(ctx) != KMI_OK) { kmi_ctx_destroy(ctx); return KMI_ERR_DEVICE; }
-  (void)hipMemset(ctx->d_totals, 0, sizeof(uint64_t) * 16);
+  (void)hipMemset(ctx->d_totals, 0, sizeof(uint64_t) * (16 + 256));
   *out = ctx;
   return KMI_OK;
 }

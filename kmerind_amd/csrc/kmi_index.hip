@@ -225,34 +225,55 @@ __global__ __launch_bounds__(kPartThreads) void hist_rank_kernel(const uint64_t 
 }
 
 // ---------------------------------------------------------------------------
-// offsets: fine_off = exclusive scan of fine_hist (u64, kNumFine+1 entries);
-//          wg_off[w][c] = fine_off[c*128] + sum_{w'<w} wg_hist[w'][c]
+// offsets: fine_off = exclusive scan of fine_hist (u64, kNumFine+1 entries), part_off[h][f] = where part h of fine bucket f
+// starts, coarse_base[c] = fine_off[c * 128]
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void fine_offsets_kernel(const uint32_t *__restrict__ fine_hist, const uint32_t *__restrict__ wg_hist,
-                                                           uint32_t groups, uint64_t *__restrict__ fine_off,
-                                                           uint64_t *__restrict__ part_off,   // [kFineParts][kNumFine] or null
-                                                           uint64_t *__restrict__ coarse_base /* [kNumCoarse] */) {
-  __shared__ uint64_t s_scan[1024 / 64 + 2];
-  constexpr int PER = kNumFine / 1024;  // 32 fine buckets per thread; a coarse bucket = 4 threads
-  uint32_t loc[kFineParts][PER];
-  uint64_t sum = 0;
+// Two small launches spread over the chip (a one-workgroup scan read the 64 K counters with a stride of 128 bytes between
+// lanes: 0.1 ms per call, twice per build): one workgroup per coarse bucket, one thread per fine bucket of it. (a) totals of the coarse buckets; (b) every workgroup scans the 256 totals for its base, then its own 128 x
+// kFineParts counters.
+__global__ __launch_bounds__(kSubPerCoarse) void fine_totals_kernel(const uint32_t *__restrict__ fine_hist, uint64_t *__restrict__ coarse_tot) {
+  __shared__ uint64_t s_scan[kSubPerCoarse / 64 + 2];
+  const uint32_t f = blockIdx.x * kSubPerCoarse + threadIdx.x;
+  uint64_t v = 0;
 #pragma unroll
-  for (int h = 0; h < kFineParts; ++h)
-#pragma unroll
-    for (int i = 0; i < PER; ++i) { loc[h][i] = fine_hist[(uint64_t)h * kNumFine + threadIdx.x * PER + i]; sum += loc[h][i]; }
+  for (int h = 0; h < kFineParts; ++h) v += fine_hist[(uint64_t)h * kNumFine + f];
   uint64_t total;
-  uint64_t off = block_exclusive_scan<uint64_t>(sum, s_scan, &total);
-  if ((threadIdx.x & 3u) == 0) coarse_base[threadIdx.x >> 2] = off;
+  (void)block_exclusive_scan<uint64_t>(v, s_scan, &total);
+  if (threadIdx.x == 0) coarse_tot[blockIdx.x] = total;
+}
+__global__ __launch_bounds__(kSubPerCoarse) void fine_offsets_spread_kernel(const uint32_t *__restrict__ fine_hist, const uint64_t *__restrict__ coarse_tot,
+                                                                           uint64_t *__restrict__ fine_off, uint64_t *__restrict__ part_off,
+                                                                           uint64_t *__restrict__ coarse_base) {
+  static_assert(kNumCoarse == 2 * kSubPerCoarse, "two coarse totals per thread");
+  __shared__ uint64_t s_scan[kSubPerCoarse / 64 + 2];
+  const uint32_t c = blockIdx.x, f = c * kSubPerCoarse + threadIdx.x;
+  // base of this coarse bucket = the totals below it (two per thread)
+  const uint32_t c0 = 2u * threadIdx.x;
+  const uint64_t t0 = coarse_tot[c0], t1 = coarse_tot[c0 + 1];
+  uint64_t grand;
+  (void)block_exclusive_scan<uint64_t>(t0 + t1, s_scan, &grand);
+  const uint64_t below = (c0 < c ? t0 : 0ull) + (c0 + 1 < c ? t1 : 0ull);
+  uint64_t base;
+  (void)block_exclusive_scan<uint64_t>(below, s_scan, &base);   // (its total: the sum over all threads)
+  uint32_t loc[kFineParts];
+  uint64_t v = 0;
 #pragma unroll
-  for (int i = 0; i < PER; ++i) {
-    fine_off[threadIdx.x * PER + i] = off;
+  for (int h = 0; h < kFineParts; ++h) { loc[h] = fine_hist[(uint64_t)h * kNumFine + f]; v += loc[h]; }
+  uint64_t off = base + block_exclusive_scan<uint64_t>(v, s_scan, (uint64_t *)nullptr);
+  if (threadIdx.x == 0) coarse_base[c] = base;
+  fine_off[f] = off;
 #pragma unroll
-    for (int h = 0; h < kFineParts; ++h) {
-      if (part_off) part_off[(uint64_t)h * kNumFine + threadIdx.x * PER + i] = off;
-      off += loc[h][i];
-    }
+  for (int h = 0; h < kFineParts; ++h) {
+    if (part_off) part_off[(uint64_t)h * kNumFine + f] = off;
+    off += loc[h];
   }
-  if (threadIdx.x == 0) fine_off[kNumFine] = total;
+  if (c == (uint32_t)kNumCoarse - 1 && threadIdx.x == 0) fine_off[kNumFine] = grand;
+}
+static void launch_fine_offsets(kmi_ctx *ctx, const uint32_t *fine_hist, uint64_t *fine_off, uint64_t *part_off, uint64_t *coarse_base) {
+  uint64_t *tot = ctx->d_totals + 16;
+  hipLaunchKernelGGL(fine_totals_kernel, dim3(kNumCoarse), dim3(kSubPerCoarse), 0, ctx->stream, fine_hist, tot);
+  hipLaunchKernelGGL(fine_offsets_spread_kernel, dim3(kNumCoarse), dim3(kSubPerCoarse), 0, ctx->stream, fine_hist, (const uint64_t *)tot, fine_off, part_off,
+                     coarse_base);
 }
 
 // wg_off[w][c] = coarse_base[c] + sum_{w' < w} wg_hist[w'][c]: one wavefront per coarse bucket, spread over the chip
@@ -2368,8 +2389,7 @@ static kmi_status partition_impl(kmi_ctx *ctx, const kmi_config *cfg, KShape sha
   }
   {
     ProfScope ps(ctx, "fine_offsets", kNumFine);
-    hipLaunchKernelGGL(fine_offsets_kernel, dim3(1), dim3(1024), 0, ctx->stream, w.fine_hist, w.wg_hist, (uint32_t)kPartGroups, w.fine_off,
-                       w.part_off, w.coarse_base);
+    launch_fine_offsets(ctx, w.fine_hist, w.fine_off, w.part_off, w.coarse_base);
     hipLaunchKernelGGL(coarse_cursors_kernel, dim3(kNumCoarse / 4), dim3(256), 0, ctx->stream, (const uint32_t *)w.wg_hist, (uint32_t)kPartGroups,
                        (const uint64_t *)w.coarse_base, w.wg_off);
   }
@@ -2517,8 +2537,7 @@ static kmi_status build_fused_impl(kmi_index *idx, const uint8_t *bytes_dev, siz
   }
   {
     ProfScope ps(ctx, "fine_offsets", kNumFine);
-    hipLaunchKernelGGL(fine_offsets_kernel, dim3(1), dim3(1024), 0, ctx->stream, w.fine_hist, w.wg_hist, (uint32_t)fused_groups<NW>(), w.fine_off,
-                       w.part_off, w.coarse_base);
+    launch_fine_offsets(ctx, w.fine_hist, w.fine_off, w.part_off, w.coarse_base);
     hipLaunchKernelGGL(coarse_cursors_kernel, dim3(kNumCoarse / 4), dim3(256), 0, ctx->stream, (const uint32_t *)w.wg_hist, (uint32_t)fused_groups<NW>(),
                        (const uint64_t *)w.coarse_base, w.wg_off);
   }
@@ -2637,8 +2656,7 @@ static kmi_status sk_back_end(kmi_index *idx, const uint64_t *rec_a, uint64_t R,
   uint64_t *coarse_base = part_off + (uint64_t)kNumFine * kFineParts;
   uint64_t h_end[kNumCoarse];
   for (int c = 0; c < kNumCoarse; ++c) h_end[c] = h_base[c] + h_cnt[c];
-  KMI_HIP(ctx, hipMemcpyAsync(cend, h_end, sizeof(h_end), hipMemcpyHostToDevice, ctx->stream));
-  KMI_HIP(ctx, hipStreamSynchronize(ctx->stream));   // (h_end is a stack array)
+  KMI_HIP(ctx, hipMemcpyAsync(cend, h_end, sizeof(h_end), hipMemcpyHostToDevice, ctx->stream));   // (h_end outlives the copy: this function synchronises before it returns)
   KMI_TRY(ws_get(ctx, WS_KEYS_B, (R + 64) * 16, &p)); uint64_t *rec_b = (uint64_t *)p;
   KMI_TRY(ws_get(ctx, WS_SPLIT_OFF, sizeof(uint32_t) * kNumFine * kFineParts + sizeof(uint64_t) * ((kNumFine + 1) + kNumFine * kFineParts + kNumCoarse) + 256, &p));
   uint32_t *fine_kmers = (uint32_t *)p;
@@ -2651,10 +2669,8 @@ static kmi_status sk_back_end(kmi_index *idx, const uint64_t *rec_a, uint64_t R,
   }
   {
     ProfScope ps(ctx, "fine_offsets", kNumFine);
-    hipLaunchKernelGGL(fine_offsets_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const uint32_t *)fine_hist, (const uint32_t *)wg_hist,
-                       (uint32_t)kPartGroups, fine_off, part_off, coarse_base);
-    hipLaunchKernelGGL(fine_offsets_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const uint32_t *)fine_kmers, (const uint32_t *)wg_hist,
-                       (uint32_t)kPartGroups, kmer_off, k_part, k_base);
+    launch_fine_offsets(ctx, fine_hist, fine_off, part_off, coarse_base);
+    launch_fine_offsets(ctx, fine_kmers, kmer_off, k_part, k_base);
   }
   {
     ProfScope ps(ctx, "sk_scatter_fine", R);

@@ -78,7 +78,7 @@ struct kmi_ctx {
   std::string err;
   struct Buf { void *p = nullptr; size_t cap = 0; } ws[kmi::WS_NUM_SLOTS];
   uint32_t *d_flags = nullptr;   // [16] error / overflow flags
-  uint64_t *d_totals = nullptr;  // [16] small device scalars
+  uint64_t *d_totals = nullptr;  // [16] small device scalars + [256] coarse-bucket totals of the fine-offset scan
   uint64_t *h_totals = nullptr;  // pinned mirror
   bool prof = false;
   std::vector<kmi::ProfRec> prof_pending;
