@@ -242,8 +242,10 @@ static kmi_status dbg_parse(kmi_ctx *ctx, const kmi_config *cfg, const uint8_t *
   void *dr;
   const uint32_t rw = shape.n_words + 1u;
   KMI_TRY(ws_get(ctx, WS_DBG_RECS, ((size_t)nt + 8) * rw * sizeof(uint64_t), &dr));
-  KMI_TRY(extract_run(ctx, &c, bytes_dev, n_bytes, 0, (uint64_t *)dr, nullptr, (size_t)nt, false, true, &nt, &ns, nullptr, rw));
-  KMI_TRY(dbg_edges(ctx, (uint64_t *)dr, (size_t)nt, bytes_dev, n_bytes, shape, true, node_form));
+  // node form: the extract pass writes the smaller strand and 1 | edge << 32 itself; the parser's form (tuples as parsed) takes
+  // the position ids and turns them into edge bytes in a second pass
+  KMI_TRY(extract_run(ctx, &c, bytes_dev, n_bytes, 0, (uint64_t *)dr, nullptr, (size_t)nt, false, true, &nt, &ns, nullptr, rw, node_form));
+  if (!node_form) KMI_TRY(dbg_edges(ctx, (uint64_t *)dr, (size_t)nt, bytes_dev, n_bytes, shape, true, false));
   *recs_out = (uint64_t *)dr; *n_out = nt;
   return KMI_OK;
 }

@@ -499,7 +499,9 @@ template <int NW, int BITS, bool WITH_IDS>
 __global__ __launch_bounds__((ExCfg<NW, BITS>::NT)) void fastq_extract_kernel(
     PackedInput in, KShape shape, bool canonical, const uint32_t *__restrict__ line_base, const uint64_t *__restrict__ hdr_base,
     uint64_t file_offset, const uint64_t *__restrict__ out_off, uint64_t out_capacity, uint64_t *__restrict__ out_kmers,
-    uint64_t *__restrict__ out_ids, ReadDesc *__restrict__ reads, uint32_t *__restrict__ flags, uint32_t kstride, uint32_t istride) {
+    uint64_t *__restrict__ out_ids, ReadDesc *__restrict__ reads, uint32_t *__restrict__ flags, uint32_t kstride, uint32_t istride,
+    const uint8_t *__restrict__ raw_edges /* de Bruijn tuples (kmi_debruijn.h): the input bytes; the id slot then takes 1 | edge byte << 32
+                                             and the key is the smaller strand, the edge byte turned with it */) {
   using Cfg = ExCfg<NW, BITS>;
   __shared__ uint32_t s_eol[Cfg::EOL_DW];
   __shared__ uint32_t s_brk[Cfg::EOL_DW];
@@ -537,9 +539,20 @@ __global__ __launch_bounds__((ExCfg<NW, BITS>::NT)) void fastq_extract_kernel(
     uint64_t rc[NW], fw[NW], key[NW];
     const uint32_t pos = s_pos[q];
     window_at<Cfg>(s_stream, pos, shape, rc, fw);
-    select_strand<NW>(rc, fw, canonical, key);
+    select_strand<NW>(rc, fw, canonical || (WITH_IDS && raw_edges != nullptr), key);
 #pragma unroll
     for (int w = 0; w < NW; ++w) out_kmers[(base + q) * kstride + w] = key[w];
+    if (WITH_IDS && raw_edges) {   // uniform
+      // edge_iterator.hpp:163-177: the bases left and right of the k-mer in its (single-line) FASTQ sequence, DNA16 codes,
+      // nothing where the read ends; reverse_complement_edges (de_bruijn_node_trait.hpp:122-124) when the other strand is kept
+      const uint64_t p0 = tile0 + pos;
+      const uint32_t lc = p0 > 0 ? raw_edges[p0 - 1] : (uint32_t)'\n';
+      const uint32_t rcch = p0 + shape.k < in.n_bytes ? raw_edges[p0 + shape.k] : (uint32_t)'\n';
+      uint32_t e = ((is_eol(lc) ? 0u : code_dna16(lc)) << 4) | (is_eol(rcch) ? 0u : code_dna16(rcch));
+      if (less_words<NW>(rc, fw)) e = (comp_code<4>(e & 0xFu) << 4) | comp_code<4>(e >> 4);
+      out_ids[(base + q) * istride] = 1ull | ((uint64_t)e << 32);
+      continue;
+    }
     if (WITH_IDS) {
       // ShortSequenceKmerId (sequence.hpp:156-157): record file offset << 16 | offset of the k-mer's
       // first base from the record start (kmer_parser.hpp:378-386)
@@ -788,7 +801,7 @@ template <int NW, int BITS>
 static kmi_status extract_run_impl(kmi_ctx *ctx, const kmi_config *cfg, const uint8_t *bytes_dev, size_t n_bytes,
                                    KShape shape, uint64_t file_offset, uint64_t *out_kmers_dev, uint64_t *out_ids_dev,
                                    float *out_quals_dev, size_t out_capacity, bool apply_strand, bool scan_done, uint64_t *n_tuples,
-                                   uint64_t *n_seqs, uint32_t rec_words) {
+                                   uint64_t *n_seqs, uint32_t rec_words, bool edges) {
   using Cfg = ExCfg<NW, BITS>;
   // rec_words != 0: out_kmers_dev is a record buffer (key words, id[, quality bits]) of rec_words words per tuple
   const uint32_t kstride = rec_words ? rec_words : (uint32_t)NW, istride = rec_words ? rec_words : 1u;
@@ -814,12 +827,13 @@ static kmi_status extract_run_impl(kmi_ctx *ctx, const kmi_config *cfg, const ui
     if (want_ids) {
       hipLaunchKernelGGL((fastq_extract_kernel<NW, BITS, true>), dim3((unsigned)r.n_tiles), dim3(Cfg::NT), 0, ctx->stream,
                          r.packed, shape, canonical, (const uint32_t *)r.line_base, (const uint64_t *)r.hdr_base, file_offset,
-                         (const uint64_t *)r.out_off, (uint64_t)out_capacity, out_kmers_dev, ids_at, reads, ctx->d_flags, kstride, istride);
+                         (const uint64_t *)r.out_off, (uint64_t)out_capacity, out_kmers_dev, ids_at, reads, ctx->d_flags, kstride, istride,
+                         edges ? bytes_dev : (const uint8_t *)nullptr);
     } else {
       hipLaunchKernelGGL((fastq_extract_kernel<NW, BITS, false>), dim3((unsigned)r.n_tiles), dim3(Cfg::NT), 0, ctx->stream,
                          r.packed, shape, canonical, (const uint32_t *)r.line_base, (const uint64_t *)r.hdr_base, file_offset,
                          (const uint64_t *)r.out_off, (uint64_t)out_capacity, out_kmers_dev, (uint64_t *)nullptr, (ReadDesc *)nullptr,
-                         ctx->d_flags, kstride, istride);
+                         ctx->d_flags, kstride, istride, (const uint8_t *)nullptr);
     }
     if (want_quals) {
       ProfScope pq(ctx, "fastq_quality", n_bytes);
@@ -952,7 +966,8 @@ kmi_status extract_count(kmi_ctx *ctx, const kmi_config *cfg, const uint8_t *byt
 
 kmi_status extract_run(kmi_ctx *ctx, const kmi_config *cfg, const uint8_t *bytes_dev, size_t n_bytes,
                        uint64_t file_offset, uint64_t *out_kmers_dev, uint64_t *out_ids_dev, size_t out_capacity,
-                       bool apply_strand, bool scan_done, uint64_t *n_tuples, uint64_t *n_seqs, float *out_quals_dev, uint32_t rec_words) {
+                       bool apply_strand, bool scan_done, uint64_t *n_tuples, uint64_t *n_seqs, float *out_quals_dev, uint32_t rec_words, bool edges) {
+  // edges (FASTQ, records): the value word of every record is 1 | edge byte << 32 and the key the smaller strand (kmi_debruijn.h)
   // rec_words != 0: out_kmers_dev takes whole records -- key words, id, and with rec_words == n_words + 2 the quality's float
   // bits -- rec_words words per tuple, the layout the multimap insert reads (out_ids_dev / out_quals_dev are then unused)
   KShape shape;
@@ -963,8 +978,9 @@ kmi_status extract_run(kmi_ctx *ctx, const kmi_config *cfg, const uint8_t *bytes
   if (cfg->seq_format == KMI_FMT_FASTA)
     return fasta_extract(ctx, cfg, bytes_dev, n_bytes, shape, file_offset, out_kmers_dev, out_ids_dev, out_capacity, apply_strand, false,
                          n_tuples, n_seqs, rec_words);
+  if (edges && (cfg->seq_format != KMI_FMT_FASTQ || rec_words != shape.n_words + 1u)) return set_err(ctx, KMI_ERR_INVALID, "edge tuples are FASTQ records of n_words + 1 words");
   KMI_DISPATCH(shape, extract_run_impl, ctx, cfg, bytes_dev, n_bytes, shape, file_offset, out_kmers_dev, out_ids_dev, out_quals_dev,
-               out_capacity, apply_strand, scan_done, n_tuples, n_seqs, rec_words);
+               out_capacity, apply_strand, scan_done, n_tuples, n_seqs, rec_words, edges);
 }
 
 // ---------------------------------------------------------------------------

@@ -227,7 +227,7 @@ kmi_status extract_count(kmi_ctx *ctx, const kmi_config *cfg, const uint8_t *byt
 kmi_status extract_run(kmi_ctx *ctx, const kmi_config *cfg, const uint8_t *bytes_dev, size_t n_bytes,
                        uint64_t file_offset, uint64_t *out_kmers_dev, uint64_t *out_ids_dev, size_t out_capacity,
                        bool apply_strand, bool scan_done, uint64_t *n_tuples, uint64_t *n_seqs, float *out_quals_dev = nullptr,
-                       uint32_t rec_words = 0);
+                       uint32_t rec_words = 0, bool edges = false);
 kmi_status upload_quality_lut(kmi_ctx *ctx);
 
 // tile scan of a FASTQ partition; the packed arrays and per-tile line bases stay in the workspace
