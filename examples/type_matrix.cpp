@@ -20,9 +20,14 @@ template <typename K> using BimolHash = bik::BimoleculeHashMapParams<K, bik::Dis
 template <typename K> using BimolSorted = bik::BimoleculeSortedMapParams<K>;
 using Special = ::bliss::kmer::hash::sparsehash::special_keys<KmerType, true>;
 
-template <typename IndexType> static size_t build_size(const std::string &file) {
+static int unsorted_seen = 0;   // a sorted-map flavour whose entries did not come back in key order
+template <typename IndexType> static size_t build_size(const std::string &file, bool expect_sorted = false) {
   IndexType idx(::kmerind::comm(0));
   idx.template build_posix<::bliss::io::FASTQParser, ::bliss::io::NSplitSequencesIterator>(file);
+  if (expect_sorted) {   // distributed_sorted_map keeps its local container sorted by Less<Key>
+    auto v = idx.to_vector();
+    for (size_t i = 1; i < v.size(); ++i) if (v[i].first < v[i - 1].first) { unsorted_seen = 1; break; }
+  }
   // exists(): one byte per input key; the all-A k-mer is not in the generated file, a stored key is
   std::vector<KmerType> q(2, KmerType(true));
   auto all = idx.to_vector();
@@ -45,11 +50,11 @@ int main(int argc, char **argv) {
   }
   const size_t c1 = build_size<bik::CountIndex<::dsc::counting_unordered_map<KmerType, uint32_t, CanonHash>>>(file);
   const size_t c2 = build_size<bik::CountIndex<::dsc::counting_densehash_map<KmerType, uint32_t, CanonHash, Special>>>(file);
-  const size_t c3 = build_size<bik::CountIndex<::dsc::counting_sorted_map<KmerType, uint32_t, CanonSorted>>>(file);
+  const size_t c3 = build_size<bik::CountIndex<::dsc::counting_sorted_map<KmerType, uint32_t, CanonSorted>>>(file, true);
   const size_t s1 = build_size<bik::CountIndex2<::dsc::counting_unordered_map<KmerType, uint32_t, SingleXor>>>(file);
-  const size_t s2 = build_size<bik::CountIndex<::dsc::counting_sorted_map<KmerType, uint32_t, SingleSorted>>>(file);
+  const size_t s2 = build_size<bik::CountIndex<::dsc::counting_sorted_map<KmerType, uint32_t, SingleSorted>>>(file, true);
   const size_t b1 = build_size<bik::CountIndex<::dsc::counting_unordered_map<KmerType, uint32_t, BimolHash>>>(file);
-  const size_t b2 = build_size<bik::CountIndex<::dsc::counting_sorted_map<KmerType, uint32_t, BimolSorted>>>(file);
+  const size_t b2 = build_size<bik::CountIndex<::dsc::counting_sorted_map<KmerType, uint32_t, BimolSorted>>>(file, true);
   // saturating_counting_densehash_map<..., uint8_t>: counts stop at 255 (a 2-mer index of this file has counts far above)
   {
     using K2 = ::bliss::common::Kmer<2, ::bliss::common::DNA, uint64_t>;
@@ -70,9 +75,9 @@ int main(int argc, char **argv) {
   }
   const size_t p1 = build_size<bik::PositionIndex<::dsc::unordered_multimap<KmerType, IdType, CanonHash>>>(file);
   const size_t p2 = build_size<bik::PositionIndex<::dsc::densehash_multimap<KmerType, IdType, CanonHash, Special>>>(file);
-  const size_t p3 = build_size<bik::PositionIndex<::dsc::sorted_multimap<KmerType, IdType, CanonSorted>>>(file);
+  const size_t p3 = build_size<bik::PositionIndex<::dsc::sorted_multimap<KmerType, IdType, CanonSorted>>>(file, true);
   std::printf("canonical %zu %zu %zu  single %zu %zu  bimolecule %zu %zu  positions %zu %zu %zu\n", c1, c2, c3, s1, s2, b1, b2, p1, p2, p3);
-  const bool ok = c1 && c1 == c2 && c2 == c3 && s1 == s2 && b1 == b2 && b1 == c1 && p1 == p2 && p2 == p3 && s1 >= c1;
+  const bool ok = c1 && c1 == c2 && c2 == c3 && s1 == s2 && b1 == b2 && b1 == c1 && p1 == p2 && p2 == p3 && s1 >= c1 && !unsorted_seen;
   std::printf(ok ? "type matrix ok\n" : "type matrix MISMATCH\n");
   return ok ? 0 : 1;
 }

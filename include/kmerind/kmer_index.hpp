@@ -240,6 +240,7 @@ struct counting_unordered_map {
   using key_type = Key; using mapped_type = T; using params = MapParams<Key>;
   static constexpr uint32_t index_kind = KMI_INDEX_COUNT;
   static constexpr bool saturating = false;   // std::plus<T>: a count type narrower than the device's 32 bits wraps
+  static constexpr bool sorted = false;       // the sorted maps hand their local entries out in key order
 };
 // saturating_counting_densehash_map (distributed_densehash_map.hpp:2903-2953, sat_plus<T>): counts stop at the largest T.
 // The device counts in 32 bits; what a caller reads is min(count, max(T)), which is what a chain of sat_plus(+1) gives.
@@ -257,6 +258,7 @@ struct unordered_multimap {
   // two words on the device, the float's bits in the low half of the second)
   static constexpr uint32_t index_kind = sizeof(T) == sizeof(uint64_t) ? KMI_INDEX_POSITION : KMI_INDEX_POSQUAL;
   static constexpr bool saturating = false;
+  static constexpr bool sorted = false;
   static_assert(sizeof(T) == sizeof(uint64_t) || sizeof(T) == 2 * sizeof(uint64_t), "values are one (id) or two ((id, quality)) 64-bit words");
 };
 template <typename Key, typename T, template <typename> class MapParams, typename SpecialKeys = void>
@@ -275,9 +277,13 @@ struct SortedMapParams {
   static constexpr uint32_t dist_hash = KMI_HASH_MURMUR, store_hash = KMI_HASH_MURMUR, dist_trans = KMI_DIST_MODEL;
 };
 template <typename Key, typename T, template <typename> class MapParams>
-struct counting_sorted_map : counting_unordered_map<Key, T, MapParams> {};
+struct counting_sorted_map : counting_unordered_map<Key, T, MapParams> { static constexpr bool sorted = true; };
+// (distributed_sorted_map.hpp keeps the local container a vector sorted by Less<Key>: what to_vector / cbegin..cend of these
+// tags walk is in ascending key order -- Kmer::operator< for the std::less the *SortedMapParams aliases default to --, equal
+// keys of the multimap in the order the device holds them. The range PARTITION of keys over ranks by sampled splitters is
+// not reproduced: which rank holds a key is internal here as it is there.)
 template <typename Key, typename T, template <typename> class MapParams>
-struct sorted_multimap : unordered_multimap<Key, T, MapParams> {};
+struct sorted_multimap : unordered_multimap<Key, T, MapParams> { static constexpr bool sorted = true; };
 
 }  // namespace dsc
 
@@ -584,6 +590,7 @@ class Index {
       ::kmerind::check(ctx, kmi_index_export_tuples_host(idx, keys.data(), vals.data(), n, &got));
       std::vector<TupleType> out(got);
       for (uint64_t i = 0; i < got; ++i) out[i] = std::make_pair(KmerType(&keys[i * KmerType::nWords]), detail::stored_value<MapType, ValueType>(&vals[i * vw]));
+      if (MapType::sorted) std::stable_sort(out.begin(), out.end(), [](const TupleType &a, const TupleType &b) { return a.first < b.first; });
       return out;
     }
     std::vector<uint64_t> keys(n * KmerType::nWords + 1);
@@ -591,6 +598,7 @@ class Index {
     ::kmerind::check(ctx, kmi_index_export_host(idx, keys.data(), cnt.data(), n, &got));
     std::vector<TupleType> out(got);
     for (uint64_t i = 0; i < got; ++i) { const uint64_t c = cnt[i]; out[i] = std::make_pair(KmerType(&keys[i * KmerType::nWords]), detail::stored_value<MapType, ValueType>(&c)); }
+    if (MapType::sorted) std::sort(out.begin(), out.end(), [](const TupleType &a, const TupleType &b) { return a.first < b.first; });
     return out;
   }
 
