@@ -328,7 +328,9 @@ __device__ __forceinline__ void scatter_range(const uint64_t *__restrict__ in, u
                                               const KShape &shape, uint32_t strand, bool transform, const BucketFn &fn,
                                               uint64_t cursor /* of bucket threadIdx.x, threads < 256 */,
                                               uint64_t *s_stage, uint8_t *s_bkt, uint32_t *s_cnt, uint32_t *s_lofs,
-                                              uint64_t *s_gbase, uint32_t *s_part) {
+                                              uint64_t *s_gbase, uint32_t *s_part, uint64_t *__restrict__ out_vals = nullptr) {
+  // out_vals (records only): the key words go to out[dst * NW ..], the value words to out_vals[dst * VW ..] -- the arrays of a
+  // multimap index -- instead of whole records to out[dst * RW ..]
   constexpr int RW = NW + VW;   // record = key words followed by value words
   constexpr int TILE = PartCfg<RW>::TILE;
   constexpr int PT = PartCfg<RW>::PER_THREAD;
@@ -403,10 +405,20 @@ __device__ __forceinline__ void scatter_range(const uint64_t *__restrict__ in, u
       }
     }
     lds_barrier();
-    for (uint32_t s = threadIdx.x; s < nt; s += kPartThreads) {
-      const uint64_t dst = s_gbase[s_bkt[s]] + s;
+    if (VW > 0 && out_vals) {   // uniform
+      for (uint32_t s = threadIdx.x; s < nt; s += kPartThreads) {
+        const uint64_t dst = s_gbase[s_bkt[s]] + s;
 #pragma unroll
-      for (int w = 0; w < RW; ++w) out[dst * RW + w] = s_stage[(uint64_t)s * RW + w];
+        for (int w = 0; w < NW; ++w) out[dst * NW + w] = s_stage[(uint64_t)s * RW + w];
+#pragma unroll
+        for (int w = 0; w < VW; ++w) out_vals[dst * (VW ? VW : 1) + w] = s_stage[(uint64_t)s * RW + NW + w];
+      }
+    } else {
+      for (uint32_t s = threadIdx.x; s < nt; s += kPartThreads) {
+        const uint64_t dst = s_gbase[s_bkt[s]] + s;
+#pragma unroll
+        for (int w = 0; w < RW; ++w) out[dst * RW + w] = s_stage[(uint64_t)s * RW + w];
+      }
     }
     // no barrier here: the next tile's S0 only touches s_cnt (reset in S1 above) and its S2/S3
     // writes are separated from this copy-out by the two barriers in between
@@ -439,7 +451,7 @@ template <int NW, int BITS, int VW = 0>
 __global__ __launch_bounds__(kPartThreads) void scatter_fine_kernel(const uint64_t *__restrict__ in, uint64_t *__restrict__ out, KShape shape,
                                                                    const uint64_t *__restrict__ fine_off, const uint64_t *__restrict__ part_off,
                                                                    const uint64_t *__restrict__ wg_off, uint32_t groups, int mode = BUCKET_SUB,
-                                                                   uint32_t layout_w = 0) {
+                                                                   uint32_t layout_w = 0, uint64_t *__restrict__ out_vals = nullptr) {
   KMI_SCATTER_LDS(NW + VW)
   const uint32_t gpp = groups / kFineParts;   // K2 / E2 workgroups per part
   const uint32_t c = blockIdx.x / kFineParts, h = blockIdx.x % kFineParts;
@@ -447,7 +459,7 @@ __global__ __launch_bounds__(kPartThreads) void scatter_fine_kernel(const uint64
   const uint64_t b = wg_off[(uint64_t)(h * gpp) * kNumCoarse + c];
   const uint64_t e = (h + 1 < (uint32_t)kFineParts) ? wg_off[(uint64_t)((h + 1) * gpp) * kNumCoarse + c] : fine_off[(c + 1) * kSubPerCoarse];
   BucketFn fn; fn.mode = mode; fn.shape = shape; fn.dist_hash = 0; fn.farm_ndebug = false; fn.nranks = 1; fn.sub = 1; fn.layout_w = layout_w;
-  if (b < e) scatter_range<NW, BITS, VW>(in, b, e, out, shape, 0u, false, fn, cursor, s_stage, s_bkt, s_cnt, s_lofs, s_gbase, s_part);
+  if (b < e) scatter_range<NW, BITS, VW>(in, b, e, out, shape, 0u, false, fn, cursor, s_stage, s_bkt, s_cnt, s_lofs, s_gbase, s_part, out_vals);
 }
 
 
@@ -2378,7 +2390,10 @@ static kmi_status get_part_ws(kmi_ctx *ctx, size_t n, int nw, WsSlot slot_a, WsS
 // K1 + offsets + K2 + P2 on `n` keys; result in slot `slot_b`, scratch in `slot_a`
 template <int NW, int BITS, int VW = 0>
 static kmi_status partition_impl(kmi_ctx *ctx, const kmi_config *cfg, KShape shape, const uint64_t *keys_dev, size_t n, bool transform,
-                                 WsSlot slot_a, WsSlot slot_b, Partitioned *out, uint32_t layout_w = 0) {
+                                 WsSlot slot_a, WsSlot slot_b, Partitioned *out, uint32_t layout_w = 0, uint64_t *split_keys = nullptr,
+                                 uint64_t *split_vals = nullptr) {
+  // split_keys / split_vals (records): the last pass writes key words and value words into these two arrays (n entries each)
+  // instead of records into the workspace -- the first insert into an empty multimap index needs no further copy
   PartWs w;
   KMI_TRY(get_part_ws(ctx, n, NW + VW, slot_a, slot_b, &w));
   KMI_HIP(ctx, hipMemsetAsync(w.fine_hist, 0, sizeof(uint32_t) * kNumFine * kFineParts, ctx->stream));
@@ -2406,12 +2421,12 @@ static kmi_status partition_impl(kmi_ctx *ctx, const kmi_config *cfg, KShape sha
                          w.buf_b, (const uint64_t *)w.fine_off, (const uint64_t *)w.part_off, (const uint64_t *)w.wg_off, (uint32_t)kPartGroups,
                          layout_w, shape.k);
     else
-      hipLaunchKernelGGL((scatter_fine_kernel<NW, BITS, VW>), dim3(kNumCoarse * kFineParts), dim3(kPartThreads), 0, ctx->stream, w.buf_a, w.buf_b,
-                         shape, (const uint64_t *)w.fine_off, (const uint64_t *)w.part_off, (const uint64_t *)w.wg_off, (uint32_t)kPartGroups,
-                         (int)BUCKET_SUB, layout_w);
+      hipLaunchKernelGGL((scatter_fine_kernel<NW, BITS, VW>), dim3(kNumCoarse * kFineParts), dim3(kPartThreads), 0, ctx->stream, w.buf_a,
+                         (VW > 0 && split_keys) ? split_keys : w.buf_b, shape, (const uint64_t *)w.fine_off, (const uint64_t *)w.part_off,
+                         (const uint64_t *)w.wg_off, (uint32_t)kPartGroups, (int)BUCKET_SUB, layout_w, (VW > 0 && split_keys) ? split_vals : (uint64_t *)nullptr);
   }
   KMI_HIP(ctx, hipGetLastError());
-  out->keys = w.buf_b; out->fine_off = w.fine_off;
+  out->keys = (VW > 0 && split_keys) ? split_keys : w.buf_b; out->fine_off = w.fine_off;
   out->scratch = (NW == 1 && VW == 0) ? w.buf_a : nullptr;
   return KMI_OK;
 }
@@ -2912,6 +2927,20 @@ static kmi_status mm_insert_vw(kmi_index *idx, const uint64_t *recs_dev, size_t 
   kmi_ctx *ctx = idx->ctx;
   if (n == 0) return KMI_OK;
   Partitioned part;
+  if (!idx->has_data || idx->n_entries == 0) {
+    // an empty index: the fine partition of the records IS the index, so its last pass writes the key and value arrays directly
+    uint64_t *nk, *nv, *noff;
+    size_t kb, vb;
+    KMI_TRY(alloc_mm_arrays(ctx, n, NW, VW, &nk, &nv, &noff, &kb, &vb));
+    kmi_status st = partition_impl<NW, BITS, VW>(ctx, &idx->cfg, idx->shape, recs_dev, n, transform, WS_KEYS_A, WS_KEYS_B, &part, 0u, nk, nv);
+    if (st == KMI_OK && hipMemcpyAsync(noff, part.fine_off, kOffBytes, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess) st = KMI_ERR_DEVICE;
+    if (st == KMI_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) st = KMI_ERR_DEVICE;
+    if (st != KMI_OK) { pool_free(ctx, nk, kb); pool_free(ctx, nv, vb); pool_free(ctx, noff, kOffBytes); return st; }
+    free_index_arrays(idx);
+    idx->keys = nk; idx->mvals = nv; idx->bucket_off = noff; idx->n_entries = n; idx->has_data = true;
+    idx->keys_bytes = kb; idx->mvals_bytes = vb;
+    return KMI_OK;
+  }
   KMI_TRY((partition_impl<NW, BITS, VW>(ctx, &idx->cfg, idx->shape, recs_dev, n, transform, WS_KEYS_A, WS_KEYS_B, &part)));
   const uint64_t total = n + idx->n_entries;
   uint64_t *nk, *nv, *noff;
