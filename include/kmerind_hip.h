@@ -334,8 +334,9 @@ kmi_status kmi_index_update_pairs_dev(kmi_index *idx, const uint64_t *records_de
  * exchange can move those instead: the owner of a k-mer is then the rank that owns its MINIMIZER's bucket (the top
  * log2(nranks) bits of the 18 bucket bits), not hash(k-mer) % nranks. Which rank holds a k-mer is not observable through
  * Index (count / find / erase / size are collectives); the union of the ranks' maps is the reference's map, bit for bit.
- *   produce: this rank's FASTQ share -> records grouped by owner rank in library workspace (*records_dev, valid until the
- *            next call on the context; 2 words per record), send_counts_host[nranks] in records. *produced = 0: this
+ *   produce: this rank's FASTQ share -> records grouped by owner rank (2 words per record), send_counts_host[nranks] in
+ *            records. They are written to out_records_dev when that buffer (out_capacity records; may be NULL) holds them
+ *            all, else to library workspace valid until the next call on the context; *records_dev says where they are. *produced = 0: this
  *            path does not apply (shape, rank count) or an input exceeded a capacity of the fused front end -- EVERY
  *            rank must then take the k-mer route for this input (agree on min(*produced) over ranks first);
  *   (caller: all-to-all of the records, 16-byte elements)
@@ -346,7 +347,8 @@ kmi_status kmi_index_update_pairs_dev(kmi_index *idx, const uint64_t *records_de
  *            index that is filled with k-mers routed by kmi_route_owner_dev only (an input none of whose parts could
  *            be produced as records). */
 kmi_status kmi_index_sk_produce_dev(kmi_index *idx, const uint8_t *bytes_dev, size_t n_bytes, uint32_t nranks,
-                                    const uint64_t **records_dev, uint64_t *n_records, uint64_t *send_counts_host, int *produced);
+                                    uint64_t *out_records_dev, size_t out_capacity, const uint64_t **records_dev,
+                                    uint64_t *n_records, uint64_t *send_counts_host, int *produced);
 kmi_status kmi_index_sk_consume_dev(kmi_index *idx, const uint64_t *records_dev, size_t n_records, uint32_t nranks);
 kmi_status kmi_route_owner_dev(kmi_ctx *ctx, const kmi_config *cfg, const uint64_t *keys_dev, size_t n, uint32_t nranks,
                                uint64_t *out_keys_dev, uint64_t *send_counts_host);

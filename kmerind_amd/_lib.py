@@ -125,7 +125,7 @@ SIGNATURES = {
     "kmi_index_size_dist": (C.c_int, [_P, _P, C.POINTER(_u64)]),
     "kmi_index_update_pairs_host": (C.c_int, [_P, _P, _sz, _u32, C.POINTER(_u64)]),
     "kmi_index_update_pairs_dev": (C.c_int, [_P, _P, _sz, _u32, C.POINTER(_u64)]),
-    "kmi_index_sk_produce_dev": (C.c_int, [_P, _P, _sz, _u32, C.POINTER(_P), C.POINTER(_u64), _P, C.POINTER(C.c_int)]),
+    "kmi_index_sk_produce_dev": (C.c_int, [_P, _P, _sz, _u32, _P, _sz, C.POINTER(_P), C.POINTER(_u64), _P, C.POINTER(C.c_int)]),
     "kmi_index_sk_consume_dev": (C.c_int, [_P, _P, _sz, _u32]),
     "kmi_route_owner_dev": (C.c_int, [_P, _CFG, _P, _sz, _u32, _P, _P]),
     "kmi_index_owner_ranks": (C.c_int, [_P, C.POINTER(_u32)]),

@@ -2592,7 +2592,8 @@ struct SkFront {
 };
 
 template <int W>
-static kmi_status sk_front_end(kmi_ctx *ctx, const kmi_config *cfg, const KShape &shape, const FastqScan &sc, uint32_t lp, SkFront *f) {
+static kmi_status sk_front_end(kmi_ctx *ctx, const kmi_config *cfg, const KShape &shape, const FastqScan &sc, uint32_t lp, SkFront *f,
+                               uint64_t *out = nullptr, size_t out_cap = 0 /* records: the caller's buffer takes them when they fit */) {
   constexpr int NW = 1, BITS = 2;
   f->ok = false;
   const uint64_t n = sc.n_tuples, n_tiles = sc.n_tiles;
@@ -2637,7 +2638,8 @@ static kmi_status sk_front_end(kmi_ctx *ctx, const kmi_config *cfg, const KShape
   if (h_flag) return KMI_OK;              // a run with more items than a lane's list holds, or a tile with more than its share
   uint64_t R = 0;
   for (int c = 0; c < kNumCoarse; ++c) { R += h_cnt[c]; f->h_cnt[c] = h_cnt[c]; f->h_base[c] = h_cnt[kNumCoarse + c]; }
-  KMI_TRY(ws_get(ctx, WS_KEYS_A, (R + 64) * 16, &p)); uint64_t *rec_a = (uint64_t *)p;
+  uint64_t *rec_a = out;
+  if (!out || R + 64 > out_cap) { KMI_TRY(ws_get(ctx, WS_KEYS_A, (R + 64) * 16, &p)); rec_a = (uint64_t *)p; }   // (64 records of slack behind the last one)
   {
     ProfScope ps(ctx, "sk_scatter", n);
     if (canonical)
@@ -2770,7 +2772,7 @@ static kmi_status build_superkmer_w(kmi_index *idx, const FastqScan &sc, bool *d
 // groups of 256 / nranks consecutive coarse buckets), send_counts = records per rank.
 template <int W>
 static kmi_status sk_produce_w(kmi_index *idx, const uint8_t *bytes_dev, size_t n_bytes, uint32_t nranks, const uint64_t **recs_out, uint64_t *n_records,
-                               uint64_t *send_counts, int *produced) {
+                               uint64_t *send_counts, int *produced, uint64_t *out, size_t out_cap) {
   kmi_ctx *ctx = idx->ctx;
   *produced = 0; *recs_out = nullptr; *n_records = 0;
   for (uint32_t r = 0; r < nranks; ++r) send_counts[r] = 0;
@@ -2780,7 +2782,7 @@ static kmi_status sk_produce_w(kmi_index *idx, const uint8_t *bytes_dev, size_t 
   if (sc.n_tuples == 0) { KMI_TRY(fastq_length_verdict(ctx)); *produced = 1; return KMI_OK; }
   const uint32_t lp = 31u - (uint32_t)__builtin_clz(nranks);
   SkFront f;
-  KMI_TRY((sk_front_end<W>(ctx, &idx->cfg, idx->shape, sc, lp, &f)));
+  KMI_TRY((sk_front_end<W>(ctx, &idx->cfg, idx->shape, sc, lp, &f, out, out_cap)));
   if (!f.ok) return KMI_OK;
   const uint32_t per = (uint32_t)kNumCoarse / nranks;
   for (uint32_t c = 0; c < (uint32_t)kNumCoarse; ++c) send_counts[c / per] += f.h_cnt[c];
@@ -4069,8 +4071,8 @@ kmi_status kmi_dbg_size_dist(kmi_dbg *g, kmi_comm *comm, uint64_t *n) {
 }
 
 // ---- builds over ranks through exchanged super-k-mer records
-kmi_status kmi_index_sk_produce_dev(kmi_index *idx, const uint8_t *bytes_dev, size_t n_bytes, uint32_t nranks, const uint64_t **records_dev,
-                                    uint64_t *n_records, uint64_t *send_counts_host, int *produced) {
+kmi_status kmi_index_sk_produce_dev(kmi_index *idx, const uint8_t *bytes_dev, size_t n_bytes, uint32_t nranks, uint64_t *out_records_dev,
+                                    size_t out_capacity, const uint64_t **records_dev, uint64_t *n_records, uint64_t *send_counts_host, int *produced) {
   if (!idx || !records_dev || !n_records || !send_counts_host || !produced) return KMI_ERR_INVALID;
   kmi_ctx *ctx = idx->ctx;
   KMI_HIP(ctx, hipSetDevice(ctx->device));
@@ -4079,9 +4081,10 @@ kmi_status kmi_index_sk_produce_dev(kmi_index *idx, const uint8_t *bytes_dev, si
   if (!w || nranks < 2 || nranks > 8 || (nranks & (nranks - 1u))) return KMI_OK;   // not a case of this path: the caller routes k-mers
   if (ctx->sk_dbg == 7) return KMI_OK;   // (test knob: as if the input had exceeded a capacity of the front end)
   if (n_bytes) KMI_TRY(align_input(ctx, &bytes_dev, n_bytes));
-  return w == 19u ? sk_produce_w<19>(idx, bytes_dev, n_bytes, nranks, records_dev, n_records, send_counts_host, produced)
-       : (w == 13u ? sk_produce_w<13>(idx, bytes_dev, n_bytes, nranks, records_dev, n_records, send_counts_host, produced)
-                   : sk_produce_w<7>(idx, bytes_dev, n_bytes, nranks, records_dev, n_records, send_counts_host, produced));
+  if (!out_records_dev) out_capacity = 0;
+  return w == 19u ? sk_produce_w<19>(idx, bytes_dev, n_bytes, nranks, records_dev, n_records, send_counts_host, produced, out_records_dev, out_capacity)
+       : (w == 13u ? sk_produce_w<13>(idx, bytes_dev, n_bytes, nranks, records_dev, n_records, send_counts_host, produced, out_records_dev, out_capacity)
+                   : sk_produce_w<7>(idx, bytes_dev, n_bytes, nranks, records_dev, n_records, send_counts_host, produced, out_records_dev, out_capacity));
 }
 
 kmi_status kmi_index_sk_consume_dev(kmi_index *idx, const uint64_t *records_dev, size_t n_records, uint32_t nranks) {

@@ -159,6 +159,7 @@ class DistributedCountIndex:
         self._cap = 0
         self._verified = False                     # the first exchange of this object carries checksums (verify_exchange)
         self.last_send_counts = None               # pairs sent to every rank by the last build (peer balance)
+        self._sk_cap = {}                          # records the chunks of the last super-k-mer build produced (send buffer sizes)
 
     def _buffers(self, n, dev):
         if n > self._cap or not hasattr(self, "_keys"):     # (a first build that yields no k-mer still needs the buffers)
@@ -226,8 +227,14 @@ class DistributedCountIndex:
         for c in range(nch):
             recs_p, n, produced = C.c_void_p(), C.c_uint64(), C.c_int(0)
             sc = np.zeros(self.world, dtype=np.uint64)
-            self.ctx.check(L.lib.kmi_index_sk_produce_dev(self.index.h, C.c_void_p(dptr + bounds[c]), bounds[c + 1] - bounds[c], self.world,
+            # the records go straight into the send buffer when it is large enough (150-bp reads give one record per 24 input
+            # bytes; the size of the last chunk's is remembered), else into library workspace and are copied over
+            cb = bounds[c + 1] - bounds[c]
+            cap = max(int(cb * 0.05) + 4096, int(self._sk_cap.get(c, 0) * 1.05))
+            send = torch.empty((cap, 2), dtype=torch.int64, device=device)
+            self.ctx.check(L.lib.kmi_index_sk_produce_dev(self.index.h, C.c_void_p(dptr + bounds[c]), cb, self.world, C.c_void_p(send.data_ptr()), cap,
                                                           C.byref(recs_p), C.byref(n), sc.ctypes.data_as(C.c_void_p), C.byref(produced)))
+            self._sk_cap[c] = n.value
             counts = [int(x) for x in sc]
             # the send counts go round with the verdict: a rank that could not produce this chunk says so with -1
             t = torch.tensor(counts if produced.value else [-1] * self.world, dtype=torch.int64, device=cdev)
@@ -237,8 +244,10 @@ class DistributedCountIndex:
             if not produced.value or min(rc) < 0:                      # (every rank hears from every rank: all see the same verdict)
                 kmer_chunks.append(c)
                 continue
-            send = torch.empty((n.value, 2), dtype=torch.int64, device=device)
-            if n.value:
+            if recs_p.value == send.data_ptr() or n.value == 0:
+                send = send[: n.value]
+            else:
+                send = torch.empty((n.value, 2), dtype=torch.int64, device=device)
                 self.ctx.check(L.lib.kmi_copy_on_device(self.ctx.h, C.c_void_p(send.data_ptr()), recs_p, n.value * 16))
             total_sc = [a + b for a, b in zip(total_sc, counts)]
             n_in = sum(rc)

@@ -33,8 +33,8 @@ def main():
         for rep in range(2 if r == 0 else 1):
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            ctx.check(L.lib.kmi_index_sk_produce_dev(idx.h, C.c_void_p(d.data_ptr()), host.size, world, C.byref(recs), C.byref(n), sc.ctypes.data_as(C.c_void_p),
-                                                     C.byref(produced)))
+            ctx.check(L.lib.kmi_index_sk_produce_dev(idx.h, C.c_void_p(d.data_ptr()), host.size, world, None, 0, C.byref(recs), C.byref(n),
+                                                     sc.ctypes.data_as(C.c_void_p), C.byref(produced)))
             torch.cuda.synchronize()
             if r == 0:
                 t_front = time.perf_counter() - t0
