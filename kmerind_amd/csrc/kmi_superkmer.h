@@ -467,12 +467,16 @@ __global__ __launch_bounds__(kPartThreads) void sk_recv_hist_kernel(const uint64
 // starts at or before g -- the records mark their first k-mer in a byte array (own[P_r] = r + 1), the step reads own[g]
 // and takes a running maximum over the lanes (DPP scan) -- its words come over the lane crossbar (ds_bpermute), and its
 // k-mer j = g - P_r is cut out of the record's 128 bits; the forward strand comes from one reverse complement.
+#ifndef KMI_SK_H1
+#define KMI_SK_H1 1536   // (2048 left the k-mer table 1000 slots less: config 2 the same, 0.2 - 0.3 ms slower where buckets hold 3800 keys)
+#endif
 template <int OWN_>
 struct SkTabCfg {
   static constexpr int NT = 1024, NWAVES = NT / kWave;
   static constexpr int OWN = OWN_;                       // k-mers of a batch of 64 records at most (64 x nmax)
-  static constexpr int S1 = 2048 + 64;                   // record table slots (20 bytes each)
-  static constexpr int L1 = 1536;                        // records it takes before the rest goes direct
+  static constexpr int H1 = KMI_SK_H1;                   // record table home slots
+  static constexpr int S1 = H1 + 64;                     // record table slots (20 bytes each)
+  static constexpr int L1 = H1 * 3 / 4;                  // records it takes before the rest goes direct
   static constexpr int FIXED = NWAVES * (OWN + kMissQ * 12) + S1 * 20 + 2560;   // + control words and the pass stack
   static constexpr int S2 = ((160 * 1024 - FIXED) / 12) / 64 * 64;   // k-mer table slots (12 bytes each)
   static constexpr int CAP2 = S2 - 64, LIMIT2 = CAP2 * 4 / 5;   // LIMIT2: distinct keys of a pass before the bucket is split
@@ -691,7 +695,7 @@ __global__ __launch_bounds__(1024) void sk_reduce_kernel(const uint64_t *__restr
           // first empty one is claimed; a record that finds neither in two such windows is expanded directly
           uint32_t h = ((uint32_t)rec.x ^ (uint32_t)(rec.x >> 32)) * 0x9E3779B1u ^ ((uint32_t)rec.y ^ (uint32_t)(rec.y >> 32)) * 0x85EBCA6Bu;
           h ^= h >> 15;
-          const uint32_t s0 = h >> 21;   // 2048 home slots (+ 64 of padding)
+          const uint32_t s0 = ((h >> 16) * (uint32_t)T::H1) >> 16;   // H1 home slots (+ 64 of padding)
           for (uint32_t s = s0; direct && s < s0 + 8u; s += 4u) {   // (a second window of four for the few that find the first one taken)
             ulonglong2 e[4];
 #pragma unroll
