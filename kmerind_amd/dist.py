@@ -51,7 +51,10 @@ def verify_exchange(send, sc, recv, rc, group=None, stage_through_host=False):
     world = dist.get_world_size(group)
 
     def sums(t, counts):
-        flat = t.reshape(t.shape[0], -1).to(torch.int64) if t.dim() > 1 else t.to(torch.int64).reshape(-1, 1)
+        width = 1
+        for d in t.shape[1:]:
+            width *= int(d)
+        flat = t.reshape(t.shape[0], width).to(torch.int64)       # (an explicit width: a rank may have nothing to send)
         out, off = [], 0
         for c in counts:
             out.append(flat[off:off + c].sum() if c else torch.zeros((), dtype=torch.int64, device=t.device))

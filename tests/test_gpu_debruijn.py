@@ -252,3 +252,28 @@ def test_reference_sample_program_through_the_facade():
         ak, ac = om.export(canonical=True)
         assert got == (om.size(), om.size(), fk.shape[0], int(fk[:, 0].sum()), int((fc[:, :8].astype(np.uint64) * w).sum()), nbr,
                        int(ac[:, 0].astype(np.uint64).sum() + ac[:, 7].astype(np.uint64).sum()))
+
+
+def test_degenerate_inputs(ctx):
+    """nothing, reads shorter than k, a read of exactly k bases (one node without edges), CRLF line ends"""
+    import kmerind_amd as K
+    k = 21
+    s = orc.kspec(k)
+    g = K.DeBruijnNodes(ctx, K.make_config(k))
+    g.build(b"")
+    assert g.local_size() == 0 and g.find(np.zeros((3, 1), np.uint64))[0].shape[0] == 0
+    g.build(b"@a\nACGT\n+\nIIII\n@b\nACGTACGT\n+\nIIIIIIII\n")
+    assert g.local_size() == 0
+    exact = b"@c\nACGTTGCAACGTTGCAACGTA\n+\n" + b"I" * 21 + b"\n"
+    g.build(exact)
+    keys, cnt = g.to_vector()
+    assert keys.shape[0] == 1 and cnt.tolist() == [[0] * 8 + [1]]
+    crlf = b"@d\r\nACGTTGCAACGTTGCAACGTACCGT\r\n+\r\n" + b"I" * 25 + b"\r\n"
+    om = orc.DbgMap(s)
+    om.insert(*orc.dbg_parse(s, exact))
+    om.insert(*orc.dbg_parse(s, crlf))
+    g.build(crlf)
+    assert (_nodes(*g.to_vector()) == _nodes(*om.export(canonical=True))).all()
+    gk, ge = g.parse(crlf)
+    ok, oe = orc.dbg_parse(s, crlf)
+    assert (gk == ok).all() and (ge == oe).all()

@@ -209,3 +209,54 @@ def test_distributed_position_quality_index_in_batches():
     got_v = np.concatenate([ret[r][1] for r in range(world)])
     assert (orc.sorted_rows(got_k, got_v) == orc.sorted_rows(rk, rv)).all()
     assert all(ret[r][2] == ref.size() for r in range(world))
+
+
+def _lopsided_worker(rank, world, port, data, k, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import torch
+        import kmerind_amd as K
+        from kmerind_amd import dist as kdist
+        dev = torch.device("cuda", 0)
+        ctx = K.Context(0, rank=rank, nranks=world)
+        didx = kdist.DistributedCountIndex(ctx, K.make_config(k), stage_through_host=True, device=dev)
+        # rank 0 holds everything, rank 1 an empty share (it still enters every collective); then a share of reads shorter than k
+        mine = data if rank == 0 else b""
+        buf = np.frombuffer(mine, dtype=np.uint8)
+        d = torch.from_numpy(np.concatenate([buf, np.zeros(64, np.uint8)])).to(dev)
+        didx.build_device(d.data_ptr(), buf.size, dev, mode="superkmer")
+        short = b"".join(b"@s%d\nACGTACGTAC\n+\nIIIIIIIIII\n" % i for i in range(50)) if rank == 1 else b""
+        buf2 = np.frombuffer(short, dtype=np.uint8)
+        d2 = torch.from_numpy(np.concatenate([buf2, np.zeros(64, np.uint8)])).to(dev)
+        didx.build_device(d2.data_ptr(), buf2.size, dev, mode="superkmer")
+        keys, cnts = didx.index.to_vector()
+        q = orc.extract(orc.kspec(k), data, orc.FASTQ)["kmers"][rank::7][:400]
+        fk, fv = didx.find(q)
+        ret[rank] = (keys.copy(), cnts.copy(), didx.size(), q.copy(), fk.copy(), fv.copy(), didx.last_mode)
+        didx.close()
+        ctx.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_superkmer_exchange_with_an_empty_share_and_reads_shorter_than_k():
+    import kmerind_amd as K
+    world, k = 2, 31
+    data = bytes(K.synth_fastq(seed=12, genome_len=20_000, n_reads=1_500))
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_lopsided_worker, args=(world, _free_port(), data, k, ret), nprocs=world, join=True)
+    s = orc.kspec(k)
+    ref = orc.CountMap(s, orc.CANONICAL)
+    ref.insert(orc.extract(s, data, orc.FASTQ)["kmers"])
+    rk, rc = ref.export()
+    keys = np.concatenate([ret[r][0] for r in range(world)])
+    cnts = np.concatenate([ret[r][1] for r in range(world)])
+    a, b = orc.sorted_pairs(keys, cnts), orc.sorted_pairs(rk, rc)
+    assert a[0].shape == b[0].shape and (a[0] == b[0]).all() and (a[1] == b[1]).all()
+    for r in range(world):
+        assert ret[r][2] == ref.size() and ret[r][6] == "superkmer" and ret[r][0].shape[0] > 0
+        ek, ev = ref.find(ret[r][3])
+        x, y = orc.sorted_pairs(ret[r][4], ret[r][5]), orc.sorted_pairs(ek, ev)
+        assert x[0].shape == y[0].shape and (x[0] == y[0]).all() and (x[1] == y[1]).all()
