@@ -470,6 +470,9 @@ __global__ __launch_bounds__(kPartThreads) void sk_recv_hist_kernel(const uint64
 #ifndef KMI_SK_H1
 #define KMI_SK_H1 1536   // (2048 left the k-mer table 1000 slots less: config 2 the same, 0.2 - 0.3 ms slower where buckets hold 3800 keys)
 #endif
+#ifndef KMI_SK_FILL
+#define KMI_SK_FILL 80
+#endif
 template <int OWN_>
 struct SkTabCfg {
   static constexpr int NT = 1024, NWAVES = NT / kWave;
@@ -479,7 +482,7 @@ struct SkTabCfg {
   static constexpr int L1 = H1 * 3 / 4;                  // records it takes before the rest goes direct
   static constexpr int FIXED = NWAVES * (OWN + kMissQ * 12) + S1 * 20 + 2560;   // + control words and the pass stack
   static constexpr int S2 = ((160 * 1024 - FIXED) / 12) / 64 * 64;   // k-mer table slots (12 bytes each)
-  static constexpr int CAP2 = S2 - 64, LIMIT2 = CAP2 * 4 / 5;   // LIMIT2: distinct keys of a pass before the bucket is split
+  static constexpr int CAP2 = S2 - 64, LIMIT2 = CAP2 * KMI_SK_FILL / 100;   // LIMIT2: distinct keys of a pass before the bucket is split
 };
 
 // slot hash of the k-mer table (private to this kernel: two multiplies instead of the placement hash's three)
