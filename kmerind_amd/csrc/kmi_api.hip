@@ -16,6 +16,14 @@ kmi_status ws_get(kmi_ctx *ctx, WsSlot slot, size_t bytes, void **out) {
   if (bytes == 0) bytes = 256;
   if (b.cap < bytes) {
     if (b.p) { KMI_HIP(ctx, hipStreamSynchronize(ctx->stream)); KMI_HIP(ctx, hipFree(b.p)); b.p = nullptr; b.cap = 0; }
+    // a block an index gave back fits (ws_detach hands workspace buffers to indexes; they return through the spare list)
+    for (size_t i = 0; i < ctx->spare.size(); ++i)
+      if (ctx->spare[i].bytes >= bytes && ctx->spare[i].bytes / 2 <= bytes) {
+        b.p = ctx->spare[i].p; b.cap = ctx->spare[i].bytes;
+        ctx->spare.erase(ctx->spare.begin() + (long)i);
+        *out = b.p;
+        return KMI_OK;
+      }
     size_t cap = bytes + bytes / 16 + 4096;
     hipError_t e = hipMalloc(&b.p, cap);
     if (e != hipSuccess) { b.p = nullptr; return set_err(ctx, KMI_ERR_NOMEM, "hipMalloc failed: %s", hipGetErrorString(e)); }
@@ -23,6 +31,15 @@ kmi_status ws_get(kmi_ctx *ctx, WsSlot slot, size_t bytes, void **out) {
   }
   *out = b.p;
   return KMI_OK;
+}
+
+// the slot's buffer leaves the workspace (its new owner frees it with pool_free(p, *bytes)); false: the slot holds another buffer
+bool ws_detach(kmi_ctx *ctx, WsSlot slot, const void *p, size_t *bytes) {
+  kmi_ctx::Buf &b = ctx->ws[slot];
+  if (!b.p || b.p != p) return false;
+  *bytes = b.cap;
+  b.p = nullptr; b.cap = 0;
+  return true;
 }
 
 void ws_release(kmi_ctx *ctx, WsSlot slot) {

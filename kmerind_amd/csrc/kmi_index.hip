@@ -2447,7 +2447,9 @@ static kmi_status read_total(kmi_ctx *ctx, int slot, uint64_t *v) {
 // replace the index arrays by the compacted content of tmp
 template <int NW>
 static kmi_status adopt_tmp(kmi_index *idx, const uint64_t *tmp_keys, const uint32_t *tmp_vals, const uint64_t *src_a, const uint64_t *src_b,
-                            const uint32_t *out_cnt, bool fastq_verdict = false) {
+                            const uint32_t *out_cnt, bool fastq_verdict = false, uint64_t n_slots = 0) {
+  // n_slots (the output slots of the reduce, when they start at 0 and src_b is null): a reduce that found every key distinct
+  // filled all of them, so the workspace buffers ARE the index arrays -- they change owner instead of being copied
   kmi_ctx *ctx = idx->ctx;
   uint64_t *new_off = nullptr;
   KMI_HIP(ctx, pool_alloc(ctx, (void **)&new_off, kOffBytes));
@@ -2459,6 +2461,18 @@ static kmi_status adopt_tmp(kmi_index *idx, const uint64_t *tmp_keys, const uint
   kmi_status st_total = read_total(ctx, 4, &total);
   if (st_total == KMI_OK && fastq_verdict) st_total = fastq_length_verdict(ctx);   // the index stays as it was on a parse error
   if (st_total != KMI_OK) { pool_free(ctx, new_off, kOffBytes); return st_total; }
+  if (n_slots && total == n_slots && !src_b && ctx->ws[WS_TMP_KEYS].p == (const void *)tmp_keys && ctx->ws[WS_TMP_VALS].p == (const void *)tmp_vals) {
+    size_t kb0 = 0, vb0 = 0;
+    (void)ws_detach(ctx, WS_TMP_KEYS, tmp_keys, &kb0);
+    (void)ws_detach(ctx, WS_TMP_VALS, tmp_vals, &vb0);
+    KMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    pool_free(ctx, idx->keys, idx->keys_bytes);
+    pool_free(ctx, idx->vals, idx->vals_bytes);
+    pool_free(ctx, idx->bucket_off, kOffBytes);
+    idx->keys = const_cast<uint64_t *>(tmp_keys); idx->vals = const_cast<uint32_t *>(tmp_vals); idx->bucket_off = new_off;
+    idx->n_entries = total; idx->has_data = true; idx->keys_bytes = kb0; idx->vals_bytes = vb0;
+    return KMI_OK;
+  }
   uint64_t *nk = nullptr; uint32_t *nv = nullptr;
   const size_t kb = (total ? total : 1) * NW * sizeof(uint64_t), vb = (total ? total : 1) * sizeof(uint32_t);
   hipError_t e1 = pool_alloc(ctx, (void **)&nk, kb);
@@ -2502,7 +2516,8 @@ static kmi_status reduce_and_adopt(kmi_index *idx, const Partitioned &part, size
                        idx->shape.n_bits == 64u * NW, part.scratch);
   }
   KMI_HIP(ctx, hipGetLastError());
-  return adopt_tmp<NW>(idx, tmp_keys, tmp_vals, part.fine_off, idx->has_data ? idx->bucket_off : nullptr, out_cnt, fastq_verdict);
+  return adopt_tmp<NW>(idx, tmp_keys, tmp_vals, part.fine_off, idx->has_data ? idx->bucket_off : nullptr, out_cnt, fastq_verdict,
+                       idx->has_data ? 0 : (uint64_t)n);
 }
 
 template <int NW, int BITS>
@@ -2593,17 +2608,22 @@ struct SkFront {
 
 template <int W>
 static kmi_status sk_front_end(kmi_ctx *ctx, const kmi_config *cfg, const KShape &shape, const FastqScan &sc, uint32_t lp, SkFront *f,
-                               uint64_t *out = nullptr, size_t out_cap = 0 /* records: the caller's buffer takes them when they fit */) {
+                               uint64_t *out = nullptr, size_t out_cap = 0 /* records: the caller's buffer takes them when they fit */,
+                               const FastaScan *fa = nullptr /* FASTA: the compacted character stream instead of the FASTQ scan */) {
   constexpr int NW = 1, BITS = 2;
   f->ok = false;
-  const uint64_t n = sc.n_tuples, n_tiles = sc.n_tiles;
+  uint64_t n = fa ? 0 : sc.n_tuples;   // (FASTA: the run pass counts the windows)
+  const uint64_t n_tiles = fa ? (fa->n_chars + 8191) / 8192 : sc.n_tiles;
   const uint32_t k = shape.k;
-  PackedInput in; in.eol = sc.pk_eol; in.stream = sc.pk_stream; in.n_bytes = sc.n_bytes; in.n_cover = sc.n_cover; in.n_valid = sc.n_bytes; in.brk = sc.pk_brk;
-  const bool split = sc.pk_brk != nullptr;
+  PackedInput in;
+  if (fa) { in.eol = fa->pk_break; in.stream = fa->pk_stream; in.n_bytes = fa->n_chars; in.n_cover = fa->n_cover; in.n_valid = fa->n_valid; in.brk = nullptr; }
+  else { in.eol = sc.pk_eol; in.stream = sc.pk_stream; in.n_bytes = sc.n_bytes; in.n_cover = sc.n_cover; in.n_valid = sc.n_bytes; in.brk = sc.pk_brk; }
+  const bool split = !fa && sc.pk_brk != nullptr;
   const bool canonical = cfg->strand != KMI_STRAND_SINGLE;
   using LP = ListPassCfg<NW, BITS>;
-  const uint32_t seg = sk_segment_of((uint32_t)W), ipt = sk_items_per_tile((uint32_t)W);
-  const uint32_t stride = LP::run_stride(k, seg, split);
+  // (a tile of the compacted FASTA stream is all windows: 8192 of them against the 3100 of a FASTQ tile -- twice the item slots)
+  const uint32_t seg = sk_segment_of((uint32_t)W), ipt = sk_items_per_tile((uint32_t)W) * (fa ? 2u : 1u);
+  const uint32_t stride = fa ? 8192u / seg + 72u : LP::run_stride(k, seg, split);
   void *p;
   KMI_TRY(ws_get(ctx, WS_ENT_LIST, sizeof(uint32_t) * ((size_t)n_tiles * stride + 64), &p)); uint32_t *ent = (uint32_t *)p;
   KMI_TRY(ws_get(ctx, WS_ENT_CNT, sizeof(uint32_t) * (n_tiles + 8), &p)); uint32_t *ent_cnt = (uint32_t *)p;
@@ -2613,7 +2633,12 @@ static kmi_status sk_front_end(kmi_ctx *ctx, const kmi_config *cfg, const KShape
   KMI_TRY(ws_get(ctx, WS_CURSOR, sizeof(uint64_t) * kPartGroups * kNumCoarse, &p)); uint64_t *wg_off = (uint64_t *)p;
   KMI_TRY(ws_get(ctx, WS_MISC, sizeof(uint64_t) * kNumCoarse * 3, &p)); uint64_t *cnt = (uint64_t *)p, *base = cnt + kNumCoarse;
   KMI_HIP(ctx, hipMemsetAsync(ctx->d_flags + 9, 0, sizeof(uint32_t), ctx->stream));
-  {
+  if (fa) {
+    ProfScope ps(ctx, "fasta_runs", fa->n_chars);
+    KMI_HIP(ctx, hipMemsetAsync(ctx->d_totals + 6, 0, sizeof(uint64_t), ctx->stream));
+    hipLaunchKernelGGL(fasta_runs_kernel, dim3(2048), dim3(256), 0, ctx->stream, reinterpret_cast<const uint32_t *>(fa->pk_break), fa->n_chars, fa->n_valid,
+                       fa->n_cover, n_tiles, k, seg, ent, ent_cnt, stride, (unsigned long long *)(ctx->d_totals + 6), ctx->d_flags);
+  } else {
     ProfScope ps(ctx, "fastq_list", n);
     const uint32_t wave_lds = LP::wave_lds_bytes(k, split);
     hipLaunchKernelGGL((fastq_list_kernel<NW, BITS, true>), dim3(kListGroups), dim3(kListThreads), wave_lds * (kListThreads / kWave), ctx->stream, in,
@@ -2633,8 +2658,9 @@ static kmi_status sk_front_end(kmi_ctx *ctx, const kmi_config *cfg, const KShape
   uint32_t h_flag = 0;
   KMI_HIP(ctx, hipMemcpyAsync(h_cnt, cnt, sizeof(uint64_t) * 2 * kNumCoarse, hipMemcpyDeviceToHost, ctx->stream));
   KMI_HIP(ctx, hipMemcpyAsync(&h_flag, ctx->d_flags + 9, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+  if (fa) KMI_HIP(ctx, hipMemcpyAsync(&n, ctx->d_totals + 6, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
   KMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  KMI_TRY(fastq_length_verdict(ctx));     // the seq / qual length rule rode on the list pass: the index stays as it was on a parse error
+  if (!fa) KMI_TRY(fastq_length_verdict(ctx));     // the seq / qual length rule rode on the list pass: the index stays as it was on a parse error
   if (h_flag) return KMI_OK;              // a run with more items than a lane's list holds, or a tile with more than its share
   uint64_t R = 0;
   for (int c = 0; c < kNumCoarse; ++c) { R += h_cnt[c]; f->h_cnt[c] = h_cnt[c]; f->h_base[c] = h_cnt[kNumCoarse + c]; }
@@ -2734,7 +2760,7 @@ static kmi_status sk_back_end(kmi_index *idx, const uint64_t *rec_a, uint64_t R,
   if (!idx->has_data || idx->n_entries == 0) {
     // the index IS the reduce output: entries grouped by minimizer bucket. Queries partition their keys by the same function
     // (fine15_of_key); whatever needs the placement-hash layout converts the entries once (ensure_layout).
-    KMI_TRY((adopt_tmp<NW>(idx, tmp_keys, tmp_vals, kmer_off, nullptr, out_cnt)));
+    KMI_TRY((adopt_tmp<NW>(idx, tmp_keys, tmp_vals, kmer_off, nullptr, out_cnt, false, n)));
     idx->layout_w = layout;
     if (n) ctx->sk_inv_dup = (float)((double)idx->n_entries / (double)n);   // where the buckets of the next build start (sk_reduce_kernel)
     return KMI_OK;
@@ -2764,6 +2790,20 @@ static kmi_status build_superkmer_w(kmi_index *idx, const FastqScan &sc, bool *d
   KMI_TRY((sk_front_end<W>(idx->ctx, &idx->cfg, idx->shape, sc, 0u, &f)));
   if (!f.ok) return KMI_OK;
   *done = true;
+  return sk_back_end<W>(idx, f.recs, f.n_records, f.h_cnt, f.h_base, f.wg_off, f.n_kmers, 0u);
+}
+
+// FASTA count index through super-k-mers: the compacted character stream of kmi_fasta.hip is "FASTQ without line roles", its
+// run list comes from the break bitmap (fasta_runs_kernel), everything behind it is the FASTQ build's
+template <int W>
+static kmi_status build_superkmer_fasta_w(kmi_index *idx, const FastaScan &fa, bool *done) {
+  *done = false;
+  SkFront f;
+  FastqScan none{};
+  KMI_TRY((sk_front_end<W>(idx->ctx, &idx->cfg, idx->shape, none, 0u, &f, nullptr, 0, &fa)));
+  if (!f.ok) return KMI_OK;
+  *done = true;
+  if (f.n_records == 0) return KMI_OK;
   return sk_back_end<W>(idx, f.recs, f.n_records, f.h_cnt, f.h_base, f.wg_off, f.n_kmers, 0u);
 }
 
@@ -3472,6 +3512,15 @@ kmi_status kmi_index_build_dev(kmi_index *idx, const uint8_t *bytes_dev, size_t 
   KMI_TRY(align_input(ctx, &bytes_dev, n_bytes));
   if (idx->val_words == 0 && idx->cfg.seq_format == KMI_FMT_FASTQ) return index_build_fused(idx, bytes_dev, n_bytes);
   if (idx->val_words == 0) {
+    const uint32_t w = (idx->shape.n_words == 1 && idx->shape.bits == 2 && ctx->fused_superkmer) ? sk_window_of(idx->shape.k) : 0u;
+    if (w) {   // FASTA count index of one-word DNA k-mers: super-k-mers cut from the compacted stream (falls through when a capacity is exceeded)
+      FastaScan fa;
+      KMI_TRY(fasta_scan(ctx, &idx->cfg, bytes_dev, n_bytes, file_offset, false, &fa));
+      if (fa.n_chars < idx->shape.k) return KMI_OK;
+      bool done = false;
+      kmi_status st = w == 19u ? build_superkmer_fasta_w<19>(idx, fa, &done) : (w == 13u ? build_superkmer_fasta_w<13>(idx, fa, &done) : build_superkmer_fasta_w<7>(idx, fa, &done));
+      if (st != KMI_OK || done) return st;
+    }
     // FASTA count index: tuples from the compacted-stream extract, then the key insert path
     uint64_t nt = 0, ns = 0;
     KMI_TRY(extract_count(ctx, &idx->cfg, bytes_dev, n_bytes, &nt, &ns));

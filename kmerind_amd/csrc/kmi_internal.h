@@ -144,6 +144,7 @@ inline kmi_status set_err(kmi_ctx *ctx, kmi_status st, const char *fmt, const ch
 // workspace slot of at least `bytes` (contents are not preserved when it grows)
 kmi_status ws_get(kmi_ctx *ctx, WsSlot slot, size_t bytes, void **out);
 void ws_release(kmi_ctx *ctx, WsSlot slot);
+bool ws_detach(kmi_ctx *ctx, WsSlot slot, const void *p, size_t *bytes);
 
 // profiling hooks around one kernel launch
 void prof_begin(kmi_ctx *ctx, const char *name, uint64_t units);

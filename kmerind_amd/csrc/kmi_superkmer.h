@@ -84,6 +84,80 @@ __device__ __forceinline__ uint32_t sk_lo(const SkWin &w) { return __builtin_amd
 __device__ __forceinline__ uint32_t sk_hi(const SkWin &w) { return __builtin_amdgcn_alignbit(w.r2, w.r1, w.sh); }
 
 // ---------------------------------------------------------------------------
+// L (FASTA): the run list of a compacted character stream (kmi_fasta.hip: every position is a base, bit r of the break bitmap
+// = character r opens a record, or lies behind an N under the N-split rule). Window r is a k-mer iff no break bit falls in
+// (r, r + k) and r + k <= n_chars (and r < n_valid in a partition). One wavefront per tile of 8192 positions, lane l owns
+// the 128 window positions from 128 l: its runs of valid windows, cut every `seg`, become entries (tile position | (windows
+// - 1) << 13) exactly as fastq_list<RUNS> writes them for FASTQ lines.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void fasta_runs_kernel(const uint32_t *__restrict__ brk, uint64_t n_chars, uint64_t n_valid, uint64_t n_cover,
+                                                        uint64_t n_tiles, uint32_t k, uint32_t seg, uint32_t *__restrict__ ent,
+                                                        uint32_t *__restrict__ ent_cnt, uint32_t stride, unsigned long long *__restrict__ n_windows,
+                                                        uint32_t *__restrict__ flags) {
+  const uint32_t lane = lane_id();
+  const uint64_t n_words = n_cover / 32;
+  const uint64_t n_waves = (uint64_t)gridDim.x * (blockDim.x / kWave);
+  for (uint64_t t = (uint64_t)blockIdx.x * (blockDim.x / kWave) + wave_id(); t < n_tiles; t += n_waves) {
+    const uint64_t p0 = t * 8192ull + (uint64_t)lane * 128ull;
+    // break bits of positions p0 + 1 .. p0 + 191 (k <= 32): three 64-bit words starting one position up
+    uint64_t x[3];
+    {
+      uint32_t w[7];
+      const uint64_t w0 = p0 >> 5;
+#pragma unroll
+      for (int i = 0; i < 7; ++i) w[i] = (w0 + i < n_words) ? brk[w0 + i] : 0u;
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const uint64_t lo = (uint64_t)w[2 * j] | ((uint64_t)w[2 * j + 1] << 32), hi = (uint64_t)w[2 * j + 2];
+        x[j] = (lo >> 1) | (hi << 63);   // (p0 is a multiple of 32: bit 0 of w[0] is position p0 itself)
+      }
+    }
+    smear_right<3>(x, k - 1u);          // bit i: a break in (p0 + i, p0 + i + k)
+    uint64_t v0 = ~x[0], v1 = ~x[1];    // valid window starts p0 + 0..63, p0 + 64..127
+    {
+      // r + k <= n_chars and r < n_valid
+      const uint64_t lim_a = n_chars >= k ? n_chars - k + 1u : 0u, lim = lim_a < n_valid ? lim_a : n_valid;   // windows start below lim
+      const uint64_t room = lim > p0 ? lim - p0 : 0u;
+      v0 &= room >= 64 ? ~0ull : ((1ull << room) - 1ull);
+      const uint64_t room1 = room > 64 ? room - 64 : 0u;
+      v1 &= room1 >= 64 ? ~0ull : ((1ull << room1) - 1ull);
+    }
+    const uint32_t nwin = (uint32_t)__popcll(v0) + (uint32_t)__popcll(v1);
+    // two walks over the lane's 128 bits: count the entries, then write them behind the lanes before
+    auto walk = [&](uint32_t base, bool write) -> uint32_t {
+      uint64_t a = v0, b = v1;
+      uint32_t c = 0;
+      while (a | b) {
+        const uint32_t p = a ? (uint32_t)__builtin_ctzll(a) : 64u + (uint32_t)__builtin_ctzll(b);
+        // ones from p on: shift the 128 bits down by p and count the trailing ones
+        uint64_t lo, hi;
+        if (p >= 64u) { lo = b >> (p - 64u); hi = 0; } else { lo = p ? ((a >> p) | (b << (64u - p))) : a; hi = b >> p; }
+        uint32_t run = (~lo) ? (uint32_t)__builtin_ctzll(~lo) : 64u + ((~hi) ? (uint32_t)__builtin_ctzll(~hi) : 64u);
+        run = run > seg ? seg : run;
+        if (write && base + c < stride) ent[t * stride + base + c] = (lane * 128u + p) | ((run - 1u) << 13);
+        ++c;
+        // clear [p, p + run)
+        const uint32_t e = p + run;
+        const uint64_t m0 = (e >= 64u ? ~0ull : ((1ull << e) - 1ull)) & ~(p >= 64u ? ~0ull : ((1ull << p) - 1ull));
+        const uint64_t m1 = (e <= 64u ? 0ull : (e >= 128u ? ~0ull : ((1ull << (e - 64u)) - 1ull))) & ~(p <= 64u ? 0ull : ((1ull << (p - 64u)) - 1ull));
+        a &= ~m0; b &= ~m1;
+      }
+      return c;
+    };
+    const uint32_t cnt = walk(0u, false);
+    const uint32_t inc = wave_inclusive_scan(cnt);
+    const uint32_t total = __shfl(inc, kWave - 1, kWave);
+    (void)walk(inc - cnt, true);
+    const uint32_t wsum = wave_reduce_sum(nwin);
+    if (lane == 0) {
+      ent_cnt[t] = total < stride ? total : stride;
+      if (total > stride) atomicOr(&flags[9], 1u);   // more runs than the tile's slots: the caller takes the k-mer path
+      if (wsum) atomicAdd(n_windows, (unsigned long long)wsum);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
 // M: minimizers and super-k-mer boundaries, one lane per run
 // ---------------------------------------------------------------------------
 template <int W>
@@ -591,7 +665,8 @@ __global__ __launch_bounds__(1024) void sk_reduce_kernel(const uint64_t *__restr
     const uint32_t fbits = pass & 0xffu, fval = pass >> 8;
     lds_barrier();                            // everyone has read the stack
     // a bucket that needs four passes or more holds little duplication: counting identical records first would only cost
-    const bool use_t1 = fbits < 2u;
+    // ... and so does an input whose last build found more than every second k-mer distinct (a genome: nothing to count twice)
+    const bool use_t1 = fbits < 2u && !(inv_dup > 0.5f);
     for (uint32_t i = threadIdx.x; i < (uint32_t)T::S2; i += T::NT) { s_tk[i] = kEmptyKey; s_tv[i] = 0; }
     if (use_t1) for (uint32_t i = threadIdx.x; i < (uint32_t)T::S1; i += T::NT) { s_r[i] = make_ulonglong2(kEmptyKey, W1_INIT); s_rc[i] = 0; }
     if (threadIdx.x == 0) { s_ctl[0] = 0; s_ctl[1] = 0; s_ctl[2] = 0; s_ctl[3] = 0; s_ctl[5] = sp - 1; s_ctl[8] = 0; }
