@@ -171,3 +171,38 @@ def test_fasta_split_over_ranks_equals_whole_file(ctx, k, alpha):
     km, ids, _ = ctx.read_file(cfg, inputs[0], file_offset=1000, with_ids=True)
     w0 = orc.extract(s, inputs[0], orc.FASTA, file_offset=1000, want_ids=True)
     assert (km == w0["kmers"]).all() and (ids == w0["ids"]).all()
+
+
+@pytest.mark.parametrize("k,strand,seq_filter", [(31, "canonical", "all"), (25, "single", "all"), (19, "canonical", "all"), (31, "canonical", "n_split"),
+                                                 (31, "canonical", "n_filter")])
+def test_fasta_count_index_goes_through_super_kmers(ctx, k, strand, seq_filter):
+    """A FASTA count index of one-word DNA k-mers (k >= 17) is built from super-k-mers cut out of the compacted character stream
+    (fasta_runs -> sk_minimizer -> ... -> sk_reduce): those kernels must have run, and the index must be the oracle's -- multi-line
+    records, short and empty ones, comment lines, lower case, N (an A inside a 2-bit k-mer; a cut under the sequence filters);
+    a second build merges into the entries of the first; queries find what was built."""
+    import kmerind_amd as K
+    rng = np.random.default_rng(k)
+    data = _synthetic_fasta(rng, 60, max_len=4000) + b">long\n" + bytes(rng.choice(list(b"ACGT"), size=30_000).tolist()) + b"\n"
+    data2 = _synthetic_fasta(rng, 25, max_len=2500)
+    s = orc.kspec(k, orc.DNA)
+    filt = {"all": orc.SEQ_ALL, "n_split": orc.SEQ_N_SPLIT, "n_filter": orc.SEQ_N_FILTER}[seq_filter]
+    om = orc.CountMap(s, orc.CANONICAL if strand == "canonical" else orc.SINGLE)
+    idx = K.CountIndex(ctx, K.make_config(k, "DNA", strand=strand, seq_format="fasta", seq_filter=seq_filter))
+    ctx.profile(True)
+    ctx.profile_reset()
+    idx.build(data)
+    names = {p["name"] for p in ctx.profile_get() if p["launches"]}
+    ctx.profile(False)
+    assert {"fasta_runs", "sk_minimizer", "sk_scatter", "sk_reduce"} <= names and "fasta_extract" not in names, names
+    ex = orc.extract(s, data, orc.FASTA, seq_filter=filt)["kmers"]
+    om.insert(ex)
+    a, b = orc.sorted_pairs(*idx.to_vector()), orc.sorted_pairs(*om.export())
+    assert a[0].shape == b[0].shape and (a[0] == b[0]).all() and (a[1] == b[1]).all()
+    idx.build(data2)
+    om.insert(orc.extract(s, data2, orc.FASTA, seq_filter=filt)["kmers"])
+    a, b = orc.sorted_pairs(*idx.to_vector()), orc.sorted_pairs(*om.export())
+    assert a[0].shape == b[0].shape and (a[0] == b[0]).all() and (a[1] == b[1]).all()
+    q = np.concatenate([ex[::17], rng.integers(0, 1 << (2 * k - 1), size=(300, 1), dtype=np.uint64)])
+    fa, fb = orc.sorted_pairs(*idx.find(q)), orc.sorted_pairs(*[x.astype(np.uint64) if x.dtype != np.uint64 else x for x in om.find(q)])
+    assert fa[0].shape == fb[0].shape and (fa[0] == fb[0]).all() and (fa[1] == fb[1]).all()
+    idx.close()
