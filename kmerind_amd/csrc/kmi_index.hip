@@ -3363,6 +3363,20 @@ static kmi_status merge_impl(kmi_index *idx, uint32_t nparts, const uint64_t *ke
 
 }  // namespace kmi
 
+// dispatch of the two halves on the window width
+static kmi_status sk_produce(kmi_index *idx, uint32_t w, const uint8_t *bytes_dev, size_t n_bytes, uint32_t nranks, const uint64_t **recs, uint64_t *n_records,
+                             uint64_t *send_counts, int *produced, uint64_t *out, size_t out_cap) {
+  return w == 19u ? sk_produce_w<19>(idx, bytes_dev, n_bytes, nranks, recs, n_records, send_counts, produced, out, out_cap)
+       : (w == 13u ? sk_produce_w<13>(idx, bytes_dev, n_bytes, nranks, recs, n_records, send_counts, produced, out, out_cap)
+                   : sk_produce_w<7>(idx, bytes_dev, n_bytes, nranks, recs, n_records, send_counts, produced, out, out_cap));
+}
+static kmi_status sk_consume(kmi_index *idx, uint32_t w, const uint64_t *recs_dev, uint64_t n_records, uint32_t nranks) {
+  if (n_records == 0) { idx->owner_lp = 31u - (uint32_t)__builtin_clz(nranks); return KMI_OK; }
+  return w == 19u ? sk_consume_w<19>(idx, recs_dev, n_records, nranks) : (w == 13u ? sk_consume_w<13>(idx, recs_dev, n_records, nranks)
+                                                                                     : sk_consume_w<7>(idx, recs_dev, n_records, nranks));
+}
+static bool sk_rank_count(uint32_t p) { return p == 1u || p == 2u || p == 4u || p == 8u; }
+
 #include "kmi_debruijn.h"
 #include "kmi_update.h"
 
@@ -3776,7 +3790,9 @@ kmi_status kmi_index_insert_dist_host(kmi_index *idx, kmi_comm *comm, const uint
   KMI_TRY(ws_get(ctx, WS_DIST_A, (n + 8) * kb, &d_send));
   if (n) KMI_HIP(ctx, hipMemcpyAsync(d_in, kmers, n * kb, hipMemcpyHostToDevice, ctx->stream));
   std::vector<uint64_t> sc(p, 0), rc;
-  KMI_TRY(kmi_route_dev(ctx, &idx->cfg, (const uint64_t *)d_in, n, (uint32_t)p, (uint64_t *)d_send, sc.data()));   // InputTransform + grouping by KeyToRank
+  // InputTransform + grouping by KeyToRank -- or by the owner of the minimizer's bucket when that is how the entries are distributed
+  if (idx->owner_lp && idx->n_entries) KMI_TRY(kmi_route_owner_dev(ctx, &idx->cfg, (const uint64_t *)d_in, n, (uint32_t)p, (uint64_t *)d_send, sc.data()));
+  else KMI_TRY(kmi_route_dev(ctx, &idx->cfg, (const uint64_t *)d_in, n, (uint32_t)p, (uint64_t *)d_send, sc.data()));
   uint64_t total = 0;
   KMI_TRY(dist_exchange(comm, d_send, sc.data(), kb, WS_DIST_B, &d_recv, rc, &total));
   return index_insert(idx, (const uint64_t *)d_recv, (size_t)total, false);
@@ -3820,8 +3836,34 @@ kmi_status kmi_index_build_dist_host(kmi_index *idx, kmi_comm *comm, const uint8
   uint64_t nt = 0, ns = 0, total = 0;
   if (n_bytes) KMI_TRY(extract_count(ctx, &idx->cfg, (const uint8_t *)d_bytes, n_bytes, &nt, &ns));   // (an empty share still enters the collectives)
   if (vw == 0) {
+    const uint32_t skw = sk_width_of(idx);
+    const bool by_owner = idx->owner_lp != 0 && idx->n_entries != 0;      // the entries are already distributed by minimizer owner
+    if (skw && sk_rank_count((uint32_t)p) && (idx->n_entries == 0 || (1u << idx->owner_lp) == (uint32_t)p)) {
+      // the ranks exchange the super-k-mer records of the fused build instead of k-mers (kmi_index_sk_produce_dev): every rank or none
+      const uint64_t *recs = nullptr;
+      uint64_t nrec = 0, agree = 0;
+      int produced = 0;
+      const uint8_t *src = (const uint8_t *)d_bytes;
+      if (n_bytes) KMI_TRY(align_input(ctx, &src, n_bytes));
+      KMI_TRY(sk_produce(idx, skw, src, n_bytes, (uint32_t)p, &recs, &nrec, sc.data(), &produced, nullptr, 0));
+      agree = produced ? 1u : 0u;
+      KMI_TRY(kmi::comm_allreduce_sum(comm, &agree));
+      if (agree == (uint64_t)p) {
+        KMI_TRY(dist_exchange(comm, recs, sc.data(), 16, WS_DIST_B, &d_recv, rc, &total));
+        return sk_consume(idx, skw, (const uint64_t *)d_recv, total, (uint32_t)p);
+      }
+      for (int r = 0; r < p; ++r) sc[r] = 0;   // some rank could not: the k-mer route below, for everybody
+    }
     KMI_TRY(ws_get(ctx, WS_DIST_A, (nt + 64) * nw * sizeof(uint64_t), &d_send));
-    if (nt && idx->cfg.seq_format == KMI_FMT_FASTQ) {
+    if (by_owner) {
+      // k-mers into an index that is distributed by minimizer owner go to those owners
+      void *d_keys;
+      KMI_TRY(ws_get(ctx, WS_OUTPUT, (nt + 64) * nw * sizeof(uint64_t), &d_keys));
+      if (nt) {
+        KMI_TRY(extract_run(ctx, &idx->cfg, (const uint8_t *)d_bytes, n_bytes, file_offset, (uint64_t *)d_keys, nullptr, (size_t)nt, true, true, &nt, &ns));
+        KMI_TRY(kmi_route_owner_dev(ctx, &idx->cfg, (const uint64_t *)d_keys, (size_t)nt, (uint32_t)p, (uint64_t *)d_send, sc.data()));
+      }
+    } else if (nt && idx->cfg.seq_format == KMI_FMT_FASTQ) {
       // read_file + the bucketing half of imxx::distribute, fused: the tuple array in file order never exists
       KMI_TRY(kmi_extract_route_dev(ctx, &idx->cfg, (const uint8_t *)d_bytes, n_bytes, (uint32_t)p, (uint64_t *)d_send, (size_t)nt, &nt, &ns, sc.data()));
     } else if (nt) {
@@ -3861,7 +3903,8 @@ static kmi_status query_dist_host(kmi_index *idx, kmi_comm *comm, int mode, cons
   KMI_TRY(ws_get(ctx, WS_DIST_A, (nq + 8) * kb, &d_send));
   if (nq) KMI_HIP(ctx, hipMemcpyAsync(d_in, queries, nq * kb, hipMemcpyHostToDevice, ctx->stream));
   std::vector<uint64_t> sc(p, 0), rc;
-  KMI_TRY(kmi_route_dev(ctx, &idx->cfg, (const uint64_t *)d_in, nq, (uint32_t)p, (uint64_t *)d_send, sc.data()));
+  if (idx->owner_lp) KMI_TRY(kmi_route_owner_dev(ctx, &idx->cfg, (const uint64_t *)d_in, nq, (uint32_t)p, (uint64_t *)d_send, sc.data()));
+  else KMI_TRY(kmi_route_dev(ctx, &idx->cfg, (const uint64_t *)d_in, nq, (uint32_t)p, (uint64_t *)d_send, sc.data()));
   uint64_t total = 0;
   KMI_TRY(dist_exchange(comm, d_send, sc.data(), kb, WS_DIST_B, &d_q, rc, &total));
   if (mode == Q_ERASE) {
@@ -4127,13 +4170,11 @@ kmi_status kmi_index_sk_produce_dev(kmi_index *idx, const uint8_t *bytes_dev, si
   KMI_HIP(ctx, hipSetDevice(ctx->device));
   *produced = 0; *records_dev = nullptr; *n_records = 0;
   const uint32_t w = sk_width_of(idx);
-  if (!w || nranks < 2 || nranks > 8 || (nranks & (nranks - 1u))) return KMI_OK;   // not a case of this path: the caller routes k-mers
+  if (!w || !sk_rank_count(nranks)) return KMI_OK;   // not a case of this path: the caller routes k-mers
   if (ctx->sk_dbg == 7) return KMI_OK;   // (test knob: as if the input had exceeded a capacity of the front end)
   if (n_bytes) KMI_TRY(align_input(ctx, &bytes_dev, n_bytes));
   if (!out_records_dev) out_capacity = 0;
-  return w == 19u ? sk_produce_w<19>(idx, bytes_dev, n_bytes, nranks, records_dev, n_records, send_counts_host, produced, out_records_dev, out_capacity)
-       : (w == 13u ? sk_produce_w<13>(idx, bytes_dev, n_bytes, nranks, records_dev, n_records, send_counts_host, produced, out_records_dev, out_capacity)
-                   : sk_produce_w<7>(idx, bytes_dev, n_bytes, nranks, records_dev, n_records, send_counts_host, produced, out_records_dev, out_capacity));
+  return sk_produce(idx, w, bytes_dev, n_bytes, nranks, records_dev, n_records, send_counts_host, produced, out_records_dev, out_capacity);
 }
 
 kmi_status kmi_index_sk_consume_dev(kmi_index *idx, const uint64_t *records_dev, size_t n_records, uint32_t nranks) {
@@ -4141,10 +4182,9 @@ kmi_status kmi_index_sk_consume_dev(kmi_index *idx, const uint64_t *records_dev,
   kmi_ctx *ctx = idx->ctx;
   KMI_HIP(ctx, hipSetDevice(ctx->device));
   const uint32_t w = sk_width_of(idx);
-  if (!w || nranks < 2 || nranks > 8 || (nranks & (nranks - 1u))) return set_err(ctx, KMI_ERR_INVALID, "no super-k-mer build for this index / rank count");
+  if (!w || !sk_rank_count(nranks)) return set_err(ctx, KMI_ERR_INVALID, "no super-k-mer build for this index / rank count");
   if (n_records && !records_dev) return set_err(ctx, KMI_ERR_INVALID, "null buffer");
-  return w == 19u ? sk_consume_w<19>(idx, records_dev, n_records, nranks) : (w == 13u ? sk_consume_w<13>(idx, records_dev, n_records, nranks)
-                                                                                       : sk_consume_w<7>(idx, records_dev, n_records, nranks));
+  return sk_consume(idx, w, records_dev, n_records, nranks);
 }
 
 kmi_status kmi_index_set_owner_ranks(kmi_index *idx, uint32_t nranks) {

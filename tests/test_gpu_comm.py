@@ -63,8 +63,13 @@ def test_count_index_collectives_over_rccl(dist_ctx, strand):
     ex = orc.extract(s, data, orc.FASTQ)["kmers"]
     om = orc.CountMap(s, st)
     idx = K.CountIndex(ctx, K.make_config(k, "DNA", strand=strand))
-    # build: parse -> route -> RCCL -> insert
+    # build: the fused build's super-k-mer records grouped by owner rank -> RCCL -> the back end (kmi_index_sk_produce / consume)
+    ctx.profile(True)
+    ctx.profile_reset()
     ctx.check(L.lib.kmi_index_build_dist_host(idx.h, comm, data.ctypes.data_as(C.c_void_p), data.size, 0))
+    names = {p["name"] for p in ctx.profile_get() if p["launches"]}
+    ctx.profile(False)
+    assert {"sk_scatter", "sk_recv_scatter", "sk_reduce"} <= names, names
     om.insert(ex)
     # insert of k-mers: route -> RCCL -> insert
     extra = np.ascontiguousarray(ex[::7])
