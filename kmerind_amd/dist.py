@@ -212,7 +212,7 @@ class DistributedCountIndex:
         from . import _lib as L
         staged = self._staged()
         cdev = torch.device("cpu") if staged else device
-        ok = self.world in (2, 4, 8) and (self.index.local_size() == 0 or self.index.owner_ranks() == self.world)
+        ok = self.world in (1, 2, 4, 8) and (self.index.local_size() == 0 or self.index.owner_ranks() == self.world)   # (1: rehearsals)
         bounds = [0, nbytes] if not bounds else [int(b) for b in bounds]
         assert bounds[0] == 0 and bounds[-1] == nbytes and all(a <= b for a, b in zip(bounds, bounds[1:]))
         nch = len(bounds) - 1
