@@ -336,7 +336,9 @@ kmi_status kmi_index_update_pairs_dev(kmi_index *idx, const uint64_t *records_de
  * Index (count / find / erase / size are collectives); the union of the ranks' maps is the reference's map, bit for bit.
  *   produce: this rank's FASTQ share -> records grouped by owner rank (2 words per record), send_counts_host[nranks] in
  *            records. They are written to out_records_dev when that buffer (out_capacity records; may be NULL) holds them
- *            all, else to library workspace valid until the next call on the context; *records_dev says where they are. *produced = 0: this
+ *            all, else to library workspace valid until the next call on the context; *records_dev says where they are.
+ *            They are written on the context's stream and the call does not wait for that: read them on that stream, on a
+ *            stream ordered behind it (a collective issued from it), or through kmi_copy_on_device. *produced = 0: this
  *            path does not apply (shape, rank count) or an input exceeded a capacity of the fused front end -- EVERY
  *            rank must then take the k-mer route for this input (agree on min(*produced) over ranks first);
  *   (caller: all-to-all of the records, 16-byte elements)

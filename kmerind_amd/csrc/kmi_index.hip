@@ -2655,12 +2655,14 @@ static kmi_status sk_front_end(kmi_ctx *ctx, const kmi_config *cfg, const KShape
   }
   KMI_HIP(ctx, hipGetLastError());
   uint64_t h_cnt[2 * kNumCoarse];
-  uint32_t h_flag = 0;
+  uint32_t h_flags[10] = {0};
   KMI_HIP(ctx, hipMemcpyAsync(h_cnt, cnt, sizeof(uint64_t) * 2 * kNumCoarse, hipMemcpyDeviceToHost, ctx->stream));
-  KMI_HIP(ctx, hipMemcpyAsync(&h_flag, ctx->d_flags + 9, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+  KMI_HIP(ctx, hipMemcpyAsync(h_flags, ctx->d_flags, sizeof(h_flags), hipMemcpyDeviceToHost, ctx->stream));
   if (fa) KMI_HIP(ctx, hipMemcpyAsync(&n, ctx->d_totals + 6, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
   KMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  if (!fa) KMI_TRY(fastq_length_verdict(ctx));     // the seq / qual length rule rode on the list pass: the index stays as it was on a parse error
+  // the seq / qual length rule rode on the list pass (flag word 0, bit 2: fastq_length_verdict's): the index stays as it was on a parse error
+  if (!fa && (h_flags[0] & 4u)) return fastq_length_verdict(ctx);
+  const uint32_t h_flag = h_flags[9];
   if (h_flag) return KMI_OK;              // a run with more items than a lane's list holds, or a tile with more than its share
   uint64_t R = 0;
   for (int c = 0; c < kNumCoarse; ++c) { R += h_cnt[c]; f->h_cnt[c] = h_cnt[c]; f->h_base[c] = h_cnt[kNumCoarse + c]; }
@@ -2827,7 +2829,8 @@ static kmi_status sk_produce_w(kmi_index *idx, const uint8_t *bytes_dev, size_t 
   const uint32_t per = (uint32_t)kNumCoarse / nranks;
   for (uint32_t c = 0; c < (uint32_t)kNumCoarse; ++c) send_counts[c / per] += f.h_cnt[c];
   *recs_out = f.recs; *n_records = f.n_records; *produced = 1;
-  KMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  // (the records are being written on the context's stream: whoever reads them is ordered behind it -- a collective on a stream
+  // that waits for this one, the library's own exchange, or kmi_copy_on_device)
   return KMI_OK;
 }
 
