@@ -665,8 +665,10 @@ __global__ __launch_bounds__(1024) void sk_reduce_kernel(const uint64_t *__restr
     const uint32_t fbits = pass & 0xffu, fval = pass >> 8;
     lds_barrier();                            // everyone has read the stack
     // a bucket that needs four passes or more holds little duplication: counting identical records first would only cost
-    // ... and so does an input whose last build found more than every second k-mer distinct (a genome: nothing to count twice)
-    const bool use_t1 = fbits < 2u && !(inv_dup > 0.5f);
+    // ... unless the context's last build says otherwise: with its duplication known, the record table is used whenever less
+    // than every second k-mer was distinct (a large input at sequencing coverage goes through in many passes AND repeats its
+    // records) and never for an input without duplication (a genome: nothing to count twice)
+    const bool use_t1 = inv_dup > 0.f ? inv_dup <= 0.5f : fbits < 2u;
     for (uint32_t i = threadIdx.x; i < (uint32_t)T::S2; i += T::NT) { s_tk[i] = kEmptyKey; s_tv[i] = 0; }
     if (use_t1) for (uint32_t i = threadIdx.x; i < (uint32_t)T::S1; i += T::NT) { s_r[i] = make_ulonglong2(kEmptyKey, W1_INIT); s_rc[i] = 0; }
     if (threadIdx.x == 0) { s_ctl[0] = 0; s_ctl[1] = 0; s_ctl[2] = 0; s_ctl[3] = 0; s_ctl[5] = sp - 1; s_ctl[8] = 0; }
