@@ -544,6 +544,9 @@ __global__ __launch_bounds__(kPartThreads) void sk_recv_hist_kernel(const uint64
 #ifndef KMI_SK_H1
 #define KMI_SK_H1 1536   // (2048 left the k-mer table 1000 slots less: config 2 the same, 0.2 - 0.3 ms slower where buckets hold 3800 keys)
 #endif
+#ifndef KMI_SK_T1_DUP
+#define KMI_SK_T1_DUP 0.5f   // distinct k-mers per occurrence up to which identical records are worth counting first
+#endif
 #ifndef KMI_SK_FILL
 #define KMI_SK_FILL 80
 #endif
@@ -668,7 +671,7 @@ __global__ __launch_bounds__(1024) void sk_reduce_kernel(const uint64_t *__restr
     // ... unless the context's last build says otherwise: with its duplication known, the record table is used whenever less
     // than every second k-mer was distinct (a large input at sequencing coverage goes through in many passes AND repeats its
     // records) and never for an input without duplication (a genome: nothing to count twice)
-    const bool use_t1 = inv_dup > 0.f ? inv_dup <= 0.5f : fbits < 2u;
+    const bool use_t1 = inv_dup > 0.f ? inv_dup <= KMI_SK_T1_DUP : fbits < 2u;
     for (uint32_t i = threadIdx.x; i < (uint32_t)T::S2; i += T::NT) { s_tk[i] = kEmptyKey; s_tv[i] = 0; }
     if (use_t1) for (uint32_t i = threadIdx.x; i < (uint32_t)T::S1; i += T::NT) { s_r[i] = make_ulonglong2(kEmptyKey, W1_INIT); s_rc[i] = 0; }
     if (threadIdx.x == 0) { s_ctl[0] = 0; s_ctl[1] = 0; s_ctl[2] = 0; s_ctl[3] = 0; s_ctl[5] = sp - 1; s_ctl[8] = 0; }
