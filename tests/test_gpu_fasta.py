@@ -206,3 +206,26 @@ def test_fasta_count_index_goes_through_super_kmers(ctx, k, strand, seq_filter):
     fa, fb = orc.sorted_pairs(*idx.find(q)), orc.sorted_pairs(*[x.astype(np.uint64) if x.dtype != np.uint64 else x for x in om.find(q)])
     assert fa[0].shape == fb[0].shape and (fa[0] == fb[0]).all() and (fa[1] == fb[1]).all()
     idx.close()
+
+
+def test_fasta_with_more_runs_than_a_tile_has_slots_takes_the_kmer_path(ctx):
+    """thousands of 40-base records: a tile of the compacted stream then holds more window runs than the run list has slots
+    for, the super-k-mer front end says so and the build takes the k-mer pipeline -- same index"""
+    import kmerind_amd as K
+    k = 31
+    rng = np.random.default_rng(3)
+    recs = [b">r%d\n" % i + bytes(rng.choice(list(b"ACGT"), size=40).tolist()) + b"\n" for i in range(6000)]
+    data = b"".join(recs)
+    s = orc.kspec(k, orc.DNA)
+    om = orc.CountMap(s, orc.CANONICAL)
+    om.insert(orc.extract(s, data, orc.FASTA)["kmers"])
+    idx = K.CountIndex(ctx, K.make_config(k, "DNA", seq_format="fasta"))
+    ctx.profile(True)
+    ctx.profile_reset()
+    idx.build(data)
+    names = {p["name"] for p in ctx.profile_get() if p["launches"]}
+    ctx.profile(False)
+    assert "fasta_runs" in names and "fasta_extract" in names and "sk_reduce" not in names, names
+    a, b = orc.sorted_pairs(*idx.to_vector()), orc.sorted_pairs(*om.export())
+    assert a[0].shape == b[0].shape and (a[0] == b[0]).all() and (a[1] == b[1]).all()
+    idx.close()
