@@ -25,13 +25,14 @@ __device__ __forceinline__ uint32_t sk_order_hash(uint32_t c) {
   return h;
 }
 // bucket bits of a minimizer (from the low 27 bits of its order hash: the high bits of a MINIMUM are nearly always zero)
-__device__ __forceinline__ uint32_t sk_bucket_bits(uint32_t hv27) {
+__device__ __forceinline__ uint32_t sk_bucket_bits20(uint32_t hv27) {
   uint32_t h = (hv27 ^ 0x5bd1e995u) * 0x85EBCA6Bu;
   h ^= h >> 13;
   h *= 0xC2B2AE35u;
   h ^= h >> 16;
-  return h >> 14;   // 18 bits
+  return h >> 12;   // 20 bits: the 18 bucket bits and two more below them (a build over ranks fills the sub-bucket bits it shifts out with them)
 }
+__device__ __forceinline__ uint32_t sk_bucket_bits(uint32_t hv27) { return sk_bucket_bits20(hv27) >> 2; }   // 18 bits
 // forward strand of an m-mer from its complement-stream window (m <= 16: 32 bits)
 __device__ __forceinline__ uint32_t sk_fwd_of(uint32_t r, uint32_t m) {
   uint32_t x = __builtin_bitreverse32(~r);                    // complement codes -> forward codes, first base to the top

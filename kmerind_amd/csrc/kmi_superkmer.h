@@ -288,15 +288,15 @@ __global__ __launch_bounds__(kSkThreads, 2) void sk_minimizer_kernel(PackedInput
     }
     if (cnt > (uint32_t)CAP + 1u) { atomicOr(&flags[9], 1u); cnt = 1; }
     cnt = cnt ? cnt - 1u : 0u;   // real items: slots 1 .. cnt
-    // items in their final form (window offset | (n - 1) << 7 | bucket bits << 12) + the coarse counts
+    // items in their final form (window offset | (n - 1) << 7 | bucket bits << 12 | two further hash bits << 30) + the coarse counts
     {
       uint32_t off = 0;
       for (uint32_t j = 1; j <= cnt; ++j) {
         const uint32_t it = s_list[j * NT + threadIdx.x];
         const uint32_t n1 = it & 31u;
-        const uint32_t h18 = sk_bucket_bits(it >> 5);
+        const uint32_t h20 = sk_bucket_bits20(it >> 5), h18 = h20 >> 2;
         atomicAdd(&s_cnt[h18 >> 10], 1u);
-        s_list[j * NT + threadIdx.x] = off | (n1 << 7) | (h18 << 12);
+        s_list[j * NT + threadIdx.x] = off | (n1 << 7) | (h18 << 12) | ((h20 & 3u) << 30);   // (+ two more hash bits on top)
         off += n1 + 1u;
       }
     }
@@ -432,7 +432,7 @@ __global__ __launch_bounds__(kSkThreads, 2) void sk_scatter_kernel(PackedInput i
     }
 #pragma unroll
     for (int j = 0; j < CAP; ++j)
-      if ((uint32_t)j < cnt) atomicAdd(&s_cnt[it[j] >> 22], 1u);
+      if ((uint32_t)j < cnt) atomicAdd(&s_cnt[(it[j] >> 22) & 255u], 1u);
     lds_barrier();
     uint32_t c = 0, inc = 0;
     if (threadIdx.x < kNumCoarse) {
@@ -455,15 +455,17 @@ __global__ __launch_bounds__(kSkThreads, 2) void sk_scatter_kernel(PackedInput i
     lds_barrier();
 #pragma unroll
     for (int j = 0; j < CAP; ++j)
-      if ((uint32_t)j < cnt) s_stage[atomicAdd(&s_cur[it[j] >> 22], 1u)] = (uint16_t)((threadIdx.x << 5) | (uint32_t)j);
+      if ((uint32_t)j < cnt) s_stage[atomicAdd(&s_cur[(it[j] >> 22) & 255u], 1u)] = (uint16_t)((threadIdx.x << 5) | (uint32_t)j);
     lds_barrier();
     const uint32_t total = s_total;
     for (uint32_t s = threadIdx.x; s < total; s += NT) {
       const uint32_t e = s_stage[s], rl = e >> 5, j = e & 31u;
       const uint32_t item = wg_items[s_ioff[rl] + j];
-      const uint32_t h18 = item >> 12, n1 = (item >> 7) & 31u;
+      const uint32_t h18 = (item >> 12) & 0x3ffffu, n1 = (item >> 7) & 31u, extra = item >> 30;
+      // the bucket bits as the owner will read them: the lp rank bits shifted out, the two spare hash bits shifted in below
+      const uint32_t hs = ((h18 << lp) & 0x3ffffu) | (lp <= 2u ? extra >> (2u - lp) : extra << (lp - 2u));
       uint64_t w0, w1;
-      sk_assemble_row<CANON>(s_row + rl * kSkRowDw, s_bit0[rl] + 2u * (item & 127u), k + n1, n1, (h18 << lp) & 0x3ffffu, w0, w1);
+      sk_assemble_row<CANON>(s_row + rl * kSkRowDw, s_bit0[rl] + 2u * (item & 127u), k + n1, n1, hs, w0, w1);
       reinterpret_cast<ulonglong2 *>(out)[s_gbase[h18 >> 10] + s] = make_ulonglong2(w0, w1);
     }
     SkRound nxt;
@@ -613,7 +615,7 @@ __global__ __launch_bounds__(1024) void sk_reduce_kernel(const uint64_t *__restr
                                                         uint64_t *__restrict__ tmp_keys, uint32_t *__restrict__ tmp_vals,
                                                         uint32_t *__restrict__ out_cnt, uint32_t *__restrict__ flags, int dbg,
                                                         uint32_t start_bits /* filter bits every bucket starts with (the level most buckets of the last build ended at) */,
-                                                        uint32_t lp /* the low lp sub-bucket bits of the records are zero (records received in a build over 2^lp ranks) */,
+                                                        uint32_t lp /* records received in a build over 2^lp ranks: their low max(0, lp - 2) sub-bucket bits are zero */,
                                                         float inv_dup /* distinct k-mers per k-mer occurrence of the context's last build (0: none yet) */) {
   using T = SkTabCfg<OWN_>;
   constexpr int NWAVES = T::NWAVES;
@@ -676,10 +678,10 @@ __global__ __launch_bounds__(1024) void sk_reduce_kernel(const uint64_t *__restr
     if (use_t1) for (uint32_t i = threadIdx.x; i < (uint32_t)T::S1; i += T::NT) { s_r[i] = make_ulonglong2(kEmptyKey, W1_INIT); s_rc[i] = 0; }
     if (threadIdx.x == 0) { s_ctl[0] = 0; s_ctl[1] = 0; s_ctl[2] = 0; s_ctl[3] = 0; s_ctl[5] = sp - 1; s_ctl[8] = 0; }
     lds_barrier();
-    // the first three filter bits (3 - lp in a build over ranks) are the records' sub-bucket bits (whole records are skipped), the
+    // the first three filter bits (two in a build over 8 ranks) are the records' sub-bucket bits (whole records are skipped), the
     // others come from the key's hash
-    const uint32_t rmax = 3u - lp;   // (the sub-bucket bits that carry information)
-    const uint32_t rbits = fbits < rmax ? fbits : rmax, rmask = ((1u << rbits) - 1u) << lp, rval = (fval & ((1u << rbits) - 1u)) << lp;
+    const uint32_t dead = lp > 2u ? lp - 2u : 0u, rmax = 3u - dead;   // (sub-bucket bits without information: two spare hash bits refill the rest)
+    const uint32_t rbits = fbits < rmax ? fbits : rmax, rmask = ((1u << rbits) - 1u) << dead, rval = (fval & ((1u << rbits) - 1u)) << dead;
     const uint32_t hbits = fbits - rbits, hmask = (1u << hbits) - 1u, hval = fval >> rbits;
     uint32_t mn = 0;   // (key, weight) pairs waiting in the miss queue (uniform)
     uint32_t pending = 0;   // slots this wavefront claimed in line since it last reported to the shared fill counter (uniform)
