@@ -1,7 +1,8 @@
 // De Bruijn graph nodes: the reference's in-tree consumer of Index (test/test/debruijn/, driven by
 // test/test/test_de_bruijn_graph_construction.cpp:96-133) on the same extract -> partition -> reduce kernels.
 //
-//   de_bruijn_parser (de_bruijn_construct_engine.hpp:90-158)     -> dbg_edges_kernel over the position tuples of the extract pass
+//   de_bruijn_parser (de_bruijn_construct_engine.hpp:90-158)     -> the extract pass in its edge form (fastq_extract_kernel, raw_edges) for a
+//                                                                   build; dbg_edges_kernel over position tuples for the parser's own output
 //   de_bruijn_nodes_distributed::local_insert (..._distributed.hpp:91-159) with
 //   node::edge_counts<DNA16, int32_t> / node::edge_exists<DNA16> (de_bruijn_node_trait.hpp:139-336)
 //                                                                -> weighted count insert of (k-mer, 1 | edge << 32) records
