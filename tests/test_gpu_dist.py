@@ -260,3 +260,103 @@ def test_superkmer_exchange_with_an_empty_share_and_reads_shorter_than_k():
         ek, ev = ref.find(ret[r][3])
         x, y = orc.sorted_pairs(ret[r][4], ret[r][5]), orc.sorted_pairs(ek, ev)
         assert x[0].shape == y[0].shape and (x[0] == y[0]).all() and (x[1] == y[1]).all()
+
+
+def test_super_kmer_exchange_four_ranks_one_gpu():
+    """four ranks sharing the GPU (two rank bits shifted out of the bucket bits, both refilled from the items' spare hash bits)"""
+    import kmerind_amd as K
+    world, k = 4, 31
+    data = bytes(K.synth_fastq(seed=14, genome_len=25_000, n_reads=2_400))
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), data, k, "canonical", "superkmer", ret), nprocs=world, join=True)
+    s = orc.kspec(k)
+    ref = orc.CountMap(s, orc.CANONICAL)
+    ref.insert(orc.extract(s, data, orc.FASTQ)["kmers"])
+    keys = np.concatenate([ret[r][0] for r in range(world)])
+    cnts = np.concatenate([ret[r][1] for r in range(world)])
+    a, b = orc.sorted_pairs(keys, cnts), orc.sorted_pairs(*ref.export())
+    assert a[0].shape == b[0].shape and (a[0] == b[0]).all() and (a[1] == b[1]).all()
+    for r in range(world):
+        assert ret[r][2] == ref.size() and ret[r][9] == "superkmer"
+        q = ret[r][3]
+        ek, ev = ref.find(q)
+        x, y = orc.sorted_pairs(ret[r][6], ret[r][7]), orc.sorted_pairs(ek, ev)
+        assert x[0].shape == y[0].shape and (x[0] == y[0]).all() and (x[1] == y[1]).all()
+
+
+@pytest.mark.parametrize("world,k", [(8, 31), (8, 19), (4, 25)])
+def test_super_kmer_exchange_replayed_on_one_device(world, k):
+    """the whole N-rank build in one process (a GPU box takes at most six processes, so eight ranks cannot share it): every
+    rank's reads through kmi_index_sk_produce_dev, the records regrouped by owner as the all-to-all would, every owner's share
+    through kmi_index_sk_consume_dev into its own index; the union must be the oracle's single map, no key on two ranks, and
+    kmi_route_owner_dev must send every key to the rank that holds it"""
+    import ctypes as C
+    import kmerind_amd as K
+    from kmerind_amd import _lib as L
+    from kmerind_amd import fileio
+    ctx = K.Context(0)
+    cfg = K.make_config(k)
+    s = orc.kspec(k)
+    data = bytes(K.synth_fastq(seed=20 + world, genome_len=40_000, n_reads=3_000))
+    parts = fileio.partition_fastq(data, world)
+    idxs = [K.CountIndex(ctx, cfg) for _ in range(world)]
+    inbox = [[] for _ in range(world)]
+    for r in range(world):
+        b, e = parts[r]
+        buf = np.frombuffer(data[b:e], dtype=np.uint8)
+        d = ctx.alloc(buf.size + 64)
+        ctx.to_device(d, buf)
+        recs, n, produced = C.c_void_p(), C.c_uint64(), C.c_int()
+        sc = np.zeros(world, dtype=np.uint64)
+        ctx.check(L.lib.kmi_index_sk_produce_dev(idxs[r].h, C.c_void_p(d), buf.size, world, None, 0, C.byref(recs), C.byref(n), sc.ctypes.data_as(C.c_void_p),
+                                                 C.byref(produced)))
+        assert produced.value == 1 and int(sc.sum()) == n.value
+        ctx.synchronize()
+        host = np.zeros((n.value, 2), dtype=np.uint64)
+        ctx.to_host(host, recs.value)
+        ctx.free(d)
+        off = 0
+        for o in range(world):
+            inbox[o].append(host[off:off + int(sc[o])])
+            off += int(sc[o])
+    all_keys, owners = [], []
+    for o in range(world):
+        got = np.ascontiguousarray(np.concatenate(inbox[o]))
+        d = ctx.alloc(got.nbytes + 64)
+        ctx.to_device(d, got)
+        ctx.check(L.lib.kmi_index_sk_consume_dev(idxs[o].h, C.c_void_p(d), got.shape[0], world))
+        ctx.free(d)
+        assert idxs[o].owner_ranks() == world
+        kk, cc = idxs[o].to_vector()
+        all_keys.append((kk, cc))
+        owners.append(np.full(kk.shape[0], o))
+    keys = np.concatenate([x[0] for x in all_keys])
+    cnts = np.concatenate([x[1] for x in all_keys])
+    ref = orc.CountMap(s, orc.CANONICAL)
+    ref.insert(orc.extract(s, data, orc.FASTQ)["kmers"])
+    a, b = orc.sorted_pairs(keys, cnts), orc.sorted_pairs(*ref.export())
+    assert a[0].shape == b[0].shape and (a[0] == b[0]).all() and (a[1] == b[1]).all()
+    assert min(x[0].shape[0] for x in all_keys) > 0
+    # the router agrees with where the keys are
+    owner_of = dict(zip(keys[:, 0].tolist(), np.concatenate(owners).tolist()))
+    q = np.ascontiguousarray(orc.extract(s, data, orc.FASTQ)["kmers"][::5])
+    dq, ds = ctx.alloc(q.nbytes + 64), ctx.alloc(q.nbytes + 64)
+    ctx.to_device(dq, q)
+    sc = np.zeros(world, dtype=np.uint64)
+    ctx.check(L.lib.kmi_route_owner_dev(ctx.h, C.byref(cfg), C.c_void_p(dq), q.shape[0], world, C.c_void_p(ds), sc.ctypes.data_as(C.c_void_p)))
+    routed = np.zeros_like(q)
+    ctx.to_host(routed, ds)
+    ctx.free(dq); ctx.free(ds)
+    off = 0
+    for o in range(world):
+        seg = routed[off:off + int(sc[o]), 0]
+        assert all(owner_of[int(x)] == o for x in seg.tolist())
+        off += int(sc[o])
+    assert off == q.shape[0]
+    # and every owner answers the keys routed to it
+    fk, fv = idxs[3].find(q)
+    assert fk.shape[0] == np.unique(routed[int(sc[:3].sum()):int(sc[:4].sum())], axis=0).shape[0]
+    for ix in idxs:
+        ix.close()
+    ctx.close()
