@@ -2885,7 +2885,8 @@ static kmi_status index_build_fused(kmi_index *idx, const uint8_t *bytes_dev, si
     KMI_TRY(fastq_scan(ctx, &idx->cfg, bytes_dev, n_bytes, &sc, false));
     if (sc.n_tuples == 0) return KMI_OK;
     bool done = false;
-    kmi_status st = w == 19u ? build_superkmer_w<19>(idx, sc, &done) : (w == 13u ? build_superkmer_w<13>(idx, sc, &done) : build_superkmer_w<7>(idx, sc, &done));
+    kmi_status st = w == 19u ? build_superkmer_w<19>(idx, sc, &done) : (w == 13u ? build_superkmer_w<13>(idx, sc, &done)
+                  : (w == 11u ? build_superkmer_w<11>(idx, sc, &done) : build_superkmer_w<7>(idx, sc, &done)));
     if (st != KMI_OK || done) return st;
   }
   KMI_DISPATCH(idx->shape, build_fused_impl, idx, bytes_dev, n_bytes);
@@ -3371,12 +3372,13 @@ static kmi_status sk_produce(kmi_index *idx, uint32_t w, const uint8_t *bytes_de
                              uint64_t *send_counts, int *produced, uint64_t *out, size_t out_cap) {
   return w == 19u ? sk_produce_w<19>(idx, bytes_dev, n_bytes, nranks, recs, n_records, send_counts, produced, out, out_cap)
        : (w == 13u ? sk_produce_w<13>(idx, bytes_dev, n_bytes, nranks, recs, n_records, send_counts, produced, out, out_cap)
-                   : sk_produce_w<7>(idx, bytes_dev, n_bytes, nranks, recs, n_records, send_counts, produced, out, out_cap));
+       : (w == 11u ? sk_produce_w<11>(idx, bytes_dev, n_bytes, nranks, recs, n_records, send_counts, produced, out, out_cap)
+                   : sk_produce_w<7>(idx, bytes_dev, n_bytes, nranks, recs, n_records, send_counts, produced, out, out_cap)));
 }
 static kmi_status sk_consume(kmi_index *idx, uint32_t w, const uint64_t *recs_dev, uint64_t n_records, uint32_t nranks) {
   if (n_records == 0) { idx->owner_lp = 31u - (uint32_t)__builtin_clz(nranks); return KMI_OK; }
   return w == 19u ? sk_consume_w<19>(idx, recs_dev, n_records, nranks) : (w == 13u ? sk_consume_w<13>(idx, recs_dev, n_records, nranks)
-                                                                                     : sk_consume_w<7>(idx, recs_dev, n_records, nranks));
+       : (w == 11u ? sk_consume_w<11>(idx, recs_dev, n_records, nranks) : sk_consume_w<7>(idx, recs_dev, n_records, nranks)));
 }
 static bool sk_rank_count(uint32_t p) { return p == 1u || p == 2u || p == 4u || p == 8u; }
 
@@ -3535,7 +3537,8 @@ kmi_status kmi_index_build_dev(kmi_index *idx, const uint8_t *bytes_dev, size_t 
       KMI_TRY(fasta_scan(ctx, &idx->cfg, bytes_dev, n_bytes, file_offset, false, &fa));
       if (fa.n_chars < idx->shape.k) return KMI_OK;
       bool done = false;
-      kmi_status st = w == 19u ? build_superkmer_fasta_w<19>(idx, fa, &done) : (w == 13u ? build_superkmer_fasta_w<13>(idx, fa, &done) : build_superkmer_fasta_w<7>(idx, fa, &done));
+      kmi_status st = w == 19u ? build_superkmer_fasta_w<19>(idx, fa, &done) : (w == 13u ? build_superkmer_fasta_w<13>(idx, fa, &done)
+                    : (w == 11u ? build_superkmer_fasta_w<11>(idx, fa, &done) : build_superkmer_fasta_w<7>(idx, fa, &done)));
       if (st != KMI_OK || done) return st;
     }
     // FASTA count index: tuples from the compacted-stream extract, then the key insert path

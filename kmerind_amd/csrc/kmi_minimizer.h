@@ -6,14 +6,15 @@
 
 namespace kmi {
 
-// (W, m) by k: W = 19 for k 29..32 (m = 11..14), 13 for k 23..28 (m = 11..16), 7 for k 17..22 (m = 11..16); an m-mer
-// always fits 32 bits and has at least 2 M canonical values (bucket balance). Smaller k keep the k-mer pipeline.
-__host__ __device__ inline uint32_t sk_window_of(uint32_t k) { return k >= 29u ? 19u : (k >= 23u ? 13u : (k >= 17u ? 7u : 0u)); }
+// (W, m) by k: W = 19 for k 29..32 (m = 11..14), 13 for k 23..28 (m = 11..16), 11 for k 21, 22 (m = 11, 12), 7 for k 17..20
+// (m = 11..14); an m-mer always fits 32 bits and has at least 2 M canonical values (bucket balance). Smaller k keep the k-mer
+// pipeline.
+__host__ __device__ inline uint32_t sk_window_of(uint32_t k) { return k >= 29u ? 19u : (k >= 23u ? 13u : (k >= 21u ? 11u : (k >= 17u ? 7u : 0u))); }
 // A run entry is one lane's work and its items one lane's list: entries are cut every so many windows that they hold about
 // 12 items whatever W is (a super-k-mer averages (W + 1) / 2 windows)
-__host__ __device__ inline uint32_t sk_segment_of(uint32_t w) { return w >= 19u ? 128u : (w >= 13u ? 80u : 44u); }
-// capacity of the item stream per 8 KB scan tile (26 reads of 150 bases: about 330 / 500 / 850 items are used)
-__host__ __device__ inline uint32_t sk_items_per_tile(uint32_t w) { return w >= 19u ? 1024u : (w >= 13u ? 1536u : 2560u); }
+__host__ __device__ inline uint32_t sk_segment_of(uint32_t w) { return w >= 19u ? 128u : (w >= 13u ? 80u : (w >= 11u ? 64u : 44u)); }
+// capacity of the item stream per 8 KB scan tile (26 reads of 150 bases: about 330 / 500 / 600 / 850 items are used)
+__host__ __device__ inline uint32_t sk_items_per_tile(uint32_t w) { return w >= 19u ? 1024u : (w >= 13u ? 1536u : (w >= 11u ? 2048u : 2560u)); }
 // longest super-k-mer kept in one record: k + n - 1 <= 51 bases (102 bits) and n - 1 in 5 bits
 __host__ __device__ inline uint32_t sk_nmax_of(uint32_t k) { return (52u - k) < 32u ? (52u - k) : 32u; }
 
