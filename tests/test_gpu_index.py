@@ -607,7 +607,7 @@ def test_weighted_pairs_insert_adds_the_values(ctx, k, alpha, strand):
     idx2.close()
 
 
-@pytest.mark.parametrize("k,strand", [(31, "canonical"), (32, "single"), (29, "canonical"), (28, "canonical"), (23, "single"), (21, "canonical"), (17, "canonical")])
+@pytest.mark.parametrize("k,strand", [(31, "canonical"), (32, "single"), (29, "canonical"), (28, "canonical"), (23, "single"), (21, "canonical"), (22, "single"), (20, "canonical"), (17, "canonical")])
 def test_superkmer_build_ran_and_matches_oracle(ctx, k, strand):
     """The fused FASTQ build of one-word DNA k-mers (k >= 17) goes through super-k-mers (kmi_superkmer.h): the kernels must
     actually have run (no silent fall-back to the k-mer pipeline) and the index must be the oracle's, also when the build
