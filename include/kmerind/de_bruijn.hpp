@@ -190,9 +190,9 @@ class NodeIndex {
 
   // find (test_de_bruijn_graph_construction.cpp:114): one (stored k-mer, node) per distinct query key that is a node
   std::vector<TupleType> find(std::vector<KmerType> &query) const {
-    if (comm.size() > 1) throw std::invalid_argument("find with size() > 1 is not wired for the node map");
     kmi_results r{};
-    ::kmerind::check(ctx, kmi_dbg_find_host(g, ::bliss::index::kmer::detail::words_of(query), query.size(), &r));
+    if (rccl) ::kmerind::check(ctx, kmi_dbg_find_dist_host(g, rccl, ::bliss::index::kmer::detail::words_of(query), query.size(), &r));   // collective
+    else ::kmerind::check(ctx, kmi_dbg_find_host(g, ::bliss::index::kmer::detail::words_of(query), query.size(), &r));
     std::vector<TupleType> out;
     out.reserve(r.n);
     for (uint64_t i = 0; i < r.n; ++i)

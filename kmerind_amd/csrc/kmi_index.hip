@@ -4163,6 +4163,53 @@ kmi_status kmi_dbg_build_dist_host(kmi_dbg *g, kmi_comm *comm, const uint8_t *by
   return dbg_insert(g, (const uint64_t *)d_recv, (size_t)total);
 }
 
+// find() of the node map over ranks: query keys to the ranks that own their canonical k-mer (the node map's KeyToRank), every
+// source's keys answered on their own, one return exchange of (k-mer, node) -- distributed_unordered_map.hpp:564-687 as the
+// node map inherits it (de_bruijn_nodes_distributed.hpp:61)
+kmi_status kmi_dbg_find_dist_host(kmi_dbg *g, kmi_comm *comm, const uint64_t *queries, size_t nq, kmi_results *out) {
+  if (!g || !out) return KMI_ERR_INVALID;
+  KMI_TRY(dist_check(g->nodes, comm));
+  kmi_ctx *ctx = g->ctx;
+  const int p = kmi::comm_size(comm);
+  if (p == 1 && !ctx->force_dist) return kmi_dbg_find_host(g, queries, nq, out);
+  memset(out, 0, sizeof(*out));
+  if (nq && !queries) return set_err(ctx, KMI_ERR_INVALID, "null buffer");
+  const uint32_t nw = g->shape.n_words;
+  const size_t kb = nw * sizeof(uint64_t), vb = kDbgValueWords * sizeof(uint64_t);
+  void *d_in, *d_send, *d_q;
+  KMI_TRY(ws_get(ctx, WS_INPUT, (nq + 8) * kb, &d_in));
+  KMI_TRY(ws_get(ctx, WS_DIST_A, (nq + 8) * kb, &d_send));
+  if (nq) KMI_HIP(ctx, hipMemcpyAsync(d_in, queries, nq * kb, hipMemcpyHostToDevice, ctx->stream));
+  std::vector<uint64_t> sc(p, 0), rc;
+  KMI_TRY(kmi_route_dev(ctx, &g->nodes->cfg, (const uint64_t *)d_in, nq, (uint32_t)p, (uint64_t *)d_send, sc.data()));
+  uint64_t total = 0;
+  KMI_TRY(dist_exchange(comm, d_send, sc.data(), kb, WS_DIST_B, &d_q, rc, &total));
+  void *d_rk, *d_rv;
+  KMI_TRY(ws_get(ctx, WS_DIST_C, (total + 8) * kb, &d_rk));
+  KMI_TRY(ws_get(ctx, WS_DIST_D, (total + 8) * vb, &d_rv));
+  std::vector<uint64_t> back(p, 0), got;
+  uint64_t off = 0, pos = 0;
+  for (int s = 0; s < p; ++s) {
+    uint64_t n = 0;
+    if (rc[s]) KMI_TRY(dbg_find(g, (const uint64_t *)d_q + off * nw, (size_t)rc[s], (uint64_t *)d_rk + pos * nw, (uint64_t *)d_rv + pos * kDbgValueWords, &n));
+    back[s] = n; off += rc[s]; pos += n;
+  }
+  void *d_ak, *d_av;
+  uint64_t n_mine = 0, n_mine2 = 0;
+  KMI_TRY(dist_exchange(comm, d_rk, back.data(), kb, WS_DIST_A, &d_ak, got, &n_mine));
+  KMI_TRY(dist_exchange(comm, d_rv, back.data(), vb, WS_DIST_B, &d_av, got, &n_mine2));
+  out->n = n_mine;
+  out->keys = (uint64_t *)malloc((n_mine ? n_mine : 1) * kb);
+  out->values = (uint64_t *)malloc((n_mine ? n_mine : 1) * vb);
+  if (!out->keys || !out->values) return set_err(ctx, KMI_ERR_NOMEM, "host malloc failed");
+  if (n_mine) {
+    KMI_HIP(ctx, hipMemcpyAsync(out->keys, d_ak, n_mine * kb, hipMemcpyDeviceToHost, ctx->stream));
+    KMI_HIP(ctx, hipMemcpyAsync(out->values, d_av, n_mine * vb, hipMemcpyDeviceToHost, ctx->stream));
+  }
+  KMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return KMI_OK;
+}
+
 kmi_status kmi_dbg_size_dist(kmi_dbg *g, kmi_comm *comm, uint64_t *n) {
   if (!g) return KMI_ERR_INVALID;
   return kmi_index_size_dist(g->nodes, comm, n);

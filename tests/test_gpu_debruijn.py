@@ -210,6 +210,14 @@ def test_build_over_rccl_one_rank_self_exchange(monkeypatch):
             ctx.check(L.lib.kmi_dbg_size_dist(g.h, comm, C.byref(n)))
             assert n.value == om.size()
             assert (_nodes(*g.to_vector()) == _nodes(*om.export(canonical=True))).all()
+        # find() over the communicator: keys to their owners, answers back
+        q = np.ascontiguousarray(np.concatenate([orc.dbg_parse(s, data)[0][::9], np.random.default_rng(2).integers(0, 1 << 62, (300, 1), dtype=np.uint64)]))
+        r = L.Results()
+        ctx.check(L.lib.kmi_dbg_find_dist_host(g.h, comm, q.ctypes.data_as(C.c_void_p), q.shape[0], C.byref(r)))
+        fk = np.ctypeslib.as_array(r.keys, shape=(r.n,)).copy().reshape(-1, 1)
+        fv = np.ctypeslib.as_array(r.values, shape=(r.n * 5,)).copy().view(np.uint32).reshape(r.n, 10)[:, :9].copy()
+        L.lib.kmi_results_free(C.byref(r))
+        assert (_nodes(fk, fv) == _nodes(*om.find(q, canonical=True))).all()
         g.close()
     finally:
         L.lib.kmi_comm_destroy(comm)
