@@ -201,9 +201,9 @@ class NodeIndex {
     return out;
   }
   std::vector<std::pair<KmerType, size_t>> count(std::vector<KmerType> &query) const {
-    if (comm.size() > 1) throw std::invalid_argument("count with size() > 1 is not wired for the node map");
     kmi_results r{};
-    ::kmerind::check(ctx, kmi_dbg_count_host(g, ::bliss::index::kmer::detail::words_of(query), query.size(), &r));
+    if (rccl) ::kmerind::check(ctx, kmi_dbg_count_dist_host(g, rccl, ::bliss::index::kmer::detail::words_of(query), query.size(), &r));   // collective
+    else ::kmerind::check(ctx, kmi_dbg_count_host(g, ::bliss::index::kmer::detail::words_of(query), query.size(), &r));
     std::vector<std::pair<KmerType, size_t>> out(r.n);
     for (uint64_t i = 0; i < r.n; ++i) out[i] = std::make_pair(KmerType(r.keys + i * KmerType::nWords), (size_t)r.values[i]);
     kmi_results_free(&r);

@@ -403,6 +403,7 @@ kmi_status kmi_dbg_export_host(kmi_dbg *g, uint64_t *keys, uint32_t *counts9, si
  * KeyToRank gives their canonical k-mer (the distribute step of insert, de_bruijn_nodes_distributed.hpp:243-250) */
 kmi_status kmi_dbg_build_dist_host(kmi_dbg *g, kmi_comm *comm, const uint8_t *bytes, size_t n_bytes);
 kmi_status kmi_dbg_find_dist_host(kmi_dbg *g, kmi_comm *comm, const uint64_t *queries, size_t nq, kmi_results *out); /* find(): collective */
+kmi_status kmi_dbg_count_dist_host(kmi_dbg *g, kmi_comm *comm, const uint64_t *queries, size_t nq, kmi_results *out); /* count(): collective */
 kmi_status kmi_dbg_size_dist(kmi_dbg *g, kmi_comm *comm, uint64_t *n);                                /* size() */
 
 /* ---- measurement support --------------------------------------------------- */

@@ -4210,6 +4210,12 @@ kmi_status kmi_dbg_find_dist_host(kmi_dbg *g, kmi_comm *comm, const uint64_t *qu
   return KMI_OK;
 }
 
+// count() over ranks: the node map's keys live in a count index, whose collective answers 1 per node held
+kmi_status kmi_dbg_count_dist_host(kmi_dbg *g, kmi_comm *comm, const uint64_t *queries, size_t nq, kmi_results *out) {
+  if (!g) return KMI_ERR_INVALID;
+  return kmi_index_count_dist_host(g->nodes, comm, queries, nq, out);
+}
+
 kmi_status kmi_dbg_size_dist(kmi_dbg *g, kmi_comm *comm, uint64_t *n) {
   if (!g) return KMI_ERR_INVALID;
   return kmi_index_size_dist(g->nodes, comm, n);

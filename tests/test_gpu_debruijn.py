@@ -218,6 +218,12 @@ def test_build_over_rccl_one_rank_self_exchange(monkeypatch):
         fv = np.ctypeslib.as_array(r.values, shape=(r.n * 5,)).copy().view(np.uint32).reshape(r.n, 10)[:, :9].copy()
         L.lib.kmi_results_free(C.byref(r))
         assert (_nodes(fk, fv) == _nodes(*om.find(q, canonical=True))).all()
+        r = L.Results()
+        ctx.check(L.lib.kmi_dbg_count_dist_host(g.h, comm, q.ctypes.data_as(C.c_void_p), q.shape[0], C.byref(r)))
+        ck = np.ctypeslib.as_array(r.keys, shape=(r.n,)).copy()
+        cv = np.ctypeslib.as_array(r.values, shape=(r.n,)).copy()
+        L.lib.kmi_results_free(C.byref(r))
+        assert sorted(ck[cv > 0].tolist()) == sorted(set(fk[:, 0].tolist())) and set(cv.tolist()) <= {0, 1}
         g.close()
     finally:
         L.lib.kmi_comm_destroy(comm)
