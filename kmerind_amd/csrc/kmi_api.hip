@@ -58,7 +58,7 @@ void prof_begin(kmi_ctx *ctx, const char *name, uint64_t units) {
   ctx->prof_pending.push_back(r);
 }
 
-void prof_end(kmi_ctx *ctx) { (void)hipEventRecord(ctx->prof_pending.back().e1, ctx->stream); }
+void prof_end(kmi_ctx *ctx, size_t slot) { if (slot < ctx->prof_pending.size()) (void)hipEventRecord(ctx->prof_pending[slot].e1, ctx->stream); }
 
 static void prof_flush(kmi_ctx *ctx) {
   if (ctx->prof_pending.empty()) return;

@@ -367,7 +367,7 @@ __constant__ uint64_t c_exp2_tab[32];   // T[i] = bits(2^(i/32)) - (i << 47)
 // (Szabolcs Nagy / ARM optimized routines): x = k/32 + r, 2^x = 2^(k/32) * p(r) in double,
 // p(r) = C0 r^3 + C1 r^2 + C2 r + 1, one rounding to float at the end. tests/cpu/exp2f_check.c
 // compares the same restatement with the host libm on 2e7 inputs.
-__device__ __forceinline__ float exp2f_libm(float x) {
+__device__ __forceinline__ float exp2f_libm(float x, const uint64_t *__restrict__ tab /* c_exp2_tab or a copy of it */) {
   if (x <= -150.0f) return 0.0f;
   const double C0 = 0x1.c6af84b912394p-5, C1 = 0x1.ebfce50fac4f3p-3, C2 = 0x1.62e42ff0c52d6p-1;
   const double SHIFT = 0x1.8p+52 / 32;
@@ -376,7 +376,7 @@ __device__ __forceinline__ float exp2f_libm(float x) {
   const uint64_t ki = (uint64_t)__double_as_longlong(kd);
   kd -= SHIFT;
   const double r = xd - kd;
-  const uint64_t t = c_exp2_tab[ki & 31u] + (ki << (52 - 5));
+  const uint64_t t = tab[ki & 31u] + (ki << (52 - 5));
   const double sc = __longlong_as_double((long long)t);
   const double z = fma(C0, r, C1);
   const double r2 = r * r;
@@ -397,8 +397,8 @@ struct ReadDesc { uint64_t seq_pos, out_off; };   // slot = sequence index of th
 //  * the values leave through a 64 x 16 LDS tile: every 16 windows the lanes write each read's 16 floats as one 64-byte line.
 constexpr int kQualChunk = 64;                        // windows per chunk (a multiple of 16)
 constexpr int kQualThreads = 256;
-inline uint32_t qual_row_bytes(uint32_t k) { return (((kQualChunk + k + 3u) / 4u) | 1u) * 4u; }
-inline size_t qual_lds_bytes(uint32_t k) { return (size_t)(kQualThreads / kWave) * (64u * qual_row_bytes(k) + 64u * 17u * 4u) + 96u * 4u; }
+inline uint32_t qual_row_bytes(uint32_t k) { return (((kQualChunk + k + 3u) / 4u + 1u) | 1u) * 4u; }   // the aligned dwords that cover chunk + k characters at any shift; odd
+inline size_t qual_lds_bytes(uint32_t k) { return (size_t)(kQualThreads / kWave) * (64u * qual_row_bytes(k) + 64u * 17u * 4u + 64u * 12u) + 96u * 4u + 32u * 8u; }
 
 __global__ __launch_bounds__(kQualThreads) void fastq_quality_kernel(const uint8_t *__restrict__ bytes, uint64_t n_bytes,
                                                                     const uint32_t *__restrict__ eolw, uint64_t n_words, uint32_t k,
@@ -410,9 +410,15 @@ __global__ __launch_bounds__(kQualThreads) void fastq_quality_kernel(const uint8
   constexpr uint32_t W = kQualChunk;
   const uint32_t lane = lane_id(), wv = wave_id();
   float *s_lut = reinterpret_cast<float *>(s_q);                                            // [96]
-  uint8_t *rows = s_q + 96u * 4u + (size_t)wv * (64u * row_bytes + 64u * 17u * 4u);          // [64][row_bytes]
+  uint64_t *s_exp = reinterpret_cast<uint64_t *>(s_q + 96u * 4u);                           // [32]: per-lane index, so not left in constant memory
+  uint8_t *rows = s_q + 96u * 4u + 32u * 8u + (size_t)wv * (64u * row_bytes + 64u * 17u * 4u + 64u * 12u);   // [64][row_bytes]
   float *tile = reinterpret_cast<float *>(rows + 64u * row_bytes);                          // [64][17]
+  uint64_t *s_qp = reinterpret_cast<uint64_t *>(tile + 64u * 17u);                          // [64]: quality line of every read of the batch
+  uint32_t *s_nw = reinterpret_cast<uint32_t *>(s_qp + 64);                                 // [64]: its windows
+  uint32_t *rows32 = reinterpret_cast<uint32_t *>(rows);
+  const uint32_t rdw = row_bytes / 4u;
   if (threadIdx.x < 96) s_lut[threadIdx.x] = c_qual_lut[threadIdx.x];
+  else if (threadIdx.x < 128) s_exp[threadIdx.x - 96] = c_exp2_tab[threadIdx.x - 96];
   lds_barrier();
   const float lo = s_lut[0], hi = s_lut[95];
   auto wave_sync = [&]() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); };
@@ -444,24 +450,33 @@ __global__ __launch_bounds__(kQualThreads) void fastq_quality_kernel(const uint8
     uint32_t max_win = n_win;
 #pragma unroll
     for (int d = kWave / 2; d > 0; d >>= 1) { const uint32_t t = (uint32_t)__shfl_xor((int)max_win, d, kWave); max_win = t > max_win ? t : max_win; }
+    s_qp[lane] = q; s_nw[lane] = n_win;
+    wave_sync();
     float sum = 0.0f;
     uint32_t bad = 0;
     for (uint32_t w0 = 0; w0 < max_win; w0 += W) {
-      // characters cs .. of every read that has windows in this chunk: the one that leaves window w0 - 1 onward
+      // characters cs .. of every read that has windows in this chunk (the one that leaves window w0 - 1 onward), as the ALIGNED
+      // dwords that cover them: sixteen lanes per read, four reads per load instruction, no load waits on another. A dword
+      // that overlaps the buffer lies in pages the buffer touches; one that does not is not read.
       const uint32_t cs = w0 ? w0 - 1u : 0u;
-      for (uint32_t i = 0; i < (uint32_t)kWave; ++i) {
-        const uint32_t nwi = (uint32_t)__shfl((int)n_win, (int)i, kWave);
-        if (nwi <= w0) continue;                                      // wave-uniform
-        const uint64_t qi = ((uint64_t)(uint32_t)__shfl((int)(q >> 32), (int)i, kWave) << 32) | (uint32_t)__shfl((int)(uint32_t)q, (int)i, kWave);
-        const uint32_t wend = nwi < w0 + W ? nwi : w0 + W;           // windows [w0, wend) of read i
-        const uint32_t nc = wend + k - 1u - cs;                      // characters cs .. cs + nc - 1
-        for (uint32_t x = lane; x < nc; x += kWave) {
-          const uint64_t p = qi + cs + x;
-          rows[i * row_bytes + x] = p < n_bytes ? bytes[p] : (uint8_t)0;
+      const uintptr_t buf0 = (uintptr_t)bytes, buf1 = buf0 + n_bytes;
+#pragma unroll 4
+      for (uint32_t i4 = 0; i4 < (uint32_t)kWave; i4 += 4) {
+        const uint32_t i = i4 + (lane >> 4);
+        if (s_nw[i] <= w0) continue;
+        const uintptr_t a0 = (buf0 + s_qp[i] + cs) & ~(uintptr_t)3;
+        for (uint32_t d = lane & 15u; d < rdw; d += 16u) {
+          const uintptr_t a = a0 + 4u * d;
+          uint32_t v = 0;
+          if (a + 4u > buf0 && a < buf1) {
+            v = *reinterpret_cast<const uint32_t *>(a);
+            if (a + 4u > buf1) v &= (1u << (8u * (uint32_t)(buf1 - a))) - 1u;     // past the end reads as 0, as before
+          }
+          rows32[i * rdw + d] = v;
         }
       }
       wave_sync();
-      const uint8_t *my = rows + lane * row_bytes;
+      const uint8_t *my = rows + lane * row_bytes + (uint32_t)((buf0 + q + cs) & 3u);
       if (w0 == 0 && n_win) {                                         // init(): quality_score_iterator.hpp:99-115
         for (uint32_t i = 0; i < k; ++i) { const float x = decode(my[i]); if (x > lo && x < hi) sum += x; else ++bad; }
       }
@@ -475,7 +490,7 @@ __global__ __launch_bounds__(kQualThreads) void fastq_quality_kernel(const uint8
               if (ov > lo && ov < hi) sum -= ov; else --bad;
               if (nv > lo && nv < hi) sum += nv; else ++bad;
             }
-            tile[lane * 17u + t] = bad ? 0.0f : exp2f_libm(sum);      // getValue(): :166-173
+            tile[lane * 17u + t] = bad ? 0.0f : exp2f_libm(sum, s_exp);     // getValue(): :166-173
           }
         }
         wave_sync();
@@ -840,7 +855,7 @@ static kmi_status extract_run_impl(kmi_ctx *ctx, const kmi_config *cfg, const ui
       hipLaunchKernelGGL(fastq_quality_kernel, dim3(2048), dim3(kQualThreads), qual_lds_bytes(shape.k), ctx->stream, bytes_dev,
                          (uint64_t)n_bytes, (const uint32_t *)r.packed.eol, (uint64_t)(r.packed.n_cover / 32), shape.k,
                          qual_row_bytes(shape.k), (const ReadDesc *)reads, (const uint64_t *)(ctx->d_totals + 2), out_quals_dev,
-                         rec_words ? out_kmers_dev + NW + 1 : (uint64_t *)nullptr, rec_words);
+                         rec_words == (uint32_t)NW + 2u ? out_kmers_dev + NW + 1 : (uint64_t *)nullptr, rec_words);
     }
   }
   KMI_HIP(ctx, hipGetLastError());
@@ -969,11 +984,12 @@ kmi_status extract_run(kmi_ctx *ctx, const kmi_config *cfg, const uint8_t *bytes
                        bool apply_strand, bool scan_done, uint64_t *n_tuples, uint64_t *n_seqs, float *out_quals_dev, uint32_t rec_words, bool edges) {
   // edges (FASTQ, records): the value word of every record is 1 | edge byte << 32 and the key the smaller strand (kmi_debruijn.h)
   // rec_words != 0: out_kmers_dev takes whole records -- key words, id, and with rec_words == n_words + 2 the quality's float
-  // bits -- rec_words words per tuple, the layout the multimap insert reads (out_ids_dev / out_quals_dev are then unused)
+  // bits -- rec_words words per tuple, the layout the multimap insert reads (out_ids_dev is then unused; out_quals_dev beside
+  // records of n_words + 1 words takes the qualities as one dense float array)
   KShape shape;
   if (!valid_config(cfg, &shape)) return set_err(ctx, KMI_ERR_INVALID, "bad kmi_config");
   if (n_bytes == 0) { if (n_tuples) *n_tuples = 0; if (n_seqs) *n_seqs = 0; return KMI_OK; }
-  if ((out_quals_dev && !out_ids_dev) || ((out_quals_dev || rec_words == shape.n_words + 2u) && cfg->seq_format != KMI_FMT_FASTQ))
+  if ((out_quals_dev && !out_ids_dev && !rec_words) || ((out_quals_dev || rec_words == shape.n_words + 2u) && cfg->seq_format != KMI_FMT_FASTQ))
     return set_err(ctx, KMI_ERR_INVALID, "k-mer qualities need FASTQ input and are produced together with the ids");
   if (cfg->seq_format == KMI_FMT_FASTA)
     return fasta_extract(ctx, cfg, bytes_dev, n_bytes, shape, file_offset, out_kmers_dev, out_ids_dev, out_capacity, apply_strand, false,

@@ -158,7 +158,8 @@ __global__ __launch_bounds__(kPartThreads) void hist_fine_kernel(const uint64_t 
                                                                 uint32_t strand, bool transform,
                                                                 uint32_t *__restrict__ fine_hist,     // [kFineParts][kNumFine] global
                                                                 uint32_t *__restrict__ wg_hist,       // [groups][256]
-                                                                uint32_t layout_w = 0) {
+                                                                uint32_t layout_w = 0,
+                                                                uint32_t in_rw = NW + VW /* words per input record (scatter_range: in_q) */) {
   __shared__ uint32_t s_hist[kNumFine];
   for (int i = threadIdx.x; i < kNumFine; i += kPartThreads) s_hist[i] = 0;
   lds_barrier();
@@ -175,7 +176,7 @@ __global__ __launch_bounds__(kPartThreads) void hist_fine_kernel(const uint64_t 
       ok[u] = i < e;
       if (ok[u]) {
 #pragma unroll
-        for (int w = 0; w < NW; ++w) raw[u][w] = keys[i * (NW + VW) + w];
+        for (int w = 0; w < NW; ++w) raw[u][w] = keys[i * in_rw + w];
       }
     }
 #pragma unroll
@@ -328,7 +329,10 @@ __device__ __forceinline__ void scatter_range(const uint64_t *__restrict__ in, u
                                               const KShape &shape, uint32_t strand, bool transform, const BucketFn &fn,
                                               uint64_t cursor /* of bucket threadIdx.x, threads < 256 */,
                                               uint64_t *s_stage, uint8_t *s_bkt, uint32_t *s_cnt, uint32_t *s_lofs,
-                                              uint64_t *s_gbase, uint32_t *s_part, uint64_t *__restrict__ out_vals = nullptr) {
+                                              uint64_t *s_gbase, uint32_t *s_part, uint64_t *__restrict__ out_vals = nullptr,
+                                              const float *__restrict__ in_q = nullptr) {
+  // in_q (records only): the input records are one word short and their last value word is the float in_q[i] (its bits in the
+  // low half) -- the quality values of a position + quality build, which leave their kernel as one dense array
   // out_vals (records only): the key words go to out[dst * NW ..], the value words to out_vals[dst * VW ..] -- the arrays of a
   // multimap index -- instead of whole records to out[dst * RW ..]
   constexpr int RW = NW + VW;   // record = key words followed by value words
@@ -342,8 +346,14 @@ __device__ __forceinline__ void scatter_range(const uint64_t *__restrict__ in, u
     for (int j = 0; j < PT; ++j) {
       uint64_t i = t0 + (uint64_t)j * kPartThreads + threadIdx.x;
       i = (i < end) ? i : end - 1;
+      if (VW > 0 && in_q) {   // uniform
 #pragma unroll
-      for (int w = 0; w < RW; ++w) raw[j][w] = in[i * RW + w];
+        for (int w = 0; w < RW - 1; ++w) raw[j][w] = in[i * (RW - 1) + w];
+        raw[j][RW - 1] = (uint64_t)__float_as_uint(in_q[i]);
+      } else {
+#pragma unroll
+        for (int w = 0; w < RW; ++w) raw[j][w] = in[i * RW + w];
+      }
     }
   };
   load_tile(begin);
@@ -437,13 +447,13 @@ __device__ __forceinline__ void scatter_range(const uint64_t *__restrict__ in, u
 template <int NW, int BITS, int VW = 0>
 __global__ __launch_bounds__(kPartThreads) void scatter_chunks_kernel(const uint64_t *__restrict__ in, uint64_t n, uint64_t *__restrict__ out,
                                                                      KShape shape, uint32_t strand, bool transform, BucketFn fn,
-                                                                     const uint64_t *__restrict__ wg_off) {
+                                                                     const uint64_t *__restrict__ wg_off, const float *__restrict__ in_q = nullptr) {
   KMI_SCATTER_LDS(NW + VW)
   const uint64_t cursor = (threadIdx.x < kNumCoarse) ? wg_off[(uint64_t)blockIdx.x * kNumCoarse + threadIdx.x] : 0ull;
   const uint64_t chunk = part_chunk(n, gridDim.x, PartCfg<NW + VW>::TILE);
   const uint64_t b = (uint64_t)blockIdx.x * chunk;
   const uint64_t e = (b + chunk < n) ? b + chunk : n;
-  if (b < e) scatter_range<NW, BITS, VW>(in, b, e, out, shape, strand, transform, fn, cursor, s_stage, s_bkt, s_cnt, s_lofs, s_gbase, s_part);
+  if (b < e) scatter_range<NW, BITS, VW>(in, b, e, out, shape, strand, transform, fn, cursor, s_stage, s_bkt, s_cnt, s_lofs, s_gbase, s_part, nullptr, in_q);
 }
 
 // P2: workgroup (c, h) splits the part of coarse bucket c that K2 groups [h*256,(h+1)*256) wrote
@@ -2391,7 +2401,9 @@ static kmi_status get_part_ws(kmi_ctx *ctx, size_t n, int nw, WsSlot slot_a, WsS
 template <int NW, int BITS, int VW = 0>
 static kmi_status partition_impl(kmi_ctx *ctx, const kmi_config *cfg, KShape shape, const uint64_t *keys_dev, size_t n, bool transform,
                                  WsSlot slot_a, WsSlot slot_b, Partitioned *out, uint32_t layout_w = 0, uint64_t *split_keys = nullptr,
-                                 uint64_t *split_vals = nullptr) {
+                                 uint64_t *split_vals = nullptr, const float *in_q = nullptr) {
+  // in_q (records of two value words): keys_dev holds (key words, first value word) and the second value word of record i is
+  // in_q[i] (scatter_range)
   // split_keys / split_vals (records): the last pass writes key words and value words into these two arrays (n entries each)
   // instead of records into the workspace -- the first insert into an empty multimap index needs no further copy
   PartWs w;
@@ -2400,7 +2412,7 @@ static kmi_status partition_impl(kmi_ctx *ctx, const kmi_config *cfg, KShape sha
   {
     ProfScope ps(ctx, "hist_fine", n);
     hipLaunchKernelGGL((hist_fine_kernel<NW, BITS, VW>), dim3(kPartGroups), dim3(kPartThreads), 0, ctx->stream, keys_dev, (uint64_t)n, shape,
-                       cfg->strand, transform, w.fine_hist, w.wg_hist, layout_w);
+                       cfg->strand, transform, w.fine_hist, w.wg_hist, layout_w, (uint32_t)(NW + VW) - ((VW > 0 && in_q) ? 1u : 0u));
   }
   {
     ProfScope ps(ctx, "fine_offsets", kNumFine);
@@ -2412,7 +2424,7 @@ static kmi_status partition_impl(kmi_ctx *ctx, const kmi_config *cfg, KShape sha
   {
     ProfScope ps(ctx, "scatter_coarse", n);
     hipLaunchKernelGGL((scatter_chunks_kernel<NW, BITS, VW>), dim3(kPartGroups), dim3(kPartThreads), 0, ctx->stream, keys_dev, (uint64_t)n, w.buf_a,
-                       shape, cfg->strand, transform, fn, w.wg_off);
+                       shape, cfg->strand, transform, fn, w.wg_off, (VW > 0) ? in_q : (const float *)nullptr);
   }
   {
     ProfScope ps(ctx, "scatter_fine", n);
@@ -2969,7 +2981,7 @@ static kmi_status alloc_mm_arrays(kmi_ctx *ctx, uint64_t total, int nw, int vw, 
 }
 
 template <int NW, int BITS, int VW>
-static kmi_status mm_insert_vw(kmi_index *idx, const uint64_t *recs_dev, size_t n, bool transform) {
+static kmi_status mm_insert_vw(kmi_index *idx, const uint64_t *recs_dev, size_t n, bool transform, const float *in_q = nullptr) {
   kmi_ctx *ctx = idx->ctx;
   if (n == 0) return KMI_OK;
   Partitioned part;
@@ -2978,7 +2990,7 @@ static kmi_status mm_insert_vw(kmi_index *idx, const uint64_t *recs_dev, size_t 
     uint64_t *nk, *nv, *noff;
     size_t kb, vb;
     KMI_TRY(alloc_mm_arrays(ctx, n, NW, VW, &nk, &nv, &noff, &kb, &vb));
-    kmi_status st = partition_impl<NW, BITS, VW>(ctx, &idx->cfg, idx->shape, recs_dev, n, transform, WS_KEYS_A, WS_KEYS_B, &part, 0u, nk, nv);
+    kmi_status st = partition_impl<NW, BITS, VW>(ctx, &idx->cfg, idx->shape, recs_dev, n, transform, WS_KEYS_A, WS_KEYS_B, &part, 0u, nk, nv, in_q);
     if (st == KMI_OK && hipMemcpyAsync(noff, part.fine_off, kOffBytes, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess) st = KMI_ERR_DEVICE;
     if (st == KMI_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) st = KMI_ERR_DEVICE;
     if (st != KMI_OK) { pool_free(ctx, nk, kb); pool_free(ctx, nv, vb); pool_free(ctx, noff, kOffBytes); return st; }
@@ -2987,7 +2999,7 @@ static kmi_status mm_insert_vw(kmi_index *idx, const uint64_t *recs_dev, size_t 
     idx->keys_bytes = kb; idx->mvals_bytes = vb;
     return KMI_OK;
   }
-  KMI_TRY((partition_impl<NW, BITS, VW>(ctx, &idx->cfg, idx->shape, recs_dev, n, transform, WS_KEYS_A, WS_KEYS_B, &part)));
+  KMI_TRY((partition_impl<NW, BITS, VW>(ctx, &idx->cfg, idx->shape, recs_dev, n, transform, WS_KEYS_A, WS_KEYS_B, &part, 0u, nullptr, nullptr, in_q)));
   const uint64_t total = n + idx->n_entries;
   uint64_t *nk, *nv, *noff;
   size_t kb, vb;
@@ -3007,14 +3019,15 @@ static kmi_status mm_insert_vw(kmi_index *idx, const uint64_t *recs_dev, size_t 
 }
 
 template <int NW, int BITS>
-static kmi_status mm_insert_impl(kmi_index *idx, const uint64_t *recs_dev, size_t n, bool transform) {
-  if (idx->val_words == 1) return mm_insert_vw<NW, BITS, 1>(idx, recs_dev, n, transform);
-  if (idx->val_words == 2) return mm_insert_vw<NW, BITS, 2>(idx, recs_dev, n, transform);
+static kmi_status mm_insert_impl(kmi_index *idx, const uint64_t *recs_dev, size_t n, bool transform, const float *in_q) {
+  if (idx->val_words == 1) return in_q ? set_err(idx->ctx, KMI_ERR_INVALID, "quality values for a position index") : mm_insert_vw<NW, BITS, 1>(idx, recs_dev, n, transform);
+  if (idx->val_words == 2) return mm_insert_vw<NW, BITS, 2>(idx, recs_dev, n, transform, in_q);
   return set_err(idx->ctx, KMI_ERR_INVALID, "not a multimap index");
 }
 
-static kmi_status index_insert_records(kmi_index *idx, const uint64_t *recs_dev, size_t n, bool transform) {
-  KMI_DISPATCH(idx->shape, mm_insert_impl, idx, recs_dev, n, transform);
+static kmi_status index_insert_records(kmi_index *idx, const uint64_t *recs_dev, size_t n, bool transform, const float *in_q = nullptr) {
+  // in_q: the records are (key words, id) and the quality word of record i is the float in_q[i] (position + quality index)
+  KMI_DISPATCH(idx->shape, mm_insert_impl, idx, recs_dev, n, transform, in_q);
 }
 
 // Index::insert(std::vector<std::pair<Kmer, T>>&) of the counting maps: the value of every pair is ADDED
@@ -3555,13 +3568,20 @@ kmi_status kmi_index_build_dev(kmi_index *idx, const uint8_t *bytes_dev, size_t 
   uint64_t nt = 0, ns = 0;
   KMI_TRY(extract_count(ctx, &idx->cfg, bytes_dev, n_bytes, &nt, &ns));
   if (nt == 0) return KMI_OK;
-  // the tuples leave the extract pass as records (key words, id[, quality bits]): what the multimap insert reads
-  void *dr;
+  // the tuples leave the extract pass as records (key words, id): what the multimap insert reads. The quality values of a
+  // FASTQ position + quality build leave their kernel as one dense float array, which the first partition pass reads beside
+  // the records (a quality word written into 24-byte records afterwards costs a read-modify-write of every line)
+  const bool fastq_q = vw == 2 && idx->cfg.seq_format == KMI_FMT_FASTQ;
+  void *dr, *dq = nullptr;
+  if (fastq_q) {
+    KMI_TRY(ws_get(ctx, WS_INPUT2, (size_t)nt * (nw + 1) * sizeof(uint64_t), &dr));
+    KMI_TRY(ws_get(ctx, WS_OUTPUT2, (size_t)nt * sizeof(float) + 64, &dq));
+    KMI_TRY(extract_run(ctx, &idx->cfg, bytes_dev, n_bytes, file_offset, (uint64_t *)dr, nullptr, (size_t)nt, false, true, &nt, &ns, (float *)dq,
+                        nw + 1));
+    return index_insert_records(idx, (const uint64_t *)dr, (size_t)nt, true, (const float *)dq);
+  }
   KMI_TRY(ws_get(ctx, WS_INPUT2, (size_t)nt * (nw + vw) * sizeof(uint64_t), &dr));
-  if (vw == 2 && idx->cfg.seq_format != KMI_FMT_FASTQ)   // (id, quality) values without quality lines: the quality word stays zero
-    KMI_HIP(ctx, hipMemsetAsync(dr, 0, (size_t)nt * (nw + vw) * sizeof(uint64_t), ctx->stream));
-  const uint32_t rec_words = nw + ((vw == 2 && idx->cfg.seq_format != KMI_FMT_FASTQ) ? 1u : vw);
-  if (rec_words == nw + vw) {
+  if (vw == 1) {
     KMI_TRY(extract_run(ctx, &idx->cfg, bytes_dev, n_bytes, file_offset, (uint64_t *)dr, nullptr, (size_t)nt, false, true, &nt, &ns, nullptr,
                         nw + vw));
   } else {

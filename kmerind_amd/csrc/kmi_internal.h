@@ -148,12 +148,14 @@ bool ws_detach(kmi_ctx *ctx, WsSlot slot, const void *p, size_t *bytes);
 
 // profiling hooks around one kernel launch
 void prof_begin(kmi_ctx *ctx, const char *name, uint64_t units);
-void prof_end(kmi_ctx *ctx);
+void prof_end(kmi_ctx *ctx, size_t slot);
 
-struct ProfScope {
+struct ProfScope {   // scopes may nest: each closes the record it opened
   kmi_ctx *c;
-  ProfScope(kmi_ctx *ctx, const char *name, uint64_t units) : c(ctx) { if (c->prof) prof_begin(c, name, units); }
-  ~ProfScope() { if (c->prof) prof_end(c); }
+  size_t slot;
+  bool on;
+  ProfScope(kmi_ctx *ctx, const char *name, uint64_t units) : c(ctx), slot(0), on(ctx->prof) { if (on) { slot = c->prof_pending.size(); prof_begin(c, name, units); } }
+  ~ProfScope() { if (on) prof_end(c, slot); }
 };
 
 inline bool valid_config(const kmi_config *cfg, KShape *shape) {
