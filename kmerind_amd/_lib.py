@@ -83,6 +83,7 @@ SIGNATURES = {
     "kmi_fastq_partition_dev": (C.c_int, [_P, _P, _sz, _u32, _P]),
     "kmi_route_dev": (C.c_int, [_P, _CFG, _P, _sz, _u32, _P, _P]),
     "kmi_route_tuples_dev": (C.c_int, [_P, _CFG, _P, _sz, _u32, _u32, _P, _P]),
+    "kmi_extract_route_records_dev": (C.c_int, [_P, _CFG, _P, _sz, _u64, _u32, _P, _sz, C.POINTER(_u64), C.POINTER(_u64), _P]),
     "kmi_extract_route_dev": (C.c_int, [_P, _P, _P, _sz, C.c_uint32, _P, _sz, C.POINTER(_u64), C.POINTER(_u64), _P]),
     "kmi_index_create": (C.c_int, [_P, _CFG, C.POINTER(_P)]),
     "kmi_index_destroy": (C.c_int, [_P]),

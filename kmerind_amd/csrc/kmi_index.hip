@@ -207,7 +207,8 @@ __global__ __launch_bounds__(kPartThreads) void hist_fine_kernel(const uint64_t 
 
 template <int NW, int BITS, int VW = 0>
 __global__ __launch_bounds__(kPartThreads) void hist_rank_kernel(const uint64_t *__restrict__ keys, uint64_t n, KShape shape,
-                                                                uint32_t strand, BucketFn fn, uint32_t *__restrict__ wg_hist) {
+                                                                uint32_t strand, BucketFn fn, uint32_t *__restrict__ wg_hist,
+                                                                uint32_t in_rw = NW + VW /* words per input record (scatter_range: in_q) */) {
   __shared__ uint32_t s_hist[kNumCoarse];
   if (threadIdx.x < kNumCoarse) s_hist[threadIdx.x] = 0;
   lds_barrier();
@@ -217,7 +218,7 @@ __global__ __launch_bounds__(kPartThreads) void hist_rank_kernel(const uint64_t 
   for (uint64_t i = b + threadIdx.x; i < e; i += kPartThreads) {
     uint64_t raw[NW], k[NW];
 #pragma unroll
-    for (int w = 0; w < NW; ++w) raw[w] = keys[i * (NW + VW) + w];
+    for (int w = 0; w < NW; ++w) raw[w] = keys[i * in_rw + w];
     strand_key<NW, BITS>(raw, k, shape, strand);
     atomicAdd(&s_hist[bucket_of<NW>(k, fn)], 1u);
   }
@@ -3186,7 +3187,8 @@ static kmi_status read_rank_counts(kmi_ctx *ctx, const uint64_t *cnt_dev, uint32
 
 template <int NW, int BITS, int VW>
 static kmi_status route_vw(kmi_ctx *ctx, const kmi_config *cfg, KShape shape, const uint64_t *keys_dev, size_t n, uint32_t nranks,
-                           uint64_t *out_keys_dev, uint64_t *send_counts_host) {
+                           uint64_t *out_keys_dev, uint64_t *send_counts_host, const float *in_q = nullptr) {
+  // in_q (VW == 2): the input records are (key words, id), the quality word of record i is in_q[i] (scatter_range)
   void *p;
   KMI_TRY(ws_get(ctx, WS_WGHIST, sizeof(uint32_t) * kPartGroups * kNumCoarse, &p)); uint32_t *wg_hist = (uint32_t *)p;
   KMI_TRY(ws_get(ctx, WS_CURSOR, sizeof(uint64_t) * kPartGroups * kNumCoarse, &p)); uint64_t *wg_off = (uint64_t *)p;
@@ -3198,7 +3200,7 @@ static kmi_status route_vw(kmi_ctx *ctx, const kmi_config *cfg, KShape shape, co
   {
     ProfScope ps(ctx, "hist_rank", n);
     hipLaunchKernelGGL((hist_rank_kernel<NW, BITS, VW>), dim3(kPartGroups), dim3(kPartThreads), 0, ctx->stream, keys_dev, (uint64_t)n, shape,
-                       cfg->strand, fn, wg_hist);
+                       cfg->strand, fn, wg_hist, (uint32_t)(NW + VW) - ((VW > 0 && in_q) ? 1u : 0u));
   }
   {
     ProfScope ps(ctx, "rank_offsets", nb);
@@ -3207,7 +3209,7 @@ static kmi_status route_vw(kmi_ctx *ctx, const kmi_config *cfg, KShape shape, co
   {
     ProfScope ps(ctx, "scatter_rank", n);
     hipLaunchKernelGGL((scatter_chunks_kernel<NW, BITS, VW>), dim3(kPartGroups), dim3(kPartThreads), 0, ctx->stream, keys_dev, (uint64_t)n,
-                       out_keys_dev, shape, cfg->strand, true, fn, (const uint64_t *)wg_off);
+                       out_keys_dev, shape, cfg->strand, true, fn, (const uint64_t *)wg_off, (VW > 0) ? in_q : (const float *)nullptr);
   }
   KMI_HIP(ctx, hipGetLastError());
   return read_rank_counts(ctx, cnt, nranks, fn.sub, send_counts_host);
@@ -3249,6 +3251,13 @@ static kmi_status route_impl(kmi_ctx *ctx, const kmi_config *cfg, KShape shape, 
   if (value_words == 1) return route_vw<NW, BITS, 1>(ctx, cfg, shape, keys_dev, n, nranks, out_keys_dev, send_counts_host);
   if (value_words == 2) return route_vw<NW, BITS, 2>(ctx, cfg, shape, keys_dev, n, nranks, out_keys_dev, send_counts_host);
   return set_err(ctx, KMI_ERR_INVALID, "value_words must be 0, 1 or 2");
+}
+
+template <int NW, int BITS>
+static kmi_status route_records_q(kmi_ctx *ctx, const kmi_config *cfg, KShape shape, const uint64_t *recs, size_t n, uint32_t nranks, const float *in_q,
+                                  uint64_t *out, uint64_t *send_counts_host) {
+  if (in_q) return route_vw<NW, BITS, 2>(ctx, cfg, shape, recs, n, nranks, out, send_counts_host, in_q);
+  return route_vw<NW, BITS, 1>(ctx, cfg, shape, recs, n, nranks, out, send_counts_host);
 }
 
 // read_file + the bucketing half of imxx::distribute in one go (FASTQ): keys of this rank's reads, transformed and
@@ -3436,6 +3445,38 @@ kmi_status kmi_extract_route_dev(kmi_ctx *ctx, const kmi_config *cfg, const uint
   if (n_bytes == 0) { for (uint32_t r = 0; r < nranks; ++r) send_counts_host[r] = 0; return KMI_OK; }
   KMI_TRY(align_input(ctx, &bytes_dev, n_bytes));
   KMI_DISPATCH(shape, extract_route_impl, ctx, cfg, shape, bytes_dev, n_bytes, nranks, out_keys_dev, out_capacity, n_tuples, n_seqs, send_counts_host);
+}
+
+// the tuples of the position indexes parsed and grouped by destination rank in one call: the records in file order stay in
+// the workspace as (k-mer, id) and the quality values as one dense float array, which the scatter by rank reads beside them
+kmi_status kmi_extract_route_records_dev(kmi_ctx *ctx, const kmi_config *cfg, const uint8_t *bytes_dev, size_t n_bytes, uint64_t file_offset,
+                                         uint32_t nranks, uint64_t *out_records_dev, size_t out_capacity, uint64_t *n_tuples, uint64_t *n_seqs,
+                                         uint64_t *send_counts_host) {
+  if (!ctx) return KMI_ERR_INVALID;
+  KShape shape;
+  if (!valid_config(cfg, &shape)) return set_err(ctx, KMI_ERR_INVALID, "bad kmi_config");
+  if (nranks == 0 || nranks > (uint32_t)kNumCoarse || !send_counts_host) return set_err(ctx, KMI_ERR_INVALID, "nranks must be in 1..256");
+  if (cfg->index_kind == KMI_INDEX_COUNT) return set_err(ctx, KMI_ERR_INVALID, "records are the tuples of the position indexes (index_kind POSITION / POSQUAL)");
+  if (cfg->index_kind == KMI_INDEX_POSQUAL && cfg->seq_format != KMI_FMT_FASTQ) return set_err(ctx, KMI_ERR_INVALID, "quality values need FASTQ input");
+  KMI_HIP(ctx, hipSetDevice(ctx->device));
+  if (n_tuples) *n_tuples = 0;
+  if (n_seqs) *n_seqs = 0;
+  for (uint32_t r = 0; r < nranks; ++r) send_counts_host[r] = 0;
+  if (n_bytes == 0) return KMI_OK;
+  KMI_TRY(align_input(ctx, &bytes_dev, n_bytes));
+  uint64_t nt = 0, ns = 0;
+  KMI_TRY(extract_count(ctx, cfg, bytes_dev, n_bytes, &nt, &ns));
+  if (n_tuples) *n_tuples = nt;
+  if (n_seqs) *n_seqs = ns;
+  if (nt == 0) return KMI_OK;
+  if (nt > out_capacity) return set_err(ctx, KMI_ERR_OVERFLOW, "extract_route_records: output capacity too small");
+  const uint32_t nw = shape.n_words;
+  const bool q = cfg->index_kind == KMI_INDEX_POSQUAL;
+  void *dr, *dq = nullptr;
+  KMI_TRY(ws_get(ctx, WS_INPUT2, (size_t)nt * (nw + 1) * sizeof(uint64_t), &dr));
+  if (q) KMI_TRY(ws_get(ctx, WS_OUTPUT2, (size_t)nt * sizeof(float) + 64, &dq));
+  KMI_TRY(extract_run(ctx, cfg, bytes_dev, n_bytes, file_offset, (uint64_t *)dr, nullptr, (size_t)nt, false, true, &nt, &ns, (float *)dq, nw + 1));
+  KMI_DISPATCH(shape, route_records_q, ctx, cfg, shape, (const uint64_t *)dr, (size_t)nt, nranks, (const float *)dq, out_records_dev, send_counts_host);
 }
 
 kmi_status kmi_index_create(kmi_ctx *ctx, const kmi_config *cfg, kmi_index **out) {

@@ -404,7 +404,7 @@ class DistributedPositionIndex(DistributedCountIndex):
     """PositionIndex / PositionQualityIndex over all ranks (Index<unordered_multimap>::build_* + insert with comm.size() > 1,
     kmer_index.hpp:148-225, distributed_unordered_map.hpp:1466-1515): every (k-mer, value) tuple is kept, so nothing can be
     combined before the exchange. Per batch of this rank's partition, all on the device: parse the tuples as records
-    (kmi_extract_records_dev: key words, id[, quality bits]), transform and group them by KeyToRank (kmi_route_tuples_dev),
+    (key words, id[, quality bits]), transformed and grouped by KeyToRank (kmi_extract_route_records_dev),
     exchange the records, insert what arrives (kmi_index_insert_tuples_dev). The partition goes through in record-aligned
     batches (kmi_fastq_partition_dev), so the tuple array of a whole partition -- 72 GB per GPU for 200 M reads on 8 --
     never has to exist at once; count / find / erase are the routed queries of the base class."""
@@ -444,18 +444,16 @@ class DistributedPositionIndex(DistributedCountIndex):
             if e > b:
                 self.ctx.check(L.lib.kmi_extract_count_dev(self.ctx.h, C.byref(self.cfg), C.c_void_p(dptr + b), e - b, C.byref(nt), C.byref(ns)))
             n = int(nt.value)
-            rec = torch.empty((n + 8, rw), dtype=torch.int64, device=dev)
             send = torch.empty((n + 8, rw), dtype=torch.int64, device=dev)
             counts = np.zeros(self.world, dtype=np.uint64)
             if n:
-                self.ctx.check(L.lib.kmi_extract_records_dev(self.ctx.h, C.byref(self.cfg), C.c_void_p(dptr + b), e - b, file_offset + b,
-                                                              C.c_void_p(rec.data_ptr()), n, C.byref(nt), C.byref(ns)))
-                self.ctx.check(L.lib.kmi_route_tuples_dev(self.ctx.h, C.byref(self.cfg), C.c_void_p(rec.data_ptr()), n, self.world,
-                                                          self.value_words, C.c_void_p(send.data_ptr()), counts.ctypes.data_as(C.c_void_p)))
+                self.ctx.check(L.lib.kmi_extract_route_records_dev(self.ctx.h, C.byref(self.cfg), C.c_void_p(dptr + b), e - b, file_offset + b,
+                                                                    self.world, C.c_void_p(send.data_ptr()), n, C.byref(nt), C.byref(ns),
+                                                                    counts.ctypes.data_as(C.c_void_p)))
             recv, _ = self._exchange_dev(send[:n], [int(c) for c in counts])
             if recv.shape[0]:
                 self.ctx.check(L.lib.kmi_index_insert_tuples_dev(self.index.h, C.c_void_p(recv.data_ptr()), recv.shape[0]))
-            del rec, send, recv
+            del send, recv
         del cdev
 
     def close(self):

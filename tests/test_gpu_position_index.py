@@ -129,3 +129,44 @@ def test_route_tuples_matches_key_to_rank(ctx):
         exp = np.concatenate([canon[ranks == r], ex["ids"][ranks == r][:, None]], axis=1)
         assert (orc.sorted_rows(seg) == orc.sorted_rows(exp)).all()
         off += int(counts[r])
+
+
+@pytest.mark.parametrize("kind", ["position", "posqual"])
+def test_extract_route_records_matches_key_to_rank(ctx, kind):
+    """kmi_extract_route_records_dev = kmi_extract_records_dev + kmi_route_tuples_dev: the (k-mer, id[, quality]) tuples of a
+    FASTQ buffer at a file offset, canonical k-mers grouped by KeyToRank with their values carried along"""
+    import ctypes as C
+    import kmerind_amd as K
+    from kmerind_amd import _lib as L
+    k, p, off0 = 31, 3, 7_000_000
+    s = orc.kspec(k, orc.DNA)
+    cfg = K.make_config(k, "DNA", strand="canonical", index_kind=kind)
+    data = bytes(K.synth_fastq(seed=12, genome_len=30000, n_reads=700))
+    ex = orc.extract(s, data, orc.FASTQ, want_ids=True, want_quals=(kind == "posqual"), file_offset=off0)
+    cols = [ex["kmers"], ex["ids"][:, None]]
+    if kind == "posqual":
+        cols.append(ex["quals"].astype(np.float32).view(np.uint32).astype(np.uint64)[:, None])
+    n, rw = ex["kmers"].shape[0], len(cols) + ex["kmers"].shape[1] - 1
+    raw = np.frombuffer(data, dtype=np.uint8)
+    din, dout = ctx.alloc(raw.nbytes + 64), ctx.alloc((n + 8) * rw * 8)
+    ctx.to_device(din, raw)
+    counts = np.zeros(p, dtype=np.uint64)
+    nt, ns = C.c_uint64(0), C.c_uint64(0)
+    ctx.check(L.lib.kmi_extract_route_records_dev(ctx.h, C.byref(cfg), C.c_void_p(din), raw.nbytes, off0, p, C.c_void_p(dout), n,
+                                                  C.byref(nt), C.byref(ns), counts.ctypes.data_as(C.c_void_p)))
+    assert nt.value == n and ns.value == 700
+    out = np.zeros((n, rw), dtype=np.uint64)
+    ctx.to_host(out, dout)
+    with pytest.raises(L.KmiError):      # capacity
+        ctx.check(L.lib.kmi_extract_route_records_dev(ctx.h, C.byref(cfg), C.c_void_p(din), raw.nbytes, off0, p, C.c_void_p(dout), n - 1,
+                                                      C.byref(nt), C.byref(ns), counts.copy().ctypes.data_as(C.c_void_p)))
+    ctx.free(din); ctx.free(dout)
+    canon = orc.canonical(s, ex["kmers"])
+    ranks = orc.key_to_rank(s, orc.MURMUR, orc.CANONICAL, canon, p)
+    assert counts.tolist() == np.bincount(ranks, minlength=p).tolist()
+    exp_all = np.concatenate([canon] + cols[1:], axis=1)
+    off = 0
+    for r in range(p):
+        seg = out[off:off + int(counts[r])]
+        assert (orc.sorted_rows(seg) == orc.sorted_rows(exp_all[ranks == r])).all()
+        off += int(counts[r])
