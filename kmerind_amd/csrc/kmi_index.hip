@@ -3944,13 +3944,10 @@ kmi_status kmi_index_build_dist_host(kmi_index *idx, kmi_comm *comm, const uint8
   }
   if (vw == 2 && idx->cfg.seq_format != KMI_FMT_FASTQ)
     return set_err(ctx, KMI_ERR_INVALID, "a position + quality index over ranks is built from FASTQ partitions");
-  void *d_rec;
-  KMI_TRY(ws_get(ctx, WS_INPUT2, (nt + 64) * rw * sizeof(uint64_t), &d_rec));
   KMI_TRY(ws_get(ctx, WS_DIST_A, (nt + 64) * rw * sizeof(uint64_t), &d_send));
-  if (nt) {
-    KMI_TRY(extract_run(ctx, &idx->cfg, (const uint8_t *)d_bytes, n_bytes, file_offset, (uint64_t *)d_rec, nullptr, (size_t)nt, false, true, &nt, &ns, nullptr, rw));
-    KMI_TRY(kmi_route_tuples_dev(ctx, &idx->cfg, (const uint64_t *)d_rec, (size_t)nt, (uint32_t)p, vw, (uint64_t *)d_send, sc.data()));
-  }
+  if (nt)
+    KMI_TRY(kmi_extract_route_records_dev(ctx, &idx->cfg, (const uint8_t *)d_bytes, n_bytes, file_offset, (uint32_t)p, (uint64_t *)d_send, (size_t)nt + 64,
+                                          &nt, &ns, sc.data()));
   KMI_TRY(dist_exchange(comm, d_send, sc.data(), rw * sizeof(uint64_t), WS_DIST_B, &d_recv, rc, &total));
   return index_insert_records(idx, (const uint64_t *)d_recv, (size_t)total, true);
 }
