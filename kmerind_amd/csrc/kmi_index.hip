@@ -2745,7 +2745,7 @@ static kmi_status sk_back_end(kmi_index *idx, const uint64_t *rec_a, uint64_t R,
     ProfScope ps(ctx, "sk_reduce", n);
     const uint32_t nmax = sk_nmax_of(k);
 #define KMI_SK_REDUCE(CANON, OWN)                                                                                                        \
-    hipLaunchKernelGGL((sk_reduce_kernel<CANON, OWN>), dim3(kNumFine), dim3(1024), 0, ctx->stream, (const uint64_t *)rec_b,              \
+    hipLaunchKernelGGL((sk_reduce_kernel<CANON, OWN>), dim3(kNumFine), dim3(KMI_SK_NT), 0, ctx->stream, (const uint64_t *)rec_b,              \
                        (const uint64_t *)fine_off, k, (const uint64_t *)kmer_off, tmp_keys, tmp_vals, out_cnt, ctx->d_flags, ctx->sk_dbg, ctx->sk_level_hint, lp, ctx->sk_inv_dup)
     if (nmax <= 21u) { if (canonical) KMI_SK_REDUCE(true, 64 * 21); else KMI_SK_REDUCE(false, 64 * 21); }
     else if (nmax <= 24u) { if (canonical) KMI_SK_REDUCE(true, 64 * 24); else KMI_SK_REDUCE(false, 64 * 24); }

@@ -552,15 +552,21 @@ __global__ __launch_bounds__(kPartThreads) void sk_recv_hist_kernel(const uint64
 #ifndef KMI_SK_FILL
 #define KMI_SK_FILL 80
 #endif
+#ifndef KMI_SK_NT
+#define KMI_SK_NT 1024      // threads of a sk_reduce workgroup ...
+#endif
+#ifndef KMI_SK_LDS_KB
+#define KMI_SK_LDS_KB 160   // ... and the LDS it may take (512 threads with 80 KB: two workgroups per CU)
+#endif
 template <int OWN_>
 struct SkTabCfg {
-  static constexpr int NT = 1024, NWAVES = NT / kWave;
+  static constexpr int NT = KMI_SK_NT, NWAVES = NT / kWave;
   static constexpr int OWN = OWN_;                       // k-mers of a batch of 64 records at most (64 x nmax)
   static constexpr int H1 = KMI_SK_H1;                   // record table home slots
   static constexpr int S1 = H1 + 64;                     // record table slots (20 bytes each)
   static constexpr int L1 = H1 * 3 / 4;                  // records it takes before the rest goes direct
   static constexpr int FIXED = NWAVES * (OWN + kMissQ * 12) + S1 * 20 + 2560;   // + control words and the pass stack
-  static constexpr int S2 = ((160 * 1024 - FIXED) / 12) / 64 * 64;   // k-mer table slots (12 bytes each)
+  static constexpr int S2 = ((KMI_SK_LDS_KB * 1024 - FIXED) / 12) / 64 * 64;   // k-mer table slots (12 bytes each)
   static constexpr int CAP2 = S2 - 64, LIMIT2 = CAP2 * KMI_SK_FILL / 100;   // LIMIT2: distinct keys of a pass before the bucket is split
 };
 
@@ -610,7 +616,7 @@ __device__ __attribute__((noinline)) uint32_t sk_probe_insert(lds_u64_t *tkeys, 
 }
 
 template <bool CANON, int OWN_>
-__global__ __launch_bounds__(1024) void sk_reduce_kernel(const uint64_t *__restrict__ recs, const uint64_t *__restrict__ rec_off, uint32_t k,
+__global__ __launch_bounds__(KMI_SK_NT) void sk_reduce_kernel(const uint64_t *__restrict__ recs, const uint64_t *__restrict__ rec_off, uint32_t k,
                                                         const uint64_t *__restrict__ kmer_off /* k-mers before every bucket */,
                                                         uint64_t *__restrict__ tmp_keys, uint32_t *__restrict__ tmp_vals,
                                                         uint32_t *__restrict__ out_cnt, uint32_t *__restrict__ flags, int dbg,
