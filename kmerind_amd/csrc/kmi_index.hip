@@ -56,6 +56,7 @@ __host__ __device__ inline uint32_t coarse_of(uint32_t h) { return h >> (32 - kC
 // LDS tile of the partition kernels by record width RW (key words + value words): 64 KB of records
 template <int RW> struct PartCfg {
   static constexpr int TILE = (RW == 1) ? 8192 : (RW == 2 ? 4096 : (RW <= 4 ? 2048 : 1024));   // records per tile
+  static constexpr int CTILE = (RW == 3) ? 3072 : TILE;   // ... of the passes over input chunks (K1 / K2): 24-byte records over 256 buckets leave in runs of 8 with 2048, 72 KB still fits twice per CU (scatter_coarse 16.0 -> 13.7 ms per 1.2e9; P2 is slower with it)
   static constexpr int PER_THREAD = TILE / kPartThreads;                                         // 8, 4, 2, 1
 };
 
@@ -163,7 +164,7 @@ __global__ __launch_bounds__(kPartThreads) void hist_fine_kernel(const uint64_t 
   __shared__ uint32_t s_hist[kNumFine];
   for (int i = threadIdx.x; i < kNumFine; i += kPartThreads) s_hist[i] = 0;
   lds_barrier();
-  const uint64_t chunk = part_chunk(n, gridDim.x, PartCfg<NW + VW>::TILE);
+  const uint64_t chunk = part_chunk(n, gridDim.x, PartCfg<NW + VW>::CTILE);
   const uint64_t b = (uint64_t)blockIdx.x * chunk;
   const uint64_t e = (b + chunk < n) ? b + chunk : n;
   constexpr int U = (NW == 1) ? kLoadBatch : (NW == 2 ? 4 : 2);
@@ -212,7 +213,7 @@ __global__ __launch_bounds__(kPartThreads) void hist_rank_kernel(const uint64_t 
   __shared__ uint32_t s_hist[kNumCoarse];
   if (threadIdx.x < kNumCoarse) s_hist[threadIdx.x] = 0;
   lds_barrier();
-  const uint64_t chunk = part_chunk(n, gridDim.x, PartCfg<NW + VW>::TILE);
+  const uint64_t chunk = part_chunk(n, gridDim.x, PartCfg<NW + VW>::CTILE);
   const uint64_t b = (uint64_t)blockIdx.x * chunk;
   const uint64_t e = (b + chunk < n) ? b + chunk : n;
   for (uint64_t i = b + threadIdx.x; i < e; i += kPartThreads) {
@@ -325,7 +326,7 @@ static void launch_rank_offsets(hipStream_t stream, const uint32_t *wg_hist, uin
 // (S4) contiguous copy-out. Four barriers per tile; the running output cursor of bucket b lives
 // in a register of thread b; the next tile's keys are already in flight during S1-S4.
 // ---------------------------------------------------------------------------
-template <int NW, int BITS, int VW = 0>
+template <int NW, int BITS, int VW = 0, int TILE_ = PartCfg<NW + VW>::TILE>
 __device__ __forceinline__ void scatter_range(const uint64_t *__restrict__ in, uint64_t begin, uint64_t end, uint64_t *__restrict__ out,
                                               const KShape &shape, uint32_t strand, bool transform, const BucketFn &fn,
                                               uint64_t cursor /* of bucket threadIdx.x, threads < 256 */,
@@ -337,8 +338,8 @@ __device__ __forceinline__ void scatter_range(const uint64_t *__restrict__ in, u
   // out_vals (records only): the key words go to out[dst * NW ..], the value words to out_vals[dst * VW ..] -- the arrays of a
   // multimap index -- instead of whole records to out[dst * RW ..]
   constexpr int RW = NW + VW;   // record = key words followed by value words
-  constexpr int TILE = PartCfg<RW>::TILE;
-  constexpr int PT = PartCfg<RW>::PER_THREAD;
+  constexpr int TILE = TILE_;
+  constexpr int PT = TILE_ / kPartThreads;
   if (threadIdx.x < kNumCoarse) s_cnt[threadIdx.x] = 0;
   lds_barrier();
   uint64_t raw[PT][RW];
@@ -436,9 +437,9 @@ __device__ __forceinline__ void scatter_range(const uint64_t *__restrict__ in, u
   }
 }
 
-#define KMI_SCATTER_LDS(RW)                                        \
-  __shared__ uint64_t s_stage[PartCfg<RW>::TILE * (RW)];           \
-  __shared__ uint8_t s_bkt[PartCfg<RW>::TILE];                     \
+#define KMI_SCATTER_LDS(RW, TL)                                    \
+  __shared__ uint64_t s_stage[(TL) * (RW)];                        \
+  __shared__ uint8_t s_bkt[TL];                                    \
   __shared__ uint32_t s_cnt[kNumCoarse];                           \
   __shared__ uint32_t s_lofs[kNumCoarse];                          \
   __shared__ uint64_t s_gbase[kNumCoarse];                         \
@@ -449,12 +450,12 @@ template <int NW, int BITS, int VW = 0>
 __global__ __launch_bounds__(kPartThreads) void scatter_chunks_kernel(const uint64_t *__restrict__ in, uint64_t n, uint64_t *__restrict__ out,
                                                                      KShape shape, uint32_t strand, bool transform, BucketFn fn,
                                                                      const uint64_t *__restrict__ wg_off, const float *__restrict__ in_q = nullptr) {
-  KMI_SCATTER_LDS(NW + VW)
+  KMI_SCATTER_LDS(NW + VW, (PartCfg<NW + VW>::CTILE))
   const uint64_t cursor = (threadIdx.x < kNumCoarse) ? wg_off[(uint64_t)blockIdx.x * kNumCoarse + threadIdx.x] : 0ull;
-  const uint64_t chunk = part_chunk(n, gridDim.x, PartCfg<NW + VW>::TILE);
+  const uint64_t chunk = part_chunk(n, gridDim.x, PartCfg<NW + VW>::CTILE);
   const uint64_t b = (uint64_t)blockIdx.x * chunk;
   const uint64_t e = (b + chunk < n) ? b + chunk : n;
-  if (b < e) scatter_range<NW, BITS, VW>(in, b, e, out, shape, strand, transform, fn, cursor, s_stage, s_bkt, s_cnt, s_lofs, s_gbase, s_part, nullptr, in_q);
+  if (b < e) scatter_range<NW, BITS, VW, PartCfg<NW + VW>::CTILE>(in, b, e, out, shape, strand, transform, fn, cursor, s_stage, s_bkt, s_cnt, s_lofs, s_gbase, s_part, nullptr, in_q);
 }
 
 // P2: workgroup (c, h) splits the part of coarse bucket c that K2 groups [h*256,(h+1)*256) wrote
@@ -463,7 +464,7 @@ __global__ __launch_bounds__(kPartThreads) void scatter_fine_kernel(const uint64
                                                                    const uint64_t *__restrict__ fine_off, const uint64_t *__restrict__ part_off,
                                                                    const uint64_t *__restrict__ wg_off, uint32_t groups, int mode = BUCKET_SUB,
                                                                    uint32_t layout_w = 0, uint64_t *__restrict__ out_vals = nullptr) {
-  KMI_SCATTER_LDS(NW + VW)
+  KMI_SCATTER_LDS(NW + VW, (PartCfg<NW + VW>::TILE))
   const uint32_t gpp = groups / kFineParts;   // K2 / E2 workgroups per part
   const uint32_t c = blockIdx.x / kFineParts, h = blockIdx.x % kFineParts;
   const uint64_t cursor = (threadIdx.x < kSubPerCoarse) ? part_off[(uint64_t)h * kNumFine + c * kSubPerCoarse + threadIdx.x] : 0ull;
