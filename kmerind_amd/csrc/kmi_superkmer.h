@@ -556,7 +556,8 @@ __global__ __launch_bounds__(kPartThreads) void sk_recv_hist_kernel(const uint64
 #define KMI_SK_NT 1024      // threads of a sk_reduce workgroup ...
 #endif
 #ifndef KMI_SK_LDS_KB
-#define KMI_SK_LDS_KB 160   // ... and the LDS it may take (512 threads with 80 KB: two workgroups per CU)
+#define KMI_SK_LDS_KB 160   // ... and the LDS it may take. Measured on config 2 (3.55 ms): 512 threads / 80 KB, two workgroups per CU, H1 768 or
+                            // 512: 3.60 - 3.63 (same wavefronts per CU, twice the passes); 1024 threads / 80 KB, H1 512 / 256: 7.0 / 8.2 ms
 #endif
 template <int OWN_>
 struct SkTabCfg {
