@@ -395,7 +395,7 @@ struct ReadDesc { uint64_t seq_pos, out_off; };   // slot = sequence index of th
 //    (coalesced), chunk by chunk (kQualChunk windows), into a row per read; the row stride is an odd number of dwords, so
 //    the per-lane walk over "its" row is conflict free;
 //  * the values leave through a 64 x 16 LDS tile: every 16 windows the lanes write each read's 16 floats as one 64-byte line.
-constexpr int kQualChunk = 64;                        // windows per chunk (a multiple of 16)
+constexpr int kQualChunk = 32;                        // windows per chunk (a multiple of 16)
 constexpr int kQualThreads = 256;
 inline uint32_t qual_row_bytes(uint32_t k) { return (((kQualChunk + k + 3u) / 4u + 1u) | 1u) * 4u; }   // the aligned dwords that cover chunk + k characters at any shift; odd
 inline size_t qual_lds_bytes(uint32_t k) { return (size_t)(kQualThreads / kWave) * (64u * qual_row_bytes(k) + 64u * 17u * 4u + 64u * 12u) + 96u * 4u + 32u * 8u; }
