@@ -302,6 +302,21 @@ __global__ __launch_bounds__(256) void fastq_check_lengths_kernel(const uint32_t
 // pass 3: tuples in file order. Work is re-distributed over the tile's compacted window list,
 // so consecutive lanes produce consecutive tuples and the stores are coalesced without staging.
 // ---------------------------------------------------------------------------
+// a whole record (key words, one value word) of an even number of words as 16-byte stores: half the write transactions of
+// word-by-word stores with a record's stride between lanes
+template <int NW>
+__device__ __forceinline__ void store_record_vec(uint64_t *__restrict__ recs, uint64_t i, const uint64_t (&key)[NW], uint64_t val) {
+  static_assert((NW + 1) % 2 == 0, "records of an even number of words");
+  uint64_t w[NW + 1];
+#pragma unroll
+  for (int j = 0; j < NW; ++j) w[j] = key[j];
+  w[NW] = val;
+  ulonglong2 *dst = reinterpret_cast<ulonglong2 *>(recs + i * (NW + 1));
+#pragma unroll
+  for (int j = 0; j < (NW + 1) / 2; ++j) dst[j] = make_ulonglong2(w[2 * j], w[2 * j + 1]);
+}
+template <int NW> constexpr bool kRecVec = (NW + 1) % 2 == 0;
+
 // FASTA: the same pass over the compacted character stream (in.eol = record-start bits, in.n_bytes = characters)
 template <int NW, int BITS, bool WITH_IDS>
 __global__ __launch_bounds__((ExCfg<NW, BITS>::NT)) void fasta_extract_kernel(
@@ -322,11 +337,16 @@ __global__ __launch_bounds__((ExCfg<NW, BITS>::NT)) void fasta_extract_kernel(
     if (threadIdx.x == 0 && total) atomicOr(&flags[1], 1u);
     return;
   }
+  // records of (key words, id) at a 16-byte aligned address
+  const bool vec = WITH_IDS && kstride == (uint32_t)NW + 1u && istride == kstride && out_ids == out_kmers + NW && ((uintptr_t)out_kmers & 15u) == 0;
   for (uint32_t q = threadIdx.x; q < total; q += Cfg::NT) {
     uint64_t rc[NW], fw[NW], key[NW];
     const uint32_t pos = s_pos[q];
     window_at<Cfg>(s_stream, pos, shape, rc, fw);
     select_strand<NW>(rc, fw, canonical, key);
+    if constexpr (WITH_IDS && kRecVec<NW>) {
+      if (vec) { store_record_vec<NW>(out_kmers, base + q, key, ids_by_rank[tile0 + pos]); continue; }   // uniform
+    }
 #pragma unroll
     for (int w = 0; w < NW; ++w) out_kmers[(base + q) * kstride + w] = key[w];
     if (WITH_IDS) out_ids[(base + q) * istride] = ids_by_rank[tile0 + pos];
@@ -550,13 +570,17 @@ __global__ __launch_bounds__((ExCfg<NW, BITS>::NT)) void fastq_extract_kernel(
     return;
   }
   const uint64_t tile0 = (uint64_t)blockIdx.x * Cfg::TILE;
+  // records of (key words, id) at a 16-byte aligned address leave as 16-byte stores (store_record_vec)
+  const bool vec = WITH_IDS && kRecVec<NW> && kstride == (uint32_t)NW + 1u && istride == kstride && out_ids == out_kmers + NW && ((uintptr_t)out_kmers & 15u) == 0;
   for (uint32_t q = threadIdx.x; q < total; q += Cfg::NT) {
     uint64_t rc[NW], fw[NW], key[NW];
     const uint32_t pos = s_pos[q];
     window_at<Cfg>(s_stream, pos, shape, rc, fw);
     select_strand<NW>(rc, fw, canonical || (WITH_IDS && raw_edges != nullptr), key);
+    if (!vec) {
 #pragma unroll
-    for (int w = 0; w < NW; ++w) out_kmers[(base + q) * kstride + w] = key[w];
+      for (int w = 0; w < NW; ++w) out_kmers[(base + q) * kstride + w] = key[w];
+    }
     if (WITH_IDS && raw_edges) {   // uniform
       // edge_iterator.hpp:163-177: the bases left and right of the k-mer in its (single-line) FASTQ sequence, DNA16 codes,
       // nothing where the read ends; reverse_complement_edges (de_bruijn_node_trait.hpp:122-124) when the other strand is kept
@@ -565,6 +589,9 @@ __global__ __launch_bounds__((ExCfg<NW, BITS>::NT)) void fastq_extract_kernel(
       const uint32_t rcch = p0 + shape.k < in.n_bytes ? raw_edges[p0 + shape.k] : (uint32_t)'\n';
       uint32_t e = ((is_eol(lc) ? 0u : code_dna16(lc)) << 4) | (is_eol(rcch) ? 0u : code_dna16(rcch));
       if (less_words<NW>(rc, fw)) e = (comp_code<4>(e & 0xFu) << 4) | comp_code<4>(e >> 4);
+      if constexpr (WITH_IDS && kRecVec<NW>) {
+        if (vec) { store_record_vec<NW>(out_kmers, base + q, key, 1ull | ((uint64_t)e << 32)); continue; }
+      }
       out_ids[(base + q) * istride] = 1ull | ((uint64_t)e << 32);
       continue;
     }
@@ -579,7 +606,11 @@ __global__ __launch_bounds__((ExCfg<NW, BITS>::NT)) void fastq_extract_kernel(
       else rec = hdr_base[blockIdx.x];
       const uint64_t rec_off = file_offset + rec - 1u, d = tile0 + pos - (rec - 1u);
       if (rec == 0 || d > 0xFFFFu) atomicOr(&flags[3], 1u);   // ShortSequenceKmerId increment overflow (sequence.hpp:177-183)
-      out_ids[(base + q) * istride] = ((rec_off & 0xFFFFFFFFFFull) << 16) | (d & 0xFFFFull);
+      bool stored = false;
+      if constexpr (kRecVec<NW>) {
+        if (vec) { store_record_vec<NW>(out_kmers, base + q, key, ((rec_off & 0xFFFFFFFFFFull) << 16) | (d & 0xFFFFull)); stored = true; }
+      }
+      if (!stored) out_ids[(base + q) * istride] = ((rec_off & 0xFFFFFFFFFFull) << 16) | (d & 0xFFFFull);
       // first window of its read (the window starts on the line start of the sequence line)
       if (reads && ((s_lsmask[j] >> p) & 1u)) {
         // the descriptor slot is the read's sequence index: its sequence line is line 4 * index + 1 of the buffer

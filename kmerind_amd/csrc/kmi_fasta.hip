@@ -243,6 +243,8 @@ __global__ __launch_bounds__((FaCfg::NT)) void fasta_compact_kernel(const uint8_
   __shared__ uint32_t s_scanm[FaCfg::NT / 64 + 2];
   __shared__ uint32_t s_scan[FaCfg::NT / 64 + 2];
   __shared__ uint32_t s_bits[(FaCfg::TILE * BITS) / 32 + 4];   // the tile's characters, aligned to the global dword grid
+  __shared__ uint32_t s_loc[FaCfg::TILE];                      // ids: every character's byte in the tile | record starts of the tile before it << 13
+  static_assert(FaCfg::TILE <= 8192, "s_loc packs the byte offset into 13 bits");
   for (int i = threadIdx.x; i < (FaCfg::TILE * BITS) / 32 + 4; i += FaCfg::NT) s_bits[i] = 0;
   const uint64_t tile0 = (uint64_t)blockIdx.x * FaCfg::TILE;
   const FaTileBase tb = base[blockIdx.x];
@@ -300,13 +302,9 @@ __global__ __launch_bounds__((FaCfg::NT)) void fasta_compact_kernel(const uint8_
       const uint32_t bit = m * BITS;
       if (bit < 64) run_lo |= cc << bit;
       if (bit + BITS > 64) run_hi |= (uint32_t)(cc >> (64 - bit));
-      if (ids) {
-        // sequence index = record starts at or before this character - 1 (+1 when the buffer begins with orphan lines)
-        const uint64_t ev_before = tb.ev + le + (uint32_t)__builtin_popcount(r.ev & ((2u << p) - 1u));
-        const uint64_t seq_index = ev_before - 1u + index_shift;
-        const uint64_t pos = file_offset + tile0 + (uint64_t)threadIdx.x * C + p;
-        ids[rank0 + m] = (pos & 0xFFFFFFFFFFull) | ((seq_index & 0xFFFFull) << 40);
-      }
+      if (ids)   // (written after the barrier, a tile's ids as consecutive words: one 8-byte store per character from here is one
+                 // memory transaction per character, 7.8 ms per Gbp)
+        s_loc[lr + m] = (threadIdx.x * C + p) | ((le + (uint32_t)__builtin_popcount(r.ev & ((2u << p) - 1u))) << 13);
       ++m; rest &= rest - 1u;
     }
     if (m) {
@@ -329,6 +327,15 @@ __global__ __launch_bounds__((FaCfg::NT)) void fasta_compact_kernel(const uint8_
     const uint32_t v = s_bits[i];
     if (i == 0 || i == ndw - 1) { if (v) atomicOr(&pk_stream[gd0 + i], v); }
     else pk_stream[gd0 + i] = v;
+  }
+  if (ids) {   // uniform
+    for (uint32_t i = threadIdx.x; i < tile_chars; i += FaCfg::NT) {
+      const uint32_t v = s_loc[i];
+      // sequence index = record starts at or before this character - 1 (+1 when the buffer begins with orphan lines)
+      const uint64_t seq_index = (uint64_t)tb.ev + (v >> 13) - 1u + index_shift;
+      const uint64_t pos = file_offset + tile0 + (v & 8191u);
+      ids[tb.rank + i] = (pos & 0xFFFFFFFFFFull) | ((seq_index & 0xFFFFull) << 40);
+    }
   }
 }
 
