@@ -75,3 +75,29 @@ def test_position_quality_index(ctx):
     ok, oc = mm.count(q)
     assert (orc.sorted_rows(ck, cc) == orc.sorted_rows(ok, oc)).all()
     idx.close()
+
+
+def test_position_quality_index_many_tiles(ctx):
+    """200 k reads (24 M tuples): the build's first partition pass reads the (k-mer, id) records and the dense quality array over
+    thousands of tiles; every (canonical k-mer, id, quality bits) row of the index against the oracle's tuples, as sorted mixes"""
+    import kmerind_amd as K
+    k = 31
+    s = orc.kspec(k, orc.DNA)
+    cfg = K.make_config(k, "DNA", strand="canonical", index_kind="posqual")
+    data = bytes(K.synth_fastq(seed=21, genome_len=2_000_000, n_reads=200_000))
+    ex = orc.extract(s, data, orc.FASTQ, want_ids=True, want_quals=True, file_offset=123_456_789)
+    idx = K.PositionIndex(ctx, cfg)
+    idx.build(data, file_offset=123_456_789)
+    assert idx.local_size() == ex["kmers"].shape[0] == 200_000 * 120
+    gk, gv = idx.to_vector()
+    idx.close()
+
+    def mix(kmers, ids, qbits):
+        with np.errstate(over="ignore"):
+            m = kmers.astype(np.uint64) * np.uint64(0x9E3779B97F4A7C15)
+            m ^= (ids.astype(np.uint64) + np.uint64(0x7F4A7C15)) * np.uint64(0xC2B2AE3D27D4EB4F)
+            m ^= (qbits.astype(np.uint64) + np.uint64(1)) * np.uint64(0x165667B19E3779F9)
+        return np.sort(m)
+    exp = mix(orc.canonical(s, ex["kmers"])[:, 0], ex["ids"], ex["quals"].view(np.uint32))
+    got = mix(gk[:, 0], gv[:, 0], gv[:, 1])
+    assert (exp == got).all()
