@@ -332,9 +332,11 @@ __device__ __forceinline__ void scatter_range(const uint64_t *__restrict__ in, u
                                               uint64_t cursor /* of bucket threadIdx.x, threads < 256 */,
                                               uint64_t *s_stage, uint8_t *s_bkt, uint32_t *s_cnt, uint32_t *s_lofs,
                                               uint64_t *s_gbase, uint32_t *s_part, uint64_t *__restrict__ out_vals = nullptr,
-                                              const float *__restrict__ in_q = nullptr) {
+                                              const float *__restrict__ in_q = nullptr, const uint64_t *__restrict__ in_v = nullptr) {
   // in_q (records only): the input records are one word short and their last value word is the float in_q[i] (its bits in the
   // low half) -- the quality values of a position + quality build, which leave their kernel as one dense array
+  // in_v (records only): the input is split -- `in` holds the key words alone, in_v[i] the first value word of record i (and
+  // in_q[i], or zero without in_q, the second): the arrays the tuple parsers write, so the histogram pass reads keys only
   // out_vals (records only): the key words go to out[dst * NW ..], the value words to out_vals[dst * VW ..] -- the arrays of a
   // multimap index -- instead of whole records to out[dst * RW ..]
   constexpr int RW = NW + VW;   // record = key words followed by value words
@@ -348,7 +350,12 @@ __device__ __forceinline__ void scatter_range(const uint64_t *__restrict__ in, u
     for (int j = 0; j < PT; ++j) {
       uint64_t i = t0 + (uint64_t)j * kPartThreads + threadIdx.x;
       i = (i < end) ? i : end - 1;
-      if (VW > 0 && in_q) {   // uniform
+      if (VW > 0 && in_v) {   // uniform
+#pragma unroll
+        for (int w = 0; w < NW; ++w) raw[j][w] = in[i * NW + w];
+        raw[j][NW] = in_v[i];
+        if (VW > 1) raw[j][RW - 1] = in_q ? (uint64_t)__float_as_uint(in_q[i]) : 0ull;
+      } else if (VW > 0 && in_q) {   // uniform
 #pragma unroll
         for (int w = 0; w < RW - 1; ++w) raw[j][w] = in[i * (RW - 1) + w];
         raw[j][RW - 1] = (uint64_t)__float_as_uint(in_q[i]);
@@ -449,13 +456,14 @@ __device__ __forceinline__ void scatter_range(const uint64_t *__restrict__ in, u
 template <int NW, int BITS, int VW = 0>
 __global__ __launch_bounds__(kPartThreads) void scatter_chunks_kernel(const uint64_t *__restrict__ in, uint64_t n, uint64_t *__restrict__ out,
                                                                      KShape shape, uint32_t strand, bool transform, BucketFn fn,
-                                                                     const uint64_t *__restrict__ wg_off, const float *__restrict__ in_q = nullptr) {
+                                                                     const uint64_t *__restrict__ wg_off, const float *__restrict__ in_q = nullptr,
+                                                                     const uint64_t *__restrict__ in_v = nullptr) {
   KMI_SCATTER_LDS(NW + VW, (PartCfg<NW + VW>::CTILE))
   const uint64_t cursor = (threadIdx.x < kNumCoarse) ? wg_off[(uint64_t)blockIdx.x * kNumCoarse + threadIdx.x] : 0ull;
   const uint64_t chunk = part_chunk(n, gridDim.x, PartCfg<NW + VW>::CTILE);
   const uint64_t b = (uint64_t)blockIdx.x * chunk;
   const uint64_t e = (b + chunk < n) ? b + chunk : n;
-  if (b < e) scatter_range<NW, BITS, VW, PartCfg<NW + VW>::CTILE>(in, b, e, out, shape, strand, transform, fn, cursor, s_stage, s_bkt, s_cnt, s_lofs, s_gbase, s_part, nullptr, in_q);
+  if (b < e) scatter_range<NW, BITS, VW, PartCfg<NW + VW>::CTILE>(in, b, e, out, shape, strand, transform, fn, cursor, s_stage, s_bkt, s_cnt, s_lofs, s_gbase, s_part, nullptr, in_q, in_v);
 }
 
 // P2: workgroup (c, h) splits the part of coarse bucket c that K2 groups [h*256,(h+1)*256) wrote
@@ -2403,9 +2411,9 @@ static kmi_status get_part_ws(kmi_ctx *ctx, size_t n, int nw, WsSlot slot_a, WsS
 template <int NW, int BITS, int VW = 0>
 static kmi_status partition_impl(kmi_ctx *ctx, const kmi_config *cfg, KShape shape, const uint64_t *keys_dev, size_t n, bool transform,
                                  WsSlot slot_a, WsSlot slot_b, Partitioned *out, uint32_t layout_w = 0, uint64_t *split_keys = nullptr,
-                                 uint64_t *split_vals = nullptr, const float *in_q = nullptr) {
+                                 uint64_t *split_vals = nullptr, const float *in_q = nullptr, const uint64_t *in_v = nullptr) {
   // in_q (records of two value words): keys_dev holds (key words, first value word) and the second value word of record i is
-  // in_q[i] (scatter_range)
+  // in_q[i]; in_v: keys_dev holds the key words alone, the value words come from in_v / in_q (scatter_range)
   // split_keys / split_vals (records): the last pass writes key words and value words into these two arrays (n entries each)
   // instead of records into the workspace -- the first insert into an empty multimap index needs no further copy
   PartWs w;
@@ -2414,7 +2422,8 @@ static kmi_status partition_impl(kmi_ctx *ctx, const kmi_config *cfg, KShape sha
   {
     ProfScope ps(ctx, "hist_fine", n);
     hipLaunchKernelGGL((hist_fine_kernel<NW, BITS, VW>), dim3(kPartGroups), dim3(kPartThreads), 0, ctx->stream, keys_dev, (uint64_t)n, shape,
-                       cfg->strand, transform, w.fine_hist, w.wg_hist, layout_w, (uint32_t)(NW + VW) - ((VW > 0 && in_q) ? 1u : 0u));
+                       cfg->strand, transform, w.fine_hist, w.wg_hist, layout_w,
+                       (VW > 0 && in_v) ? (uint32_t)NW : (uint32_t)(NW + VW) - ((VW > 0 && in_q) ? 1u : 0u));
   }
   {
     ProfScope ps(ctx, "fine_offsets", kNumFine);
@@ -2426,7 +2435,8 @@ static kmi_status partition_impl(kmi_ctx *ctx, const kmi_config *cfg, KShape sha
   {
     ProfScope ps(ctx, "scatter_coarse", n);
     hipLaunchKernelGGL((scatter_chunks_kernel<NW, BITS, VW>), dim3(kPartGroups), dim3(kPartThreads), 0, ctx->stream, keys_dev, (uint64_t)n, w.buf_a,
-                       shape, cfg->strand, transform, fn, w.wg_off, (VW > 0) ? in_q : (const float *)nullptr);
+                       shape, cfg->strand, transform, fn, w.wg_off, (VW > 0) ? in_q : (const float *)nullptr,
+                       (VW > 0) ? in_v : (const uint64_t *)nullptr);
   }
   {
     ProfScope ps(ctx, "scatter_fine", n);
@@ -2983,7 +2993,8 @@ static kmi_status alloc_mm_arrays(kmi_ctx *ctx, uint64_t total, int nw, int vw, 
 }
 
 template <int NW, int BITS, int VW>
-static kmi_status mm_insert_vw(kmi_index *idx, const uint64_t *recs_dev, size_t n, bool transform, const float *in_q = nullptr) {
+static kmi_status mm_insert_vw(kmi_index *idx, const uint64_t *recs_dev, size_t n, bool transform, const float *in_q = nullptr,
+                               const uint64_t *in_v = nullptr) {
   kmi_ctx *ctx = idx->ctx;
   if (n == 0) return KMI_OK;
   Partitioned part;
@@ -2992,7 +3003,7 @@ static kmi_status mm_insert_vw(kmi_index *idx, const uint64_t *recs_dev, size_t 
     uint64_t *nk, *nv, *noff;
     size_t kb, vb;
     KMI_TRY(alloc_mm_arrays(ctx, n, NW, VW, &nk, &nv, &noff, &kb, &vb));
-    kmi_status st = partition_impl<NW, BITS, VW>(ctx, &idx->cfg, idx->shape, recs_dev, n, transform, WS_KEYS_A, WS_KEYS_B, &part, 0u, nk, nv, in_q);
+    kmi_status st = partition_impl<NW, BITS, VW>(ctx, &idx->cfg, idx->shape, recs_dev, n, transform, WS_KEYS_A, WS_KEYS_B, &part, 0u, nk, nv, in_q, in_v);
     if (st == KMI_OK && hipMemcpyAsync(noff, part.fine_off, kOffBytes, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess) st = KMI_ERR_DEVICE;
     if (st == KMI_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) st = KMI_ERR_DEVICE;
     if (st != KMI_OK) { pool_free(ctx, nk, kb); pool_free(ctx, nv, vb); pool_free(ctx, noff, kOffBytes); return st; }
@@ -3001,7 +3012,7 @@ static kmi_status mm_insert_vw(kmi_index *idx, const uint64_t *recs_dev, size_t 
     idx->keys_bytes = kb; idx->mvals_bytes = vb;
     return KMI_OK;
   }
-  KMI_TRY((partition_impl<NW, BITS, VW>(ctx, &idx->cfg, idx->shape, recs_dev, n, transform, WS_KEYS_A, WS_KEYS_B, &part, 0u, nullptr, nullptr, in_q)));
+  KMI_TRY((partition_impl<NW, BITS, VW>(ctx, &idx->cfg, idx->shape, recs_dev, n, transform, WS_KEYS_A, WS_KEYS_B, &part, 0u, nullptr, nullptr, in_q, in_v)));
   const uint64_t total = n + idx->n_entries;
   uint64_t *nk, *nv, *noff;
   size_t kb, vb;
@@ -3021,15 +3032,17 @@ static kmi_status mm_insert_vw(kmi_index *idx, const uint64_t *recs_dev, size_t 
 }
 
 template <int NW, int BITS>
-static kmi_status mm_insert_impl(kmi_index *idx, const uint64_t *recs_dev, size_t n, bool transform, const float *in_q) {
-  if (idx->val_words == 1) return in_q ? set_err(idx->ctx, KMI_ERR_INVALID, "quality values for a position index") : mm_insert_vw<NW, BITS, 1>(idx, recs_dev, n, transform);
-  if (idx->val_words == 2) return mm_insert_vw<NW, BITS, 2>(idx, recs_dev, n, transform, in_q);
+static kmi_status mm_insert_impl(kmi_index *idx, const uint64_t *recs_dev, size_t n, bool transform, const float *in_q, const uint64_t *in_v) {
+  if (idx->val_words == 1) return in_q ? set_err(idx->ctx, KMI_ERR_INVALID, "quality values for a position index") : mm_insert_vw<NW, BITS, 1>(idx, recs_dev, n, transform, nullptr, in_v);
+  if (idx->val_words == 2) return mm_insert_vw<NW, BITS, 2>(idx, recs_dev, n, transform, in_q, in_v);
   return set_err(idx->ctx, KMI_ERR_INVALID, "not a multimap index");
 }
 
-static kmi_status index_insert_records(kmi_index *idx, const uint64_t *recs_dev, size_t n, bool transform, const float *in_q = nullptr) {
+static kmi_status index_insert_records(kmi_index *idx, const uint64_t *recs_dev, size_t n, bool transform, const float *in_q = nullptr,
+                                       const uint64_t *in_v = nullptr) {
   // in_q: the records are (key words, id) and the quality word of record i is the float in_q[i] (position + quality index)
-  KMI_DISPATCH(idx->shape, mm_insert_impl, idx, recs_dev, n, transform, in_q);
+  // in_v: recs_dev holds the key words alone, in_v the ids (and in_q the qualities, or none: zero)
+  KMI_DISPATCH(idx->shape, mm_insert_impl, idx, recs_dev, n, transform, in_q, in_v);
 }
 
 // Index::insert(std::vector<std::pair<Kmer, T>>&) of the counting maps: the value of every pair is ADDED
@@ -3610,33 +3623,16 @@ kmi_status kmi_index_build_dev(kmi_index *idx, const uint8_t *bytes_dev, size_t 
   uint64_t nt = 0, ns = 0;
   KMI_TRY(extract_count(ctx, &idx->cfg, bytes_dev, n_bytes, &nt, &ns));
   if (nt == 0) return KMI_OK;
-  // the tuples leave the extract pass as records (key words, id): what the multimap insert reads. The quality values of a
-  // FASTQ position + quality build leave their kernel as one dense float array, which the first partition pass reads beside
-  // the records (a quality word written into 24-byte records afterwards costs a read-modify-write of every line)
-  const bool fastq_q = vw == 2 && idx->cfg.seq_format == KMI_FMT_FASTQ;
-  void *dr, *dq = nullptr;
-  if (fastq_q) {
-    KMI_TRY(ws_get(ctx, WS_INPUT2, (size_t)nt * (nw + 1) * sizeof(uint64_t), &dr));
-    KMI_TRY(ws_get(ctx, WS_OUTPUT2, (size_t)nt * sizeof(float) + 64, &dq));
-    KMI_TRY(extract_run(ctx, &idx->cfg, bytes_dev, n_bytes, file_offset, (uint64_t *)dr, nullptr, (size_t)nt, false, true, &nt, &ns, (float *)dq,
-                        nw + 1));
-    return index_insert_records(idx, (const uint64_t *)dr, (size_t)nt, true, (const float *)dq);
-  }
-  KMI_TRY(ws_get(ctx, WS_INPUT2, (size_t)nt * (nw + vw) * sizeof(uint64_t), &dr));
-  if (vw == 1) {
-    KMI_TRY(extract_run(ctx, &idx->cfg, bytes_dev, n_bytes, file_offset, (uint64_t *)dr, nullptr, (size_t)nt, false, true, &nt, &ns, nullptr,
-                        nw + vw));
-  } else {
-    // FASTA under a position + quality index: separate arrays, then the interleave pass leaves the quality word empty
-    void *dk, *di;
-    KMI_TRY(ws_get(ctx, WS_OUTPUT, (size_t)nt * nw * sizeof(uint64_t), &dk));
-    KMI_TRY(ws_get(ctx, WS_OUTPUT2, (size_t)nt * sizeof(uint64_t), &di));
-    KMI_TRY(extract_run(ctx, &idx->cfg, bytes_dev, n_bytes, file_offset, (uint64_t *)dk, (uint64_t *)di, (size_t)nt, false, true, &nt, &ns));
-    hipLaunchKernelGGL(interleave_records_kernel, dim3(2048), dim3(256), 0, ctx->stream, (const uint64_t *)dk, (const uint64_t *)di,
-                       (const float *)nullptr, nt, nw, vw, (uint64_t *)dr);
-    KMI_HIP(ctx, hipGetLastError());
-  }
-  return index_insert_records(idx, (const uint64_t *)dr, (size_t)nt, true);
+  // the tuples leave the extract pass as the parsers' separate arrays -- k-mers, ids and (FASTQ, position + quality) one dense
+  // float array -- and the first partition pass gathers a record from them: its histogram reads the k-mers alone, and a quality
+  // word written into 24-byte records afterwards would cost a read-modify-write of every line. (Without quality lines the
+  // quality word of a position + quality index stays zero.)
+  void *dk, *di, *dq = nullptr;
+  KMI_TRY(ws_get(ctx, WS_OUTPUT, (size_t)nt * nw * sizeof(uint64_t), &dk));
+  KMI_TRY(ws_get(ctx, WS_OUTPUT2, (size_t)nt * sizeof(uint64_t), &di));
+  if (vw == 2 && idx->cfg.seq_format == KMI_FMT_FASTQ) KMI_TRY(ws_get(ctx, WS_INPUT2, (size_t)nt * sizeof(float) + 64, &dq));
+  KMI_TRY(extract_run(ctx, &idx->cfg, bytes_dev, n_bytes, file_offset, (uint64_t *)dk, (uint64_t *)di, (size_t)nt, false, true, &nt, &ns, (float *)dq));
+  return index_insert_records(idx, (const uint64_t *)dk, (size_t)nt, true, (const float *)dq, (const uint64_t *)di);
 }
 
 kmi_status kmi_index_build_host(kmi_index *idx, const uint8_t *bytes, size_t n_bytes, uint64_t file_offset) {
