@@ -3562,19 +3562,6 @@ kmi_status kmi_index_insert_host(kmi_index *idx, const uint64_t *kmers, size_t n
   return index_insert(idx, (const uint64_t *)din, n, true);
 }
 
-// records (key, id) of a FASTQ partition for the position index
-__global__ __launch_bounds__(256) void interleave_records_kernel(const uint64_t *__restrict__ keys, const uint64_t *__restrict__ ids,
-                                                                const float *__restrict__ quals, uint64_t n, uint32_t nw, uint32_t vw,
-                                                                uint64_t *__restrict__ recs) {
-  const uint32_t rw = nw + vw;
-  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
-    for (uint32_t w = 0; w < nw; ++w) recs[i * rw + w] = keys[i * nw + w];
-    recs[i * rw + nw] = ids[i];
-    // std::pair<id, float>: the float sits in the low half of the second word, padding above it is zero
-    if (vw > 1) recs[i * rw + nw + 1] = quals ? (uint64_t)__float_as_uint(quals[i]) : 0ull;
-  }
-}
-
 kmi_status kmi_index_set_seq_format(kmi_index *idx, uint32_t seq_format) {
   if (!idx) return KMI_ERR_INVALID;
   if (seq_format > KMI_FMT_FASTA) return set_err(idx->ctx, KMI_ERR_INVALID, "unknown sequence format");
