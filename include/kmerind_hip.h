@@ -194,7 +194,7 @@ kmi_status kmi_extract_route_dev(kmi_ctx *ctx, const kmi_config *cfg, const uint
 
 /* the same for the (k-mer, value) tuples of the position indexes (index_kind POSITION / POSQUAL): kmi_extract_records_dev +
  * kmi_route_tuples_dev in one call, records of n_words + value_words words grouped by destination rank in out_records_dev;
- * the records in file order never leave the workspace (read_file_* + imxx::distribute of Index::build_* with a multimap,
+ * the tuples in file order never leave the workspace (read_file_* + imxx::distribute of Index::build_* with a multimap,
  * kmer_index.hpp:148-225, distributed_unordered_map.hpp:1466-1515) */
 kmi_status kmi_extract_route_records_dev(kmi_ctx *ctx, const kmi_config *cfg, const uint8_t *bytes_dev, size_t n_bytes, uint64_t file_offset,
                                          uint32_t nranks, uint64_t *out_records_dev, size_t out_capacity, uint64_t *n_tuples,

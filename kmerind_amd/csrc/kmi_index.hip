@@ -3201,8 +3201,9 @@ static kmi_status read_rank_counts(kmi_ctx *ctx, const uint64_t *cnt_dev, uint32
 
 template <int NW, int BITS, int VW>
 static kmi_status route_vw(kmi_ctx *ctx, const kmi_config *cfg, KShape shape, const uint64_t *keys_dev, size_t n, uint32_t nranks,
-                           uint64_t *out_keys_dev, uint64_t *send_counts_host, const float *in_q = nullptr) {
-  // in_q (VW == 2): the input records are (key words, id), the quality word of record i is in_q[i] (scatter_range)
+                           uint64_t *out_keys_dev, uint64_t *send_counts_host, const float *in_q = nullptr, const uint64_t *in_v = nullptr) {
+  // in_q (VW == 2): the input records are (key words, id), the quality word of record i is in_q[i]; in_v: keys_dev holds the
+  // key words alone and in_v the ids (scatter_range)
   void *p;
   KMI_TRY(ws_get(ctx, WS_WGHIST, sizeof(uint32_t) * kPartGroups * kNumCoarse, &p)); uint32_t *wg_hist = (uint32_t *)p;
   KMI_TRY(ws_get(ctx, WS_CURSOR, sizeof(uint64_t) * kPartGroups * kNumCoarse, &p)); uint64_t *wg_off = (uint64_t *)p;
@@ -3214,7 +3215,7 @@ static kmi_status route_vw(kmi_ctx *ctx, const kmi_config *cfg, KShape shape, co
   {
     ProfScope ps(ctx, "hist_rank", n);
     hipLaunchKernelGGL((hist_rank_kernel<NW, BITS, VW>), dim3(kPartGroups), dim3(kPartThreads), 0, ctx->stream, keys_dev, (uint64_t)n, shape,
-                       cfg->strand, fn, wg_hist, (uint32_t)(NW + VW) - ((VW > 0 && in_q) ? 1u : 0u));
+                       cfg->strand, fn, wg_hist, (VW > 0 && in_v) ? (uint32_t)NW : (uint32_t)(NW + VW) - ((VW > 0 && in_q) ? 1u : 0u));
   }
   {
     ProfScope ps(ctx, "rank_offsets", nb);
@@ -3223,7 +3224,8 @@ static kmi_status route_vw(kmi_ctx *ctx, const kmi_config *cfg, KShape shape, co
   {
     ProfScope ps(ctx, "scatter_rank", n);
     hipLaunchKernelGGL((scatter_chunks_kernel<NW, BITS, VW>), dim3(kPartGroups), dim3(kPartThreads), 0, ctx->stream, keys_dev, (uint64_t)n,
-                       out_keys_dev, shape, cfg->strand, true, fn, (const uint64_t *)wg_off, (VW > 0) ? in_q : (const float *)nullptr);
+                       out_keys_dev, shape, cfg->strand, true, fn, (const uint64_t *)wg_off, (VW > 0) ? in_q : (const float *)nullptr,
+                       (VW > 0) ? in_v : (const uint64_t *)nullptr);
   }
   KMI_HIP(ctx, hipGetLastError());
   return read_rank_counts(ctx, cnt, nranks, fn.sub, send_counts_host);
@@ -3268,10 +3270,10 @@ static kmi_status route_impl(kmi_ctx *ctx, const kmi_config *cfg, KShape shape, 
 }
 
 template <int NW, int BITS>
-static kmi_status route_records_q(kmi_ctx *ctx, const kmi_config *cfg, KShape shape, const uint64_t *recs, size_t n, uint32_t nranks, const float *in_q,
-                                  uint64_t *out, uint64_t *send_counts_host) {
-  if (in_q) return route_vw<NW, BITS, 2>(ctx, cfg, shape, recs, n, nranks, out, send_counts_host, in_q);
-  return route_vw<NW, BITS, 1>(ctx, cfg, shape, recs, n, nranks, out, send_counts_host);
+static kmi_status route_records_q(kmi_ctx *ctx, const kmi_config *cfg, KShape shape, const uint64_t *keys, const uint64_t *ids, size_t n, uint32_t nranks,
+                                  const float *in_q, uint64_t *out, uint64_t *send_counts_host) {
+  if (in_q) return route_vw<NW, BITS, 2>(ctx, cfg, shape, keys, n, nranks, out, send_counts_host, in_q, ids);
+  return route_vw<NW, BITS, 1>(ctx, cfg, shape, keys, n, nranks, out, send_counts_host, nullptr, ids);
 }
 
 // read_file + the bucketing half of imxx::distribute in one go (FASTQ): keys of this rank's reads, transformed and
@@ -3461,8 +3463,8 @@ kmi_status kmi_extract_route_dev(kmi_ctx *ctx, const kmi_config *cfg, const uint
   KMI_DISPATCH(shape, extract_route_impl, ctx, cfg, shape, bytes_dev, n_bytes, nranks, out_keys_dev, out_capacity, n_tuples, n_seqs, send_counts_host);
 }
 
-// the tuples of the position indexes parsed and grouped by destination rank in one call: the records in file order stay in
-// the workspace as (k-mer, id) and the quality values as one dense float array, which the scatter by rank reads beside them
+// the tuples of the position indexes parsed and grouped by destination rank in one call: the tuples in file order stay in the
+// workspace as the parsers' k-mer, id and quality arrays, from which the scatter by rank gathers its records
 kmi_status kmi_extract_route_records_dev(kmi_ctx *ctx, const kmi_config *cfg, const uint8_t *bytes_dev, size_t n_bytes, uint64_t file_offset,
                                          uint32_t nranks, uint64_t *out_records_dev, size_t out_capacity, uint64_t *n_tuples, uint64_t *n_seqs,
                                          uint64_t *send_counts_host) {
@@ -3486,11 +3488,13 @@ kmi_status kmi_extract_route_records_dev(kmi_ctx *ctx, const kmi_config *cfg, co
   if (nt > out_capacity) return set_err(ctx, KMI_ERR_OVERFLOW, "extract_route_records: output capacity too small");
   const uint32_t nw = shape.n_words;
   const bool q = cfg->index_kind == KMI_INDEX_POSQUAL;
-  void *dr, *dq = nullptr;
-  KMI_TRY(ws_get(ctx, WS_INPUT2, (size_t)nt * (nw + 1) * sizeof(uint64_t), &dr));
-  if (q) KMI_TRY(ws_get(ctx, WS_OUTPUT2, (size_t)nt * sizeof(float) + 64, &dq));
-  KMI_TRY(extract_run(ctx, cfg, bytes_dev, n_bytes, file_offset, (uint64_t *)dr, nullptr, (size_t)nt, false, true, &nt, &ns, (float *)dq, nw + 1));
-  KMI_DISPATCH(shape, route_records_q, ctx, cfg, shape, (const uint64_t *)dr, (size_t)nt, nranks, (const float *)dq, out_records_dev, send_counts_host);
+  void *dk, *di, *dq = nullptr;
+  KMI_TRY(ws_get(ctx, WS_OUTPUT, (size_t)nt * nw * sizeof(uint64_t), &dk));
+  KMI_TRY(ws_get(ctx, WS_OUTPUT2, (size_t)nt * sizeof(uint64_t), &di));
+  if (q) KMI_TRY(ws_get(ctx, WS_INPUT2, (size_t)nt * sizeof(float) + 64, &dq));
+  KMI_TRY(extract_run(ctx, cfg, bytes_dev, n_bytes, file_offset, (uint64_t *)dk, (uint64_t *)di, (size_t)nt, false, true, &nt, &ns, (float *)dq));
+  KMI_DISPATCH(shape, route_records_q, ctx, cfg, shape, (const uint64_t *)dk, (const uint64_t *)di, (size_t)nt, nranks, (const float *)dq, out_records_dev,
+               send_counts_host);
 }
 
 kmi_status kmi_index_create(kmi_ctx *ctx, const kmi_config *cfg, kmi_index **out) {
