@@ -168,15 +168,20 @@ kmi_status kmi_ctx_create(int device, int rank, int nranks, void *stream, kmi_ct
   kmi_ctx *ctx = new kmi_ctx();
   if (const char *fp = getenv("KMI_FUSED_PATH")) ctx->fused_superkmer = strcmp(fp, "kmer") != 0;
   if (const char *dg = getenv("KMI_SK_DBG")) ctx->sk_dbg = atoi(dg);
+  if (const char *sm = getenv("KMI_SPARSE_MIN")) ctx->sparse_min = strtoull(sm, nullptr, 10);
   if (const char *fd = getenv("KMI_FORCE_DIST")) ctx->force_dist = atoi(fd) != 0;
   ctx->device = device; ctx->rank = rank; ctx->nranks = nranks; ctx->stream = (hipStream_t)stream;
-  if (hipMalloc((void **)&ctx->d_flags, sizeof(uint32_t) * 40) != hipSuccess ||
+  if (hipMalloc((void **)&ctx->d_flags, sizeof(uint32_t) * 64) != hipSuccess ||
       hipMalloc((void **)&ctx->d_totals, sizeof(uint64_t) * (16 + 256)) != hipSuccess ||
       hipHostMalloc((void **)&ctx->h_totals, sizeof(uint64_t) * 16, hipHostMallocDefault) != hipSuccess) {
     delete ctx;
     return KMI_ERR_DEVICE;
   }
-  (void)hipMemset(ctx->d_flags, 0, sizeof(uint32_t) * 40);
+  (void)hipMemset(ctx->d_flags, 0, sizeof(uint32_t) * 64);
+  {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) ctx->n_cus = (uint32_t)prop.multiProcessorCount;
+  }
   if (upload_quality_lut(ctx) != KMI_OK) { kmi_ctx_destroy(ctx); return KMI_ERR_DEVICE; }
   (void)hipMemset(ctx->d_totals, 0, sizeof(uint64_t) * (16 + 256));
   *out = ctx;

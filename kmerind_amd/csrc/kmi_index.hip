@@ -2191,14 +2191,15 @@ __global__ __launch_bounds__((QTabCfg<NW>::NT)) void bucket_query_kernel(int mod
                                                                        const uint64_t *__restrict__ idx_off, uint64_t *__restrict__ tmp_keys,
                                                                        uint64_t *__restrict__ tmp_vals64, uint32_t *__restrict__ tmp_vals32,
                                                                        uint32_t *__restrict__ out_cnt, uint32_t *__restrict__ flags,
-                                                                       bool emit_index) {
+                                                                       bool emit_index, const uint32_t *__restrict__ idx_cnt = nullptr) {
+  // idx_cnt (sparse index, count / find of a counting map only): bucket b holds idx_cnt[b] entries from idx_off[b]
   // emit_index (find on a counting map): the value of a hit is the entry's position in the index arrays instead of its count
   // (the de Bruijn node map gathers the node's edge counts from there)
   KMI_TABLE_LDS_CFG(NW, QTabCfg<NW>)
   constexpr int OW = VW ? VW : 1;
   const uint32_t b = blockIdx.x;
   const uint64_t qb = q_off[b], qe = q_off[b + 1];
-  const uint64_t ib = idx_off ? idx_off[b] : 0ull, ie = idx_off ? idx_off[b + 1] : 0ull;
+  const uint64_t ib = idx_off ? idx_off[b] : 0ull, ie = idx_off ? (idx_cnt ? ib + idx_cnt[b] : idx_off[b + 1]) : 0ull;
   // output slot base: count results are bounded by the bucket's queries; erase survivors and multimap
   // find hits by the bucket's entries
   const bool by_entries = (mode == Q_ERASE) || (VW > 0 && mode == Q_FIND);
@@ -2350,6 +2351,11 @@ struct kmi_index {
   uint64_t *mvals = nullptr;      // [n_entries * val_words] values (multimap)
   uint32_t val_words = 0;         // 0: counting map; 1: position id; 2: position id + quality
   uint64_t *bucket_off = nullptr; // [kNumFine + 1]
+  // SPARSE form (what a large super-k-mer build leaves: the reduce's output buffers as they are, no compaction pass): bucket b
+  // holds bucket_cnt[b] entries from bucket_off[b], with unused slots behind them; dense_off = the offsets the compacted
+  // arrays will have. Count / find read it as it is; everything else calls ensure_dense first.
+  uint32_t *bucket_cnt = nullptr; // [kNumFine]; null = dense (bucket b = [bucket_off[b], bucket_off[b + 1]))
+  uint64_t *dense_off = nullptr;  // [kNumFine + 1] (sparse form only)
   uint64_t n_entries = 0;
   bool has_data = false;
   uint32_t owner_lp = 0;          // the entries are this rank's share of a build over 2^owner_lp ranks by minimizer-bucket owner (sk_consume)
@@ -2365,6 +2371,7 @@ struct Partitioned;
 static kmi_status index_insert_pairs(kmi_index *idx, const uint64_t *recs_dev, size_t n, bool transform, bool distinct_in,
                                      Partitioned *part_out = nullptr);
 static kmi_status ensure_layout(kmi_index *idx, uint32_t target_w);
+static kmi_status ensure_dense(kmi_index *idx);
 static void free_index_arrays(kmi_index *idx);
 template <int NW>
 __global__ void zip_pairs_kernel(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ vals, uint64_t n, uint64_t *__restrict__ recs);
@@ -2471,7 +2478,9 @@ static kmi_status read_total(kmi_ctx *ctx, int slot, uint64_t *v) {
 // replace the index arrays by the compacted content of tmp
 template <int NW>
 static kmi_status adopt_tmp(kmi_index *idx, const uint64_t *tmp_keys, const uint32_t *tmp_vals, const uint64_t *src_a, const uint64_t *src_b,
-                            const uint32_t *out_cnt, bool fastq_verdict = false, uint64_t n_slots = 0) {
+                            const uint32_t *out_cnt, bool fastq_verdict = false, uint64_t n_slots = 0, bool allow_sparse = false) {
+  // allow_sparse (with n_slots, one-word keys): a large output is adopted as it lies -- bucket b = out_cnt[b] entries from src_a[b] --
+  // instead of being compacted now (kmi_index::bucket_cnt; ensure_dense does it when something needs dense arrays)
   // n_slots (the output slots of the reduce, when they start at 0 and src_b is null): a reduce that found every key distinct
   // filled all of them, so the workspace buffers ARE the index arrays -- they change owner instead of being copied
   kmi_ctx *ctx = idx->ctx;
@@ -2490,12 +2499,30 @@ static kmi_status adopt_tmp(kmi_index *idx, const uint64_t *tmp_keys, const uint
     (void)ws_detach(ctx, WS_TMP_KEYS, tmp_keys, &kb0);
     (void)ws_detach(ctx, WS_TMP_VALS, tmp_vals, &vb0);
     KMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    pool_free(ctx, idx->keys, idx->keys_bytes);
-    pool_free(ctx, idx->vals, idx->vals_bytes);
-    pool_free(ctx, idx->bucket_off, kOffBytes);
+    free_index_arrays(idx);
     idx->keys = const_cast<uint64_t *>(tmp_keys); idx->vals = const_cast<uint32_t *>(tmp_vals); idx->bucket_off = new_off;
     idx->n_entries = total; idx->has_data = true; idx->keys_bytes = kb0; idx->vals_bytes = vb0;
     return KMI_OK;
+  }
+  if (NW == 1 && allow_sparse && n_slots >= ctx->sparse_min && !src_b && ctx->ws[WS_TMP_KEYS].p == (const void *)tmp_keys &&
+      ctx->ws[WS_TMP_VALS].p == (const void *)tmp_vals) {
+    uint64_t *off = nullptr; uint32_t *cnt = nullptr;
+    hipError_t e1 = pool_alloc(ctx, (void **)&off, kOffBytes);
+    hipError_t e2 = pool_alloc(ctx, (void **)&cnt, sizeof(uint32_t) * kNumFine);
+    if (e1 == hipSuccess && e2 == hipSuccess) {
+      KMI_HIP(ctx, hipMemcpyAsync(off, src_a, kOffBytes, hipMemcpyDeviceToDevice, ctx->stream));
+      KMI_HIP(ctx, hipMemcpyAsync(cnt, out_cnt, sizeof(uint32_t) * kNumFine, hipMemcpyDeviceToDevice, ctx->stream));
+      size_t kb0 = 0, vb0 = 0;
+      (void)ws_detach(ctx, WS_TMP_KEYS, tmp_keys, &kb0);
+      (void)ws_detach(ctx, WS_TMP_VALS, tmp_vals, &vb0);
+      KMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      free_index_arrays(idx);
+      idx->keys = const_cast<uint64_t *>(tmp_keys); idx->vals = const_cast<uint32_t *>(tmp_vals); idx->bucket_off = off; idx->bucket_cnt = cnt;
+      idx->dense_off = new_off; idx->n_entries = total; idx->has_data = true; idx->keys_bytes = kb0; idx->vals_bytes = vb0;
+      return KMI_OK;
+    }
+    if (off) pool_free(ctx, off, kOffBytes);
+    if (cnt) pool_free(ctx, cnt, sizeof(uint32_t) * kNumFine);
   }
   uint64_t *nk = nullptr; uint32_t *nv = nullptr;
   const size_t kb = (total ? total : 1) * NW * sizeof(uint64_t), vb = (total ? total : 1) * sizeof(uint32_t);
@@ -2514,9 +2541,7 @@ static kmi_status adopt_tmp(kmi_index *idx, const uint64_t *tmp_keys, const uint
   }
   KMI_HIP(ctx, hipGetLastError());
   KMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  pool_free(ctx, idx->keys, idx->keys_bytes);
-  pool_free(ctx, idx->vals, idx->vals_bytes);
-  pool_free(ctx, idx->bucket_off, kOffBytes);
+  free_index_arrays(idx);
   idx->keys = nk; idx->vals = nv; idx->bucket_off = new_off; idx->n_entries = total; idx->has_data = true;
   idx->keys_bytes = kb; idx->vals_bytes = vb;
   return KMI_OK;
@@ -2755,12 +2780,21 @@ static kmi_status sk_back_end(kmi_index *idx, const uint64_t *rec_a, uint64_t R,
   {
     ProfScope ps(ctx, "sk_reduce", n);
     const uint32_t nmax = sk_nmax_of(k);
-#define KMI_SK_REDUCE(CANON, OWN)                                                                                                        \
-    hipLaunchKernelGGL((sk_reduce_kernel<CANON, OWN>), dim3(kNumFine), dim3(KMI_SK_NT), 0, ctx->stream, (const uint64_t *)rec_b,              \
-                       (const uint64_t *)fine_off, k, (const uint64_t *)kmer_off, tmp_keys, tmp_vals, out_cnt, ctx->d_flags, ctx->sk_dbg, ctx->sk_level_hint, lp, ctx->sk_inv_dup)
-    if (nmax <= 21u) { if (canonical) KMI_SK_REDUCE(true, 64 * 21); else KMI_SK_REDUCE(false, 64 * 21); }
-    else if (nmax <= 24u) { if (canonical) KMI_SK_REDUCE(true, 64 * 24); else KMI_SK_REDUCE(false, 64 * 24); }
-    else { if (canonical) KMI_SK_REDUCE(true, 64 * 32); else KMI_SK_REDUCE(false, 64 * 32); }
+    // persistent workgroups (one per CU: each takes the whole LDS) pull the buckets from a queue word
+    uint32_t *queue = ctx->d_flags + 40;
+    KMI_HIP(ctx, hipMemsetAsync(queue, 0, sizeof(uint32_t), ctx->stream));
+    const uint32_t wgs = ctx->n_cus ? ctx->n_cus : 256u;
+#define KMI_SK_REDUCE(CANON, OWN, SPECIAL)                                                                                               \
+    hipLaunchKernelGGL((sk_reduce_kernel<CANON, OWN, SPECIAL>), dim3(wgs), dim3(KMI_SK_NT), 0, ctx->stream, (const uint64_t *)rec_b,        \
+                       (const uint64_t *)fine_off, k, (const uint64_t *)kmer_off, tmp_keys, tmp_vals, out_cnt, ctx->d_flags, queue, (uint32_t)kNumFine, \
+                       ctx->sk_level_hint, lp, ctx->sk_inv_dup)
+    if (ctx->sk_dbg == 1 && canonical && nmax <= 21u)   // A/B: the one-workgroup-per-bucket form
+      hipLaunchKernelGGL((sk_reduce_v1_kernel<true, 64 * 21>), dim3(kNumFine), dim3(KMI_SK_NT), 0, ctx->stream, (const uint64_t *)rec_b,
+                         (const uint64_t *)fine_off, k, (const uint64_t *)kmer_off, tmp_keys, tmp_vals, out_cnt, ctx->d_flags, 0, ctx->sk_level_hint, lp, ctx->sk_inv_dup);
+    else if (k == 32u) { if (canonical) KMI_SK_REDUCE(true, 64 * 21, true); else KMI_SK_REDUCE(false, 64 * 21, true); }   // (a 32-mer can equal the empty marker)
+    else if (nmax <= 21u) { if (canonical) KMI_SK_REDUCE(true, 64 * 21, false); else KMI_SK_REDUCE(false, 64 * 21, false); }
+    else if (nmax <= 24u) { if (canonical) KMI_SK_REDUCE(true, 64 * 24, false); else KMI_SK_REDUCE(false, 64 * 24, false); }
+    else { if (canonical) KMI_SK_REDUCE(true, 64 * 32, false); else KMI_SK_REDUCE(false, 64 * 32, false); }
 #undef KMI_SK_REDUCE
   }
   KMI_HIP(ctx, hipGetLastError());
@@ -2786,7 +2820,7 @@ static kmi_status sk_back_end(kmi_index *idx, const uint64_t *rec_a, uint64_t R,
   if (!idx->has_data || idx->n_entries == 0) {
     // the index IS the reduce output: entries grouped by minimizer bucket. Queries partition their keys by the same function
     // (fine15_of_key); whatever needs the placement-hash layout converts the entries once (ensure_layout).
-    KMI_TRY((adopt_tmp<NW>(idx, tmp_keys, tmp_vals, kmer_off, nullptr, out_cnt, false, n)));
+    KMI_TRY((adopt_tmp<NW>(idx, tmp_keys, tmp_vals, kmer_off, nullptr, out_cnt, false, n, true)));
     idx->layout_w = layout;
     if (n) ctx->sk_inv_dup = (float)((double)idx->n_entries / (double)n);   // where the buckets of the next build start (sk_reduce_kernel)
     return KMI_OK;
@@ -2926,6 +2960,9 @@ static void free_index_arrays(kmi_index *idx) {
   pool_free(ctx, idx->vals, idx->vals_bytes);
   pool_free(ctx, idx->mvals, idx->mvals_bytes);
   pool_free(ctx, idx->bucket_off, kOffBytes);
+  if (idx->bucket_cnt) pool_free(ctx, idx->bucket_cnt, sizeof(uint32_t) * kNumFine);
+  if (idx->dense_off) pool_free(ctx, idx->dense_off, kOffBytes);
+  idx->bucket_cnt = nullptr; idx->dense_off = nullptr;
   idx->keys = nullptr; idx->vals = nullptr; idx->mvals = nullptr; idx->bucket_off = nullptr;
   idx->keys_bytes = idx->vals_bytes = idx->mvals_bytes = 0;
 }
@@ -2969,7 +3006,41 @@ static kmi_status relayout_impl(kmi_index *idx, uint32_t target_w) {
   return KMI_OK;
 }
 static kmi_status relayout_dispatch(kmi_index *idx, uint32_t target_w) { KMI_DISPATCH(idx->shape, relayout_impl, idx, target_w); }
+// sparse -> dense: the compaction pass the build left out (bucket_compact_kernel into arrays of exactly n_entries)
+template <int NW, int BITS>
+static kmi_status densify_impl(kmi_index *idx) {
+  kmi_ctx *ctx = idx->ctx;
+  const uint64_t total = idx->n_entries;
+  uint64_t *nk = nullptr; uint32_t *nv = nullptr;
+  const size_t kb = (total ? total : 1) * NW * sizeof(uint64_t), vb = (total ? total : 1) * sizeof(uint32_t);
+  hipError_t e1 = pool_alloc(ctx, (void **)&nk, kb);
+  hipError_t e2 = pool_alloc(ctx, (void **)&nv, vb);
+  if (e1 != hipSuccess || e2 != hipSuccess) {
+    if (nk) pool_free(ctx, nk, kb);
+    if (nv) pool_free(ctx, nv, vb);
+    return set_err(ctx, KMI_ERR_NOMEM, "hipMalloc failed for the index arrays");
+  }
+  {
+    ProfScope ps(ctx, "bucket_compact", total);
+    hipLaunchKernelGGL((bucket_compact_kernel<NW, uint32_t>), dim3(kNumFine), dim3(256), 0, ctx->stream, (const uint64_t *)idx->keys,
+                       (const uint32_t *)idx->vals, (const uint64_t *)idx->bucket_off, (const uint64_t *)nullptr, (const uint64_t *)idx->dense_off, nk, nv);
+  }
+  KMI_HIP(ctx, hipGetLastError());
+  KMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  pool_free(ctx, idx->keys, idx->keys_bytes);
+  pool_free(ctx, idx->vals, idx->vals_bytes);
+  pool_free(ctx, idx->bucket_off, kOffBytes);
+  pool_free(ctx, idx->bucket_cnt, sizeof(uint32_t) * kNumFine);
+  idx->keys = nk; idx->vals = nv; idx->bucket_off = idx->dense_off; idx->dense_off = nullptr; idx->bucket_cnt = nullptr;
+  idx->keys_bytes = kb; idx->vals_bytes = vb;
+  return KMI_OK;
+}
+static kmi_status ensure_dense(kmi_index *idx) {
+  if (!idx->bucket_cnt) return KMI_OK;
+  return densify_impl<1, 2>(idx);   // (only one-word 2-bit builds leave the sparse form)
+}
 static kmi_status ensure_layout(kmi_index *idx, uint32_t target_w) {
+  KMI_TRY(ensure_dense(idx));
   if (idx->layout_w == target_w) return KMI_OK;
   if (!idx->has_data || idx->n_entries == 0 || idx->val_words) { idx->layout_w = idx->val_words ? 0u : target_w; return KMI_OK; }
   return relayout_dispatch(idx, target_w);
@@ -3107,6 +3178,7 @@ static kmi_status query_vw(kmi_index *idx, int mode, const uint64_t *q_dev, size
   if (n_out) *n_out = 0;
   if (nq == 0) return KMI_OK;
   if (mode == Q_ERASE && !idx->has_data) return KMI_OK;
+  if (mode == Q_ERASE || VW > 0 || idx->find_emits_index) KMI_TRY(ensure_dense(idx));
   Partitioned part;
   KMI_TRY((partition_impl<NW, BITS>(ctx, &idx->cfg, idx->shape, q_dev, nq, true, WS_QUERY_A, WS_QUERY_B, &part, idx->has_data ? idx->layout_w : 0u)));
   void *p;
@@ -3120,7 +3192,7 @@ static kmi_status query_vw(kmi_index *idx, int mode, const uint64_t *q_dev, size
     hipLaunchKernelGGL((bucket_query_kernel<NW, VW>), dim3(kNumFine), dim3(QTabCfg<NW>::NT), 0, ctx->stream, mode, (const uint64_t *)part.keys,
                        (const uint64_t *)part.fine_off, (const uint64_t *)idx->keys, (const uint32_t *)idx->vals, (const uint64_t *)idx->mvals,
                        (const uint64_t *)(idx->has_data ? idx->bucket_off : nullptr), tmp_keys, (uint64_t *)tmp_vals, (uint32_t *)tmp_vals,
-                       out_cnt, ctx->d_flags, idx->find_emits_index && mode == Q_FIND && VW == 0);
+                       out_cnt, ctx->d_flags, idx->find_emits_index && mode == Q_FIND && VW == 0, (const uint32_t *)idx->bucket_cnt);
   }
   KMI_HIP(ctx, hipGetLastError());
   const uint64_t *src_off = (by_entries && idx->has_data) ? idx->bucket_off : part.fine_off;
@@ -3662,6 +3734,7 @@ kmi_status kmi_index_export_host(kmi_index *idx, uint64_t *keys, uint32_t *count
   if (idx->n_entries == 0) return KMI_OK;
   if (capacity < idx->n_entries) return set_err(ctx, KMI_ERR_OVERFLOW, "export: capacity too small");
   KMI_HIP(ctx, hipSetDevice(ctx->device));
+  KMI_TRY(ensure_dense(idx));
   if (keys) KMI_HIP(ctx, hipMemcpyAsync(keys, idx->keys, idx->n_entries * idx->shape.n_words * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
   if (counts) KMI_HIP(ctx, hipMemcpyAsync(counts, idx->vals, idx->n_entries * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
   KMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -3771,6 +3844,7 @@ kmi_status kmi_index_export_tuples_host(kmi_index *idx, uint64_t *keys, uint64_t
   if (idx->n_entries == 0) return KMI_OK;
   if (capacity < idx->n_entries) return set_err(ctx, KMI_ERR_OVERFLOW, "export: capacity too small");
   KMI_HIP(ctx, hipSetDevice(ctx->device));
+  KMI_TRY(ensure_dense(idx));
   if (keys) KMI_HIP(ctx, hipMemcpyAsync(keys, idx->keys, idx->n_entries * idx->shape.n_words * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
   if (values) KMI_HIP(ctx, hipMemcpyAsync(values, idx->mvals, idx->n_entries * idx->val_words * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
   KMI_HIP(ctx, hipStreamSynchronize(ctx->stream));

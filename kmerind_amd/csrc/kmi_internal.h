@@ -77,7 +77,8 @@ struct kmi_ctx {
   hipStream_t stream = nullptr;
   std::string err;
   struct Buf { void *p = nullptr; size_t cap = 0; } ws[kmi::WS_NUM_SLOTS];
-  uint32_t *d_flags = nullptr;   // [16] error / overflow flags
+  uint32_t *d_flags = nullptr;   // [64] error / overflow flags, pass-structure votes (16..33), work-queue words (40..)
+  uint32_t n_cus = 0;            // compute units of the device (grids of persistent workgroups)
   uint64_t *d_totals = nullptr;  // [16] small device scalars + [256] coarse-bucket totals of the fine-offset scan
   uint64_t *h_totals = nullptr;  // pinned mirror
   bool prof = false;
@@ -92,6 +93,7 @@ struct kmi_ctx {
   bool force_dist = false;       // KMI_FORCE_DIST=1: the *_dist_* entry points run their exchange even with one rank (RCCL self exchange: tests)
   uint32_t sk_level_hint = 0;    // sk_reduce: filter bits the buckets of the next build start with (majority of the last build)
   float sk_inv_dup = 0.f;        // sk_reduce: distinct k-mers per k-mer occurrence of the last build (a bucket's expected fill; 0: unknown)
+  uint64_t sparse_min = 1ull << 26;   // output slots from which a super-k-mer build leaves its index in the sparse form (KMI_SPARSE_MIN)
   int sk_dbg = 0;                // KMI_SK_DBG: timing experiments of sk_reduce (results are wrong when set)
   bool fa_part_set = false;      // kmi_ctx_set_fasta_partition
   kmi_fasta_partition fa_part{};

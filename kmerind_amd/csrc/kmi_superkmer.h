@@ -617,7 +617,7 @@ __device__ __attribute__((noinline)) uint32_t sk_probe_insert(lds_u64_t *tkeys, 
 }
 
 template <bool CANON, int OWN_>
-__global__ __launch_bounds__(KMI_SK_NT) void sk_reduce_kernel(const uint64_t *__restrict__ recs, const uint64_t *__restrict__ rec_off, uint32_t k,
+__global__ __launch_bounds__(KMI_SK_NT) void sk_reduce_v1_kernel(const uint64_t *__restrict__ recs, const uint64_t *__restrict__ rec_off, uint32_t k,
                                                         const uint64_t *__restrict__ kmer_off /* k-mers before every bucket */,
                                                         uint64_t *__restrict__ tmp_keys, uint32_t *__restrict__ tmp_vals,
                                                         uint32_t *__restrict__ out_cnt, uint32_t *__restrict__ flags, int dbg,
@@ -886,6 +886,346 @@ __global__ __launch_bounds__(KMI_SK_NT) void sk_reduce_kernel(const uint64_t *__
   if (threadIdx.x == 0) {
     out_cnt[b] = s_ctl[4];
     if (s_ctl[9] || start_bits) atomicAdd(&flags[16 + (s_ctl[9] > 8u ? 8u : s_ctl[9])], 1u);   // (level 0 is only recorded when someone could be misled)
+  }
+}
+
+
+// ---- sk_reduce (persistent form) -------------------------------------------------------------------------------------
+// The same two tables and the same expansion, organised so that nothing is paid per bucket that can be paid per workgroup:
+//  * one workgroup per CU stays resident and pulls fine buckets from a queue (one atomic per bucket, issued a bucket ahead);
+//  * the tables are cleared ONCE; afterwards the sweep that emits a pass's (k-mer, count) pairs leaves every slot it read
+//    empty, and phase B empties every record slot it expands -- a pass starts on clean tables without a clear of its own;
+//  * records that find no room in T1 go to a short overflow list and are expanded in phase B with everything else (the
+//    direct expansions inside phase A cost a whole expansion step for the two or three records of a batch that needed one);
+//  * the first records of the NEXT bucket are loaded before the emit sweep of the current one, so a bucket does not start
+//    with two dependent trips to HBM (its offsets, then its records).
+constexpr int kSkOvf = 192;   // overflow list entries (records that T1 did not take)
+template <int OWN_>
+struct SkTab2 {
+  static constexpr int NT = KMI_SK_NT, NWAVES = NT / kWave;
+  static constexpr int OWN = OWN_;
+  static constexpr int H1 = KMI_SK_H1, S1 = H1 + 64, L1 = H1 * 3 / 4;
+  static constexpr int FIXED = NWAVES * (OWN + kMissQ * 12) + S1 * 20 + kSkOvf * 16 + 2560;
+  static constexpr int S2 = ((KMI_SK_LDS_KB * 1024 - FIXED) / 12) / 64 * 64;
+  static constexpr int CAP2 = S2 - 64, LIMIT2 = CAP2 * KMI_SK_FILL / 100;
+};
+
+template <bool CANON, int OWN_, bool SPECIAL>
+__global__ __launch_bounds__(KMI_SK_NT) void sk_reduce_kernel(const uint64_t *__restrict__ recs, const uint64_t *__restrict__ rec_off, uint32_t k,
+                                                        const uint64_t *__restrict__ kmer_off /* k-mers before every bucket */,
+                                                        uint64_t *__restrict__ tmp_keys, uint32_t *__restrict__ tmp_vals,
+                                                        uint32_t *__restrict__ out_cnt, uint32_t *__restrict__ flags,
+                                                        uint32_t *__restrict__ queue /* zero at launch: the next bucket to hand out */, uint32_t n_buckets,
+                                                        uint32_t start_bits, uint32_t lp, float inv_dup) {
+  using T = SkTab2<OWN_>;
+  constexpr int NWAVES = T::NWAVES;
+  constexpr uint64_t W1_INIT = ~0ull;   // never a record's second word (its top three bits are zero)
+  enum { C_DIST = 0, C_OVF = 1, C_SPC = 2, C_SPS = 3, C_EMIT = 4, C_SP = 5, C_OVN = 6, C_T1N = 8, C_LVL = 9, C_NEXT = 10 /* and 11 */ };
+  __shared__ uint64_t s_tk[T::S2];
+  __shared__ uint32_t s_tv[T::S2];
+  __shared__ ulonglong2 s_r[T::S1];
+  __shared__ uint32_t s_rc[T::S1];
+  __shared__ ulonglong2 s_ovf[kSkOvf];
+  __shared__ uint64_t s_missq[NWAVES * kMissQ];
+  __shared__ uint32_t s_missw[NWAVES * kMissQ];
+  __shared__ uint8_t s_own[NWAVES * T::OWN];
+  __shared__ uint32_t s_ctl[12];
+  __shared__ uint32_t s_stack[320];
+  const uint32_t lane = lane_id(), wv = wave_id();
+  lds_u64_t *const tkeys = (lds_u64_t *)s_tk;
+  lds_u32_t *const tvals = (lds_u32_t *)s_tv;
+  lds_u32_t *const tdist = (lds_u32_t *)&s_ctl[C_DIST];
+  lds_u32_t *const tovf = (lds_u32_t *)&s_ctl[C_OVF];
+  uint64_t *const mq = s_missq + wv * kMissQ;
+  uint32_t *const mw = s_missw + wv * kMissQ;
+  uint8_t *const wown = s_own + wv * T::OWN;
+  const uint32_t kb = 2u * k;                                   // 34 .. 64
+  const uint32_t kmask_hi = kb >= 64u ? 0xffffffffu : ((1u << (kb - 32u)) - 1u);
+  const uint32_t pad = 64u - kb;                                // 0 .. 30
+  const bool use_t1_known = inv_dup > 0.f;
+  // ---- once per workgroup: clean tables, clean marks, the first bucket
+  for (uint32_t i = threadIdx.x; i < (uint32_t)(NWAVES * T::OWN / 4); i += T::NT) reinterpret_cast<uint32_t *>(s_own)[i] = 0;
+  for (uint32_t i = threadIdx.x; i < (uint32_t)T::S2; i += T::NT) { s_tk[i] = kEmptyKey; s_tv[i] = 0; }
+  for (uint32_t i = threadIdx.x; i < (uint32_t)T::S1; i += T::NT) { s_r[i] = make_ulonglong2(kEmptyKey, W1_INIT); s_rc[i] = 0; }
+  if (threadIdx.x < 12) s_ctl[threadIdx.x] = 0;
+  if (threadIdx.x == 0) s_ctl[C_NEXT] = atomicAdd(queue, 1u);
+  lds_barrier();
+  uint32_t b = __builtin_amdgcn_readfirstlane(s_ctl[C_NEXT]);
+  uint32_t par = 1;                      // which of the two "next bucket" words this bucket publishes
+  bool pf_ok = false;                    // pf / pf_rb / pf_re hold the start of bucket b
+  ulonglong2 pf = make_ulonglong2(0, 0);
+  uint64_t pf_rb = 0, pf_re = 0, pf_k0 = 0, pf_k1 = 0;
+  // all k-mers of a batch of records (w0, w1, weight wt; n = 0: none) into the k-mer table
+  uint32_t mn = 0, pending = 0, my_claims = 0, hbits = 0, hmask = 0, hval = 0;
+  auto expand = [&](uint64_t w0, uint64_t w1, uint32_t wt, uint32_t n) {
+    const uint32_t inc = wave_inclusive_sum_dpp(n);
+    const uint32_t pre = inc - n;
+    const uint32_t total = __builtin_amdgcn_readlane(inc, kWave - 1);
+    if (total == 0u) return;   // uniform
+    if (n) wown[pre] = (uint8_t)(lane + 1u);
+    uint32_t carry = 0;   // record (+ 1) the previous step ended in
+    for (uint32_t g0 = 0; g0 < total; g0 += kWave) {
+      const uint32_t g = g0 + lane;
+      const bool act = g < total;
+      uint32_t o = act ? (uint32_t)wown[g] : 0u;
+      o = wave_inclusive_max_dpp(o);
+      o = o > carry ? o : carry;
+      carry = __builtin_amdgcn_readlane(o, kWave - 1);
+      const int rl = (int)((o ? o - 1u : 0u) << 2);   // byte address of the lane that holds the record
+      const uint32_t j = g - (uint32_t)__builtin_amdgcn_ds_bpermute(rl, (int)pre);
+      const uint32_t a0 = (uint32_t)__builtin_amdgcn_ds_bpermute(rl, (int)(uint32_t)w0), a1 = (uint32_t)__builtin_amdgcn_ds_bpermute(rl, (int)(uint32_t)(w0 >> 32));
+      const uint32_t a2 = (uint32_t)__builtin_amdgcn_ds_bpermute(rl, (int)(uint32_t)w1), a3 = (uint32_t)__builtin_amdgcn_ds_bpermute(rl, (int)(uint32_t)(w1 >> 32));
+      const uint32_t kw = (uint32_t)__builtin_amdgcn_ds_bpermute(rl, (int)wt);
+      // k-mer j of the record: 2 k bits from bit 2 j of its 128 (j <= 31: the window starts in word 0 or 1). All of it on 32-bit
+      // registers -- funnel shifts (v_alignbit) and single-word bit tricks: the 64-bit shifts this replaces issue at a quarter
+      // of the rate, and the kernel is bound by instruction issue.
+      const bool w1sel = j >= 16u;
+      const uint32_t bit = (2u * j) & 31u;
+      const uint32_t b0 = w1sel ? a1 : a0, b1 = w1sel ? a2 : a1, b2 = w1sel ? a3 : a2;
+      const uint32_t rc_lo = __builtin_amdgcn_alignbit(b1, b0, bit);
+      const uint32_t rc_hi = __builtin_amdgcn_alignbit(b2, b1, bit) & kmask_hi;   // (k >= 17: the low word is all k-mer)
+      // forward strand = reverse complement of that: bit-reverse the 64 bits (the words change places), swap the two bits of
+      // every base back, complement, and bring the 2 k bits down from the top (the complemented pad bits fall off below)
+      const uint32_t r_hi = __builtin_bitreverse32(rc_lo), r_lo = __builtin_bitreverse32(rc_hi);
+      const uint32_t s_hi = ~(((r_hi >> 1) & 0x55555555u) | ((r_hi << 1) & 0xAAAAAAAAu));
+      const uint32_t s_lo = ~(((r_lo >> 1) & 0x55555555u) | ((r_lo << 1) & 0xAAAAAAAAu));
+      const uint32_t fw_lo = __builtin_amdgcn_alignbit(s_hi, s_lo, pad), fw_hi = s_hi >> pad;
+      const uint64_t rc = (uint64_t)rc_lo | ((uint64_t)rc_hi << 32), fw = (uint64_t)fw_lo | ((uint64_t)fw_hi << 32);
+      const uint64_t key = CANON ? (fw < rc ? fw : rc) : fw;
+      // table fast path: the home slot and the one behind it in one read
+      const uint32_t h = sk_slot_hash(key);
+      const uint32_t slot = sk_slot_of(h, (uint32_t)T::CAP2);
+      bool v = act && (h & hmask) == hval;   // (the pass's share of the hash space: mask 0 / value 0 takes everything; the slot comes from the high bits)
+      if (SPECIAL && v && key == kEmptyKey) { s_ctl[C_SPS] = 1; atomicAdd(&s_ctl[C_SPC], kw); v = false; }   // (k = 32 only)
+      const uint64_t c0 = __atomic_load_n(&s_tk[slot], __ATOMIC_RELAXED), c1 = __atomic_load_n(&s_tk[slot + 1u], __ATOMIC_RELAXED);
+      bool hit0 = v && c0 == key;
+      const bool hit1 = v && c1 == key;
+      bool won = false;
+      if (v && c0 == kEmptyKey) {   // first sighting with a free home slot: claimed here, in line (most first sightings are)
+        const unsigned long long old = atomicCAS((unsigned long long *)&s_tk[slot], (unsigned long long)kEmptyKey, (unsigned long long)key);
+        won = old == kEmptyKey;
+        hit0 = won || old == key;
+      }
+      my_claims += won ? 1u : 0u;   // (per lane; the wavefront adds them up once per batch)
+      if (hit0 || hit1) atomicAdd(&s_tv[slot + (hit0 ? 0u : 1u)], kw);
+      const bool miss = v && !hit0 && !hit1;
+      const unsigned long long mm = __ballot(miss);
+      if (mm) {
+        const uint32_t pos = mn + __builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0u));
+        if (miss) { mq[pos] = key; mw[pos] = kw; }
+        mn += (uint32_t)__popcll(mm);
+        if (mn >= (uint32_t)kWave) {
+          pending = sk_probe_insert(tkeys, tvals, tdist, tovf, (const lds_u64_t *)mq, (const lds_u32_t *)mw, mn - kWave, kWave, (uint32_t)T::CAP2,
+                                    (uint32_t)T::S2 - 1u, (uint32_t)T::LIMIT2, pending);
+          mn -= kWave;
+        }
+      }
+    }
+    if (n) wown[pre] = 0;   // the marks go back to zero for the next batch
+    // fill level: this batch's in-line claims go to the shared counter (one scan + one LDS add per batch of records)
+    const uint32_t batch_claims = __builtin_amdgcn_readlane(wave_inclusive_sum_dpp(my_claims), kWave - 1);
+    my_claims = 0;
+    pending += batch_claims;
+    if (pending >= 32u) {   // uniform
+      if (lane == 0 && atomicAdd(&s_ctl[C_DIST], pending) + pending >= (uint32_t)T::LIMIT2) s_ctl[C_OVF] = 1;
+      pending = 0;
+    }
+  };
+  while (b < n_buckets) {   // uniform
+    uint32_t q_next = 0;
+    if (threadIdx.x == 0) q_next = atomicAdd(queue, 1u);   // (stays in a register until phase A is done: nobody waits for it)
+    const uint64_t rb = pf_ok ? pf_rb : rec_off[b], re = pf_ok ? pf_re : rec_off[b + 1];
+    const uint32_t n_rec = (uint32_t)(re - rb);
+    const ulonglong2 *const src = reinterpret_cast<const ulonglong2 *>(recs) + rb;
+    const uint32_t share = (n_rec + NWAVES - 1) / NWAVES;
+    const uint32_t r_lo = wv * share < n_rec ? wv * share : n_rec;
+    const uint32_t r_hi = r_lo + share < n_rec ? r_lo + share : n_rec;
+    ulonglong2 first = pf;
+    if (!pf_ok) { first = make_ulonglong2(0, 0); if (r_lo + lane < r_hi) first = src[r_lo + lane]; }
+    const uint64_t tmp0 = pf_ok ? pf_k0 : kmer_off[b], tmp1 = pf_ok ? pf_k1 : kmer_off[b + 1];
+    pf_ok = false;
+    if (threadIdx.x == 0) {
+      uint32_t hb = start_bits > 8u ? 8u : start_bits;
+      if (use_t1_known && n_rec) {
+        // a bucket expected above 88 % of what a pass takes starts one level down (a lost attempt costs a whole pass, and the
+        // buckets that overflow are the large ones)
+        const float pred = (float)(tmp1 - tmp0) * inv_dup;
+        float room = 0.88f * (float)T::LIMIT2 * (float)(1u << hb);
+        while (hb < 8u && pred > room) { ++hb; room *= 2.f; }
+      }
+      const uint32_t np = n_rec ? (1u << hb) : 0u;
+      for (uint32_t v = 0; v < np; ++v) s_stack[v] = hb | (v << 8);
+      s_ctl[C_SP] = np; s_ctl[C_EMIT] = 0; s_ctl[C_LVL] = hb;
+    }
+    bool first_pass = true;
+    lds_barrier();
+    while (true) {
+      const uint32_t sp = s_ctl[C_SP];
+      if (sp == 0) break;                       // uniform
+      const uint32_t pass = s_stack[sp - 1];
+      const uint32_t fbits = pass & 0xffu, fval = pass >> 8;
+      lds_barrier();                            // everyone has read the stack
+      if (threadIdx.x == 0) s_ctl[C_SP] = sp - 1;
+      const bool use_t1 = use_t1_known ? inv_dup <= KMI_SK_T1_DUP : fbits < 2u;
+      // the first three filter bits (two in a build over 8 ranks) are the records' sub-bucket bits (whole records are skipped), the
+      // others come from the key's hash
+      const uint32_t dead = lp > 2u ? lp - 2u : 0u, rmax = 3u - dead;
+      const uint32_t rbits = fbits < rmax ? fbits : rmax, rmask = ((1u << rbits) - 1u) << dead, rval = (fval & ((1u << rbits) - 1u)) << dead;
+      hbits = fbits - rbits; hmask = (1u << hbits) - 1u; hval = fval >> rbits;
+      mn = 0; pending = 0; my_claims = 0;
+      // ---- phase A: identical records are counted; what T1 does not take waits in the overflow list
+      {
+        ulonglong2 nxt = first;
+        if (!first_pass) { nxt = make_ulonglong2(0, 0); if (r_lo + lane < r_hi) nxt = src[r_lo + lane]; }
+        for (uint32_t r0 = r_lo; r0 < r_hi; r0 += kWave) {
+          if (__atomic_load_n(&s_ctl[C_OVF], __ATOMIC_RELAXED)) break;   // this pass is lost already
+          const ulonglong2 rec = nxt;
+          const bool have = r0 + lane < r_hi;
+          if (r0 + kWave + lane < r_hi) nxt = src[r0 + kWave + lane];   // in flight while this batch is worked on
+          uint32_t n = have ? ((uint32_t)(rec.y >> kRecNShift) & 31u) + 1u : 0u;
+          if ((rec_hash18(rec.y) & rmask) != rval) n = 0;
+          bool direct = n != 0u;   // still to be placed
+          if (use_t1) {
+            if (direct && rec.x != kEmptyKey) {
+              // four consecutive slots in one go (independent reads): the first that holds this record takes the count, else the
+              // first empty one is claimed; a second window of four for the few that find the first one taken
+              uint32_t h = ((uint32_t)rec.x ^ (uint32_t)(rec.x >> 32)) * 0x9E3779B1u ^ ((uint32_t)rec.y ^ (uint32_t)(rec.y >> 32)) * 0x85EBCA6Bu;
+              h ^= h >> 15;
+              const uint32_t s0 = ((h >> 16) * (uint32_t)T::H1) >> 16;   // H1 home slots (+ 64 of padding)
+              for (uint32_t s = s0; direct && s < s0 + 8u; s += 4u) {
+                ulonglong2 e[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) e[i] = s_r[s + i];
+                int hit = -1, free_ = -1;
+#pragma unroll
+                for (int i = 3; i >= 0; --i) {
+                  const bool same = e[i].x == rec.x && e[i].y == rec.y, empty = e[i].x == kEmptyKey;
+                  if (same) { hit = i; free_ = -1; } else if (empty) { free_ = i; hit = -1; }   // (the earliest of either kind wins)
+                }
+                if (hit >= 0) { atomicAdd(&s_rc[s + hit], 1u); direct = false; }
+                else if (free_ >= 0) {
+                  if (__atomic_load_n(&s_ctl[C_T1N], __ATOMIC_RELAXED) >= (uint32_t)T::L1) break;   // full enough
+                  const unsigned long long old = atomicCAS((unsigned long long *)&s_r[s + free_].x, (unsigned long long)kEmptyKey, (unsigned long long)rec.x);
+                  if (old == kEmptyKey) {   // claimed
+                    __atomic_store_n(&s_r[s + free_].y, rec.y, __ATOMIC_RELAXED);
+                    atomicAdd(&s_rc[s + free_], 1u);
+                    atomicAdd(&s_ctl[C_T1N], 1u);
+                    direct = false;
+                  } else if (old == rec.x && __atomic_load_n(&s_r[s + free_].y, __ATOMIC_RELAXED) == rec.y) {
+                    // lost the slot to a copy of the same record that arrived in the same step: counted with it
+                    atomicAdd(&s_rc[s + free_], 1u);
+                    direct = false;
+                  } else break;   // lost it to another record
+                }
+              }
+            }
+            if (direct) {   // the overflow list takes it (phase B expands it with weight 1)
+              const uint32_t oi = atomicAdd(&s_ctl[C_OVN], 1u);
+              if (oi < (uint32_t)kSkOvf) { s_ovf[oi] = rec; direct = false; }
+            }
+          }
+          if (__any(direct)) expand(rec.x, rec.y, 1u, direct ? n : 0u);
+        }
+      }
+      if (first_pass && threadIdx.x == 0) s_ctl[C_NEXT + par] = q_next;
+      lds_barrier();   // T1 and the overflow list complete; the next bucket is known
+      uint32_t nbk = 0;
+      if (first_pass) {   // the next bucket's range: two scalar loads that return during phase B
+        nbk = __builtin_amdgcn_readfirstlane(s_ctl[C_NEXT + par]);
+        if (nbk < n_buckets) { pf_rb = rec_off[nbk]; pf_re = rec_off[nbk + 1]; pf_k0 = kmer_off[nbk]; pf_k1 = kmer_off[nbk + 1]; }
+      }
+      // ---- phase B: every distinct record once with its multiplicity, then the overflow list; the slots are left empty
+      if (use_t1) {
+        const uint32_t n_ovf = s_ctl[C_OVN] < (uint32_t)kSkOvf ? s_ctl[C_OVN] : (uint32_t)kSkOvf;
+        for (uint32_t s0 = wv * kWave; s0 < (uint32_t)T::S1 + n_ovf; s0 += T::NT) {
+          const uint32_t s = s0 + lane;
+          uint64_t w0 = kEmptyKey, w1 = 0; uint32_t wt = 0;
+          if (s < (uint32_t)T::S1) {
+            const ulonglong2 ent = s_r[s];
+            w0 = ent.x; w1 = ent.y; wt = s_rc[s];
+            if (w0 != kEmptyKey) { s_r[s] = make_ulonglong2(kEmptyKey, W1_INIT); s_rc[s] = 0; }
+          } else if (s - (uint32_t)T::S1 < n_ovf) {
+            const ulonglong2 ent = s_ovf[s - (uint32_t)T::S1];
+            w0 = ent.x; w1 = ent.y; wt = 1u;
+          }
+          uint32_t n = wt ? ((uint32_t)(w1 >> kRecNShift) & 31u) + 1u : 0u;
+          if (__atomic_load_n(&s_ctl[C_OVF], __ATOMIC_RELAXED)) n = 0;   // lost pass: the sweep goes on only to empty the slots
+          if (__any(n != 0u)) expand(w0, w1, wt, n);
+        }
+      }
+      if (mn) {
+        pending = sk_probe_insert(tkeys, tvals, tdist, tovf, (const lds_u64_t *)mq, (const lds_u32_t *)mw, 0u, mn, (uint32_t)T::CAP2, (uint32_t)T::S2 - 1u,
+                                  (uint32_t)T::LIMIT2, pending);
+        mn = 0;
+      }
+      if (pending && lane == 0 && atomicAdd(&s_ctl[C_DIST], pending) + pending >= (uint32_t)T::LIMIT2) s_ctl[C_OVF] = 1;
+      if (first_pass && nbk < n_buckets) {   // the next bucket's first records, in flight during the emit sweep
+        const uint32_t nn = (uint32_t)(pf_re - pf_rb), nshare = (nn + NWAVES - 1) / NWAVES;
+        const uint32_t nlo = wv * nshare < nn ? wv * nshare : nn, nhi = nlo + nshare < nn ? nlo + nshare : nn;
+        pf = make_ulonglong2(0, 0);
+        if (nlo + lane < nhi) pf = reinterpret_cast<const ulonglong2 *>(recs)[pf_rb + nlo + lane];
+        pf_ok = true;
+      }
+      first_pass = false;
+      lds_barrier();
+      const bool lost = s_ctl[C_OVF] != 0u;
+      lds_barrier();   // everyone has read the verdict (the resets below overwrite it)
+      if (threadIdx.x == 0) { s_ctl[C_DIST] = 0; s_ctl[C_OVF] = 0; s_ctl[C_T1N] = 0; s_ctl[C_OVN] = 0; }
+      if (lost) {
+        // Overflow: this pass is split -- straight to the level most buckets of this build ended at (flags[16 + L] counts the
+        // buckets that finished with L filter bits) instead of one bit at a time. The table is emptied without being read.
+        for (uint32_t i = threadIdx.x; i < (uint32_t)T::S2; i += T::NT) { s_tk[i] = kEmptyKey; s_tv[i] = 0; }
+        if (threadIdx.x == 0) {
+          s_ctl[C_SPC] = 0; s_ctl[C_SPS] = 0;
+          if (fbits >= 18u) atomicOr(&flags[2], 1u);   // 3 record bits + 15 hash bits: 2^18 tables did not hold the bucket
+          else {
+            uint32_t best = 0, best_n = 0;
+            for (uint32_t l = 0; l <= 8u; ++l) {
+              const uint32_t c = __hip_atomic_load(&flags[16 + l], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              if (c > best_n) { best_n = c; best = l; }
+            }
+            uint32_t target = best > fbits ? best : fbits + 1u;
+            if (target > fbits + 6u) target = fbits + 6u;     // (64 children at most at a time: the stack holds 320)
+            uint32_t spn = s_ctl[C_SP];
+            for (uint32_t v = 0; v < (1u << (target - fbits)); ++v) s_stack[spn++] = target | ((fval | (v << fbits)) << 8);
+            s_ctl[C_SP] = spn;
+            if (target > s_ctl[C_LVL]) s_ctl[C_LVL] = target;
+          }
+        }
+        lds_barrier();
+        continue;
+      }
+      // emit behind what the earlier passes left (disjoint key sets); every slot read is left empty
+      {
+        uint32_t *s_out = &s_ctl[C_EMIT];
+        for (uint32_t s = threadIdx.x; s < (uint32_t)((T::S2 + kWave - 1) / kWave * kWave); s += T::NT) {
+          uint64_t key = kEmptyKey; uint32_t val = 0;
+          if (s < (uint32_t)T::S2) { key = s_tk[s]; val = s_tv[s]; }
+          const bool used = key != kEmptyKey;
+          const uint32_t pos = wave_alloc(s_out, used);
+          if (used) { tmp_keys[tmp0 + pos] = key; tmp_vals[tmp0 + pos] = val; s_tk[s] = kEmptyKey; s_tv[s] = 0; }
+        }
+        lds_barrier();
+        if (threadIdx.x == 0) {
+          if (s_ctl[C_SPS]) {
+            const uint32_t pos = atomicAdd(s_out, 1u);
+            tmp_keys[tmp0 + pos] = kEmptyKey;
+            tmp_vals[tmp0 + pos] = s_ctl[C_SPC];
+          }
+          s_ctl[C_SPC] = 0; s_ctl[C_SPS] = 0;
+          s_tv[T::S2 - 1] = 0;   // (the parking slot of lost walks never holds a key; its count is dropped here)
+        }
+      }
+      lds_barrier();
+    }
+    if (threadIdx.x == 0) {
+      out_cnt[b] = s_ctl[C_EMIT];
+      if (n_rec && (s_ctl[C_LVL] || start_bits)) atomicAdd(&flags[16 + (s_ctl[C_LVL] > 8u ? 8u : s_ctl[C_LVL])], 1u);
+    }
+    if (n_rec == 0u && threadIdx.x == 0) s_ctl[C_NEXT + par] = q_next;   // (an empty bucket never reached the pass loop)
+    lds_barrier();   // everyone has left the pass loop (the next bucket's set-up rewrites the stack words)
+    b = __builtin_amdgcn_readfirstlane(s_ctl[C_NEXT + par]);
+    par ^= 1u;
   }
 }
 

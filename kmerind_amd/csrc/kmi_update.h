@@ -99,6 +99,7 @@ static kmi_status update_pairs_impl(kmi_index *idx, uint64_t *recs_dev, size_t n
   kmi_ctx *ctx = idx->ctx;
   *n_updated = 0;
   if (n == 0 || !idx->has_data || idx->n_entries == 0) return KMI_OK;   // (this->empty(): nothing to update)
+  KMI_TRY(ensure_dense(idx));
   if (op == KMI_UPDATE_ASSIGN) {
     if (n >> 32) return set_err(ctx, KMI_ERR_INVALID, "update(assign): at most 2^32 - 1 pairs per call (their order rides in the record)");
     hipLaunchKernelGGL((update_tag_order_kernel<NW>), dim3(2048), dim3(256), 0, ctx->stream, recs_dev, (uint64_t)n);

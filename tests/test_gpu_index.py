@@ -632,6 +632,55 @@ def test_superkmer_build_ran_and_matches_oracle(ctx, k, strand):
     idx.close()
 
 
+@pytest.mark.parametrize("k,strand", [(31, "canonical"), (23, "single")])
+def test_sparse_index_after_superkmer_build(monkeypatch, k, strand):
+    """A large super-k-mer build leaves the reduce's output buffers as the index (per-bucket start + count, unused slots behind
+    every bucket: no compaction pass); count and find read that form, everything else makes it dense first. KMI_SPARSE_MIN=1
+    forces the form on a small input: same answers before and after, same map, and the dense paths (insert, erase) still work."""
+    import kmerind_amd as K
+    monkeypatch.setenv("KMI_SPARSE_MIN", "1")
+    c2 = K.Context(0)
+    s = orc.kspec(k, orc.DNA)
+    data = K.synth_fastq(seed=5 * k, genome_len=40_000, n_reads=5_000)
+    kmers = orc.extract(s, data, orc.FASTQ)["kmers"]
+    om = orc.CountMap(s, STRAND[strand])
+    om.insert(kmers)
+    idx = K.CountIndex(c2, K.make_config(k, "DNA", strand=strand))
+    c2.profile(True)
+    c2.profile_reset()
+    idx.build(data)
+    names = {p["name"] for p in c2.profile_get() if p["launches"]}
+    assert "sk_reduce" in names and "bucket_compact" not in names, names      # no compaction inside the build
+    assert idx.local_size() == om.export()[0].shape[0]
+    rng = np.random.default_rng(k)
+    q = np.concatenate([kmers[rng.integers(0, kmers.shape[0], 3000)], rng.integers(0, 1 << 62, (500, 1), dtype=np.uint64) & np.uint64((1 << (2 * k)) - 1 if k < 32 else 0xFFFFFFFFFFFFFFFF)])
+    for fn, ofn in ((idx.count, om.count), (idx.find, om.find)):
+        gk, gv = fn(q)
+        ek, ev = ofn(q)
+        a, b = orc.sorted_pairs(gk, gv), orc.sorted_pairs(ek, ev.astype(np.uint64))
+        assert a[0].shape == b[0].shape and (a[0] == b[0]).all() and (a[1] == b[1]).all()
+    _same_map(idx, om)                                                         # to_vector: the index is made dense here
+    gk, gv = idx.count(q)                                                      # and answers the same afterwards
+    ek, ev = om.count(q)
+    a, b = orc.sorted_pairs(gk, gv), orc.sorted_pairs(ek, ev.astype(np.uint64))
+    assert (a[0] == b[0]).all() and (a[1] == b[1]).all()
+    idx.clear()
+    idx.build(data)                                                            # sparse again ...
+    idx.insert(kmers[:1000])                                                   # ... and an insert into it
+    om.insert(kmers[:1000])
+    _same_map(idx, om)
+    idx.clear()
+    idx.build(data)
+    idx.erase(kmers[:500])                                                     # erase from the sparse form
+    om2 = orc.CountMap(s, STRAND[strand])
+    om2.insert(kmers)
+    om2.erase(kmers[:500])
+    _same_map(idx, om2)
+    c2.profile(False)
+    idx.close()
+    c2.close()
+
+
 def test_kmer_pipeline_still_selectable(monkeypatch):
     """KMI_FUSED_PATH=kmer at context creation keeps the fused build on the k-mer pipeline (the fall-back of the super-k-mer
     path when a run or a tile exceeds its item capacity): same index."""
