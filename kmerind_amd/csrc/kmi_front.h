@@ -1,0 +1,494 @@
+// kmi_front.h -- the FASTQ front end of the super-k-mer build in ONE pass over the input bytes (included by kmi_index.hip).
+//
+// What it replaces: fastq_scan_tiles (classify every byte, EOL bitmap, packed stream), fastq_scan_offsets (line bases),
+// fastq_list (runs of k-mer windows per tile) and sk_minimizer (the walk) -- i.e. FASTQParser::get_next_record
+// (fastq_loader.hpp:389-467) + KmerParser's window loop (kmer_parser.hpp:85-294) of the reference, in the formulation of
+// kmi_extract.hip: a line is a maximal run of non-EOL bytes and line index % 4 is its role. Those four kernels spent 3.1 of the
+// build's 9 ms issuing instructions on bytes that never become k-mers: every byte was classified into a 2-bit code although 52 %
+// of a record are header, '+' and quality, and the line bookkeeping went through three passes over bitmaps.
+//
+// Here every WAVEFRONT owns a byte range and runs on its own (no workgroup barrier in the kernel):
+//   produce   64 lanes x 32 bytes: EOL bits only (SWAR), line starts / ends ranked with one DPP scan, their positions into two
+//             small rings in LDS; complete lines get their role from the line index; sequence lines become runs of windows
+//   consume   as soon as 64 runs wait: one lane per run loads the read's own bytes, packs THEM (and nothing else) into 2-bit
+//             complement codes -- the run's row, kept for the scatter pass -- and walks the minimizers exactly as
+//             sk_minimizer did (rolling canonical m-mer, order hash, sliding minimum over W positions)
+// The line index of a range's first line is INFERRED (first line that starts with '@' whose second successor starts with '+':
+// the reference's own find_first_record idea, fastq_loader.hpp:269-364) and the ranges are chained afterwards (front_verify):
+// the index of range r + 1 must be that of range r plus its lines. Anything the fast path is not sure about -- a marker that
+// is not where the role says, sequence and quality lines of different length, an inference without exactly one candidate, a
+// chain that does not close, a capacity exceeded -- raises ONE flag and the caller runs the general path (fastq_scan + list +
+// minimizer), which also words the error. So this path is exact on well-formed input and silent on everything else.
+#pragma once
+
+namespace kmi {
+
+constexpr int kFrWaves = 4, kFrThreads = kFrWaves * kWave;
+constexpr uint32_t kFrRing = 256;        // line events a wavefront keeps (power of two); a 2 KB step may add half of it
+constexpr uint32_t kFrRunQ = 256;        // waiting runs (power of two): 64 are taken at a time, a step adds at most 128
+constexpr uint32_t kFrStep = 2048;       // bytes per produce step: 64 lanes x 32
+constexpr uint32_t kFrRowDw = 12;        // a run's packed row: 192 bases (a run holds at most 128 + 31)
+constexpr uint32_t kFrNone = 0xffu;      // FrRange::l0 of a range that owns no line
+
+struct FrRange { uint32_t l0, n_lines, n_runs, n_items; };
+struct __attribute__((packed, aligned(1))) FrU4 { uint32_t x, y, z, w; };   // sixteen bytes at any address
+
+// bytes per lane of a run, in dwords: seg + kmax - 1 bases
+template <int W> struct FrCfg {
+  static constexpr int SEG = W >= 19 ? 128 : (W >= 13 ? 80 : (W >= 11 ? 64 : 44));
+  static constexpr int KMAX = W >= 19 ? 32 : (W >= 13 ? 28 : (W >= 11 ? 22 : 20));
+  static constexpr int ND = (SEG + KMAX - 1 + 3) / 4;   // 40, 27, 22, 16
+  static constexpr int NR = (ND + 3) / 4;               // packed words that can hold a base: 10, 7, 6, 4
+};
+
+// 0x80 in every byte of w that is '\n' or '\r' (exact): x = w ^ 0x0A.. turns them into 0x00 / 0x07; a byte is one of the two iff
+// its high five bits are clear and its low three are 000 or 111, i.e. iff (x & 0xF8) | (((x & 7) + 1) & 6) is zero
+__device__ __forceinline__ uint32_t eol_flags(uint32_t w) {
+  const uint32_t x = w ^ 0x0A0A0A0Au;
+  const uint32_t z = ((x & 0x07070707u) + 0x01010101u) & 0x06060606u;
+  return zero_bytes((x & 0xF8F8F8F8u) | z);
+}
+// four bases -> four complement codes in the low byte; anything but A C G T (either case) counts as A, like DNA::FROM_ASCII
+__device__ __forceinline__ uint32_t pack_dna4(uint32_t w) {
+  const uint32_t x = w & 0xDFDFDFDFu;                          // fold case
+  const uint32_t idx = (x >> 1) & 0x03030303u;                 // A 0, C 1, T 2, G 3
+  const uint32_t expect = byte_perm(0u, 0x47544341u, idx);     // 'A','C','T','G'
+  const uint32_t ok = zero_bytes(x ^ expect);                  // 0x80 per base byte
+  const uint32_t lut = byte_perm(0u, 0x01000203u, idx);        // complement codes: A 3, C 2, T 0, G 1
+  const uint32_t v1 = ok >> 7, vm = v1 | (v1 << 1);
+  const uint32_t cc = (lut & vm) | (0x03030303u & ~vm);
+  const uint32_t p1 = cc | (cc >> 6);
+  return (p1 | (p1 >> 12)) & 0xFFu;
+}
+
+template <int W>
+__global__ __launch_bounds__(kFrThreads) void sk_front_kernel(const uint8_t *__restrict__ bytes, uint64_t n_bytes, uint64_t range_bytes, uint32_t n_ranges,
+                                                             uint32_t k, bool rna, uint32_t run_cap, uint32_t item_cap, uint32_t ranges_per_group,
+                                                             FrRange *__restrict__ info, uint32_t *__restrict__ run_items, uint32_t *__restrict__ rows,
+                                                             uint32_t *__restrict__ items, uint32_t *__restrict__ wg_hist,
+                                                             unsigned long long *__restrict__ n_windows, uint32_t *__restrict__ flags) {
+  using F = FrCfg<W>;
+  constexpr int CAP = kSkListCap;
+  constexpr uint32_t INF = 0xffffffffu, RM = kFrRing - 1u, QM = kFrRunQ - 1u;
+  __shared__ uint32_t s_S[kFrWaves][kFrRing], s_E[kFrWaves][kFrRing], s_rq[kFrWaves][kFrRunQ];
+  __shared__ uint32_t s_list[kFrWaves][(CAP + 2) * kWave];   // [slot][lane]; slot 0 takes the opening dummy, slot CAP + 1 what does not fit
+  __shared__ uint32_t s_hist[kFrWaves][kNumCoarse];
+  const uint32_t lane = lane_id(), wv = wave_id();
+  uint32_t *const S = s_S[wv], *const E = s_E[wv], *const rq = s_rq[wv], *const list = s_list[wv], *const hist = s_hist[wv];
+  auto wave_sync = [&]() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); };
+  const uint32_t m = k - (uint32_t)W + 1u;
+  const uint32_t mmask = (m >= 16u) ? 0xffffffffu : ((1u << (2u * m)) - 1u);
+  const uint32_t topsh = 2u * m - 2u;
+  const uint32_t nmax = sk_nmax_of(k);
+  const uint32_t seg = (uint32_t)F::SEG;
+  const uint32_t n_waves = gridDim.x * (uint32_t)kFrWaves;
+  for (uint32_t r = blockIdx.x * (uint32_t)kFrWaves + wv; r < n_ranges; r += n_waves) {   // (uniform per wavefront)
+    const uint64_t B = (uint64_t)r * range_bytes;
+    const uint32_t len = (uint32_t)((n_bytes - B < range_bytes) ? (n_bytes - B) : range_bytes);
+    for (uint32_t i = lane; i < (uint32_t)kNumCoarse; i += kWave) hist[i] = 0;
+    uint32_t why = 0; bool bail = false;                               // this range gives up: the caller takes the general path
+    uint32_t carry = (B == 0) ? 1u : (is_eol((uint32_t)__builtin_amdgcn_readfirstlane((int)bytes[B - 1])) ? 1u : 0u);   // EOL status of the byte before the next step
+    const uint32_t eoff = carry ? 0u : 1u;           // the range starts inside a line: that line's end is not ours
+    uint32_t n_starts = 0, n_ends = 0, n_owned = 0, done = 0, l0 = (r == 0) ? 0u : INF;
+    if (r == 0 && __builtin_amdgcn_readfirstlane((int)bytes[0]) != (int)'@') { why |= 2u; bail = true; }      // (get_next_record refuses a partition that does not begin with '@')
+    uint32_t rq_head = 0, rq_tail = 0, run_count = 0, item_count = 0;
+    unsigned long long windows = 0;                  // (lane 0's copy counts)
+    uint32_t p = 0;                                  // next step's position inside the range
+    bool producing = true;
+    // the step's 32 bytes per lane are loaded one step ahead (a step costs a few hundred instructions: without the prefetch
+    // every one of them began with a trip to HBM that nothing else in this wavefront could hide)
+    FrU4 n0, n1;
+    n0.x = n0.y = n0.z = n0.w = 0; n1 = n0;
+    if (B + 32ull * lane + 32 <= n_bytes) { n0 = *reinterpret_cast<const FrU4 *>(bytes + B + 32ull * lane); n1 = *reinterpret_cast<const FrU4 *>(bytes + B + 32ull * lane + 16); }
+    // the first byte of a header / '+' line is loaded when the line completes and compared one step later (nothing waits for it)
+    uint32_t mk_ch = 0, mk_want = 0;
+    while (!bail) {
+      // ---------------------------------------------------------------- produce
+      while (producing && rq_tail - rq_head < (uint32_t)kWave && !bail) {
+        const uint64_t g = B + p + 32ull * lane;
+        uint32_t eol = 0;
+        const FrU4 v0 = n0, v1 = n1;
+        {
+          const uint64_t gn = g + kFrStep;
+          if (gn + 32 <= n_bytes) { n0 = *reinterpret_cast<const FrU4 *>(bytes + gn); n1 = *reinterpret_cast<const FrU4 *>(bytes + gn + 16); }
+        }
+        if (g + 32 <= n_bytes) {
+          // the flags (0x80 per EOL byte) of two dwords gathered into one byte by two dot products with bit weights; << 7 too far
+          uint32_t d0 = __builtin_amdgcn_udot4(eol_flags(v0.x), 0x08040201u, 0u, false);
+          d0 = __builtin_amdgcn_udot4(eol_flags(v0.y), 0x80402010u, d0, false);
+          uint32_t d1 = __builtin_amdgcn_udot4(eol_flags(v0.z), 0x08040201u, 0u, false);
+          d1 = __builtin_amdgcn_udot4(eol_flags(v0.w), 0x80402010u, d1, false);
+          uint32_t d2 = __builtin_amdgcn_udot4(eol_flags(v1.x), 0x08040201u, 0u, false);
+          d2 = __builtin_amdgcn_udot4(eol_flags(v1.y), 0x80402010u, d2, false);
+          uint32_t d3 = __builtin_amdgcn_udot4(eol_flags(v1.z), 0x08040201u, 0u, false);
+          d3 = __builtin_amdgcn_udot4(eol_flags(v1.w), 0x80402010u, d3, false);
+          eol = (d0 >> 7) | (d1 << 1) | (d2 << 9) | (d3 << 17);
+        } else {
+#pragma unroll 1
+          for (uint32_t i = 0; i < 32u; ++i) {
+            const bool e = (g + i >= n_bytes) || is_eol(bytes[g + i]);   // bytes past the end count as EOL
+            eol |= (e ? 1u : 0u) << i;
+          }
+        }
+        const uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp((int)carry, (int)(eol >> 31), 0x138 /* wave_shr:1 */, 0xf, 0xf, false);   // lane 0 keeps the carry
+        const uint32_t before = (eol << 1) | prev;
+        uint32_t ls = ~eol & before, le = eol & ~before;
+        const uint32_t base = p + 32u * lane;
+        const uint32_t ns = (uint32_t)__builtin_popcount(ls), ne = (uint32_t)__builtin_popcount(le);
+        // owned line starts: positions below the range's length
+        const uint32_t no = base < len ? ns : 0u;
+        const uint32_t packed = ns | (ne << 10) | (no << 20);
+        const uint32_t inc = wave_inclusive_sum_dpp(packed);
+        const uint32_t tot = __builtin_amdgcn_readlane(inc, kWave - 1);
+        const uint32_t NS = tot & 1023u, NE = (tot >> 10) & 1023u, NO = tot >> 20;
+        if (NS > kFrRing / 2u || NE > kFrRing / 2u) { why |= 4u; bail = true; break; }   // lines of a few bytes: not this path's input
+        uint32_t rs = n_starts + ((inc - packed) & 1023u), re = n_ends + (((inc - packed) >> 10) & 1023u);
+        while (ls) { S[rs & RM] = base + (uint32_t)__builtin_ctz(ls); ++rs; ls &= ls - 1u; }
+        while (le) { E[re & RM] = base + (uint32_t)__builtin_ctz(le); ++re; le &= le - 1u; }
+        n_starts += NS; n_ends += NE; n_owned += NO;
+        carry = (uint32_t)__builtin_amdgcn_readlane(eol, kWave - 1) >> 31;   // (the builtin returns a signed int)
+        p += kFrStep;
+        const bool at_eof = B + p > n_bytes;                 // (a step that reached past the end has produced the last line's end)
+        wave_sync();                                         // the events are in the rings
+        // ---- the line index of the first line (once)
+        if (l0 == INF && n_starts > 0u) {
+          if ((uint32_t)__builtin_amdgcn_readfirstlane((int)S[0]) >= len) l0 = kFrNone;                     // the range owns no line: nothing to do here
+          else if (at_eof && n_starts < 6u) {
+            // the buffer ends here: a well-formed file ends with a quality line, so the lines of this range end on index 3 (mod 4);
+            // like every inferred index this one is confirmed by the chain over the ranges
+            l0 = (0u - n_starts) & 3u;
+          } else if (n_starts >= 6u) {
+            const uint32_t nl = 6u;
+            uint32_t c = 0;
+            if (lane < nl) c = bytes[B + S[lane]];
+            const uint32_t c2 = __shfl_down(c, 2, kWave);
+            const bool cand = lane < 4u && lane + 2u < nl && c == (uint32_t)'@' && c2 == (uint32_t)'+';
+            const unsigned long long cm = __ballot(cand);
+            if (__popcll(cm) != 1) { why |= 8u; bail = true; break; }   // none, or more than one: the general path decides
+            l0 = (4u - (uint32_t)__builtin_ctzll(cm)) & 3u;
+          }
+        }
+        if (l0 == kFrNone) { producing = false; break; }
+        // ---- lines whose end is known: roles, markers, the length rule, runs
+        if (l0 != INF) {
+          const uint32_t complete = n_ends >= eoff ? (n_starts < n_ends - eoff ? n_starts : n_ends - eoff) : 0u;
+          for (uint32_t j0 = done; j0 < complete && !bail; j0 += kWave) {
+            const uint32_t j = j0 + lane;
+            const bool have = j < complete;
+            uint32_t sj = 0, L = 0, role = 4;
+            if (have) { sj = S[j & RM]; L = E[(j + eoff) & RM] - sj; role = (l0 + j) & 3u; }
+            const bool owned = have && sj < len;
+            bool bad = false;
+            if (mk_want && mk_ch != mk_want) bad = true;   // the previous batch's marker
+            mk_want = 0;
+            if (owned && (role == 0u || role == 2u)) { mk_ch = bytes[B + sj]; mk_want = role == 0u ? (uint32_t)'@' : (uint32_t)'+'; }
+            if (have && role == 3u && j >= 2u && S[(j - 2u) & RM] < len) bad = bad || (E[(j - 2u + eoff) & RM] - S[(j - 2u) & RM] != L);
+            if (__any(bad)) {
+              why |= 16u; bail = true; break;
+            }
+            uint32_t nr = 0, nwin = 0;
+            if (owned && role == 1u && L >= k) { nwin = L - k + 1u; nr = (nwin + seg - 1u) / seg; }
+            const uint32_t rinc = wave_inclusive_sum_dpp(nr);
+            const uint32_t rtot = __builtin_amdgcn_readlane(rinc, kWave - 1);
+            if ((rq_tail + rtot - rq_head > kFrRunQ || __any(have && (sj >> 24))) && rtot) { { why |= 32u; bail = true; break; } }   // a long read's many runs, or a range past 16 MB
+            uint32_t o = rq_tail + rinc - nr;
+            for (uint32_t i = 0; i < nr; ++i) {
+              const uint32_t left = nwin - i * seg;
+              rq[(o + i) & QM] = (sj + i * seg) | (((left < seg ? left : seg) - 1u) << 24);
+            }
+            rq_tail += rtot;
+          }
+          if (bail) break;
+          done = complete;
+          // done when the range is scanned and the two lines behind its last one are complete (their quality lines are checked here)
+          if (at_eof || (p >= len && complete >= n_owned + 2u)) producing = false;
+        } else if (at_eof) { producing = false; }   // (no line start at all)
+        wave_sync();                                         // the queue is written; the rings may be overwritten by the next step
+      }
+      if (bail) break;
+      // ---------------------------------------------------------------- consume
+      const uint32_t avail = rq_tail - rq_head;
+      if (avail == 0u) { if (!producing) break; continue; }
+      const uint32_t take = avail < (uint32_t)kWave ? avail : (uint32_t)kWave;
+      const bool mine = lane < take;
+      const uint32_t rv = mine ? rq[(rq_head + lane) & QM] : 0u;
+      rq_head += take;
+      if (run_count + take > run_cap) { why |= 64u; bail = true; break; }
+      const uint32_t L = mine ? (rv >> 24) + 1u : 0u;        // windows of the run
+      const uint64_t g0 = B + (rv & 0xffffffu);              // its first base
+      {
+        const uint32_t wsum = __builtin_amdgcn_readlane(wave_inclusive_sum_dpp(L), kWave - 1);
+        windows += wsum;
+      }
+      // ---- the run's bytes -> its packed row (complement codes, base i at bits 2 i)
+      uint32_t rw[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) rw[i] = 0;
+      if (mine) {
+        if (g0 + 16ull * F::NR <= n_bytes) {
+#pragma unroll
+          for (int q = 0; q < F::NR; ++q) {
+            FrU4 v = *reinterpret_cast<const FrU4 *>(bytes + g0 + 16 * q);   // (a read starts at any byte: unaligned 16-byte loads)
+            if (rna) { v.x = swap_tu_dword(v.x); v.y = swap_tu_dword(v.y); v.z = swap_tu_dword(v.z); v.w = swap_tu_dword(v.w); }
+            rw[q] = pack_dna4(v.x) | (pack_dna4(v.y) << 8) | (pack_dna4(v.z) << 16) | (pack_dna4(v.w) << 24);
+          }
+        } else {   // the last reads of the buffer: byte by byte, nothing read past the end
+          const uint32_t nb = L + k - 1u;
+#pragma unroll 1
+          for (uint32_t i = 0; i < nb; ++i) {
+            uint32_t c = bytes[g0 + i];
+            if (rna) c = swap_tu_dword(c) & 0xffu;
+            const uint32_t code = pack_dna4(c | 0x0A0A0A00u) & 3u;
+            const uint32_t wi = i >> 4, sh = (i & 15u) * 2u;
+#pragma unroll
+            for (int q = 0; q < F::NR; ++q) rw[q] |= (wi == (uint32_t)q) ? (code << sh) : 0u;
+          }
+        }
+      }
+      // the row leaves now (the walk below consumes its registers): three 16-byte stores per lane, consecutive rows
+      if (mine) {
+        const uint64_t ri = (uint64_t)r * run_cap + run_count + lane;
+        uint4 *rp = reinterpret_cast<uint4 *>(rows + ri * kFrRowDw);
+        rp[0] = make_uint4(rw[0], rw[1], rw[2], rw[3]);
+        rp[1] = make_uint4(rw[4], rw[5], rw[6], rw[7]);
+        rp[2] = make_uint4(rw[8], rw[9], rw[10], rw[11]);
+      }
+      // ---- the walk (sk_minimizer_kernel's). The row is kept ALIGNED to the block being walked: after the first m - 1 bases are
+      // shifted out once, the W codes of a block are the low 2 W bits of rw[0..1], and the row moves down by W bases per block
+      // (static funnel shifts) -- no indexing of the register array by a run-time value, which the compiler answers with scratch.
+      uint32_t cnt = 0;
+      {
+        const uint32_t nblk = mine ? (L + (uint32_t)W - 2u) / (uint32_t)W + 1u : 0u;   // m-mer positions 0 .. L + W - 2
+        uint32_t R = rw[0] & mmask, Fw = sk_fwd_of(rw[0] & mmask, m);
+        {
+          const uint32_t sh0 = 2u * (m - 1u);   // 4 .. 30 (m <= 16)
+#pragma unroll
+          for (int i = 0; i < F::NR; ++i) rw[i] = __builtin_amdgcn_alignbit(rw[i + 1], rw[i], sh0);
+        }
+        uint32_t sprev[W + 1];
+#pragma unroll
+        for (int j = 0; j <= W; ++j) sprev[j] = INF;
+        uint32_t prevv = 0, slen = nmax;   // the first window opens a super-k-mer like any other boundary; the dummy lands in slot 0
+        for (uint32_t b = 0; __any(b < nblk); ++b) {
+          const uint32_t clo = rw[0], chi = rw[1];
+          {
+            constexpr int WS = (2 * W) / 32, BS = (2 * W) % 32;
+#pragma unroll
+            for (int i = 0; i < F::NR; ++i) rw[i] = __builtin_amdgcn_alignbit(rw[i + WS + 1], rw[i + WS], BS);
+          }
+          uint32_t hh[W];
+          uint32_t pm = INF;
+#pragma unroll
+          for (int j = 0; j < W; ++j) {
+            const uint32_t q = b * (uint32_t)W + (uint32_t)j;   // (the same in every lane)
+            if (j > 0 || b > 0) {
+              const uint32_t c = (j < 16) ? ((clo >> (2 * (j & 15))) & 3u) : ((chi >> (2 * (j & 15))) & 3u);
+              R = (R >> 2) | (c << topsh);
+              Fw = ((Fw << 2) | (c ^ 3u)) & mmask;
+            }
+            const uint32_t h = sk_order_hash(R < Fw ? R : Fw);
+            hh[j] = h;
+            pm = pm < h ? pm : h;
+            const uint32_t sp = sprev[j + 1];
+            const uint32_t curv = sp < pm ? sp : pm;
+            const bool valid = q - (uint32_t)(W - 1) < L;   // window i = q - (W - 1); wraps to a large number below zero
+            const bool fresh = valid && (curv != prevv || slen >= nmax);
+            if (fresh) {   // close (prevv, slen)
+              const uint32_t slot = cnt < (uint32_t)CAP + 1u ? cnt : (uint32_t)CAP + 1u;
+              list[slot * kWave + lane] = (prevv << 5) | (slen - 1u);
+              ++cnt;
+              prevv = curv;
+              slen = 0u;
+            }
+            slen += valid ? 1u : 0u;
+          }
+          sprev[W] = INF;
+          sprev[W - 1] = hh[W - 1];
+#pragma unroll
+          for (int j = W - 2; j >= 0; --j) sprev[j] = hh[j] < sprev[j + 1] ? hh[j] : sprev[j + 1];
+        }
+        if (mine) {   // the last super-k-mer
+          const uint32_t slot = cnt < (uint32_t)CAP + 1u ? cnt : (uint32_t)CAP + 1u;
+          list[slot * kWave + lane] = (prevv << 5) | (slen - 1u);
+          ++cnt;
+        }
+      }
+      if (__any(cnt > (uint32_t)CAP + 1u)) { why |= 128u; bail = true; break; }
+      cnt = cnt ? cnt - 1u : 0u;   // real items: slots 1 .. cnt
+      // items in their final form (window offset | (n - 1) << 7 | bucket bits << 12 | two further hash bits << 30) + the coarse counts
+      {
+        uint32_t off = 0;
+        for (uint32_t j = 1; j <= cnt; ++j) {
+          const uint32_t it = list[j * kWave + lane];
+          const uint32_t n1 = it & 31u;
+          const uint32_t h20 = sk_bucket_bits20(it >> 5), h18 = h20 >> 2;
+          atomicAdd(&hist[h18 >> 10], 1u);
+          list[j * kWave + lane] = off | (n1 << 7) | (h18 << 12) | ((h20 & 3u) << 30);
+          off += n1 + 1u;
+        }
+      }
+      const uint32_t cinc = wave_inclusive_sum_dpp(cnt);
+      const uint32_t ctot = __builtin_amdgcn_readlane(cinc, kWave - 1);
+      if (item_count + ctot > item_cap) { why |= 256u; bail = true; break; }
+      if (mine) {
+        const uint32_t ex = item_count + cinc - cnt;
+        uint32_t *dst = items + (uint64_t)r * item_cap + ex;
+        for (uint32_t j = 0; j < cnt; ++j) dst[j] = list[(j + 1u) * kWave + lane];
+        const uint64_t ri = (uint64_t)r * run_cap + run_count + lane;
+        run_items[ri] = ex | (cnt << 26);
+      }
+      run_count += take;
+      item_count += ctot;
+      wave_sync();   // the list is read; the next batch overwrites it
+    }
+    if (!bail && __any(mk_want && mk_ch != mk_want)) { why |= 16u; bail = true; }   // the last batch's markers
+    if (bail) { if (lane == 0) { atomicOr(&flags[9], 4u); atomicOr(&flags[10], why); } }
+    wave_sync();
+    if (lane == 0) {
+      FrRange fr; fr.l0 = (l0 == INF) ? kFrNone : l0; fr.n_lines = (l0 == INF || l0 == kFrNone) ? 0u : n_owned; fr.n_runs = run_count; fr.n_items = item_count;
+      info[r] = fr;
+      if (windows) atomicAdd(n_windows, windows);
+    }
+    const uint32_t grp = r / ranges_per_group;
+    for (uint32_t i = lane; i < (uint32_t)kNumCoarse; i += kWave) {
+      const uint32_t c = hist[i];
+      if (c) atomicAdd(&wg_hist[(uint64_t)grp * kNumCoarse + i], c);
+    }
+    wave_sync();
+  }
+}
+
+// S for the fused front end: the scatter pass over the runs a group of ranges left (run_items / rows / items at fixed strides per
+// range). The round structure, the LDS bucket sort and the copy-out are sk_scatter_kernel's; what differs is where a lane finds
+// its run: run number G of the group lies in the range whose prefix of run counts covers it, its row is read as three aligned
+// 16-byte loads and starts at the run's first base.
+constexpr int kFrRowLds = kFrRowDw + 1;   // odd stride: rows on different banks
+constexpr uint32_t kFrMaxGroupRanges = 128;
+template <bool CANON>
+__global__ __launch_bounds__(kSkThreads, 2) void sk_scatter_rows_kernel(const FrRange *__restrict__ info, uint32_t n_ranges, uint32_t rpg, uint32_t run_cap,
+                                                                       uint32_t item_cap, uint32_t k, const uint32_t *__restrict__ run_items,
+                                                                       const uint32_t *__restrict__ rows, const uint32_t *__restrict__ items,
+                                                                       const uint64_t *__restrict__ wg_off, uint64_t *__restrict__ out, uint32_t lp) {
+  constexpr int NT = kSkThreads, CAP = kSkListCap;
+  __shared__ uint16_t s_stage[CAP * NT];
+  __shared__ uint32_t s_row[NT * kFrRowLds + 4];
+  __shared__ uint32_t s_ioff[NT];       // first item of every run, relative to the group's first item region
+  __shared__ uint32_t s_cnt[kNumCoarse];
+  __shared__ uint32_t s_cur[kNumCoarse];
+  __shared__ uint64_t s_gbase[kNumCoarse];
+  __shared__ uint32_t s_part[kNumCoarse / kWave];
+  __shared__ uint32_t s_total;
+  __shared__ uint32_t s_pre[kFrMaxGroupRanges + 1];   // runs before every range of the group
+  uint64_t cursor = (threadIdx.x < kNumCoarse) ? wg_off[(uint64_t)blockIdx.x * kNumCoarse + threadIdx.x] : 0ull;
+  if (threadIdx.x < kNumCoarse) s_cnt[threadIdx.x] = 0;
+  const uint32_t r_first = blockIdx.x * rpg;
+  const uint32_t nr = r_first >= n_ranges ? 0u : (n_ranges - r_first < rpg ? n_ranges - r_first : rpg);
+  if (threadIdx.x == 0) {
+    uint32_t acc = 0;
+    for (uint32_t q = 0; q < nr; ++q) { s_pre[q] = acc; acc += info[r_first + q].n_runs; }
+    s_pre[nr] = acc;
+  }
+  lds_barrier();
+  const uint32_t total_runs = s_pre[nr];
+  const uint32_t *const g_items = items + (uint64_t)r_first * item_cap;
+  for (uint32_t rb = 0; rb < total_runs; rb += NT) {
+    lds_barrier();   // the previous round's stage and run tables are done with; the counters are clear
+    uint32_t cnt = 0;
+    uint32_t it[CAP];
+    {
+      const uint32_t G = rb + threadIdx.x;
+      uint32_t ri = 0, q = 0;
+      if (G < total_runs) {
+        for (uint32_t i = 1; i < nr; ++i) q += (G >= s_pre[i]) ? 1u : 0u;
+        const uint64_t run = (uint64_t)(r_first + q) * run_cap + (G - s_pre[q]);
+        ri = run_items[run];
+        const uint4 *rp = reinterpret_cast<const uint4 *>(rows + run * kFrRowDw);
+        const uint4 q0 = rp[0], q1 = rp[1], q2 = rp[2];
+        uint32_t *row = s_row + threadIdx.x * kFrRowLds;
+        row[0] = q0.x; row[1] = q0.y; row[2] = q0.z; row[3] = q0.w; row[4] = q1.x; row[5] = q1.y; row[6] = q1.z; row[7] = q1.w;
+        row[8] = q2.x; row[9] = q2.y; row[10] = q2.z; row[11] = q2.w; row[12] = 0;
+      }
+      cnt = ri >> 26;
+      const uint32_t ioff = q * item_cap + (ri & 0x3ffffffu);
+      const uint32_t *src = g_items + ioff;
+#pragma unroll
+      for (int j = 0; j < CAP; ++j) it[j] = ((uint32_t)j < cnt) ? src[j] : 0u;
+      s_ioff[threadIdx.x] = ioff;
+    }
+#pragma unroll
+    for (int j = 0; j < CAP; ++j)
+      if ((uint32_t)j < cnt) atomicAdd(&s_cnt[(it[j] >> 22) & 255u], 1u);
+    lds_barrier();
+    uint32_t c = 0, inc = 0;
+    if (threadIdx.x < kNumCoarse) {
+      c = s_cnt[threadIdx.x];
+      s_cnt[threadIdx.x] = 0;
+      inc = wave_inclusive_sum_dpp(c);
+      if (lane_id() == kWave - 1) s_part[wave_id()] = inc;
+    }
+    lds_barrier();
+    if (threadIdx.x < kNumCoarse) {
+      uint32_t pre = 0;
+#pragma unroll
+      for (uint32_t w = 0; w < kNumCoarse / kWave; ++w) pre += (w < wave_id()) ? s_part[w] : 0u;
+      const uint32_t lo = pre + inc - c;
+      s_cur[threadIdx.x] = lo;
+      s_gbase[threadIdx.x] = cursor - lo;
+      cursor += c;
+      if (threadIdx.x == kNumCoarse - 1) s_total = pre + inc;
+    }
+    lds_barrier();
+#pragma unroll
+    for (int j = 0; j < CAP; ++j)
+      if ((uint32_t)j < cnt) s_stage[atomicAdd(&s_cur[(it[j] >> 22) & 255u], 1u)] = (uint16_t)((threadIdx.x << 5) | (uint32_t)j);
+    lds_barrier();
+    const uint32_t total = s_total;
+    for (uint32_t s = threadIdx.x; s < total; s += NT) {
+      const uint32_t e = s_stage[s], rl = e >> 5, j = e & 31u;
+      const uint32_t item = g_items[s_ioff[rl] + j];
+      const uint32_t h18 = (item >> 12) & 0x3ffffu, n1 = (item >> 7) & 31u, extra = item >> 30;
+      // the bucket bits as the owner will read them: the lp rank bits shifted out, the two spare hash bits shifted in below
+      const uint32_t hs = ((h18 << lp) & 0x3ffffu) | (lp <= 2u ? extra >> (2u - lp) : extra << (lp - 2u));
+      uint64_t w0, w1;
+      sk_assemble_row<CANON>(s_row + rl * kFrRowLds, 2u * (item & 127u), k + n1, n1, hs, w0, w1);
+      reinterpret_cast<ulonglong2 *>(out)[s_gbase[h18 >> 10] + s] = make_ulonglong2(w0, w1);
+    }
+  }
+}
+
+// the chain of the ranges' line indices: range r + 1 starts where range r ended (mod 4); totals: lines, runs, items
+__global__ __launch_bounds__(1024) void sk_front_verify_kernel(const FrRange *__restrict__ info, uint32_t n_ranges, uint32_t ranges_per_group,
+                                                             uint64_t *__restrict__ group_runs /* [groups]: runs of every group */,
+                                                             uint64_t *__restrict__ totals /* [0] lines [1] runs [2] items */, uint32_t *__restrict__ flags) {
+  __shared__ uint64_t s_scan[1024 / 64 + 2];
+  __shared__ uint32_t s_bad;
+  if (threadIdx.x == 0) s_bad = 0;
+  lds_barrier();
+  uint64_t carry = 0, runs = 0, its = 0;
+  for (uint32_t r0 = 0; r0 < n_ranges; r0 += 1024) {
+    const uint32_t r = r0 + threadIdx.x;
+    FrRange fr; fr.l0 = kFrNone; fr.n_lines = 0; fr.n_runs = 0; fr.n_items = 0;
+    if (r < n_ranges) fr = info[r];
+    uint64_t tot;
+    const uint64_t before = carry + block_exclusive_scan<uint64_t>((uint64_t)fr.n_lines, s_scan, &tot);
+    if (fr.l0 != kFrNone && fr.n_lines && ((uint32_t)before & 3u) != fr.l0) s_bad = 1;
+    carry += tot;
+    uint64_t t2;
+    (void)block_exclusive_scan<uint64_t>((uint64_t)fr.n_runs, s_scan, &t2); runs += t2;
+    (void)block_exclusive_scan<uint64_t>((uint64_t)fr.n_items, s_scan, &t2); its += t2;
+  }
+  lds_barrier();
+  if (threadIdx.x == 0) {
+    totals[0] = carry; totals[1] = runs; totals[2] = its;
+    if (s_bad) atomicOr(&flags[9], 4u);
+  }
+  // runs per group (what a scatter workgroup will walk)
+  const uint32_t groups = (n_ranges + ranges_per_group - 1) / ranges_per_group;
+  for (uint32_t g = threadIdx.x; g < groups; g += blockDim.x) {
+    uint64_t s = 0;
+    for (uint32_t r = g * ranges_per_group; r < (g + 1) * ranges_per_group && r < n_ranges; ++r) s += info[r].n_runs;
+    group_runs[g] = s;
+  }
+}
+
+}  // namespace kmi

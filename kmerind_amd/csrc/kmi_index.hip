@@ -2336,6 +2336,7 @@ __global__ __launch_bounds__(256) void bucket_compact_words_kernel(const uint64_
 }  // namespace kmi
 
 #include "kmi_superkmer.h"
+#include "kmi_front.h"
 
 // ===========================================================================
 // host side
@@ -2515,8 +2516,7 @@ static kmi_status adopt_tmp(kmi_index *idx, const uint64_t *tmp_keys, const uint
       size_t kb0 = 0, vb0 = 0;
       (void)ws_detach(ctx, WS_TMP_KEYS, tmp_keys, &kb0);
       (void)ws_detach(ctx, WS_TMP_VALS, tmp_vals, &vb0);
-      KMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
-      free_index_arrays(idx);
+      free_index_arrays(idx);   // (the two copies above are ordered on the stream like everything that may reuse these blocks)
       idx->keys = const_cast<uint64_t *>(tmp_keys); idx->vals = const_cast<uint32_t *>(tmp_vals); idx->bucket_off = off; idx->bucket_cnt = cnt;
       idx->dense_off = new_off; idx->n_entries = total; idx->has_data = true; idx->keys_bytes = kb0; idx->vals_bytes = vb0;
       return KMI_OK;
@@ -2650,7 +2650,7 @@ static kmi_status build_fused_impl(kmi_index *idx, const uint8_t *bytes_dev, siz
 struct SkFront {
   bool ok = false;                 // false: a run or a tile exceeded its item capacity (the caller takes the k-mer path)
   uint64_t *recs = nullptr;        // WS_KEYS_A
-  uint64_t n_records = 0, n_kmers = 0;
+  uint64_t n_records = 0, n_kmers = 0, n_seqs = 0;
   uint64_t h_cnt[kNumCoarse], h_base[kNumCoarse];
   uint64_t *wg_off = nullptr;      // [kPartGroups][kNumCoarse] (WS_CURSOR)
 };
@@ -2731,6 +2731,98 @@ static kmi_status sk_front_end(kmi_ctx *ctx, const kmi_config *cfg, const KShape
   return KMI_OK;
 }
 
+// The same front end in one pass over the bytes (kmi_front.h): FASTQ without a sequence filter. *took = false: the fast path
+// declined (a shape it does not take, or something in the input it is not sure about) and nothing was changed -- the caller
+// runs fastq_scan + sk_front_end, which also words parse errors.
+template <int W>
+static kmi_status sk_front_fast(kmi_ctx *ctx, const kmi_config *cfg, const KShape &shape, const uint8_t *bytes_dev, size_t n_bytes, uint32_t lp, SkFront *f,
+                                bool *took, uint64_t *out = nullptr, size_t out_cap = 0) {
+  *took = false;
+  f->ok = false;
+  if (!ctx->front_fused || cfg->seq_format != KMI_FMT_FASTQ || cfg->seq_filter != KMI_SEQ_ALL || n_bytes < 64) return KMI_OK;
+  const uint32_t k = shape.k;
+  const bool canonical = cfg->strand != KMI_STRAND_SINGLE;
+  // ranges: one per resident wavefront of the front kernel when the input is large; never below the context's minimum
+  if (!ctx->front_waves) {
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, sk_front_kernel<19>, kFrThreads, 0) != hipSuccess || per_cu <= 0) per_cu = 2;
+    ctx->front_waves = (uint32_t)per_cu * (ctx->n_cus ? ctx->n_cus : 256u) * (uint32_t)kFrWaves;
+  }
+  uint64_t range_bytes = (n_bytes + ctx->front_waves - 1) / ctx->front_waves;
+  range_bytes = (range_bytes + kFrStep - 1) / kFrStep * kFrStep;
+  if (range_bytes < ctx->front_min_range) range_bytes = ctx->front_min_range;
+  if (range_bytes > (8ull << 20)) range_bytes = 8ull << 20;
+  const uint64_t n_ranges64 = (n_bytes + range_bytes - 1) / range_bytes;
+  const uint32_t rpg = (uint32_t)((n_ranges64 + kPartGroups - 1) / kPartGroups);
+  if (rpg > kFrMaxGroupRanges) return KMI_OK;
+  const uint32_t n_ranges = (uint32_t)n_ranges64;
+  const uint32_t run_cap = (uint32_t)(range_bytes / 64) + 64u, item_cap = (uint32_t)(range_bytes / 8) + 64u;
+  void *p;
+  KMI_TRY(ws_get(ctx, WS_TILE_INFO, sizeof(FrRange) * (n_ranges + 1), &p)); FrRange *info = (FrRange *)p;
+  KMI_TRY(ws_get(ctx, WS_TILE_BASE, sizeof(uint64_t) * (kPartGroups + 1), &p)); uint64_t *group_runs = (uint64_t *)p;
+  KMI_TRY(ws_get(ctx, WS_ENT_LIST, sizeof(uint32_t) * ((size_t)n_ranges * run_cap + 64), &p)); uint32_t *run_items = (uint32_t *)p;
+  KMI_TRY(ws_get(ctx, WS_PK_STREAM, sizeof(uint32_t) * kFrRowDw * ((size_t)n_ranges * run_cap + 64), &p)); uint32_t *rows = (uint32_t *)p;
+  KMI_TRY(ws_get(ctx, WS_SK_ITEMS, sizeof(uint32_t) * ((size_t)n_ranges * item_cap + 64), &p)); uint32_t *items = (uint32_t *)p;
+  KMI_TRY(ws_get(ctx, WS_WGHIST, sizeof(uint32_t) * kPartGroups * kNumCoarse, &p)); uint32_t *wg_hist = (uint32_t *)p;
+  KMI_TRY(ws_get(ctx, WS_CURSOR, sizeof(uint64_t) * kPartGroups * kNumCoarse, &p)); uint64_t *wg_off = (uint64_t *)p;
+  KMI_TRY(ws_get(ctx, WS_MISC, sizeof(uint64_t) * kNumCoarse * 3, &p)); uint64_t *cnt = (uint64_t *)p, *base = cnt + kNumCoarse;
+  KMI_HIP(ctx, hipMemsetAsync(ctx->d_flags, 0, sizeof(uint32_t) * 16, ctx->stream));
+  KMI_HIP(ctx, hipMemsetAsync(ctx->d_totals + 6, 0, sizeof(uint64_t), ctx->stream));
+  KMI_HIP(ctx, hipMemsetAsync(wg_hist, 0, sizeof(uint32_t) * kPartGroups * kNumCoarse, ctx->stream));
+  {
+    ProfScope ps(ctx, "sk_front", n_bytes);
+    const uint32_t wgs = (n_ranges + kFrWaves - 1) / kFrWaves;
+    hipLaunchKernelGGL((sk_front_kernel<W>), dim3(wgs), dim3(kFrThreads), 0, ctx->stream, bytes_dev, (uint64_t)n_bytes, range_bytes, n_ranges, k, is_rna(cfg),
+                       run_cap, item_cap, rpg, info, run_items, rows, items, wg_hist, (unsigned long long *)(ctx->d_totals + 6), ctx->d_flags);
+  }
+  {
+    ProfScope ps(ctx, "sk_offsets", kNumCoarse);
+    hipLaunchKernelGGL(sk_front_verify_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const FrRange *)info, n_ranges, rpg, group_runs, ctx->d_totals + 12, ctx->d_flags);
+    launch_rank_offsets(ctx->stream, (const uint32_t *)wg_hist, (uint32_t)kPartGroups, (uint32_t)kNumCoarse, cnt, base, wg_off);
+  }
+  KMI_HIP(ctx, hipGetLastError());
+  uint64_t h_cnt[2 * kNumCoarse], h_tot[3] = {0, 0, 0}, n = 0;
+  uint32_t h_flag = 0;
+  KMI_HIP(ctx, hipMemcpyAsync(h_cnt, cnt, sizeof(uint64_t) * 2 * kNumCoarse, hipMemcpyDeviceToHost, ctx->stream));
+  KMI_HIP(ctx, hipMemcpyAsync(&h_flag, ctx->d_flags + 9, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+  KMI_HIP(ctx, hipMemcpyAsync(h_tot, ctx->d_totals + 12, sizeof(h_tot), hipMemcpyDeviceToHost, ctx->stream));
+  KMI_HIP(ctx, hipMemcpyAsync(&n, ctx->d_totals + 6, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+  KMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (h_flag) {   // not this path's input (or not well-formed): the general path decides
+    if (getenv("KMI_FRONT_DEBUG")) {
+      uint32_t why = 0;
+      (void)hipMemcpy(&why, ctx->d_flags + 10, sizeof(why), hipMemcpyDeviceToHost);
+      fprintf(stderr, "sk_front declined: reasons 0x%x (2 first byte, 4 crowded lines, 8 inference, 16 marker / length, 32 run queue, 64 run capacity, 128 items per run, 256 item capacity; 0 = the chain of line indices)\n", why);
+    }
+    KMI_HIP(ctx, hipMemsetAsync(ctx->d_flags + 9, 0, 2 * sizeof(uint32_t), ctx->stream));
+    return KMI_OK;
+  }
+  *took = true;
+  uint64_t R = 0;
+  for (int c = 0; c < kNumCoarse; ++c) { R += h_cnt[c]; f->h_cnt[c] = h_cnt[c]; f->h_base[c] = h_cnt[kNumCoarse + c]; }
+  f->n_records = R; f->n_kmers = n; f->wg_off = wg_off; f->recs = nullptr; f->n_seqs = (h_tot[0] + 2) / 4;
+  if (n == 0) { f->ok = true; return KMI_OK; }
+  uint64_t *rec_a = out;
+  if (!out || R + 64 > out_cap) { KMI_TRY(ws_get(ctx, WS_KEYS_A, (R + 64) * 16, &p)); rec_a = (uint64_t *)p; }
+  {
+    ProfScope ps(ctx, "sk_scatter", n);
+    if (canonical)
+      hipLaunchKernelGGL(sk_scatter_rows_kernel<true>, dim3(kPartGroups), dim3(kSkThreads), 0, ctx->stream, (const FrRange *)info, n_ranges, rpg, run_cap, item_cap, k,
+                         (const uint32_t *)run_items, (const uint32_t *)rows, (const uint32_t *)items, (const uint64_t *)wg_off, rec_a, lp);
+    else
+      hipLaunchKernelGGL(sk_scatter_rows_kernel<false>, dim3(kPartGroups), dim3(kSkThreads), 0, ctx->stream, (const FrRange *)info, n_ranges, rpg, run_cap, item_cap, k,
+                         (const uint32_t *)run_items, (const uint32_t *)rows, (const uint32_t *)items, (const uint64_t *)wg_off, rec_a, lp);
+  }
+  KMI_HIP(ctx, hipGetLastError());
+  f->ok = true; f->recs = rec_a;
+  return KMI_OK;
+}
+template <int W>
+static kmi_status sk_front_fast_any(kmi_ctx *ctx, const kmi_config *cfg, const KShape &shape, const uint8_t *bytes_dev, size_t n_bytes, uint32_t lp, SkFront *f,
+                                    bool *took, uint64_t *out = nullptr, size_t out_cap = 0) {
+  return sk_front_fast<W>(ctx, cfg, shape, bytes_dev, n_bytes, lp, f, took, out, out_cap);
+}
+
 // Back end: records grouped by coarse bucket (rec_a; group c = [h_base[c], h_base[c] + h_cnt[c]), written by kPartGroups
 // workgroups at wg_off[g][c]) -> fine buckets -> sk_reduce -> the index (layout W | lp << 8), or added to what it holds.
 template <int W>
@@ -2798,29 +2890,24 @@ static kmi_status sk_back_end(kmi_index *idx, const uint64_t *rec_a, uint64_t R,
 #undef KMI_SK_REDUCE
   }
   KMI_HIP(ctx, hipGetLastError());
-  {   // the level most buckets ended at: where the buckets of the NEXT build (batch, step) of this context start
-    uint32_t lv[9] = {0};
-    KMI_HIP(ctx, hipMemcpyAsync(lv, ctx->d_flags + 16, sizeof(lv), hipMemcpyDeviceToHost, ctx->stream));
-    KMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  // the level most buckets ended at: where the buckets of the NEXT build (batch, step) of this context start. The copy is queued
+  // here and read after the synchronisation adopt_tmp needs anyway (one host round trip less per build).
+  KMI_HIP(ctx, hipMemcpyAsync(ctx->h_totals + 8 /* pinned; words 8..12 */, ctx->d_flags + 16, sizeof(uint32_t) * 9, hipMemcpyDeviceToHost, ctx->stream));
+  auto read_levels = [&]() {
+    const uint32_t *lv = reinterpret_cast<const uint32_t *>(ctx->h_totals + 8);
     uint64_t seen = 0; uint32_t best = 0;
     for (uint32_t l = 0; l < 9; ++l) { seen += lv[l]; if (lv[l] > lv[best]) best = l; }
     // (level 0 finishes are only recorded once the hint is non-zero: no record at all means "everything fit at level 0")
     if (seen == 0) ctx->sk_level_hint = 0;
     else if (ctx->sk_level_hint == 0) { uint64_t up = seen; ctx->sk_level_hint = (up * 2 > (uint64_t)kNumFine) ? best : 0u; }
     else ctx->sk_level_hint = best;
-  }
-  if (ctx->sk_dbg == 6) {
-    uint32_t hf[40];
-    (void)hipMemcpy(hf, ctx->d_flags, sizeof(hf), hipMemcpyDeviceToHost);
-    fprintf(stderr, "sk_reduce: records %u, direct %u, T1 entries %u; buckets without / with a split at level 0: %u / %u, level 1: %u / %u\n", hf[10], hf[11],
-            hf[12], hf[16], hf[17], hf[18], hf[19]);
-    (void)hipMemset(ctx->d_flags + 10, 0, 3 * sizeof(uint32_t));
-  }
+  };
   const uint32_t layout = (uint32_t)W | (lp << 8);
   if (!idx->has_data || idx->n_entries == 0) {
     // the index IS the reduce output: entries grouped by minimizer bucket. Queries partition their keys by the same function
     // (fine15_of_key); whatever needs the placement-hash layout converts the entries once (ensure_layout).
     KMI_TRY((adopt_tmp<NW>(idx, tmp_keys, tmp_vals, kmer_off, nullptr, out_cnt, false, n, true)));
+    read_levels();
     idx->layout_w = layout;
     if (n) ctx->sk_inv_dup = (float)((double)idx->n_entries / (double)n);   // where the buckets of the next build start (sk_reduce_kernel)
     return KMI_OK;
@@ -2829,6 +2916,7 @@ static kmi_status sk_back_end(kmi_index *idx, const uint64_t *rec_a, uint64_t R,
   kmi_index scratch;
   scratch.ctx = ctx; scratch.cfg = idx->cfg; scratch.shape = idx->shape; scratch.val_words = 0;
   kmi_status st = adopt_tmp<NW>(&scratch, tmp_keys, tmp_vals, kmer_off, nullptr, out_cnt);
+  if (st == KMI_OK) read_levels();
   if (st == KMI_OK && n) ctx->sk_inv_dup = (float)((double)scratch.n_entries / (double)n);
   if (st == KMI_OK && scratch.n_entries) {
     st = ws_get(ctx, WS_OUTPUT, (scratch.n_entries + 64) * 2 * sizeof(uint64_t), &p);   // (WS_INPUT2 is the re-layout's)
@@ -2877,13 +2965,18 @@ static kmi_status sk_produce_w(kmi_index *idx, const uint8_t *bytes_dev, size_t 
   *produced = 0; *recs_out = nullptr; *n_records = 0;
   for (uint32_t r = 0; r < nranks; ++r) send_counts[r] = 0;
   if (n_bytes == 0) { *produced = 1; return KMI_OK; }
-  FastqScan sc;
-  KMI_TRY(fastq_scan(ctx, &idx->cfg, bytes_dev, n_bytes, &sc, false));
-  if (sc.n_tuples == 0) { KMI_TRY(fastq_length_verdict(ctx)); *produced = 1; return KMI_OK; }
   const uint32_t lp = 31u - (uint32_t)__builtin_clz(nranks);
   SkFront f;
-  KMI_TRY((sk_front_end<W>(ctx, &idx->cfg, idx->shape, sc, lp, &f, out, out_cap)));
-  if (!f.ok) return KMI_OK;
+  bool took = false;
+  KMI_TRY((sk_front_fast<W>(ctx, &idx->cfg, idx->shape, bytes_dev, n_bytes, lp, &f, &took, out, out_cap)));
+  if (took && f.ok && f.n_kmers == 0) { *produced = 1; return KMI_OK; }
+  if (!took || !f.ok) {
+    FastqScan sc;
+    KMI_TRY(fastq_scan(ctx, &idx->cfg, bytes_dev, n_bytes, &sc, false));
+    if (sc.n_tuples == 0) { KMI_TRY(fastq_length_verdict(ctx)); *produced = 1; return KMI_OK; }
+    KMI_TRY((sk_front_end<W>(ctx, &idx->cfg, idx->shape, sc, lp, &f, out, out_cap)));
+    if (!f.ok) return KMI_OK;
+  }
   const uint32_t per = (uint32_t)kNumCoarse / nranks;
   for (uint32_t c = 0; c < (uint32_t)kNumCoarse; ++c) send_counts[c / per] += f.h_cnt[c];
   *recs_out = f.recs; *n_records = f.n_records; *produced = 1;
@@ -2935,16 +3028,33 @@ static uint32_t sk_width_of(const kmi_index *idx) {
              ? sk_window_of(idx->shape.k) : 0u;
 }
 
+template <int W>
+static kmi_status build_superkmer_fast_w(kmi_index *idx, const uint8_t *bytes_dev, size_t n_bytes, bool *done) {
+  *done = false;
+  SkFront f;
+  bool took = false;
+  KMI_TRY((sk_front_fast<W>(idx->ctx, &idx->cfg, idx->shape, bytes_dev, n_bytes, 0u, &f, &took)));
+  if (!took || !f.ok) return KMI_OK;
+  *done = true;
+  if (f.n_kmers == 0) return KMI_OK;
+  return sk_back_end<W>(idx, f.recs, f.n_records, f.h_cnt, f.h_base, f.wg_off, f.n_kmers, 0u);
+}
+
 static kmi_status index_build_fused(kmi_index *idx, const uint8_t *bytes_dev, size_t n_bytes) {
   const uint32_t w = (idx->shape.n_words == 1 && idx->shape.bits == 2 && idx->ctx->fused_superkmer) ? sk_window_of(idx->shape.k) : 0u;
   if (w) {
     kmi_ctx *ctx = idx->ctx;
+    bool done = false;
+    // one pass over the bytes when the input allows it (kmi_front.h) ...
+    kmi_status st = w == 19u ? build_superkmer_fast_w<19>(idx, bytes_dev, n_bytes, &done) : (w == 13u ? build_superkmer_fast_w<13>(idx, bytes_dev, n_bytes, &done)
+                  : (w == 11u ? build_superkmer_fast_w<11>(idx, bytes_dev, n_bytes, &done) : build_superkmer_fast_w<7>(idx, bytes_dev, n_bytes, &done)));
+    if (st != KMI_OK || done) return st;
+    // ... else the general front end: scan (which words parse errors), list, minimizer
     FastqScan sc;
     KMI_TRY(fastq_scan(ctx, &idx->cfg, bytes_dev, n_bytes, &sc, false));
     if (sc.n_tuples == 0) return KMI_OK;
-    bool done = false;
-    kmi_status st = w == 19u ? build_superkmer_w<19>(idx, sc, &done) : (w == 13u ? build_superkmer_w<13>(idx, sc, &done)
-                  : (w == 11u ? build_superkmer_w<11>(idx, sc, &done) : build_superkmer_w<7>(idx, sc, &done)));
+    st = w == 19u ? build_superkmer_w<19>(idx, sc, &done) : (w == 13u ? build_superkmer_w<13>(idx, sc, &done)
+       : (w == 11u ? build_superkmer_w<11>(idx, sc, &done) : build_superkmer_w<7>(idx, sc, &done)));
     if (st != KMI_OK || done) return st;
   }
   KMI_DISPATCH(idx->shape, build_fused_impl, idx, bytes_dev, n_bytes);

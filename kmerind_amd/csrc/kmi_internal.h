@@ -93,6 +93,9 @@ struct kmi_ctx {
   bool force_dist = false;       // KMI_FORCE_DIST=1: the *_dist_* entry points run their exchange even with one rank (RCCL self exchange: tests)
   uint32_t sk_level_hint = 0;    // sk_reduce: filter bits the buckets of the next build start with (majority of the last build)
   float sk_inv_dup = 0.f;        // sk_reduce: distinct k-mers per k-mer occurrence of the last build (a bucket's expected fill; 0: unknown)
+  bool front_fused = true;       // FASTQ front end of the super-k-mer build in one pass (kmi_front.h); KMI_FRONT=general: scan + list + minimizer
+  uint32_t front_waves = 0;      // resident wavefronts of the front kernel (ranges of a large input); 0: not asked yet
+  uint64_t front_min_range = 64ull << 10;   // smallest byte range of a wavefront (KMI_FRONT_MIN_RANGE: tests shrink it)
   uint64_t sparse_min = 1ull << 26;   // output slots from which a super-k-mer build leaves its index in the sparse form (KMI_SPARSE_MIN)
   int sk_dbg = 0;                // KMI_SK_DBG: timing experiments of sk_reduce (results are wrong when set)
   bool fa_part_set = false;      // kmi_ctx_set_fasta_partition

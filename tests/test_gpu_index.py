@@ -622,7 +622,7 @@ def test_superkmer_build_ran_and_matches_oracle(ctx, k, strand):
     idx.build(data[:half])
     names = {p["name"] for p in ctx.profile_get() if p["launches"]}
     ctx.profile(False)
-    assert {"sk_minimizer", "sk_scatter", "sk_reduce"} <= names and "fastq_scatter" not in names, names
+    assert {"sk_front", "sk_scatter", "sk_reduce"} <= names and "fastq_scatter" not in names and "fastq_scan_tiles" not in names, names
     om = orc.CountMap(s, STRAND[strand])
     om.insert(orc.extract(s, data[:half], orc.FASTQ)["kmers"])
     _same_map(idx, om)
@@ -679,6 +679,84 @@ def test_sparse_index_after_superkmer_build(monkeypatch, k, strand):
     c2.profile(False)
     idx.close()
     c2.close()
+
+
+def _fastq_variant(rng, n_reads, kind):
+    """FASTQ text the one-pass front end has to get right or hand over: ragged read lengths, long headers, CRLF, blank lines, lower
+    case and N bases, quality lines that start with '@' or '+', no EOL at the end"""
+    out = []
+    for i in range(n_reads):
+        L = int(rng.integers(20, 260)) if kind != "fixed" else 150
+        seq = "".join("ACGT"[c] for c in rng.integers(0, 4, L))
+        if kind == "lowerN" and i % 7 == 0:
+            seq = seq[:L // 3] + "N" * 5 + seq[L // 3 + 5:].lower()
+        qual = "".join(chr(int(c)) for c in rng.integers(35, 74, L))
+        if i % 5 == 0: qual = "@" + qual[1:]
+        if i % 11 == 0: qual = "+" + qual[1:]
+        hdr = "@r%d %s" % (i, "x" * int(rng.integers(0, 40)))
+        eol = "\r\n" if kind == "crlf" else "\n"
+        rec = hdr + eol + seq + eol + "+" + (hdr[1:] if i % 3 == 0 else "") + eol + qual + eol
+        if kind == "blank" and i % 13 == 0: rec += eol
+        out.append(rec)
+    txt = "".join(out)
+    if kind == "noeol": txt = txt.rstrip("\r\n")
+    return np.frombuffer(txt.encode(), dtype=np.uint8).copy()
+
+
+@pytest.mark.parametrize("kind", ["fixed", "ragged", "crlf", "blank", "lowerN", "noeol"])
+@pytest.mark.parametrize("k,strand", [(31, "canonical"), (21, "single")])
+def test_one_pass_front_end_matches_general_path(monkeypatch, kind, k, strand):
+    """kmi_front.h: EOL scan, line roles, packing and the minimizer walk in one pass, every wavefront on a byte range of its own
+    whose first line index is inferred and chained afterwards. Ranges of 2 KB make hundreds of inferences on a small input;
+    the index must be the oracle's whatever the text looks like (and the kernels must be the one-pass ones)."""
+    import kmerind_amd as K
+    monkeypatch.setenv("KMI_FRONT_MIN_RANGE", "2048")
+    c2 = K.Context(0)
+    rng = np.random.default_rng(hash((kind, k)) & 0xffff)
+    data = _fastq_variant(rng, 1500, kind)
+    s = orc.kspec(k, orc.DNA)
+    idx = K.CountIndex(c2, K.make_config(k, "DNA", strand=strand))
+    c2.profile(True)
+    c2.profile_reset()
+    idx.build(data)
+    names = {p["name"] for p in c2.profile_get() if p["launches"]}
+    c2.profile(False)
+    assert "sk_front" in names and "fastq_scan_tiles" not in names, names
+    om = orc.CountMap(s, STRAND[strand])
+    om.insert(orc.extract(s, data, orc.FASTQ)["kmers"])
+    _same_map(idx, om)
+    idx.close()
+    c2.close()
+
+
+@pytest.mark.parametrize("damage", ["no_at", "no_plus", "qual_short", "first_byte"])
+def test_one_pass_front_end_hands_malformed_input_to_the_general_path(monkeypatch, damage):
+    """Whatever the one-pass front end is not sure about goes to the general path, which words the error exactly as before."""
+    import kmerind_amd as K
+    monkeypatch.setenv("KMI_FRONT_MIN_RANGE", "2048")
+    c2 = K.Context(0)
+    rng = np.random.default_rng(3)
+    txt = bytes(_fastq_variant(rng, 400, "fixed")).decode()
+    lines = txt.split("\n")                      # four lines per record, no blank ones in this variant
+    i = 4 * 250
+    if damage == "no_at": lines[i] = "r" + lines[i][1:]
+    if damage == "no_plus": lines[i + 2] = "-" + lines[i + 2][1:]
+    if damage == "qual_short": lines[i + 3] = lines[i + 3][:-3]
+    bad = "\n".join(lines)
+    if damage == "first_byte": bad = "\n" + txt
+    data = np.frombuffer(bad.encode(), dtype=np.uint8).copy()
+    idx = K.CountIndex(c2, K.make_config(31, "DNA", strand="canonical"))
+    with pytest.raises(K._lib.KmiError) as e1:
+        idx.build(data)
+    monkeypatch.setenv("KMI_FRONT", "general")
+    c3 = K.Context(0)
+    idx3 = K.CountIndex(c3, K.make_config(31, "DNA", strand="canonical"))
+    with pytest.raises(K._lib.KmiError) as e3:
+        idx3.build(data)
+    assert str(e1.value) == str(e3.value)
+    assert idx.local_size() == 0
+    idx.close(); idx3.close()
+    c2.close(); c3.close()
 
 
 def test_kmer_pipeline_still_selectable(monkeypatch):
