@@ -72,6 +72,10 @@ def main():
                          "pairs; 'raw' routes every k-mer occurrence as the reference does (kmi_extract_route_dev + insert); 'auto': "
                          "super-k-mers over 2 / 4 / 8 ranks, else combine when the rank's own reads cover the genome at least 2.5 "
                          "times (the pairs are then a fraction of the occurrences), else raw")
+    ap.add_argument("--transport", default="kmi", choices=["kmi", "torch"],
+                    help="N > 1 with the super-k-mer exchange: 'kmi' = the product's own RCCL layer (kmi_comm_* + kmi_index_build_dist_dev: "
+                         "chunked, the exchange of a chunk on its own stream beside the next chunk's front end: what Index::build_partition "
+                         "runs); 'torch' = kmerind_amd.dist over torch.distributed")
     ap.add_argument("--force-dist", action="store_true",
                     help="run the N > 1 code path (routing + all_to_all_single + insert) even with one rank: exercises the RCCL calls on one GPU")
     ap.add_argument("--chunks", type=int, default=4, help="N > 1: chunks per step (exchange of one overlaps parsing of the next)")
@@ -129,6 +133,8 @@ def main():
             n_reads * world // 1_000_000, genome_len // 1_000_000, "; N=8 is config 3 verbatim" if world != 8 else " = config 3 verbatim")
     peer_counts, verified = None, False
 
+    if args.force_dist:
+        os.environ["KMI_FORCE_DIST"] = "1"                 # the library's collectives run their exchange with one rank too
     stream = torch.cuda.current_stream(dev)
     ctx = K.Context(device=local_rank, rank=rank, nranks=world, stream=stream.cuda_stream)
     cfg = K.make_config(k, "DNA", strand="canonical", dist_hash="murmur", store_hash="murmur")
@@ -145,6 +151,24 @@ def main():
         ("superkmer" if world in (2, 4, 8) else ("combine" if local_cov >= 2.5 else "raw"))
     combine = multi and dist_mode in ("combine", "superkmer")     # both run through kmerind_amd.dist.DistributedCountIndex
     nch = 1
+    kmi_comm = None
+    use_kmi = multi and dist_mode == "superkmer" and args.transport == "kmi" and args.backend == "nccl"
+    if use_kmi:
+        # the product's own exchange: an ncclUniqueId from rank 0 goes round once (torch.distributed is only the messenger
+        # here, and the barrier / MAX of the timing contract), everything of the step is kmi_index_build_dist_dev
+        uid = torch.zeros(128, dtype=torch.uint8)
+        if rank == 0:
+            raw = (C.c_char * 128)()
+            ctx.check(L.lib.kmi_comm_unique_id(raw))
+            uid = torch.frombuffer(bytearray(bytes(raw)), dtype=torch.uint8).clone()
+        if world > 1:
+            uid_dev = uid.to(dev)
+            dist.broadcast(uid_dev, src=0)
+            uid = uid_dev.cpu()
+        kmi_comm = C.c_void_p()
+        ctx.check(L.lib.kmi_comm_create(ctx.h, (C.c_char * 128).from_buffer_copy(bytes(uid.numpy().tobytes())), C.byref(kmi_comm)))
+        nch = int(os.environ.get("KMI_DIST_CHUNKS", "4"))
+        combine = False
     if combine:
         # N > 1, combine-first (kmerind_amd.dist.DistributedCountIndex): local count index of the rank's reads (the one-rank
         # pipeline), split by KeyToRank, all_to_all_single of (k-mer, count) pairs + per-bucket counts, merge.
@@ -184,6 +208,10 @@ def main():
         idx.clear()
         if not multi:
             idx.build_device(d_bytes.data_ptr(), nbytes)
+            return
+        if use_kmi:
+            ctx.check(L.lib.kmi_index_build_dist_dev(idx.h, kmi_comm, C.c_void_p(d_bytes.data_ptr()), nbytes, 0))
+            verified = True
             return
         if combine:
             didx.build_device(d_bytes.data_ptr(), nbytes, dev, mode=dist_mode, bounds=sk_bounds)     # (its first exchange carries checksums)
@@ -298,10 +326,14 @@ def main():
         out = {"metric": "kmers_per_sec_indexed", "value": value, "unit": "k-mers/s", "n_gpus": world,
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
                "scaling": "weak" if world > 1 else None, "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-               "config": {"workload": "k=%d DNA CountIndex (canonical), %d synthetic %d-bp reads per GPU as 315-byte "
+               "config": {"input_residency": "hbm (the timed step starts from FASTQ bytes resident in device memory; the host-resident rate is extra.host_resident_kmers_per_s)",
+                          "workload": "k=%d DNA CountIndex (canonical), %d synthetic %d-bp reads per GPU as 315-byte "
                                       "FASTQ records, genome %d bp, seed %d%s" % (k, n_reads, read_len, genome_len, seed, workload_tag),
                           "kmers_per_step": total_kmers, "distinct_kmers": distinct,
                           "exchange": "none (1 rank)" if not multi else
+                          ("kmi_comm (the library's RCCL layer): grouped ncclSend / ncclRecv of 16-byte super-k-mer records (owner = the "
+                           "minimizer bucket's rank), %d record-aligned chunks per step, the exchange of a chunk on its own stream beside "
+                           "the next chunk's front end (kmi_index_build_dist_dev)" % nch) if use_kmi else
                           "%s all_to_all_single (counts + payload), %d chunks per step, overlapped with parsing" %
                           ("RCCL" if args.backend == "nccl" else "gloo (rehearsal)", nch) if not combine else
                           ("%%s all_to_all_single of 16-byte super-k-mer records (owner = the minimizer bucket's rank), %d chunks per step, "
@@ -310,7 +342,7 @@ def main():
                           ("RCCL" if args.backend == "nccl" else "gloo (rehearsal)")},
                "roofline": roofline}
         if multi:
-            out["config"].update({"dist_mode": dist_mode, "backend": backend_name, "rccl_ranks": group_ranks if args.backend == "nccl" else 0,
+            out["config"].update({"dist_mode": dist_mode, "transport": "kmi" if use_kmi else "torch", "backend": backend_name, "rccl_ranks": group_ranks if args.backend == "nccl" else 0,
                                   "group_ranks": group_ranks, "peer_bucket_max_over_mean": peer_ratio,
                                   "exchange_checksum": "verified on the first exchange" if verified else "not run"})
         if not multi and not args.no_extra:
@@ -319,6 +351,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(host, args, k, n_reads)
         print(json.dumps(out), flush=True)
 
+    if kmi_comm is not None:
+        L.lib.kmi_comm_destroy(kmi_comm)
     if combine:
         didx.close()
     else:

@@ -319,6 +319,12 @@ kmi_status kmi_comm_allreduce_sum_u64(kmi_comm *comm, uint64_t *value_host);
 kmi_status kmi_index_insert_dist_host(kmi_index *idx, kmi_comm *comm, const uint64_t *kmers, size_t n);
 kmi_status kmi_index_insert_tuples_dist_host(kmi_index *idx, kmi_comm *comm, const uint64_t *kmers, const uint64_t *values, size_t n);
 kmi_status kmi_index_build_dist_host(kmi_index *idx, kmi_comm *comm, const uint8_t *bytes, size_t n_bytes, uint64_t file_offset);
+/* the same with this rank's share already in HBM. The count index of one-word 2-bit k-mers (k >= 17, FASTQ, 2 / 4 / 8 ranks)
+ * travels as super-k-mer records in record-aligned chunks (KMI_DIST_CHUNKS, default 4): the records of chunk c are exchanged on
+ * the communicator's own stream while the front end of chunk c + 1 runs, the counts of a chunk carry every sender's largest
+ * message (so all ranks cut the transfer into the same pieces without another collective) and an exchange whose largest message
+ * exceeds every one that carried checksums before is verified on arrival. */
+kmi_status kmi_index_build_dist_dev(kmi_index *idx, kmi_comm *comm, const uint8_t *bytes_dev, size_t n_bytes, uint64_t file_offset);
 kmi_status kmi_index_count_dist_host(kmi_index *idx, kmi_comm *comm, const uint64_t *queries, size_t nq, kmi_results *out);
 kmi_status kmi_index_find_dist_host(kmi_index *idx, kmi_comm *comm, const uint64_t *queries, size_t nq, kmi_results *out);
 kmi_status kmi_index_erase_dist_host(kmi_index *idx, kmi_comm *comm, const uint64_t *queries, size_t nq, uint64_t *n_erased_local);
@@ -363,6 +369,10 @@ kmi_status kmi_index_sk_consume_dev(kmi_index *idx, const uint64_t *records_dev,
 kmi_status kmi_route_owner_dev(kmi_ctx *ctx, const kmi_config *cfg, const uint64_t *keys_dev, size_t n, uint32_t nranks,
                                uint64_t *out_keys_dev, uint64_t *send_counts_host);
 kmi_status kmi_index_owner_ranks(kmi_index *idx, uint32_t *nranks);
+/* *w = the minimizer window W the super-k-mer paths take for this index's FASTQ builds, 0 where they do not apply (multi-word
+ * k-mers, 3- / 4-bit alphabets, k < 17, a multimap, a context created with KMI_FUSED_PATH=kmer): callers that choose between
+ * the record exchange and another route decide from this, identically on every rank */
+kmi_status kmi_index_sk_width(kmi_index *idx, uint32_t *w);
 kmi_status kmi_index_set_owner_ranks(kmi_index *idx, uint32_t nranks);
 
 /* ---- de Bruijn graph nodes ------------------------------------------------------

@@ -120,6 +120,7 @@ SIGNATURES = {
     "kmi_index_insert_dist_host": (C.c_int, [_P, _P, _P, _sz]),
     "kmi_index_insert_tuples_dist_host": (C.c_int, [_P, _P, _P, _P, _sz]),
     "kmi_index_build_dist_host": (C.c_int, [_P, _P, _P, _sz, _u64]),
+    "kmi_index_build_dist_dev": (C.c_int, [_P, _P, _P, _sz, _u64]),
     "kmi_index_count_dist_host": (C.c_int, [_P, _P, _P, _sz, C.POINTER(Results)]),
     "kmi_index_find_dist_host": (C.c_int, [_P, _P, _P, _sz, C.POINTER(Results)]),
     "kmi_index_erase_dist_host": (C.c_int, [_P, _P, _P, _sz, C.POINTER(_u64)]),
@@ -130,6 +131,7 @@ SIGNATURES = {
     "kmi_index_sk_consume_dev": (C.c_int, [_P, _P, _sz, _u32]),
     "kmi_route_owner_dev": (C.c_int, [_P, _CFG, _P, _sz, _u32, _P, _P]),
     "kmi_index_owner_ranks": (C.c_int, [_P, C.POINTER(_u32)]),
+    "kmi_index_sk_width": (C.c_int, [_P, C.POINTER(_u32)]),
     "kmi_index_set_owner_ranks": (C.c_int, [_P, _u32]),
     "kmi_dbg_create": (C.c_int, [_P, _CFG, _u32, C.POINTER(_P)]),
     "kmi_dbg_destroy": (C.c_int, [_P]),

@@ -43,6 +43,7 @@ class Context:
             raise L.KmiError(st, "kmi_ctx_create failed (no usable HIP device? there is no CPU fallback)")
         self.h = h
         self.rank, self.nranks, self.device = rank, nranks, device
+        self.stream = int(stream or 0)
 
     def close(self):
         if getattr(self, "h", None):
@@ -189,7 +190,8 @@ class CountIndex:
 
     def close(self):
         if getattr(self, "h", None):
-            lib.kmi_index_destroy(self.h)
+            if getattr(self.ctx, "h", None):   # (a context that is gone took the device blocks with it: nothing to hand back through it)
+                lib.kmi_index_destroy(self.h)
             self.h = None
 
     def __del__(self):

@@ -168,6 +168,7 @@ kmi_status kmi_ctx_create(int device, int rank, int nranks, void *stream, kmi_ct
   kmi_ctx *ctx = new kmi_ctx();
   if (const char *fp = getenv("KMI_FUSED_PATH")) ctx->fused_superkmer = strcmp(fp, "kmer") != 0;
   if (const char *dg = getenv("KMI_SK_DBG")) ctx->sk_dbg = atoi(dg);
+  if (const char *dc = getenv("KMI_DIST_CHUNKS")) { ctx->dist_chunks = (uint32_t)atoi(dc); if (ctx->dist_chunks < 1) ctx->dist_chunks = 1; if (ctx->dist_chunks > 64) ctx->dist_chunks = 64; }
   if (const char *fr = getenv("KMI_FRONT")) ctx->front_fused = strcmp(fr, "general") != 0;
   if (const char *mr = getenv("KMI_FRONT_MIN_RANGE")) { ctx->front_min_range = strtoull(mr, nullptr, 10); ctx->front_min_range = (ctx->front_min_range + 2047) / 2048 * 2048; if (!ctx->front_min_range) ctx->front_min_range = 2048; }
   if (const char *sm = getenv("KMI_SPARSE_MIN")) ctx->sparse_min = strtoull(sm, nullptr, 10);

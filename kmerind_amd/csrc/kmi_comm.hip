@@ -81,6 +81,9 @@ struct kmi_comm {
   ncclComm_t_ nccl = nullptr;
   int rank = 0, nranks = 1;
   bool verified = false;          // the first payload exchange carries checksums
+  uint64_t verified_bytes = 0;    // the largest peer message an exchange with checksums has carried so far
+  hipStream_t xstream = nullptr;  // payload exchanges that overlap the context's stream (comm_all_to_all_v_async)
+  hipEvent_t ev_ready = nullptr, ev_done = nullptr;
   uint64_t *d_small = nullptr;    // [8 * nranks + 8] device scratch: counts, sums, offsets
   uint64_t *h_small = nullptr;    // pinned mirror
 };
@@ -114,15 +117,19 @@ kmi_status comm_all_to_all_counts(kmi_comm *c, const uint64_t *send_counts, uint
   return KMI_OK;
 }
 
-static kmi_status a2a_bytes(kmi_comm *c, const char *send, const uint64_t *sbytes, char *recv, const uint64_t *rbytes) {
+static kmi_status a2a_bytes(kmi_comm *c, const char *send, const uint64_t *sbytes, char *recv, const uint64_t *rbytes,
+                            hipStream_t on = nullptr, uint64_t known_gmax = ~0ull, uint64_t *gmax_out = nullptr) {
+  // on: the stream the transfers are queued on (default: the context's); known_gmax: the largest peer message anywhere when
+  // the caller has it already (it rode on the count exchange) -- no all-reduce, no host synchronisation in here then
   kmi_ctx *ctx = c->ctx;
   const int p = c->nranks;
+  hipStream_t st = on ? on : ctx->stream;
   constexpr uint64_t kPiece = (1ull << 30) - 4096;   // per peer and transfer
   uint64_t biggest = 0;
   for (int r = 0; r < p; ++r) { biggest = std::max(biggest, sbytes[r]); biggest = std::max(biggest, rbytes[r]); }
   // the number of pieces must agree on every rank: it follows from the largest message anywhere
-  uint64_t gmax = biggest;
-  if (p > 1) {
+  uint64_t gmax = known_gmax != ~0ull ? std::max(known_gmax, biggest) : biggest;
+  if (p > 1 && known_gmax == ~0ull) {
     c->h_small[4 * p] = biggest;
     KMI_HIP(ctx, hipMemcpyAsync(c->d_small + 4 * p, c->h_small + 4 * p, sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
     KMI_NCCL(c, rccl().AllReduce(c->d_small + 4 * p, c->d_small + 4 * p + 1, 1, kNcclUint64, 2 /* ncclMax */, c->nccl, ctx->stream));
@@ -130,6 +137,7 @@ static kmi_status a2a_bytes(kmi_comm *c, const char *send, const uint64_t *sbyte
     KMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
     gmax = c->h_small[4 * p + 1];
   }
+  if (gmax_out) *gmax_out = gmax;
   const uint64_t pieces = gmax ? (gmax + kPiece - 1) / kPiece : 1;
   std::vector<uint64_t> soff(p + 1, 0), roff(p + 1, 0);
   for (int r = 0; r < p; ++r) { soff[r + 1] = soff[r] + sbytes[r]; roff[r + 1] = roff[r] + rbytes[r]; }
@@ -138,8 +146,8 @@ static kmi_status a2a_bytes(kmi_comm *c, const char *send, const uint64_t *sbyte
     for (int r = 0; r < p; ++r) {
       const uint64_t slo = sbytes[r] * q / pieces, shi = sbytes[r] * (q + 1) / pieces;
       const uint64_t rlo = rbytes[r] * q / pieces, rhi = rbytes[r] * (q + 1) / pieces;
-      if (shi > slo) KMI_NCCL(c, rccl().Send(send + soff[r] + slo, shi - slo, kNcclUint8, r, c->nccl, ctx->stream));
-      if (rhi > rlo) KMI_NCCL(c, rccl().Recv(recv + roff[r] + rlo, rhi - rlo, kNcclUint8, r, c->nccl, ctx->stream));
+      if (shi > slo) KMI_NCCL(c, rccl().Send(send + soff[r] + slo, shi - slo, kNcclUint8, r, c->nccl, st));
+      if (rhi > rlo) KMI_NCCL(c, rccl().Recv(recv + roff[r] + rlo, rhi - rlo, kNcclUint8, r, c->nccl, st));
     }
     KMI_NCCL(c, rccl().GroupEnd());
   }
@@ -154,10 +162,14 @@ kmi_status comm_all_to_all_v(kmi_comm *c, const void *send_dev, const uint64_t *
   const int p = c->nranks;
   std::vector<uint64_t> sb(p), rb(p);
   for (int r = 0; r < p; ++r) { sb[r] = send_counts[r] * elem_bytes; rb[r] = recv_counts[r] * elem_bytes; }
-  KMI_TRY(a2a_bytes(c, (const char *)send_dev, sb.data(), (char *)recv_dev, rb.data()));
-  if (!c->verified && elem_bytes % 8 == 0) {
-    // first exchange of this communicator: the sender's sum of every message travels behind it and is compared on arrival
+  uint64_t gmax = 0;
+  KMI_TRY(a2a_bytes(c, (const char *)send_dev, sb.data(), (char *)recv_dev, rb.data(), nullptr, ~0ull, &gmax));
+  if ((!c->verified || gmax > c->verified_bytes) && elem_bytes % 8 == 0) {
+    // the first exchange of this communicator, and every later one whose largest peer message is larger than any that was
+    // checked before (the 1 GiB behaviour is a property of message size): the sender's sum of every message travels behind it
+    // and is compared on arrival (gmax is the same on every rank, so all ranks verify or none)
     c->verified = true;
+    c->verified_bytes = std::max(c->verified_bytes, gmax);
     uint64_t *h = c->h_small + 5 * p + 2;           // [p + 1] send offsets (words), [p + 1] recv offsets
     h[0] = 0;
     for (int r = 0; r < p; ++r) h[r + 1] = h[r] + sb[r] / 8;
@@ -180,6 +192,57 @@ kmi_status comm_all_to_all_v(kmi_comm *c, const void *send_dev, const uint64_t *
     for (int r = 0; r < p; ++r)
       if (got[r] != got[p + r]) return set_err(ctx, KMI_ERR_DEVICE, "all-to-all payload corrupted: a peer message does not match its sender's checksum%s", "");
   }
+  return KMI_OK;
+}
+
+// counts with a rider: every peer also receives the sender's largest message (bytes), so all ranks know the largest message of
+// the coming payload exchange without another collective; a sender that has nothing valid to send says so with count = ~0
+kmi_status comm_all_to_all_counts2(kmi_comm *c, const uint64_t *send_counts, uint64_t my_largest_bytes, uint64_t *recv_counts, uint64_t *largest_bytes) {
+  kmi_ctx *ctx = c->ctx;
+  const int p = c->nranks;
+  uint64_t *d_s = c->d_small, *d_r = c->d_small + 2 * p;
+  for (int r = 0; r < p; ++r) { c->h_small[2 * r] = send_counts[r]; c->h_small[2 * r + 1] = my_largest_bytes; }
+  KMI_HIP(ctx, hipMemcpyAsync(d_s, c->h_small, sizeof(uint64_t) * 2 * p, hipMemcpyHostToDevice, ctx->stream));
+  KMI_NCCL(c, rccl().GroupStart());
+  for (int r = 0; r < p; ++r) {
+    KMI_NCCL(c, rccl().Send(d_s + 2 * r, 2 * sizeof(uint64_t), kNcclUint8, r, c->nccl, ctx->stream));
+    KMI_NCCL(c, rccl().Recv(d_r + 2 * r, 2 * sizeof(uint64_t), kNcclUint8, r, c->nccl, ctx->stream));
+  }
+  KMI_NCCL(c, rccl().GroupEnd());
+  KMI_HIP(ctx, hipMemcpyAsync(c->h_small + 2 * p, d_r, sizeof(uint64_t) * 2 * p, hipMemcpyDeviceToHost, ctx->stream));
+  KMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  uint64_t big = 0;
+  for (int r = 0; r < p; ++r) { recv_counts[r] = c->h_small[2 * p + 2 * r]; big = std::max(big, c->h_small[2 * p + 2 * r + 1]); }
+  *largest_bytes = big;
+  return KMI_OK;
+}
+
+// all2allv that does not hold the context's stream: queued on the communicator's own stream behind everything the context's
+// stream holds now (the send buffer's producer), so the caller's next kernels run beside the transfer. No host synchronisation.
+// largest_bytes: the largest peer message anywhere (comm_all_to_all_counts2). An exchange larger than any that carried checksums
+// so far is done the synchronous, verified way instead. comm_exchange_join orders the context's stream behind the transfers.
+kmi_status comm_all_to_all_v_async(kmi_comm *c, const void *send_dev, const uint64_t *send_counts, void *recv_dev, const uint64_t *recv_counts,
+                                   size_t elem_bytes, uint64_t largest_bytes) {
+  kmi_ctx *ctx = c->ctx;
+  const int p = c->nranks;
+  if (!c->verified || largest_bytes > c->verified_bytes)
+    return comm_all_to_all_v(c, send_dev, send_counts, recv_dev, recv_counts, elem_bytes);
+  std::vector<uint64_t> sb(p), rb(p);
+  for (int r = 0; r < p; ++r) { sb[r] = send_counts[r] * elem_bytes; rb[r] = recv_counts[r] * elem_bytes; }
+  KMI_HIP(ctx, hipEventRecord(c->ev_ready, ctx->stream));
+  KMI_HIP(ctx, hipStreamWaitEvent(c->xstream, c->ev_ready, 0));
+  KMI_TRY(a2a_bytes(c, (const char *)send_dev, sb.data(), (char *)recv_dev, rb.data(), c->xstream, largest_bytes));
+  return KMI_OK;
+}
+kmi_status comm_exchange_join(kmi_comm *c) {
+  kmi_ctx *ctx = c->ctx;
+  KMI_HIP(ctx, hipEventRecord(c->ev_done, c->xstream));
+  KMI_HIP(ctx, hipStreamWaitEvent(ctx->stream, c->ev_done, 0));
+  return KMI_OK;
+}
+// the host waits for the transfers queued so far (a send buffer is about to be rewritten)
+kmi_status comm_exchange_wait(kmi_comm *c) {
+  KMI_HIP(c->ctx, hipStreamSynchronize(c->xstream));
   return KMI_OK;
 }
 
@@ -229,7 +292,10 @@ kmi_status kmi_comm_create(kmi_ctx *ctx, const void *id, kmi_comm **out) {
     return kmi::set_err(ctx, KMI_ERR_DEVICE, "ncclCommInitRank failed: %s", rccl().GetErrorString ? rccl().GetErrorString(r) : "rccl error");
   }
   const size_t small = sizeof(uint64_t) * (8 * (size_t)c->nranks + 16);
-  if (hipMalloc((void **)&c->d_small, small) != hipSuccess || hipHostMalloc((void **)&c->h_small, small) != hipSuccess) {
+  if (hipMalloc((void **)&c->d_small, small) != hipSuccess || hipHostMalloc((void **)&c->h_small, small) != hipSuccess ||
+      hipStreamCreateWithFlags(&c->xstream, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming) != hipSuccess) {
     kmi_comm_destroy(c);
     return kmi::set_err(ctx, KMI_ERR_NOMEM, "communicator scratch%s", "");
   }
@@ -241,7 +307,11 @@ kmi_status kmi_comm_destroy(kmi_comm *c) {
   if (!c) return KMI_OK;
   (void)hipSetDevice(c->ctx->device);
   (void)hipStreamSynchronize(c->ctx->stream);
+  if (c->xstream) (void)hipStreamSynchronize(c->xstream);
   if (c->nccl && rccl().ok) (void)rccl().CommDestroy(c->nccl);
+  if (c->xstream) (void)hipStreamDestroy(c->xstream);
+  if (c->ev_ready) (void)hipEventDestroy(c->ev_ready);
+  if (c->ev_done) (void)hipEventDestroy(c->ev_done);
   if (c->d_small) (void)hipFree(c->d_small);
   if (c->h_small) (void)hipHostFree(c->h_small);
   delete c;

@@ -2180,7 +2180,7 @@ __global__ __launch_bounds__(256) void bucket_compact_kernel(const uint64_t *__r
 // Q: per fine bucket query. mode 0 = count (emit every distinct query key with 0/1),
 // 1 = find (emit (key, stored count) of hits), 2 = erase (emit surviving index entries)
 // ---------------------------------------------------------------------------
-enum QueryMode { Q_COUNT = 0, Q_FIND = 1, Q_ERASE = 2 };
+enum QueryMode { Q_COUNT = 0, Q_FIND = 1, Q_ERASE = 2, Q_HITS = 3 /* find without output: hits per bucket (sizes a multimap find) */ };
 
 // VW = 0: counting map (values are u32 counts in idx_vals32); VW > 0: multimap (every entry carries
 // VW 64-bit value words in idx_mvals, a key may occur many times). Output value stride OW = max(1, VW).
@@ -2191,8 +2191,10 @@ __global__ __launch_bounds__((QTabCfg<NW>::NT)) void bucket_query_kernel(int mod
                                                                        const uint64_t *__restrict__ idx_off, uint64_t *__restrict__ tmp_keys,
                                                                        uint64_t *__restrict__ tmp_vals64, uint32_t *__restrict__ tmp_vals32,
                                                                        uint32_t *__restrict__ out_cnt, uint32_t *__restrict__ flags,
-                                                                       bool emit_index, const uint32_t *__restrict__ idx_cnt = nullptr) {
+                                                                       bool emit_index, const uint32_t *__restrict__ idx_cnt = nullptr,
+                                                                       const uint64_t *__restrict__ out_off = nullptr) {
   // idx_cnt (sparse index, count / find of a counting map only): bucket b holds idx_cnt[b] entries from idx_off[b]
+  // out_off (find of a multimap after a Q_HITS pass): bucket b's results go to out_off[b] -- compact, no slot per index entry
   // emit_index (find on a counting map): the value of a hit is the entry's position in the index arrays instead of its count
   // (the de Bruijn node map gathers the node's edge counts from there)
   KMI_TABLE_LDS_CFG(NW, QTabCfg<NW>)
@@ -2203,7 +2205,7 @@ __global__ __launch_bounds__((QTabCfg<NW>::NT)) void bucket_query_kernel(int mod
   // output slot base: count results are bounded by the bucket's queries; erase survivors and multimap
   // find hits by the bucket's entries
   const bool by_entries = (mode == Q_ERASE) || (VW > 0 && mode == Q_FIND);
-  const uint64_t tmp0 = by_entries ? ib : qb;
+  const uint64_t tmp0 = out_off ? out_off[b] : (by_entries ? ib : qb);
   uint32_t *s_out = &s_ctl[4];
   auto emit_entry = [&](uint32_t pos, const uint64_t (&k)[NW], uint64_t i) {
 #pragma unroll
@@ -2264,6 +2266,8 @@ __global__ __launch_bounds__((QTabCfg<NW>::NT)) void bucket_query_kernel(int mod
         } else if (mode == Q_FIND) {
           const uint32_t pos = wave_alloc(s_out, hit);
           if (hit) emit_entry(pos, k, i);
+        } else if (mode == Q_HITS) {
+          (void)wave_alloc(s_out, hit);
         } else {
           const uint32_t pos = wave_alloc(s_out, !hit);
           if (!hit) emit_entry(pos, k, i);
@@ -2972,6 +2976,7 @@ static kmi_status sk_produce_w(kmi_index *idx, const uint8_t *bytes_dev, size_t 
   if (took && f.ok && f.n_kmers == 0) { *produced = 1; return KMI_OK; }
   if (!took || !f.ok) {
     FastqScan sc;
+    KMI_TRY(align_input(ctx, &bytes_dev, n_bytes));   // (the scan's 16-byte loads)
     KMI_TRY(fastq_scan(ctx, &idx->cfg, bytes_dev, n_bytes, &sc, false));
     if (sc.n_tuples == 0) { KMI_TRY(fastq_length_verdict(ctx)); *produced = 1; return KMI_OK; }
     KMI_TRY((sk_front_end<W>(ctx, &idx->cfg, idx->shape, sc, lp, &f, out, out_cap)));
@@ -3282,7 +3287,7 @@ static kmi_status index_insert_pairs(kmi_index *idx, const uint64_t *recs_dev, s
 // queries: results compacted into out_keys_dev / out_vals_dev (max(1, val_words) u64 per result)
 template <int NW, int BITS, int VW>
 static kmi_status query_vw(kmi_index *idx, int mode, const uint64_t *q_dev, size_t nq, uint64_t *out_keys_dev, uint64_t *out_vals_dev,
-                           uint64_t out_capacity, uint64_t *n_out) {
+                           uint64_t out_capacity, uint64_t *n_out, uint64_t **auto_keys = nullptr, uint64_t **auto_vals = nullptr) {
   kmi_ctx *ctx = idx->ctx;
   constexpr int OW = VW ? VW : 1;
   if (n_out) *n_out = 0;
@@ -3292,7 +3297,39 @@ static kmi_status query_vw(kmi_index *idx, int mode, const uint64_t *q_dev, size
   Partitioned part;
   KMI_TRY((partition_impl<NW, BITS>(ctx, &idx->cfg, idx->shape, q_dev, nq, true, WS_QUERY_A, WS_QUERY_B, &part, idx->has_data ? idx->layout_w : 0u)));
   void *p;
-  const bool by_entries = (mode == Q_ERASE) || (VW > 0 && mode == Q_FIND);
+  if (VW > 0 && mode == Q_FIND) {
+    // a multimap find returns every entry of a queried key: sized by a pass that only counts the hits per bucket, then written
+    // compactly (a slot per index entry, as erase uses, would be the size of the index -- 72 GB on one rank of config 5)
+    KMI_TRY(ws_get(ctx, WS_BUCKET_CNT, sizeof(uint32_t) * kNumFine, &p)); uint32_t *out_cnt = (uint32_t *)p;
+    KMI_TRY(ws_get(ctx, WS_BUCKET_OFF, sizeof(uint64_t) * (kNumFine + 1), &p)); uint64_t *res_off = (uint64_t *)p;
+    {
+      ProfScope ps(ctx, "bucket_query_hits", nq);
+      hipLaunchKernelGGL((bucket_query_kernel<NW, VW>), dim3(kNumFine), dim3(QTabCfg<NW>::NT), 0, ctx->stream, (int)Q_HITS, (const uint64_t *)part.keys,
+                         (const uint64_t *)part.fine_off, (const uint64_t *)idx->keys, (const uint32_t *)idx->vals, (const uint64_t *)idx->mvals,
+                         (const uint64_t *)(idx->has_data ? idx->bucket_off : nullptr), (uint64_t *)nullptr, (uint64_t *)nullptr, (uint32_t *)nullptr,
+                         out_cnt, ctx->d_flags, false, (const uint32_t *)nullptr, (const uint64_t *)nullptr);
+      hipLaunchKernelGGL(bucket_offsets_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const uint32_t *)out_cnt, res_off, ctx->d_totals, 5);
+    }
+    uint64_t total = 0;
+    KMI_TRY(read_total(ctx, 5, &total));
+    if (n_out) *n_out = total;
+    if (auto_keys) {   // the caller takes the results where this function puts them
+      KMI_TRY(ws_get(ctx, WS_OUTPUT, (total ? total : 1) * NW * sizeof(uint64_t), &p)); out_keys_dev = (uint64_t *)p;
+      KMI_TRY(ws_get(ctx, WS_OUTPUT2, (total ? total : 1) * OW * sizeof(uint64_t), &p)); out_vals_dev = (uint64_t *)p;
+      *auto_keys = out_keys_dev; *auto_vals = out_vals_dev;
+    } else if (total > out_capacity) return set_err(ctx, KMI_ERR_OVERFLOW, "query: result capacity too small");
+    if (total) {
+      ProfScope ps(ctx, "bucket_query_find", nq);
+      hipLaunchKernelGGL((bucket_query_kernel<NW, VW>), dim3(kNumFine), dim3(QTabCfg<NW>::NT), 0, ctx->stream, (int)Q_FIND, (const uint64_t *)part.keys,
+                         (const uint64_t *)part.fine_off, (const uint64_t *)idx->keys, (const uint32_t *)idx->vals, (const uint64_t *)idx->mvals,
+                         (const uint64_t *)(idx->has_data ? idx->bucket_off : nullptr), out_keys_dev, out_vals_dev, (uint32_t *)out_vals_dev,
+                         out_cnt, ctx->d_flags, false, (const uint32_t *)nullptr, (const uint64_t *)res_off);
+    }
+    KMI_HIP(ctx, hipGetLastError());
+    KMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return KMI_OK;
+  }
+  const bool by_entries = (mode == Q_ERASE);
   const uint64_t cap = by_entries ? std::max<uint64_t>(idx->n_entries, 1) : nq;
   KMI_TRY(ws_get(ctx, WS_TMP_KEYS, cap * NW * sizeof(uint64_t), &p)); uint64_t *tmp_keys = (uint64_t *)p;
   KMI_TRY(ws_get(ctx, WS_TMP_VALS, cap * OW * sizeof(uint64_t), &p)); void *tmp_vals = p;
@@ -3351,15 +3388,16 @@ static kmi_status query_vw(kmi_index *idx, int mode, const uint64_t *q_dev, size
 
 template <int NW, int BITS>
 static kmi_status query_impl(kmi_index *idx, int mode, const uint64_t *q_dev, size_t nq, uint64_t *out_keys_dev, uint64_t *out_vals_dev,
-                             uint64_t out_capacity, uint64_t *n_out) {
+                             uint64_t out_capacity, uint64_t *n_out, uint64_t **auto_keys, uint64_t **auto_vals) {
   if (idx->val_words == 0) return query_vw<NW, BITS, 0>(idx, mode, q_dev, nq, out_keys_dev, out_vals_dev, out_capacity, n_out);
-  if (idx->val_words == 1) return query_vw<NW, BITS, 1>(idx, mode, q_dev, nq, out_keys_dev, out_vals_dev, out_capacity, n_out);
-  return query_vw<NW, BITS, 2>(idx, mode, q_dev, nq, out_keys_dev, out_vals_dev, out_capacity, n_out);
+  if (idx->val_words == 1) return query_vw<NW, BITS, 1>(idx, mode, q_dev, nq, out_keys_dev, out_vals_dev, out_capacity, n_out, auto_keys, auto_vals);
+  return query_vw<NW, BITS, 2>(idx, mode, q_dev, nq, out_keys_dev, out_vals_dev, out_capacity, n_out, auto_keys, auto_vals);
 }
 
 static kmi_status index_query(kmi_index *idx, int mode, const uint64_t *q_dev, size_t nq, uint64_t *out_keys_dev, uint64_t *out_vals_dev,
-                              uint64_t out_capacity, uint64_t *n_out) {
-  KMI_DISPATCH(idx->shape, query_impl, idx, mode, q_dev, nq, out_keys_dev, out_vals_dev, out_capacity, n_out);
+                              uint64_t out_capacity, uint64_t *n_out, uint64_t **auto_keys = nullptr, uint64_t **auto_vals = nullptr) {
+  // auto_keys / auto_vals (find of a multimap): the results are left in workspace buffers sized to the hits, returned here
+  KMI_DISPATCH(idx->shape, query_impl, idx, mode, q_dev, nq, out_keys_dev, out_vals_dev, out_capacity, n_out, auto_keys, auto_vals);
 }
 
 // results of a multimap find are bounded by the entries, everything else by the queries
@@ -3604,6 +3642,9 @@ static bool sk_rank_count(uint32_t p) { return p == 1u || p == 2u || p == 4u || 
 
 #include "kmi_debruijn.h"
 #include "kmi_update.h"
+
+struct kmi_comm;
+static kmi_status dist_state(kmi_index *idx, kmi_comm *comm, uint64_t *holders, uint64_t *owner_p, uint64_t *owner_any);
 
 extern "C" {
 
@@ -3871,12 +3912,14 @@ static kmi_status query_host(kmi_index *idx, int mode, const uint64_t *queries, 
   void *dq, *dk = nullptr, *dv = nullptr;
   KMI_TRY(ws_get(ctx, WS_INPUT, nq * nw * sizeof(uint64_t), &dq));
   KMI_HIP(ctx, hipMemcpyAsync(dq, queries, nq * nw * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
-  if (mode != Q_ERASE) {
+  const bool sized_inside = idx->val_words > 0 && mode == Q_FIND;   // a multimap find sizes its result buffers from a count of the hits
+  if (mode != Q_ERASE && !sized_inside) {
     KMI_TRY(ws_get(ctx, WS_OUTPUT, (bound ? bound : 1) * nw * sizeof(uint64_t), &dk));
     KMI_TRY(ws_get(ctx, WS_OUTPUT2, (bound ? bound : 1) * ow * sizeof(uint64_t), &dv));
   }
   uint64_t n = 0;
-  KMI_TRY(index_query(idx, mode, (const uint64_t *)dq, nq, (uint64_t *)dk, (uint64_t *)dv, bound, &n));
+  if (sized_inside) KMI_TRY(index_query(idx, mode, (const uint64_t *)dq, nq, nullptr, nullptr, 0, &n, (uint64_t **)&dk, (uint64_t **)&dv));
+  else KMI_TRY(index_query(idx, mode, (const uint64_t *)dq, nq, (uint64_t *)dk, (uint64_t *)dv, bound, &n));
   if (mode == Q_ERASE) { if (n_erased) *n_erased = n; return KMI_OK; }
   out->n = n;
   out->keys = (uint64_t *)malloc((n ? n : 1) * nw * sizeof(uint64_t));
@@ -4030,8 +4073,13 @@ kmi_status kmi_index_insert_dist_host(kmi_index *idx, kmi_comm *comm, const uint
   if (n) KMI_HIP(ctx, hipMemcpyAsync(d_in, kmers, n * kb, hipMemcpyHostToDevice, ctx->stream));
   std::vector<uint64_t> sc(p, 0), rc;
   // InputTransform + grouping by KeyToRank -- or by the owner of the minimizer's bucket when that is how the entries are distributed
-  if (idx->owner_lp && idx->n_entries) KMI_TRY(kmi_route_owner_dev(ctx, &idx->cfg, (const uint64_t *)d_in, n, (uint32_t)p, (uint64_t *)d_send, sc.data()));
-  else KMI_TRY(kmi_route_dev(ctx, &idx->cfg, (const uint64_t *)d_in, n, (uint32_t)p, (uint64_t *)d_send, sc.data()));
+  // (agreed over the ranks: a rank that happens to hold nothing must not route differently from its peers)
+  uint64_t holders = 0, owner_p = 0, owner_any = 0;
+  KMI_TRY(dist_state(idx, comm, &holders, &owner_p, &owner_any));
+  if (owner_any && holders) {
+    if (!idx->owner_lp) idx->owner_lp = 31u - (uint32_t)__builtin_clz((uint32_t)p);
+    KMI_TRY(kmi_route_owner_dev(ctx, &idx->cfg, (const uint64_t *)d_in, n, (uint32_t)p, (uint64_t *)d_send, sc.data()));
+  } else KMI_TRY(kmi_route_dev(ctx, &idx->cfg, (const uint64_t *)d_in, n, (uint32_t)p, (uint64_t *)d_send, sc.data()));
   uint64_t total = 0;
   KMI_TRY(dist_exchange(comm, d_send, sc.data(), kb, WS_DIST_B, &d_recv, rc, &total));
   return index_insert(idx, (const uint64_t *)d_recv, (size_t)total, false);
@@ -4061,67 +4109,183 @@ kmi_status kmi_index_insert_tuples_dist_host(kmi_index *idx, kmi_comm *comm, con
   return index_insert_records(idx, (const uint64_t *)d_recv, (size_t)total, true);   // (the transform is idempotent)
 }
 
-kmi_status kmi_index_build_dist_host(kmi_index *idx, kmi_comm *comm, const uint8_t *bytes, size_t n_bytes, uint64_t file_offset) {
+}  // extern "C"
+
+// one 64-bit all-reduce carries what every rank must agree on before it picks a route: field 0 (bits 0..15) ranks that hold
+// entries, field 1 (16..31) ranks whose entries are distributed by minimizer owner over exactly p ranks, field 2 (32..47) ranks
+// whose entries are distributed by owner at all
+static kmi_status dist_state(kmi_index *idx, kmi_comm *comm, uint64_t *holders, uint64_t *owner_p, uint64_t *owner_any) {
+  const int p = kmi::comm_size(comm);
+  uint64_t v = (idx->n_entries ? 1ull : 0ull) | ((idx->owner_lp && (1u << idx->owner_lp) == (uint32_t)p) ? 1ull << 16 : 0ull) | (idx->owner_lp ? 1ull << 32 : 0ull);
+  KMI_TRY(kmi::comm_allreduce_sum(comm, &v));
+  *holders = v & 0xffffu; *owner_p = (v >> 16) & 0xffffu; *owner_any = (v >> 32) & 0xffffu;
+  return KMI_OK;
+}
+
+// The count index over ranks through exchanged super-k-mer records, CHUNKED: the rank's share is cut into record-aligned chunks;
+// the records of chunk c travel on the communicator's stream while the front end of chunk c + 1 runs on the context's; the
+// counts of a chunk ride with the verdict ("this rank could not produce it": then every rank sends that chunk as k-mers to the
+// same owners afterwards) and with the sender's largest message. What arrived is consumed in one go.
+template <int W>
+static kmi_status build_dist_superkmer(kmi_index *idx, kmi_comm *comm, const uint8_t *d_bytes, size_t n_bytes, uint64_t file_offset) {
+  kmi_ctx *ctx = idx->ctx;
+  const int p = kmi::comm_size(comm);
+  const uint32_t lp = 31u - (uint32_t)__builtin_clz((uint32_t)p);
+  const uint32_t nch = (idx->cfg.seq_format == KMI_FMT_FASTQ) ? ctx->dist_chunks : 1u;
+  std::vector<uint64_t> cuts(nch + 1, 0);
+  if (n_bytes) {
+    if (nch > 1) KMI_TRY(kmi_fastq_partition_dev(ctx, d_bytes, n_bytes, nch, cuts.data()));
+    else cuts[1] = n_bytes;
+  }
+  // the receive pool: every rank's bytes are known after one all-reduce; a rank receives about a p-th of all records
+  uint64_t all_bytes = n_bytes;
+  KMI_TRY(kmi::comm_allreduce_sum(comm, &all_bytes));
+  uint64_t pool_cap = (uint64_t)((double)all_bytes / p * 0.06 * 1.3) + 65536;
+  void *pv;
+  KMI_TRY(ws_get(ctx, WS_DIST_B, pool_cap * 16, &pv));
+  uint64_t *pool = (uint64_t *)pv;
+  uint64_t pool_pos = 0;
+  bool pool_in_b = true;
+  uint64_t *sendbuf[2] = {nullptr, nullptr};
+  size_t send_cap[2] = {0, 0};
+  std::vector<uint32_t> failed;
+  std::vector<uint64_t> sc(p), rc(p);
+  idx->owner_lp = lp;   // (every rank is here: the route was agreed on)
+  for (uint32_t c = 0; c < nch; ++c) {
+    const size_t cb = (size_t)(cuts[c + 1] - cuts[c]);
+    const int sb = (int)(c & 1u);
+    const size_t want = (size_t)((double)cb * 0.06) + 8192;
+    if (c >= 2) KMI_TRY(kmi::comm_exchange_wait(comm));   // the buffer's previous message has left (the transfer before the last is done)
+    if (send_cap[sb] < want) { KMI_TRY(ws_get(ctx, sb ? WS_DIST_C : WS_DIST_A, want * 16, &pv)); sendbuf[sb] = (uint64_t *)pv; send_cap[sb] = want; }
+    const uint64_t *recs = nullptr;
+    uint64_t nrec = 0;
+    int produced = 0;
+    const uint8_t *src = d_bytes + cuts[c];   // (any address: the one-pass front end loads unaligned; the general one aligns its input itself)
+    KMI_TRY(sk_produce(idx, (uint32_t)W, src, cb, (uint32_t)p, &recs, &nrec, sc.data(), &produced, sendbuf[sb], send_cap[sb]));
+    if (produced && nrec && recs != sendbuf[sb]) {   // more records than the buffer was sized for: a larger one, and a copy out of the workspace
+      KMI_TRY(kmi::comm_exchange_wait(comm));
+      KMI_TRY(ws_get(ctx, sb ? WS_DIST_C : WS_DIST_A, (nrec + 64) * 16, &pv)); sendbuf[sb] = (uint64_t *)pv; send_cap[sb] = nrec + 64;
+      KMI_HIP(ctx, hipMemcpyAsync(sendbuf[sb], recs, nrec * 16, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    uint64_t mine = 0, largest = 0;
+    for (int r = 0; r < p; ++r) mine = std::max(mine, sc[r] * 16);
+    std::vector<uint64_t> tell(sc);
+    if (!produced) for (int r = 0; r < p; ++r) tell[r] = ~0ull;
+    KMI_TRY(kmi::comm_all_to_all_counts2(comm, tell.data(), mine, rc.data(), &largest));
+    bool all_ok = produced != 0;
+    for (int r = 0; r < p; ++r) all_ok = all_ok && rc[r] != ~0ull;
+    if (!all_ok) { failed.push_back(c); continue; }
+    uint64_t n_in = 0;
+    for (int r = 0; r < p; ++r) n_in += rc[r];
+    if (pool_pos + n_in > pool_cap) {   // the estimate was short (a very uneven input): a pool twice the need, what arrived so far moves over
+      KMI_TRY(kmi::comm_exchange_wait(comm));
+      const uint64_t ncap = 2 * (pool_pos + n_in) + 65536;
+      KMI_TRY(ws_get(ctx, pool_in_b ? WS_DIST_D : WS_DIST_B, ncap * 16, &pv));
+      if (pool_pos) KMI_HIP(ctx, hipMemcpyAsync(pv, pool, pool_pos * 16, hipMemcpyDeviceToDevice, ctx->stream));
+      pool = (uint64_t *)pv; pool_cap = ncap; pool_in_b = !pool_in_b;
+    }
+    KMI_TRY(kmi::comm_all_to_all_v_async(comm, sendbuf[sb], sc.data(), pool + 2 * pool_pos, rc.data(), 16, largest));
+    pool_pos += n_in;
+  }
+  KMI_TRY(kmi::comm_exchange_join(comm));
+  if (pool_pos) KMI_TRY(sk_consume(idx, (uint32_t)W, pool, pool_pos, (uint32_t)p));
+  idx->owner_lp = lp;
+  // chunks some rank could not produce as records: their k-mers, routed to the same owners (collective: every rank has the same list)
+  for (uint32_t c : failed) {
+    const size_t cb = (size_t)(cuts[c + 1] - cuts[c]);
+    const uint32_t nw = idx->shape.n_words;
+    uint64_t nt = 0, ns = 0, total = 0;
+    const uint8_t *src = d_bytes + cuts[c];
+    if (cb) { KMI_TRY(align_input(ctx, &src, cb)); KMI_TRY(extract_count(ctx, &idx->cfg, src, cb, &nt, &ns)); }
+    void *d_keys, *d_send, *d_recv;
+    KMI_TRY(ws_get(ctx, WS_OUTPUT, (nt + 64) * nw * sizeof(uint64_t), &d_keys));
+    KMI_TRY(ws_get(ctx, WS_DIST_A, (nt + 64) * nw * sizeof(uint64_t), &d_send));
+    send_cap[0] = 0;
+    for (int r = 0; r < p; ++r) sc[r] = 0;
+    if (nt) {
+      KMI_TRY(extract_run(ctx, &idx->cfg, src, cb, file_offset + cuts[c], (uint64_t *)d_keys, nullptr, (size_t)nt, true, true, &nt, &ns));
+      KMI_TRY(kmi_route_owner_dev(ctx, &idx->cfg, (const uint64_t *)d_keys, (size_t)nt, (uint32_t)p, (uint64_t *)d_send, sc.data()));
+    }
+    std::vector<uint64_t> rcv;
+    KMI_TRY(dist_exchange(comm, d_send, sc.data(), nw * sizeof(uint64_t), WS_DIST_D, &d_recv, rcv, &total));
+    KMI_TRY(index_insert(idx, (const uint64_t *)d_recv, (size_t)total, false));
+    idx->owner_lp = lp;
+  }
+  return KMI_OK;
+}
+
+extern "C" {
+
+kmi_status kmi_index_build_dist_dev(kmi_index *idx, kmi_comm *comm, const uint8_t *d_bytes, size_t n_bytes, uint64_t file_offset) {
   KMI_TRY(dist_check(idx, comm));
   kmi_ctx *ctx = idx->ctx;
   const int p = kmi::comm_size(comm);
-  if (p == 1 && !ctx->force_dist) return kmi_index_build_host(idx, bytes, n_bytes, file_offset);
-  if (n_bytes && !bytes) return set_err(ctx, KMI_ERR_INVALID, "null buffer");
+  if (p == 1 && !ctx->force_dist) return kmi_index_build_dev(idx, d_bytes, n_bytes, file_offset);
+  if (n_bytes && !d_bytes) return set_err(ctx, KMI_ERR_INVALID, "null buffer");
   const uint32_t nw = idx->shape.n_words, vw = idx->val_words, rw = nw + vw;
-  void *d_bytes, *d_send = nullptr, *d_recv;
-  KMI_TRY(ws_get(ctx, WS_INPUT, n_bytes + 64, &d_bytes));
-  if (n_bytes) KMI_HIP(ctx, hipMemcpyAsync(d_bytes, bytes, n_bytes, hipMemcpyHostToDevice, ctx->stream));
+  void *d_send = nullptr, *d_recv;
   std::vector<uint64_t> sc(p, 0), rc;
   uint64_t nt = 0, ns = 0, total = 0;
-  if (n_bytes) KMI_TRY(extract_count(ctx, &idx->cfg, (const uint8_t *)d_bytes, n_bytes, &nt, &ns));   // (an empty share still enters the collectives)
   if (vw == 0) {
+    // the route follows from state every rank has agreed on (never from one rank's own entry count: a rank with an empty share
+    // would otherwise take another branch than its peers, and the branches issue different collectives)
+    uint64_t holders = 0, owner_p = 0, owner_any = 0;
+    KMI_TRY(dist_state(idx, comm, &holders, &owner_p, &owner_any));
+    if (owner_any && owner_any != (uint64_t)p && holders)
+      return set_err(ctx, KMI_ERR_INVALID, "the ranks disagree on how this index is distributed (some by minimizer owner, some not)");
     const uint32_t skw = sk_width_of(idx);
-    const bool by_owner = idx->owner_lp != 0 && idx->n_entries != 0;      // the entries are already distributed by minimizer owner
-    if (skw && sk_rank_count((uint32_t)p) && (idx->n_entries == 0 || (1u << idx->owner_lp) == (uint32_t)p)) {
-      // the ranks exchange the super-k-mer records of the fused build instead of k-mers (kmi_index_sk_produce_dev): every rank or none
-      const uint64_t *recs = nullptr;
-      uint64_t nrec = 0, agree = 0;
-      int produced = 0;
-      const uint8_t *src = (const uint8_t *)d_bytes;
-      if (n_bytes) KMI_TRY(align_input(ctx, &src, n_bytes));
-      KMI_TRY(sk_produce(idx, skw, src, n_bytes, (uint32_t)p, &recs, &nrec, sc.data(), &produced, nullptr, 0));
-      agree = produced ? 1u : 0u;
-      KMI_TRY(kmi::comm_allreduce_sum(comm, &agree));
-      if (agree == (uint64_t)p) {
-        KMI_TRY(dist_exchange(comm, recs, sc.data(), 16, WS_DIST_B, &d_recv, rc, &total));
-        return sk_consume(idx, skw, (const uint64_t *)d_recv, total, (uint32_t)p);
+    const bool by_owner = owner_any != 0 && holders != 0;                 // the entries are already distributed by minimizer owner
+    if (skw && sk_rank_count((uint32_t)p) && (holders == 0 || owner_p == (uint64_t)p)) {
+      if (holders == 0) idx->owner_lp = 0;
+      switch (skw) {
+        case 19: return build_dist_superkmer<19>(idx, comm, d_bytes, n_bytes, file_offset);
+        case 13: return build_dist_superkmer<13>(idx, comm, d_bytes, n_bytes, file_offset);
+        case 11: return build_dist_superkmer<11>(idx, comm, d_bytes, n_bytes, file_offset);
+        default: return build_dist_superkmer<7>(idx, comm, d_bytes, n_bytes, file_offset);
       }
-      for (int r = 0; r < p; ++r) sc[r] = 0;   // some rank could not: the k-mer route below, for everybody
     }
+    if (n_bytes) KMI_TRY(extract_count(ctx, &idx->cfg, d_bytes, n_bytes, &nt, &ns));   // (an empty share still enters the collectives)
     KMI_TRY(ws_get(ctx, WS_DIST_A, (nt + 64) * nw * sizeof(uint64_t), &d_send));
     if (by_owner) {
       // k-mers into an index that is distributed by minimizer owner go to those owners
       void *d_keys;
       KMI_TRY(ws_get(ctx, WS_OUTPUT, (nt + 64) * nw * sizeof(uint64_t), &d_keys));
       if (nt) {
-        KMI_TRY(extract_run(ctx, &idx->cfg, (const uint8_t *)d_bytes, n_bytes, file_offset, (uint64_t *)d_keys, nullptr, (size_t)nt, true, true, &nt, &ns));
+        KMI_TRY(extract_run(ctx, &idx->cfg, d_bytes, n_bytes, file_offset, (uint64_t *)d_keys, nullptr, (size_t)nt, true, true, &nt, &ns));
         KMI_TRY(kmi_route_owner_dev(ctx, &idx->cfg, (const uint64_t *)d_keys, (size_t)nt, (uint32_t)p, (uint64_t *)d_send, sc.data()));
       }
     } else if (nt && idx->cfg.seq_format == KMI_FMT_FASTQ) {
       // read_file + the bucketing half of imxx::distribute, fused: the tuple array in file order never exists
-      KMI_TRY(kmi_extract_route_dev(ctx, &idx->cfg, (const uint8_t *)d_bytes, n_bytes, (uint32_t)p, (uint64_t *)d_send, (size_t)nt, &nt, &ns, sc.data()));
+      KMI_TRY(kmi_extract_route_dev(ctx, &idx->cfg, d_bytes, n_bytes, (uint32_t)p, (uint64_t *)d_send, (size_t)nt, &nt, &ns, sc.data()));
     } else if (nt) {
       void *d_keys;
       KMI_TRY(ws_get(ctx, WS_OUTPUT, (nt + 64) * nw * sizeof(uint64_t), &d_keys));
-      KMI_TRY(extract_run(ctx, &idx->cfg, (const uint8_t *)d_bytes, n_bytes, file_offset, (uint64_t *)d_keys, nullptr, (size_t)nt, true, true, &nt, &ns));
+      KMI_TRY(extract_run(ctx, &idx->cfg, d_bytes, n_bytes, file_offset, (uint64_t *)d_keys, nullptr, (size_t)nt, true, true, &nt, &ns));
       KMI_TRY(kmi_route_dev(ctx, &idx->cfg, (const uint64_t *)d_keys, (size_t)nt, (uint32_t)p, (uint64_t *)d_send, sc.data()));
     }
     KMI_TRY(dist_exchange(comm, d_send, sc.data(), nw * sizeof(uint64_t), WS_DIST_B, &d_recv, rc, &total));
     return index_insert(idx, (const uint64_t *)d_recv, (size_t)total, false);
   }
+  if (n_bytes) KMI_TRY(extract_count(ctx, &idx->cfg, d_bytes, n_bytes, &nt, &ns));
   if (vw == 2 && idx->cfg.seq_format != KMI_FMT_FASTQ)
     return set_err(ctx, KMI_ERR_INVALID, "a position + quality index over ranks is built from FASTQ partitions");
   KMI_TRY(ws_get(ctx, WS_DIST_A, (nt + 64) * rw * sizeof(uint64_t), &d_send));
   if (nt)
-    KMI_TRY(kmi_extract_route_records_dev(ctx, &idx->cfg, (const uint8_t *)d_bytes, n_bytes, file_offset, (uint32_t)p, (uint64_t *)d_send, (size_t)nt + 64,
+    KMI_TRY(kmi_extract_route_records_dev(ctx, &idx->cfg, d_bytes, n_bytes, file_offset, (uint32_t)p, (uint64_t *)d_send, (size_t)nt + 64,
                                           &nt, &ns, sc.data()));
   KMI_TRY(dist_exchange(comm, d_send, sc.data(), rw * sizeof(uint64_t), WS_DIST_B, &d_recv, rc, &total));
   return index_insert_records(idx, (const uint64_t *)d_recv, (size_t)total, true);
+}
+
+kmi_status kmi_index_build_dist_host(kmi_index *idx, kmi_comm *comm, const uint8_t *bytes, size_t n_bytes, uint64_t file_offset) {
+  KMI_TRY(dist_check(idx, comm));
+  kmi_ctx *ctx = idx->ctx;
+  if (kmi::comm_size(comm) == 1 && !ctx->force_dist) return kmi_index_build_host(idx, bytes, n_bytes, file_offset);
+  if (n_bytes && !bytes) return set_err(ctx, KMI_ERR_INVALID, "null buffer");
+  void *d_bytes;
+  KMI_TRY(ws_get(ctx, WS_INPUT, n_bytes + 64, &d_bytes));
+  if (n_bytes) KMI_HIP(ctx, hipMemcpyAsync(d_bytes, bytes, n_bytes, hipMemcpyHostToDevice, ctx->stream));
+  return kmi_index_build_dist_dev(idx, comm, (const uint8_t *)d_bytes, n_bytes, file_offset);
 }
 
 static kmi_status query_dist_host(kmi_index *idx, kmi_comm *comm, int mode, const uint64_t *queries, size_t nq, kmi_results *out, uint64_t *n_erased) {
@@ -4482,6 +4646,12 @@ kmi_status kmi_index_set_owner_ranks(kmi_index *idx, uint32_t nranks) {
   if (idx->has_data && idx->n_entries && (1u << idx->owner_lp) != nranks)
     return set_err(idx->ctx, KMI_ERR_INVALID, "the index holds entries distributed another way");
   idx->owner_lp = 31u - (uint32_t)__builtin_clz(nranks);
+  return KMI_OK;
+}
+
+kmi_status kmi_index_sk_width(kmi_index *idx, uint32_t *w) {
+  if (!idx || !w) return KMI_ERR_INVALID;
+  *w = kmi::sk_width_of(idx);
   return KMI_OK;
 }
 

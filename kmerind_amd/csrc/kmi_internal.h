@@ -93,6 +93,7 @@ struct kmi_ctx {
   bool force_dist = false;       // KMI_FORCE_DIST=1: the *_dist_* entry points run their exchange even with one rank (RCCL self exchange: tests)
   uint32_t sk_level_hint = 0;    // sk_reduce: filter bits the buckets of the next build start with (majority of the last build)
   float sk_inv_dup = 0.f;        // sk_reduce: distinct k-mers per k-mer occurrence of the last build (a bucket's expected fill; 0: unknown)
+  uint32_t dist_chunks = 4;      // record-aligned chunks of a rank's share in the build over ranks (exchange of one beside the front end of the next; KMI_DIST_CHUNKS)
   bool front_fused = true;       // FASTQ front end of the super-k-mer build in one pass (kmi_front.h); KMI_FRONT=general: scan + list + minimizer
   uint32_t front_waves = 0;      // resident wavefronts of the front kernel (ranges of a large input); 0: not asked yet
   uint64_t front_min_range = 64ull << 10;   // smallest byte range of a wavefront (KMI_FRONT_MIN_RANGE: tests shrink it)
@@ -225,6 +226,11 @@ kmi_status comm_all_to_all_counts(kmi_comm *c, const uint64_t *send_counts, uint
 kmi_status comm_all_to_all_v(kmi_comm *c, const void *send_dev, const uint64_t *send_counts, void *recv_dev, const uint64_t *recv_counts,
                              size_t elem_bytes);
 kmi_status comm_allreduce_sum(kmi_comm *c, uint64_t *value);
+kmi_status comm_all_to_all_counts2(kmi_comm *c, const uint64_t *send_counts, uint64_t my_largest_bytes, uint64_t *recv_counts, uint64_t *largest_bytes);
+kmi_status comm_all_to_all_v_async(kmi_comm *c, const void *send_dev, const uint64_t *send_counts, void *recv_dev, const uint64_t *recv_counts,
+                                   size_t elem_bytes, uint64_t largest_bytes);
+kmi_status comm_exchange_join(kmi_comm *c);
+kmi_status comm_exchange_wait(kmi_comm *c);
 kmi_ctx *comm_ctx(kmi_comm *c);
 int comm_size(kmi_comm *c);
 int comm_rank(kmi_comm *c);

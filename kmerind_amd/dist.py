@@ -212,7 +212,11 @@ class DistributedCountIndex:
         from . import _lib as L
         staged = self._staged()
         cdev = torch.device("cpu") if staged else device
-        ok = self.world in (1, 2, 4, 8) and (self.index.local_size() == 0 or self.index.owner_ranks() == self.world)   # (1: rehearsals)
+        # the path applies to FASTQ builds of one-word 2-bit k-mers with k >= 17 on 1 (rehearsals), 2, 4 or 8 ranks, into an index
+        # that is empty or was built this way (kmi_index_sk_width: 0 for every other shape, and with KMI_FUSED_PATH=kmer)
+        skw = C.c_uint32(0)
+        self.ctx.check(L.lib.kmi_index_sk_width(self.index.h, C.byref(skw)))
+        ok = skw.value != 0 and self.world in (1, 2, 4, 8) and (self.index.local_size() == 0 or self.index.owner_ranks() == self.world)
         bounds = [0, nbytes] if not bounds else [int(b) for b in bounds]
         assert bounds[0] == 0 and bounds[-1] == nbytes and all(a <= b for a, b in zip(bounds, bounds[1:]))
         nch = len(bounds) - 1
@@ -223,7 +227,9 @@ class DistributedCountIndex:
             return False
         if int(flag[1].item()) != nch or -int(flag[2].item()) != nch:
             raise RuntimeError("build_device(bounds=...): the ranks disagree on the number of chunks")
-        self.ctx.check(L.lib.kmi_index_set_owner_ranks(self.index.h, self.world))
+        self.ctx.check(L.lib.kmi_index_set_owner_ranks(self.index.h, self.world))   # (only after every rank agreed)
+        # the library writes the records on the context's stream; torch's collectives are ordered behind torch's current stream
+        same_stream = getattr(self.ctx, "stream", 0) == (torch.cuda.current_stream(device).cuda_stream if device is not None and device.type == "cuda" else 0)
         recv_parts, works, sends, kmer_chunks = [], [], [], []
         total_sc = [0] * self.world
         pool, pool_pos = None, 0          # one receive buffer for all chunks (sized after the first one), so nothing is concatenated
@@ -239,12 +245,18 @@ class DistributedCountIndex:
                                                           C.byref(recs_p), C.byref(n), sc.ctypes.data_as(C.c_void_p), C.byref(produced)))
             self._sk_cap[c] = n.value
             counts = [int(x) for x in sc]
-            # the send counts go round with the verdict: a rank that could not produce this chunk says so with -1
-            t = torch.tensor(counts if produced.value else [-1] * self.world, dtype=torch.int64, device=cdev)
+            if not same_stream:
+                self.ctx.synchronize()                                  # the records are complete before torch reads them
+            # the send counts go round with the verdict (a rank that could not produce this chunk says so with -1) and with the
+            # sender's largest message: every rank hears from every rank, so all see the same verdict and the same maximum
+            mine = max(counts + [0])
+            t = torch.tensor([[cnt if produced.value else -1, mine] for cnt in counts], dtype=torch.int64, device=cdev)
             r = torch.empty_like(t)
             dist.all_to_all_single(r, t, group=self.group)
-            rc = [int(x) for x in r.tolist()]
-            if not produced.value or min(rc) < 0:                      # (every rank hears from every rank: all see the same verdict)
+            rl = r.tolist()
+            rc = [int(x[0]) for x in rl]
+            largest = max(int(x[1]) for x in rl)
+            if not produced.value or min(rc) < 0:
                 kmer_chunks.append(c)
                 continue
             if recs_p.value == send.data_ptr() or n.value == 0:
@@ -255,7 +267,7 @@ class DistributedCountIndex:
             total_sc = [a + b for a, b in zip(total_sc, counts)]
             n_in = sum(rc)
             first = not self._verified
-            if staged or first or max(counts + rc + [0]) * 2 > MSG_MAX_WORDS:
+            if staged or first or largest * 2 > MSG_MAX_WORDS:           # (the same branch on every rank)
                 recv, rc2 = self._exchange_dev(send, counts)          # (synchronous; pieces where a message is too large)
                 assert rc2 == rc
                 if first:

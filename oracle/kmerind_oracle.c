@@ -1306,4 +1306,104 @@ double orc_bench_count_index(const uint8_t *bytes, size_t n, uint32_t k, uint32_
   return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
 }
 
+/* ---- the whole thread-rank build in slices, with checksums of the final maps (tests: full-size parity) ------------------
+ * The same path as orc_bench_count_index (parse -> canonical -> murmur KeyToRank -> stable bucket -> in-memory all-to-all ->
+ * per-rank chained map), but the input goes through in `slices` record-aligned pieces and every rank keeps its map across
+ * them, so the memory in flight is one slice's tuples. out[0] = k-mers, out[1] = distinct keys, out[2] = sum of counts,
+ * out[3] = sum of key * count (mod 2^64), out[4] = xor of key * (2 count + 1) (mod 2^64). */
+typedef struct {
+  const uint8_t *bytes; size_t n;
+  orc_kspec spec; uint32_t strand, T, tid;
+  const size_t *part_begin;
+  pthread_barrier_t *bar;
+  uint64_t **send_buf; uint64_t **send_counts;
+  orc_count_map **maps;
+  uint64_t n_kmers;
+} full_arg;
+
+static void *full_worker(void *vp) {
+  full_arg *a = (full_arg *)vp;
+  const orc_kspec *s = &a->spec;
+  const uint32_t T = a->T, me = a->tid;
+  const size_t b = a->part_begin[me], e = a->part_begin[me + 1];
+  size_t nseq = 0;
+  const size_t cap = (e > b) ? (e - b) / 2 + 1024 : 1;   /* a FASTQ record gives fewer than half a tuple per byte */
+  uint64_t *km = (uint64_t *)malloc(sizeof(uint64_t) * s->n_words * cap);
+  long nk = (e > b) ? orc_extract(s, ORC_FMT_FASTQ, a->bytes + b, e - b, b, km, NULL, NULL, cap, &nseq) : 0;
+  if (nk < 0) nk = 0;
+  a->n_kmers = (uint64_t)nk;
+  if (a->strand == ORC_STRAND_CANONICAL)
+    for (long i = 0; i < nk; ++i) canonical_fast(s, km + (size_t)i * s->n_words, km + (size_t)i * s->n_words);
+  uint32_t *ranks = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)(nk ? nk : 1));
+  uint64_t *i2o = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)(nk ? nk : 1));
+  orc_key_to_rank(s, ORC_HASH_MURMUR, a->strand, km, (size_t)nk, T, ranks);
+  orc_stable_bucket(ranks, (size_t)nk, T, a->send_counts[me], i2o);
+  uint64_t *perm = (uint64_t *)malloc(sizeof(uint64_t) * s->n_words * (size_t)(nk ? nk : 1));
+  for (long i = 0; i < nk; ++i)
+    memcpy(perm + i2o[i] * s->n_words, km + (size_t)i * s->n_words, s->n_words * sizeof(uint64_t));
+  free(km); free(ranks); free(i2o);
+  a->send_buf[me] = perm;
+  pthread_barrier_wait(a->bar);
+  for (uint32_t src = 0; src < T; ++src) {      /* what this rank receives, source by source, straight into its map */
+    uint64_t off = 0;
+    for (uint32_t d = 0; d < me; ++d) off += a->send_counts[src][d];
+    orc_count_map_insert(a->maps[me], a->send_buf[src] + off * s->n_words, (size_t)a->send_counts[src][me]);
+  }
+  pthread_barrier_wait(a->bar);
+  free(a->send_buf[me]);
+  return NULL;
+}
+
+int orc_count_full(const uint8_t *bytes, size_t n, uint32_t k, uint32_t strand, uint32_t threads, uint32_t slices, uint64_t *out) {
+  orc_kspec spec;
+  if (orc_kspec_init(&spec, k, ORC_DNA) != 0 || threads == 0 || slices == 0 || spec.n_words != 1) return -1;
+  const uint32_t T = threads;
+  orc_count_map **maps = (orc_count_map **)calloc(T, sizeof(orc_count_map *));
+  for (uint32_t t = 0; t < T; ++t) {
+    maps[t] = orc_count_map_create(&spec, ORC_STRAND_SINGLE, ORC_HASH_MURMUR);   /* keys arrive input-transformed */
+    if (strand == ORC_STRAND_BIMOLECULE) maps[t]->strand = ORC_STRAND_BIMOLECULE;
+  }
+  uint64_t **send_buf = (uint64_t **)calloc(T, sizeof(uint64_t *));
+  uint64_t **send_counts = (uint64_t **)calloc(T, sizeof(uint64_t *));
+  for (uint32_t t = 0; t < T; ++t) send_counts[t] = (uint64_t *)calloc(T, sizeof(uint64_t));
+  full_arg *args = (full_arg *)calloc(T, sizeof(full_arg));
+  pthread_t *th = (pthread_t *)calloc(T, sizeof(pthread_t));
+  size_t *pb = (size_t *)malloc(sizeof(size_t) * (T + 1));
+  uint64_t nk = 0;
+  size_t s_begin = 0;
+  for (uint32_t sl = 0; sl < slices; ++sl) {
+    const size_t s_end = (sl + 1 == slices) ? n : fastq_align(bytes, n, (size_t)((double)n * (sl + 1) / slices));
+    const size_t sn = s_end > s_begin ? s_end - s_begin : 0;
+    for (uint32_t t = 0; t < T; ++t) pb[t] = s_begin + fastq_align(bytes + s_begin, sn, (size_t)((double)sn * t / T));
+    pb[T] = s_begin + sn;
+    for (uint32_t t = 1; t <= T; ++t) if (pb[t] < pb[t - 1]) pb[t] = pb[t - 1];
+    pthread_barrier_t bar; pthread_barrier_init(&bar, NULL, T);
+    for (uint32_t t = 0; t < T; ++t) {
+      memset(send_counts[t], 0, sizeof(uint64_t) * T);
+      args[t].bytes = bytes; args[t].n = n; args[t].spec = spec; args[t].strand = strand; args[t].T = T; args[t].tid = t;
+      args[t].part_begin = pb; args[t].bar = &bar; args[t].send_buf = send_buf; args[t].send_counts = send_counts; args[t].maps = maps;
+      pthread_create(&th[t], NULL, full_worker, &args[t]);
+    }
+    for (uint32_t t = 0; t < T; ++t) { pthread_join(th[t], NULL); nk += args[t].n_kmers; }
+    pthread_barrier_destroy(&bar);
+    s_begin = s_end;
+  }
+  uint64_t nd = 0, sc = 0, skc = 0, x = 0;
+  for (uint32_t t = 0; t < T; ++t) {
+    const orc_count_map *m = maps[t];
+    for (size_t b = 0; b < m->n_buckets; ++b)
+      for (cm_node *node = m->buckets[b]; node; node = node->next) {
+        ++nd; sc += node->count; skc += node->key[0] * (uint64_t)node->count; x ^= node->key[0] * (2ull * node->count + 1ull);
+      }
+    orc_count_map_destroy(maps[t]);
+  }
+  out[0] = nk; out[1] = nd; out[2] = sc; out[3] = skc; out[4] = x;
+  for (uint32_t t = 0; t < T; ++t) free(send_counts[t]);
+  free(send_counts); free(send_buf); free(args); free(th); free(pb); free(maps);
+  return 0;
+}
+
+/* the record-aligned start at or after `pos` (the 4-line rule above), for the tests of the on-device partition search */
+size_t orc_fastq_align(const uint8_t *bytes, size_t n, size_t pos) { return fastq_align(bytes, n, pos); }
+
 void orc_free(void *p) { free(p); }

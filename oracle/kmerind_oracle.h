@@ -214,6 +214,11 @@ size_t orc_dbg_map_find(orc_dbg_map *m, const uint64_t *queries, size_t nq, uint
  * per rank parse (record-aligned byte range) -> KeyToRank (murmur h[1] % T) ->
  * stable bucket -> in-memory exchange -> per-rank counting map insert.
  * Returns elapsed seconds (read+insert sections); outputs totals. */
+/* the thread-rank build of a whole FASTQ buffer in `slices` pieces (maps kept across them) with checksums of the result:
+ * out[0] k-mers, [1] distinct keys, [2] sum of counts, [3] sum of key * count, [4] xor of key * (2 count + 1) (mod 2^64) */
+int orc_count_full(const uint8_t *bytes, size_t n, uint32_t k, uint32_t strand, uint32_t threads, uint32_t slices, uint64_t *out);
+/* record-aligned position at or after pos (fastq_loader.hpp:269-364, the 4-line rule) */
+size_t orc_fastq_align(const uint8_t *bytes, size_t n, size_t pos);
 double orc_bench_count_index(const uint8_t *bytes, size_t n, uint32_t k, uint32_t strand,
                              uint32_t threads, uint64_t *n_kmers, uint64_t *n_distinct);
 

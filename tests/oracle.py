@@ -117,6 +117,10 @@ lib.orc_dbg_map_find.restype = C.c_size_t
 lib.orc_bench_count_index.argtypes = [_u8p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32,
                                       C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
 lib.orc_bench_count_index.restype = C.c_double
+lib.orc_count_full.argtypes = [_u8p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]
+lib.orc_count_full.restype = C.c_int
+lib.orc_fastq_align.argtypes = [_u8p, C.c_size_t, C.c_size_t]
+lib.orc_fastq_align.restype = C.c_size_t
 
 
 def kspec(k, alphabet=DNA):
@@ -368,6 +372,30 @@ def bench_count_index(data, k, strand, threads):
     nk, nd = C.c_uint64(0), C.c_uint64(0)
     t = lib.orc_bench_count_index(b, b.size, k, strand, threads, C.byref(nk), C.byref(nd))
     return t, nk.value, nd.value
+
+
+def count_full(data, k, strand, threads, slices):
+    """the thread-rank build of a whole FASTQ buffer: dict(kmers, distinct, sum_counts, sum_key_count, xor_mix) (sums mod 2^64)"""
+    b = _as_bytes(data)
+    out = (C.c_uint64 * 5)()
+    rc = lib.orc_count_full(b, b.size, k, strand, threads, slices, out)
+    assert rc == 0
+    return dict(kmers=out[0], distinct=out[1], sum_counts=out[2], sum_key_count=out[3], xor_mix=out[4])
+
+
+def map_checksums(keys, counts):
+    """the same checksums from (keys, counts) arrays of a one-word count map"""
+    k = np.asarray(keys, dtype=np.uint64).reshape(-1)
+    c = np.asarray(counts).astype(np.uint64)
+    with np.errstate(over="ignore"):
+        skc = int((k * c).sum(dtype=np.uint64))
+        x = int(np.bitwise_xor.reduce(k * (np.uint64(2) * c + np.uint64(1)))) if k.size else 0
+    return dict(distinct=int(k.size), sum_counts=int(c.sum(dtype=np.uint64)), sum_key_count=skc, xor_mix=x)
+
+
+def fastq_align(data, pos):
+    b = _as_bytes(data)
+    return int(lib.orc_fastq_align(b, b.size, pos))
 
 
 # ---- reference hash library (vendored MurmurHash3.cpp / farmhash.cc compiled as-is)

@@ -61,15 +61,18 @@ def test_bench_starts_its_own_ranks():
         assert 1_900_000 < d["config"]["distinct_kmers"] <= 2_000_000
 
 
-def test_bench_one_rank_rccl_rehearsal_of_the_super_kmer_exchange():
+@pytest.mark.parametrize("transport", ["kmi", "torch"])
+def test_bench_one_rank_rccl_rehearsal_of_the_super_kmer_exchange(transport):
     """`bench.py --force-dist --dist-mode superkmer`: the N > 1 flow with one rank over RCCL (self exchange): records produced in
-    chunks, asynchronous all_to_all_single, consume -- the calls the 8-GPU run makes"""
+    chunks, asynchronous exchange, consume -- the calls the 8-GPU run makes. transport kmi (the default): the library's own RCCL
+    layer and kmi_index_build_dist_dev (what Index::build_partition runs); torch: kmerind_amd.dist over torch.distributed."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--force-dist", "--dist-mode", "superkmer", "--steps", "2", "--warmup", "1",
-                          "--reads", "200000", "--genome", "2000000", "--no-cpu-baseline", "--no-extra"], capture_output=True, text=True,
-                         timeout=900, cwd=ROOT, env=env)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--force-dist", "--dist-mode", "superkmer", "--transport", transport,
+                          "--steps", "2", "--warmup", "1", "--reads", "200000", "--genome", "2000000", "--no-cpu-baseline", "--no-extra"],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
     d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
     assert d["config"]["dist_mode"] == "superkmer" and d["config"]["backend"] == "nccl" and d["config"]["rccl_ranks"] == 1
+    assert d["config"]["transport"] == transport
     assert d["config"]["exchange_checksum"].startswith("verified") and 1_900_000 < d["config"]["distinct_kmers"] <= 2_000_000
     assert "sk_recv_scatter" in d["roofline"]["kernels_ms_per_step"]

@@ -267,7 +267,7 @@ def test_position_id_overflow_is_reported(ctx):
 
 def test_fastq_partition_on_the_device_matches_the_host_rule(ctx):
     """kmi_fastq_partition_dev = FASTQParser::find_first_record per split point (fastq_loader.hpp:269-364): same record-aligned
-    ranges as kmerind_amd.fileio.partition_fastq, also when quality lines begin with '@' or '+' and for more parts than records"""
+    ranges as the oracle's restatement of that rule (orc_fastq_align) and as kmerind_amd.fileio.partition_fastq, also when quality lines begin with '@' or '+' and for more parts than records"""
     import kmerind_amd as K
     from kmerind_amd import fileio
     files = [open(os.path.join(GOLD, "data", n), "rb").read() for n in ("natural.fastq", "test.small.fastq", "test.medium.fastq")]
@@ -279,7 +279,13 @@ def test_fastq_partition_on_the_device_matches_the_host_rule(ctx):
         d = ctx.alloc(buf.size + 64)
         ctx.to_device(d, buf)
         for parts in (1, 2, 3, 5, 8, 16, 257):
-            assert fileio.partition_fastq_device(ctx, d, buf.size, parts) == fileio.partition_fastq(data, parts), parts
+            got = fileio.partition_fastq_device(ctx, d, buf.size, parts)
+            # the oracle's restatement of the rule (oracle/kmerind_oracle.c fastq_align), split point by split point
+            cuts = [orc.fastq_align(data, buf.size * r // parts) for r in range(parts)] + [buf.size]
+            for r in range(1, parts + 1):
+                cuts[r] = max(cuts[r], cuts[r - 1])
+            assert got == [(cuts[r], cuts[r + 1]) for r in range(parts)], parts
+            assert got == fileio.partition_fastq(data, parts), parts          # (and the host-side helper agrees)
         ctx.free(d)
 
 

@@ -359,3 +359,25 @@ def test_std_hasher_against_the_standard_library_the_reference_calls():
         assert [int(x) for x in got] == want
         shift = min(s.n_bits, 64) - min(32, s.n_bits)
         assert [int(x) for x in orc.kmer_hash(s, orc.STD, True, km)] == [h >> shift for h in want]
+
+
+def test_count_full_checksums_match_the_single_map():
+    """orc_count_full (thread ranks, slices, checksums of the maps: what the full-size GPU tests compare with) against the oracle's
+    one-map build of the same reads"""
+    rng = np.random.default_rng(5)
+    genome = "".join("ACGT"[c] for c in rng.integers(0, 4, 3000))
+    recs = []
+    for i in range(400):
+        st = int(rng.integers(0, 3000 - 100)); L = int(rng.integers(40, 100))
+        recs.append("@r%d\n%s\n+\n%s\n" % (i, genome[st:st + L], "I" * L))
+    data = "".join(recs).encode()
+    for k, strand in ((31, orc.CANONICAL), (21, orc.SINGLE)):
+        s = orc.kspec(k)
+        om = orc.CountMap(s, strand)
+        kmers = orc.extract(s, data, orc.FASTQ)["kmers"]
+        om.insert(kmers)
+        want = orc.map_checksums(*om.export())
+        for threads, slices in ((1, 1), (3, 2), (4, 5)):
+            got = orc.count_full(data, k, strand, threads, slices)
+            assert got["kmers"] == kmers.shape[0]
+            assert {x: got[x] for x in want} == want
