@@ -63,6 +63,20 @@ int main(int argc, char **argv) {
       for (auto &e : cidx.to_vector()) s4 += e.second;
       std::printf("device max hit %zu sum %llu assign hit %zu sum %llu\n", h2, s3, h3, s4);
     }
+    {
+      // Index::build_posix (kmer_index.hpp:239-372): the file entry point itself; with KMI_FORCE_DIST=1 this is the path of
+      // comm.size() > 1 -- the rank's byte range plus look-ahead, record-aligned on the device, the collective build
+      CountIdx fidx(comm);
+      fidx.build_posix<::bliss::io::FASTQParser, ::bliss::io::SequencesIterator>(fastq);
+      unsigned long long fs = 0;
+      for (auto &e : fidx.to_vector()) fs += e.second;
+      std::vector<KmerType> q;
+      for (size_t i = 0; i < tuples.size(); i += 4) q.push_back(tuples[i].first);
+      q.push_back(KmerType());
+      unsigned long long ex = 0;
+      for (unsigned char b : fidx.exists(q)) ex += b;
+      std::printf("build_posix entries %zu sum %llu exists %llu of %zu\n", fidx.local_size(), fs, ex, q.size());
+    }
     auto &view = cidx.get_map();
     std::printf("get_map local_size %zu size %zu\n", view.local_size(), view.size());
     // ---- PositionQualityIndex: (k-mer, (id, quality)) tuples through read_file + insert, then find

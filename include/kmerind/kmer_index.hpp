@@ -23,6 +23,7 @@
 
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <limits>
@@ -356,6 +357,26 @@ inline std::vector<uint8_t> read_whole_file(const std::string &filename) {
   std::fclose(f);
   return buf;
 }
+// what ONE rank of p reads of a file (partitioned_file, file.hpp:1216-1430): its nominal byte range [n r / p, n (r + 1) / p) plus
+// `lookahead` bytes (where its last record ends and the next rank's first begins); *reaches_eof: the buffer ends with the file
+struct FileRange { std::vector<uint8_t> bytes; uint64_t offset = 0, nominal = 0; bool reaches_eof = false; };
+inline FileRange read_file_range(const std::string &filename, int rank, int p, uint64_t lookahead) {
+  FILE *f = std::fopen(filename.c_str(), "rb");
+  if (!f) throw std::invalid_argument("cannot open " + filename);
+  std::fseek(f, 0, SEEK_END);
+  const uint64_t n = (uint64_t)std::ftell(f);
+  const uint64_t lo = n / (uint64_t)p * (uint64_t)rank + (n % (uint64_t)p) * (uint64_t)rank / (uint64_t)p;
+  const uint64_t hi = (rank + 1 == p) ? n : n / (uint64_t)p * (uint64_t)(rank + 1) + (n % (uint64_t)p) * (uint64_t)(rank + 1) / (uint64_t)p;
+  uint64_t end = hi + lookahead;
+  if (end > n || end < hi) end = n;
+  FileRange r;
+  r.offset = lo; r.nominal = hi - lo; r.reaches_eof = end == n;
+  r.bytes.resize((size_t)(end - lo));
+  std::fseek(f, (long)lo, SEEK_SET);
+  if (end > lo && std::fread(r.bytes.data(), 1, (size_t)(end - lo), f) != (size_t)(end - lo)) { std::fclose(f); throw std::runtime_error("short read on " + filename); }
+  std::fclose(f);
+  return r;
+}
 inline uint32_t format_of(const std::string &filename) {  // kmer_index.hpp:243-254
   auto ends = [&](const char *e) { size_t l = std::strlen(e); return filename.size() >= l && filename.compare(filename.size() - l, l, e) == 0; };
   if (ends(".fastq") || ends(".fq")) return KMI_FMT_FASTQ;
@@ -407,6 +428,10 @@ class Index {
       if (comm.unique_id.size() != KMI_COMM_ID_BYTES)
         throw std::invalid_argument("comm.size() > 1 needs comm.unique_id (kmerind::comm::make_unique_id() on rank 0, handed to every rank) or comm.exchange");
       ::kmerind::check(ctx, kmi_comm_create(ctx, comm.unique_id.data(), &rccl));
+    } else if (comm.size() == 1) {
+      // KMI_FORCE_DIST=1 (rehearsals on one GPU): a one-rank communicator, and every member takes the path it takes over ranks
+      const char *fd = std::getenv("KMI_FORCE_DIST");
+      if (fd && std::atoi(fd) != 0) ::kmerind::check(ctx, kmi_comm_create(ctx, nullptr, &rccl));
     }
   }
   Index(const Index &) = delete;
@@ -437,23 +462,21 @@ class Index {
   // exists() of the densehash maps (distributed_densehash_map.hpp:1465-1560): one byte per INPUT key, in input order
   // (1 = stored). The device answers per distinct transformed key; the bytes are filled on the host from that answer.
   std::vector<unsigned char> exists(std::vector<KmerType> &query) const {
-    if (comm.size() > 1) throw std::invalid_argument("exists with size() > 1 is not wired through comm.exchange");
     std::vector<unsigned char> out(query.size(), 0);
-    if (query.empty()) return out;
     const size_t nw = KmerType::nWords;
+    // count() answers per distinct transformed key, over ranks too (the query keys travel to their owners and the answers come
+    // back to the rank that asked); with size() > 1 every rank calls, possibly with an empty vector
+    std::vector<std::pair<KmerType, size_t>> cnt = count(query);
+    if (query.empty()) return out;
+    std::sort(cnt.begin(), cnt.end(), [](const std::pair<KmerType, size_t> &a, const std::pair<KmerType, size_t> &b) { return a.first < b.first; });
     std::vector<uint64_t> t(query.size() * nw);
     const uint64_t *w = detail::words_of(query);
     if (cfg.strand == KMI_STRAND_SINGLE) std::memcpy(t.data(), w, t.size() * sizeof(uint64_t));
     else ::kmerind::check(ctx, kmi_canonical_host(ctx, &cfg, w, query.size(), t.data()));   // the key the map stores
-    kmi_results r{};
-    ::kmerind::check(ctx, kmi_index_count_host(idx, w, query.size(), &r));
-    std::map<KmerType, bool> present;
-    constexpr unsigned ow = detail::stored_words<MapType, ValueType>();
-    for (uint64_t i = 0; i < r.n; ++i) present[KmerType(r.keys + i * nw)] = r.values[i * ow] != 0;
-    kmi_results_free(&r);
     for (size_t i = 0; i < query.size(); ++i) {
-      auto it = present.find(KmerType(&t[i * nw]));
-      out[i] = (it != present.end() && it->second) ? 1 : 0;
+      const KmerType key(&t[i * nw]);
+      auto it = std::lower_bound(cnt.begin(), cnt.end(), key, [](const std::pair<KmerType, size_t> &a, const KmerType &b) { return a.first < b; });
+      out[i] = (it != cnt.end() && !(key < it->first) && it->second != 0) ? 1 : 0;
     }
     return out;
   }
@@ -515,7 +538,7 @@ class Index {
   // the host over the entries the device returns; the changed values go back as (key, value) pairs. Counting maps, one rank.
   template <typename Updater> size_t update(std::vector<TupleType> &input, bool /*sorted_input*/, Updater const &op) {
     static_assert(MapType::index_kind == KMI_INDEX_COUNT, "update() is a member of the counting / reduction maps");
-    if (comm.size() > 1) throw std::invalid_argument("update with size() > 1 is not wired through the exchange");
+    if (comm.size() > 1) throw std::invalid_argument("update() with a host functor and size() > 1: the pairs would have to visit their owners' hosts; use the kmerind::updater forms (add / max / min / assign), which run on the owners' devices");
     if (input.empty() || local_size() == 0) return 0;
     constexpr unsigned nw = KmerType::nWords;
     std::vector<KmerType> keys(input.size());
@@ -618,7 +641,7 @@ class Index {
   void build_partition(const uint8_t *bytes, size_t n_bytes, uint64_t file_offset, uint32_t fmt = KMI_FMT_FASTQ, uint32_t seq_filter = KMI_SEQ_ALL) {
     ::kmerind::check(ctx, kmi_index_set_seq_format(idx, fmt));
     ::kmerind::check(ctx, kmi_index_set_seq_filter(idx, seq_filter));
-    if (comm.size() == 1) { ::kmerind::check(ctx, kmi_index_build_host(idx, bytes, n_bytes, file_offset)); return; }
+    if (comm.size() == 1 && !rccl) { ::kmerind::check(ctx, kmi_index_build_host(idx, bytes, n_bytes, file_offset)); return; }
     need_rccl("build_partition");
     ::kmerind::check(ctx, kmi_index_build_dist_host(idx, rccl, bytes, n_bytes, file_offset));
   }
@@ -629,8 +652,8 @@ class Index {
  protected:
   size_t update_on_device(std::vector<TupleType> &input, uint32_t op) {
     static_assert(MapType::index_kind == KMI_INDEX_COUNT, "update() is a member of the counting / reduction maps");
-    if (comm.size() > 1) throw std::invalid_argument("update with size() > 1 is not wired through the exchange");
-    if (input.empty()) return 0;
+    if (comm.size() > 1) need_rccl("update");
+    if (input.empty() && comm.size() == 1) return 0;
     constexpr unsigned nw = KmerType::nWords;
     std::vector<uint64_t> rec(input.size() * (nw + 1) + 1);
     for (size_t i = 0; i < input.size(); ++i) {
@@ -638,7 +661,9 @@ class Index {
       rec[i * (nw + 1) + nw] = (uint64_t)input[i].second & 0xffffffffull;
     }
     uint64_t n = 0;
-    ::kmerind::check(ctx, kmi_index_update_pairs_host(idx, rec.data(), input.size(), op, &n));
+    // over ranks the pairs travel to the owners of their keys first (collective); the return value counts the pairs applied HERE
+    if (rccl) ::kmerind::check(ctx, kmi_index_update_pairs_dist_host(idx, rccl, rec.data(), input.size(), op, &n));
+    else ::kmerind::check(ctx, kmi_index_update_pairs_host(idx, rec.data(), input.size(), op, &n));
     return (size_t)n;
   }
   template <typename Predicate> static std::vector<TupleType> filtered(std::vector<TupleType> v, Predicate const &pred) {
@@ -664,15 +689,27 @@ class Index {
   template <template <typename> class SeqParser> void build_file(const std::string &filename, uint32_t seq_filter = KMI_SEQ_ALL) {
     uint32_t fmt = detail::format_of(filename);
     if (fmt != SeqParser<const unsigned char *>::KMI) throw std::invalid_argument("Specified File Parser template parameter does not support files with this extension.");
-    if (comm.size() > 1) throw std::invalid_argument("build_* with size() > 1: hand every rank its record-aligned partition (build_partition)");
-    std::vector<uint8_t> bytes = detail::read_whole_file(filename);
     ::kmerind::check(ctx, kmi_index_set_seq_format(idx, fmt));
     ::kmerind::check(ctx, kmi_index_set_seq_filter(idx, seq_filter));
+    if (comm.size() > 1 || (rccl && fmt == KMI_FMT_FASTQ)) {
+      // every rank reads ITS byte range of the file plus look-ahead, finds where its partition begins and ends with the
+      // four-line rule on the device (both neighbours decide at the same file position) and enters the collective build
+      // (partitioned_file + FASTQParser::find_first_record, file.hpp:1216-1430, fastq_loader.hpp:269-364)
+      need_rccl("build_posix / build_mmap / build_mpiio");
+      if (fmt != KMI_FMT_FASTQ) throw std::invalid_argument("build_* with size() > 1 reads FASTQ partitions; a FASTA file over ranks goes through build_partition with kmi_ctx_set_fasta_partition");
+      for (uint64_t look = 1ull << 20;; look *= 8) {
+        detail::FileRange r = detail::read_file_range(filename, comm.rank(), comm.size(), look);
+        int need_more = 0;
+        ::kmerind::check(ctx, kmi_index_build_range_dist_host(idx, rccl, r.bytes.data(), r.bytes.size(), r.offset, r.nominal, r.reaches_eof ? 1 : 0, &need_more));
+        if (!need_more) return;
+      }
+    }
+    std::vector<uint8_t> bytes = detail::read_whole_file(filename);
     ::kmerind::check(ctx, kmi_index_build_host(idx, bytes.data(), bytes.size(), 0));
   }
   void insert_words(const uint64_t *words, size_t n) {
-    if (comm.size() == 1) { ::kmerind::check(ctx, kmi_index_insert_host(idx, words, n)); return; }
     if (rccl) { ::kmerind::check(ctx, kmi_index_insert_dist_host(idx, rccl, words, n)); return; }
+    if (comm.size() == 1) { ::kmerind::check(ctx, kmi_index_insert_host(idx, words, n)); return; }
     std::vector<uint64_t> mine = route_words(words, n);
     ::kmerind::check(ctx, kmi_index_insert_host(idx, mine.data(), mine.size() / KmerType::nWords));
   }
@@ -702,11 +739,10 @@ class Index {
   void insert_tuples(std::vector<TupleType> &temp, std::true_type /* counting map */) {
     auto w = detail::words_of_pairs(temp);
     constexpr unsigned nw = KmerType::nWords;
-    if (comm.size() > 1) {
-      // over ranks the occurrences travel as keys; weights other than 1 only come from callers that reduced before, and those
-      // insert on the rank that owns the keys
+    if (comm.size() > 1 && !rccl) {
+      // (through comm.exchange only keys travel: weights other than 1 need the library's own exchange)
       for (const TupleType &t : temp)
-        if (weight_word(t)[0] != 1ull) throw std::invalid_argument("weighted (k-mer, count) insert with size() > 1: insert the pairs on the rank that owns them");
+        if (weight_word(t)[0] != 1ull) throw std::invalid_argument("weighted (k-mer, count) insert with size() > 1 needs the RCCL communicator (comm.unique_id)");
       insert_words(w.data(), temp.size());
       return;
     }
@@ -715,14 +751,15 @@ class Index {
       std::memcpy(&rec[i * (nw + 1)], &w[i * nw], sizeof(uint64_t) * nw);
       rec[i * (nw + 1) + nw] = weight_word(temp[i])[0] & 0xffffffffull;
     }
-    ::kmerind::check(ctx, kmi_index_insert_pairs_host(idx, rec.data(), temp.size()));
+    if (rccl) ::kmerind::check(ctx, kmi_index_insert_pairs_dist_host(idx, rccl, rec.data(), temp.size()));   // the pairs go to their keys' owners
+    else ::kmerind::check(ctx, kmi_index_insert_pairs_host(idx, rec.data(), temp.size()));
   }
   void insert_tuples(std::vector<TupleType> &temp, std::false_type /* multimap: (k-mer, position id[, quality]) */) {
     auto w = detail::words_of_pairs(temp);
     constexpr unsigned vw = detail::value_words<ValueType>::N;
     std::vector<uint64_t> vals(temp.size() * vw + 1);
     for (size_t i = 0; i < temp.size(); ++i) detail::value_words<ValueType>::to(temp[i].second, &vals[i * vw]);
-    if (comm.size() == 1) { ::kmerind::check(ctx, kmi_index_insert_tuples_host(idx, w.data(), vals.data(), temp.size())); return; }
+    if (comm.size() == 1 && !rccl) { ::kmerind::check(ctx, kmi_index_insert_tuples_host(idx, w.data(), vals.data(), temp.size())); return; }
     need_rccl("multimap insert");
     ::kmerind::check(ctx, kmi_index_insert_tuples_dist_host(idx, rccl, w.data(), vals.data(), temp.size()));
   }
@@ -783,12 +820,24 @@ struct KmerFileHelper {
     c.k = Kmer::size; c.alphabet = Kmer::KmerAlphabet::KMI; c.seq_format = SeqParser<const unsigned char *>::KMI;
     c.index_kind = tuple_kind<typename KmerParser::value_type, Kmer>();
     c.seq_filter = SeqIterType<const unsigned char *, SeqParser>::KMI;
-    if (comm.size() > 1) throw std::invalid_argument("read_file_* with size() > 1: pass each rank its own record-aligned partition");
-    std::vector<uint8_t> bytes = ::bliss::index::kmer::detail::read_whole_file(filename);
     kmi_ctx *ctx = nullptr;
     ::kmerind::check(nullptr, kmi_ctx_create(comm.device, comm.rank(), comm.size(), comm.stream, &ctx));
     kmi_tuples t{};
-    kmi_status st = kmi_extract_host(ctx, &c, bytes.data(), bytes.size(), 0, &t);
+    kmi_status st = KMI_OK;
+    if (comm.size() > 1) {
+      // this rank's partition of the file: its byte range plus look-ahead, cut at record starts by the four-line rule (no
+      // communication: both neighbours apply the rule at the same file position); the ids carry the file offsets
+      if (c.seq_format != KMI_FMT_FASTQ) { kmi_ctx_destroy(ctx); throw std::invalid_argument("read_file_* with size() > 1 reads FASTQ partitions"); }
+      for (uint64_t look = 1ull << 20;; look *= 8) {
+        ::bliss::index::kmer::detail::FileRange r = ::bliss::index::kmer::detail::read_file_range(filename, comm.rank(), comm.size(), look);
+        int need_more = 0;
+        st = kmi_extract_range_host(ctx, &c, r.bytes.data(), r.bytes.size(), r.offset, r.nominal, r.reaches_eof ? 1 : 0, &need_more, &t);
+        if (st != KMI_OK || !need_more) break;
+      }
+    } else {
+      std::vector<uint8_t> bytes = ::bliss::index::kmer::detail::read_whole_file(filename);
+      st = kmi_extract_host(ctx, &c, bytes.data(), bytes.size(), 0, &t);
+    }
     if (st != KMI_OK) { std::string m = kmi_last_error(ctx); kmi_ctx_destroy(ctx); if (st == KMI_ERR_PARSE) throw std::logic_error(m); throw std::invalid_argument(m); }
     const size_t before = result.size();
     result.reserve(before + t.n_tuples);

@@ -149,6 +149,13 @@ typedef struct {
 kmi_status kmi_extract_host(kmi_ctx *ctx, const kmi_config *cfg, const uint8_t *bytes, size_t n_bytes,
                             uint64_t file_offset, kmi_tuples *out /* buffers malloc'd; kmi_tuples_free */);
 void kmi_tuples_free(kmi_tuples *t);
+/* read_file_* of one rank of several (kmer_file_helper.hpp:550-579 over partitioned_file, file.hpp:1216-1430), FASTQ: the rank read
+ * file bytes [buffer_offset, buffer_offset + n_bytes) -- its nominal byte range (nominal_bytes) plus look-ahead -- and parses the
+ * records from the first record start at or after its first byte to the first one at or after the nominal end. *need_more = 1
+ * (nothing parsed): the partition's end is not decidable inside the buffer and the buffer does not reach the file's end. */
+kmi_status kmi_extract_range_host(kmi_ctx *ctx, const kmi_config *cfg, const uint8_t *bytes, size_t n_bytes, uint64_t buffer_offset,
+                                  uint64_t nominal_bytes, int reaches_eof, int *need_more, kmi_tuples *out);
+
 /* device form: out_kmers_dev capacity in tuples (use kmi_extract_count_dev first, or pass an upper bound n_bytes). bytes_dev
  * may point anywhere (a record-aligned batch inside a larger buffer): an input that is not 16-byte aligned is copied once,
  * device to device, to an aligned workspace buffer. */
@@ -170,6 +177,11 @@ kmi_status kmi_extract_records_dev(kmi_ctx *ctx, const kmi_config *cfg, const ui
  * partitioned_file applies it, file.hpp:1216-1430); cuts[n_parts] = n_bytes; the ranges [cuts[r], cuts[r + 1]) tile the
  * buffer. What every rank hands to kmi_index_build_* / kmi_extract_* when one buffer is split between ranks or batches. */
 kmi_status kmi_fastq_partition_dev(kmi_ctx *ctx, const uint8_t *bytes_dev, size_t n_bytes, uint32_t n_parts, uint64_t *cuts_host /* n_parts + 1 */);
+/* the same rule for explicit positions: starts_host[i] = first record start at or after positions_host[i] in the buffer (n_bytes
+ * when the buffer holds none behind it). What a rank that read only ITS byte range of a file (plus some look-ahead) uses to find
+ * where its partition begins and ends (file.hpp:1342-1422): both neighbours apply the rule at the same file position. */
+kmi_status kmi_fastq_find_records_dev(kmi_ctx *ctx, const uint8_t *bytes_dev, size_t n_bytes, int buffer_starts_file /* byte 0 = the file's first byte */,
+                                      const uint64_t *positions_host, uint32_t n_pos, uint64_t *starts_host);
 
 /* ---- L4: the exchange step of imxx::distribute (incremental_mxx.hpp:1039-1109):
  * assign_to_buckets + bucket_to_permutation + permute on the device. Output is the
@@ -325,6 +337,19 @@ kmi_status kmi_index_build_dist_host(kmi_index *idx, kmi_comm *comm, const uint8
  * message (so all ranks cut the transfer into the same pieces without another collective) and an exchange whose largest message
  * exceeds every one that carried checksums before is verified on arrival. */
 kmi_status kmi_index_build_dist_dev(kmi_index *idx, kmi_comm *comm, const uint8_t *bytes_dev, size_t n_bytes, uint64_t file_offset);
+/* Index::build_posix / build_mmap / build_mpiio(filename, comm) with comm.size() > 1 (kmer_index.hpp:239-372 over
+ * partitioned_file, file.hpp:1216-1430), FASTQ: `bytes` = what this rank read of the file, file bytes [buffer_offset,
+ * buffer_offset + n_bytes) -- its nominal range [buffer_offset, buffer_offset + nominal_bytes) plus look-ahead. The partition
+ * begins at the first record start at or after the buffer's first byte (the file's first byte for buffer_offset 0) and ends at the
+ * first record start at or after the nominal end (four-line rule, on the device); reaches_eof says that the buffer ends with the
+ * file. *need_more = 1 and nothing done when the end cannot be decided inside the buffer: read further and call again (no
+ * collective has been entered). Then the collective build of that partition. Works for comm.size() == 1 too. */
+kmi_status kmi_index_build_range_dist_host(kmi_index *idx, kmi_comm *comm, const uint8_t *bytes, size_t n_bytes, uint64_t buffer_offset,
+                                           uint64_t nominal_bytes, int reaches_eof, int *need_more);
+/* weighted insert and update() of the counting maps with comm.size() > 1: the pairs travel to the ranks that own their keys
+ * (records: n x (n_words key words, one value word); *n_updated = pairs applied on THIS rank) */
+kmi_status kmi_index_insert_pairs_dist_host(kmi_index *idx, kmi_comm *comm, const uint64_t *records, size_t n);
+kmi_status kmi_index_update_pairs_dist_host(kmi_index *idx, kmi_comm *comm, const uint64_t *records, size_t n, uint32_t op, uint64_t *n_updated);
 kmi_status kmi_index_count_dist_host(kmi_index *idx, kmi_comm *comm, const uint64_t *queries, size_t nq, kmi_results *out);
 kmi_status kmi_index_find_dist_host(kmi_index *idx, kmi_comm *comm, const uint64_t *queries, size_t nq, kmi_results *out);
 kmi_status kmi_index_erase_dist_host(kmi_index *idx, kmi_comm *comm, const uint64_t *queries, size_t nq, uint64_t *n_erased_local);

@@ -121,6 +121,11 @@ SIGNATURES = {
     "kmi_index_insert_tuples_dist_host": (C.c_int, [_P, _P, _P, _P, _sz]),
     "kmi_index_build_dist_host": (C.c_int, [_P, _P, _P, _sz, _u64]),
     "kmi_index_build_dist_dev": (C.c_int, [_P, _P, _P, _sz, _u64]),
+    "kmi_index_build_range_dist_host": (C.c_int, [_P, _P, _P, _sz, _u64, _u64, C.c_int, C.POINTER(C.c_int)]),
+    "kmi_index_insert_pairs_dist_host": (C.c_int, [_P, _P, _P, _sz]),
+    "kmi_index_update_pairs_dist_host": (C.c_int, [_P, _P, _P, _sz, _u32, C.POINTER(_u64)]),
+    "kmi_extract_range_host": (C.c_int, [_P, _CFG, _P, _sz, _u64, _u64, C.c_int, C.POINTER(C.c_int), C.POINTER(Tuples)]),
+    "kmi_fastq_find_records_dev": (C.c_int, [_P, _P, _sz, C.c_int, _P, _u32, _P]),
     "kmi_index_count_dist_host": (C.c_int, [_P, _P, _P, _sz, C.POINTER(Results)]),
     "kmi_index_find_dist_host": (C.c_int, [_P, _P, _P, _sz, C.POINTER(Results)]),
     "kmi_index_erase_dist_host": (C.c_int, [_P, _P, _P, _sz, C.POINTER(_u64)]),

@@ -357,6 +357,31 @@ kmi_status kmi_extract_host(kmi_ctx *ctx, const kmi_config *cfg, const uint8_t *
   return KMI_OK;
 }
 
+// read_file_* of ONE rank of several (kmer_file_helper.hpp:550-579 over partitioned_file, file.hpp:1216-1430), FASTQ: the rank
+// read file bytes [buffer_offset, buffer_offset + n_bytes) = its nominal range of nominal_bytes plus look-ahead; its partition
+// runs from the first record start at or after the buffer's first byte to the first one at or after the nominal end
+// (kmi_fastq_find_records_dev). *need_more = 1, nothing parsed: the end is not decidable inside the buffer -- read further.
+kmi_status kmi_extract_range_host(kmi_ctx *ctx, const kmi_config *cfg, const uint8_t *bytes, size_t n_bytes, uint64_t buffer_offset,
+                                  uint64_t nominal_bytes, int reaches_eof, int *need_more, kmi_tuples *out) {
+  if (!ctx || !out || !need_more) return KMI_ERR_INVALID;
+  memset(out, 0, sizeof(*out));
+  *need_more = 0;
+  if (cfg->seq_format != KMI_FMT_FASTQ) return set_err(ctx, KMI_ERR_INVALID, "a byte range of a file is cut at FASTQ record starts here");
+  if (n_bytes == 0) return KMI_OK;
+  if (!bytes) return set_err(ctx, KMI_ERR_INVALID, "null buffer");
+  KMI_HIP(ctx, hipSetDevice(ctx->device));
+  if (nominal_bytes > n_bytes) nominal_bytes = n_bytes;
+  void *din;
+  KMI_TRY(ws_get(ctx, WS_INPUT2, n_bytes + 64, &din));
+  KMI_HIP(ctx, hipMemcpyAsync(din, bytes, n_bytes, hipMemcpyHostToDevice, ctx->stream));
+  uint64_t pos[2] = {0, nominal_bytes}, cut[2] = {0, n_bytes};
+  KMI_TRY(kmi_fastq_find_records_dev(ctx, (const uint8_t *)din, n_bytes, buffer_offset == 0, pos, 2, cut));
+  if (nominal_bytes >= n_bytes) cut[1] = n_bytes;
+  if (!reaches_eof && (cut[1] >= n_bytes || (cut[0] >= n_bytes && buffer_offset != 0))) { *need_more = 1; return KMI_OK; }
+  if (cut[1] < cut[0]) cut[1] = cut[0];
+  return kmi_extract_host(ctx, cfg, bytes + cut[0], (size_t)(cut[1] - cut[0]), buffer_offset + cut[0], out);
+}
+
 void kmi_tuples_free(kmi_tuples *t) {
   if (!t) return;
   free(t->kmers); free(t->ids); free(t->quals);

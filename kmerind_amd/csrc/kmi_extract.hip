@@ -1036,12 +1036,11 @@ kmi_status extract_run(kmi_ctx *ctx, const kmi_config *cfg, const uint8_t *bytes
 // of the line the split falls in, look at the first characters of the next four lines; a record starts at the line
 // where '@' is followed two lines later by '+' (a quality line may itself begin with '@').
 // ---------------------------------------------------------------------------
-__global__ void fastq_find_first_records_kernel(const uint8_t *__restrict__ bytes, uint64_t n, uint32_t n_parts, uint64_t *__restrict__ cuts) {
-  const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (r > n_parts) return;
-  if (r == n_parts) { cuts[r] = n; return; }
-  const uint64_t pos = n / n_parts * r + (n % n_parts) * r / n_parts;   // = floor(n r / n_parts) without overflow
-  if (pos == 0) { cuts[r] = 0; return; }
+// first record start at or after `pos` (n when there is none in the buffer)
+__device__ __forceinline__ uint64_t fastq_first_record_from(const uint8_t *__restrict__ bytes, uint64_t n, uint64_t pos, bool starts_file = true) {
+  // starts_file = false: byte 0 of the buffer lies somewhere inside the file, so position 0 is examined like any other
+  if (pos == 0 && starts_file) return 0;
+  if (pos >= n) return n;
   auto eol = [&](uint64_t i) { return bytes[i] == '\n' || bytes[i] == '\r'; };
   uint64_t i = pos;
   while (i < n && !eol(i)) ++i;          // the rest of this (partial) line
@@ -1049,7 +1048,7 @@ __global__ void fastq_find_first_records_kernel(const uint8_t *__restrict__ byte
   uint8_t firsts[4];
   for (int l = 0; l < 4; ++l) {
     while (i < n && eol(i)) ++i;
-    if (i >= n) { cuts[r] = n; return; }
+    if (i >= n) return n;
     starts[l] = i; firsts[l] = bytes[i];
     while (i < n && !eol(i)) ++i;
   }
@@ -1058,7 +1057,19 @@ __global__ void fastq_find_first_records_kernel(const uint8_t *__restrict__ byte
   else if (firsts[1] == '@' && firsts[3] == '+') c = starts[1];
   else if (firsts[0] == '+' && firsts[2] == '@') c = starts[2];
   else if (firsts[1] == '+' && firsts[3] == '@') c = starts[3];
-  cuts[r] = c;
+  return c;
+}
+__global__ void fastq_find_first_records_kernel(const uint8_t *__restrict__ bytes, uint64_t n, uint32_t n_parts, uint64_t *__restrict__ cuts) {
+  const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r > n_parts) return;
+  if (r == n_parts) { cuts[r] = n; return; }
+  const uint64_t pos = n / n_parts * r + (n % n_parts) * r / n_parts;   // = floor(n r / n_parts) without overflow
+  cuts[r] = fastq_first_record_from(bytes, n, pos);
+}
+// the same for explicit positions (cuts[i] holds position i on entry, the record start on exit)
+__global__ void fastq_find_records_at_kernel(const uint8_t *__restrict__ bytes, uint64_t n, uint32_t n_pos, uint64_t *__restrict__ cuts, bool starts_file) {
+  const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < n_pos) cuts[r] = fastq_first_record_from(bytes, n, cuts[r], starts_file);
 }
 
 }  // namespace kmi
@@ -1076,6 +1087,23 @@ extern "C" kmi_status kmi_fastq_partition_dev(kmi_ctx *ctx, const uint8_t *bytes
   KMI_HIP(ctx, hipMemcpyAsync(cuts_host, p, sizeof(uint64_t) * ((size_t)n_parts + 1), hipMemcpyDeviceToHost, ctx->stream));
   KMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
   for (uint32_t r = 1; r <= n_parts; ++r) cuts_host[r] = std::max(cuts_host[r], cuts_host[r - 1]);   // ranges tile the buffer
+  return KMI_OK;
+}
+
+extern "C" kmi_status kmi_fastq_find_records_dev(kmi_ctx *ctx, const uint8_t *bytes_dev, size_t n_bytes, int buffer_starts_file,
+                                                 const uint64_t *positions_host, uint32_t n_pos, uint64_t *starts_host) {
+  using namespace kmi;
+  if (!ctx || !positions_host || !starts_host) return KMI_ERR_INVALID;
+  KMI_HIP(ctx, hipSetDevice(ctx->device));
+  if (n_pos == 0) return KMI_OK;
+  void *p;
+  KMI_TRY(ws_get(ctx, WS_MISC, sizeof(uint64_t) * (size_t)n_pos, &p));
+  KMI_HIP(ctx, hipMemcpyAsync(p, positions_host, sizeof(uint64_t) * n_pos, hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(fastq_find_records_at_kernel, dim3((n_pos + 63) / 64), dim3(64), 0, ctx->stream, bytes_dev, (uint64_t)n_bytes, n_pos, (uint64_t *)p,
+                     buffer_starts_file != 0);
+  KMI_HIP(ctx, hipGetLastError());
+  KMI_HIP(ctx, hipMemcpyAsync(starts_host, p, sizeof(uint64_t) * n_pos, hipMemcpyDeviceToHost, ctx->stream));
+  KMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return KMI_OK;
 }
 

@@ -3421,9 +3421,12 @@ static kmi_status read_rank_counts(kmi_ctx *ctx, const uint64_t *cnt_dev, uint32
 
 template <int NW, int BITS, int VW>
 static kmi_status route_vw(kmi_ctx *ctx, const kmi_config *cfg, KShape shape, const uint64_t *keys_dev, size_t n, uint32_t nranks,
-                           uint64_t *out_keys_dev, uint64_t *send_counts_host, const float *in_q = nullptr, const uint64_t *in_v = nullptr) {
+                           uint64_t *out_keys_dev, uint64_t *send_counts_host, const float *in_q = nullptr, const uint64_t *in_v = nullptr,
+                           bool by_owner = false) {
   // in_q (VW == 2): the input records are (key words, id), the quality word of record i is in_q[i]; in_v: keys_dev holds the
   // key words alone and in_v the ids (scatter_range)
+  // by_owner (one-word 2-bit keys): the rank is the owner of the key's minimizer bucket (an index built through exchanged
+  // super-k-mers), not KeyToRank's hash
   void *p;
   KMI_TRY(ws_get(ctx, WS_WGHIST, sizeof(uint32_t) * kPartGroups * kNumCoarse, &p)); uint32_t *wg_hist = (uint32_t *)p;
   KMI_TRY(ws_get(ctx, WS_CURSOR, sizeof(uint64_t) * kPartGroups * kNumCoarse, &p)); uint64_t *wg_off = (uint64_t *)p;
@@ -3431,6 +3434,7 @@ static kmi_status route_vw(kmi_ctx *ctx, const kmi_config *cfg, KShape shape, co
   BucketFn fn; fn.mode = BUCKET_RANK; fn.shape = shape; fn.dist_hash = cfg->dist_hash; fn.farm_ndebug = cfg->farm_ndebug != 0; fn.nranks = nranks;
   fn.dist_trans = cfg->dist_trans; fn.rank_magic = rank_magic_of(nranks);
   fn.sub = rank_sub_buckets(nranks);
+  if (by_owner) { fn.owner_w = sk_window_of(shape.k); fn.dist_trans = 0; }
   const uint32_t nb = nranks * fn.sub;
   {
     ProfScope ps(ctx, "hist_rank", n);
@@ -3449,6 +3453,18 @@ static kmi_status route_vw(kmi_ctx *ctx, const kmi_config *cfg, KShape shape, co
   }
   KMI_HIP(ctx, hipGetLastError());
   return read_rank_counts(ctx, cnt, nranks, fn.sub, send_counts_host);
+}
+
+// (k-mer, count) records of a counting map grouped by destination rank: KeyToRank, or the owner of the minimizer bucket
+template <int NW, int BITS>
+static kmi_status route_pairs_impl(kmi_ctx *ctx, const kmi_config *cfg, KShape shape, const uint64_t *recs_dev, size_t n, uint32_t nranks, bool by_owner,
+                                   uint64_t *out_dev, uint64_t *send_counts_host) {
+  return route_vw<NW, BITS, 1>(ctx, cfg, shape, recs_dev, n, nranks, out_dev, send_counts_host, nullptr, nullptr, by_owner);
+}
+static kmi_status route_pairs(kmi_ctx *ctx, const kmi_config *cfg, KShape shape, const uint64_t *recs_dev, size_t n, uint32_t nranks, bool by_owner,
+                              uint64_t *out_dev, uint64_t *send_counts_host) {
+  if (n == 0) { for (uint32_t r = 0; r < nranks; ++r) send_counts_host[r] = 0; return KMI_OK; }
+  KMI_DISPATCH(shape, route_pairs_impl, ctx, cfg, shape, recs_dev, n, nranks, by_owner, out_dev, send_counts_host);
 }
 
 // queries (and anything else keyed by k-mer) to the rank that owns the key's minimizer bucket
@@ -4109,6 +4125,56 @@ kmi_status kmi_index_insert_tuples_dist_host(kmi_index *idx, kmi_comm *comm, con
   return index_insert_records(idx, (const uint64_t *)d_recv, (size_t)total, true);   // (the transform is idempotent)
 }
 
+// weighted insert and update() of the counting maps over ranks (distributed_unordered_map.hpp:1603-1618 behind insert's
+// distribute; distributed_densehash_map.hpp:1975-2030): the (k-mer, value) pairs travel to the ranks that own their keys --
+// KeyToRank, or the owner of the minimizer bucket when that is how the entries are distributed (agreed over the ranks) -- and
+// are applied there. records: n x (n_words key words, one value word).
+static kmi_status pairs_to_owners(kmi_index *idx, kmi_comm *comm, const uint64_t *records, size_t n, void **d_recv, uint64_t *total) {
+  kmi_ctx *ctx = idx->ctx;
+  const int p = kmi::comm_size(comm);
+  const uint32_t rw = idx->shape.n_words + 1;
+  void *d_in, *d_send;
+  KMI_TRY(ws_get(ctx, WS_INPUT, (n + 8) * rw * sizeof(uint64_t), &d_in));
+  KMI_TRY(ws_get(ctx, WS_DIST_A, (n + 8) * rw * sizeof(uint64_t), &d_send));
+  if (n) KMI_HIP(ctx, hipMemcpyAsync(d_in, records, n * rw * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+  uint64_t holders = 0, owner_p = 0, owner_any = 0;
+  KMI_TRY(dist_state(idx, comm, &holders, &owner_p, &owner_any));
+  const bool by_owner = owner_any != 0 && holders != 0;
+  if (by_owner && !idx->owner_lp) idx->owner_lp = 31u - (uint32_t)__builtin_clz((uint32_t)p);
+  std::vector<uint64_t> sc(p, 0), rc;
+  KMI_TRY(route_pairs(ctx, &idx->cfg, idx->shape, (const uint64_t *)d_in, n, (uint32_t)p, by_owner, (uint64_t *)d_send, sc.data()));
+  return dist_exchange(comm, d_send, sc.data(), rw * sizeof(uint64_t), WS_DIST_B, d_recv, rc, total);
+}
+
+kmi_status kmi_index_insert_pairs_dist_host(kmi_index *idx, kmi_comm *comm, const uint64_t *records, size_t n) {
+  KMI_TRY(dist_check(idx, comm));
+  kmi_ctx *ctx = idx->ctx;
+  if (idx->val_words) return set_err(ctx, KMI_ERR_INVALID, "(k-mer, count) pairs go into a count index");
+  if (n && !records) return set_err(ctx, KMI_ERR_INVALID, "null buffer");
+  if (kmi::comm_size(comm) == 1 && !ctx->force_dist) return kmi_index_insert_pairs_host(idx, records, n);
+  void *d_recv; uint64_t total = 0;
+  KMI_TRY(pairs_to_owners(idx, comm, records, n, &d_recv, &total));
+  const uint32_t lp = idx->owner_lp;
+  kmi_status st = index_insert_pairs(idx, (const uint64_t *)d_recv, (size_t)total, true, false);   // (the strand transform is idempotent)
+  idx->owner_lp = lp;
+  return st;
+}
+
+kmi_status kmi_index_update_pairs_dist_host(kmi_index *idx, kmi_comm *comm, const uint64_t *records, size_t n, uint32_t op, uint64_t *n_updated) {
+  KMI_TRY(dist_check(idx, comm));
+  kmi_ctx *ctx = idx->ctx;
+  if (!n_updated) return KMI_ERR_INVALID;
+  *n_updated = 0;
+  if (idx->val_words) return set_err(ctx, KMI_ERR_INVALID, "update() is a member of the counting maps");
+  if (op > KMI_UPDATE_ASSIGN) return set_err(ctx, KMI_ERR_INVALID, "unknown updater");
+  if (n && !records) return set_err(ctx, KMI_ERR_INVALID, "null buffer");
+  if (kmi::comm_size(comm) == 1 && !ctx->force_dist) return kmi_index_update_pairs_host(idx, records, n, op, n_updated);
+  void *d_recv; uint64_t total = 0;
+  KMI_TRY(pairs_to_owners(idx, comm, records, n, &d_recv, &total));   // (pairs of one key arrive in source-rank order, each source's in input order)
+  if (total == 0) return KMI_OK;
+  return index_update_pairs(idx, (uint64_t *)d_recv, (size_t)total, (int)op, n_updated);
+}
+
 }  // extern "C"
 
 // one 64-bit all-reduce carries what every rank must agree on before it picks a route: field 0 (bits 0..15) ranks that hold
@@ -4275,6 +4341,29 @@ kmi_status kmi_index_build_dist_dev(kmi_index *idx, kmi_comm *comm, const uint8_
                                           &nt, &ns, sc.data()));
   KMI_TRY(dist_exchange(comm, d_send, sc.data(), rw * sizeof(uint64_t), WS_DIST_B, &d_recv, rc, &total));
   return index_insert_records(idx, (const uint64_t *)d_recv, (size_t)total, true);
+}
+
+kmi_status kmi_index_build_range_dist_host(kmi_index *idx, kmi_comm *comm, const uint8_t *bytes, size_t n_bytes, uint64_t buffer_offset,
+                                           uint64_t nominal_bytes, int reaches_eof, int *need_more) {
+  KMI_TRY(dist_check(idx, comm));
+  kmi_ctx *ctx = idx->ctx;
+  if (!need_more) return KMI_ERR_INVALID;
+  *need_more = 0;
+  if (n_bytes && !bytes) return set_err(ctx, KMI_ERR_INVALID, "null buffer");
+  if (idx->cfg.seq_format != KMI_FMT_FASTQ) return set_err(ctx, KMI_ERR_INVALID, "a byte range of a file is cut at FASTQ record starts here (a FASTA partition comes with kmi_ctx_set_fasta_partition)");
+  if (nominal_bytes > n_bytes) nominal_bytes = n_bytes;
+  void *d_bytes;
+  KMI_TRY(ws_get(ctx, WS_INPUT, n_bytes + 64, &d_bytes));
+  uint64_t pos[2] = {0, nominal_bytes}, cut[2] = {0, n_bytes};
+  if (n_bytes) {
+    KMI_HIP(ctx, hipMemcpyAsync(d_bytes, bytes, n_bytes, hipMemcpyHostToDevice, ctx->stream));
+    KMI_TRY(kmi_fastq_find_records_dev(ctx, (const uint8_t *)d_bytes, n_bytes, buffer_offset == 0, pos, 2, cut));
+    if (nominal_bytes >= n_bytes) cut[1] = n_bytes;   // (the nominal range is the rest of the buffer)
+  }
+  if (cut[1] >= n_bytes && !reaches_eof && n_bytes) { *need_more = 1; return KMI_OK; }   // no record start behind the nominal end in what was read
+  if (cut[0] >= n_bytes && !reaches_eof && n_bytes && buffer_offset != 0) { *need_more = 1; return KMI_OK; }
+  if (cut[1] < cut[0]) cut[1] = cut[0];
+  return kmi_index_build_dist_dev(idx, comm, (const uint8_t *)d_bytes + cut[0], (size_t)(cut[1] - cut[0]), buffer_offset + cut[0]);
 }
 
 kmi_status kmi_index_build_dist_host(kmi_index *idx, kmi_comm *comm, const uint8_t *bytes, size_t n_bytes, uint64_t file_offset) {

@@ -14,11 +14,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 DATA = os.path.join(ROOT, "tests", "golden", "data")
 
 
-def _run(binary, fastq, ratio):
+def _run(binary, fastq, ratio, force_dist=False):
     exe = os.path.join(ROOT, "examples", binary)
     if not os.path.exists(exe):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "examples")])
-    out = subprocess.run([exe, "-F", fastq, "-S", str(ratio)], capture_output=True, text=True, timeout=300)
+    env = dict(os.environ, KMI_FORCE_DIST="1") if force_dist else None
+    out = subprocess.run([exe, "-F", fastq, "-S", str(ratio)], capture_output=True, text=True, timeout=300, env=env)
     assert out.returncode == 0, out.stderr
     nums = {}
     for key, pat in (("total", r"total size is (\d+)"), ("distinct", r"after insert/rehash is (\d+)"),
@@ -36,10 +37,13 @@ def _run(binary, fastq, ratio):
     ("bench_count_k31_single_farm", 31, orc.SINGLE, "natural.fastq"),
     ("bench_count_k21_dna", 21, orc.CANONICAL, "test.unitiqs.fastq"),
 ])
-def test_benchmark_harness_matches_oracle(binary, k, strand, fname):
+@pytest.mark.parametrize("force_dist", [False, True])
+def test_benchmark_harness_matches_oracle(binary, k, strand, fname, force_dist):
+    """the reference's BenchmarkKmerIndex sequence through the facade; force_dist: the SAME binary with KMI_FORCE_DIST=1 -- a one-rank
+    RCCL communicator, so insert (weighted pairs to their owners), size, count, find and erase take the collectives of size() > 1"""
     path = os.path.join(DATA, fname)
     ratio = 3
-    got = _run(binary, path, ratio)
+    got = _run(binary, path, ratio, force_dist)
     s = orc.kspec(k)
     ex = orc.extract(s, open(path, "rb").read(), orc.FASTQ)
     m = orc.CountMap(s, strand)
@@ -197,14 +201,16 @@ def test_position_quality_index_harness_matches_oracle():
     assert got["after_erase"] == (m.size(),)
 
 
-def test_weighted_insert_iterators_and_posqual_through_the_facade():
+@pytest.mark.parametrize("force_dist", [False, True])
+def test_weighted_insert_iterators_and_posqual_through_the_facade(force_dist):
     """examples/facade_extras.cpp: insert(vector<pair<Kmer, count>>) adds the values (weights 1 then 3 per occurrence ->
     4 x occurrences), cbegin()/cend()/get_map() walk this rank's entries, PositionQualityIndex tuples round-trip."""
     exe = os.path.join(ROOT, "examples", "facade_extras")
     if not os.path.exists(exe):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "examples")])
     path = os.path.join(DATA, "natural.fastq")
-    out = subprocess.run([exe, path], capture_output=True, text=True, timeout=300)
+    env = dict(os.environ, KMI_FORCE_DIST="1") if force_dist else None
+    out = subprocess.run([exe, path], capture_output=True, text=True, timeout=300, env=env)
     assert out.returncode == 0, out.stderr
 
     def grab(pat):
@@ -236,6 +242,10 @@ def test_weighted_insert_iterators_and_posqual_through_the_facade():
     for j, kk in enumerate(canon[::3].tolist()):
         val[tuple(kk)] = j % 1000
     assert grab(r"device max hit (\d+) sum (\d+) assign hit (\d+) sum (\d+)") == (len(canon[::7]), s3, len(canon[::3]), sum(val.values()))
+    # build_posix (with KMI_FORCE_DIST=1: the byte-range + record-aligned + collective form of size() > 1) and exists()
+    present = {tuple(kk) for kk in keys.tolist()}
+    qq = canon[::4].tolist()
+    assert grab(r"build_posix entries (\d+) sum (\d+) exists (\d+) of (\d+)") == (cm.size(), n, sum(1 for kk in qq if tuple(kk) in present), len(qq) + 1)
     assert grab(r"get_map local_size (\d+) size (\d+)") == (cm.size(), cm.size())
     vals = np.stack([ex["ids"], ex["quals"].view(np.uint32).astype(np.uint64)], axis=1)
     mm = orc.MultiMap(s, orc.CANONICAL, vw=2)
