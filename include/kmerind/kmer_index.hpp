@@ -424,6 +424,8 @@ class Index {
     cfg = detail::make_config<MapType>(KMI_FMT_FASTQ);
     ::kmerind::check(nullptr, kmi_ctx_create(comm.device, comm.rank(), comm.size(), comm.stream, &ctx));
     ::kmerind::check(ctx, kmi_index_create(ctx, &cfg, &idx));
+    // sat_plus of a 32-bit count runs on the device (narrower count types saturate when they are read, count_of)
+    if (MapType::saturating && MapType::index_kind == KMI_INDEX_COUNT) ::kmerind::check(ctx, kmi_index_set_saturating(idx, 1));
     if (comm.size() > 1 && !comm.exchange) {   // the exchange runs inside the library over RCCL (collective: every rank constructs)
       if (comm.unique_id.size() != KMI_COMM_ID_BYTES)
         throw std::invalid_argument("comm.size() > 1 needs comm.unique_id (kmerind::comm::make_unique_id() on rank 0, handed to every rank) or comm.exchange");

@@ -119,6 +119,13 @@ typedef struct {
   uint32_t reserved;
 } kmi_fasta_partition;
 kmi_status kmi_ctx_set_fasta_partition(kmi_ctx *ctx, const kmi_fasta_partition *part);
+/* the same bookkeeping computed ON THE DEVICE for every block of an n_parts-way split of a FASTA buffer that sits in HBM (the
+ * partition negotiation of file.hpp:1436-1610 + fasta_loader.hpp:202-470): block r = bytes [begin_end_host[2 r], begin_end_host
+ * [2 r + 1]) of the buffer -- its nominal range [floor(n r / p), floor(n (r + 1) / p)) plus the overlap that holds k - 1 further
+ * sequence characters -- and parts_host[r] what kmi_ctx_set_fasta_partition wants for it. Machine state and record count at a byte
+ * come from prefix sums over the scan's tile summaries. */
+kmi_status kmi_fasta_partition_dev(kmi_ctx *ctx, const uint8_t *bytes_dev, size_t n_bytes, uint32_t n_parts, uint32_t k,
+                                   uint64_t *begin_end_host /* 2 * n_parts */, kmi_fasta_partition *parts_host /* n_parts */);
 
 /* ---- L2: k-mer value ops on arrays (parity surface for kmer.hpp / kmer_transform.hpp) */
 /* Kmer::reverse_complement (kmer.hpp:1118-1127) on n k-mers */
@@ -398,6 +405,11 @@ kmi_status kmi_index_owner_ranks(kmi_index *idx, uint32_t *nranks);
  * k-mers, 3- / 4-bit alphabets, k < 17, a multimap, a context created with KMI_FUSED_PATH=kmer): callers that choose between
  * the record exchange and another route decide from this, identically on every rank */
 kmi_status kmi_index_sk_width(kmi_index *idx, uint32_t *w);
+/* the reducer of a counting map: 0 (default) = std::plus<uint32_t>, counts wrap (distributed_unordered_map.hpp:1603-1618);
+ * 1 = sat_plus<uint32_t> of saturating_counting_densehash_map (distributed_densehash_map.hpp:2903-2912): a count that would pass
+ * 2^32 - 1 stays there. Applies wherever counts are ADDED -- weighted pairs, merging into an index that holds entries, parts
+ * received from other ranks. (A single call is assumed to hold fewer than 2^32 occurrences of one key.) */
+kmi_status kmi_index_set_saturating(kmi_index *idx, int on);
 kmi_status kmi_index_set_owner_ranks(kmi_index *idx, uint32_t nranks);
 
 /* ---- de Bruijn graph nodes ------------------------------------------------------

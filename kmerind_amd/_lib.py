@@ -62,6 +62,7 @@ SIGNATURES = {
     "kmi_ctx_create": (C.c_int, [C.c_int, C.c_int, C.c_int, _P, C.POINTER(_P)]),
     "kmi_ctx_destroy": (C.c_int, [_P]),
     "kmi_ctx_set_fasta_partition": (C.c_int, [_P, _P]),
+    "kmi_fasta_partition_dev": (C.c_int, [_P, _P, _sz, _u32, _u32, _P, _P]),
     "kmi_last_error": (C.c_char_p, [_P]),
     "kmi_kmer_shape": (C.c_int, [_CFG, C.POINTER(_u32), C.POINTER(_u32), C.POINTER(_u32)]),
     "kmi_free_host": (None, [_P]),
@@ -137,6 +138,7 @@ SIGNATURES = {
     "kmi_route_owner_dev": (C.c_int, [_P, _CFG, _P, _sz, _u32, _P, _P]),
     "kmi_index_owner_ranks": (C.c_int, [_P, C.POINTER(_u32)]),
     "kmi_index_sk_width": (C.c_int, [_P, C.POINTER(_u32)]),
+    "kmi_index_set_saturating": (C.c_int, [_P, C.c_int]),
     "kmi_index_set_owner_ranks": (C.c_int, [_P, _u32]),
     "kmi_dbg_create": (C.c_int, [_P, _CFG, _u32, C.POINTER(_P)]),
     "kmi_dbg_destroy": (C.c_int, [_P]),

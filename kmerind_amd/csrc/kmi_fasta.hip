@@ -471,4 +471,108 @@ kmi_status fasta_scan(kmi_ctx *ctx, const kmi_config *cfg, const uint8_t *bytes_
   return KMI_OK;
 }
 
+
+// ---- FASTA partition bookkeeping on the device (file.hpp:1436-1610, fasta_loader.hpp:202-470): what FASTAParser::init_parser
+// learns from the neighbouring ranks, for every block of an n_parts-way split of a buffer that sits in HBM. The state of the
+// line-kind machine and the records started so far at ANY byte are the tile bases of the scan above (prefix sums over the tile
+// summaries) plus a walk of at most one 8 KB tile; the end of a block's overlap (k - 1 further sequence characters) is a short
+// walk forward. One thread per block: the walks are a few thousand bytes.
+struct FaPart { uint64_t begin, end, valid_bytes, start_state, at_line_start, records_before, index_shift; };
+
+__global__ void fasta_partition_cuts_kernel(const uint8_t *__restrict__ bytes, uint64_t n, uint32_t n_parts, uint32_t k, const FaTileBase *__restrict__ base,
+                                            FaPart *__restrict__ out) {
+  const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n_parts) return;
+  auto cut = [&](uint32_t i) -> uint64_t { return i >= n_parts ? n : n / n_parts * i + (n % n_parts) * i / n_parts; };
+  auto line_start = [&](uint64_t i) { return i == 0 || bytes[i - 1] == '\n'; };
+  auto step = [&](uint32_t &state, uint64_t &ev, uint8_t c) {   // the line that starts with byte c
+    if (c == '>' || c == ';') state = FA_H;
+    else { if (state == FA_H) ++ev; state = (state == FA_O) ? FA_O : FA_S; }
+  };
+  // machine state just before byte pos is looked at (kind of the line byte pos - 1 sits on), records started before pos
+  auto state_at = [&](uint64_t pos, uint32_t &state, uint64_t &ev) {
+    const uint64_t t = pos / FaCfg::TILE, t0 = t * FaCfg::TILE;
+    state = base[t].state; ev = base[t].ev;
+    for (uint64_t i = t0; i < pos; ++i) if (line_start(i)) step(state, ev, bytes[i]);
+  };
+  const uint64_t b = cut(r), e = cut(r + 1);
+  FaPart o;
+  o.index_shift = (n && (bytes[0] == '>' || bytes[0] == ';')) ? 0u : 1u;
+  if (b >= n) { o.begin = n; o.end = n; o.valid_bytes = 0; o.start_state = FA_O; o.at_line_start = 1; o.records_before = 0; out[r] = o; return; }
+  uint32_t st; uint64_t ev;
+  state_at(b, st, ev);
+  const bool ls = line_start(b);
+  uint32_t start_state = st;          // a line that STARTS at b is classified by the machine itself from the previous line's kind
+  if (!ls) start_state = st;          // (st is the kind of the line b sits on: its start lies before b)
+  o.begin = b; o.valid_bytes = e - b;
+  o.start_state = (b == 0) ? (uint32_t)FA_O : start_state;
+  o.at_line_start = ls ? 1u : 0u;
+  o.records_before = ev;
+  // the overlap: bytes up to and including the (k - 1)-th sequence character at or behind e
+  uint64_t end = e;
+  if (k > 1 && e < n) {
+    uint32_t se; uint64_t ee;
+    state_at(e, se, ee);
+    uint32_t need = k - 1u;
+    uint64_t i = e;
+    for (; i < n && need; ++i) {
+      const uint8_t c = bytes[i];
+      if (line_start(i)) step(se, ee, c);
+      if (se == FA_S && c != '\n' && c != '\r') --need;
+    }
+    end = need ? n : i;
+  }
+  o.end = end < e ? e : (end > n ? n : end);
+  out[r] = o;
+}
+
+}  // namespace kmi
+
+extern "C" kmi_status kmi_fasta_partition_dev(kmi_ctx *ctx, const uint8_t *bytes_dev, size_t n_bytes, uint32_t n_parts, uint32_t k,
+                                              uint64_t *begin_end_host, kmi_fasta_partition *parts_host) {
+  using namespace kmi;
+  if (!ctx || !begin_end_host || !parts_host || n_parts == 0 || k == 0) return KMI_ERR_INVALID;
+  KMI_HIP(ctx, hipSetDevice(ctx->device));
+  if (n_bytes == 0) {
+    for (uint32_t r = 0; r < n_parts; ++r) {
+      begin_end_host[2 * r] = begin_end_host[2 * r + 1] = 0;
+      kmi_fasta_partition q; memset(&q, 0, sizeof(q)); q.at_line_start = 1; q.index_shift = 1; parts_host[r] = q;
+    }
+    return KMI_OK;
+  }
+  const uint64_t n_tiles = (n_bytes + FaCfg::TILE - 1) / FaCfg::TILE;
+  const uint64_t n_blocks = (n_tiles + 1023) / 1024;
+  void *p;
+  KMI_TRY(ws_get(ctx, WS_TILE_INFO, sizeof(FaTileInfo) * (n_tiles + 1), &p)); FaTileInfo *info = (FaTileInfo *)p;
+  KMI_TRY(ws_get(ctx, WS_TILE_HDR, sizeof(FaTileBase) * (n_tiles + 1), &p)); FaTileBase *base = (FaTileBase *)p;
+  KMI_TRY(ws_get(ctx, WS_MISC, sizeof(FaTileSum) * (n_blocks + 1) + sizeof(FaPart) * ((size_t)n_parts + 1), &p)); FaTileSum *sums = (FaTileSum *)p;
+  FaPart *d_parts = (FaPart *)(sums + n_blocks + 1);
+  {
+    ProfScope ps(ctx, "fasta_scan_tiles", n_bytes);
+    hipLaunchKernelGGL(fasta_scan_tiles_kernel, dim3((unsigned)n_tiles), dim3(FaCfg::NT), 0, ctx->stream, bytes_dev, (uint64_t)n_bytes, true, info);
+  }
+  {
+    ProfScope ps(ctx, "fasta_scan_offsets", n_tiles);
+    hipLaunchKernelGGL(fasta_offsets_reduce_kernel, dim3((unsigned)n_blocks), dim3(1024), 0, ctx->stream, (const FaTileInfo *)info, n_tiles, sums);
+    hipLaunchKernelGGL(fasta_offsets_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, sums, n_blocks, (uint32_t)FA_O, ctx->d_totals);
+    hipLaunchKernelGGL(fasta_offsets_apply_kernel, dim3((unsigned)n_blocks), dim3(1024), 0, ctx->stream, (const FaTileInfo *)info, n_tiles,
+                       (const FaTileSum *)sums, base);
+  }
+  hipLaunchKernelGGL(fasta_partition_cuts_kernel, dim3((n_parts + 63) / 64), dim3(64), 0, ctx->stream, bytes_dev, (uint64_t)n_bytes, n_parts, k,
+                     (const FaTileBase *)base, d_parts);
+  KMI_HIP(ctx, hipGetLastError());
+  std::vector<FaPart> h(n_parts);
+  KMI_HIP(ctx, hipMemcpyAsync(h.data(), d_parts, sizeof(FaPart) * n_parts, hipMemcpyDeviceToHost, ctx->stream));
+  KMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  for (uint32_t r = 0; r < n_parts; ++r) {
+    begin_end_host[2 * r] = h[r].begin; begin_end_host[2 * r + 1] = h[r].end;
+    kmi_fasta_partition q; memset(&q, 0, sizeof(q));
+    q.valid_bytes = h[r].valid_bytes; q.start_state = (uint32_t)h[r].start_state; q.at_line_start = (uint32_t)h[r].at_line_start;
+    q.records_before = h[r].records_before; q.index_shift = (uint32_t)h[r].index_shift;
+    parts_host[r] = q;
+  }
+  return KMI_OK;
+}
+
+namespace kmi {
 }  // namespace kmi

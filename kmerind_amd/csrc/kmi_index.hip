@@ -1331,6 +1331,14 @@ __device__ __forceinline__ uint32_t wave_alloc(uint32_t *ctr, bool want) {
   base = __shfl(base, leader, kWave);
   return base + (uint32_t)__popcll(m & ((1ull << lane_id()) - 1ull));
 }
+// count += w for a counting map: std::plus<uint32_t> wraps; sat_plus (distributed_densehash_map.hpp:2903-2912) stops at the type's
+// maximum. An add that wraps (old > ~w) puts the ceiling back; every later add to that counter wraps again and does the same, so
+// once a key's total has passed 2^32 - 1 the counter ends on the ceiling whatever the interleaving of the lanes.
+__device__ __forceinline__ void count_add(uint32_t *p, uint32_t w, bool sat) {
+  if (!sat) { atomicAdd(p, w); return; }
+  const uint32_t old = atomicAdd(p, w);
+  if (old > ~w) atomicMax(p, 0xffffffffu);
+}
 constexpr uint32_t kTagEmpty = 0u, kTagLock = 1u;
 
 template <int NW> struct LdsTable {
@@ -1793,7 +1801,7 @@ __global__ __launch_bounds__((TabCfg<NW>::NT)) void bucket_reduce_kernel(const u
                                                                         const uint64_t *__restrict__ old_off, uint64_t *__restrict__ tmp_keys,
                                                                         uint32_t *__restrict__ tmp_vals, uint32_t *__restrict__ out_cnt,
                                                                         uint32_t *__restrict__ flags, bool full_word_keys,
-                                                                        uint64_t *scratch /* as large as new_keys and free, or null */) {
+                                                                        uint64_t *scratch /* as large as new_keys and free, or null */, bool sat = false) {
   KMI_TABLE_LDS(NW)
   __shared__ uint64_t s_missq[(NW == 1) ? (TabCfg<NW>::NT / kWave) * kMissQ : 1];   // per-wavefront miss queues (table_insert_flat)
   uint64_t *wq = s_missq + ((NW == 1) ? wave_id() * kMissQ : 0);
@@ -1835,8 +1843,8 @@ __global__ __launch_bounds__((TabCfg<NW>::NT)) void bucket_reduce_kernel(const u
         const uint32_t h = place_hash<NW>(k);
         if (pass_of(h, npass) != pass) return;
         int s = table_upsert<NW>(tab, k, h);
-        if (s >= 0) atomicAdd(&tab.vals[s], old_vals[i]);
-        else if (s == -2) atomicAdd(tab.special, old_vals[i]);
+        if (s >= 0) count_add(&tab.vals[s], old_vals[i], sat);
+        else if (s == -2) count_add(tab.special, old_vals[i], sat);
       });
       if constexpr (NW == 1) {
         if (npass == 1 && ob == oe && check_on) {   // nothing to merge: the first load step tells whether the bucket fits (CHECK)
@@ -2011,7 +2019,7 @@ __global__ __launch_bounds__((TabCfg<NW>::NT)) void bucket_merge_kernel(const ui
                                                                        const uint64_t *__restrict__ old_keys, const uint32_t *__restrict__ old_vals,
                                                                        const uint64_t *__restrict__ old_off, uint64_t *__restrict__ tmp_keys,
                                                                        uint32_t *__restrict__ tmp_vals, uint32_t *__restrict__ out_cnt,
-                                                                       uint32_t *__restrict__ flags) {
+                                                                       uint32_t *__restrict__ flags, bool sat = false) {
   KMI_TABLE_LDS(NW)
   const uint32_t b = blockIdx.x;
   const uint64_t ob = old_off ? old_off[b] : 0ull, oe = old_off ? old_off[b + 1] : 0ull;
@@ -2030,8 +2038,8 @@ __global__ __launch_bounds__((TabCfg<NW>::NT)) void bucket_merge_kernel(const ui
           const uint32_t h = place_hash<NW>(k);
           if (pass_of(h, npass) != pass) return;
           int s = table_upsert<NW>(tab, k, h);
-          if (s >= 0) atomicAdd(&tab.vals[s], vals[i]);
-          else if (s == -2) atomicAdd(tab.special, vals[i]);
+          if (s >= 0) count_add(&tab.vals[s], vals[i], sat);
+          else if (s == -2) count_add(tab.special, vals[i], sat);
         });
       };
       add(old_keys, old_vals, ob, oe);
@@ -2075,7 +2083,7 @@ __global__ __launch_bounds__((TabCfg<NW>::NT)) void bucket_reduce_pairs_kernel(c
                                                                               const uint64_t *__restrict__ old_keys, const uint32_t *__restrict__ old_vals,
                                                                               const uint64_t *__restrict__ old_off, uint64_t *__restrict__ tmp_keys,
                                                                               uint32_t *__restrict__ tmp_vals, uint32_t *__restrict__ out_cnt,
-                                                                              uint32_t *__restrict__ flags) {
+                                                                              uint32_t *__restrict__ flags, bool sat = false) {
   KMI_TABLE_LDS(NW)
   constexpr int RW = NW + 1;
   const uint32_t b = blockIdx.x;
@@ -2095,8 +2103,8 @@ __global__ __launch_bounds__((TabCfg<NW>::NT)) void bucket_reduce_pairs_kernel(c
         const uint32_t h = place_hash<NW>(k);
         if (pass_of(h, npass) != pass) return;
         int s = table_upsert<NW>(tab, k, h);
-        if (s >= 0) atomicAdd(&tab.vals[s], old_vals[i]);
-        else if (s == -2) atomicAdd(tab.special, old_vals[i]);
+        if (s >= 0) count_add(&tab.vals[s], old_vals[i], sat);
+        else if (s == -2) count_add(tab.special, old_vals[i], sat);
       });
       for (uint64_t i = nb + threadIdx.x; i < ne; i += blockDim.x) {
         uint64_t k[NW];
@@ -2106,8 +2114,8 @@ __global__ __launch_bounds__((TabCfg<NW>::NT)) void bucket_reduce_pairs_kernel(c
         const uint32_t h = place_hash<NW>(k);
         if (pass_of(h, npass) != pass) continue;
         int s = table_upsert<NW>(tab, k, h);
-        if (s >= 0) atomicAdd(&tab.vals[s], v);
-        else if (s == -2) atomicAdd(tab.special, v);
+        if (s >= 0) count_add(&tab.vals[s], v, sat);
+        else if (s == -2) count_add(tab.special, v, sat);
       }
       lds_barrier();
       if (*tab.overflow) { failed = true; break; }
@@ -2363,6 +2371,7 @@ struct kmi_index {
   uint64_t *dense_off = nullptr;  // [kNumFine + 1] (sparse form only)
   uint64_t n_entries = 0;
   bool has_data = false;
+  bool saturating = false;        // count += w stops at 2^32 - 1 (sat_plus) instead of wrapping (std::plus): kmi_index_set_saturating
   uint32_t owner_lp = 0;          // the entries are this rank's share of a build over 2^owner_lp ranks by minimizer-bucket owner (sk_consume)
   bool find_emits_index = false;  // find() of a counting map reports entry positions instead of counts (kmi_debruijn.h)
   uint32_t layout_w = 0;          // what the fine buckets mean: 0 = top bits of the placement hash; W = minimizer bucket (fine15_of_key)
@@ -2566,7 +2575,7 @@ static kmi_status reduce_and_adopt(kmi_index *idx, const Partitioned &part, size
     hipLaunchKernelGGL((bucket_reduce_kernel<NW>), dim3(kNumFine), dim3(TabCfg<NW>::NT), 0, ctx->stream, (const uint64_t *)part.keys,
                        (const uint64_t *)part.fine_off, (const uint64_t *)idx->keys, (const uint32_t *)idx->vals,
                        (const uint64_t *)(idx->has_data ? idx->bucket_off : nullptr), tmp_keys, tmp_vals, out_cnt, ctx->d_flags,
-                       idx->shape.n_bits == 64u * NW, part.scratch);
+                       idx->shape.n_bits == 64u * NW, part.scratch, idx->saturating);
   }
   KMI_HIP(ctx, hipGetLastError());
   return adopt_tmp<NW>(idx, tmp_keys, tmp_vals, part.fine_off, idx->has_data ? idx->bucket_off : nullptr, out_cnt, fastq_verdict,
@@ -2918,7 +2927,7 @@ static kmi_status sk_back_end(kmi_index *idx, const uint64_t *rec_a, uint64_t R,
   }
   // the index holds entries already: the new ones become a scratch index, whose pairs are added to the old
   kmi_index scratch;
-  scratch.ctx = ctx; scratch.cfg = idx->cfg; scratch.shape = idx->shape; scratch.val_words = 0;
+  scratch.ctx = ctx; scratch.cfg = idx->cfg; scratch.shape = idx->shape; scratch.val_words = 0; scratch.saturating = idx->saturating;
   kmi_status st = adopt_tmp<NW>(&scratch, tmp_keys, tmp_vals, kmer_off, nullptr, out_cnt);
   if (st == KMI_OK) read_levels();
   if (st == KMI_OK && n) ctx->sk_inv_dup = (float)((double)scratch.n_entries / (double)n);
@@ -3274,7 +3283,7 @@ static kmi_status insert_pairs_impl(kmi_index *idx, const uint64_t *recs_dev, si
     ProfScope ps(ctx, "bucket_reduce_pairs", n);
     hipLaunchKernelGGL((bucket_reduce_pairs_kernel<NW>), dim3(kNumFine), dim3(TabCfg<NW>::NT), 0, ctx->stream, (const uint64_t *)part.keys,
                        (const uint64_t *)part.fine_off, (const uint64_t *)idx->keys, (const uint32_t *)idx->vals,
-                       (const uint64_t *)(idx->has_data ? idx->bucket_off : nullptr), tmp_keys, tmp_vals, out_cnt, ctx->d_flags);
+                       (const uint64_t *)(idx->has_data ? idx->bucket_off : nullptr), tmp_keys, tmp_vals, out_cnt, ctx->d_flags, idx->saturating);
   }
   KMI_HIP(ctx, hipGetLastError());
   return adopt_tmp<NW>(idx, tmp_keys, tmp_vals, part.fine_off, idx->has_data ? idx->bucket_off : nullptr, out_cnt);
@@ -3633,7 +3642,7 @@ static kmi_status merge_impl(kmi_index *idx, uint32_t nparts, const uint64_t *ke
     hipLaunchKernelGGL((bucket_merge_kernel<NW>), dim3(kNumFine), dim3(TabCfg<NW>::NT), 0, ctx->stream, keys_dev, counts_dev, nparts,
                        (const uint64_t *)base, (const uint64_t *)boff, (const uint64_t *)comb, (const uint64_t *)idx->keys,
                        (const uint32_t *)idx->vals, (const uint64_t *)(idx->has_data ? idx->bucket_off : nullptr), tmp_keys, tmp_vals, out_cnt,
-                       ctx->d_flags);
+                       ctx->d_flags, idx->saturating);
   }
   KMI_HIP(ctx, hipGetLastError());
   return adopt_tmp<NW>(idx, tmp_keys, tmp_vals, comb, idx->has_data ? idx->bucket_off : nullptr, out_cnt);
@@ -4735,6 +4744,13 @@ kmi_status kmi_index_set_owner_ranks(kmi_index *idx, uint32_t nranks) {
   if (idx->has_data && idx->n_entries && (1u << idx->owner_lp) != nranks)
     return set_err(idx->ctx, KMI_ERR_INVALID, "the index holds entries distributed another way");
   idx->owner_lp = 31u - (uint32_t)__builtin_clz(nranks);
+  return KMI_OK;
+}
+
+kmi_status kmi_index_set_saturating(kmi_index *idx, int on) {
+  if (!idx) return KMI_ERR_INVALID;
+  if (idx->val_words) return set_err(idx->ctx, KMI_ERR_INVALID, "saturating counts belong to the counting maps");
+  idx->saturating = on != 0;
   return KMI_OK;
 }
 

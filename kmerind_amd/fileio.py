@@ -132,3 +132,16 @@ def partition_fasta(data, n_parts, k):
         out.append(dict(begin=b, end=end, valid_bytes=e - b, start_state=st, at_line_start=ls, records_before=records_before,
                         index_shift=index_shift))
     return out
+
+
+def partition_fasta_device(ctx, dptr, nbytes, n_parts, k):
+    """partition_fasta for a buffer resident in HBM: the bookkeeping runs on the device (kmi_fasta_partition_dev: tile summaries of
+    the line-kind machine, prefix sums, one short walk per block); same dicts as partition_fasta"""
+    import ctypes as C
+    from . import _lib as L
+    be = np.zeros(2 * n_parts, dtype=np.uint64)
+    parts = (L.FastaPartition * n_parts)()
+    ctx.check(L.lib.kmi_fasta_partition_dev(ctx.h, C.c_void_p(dptr), nbytes, n_parts, k, be.ctypes.data_as(C.c_void_p), parts))
+    return [dict(begin=int(be[2 * r]), end=int(be[2 * r + 1]), valid_bytes=int(parts[r].valid_bytes), start_state=int(parts[r].start_state),
+                 at_line_start=int(parts[r].at_line_start), records_before=int(parts[r].records_before), index_shift=int(parts[r].index_shift))
+            for r in range(n_parts)]

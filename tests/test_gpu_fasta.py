@@ -149,8 +149,14 @@ def test_fasta_split_over_ranks_equals_whole_file(ctx, k, alpha):
     inputs.append(_synthetic_fasta(rng, 25, line=70, eol=b"\r\n", orphan=False))
     for data in inputs:
         whole = orc.extract(s, data, orc.FASTA, file_offset=1000, want_ids=True)
-        for p in (2, 3, 7, 16):
-            parts = fileio.partition_fasta(data, p, k)
+        buf = np.frombuffer(data, dtype=np.uint8)
+        d = ctx.alloc(buf.size + 64)
+        ctx.to_device(d, buf)
+        for p in (2, 3, 5, 7, 8, 16):
+            # the bookkeeping of every block computed ON THE DEVICE (kmi_fasta_partition_dev); the host-side helper must agree,
+            # and the blocks' tuples must add up to the oracle's parse of the whole file (below)
+            parts = fileio.partition_fasta_device(ctx, d, buf.size, p, k)
+            assert parts == fileio.partition_fasta(data, p, k), (p, len(data))
             got_k, got_i = [], []
             for part in parts:
                 block = data[part["begin"]:part["end"]]
@@ -167,6 +173,7 @@ def test_fasta_split_over_ranks_equals_whole_file(ctx, k, alpha):
             assert gk.shape == whole["kmers"].shape, (p, len(data))
             assert (gk == whole["kmers"]).all(), (p, len(data))
             assert (gi == whole["ids"]).all(), (p, len(data))
+        ctx.free(d)
     # whole-file behaviour is back once the partition is cleared
     km, ids, _ = ctx.read_file(cfg, inputs[0], file_offset=1000, with_ids=True)
     w0 = orc.extract(s, inputs[0], orc.FASTA, file_offset=1000, want_ids=True)

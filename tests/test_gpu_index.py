@@ -759,6 +759,33 @@ def test_one_pass_front_end_hands_malformed_input_to_the_general_path(monkeypatc
     c2.close(); c3.close()
 
 
+@pytest.mark.parametrize("k", [31, 40])
+def test_saturating_counts_stop_at_the_ceiling(ctx, k):
+    """sat_plus<uint32_t> (distributed_densehash_map.hpp:2903-2912) on the device: weighted pairs that push a key past 2^32 - 1 --
+    within one call, and on top of a stored count -- leave it AT 2^32 - 1; the default reducer (std::plus) wraps"""
+    import ctypes as C
+    import kmerind_amd as K
+    from kmerind_amd import _lib as L
+    s = orc.kspec(k, orc.DNA)
+    rng = np.random.default_rng(k)
+    keys = orc.canonical(s, rng.integers(0, 1 << 62, (200, s.n_words), dtype=np.uint64) & np.uint64((1 << 62) - 1 if s.n_words == 1 else 0xFFFF))
+    keys = np.unique(keys, axis=0)
+    big = np.full(keys.shape[0], 0x80000000, dtype=np.uint32)
+    for sat in (0, 1):
+        idx = K.CountIndex(ctx, K.make_config(k, "DNA", strand="single"))
+        ctx.check(L.lib.kmi_index_set_saturating(idx.h, sat))
+        idx.insert_pairs(np.concatenate([keys, keys, keys[:50]]), np.concatenate([big, big, big[:50]]))      # 2 x 2^31 (and 3 x for the first 50) in ONE call
+        kk, cc = idx.to_vector()
+        want = {tuple(r): ((0xFFFFFFFF if sat else ((3 if i < 50 else 2) * 0x80000000) & 0xFFFFFFFF)) for i, r in enumerate(keys.tolist())}
+        assert {tuple(r): int(c) for r, c in zip(kk.tolist(), cc.tolist())} == want
+        idx.insert_pairs(keys[:10], np.full(10, 7, dtype=np.uint32))                                        # on top of the stored counts
+        kk, cc = idx.to_vector()
+        got = {tuple(r): int(c) for r, c in zip(kk.tolist(), cc.tolist())}
+        for i, r in enumerate(keys[:10].tolist()):
+            assert got[tuple(r)] == (0xFFFFFFFF if sat else (want[tuple(r)] + 7) & 0xFFFFFFFF)
+        idx.close()
+
+
 def test_kmer_pipeline_still_selectable(monkeypatch):
     """KMI_FUSED_PATH=kmer at context creation keeps the fused build on the k-mer pipeline (the fall-back of the super-k-mer
     path when a run or a tile exceeds its item capacity): same index."""
