@@ -40,8 +40,10 @@ KERNEL_ALG_BYTES = {
     "bucket_compact": 2 * 12.0 / 12,
     # fused build through super-k-mers (kmi_superkmer.h): a record is 16 bytes for about 9.3 k-mers (0.108 records per k-mer,
     # 1.73 B per k-mer), an item 4 bytes per record, a run entry 4 bytes per read
-    "sk_minimizer": 2.625 * 2 / 8 + 0.03 + 0.43 + 0.03,    # packed stream + run list in; items + per-run item index out
-    "sk_scatter": 2.625 * 2 / 8 + 0.43 + 0.06 + 1.73,      # stream + items + run tables in; records out
+    "sk_minimizer": 2.625 * 2 / 8 + 0.03 + 0.43 + 0.03,    # packed stream + run list in; items + per-run item index out (general front end)
+    # one-pass front end (kmi_front.h): input bytes in; per run a 48-byte packed row + a 4-byte item index, per record a 4-byte item out
+    "sk_front": 2.625 + 48.0 / 120 + 0.43 + 0.03,
+    "sk_scatter": 48.0 / 120 + 0.43 + 0.03 + 1.73,         # rows + items + run index in; records out
     "sk_fine_count": 1.73,                                 # records in
     "sk_scatter_fine": 2 * 1.73,                           # records in, records out
     "sk_reduce": 1.73 + 12.0 / 12,                         # records in; (key, count) of each distinct key out
@@ -476,7 +478,28 @@ def extra_rates(ctx, cfg, idx, d_bytes, nbytes, n_kmers, dev, torch, host=None):
             host_note = "pinned host buffer, one H2D copy (%.1f GB/s incl. the build) + the build, %.1f ms" % (nbytes / t_host / 1e9, t_host * 1e3)
         except Exception as e:   # pinning 3 GB can fail on a small box: the side measurement must not break the bench line
             host_note = "failed: " + str(e)[:80]
-    return {"host_resident_kmers_per_s": host_rate, "host_resident_note": host_note,
+    # what the context carries from one build to the next (workspace blocks; sk_reduce's pass structure and duplication hints):
+    # (a) the FIRST build of a fresh context, allocations included; (b) a build of the warm context with the hints forgotten
+    cold = {}
+    try:
+        ctx2 = K.Context(device=ctx.device, stream=ctx.stream)
+        idx4 = K.CountIndex(ctx2, cfg)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        idx4.build_device(d_bytes.data_ptr(), nbytes)
+        torch.cuda.synchronize(dev)
+        cold["first_build_of_a_fresh_context_ms"] = round((time.perf_counter() - t0) * 1e3, 2)
+        idx4.close(); ctx2.close()
+
+        def no_hints():
+            idx.clear()
+            ctx.check(L.lib.kmi_ctx_reset_hints(ctx.h))
+            idx.build_device(d_bytes.data_ptr(), nbytes)
+        cold["build_without_carried_hints_ms"] = round(timed(no_hints) * 1e3, 3)
+        idx.clear(); idx.build_device(d_bytes.data_ptr(), nbytes)      # (leaves the index as the timed steps left it)
+    except Exception as e:
+        cold["error"] = str(e)[:80]
+    return {"cold": cold, "host_resident_kmers_per_s": host_rate, "host_resident_note": host_note,
             "extract_only_kmers_per_s": n_kmers / t_extract, "insert_only_kmers_per_s": n_kmers / t_insert,
             "count_queries_per_s": nq / t_count, "find_queries_per_s": nq / t_find, "queries": nq,
             "distinct_query_keys": n_distinct_q, "found": n_out.value,

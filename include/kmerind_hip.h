@@ -91,6 +91,9 @@ typedef struct kmi_index kmi_index; /* replaces MapType (dsc::counting_*_map etc
  * comm.rank()/comm.size(). stream = hipStream_t (NULL = default stream). */
 kmi_status kmi_ctx_create(int device, int rank, int nranks, void *stream, kmi_ctx **out);
 kmi_status kmi_ctx_destroy(kmi_ctx *ctx);
+/* forget what the context learned from its builds so far (the pass structure and the duplication the per-bucket reduce starts
+ * from): the next build runs as the first one of a context would, with the workspace blocks still in place */
+kmi_status kmi_ctx_reset_hints(kmi_ctx *ctx);
 const char *kmi_last_error(const kmi_ctx *ctx);
 /* derived Kmer shape (padding.hpp:67-90): words per k-mer, hashed byte length */
 kmi_status kmi_kmer_shape(const kmi_config *cfg, uint32_t *n_words, uint32_t *n_bits, uint32_t *n_bytes);

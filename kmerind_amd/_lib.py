@@ -62,6 +62,7 @@ SIGNATURES = {
     "kmi_ctx_create": (C.c_int, [C.c_int, C.c_int, C.c_int, _P, C.POINTER(_P)]),
     "kmi_ctx_destroy": (C.c_int, [_P]),
     "kmi_ctx_set_fasta_partition": (C.c_int, [_P, _P]),
+    "kmi_ctx_reset_hints": (C.c_int, [_P]),
     "kmi_fasta_partition_dev": (C.c_int, [_P, _P, _sz, _u32, _u32, _P, _P]),
     "kmi_last_error": (C.c_char_p, [_P]),
     "kmi_kmer_shape": (C.c_int, [_CFG, C.POINTER(_u32), C.POINTER(_u32), C.POINTER(_u32)]),

@@ -191,6 +191,12 @@ kmi_status kmi_ctx_create(int device, int rank, int nranks, void *stream, kmi_ct
   return KMI_OK;
 }
 
+kmi_status kmi_ctx_reset_hints(kmi_ctx *ctx) {
+  if (!ctx) return KMI_ERR_INVALID;
+  ctx->sk_level_hint = 0; ctx->sk_inv_dup = 0.f;
+  return KMI_OK;
+}
+
 kmi_status kmi_ctx_destroy(kmi_ctx *ctx) {
   if (!ctx) return KMI_OK;
   (void)hipSetDevice(ctx->device);

@@ -1,5 +1,4 @@
 set -o pipefail
-mkdir -p gpurun_out/r03_k
-timeout -k 10 600 python -m pytest tests/test_gpu_fasta.py tests/test_gpu_index.py tests/test_abi_and_host.py tests/test_gpu_facade.py -x -q > gpurun_out/r03_k/pytest.log 2>&1; echo "pytest rc=$?" > gpurun_out/r03_k/rc.txt
-tail -25 gpurun_out/r03_k/pytest.log
-cat gpurun_out/r03_k/rc.txt
+bash tools/profile_round.sh r03_m > gpurun_out/r03_m_profile.log 2>&1; echo "profile rc=$?"
+tail -3 gpurun_out/r03_m_profile.log
+cat gpurun_out/r03_m/bench.json | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['roofline']['frac'], d['roofline']['kernels_ms_per_step']); print(d['extra']['cold'], d['extra']['host_resident_note']); print(d['cpu_baseline'])"
