@@ -169,8 +169,9 @@ kmi_status kmi_ctx_create(int device, int rank, int nranks, void *stream, kmi_ct
   if (const char *fp = getenv("KMI_FUSED_PATH")) ctx->fused_superkmer = strcmp(fp, "kmer") != 0;
   if (const char *dg = getenv("KMI_SK_DBG")) ctx->sk_dbg = atoi(dg);
   if (const char *dc = getenv("KMI_DIST_CHUNKS")) { ctx->dist_chunks = (uint32_t)atoi(dc); if (ctx->dist_chunks < 1) ctx->dist_chunks = 1; if (ctx->dist_chunks > 64) ctx->dist_chunks = 64; }
+  if (const char *sl = getenv("KMI_SK_SLACK")) ctx->sk_slack = atoi(sl) != 0;
   if (const char *fr = getenv("KMI_FRONT")) ctx->front_fused = strcmp(fr, "general") != 0;
-  if (const char *mr = getenv("KMI_FRONT_MIN_RANGE")) { ctx->front_min_range = strtoull(mr, nullptr, 10); ctx->front_min_range = (ctx->front_min_range + 2047) / 2048 * 2048; if (!ctx->front_min_range) ctx->front_min_range = 2048; }
+  if (const char *mr = getenv("KMI_FRONT_MIN_RANGE")) { ctx->front_min_range = strtoull(mr, nullptr, 10); ctx->front_min_range = (ctx->front_min_range + 4095) / 4096 * 4096; if (!ctx->front_min_range) ctx->front_min_range = 4096; }
   if (const char *sm = getenv("KMI_SPARSE_MIN")) ctx->sparse_min = strtoull(sm, nullptr, 10);
   if (const char *fd = getenv("KMI_FORCE_DIST")) ctx->force_dist = atoi(fd) != 0;
   ctx->device = device; ctx->rank = rank; ctx->nranks = nranks; ctx->stream = (hipStream_t)stream;

@@ -8,7 +8,7 @@
 // of a record are header, '+' and quality, and the line bookkeeping went through three passes over bitmaps.
 //
 // Here every WAVEFRONT owns a byte range and runs on its own (no workgroup barrier in the kernel):
-//   produce   64 lanes x 32 bytes: EOL bits only (SWAR), line starts / ends ranked with one DPP scan, their positions into two
+//   produce   64 lanes x 64 bytes: EOL bits only (SWAR), line starts / ends ranked with one DPP scan, their positions into two
 //             small rings in LDS; complete lines get their role from the line index; sequence lines become runs of windows
 //   consume   as soon as 64 runs wait: one lane per run loads the read's own bytes, packs THEM (and nothing else) into 2-bit
 //             complement codes -- the run's row, kept for the scatter pass -- and walks the minimizers exactly as
@@ -26,7 +26,7 @@ namespace kmi {
 constexpr int kFrWaves = 4, kFrThreads = kFrWaves * kWave;
 constexpr uint32_t kFrRing = 256;        // line events a wavefront keeps (power of two); a 2 KB step may add half of it
 constexpr uint32_t kFrRunQ = 256;        // waiting runs (power of two): 64 are taken at a time, a step adds at most 128
-constexpr uint32_t kFrStep = 2048;       // bytes per produce step: 64 lanes x 32
+constexpr uint32_t kFrStep = 4096;       // bytes per produce step: 64 lanes x 64
 constexpr uint32_t kFrRowDw = 12;        // a run's packed row: 192 bases (a run holds at most 128 + 31)
 constexpr uint32_t kFrNone = 0xffu;      // FrRange::l0 of a range that owns no line
 
@@ -97,56 +97,73 @@ __global__ __launch_bounds__(kFrThreads) void sk_front_kernel(const uint8_t *__r
     bool producing = true;
     // the step's 32 bytes per lane are loaded one step ahead (a step costs a few hundred instructions: without the prefetch
     // every one of them began with a trip to HBM that nothing else in this wavefront could hide)
-    FrU4 n0, n1;
-    n0.x = n0.y = n0.z = n0.w = 0; n1 = n0;
-    if (B + 32ull * lane + 32 <= n_bytes) { n0 = *reinterpret_cast<const FrU4 *>(bytes + B + 32ull * lane); n1 = *reinterpret_cast<const FrU4 *>(bytes + B + 32ull * lane + 16); }
+    FrU4 n0, n1, n2, n3;
+    n0.x = n0.y = n0.z = n0.w = 0; n1 = n0; n2 = n0; n3 = n0;
+    if (B + 64ull * lane + 64 <= n_bytes) {
+      const uint8_t *q = bytes + B + 64ull * lane;
+      n0 = *reinterpret_cast<const FrU4 *>(q); n1 = *reinterpret_cast<const FrU4 *>(q + 16);
+      n2 = *reinterpret_cast<const FrU4 *>(q + 32); n3 = *reinterpret_cast<const FrU4 *>(q + 48);
+    }
     // the first byte of a header / '+' line is loaded when the line completes and compared one step later (nothing waits for it)
     uint32_t mk_ch = 0, mk_want = 0;
+    // EOL bits of 32 bytes: the flags (0x80 per EOL byte) of two dwords gathered into one byte by two dot products with bit
+    // weights (the product sits 7 bits too high)
+    auto eol32 = [](const FrU4 &a, const FrU4 &b) -> uint32_t {
+      uint32_t d0 = __builtin_amdgcn_udot4(eol_flags(a.x), 0x08040201u, 0u, false);
+      d0 = __builtin_amdgcn_udot4(eol_flags(a.y), 0x80402010u, d0, false);
+      uint32_t d1 = __builtin_amdgcn_udot4(eol_flags(a.z), 0x08040201u, 0u, false);
+      d1 = __builtin_amdgcn_udot4(eol_flags(a.w), 0x80402010u, d1, false);
+      uint32_t d2 = __builtin_amdgcn_udot4(eol_flags(b.x), 0x08040201u, 0u, false);
+      d2 = __builtin_amdgcn_udot4(eol_flags(b.y), 0x80402010u, d2, false);
+      uint32_t d3 = __builtin_amdgcn_udot4(eol_flags(b.z), 0x08040201u, 0u, false);
+      d3 = __builtin_amdgcn_udot4(eol_flags(b.w), 0x80402010u, d3, false);
+      return (d0 >> 7) | (d1 << 1) | (d2 << 9) | (d3 << 17);
+    };
     while (!bail) {
       // ---------------------------------------------------------------- produce
       while (producing && rq_tail - rq_head < (uint32_t)kWave && !bail) {
-        const uint64_t g = B + p + 32ull * lane;
-        uint32_t eol = 0;
-        const FrU4 v0 = n0, v1 = n1;
+        const uint64_t g = B + p + 64ull * lane;
+        uint32_t eol_lo = 0, eol_hi = 0;
+        const FrU4 v0 = n0, v1 = n1, v2 = n2, v3 = n3;
         {
           const uint64_t gn = g + kFrStep;
-          if (gn + 32 <= n_bytes) { n0 = *reinterpret_cast<const FrU4 *>(bytes + gn); n1 = *reinterpret_cast<const FrU4 *>(bytes + gn + 16); }
-        }
-        if (g + 32 <= n_bytes) {
-          // the flags (0x80 per EOL byte) of two dwords gathered into one byte by two dot products with bit weights; << 7 too far
-          uint32_t d0 = __builtin_amdgcn_udot4(eol_flags(v0.x), 0x08040201u, 0u, false);
-          d0 = __builtin_amdgcn_udot4(eol_flags(v0.y), 0x80402010u, d0, false);
-          uint32_t d1 = __builtin_amdgcn_udot4(eol_flags(v0.z), 0x08040201u, 0u, false);
-          d1 = __builtin_amdgcn_udot4(eol_flags(v0.w), 0x80402010u, d1, false);
-          uint32_t d2 = __builtin_amdgcn_udot4(eol_flags(v1.x), 0x08040201u, 0u, false);
-          d2 = __builtin_amdgcn_udot4(eol_flags(v1.y), 0x80402010u, d2, false);
-          uint32_t d3 = __builtin_amdgcn_udot4(eol_flags(v1.z), 0x08040201u, 0u, false);
-          d3 = __builtin_amdgcn_udot4(eol_flags(v1.w), 0x80402010u, d3, false);
-          eol = (d0 >> 7) | (d1 << 1) | (d2 << 9) | (d3 << 17);
-        } else {
-#pragma unroll 1
-          for (uint32_t i = 0; i < 32u; ++i) {
-            const bool e = (g + i >= n_bytes) || is_eol(bytes[g + i]);   // bytes past the end count as EOL
-            eol |= (e ? 1u : 0u) << i;
+          if (gn + 64 <= n_bytes) {
+            const uint8_t *q = bytes + gn;
+            n0 = *reinterpret_cast<const FrU4 *>(q); n1 = *reinterpret_cast<const FrU4 *>(q + 16);
+            n2 = *reinterpret_cast<const FrU4 *>(q + 32); n3 = *reinterpret_cast<const FrU4 *>(q + 48);
           }
         }
-        const uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp((int)carry, (int)(eol >> 31), 0x138 /* wave_shr:1 */, 0xf, 0xf, false);   // lane 0 keeps the carry
-        const uint32_t before = (eol << 1) | prev;
-        uint32_t ls = ~eol & before, le = eol & ~before;
-        const uint32_t base = p + 32u * lane;
-        const uint32_t ns = (uint32_t)__builtin_popcount(ls), ne = (uint32_t)__builtin_popcount(le);
-        // owned line starts: positions below the range's length
+        if (g + 64 <= n_bytes) {
+          eol_lo = eol32(v0, v1); eol_hi = eol32(v2, v3);
+        } else {
+#pragma unroll 1
+          for (uint32_t i = 0; i < 64u; ++i) {
+            const bool e = (g + i >= n_bytes) || is_eol(bytes[g + i]);   // bytes past the end count as EOL
+            if (i < 32u) eol_lo |= (e ? 1u : 0u) << i; else eol_hi |= (e ? 1u : 0u) << (i - 32u);
+          }
+        }
+        const uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp((int)carry, (int)(eol_hi >> 31), 0x138 /* wave_shr:1 */, 0xf, 0xf, false);   // lane 0 keeps the carry
+        const uint32_t before_lo = (eol_lo << 1) | prev, before_hi = (eol_hi << 1) | (eol_lo >> 31);
+        uint32_t ls_lo = ~eol_lo & before_lo, ls_hi = ~eol_hi & before_hi, le_lo = eol_lo & ~before_lo, le_hi = eol_hi & ~before_hi;
+        const uint32_t base = p + 64u * lane;
+        const uint32_t ns = (uint32_t)__builtin_popcount(ls_lo) + (uint32_t)__builtin_popcount(ls_hi);
+        const uint32_t ne = (uint32_t)__builtin_popcount(le_lo) + (uint32_t)__builtin_popcount(le_hi);
+        if (__any(ns > 8u || ne > 8u)) { why |= 4u; bail = true; break; }   // lines of a few bytes: not this path's input (and the packed sums below stay inside their fields)
+        // owned line starts: positions below the range's length (whole lanes: a range's length is a multiple of 64 except where the
+        // buffer ends, and no line starts behind its end)
         const uint32_t no = base < len ? ns : 0u;
         const uint32_t packed = ns | (ne << 10) | (no << 20);
         const uint32_t inc = wave_inclusive_sum_dpp(packed);
         const uint32_t tot = __builtin_amdgcn_readlane(inc, kWave - 1);
         const uint32_t NS = tot & 1023u, NE = (tot >> 10) & 1023u, NO = tot >> 20;
-        if (NS > kFrRing / 2u || NE > kFrRing / 2u) { why |= 4u; bail = true; break; }   // lines of a few bytes: not this path's input
+        if (NS > kFrRing / 2u || NE > kFrRing / 2u) { why |= 4u; bail = true; break; }
         uint32_t rs = n_starts + ((inc - packed) & 1023u), re = n_ends + (((inc - packed) >> 10) & 1023u);
-        while (ls) { S[rs & RM] = base + (uint32_t)__builtin_ctz(ls); ++rs; ls &= ls - 1u; }
-        while (le) { E[re & RM] = base + (uint32_t)__builtin_ctz(le); ++re; le &= le - 1u; }
+        while (ls_lo) { S[rs & RM] = base + (uint32_t)__builtin_ctz(ls_lo); ++rs; ls_lo &= ls_lo - 1u; }
+        while (ls_hi) { S[rs & RM] = base + 32u + (uint32_t)__builtin_ctz(ls_hi); ++rs; ls_hi &= ls_hi - 1u; }
+        while (le_lo) { E[re & RM] = base + (uint32_t)__builtin_ctz(le_lo); ++re; le_lo &= le_lo - 1u; }
+        while (le_hi) { E[re & RM] = base + 32u + (uint32_t)__builtin_ctz(le_hi); ++re; le_hi &= le_hi - 1u; }
         n_starts += NS; n_ends += NE; n_owned += NO;
-        carry = (uint32_t)__builtin_amdgcn_readlane(eol, kWave - 1) >> 31;   // (the builtin returns a signed int)
+        carry = (uint32_t)__builtin_amdgcn_readlane(eol_hi, kWave - 1) >> 31;   // (the builtin returns a signed int)
         p += kFrStep;
         const bool at_eof = B + p > n_bytes;                 // (a step that reached past the end has produced the last line's end)
         wave_sync();                                         // the events are in the rings

@@ -2840,9 +2840,13 @@ static kmi_status sk_front_fast_any(kmi_ctx *ctx, const kmi_config *cfg, const K
 // workgroups at wg_off[g][c]) -> fine buckets -> sk_reduce -> the index (layout W | lp << 8), or added to what it holds.
 template <int W>
 static kmi_status sk_back_end(kmi_index *idx, const uint64_t *rec_a, uint64_t R, const uint64_t *h_cnt, const uint64_t *h_base, const uint64_t *wg_off,
-                              uint64_t n, uint32_t lp) {
+                              uint64_t n, uint32_t lp, bool exact = false) {
+  // exact = false (an index without entries): the fine buckets get room instead of exact offsets, so the records are not read an
+  // extra time to be counted (sk_scatter_fine_slack_kernel); a bucket that outgrows its room sends the build through here again
+  // with exact = true
   constexpr int NW = 1;
   kmi_ctx *ctx = idx->ctx;
+  const bool slack = !exact && ctx->sk_slack && (!idx->has_data || idx->n_entries == 0) && R >= 4096;
   const uint32_t k = idx->shape.k;
   const bool canonical = idx->cfg.strand != KMI_STRAND_SINGLE;
   void *p;
@@ -2856,26 +2860,55 @@ static kmi_status sk_back_end(kmi_index *idx, const uint64_t *rec_a, uint64_t R,
   uint64_t h_end[kNumCoarse];
   for (int c = 0; c < kNumCoarse; ++c) h_end[c] = h_base[c] + h_cnt[c];
   KMI_HIP(ctx, hipMemcpyAsync(cend, h_end, sizeof(h_end), hipMemcpyHostToDevice, ctx->stream));   // (h_end outlives the copy: this function synchronises before it returns)
-  KMI_TRY(ws_get(ctx, WS_KEYS_B, (R + 64) * 16, &p)); uint64_t *rec_b = (uint64_t *)p;
+  // the slack layout: every fine bucket of coarse bucket c has room for 13/8 of c's mean share + 64 (minimizer buckets are uneven: 1.45 x the mean was the largest of config 2), in steps of 8 records
+  uint64_t h_region[kNumCoarse], total_b = 0;
+  uint32_t h_cap[kNumCoarse];
+  for (int c = 0; c < kNumCoarse; ++c) {
+    const uint64_t cap = ((h_cnt[c] * 13 / 8 + kSubPerCoarse - 1) / kSubPerCoarse + 64 + 7) / 8 * 8;
+    h_cap[c] = (uint32_t)cap; h_region[c] = total_b; total_b += cap * kSubPerCoarse;
+  }
+  KMI_TRY(ws_get(ctx, WS_KEYS_B, ((slack ? total_b : R) + 64) * 16, &p)); uint64_t *rec_b = (uint64_t *)p;
   KMI_TRY(ws_get(ctx, WS_SPLIT_OFF, sizeof(uint32_t) * kNumFine * kFineParts + sizeof(uint64_t) * ((kNumFine + 1) + kNumFine * kFineParts + kNumCoarse) + 256, &p));
   uint32_t *fine_kmers = (uint32_t *)p;
   uint64_t *kmer_off = (uint64_t *)((char *)p + sizeof(uint32_t) * kNumFine * kFineParts);
   uint64_t *k_part = kmer_off + (kNumFine + 1), *k_base = k_part + (uint64_t)kNumFine * kFineParts;
-  {
-    ProfScope ps(ctx, "sk_fine_count", R);
-    hipLaunchKernelGGL(sk_fine_count_kernel, dim3(kNumCoarse * kFineParts), dim3(1024), 0, ctx->stream, (const uint64_t *)rec_a,
-                       (const uint64_t *)wg_off, (const uint64_t *)cend, (uint32_t)kPartGroups, fine_hist, fine_kmers);
-  }
-  {
-    ProfScope ps(ctx, "fine_offsets", kNumFine);
-    launch_fine_offsets(ctx, fine_hist, fine_off, part_off, coarse_base);
-    launch_fine_offsets(ctx, fine_kmers, kmer_off, k_part, k_base);
-  }
-  {
-    ProfScope ps(ctx, "sk_scatter_fine", R);
-    hipLaunchKernelGGL((scatter_fine_kernel<1, 2, 1>), dim3(kNumCoarse * kFineParts), dim3(kPartThreads), 0, ctx->stream, (const uint64_t *)rec_a,
-                       rec_b, idx->shape, (const uint64_t *)fine_off, (const uint64_t *)part_off, (const uint64_t *)wg_off,
-                       (uint32_t)kPartGroups, (int)BUCKET_REC, 0u);
+  uint64_t *d_region = nullptr; uint32_t *d_cap = nullptr, *fine_cnt = nullptr;
+  if (slack) {
+    KMI_TRY(ws_get(ctx, WS_BUCKET_OFF, sizeof(uint64_t) * kNumCoarse + sizeof(uint32_t) * kNumCoarse + 64, &p));
+    d_region = (uint64_t *)p; d_cap = (uint32_t *)(d_region + kNumCoarse);
+    fine_cnt = fine_hist;   // (the first half of the histogram block: records per fine bucket, counted as they are appended)
+    KMI_HIP(ctx, hipMemcpyAsync(d_region, h_region, sizeof(h_region), hipMemcpyHostToDevice, ctx->stream));
+    KMI_HIP(ctx, hipMemcpyAsync(d_cap, h_cap, sizeof(h_cap), hipMemcpyHostToDevice, ctx->stream));
+    KMI_HIP(ctx, hipMemsetAsync(fine_cnt, 0, sizeof(uint32_t) * kNumFine, ctx->stream));
+    KMI_HIP(ctx, hipMemsetAsync(fine_kmers, 0, sizeof(uint32_t) * kNumFine * kFineParts, ctx->stream));
+    KMI_HIP(ctx, hipMemsetAsync(ctx->d_flags + 34, 0, sizeof(uint32_t), ctx->stream));
+    {
+      ProfScope ps(ctx, "sk_scatter_fine", R);
+      hipLaunchKernelGGL(sk_scatter_fine_slack_kernel, dim3(kNumCoarse * kFineParts), dim3(kPartThreads), 0, ctx->stream, (const uint64_t *)rec_a, rec_b,
+                         (const uint64_t *)wg_off, (const uint64_t *)cend, (uint32_t)kPartGroups, (const uint64_t *)d_region, (const uint32_t *)d_cap,
+                         fine_cnt, fine_kmers, ctx->d_flags);
+    }
+    {
+      ProfScope ps(ctx, "fine_offsets", kNumFine);
+      launch_fine_offsets(ctx, fine_kmers, kmer_off, k_part, k_base);
+    }
+  } else {
+    {
+      ProfScope ps(ctx, "sk_fine_count", R);
+      hipLaunchKernelGGL(sk_fine_count_kernel, dim3(kNumCoarse * kFineParts), dim3(1024), 0, ctx->stream, (const uint64_t *)rec_a,
+                         (const uint64_t *)wg_off, (const uint64_t *)cend, (uint32_t)kPartGroups, fine_hist, fine_kmers);
+    }
+    {
+      ProfScope ps(ctx, "fine_offsets", kNumFine);
+      launch_fine_offsets(ctx, fine_hist, fine_off, part_off, coarse_base);
+      launch_fine_offsets(ctx, fine_kmers, kmer_off, k_part, k_base);
+    }
+    {
+      ProfScope ps(ctx, "sk_scatter_fine", R);
+      hipLaunchKernelGGL((scatter_fine_kernel<1, 2, 1>), dim3(kNumCoarse * kFineParts), dim3(kPartThreads), 0, ctx->stream, (const uint64_t *)rec_a,
+                         rec_b, idx->shape, (const uint64_t *)fine_off, (const uint64_t *)part_off, (const uint64_t *)wg_off,
+                         (uint32_t)kPartGroups, (int)BUCKET_REC, 0u);
+    }
   }
   // per bucket: as many output slots as it has k-mers (bucket_reduce_kernel's contract), compacted by adopt_tmp
   KMI_TRY(ws_get(ctx, WS_TMP_KEYS, (n + 64) * sizeof(uint64_t), &p)); uint64_t *tmp_keys = (uint64_t *)p;
@@ -2892,8 +2925,8 @@ static kmi_status sk_back_end(kmi_index *idx, const uint64_t *rec_a, uint64_t R,
 #define KMI_SK_REDUCE(CANON, OWN, SPECIAL)                                                                                               \
     hipLaunchKernelGGL((sk_reduce_kernel<CANON, OWN, SPECIAL>), dim3(wgs), dim3(KMI_SK_NT), 0, ctx->stream, (const uint64_t *)rec_b,        \
                        (const uint64_t *)fine_off, k, (const uint64_t *)kmer_off, tmp_keys, tmp_vals, out_cnt, ctx->d_flags, queue, (uint32_t)kNumFine, \
-                       ctx->sk_level_hint, lp, ctx->sk_inv_dup)
-    if (ctx->sk_dbg == 1 && canonical && nmax <= 21u)   // A/B: the one-workgroup-per-bucket form
+                       ctx->sk_level_hint, lp, ctx->sk_inv_dup, (const uint64_t *)d_region, (const uint32_t *)d_cap, (const uint32_t *)fine_cnt)
+    if (ctx->sk_dbg == 1 && canonical && nmax <= 21u && !slack)   // A/B: the one-workgroup-per-bucket form
       hipLaunchKernelGGL((sk_reduce_v1_kernel<true, 64 * 21>), dim3(kNumFine), dim3(KMI_SK_NT), 0, ctx->stream, (const uint64_t *)rec_b,
                          (const uint64_t *)fine_off, k, (const uint64_t *)kmer_off, tmp_keys, tmp_vals, out_cnt, ctx->d_flags, 0, ctx->sk_level_hint, lp, ctx->sk_inv_dup);
     else if (k == 32u) { if (canonical) KMI_SK_REDUCE(true, 64 * 21, true); else KMI_SK_REDUCE(false, 64 * 21, true); }   // (a 32-mer can equal the empty marker)
@@ -2903,6 +2936,9 @@ static kmi_status sk_back_end(kmi_index *idx, const uint64_t *rec_a, uint64_t R,
 #undef KMI_SK_REDUCE
   }
   KMI_HIP(ctx, hipGetLastError());
+  // a fine bucket that outgrew its room? (its records beyond the room were not written: this attempt's result is void; read with
+  // the level votes below)
+  if (slack) KMI_HIP(ctx, hipMemcpyAsync(ctx->h_totals + 14, ctx->d_flags + 34, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
   // the level most buckets ended at: where the buckets of the NEXT build (batch, step) of this context start. The copy is queued
   // here and read after the synchronisation adopt_tmp needs anyway (one host round trip less per build).
   KMI_HIP(ctx, hipMemcpyAsync(ctx->h_totals + 8 /* pinned; words 8..12 */, ctx->d_flags + 16, sizeof(uint32_t) * 9, hipMemcpyDeviceToHost, ctx->stream));
@@ -2920,6 +2956,10 @@ static kmi_status sk_back_end(kmi_index *idx, const uint64_t *rec_a, uint64_t R,
     // the index IS the reduce output: entries grouped by minimizer bucket. Queries partition their keys by the same function
     // (fine15_of_key); whatever needs the placement-hash layout converts the entries once (ensure_layout).
     KMI_TRY((adopt_tmp<NW>(idx, tmp_keys, tmp_vals, kmer_off, nullptr, out_cnt, false, n, true)));
+    if (slack && *reinterpret_cast<const uint32_t *>(ctx->h_totals + 14)) {
+      KMI_TRY(kmi_index_clear(idx));
+      return sk_back_end<W>(idx, rec_a, R, h_cnt, h_base, wg_off, n, lp, true);
+    }
     read_levels();
     idx->layout_w = layout;
     if (n) ctx->sk_inv_dup = (float)((double)idx->n_entries / (double)n);   // where the buckets of the next build start (sk_reduce_kernel)

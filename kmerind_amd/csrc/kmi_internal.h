@@ -94,6 +94,7 @@ struct kmi_ctx {
   uint32_t sk_level_hint = 0;    // sk_reduce: filter bits the buckets of the next build start with (majority of the last build)
   float sk_inv_dup = 0.f;        // sk_reduce: distinct k-mers per k-mer occurrence of the last build (a bucket's expected fill; 0: unknown)
   uint32_t dist_chunks = 4;      // record-aligned chunks of a rank's share in the build over ranks (exchange of one beside the front end of the next; KMI_DIST_CHUNKS)
+  bool sk_slack = true;          // fine buckets with room instead of a counting pass (sk_scatter_fine_slack_kernel); KMI_SK_SLACK=0: always count
   bool front_fused = true;       // FASTQ front end of the super-k-mer build in one pass (kmi_front.h); KMI_FRONT=general: scan + list + minimizer
   uint32_t front_waves = 0;      // resident wavefronts of the front kernel (ranges of a large input); 0: not asked yet
   uint64_t front_min_range = 64ull << 10;   // smallest byte range of a wavefront (KMI_FRONT_MIN_RANGE: tests shrink it)

@@ -501,6 +501,99 @@ __global__ __launch_bounds__(1024) void sk_fine_count_kernel(const uint64_t *__r
   }
 }
 
+// P without a counting pass: the fine buckets of coarse bucket c get room for fine_cap[c] records each (a quarter above the
+// mean share of c's records, which the front end counted), and a workgroup appends its tile's records of a fine bucket behind
+// what the bucket holds so far -- one global atomic per (tile, fine bucket), 128 per 4096 records -- instead of writing to
+// offsets a histogram pass (sk_fine_count: one more read of all records) would have prepared. It also adds up the k-mers per fine
+// bucket (the reduce's output ranges). A bucket that outgrows its room raises flags[34]: the caller then takes the exact path.
+// Bucket b's records end up at fine_region[b >> 7] + (b & 127) * fine_cap[b >> 7], fine_cnt[b] of them, in no particular order.
+constexpr int kSlackTile = 4096;
+__global__ __launch_bounds__(kPartThreads) void sk_scatter_fine_slack_kernel(const uint64_t *__restrict__ recs, uint64_t *__restrict__ out,
+                                                                           const uint64_t *__restrict__ wg_off, const uint64_t *__restrict__ coarse_end,
+                                                                           uint32_t groups, const uint64_t *__restrict__ fine_region,
+                                                                           const uint32_t *__restrict__ fine_cap, uint32_t *__restrict__ fine_cnt,
+                                                                           uint32_t *__restrict__ fine_kmers, uint32_t *__restrict__ flags) {
+  constexpr int TILE = kSlackTile, PT = TILE / kPartThreads;
+  __shared__ ulonglong2 s_stage[TILE];
+  __shared__ uint8_t s_bkt[TILE];
+  __shared__ uint32_t s_cnt[kSubPerCoarse], s_k[kSubPerCoarse], s_lofs[kSubPerCoarse];
+  __shared__ uint64_t s_gbase[kSubPerCoarse];
+  __shared__ uint32_t s_part[kSubPerCoarse / kWave];
+  const uint32_t gpp = groups / kFineParts;
+  const uint32_t c = blockIdx.x / kFineParts, h = blockIdx.x % kFineParts;
+  const uint64_t b = wg_off[(uint64_t)(h * gpp) * kNumCoarse + c];
+  const uint64_t e = (h + 1 < (uint32_t)kFineParts) ? wg_off[(uint64_t)((h + 1) * gpp) * kNumCoarse + c] : coarse_end[c];
+  const uint64_t region = fine_region[c];
+  const uint32_t cap = fine_cap[c];
+  if (threadIdx.x < kSubPerCoarse) { s_cnt[threadIdx.x] = 0; s_k[threadIdx.x] = 0; }
+  lds_barrier();
+  const ulonglong2 *src = reinterpret_cast<const ulonglong2 *>(recs);
+  ulonglong2 raw[PT];
+  auto load_tile = [&](uint64_t t0) {
+#pragma unroll
+    for (int j = 0; j < PT; ++j) {
+      uint64_t i = t0 + (uint64_t)j * kPartThreads + threadIdx.x;
+      i = (i < e) ? i : (e ? e - 1 : 0);
+      raw[j] = src[i];
+    }
+  };
+  if (b < e) load_tile(b);
+  for (uint64_t t0 = b; t0 < e; t0 += TILE) {
+    const uint32_t nt = (uint32_t)((e - t0 < (uint64_t)TILE) ? (e - t0) : (uint64_t)TILE);
+    ulonglong2 rec[PT];
+    uint32_t bk[PT], rk[PT];
+#pragma unroll
+    for (int j = 0; j < PT; ++j) {
+      const uint32_t li = j * kPartThreads + threadIdx.x;
+      rec[j] = raw[j];
+      bk[j] = 0xffffffffu;
+      if (li < nt) {
+        bk[j] = rec_fine_sub(rec[j].y);
+        rk[j] = atomicAdd(&s_cnt[bk[j]], 1u);
+        atomicAdd(&s_k[bk[j]], ((uint32_t)(rec[j].y >> kRecNShift) & 31u) + 1u);
+      }
+    }
+    if (t0 + TILE < e) load_tile(t0 + TILE);   // in flight until the next iteration needs it
+    lds_barrier();
+    uint32_t cnt = 0, inc = 0;
+    if (threadIdx.x < kSubPerCoarse) {              // two whole waves
+      cnt = s_cnt[threadIdx.x];
+      const uint32_t km = s_k[threadIdx.x];
+      s_cnt[threadIdx.x] = 0; s_k[threadIdx.x] = 0;
+      inc = wave_inclusive_sum_dpp(cnt);
+      if (lane_id() == kWave - 1) s_part[wave_id()] = inc;
+      const uint32_t f = c * kSubPerCoarse + threadIdx.x;
+      uint32_t at = 0;
+      if (cnt) { at = atomicAdd(&fine_cnt[f], cnt); atomicAdd(&fine_kmers[f], km); }
+      // room for this tile's share? (a bucket that outgrows it keeps counting, so the caller sees by how much, but writes nothing)
+      const bool fits = (uint64_t)at + cnt <= (uint64_t)cap;
+      if (!fits) atomicOr(&flags[34], 1u);
+      s_gbase[threadIdx.x] = fits ? region + (uint64_t)threadIdx.x * cap + at : ~0ull;
+    }
+    lds_barrier();
+    if (threadIdx.x < kSubPerCoarse) {
+      const uint32_t lo = (wave_id() ? s_part[0] : 0u) + inc - cnt;
+      s_lofs[threadIdx.x] = lo;
+      if (s_gbase[threadIdx.x] != ~0ull) s_gbase[threadIdx.x] -= lo;
+    }
+    lds_barrier();
+#pragma unroll
+    for (int j = 0; j < PT; ++j) {
+      if (bk[j] != 0xffffffffu) {
+        const uint32_t pos = s_lofs[bk[j]] + rk[j];
+        s_stage[pos] = rec[j];
+        s_bkt[pos] = (uint8_t)bk[j];
+      }
+    }
+    lds_barrier();
+    for (uint32_t s = threadIdx.x; s < nt; s += kPartThreads) {
+      const uint64_t gb = s_gbase[s_bkt[s]];
+      if (gb != ~0ull) reinterpret_cast<ulonglong2 *>(out)[gb + s] = s_stage[s];
+    }
+    // (no barrier here: the next tile's counting only touches s_cnt / s_k, reset above; its staging is two barriers away)
+  }
+}
+
 // Records that arrived from the other ranks of a build (a flat array, every source's part grouped by the sender's buckets):
 // coarse-bucket counts of every workgroup's chunk (the chunks scatter_chunks_kernel will take) and the k-mers they hold
 __global__ __launch_bounds__(kPartThreads) void sk_recv_hist_kernel(const uint64_t *__restrict__ recs, uint64_t n, uint32_t *__restrict__ wg_hist,
@@ -916,7 +1009,18 @@ __global__ __launch_bounds__(KMI_SK_NT) void sk_reduce_kernel(const uint64_t *__
                                                         uint64_t *__restrict__ tmp_keys, uint32_t *__restrict__ tmp_vals,
                                                         uint32_t *__restrict__ out_cnt, uint32_t *__restrict__ flags,
                                                         uint32_t *__restrict__ queue /* zero at launch: the next bucket to hand out */, uint32_t n_buckets,
-                                                        uint32_t start_bits, uint32_t lp, float inv_dup) {
+                                                        uint32_t start_bits, uint32_t lp, float inv_dup,
+                                                        const uint64_t *__restrict__ fine_region = nullptr, const uint32_t *__restrict__ fine_cap = nullptr,
+                                                        const uint32_t *__restrict__ fine_cnt = nullptr) {
+  // fine_region / fine_cap / fine_cnt (the slack scatter's layout): bucket b's records are fine_cnt[b] records from
+  // fine_region[b >> 7] + (b & 127) * fine_cap[b >> 7]; null: records [rec_off[b], rec_off[b + 1])
+  auto records_of = [&](uint32_t bb, uint64_t &lo, uint64_t &hi) {
+    if (fine_cnt) {   // (a bucket that outgrew its room voids the build; what was written before it did stays within the room)
+      const uint32_t cap = fine_cap[bb >> 7], cnt = fine_cnt[bb];
+      lo = fine_region[bb >> 7] + (uint64_t)(bb & 127u) * cap; hi = lo + (cnt < cap ? cnt : cap);
+    }
+    else { lo = rec_off[bb]; hi = rec_off[bb + 1]; }
+  };
   using T = SkTab2<OWN_>;
   constexpr int NWAVES = T::NWAVES;
   constexpr uint64_t W1_INIT = ~0ull;   // never a record's second word (its top three bits are zero)
@@ -1034,7 +1138,8 @@ __global__ __launch_bounds__(KMI_SK_NT) void sk_reduce_kernel(const uint64_t *__
   while (b < n_buckets) {   // uniform
     uint32_t q_next = 0;
     if (threadIdx.x == 0) q_next = atomicAdd(queue, 1u);   // (stays in a register until phase A is done: nobody waits for it)
-    const uint64_t rb = pf_ok ? pf_rb : rec_off[b], re = pf_ok ? pf_re : rec_off[b + 1];
+    uint64_t rb = pf_rb, re = pf_re;
+    if (!pf_ok) records_of(b, rb, re);
     const uint32_t n_rec = (uint32_t)(re - rb);
     const ulonglong2 *const src = reinterpret_cast<const ulonglong2 *>(recs) + rb;
     const uint32_t share = (n_rec + NWAVES - 1) / NWAVES;
@@ -1132,7 +1237,7 @@ __global__ __launch_bounds__(KMI_SK_NT) void sk_reduce_kernel(const uint64_t *__
       uint32_t nbk = 0;
       if (first_pass) {   // the next bucket's range: two scalar loads that return during phase B
         nbk = __builtin_amdgcn_readfirstlane(s_ctl[C_NEXT + par]);
-        if (nbk < n_buckets) { pf_rb = rec_off[nbk]; pf_re = rec_off[nbk + 1]; pf_k0 = kmer_off[nbk]; pf_k1 = kmer_off[nbk + 1]; }
+        if (nbk < n_buckets) { records_of(nbk, pf_rb, pf_re); pf_k0 = kmer_off[nbk]; pf_k1 = kmer_off[nbk + 1]; }
       }
       // ---- phase B: every distinct record once with its multiplicity, then the overflow list; the slots are left empty
       if (use_t1) {

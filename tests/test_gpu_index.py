@@ -681,6 +681,29 @@ def test_sparse_index_after_superkmer_build(monkeypatch, k, strand):
     c2.close()
 
 
+def test_fine_buckets_with_room_and_the_counted_fallback(ctx):
+    """A fresh index's build gives every fine bucket of the super-k-mer records room (13/8 of its coarse bucket's mean share + 64)
+    instead of counting the records first; input whose minimizers crowd a few buckets outgrows the room, which voids that attempt
+    and repeats the back end with counted, exact offsets (sk_fine_count). Both outcomes are the oracle's map."""
+    import kmerind_amd as K
+    s = orc.kspec(31, orc.DNA)
+    even = K.synth_fastq(seed=91, genome_len=80_000, n_reads=6_000)
+    one = even[:315]
+    crowded = np.concatenate([even[: 3_000 * 315]] + [one] * 3_000)           # 3000 copies of one read: ~10 buckets get them all
+    for data, counted in ((even, False), (crowded, True)):
+        idx = K.CountIndex(ctx, K.make_config(31, "DNA", strand="canonical"))
+        ctx.profile(True)
+        ctx.profile_reset()
+        idx.build(data)
+        names = {p["name"] for p in ctx.profile_get() if p["launches"]}
+        ctx.profile(False)
+        assert "sk_reduce" in names and ("sk_fine_count" in names) == counted, names
+        om = orc.CountMap(s, STRAND["canonical"])
+        om.insert(orc.extract(s, data, orc.FASTQ)["kmers"])
+        _same_map(idx, om)
+        idx.close()
+
+
 def _fastq_variant(rng, n_reads, kind):
     """FASTQ text the one-pass front end has to get right or hand over: ragged read lengths, long headers, CRLF, blank lines, lower
     case and N bases, quality lines that start with '@' or '+', no EOL at the end"""
