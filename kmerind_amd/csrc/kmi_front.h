@@ -35,7 +35,7 @@ struct __attribute__((packed, aligned(1))) FrU4 { uint32_t x, y, z, w; };   // s
 
 // bytes per lane of a run, in dwords: seg + kmax - 1 bases
 template <int W> struct FrCfg {
-  static constexpr int SEG = W >= 19 ? 128 : (W >= 13 ? 80 : (W >= 11 ? 64 : 44));
+  static constexpr int SEG = W >= 19 ? 127 : (W >= 13 ? 80 : (W >= 11 ? 64 : 44));   // (< 128: window number 127 marks "behind the run" in the walk's entries)
   static constexpr int KMAX = W >= 19 ? 32 : (W >= 13 ? 28 : (W >= 11 ? 22 : 20));
   static constexpr int ND = (SEG + KMAX - 1 + 3) / 4;   // 40, 27, 22, 16
   static constexpr int NR = (ND + 3) / 4;               // packed words that can hold a base: 10, 7, 6, 4
@@ -82,6 +82,12 @@ __global__ __launch_bounds__(kFrThreads) void sk_front_kernel(const uint8_t *__r
   const uint32_t nmax = sk_nmax_of(k);
   const uint32_t seg = (uint32_t)F::SEG;
   const uint32_t n_waves = gridDim.x * (uint32_t)kFrWaves;
+#ifdef KMI_FR_TIMING
+  unsigned long long acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tq = clock64();
+#define FQ_MARK(i) { const unsigned long long now_ = clock64(); acc[i] += now_ - tq; tq = now_; }
+#else
+#define FQ_MARK(i)
+#endif
   for (uint32_t r = blockIdx.x * (uint32_t)kFrWaves + wv; r < n_ranges; r += n_waves) {   // (uniform per wavefront)
     const uint64_t B = (uint64_t)r * range_bytes;
     const uint32_t len = (uint32_t)((n_bytes - B < range_bytes) ? (n_bytes - B) : range_bytes);
@@ -133,6 +139,7 @@ __global__ __launch_bounds__(kFrThreads) void sk_front_kernel(const uint8_t *__r
             n2 = *reinterpret_cast<const FrU4 *>(q + 32); n3 = *reinterpret_cast<const FrU4 *>(q + 48);
           }
         }
+        FQ_MARK(0)
         if (g + 64 <= n_bytes) {
           eol_lo = eol32(v0, v1); eol_hi = eol32(v2, v3);
         } else {
@@ -142,6 +149,7 @@ __global__ __launch_bounds__(kFrThreads) void sk_front_kernel(const uint8_t *__r
             if (i < 32u) eol_lo |= (e ? 1u : 0u) << i; else eol_hi |= (e ? 1u : 0u) << (i - 32u);
           }
         }
+        FQ_MARK(1)
         const uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp((int)carry, (int)(eol_hi >> 31), 0x138 /* wave_shr:1 */, 0xf, 0xf, false);   // lane 0 keeps the carry
         const uint32_t before_lo = (eol_lo << 1) | prev, before_hi = (eol_hi << 1) | (eol_lo >> 31);
         uint32_t ls_lo = ~eol_lo & before_lo, ls_hi = ~eol_hi & before_hi, le_lo = eol_lo & ~before_lo, le_hi = eol_hi & ~before_hi;
@@ -223,6 +231,7 @@ __global__ __launch_bounds__(kFrThreads) void sk_front_kernel(const uint8_t *__r
         wave_sync();                                         // the queue is written; the rings may be overwritten by the next step
       }
       if (bail) break;
+      FQ_MARK(2)
       // ---------------------------------------------------------------- consume
       const uint32_t avail = rq_tail - rq_head;
       if (avail == 0u) { if (!producing) break; continue; }
@@ -262,6 +271,7 @@ __global__ __launch_bounds__(kFrThreads) void sk_front_kernel(const uint8_t *__r
           }
         }
       }
+      FQ_MARK(3)
       // the row leaves now (the walk below consumes its registers): three 16-byte stores per lane, consecutive rows
       if (mine) {
         const uint64_t ri = (uint64_t)r * run_cap + run_count + lane;
@@ -273,6 +283,11 @@ __global__ __launch_bounds__(kFrThreads) void sk_front_kernel(const uint8_t *__r
       // ---- the walk (sk_minimizer_kernel's). The row is kept ALIGNED to the block being walked: after the first m - 1 bases are
       // shifted out once, the W codes of a block are the low 2 W bits of rw[0..1], and the row moves down by W bases per block
       // (static funnel shifts) -- no indexing of the register array by a run-time value, which the compiler answers with scratch.
+      // An entry is written when a super-k-mer OPENS: (low 25 bits of the minimizer's order hash) << 7 | its first window. The walk
+      // has no branch: EVERY position stores its (minimizer, window) into the slot behind the last entry, and the slot pointer
+      // steps on when the minimizer differs from the one before -- a store that is not followed by a step is overwritten by the
+      // next one. Lengths come from the next entry's window afterwards. Positions behind a lane's last window (short reads, the
+      // last block) go on writing entries; their window numbers are >= L and the pass below skips them.
       uint32_t cnt = 0;
       {
         const uint32_t nblk = mine ? (L + (uint32_t)W - 2u) / (uint32_t)W + 1u : 0u;   // m-mer positions 0 .. L + W - 2
@@ -285,8 +300,13 @@ __global__ __launch_bounds__(kFrThreads) void sk_front_kernel(const uint8_t *__r
         uint32_t sprev[W + 1];
 #pragma unroll
         for (int j = 0; j <= W; ++j) sprev[j] = INF;
-        uint32_t prevv = 0, slen = nmax;   // the first window opens a super-k-mer like any other boundary; the dummy lands in slot 0
-        for (uint32_t b = 0; __any(b < nblk); ++b) {
+        // (LDS byte addresses: this lane's slot 0; the last slot a pointer may rest on is CAP: what is stored behind it lands in CAP + 1)
+        const uint32_t a_first = (uint32_t)(uintptr_t)((lds_u32_t *)list + lane), a_stop = a_first + (uint32_t)CAP * 4u * kWave;
+        uint32_t addr = a_first;   // the slot the next entry goes to
+        uint32_t prevv = 0;
+        const uint32_t nblk_max = (uint32_t)__builtin_amdgcn_readlane((int)wave_inclusive_max_dpp(nblk), kWave - 1);
+        auto block = [&](auto first_block, uint32_t wbase /* window that ends at position 0 of the block (b W - (W - 1)) */) {
+          constexpr bool FIRST = decltype(first_block)::value;
           const uint32_t clo = rw[0], chi = rw[1];
           {
             constexpr int WS = (2 * W) / 32, BS = (2 * W) % 32;
@@ -297,8 +317,7 @@ __global__ __launch_bounds__(kFrThreads) void sk_front_kernel(const uint8_t *__r
           uint32_t pm = INF;
 #pragma unroll
           for (int j = 0; j < W; ++j) {
-            const uint32_t q = b * (uint32_t)W + (uint32_t)j;   // (the same in every lane)
-            if (j > 0 || b > 0) {
+            if (j > 0 || !FIRST) {
               const uint32_t c = (j < 16) ? ((clo >> (2 * (j & 15))) & 3u) : ((chi >> (2 * (j & 15))) & 3u);
               R = (R >> 2) | (c << topsh);
               Fw = ((Fw << 2) | (c ^ 3u)) & mmask;
@@ -306,57 +325,73 @@ __global__ __launch_bounds__(kFrThreads) void sk_front_kernel(const uint8_t *__r
             const uint32_t h = sk_order_hash(R < Fw ? R : Fw);
             hh[j] = h;
             pm = pm < h ? pm : h;
+            if (FIRST && j < W - 1) continue;                     // no window ends before position W - 1
             const uint32_t sp = sprev[j + 1];
             const uint32_t curv = sp < pm ? sp : pm;
-            const bool valid = q - (uint32_t)(W - 1) < L;   // window i = q - (W - 1); wraps to a large number below zero
-            const bool fresh = valid && (curv != prevv || slen >= nmax);
-            if (fresh) {   // close (prevv, slen)
-              const uint32_t slot = cnt < (uint32_t)CAP + 1u ? cnt : (uint32_t)CAP + 1u;
-              list[slot * kWave + lane] = (prevv << 5) | (slen - 1u);
-              ++cnt;
-              prevv = curv;
-              slen = 0u;
-            }
-            slen += valid ? 1u : 0u;
+            const uint32_t wi = wbase + (uint32_t)j < 127u ? wbase + (uint32_t)j : 127u;   // (the same in every lane)
+            *(lds_u32_t *)(uintptr_t)addr = (curv << 7) | wi;
+            const uint32_t step = (FIRST || curv != prevv) ? 4u * kWave : 0u;   // (window 0 opens whatever the value)
+            addr = addr + step < a_stop ? addr + step : a_stop;
+            prevv = curv;
           }
           sprev[W] = INF;
           sprev[W - 1] = hh[W - 1];
 #pragma unroll
           for (int j = W - 2; j >= 0; --j) sprev[j] = hh[j] < sprev[j + 1] ? hh[j] : sprev[j + 1];
-        }
-        if (mine) {   // the last super-k-mer
-          const uint32_t slot = cnt < (uint32_t)CAP + 1u ? cnt : (uint32_t)CAP + 1u;
-          list[slot * kWave + lane] = (prevv << 5) | (slen - 1u);
-          ++cnt;
-        }
+        };
+        if (nblk_max) block(std::true_type{}, 0u - (uint32_t)(W - 1));
+        for (uint32_t b = 1; b < nblk_max; ++b) block(std::false_type{}, b * (uint32_t)W - (uint32_t)(W - 1));
+        cnt = (addr - a_first) / (4u * kWave);   // entries 0 .. cnt - 1 (those behind the last window included); CAP: maybe more than fit
       }
-      if (__any(cnt > (uint32_t)CAP + 1u)) { why |= 128u; bail = true; break; }
-      cnt = cnt ? cnt - 1u : 0u;   // real items: slots 1 .. cnt
-      // items in their final form (window offset | (n - 1) << 7 | bucket bits << 12 | two further hash bits << 30) + the coarse counts
+      FQ_MARK(4)
+      if (__any(cnt >= (uint32_t)CAP)) { why |= 128u; bail = true; break; }
+      wave_sync();
+      // items in their final form (window offset | (n - 1) << 7 | bucket bits << 12 | two further hash bits << 30) + the coarse counts.
+      // Backwards, written from the top of the list down: a super-k-mer longer than nmax windows (one minimizer repeated: low
+      // complexity) becomes several items, and what is written must not reach what has not been read yet.
+      uint32_t top = (uint32_t)CAP + 2u;   // items end up in slots top .. CAP + 1
       {
-        uint32_t off = 0;
-        for (uint32_t j = 1; j <= cnt; ++j) {
-          const uint32_t it = list[j * kWave + lane];
-          const uint32_t n1 = it & 31u;
-          const uint32_t h20 = sk_bucket_bits20(it >> 5), h18 = h20 >> 2;
-          atomicAdd(&hist[h18 >> 10], 1u);
-          list[j * kWave + lane] = off | (n1 << 7) | (h18 << 12) | ((h20 & 3u) << 30);
-          off += n1 + 1u;
+        uint32_t nxt_w = L;
+        const uint32_t cmax = (uint32_t)__builtin_amdgcn_readlane((int)wave_inclusive_max_dpp(cnt), kWave - 1);
+        uint32_t it_nx = cmax ? list[(cmax - 1u) * kWave + lane] : 0u;   // (read one turn ahead; a turn writes above the entry it works on)
+        for (uint32_t jj = cmax; jj-- > 0u;) {
+          const uint32_t it = it_nx;
+          if (jj) it_nx = list[(jj - 1u) * kWave + lane];
+          const uint32_t w0 = it & 127u;
+          if (jj < cnt && w0 < L) {
+            const uint32_t h20 = sk_bucket_bits20(it >> 7), h18 = h20 >> 2;
+            uint32_t left = nxt_w - w0;                 // windows of this super-k-mer (>= 1)
+            nxt_w = w0;
+            while (left) {                               // (one turn unless the super-k-mer is longer than nmax)
+              uint32_t n = left;                         // the last piece first: what nmax-window pieces leave over
+              while (n > nmax) n -= nmax;
+              left -= n;
+              if (top <= jj || top <= 2u) { top = 0xffffffffu; left = 0; break; }   // no room (CAP items at most, none over an entry still to be read): checked below
+              --top;
+              atomicAdd(&hist[h18 >> 10], 1u);
+              list[top * kWave + lane] = (w0 + left) | ((n - 1u) << 7) | (h18 << 12) | ((h20 & 3u) << 30);
+            }
+            if (top == 0xffffffffu) break;
+          }
         }
       }
+      if (__any(top == 0xffffffffu)) { why |= 128u; bail = true; break; }
+      cnt = cnt ? (uint32_t)CAP + 2u - top : 0u;
+      FQ_MARK(5)
       const uint32_t cinc = wave_inclusive_sum_dpp(cnt);
       const uint32_t ctot = __builtin_amdgcn_readlane(cinc, kWave - 1);
       if (item_count + ctot > item_cap) { why |= 256u; bail = true; break; }
       if (mine) {
         const uint32_t ex = item_count + cinc - cnt;
         uint32_t *dst = items + (uint64_t)r * item_cap + ex;
-        for (uint32_t j = 0; j < cnt; ++j) dst[j] = list[(j + 1u) * kWave + lane];
+        for (uint32_t j = 0; j < cnt; ++j) dst[j] = list[(top + j) * kWave + lane];
         const uint64_t ri = (uint64_t)r * run_cap + run_count + lane;
         run_items[ri] = ex | (cnt << 26);
       }
       run_count += take;
       item_count += ctot;
       wave_sync();   // the list is read; the next batch overwrites it
+      FQ_MARK(6)
     }
     if (!bail && __any(mk_want && mk_ch != mk_want)) { why |= 16u; bail = true; }   // the last batch's markers
     if (bail) { if (lane == 0) { atomicOr(&flags[9], 4u); atomicOr(&flags[10], why); } }
@@ -372,7 +407,11 @@ __global__ __launch_bounds__(kFrThreads) void sk_front_kernel(const uint8_t *__r
       if (c) atomicAdd(&wg_hist[(uint64_t)grp * kNumCoarse + i], c);
     }
     wave_sync();
+    FQ_MARK(7)
   }
+#ifdef KMI_FR_TIMING
+  if (lane == 0) for (int i = 0; i < 8; ++i) atomicAdd(&reinterpret_cast<unsigned long long *>(flags + 48)[i], acc[i]);
+#endif
 }
 
 // S for the fused front end: the scatter pass over the runs a group of ranges left (run_items / rows / items at fixed strides per
@@ -428,8 +467,13 @@ __global__ __launch_bounds__(kSkThreads, 2) void sk_scatter_rows_kernel(const Fr
       cnt = ri >> 26;
       const uint32_t ioff = q * item_cap + (ri & 0x3ffffffu);
       const uint32_t *src = g_items + ioff;
+      // (sixteen bytes at a time: an item list starts at any dword; what is read behind the run's items is not used)
 #pragma unroll
-      for (int j = 0; j < CAP; ++j) it[j] = ((uint32_t)j < cnt) ? src[j] : 0u;
+      for (int q = 0; q < CAP / 4; ++q) {
+        FrU4 v; v.x = v.y = v.z = v.w = 0;
+        if ((uint32_t)(4 * q) < cnt) v = *reinterpret_cast<const FrU4 *>(src + 4 * q);
+        it[4 * q] = v.x; it[4 * q + 1] = v.y; it[4 * q + 2] = v.z; it[4 * q + 3] = v.w;
+      }
       s_ioff[threadIdx.x] = ioff;
     }
 #pragma unroll

@@ -2790,6 +2790,15 @@ static kmi_status sk_front_fast(kmi_ctx *ctx, const kmi_config *cfg, const KShap
   }
   {
     ProfScope ps(ctx, "sk_offsets", kNumCoarse);
+#ifdef KMI_FR_TIMING
+    {
+      unsigned long long t[8];
+      hipStreamSynchronize(ctx->stream);
+      hipMemcpy(t, ctx->d_flags + 48, sizeof(t), hipMemcpyDeviceToHost);
+      fprintf(stderr, "sk_front wave clocks: wait-bytes %llu  eol %llu  lines %llu  load+pack %llu  walk %llu  final %llu  copy-out %llu  rest %llu\n", t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[7]);
+      hipMemset(ctx->d_flags + 48, 0, sizeof(t));
+    }
+#endif
     hipLaunchKernelGGL(sk_front_verify_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const FrRange *)info, n_ranges, rpg, group_runs, ctx->d_totals + 12, ctx->d_flags);
     launch_rank_offsets(ctx->stream, (const uint32_t *)wg_hist, (uint32_t)kPartGroups, (uint32_t)kNumCoarse, cnt, base, wg_off);
   }
@@ -2936,6 +2945,15 @@ static kmi_status sk_back_end(kmi_index *idx, const uint64_t *rec_a, uint64_t R,
 #undef KMI_SK_REDUCE
   }
   KMI_HIP(ctx, hipGetLastError());
+#ifdef KMI_SK_TIMING
+  {
+    unsigned long long t[8];
+    hipStreamSynchronize(ctx->stream);
+    hipMemcpy(t, ctx->d_flags + 48, sizeof(t), hipMemcpyDeviceToHost);
+    fprintf(stderr, "sk_reduce wave clocks: A-T1 %llu  A-direct %llu  A-wait %llu  B-work %llu  B-wait %llu  emit %llu  between %llu\n", t[0], t[1], t[2], t[3], t[4], t[5], t[6]);
+    hipMemset(ctx->d_flags + 48, 0, sizeof(t));
+  }
+#endif
   // a fine bucket that outgrew its room? (its records beyond the room were not written: this attempt's result is void; read with
   // the level votes below)
   if (slack) KMI_HIP(ctx, hipMemcpyAsync(ctx->h_totals + 14, ctx->d_flags + 34, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));

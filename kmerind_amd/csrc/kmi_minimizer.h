@@ -25,15 +25,16 @@ __device__ __forceinline__ uint32_t sk_order_hash(uint32_t c) {
   h ^= h >> 15;
   return h;
 }
-// bucket bits of a minimizer (from the low 27 bits of its order hash: the high bits of a MINIMUM are nearly always zero)
-__device__ __forceinline__ uint32_t sk_bucket_bits20(uint32_t hv27) {
-  uint32_t h = (hv27 ^ 0x5bd1e995u) * 0x85EBCA6Bu;
+// bucket bits of a minimizer (from the low 25 bits of its order hash: the high bits of a MINIMUM are mostly zero, and a list entry of
+// the walks keeps seven bits beside them)
+__device__ __forceinline__ uint32_t sk_bucket_bits20(uint32_t hv25) {
+  uint32_t h = (hv25 ^ 0x5bd1e995u) * 0x85EBCA6Bu;
   h ^= h >> 13;
   h *= 0xC2B2AE35u;
   h ^= h >> 16;
   return h >> 12;   // 20 bits: the 18 bucket bits and two more below them (a build over ranks fills the sub-bucket bits it shifts out with them)
 }
-__device__ __forceinline__ uint32_t sk_bucket_bits(uint32_t hv27) { return sk_bucket_bits20(hv27) >> 2; }   // 18 bits
+__device__ __forceinline__ uint32_t sk_bucket_bits(uint32_t hv25) { return sk_bucket_bits20(hv25) >> 2; }   // 18 bits
 // forward strand of an m-mer from its complement-stream window (m <= 16: 32 bits)
 __device__ __forceinline__ uint32_t sk_fwd_of(uint32_t r, uint32_t m) {
   uint32_t x = __builtin_bitreverse32(~r);                    // complement codes -> forward codes, first base to the top
@@ -58,7 +59,7 @@ __device__ __forceinline__ uint32_t sk_key_bucket18(uint64_t key, uint32_t k, ui
     const uint32_t h = sk_order_hash(f < r ? f : r);
     best = h < best ? h : best;
   }
-  return sk_bucket_bits(best & 0x7ffffffu);
+  return sk_bucket_bits(best & 0x1ffffffu);
 }
 
 }  // namespace kmi

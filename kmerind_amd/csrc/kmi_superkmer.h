@@ -268,7 +268,7 @@ __global__ __launch_bounds__(kSkThreads, 2) void sk_minimizer_kernel(PackedInput
           const bool fresh = valid && (curv != prev || len >= nmax);
           if (fresh) {   // close (prev, len)
             const uint32_t slot = cnt < (uint32_t)CAP + 1u ? cnt : (uint32_t)CAP + 1u;
-            s_list[slot * NT + threadIdx.x] = (prev << 5) | (len - 1u);
+            s_list[slot * NT + threadIdx.x] = (prev << 7) | (len - 1u);
             ++cnt;
             prev = curv;
             len = 0u;
@@ -282,7 +282,7 @@ __global__ __launch_bounds__(kSkThreads, 2) void sk_minimizer_kernel(PackedInput
       }
       if (mine) {   // the last super-k-mer
         const uint32_t slot = cnt < (uint32_t)CAP + 1u ? cnt : (uint32_t)CAP + 1u;
-        s_list[slot * NT + threadIdx.x] = (prev << 5) | (len - 1u);
+        s_list[slot * NT + threadIdx.x] = (prev << 7) | (len - 1u);
         ++cnt;
       }
     }
@@ -293,8 +293,8 @@ __global__ __launch_bounds__(kSkThreads, 2) void sk_minimizer_kernel(PackedInput
       uint32_t off = 0;
       for (uint32_t j = 1; j <= cnt; ++j) {
         const uint32_t it = s_list[j * NT + threadIdx.x];
-        const uint32_t n1 = it & 31u;
-        const uint32_t h20 = sk_bucket_bits20(it >> 5), h18 = h20 >> 2;
+        const uint32_t n1 = it & 127u;
+        const uint32_t h20 = sk_bucket_bits20(it >> 7), h18 = h20 >> 2;
         atomicAdd(&s_cnt[h18 >> 10], 1u);
         s_list[j * NT + threadIdx.x] = off | (n1 << 7) | (h18 << 12) | ((h20 & 3u) << 30);   // (+ two more hash bits on top)
         off += n1 + 1u;
@@ -1242,15 +1242,24 @@ __global__ __launch_bounds__(KMI_SK_NT) void sk_reduce_kernel(const uint64_t *__
       // ---- phase B: every distinct record once with its multiplicity, then the overflow list; the slots are left empty
       if (use_t1) {
         const uint32_t n_ovf = s_ctl[C_OVN] < (uint32_t)kSkOvf ? s_ctl[C_OVN] : (uint32_t)kSkOvf;
-        for (uint32_t s0 = wv * kWave; s0 < (uint32_t)T::S1 + n_ovf; s0 += T::NT) {
-          const uint32_t s = s0 + lane;
+        // every wavefront sweeps an equal share of the record slots AND an equal share of the overflow list (the list is dense, the
+        // slots are half empty: whole 64-entry blocks dealt out in turn left three wavefronts with three times the k-mers of four
+        // others, and a sixth of the kernel went by at the barrier behind this phase)
+        constexpr uint32_t PER1 = ((uint32_t)T::S1 + NWAVES - 1) / NWAVES;
+        const uint32_t per_o = (n_ovf + NWAVES - 1) / NWAVES;
+        const uint32_t t_lo = wv * PER1, t_hi = t_lo + PER1 < (uint32_t)T::S1 ? t_lo + PER1 : (uint32_t)T::S1;
+        const uint32_t o_lo = wv * per_o < n_ovf ? wv * per_o : n_ovf, o_hi = o_lo + per_o < n_ovf ? o_lo + per_o : n_ovf;
+        const uint32_t n_mine = (t_hi - t_lo) + (o_hi - o_lo);
+        for (uint32_t i0 = 0; i0 < n_mine; i0 += kWave) {
+          const uint32_t i = i0 + lane;
           uint64_t w0 = kEmptyKey, w1 = 0; uint32_t wt = 0;
-          if (s < (uint32_t)T::S1) {
+          if (i < t_hi - t_lo) {
+            const uint32_t s = t_lo + i;
             const ulonglong2 ent = s_r[s];
             w0 = ent.x; w1 = ent.y; wt = s_rc[s];
             if (w0 != kEmptyKey) { s_r[s] = make_ulonglong2(kEmptyKey, W1_INIT); s_rc[s] = 0; }
-          } else if (s - (uint32_t)T::S1 < n_ovf) {
-            const ulonglong2 ent = s_ovf[s - (uint32_t)T::S1];
+          } else if (i < n_mine) {
+            const ulonglong2 ent = s_ovf[o_lo + (i - (t_hi - t_lo))];
             w0 = ent.x; w1 = ent.y; wt = 1u;
           }
           uint32_t n = wt ? ((uint32_t)(w1 >> kRecNShift) & 31u) + 1u : 0u;
