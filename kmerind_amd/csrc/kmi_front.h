@@ -420,23 +420,32 @@ __global__ __launch_bounds__(kFrThreads) void sk_front_kernel(const uint8_t *__r
 // 16-byte loads and starts at the run's first base.
 constexpr int kFrRowLds = kFrRowDw + 1;   // odd stride: rows on different banks
 constexpr uint32_t kFrMaxGroupRanges = 128;
+constexpr int kFrScThreads = 512;         // runs per round of the scatter pass ...
+constexpr int kFrScItems = 7680;          // ... as long as their items fit here (about 14 per run of 120 windows); a round takes fewer runs otherwise
 template <bool CANON>
-__global__ __launch_bounds__(kSkThreads, 2) void sk_scatter_rows_kernel(const FrRange *__restrict__ info, uint32_t n_ranges, uint32_t rpg, uint32_t run_cap,
-                                                                       uint32_t item_cap, uint32_t k, const uint32_t *__restrict__ run_items,
-                                                                       const uint32_t *__restrict__ rows, const uint32_t *__restrict__ items,
-                                                                       const uint64_t *__restrict__ wg_off, uint64_t *__restrict__ out, uint32_t lp) {
-  constexpr int NT = kSkThreads, CAP = kSkListCap;
-  __shared__ uint16_t s_stage[CAP * NT];
+__global__ __launch_bounds__(kFrScThreads, 2) void sk_scatter_rows_kernel(const FrRange *__restrict__ info, uint32_t n_ranges, uint32_t rpg, uint32_t run_cap,
+                                                                         uint32_t item_cap, uint32_t k, const uint32_t *__restrict__ run_items,
+                                                                         const uint32_t *__restrict__ rows, const uint32_t *__restrict__ items,
+                                                                         const uint64_t *__restrict__ wg_off, uint64_t *__restrict__ out, uint32_t lp) {
+  // One lane per run; the round's items are brought into LDS ONCE (sixteen bytes at a time from each run's list) and everything
+  // after that -- bucket counts, the bucket sort of (run, item) references, the copy-out that assembles the records -- reads
+  // them there. (Kept in registers and re-read from global memory for the copy-out, the items made this kernel wait on the
+  // texture addresser: one dword from a different cache line per lane and record.)
+  constexpr int NT = kFrScThreads, CAP = kSkListCap, ICAP = kFrScItems;
+  static_assert(ICAP >= CAP, "a run's items must fit a round");
+  __shared__ uint16_t s_stage[ICAP];
+  __shared__ uint32_t s_items[ICAP + 4];
   __shared__ uint32_t s_row[NT * kFrRowLds + 4];
-  __shared__ uint32_t s_ioff[NT];       // first item of every run, relative to the group's first item region
+  __shared__ uint32_t s_ibase[NT];      // first item of every run in s_items
   __shared__ uint32_t s_cnt[kNumCoarse];
   __shared__ uint32_t s_cur[kNumCoarse];
   __shared__ uint64_t s_gbase[kNumCoarse];
   __shared__ uint32_t s_part[kNumCoarse / kWave];
-  __shared__ uint32_t s_total;
+  __shared__ uint32_t s_scan[NT / kWave + 2];
   __shared__ uint32_t s_pre[kFrMaxGroupRanges + 1];   // runs before every range of the group
-  uint64_t cursor = (threadIdx.x < kNumCoarse) ? wg_off[(uint64_t)blockIdx.x * kNumCoarse + threadIdx.x] : 0ull;
-  if (threadIdx.x < kNumCoarse) s_cnt[threadIdx.x] = 0;
+  const bool bl = threadIdx.x < kNumCoarse;   // the lanes that keep a coarse bucket's counters
+  uint64_t cursor = bl ? wg_off[(uint64_t)blockIdx.x * kNumCoarse + threadIdx.x] : 0ull;
+  if (bl) s_cnt[threadIdx.x] = 0;
   const uint32_t r_first = blockIdx.x * rpg;
   const uint32_t nr = r_first >= n_ranges ? 0u : (n_ranges - r_first < rpg ? n_ranges - r_first : rpg);
   if (threadIdx.x == 0) {
@@ -447,66 +456,75 @@ __global__ __launch_bounds__(kSkThreads, 2) void sk_scatter_rows_kernel(const Fr
   lds_barrier();
   const uint32_t total_runs = s_pre[nr];
   const uint32_t *const g_items = items + (uint64_t)r_first * item_cap;
-  for (uint32_t rb = 0; rb < total_runs; rb += NT) {
-    lds_barrier();   // the previous round's stage and run tables are done with; the counters are clear
-    uint32_t cnt = 0;
-    uint32_t it[CAP];
-    {
-      const uint32_t G = rb + threadIdx.x;
-      uint32_t ri = 0, q = 0;
-      if (G < total_runs) {
-        for (uint32_t i = 1; i < nr; ++i) q += (G >= s_pre[i]) ? 1u : 0u;
-        const uint64_t run = (uint64_t)(r_first + q) * run_cap + (G - s_pre[q]);
-        ri = run_items[run];
-        const uint4 *rp = reinterpret_cast<const uint4 *>(rows + run * kFrRowDw);
-        const uint4 q0 = rp[0], q1 = rp[1], q2 = rp[2];
-        uint32_t *row = s_row + threadIdx.x * kFrRowLds;
-        row[0] = q0.x; row[1] = q0.y; row[2] = q0.z; row[3] = q0.w; row[4] = q1.x; row[5] = q1.y; row[6] = q1.z; row[7] = q1.w;
-        row[8] = q2.x; row[9] = q2.y; row[10] = q2.z; row[11] = q2.w; row[12] = 0;
-      }
-      cnt = ri >> 26;
-      const uint32_t ioff = q * item_cap + (ri & 0x3ffffffu);
-      const uint32_t *src = g_items + ioff;
-      // (sixteen bytes at a time: an item list starts at any dword; what is read behind the run's items is not used)
-#pragma unroll
-      for (int q = 0; q < CAP / 4; ++q) {
-        FrU4 v; v.x = v.y = v.z = v.w = 0;
-        if ((uint32_t)(4 * q) < cnt) v = *reinterpret_cast<const FrU4 *>(src + 4 * q);
-        it[4 * q] = v.x; it[4 * q + 1] = v.y; it[4 * q + 2] = v.z; it[4 * q + 3] = v.w;
-      }
-      s_ioff[threadIdx.x] = ioff;
+  for (uint32_t rb = 0; rb < total_runs;) {
+    // ---- this round's runs: as many of the next NT as their items fit
+    const uint32_t G = rb + threadIdx.x;
+    uint32_t ri = 0, q = 0;
+    uint64_t run = 0;
+    if (G < total_runs) {
+      for (uint32_t i = 1; i < nr; ++i) q += (G >= s_pre[i]) ? 1u : 0u;
+      run = (uint64_t)(r_first + q) * run_cap + (G - s_pre[q]);
+      ri = run_items[run];
     }
+    uint32_t cnt = ri >> 26;
+    uint32_t total;
+    const uint32_t pre = block_exclusive_scan<uint32_t>(cnt, s_scan, &total);
+    const bool taken = G < total_runs && pre + cnt <= (uint32_t)ICAP;   // (a prefix of the lanes: the sums only grow)
+    const uint32_t n_taken = (uint32_t)__syncthreads_count(taken);     // >= 1: one run's items always fit
+    if (!taken) cnt = 0;
+    if (taken) {
+      const uint4 *rp = reinterpret_cast<const uint4 *>(rows + run * kFrRowDw);
+      const uint4 q0 = rp[0], q1 = rp[1], q2 = rp[2];
+      uint32_t *row = s_row + threadIdx.x * kFrRowLds;
+      row[0] = q0.x; row[1] = q0.y; row[2] = q0.z; row[3] = q0.w; row[4] = q1.x; row[5] = q1.y; row[6] = q1.z; row[7] = q1.w;
+      row[8] = q2.x; row[9] = q2.y; row[10] = q2.z; row[11] = q2.w; row[12] = 0;
+      // the items: sixteen bytes at a time (a list starts at any dword; what is read behind the run's items is not used)
+      const uint32_t *src = g_items + (q * item_cap + (ri & 0x3ffffffu));
 #pragma unroll
-    for (int j = 0; j < CAP; ++j)
-      if ((uint32_t)j < cnt) atomicAdd(&s_cnt[(it[j] >> 22) & 255u], 1u);
+      for (int v4 = 0; v4 < CAP / 4; ++v4) {
+        if ((uint32_t)(4 * v4) < cnt) {
+          const FrU4 v = *reinterpret_cast<const FrU4 *>(src + 4 * v4);
+          const uint32_t it[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if ((uint32_t)(4 * v4 + e) < cnt) { s_items[pre + 4 * v4 + e] = it[e]; atomicAdd(&s_cnt[(it[e] >> 22) & 255u], 1u); }
+        }
+      }
+    }
+    s_ibase[threadIdx.x] = pre;
     lds_barrier();
+    // ---- bucket offsets of the round
     uint32_t c = 0, inc = 0;
-    if (threadIdx.x < kNumCoarse) {
+    if (bl) {
       c = s_cnt[threadIdx.x];
       s_cnt[threadIdx.x] = 0;
       inc = wave_inclusive_sum_dpp(c);
       if (lane_id() == kWave - 1) s_part[wave_id()] = inc;
     }
     lds_barrier();
-    if (threadIdx.x < kNumCoarse) {
-      uint32_t pre = 0;
+    if (bl) {
+      uint32_t wpre = 0;
 #pragma unroll
-      for (uint32_t w = 0; w < kNumCoarse / kWave; ++w) pre += (w < wave_id()) ? s_part[w] : 0u;
-      const uint32_t lo = pre + inc - c;
+      for (uint32_t w = 0; w < kNumCoarse / kWave; ++w) wpre += (w < wave_id()) ? s_part[w] : 0u;
+      const uint32_t lo = wpre + inc - c;
       s_cur[threadIdx.x] = lo;
       s_gbase[threadIdx.x] = cursor - lo;
       cursor += c;
-      if (threadIdx.x == kNumCoarse - 1) s_total = pre + inc;
     }
     lds_barrier();
-#pragma unroll
-    for (int j = 0; j < CAP; ++j)
-      if ((uint32_t)j < cnt) s_stage[atomicAdd(&s_cur[(it[j] >> 22) & 255u], 1u)] = (uint16_t)((threadIdx.x << 5) | (uint32_t)j);
+    // ---- references (run << 5 | item) in bucket order
+    for (uint32_t j = 0; j < cnt; ++j) {
+      const uint32_t item = s_items[pre + j];
+      s_stage[atomicAdd(&s_cur[(item >> 22) & 255u], 1u)] = (uint16_t)((threadIdx.x << 5) | j);
+    }
     lds_barrier();
-    const uint32_t total = s_total;
-    for (uint32_t s = threadIdx.x; s < total; s += NT) {
+    // ---- copy-out: every lane assembles the record of one sorted position
+    const uint32_t n_items = pre + cnt;   // (of the last taken lane: the round's total)
+    const uint32_t round_items = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_cur[kNumCoarse - 1]);   // the last bucket's end = all items of the round
+    (void)n_items;
+    for (uint32_t s = threadIdx.x; s < round_items; s += NT) {
       const uint32_t e = s_stage[s], rl = e >> 5, j = e & 31u;
-      const uint32_t item = g_items[s_ioff[rl] + j];
+      const uint32_t item = s_items[s_ibase[rl] + j];
       const uint32_t h18 = (item >> 12) & 0x3ffffu, n1 = (item >> 7) & 31u, extra = item >> 30;
       // the bucket bits as the owner will read them: the lp rank bits shifted out, the two spare hash bits shifted in below
       const uint32_t hs = ((h18 << lp) & 0x3ffffu) | (lp <= 2u ? extra >> (2u - lp) : extra << (lp - 2u));
@@ -514,6 +532,8 @@ __global__ __launch_bounds__(kSkThreads, 2) void sk_scatter_rows_kernel(const Fr
       sk_assemble_row<CANON>(s_row + rl * kFrRowLds, 2u * (item & 127u), k + n1, n1, hs, w0, w1);
       reinterpret_cast<ulonglong2 *>(out)[s_gbase[h18 >> 10] + s] = make_ulonglong2(w0, w1);
     }
+    rb += n_taken;
+    lds_barrier();   // the stage, the items and the run tables are done with; the counters are clear
   }
 }
 

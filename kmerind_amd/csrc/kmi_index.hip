@@ -2829,10 +2829,10 @@ static kmi_status sk_front_fast(kmi_ctx *ctx, const kmi_config *cfg, const KShap
   {
     ProfScope ps(ctx, "sk_scatter", n);
     if (canonical)
-      hipLaunchKernelGGL(sk_scatter_rows_kernel<true>, dim3(kPartGroups), dim3(kSkThreads), 0, ctx->stream, (const FrRange *)info, n_ranges, rpg, run_cap, item_cap, k,
+      hipLaunchKernelGGL(sk_scatter_rows_kernel<true>, dim3(kPartGroups), dim3(kFrScThreads), 0, ctx->stream, (const FrRange *)info, n_ranges, rpg, run_cap, item_cap, k,
                          (const uint32_t *)run_items, (const uint32_t *)rows, (const uint32_t *)items, (const uint64_t *)wg_off, rec_a, lp);
     else
-      hipLaunchKernelGGL(sk_scatter_rows_kernel<false>, dim3(kPartGroups), dim3(kSkThreads), 0, ctx->stream, (const FrRange *)info, n_ranges, rpg, run_cap, item_cap, k,
+      hipLaunchKernelGGL(sk_scatter_rows_kernel<false>, dim3(kPartGroups), dim3(kFrScThreads), 0, ctx->stream, (const FrRange *)info, n_ranges, rpg, run_cap, item_cap, k,
                          (const uint32_t *)run_items, (const uint32_t *)rows, (const uint32_t *)items, (const uint64_t *)wg_off, rec_a, lp);
   }
   KMI_HIP(ctx, hipGetLastError());
