@@ -3,7 +3,7 @@
 // distributed_unordered_map.hpp:1603-1618), get_map() / cbegin() / cend() (:120-125, 377-384), and the
 // PositionQualityIndex alias (:405-406) with its (ShortSequenceKmerId, float) values. Prints numbers the test checks
 // in tests/test_gpu_facade.py.
-//   usage: facade_extras file.fastq
+//   usage: facade_extras file.fastq [file.fasta]
 #include <cstdio>
 #include <cstring>
 #include <map>
@@ -76,6 +76,18 @@ int main(int argc, char **argv) {
       unsigned long long ex = 0;
       for (unsigned char b : fidx.exists(q)) ex += b;
       std::printf("build_posix entries %zu sum %llu exists %llu of %zu\n", fidx.local_size(), fs, ex, q.size());
+    }
+    if (argc > 2) {
+      // the same entry point on a FASTA file (with KMI_FORCE_DIST=1: every rank reads the file whole and keeps its block of an
+      // equal split, the block bookkeeping computed on the device), and read_file_posix on it
+      const std::string fasta = argv[2];
+      CountIdx aidx(comm);
+      aidx.build_posix<::bliss::io::FASTAParser, ::bliss::io::SequencesIterator>(fasta);
+      unsigned long long as = 0;
+      for (auto &e : aidx.to_vector()) as += e.second;
+      std::vector<std::pair<KmerType, uint32_t>> at;
+      ::bliss::io::KmerFileHelper::read_file_posix<typename CountIdx::KmerParserType, ::bliss::io::FASTAParser, ::bliss::io::SequencesIterator>(fasta, at, comm);
+      std::printf("fasta build_posix entries %zu sum %llu tuples %zu\n", aidx.local_size(), as, at.size());
     }
     auto &view = cidx.get_map();
     std::printf("get_map local_size %zu size %zu\n", view.local_size(), view.size());

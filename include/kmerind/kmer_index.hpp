@@ -693,12 +693,19 @@ class Index {
     if (fmt != SeqParser<const unsigned char *>::KMI) throw std::invalid_argument("Specified File Parser template parameter does not support files with this extension.");
     ::kmerind::check(ctx, kmi_index_set_seq_format(idx, fmt));
     ::kmerind::check(ctx, kmi_index_set_seq_filter(idx, seq_filter));
-    if (comm.size() > 1 || (rccl && fmt == KMI_FMT_FASTQ)) {
+    if (comm.size() > 1 || rccl) {
       // every rank reads ITS byte range of the file plus look-ahead, finds where its partition begins and ends with the
       // four-line rule on the device (both neighbours decide at the same file position) and enters the collective build
       // (partitioned_file + FASTQParser::find_first_record, file.hpp:1216-1430, fastq_loader.hpp:269-364)
       need_rccl("build_posix / build_mmap / build_mpiio");
-      if (fmt != KMI_FMT_FASTQ) throw std::invalid_argument("build_* with size() > 1 reads FASTQ partitions; a FASTA file over ranks goes through build_partition with kmi_ctx_set_fasta_partition");
+      if (fmt == KMI_FMT_FASTA) {
+        // FASTA: every rank reads the file whole (a block's bookkeeping -- which record it starts in, in which state -- needs what
+        // lies before it; the reference gets it from collectives over the blocks, fasta_loader.hpp:202-470) and keeps its block
+        std::vector<uint8_t> whole = detail::read_whole_file(filename);
+        ::kmerind::check(ctx, kmi_index_build_fasta_file_dist_host(idx, rccl, whole.data(), whole.size()));
+        return;
+      }
+      if (fmt != KMI_FMT_FASTQ) throw std::invalid_argument("build_* with size() > 1 reads FASTQ or FASTA files");
       for (uint64_t look = 1ull << 20;; look *= 8) {
         detail::FileRange r = detail::read_file_range(filename, comm.rank(), comm.size(), look);
         int need_more = 0;
@@ -829,7 +836,10 @@ struct KmerFileHelper {
     if (comm.size() > 1) {
       // this rank's partition of the file: its byte range plus look-ahead, cut at record starts by the four-line rule (no
       // communication: both neighbours apply the rule at the same file position); the ids carry the file offsets
-      if (c.seq_format != KMI_FMT_FASTQ) { kmi_ctx_destroy(ctx); throw std::invalid_argument("read_file_* with size() > 1 reads FASTQ partitions"); }
+      if (c.seq_format == KMI_FMT_FASTA) {   // (every rank reads the file whole and keeps its block: see Index::build_file)
+        std::vector<uint8_t> whole = ::bliss::index::kmer::detail::read_whole_file(filename);
+        st = kmi_extract_fasta_block_host(ctx, &c, whole.data(), whole.size(), (uint32_t)comm.rank(), (uint32_t)comm.size(), &t);
+      } else
       for (uint64_t look = 1ull << 20;; look *= 8) {
         ::bliss::index::kmer::detail::FileRange r = ::bliss::index::kmer::detail::read_file_range(filename, comm.rank(), comm.size(), look);
         int need_more = 0;

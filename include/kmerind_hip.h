@@ -166,6 +166,12 @@ void kmi_tuples_free(kmi_tuples *t);
 kmi_status kmi_extract_range_host(kmi_ctx *ctx, const kmi_config *cfg, const uint8_t *bytes, size_t n_bytes, uint64_t buffer_offset,
                                   uint64_t nominal_bytes, int reaches_eof, int *need_more, kmi_tuples *out);
 
+/* the same for FASTA (fasta_loader.hpp:202-470 over file.hpp:1436-1610): every rank holds the WHOLE file; the tuples of block
+ * `rank` of an equal nranks-way split come back, the block bookkeeping (valid range, machine state, records before) being computed
+ * on the device from the whole buffer (kmi_fasta_partition_dev). The union over the ranks is the file's tuples, each once. */
+kmi_status kmi_extract_fasta_block_host(kmi_ctx *ctx, const kmi_config *cfg, const uint8_t *bytes, size_t n_bytes, uint32_t rank,
+                                        uint32_t nranks, kmi_tuples *out);
+
 /* device form: out_kmers_dev capacity in tuples (use kmi_extract_count_dev first, or pass an upper bound n_bytes). bytes_dev
  * may point anywhere (a record-aligned batch inside a larger buffer): an input that is not 16-byte aligned is copied once,
  * device to device, to an aligned workspace buffer. */
@@ -356,6 +362,9 @@ kmi_status kmi_index_build_dist_dev(kmi_index *idx, kmi_comm *comm, const uint8_
  * collective has been entered). Then the collective build of that partition. Works for comm.size() == 1 too. */
 kmi_status kmi_index_build_range_dist_host(kmi_index *idx, kmi_comm *comm, const uint8_t *bytes, size_t n_bytes, uint64_t buffer_offset,
                                            uint64_t nominal_bytes, int reaches_eof, int *need_more);
+/* the same for a FASTA file: every rank passes the WHOLE file; it keeps block comm.rank() of an equal split (bookkeeping on the
+ * device, kmi_fasta_partition_dev) and enters the collective build with it. Works for comm.size() == 1 too. */
+kmi_status kmi_index_build_fasta_file_dist_host(kmi_index *idx, kmi_comm *comm, const uint8_t *bytes, size_t n_bytes);
 /* weighted insert and update() of the counting maps with comm.size() > 1: the pairs travel to the ranks that own their keys
  * (records: n x (n_words key words, one value word); *n_updated = pairs applied on THIS rank) */
 kmi_status kmi_index_insert_pairs_dist_host(kmi_index *idx, kmi_comm *comm, const uint64_t *records, size_t n);

@@ -115,14 +115,20 @@ class Context:
         return out
 
     # ---- KmerFileHelper::read_file_* equivalent on an in-memory, record-aligned partition
-    def read_file(self, cfg, data, file_offset=0, with_ids=False, with_quals=False):
+    def read_file(self, cfg, data, file_offset=0, with_ids=False, with_quals=False, fasta_block=None):
         """returns (kmers[n, n_words], n_seqs) in file order, as parsed (no strand transform);
-        with_ids (position index kinds): (kmers, ids, n_seqs), ids = Short/LongSequenceKmerId words"""
+        with_ids (position index kinds): (kmers, ids, n_seqs), ids = Short/LongSequenceKmerId words.
+        fasta_block = (rank, nranks): `data` is a WHOLE FASTA file and the tuples of that rank's block of an equal split come back
+        (kmi_extract_fasta_block_host: what read_file_* does on one rank of several)"""
         buf = np.frombuffer(bytes(data), dtype=np.uint8) if isinstance(data, (bytes, bytearray)) else \
             np.ascontiguousarray(data, dtype=np.uint8)
         t = L.Tuples()
-        self.check(lib.kmi_extract_host(self.h, C.byref(cfg), buf.ctypes.data_as(C.c_void_p), buf.size, file_offset,
-                                        C.byref(t)))
+        if fasta_block is not None:
+            self.check(lib.kmi_extract_fasta_block_host(self.h, C.byref(cfg), buf.ctypes.data_as(C.c_void_p), buf.size,
+                                                        int(fasta_block[0]), int(fasta_block[1]), C.byref(t)))
+        else:
+            self.check(lib.kmi_extract_host(self.h, C.byref(cfg), buf.ctypes.data_as(C.c_void_p), buf.size, file_offset,
+                                            C.byref(t)))
         nw = self.shape(cfg)[0]
         n = t.n_tuples
         kmers = np.ctypeslib.as_array(t.kmers, shape=(n * nw,)).copy().reshape(n, nw) if n else \

@@ -389,6 +389,28 @@ kmi_status kmi_extract_range_host(kmi_ctx *ctx, const kmi_config *cfg, const uin
   return kmi_extract_host(ctx, cfg, bytes + cut[0], (size_t)(cut[1] - cut[0]), buffer_offset + cut[0], out);
 }
 
+kmi_status kmi_extract_fasta_block_host(kmi_ctx *ctx, const kmi_config *cfg, const uint8_t *bytes, size_t n_bytes, uint32_t rank, uint32_t nranks,
+                                        kmi_tuples *out) {
+  // the tuples of block `rank` of an equal nranks-way split of a FASTA buffer every rank holds whole (see
+  // kmi_index_build_fasta_file_dist_host): the union over the ranks is the file's tuples, each exactly once
+  if (!ctx || !cfg || !out || nranks == 0 || rank >= nranks) return KMI_ERR_INVALID;
+  memset(out, 0, sizeof(*out));
+  if (cfg->seq_format != KMI_FMT_FASTA) return set_err(ctx, KMI_ERR_INVALID, "not FASTA");
+  if (n_bytes == 0) return KMI_OK;
+  if (!bytes) return set_err(ctx, KMI_ERR_INVALID, "null buffer");
+  KMI_HIP(ctx, hipSetDevice(ctx->device));
+  void *din;
+  KMI_TRY(ws_get(ctx, WS_INPUT2, n_bytes + 64, &din));
+  KMI_HIP(ctx, hipMemcpyAsync(din, bytes, n_bytes, hipMemcpyHostToDevice, ctx->stream));
+  std::vector<uint64_t> be(2 * (size_t)nranks);
+  std::vector<kmi_fasta_partition> parts(nranks);
+  KMI_TRY(kmi_fasta_partition_dev(ctx, (const uint8_t *)din, n_bytes, nranks, cfg->k, be.data(), parts.data()));
+  KMI_TRY(kmi_ctx_set_fasta_partition(ctx, &parts[rank]));
+  const kmi_status st = kmi_extract_host(ctx, cfg, bytes + be[2 * rank], (size_t)(be[2 * rank + 1] - be[2 * rank]), be[2 * rank], out);
+  (void)kmi_ctx_set_fasta_partition(ctx, nullptr);
+  return st;
+}
+
 void kmi_tuples_free(kmi_tuples *t) {
   if (!t) return;
   free(t->kmers); free(t->ids); free(t->quals);

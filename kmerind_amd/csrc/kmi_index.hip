@@ -4433,6 +4433,27 @@ kmi_status kmi_index_build_range_dist_host(kmi_index *idx, kmi_comm *comm, const
   return kmi_index_build_dist_dev(idx, comm, (const uint8_t *)d_bytes + cut[0], (size_t)(cut[1] - cut[0]), buffer_offset + cut[0]);
 }
 
+kmi_status kmi_index_build_fasta_file_dist_host(kmi_index *idx, kmi_comm *comm, const uint8_t *bytes, size_t n_bytes) {
+  // every rank holds the WHOLE FASTA file; the block bookkeeping of an equal split over the ranks (where each block's valid range
+  // begins, the machine state and the record count there: file.hpp:1436-1610 + fasta_loader.hpp:202-470) is computed on the device
+  // from the whole buffer, every rank keeps its own block and enters the collective build with it
+  KMI_TRY(dist_check(idx, comm));
+  kmi_ctx *ctx = idx->ctx;
+  if (idx->cfg.seq_format != KMI_FMT_FASTA) return set_err(ctx, KMI_ERR_INVALID, "not a FASTA index");
+  if (n_bytes && !bytes) return set_err(ctx, KMI_ERR_INVALID, "null buffer");
+  const uint32_t p = (uint32_t)kmi::comm_size(comm), r = (uint32_t)kmi::comm_rank(comm);
+  void *d_bytes;
+  KMI_TRY(ws_get(ctx, WS_INPUT, n_bytes + 64, &d_bytes));
+  if (n_bytes) KMI_HIP(ctx, hipMemcpyAsync(d_bytes, bytes, n_bytes, hipMemcpyHostToDevice, ctx->stream));
+  std::vector<uint64_t> be(2 * (size_t)p);
+  std::vector<kmi_fasta_partition> parts(p);
+  KMI_TRY(kmi_fasta_partition_dev(ctx, (const uint8_t *)d_bytes, n_bytes, p, idx->shape.k, be.data(), parts.data()));
+  KMI_TRY(kmi_ctx_set_fasta_partition(ctx, &parts[r]));
+  const kmi_status st = kmi_index_build_dist_dev(idx, comm, (const uint8_t *)d_bytes + be[2 * r], (size_t)(be[2 * r + 1] - be[2 * r]), be[2 * r]);
+  (void)kmi_ctx_set_fasta_partition(ctx, nullptr);
+  return st;
+}
+
 kmi_status kmi_index_build_dist_host(kmi_index *idx, kmi_comm *comm, const uint8_t *bytes, size_t n_bytes, uint64_t file_offset) {
   KMI_TRY(dist_check(idx, comm));
   kmi_ctx *ctx = idx->ctx;

@@ -210,7 +210,8 @@ def test_weighted_insert_iterators_and_posqual_through_the_facade(force_dist):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "examples")])
     path = os.path.join(DATA, "natural.fastq")
     env = dict(os.environ, KMI_FORCE_DIST="1") if force_dist else None
-    out = subprocess.run([exe, path], capture_output=True, text=True, timeout=300, env=env)
+    fasta = os.path.join(DATA, "natural.fasta")
+    out = subprocess.run([exe, path, fasta], capture_output=True, text=True, timeout=300, env=env)
     assert out.returncode == 0, out.stderr
 
     def grab(pat):
@@ -246,6 +247,11 @@ def test_weighted_insert_iterators_and_posqual_through_the_facade(force_dist):
     present = {tuple(kk) for kk in keys.tolist()}
     qq = canon[::4].tolist()
     assert grab(r"build_posix entries (\d+) sum (\d+) exists (\d+) of (\d+)") == (cm.size(), n, sum(1 for kk in qq if tuple(kk) in present), len(qq) + 1)
+    # the same on a FASTA file (KMI_FORCE_DIST=1: whole file on every rank, this rank's block, the collective build)
+    fa = orc.extract(s, open(fasta, "rb").read(), orc.FASTA)
+    fm = orc.CountMap(s, orc.CANONICAL)
+    fm.insert(fa["kmers"])
+    assert grab(r"fasta build_posix entries (\d+) sum (\d+) tuples (\d+)") == (fm.size(), fa["kmers"].shape[0], fa["kmers"].shape[0])
     assert grab(r"get_map local_size (\d+) size (\d+)") == (cm.size(), cm.size())
     vals = np.stack([ex["ids"], ex["quals"].view(np.uint32).astype(np.uint64)], axis=1)
     mm = orc.MultiMap(s, orc.CANONICAL, vw=2)

@@ -236,3 +236,22 @@ def test_fasta_with_more_runs_than_a_tile_has_slots_takes_the_kmer_path(ctx):
     a, b = orc.sorted_pairs(*idx.to_vector()), orc.sorted_pairs(*om.export())
     assert a[0].shape == b[0].shape and (a[0] == b[0]).all() and (a[1] == b[1]).all()
     idx.close()
+
+
+@pytest.mark.parametrize("k,alpha", [(31, "DNA"), (63, "DNA5")])
+def test_fasta_block_of_one_rank_of_several(ctx, k, alpha):
+    """read_file_* on one rank of several, FASTA (kmi_extract_fasta_block_host): every rank holds the whole file and parses block
+    `rank` of an equal split, the bookkeeping computed on the device; the blocks in rank order are the oracle's parse of the file."""
+    import kmerind_amd as K
+    s = orc.kspec(k, ALPHA[alpha])
+    cfg = K.make_config(k, alpha, seq_format="fasta", index_kind="position")
+    rng = np.random.default_rng(7 * k)
+    inputs = [open(os.path.join(GOLD, "data", name), "rb").read() for name in FILES]
+    inputs.append(_synthetic_fasta(rng, 30, line=60, eol=b"\n", orphan=True))
+    for data in inputs:
+        whole = orc.extract(s, data, orc.FASTA, file_offset=0, want_ids=True)
+        for p in (1, 2, 3, 5):
+            got = [ctx.read_file(cfg, data, with_ids=True, fasta_block=(r, p)) for r in range(p)]
+            gk = np.concatenate([g[0] for g in got])
+            gi = np.concatenate([g[1] for g in got])
+            assert gk.shape == whole["kmers"].shape and (gk == whole["kmers"]).all() and (gi == whole["ids"]).all(), (p, len(data))
