@@ -992,7 +992,10 @@ __global__ __launch_bounds__(KMI_SK_NT) void sk_reduce_v1_kernel(const uint64_t 
 //    direct expansions inside phase A cost a whole expansion step for the two or three records of a batch that needed one);
 //  * the first records of the NEXT bucket are loaded before the emit sweep of the current one, so a bucket does not start
 //    with two dependent trips to HBM (its offsets, then its records).
-constexpr int kSkOvf = 192;   // overflow list entries (records that T1 did not take)
+#ifndef KMI_SK_OVF
+#define KMI_SK_OVF 448   // overflow list entries (records that T1 did not take). With H1 1536: 100 record slots + 28 list entries per wavefront in phase B = two full steps of 64 lanes; 192: 3.12 ms, 384: 2.98, 448: 2.97, 512: 3.00 (config 2)
+#endif
+constexpr int kSkOvf = KMI_SK_OVF;
 template <int OWN_>
 struct SkTab2 {
   static constexpr int NT = KMI_SK_NT, NWAVES = NT / kWave;
@@ -1061,13 +1064,50 @@ __global__ __launch_bounds__(KMI_SK_NT) void sk_reduce_kernel(const uint64_t *__
   uint64_t pf_rb = 0, pf_re = 0, pf_k0 = 0, pf_k1 = 0;
   // all k-mers of a batch of records (w0, w1, weight wt; n = 0: none) into the k-mer table
   uint32_t mn = 0, pending = 0, my_claims = 0, hbits = 0, hmask = 0, hval = 0;
+  // one k-mer (key, weight kw; v: it is this pass's) into the k-mer table: the home slot and the one behind it in one read, a first
+  // sighting with a free home slot claimed in line, everything else through the wavefront's miss queue
+  auto to_table = [&](uint64_t key, uint32_t kw, bool v) {
+    const uint32_t h = sk_slot_hash(key);
+    const uint32_t slot = sk_slot_of(h, (uint32_t)T::CAP2);
+    v = v && (h & hmask) == hval;   // (the pass's share of the hash space: mask 0 / value 0 takes everything; the slot comes from the high bits)
+    if (SPECIAL && v && key == kEmptyKey) { s_ctl[C_SPS] = 1; atomicAdd(&s_ctl[C_SPC], kw); v = false; }   // (k = 32 only)
+    const uint64_t c0 = __atomic_load_n(&s_tk[slot], __ATOMIC_RELAXED), c1 = __atomic_load_n(&s_tk[slot + 1u], __ATOMIC_RELAXED);
+    bool hit0 = v && c0 == key;
+    const bool hit1 = v && c1 == key;
+    bool won = false;
+    if (v && c0 == kEmptyKey) {   // first sighting with a free home slot: claimed here, in line (most first sightings are)
+      const unsigned long long old = atomicCAS((unsigned long long *)&s_tk[slot], (unsigned long long)kEmptyKey, (unsigned long long)key);
+      won = old == kEmptyKey;
+      hit0 = won || old == key;
+    }
+    my_claims += won ? 1u : 0u;   // (per lane; the wavefront adds them up once per batch)
+    if (hit0 || hit1) atomicAdd(&s_tv[slot + (hit0 ? 0u : 1u)], kw);
+    const bool miss = v && !hit0 && !hit1;
+    const unsigned long long mm = __ballot(miss);
+    if (mm) {
+      const uint32_t pos = mn + __builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0u));
+      if (miss) { mq[pos] = key; mw[pos] = kw; }
+      mn += (uint32_t)__popcll(mm);
+      if (mn >= (uint32_t)kWave) {
+        pending = sk_probe_insert(tkeys, tvals, tdist, tovf, (const lds_u64_t *)mq, (const lds_u32_t *)mw, mn - kWave, kWave, (uint32_t)T::CAP2,
+                                  (uint32_t)T::S2 - 1u, (uint32_t)T::LIMIT2, pending);
+        mn -= kWave;
+      }
+    }
+  };
+  // all k-mers of a batch of records (w0, w1, weight wt; n = 0: none) into the k-mer table. A lane takes TWO neighbouring k-mers
+  // of one record (a unit): finding the record of a unit (marks, running maximum, six words over the lane crossbar) is paid once
+  // for both, and the second k-mer is the first one moved on by a base -- a handful of instructions instead of a second cut
+  // and reverse complement. (One k-mer per lane: 80 issue slots per k-mer, with this 60; the phase is bound by issue.)
   auto expand = [&](uint64_t w0, uint64_t w1, uint32_t wt, uint32_t n) {
-    const uint32_t inc = wave_inclusive_sum_dpp(n);
-    const uint32_t pre = inc - n;
+    const uint32_t nu = (n + 1u) >> 1;
+    const uint32_t inc = wave_inclusive_sum_dpp(nu);
+    const uint32_t pre = inc - nu;
     const uint32_t total = __builtin_amdgcn_readlane(inc, kWave - 1);
     if (total == 0u) return;   // uniform
-    if (n) wown[pre] = (uint8_t)(lane + 1u);
+    if (nu) wown[pre] = (uint8_t)(lane + 1u);
     uint32_t carry = 0;   // record (+ 1) the previous step ended in
+    const uint32_t top_sh = kb - 34u;   // where the last base of a k-mer starts in its high word (k >= 17)
     for (uint32_t g0 = 0; g0 < total; g0 += kWave) {
       const uint32_t g = g0 + lane;
       const bool act = g < total;
@@ -1076,15 +1116,16 @@ __global__ __launch_bounds__(KMI_SK_NT) void sk_reduce_kernel(const uint64_t *__
       o = o > carry ? o : carry;
       carry = __builtin_amdgcn_readlane(o, kWave - 1);
       const int rl = (int)((o ? o - 1u : 0u) << 2);   // byte address of the lane that holds the record
-      const uint32_t j = g - (uint32_t)__builtin_amdgcn_ds_bpermute(rl, (int)pre);
+      const uint32_t j = 2u * (g - (uint32_t)__builtin_amdgcn_ds_bpermute(rl, (int)pre));
       const uint32_t a0 = (uint32_t)__builtin_amdgcn_ds_bpermute(rl, (int)(uint32_t)w0), a1 = (uint32_t)__builtin_amdgcn_ds_bpermute(rl, (int)(uint32_t)(w0 >> 32));
       const uint32_t a2 = (uint32_t)__builtin_amdgcn_ds_bpermute(rl, (int)(uint32_t)w1), a3 = (uint32_t)__builtin_amdgcn_ds_bpermute(rl, (int)(uint32_t)(w1 >> 32));
       const uint32_t kw = (uint32_t)__builtin_amdgcn_ds_bpermute(rl, (int)wt);
+      const bool two = act && j + 1u <= ((a3 >> (kRecNShift - 32)) & 31u);   // k-mer j + 1 exists (the record holds n - 1)
       // k-mer j of the record: 2 k bits from bit 2 j of its 128 (j <= 31: the window starts in word 0 or 1). All of it on 32-bit
       // registers -- funnel shifts (v_alignbit) and single-word bit tricks: the 64-bit shifts this replaces issue at a quarter
-      // of the rate, and the kernel is bound by instruction issue.
+      // of the rate.
       const bool w1sel = j >= 16u;
-      const uint32_t bit = (2u * j) & 31u;
+      const uint32_t bit = (2u * j) & 31u;   // (j is even: at most 28, so k-mer j + 1 starts in the same word)
       const uint32_t b0 = w1sel ? a1 : a0, b1 = w1sel ? a2 : a1, b2 = w1sel ? a3 : a2;
       const uint32_t rc_lo = __builtin_amdgcn_alignbit(b1, b0, bit);
       const uint32_t rc_hi = __builtin_amdgcn_alignbit(b2, b1, bit) & kmask_hi;   // (k >= 17: the low word is all k-mer)
@@ -1094,38 +1135,18 @@ __global__ __launch_bounds__(KMI_SK_NT) void sk_reduce_kernel(const uint64_t *__
       const uint32_t s_hi = ~(((r_hi >> 1) & 0x55555555u) | ((r_hi << 1) & 0xAAAAAAAAu));
       const uint32_t s_lo = ~(((r_lo >> 1) & 0x55555555u) | ((r_lo << 1) & 0xAAAAAAAAu));
       const uint32_t fw_lo = __builtin_amdgcn_alignbit(s_hi, s_lo, pad), fw_hi = s_hi >> pad;
+      // k-mer j + 1: the window one base on; its forward strand is the first one's moved up by a base, the complement of the
+      // window's new last base below it
+      const uint32_t rc2_lo = __builtin_amdgcn_alignbit(b1, b0, bit + 2u);
+      const uint32_t rc2_hi = __builtin_amdgcn_alignbit(b2, b1, bit + 2u) & kmask_hi;
+      const uint32_t fw2_lo = (fw_lo << 2) | (((rc2_hi >> top_sh) & 3u) ^ 3u);
+      const uint32_t fw2_hi = __builtin_amdgcn_alignbit(fw_hi, fw_lo, 30u) & kmask_hi;
       const uint64_t rc = (uint64_t)rc_lo | ((uint64_t)rc_hi << 32), fw = (uint64_t)fw_lo | ((uint64_t)fw_hi << 32);
-      const uint64_t key = CANON ? (fw < rc ? fw : rc) : fw;
-      // table fast path: the home slot and the one behind it in one read
-      const uint32_t h = sk_slot_hash(key);
-      const uint32_t slot = sk_slot_of(h, (uint32_t)T::CAP2);
-      bool v = act && (h & hmask) == hval;   // (the pass's share of the hash space: mask 0 / value 0 takes everything; the slot comes from the high bits)
-      if (SPECIAL && v && key == kEmptyKey) { s_ctl[C_SPS] = 1; atomicAdd(&s_ctl[C_SPC], kw); v = false; }   // (k = 32 only)
-      const uint64_t c0 = __atomic_load_n(&s_tk[slot], __ATOMIC_RELAXED), c1 = __atomic_load_n(&s_tk[slot + 1u], __ATOMIC_RELAXED);
-      bool hit0 = v && c0 == key;
-      const bool hit1 = v && c1 == key;
-      bool won = false;
-      if (v && c0 == kEmptyKey) {   // first sighting with a free home slot: claimed here, in line (most first sightings are)
-        const unsigned long long old = atomicCAS((unsigned long long *)&s_tk[slot], (unsigned long long)kEmptyKey, (unsigned long long)key);
-        won = old == kEmptyKey;
-        hit0 = won || old == key;
-      }
-      my_claims += won ? 1u : 0u;   // (per lane; the wavefront adds them up once per batch)
-      if (hit0 || hit1) atomicAdd(&s_tv[slot + (hit0 ? 0u : 1u)], kw);
-      const bool miss = v && !hit0 && !hit1;
-      const unsigned long long mm = __ballot(miss);
-      if (mm) {
-        const uint32_t pos = mn + __builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0u));
-        if (miss) { mq[pos] = key; mw[pos] = kw; }
-        mn += (uint32_t)__popcll(mm);
-        if (mn >= (uint32_t)kWave) {
-          pending = sk_probe_insert(tkeys, tvals, tdist, tovf, (const lds_u64_t *)mq, (const lds_u32_t *)mw, mn - kWave, kWave, (uint32_t)T::CAP2,
-                                    (uint32_t)T::S2 - 1u, (uint32_t)T::LIMIT2, pending);
-          mn -= kWave;
-        }
-      }
+      const uint64_t rc2 = (uint64_t)rc2_lo | ((uint64_t)rc2_hi << 32), fw2 = (uint64_t)fw2_lo | ((uint64_t)fw2_hi << 32);
+      to_table(CANON ? (fw < rc ? fw : rc) : fw, kw, act);
+      to_table(CANON ? (fw2 < rc2 ? fw2 : rc2) : fw2, kw, two);
     }
-    if (n) wown[pre] = 0;   // the marks go back to zero for the next batch
+    if (nu) wown[pre] = 0;   // the marks go back to zero for the next batch
     // fill level: this batch's in-line claims go to the shared counter (one scan + one LDS add per batch of records)
     const uint32_t batch_claims = __builtin_amdgcn_readlane(wave_inclusive_sum_dpp(my_claims), kWave - 1);
     my_claims = 0;
