@@ -282,6 +282,9 @@ kmi_status kmi_index_count_dev(kmi_index *idx, const uint64_t *queries_dev, size
                                uint64_t *out_keys_dev, uint64_t *out_values_dev, uint64_t *n_out);
 kmi_status kmi_index_find_dev(kmi_index *idx, const uint64_t *queries_dev, size_t nq,
                               uint64_t *out_keys_dev, uint64_t *out_values_dev, uint64_t *n_out);
+/* the number of entries kmi_index_find_dev would return for these queries (a multimap returns every entry of a queried key:
+ * size the result buffers with this instead of the index's entry count) */
+kmi_status kmi_index_find_hits_dev(kmi_index *idx, const uint64_t *queries_dev, size_t nq, uint64_t *n_hits);
 
 /* ---- multimap maps: PositionIndex / PositionQualityIndex (kmer_index.hpp:402-406) over
  * ::dsc::unordered_multimap (distributed_unordered_map.hpp:1466-1515). An index created with

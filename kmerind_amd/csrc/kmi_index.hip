@@ -3354,7 +3354,7 @@ static kmi_status index_insert_pairs(kmi_index *idx, const uint64_t *recs_dev, s
 // queries: results compacted into out_keys_dev / out_vals_dev (max(1, val_words) u64 per result)
 template <int NW, int BITS, int VW>
 static kmi_status query_vw(kmi_index *idx, int mode, const uint64_t *q_dev, size_t nq, uint64_t *out_keys_dev, uint64_t *out_vals_dev,
-                           uint64_t out_capacity, uint64_t *n_out, uint64_t **auto_keys = nullptr, uint64_t **auto_vals = nullptr) {
+                           uint64_t out_capacity, uint64_t *n_out, uint64_t **auto_keys = nullptr, uint64_t **auto_vals = nullptr, bool hits_only = false) {
   kmi_ctx *ctx = idx->ctx;
   constexpr int OW = VW ? VW : 1;
   if (n_out) *n_out = 0;
@@ -3380,6 +3380,7 @@ static kmi_status query_vw(kmi_index *idx, int mode, const uint64_t *q_dev, size
     uint64_t total = 0;
     KMI_TRY(read_total(ctx, 5, &total));
     if (n_out) *n_out = total;
+    if (hits_only) return KMI_OK;   // (the caller sizes its buffers with this and asks again)
     if (auto_keys) {   // the caller takes the results where this function puts them
       KMI_TRY(ws_get(ctx, WS_OUTPUT, (total ? total : 1) * NW * sizeof(uint64_t), &p)); out_keys_dev = (uint64_t *)p;
       KMI_TRY(ws_get(ctx, WS_OUTPUT2, (total ? total : 1) * OW * sizeof(uint64_t), &p)); out_vals_dev = (uint64_t *)p;
@@ -3455,16 +3456,17 @@ static kmi_status query_vw(kmi_index *idx, int mode, const uint64_t *q_dev, size
 
 template <int NW, int BITS>
 static kmi_status query_impl(kmi_index *idx, int mode, const uint64_t *q_dev, size_t nq, uint64_t *out_keys_dev, uint64_t *out_vals_dev,
-                             uint64_t out_capacity, uint64_t *n_out, uint64_t **auto_keys, uint64_t **auto_vals) {
+                             uint64_t out_capacity, uint64_t *n_out, uint64_t **auto_keys, uint64_t **auto_vals, bool hits_only) {
   if (idx->val_words == 0) return query_vw<NW, BITS, 0>(idx, mode, q_dev, nq, out_keys_dev, out_vals_dev, out_capacity, n_out);
-  if (idx->val_words == 1) return query_vw<NW, BITS, 1>(idx, mode, q_dev, nq, out_keys_dev, out_vals_dev, out_capacity, n_out, auto_keys, auto_vals);
-  return query_vw<NW, BITS, 2>(idx, mode, q_dev, nq, out_keys_dev, out_vals_dev, out_capacity, n_out, auto_keys, auto_vals);
+  if (idx->val_words == 1) return query_vw<NW, BITS, 1>(idx, mode, q_dev, nq, out_keys_dev, out_vals_dev, out_capacity, n_out, auto_keys, auto_vals, hits_only);
+  return query_vw<NW, BITS, 2>(idx, mode, q_dev, nq, out_keys_dev, out_vals_dev, out_capacity, n_out, auto_keys, auto_vals, hits_only);
 }
 
 static kmi_status index_query(kmi_index *idx, int mode, const uint64_t *q_dev, size_t nq, uint64_t *out_keys_dev, uint64_t *out_vals_dev,
-                              uint64_t out_capacity, uint64_t *n_out, uint64_t **auto_keys = nullptr, uint64_t **auto_vals = nullptr) {
+                              uint64_t out_capacity, uint64_t *n_out, uint64_t **auto_keys = nullptr, uint64_t **auto_vals = nullptr, bool hits_only = false) {
   // auto_keys / auto_vals (find of a multimap): the results are left in workspace buffers sized to the hits, returned here
-  KMI_DISPATCH(idx->shape, query_impl, idx, mode, q_dev, nq, out_keys_dev, out_vals_dev, out_capacity, n_out, auto_keys, auto_vals);
+  // hits_only (find of a multimap): *n_out = the entries the find would return, nothing written
+  KMI_DISPATCH(idx->shape, query_impl, idx, mode, q_dev, nq, out_keys_dev, out_vals_dev, out_capacity, n_out, auto_keys, auto_vals, hits_only);
 }
 
 // results of a multimap find are bounded by the entries, everything else by the queries
@@ -4040,6 +4042,13 @@ kmi_status kmi_index_find_dev(kmi_index *idx, const uint64_t *queries_dev, size_
   return index_query(idx, Q_FIND, queries_dev, nq, out_keys_dev, out_values_dev, query_result_bound(idx, Q_FIND, nq), n_out);
 }
 
+kmi_status kmi_index_find_hits_dev(kmi_index *idx, const uint64_t *queries_dev, size_t nq, uint64_t *n_hits) {
+  if (!idx || !n_hits) return KMI_ERR_INVALID;
+  KMI_HIP(idx->ctx, hipSetDevice(idx->ctx->device));
+  if (idx->val_words == 0) { *n_hits = nq; return KMI_OK; }   // (a counting map answers every distinct query key once at most)
+  return index_query(idx, Q_FIND, queries_dev, nq, nullptr, nullptr, 0, n_hits, nullptr, nullptr, true);
+}
+
 // ---- multimap (PositionIndex / PositionQualityIndex) entry points
 kmi_status kmi_index_insert_tuples_dev(kmi_index *idx, const uint64_t *records_dev, size_t n) {
   if (!idx) return KMI_ERR_INVALID;
@@ -4490,19 +4499,28 @@ static kmi_status query_dist_host(kmi_index *idx, kmi_comm *comm, int mode, cons
     if (n_erased) *n_erased = n;
     return KMI_OK;
   }
-  // every source rank's keys are answered on their own (a key two ranks ask about is answered to both)
-  uint64_t bound = 0;
-  for (int s = 0; s < p; ++s) bound += query_result_bound(idx, mode, (size_t)rc[s]);
+  // every source rank's keys are answered on their own (a key two ranks ask about is answered to both). The answers of a multimap
+  // find are sized by a count of the hits per source (a bound by the entries of the index, per source, is p times the index)
+  const bool mm_find = idx->val_words > 0 && mode == Q_FIND;
+  std::vector<uint64_t> back(p, 0), got;
+  uint64_t bound = 0, off = 0;
+  for (int s = 0; s < p; ++s) {
+    if (mm_find) {
+      if (rc[s]) KMI_TRY(index_query(idx, mode, (const uint64_t *)d_q + off * nw, (size_t)rc[s], nullptr, nullptr, 0, &back[s], nullptr, nullptr, true));
+      bound += back[s];
+    } else bound += query_result_bound(idx, mode, (size_t)rc[s]);
+    off += rc[s];
+  }
   void *d_rk, *d_rv;
   KMI_TRY(ws_get(ctx, WS_DIST_C, (bound + 8) * kb, &d_rk));
   KMI_TRY(ws_get(ctx, WS_DIST_D, (bound + 8) * vb, &d_rv));
-  std::vector<uint64_t> back(p, 0), got;
-  uint64_t off = 0, pos = 0;
+  uint64_t pos = 0;
+  off = 0;
   for (int s = 0; s < p; ++s) {
     uint64_t n = 0;
-    if (rc[s])
+    if (rc[s] && (!mm_find || back[s]))
       KMI_TRY(index_query(idx, mode, (const uint64_t *)d_q + off * nw, (size_t)rc[s], (uint64_t *)d_rk + pos * nw, (uint64_t *)d_rv + pos * ow,
-                          query_result_bound(idx, mode, (size_t)rc[s]), &n));
+                          mm_find ? back[s] : query_result_bound(idx, mode, (size_t)rc[s]), &n));
     back[s] = n; off += rc[s]; pos += n;
   }
   void *d_ak, *d_av;

@@ -369,7 +369,13 @@ class DistributedCountIndex:
             n = recv_counts[src]
             seg = mine[off:off + n]
             off += n
-            cap = n if not (self.value_words and mode == "find") else max(1, self.index.local_size())
+            cap = n
+            if self.value_words and mode == "find" and n:
+                # a multimap returns every entry of a queried key: the buffers are sized by a count of the hits (the entry count of
+                # the index per source rank would be `world` times the index)
+                hits = C.c_uint64(0)
+                self.ctx.check(L.lib.kmi_index_find_hits_dev(self.index.h, C.c_void_p(seg.data_ptr()), n, C.byref(hits)))
+                cap = int(hits.value)
             k = torch.empty((max(cap, 1), self.n_words), dtype=torch.int64, device=dev)
             v = torch.empty((max(cap, 1), vw), dtype=torch.int64, device=dev)
             n_out = C.c_uint64(0)
