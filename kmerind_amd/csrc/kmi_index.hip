@@ -2935,10 +2935,7 @@ static kmi_status sk_back_end(kmi_index *idx, const uint64_t *rec_a, uint64_t R,
     hipLaunchKernelGGL((sk_reduce_kernel<CANON, OWN, SPECIAL>), dim3(wgs), dim3(KMI_SK_NT), 0, ctx->stream, (const uint64_t *)rec_b,        \
                        (const uint64_t *)fine_off, k, (const uint64_t *)kmer_off, tmp_keys, tmp_vals, out_cnt, ctx->d_flags, queue, (uint32_t)kNumFine, \
                        ctx->sk_level_hint, lp, ctx->sk_inv_dup, (const uint64_t *)d_region, (const uint32_t *)d_cap, (const uint32_t *)fine_cnt)
-    if (ctx->sk_dbg == 1 && canonical && nmax <= 21u && !slack)   // A/B: the one-workgroup-per-bucket form
-      hipLaunchKernelGGL((sk_reduce_v1_kernel<true, 64 * 21>), dim3(kNumFine), dim3(KMI_SK_NT), 0, ctx->stream, (const uint64_t *)rec_b,
-                         (const uint64_t *)fine_off, k, (const uint64_t *)kmer_off, tmp_keys, tmp_vals, out_cnt, ctx->d_flags, 0, ctx->sk_level_hint, lp, ctx->sk_inv_dup);
-    else if (k == 32u) { if (canonical) KMI_SK_REDUCE(true, 64 * 21, true); else KMI_SK_REDUCE(false, 64 * 21, true); }   // (a 32-mer can equal the empty marker)
+    if (k == 32u) { if (canonical) KMI_SK_REDUCE(true, 64 * 21, true); else KMI_SK_REDUCE(false, 64 * 21, true); }   // (a 32-mer can equal the empty marker)
     else if (nmax <= 21u) { if (canonical) KMI_SK_REDUCE(true, 64 * 21, false); else KMI_SK_REDUCE(false, 64 * 21, false); }
     else if (nmax <= 24u) { if (canonical) KMI_SK_REDUCE(true, 64 * 24, false); else KMI_SK_REDUCE(false, 64 * 24, false); }
     else { if (canonical) KMI_SK_REDUCE(true, 64 * 32, false); else KMI_SK_REDUCE(false, 64 * 32, false); }

@@ -99,7 +99,7 @@ struct kmi_ctx {
   uint32_t front_waves = 0;      // resident wavefronts of the front kernel (ranges of a large input); 0: not asked yet
   uint64_t front_min_range = 64ull << 10;   // smallest byte range of a wavefront (KMI_FRONT_MIN_RANGE: tests shrink it)
   uint64_t sparse_min = 1ull << 26;   // output slots from which a super-k-mer build leaves its index in the sparse form (KMI_SPARSE_MIN)
-  int sk_dbg = 0;                // KMI_SK_DBG: timing experiments of sk_reduce (results are wrong when set)
+  int sk_dbg = 0;                // KMI_SK_DBG=7 (test knob): the super-k-mer front end reports a capacity as exceeded
   bool fa_part_set = false;      // kmi_ctx_set_fasta_partition
   kmi_fasta_partition fa_part{};
 };

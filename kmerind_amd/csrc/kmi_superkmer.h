@@ -630,12 +630,13 @@ __global__ __launch_bounds__(kPartThreads) void sk_recv_hist_kernel(const uint64
 // set: a record that finds no room in it (table full, long probe walk, an unlucky race between a claim and its second
 // word) is expanded directly with weight 1, so nothing depends on T1 holding every distinct record exactly once.
 //
-// Expansion (both for T1's slots and for direct records): the k-mers of a batch of 64 records (one per lane) are numbered
-// 0 .. T - 1 through the records' prefix sums, and lane l of step t takes k-mer g = 64 t + l WHATEVER record it belongs
-// to, so every lane works in every step although the records hold 1 to 20 k-mers: the record of g is the last one that
-// starts at or before g -- the records mark their first k-mer in a byte array (own[P_r] = r + 1), the step reads own[g]
-// and takes a running maximum over the lanes (DPP scan) -- its words come over the lane crossbar (ds_bpermute), and its
-// k-mer j = g - P_r is cut out of the record's 128 bits; the forward strand comes from one reverse complement.
+// Expansion (both for T1's slots and for the overflow list): the k-mers of a batch of 64 records (one per lane) are taken two
+// at a time -- a UNIT is two neighbouring k-mers of one record -- and the units are numbered 0 .. T - 1 through the records'
+// prefix sums; lane l of step t takes unit g = 64 t + l WHATEVER record it belongs to, so every lane works in every step
+// although the records hold 1 to 21 k-mers: the record of g is the last one that starts at or before g -- the records mark
+// their first unit in a byte array (own[P_r] = r + 1), the step reads own[g] and takes a running maximum over the lanes (DPP
+// scan) -- its words come over the lane crossbar (ds_bpermute), its first k-mer j = 2 (g - P_r) is cut out of the record's
+// 128 bits with one reverse complement for the forward strand, and its second k-mer is the first one moved on by a base.
 #ifndef KMI_SK_H1
 #define KMI_SK_H1 1536   // (2048 left the k-mer table 1000 slots less: config 2 the same, 0.2 - 0.3 ms slower where buckets hold 3800 keys)
 #endif
@@ -652,18 +653,6 @@ __global__ __launch_bounds__(kPartThreads) void sk_recv_hist_kernel(const uint64
 #define KMI_SK_LDS_KB 160   // ... and the LDS it may take. Measured on config 2 (3.55 ms): 512 threads / 80 KB, two workgroups per CU, H1 768 or
                             // 512: 3.60 - 3.63 (same wavefronts per CU, twice the passes); 1024 threads / 80 KB, H1 512 / 256: 7.0 / 8.2 ms
 #endif
-template <int OWN_>
-struct SkTabCfg {
-  static constexpr int NT = KMI_SK_NT, NWAVES = NT / kWave;
-  static constexpr int OWN = OWN_;                       // k-mers of a batch of 64 records at most (64 x nmax)
-  static constexpr int H1 = KMI_SK_H1;                   // record table home slots
-  static constexpr int S1 = H1 + 64;                     // record table slots (20 bytes each)
-  static constexpr int L1 = H1 * 3 / 4;                  // records it takes before the rest goes direct
-  static constexpr int FIXED = NWAVES * (OWN + kMissQ * 12) + S1 * 20 + 2560;   // + control words and the pass stack
-  static constexpr int S2 = ((KMI_SK_LDS_KB * 1024 - FIXED) / 12) / 64 * 64;   // k-mer table slots (12 bytes each)
-  static constexpr int CAP2 = S2 - 64, LIMIT2 = CAP2 * KMI_SK_FILL / 100;   // LIMIT2: distinct keys of a pass before the bucket is split
-};
-
 // slot hash of the k-mer table (private to this kernel: two multiplies instead of the placement hash's three)
 __device__ __forceinline__ uint32_t sk_slot_hash(uint64_t key) {
   uint32_t h = ((uint32_t)key ^ ((uint32_t)(key >> 32) * 0x85EBCA6Bu)) * 0x9E3779B1u;
@@ -709,282 +698,9 @@ __device__ __attribute__((noinline)) uint32_t sk_probe_insert(lds_u64_t *tkeys, 
   return add;
 }
 
-template <bool CANON, int OWN_>
-__global__ __launch_bounds__(KMI_SK_NT) void sk_reduce_v1_kernel(const uint64_t *__restrict__ recs, const uint64_t *__restrict__ rec_off, uint32_t k,
-                                                        const uint64_t *__restrict__ kmer_off /* k-mers before every bucket */,
-                                                        uint64_t *__restrict__ tmp_keys, uint32_t *__restrict__ tmp_vals,
-                                                        uint32_t *__restrict__ out_cnt, uint32_t *__restrict__ flags, int dbg,
-                                                        uint32_t start_bits /* filter bits every bucket starts with (the level most buckets of the last build ended at) */,
-                                                        uint32_t lp /* records received in a build over 2^lp ranks: their low max(0, lp - 2) sub-bucket bits are zero */,
-                                                        float inv_dup /* distinct k-mers per k-mer occurrence of the context's last build (0: none yet) */) {
-  using T = SkTabCfg<OWN_>;
-  constexpr int NWAVES = T::NWAVES;
-  constexpr uint64_t W1_INIT = ~0ull;   // never a record's second word (its top three bits are zero)
-  __shared__ uint64_t s_tk[T::S2];
-  __shared__ uint32_t s_tv[T::S2];
-  __shared__ ulonglong2 s_r[T::S1];    // T1: the record (x claimed by compare-and-swap, y stored behind it) and its multiplicity
-  __shared__ uint32_t s_rc[T::S1];
-  __shared__ uint64_t s_missq[NWAVES * kMissQ];
-  __shared__ uint32_t s_missw[NWAVES * kMissQ];
-  __shared__ uint8_t s_own[NWAVES * T::OWN];
-  __shared__ uint32_t s_ctl[12];       // 0 distinct, 1 overflow, 2 special count, 3 special set, 4 emit counter, 5 stack size, 8 records in T1
-  __shared__ uint32_t s_stack[320];    // pending passes: filter bits | value << 8 (up to 256 to start with + the splits)
-  const uint32_t b = blockIdx.x;
-  const uint64_t rb = rec_off[b], re = rec_off[b + 1];
-  if (rb == re) { if (threadIdx.x == 0) out_cnt[b] = 0; return; }
-  const uint64_t tmp0 = kmer_off[b];   // the bucket's output range: as many slots as it has k-mers (same contract as bucket_reduce_kernel)
-  const uint32_t lane = lane_id(), wv = wave_id();
-  lds_u64_t *const tkeys = (lds_u64_t *)s_tk;
-  lds_u32_t *const tvals = (lds_u32_t *)s_tv;
-  lds_u32_t *const tdist = (lds_u32_t *)&s_ctl[0];
-  lds_u32_t *const tovf = (lds_u32_t *)&s_ctl[1];
-  uint64_t *const mq = s_missq + wv * kMissQ;
-  uint32_t *const mw = s_missw + wv * kMissQ;
-  uint8_t *const wown = s_own + wv * T::OWN;
-  const uint32_t kb = 2u * k;
-  const uint64_t kmask = low_mask64(kb);
-  const bool full64 = kb == 64u;   // only then can a key equal the empty marker
-  const KShape shape = make_shape(k, 2);
-  for (uint32_t i = threadIdx.x; i < (uint32_t)(NWAVES * T::OWN / 4); i += T::NT) reinterpret_cast<uint32_t *>(s_own)[i] = 0;
-  if (threadIdx.x == 0) {
-    uint32_t hb = start_bits > 8u ? 8u : start_bits;
-    if (inv_dup > 0.f) {
-      // A bucket that will not fit fails late (the table fills up near the end of the attempt), so a lost attempt costs a whole
-      // pass -- and the buckets that overflow are the large ones. The bucket's k-mer count is known; with the duplication of the
-      // last build it says how many distinct k-mers to expect, and a bucket expected above 88 % of what a pass takes starts one
-      // level down (two passes over half the records each cost about as much as one that fits).
-      const float pred = (float)(kmer_off[b + 1] - tmp0) * inv_dup;
-      float room = 0.88f * (float)T::LIMIT2 * (float)(1u << hb);
-      while (hb < 8u && pred > room) { ++hb; room *= 2.f; }
-    }
-    for (uint32_t v = 0; v < (1u << hb); ++v) s_stack[v] = hb | (v << 8);
-    s_ctl[5] = 1u << hb; s_ctl[4] = 0; s_ctl[9] = hb;
-  }
-  lds_barrier();
-  const uint32_t n_rec = (uint32_t)(re - rb);
-  const ulonglong2 *const src = reinterpret_cast<const ulonglong2 *>(recs) + rb;
-  while (true) {
-    const uint32_t sp = s_ctl[5];
-    if (sp == 0) break;                       // uniform
-    const uint32_t pass = s_stack[sp - 1];
-    const uint32_t fbits = pass & 0xffu, fval = pass >> 8;
-    lds_barrier();                            // everyone has read the stack
-    // a bucket that needs four passes or more holds little duplication: counting identical records first would only cost
-    // ... unless the context's last build says otherwise: with its duplication known, the record table is used whenever less
-    // than every second k-mer was distinct (a large input at sequencing coverage goes through in many passes AND repeats its
-    // records) and never for an input without duplication (a genome: nothing to count twice)
-    const bool use_t1 = inv_dup > 0.f ? inv_dup <= KMI_SK_T1_DUP : fbits < 2u;
-    for (uint32_t i = threadIdx.x; i < (uint32_t)T::S2; i += T::NT) { s_tk[i] = kEmptyKey; s_tv[i] = 0; }
-    if (use_t1) for (uint32_t i = threadIdx.x; i < (uint32_t)T::S1; i += T::NT) { s_r[i] = make_ulonglong2(kEmptyKey, W1_INIT); s_rc[i] = 0; }
-    if (threadIdx.x == 0) { s_ctl[0] = 0; s_ctl[1] = 0; s_ctl[2] = 0; s_ctl[3] = 0; s_ctl[5] = sp - 1; s_ctl[8] = 0; }
-    lds_barrier();
-    // the first three filter bits (two in a build over 8 ranks) are the records' sub-bucket bits (whole records are skipped), the
-    // others come from the key's hash
-    const uint32_t dead = lp > 2u ? lp - 2u : 0u, rmax = 3u - dead;   // (sub-bucket bits without information: two spare hash bits refill the rest)
-    const uint32_t rbits = fbits < rmax ? fbits : rmax, rmask = ((1u << rbits) - 1u) << dead, rval = (fval & ((1u << rbits) - 1u)) << dead;
-    const uint32_t hbits = fbits - rbits, hmask = (1u << hbits) - 1u, hval = fval >> rbits;
-    uint32_t mn = 0;   // (key, weight) pairs waiting in the miss queue (uniform)
-    uint32_t pending = 0;   // slots this wavefront claimed in line since it last reported to the shared fill counter (uniform)
-    uint32_t my_claims = 0; // ... and this lane in the batch being expanded
-    // all k-mers of the batch's records (w0, w1, weight wt; n = 0: none) into the k-mer table
-    auto expand = [&](uint64_t w0, uint64_t w1, uint32_t wt, uint32_t n) {
-      const uint32_t inc = wave_inclusive_sum_dpp(n);
-      const uint32_t pre = inc - n;
-      const uint32_t total = __builtin_amdgcn_readlane(inc, kWave - 1);
-      if (total == 0u) return;   // uniform
-      if (n) wown[pre] = (uint8_t)(lane + 1u);
-      uint32_t carry = 0;   // record (+ 1) the previous step ended in
-      for (uint32_t g0 = 0; g0 < total; g0 += kWave) {
-        const uint32_t g = g0 + lane;
-        const bool act = g < total;
-        uint32_t o = act ? (uint32_t)wown[g] : 0u;
-        o = wave_inclusive_max_dpp(o);
-        o = o > carry ? o : carry;
-        carry = __builtin_amdgcn_readlane(o, kWave - 1);
-        const int rl = (int)((o ? o - 1u : 0u) << 2);   // byte address of the lane that holds the record
-        const uint32_t j = g - (uint32_t)__builtin_amdgcn_ds_bpermute(rl, (int)pre);
-        const uint32_t a0 = (uint32_t)__builtin_amdgcn_ds_bpermute(rl, (int)(uint32_t)w0), a1 = (uint32_t)__builtin_amdgcn_ds_bpermute(rl, (int)(uint32_t)(w0 >> 32));
-        const uint32_t a2 = (uint32_t)__builtin_amdgcn_ds_bpermute(rl, (int)(uint32_t)w1), a3 = (uint32_t)__builtin_amdgcn_ds_bpermute(rl, (int)(uint32_t)(w1 >> 32));
-        const uint32_t kw = (uint32_t)__builtin_amdgcn_ds_bpermute(rl, (int)wt);
-        const uint64_t x = (uint64_t)a0 | ((uint64_t)a1 << 32), y = (uint64_t)a2 | ((uint64_t)a3 << 32);
-        // k-mer j of the record: 2 k bits from bit 2 j of its 128
-        const uint32_t sh = 2u * j;   // 0 .. 62
-        uint64_t rc = sh ? ((x >> sh) | (y << (64u - sh))) : x;
-        rc &= kmask;
-        uint64_t key;
-        {
-          const uint64_t r1[1] = {rc};
-          uint64_t f1[1];
-          fwd_from_rc<1, 2>(r1, f1, shape);
-          key = CANON ? (f1[0] < rc ? f1[0] : rc) : f1[0];
-        }
-        if (dbg == 1) { if (key == 12345ull) s_ctl[2] = 1; continue; }   // experiment: expansion only
-        // table fast path: the home slot and the one behind it in one read
-        const uint32_t h = sk_slot_hash(key);
-        const uint32_t slot = sk_slot_of(h, (uint32_t)T::CAP2);
-        bool v = act;
-        if (hbits) v = v && (h & hmask) == hval;   // (the slot comes from the high bits)
-        if (full64 && v && key == kEmptyKey) { s_ctl[3] = 1; atomicAdd(&s_ctl[2], kw); v = false; }
-        const uint64_t c0 = __atomic_load_n(&s_tk[slot], __ATOMIC_RELAXED), c1 = __atomic_load_n(&s_tk[slot + 1u], __ATOMIC_RELAXED);
-        bool hit0 = v && c0 == key;
-        const bool hit1 = v && c1 == key;
-        bool won = false;
-        if (v && c0 == kEmptyKey) {   // first sighting with a free home slot: claimed here, in line (most first sightings are)
-          const unsigned long long old = atomicCAS((unsigned long long *)&s_tk[slot], (unsigned long long)kEmptyKey, (unsigned long long)key);
-          won = old == kEmptyKey;
-          hit0 = won || old == key;
-        }
-        my_claims += won ? 1u : 0u;   // (per lane; the wavefront adds them up once per batch)
-        if (hit0 || hit1) atomicAdd(&s_tv[slot + (hit0 ? 0u : 1u)], kw);
-        const bool miss = v && !hit0 && !hit1 && dbg != 2;
-        const unsigned long long mm = __ballot(miss);
-        if (mm) {
-          const uint32_t pos = mn + __builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0u));
-          if (miss) { mq[pos] = key; mw[pos] = kw; }
-          mn += (uint32_t)__popcll(mm);
-          if (mn >= (uint32_t)kWave) {
-            pending = sk_probe_insert(tkeys, tvals, tdist, tovf, (const lds_u64_t *)mq, (const lds_u32_t *)mw, mn - kWave, kWave, (uint32_t)T::CAP2,
-                                      (uint32_t)T::S2 - 1u, (uint32_t)T::LIMIT2, pending);
-            mn -= kWave;
-          }
-        }
-      }
-      if (n) wown[pre] = 0;   // the marks go back to zero for the next batch
-      // fill level: this batch's in-line claims go to the shared counter (one scan + one LDS add per batch of records)
-      const uint32_t batch_claims = __builtin_amdgcn_readlane(wave_inclusive_sum_dpp(my_claims), kWave - 1);
-      my_claims = 0;
-      pending += batch_claims;
-      if (pending >= 32u) {   // uniform
-        if (lane == 0 && atomicAdd(&s_ctl[0], pending) + pending >= (uint32_t)T::LIMIT2) s_ctl[1] = 1;
-        pending = 0;
-      }
-    };
-    // ---- phase A: identical records are counted, what T1 does not take is expanded directly
-    {
-      const uint32_t share = (n_rec + NWAVES - 1) / NWAVES;
-      const uint32_t r_lo = wv * share < n_rec ? wv * share : n_rec;
-      const uint32_t r_hi = r_lo + share < n_rec ? r_lo + share : n_rec;
-      ulonglong2 nxt = make_ulonglong2(0, 0);
-      if (r_lo + lane < r_hi) nxt = src[r_lo + lane];
-      for (uint32_t r0 = r_lo; r0 < r_hi; r0 += kWave) {
-        if (__atomic_load_n(&s_ctl[1], __ATOMIC_RELAXED)) break;   // this pass is lost already
-        const ulonglong2 rec = nxt;
-        const bool have = r0 + lane < r_hi;
-        if (r0 + kWave + lane < r_hi) nxt = src[r0 + kWave + lane];   // in flight while this batch is worked on
-        uint32_t n = have ? ((uint32_t)(rec.y >> kRecNShift) & 31u) + 1u : 0u;
-        if ((rec_hash18(rec.y) & rmask) != rval) n = 0;
-        if (dbg == 3) { if (rec.x == 12345ull) s_ctl[2] = 1; continue; }
-        bool direct = n != 0u;   // still to be placed
-        if (direct && use_t1 && rec.x != kEmptyKey && dbg != 4) {
-          // four consecutive slots in one go (independent reads): the first that holds this record takes the count, else the
-          // first empty one is claimed; a record that finds neither in two such windows is expanded directly
-          uint32_t h = ((uint32_t)rec.x ^ (uint32_t)(rec.x >> 32)) * 0x9E3779B1u ^ ((uint32_t)rec.y ^ (uint32_t)(rec.y >> 32)) * 0x85EBCA6Bu;
-          h ^= h >> 15;
-          const uint32_t s0 = ((h >> 16) * (uint32_t)T::H1) >> 16;   // H1 home slots (+ 64 of padding)
-          for (uint32_t s = s0; direct && s < s0 + 8u; s += 4u) {   // (a second window of four for the few that find the first one taken)
-            ulonglong2 e[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) e[i] = s_r[s + i];
-            int hit = -1, free_ = -1;
-#pragma unroll
-            for (int i = 3; i >= 0; --i) {
-              const bool same = e[i].x == rec.x && e[i].y == rec.y, empty = e[i].x == kEmptyKey;
-              if (same) { hit = i; free_ = -1; } else if (empty) { free_ = i; hit = -1; }   // (the earliest of either kind wins)
-            }
-            if (hit >= 0) { atomicAdd(&s_rc[s + hit], 1u); direct = false; }
-            else if (free_ >= 0) {
-              if (__atomic_load_n(&s_ctl[8], __ATOMIC_RELAXED) >= (uint32_t)T::L1) break;   // full enough: the rest goes direct
-              const unsigned long long old = atomicCAS((unsigned long long *)&s_r[s + free_].x, (unsigned long long)kEmptyKey, (unsigned long long)rec.x);
-              if (old == kEmptyKey) {   // claimed
-                __atomic_store_n(&s_r[s + free_].y, rec.y, __ATOMIC_RELAXED);
-                atomicAdd(&s_rc[s + free_], 1u);
-                atomicAdd(&s_ctl[8], 1u);
-                direct = false;
-              } else if (old == rec.x && __atomic_load_n(&s_r[s + free_].y, __ATOMIC_RELAXED) == rec.y) {
-                // lost the slot to a copy of the same record that arrived in the same step (copies travel together: the usual
-                // way to lose): its second word is there by now, so this copy is counted with it
-                atomicAdd(&s_rc[s + free_], 1u);
-                direct = false;
-              } else break;   // lost it to another record: direct
-            }
-          }
-        }
-        if (dbg == 6) {   // experiment: how many records go direct
-          const unsigned long long dm = __ballot(direct), nm = __ballot(n != 0u);
-          if (lane == 0) { atomicAdd(&flags[10], (uint32_t)__popcll(nm)); atomicAdd(&flags[11], (uint32_t)__popcll(dm)); }
-        }
-        if (__any(direct)) expand(rec.x, rec.y, 1u, direct ? n : 0u);
-      }
-    }
-    lds_barrier();   // T1 complete
-    if (dbg == 6 && threadIdx.x == 0) atomicAdd(&flags[12], s_ctl[8]);
-    // ---- phase B: every distinct record once, with its multiplicity
-    for (uint32_t s0 = wv * kWave; use_t1 && s0 < (uint32_t)T::S1; s0 += T::NT) {
-      if (__atomic_load_n(&s_ctl[1], __ATOMIC_RELAXED)) break;
-      const uint32_t s = s0 + lane;
-      const ulonglong2 ent = s_r[s];
-      const uint64_t w0 = ent.x, w1 = ent.y;
-      const uint32_t wt = s_rc[s];
-      const uint32_t n = (w0 != kEmptyKey && wt) ? ((uint32_t)(w1 >> kRecNShift) & 31u) + 1u : 0u;
-      if (__any(n != 0u)) expand(w0, w1, wt, n);
-    }
-    if (mn) {
-      pending = sk_probe_insert(tkeys, tvals, tdist, tovf, (const lds_u64_t *)mq, (const lds_u32_t *)mw, 0u, mn, (uint32_t)T::CAP2, (uint32_t)T::S2 - 1u,
-                                (uint32_t)T::LIMIT2, pending);
-      mn = 0;
-    }
-    if (pending && lane == 0 && atomicAdd(&s_ctl[0], pending) + pending >= (uint32_t)T::LIMIT2) s_ctl[1] = 1;
-    lds_barrier();
-    if (s_ctl[1]) {
-      // Overflow: this pass is split. How far is a property of the input (distinct k-mers per bucket), about the same for most
-      // buckets: flags[16 + L] counts the buckets that finished with L filter bits, and the split goes straight to the level
-      // most of them ended at (2^L passes, no further lost ones) instead of one bit at a time. Buckets that never overflow --
-      // all of them at sequencing coverage -- never look at these words; only the pass structure depends on them.
-      if (threadIdx.x == 0) {
-        if (fbits >= 18u) atomicOr(&flags[2], 1u);   // 3 record bits + 15 hash bits: 2^18 tables did not hold the bucket
-        else {
-          uint32_t best = 0, best_n = 0;
-          for (uint32_t l = 0; l <= 8u; ++l) {
-            const uint32_t c = __hip_atomic_load(&flags[16 + l], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (c > best_n) { best_n = c; best = l; }
-          }
-          uint32_t target = best > fbits ? best : fbits + 1u;
-          if (target > fbits + 6u) target = fbits + 6u;     // (64 children at most at a time: the stack holds 320)
-          uint32_t spn = s_ctl[5];
-          for (uint32_t v = 0; v < (1u << (target - fbits)); ++v) s_stack[spn++] = target | ((fval | (v << fbits)) << 8);
-          s_ctl[5] = spn;
-          if (target > s_ctl[9]) s_ctl[9] = target;
-        }
-      }
-      lds_barrier();
-      continue;
-    }
-    // emit behind what the earlier passes left (disjoint key sets)
-    {
-      uint32_t *s_out = &s_ctl[4];
-      for (uint32_t s = threadIdx.x; s < (uint32_t)((T::S2 + kWave - 1) / kWave * kWave); s += T::NT) {
-        const bool used = s < (uint32_t)T::S2 && s_tk[s] != kEmptyKey;
-        const uint32_t pos = wave_alloc(s_out, used);
-        if (used) { tmp_keys[tmp0 + pos] = s_tk[s]; tmp_vals[tmp0 + pos] = s_tv[s]; }
-      }
-      lds_barrier();
-      if (threadIdx.x == 0 && s_ctl[3]) {
-        const uint32_t pos = atomicAdd(s_out, 1u);
-        tmp_keys[tmp0 + pos] = kEmptyKey;
-        tmp_vals[tmp0 + pos] = s_ctl[2];
-      }
-    }
-    lds_barrier();
-  }
-  if (threadIdx.x == 0) {
-    out_cnt[b] = s_ctl[4];
-    if (s_ctl[9] || start_bits) atomicAdd(&flags[16 + (s_ctl[9] > 8u ? 8u : s_ctl[9])], 1u);   // (level 0 is only recorded when someone could be misled)
-  }
-}
 
-
-// ---- sk_reduce (persistent form) -------------------------------------------------------------------------------------
-// The same two tables and the same expansion, organised so that nothing is paid per bucket that can be paid per workgroup:
+// ---- the kernel ------------------------------------------------------------------------------------------------------
+// The two tables and the expansion described above, organised so that nothing is paid per bucket that can be paid per workgroup:
 //  * one workgroup per CU stays resident and pulls fine buckets from a queue (one atomic per bucket, issued a bucket ahead);
 //  * the tables are cleared ONCE; afterwards the sweep that emits a pass's (k-mer, count) pairs leaves every slot it read
 //    empty, and phase B empties every record slot it expands -- a pass starts on clean tables without a clear of its own;
