@@ -154,6 +154,7 @@ def main():
     combine = multi and dist_mode in ("combine", "superkmer")     # both run through kmerind_amd.dist.DistributedCountIndex
     nch = 1
     kmi_comm = None
+    transport_note = None
     use_kmi = multi and dist_mode == "superkmer" and args.transport == "kmi" and args.backend == "nccl"
     if use_kmi:
         # the product's own exchange: an ncclUniqueId from rank 0 goes round once (torch.distributed is only the messenger
@@ -168,9 +169,21 @@ def main():
             dist.broadcast(uid_dev, src=0)
             uid = uid_dev.cpu()
         kmi_comm = C.c_void_p()
-        ctx.check(L.lib.kmi_comm_create(ctx.h, (C.c_char * 128).from_buffer_copy(bytes(uid.numpy().tobytes())), C.byref(kmi_comm)))
-        nch = int(os.environ.get("KMI_DIST_CHUNKS", "4"))
-        combine = False
+        st = L.lib.kmi_comm_create(ctx.h, (C.c_char * 128).from_buffer_copy(bytes(uid.numpy().tobytes())), C.byref(kmi_comm))
+        # every rank must take the same transport: if the library's communicator could not be created on ANY rank, all of them say so
+        # loudly and take the torch.distributed transport (the line's config.transport then reads "torch (...)": never silently)
+        ok = torch.tensor([1 if st == 0 else 0], dtype=torch.int32, device=dev)
+        if world > 1:
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0:
+            sys.stderr.write("bench.py rank %d: kmi_comm_create failed on a rank (status here: %d, %s); all ranks fall back to "
+                             "--transport torch\n" % (rank, st, (L.lib.kmi_last_error(ctx.h) or b"").decode() if st else "ok"))
+            if st == 0:
+                L.lib.kmi_comm_destroy(kmi_comm)
+            kmi_comm, use_kmi, transport_note = None, False, "torch (kmi_comm_create failed on a rank: see stderr)"
+        else:
+            nch = int(os.environ.get("KMI_DIST_CHUNKS", "4"))
+            combine = False
     if combine:
         # N > 1, combine-first (kmerind_amd.dist.DistributedCountIndex): local count index of the rank's reads (the one-rank
         # pipeline), split by KeyToRank, all_to_all_single of (k-mer, count) pairs + per-bucket counts, merge.
@@ -344,7 +357,7 @@ def main():
                           ("RCCL" if args.backend == "nccl" else "gloo (rehearsal)")},
                "roofline": roofline}
         if multi:
-            out["config"].update({"dist_mode": dist_mode, "transport": "kmi" if use_kmi else "torch", "backend": backend_name, "rccl_ranks": group_ranks if args.backend == "nccl" else 0,
+            out["config"].update({"dist_mode": dist_mode, "transport": "kmi" if use_kmi else (transport_note or "torch"), "backend": backend_name, "rccl_ranks": group_ranks if args.backend == "nccl" else 0,
                                   "group_ranks": group_ranks, "peer_bucket_max_over_mean": peer_ratio,
                                   "exchange_checksum": "verified on the first exchange" if verified else "not run"})
         if not multi and not args.no_extra:
