@@ -2855,7 +2855,7 @@ static kmi_status sk_back_end(kmi_index *idx, const uint64_t *rec_a, uint64_t R,
   // with exact = true
   constexpr int NW = 1;
   kmi_ctx *ctx = idx->ctx;
-  const bool slack = !exact && ctx->sk_slack && (!idx->has_data || idx->n_entries == 0) && R >= 4096;
+  const bool slack = !exact && ctx->sk_slack && (!idx->has_data || idx->n_entries == 0) && R >= 4096;   // (room_x64 below: <= 6.1 x the records)
   const uint32_t k = idx->shape.k;
   const bool canonical = idx->cfg.strand != KMI_STRAND_SINGLE;
   void *p;
@@ -2869,14 +2869,19 @@ static kmi_status sk_back_end(kmi_index *idx, const uint64_t *rec_a, uint64_t R,
   uint64_t h_end[kNumCoarse];
   for (int c = 0; c < kNumCoarse; ++c) h_end[c] = h_base[c] + h_cnt[c];
   KMI_HIP(ctx, hipMemcpyAsync(cend, h_end, sizeof(h_end), hipMemcpyHostToDevice, ctx->stream));   // (h_end outlives the copy: this function synchronises before it returns)
-  // the slack layout: every fine bucket of coarse bucket c has room for 13/8 of c's mean share + 64 (minimizer buckets are uneven: 1.45 x the mean was the largest of config 2), in steps of 8 records; more over ranks
+  // the slack layout: every fine bucket of coarse bucket c has room for room_x64 / 64 of c's mean share + 64, in steps of 8 records
+  // How uneven minimizer buckets are depends on the minimizer length m = k - W + 1 (few canonical m-mers: a few of them take most
+  // minima) and on the rank bits of a build over ranks (a rank's buckets stand for fewer minimizer classes of a larger genome).
+  // Fullest fine bucket / its coarse bucket's mean, measured on synthetic reads: m = 11: 1.9 - 2.6, m = 12: 1.63, m >= 13: 1.36 -
+  // 1.54; for m = 13 and lp = 0 / 1 / 2 / 3: 1.45 / < 1.6 / 1.79 / 2.27.
+  const uint32_t m_len = idx->shape.k - (uint32_t)W + 1u;
+  const uint64_t room_m = m_len <= 11u ? 26u : (m_len == 12u ? 18u : 14u);            // in eighths of the mean
+  static const uint64_t room_lp[4] = {8, 10, 12, 15};                                   // in eighths
+  const uint64_t room_x64 = room_m * room_lp[lp < 4u ? lp : 3u];
   uint64_t h_region[kNumCoarse], total_b = 0;
   uint32_t h_cap[kNumCoarse];
   for (int c = 0; c < kNumCoarse; ++c) {
-    // (a rank of a build over 2^lp ranks keeps buckets that stand for fewer minimizer classes of a larger genome, which are more
-    // uneven: the fullest fine bucket was 1.45 / < 1.6 / 1.79 / 2.27 x its coarse bucket's mean for lp 0 / 1 / 2 / 3)
-    static const uint64_t room_x8[4] = {13, 16, 20, 24};
-    const uint64_t cap = ((h_cnt[c] * room_x8[lp < 4u ? lp : 3u] / 8 + kSubPerCoarse - 1) / kSubPerCoarse + 64 + 7) / 8 * 8;
+    const uint64_t cap = ((h_cnt[c] * room_x64 / 64 + kSubPerCoarse - 1) / kSubPerCoarse + 64 + 7) / 8 * 8;
     h_cap[c] = (uint32_t)cap; h_region[c] = total_b; total_b += cap * kSubPerCoarse;
   }
   KMI_TRY(ws_get(ctx, WS_KEYS_B, ((slack ? total_b : R) + 64) * 16, &p)); uint64_t *rec_b = (uint64_t *)p;
@@ -2974,8 +2979,8 @@ static kmi_status sk_back_end(kmi_index *idx, const uint64_t *rec_a, uint64_t R,
     // the index IS the reduce output: entries grouped by minimizer bucket. Queries partition their keys by the same function
     // (fine15_of_key); whatever needs the placement-hash layout converts the entries once (ensure_layout).
     KMI_TRY((adopt_tmp<NW>(idx, tmp_keys, tmp_vals, kmer_off, nullptr, out_cnt, false, n, true)));
-    if (slack && *reinterpret_cast<const uint32_t *>(ctx->h_totals + 14)) {
-      if (getenv("KMI_SLACK_DEBUG")) {   // by how much the fullest fine bucket missed its room
+    if (slack && (*reinterpret_cast<const uint32_t *>(ctx->h_totals + 14) || getenv("KMI_SLACK_DEBUG"))) {
+      if (getenv("KMI_SLACK_DEBUG")) {   // how full the fullest fine bucket was
         std::vector<uint32_t> fc(kNumFine);
         (void)hipMemcpy(fc.data(), fine_cnt, sizeof(uint32_t) * kNumFine, hipMemcpyDeviceToHost);
         double worst = 0; uint32_t over = 0;
@@ -2987,6 +2992,8 @@ static kmi_status sk_back_end(kmi_index *idx, const uint64_t *rec_a, uint64_t R,
         fprintf(stderr, "fine buckets with room: %u of %d outgrew it, the fullest holds %.3f x its coarse bucket's mean (lp %u, %llu records)\n", over,
                 (int)kNumFine, worst, lp, (unsigned long long)R);
       }
+    }
+    if (slack && *reinterpret_cast<const uint32_t *>(ctx->h_totals + 14)) {
       KMI_TRY(kmi_index_clear(idx));
       return sk_back_end<W>(idx, rec_a, R, h_cnt, h_base, wg_off, n, lp, true);
     }

@@ -682,7 +682,7 @@ def test_sparse_index_after_superkmer_build(monkeypatch, k, strand):
 
 
 def test_fine_buckets_with_room_and_the_counted_fallback(ctx):
-    """A fresh index's build gives every fine bucket of the super-k-mer records room (13/8 of its coarse bucket's mean share + 64)
+    """A fresh index's build gives every fine bucket of the super-k-mer records room (1.75 - 3.25 x its coarse bucket's mean share, by minimizer length, + 64)
     instead of counting the records first; input whose minimizers crowd a few buckets outgrows the room, which voids that attempt
     and repeats the back end with counted, exact offsets (sk_fine_count). Both outcomes are the oracle's map."""
     import kmerind_amd as K
