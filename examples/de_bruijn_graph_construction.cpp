@@ -51,6 +51,13 @@ static void testDeBruijnGraph(const kmerind::comm &comm, const std::string &file
   for (auto &r : all) self += (uint64_t)r.second.get_edge_frequency(0) + (uint64_t)r.second.get_edge_frequency(7);
   std::printf("%s nodes %zu size %zu found %zu keysum %llu edgesum %llu nbrsum %llu a_out_t_in %llu\n", tag, idx.local_size(), idx.size(),
               results.size(), (unsigned long long)keys, (unsigned long long)edges, (unsigned long long)nbr, (unsigned long long)self);
+  // erase (the node map inherits it from the distributed map): every third query key's node leaves
+  std::vector<KmerType> victims;
+  for (size_t i = 0; i < query.size(); i += 3) victims.push_back(query[i]);
+  const size_t erased = idx.erase(victims);
+  uint64_t left = 0;
+  for (auto &r : idx.to_vector()) left += word_sum(r.first) % 1000003ull;
+  std::printf("%s erased %zu left %zu keysum %llu\n", tag, erased, idx.size(), (unsigned long long)left);
 }
 
 int main(int argc, char **argv) {

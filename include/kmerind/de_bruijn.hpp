@@ -157,6 +157,10 @@ class NodeIndex {
       if (comm.unique_id.size() != KMI_COMM_ID_BYTES)
         throw std::invalid_argument("comm.size() > 1 needs comm.unique_id (kmerind::comm::make_unique_id() on rank 0, handed to every rank)");
       ::kmerind::check(ctx, kmi_comm_create(ctx, comm.unique_id.data(), &rccl));
+    } else {
+      // KMI_FORCE_DIST=1: a one-rank program goes through the code of size() > 1 (a one-rank RCCL communicator), as Index does
+      const char *fd = std::getenv("KMI_FORCE_DIST");
+      if (fd && std::atoi(fd) != 0) ::kmerind::check(ctx, kmi_comm_create(ctx, nullptr, &rccl));
     }
   }
   NodeIndex(const NodeIndex &) = delete;
@@ -172,7 +176,7 @@ class NodeIndex {
   void build_mmap(const std::string &filename) { build_file<SeqParser, SeqIterType>(filename); }
   // size() > 1: every rank hands over ITS record-aligned partition of the FASTQ file (collective)
   void build_partition(const uint8_t *bytes, size_t n_bytes) {
-    if (comm.size() == 1) { ::kmerind::check(ctx, kmi_dbg_build_host(g, bytes, n_bytes)); return; }
+    if (!rccl) { ::kmerind::check(ctx, kmi_dbg_build_host(g, bytes, n_bytes)); return; }
     ::kmerind::check(ctx, kmi_dbg_build_dist_host(g, rccl, bytes, n_bytes));
   }
 
@@ -210,6 +214,14 @@ class NodeIndex {
     return out;
   }
 
+  // erase (inherited from the distributed map, distributed_unordered_map.hpp:719-779): the nodes of these k-mers leave the map
+  size_t erase(std::vector<KmerType> &query) {
+    uint64_t n = 0;
+    if (rccl) ::kmerind::check(ctx, kmi_dbg_erase_dist_host(g, rccl, ::bliss::index::kmer::detail::words_of(query), query.size(), &n));   // collective
+    else ::kmerind::check(ctx, kmi_dbg_erase_host(g, ::bliss::index::kmer::detail::words_of(query), query.size(), &n));
+    return (size_t)n;
+  }
+
   size_t local_size() const { uint64_t n = 0; ::kmerind::check(ctx, kmi_dbg_local_size(g, &n)); return (size_t)n; }
   size_t size() const {
     uint64_t n = 0;
@@ -242,7 +254,14 @@ class NodeIndex {
     static_assert(SeqParser<const unsigned char *>::KMI == KMI_FMT_FASTQ, "the de Bruijn engine reads FASTQ (test_de_bruijn_graph_construction.cpp:65-69)");
     static_assert(SeqIterType<const unsigned char *, SeqParser>::KMI == KMI_SEQ_ALL, "the de Bruijn engine reads every record (SequencesIterator)");
     if (::bliss::index::kmer::detail::format_of(filename) != KMI_FMT_FASTQ) throw std::invalid_argument("input filename extension is not supported.");
-    if (comm.size() > 1) throw std::invalid_argument("build_* with size() > 1: hand every rank its record-aligned partition (build_partition)");
+    if (rccl) {   // every rank reads its byte range plus look-ahead; the partition is cut at record starts on the device
+      for (uint64_t look = 1ull << 20;; look *= 8) {
+        ::bliss::index::kmer::detail::FileRange r = ::bliss::index::kmer::detail::read_file_range(filename, comm.rank(), comm.size(), look);
+        int need_more = 0;
+        ::kmerind::check(ctx, kmi_dbg_build_range_dist_host(g, rccl, r.bytes.data(), r.bytes.size(), r.offset, r.nominal, r.reaches_eof ? 1 : 0, &need_more));
+        if (!need_more) return;
+      }
+    }
     std::vector<uint8_t> bytes = ::bliss::index::kmer::detail::read_whole_file(filename);
     ::kmerind::check(ctx, kmi_dbg_build_host(g, bytes.data(), bytes.size()));
   }

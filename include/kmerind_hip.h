@@ -473,6 +473,14 @@ kmi_status kmi_dbg_export_host(kmi_dbg *g, uint64_t *keys, uint32_t *counts9, si
  * KeyToRank gives their canonical k-mer (the distribute step of insert, de_bruijn_nodes_distributed.hpp:243-250) */
 kmi_status kmi_dbg_build_dist_host(kmi_dbg *g, kmi_comm *comm, const uint8_t *bytes, size_t n_bytes);
 kmi_status kmi_dbg_find_dist_host(kmi_dbg *g, kmi_comm *comm, const uint64_t *queries, size_t nq, kmi_results *out); /* find(): collective */
+/* the engine's build_posix / build_mmap(filename) with comm.size() > 1: as kmi_index_build_range_dist_host (FASTQ byte range +
+ * look-ahead, cut at record starts on the device, then the collective build) */
+kmi_status kmi_dbg_build_range_dist_host(kmi_dbg *g, kmi_comm *comm, const uint8_t *bytes, size_t n_bytes, uint64_t buffer_offset,
+                                         uint64_t nominal_bytes, int reaches_eof, int *need_more);
+/* nodes.erase(keys): the nodes of the query keys (either strand) leave the map with their edge counts (the erase the node map
+ * inherits from the distributed map, distributed_unordered_map.hpp:719-779); *n_erased = nodes removed (here / on this rank) */
+kmi_status kmi_dbg_erase_host(kmi_dbg *g, const uint64_t *queries, size_t nq, uint64_t *n_erased);
+kmi_status kmi_dbg_erase_dist_host(kmi_dbg *g, kmi_comm *comm, const uint64_t *queries, size_t nq, uint64_t *n_erased_local);
 kmi_status kmi_dbg_count_dist_host(kmi_dbg *g, kmi_comm *comm, const uint64_t *queries, size_t nq, kmi_results *out); /* count(): collective */
 kmi_status kmi_dbg_size_dist(kmi_dbg *g, kmi_comm *comm, uint64_t *n);                                /* size() */
 

@@ -420,6 +420,13 @@ class DeBruijnNodes:
     def clear(self):
         self.ctx.check(lib.kmi_dbg_clear(self.h))
 
+    def erase(self, q):
+        """erase(keys): the nodes of these k-mers (either strand) leave the map; returns how many did"""
+        q = _u64(q, self.n_words)
+        n = C.c_uint64()
+        self.ctx.check(lib.kmi_dbg_erase_host(self.h, q.ctypes.data_as(C.c_void_p), q.shape[0], C.byref(n)))
+        return n.value
+
     def local_size(self):
         n = C.c_uint64()
         self.ctx.check(lib.kmi_dbg_local_size(self.h, C.byref(n)))

@@ -288,6 +288,45 @@ static kmi_status dbg_insert_impl(kmi_dbg *g, const uint64_t *recs_dev, size_t n
 }
 static kmi_status dbg_insert(kmi_dbg *g, const uint64_t *recs_dev, size_t n) { KMI_DISPATCH(g->shape, dbg_insert_impl, g, recs_dev, n); }
 
+// nodes.erase(keys) (the erase of the distributed map the node map derives from, distributed_unordered_map.hpp:719-779): the nodes of
+// the query keys leave with their edge counts. The key array of the node index is compacted by the index's own erase; the
+// counters of the nodes that stay are carried over to the new order the way an insert carries the old nodes' counters.
+template <int NW, int BITS>
+static kmi_status dbg_erase_impl(kmi_dbg *g, const uint64_t *q_dev, size_t nq, uint64_t *n_erased) {
+  kmi_ctx *ctx = g->ctx;
+  kmi_index *idx = g->nodes;
+  if (n_erased) *n_erased = 0;
+  const uint64_t n_old = idx->has_data ? idx->n_entries : 0;
+  if (n_old == 0 || nq == 0) return KMI_OK;
+  KMI_TRY(ensure_dense(idx));
+  void *p;
+  const size_t kb = (size_t)n_old * NW * sizeof(uint64_t);
+  KMI_TRY(ws_get(ctx, WS_DBG_OLD, kb + kOffBytes + 64, &p));
+  uint64_t *old_keys = (uint64_t *)p, *old_off = (uint64_t *)((uint8_t *)p + ((kb + 15) & ~(size_t)15));
+  KMI_HIP(ctx, hipMemcpyAsync(old_keys, idx->keys, kb, hipMemcpyDeviceToDevice, ctx->stream));
+  KMI_HIP(ctx, hipMemcpyAsync(old_off, idx->bucket_off, kOffBytes, hipMemcpyDeviceToDevice, ctx->stream));
+  uint64_t gone = 0;
+  KMI_TRY(index_query(idx, Q_ERASE, q_dev, nq, nullptr, nullptr, 0, &gone));
+  if (n_erased) *n_erased = gone;
+  if (gone == 0) return KMI_OK;
+  const size_t eb = (size_t)(idx->n_entries ? idx->n_entries : 1) * 8 * sizeof(uint32_t);
+  uint32_t *ne = nullptr;
+  if (pool_alloc(ctx, (void **)&ne, eb) != hipSuccess) return set_err(ctx, KMI_ERR_NOMEM, "hipMalloc failed for the edge counts");
+  KMI_HIP(ctx, hipMemsetAsync(ne, 0, eb, ctx->stream));
+  if (idx->n_entries) {
+    ProfScope ps(ctx, "dbg_accumulate", n_old);
+    hipLaunchKernelGGL((dbg_accumulate_kernel<NW>), dim3(kNumFine), dim3(DbgCfg<NW>::NT), 0, ctx->stream, (const uint64_t *)idx->keys,
+                       (const uint64_t *)idx->bucket_off, (const uint64_t *)nullptr, (const uint64_t *)nullptr, (const uint64_t *)old_keys,
+                       (const uint32_t *)g->edges, (const uint64_t *)old_off, ne);
+  }
+  KMI_HIP(ctx, hipGetLastError());
+  KMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (g->edges) pool_free(ctx, g->edges, g->edges_bytes);
+  g->edges = ne; g->edges_bytes = eb;
+  return KMI_OK;
+}
+static kmi_status dbg_erase(kmi_dbg *g, const uint64_t *q_dev, size_t nq, uint64_t *n_erased) { KMI_DISPATCH(g->shape, dbg_erase_impl, g, q_dev, nq, n_erased); }
+
 // find(): keys of the hits + kDbgValueWords value words each
 static kmi_status dbg_find(kmi_dbg *g, const uint64_t *q_dev, size_t nq, uint64_t *out_keys_dev, uint64_t *out_vals_dev, uint64_t *n_out) {
   kmi_ctx *ctx = g->ctx;

@@ -4818,6 +4818,66 @@ kmi_status kmi_dbg_find_dist_host(kmi_dbg *g, kmi_comm *comm, const uint64_t *qu
   return KMI_OK;
 }
 
+// build_posix / build_mmap(filename) of the engine with comm.size() > 1: the rank passes the bytes it read of the FASTQ file (its
+// nominal range + look-ahead), the partition is cut at record starts on the device (kmi_index_build_range_dist_host's rule)
+kmi_status kmi_dbg_build_range_dist_host(kmi_dbg *g, kmi_comm *comm, const uint8_t *bytes, size_t n_bytes, uint64_t buffer_offset,
+                                         uint64_t nominal_bytes, int reaches_eof, int *need_more) {
+  if (!g || !need_more) return KMI_ERR_INVALID;
+  KMI_TRY(dist_check(g->nodes, comm));
+  kmi_ctx *ctx = g->ctx;
+  *need_more = 0;
+  if (n_bytes && !bytes) return set_err(ctx, KMI_ERR_INVALID, "null buffer");
+  if (nominal_bytes > n_bytes) nominal_bytes = n_bytes;
+  uint64_t pos[2] = {0, nominal_bytes}, cut[2] = {0, n_bytes};
+  if (n_bytes) {
+    KMI_HIP(ctx, hipSetDevice(ctx->device));
+    void *d_bytes;
+    KMI_TRY(ws_get(ctx, WS_INPUT2, n_bytes + 64, &d_bytes));
+    KMI_HIP(ctx, hipMemcpyAsync(d_bytes, bytes, n_bytes, hipMemcpyHostToDevice, ctx->stream));
+    KMI_TRY(kmi_fastq_find_records_dev(ctx, (const uint8_t *)d_bytes, n_bytes, buffer_offset == 0, pos, 2, cut));
+    if (nominal_bytes >= n_bytes) cut[1] = n_bytes;
+  }
+  if (cut[1] >= n_bytes && !reaches_eof && n_bytes) { *need_more = 1; return KMI_OK; }
+  if (cut[0] >= n_bytes && !reaches_eof && n_bytes && buffer_offset != 0) { *need_more = 1; return KMI_OK; }
+  if (cut[1] < cut[0]) cut[1] = cut[0];
+  return kmi_dbg_build_dist_host(g, comm, bytes + cut[0], (size_t)(cut[1] - cut[0]));
+}
+
+// erase(): the nodes of the query keys (either strand) leave the map
+kmi_status kmi_dbg_erase_host(kmi_dbg *g, const uint64_t *queries, size_t nq, uint64_t *n_erased) {
+  if (!g) return KMI_ERR_INVALID;
+  kmi_ctx *ctx = g->ctx;
+  if (n_erased) *n_erased = 0;
+  if (nq == 0) return KMI_OK;
+  if (!queries) return set_err(ctx, KMI_ERR_INVALID, "null buffer");
+  KMI_HIP(ctx, hipSetDevice(ctx->device));
+  void *dq;
+  KMI_TRY(ws_get(ctx, WS_INPUT, (nq + 8) * g->shape.n_words * sizeof(uint64_t), &dq));
+  KMI_HIP(ctx, hipMemcpyAsync(dq, queries, nq * g->shape.n_words * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+  return dbg_erase(g, (const uint64_t *)dq, nq, n_erased);
+}
+
+// ... over ranks: the keys travel to the ranks that own them (*n_erased_local = nodes that left THIS rank's part)
+kmi_status kmi_dbg_erase_dist_host(kmi_dbg *g, kmi_comm *comm, const uint64_t *queries, size_t nq, uint64_t *n_erased_local) {
+  if (!g) return KMI_ERR_INVALID;
+  KMI_TRY(dist_check(g->nodes, comm));
+  kmi_ctx *ctx = g->ctx;
+  const int p = kmi::comm_size(comm);
+  if (p == 1 && !ctx->force_dist) return kmi_dbg_erase_host(g, queries, nq, n_erased_local);
+  if (n_erased_local) *n_erased_local = 0;
+  if (nq && !queries) return set_err(ctx, KMI_ERR_INVALID, "null buffer");
+  const size_t kb = g->shape.n_words * sizeof(uint64_t);
+  void *d_in, *d_send, *d_q;
+  KMI_TRY(ws_get(ctx, WS_INPUT, (nq + 8) * kb, &d_in));
+  KMI_TRY(ws_get(ctx, WS_DIST_A, (nq + 8) * kb, &d_send));
+  if (nq) KMI_HIP(ctx, hipMemcpyAsync(d_in, queries, nq * kb, hipMemcpyHostToDevice, ctx->stream));
+  std::vector<uint64_t> sc(p, 0), rc;
+  KMI_TRY(kmi_route_dev(ctx, &g->nodes->cfg, (const uint64_t *)d_in, nq, (uint32_t)p, (uint64_t *)d_send, sc.data()));
+  uint64_t total = 0;
+  KMI_TRY(dist_exchange(comm, d_send, sc.data(), kb, WS_DIST_B, &d_q, rc, &total));
+  return dbg_erase(g, (const uint64_t *)d_q, (size_t)total, n_erased_local);
+}
+
 // count() over ranks: the node map's keys live in a count index, whose collective answers 1 per node held
 kmi_status kmi_dbg_count_dist_host(kmi_dbg *g, kmi_comm *comm, const uint64_t *queries, size_t nq, kmi_results *out) {
   if (!g) return KMI_ERR_INVALID;

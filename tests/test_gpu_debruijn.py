@@ -91,6 +91,47 @@ def test_nodes_build_insert_find(ctx, k, alpha):
     assert g.local_size() == 0 and g.find(q)[0].shape[0] == 0
 
 
+@pytest.mark.parametrize("k,alpha", [(31, "DNA"), (21, "DNA5"), (63, "DNA")])
+def test_erase_nodes(ctx, k, alpha):
+    """nodes.erase(keys) (the erase the node map inherits from the distributed map, distributed_unordered_map.hpp:719-779): the
+    nodes of the query k-mers -- given under either strand, with repeats and absent keys among them -- leave the map; every other
+    node keeps its counts (the oracle's map without those keys), and later inserts build on what stayed."""
+    import kmerind_amd as K
+    s = orc.kspec(k, ALPHA[alpha])
+    cfg = K.make_config(k, alpha)
+    data = _with_n(bytes(K.synth_fastq(seed=3 * k, genome_len=5000, n_reads=1800)), k)
+    ok, oe = orc.dbg_parse(s, data)
+    om = orc.DbgMap(s)
+    om.insert(ok, oe)
+    g = K.DeBruijnNodes(ctx, cfg)
+    g.build(data)
+    keys, counts = om.export(canonical=True)
+    rng = np.random.default_rng(k)
+    pick = rng.permutation(keys.shape[0])[: keys.shape[0] // 3]
+    victims = keys[pick]
+    absent = orc.extract(s, bytes(K.synth_fastq(seed=91, genome_len=50000, n_reads=15)), orc.FASTQ)["kmers"]
+    q = np.concatenate([victims[::2], orc.revcomp(s, victims[1::2]), absent, victims[:25]])
+    gone = {tuple(r) for r in orc.canonical(s, q).tolist()} & {tuple(r) for r in keys.tolist()}
+    assert g.erase(q) == len(gone)
+    keep = np.array([tuple(r) not in gone for r in keys.tolist()])
+    assert g.local_size() == int(keep.sum())
+    assert (_nodes(*g.to_vector()) == _nodes(keys[keep], counts[keep])).all()
+    assert g.find(victims)[0].shape[0] == 0
+    assert g.erase(victims) == 0                                    # nothing left to erase
+    # the map goes on from what stayed: a second batch meets the surviving nodes' counts
+    data2 = _with_n(bytes(K.synth_fastq(seed=3 * k, genome_len=5000, n_reads=600, first_read=2500)), k + 1)
+    k2, e2 = orc.dbg_parse(s, data2)
+    om2 = orc.DbgMap(s)
+    survivors = np.array([tuple(r) not in gone for r in orc.canonical(s, ok).tolist()])
+    om2.insert(ok[survivors], oe[survivors])
+    om2.insert(k2, e2)
+    g.insert(k2, e2)
+    assert (_nodes(*g.to_vector()) == _nodes(*om2.export(canonical=True))).all()
+    g.erase(om2.export(canonical=True)[0])                          # erase everything
+    assert g.local_size() == 0
+    g.close()
+
+
 def test_exists_nodes(ctx):
     import kmerind_amd as K
     k = 21
@@ -230,9 +271,11 @@ def test_build_over_rccl_one_rank_self_exchange(monkeypatch):
         ctx.close()
 
 
-def test_reference_sample_program_through_the_facade():
+@pytest.mark.parametrize("force_dist", [False, True])
+def test_reference_sample_program_through_the_facade(force_dist):
     """examples/de_bruijn_graph_construction.cpp (the reference's sample with kmerind/de_bruijn.hpp): node counts and checksums
-    of find(), the neighbours node_utils derives, and the whole map"""
+    of find(), the neighbours node_utils derives, the whole map, and erase; with KMI_FORCE_DIST=1 every member takes the path of
+    size() > 1 (byte range + record-aligned cut on the device, the collectives over a one-rank RCCL communicator)"""
     import re
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -240,7 +283,8 @@ def test_reference_sample_program_through_the_facade():
     if not os.path.exists(exe):
         subprocess.check_call(["make", "-C", os.path.join(root, "examples"), "de_bruijn_graph_construction"])
     path = os.path.join(GOLD, "test.debruijn.small.fastq")
-    out = subprocess.run([exe, path], capture_output=True, text=True, timeout=300)
+    env = dict(os.environ, KMI_FORCE_DIST="1") if force_dist else None
+    out = subprocess.run([exe, path], capture_output=True, text=True, timeout=300, env=env)
     assert out.returncode == 0, out.stderr
     k = 21
     s = orc.kspec(k)
@@ -266,6 +310,11 @@ def test_reference_sample_program_through_the_facade():
         ak, ac = om.export(canonical=True)
         assert got == (om.size(), om.size(), fk.shape[0], int(fk[:, 0].sum()), int((fc[:, :8].astype(np.uint64) * w).sum()), nbr,
                        int(ac[:, 0].astype(np.uint64).sum() + ac[:, 7].astype(np.uint64).sum()))
+        m = re.search(tag + r" erased (\d+) left (\d+) keysum (\d+)", out.stdout)
+        assert m, out.stdout
+        gone = {tuple(r) for r in orc.canonical(s, q[::3]).tolist()} & {tuple(r) for r in ak.tolist()}
+        stay = [r for r in ak.tolist() if tuple(r) not in gone]
+        assert tuple(int(x) for x in m.groups()) == (len(gone), len(stay), sum(int(r[0]) % 1000003 for r in stay))
 
 
 def test_degenerate_inputs(ctx):
