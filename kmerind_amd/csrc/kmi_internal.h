@@ -122,8 +122,17 @@ inline hipError_t pool_alloc(kmi_ctx *ctx, void **p, size_t bytes) {
 inline void pool_free(kmi_ctx *ctx, void *p, size_t bytes) {
   if (!p) return;
   if (bytes == 0) bytes = 256;
-  constexpr size_t kMaxSpare = 6;
-  if (ctx->spare.size() >= kMaxSpare) { (void)hipFree(ctx->spare.front().p); ctx->spare.erase(ctx->spare.begin()); }
+  // a few blocks wait here for the next owner (an index's arrays, a workspace slot: ws_get). When the list is full the SMALLEST one
+  // goes -- offset / count tables of a few hundred KB come and go with every build and must not push out the multi-GB buffers a
+  // sparse index hands back (giving those to hipFree and asking hipMalloc for them again costs hundreds of milliseconds per build)
+  constexpr size_t kMaxSpare = 12;
+  if (ctx->spare.size() >= kMaxSpare) {
+    size_t m = 0;
+    for (size_t i = 1; i < ctx->spare.size(); ++i) if (ctx->spare[i].bytes < ctx->spare[m].bytes) m = i;
+    if (ctx->spare[m].bytes >= bytes) { (void)hipFree(p); return; }   // (the newcomer is the smallest)
+    (void)hipFree(ctx->spare[m].p);
+    ctx->spare.erase(ctx->spare.begin() + (long)m);
+  }
   ctx->spare.push_back({p, bytes});
 }
 
