@@ -251,9 +251,11 @@ class NodeIndex {
  private:
   template <template <typename> class SeqParser, template <typename, template <typename> class> class SeqIterType>
   void build_file(const std::string &filename) {
-    static_assert(SeqParser<const unsigned char *>::KMI == KMI_FMT_FASTQ, "the de Bruijn engine reads FASTQ (test_de_bruijn_graph_construction.cpp:65-69)");
     static_assert(SeqIterType<const unsigned char *, SeqParser>::KMI == KMI_SEQ_ALL, "the de Bruijn engine reads every record (SequencesIterator)");
-    if (::bliss::index::kmer::detail::format_of(filename) != KMI_FMT_FASTQ) throw std::invalid_argument("input filename extension is not supported.");
+    constexpr uint32_t fmt = SeqParser<const unsigned char *>::KMI;   // FASTQParser (the reference's sample) or FASTAParser
+    if (::bliss::index::kmer::detail::format_of(filename) != fmt) throw std::invalid_argument("input filename extension is not supported.");
+    ::kmerind::check(ctx, kmi_dbg_set_seq_format(g, fmt));
+    if (rccl && fmt != KMI_FMT_FASTQ) throw std::invalid_argument("the de Bruijn engine over ranks reads FASTQ partitions");
     if (rccl) {   // every rank reads its byte range plus look-ahead; the partition is cut at record starts on the device
       for (uint64_t look = 1ull << 20;; look *= 8) {
         ::bliss::index::kmer::detail::FileRange r = ::bliss::index::kmer::detail::read_file_range(filename, comm.rank(), comm.size(), look);

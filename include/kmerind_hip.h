@@ -446,6 +446,9 @@ typedef struct kmi_dbg kmi_dbg;
 enum { KMI_DBG_EDGE_COUNTS = 0, KMI_DBG_EDGE_EXISTS = 1 };
 #define KMI_DBG_VALUE_WORDS 5 /* a node value in kmi_results.values: uint32_t counts[9] + one uint32_t of padding */
 kmi_status kmi_dbg_create(kmi_ctx *ctx, const kmi_config *cfg, uint32_t node_kind, kmi_dbg **out);   /* NodeMap(comm) */
+/* the SeqParser template argument of the engine's build_* (KMI_FMT_FASTQ / KMI_FMT_FASTA): on FASTA a record's characters are its
+ * sequence lines without their EOLs, edges follow the characters across line ends and never across a header */
+kmi_status kmi_dbg_set_seq_format(kmi_dbg *g, uint32_t seq_format);
 kmi_status kmi_dbg_destroy(kmi_dbg *g);
 kmi_status kmi_dbg_clear(kmi_dbg *g);
 kmi_status kmi_dbg_local_size(kmi_dbg *g, uint64_t *n);                                               /* local_size() */

@@ -160,6 +160,7 @@ SIGNATURES = {
     "kmi_dbg_build_dist_host": (C.c_int, [_P, _P, _P, _sz]),
     "kmi_dbg_find_dist_host": (C.c_int, [_P, _P, _P, _sz, C.POINTER(Results)]),
     "kmi_dbg_build_range_dist_host": (C.c_int, [_P, _P, _P, _sz, _u64, _u64, C.c_int, C.POINTER(C.c_int)]),
+    "kmi_dbg_set_seq_format": (C.c_int, [_P, _u32]),
     "kmi_dbg_erase_host": (C.c_int, [_P, _P, _sz, C.POINTER(_u64)]),
     "kmi_dbg_erase_dist_host": (C.c_int, [_P, _P, _P, _sz, C.POINTER(_u64)]),
     "kmi_dbg_count_dist_host": (C.c_int, [_P, _P, _P, _sz, C.POINTER(Results)]),

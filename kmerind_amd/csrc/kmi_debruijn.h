@@ -233,7 +233,8 @@ static kmi_status dbg_parse(kmi_ctx *ctx, const kmi_config *cfg, const uint8_t *
   *recs_out = nullptr; *n_out = 0;
   if (n_bytes == 0) return KMI_OK;
   kmi_config c = *cfg;
-  c.index_kind = KMI_INDEX_POSITION; c.strand = KMI_STRAND_SINGLE; c.seq_format = KMI_FMT_FASTQ; c.seq_filter = KMI_SEQ_ALL; c.dist_trans = KMI_DIST_MODEL;
+  c.index_kind = KMI_INDEX_POSITION; c.strand = KMI_STRAND_SINGLE; c.seq_filter = KMI_SEQ_ALL; c.dist_trans = KMI_DIST_MODEL;
+  const bool fasta = c.seq_format == KMI_FMT_FASTA;
   KShape shape;
   if (!valid_config(&c, &shape)) return set_err(ctx, KMI_ERR_INVALID, "bad kmi_config");
   KMI_TRY(align_input(ctx, &bytes_dev, n_bytes));
@@ -245,6 +246,14 @@ static kmi_status dbg_parse(kmi_ctx *ctx, const kmi_config *cfg, const uint8_t *
   KMI_TRY(ws_get(ctx, WS_DBG_RECS, ((size_t)nt + 8) * rw * sizeof(uint64_t), &dr));
   // node form: the extract pass writes the smaller strand and 1 | edge << 32 itself; the parser's form (tuples as parsed) takes
   // the position ids and turns them into edge bytes in a second pass
+  if (fasta) {
+    // FASTA (the parser is generic over the sequence type, de_bruijn_construct_engine.hpp:108-158): the extract pass over the compacted
+    // character stream looks the neighbours up through the characters' file positions and leaves (k-mer as parsed, edge byte)
+    KMI_TRY(extract_run(ctx, &c, bytes_dev, n_bytes, 0, (uint64_t *)dr, nullptr, (size_t)nt, false, true, &nt, &ns, nullptr, rw, true));
+    if (node_form) KMI_TRY(dbg_edges(ctx, (uint64_t *)dr, (size_t)nt, nullptr, 0, shape, false, true));
+    *recs_out = (uint64_t *)dr; *n_out = nt;
+    return KMI_OK;
+  }
   KMI_TRY(extract_run(ctx, &c, bytes_dev, n_bytes, 0, (uint64_t *)dr, nullptr, (size_t)nt, false, true, &nt, &ns, nullptr, rw, node_form));
   if (!node_form) KMI_TRY(dbg_edges(ctx, (uint64_t *)dr, (size_t)nt, bytes_dev, n_bytes, shape, true, false));
   *recs_out = (uint64_t *)dr; *n_out = nt;

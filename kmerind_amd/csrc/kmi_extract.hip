@@ -322,7 +322,9 @@ template <int NW, int BITS, bool WITH_IDS>
 __global__ __launch_bounds__((ExCfg<NW, BITS>::NT)) void fasta_extract_kernel(
     PackedInput in, KShape shape, bool canonical, const uint64_t *__restrict__ ids_by_rank, const uint64_t *__restrict__ out_off,
     uint64_t out_capacity, uint64_t *__restrict__ out_kmers, uint64_t *__restrict__ out_ids, uint32_t *__restrict__ flags,
-    uint32_t kstride /* words between the keys of consecutive tuples */, uint32_t istride /* ... between their ids */) {
+    uint32_t kstride /* words between the keys of consecutive tuples */, uint32_t istride /* ... between their ids */,
+    const uint8_t *__restrict__ raw_edges = nullptr /* de Bruijn tuples (kmi_debruijn.h): the input bytes; the id slot then takes the edge byte */,
+    uint64_t file_offset = 0) {
   using Cfg = ExCfg<NW, BITS>;
   __shared__ uint32_t s_eol[Cfg::EOL_DW];
   __shared__ uint32_t s_stream[Cfg::STREAM_DW];
@@ -344,12 +346,27 @@ __global__ __launch_bounds__((ExCfg<NW, BITS>::NT)) void fasta_extract_kernel(
     const uint32_t pos = s_pos[q];
     window_at<Cfg>(s_stream, pos, shape, rc, fw);
     select_strand<NW>(rc, fw, canonical, key);
+    uint64_t idw = 0;
+    if (WITH_IDS) {
+      idw = ids_by_rank[tile0 + pos];
+      if (raw_edges) {   // uniform
+        // edge_iterator.hpp:163-177 over the record's characters (EOLs are not characters: NonEOLIter): the characters left and right
+        // of the k-mer in its sequence, DNA16 codes, nothing where the sequence ends. Character r of the compacted stream sits at
+        // the file position its id holds (low 40 bits); a set record-start bit at r means r has no left neighbour.
+        const uint64_t r = tile0 + pos, rr = r + shape.k;
+        const uint32_t *brk = reinterpret_cast<const uint32_t *>(in.eol);
+        uint32_t e = 0;
+        if (r > 0 && !((brk[r >> 5] >> (r & 31u)) & 1u)) e |= code_dna16(raw_edges[(ids_by_rank[r - 1] & 0xFFFFFFFFFFull) - file_offset]) << 4;
+        if (rr < in.n_bytes && !((brk[rr >> 5] >> (rr & 31u)) & 1u)) e |= code_dna16(raw_edges[(ids_by_rank[rr] & 0xFFFFFFFFFFull) - file_offset]);
+        idw = e;
+      }
+    }
     if constexpr (WITH_IDS && kRecVec<NW>) {
-      if (vec) { store_record_vec<NW>(out_kmers, base + q, key, ids_by_rank[tile0 + pos]); continue; }   // uniform
+      if (vec) { store_record_vec<NW>(out_kmers, base + q, key, idw); continue; }   // uniform
     }
 #pragma unroll
     for (int w = 0; w < NW; ++w) out_kmers[(base + q) * kstride + w] = key[w];
-    if (WITH_IDS) out_ids[(base + q) * istride] = ids_by_rank[tile0 + pos];
+    if (WITH_IDS) out_ids[(base + q) * istride] = idw;
   }
 }
 
@@ -933,7 +950,7 @@ kmi_status fastq_scan(kmi_ctx *ctx, const kmi_config *cfg, const uint8_t *bytes_
 template <int NW, int BITS>
 static kmi_status fasta_extract_impl(kmi_ctx *ctx, const kmi_config *cfg, const uint8_t *bytes_dev, size_t n_bytes, KShape shape,
                                      uint64_t file_offset, uint64_t *out_kmers_dev, uint64_t *out_ids_dev, size_t out_capacity,
-                                     bool apply_strand, bool count_only, uint64_t *n_tuples, uint64_t *n_seqs, uint32_t rec_words) {
+                                     bool apply_strand, bool count_only, uint64_t *n_tuples, uint64_t *n_seqs, uint32_t rec_words, bool edges) {
   using Cfg = ExCfg<NW, BITS>;
   const uint32_t kstride = rec_words ? rec_words : (uint32_t)NW, istride = rec_words ? rec_words : 1u;
   if (rec_words) out_ids_dev = out_kmers_dev + NW;   // records: the id follows the key words
@@ -958,7 +975,7 @@ static kmi_status fasta_extract_impl(kmi_ctx *ctx, const kmi_config *cfg, const 
     if (out_ids_dev)
       hipLaunchKernelGGL((fasta_extract_kernel<NW, BITS, true>), dim3((unsigned)n_tiles), dim3(Cfg::NT), 0, ctx->stream, in, shape, canonical,
                          fs.ids_by_rank, (const uint64_t *)off, (uint64_t)out_capacity, out_kmers_dev, out_ids_dev, ctx->d_flags, kstride,
-                         istride);
+                         istride, edges ? bytes_dev : (const uint8_t *)nullptr, file_offset);
     else
       hipLaunchKernelGGL((fasta_extract_kernel<NW, BITS, false>), dim3((unsigned)n_tiles), dim3(Cfg::NT), 0, ctx->stream, in, shape, canonical,
                          (const uint64_t *)nullptr, (const uint64_t *)off, (uint64_t)out_capacity, out_kmers_dev, (uint64_t *)nullptr,
@@ -977,9 +994,9 @@ static kmi_status fasta_extract_impl(kmi_ctx *ctx, const kmi_config *cfg, const 
 
 static kmi_status fasta_extract(kmi_ctx *ctx, const kmi_config *cfg, const uint8_t *bytes_dev, size_t n_bytes, KShape shape,
                                 uint64_t file_offset, uint64_t *out_kmers_dev, uint64_t *out_ids_dev, size_t out_capacity, bool apply_strand,
-                                bool count_only, uint64_t *n_tuples, uint64_t *n_seqs, uint32_t rec_words = 0) {
+                                bool count_only, uint64_t *n_tuples, uint64_t *n_seqs, uint32_t rec_words = 0, bool edges = false) {
   KMI_DISPATCH(shape, fasta_extract_impl, ctx, cfg, bytes_dev, n_bytes, shape, file_offset, out_kmers_dev, out_ids_dev, out_capacity,
-               apply_strand, count_only, n_tuples, n_seqs, rec_words);
+               apply_strand, count_only, n_tuples, n_seqs, rec_words, edges);
 }
 
 // Illumina18QualityScoreCodec<float>::DecodeLUT by its generating formula (quality_scores.hpp:111-112):
@@ -1022,10 +1039,10 @@ kmi_status extract_run(kmi_ctx *ctx, const kmi_config *cfg, const uint8_t *bytes
   if (n_bytes == 0) { if (n_tuples) *n_tuples = 0; if (n_seqs) *n_seqs = 0; return KMI_OK; }
   if ((out_quals_dev && !out_ids_dev && !rec_words) || ((out_quals_dev || rec_words == shape.n_words + 2u) && cfg->seq_format != KMI_FMT_FASTQ))
     return set_err(ctx, KMI_ERR_INVALID, "k-mer qualities need FASTQ input and are produced together with the ids");
-  if (cfg->seq_format == KMI_FMT_FASTA)
+  if (edges && rec_words != shape.n_words + 1u) return set_err(ctx, KMI_ERR_INVALID, "edge tuples are records of n_words + 1 words");
+  if (cfg->seq_format == KMI_FMT_FASTA)   // (edges: the value word is the edge byte, the key stays as parsed; dbg_edges makes node form of it)
     return fasta_extract(ctx, cfg, bytes_dev, n_bytes, shape, file_offset, out_kmers_dev, out_ids_dev, out_capacity, apply_strand, false,
-                         n_tuples, n_seqs, rec_words);
-  if (edges && (cfg->seq_format != KMI_FMT_FASTQ || rec_words != shape.n_words + 1u)) return set_err(ctx, KMI_ERR_INVALID, "edge tuples are FASTQ records of n_words + 1 words");
+                         n_tuples, n_seqs, rec_words, edges);
   KMI_DISPATCH(shape, extract_run_impl, ctx, cfg, bytes_dev, n_bytes, shape, file_offset, out_kmers_dev, out_ids_dev, out_quals_dev,
                out_capacity, apply_strand, scan_done, n_tuples, n_seqs, rec_words, edges);
 }

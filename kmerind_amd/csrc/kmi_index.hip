@@ -4582,8 +4582,8 @@ kmi_status kmi_dbg_create(kmi_ctx *ctx, const kmi_config *cfg, uint32_t node_kin
   KShape shape;
   if (!valid_config(cfg, &shape)) return set_err(ctx, KMI_ERR_INVALID, "bad kmi_config");
   if (node_kind > KMI_DBG_EDGE_EXISTS) return set_err(ctx, KMI_ERR_INVALID, "unknown node kind");
-  if (cfg->seq_format != KMI_FMT_FASTQ || cfg->seq_filter != KMI_SEQ_ALL)
-    return set_err(ctx, KMI_ERR_INVALID, "de Bruijn nodes are built from FASTQ records without a sequence filter (as the reference's engine is)");
+  if (cfg->seq_filter != KMI_SEQ_ALL)
+    return set_err(ctx, KMI_ERR_INVALID, "de Bruijn nodes are built from every record of the input (no sequence filter), as the reference's engine is");
   kmi_dbg *g = new kmi_dbg();
   g->ctx = ctx; g->cfg = *cfg; g->shape = shape; g->node_kind = node_kind;
   kmi_config c = *cfg;   // the node map proper: both strands of a k-mer are one node, kept under the smaller one
@@ -4591,6 +4591,14 @@ kmi_status kmi_dbg_create(kmi_ctx *ctx, const kmi_config *cfg, uint32_t node_kin
   const kmi_status st = kmi_index_create(ctx, &c, &g->nodes);
   if (st != KMI_OK) { delete g; return st; }
   *out = g;
+  return KMI_OK;
+}
+
+// the SeqParser template argument of the engine's build_posix / build_mmap (FASTQParser or FASTAParser)
+kmi_status kmi_dbg_set_seq_format(kmi_dbg *g, uint32_t seq_format) {
+  if (!g) return KMI_ERR_INVALID;
+  if (seq_format > KMI_FMT_FASTA) return set_err(g->ctx, KMI_ERR_INVALID, "unknown sequence format");
+  g->cfg.seq_format = seq_format;
   return KMI_OK;
 }
 

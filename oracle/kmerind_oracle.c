@@ -1117,11 +1117,13 @@ static size_t dbg_parse_seq(const orc_kspec *s, const uint8_t *chars, size_t len
   return total;
 }
 
-long orc_dbg_parse(const orc_kspec *s, const uint8_t *bytes, size_t n, uint64_t *kmers, uint8_t *edges, size_t out_cap) {
-  long nrec = orc_fastq_records(bytes, n, 0, NULL, 0);
+/* fmt: ORC_FMT_FASTQ / ORC_FMT_FASTA -- the parser is generic over the sequence type (de_bruijn_construct_engine.hpp:108-158): the characters of a
+ * record's sequence without its EOLs (NonEOLIter), k-mers and edges over them */
+long orc_dbg_parse_fmt(const orc_kspec *s, uint32_t fmt, const uint8_t *bytes, size_t n, uint64_t *kmers, uint8_t *edges, size_t out_cap) {
+  long nrec = fmt == ORC_FMT_FASTA ? orc_fasta_records(bytes, n, 0, NULL, 0) : orc_fastq_records(bytes, n, 0, NULL, 0);
   if (nrec < 0) return -1;
   orc_record *recs = (orc_record *)malloc(sizeof(orc_record) * (size_t)(nrec ? nrec : 1));
-  orc_fastq_records(bytes, n, 0, recs, (size_t)nrec);
+  if (fmt == ORC_FMT_FASTA) orc_fasta_records(bytes, n, 0, recs, (size_t)nrec); else orc_fastq_records(bytes, n, 0, recs, (size_t)nrec);
   size_t total = 0;
   uint8_t *chars = (uint8_t *)malloc(n ? n : 1);
   for (long r = 0; r < nrec; ++r) {
@@ -1133,6 +1135,10 @@ long orc_dbg_parse(const orc_kspec *s, const uint8_t *bytes, size_t n, uint64_t 
   }
   free(chars); free(recs);
   return (long)total;
+}
+
+long orc_dbg_parse(const orc_kspec *s, const uint8_t *bytes, size_t n, uint64_t *kmers, uint8_t *edges, size_t out_cap) {
+  return orc_dbg_parse_fmt(s, ORC_FMT_FASTQ, bytes, n, kmers, edges, out_cap);
 }
 
 uint8_t orc_dbg_edges_revcomp(uint8_t exts) {

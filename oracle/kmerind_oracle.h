@@ -193,6 +193,8 @@ size_t orc_multi_map_erase(orc_multi_map *m, const uint64_t *queries, size_t nq)
  * (no strand transform) zipped with edge_iterator<CharIter, DNA16>: high nibble = DNA16 code of the base left of the k-mer
  * in the read, low nibble = base right of it, 0 where the read ends. Returns the tuple count, -1 on a parse error. */
 long orc_dbg_parse(const orc_kspec *s, const uint8_t *bytes, size_t n, uint64_t *kmers, uint8_t *edges, size_t out_cap);
+/* the same with the input format given (ORC_FMT_FASTQ / ORC_FMT_FASTA) */
+long orc_dbg_parse_fmt(const orc_kspec *s, uint32_t fmt, const uint8_t *bytes, size_t n, uint64_t *kmers, uint8_t *edges, size_t out_cap);
 /* input_edge_utils::reverse_complement_edges<DNA16> (de_bruijn_node_trait.hpp:122-124) */
 uint8_t orc_dbg_edges_revcomp(uint8_t exts);
 /* de_bruijn_nodes_distributed<Kmer, edge_counts<DNA16, int32_t> | edge_exists<DNA16>, BimoleculeHashMapParams>:

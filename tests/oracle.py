@@ -102,6 +102,8 @@ lib.orc_multi_map_erase.argtypes = [C.c_void_p, _u64p, C.c_size_t]
 lib.orc_multi_map_erase.restype = C.c_size_t
 lib.orc_dbg_parse.argtypes = [_SP, _u8p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t]
 lib.orc_dbg_parse.restype = C.c_long
+lib.orc_dbg_parse_fmt.argtypes = [_SP, C.c_uint32, _u8p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t]
+lib.orc_dbg_parse_fmt.restype = C.c_long
 lib.orc_dbg_edges_revcomp.argtypes = [C.c_uint8]
 lib.orc_dbg_edges_revcomp.restype = C.c_uint8
 lib.orc_dbg_map_create.argtypes = [_SP, C.c_uint32, C.c_int]
@@ -254,15 +256,16 @@ class CountMap:
         return lib.orc_count_map_erase(self.h, q, q.shape[0])
 
 
-def dbg_parse(s, data):
-    """de_bruijn_parser over a FASTQ buffer: (k-mers as parsed, DNA16 edge bytes: left << 4 | right)"""
+def dbg_parse(s, data, fmt=None):
+    """de_bruijn_parser over a FASTQ (or, fmt=FASTA, FASTA) buffer: (k-mers as parsed, DNA16 edge bytes: left << 4 | right)"""
     b = _as_bytes(data)
-    n = lib.orc_dbg_parse(C.byref(s), b, b.size, None, None, 0)
+    fmt = FASTQ if fmt is None else fmt
+    n = lib.orc_dbg_parse_fmt(C.byref(s), fmt, b, b.size, None, None, 0)
     if n < 0:
         raise ValueError("parse error")
     kmers = np.zeros((n, s.n_words), dtype=np.uint64)
     edges = np.zeros(n, dtype=np.uint8)
-    lib.orc_dbg_parse(C.byref(s), b, b.size, _ptr(kmers), _ptr(edges), n)
+    lib.orc_dbg_parse_fmt(C.byref(s), fmt, b, b.size, _ptr(kmers), _ptr(edges), n)
     return kmers, edges
 
 

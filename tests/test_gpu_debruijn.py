@@ -132,6 +132,42 @@ def test_erase_nodes(ctx, k, alpha):
     g.close()
 
 
+@pytest.mark.parametrize("k,alpha", [(21, "DNA"), (31, "DNA"), (63, "DNA"), (21, "DNA5")])
+def test_fasta_input(ctx, k, alpha):
+    """The engine's parser is generic over the sequence type (de_bruijn_construct_engine.hpp:108-158): on FASTA the characters of a
+    record are its sequence lines without their EOLs, so a k-mer's neighbours may sit on the line before or after it and no edge leads
+    across a header. Parser tuples bit for bit and the node map against the oracle, on the reference's FASTA files and on multi-line
+    records with N, CRLF and lines of every length."""
+    import kmerind_amd as K
+    s = orc.kspec(k, ALPHA[alpha])
+    cfg = K.make_config(k, alpha, seq_format="fasta")
+    rng = np.random.default_rng(k)
+
+    def synth(n_rec, line, eol):
+        out = []
+        for r in range(n_rec):
+            L = int(rng.integers(k - 3, max(6 * line, 3 * k)))
+            seq = "".join("ACGTN"[c] for c in rng.choice(5, size=L, p=[0.24, 0.24, 0.24, 0.24, 0.04]))
+            out.append((">r%d some text" % r).encode() + eol)
+            for i in range(0, L, line):
+                out.append(seq[i:i + line].encode() + eol)
+        return b"".join(out)
+    inputs = [open(os.path.join(GOLD, name), "rb").read() for name in ("test.fasta", "test2.fasta", "natural.fasta", "natural.withN.fasta")]
+    inputs += [synth(40, 60, b"\n"), synth(25, 7, b"\r\n"), synth(30, 1, b"\n")]
+    for data in inputs:
+        ok, oe = orc.dbg_parse(s, data, orc.FASTA)
+        g = K.DeBruijnNodes(ctx, cfg)
+        gk, ge = g.parse(data)
+        assert gk.shape == ok.shape and (gk == ok).all() and (ge == oe).all(), len(data)
+        om = orc.DbgMap(s)
+        om.insert(ok, oe)
+        g.build(data)
+        assert g.local_size() == om.size()
+        if om.size():
+            assert (_nodes(*g.to_vector()) == _nodes(*om.export(canonical=True))).all()
+        g.close()
+
+
 def test_exists_nodes(ctx):
     import kmerind_amd as K
     k = 21
