@@ -93,3 +93,17 @@ def test_reference_fixture_conservation():
         if ambiguous == 0:
             assert cnt[:, :8].sum() == 2 * (kmers.shape[0] - n_reads)
         assert keys.shape[0] == np.unique(orc.canonical(s, kmers), axis=0).shape[0]
+
+
+def test_fasta_records_hand_worked():
+    """FASTA: a record's characters are its sequence lines without their EOLs (NonEOLIter), so the neighbour of a k-mer may sit on
+    another line; no edge crosses a header. Worked by hand: record a = ACGTAC / GTTN -> ACGTACGTTN (six 5-mers), record b = AC (none)."""
+    s = orc.kspec(5)
+    kmers, edges = orc.dbg_parse(s, b">a\nACGTAC\nGTTN\n>b desc\nAC\n", orc.FASTA)
+    A, Cc, G, T, N = 1, 2, 4, 8, 15                                   # DNA16 codes
+    assert edges.tolist() == [Cc, (A << 4) | G, (Cc << 4) | T, (G << 4) | T, (T << 4) | N, A << 4]
+    expect = orc.extract(s, b">a\nACGTACGTTN\n", orc.FASTA)["kmers"]
+    assert (kmers == expect).all()
+    # CRLF line ends and a one-character line change nothing
+    k2, e2 = orc.dbg_parse(s, b">a\r\nACGTAC\r\nG\r\nTTN\r\n>b desc\r\nAC\r\n", orc.FASTA)
+    assert (k2 == kmers).all() and (e2 == edges).all()
