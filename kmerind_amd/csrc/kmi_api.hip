@@ -177,7 +177,7 @@ kmi_status kmi_ctx_create(int device, int rank, int nranks, void *stream, kmi_ct
   ctx->device = device; ctx->rank = rank; ctx->nranks = nranks; ctx->stream = (hipStream_t)stream;
   if (hipMalloc((void **)&ctx->d_flags, sizeof(uint32_t) * 64) != hipSuccess ||
       hipMalloc((void **)&ctx->d_totals, sizeof(uint64_t) * (16 + 256)) != hipSuccess ||
-      hipHostMalloc((void **)&ctx->h_totals, sizeof(uint64_t) * 16, hipHostMallocDefault) != hipSuccess) {
+      hipHostMalloc((void **)&ctx->h_totals, sizeof(uint64_t) * (16 + 1024), hipHostMallocDefault)   /* 16 words of totals + a mailbox for the front end's read-back */ != hipSuccess) {
     delete ctx;
     return KMI_ERR_DEVICE;
   }

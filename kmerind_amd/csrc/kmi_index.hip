@@ -2779,9 +2779,9 @@ static kmi_status sk_front_fast(kmi_ctx *ctx, const kmi_config *cfg, const KShap
   KMI_TRY(ws_get(ctx, WS_WGHIST, sizeof(uint32_t) * kPartGroups * kNumCoarse, &p)); uint32_t *wg_hist = (uint32_t *)p;
   KMI_TRY(ws_get(ctx, WS_CURSOR, sizeof(uint64_t) * kPartGroups * kNumCoarse, &p)); uint64_t *wg_off = (uint64_t *)p;
   KMI_TRY(ws_get(ctx, WS_MISC, sizeof(uint64_t) * kNumCoarse * 3, &p)); uint64_t *cnt = (uint64_t *)p, *base = cnt + kNumCoarse;
-  KMI_HIP(ctx, hipMemsetAsync(ctx->d_flags, 0, sizeof(uint32_t) * 16, ctx->stream));
-  KMI_HIP(ctx, hipMemsetAsync(ctx->d_totals + 6, 0, sizeof(uint64_t), ctx->stream));
-  KMI_HIP(ctx, hipMemsetAsync(wg_hist, 0, sizeof(uint32_t) * kPartGroups * kNumCoarse, ctx->stream));
+  // (flags 0 .. 15, the k-mer total and the group histograms, in one launch)
+  hipLaunchKernelGGL(sk_zero_kernel, dim3(128), dim3(1024), 0, ctx->stream, wg_hist, (uint32_t)(kPartGroups * kNumCoarse),
+                     reinterpret_cast<uint32_t *>(ctx->d_totals + 6), 2u, (uint32_t *)nullptr, 0u, ctx->d_flags, 0u, 16u, 0u, 0u);
   {
     ProfScope ps(ctx, "sk_front", n_bytes);
     const uint32_t wgs = (n_ranges + kFrWaves - 1) / kFrWaves;
@@ -2803,13 +2803,17 @@ static kmi_status sk_front_fast(kmi_ctx *ctx, const kmi_config *cfg, const KShap
     launch_rank_offsets(ctx->stream, (const uint32_t *)wg_hist, (uint32_t)kPartGroups, (uint32_t)kNumCoarse, cnt, base, wg_off);
   }
   KMI_HIP(ctx, hipGetLastError());
-  uint64_t h_cnt[2 * kNumCoarse], h_tot[3] = {0, 0, 0}, n = 0;
-  uint32_t h_flag = 0;
-  KMI_HIP(ctx, hipMemcpyAsync(h_cnt, cnt, sizeof(uint64_t) * 2 * kNumCoarse, hipMemcpyDeviceToHost, ctx->stream));
-  KMI_HIP(ctx, hipMemcpyAsync(&h_flag, ctx->d_flags + 9, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-  KMI_HIP(ctx, hipMemcpyAsync(h_tot, ctx->d_totals + 12, sizeof(h_tot), hipMemcpyDeviceToHost, ctx->stream));
-  KMI_HIP(ctx, hipMemcpyAsync(&n, ctx->d_totals + 6, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+  // what the host needs of the front end comes back into PINNED memory: four copies queued back to back and one synchronisation
+  // (into pageable memory every copy was a host round trip of its own: 0.1 ms of an idle GPU per build)
+  uint64_t *const mail = ctx->h_totals + 16;
+  const uint64_t *const h_cnt = mail, *const h_tot = mail + 2 * kNumCoarse + 1;
+  KMI_HIP(ctx, hipMemcpyAsync(mail, cnt, sizeof(uint64_t) * 2 * kNumCoarse, hipMemcpyDeviceToHost, ctx->stream));
+  KMI_HIP(ctx, hipMemcpyAsync(mail + 2 * kNumCoarse, ctx->d_flags + 9, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+  KMI_HIP(ctx, hipMemcpyAsync(mail + 2 * kNumCoarse + 1, ctx->d_totals + 12, sizeof(uint64_t) * 3, hipMemcpyDeviceToHost, ctx->stream));
+  KMI_HIP(ctx, hipMemcpyAsync(mail + 2 * kNumCoarse + 4, ctx->d_totals + 6, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
   KMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  const uint32_t h_flag = *reinterpret_cast<const uint32_t *>(mail + 2 * kNumCoarse);
+  const uint64_t n = mail[2 * kNumCoarse + 4];
   if (h_flag) {   // not this path's input (or not well-formed): the general path decides
     if (getenv("KMI_FRONT_DEBUG")) {
       uint32_t why = 0;
@@ -2896,9 +2900,9 @@ static kmi_status sk_back_end(kmi_index *idx, const uint64_t *rec_a, uint64_t R,
     fine_cnt = fine_hist;   // (the first half of the histogram block: records per fine bucket, counted as they are appended)
     KMI_HIP(ctx, hipMemcpyAsync(d_region, h_region, sizeof(h_region), hipMemcpyHostToDevice, ctx->stream));
     KMI_HIP(ctx, hipMemcpyAsync(d_cap, h_cap, sizeof(h_cap), hipMemcpyHostToDevice, ctx->stream));
-    KMI_HIP(ctx, hipMemsetAsync(fine_cnt, 0, sizeof(uint32_t) * kNumFine, ctx->stream));
-    KMI_HIP(ctx, hipMemsetAsync(fine_kmers, 0, sizeof(uint32_t) * kNumFine * kFineParts, ctx->stream));
-    KMI_HIP(ctx, hipMemsetAsync(ctx->d_flags + 34, 0, sizeof(uint32_t), ctx->stream));
+    // (the append counters, the k-mer counts, the reduce's votes -- flags 16 .. 33 --, the room flag 34 and the queue word 40)
+    hipLaunchKernelGGL(sk_zero_kernel, dim3(96), dim3(1024), 0, ctx->stream, fine_cnt, (uint32_t)kNumFine, fine_kmers, (uint32_t)(kNumFine * kFineParts),
+                       (uint32_t *)nullptr, 0u, ctx->d_flags, 16u, 35u, 40u, 41u);
     {
       ProfScope ps(ctx, "sk_scatter_fine", R);
       hipLaunchKernelGGL(sk_scatter_fine_slack_kernel, dim3(kNumCoarse * kFineParts), dim3(kPartThreads), 0, ctx->stream, (const uint64_t *)rec_a, rec_b,
@@ -2931,13 +2935,13 @@ static kmi_status sk_back_end(kmi_index *idx, const uint64_t *rec_a, uint64_t R,
   KMI_TRY(ws_get(ctx, WS_TMP_KEYS, (n + 64) * sizeof(uint64_t), &p)); uint64_t *tmp_keys = (uint64_t *)p;
   KMI_TRY(ws_get(ctx, WS_TMP_VALS, (n + 64) * sizeof(uint32_t), &p)); uint32_t *tmp_vals = (uint32_t *)p;
   KMI_TRY(ws_get(ctx, WS_BUCKET_CNT, sizeof(uint32_t) * kNumFine, &p)); uint32_t *out_cnt = (uint32_t *)p;
-  KMI_HIP(ctx, hipMemsetAsync(ctx->d_flags + 16, 0, sizeof(uint32_t) * 18, ctx->stream));   // the pass-structure votes of sk_reduce
+  if (!slack) KMI_HIP(ctx, hipMemsetAsync(ctx->d_flags + 16, 0, sizeof(uint32_t) * 18, ctx->stream));   // the pass-structure votes of sk_reduce (the slack path has zeroed them)
   {
     ProfScope ps(ctx, "sk_reduce", n);
     const uint32_t nmax = sk_nmax_of(k);
     // persistent workgroups (one per CU: each takes the whole LDS) pull the buckets from a queue word
     uint32_t *queue = ctx->d_flags + 40;
-    KMI_HIP(ctx, hipMemsetAsync(queue, 0, sizeof(uint32_t), ctx->stream));
+    if (!slack) KMI_HIP(ctx, hipMemsetAsync(queue, 0, sizeof(uint32_t), ctx->stream));
     const uint32_t wgs = ctx->n_cus ? ctx->n_cus : 256u;
 #define KMI_SK_REDUCE(CANON, OWN, SPECIAL)                                                                                               \
     hipLaunchKernelGGL((sk_reduce_kernel<CANON, OWN, SPECIAL>), dim3(wgs), dim3(KMI_SK_NT), 0, ctx->stream, (const uint64_t *)rec_b,        \

@@ -594,6 +594,19 @@ __global__ __launch_bounds__(kPartThreads) void sk_scatter_fine_slack_kernel(con
   }
 }
 
+// the words a build zeroes before its kernels start, in one launch instead of a fill per array (a fill is a kernel of its own:
+// five microseconds each on the stream, and a build has a dozen): up to three arrays of dwords and two short ranges of the flags
+__global__ __launch_bounds__(1024) void sk_zero_kernel(uint32_t *__restrict__ a, uint32_t na, uint32_t *__restrict__ b, uint32_t nb,
+                                                     uint32_t *__restrict__ c, uint32_t nc, uint32_t *__restrict__ flags, uint32_t f0, uint32_t f1,
+                                                     uint32_t g0, uint32_t g1) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
+  for (uint32_t x = i; x < na; x += stride) a[x] = 0;
+  for (uint32_t x = i; x < nb; x += stride) b[x] = 0;
+  for (uint32_t x = i; x < nc; x += stride) c[x] = 0;
+  if (i >= f0 && i < f1) flags[i] = 0;
+  if (i >= g0 && i < g1) flags[i] = 0;
+}
+
 // Records that arrived from the other ranks of a build (a flat array, every source's part grouped by the sender's buckets):
 // coarse-bucket counts of every workgroup's chunk (the chunks scatter_chunks_kernel will take) and the k-mers they hold
 __global__ __launch_bounds__(kPartThreads) void sk_recv_hist_kernel(const uint64_t *__restrict__ recs, uint64_t n, uint32_t *__restrict__ wg_hist,
