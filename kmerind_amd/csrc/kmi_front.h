@@ -426,7 +426,10 @@ template <bool CANON>
 __global__ __launch_bounds__(kFrScThreads, 2) void sk_scatter_rows_kernel(const FrRange *__restrict__ info, uint32_t n_ranges, uint32_t rpg, uint32_t run_cap,
                                                                          uint32_t item_cap, uint32_t k, const uint32_t *__restrict__ run_items,
                                                                          const uint32_t *__restrict__ rows, const uint32_t *__restrict__ items,
-                                                                         const uint64_t *__restrict__ wg_off, uint64_t *__restrict__ out, uint32_t lp) {
+                                                                         const uint64_t *__restrict__ wg_off, uint64_t *__restrict__ out, uint32_t lp,
+                                                                         const uint32_t *__restrict__ flags) {
+  // (launched before the host has looked at the front end's verdict: a front end that gave up has left tables nobody may walk)
+  if (__hip_atomic_load(&flags[9], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
   // One lane per run; the round's items are brought into LDS ONCE (sixteen bytes at a time from each run's list) and everything
   // after that -- bucket counts, the bucket sort of (run, item) references, the copy-out that assembles the records -- reads
   // them there. (Kept in registers and re-read from global memory for the copy-out, the items made this kernel wait on the

@@ -2803,6 +2803,21 @@ static kmi_status sk_front_fast(kmi_ctx *ctx, const kmi_config *cfg, const KShap
     launch_rank_offsets(ctx->stream, (const uint32_t *)wg_hist, (uint32_t)kPartGroups, (uint32_t)kNumCoarse, cnt, base, wg_off);
   }
   KMI_HIP(ctx, hipGetLastError());
+  // The scatter pass is queued BEFORE the host looks at the front end's verdict (it checks the flag itself), so the GPU does not
+  // idle through the host's round trip: its output then has to be sized by what the front end can produce at most (one item per
+  // item slot), which is three times the usual -- done for inputs up to 8 GB, and when the caller did not bring the buffer.
+  const uint64_t r_bound = (uint64_t)n_ranges * item_cap;
+  const bool early = !out && n_bytes <= (8ull << 30);
+  uint64_t *rec_a = out;
+  auto launch_scatter = [&]() {
+    ProfScope ps(ctx, "sk_scatter", n_bytes);
+    if (canonical)
+      hipLaunchKernelGGL(sk_scatter_rows_kernel<true>, dim3(kPartGroups), dim3(kFrScThreads), 0, ctx->stream, (const FrRange *)info, n_ranges, rpg, run_cap, item_cap, k,
+                         (const uint32_t *)run_items, (const uint32_t *)rows, (const uint32_t *)items, (const uint64_t *)wg_off, rec_a, lp, (const uint32_t *)ctx->d_flags);
+    else
+      hipLaunchKernelGGL(sk_scatter_rows_kernel<false>, dim3(kPartGroups), dim3(kFrScThreads), 0, ctx->stream, (const FrRange *)info, n_ranges, rpg, run_cap, item_cap, k,
+                         (const uint32_t *)run_items, (const uint32_t *)rows, (const uint32_t *)items, (const uint64_t *)wg_off, rec_a, lp, (const uint32_t *)ctx->d_flags);
+  };
   // what the host needs of the front end comes back into PINNED memory: four copies queued back to back and one synchronisation
   // (into pageable memory every copy was a host round trip of its own: 0.1 ms of an idle GPU per build)
   uint64_t *const mail = ctx->h_totals + 16;
@@ -2811,7 +2826,11 @@ static kmi_status sk_front_fast(kmi_ctx *ctx, const kmi_config *cfg, const KShap
   KMI_HIP(ctx, hipMemcpyAsync(mail + 2 * kNumCoarse, ctx->d_flags + 9, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
   KMI_HIP(ctx, hipMemcpyAsync(mail + 2 * kNumCoarse + 1, ctx->d_totals + 12, sizeof(uint64_t) * 3, hipMemcpyDeviceToHost, ctx->stream));
   KMI_HIP(ctx, hipMemcpyAsync(mail + 2 * kNumCoarse + 4, ctx->d_totals + 6, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
-  KMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (early) {
+    KMI_TRY(ws_get(ctx, WS_KEYS_A, (r_bound + 64) * 16, &p)); rec_a = (uint64_t *)p;
+    launch_scatter();
+  }
+  KMI_HIP(ctx, hipStreamSynchronize(ctx->stream));   // (early: this returns when the scatter pass has run, too)
   const uint32_t h_flag = *reinterpret_cast<const uint32_t *>(mail + 2 * kNumCoarse);
   const uint64_t n = mail[2 * kNumCoarse + 4];
   if (h_flag) {   // not this path's input (or not well-formed): the general path decides
@@ -2828,16 +2847,9 @@ static kmi_status sk_front_fast(kmi_ctx *ctx, const kmi_config *cfg, const KShap
   for (int c = 0; c < kNumCoarse; ++c) { R += h_cnt[c]; f->h_cnt[c] = h_cnt[c]; f->h_base[c] = h_cnt[kNumCoarse + c]; }
   f->n_records = R; f->n_kmers = n; f->wg_off = wg_off; f->recs = nullptr; f->n_seqs = (h_tot[0] + 2) / 4;
   if (n == 0) { f->ok = true; return KMI_OK; }
-  uint64_t *rec_a = out;
-  if (!out || R + 64 > out_cap) { KMI_TRY(ws_get(ctx, WS_KEYS_A, (R + 64) * 16, &p)); rec_a = (uint64_t *)p; }
-  {
-    ProfScope ps(ctx, "sk_scatter", n);
-    if (canonical)
-      hipLaunchKernelGGL(sk_scatter_rows_kernel<true>, dim3(kPartGroups), dim3(kFrScThreads), 0, ctx->stream, (const FrRange *)info, n_ranges, rpg, run_cap, item_cap, k,
-                         (const uint32_t *)run_items, (const uint32_t *)rows, (const uint32_t *)items, (const uint64_t *)wg_off, rec_a, lp);
-    else
-      hipLaunchKernelGGL(sk_scatter_rows_kernel<false>, dim3(kPartGroups), dim3(kFrScThreads), 0, ctx->stream, (const FrRange *)info, n_ranges, rpg, run_cap, item_cap, k,
-                         (const uint32_t *)run_items, (const uint32_t *)rows, (const uint32_t *)items, (const uint64_t *)wg_off, rec_a, lp);
+  if (!early) {
+    if (!out || R + 64 > out_cap) { KMI_TRY(ws_get(ctx, WS_KEYS_A, (R + 64) * 16, &p)); rec_a = (uint64_t *)p; }
+    launch_scatter();
   }
   KMI_HIP(ctx, hipGetLastError());
   f->ok = true; f->recs = rec_a;

@@ -134,6 +134,16 @@ inline void pool_free(kmi_ctx *ctx, void *p, size_t bytes) {
     ctx->spare.erase(ctx->spare.begin() + (long)m);
   }
   ctx->spare.push_back({p, bytes});
+  // ... and the list never holds more than 32 GB: the OLDEST blocks go first then (the arrays of a multimap that grows batch by
+  // batch come back in sizes nobody asks for again)
+  constexpr size_t kMaxSpareBytes = 32ull << 30;
+  size_t total = 0;
+  for (const auto &b : ctx->spare) total += b.bytes;
+  while (total > kMaxSpareBytes && !ctx->spare.empty()) {
+    total -= ctx->spare.front().bytes;
+    (void)hipFree(ctx->spare.front().p);
+    ctx->spare.erase(ctx->spare.begin());
+  }
 }
 
 inline kmi_status set_err(kmi_ctx *ctx, kmi_status st, const char *fmt, const char *a = "", const char *b = "") {
