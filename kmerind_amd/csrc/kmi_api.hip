@@ -209,6 +209,7 @@ kmi_status kmi_ctx_destroy(kmi_ctx *ctx) {
   for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
   if (ctx->d_flags) (void)hipFree(ctx->d_flags);
   if (ctx->d_totals) (void)hipFree(ctx->d_totals);
+  if (ctx->ev_mail) (void)hipEventDestroy(ctx->ev_mail);
   if (ctx->h_totals) (void)hipHostFree(ctx->h_totals);
   delete ctx;
   return KMI_OK;

@@ -2827,10 +2827,16 @@ static kmi_status sk_front_fast(kmi_ctx *ctx, const kmi_config *cfg, const KShap
   KMI_HIP(ctx, hipMemcpyAsync(mail + 2 * kNumCoarse + 1, ctx->d_totals + 12, sizeof(uint64_t) * 3, hipMemcpyDeviceToHost, ctx->stream));
   KMI_HIP(ctx, hipMemcpyAsync(mail + 2 * kNumCoarse + 4, ctx->d_totals + 6, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
   if (early) {
+    // the host waits for the read-backs only (an event behind them), not for the scatter pass queued behind that: what it queues
+    // next -- the back end's tables and kernels -- is on the stream before the scatter pass has finished
+    if (!ctx->ev_mail) KMI_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_mail, hipEventDisableTiming));
     KMI_TRY(ws_get(ctx, WS_KEYS_A, (r_bound + 64) * 16, &p)); rec_a = (uint64_t *)p;
+    KMI_HIP(ctx, hipEventRecord(ctx->ev_mail, ctx->stream));
     launch_scatter();
+    KMI_HIP(ctx, hipEventSynchronize(ctx->ev_mail));
+  } else {
+    KMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
   }
-  KMI_HIP(ctx, hipStreamSynchronize(ctx->stream));   // (early: this returns when the scatter pass has run, too)
   const uint32_t h_flag = *reinterpret_cast<const uint32_t *>(mail + 2 * kNumCoarse);
   const uint64_t n = mail[2 * kNumCoarse + 4];
   if (h_flag) {   // not this path's input (or not well-formed): the general path decides

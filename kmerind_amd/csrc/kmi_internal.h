@@ -80,6 +80,7 @@ struct kmi_ctx {
   uint32_t *d_flags = nullptr;   // [64] error / overflow flags, pass-structure votes (16..33), work-queue words (40..)
   uint32_t n_cus = 0;            // compute units of the device (grids of persistent workgroups)
   uint64_t *d_totals = nullptr;  // [16] small device scalars + [256] coarse-bucket totals of the fine-offset scan
+  hipEvent_t ev_mail = nullptr;  // marks "the read-backs queued so far have landed" (waited for instead of the whole stream)
   uint64_t *h_totals = nullptr;  // pinned mirror: 16 words of totals, then 1024 words for larger read-backs (one synchronisation for all of them)
   bool prof = false;
   std::vector<kmi::ProfRec> prof_pending;
