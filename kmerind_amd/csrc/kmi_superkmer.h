@@ -885,6 +885,14 @@ __global__ __launch_bounds__(KMI_SK_NT) void sk_reduce_kernel(const uint64_t *__
       pending = 0;
     }
   };
+  // per-wavefront phase clocks (-DKMI_SK_TIMING; printed by the host after every launch): where the 16 wavefronts of a workgroup spend
+  // their time -- phase A (record table, direct expansions, waiting at the barrier), phase B (expansion, waiting), emit
+#ifdef KMI_SK_TIMING
+  unsigned long long acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tq = 0;
+#define TQ_MARK(i) { const unsigned long long now_ = clock64(); acc[i] += now_ - tq; tq = now_; }
+#else
+#define TQ_MARK(i)
+#endif
   while (b < n_buckets) {   // uniform
     uint32_t q_next = 0;
     if (threadIdx.x == 0) q_next = atomicAdd(queue, 1u);   // (stays in a register until phase A is done: nobody waits for it)
@@ -914,6 +922,9 @@ __global__ __launch_bounds__(KMI_SK_NT) void sk_reduce_kernel(const uint64_t *__
     }
     bool first_pass = true;
     lds_barrier();
+#ifdef KMI_SK_TIMING
+    tq = clock64();
+#endif
     while (true) {
       const uint32_t sp = s_ctl[C_SP];
       if (sp == 0) break;                       // uniform
@@ -979,11 +990,13 @@ __global__ __launch_bounds__(KMI_SK_NT) void sk_reduce_kernel(const uint64_t *__
               if (oi < (uint32_t)kSkOvf) { s_ovf[oi] = rec; direct = false; }
             }
           }
-          if (__any(direct)) expand(rec.x, rec.y, 1u, direct ? n : 0u);
+          if (__any(direct)) { TQ_MARK(0) expand(rec.x, rec.y, 1u, direct ? n : 0u); TQ_MARK(1) }
         }
       }
+      TQ_MARK(0)
       if (first_pass && threadIdx.x == 0) s_ctl[C_NEXT + par] = q_next;
       lds_barrier();   // T1 and the overflow list complete; the next bucket is known
+      TQ_MARK(2)
       uint32_t nbk = 0;
       if (first_pass) {   // the next bucket's range: two scalar loads that return during phase B
         nbk = __builtin_amdgcn_readfirstlane(s_ctl[C_NEXT + par]);
@@ -1031,7 +1044,9 @@ __global__ __launch_bounds__(KMI_SK_NT) void sk_reduce_kernel(const uint64_t *__
         pf_ok = true;
       }
       first_pass = false;
+      TQ_MARK(3)
       lds_barrier();
+      TQ_MARK(4)
       const bool lost = s_ctl[C_OVF] != 0u;
       lds_barrier();   // everyone has read the verdict (the resets below overwrite it)
       if (threadIdx.x == 0) { s_ctl[C_DIST] = 0; s_ctl[C_OVF] = 0; s_ctl[C_T1N] = 0; s_ctl[C_OVN] = 0; }
@@ -1081,6 +1096,7 @@ __global__ __launch_bounds__(KMI_SK_NT) void sk_reduce_kernel(const uint64_t *__
         }
       }
       lds_barrier();
+      TQ_MARK(5)
     }
     if (threadIdx.x == 0) {
       out_cnt[b] = s_ctl[C_EMIT];
@@ -1090,7 +1106,11 @@ __global__ __launch_bounds__(KMI_SK_NT) void sk_reduce_kernel(const uint64_t *__
     lds_barrier();   // everyone has left the pass loop (the next bucket's set-up rewrites the stack words)
     b = __builtin_amdgcn_readfirstlane(s_ctl[C_NEXT + par]);
     par ^= 1u;
+    TQ_MARK(6)
   }
+#ifdef KMI_SK_TIMING
+  if (lane == 0) for (int i = 0; i < 8; ++i) atomicAdd(&reinterpret_cast<unsigned long long *>(flags + 48)[i], acc[i]);
+#endif
 }
 
 }  // namespace kmi
