@@ -1,7 +1,4 @@
 #!/bin/bash
-KMERIND_HIP_LIB=$PWD/ab/libskt.so timeout -k 10 300 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra > gpurun_out/b.log 2>&1 ; grep "sk_reduce wave clocks" gpurun_out/b.log | tail -1
-for v in prev cur prev cur; do
-L=$PWD/ab/lib$v.so; [ $v = cur ] && L=$PWD/kmerind_amd/libkmerind_hip.so
-KMERIND_HIP_LIB=$L timeout -k 10 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extra 2>&1 | tail -1 | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('$v', round(d['ms_per_step'],3), d['roofline']['kernels_ms_per_step']['sk_reduce'])"
+for v in base two6 two7 lin7 two7o256 base; do
+KMERIND_HIP_LIB=$PWD/ab/lib$v.so timeout -k 10 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extra 2>&1 | tail -1 | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('$v', round(d['ms_per_step'],3), d['roofline']['kernels_ms_per_step']['sk_reduce'])"
 done
-timeout -k 10 900 python -m pytest tests/test_gpu_index.py -m gpu -x -q 2>&1 | tail -2
