@@ -170,6 +170,8 @@ kmi_status kmi_ctx_create(int device, int rank, int nranks, void *stream, kmi_ct
   if (const char *dg = getenv("KMI_SK_DBG")) ctx->sk_dbg = atoi(dg);
   if (const char *dc = getenv("KMI_DIST_CHUNKS")) { ctx->dist_chunks = (uint32_t)atoi(dc); if (ctx->dist_chunks < 1) ctx->dist_chunks = 1; if (ctx->dist_chunks > 64) ctx->dist_chunks = 64; }
   if (const char *sl = getenv("KMI_SK_SLACK")) ctx->sk_slack = atoi(sl) != 0;
+  if (const char *r2 = getenv("KMI_SK_REDUCE")) ctx->sk_reduce2 = atoi(r2) == 2;
+  if (const char *ws = getenv("KMI_R2_WIN")) { ctx->sk_r2_win = (uint32_t)atoi(ws); if (ctx->sk_r2_win && ctx->sk_r2_win < 16) ctx->sk_r2_win = 16; if (ctx->sk_r2_win > 256) ctx->sk_r2_win = 256; }
   if (const char *fr = getenv("KMI_FRONT")) ctx->front_fused = strcmp(fr, "general") != 0;
   if (const char *mr = getenv("KMI_FRONT_MIN_RANGE")) { ctx->front_min_range = strtoull(mr, nullptr, 10); ctx->front_min_range = (ctx->front_min_range + 4095) / 4096 * 4096; if (!ctx->front_min_range) ctx->front_min_range = 4096; }
   if (const char *sm = getenv("KMI_SPARSE_MIN")) ctx->sparse_min = strtoull(sm, nullptr, 10);

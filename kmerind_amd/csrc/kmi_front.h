@@ -346,7 +346,8 @@ __global__ __launch_bounds__(kFrThreads) void sk_front_kernel(const uint8_t *__r
       FQ_MARK(4)
       if (__any(cnt >= (uint32_t)CAP)) { why |= 128u; bail = true; break; }
       wave_sync();
-      // items in their final form (window offset | (n - 1) << 7 | bucket bits << 12 | two further hash bits << 30) + the coarse counts.
+      // items in their final form ((n - 1) | 27 hash bits << 5: the 18 bucket bits and nine more below them; the items of a run cover
+      // its windows without a gap, so an item's first window is the sum of the lengths before it) + the coarse counts.
       // Backwards, written from the top of the list down: a super-k-mer longer than nmax windows (one minimizer repeated: low
       // complexity) becomes several items, and what is written must not reach what has not been read yet.
       uint32_t top = (uint32_t)CAP + 2u;   // items end up in slots top .. CAP + 1
@@ -359,7 +360,7 @@ __global__ __launch_bounds__(kFrThreads) void sk_front_kernel(const uint8_t *__r
           if (jj) it_nx = list[(jj - 1u) * kWave + lane];
           const uint32_t w0 = it & 127u;
           if (jj < cnt && w0 < L) {
-            const uint32_t h20 = sk_bucket_bits20(it >> 7), h18 = h20 >> 2;
+            const uint32_t h27 = sk_bucket_bits27(it >> 7);
             uint32_t left = nxt_w - w0;                 // windows of this super-k-mer (>= 1)
             nxt_w = w0;
             while (left) {                               // (one turn unless the super-k-mer is longer than nmax)
@@ -368,8 +369,8 @@ __global__ __launch_bounds__(kFrThreads) void sk_front_kernel(const uint8_t *__r
               left -= n;
               if (top <= jj || top <= 2u) { top = 0xffffffffu; left = 0; break; }   // no room (CAP items at most, none over an entry still to be read): checked below
               --top;
-              atomicAdd(&hist[h18 >> 10], 1u);
-              list[top * kWave + lane] = (w0 + left) | ((n - 1u) << 7) | (h18 << 12) | ((h20 & 3u) << 30);
+              atomicAdd(&hist[h27 >> 19], 1u);
+              list[top * kWave + lane] = (n - 1u) | (h27 << 5);
             }
             if (top == 0xffffffffu) break;
           }
@@ -418,16 +419,19 @@ __global__ __launch_bounds__(kFrThreads) void sk_front_kernel(const uint8_t *__r
 // range). The round structure, the LDS bucket sort and the copy-out are sk_scatter_kernel's; what differs is where a lane finds
 // its run: run number G of the group lies in the range whose prefix of run counts covers it, its row is read as three aligned
 // 16-byte loads and starts at the run's first base.
-constexpr int kFrRowLds = kFrRowDw + 1;   // odd stride: rows on different banks
+constexpr int kFrRowLds = 11;             // a run's ten packed words (127 + 31 bases) + one: odd stride, rows on different banks
 constexpr uint32_t kFrMaxGroupRanges = 128;
 constexpr int kFrScThreads = 512;         // runs per round of the scatter pass ...
-constexpr int kFrScItems = 7680;          // ... as long as their items fit here (about 14 per run of 120 windows); a round takes fewer runs otherwise
+constexpr int kFrScItems = 7168;          // ... as long as their items fit here (about 13 per run of 120 windows); a round takes fewer runs otherwise
 template <bool CANON>
 __global__ __launch_bounds__(kFrScThreads, 2) void sk_scatter_rows_kernel(const FrRange *__restrict__ info, uint32_t n_ranges, uint32_t rpg, uint32_t run_cap,
                                                                          uint32_t item_cap, uint32_t k, const uint32_t *__restrict__ run_items,
                                                                          const uint32_t *__restrict__ rows, const uint32_t *__restrict__ items,
                                                                          const uint64_t *__restrict__ wg_off, uint64_t *__restrict__ out, uint32_t lp,
-                                                                         const uint32_t *__restrict__ flags) {
+                                                                         bool local_fmt, const uint32_t *__restrict__ flags) {
+  // local_fmt (the records go straight to this GPU's back end, no exchange): nobody reads a record's coarse bits again -- where it
+  // lies says them -- so their place (bits 53..60 of word 1) and bit 61 take NINE further hash bits for sk_reduce2's bins; otherwise
+  // the record keeps its 18 bucket bits as the owner will read them and bits 61..63 take three.
   // (launched before the host has looked at the front end's verdict: a front end that gave up has left tables nobody may walk)
   if (__hip_atomic_load(&flags[9], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
   // One lane per run; the round's items are brought into LDS ONCE (sixteen bytes at a time from each run's list) and everything
@@ -437,7 +441,8 @@ __global__ __launch_bounds__(kFrScThreads, 2) void sk_scatter_rows_kernel(const 
   constexpr int NT = kFrScThreads, CAP = kSkListCap, ICAP = kFrScItems;
   static_assert(ICAP >= CAP, "a run's items must fit a round");
   __shared__ uint16_t s_stage[ICAP];
-  __shared__ uint32_t s_items[ICAP + 4];
+  __shared__ uint32_t s_items[ICAP + 4];    // first window | (n - 1) << 7 | the top 20 hash bits << 12
+  __shared__ uint8_t s_xbits[ICAP];         // the low seven hash bits
   __shared__ uint32_t s_row[NT * kFrRowLds + 4];
   __shared__ uint32_t s_ibase[NT];      // first item of every run in s_items
   __shared__ uint32_t s_cnt[kNumCoarse];
@@ -480,9 +485,11 @@ __global__ __launch_bounds__(kFrScThreads, 2) void sk_scatter_rows_kernel(const 
       const uint4 q0 = rp[0], q1 = rp[1], q2 = rp[2];
       uint32_t *row = s_row + threadIdx.x * kFrRowLds;
       row[0] = q0.x; row[1] = q0.y; row[2] = q0.z; row[3] = q0.w; row[4] = q1.x; row[5] = q1.y; row[6] = q1.z; row[7] = q1.w;
-      row[8] = q2.x; row[9] = q2.y; row[10] = q2.z; row[11] = q2.w; row[12] = 0;
-      // the items: sixteen bytes at a time (a list starts at any dword; what is read behind the run's items is not used)
+      row[8] = q2.x; row[9] = q2.y; row[10] = 0;   // (words 10 and 11 of the row in memory hold no base)
+      // the items: sixteen bytes at a time (a list starts at any dword; what is read behind the run's items is not used). An item's
+      // first window is the sum of the lengths before it.
       const uint32_t *src = g_items + (q * item_cap + (ri & 0x3ffffffu));
+      uint32_t woff = 0;
 #pragma unroll
       for (int v4 = 0; v4 < CAP / 4; ++v4) {
         if ((uint32_t)(4 * v4) < cnt) {
@@ -490,7 +497,13 @@ __global__ __launch_bounds__(kFrScThreads, 2) void sk_scatter_rows_kernel(const 
           const uint32_t it[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
           for (int e = 0; e < 4; ++e)
-            if ((uint32_t)(4 * v4 + e) < cnt) { s_items[pre + 4 * v4 + e] = it[e]; atomicAdd(&s_cnt[(it[e] >> 22) & 255u], 1u); }
+            if ((uint32_t)(4 * v4 + e) < cnt) {
+              const uint32_t n1 = it[e] & 31u, h27 = it[e] >> 5;
+              s_items[pre + 4 * v4 + e] = woff | (n1 << 7) | ((h27 >> 7) << 12);
+              s_xbits[pre + 4 * v4 + e] = (uint8_t)(h27 & 127u);
+              atomicAdd(&s_cnt[h27 >> 19], 1u);
+              woff += n1 + 1u;
+            }
         }
       }
     }
@@ -518,7 +531,7 @@ __global__ __launch_bounds__(kFrScThreads, 2) void sk_scatter_rows_kernel(const 
     // ---- references (run << 5 | item) in bucket order
     for (uint32_t j = 0; j < cnt; ++j) {
       const uint32_t item = s_items[pre + j];
-      s_stage[atomicAdd(&s_cur[(item >> 22) & 255u], 1u)] = (uint16_t)((threadIdx.x << 5) | j);
+      s_stage[atomicAdd(&s_cur[item >> 24], 1u)] = (uint16_t)((threadIdx.x << 5) | j);
     }
     lds_barrier();
     // ---- copy-out: every lane assembles the record of one sorted position
@@ -528,12 +541,16 @@ __global__ __launch_bounds__(kFrScThreads, 2) void sk_scatter_rows_kernel(const 
     for (uint32_t s = threadIdx.x; s < round_items; s += NT) {
       const uint32_t e = s_stage[s], rl = e >> 5, j = e & 31u;
       const uint32_t item = s_items[s_ibase[rl] + j];
-      const uint32_t h18 = (item >> 12) & 0x3ffffu, n1 = (item >> 7) & 31u, extra = item >> 30;
-      // the bucket bits as the owner will read them: the lp rank bits shifted out, the two spare hash bits shifted in below
-      const uint32_t hs = ((h18 << lp) & 0x3ffffu) | (lp <= 2u ? extra >> (2u - lp) : extra << (lp - 2u));
+      const uint32_t h27 = ((item >> 12) << 7) | (uint32_t)s_xbits[s_ibase[rl] + j], n1 = (item >> 7) & 31u;
+      // the bucket bits as the owner will read them: the lp rank bits shifted out, further hash bits shifted in below; three more
+      // (nine in the local format, which gives up the coarse bits) above them for the bins of sk_reduce2
+      const uint32_t hsh = (h27 << lp) & 0x7ffffffu;
+      uint32_t hs = hsh >> 9, top3 = (hsh >> 6) & 7u;
+      if (local_fmt) { hs = (hs & 0x3ffu) | (((hsh >> 1) & 0xffu) << 10); top3 = hsh & 1u; }
       uint64_t w0, w1;
       sk_assemble_row<CANON>(s_row + rl * kFrRowLds, 2u * (item & 127u), k + n1, n1, hs, w0, w1);
-      reinterpret_cast<ulonglong2 *>(out)[s_gbase[h18 >> 10] + s] = make_ulonglong2(w0, w1);
+      w1 |= (uint64_t)top3 << 61;
+      reinterpret_cast<ulonglong2 *>(out)[s_gbase[h27 >> 19] + s] = make_ulonglong2(w0, w1);
     }
     rb += n_taken;
     lds_barrier();   // the stage, the items and the run tables are done with; the counters are clear

@@ -2348,6 +2348,7 @@ __global__ __launch_bounds__(256) void bucket_compact_words_kernel(const uint64_
 }  // namespace kmi
 
 #include "kmi_superkmer.h"
+#include "kmi_reduce2.h"
 #include "kmi_front.h"
 
 // ===========================================================================
@@ -2749,7 +2750,7 @@ static kmi_status sk_front_end(kmi_ctx *ctx, const kmi_config *cfg, const KShape
 // runs fastq_scan + sk_front_end, which also words parse errors.
 template <int W>
 static kmi_status sk_front_fast(kmi_ctx *ctx, const kmi_config *cfg, const KShape &shape, const uint8_t *bytes_dev, size_t n_bytes, uint32_t lp, SkFront *f,
-                                bool *took, uint64_t *out = nullptr, size_t out_cap = 0) {
+                                bool *took, uint64_t *out = nullptr, size_t out_cap = 0, bool local_fmt = false) {
   *took = false;
   f->ok = false;
   if (!ctx->front_fused || cfg->seq_format != KMI_FMT_FASTQ || cfg->seq_filter != KMI_SEQ_ALL || n_bytes < 64) return KMI_OK;
@@ -2813,10 +2814,10 @@ static kmi_status sk_front_fast(kmi_ctx *ctx, const kmi_config *cfg, const KShap
     ProfScope ps(ctx, "sk_scatter", n_bytes);
     if (canonical)
       hipLaunchKernelGGL(sk_scatter_rows_kernel<true>, dim3(kPartGroups), dim3(kFrScThreads), 0, ctx->stream, (const FrRange *)info, n_ranges, rpg, run_cap, item_cap, k,
-                         (const uint32_t *)run_items, (const uint32_t *)rows, (const uint32_t *)items, (const uint64_t *)wg_off, rec_a, lp, (const uint32_t *)ctx->d_flags);
+                         (const uint32_t *)run_items, (const uint32_t *)rows, (const uint32_t *)items, (const uint64_t *)wg_off, rec_a, lp, local_fmt, (const uint32_t *)ctx->d_flags);
     else
       hipLaunchKernelGGL(sk_scatter_rows_kernel<false>, dim3(kPartGroups), dim3(kFrScThreads), 0, ctx->stream, (const FrRange *)info, n_ranges, rpg, run_cap, item_cap, k,
-                         (const uint32_t *)run_items, (const uint32_t *)rows, (const uint32_t *)items, (const uint64_t *)wg_off, rec_a, lp, (const uint32_t *)ctx->d_flags);
+                         (const uint32_t *)run_items, (const uint32_t *)rows, (const uint32_t *)items, (const uint64_t *)wg_off, rec_a, lp, local_fmt, (const uint32_t *)ctx->d_flags);
   };
   // what the host needs of the front end comes back into PINNED memory: four copies queued back to back and one synchronisation
   // (into pageable memory every copy was a host round trip of its own: 0.1 ms of an idle GPU per build)
@@ -2871,7 +2872,8 @@ static kmi_status sk_front_fast_any(kmi_ctx *ctx, const kmi_config *cfg, const K
 // workgroups at wg_off[g][c]) -> fine buckets -> sk_reduce -> the index (layout W | lp << 8), or added to what it holds.
 template <int W>
 static kmi_status sk_back_end(kmi_index *idx, const uint64_t *rec_a, uint64_t R, const uint64_t *h_cnt, const uint64_t *h_base, const uint64_t *wg_off,
-                              uint64_t n, uint32_t lp, bool exact = false) {
+                              uint64_t n, uint32_t lp, bool exact = false, bool local_fmt = false) {
+  // local_fmt: the records carry nine further hash bits where the coarse bits were (sk_scatter_rows_kernel); else three, above the bucket bits
   // exact = false (an index without entries): the fine buckets get room instead of exact offsets, so the records are not read an
   // extra time to be counted (sk_scatter_fine_slack_kernel); a bucket that outgrows its room sends the build through here again
   // with exact = true
@@ -2920,7 +2922,7 @@ static kmi_status sk_back_end(kmi_index *idx, const uint64_t *rec_a, uint64_t R,
     KMI_HIP(ctx, hipMemcpyAsync(d_cap, h_cap, sizeof(h_cap), hipMemcpyHostToDevice, ctx->stream));
     // (the append counters, the k-mer counts, the reduce's votes -- flags 16 .. 33 --, the room flag 34 and the queue word 40)
     hipLaunchKernelGGL(sk_zero_kernel, dim3(96), dim3(1024), 0, ctx->stream, fine_cnt, (uint32_t)kNumFine, fine_kmers, (uint32_t)(kNumFine * kFineParts),
-                       (uint32_t *)nullptr, 0u, ctx->d_flags, 16u, 35u, 40u, 41u);
+                       (uint32_t *)nullptr, 0u, ctx->d_flags, 16u, 35u, 40u, 48u);
     {
       ProfScope ps(ctx, "sk_scatter_fine", R);
       hipLaunchKernelGGL(sk_scatter_fine_slack_kernel, dim3(kNumCoarse * kFineParts), dim3(kPartThreads), 0, ctx->stream, (const uint64_t *)rec_a, rec_b,
@@ -2955,16 +2957,64 @@ static kmi_status sk_back_end(kmi_index *idx, const uint64_t *rec_a, uint64_t R,
   KMI_TRY(ws_get(ctx, WS_BUCKET_CNT, sizeof(uint32_t) * kNumFine, &p)); uint32_t *out_cnt = (uint32_t *)p;
   if (!slack) KMI_HIP(ctx, hipMemsetAsync(ctx->d_flags + 16, 0, sizeof(uint32_t) * 18, ctx->stream));   // the pass-structure votes of sk_reduce (the slack path has zeroed them)
   {
-    ProfScope ps(ctx, "sk_reduce", n);
     const uint32_t nmax = sk_nmax_of(k);
     // persistent workgroups (one per CU: each takes the whole LDS) pull the buckets from a queue word
     uint32_t *queue = ctx->d_flags + 40;
-    if (!slack) KMI_HIP(ctx, hipMemsetAsync(queue, 0, sizeof(uint32_t), ctx->stream));
+    if (!slack) KMI_HIP(ctx, hipMemsetAsync(queue, 0, sizeof(uint32_t) * 8, ctx->stream));   // (+ the redo pass's queue word, the redo count, a spare)
     const uint32_t wgs = ctx->n_cus ? ctx->n_cus : 256u;
+    // KMI_SK_REDUCE=2: sk_reduce2 (wavefront-private tables over the sorted bins of a bucket, kmi_reduce2.h) takes every bucket first;
+    // what it puts on its redo list -- a bin that does not fit a private table, a bucket that does not fit the stage -- goes through
+    // sk_reduce (shared tables, passes) behind it, which reads the list's length on the device. Built for the round-3 verdict and
+    // measured slower than sk_reduce on every input tried: the default is sk_reduce alone.
+    const bool two = ctx->sk_reduce2;
+    const uint32_t *redo_list = nullptr, *redo_cnt = nullptr;
+    if (two) {
+      KMI_TRY(ws_get(ctx, WS_REDO, sizeof(uint32_t) * kNumFine, &p)); uint32_t *rl = (uint32_t *)p;
+      redo_list = rl; redo_cnt = ctx->d_flags + 42;
+      // window of a batch: 64 records while a window's k-mers are mostly copies of one another; smaller where the last build found
+      // little duplication (a window's distinct k-mers have to fit a private table)
+      const float dupl = ctx->sk_inv_dup;
+      const uint32_t win = ctx->sk_r2_win ? ctx->sk_r2_win : (dupl <= 0.2f ? 32u : (dupl <= 0.45f ? 24u : 16u));
+      const uint32_t xshift = local_fmt ? 53u : 61u, xbits = local_fmt ? (uint32_t)(kR2BinBitsMax - 3) : 3u;
+      ProfScope ps(ctx, "sk_reduce", n);   // (the profile keeps the name of the kernel it replaced)
+#define KMI_SK_REDUCE2(CANON, OWN, SPECIAL)                                                                                              \
+      hipLaunchKernelGGL((sk_reduce2_kernel<CANON, OWN, SPECIAL>), dim3(wgs * kR2PerCu), dim3(KMI_R2_WAVES * 64), 0, ctx->stream, (const uint64_t *)rec_b, \
+                         (const uint64_t *)fine_off, k, (const uint64_t *)kmer_off, tmp_keys, tmp_vals, out_cnt, ctx->d_flags, queue, (uint32_t)kNumFine, \
+                         xshift, xbits, win, (const uint64_t *)d_region, (const uint32_t *)d_cap, (const uint32_t *)fine_cnt, rl, ctx->d_flags + 42)
+      // (second parameter: bytes of unit marks of a step -- 64 records of (nmax + 1) / 2 units)
+      if (k == 32u) { if (canonical) KMI_SK_REDUCE2(true, 64 * 11, true); else KMI_SK_REDUCE2(false, 64 * 11, true); }   // (a 32-mer can equal the empty marker)
+      else if (nmax <= 22u) { if (canonical) KMI_SK_REDUCE2(true, 64 * 11, false); else KMI_SK_REDUCE2(false, 64 * 11, false); }
+      else { if (canonical) KMI_SK_REDUCE2(true, 64 * 16, false); else KMI_SK_REDUCE2(false, 64 * 16, false); }
+#undef KMI_SK_REDUCE2
+      queue = ctx->d_flags + 41;
+#ifdef KMI_R2_TIMING
+      {
+        unsigned long long t[8];
+        hipStreamSynchronize(ctx->stream);
+        hipMemcpy(t, ctx->d_flags + 48, sizeof(t), hipMemcpyDeviceToHost);
+        fprintf(stderr, "sk_reduce2 wave clocks: count %llu  scan+place %llu  grab/wait-in-batches %llu  dedupe+expand %llu  emit %llu  barrier-after-place %llu  barrier-after-batches %llu  between %llu\n", t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[7]);
+        hipMemset(ctx->d_flags + 48, 0, sizeof(t));
+        unsigned long long d[128];
+        hipMemcpyFromSymbol(d, HIP_SYMBOL(g_r2_dbg), sizeof(d));
+        fprintf(stderr, "  per wavefront number (Mcycles in the batch phase / batches / steps / expand iterations):");
+        for (int w = 0; w < KMI_R2_WAVES; ++w) fprintf(stderr, "  %d: %.0f/%llu/%llu/%llu", w, d[w] / 1e6, d[32 + w], d[64 + w], d[96 + w]);
+        fprintf(stderr, "\n");
+        memset(d, 0, sizeof(d));
+        hipMemcpyToSymbol(HIP_SYMBOL(g_r2_dbg), d, sizeof(d));
+      }
+#endif
+      if (getenv("KMI_R2_DEBUG")) {
+        uint32_t st[8];
+        hipStreamSynchronize(ctx->stream);
+        hipMemcpy(st, ctx->d_flags + 40, sizeof(st), hipMemcpyDeviceToHost);
+        fprintf(stderr, "sk_reduce2: redo list %u buckets (stage: gave up %u, a part too large %u; batches that did not fit their table %u; buckets in parts %u), window %u\n", st[2], st[4], st[6], st[5], st[7], win);
+      }
+    }
+    ProfScope ps(ctx, two ? "sk_reduce_redo" : "sk_reduce", n);
 #define KMI_SK_REDUCE(CANON, OWN, SPECIAL)                                                                                               \
     hipLaunchKernelGGL((sk_reduce_kernel<CANON, OWN, SPECIAL>), dim3(wgs), dim3(KMI_SK_NT), 0, ctx->stream, (const uint64_t *)rec_b,        \
                        (const uint64_t *)fine_off, k, (const uint64_t *)kmer_off, tmp_keys, tmp_vals, out_cnt, ctx->d_flags, queue, (uint32_t)kNumFine, \
-                       ctx->sk_level_hint, lp, ctx->sk_inv_dup, (const uint64_t *)d_region, (const uint32_t *)d_cap, (const uint32_t *)fine_cnt)
+                       ctx->sk_level_hint, lp, ctx->sk_inv_dup, (const uint64_t *)d_region, (const uint32_t *)d_cap, (const uint32_t *)fine_cnt, redo_list, redo_cnt)
     if (k == 32u) { if (canonical) KMI_SK_REDUCE(true, 64 * 21, true); else KMI_SK_REDUCE(false, 64 * 21, true); }   // (a 32-mer can equal the empty marker)
     else if (nmax <= 21u) { if (canonical) KMI_SK_REDUCE(true, 64 * 21, false); else KMI_SK_REDUCE(false, 64 * 21, false); }
     else if (nmax <= 24u) { if (canonical) KMI_SK_REDUCE(true, 64 * 24, false); else KMI_SK_REDUCE(false, 64 * 24, false); }
@@ -3017,7 +3067,7 @@ static kmi_status sk_back_end(kmi_index *idx, const uint64_t *rec_a, uint64_t R,
     }
     if (slack && *reinterpret_cast<const uint32_t *>(ctx->h_totals + 14)) {
       KMI_TRY(kmi_index_clear(idx));
-      return sk_back_end<W>(idx, rec_a, R, h_cnt, h_base, wg_off, n, lp, true);
+      return sk_back_end<W>(idx, rec_a, R, h_cnt, h_base, wg_off, n, lp, true, local_fmt);
     }
     read_levels();
     idx->layout_w = layout;
@@ -3146,11 +3196,11 @@ static kmi_status build_superkmer_fast_w(kmi_index *idx, const uint8_t *bytes_de
   *done = false;
   SkFront f;
   bool took = false;
-  KMI_TRY((sk_front_fast<W>(idx->ctx, &idx->cfg, idx->shape, bytes_dev, n_bytes, 0u, &f, &took)));
+  KMI_TRY((sk_front_fast<W>(idx->ctx, &idx->cfg, idx->shape, bytes_dev, n_bytes, 0u, &f, &took, nullptr, 0, true)));
   if (!took || !f.ok) return KMI_OK;
   *done = true;
   if (f.n_kmers == 0) return KMI_OK;
-  return sk_back_end<W>(idx, f.recs, f.n_records, f.h_cnt, f.h_base, f.wg_off, f.n_kmers, 0u);
+  return sk_back_end<W>(idx, f.recs, f.n_records, f.h_cnt, f.h_base, f.wg_off, f.n_kmers, 0u, false, true);
 }
 
 static kmi_status index_build_fused(kmi_index *idx, const uint8_t *bytes_dev, size_t n_bytes) {

@@ -54,6 +54,7 @@ enum WsSlot {
   WS_DBG_RECS,        // de Bruijn node build: (k-mer, edge) records of the parsed input
   WS_DBG_OLD,         // ... keys and bucket offsets of the nodes before an insert (their edge counts move to the new order)
   WS_DBG_POS,         // ... entry positions of the nodes a find() hit
+  WS_REDO,            // sk_reduce2's redo list: buckets that go through sk_reduce behind it
   WS_ALIGNED,         // 16-byte aligned copy of an input buffer that arrived at an odd address (a batch inside a larger buffer)
   WS_NUM_SLOTS
 };
@@ -94,6 +95,8 @@ struct kmi_ctx {
   bool force_dist = false;       // KMI_FORCE_DIST=1: the *_dist_* entry points run their exchange even with one rank (RCCL self exchange: tests)
   uint32_t sk_level_hint = 0;    // sk_reduce: filter bits the buckets of the next build start with (majority of the last build)
   float sk_inv_dup = 0.f;        // sk_reduce: distinct k-mers per k-mer occurrence of the last build (a bucket's expected fill; 0: unknown)
+  bool sk_reduce2 = false;       // KMI_SK_REDUCE=2: sk_reduce2 (wavefront-private tables over sorted bins, kmi_reduce2.h) ahead of sk_reduce -- measured slower
+  uint32_t sk_r2_win = 0;        // records of sk_reduce2's batch window (KMI_R2_WIN: test knob; 0: by the last build's duplication)
   uint32_t dist_chunks = 4;      // record-aligned chunks of a rank's share in the build over ranks (exchange of one beside the front end of the next; KMI_DIST_CHUNKS)
   bool sk_slack = true;          // fine buckets with room instead of a counting pass (sk_scatter_fine_slack_kernel); KMI_SK_SLACK=0: always count
   bool front_fused = true;       // FASTQ front end of the super-k-mer build in one pass (kmi_front.h); KMI_FRONT=general: scan + list + minimizer

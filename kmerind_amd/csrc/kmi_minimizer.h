@@ -35,6 +35,15 @@ __device__ __forceinline__ uint32_t sk_bucket_bits20(uint32_t hv25) {
   return h >> 12;   // 20 bits: the 18 bucket bits and two more below them (a build over ranks fills the sub-bucket bits it shifts out with them)
 }
 __device__ __forceinline__ uint32_t sk_bucket_bits(uint32_t hv25) { return sk_bucket_bits20(hv25) >> 2; }   // 18 bits
+// the same hash, 27 bits: the 20 above and seven more below them -- the one-pass front end's items carry all of them, the records
+// what fits (kmi_reduce2.h sorts a fine bucket's records by the bits beyond the bucket: k-mers that differ there never meet)
+__device__ __forceinline__ uint32_t sk_bucket_bits27(uint32_t hv25) {
+  uint32_t h = (hv25 ^ 0x5bd1e995u) * 0x85EBCA6Bu;
+  h ^= h >> 13;
+  h *= 0xC2B2AE35u;
+  h ^= h >> 16;
+  return h >> 5;
+}
 // forward strand of an m-mer from its complement-stream window (m <= 16: 32 bits)
 __device__ __forceinline__ uint32_t sk_fwd_of(uint32_t r, uint32_t m) {
   uint32_t x = __builtin_bitreverse32(~r);                    // complement codes -> forward codes, first base to the top

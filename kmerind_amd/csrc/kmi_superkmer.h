@@ -667,15 +667,29 @@ __global__ __launch_bounds__(kPartThreads) void sk_recv_hist_kernel(const uint64
                             // 512: 3.60 - 3.63 (same wavefronts per CU, twice the passes); 1024 threads / 80 KB, H1 512 / 256: 7.0 / 8.2 ms
 #endif
 // slot hash of the k-mer table (private to this kernel: two multiplies instead of the placement hash's three)
+#ifndef KMI_SK_HASH24
+#define KMI_SK_HASH24 1
+#endif
 __device__ __forceinline__ uint32_t sk_slot_hash(uint64_t key) {
+#if KMI_SK_HASH24
+  // three 24-bit multiplies (full rate; a 32-bit multiply issues at a quarter of it) over the key's bits 0..23, 24..47, 48..63
+  const uint32_t lo = (uint32_t)key, hi = (uint32_t)(key >> 32);
+  uint32_t h = __umul24(lo, 0x9E3779u);
+  h += __umul24(__builtin_amdgcn_alignbit(hi, lo, 24), 0x85EBCBu);
+  h += __umul24(hi >> 16, 0xC2B2AFu);
+#else
   uint32_t h = ((uint32_t)key ^ ((uint32_t)(key >> 32) * 0x85EBCA6Bu)) * 0x9E3779B1u;
+#endif
   h ^= h >> 15;
   return h;
 }
-__device__ __forceinline__ uint32_t sk_slot_of(uint32_t h, uint32_t cap) { return ((h >> 16) * cap) >> 16; }   // (cap < 2^16: a 24-bit multiply)
+__device__ __forceinline__ uint32_t sk_slot_of(uint32_t h, uint32_t cap) { return __umul24(h >> 16, cap) >> 16; }   // (cap < 2^16: a 24-bit multiply)
 
 // the slow path of the k-mer table, out of line: queue entries [first, first + cnt) (key, weight), one per lane
-__device__ __attribute__((noinline)) uint32_t sk_probe_insert(lds_u64_t *tkeys, lds_u32_t *tvals, lds_u32_t *distinct, lds_u32_t *overflow,
+#ifndef KMI_SK_PROBE_ATTR
+#define KMI_SK_PROBE_ATTR __forceinline__   // (an out-of-line function begins with s_waitcnt vmcnt(0): every call waited for the record loads in flight)
+#endif
+__device__ KMI_SK_PROBE_ATTR uint32_t sk_probe_insert(lds_u64_t *tkeys, lds_u32_t *tvals, lds_u32_t *distinct, lds_u32_t *overflow,
                                                          const lds_u64_t *q, const lds_u32_t *qw, uint32_t first, uint32_t cnt,
                                                          uint32_t cap, uint32_t last, uint32_t limit, uint32_t pending) {
   const uint32_t lane = lane_id();
@@ -743,7 +757,12 @@ __global__ __launch_bounds__(KMI_SK_NT) void sk_reduce_kernel(const uint64_t *__
                                                         uint32_t *__restrict__ queue /* zero at launch: the next bucket to hand out */, uint32_t n_buckets,
                                                         uint32_t start_bits, uint32_t lp, float inv_dup,
                                                         const uint64_t *__restrict__ fine_region = nullptr, const uint32_t *__restrict__ fine_cap = nullptr,
-                                                        const uint32_t *__restrict__ fine_cnt = nullptr) {
+                                                        const uint32_t *__restrict__ fine_cnt = nullptr,
+                                                        const uint32_t *__restrict__ redo_list = nullptr, const uint32_t *__restrict__ redo_cnt = nullptr) {
+  // redo_list / redo_cnt (behind sk_reduce2_kernel, kmi_reduce2.h): the queue hands out positions of this list of bucket numbers
+  // instead of the buckets 0 .. n_buckets - 1; an empty list ends the launch at once
+  if (redo_cnt) { n_buckets = __hip_atomic_load(redo_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); if (n_buckets == 0u) return; }
+  auto bid = [&](uint32_t q) -> uint32_t { return redo_list ? redo_list[q] : q; };
   // fine_region / fine_cap / fine_cnt (the slack scatter's layout): bucket b's records are fine_cnt[b] records from
   // fine_region[b >> 7] + (b & 127) * fine_cap[b >> 7]; null: records [rec_off[b], rec_off[b + 1])
   auto records_of = [&](uint32_t bb, uint64_t &lo, uint64_t &hi) {
@@ -783,6 +802,7 @@ __global__ __launch_bounds__(KMI_SK_NT) void sk_reduce_kernel(const uint64_t *__
   for (uint32_t i = threadIdx.x; i < (uint32_t)(NWAVES * T::OWN / 4); i += T::NT) reinterpret_cast<uint32_t *>(s_own)[i] = 0;
   for (uint32_t i = threadIdx.x; i < (uint32_t)T::S2; i += T::NT) { s_tk[i] = kEmptyKey; s_tv[i] = 0; }
   for (uint32_t i = threadIdx.x; i < (uint32_t)T::S1; i += T::NT) { s_r[i] = make_ulonglong2(kEmptyKey, W1_INIT); s_rc[i] = 0; }
+  for (uint32_t i = threadIdx.x; i < (uint32_t)(NWAVES * kMissQ); i += T::NT) s_missq[i] = 0;   // (to_table2's idle compare-and-swaps land here: never the empty marker)
   if (threadIdx.x < 12) s_ctl[threadIdx.x] = 0;
   if (threadIdx.x == 0) s_ctl[C_NEXT] = atomicAdd(queue, 1u);
   lds_barrier();
@@ -817,6 +837,48 @@ __global__ __launch_bounds__(KMI_SK_NT) void sk_reduce_kernel(const uint64_t *__
       const uint32_t pos = mn + __builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0u));
       if (miss) { mq[pos] = key; mw[pos] = kw; }
       mn += (uint32_t)__popcll(mm);
+      if (mn >= (uint32_t)kWave) {
+        pending = sk_probe_insert(tkeys, tvals, tdist, tovf, (const lds_u64_t *)mq, (const lds_u32_t *)mw, mn - kWave, kWave, (uint32_t)T::CAP2,
+                                  (uint32_t)T::S2 - 1u, (uint32_t)T::LIMIT2, pending);
+        mn -= kWave;
+      }
+    }
+  };
+  // the same for the TWO k-mers of a unit, without a branch: both home slots and their neighbours are read together; a lane that has
+  // nothing to claim sends its compare-and-swap to a word of its wavefront's miss queue (never the empty marker), a lane without a
+  // hit adds zero. (One k-mer at a time, each behind `if`s: 270 instructions per step of which 100 moved the exec mask about; 190 so.)
+  uint64_t *const cas_dummy = mq + kWave + lane;
+  auto to_table2 = [&](uint64_t ka, bool va, uint64_t kc, bool vc, uint32_t kw) {
+    const uint32_t hA = sk_slot_hash(ka), hC = sk_slot_hash(kc);
+    const uint32_t sa = sk_slot_of(hA, (uint32_t)T::CAP2), sc = sk_slot_of(hC, (uint32_t)T::CAP2);
+    va = va && (hA & hmask) == hval; vc = vc && (hC & hmask) == hval;
+    if (SPECIAL) {   // (k = 32 only)
+      if (va && ka == kEmptyKey) { s_ctl[C_SPS] = 1; atomicAdd(&s_ctl[C_SPC], kw); va = false; }
+      if (vc && kc == kEmptyKey) { s_ctl[C_SPS] = 1; atomicAdd(&s_ctl[C_SPC], kw); vc = false; }
+    }
+    const uint64_t a0 = __atomic_load_n(&s_tk[sa], __ATOMIC_RELAXED), a1 = __atomic_load_n(&s_tk[sa + 1u], __ATOMIC_RELAXED);
+    const uint64_t c0 = __atomic_load_n(&s_tk[sc], __ATOMIC_RELAXED), c1 = __atomic_load_n(&s_tk[sc + 1u], __ATOMIC_RELAXED);
+    const bool ta = va && a0 == kEmptyKey, tc = vc && c0 == kEmptyKey;
+    const unsigned long long oa = atomicCAS((unsigned long long *)(ta ? &s_tk[sa] : cas_dummy), (unsigned long long)kEmptyKey, (unsigned long long)ka);
+    const unsigned long long oc = atomicCAS((unsigned long long *)(tc ? &s_tk[sc] : cas_dummy), (unsigned long long)kEmptyKey, (unsigned long long)kc);
+    const bool wa_ = ta && oa == kEmptyKey, wc_ = tc && oc == kEmptyKey;
+    const bool ha0 = va && (a0 == ka || wa_ || (ta && oa == ka)), hc0 = vc && (c0 == kc || wc_ || (tc && oc == kc));
+    const bool ha1 = va && !ha0 && a1 == ka, hc1 = vc && !hc0 && c1 == kc;
+    my_claims += (wa_ ? 1u : 0u) + (wc_ ? 1u : 0u);
+    atomicAdd(&s_tv[sa + (ha1 ? 1u : 0u)], (ha0 || ha1) ? kw : 0u);
+    atomicAdd(&s_tv[sc + (hc1 ? 1u : 0u)], (hc0 || hc1) ? kw : 0u);
+    const bool ma = va && !ha0 && !ha1, mc = vc && !hc0 && !hc1;
+    const unsigned long long mma = __ballot(ma), mmc = __ballot(mc);
+    if (mma | mmc) {   // uniform
+      if (ma) { const uint32_t pos = mn + __builtin_amdgcn_mbcnt_hi((uint32_t)(mma >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mma, 0u)); mq[pos] = ka; mw[pos] = kw; }
+      mn += (uint32_t)__popcll(mma);
+      if (mn >= (uint32_t)kWave) {
+        pending = sk_probe_insert(tkeys, tvals, tdist, tovf, (const lds_u64_t *)mq, (const lds_u32_t *)mw, mn - kWave, kWave, (uint32_t)T::CAP2,
+                                  (uint32_t)T::S2 - 1u, (uint32_t)T::LIMIT2, pending);
+        mn -= kWave;
+      }
+      if (mc) { const uint32_t pos = mn + __builtin_amdgcn_mbcnt_hi((uint32_t)(mmc >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mmc, 0u)); mq[pos] = kc; mw[pos] = kw; }
+      mn += (uint32_t)__popcll(mmc);
       if (mn >= (uint32_t)kWave) {
         pending = sk_probe_insert(tkeys, tvals, tdist, tovf, (const lds_u64_t *)mq, (const lds_u32_t *)mw, mn - kWave, kWave, (uint32_t)T::CAP2,
                                   (uint32_t)T::S2 - 1u, (uint32_t)T::LIMIT2, pending);
@@ -872,8 +934,12 @@ __global__ __launch_bounds__(KMI_SK_NT) void sk_reduce_kernel(const uint64_t *__
       const uint32_t fw2_hi = __builtin_amdgcn_alignbit(fw_hi, fw_lo, 30u) & kmask_hi;
       const uint64_t rc = (uint64_t)rc_lo | ((uint64_t)rc_hi << 32), fw = (uint64_t)fw_lo | ((uint64_t)fw_hi << 32);
       const uint64_t rc2 = (uint64_t)rc2_lo | ((uint64_t)rc2_hi << 32), fw2 = (uint64_t)fw2_lo | ((uint64_t)fw2_hi << 32);
+#ifndef KMI_SK_INSERT1
+      to_table2(CANON ? (fw < rc ? fw : rc) : fw, act, CANON ? (fw2 < rc2 ? fw2 : rc2) : fw2, two, kw);
+#else
       to_table(CANON ? (fw < rc ? fw : rc) : fw, kw, act);
       to_table(CANON ? (fw2 < rc2 ? fw2 : rc2) : fw2, kw, two);
+#endif
     }
     if (nu) wown[pre] = 0;   // the marks go back to zero for the next batch
     // fill level: this batch's in-line claims go to the shared counter (one scan + one LDS add per batch of records)
@@ -897,7 +963,8 @@ __global__ __launch_bounds__(KMI_SK_NT) void sk_reduce_kernel(const uint64_t *__
     uint32_t q_next = 0;
     if (threadIdx.x == 0) q_next = atomicAdd(queue, 1u);   // (stays in a register until phase A is done: nobody waits for it)
     uint64_t rb = pf_rb, re = pf_re;
-    if (!pf_ok) records_of(b, rb, re);
+    const uint32_t bkt = bid(b);
+    if (!pf_ok) records_of(bkt, rb, re);
     const uint32_t n_rec = (uint32_t)(re - rb);
     const ulonglong2 *const src = reinterpret_cast<const ulonglong2 *>(recs) + rb;
     const uint32_t share = (n_rec + NWAVES - 1) / NWAVES;
@@ -905,7 +972,7 @@ __global__ __launch_bounds__(KMI_SK_NT) void sk_reduce_kernel(const uint64_t *__
     const uint32_t r_hi = r_lo + share < n_rec ? r_lo + share : n_rec;
     ulonglong2 first = pf;
     if (!pf_ok) { first = make_ulonglong2(0, 0); if (r_lo + lane < r_hi) first = src[r_lo + lane]; }
-    const uint64_t tmp0 = pf_ok ? pf_k0 : kmer_off[b], tmp1 = pf_ok ? pf_k1 : kmer_off[b + 1];
+    const uint64_t tmp0 = pf_ok ? pf_k0 : kmer_off[bkt], tmp1 = pf_ok ? pf_k1 : kmer_off[bkt + 1];
     pf_ok = false;
     if (threadIdx.x == 0) {
       uint32_t hb = start_bits > 8u ? 8u : start_bits;
@@ -1000,7 +1067,7 @@ __global__ __launch_bounds__(KMI_SK_NT) void sk_reduce_kernel(const uint64_t *__
       uint32_t nbk = 0;
       if (first_pass) {   // the next bucket's range: two scalar loads that return during phase B
         nbk = __builtin_amdgcn_readfirstlane(s_ctl[C_NEXT + par]);
-        if (nbk < n_buckets) { records_of(nbk, pf_rb, pf_re); pf_k0 = kmer_off[nbk]; pf_k1 = kmer_off[nbk + 1]; }
+        if (nbk < n_buckets) { const uint32_t nbkt = bid(nbk); records_of(nbkt, pf_rb, pf_re); pf_k0 = kmer_off[nbkt]; pf_k1 = kmer_off[nbkt + 1]; }
       }
       // ---- phase B: every distinct record once with its multiplicity, then the overflow list; the slots are left empty
       if (use_t1) {
@@ -1099,7 +1166,7 @@ __global__ __launch_bounds__(KMI_SK_NT) void sk_reduce_kernel(const uint64_t *__
       TQ_MARK(5)
     }
     if (threadIdx.x == 0) {
-      out_cnt[b] = s_ctl[C_EMIT];
+      out_cnt[bkt] = s_ctl[C_EMIT];
       if (n_rec && (s_ctl[C_LVL] || start_bits)) atomicAdd(&flags[16 + (s_ctl[C_LVL] > 8u ? 8u : s_ctl[C_LVL])], 1u);
     }
     if (n_rec == 0u && threadIdx.x == 0) s_ctl[C_NEXT + par] = q_next;   // (an empty bucket never reached the pass loop)

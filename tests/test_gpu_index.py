@@ -632,6 +632,40 @@ def test_superkmer_build_ran_and_matches_oracle(ctx, k, strand):
     idx.close()
 
 
+@pytest.mark.parametrize("k,strand,win", [(31, "canonical", 0), (32, "single", 16), (21, "canonical", 64), (27, "single", 0)])
+def test_reduce2_opt_in_matches_oracle(monkeypatch, k, strand, win):
+    """KMI_SK_REDUCE=2 puts sk_reduce2 (kmi_reduce2.h: a bucket's records counting-sorted by further minimizer-hash bits in LDS,
+    wavefront-private tables over whole bins) ahead of sk_reduce, which then only redoes what sk_reduce2 declined. It is not the
+    default (measured slower), but it must stay the oracle's map: buckets of a few thousand records, both strand models, the
+    k = 32 key that equals the empty marker, several window sizes, and a second build into the existing entries."""
+    import kmerind_amd as K
+    monkeypatch.setenv("KMI_SK_REDUCE", "2")
+    if win:
+        monkeypatch.setenv("KMI_R2_WIN", str(win))
+    c2 = K.Context(0)
+    s = orc.kspec(k, orc.DNA)
+    data = K.synth_fastq(seed=11 * k, genome_len=150_000, n_reads=30_000)
+    if k == 32:   # reads of T only: the single-strand 32-mer of all ones is the table's empty marker
+        rec = np.frombuffer(b"@x\n" + b"T" * 150 + b"\n+\n" + b"I" * 150 + b"\n", dtype=np.uint8)
+        data = np.concatenate([data] + [rec] * 40)
+    idx = K.CountIndex(c2, K.make_config(k, "DNA", strand=strand))
+    c2.profile(True)
+    c2.profile_reset()
+    idx.build(data)
+    names = {p["name"] for p in c2.profile_get() if p["launches"]}
+    c2.profile(False)
+    assert {"sk_reduce", "sk_reduce_redo"} <= names, names
+    om = orc.CountMap(s, STRAND[strand])
+    om.insert(orc.extract(s, data, orc.FASTQ)["kmers"])
+    _same_map(idx, om)
+    more = K.synth_fastq(seed=13 * k, genome_len=150_000, n_reads=4_000)
+    idx.build(more)
+    om.insert(orc.extract(s, more, orc.FASTQ)["kmers"])
+    _same_map(idx, om)
+    idx.close()
+    c2.close()
+
+
 @pytest.mark.parametrize("k,strand", [(31, "canonical"), (23, "single")])
 def test_sparse_index_after_superkmer_build(monkeypatch, k, strand):
     """A large super-k-mer build leaves the reduce's output buffers as the index (per-bucket start + count, unused slots behind
