@@ -44,7 +44,8 @@ typedef enum {
   KMI_ERR_DEVICE = 2,  /* HIP runtime failure, no device */
   KMI_ERR_PARSE = 3,   /* malformed FASTQ/FASTA (reference throws std::logic_error) */
   KMI_ERR_NOMEM = 4,
-  KMI_ERR_OVERFLOW = 5 /* id overflow (sequence.hpp:177-183) or capacity exceeded */
+  KMI_ERR_OVERFLOW = 5, /* id overflow (sequence.hpp:177-183) or capacity exceeded */
+  KMI_ERR_PEER = 6      /* a collective ended because ANOTHER rank reported an error (this rank's own state is unchanged or as documented) */
 } kmi_status;
 
 enum { KMI_ALPHA_DNA = 0, KMI_ALPHA_DNA5 = 1,                   /* alphabets.hpp:127-185, 212-285 (DNA5 == DNA6) */
@@ -94,6 +95,9 @@ kmi_status kmi_ctx_destroy(kmi_ctx *ctx);
 /* forget what the context learned from its builds so far (the pass structure and the duplication the per-bucket reduce starts
  * from): the next build runs as the first one of a context would, with the workspace blocks still in place */
 kmi_status kmi_ctx_reset_hints(kmi_ctx *ctx);
+/* counters the library keeps for its tests and for diagnosis (no reference counterpart). which = 0: times a build over ranks had to
+ * enlarge its receive pool (kmi_index_build_dist_dev) */
+kmi_status kmi_ctx_debug_counter(const kmi_ctx *ctx, uint32_t which, uint64_t *value);
 const char *kmi_last_error(const kmi_ctx *ctx);
 /* derived Kmer shape (padding.hpp:67-90): words per k-mer, hashed byte length */
 kmi_status kmi_kmer_shape(const kmi_config *cfg, uint32_t *n_words, uint32_t *n_bits, uint32_t *n_bytes);
@@ -332,6 +336,21 @@ typedef struct kmi_comm kmi_comm;
 enum { KMI_COMM_ID_BYTES = 128 };
 kmi_status kmi_comm_unique_id(void *id_out /* KMI_COMM_ID_BYTES */);
 kmi_status kmi_comm_create(kmi_ctx *ctx, const void *id /* NULL allowed when nranks == 1 */, kmi_comm **out);
+/* A communicator over a messenger the APPLICATION brings instead of RCCL: the two collectives imxx::distribute needs
+ * (incremental_mxx.hpp:1087 all2all, :1098 all2allv) and the all-reduce behind size() (distributed_map_base.hpp:227-245), as
+ * callbacks over HOST buffers -- an MPI communicator (the reference's own mxx::comm: INTEGRATION.md section 4), gloo, sockets.
+ * The library stages device buffers through pinned host memory around each call, so everything built on a communicator --
+ * kmi_index_*_dist_*, kmi_dbg_*_dist_* -- runs unchanged where RCCL is not an option (ranks sharing one GPU, a cluster without
+ * xGMI). Both callbacks are collective and blocking; they return 0 on success. */
+typedef struct kmi_transport {
+  void *user;
+  /* rank r receives send_bytes[r] bytes from this rank (the messages lie back to back in `send`, rank 0's first) and this
+   * rank receives recv_bytes[r] bytes from rank r into `recv`, back to back by source rank */
+  int (*all_to_all_v)(void *user, const void *send, const uint64_t *send_bytes, void *recv, const uint64_t *recv_bytes);
+  /* values[0..n) are replaced by their sum (op 0) or maximum (op 1) over the ranks */
+  int (*allreduce_u64)(void *user, uint64_t *values, size_t n, int op);
+} kmi_transport;
+kmi_status kmi_comm_create_transport(kmi_ctx *ctx, const kmi_transport *transport /* copied */, kmi_comm **out);
 kmi_status kmi_comm_destroy(kmi_comm *comm);
 kmi_status kmi_comm_all_to_all_counts(kmi_comm *comm, const uint64_t *send_counts_host, uint64_t *recv_counts_host);
 kmi_status kmi_comm_all_to_all_v(kmi_comm *comm, const void *send_dev, const uint64_t *send_counts_host, void *recv_dev,

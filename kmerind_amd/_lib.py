@@ -16,7 +16,7 @@ if not os.path.exists(LIB_PATH):
 
 lib = C.CDLL(LIB_PATH)
 
-OK, ERR_INVALID, ERR_DEVICE, ERR_PARSE, ERR_NOMEM, ERR_OVERFLOW = range(6)
+OK, ERR_INVALID, ERR_DEVICE, ERR_PARSE, ERR_NOMEM, ERR_OVERFLOW, ERR_PEER = range(7)
 ALPHA_DNA, ALPHA_DNA5, ALPHA_RNA, ALPHA_RNA5, ALPHA_DNA16 = 0, 1, 2, 3, 4
 STRAND_SINGLE, STRAND_CANONICAL, STRAND_BIMOLECULE = 0, 1, 2
 HASH_MURMUR, HASH_FARM, HASH_IDENTITY, HASH_STD = 0, 1, 2, 3
@@ -115,6 +115,8 @@ SIGNATURES = {
     "kmi_index_merge_parts_dev": (C.c_int, [_P, _u32, _P, _P, _P]),
     "kmi_comm_unique_id": (C.c_int, [_P]),
     "kmi_comm_create": (C.c_int, [_P, _P, C.POINTER(_P)]),
+    "kmi_ctx_debug_counter": (C.c_int, [_P, _u32, C.POINTER(_u64)]),
+    "kmi_comm_create_transport": (C.c_int, [_P, _P, C.POINTER(_P)]),
     "kmi_comm_destroy": (C.c_int, [_P]),
     "kmi_comm_all_to_all_counts": (C.c_int, [_P, _P, _P]),
     "kmi_comm_all_to_all_v": (C.c_int, [_P, _P, _P, _P, _P, _sz]),

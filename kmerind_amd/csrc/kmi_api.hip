@@ -170,6 +170,8 @@ kmi_status kmi_ctx_create(int device, int rank, int nranks, void *stream, kmi_ct
   if (const char *dg = getenv("KMI_SK_DBG")) ctx->sk_dbg = atoi(dg);
   if (const char *dc = getenv("KMI_DIST_CHUNKS")) { ctx->dist_chunks = (uint32_t)atoi(dc); if (ctx->dist_chunks < 1) ctx->dist_chunks = 1; if (ctx->dist_chunks > 64) ctx->dist_chunks = 64; }
   if (const char *sl = getenv("KMI_SK_SLACK")) ctx->sk_slack = atoi(sl) != 0;
+  if (const char *ps = getenv("KMI_DIST_POOL_SLACK")) ctx->dist_pool_slack = strtoull(ps, nullptr, 10);
+  if (const char *pp = getenv("KMI_DIST_POOL_PCT")) { ctx->dist_pool_pct = (uint32_t)atoi(pp); if (ctx->dist_pool_pct < 1) ctx->dist_pool_pct = 1; }
   if (const char *r2 = getenv("KMI_SK_REDUCE")) ctx->sk_reduce2 = atoi(r2) == 2;
   if (const char *ws = getenv("KMI_R2_WIN")) { ctx->sk_r2_win = (uint32_t)atoi(ws); if (ctx->sk_r2_win && ctx->sk_r2_win < 16) ctx->sk_r2_win = 16; if (ctx->sk_r2_win > 256) ctx->sk_r2_win = 256; }
   if (const char *fr = getenv("KMI_FRONT")) ctx->front_fused = strcmp(fr, "general") != 0;
@@ -198,6 +200,14 @@ kmi_status kmi_ctx_reset_hints(kmi_ctx *ctx) {
   if (!ctx) return KMI_ERR_INVALID;
   ctx->sk_level_hint = 0; ctx->sk_inv_dup = 0.f;
   return KMI_OK;
+}
+
+kmi_status kmi_ctx_debug_counter(const kmi_ctx *ctx, uint32_t which, uint64_t *value) {
+  if (!ctx || !value) return KMI_ERR_INVALID;
+  switch (which) {
+    case 0: *value = ctx->dist_pool_regrows; return KMI_OK;
+    default: return KMI_ERR_INVALID;
+  }
 }
 
 kmi_status kmi_ctx_destroy(kmi_ctx *ctx) {

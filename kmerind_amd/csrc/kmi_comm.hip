@@ -79,6 +79,10 @@ __global__ __launch_bounds__(256) void message_sums_kernel(const uint64_t *__res
 struct kmi_comm {
   kmi_ctx *ctx = nullptr;
   ncclComm_t_ nccl = nullptr;
+  bool has_transport = false;     // kmi_comm_create_transport: the application's messenger over host buffers instead of RCCL
+  kmi_transport transport{};
+  char *h_stage[2] = {nullptr, nullptr};   // pinned staging of a transport exchange (send, receive), grown on demand
+  size_t h_stage_cap[2] = {0, 0};
   int rank = 0, nranks = 1;
   bool verified = false;          // the first payload exchange carries checksums
   uint64_t verified_bytes = 0;    // the largest peer message an exchange with checksums has carried so far
@@ -97,11 +101,45 @@ struct kmi_comm {
 
 namespace kmi {
 
+// ---- the transport backend: every collective below has a branch that goes through the application's callbacks over host memory
+static kmi_status tp_fail(kmi_comm *c, const char *what) { return set_err(c->ctx, KMI_ERR_DEVICE, "the transport's %s callback reported an error", what); }
+static kmi_status tp_stage(kmi_comm *c, int which, size_t bytes) {
+  if (c->h_stage_cap[which] >= bytes && c->h_stage[which]) return KMI_OK;
+  if (c->h_stage[which]) (void)hipHostFree(c->h_stage[which]);
+  c->h_stage[which] = nullptr; c->h_stage_cap[which] = 0;
+  const size_t cap = bytes + bytes / 4 + 4096;
+  if (hipHostMalloc((void **)&c->h_stage[which], cap) != hipSuccess) return set_err(c->ctx, KMI_ERR_NOMEM, "pinned staging buffer of a transport exchange%s", "");
+  c->h_stage_cap[which] = cap;
+  return KMI_OK;
+}
+// host words to every peer and back (counts, riders, checksums): `per` words per peer
+static kmi_status tp_words(kmi_comm *c, const uint64_t *send, uint64_t *recv, size_t per) {
+  std::vector<uint64_t> b((size_t)c->nranks, per * sizeof(uint64_t));
+  if (c->transport.all_to_all_v(c->transport.user, send, b.data(), recv, b.data()) != 0) return tp_fail(c, "all_to_all_v");
+  return KMI_OK;
+}
+// device payload: everything the context's stream has queued is done first (the send buffer's producer), then D2H, the
+// callback, H2D -- synchronous: the caller's buffers are free, and the received bytes in place, when this returns
+static kmi_status tp_bytes(kmi_comm *c, const char *send_dev, const uint64_t *sbytes, char *recv_dev, const uint64_t *rbytes) {
+  kmi_ctx *ctx = c->ctx;
+  uint64_t ts = 0, tr = 0;
+  for (int r = 0; r < c->nranks; ++r) { ts += sbytes[r]; tr += rbytes[r]; }
+  KMI_TRY(tp_stage(c, 0, (size_t)ts));
+  KMI_TRY(tp_stage(c, 1, (size_t)tr));
+  if (ts) KMI_HIP(ctx, hipMemcpyAsync(c->h_stage[0], send_dev, (size_t)ts, hipMemcpyDeviceToHost, ctx->stream));
+  KMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (c->transport.all_to_all_v(c->transport.user, c->h_stage[0], sbytes, c->h_stage[1], rbytes) != 0) return tp_fail(c, "all_to_all_v");
+  if (tr) KMI_HIP(ctx, hipMemcpyAsync(recv_dev, c->h_stage[1], (size_t)tr, hipMemcpyHostToDevice, ctx->stream));
+  KMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return KMI_OK;
+}
+
 // mxx::all2all of one 64-bit count per peer (incremental_mxx.hpp:1087)
 kmi_status comm_all_to_all_counts(kmi_comm *c, const uint64_t *send_counts, uint64_t *recv_counts) {
   kmi_ctx *ctx = c->ctx;
   const int p = c->nranks;
   if (p == 1 && !ctx->force_dist) { recv_counts[0] = send_counts[0]; return KMI_OK; }
+  if (c->has_transport) return tp_words(c, send_counts, recv_counts, 1);
   uint64_t *d_s = c->d_small, *d_r = c->d_small + p;
   memcpy(c->h_small, send_counts, sizeof(uint64_t) * p);
   KMI_HIP(ctx, hipMemcpyAsync(d_s, c->h_small, sizeof(uint64_t) * p, hipMemcpyHostToDevice, ctx->stream));
@@ -124,11 +162,18 @@ static kmi_status a2a_bytes(kmi_comm *c, const char *send, const uint64_t *sbyte
   kmi_ctx *ctx = c->ctx;
   const int p = c->nranks;
   hipStream_t st = on ? on : ctx->stream;
-  constexpr uint64_t kPiece = (1ull << 30) - 4096;   // per peer and transfer
+  // per peer and transfer (KMI_COMM_PIECE: a test knob that makes small messages travel in pieces)
+  const uint64_t kPiece = [] { const char *e = getenv("KMI_COMM_PIECE"); const uint64_t v = e ? strtoull(e, nullptr, 10) : 0; return v >= 64 ? v : (1ull << 30) - 4096; }();
   uint64_t biggest = 0;
   for (int r = 0; r < p; ++r) { biggest = std::max(biggest, sbytes[r]); biggest = std::max(biggest, rbytes[r]); }
   // the number of pieces must agree on every rank: it follows from the largest message anywhere
   uint64_t gmax = known_gmax != ~0ull ? std::max(known_gmax, biggest) : biggest;
+  if (c->has_transport) {
+    // (no pieces: the message limit is RCCL's; the largest message is still agreed on, for the callers that verify by size)
+    if (p > 1 && known_gmax == ~0ull && c->transport.allreduce_u64(c->transport.user, &gmax, 1, 1) != 0) return tp_fail(c, "allreduce_u64");
+    if (gmax_out) *gmax_out = gmax;
+    return tp_bytes(c, send, sbytes, recv, rbytes);
+  }
   if (p > 1 && known_gmax == ~0ull) {
     c->h_small[4 * p] = biggest;
     KMI_HIP(ctx, hipMemcpyAsync(c->d_small + 4 * p, c->h_small + 4 * p, sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
@@ -202,6 +247,13 @@ kmi_status comm_all_to_all_counts2(kmi_comm *c, const uint64_t *send_counts, uin
   const int p = c->nranks;
   uint64_t *d_s = c->d_small, *d_r = c->d_small + 2 * p;
   for (int r = 0; r < p; ++r) { c->h_small[2 * r] = send_counts[r]; c->h_small[2 * r + 1] = my_largest_bytes; }
+  if (c->has_transport) {
+    KMI_TRY(tp_words(c, c->h_small, c->h_small + 2 * p, 2));
+    uint64_t big = 0;
+    for (int r = 0; r < p; ++r) { recv_counts[r] = c->h_small[2 * p + 2 * r]; big = std::max(big, c->h_small[2 * p + 2 * r + 1]); }
+    *largest_bytes = big;
+    return KMI_OK;
+  }
   KMI_HIP(ctx, hipMemcpyAsync(d_s, c->h_small, sizeof(uint64_t) * 2 * p, hipMemcpyHostToDevice, ctx->stream));
   KMI_NCCL(c, rccl().GroupStart());
   for (int r = 0; r < p; ++r) {
@@ -225,7 +277,7 @@ kmi_status comm_all_to_all_v_async(kmi_comm *c, const void *send_dev, const uint
                                    size_t elem_bytes, uint64_t largest_bytes) {
   kmi_ctx *ctx = c->ctx;
   const int p = c->nranks;
-  if (!c->verified || largest_bytes > c->verified_bytes)
+  if (!c->verified || largest_bytes > c->verified_bytes || c->has_transport)   // (a transport exchange is synchronous: nothing to overlap)
     return comm_all_to_all_v(c, send_dev, send_counts, recv_dev, recv_counts, elem_bytes);
   std::vector<uint64_t> sb(p), rb(p);
   for (int r = 0; r < p; ++r) { sb[r] = send_counts[r] * elem_bytes; rb[r] = recv_counts[r] * elem_bytes; }
@@ -250,6 +302,7 @@ kmi_status comm_allreduce_sum(kmi_comm *c, uint64_t *value) {
   kmi_ctx *ctx = c->ctx;
   if (c->nranks == 1) return KMI_OK;
   const int p = c->nranks;
+  if (c->has_transport) return c->transport.allreduce_u64(c->transport.user, value, 1, 0) != 0 ? tp_fail(c, "allreduce_u64") : KMI_OK;
   c->h_small[4 * p] = *value;
   KMI_HIP(ctx, hipMemcpyAsync(c->d_small + 4 * p, c->h_small + 4 * p, sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
   KMI_NCCL(c, rccl().AllReduce(c->d_small + 4 * p, c->d_small + 4 * p + 1, 1, kNcclUint64, kNcclSum, c->nccl, ctx->stream));
@@ -303,9 +356,29 @@ kmi_status kmi_comm_create(kmi_ctx *ctx, const void *id, kmi_comm **out) {
   return KMI_OK;
 }
 
+kmi_status kmi_comm_create_transport(kmi_ctx *ctx, const kmi_transport *transport, kmi_comm **out) {
+  if (!ctx || !out || !transport) return KMI_ERR_INVALID;
+  if (!transport->all_to_all_v || !transport->allreduce_u64) return kmi::set_err(ctx, KMI_ERR_INVALID, "a transport needs both callbacks%s", "");
+  KMI_HIP(ctx, hipSetDevice(ctx->device));
+  kmi_comm *c = new kmi_comm();
+  c->ctx = ctx; c->rank = ctx->rank; c->nranks = ctx->nranks;
+  c->has_transport = true; c->transport = *transport;
+  const size_t small = sizeof(uint64_t) * (8 * (size_t)c->nranks + 16);
+  if (hipMalloc((void **)&c->d_small, small) != hipSuccess || hipHostMalloc((void **)&c->h_small, small) != hipSuccess ||
+      hipStreamCreateWithFlags(&c->xstream, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming) != hipSuccess) {
+    kmi_comm_destroy(c);
+    return kmi::set_err(ctx, KMI_ERR_NOMEM, "communicator scratch%s", "");
+  }
+  *out = c;
+  return KMI_OK;
+}
+
 kmi_status kmi_comm_destroy(kmi_comm *c) {
   if (!c) return KMI_OK;
   (void)hipSetDevice(c->ctx->device);
+  for (int i = 0; i < 2; ++i) if (c->h_stage[i]) (void)hipHostFree(c->h_stage[i]);
   (void)hipStreamSynchronize(c->ctx->stream);
   if (c->xstream) (void)hipStreamSynchronize(c->xstream);
   if (c->nccl && rccl().ok) (void)rccl().CommDestroy(c->nccl);

@@ -3821,6 +3821,10 @@ static bool sk_rank_count(uint32_t p) { return p == 1u || p == 2u || p == 4u || 
 
 struct kmi_comm;
 static kmi_status dist_state(kmi_index *idx, kmi_comm *comm, uint64_t *holders, uint64_t *owner_p, uint64_t *owner_any);
+// every rank brings the status of what it has just done on its own; all leave with an error if any did (its own, or KMI_ERR_PEER):
+// one all-reduce, placed where the next step is a collective that a rank which has already returned would leave its peers waiting in
+static kmi_status dist_agree(kmi_comm *comm, kmi_status mine);
+static int comm_rank_of(kmi_comm *comm);
 
 extern "C" {
 
@@ -4344,6 +4348,16 @@ kmi_status kmi_index_update_pairs_dist_host(kmi_index *idx, kmi_comm *comm, cons
 
 }  // extern "C"
 
+static int comm_rank_of(kmi_comm *comm) { return kmi::comm_rank(comm); }
+static kmi_status dist_agree(kmi_comm *comm, kmi_status mine) {
+  uint64_t bad = mine != KMI_OK ? 1u : 0u;
+  const kmi_status st = kmi::comm_allreduce_sum(comm, &bad);
+  if (mine != KMI_OK) return mine;
+  if (st != KMI_OK) return st;
+  if (bad) return set_err(kmi::comm_ctx(comm), KMI_ERR_PEER, "the collective was given up: another rank reported an error");
+  return KMI_OK;
+}
+
 // one 64-bit all-reduce carries what every rank must agree on before it picks a route: field 0 (bits 0..15) ranks that hold
 // entries, field 1 (16..31) ranks whose entries are distributed by minimizer owner over exactly p ranks, field 2 (32..47) ranks
 // whose entries are distributed by owner at all
@@ -4373,7 +4387,7 @@ static kmi_status build_dist_superkmer(kmi_index *idx, kmi_comm *comm, const uin
   // the receive pool: every rank's bytes are known after one all-reduce; a rank receives about a p-th of all records
   uint64_t all_bytes = n_bytes;
   KMI_TRY(kmi::comm_allreduce_sum(comm, &all_bytes));
-  uint64_t pool_cap = (uint64_t)((double)all_bytes / p * 0.06 * 1.3) + 65536;
+  uint64_t pool_cap = (uint64_t)((double)all_bytes / p * 0.06 * 1.3 * ctx->dist_pool_pct / 100.0) + ctx->dist_pool_slack;
   void *pv;
   KMI_TRY(ws_get(ctx, WS_DIST_B, pool_cap * 16, &pv));
   uint64_t *pool = (uint64_t *)pv;
@@ -4383,36 +4397,56 @@ static kmi_status build_dist_superkmer(kmi_index *idx, kmi_comm *comm, const uin
   size_t send_cap[2] = {0, 0};
   std::vector<uint32_t> failed;
   std::vector<uint64_t> sc(p), rc(p);
-  idx->owner_lp = lp;   // (every rank is here: the route was agreed on)
-  for (uint32_t c = 0; c < nch; ++c) {
+  const uint32_t lp_before = idx->owner_lp;
+  idx->owner_lp = lp;   // (every rank is here: the route was agreed on; an error below puts the old value back)
+  // A rank that fails on its own -- a parse or length verdict of its front end, a workspace it cannot get -- still enters the
+  // chunk's count exchange and says so there (count = kHardError), so that every rank leaves this function with an error instead
+  // of waiting in a send / receive for a peer that has already returned.
+  constexpr uint64_t kNotProduced = ~0ull, kHardError = ~0ull - 1ull;
+  kmi_status st_local = KMI_OK;
+  bool peer_error = false;
+  for (uint32_t c = 0; c < nch && st_local == KMI_OK && !peer_error; ++c) {
     const size_t cb = (size_t)(cuts[c + 1] - cuts[c]);
     const int sb = (int)(c & 1u);
-    const size_t want = (size_t)((double)cb * 0.06) + 8192;
-    if (c >= 2) KMI_TRY(kmi::comm_exchange_wait(comm));   // the buffer's previous message has left (the transfer before the last is done)
-    if (send_cap[sb] < want) { KMI_TRY(ws_get(ctx, sb ? WS_DIST_C : WS_DIST_A, want * 16, &pv)); sendbuf[sb] = (uint64_t *)pv; send_cap[sb] = want; }
-    const uint64_t *recs = nullptr;
-    uint64_t nrec = 0;
     int produced = 0;
-    const uint8_t *src = d_bytes + cuts[c];   // (any address: the one-pass front end loads unaligned; the general one aligns its input itself)
-    KMI_TRY(sk_produce(idx, (uint32_t)W, src, cb, (uint32_t)p, &recs, &nrec, sc.data(), &produced, sendbuf[sb], send_cap[sb]));
-    if (produced && nrec && recs != sendbuf[sb]) {   // more records than the buffer was sized for: a larger one, and a copy out of the workspace
-      KMI_TRY(kmi::comm_exchange_wait(comm));
-      KMI_TRY(ws_get(ctx, sb ? WS_DIST_C : WS_DIST_A, (nrec + 64) * 16, &pv)); sendbuf[sb] = (uint64_t *)pv; send_cap[sb] = nrec + 64;
-      KMI_HIP(ctx, hipMemcpyAsync(sendbuf[sb], recs, nrec * 16, hipMemcpyDeviceToDevice, ctx->stream));
-    }
+    auto produce_chunk = [&]() -> kmi_status {
+      const size_t want = (size_t)((double)cb * 0.06) + 8192;
+      if (c >= 2) KMI_TRY(kmi::comm_exchange_wait(comm));   // the buffer's previous message has left (the transfer before the last is done)
+      if (send_cap[sb] < want) { KMI_TRY(ws_get(ctx, sb ? WS_DIST_C : WS_DIST_A, want * 16, &pv)); sendbuf[sb] = (uint64_t *)pv; send_cap[sb] = want; }
+      const uint64_t *recs = nullptr;
+      uint64_t nrec = 0;
+      const uint8_t *src = d_bytes + cuts[c];   // (any address: the one-pass front end loads unaligned; the general one aligns its input itself)
+      if (ctx->sk_dbg == 9 && comm_rank_of(comm) == 1 && c == 1) return set_err(ctx, KMI_ERR_PARSE, "test knob KMI_SK_DBG=9: rank 1 fails on its second chunk");
+      KMI_TRY(sk_produce(idx, (uint32_t)W, src, cb, (uint32_t)p, &recs, &nrec, sc.data(), &produced, sendbuf[sb], send_cap[sb]));
+      if (produced && nrec && recs != sendbuf[sb]) {   // more records than the buffer was sized for: a larger one, and a copy out of the workspace
+        KMI_TRY(kmi::comm_exchange_wait(comm));
+        KMI_TRY(ws_get(ctx, sb ? WS_DIST_C : WS_DIST_A, (nrec + 64) * 16, &pv)); sendbuf[sb] = (uint64_t *)pv; send_cap[sb] = nrec + 64;
+        KMI_HIP(ctx, hipMemcpyAsync(sendbuf[sb], recs, nrec * 16, hipMemcpyDeviceToDevice, ctx->stream));
+      }
+      return KMI_OK;
+    };
+    st_local = produce_chunk();
     uint64_t mine = 0, largest = 0;
     for (int r = 0; r < p; ++r) mine = std::max(mine, sc[r] * 16);
     std::vector<uint64_t> tell(sc);
-    if (!produced) for (int r = 0; r < p; ++r) tell[r] = ~0ull;
-    KMI_TRY(kmi::comm_all_to_all_counts2(comm, tell.data(), mine, rc.data(), &largest));
+    if (st_local != KMI_OK) { for (int r = 0; r < p; ++r) tell[r] = kHardError; mine = 0; }
+    else if (!produced) for (int r = 0; r < p; ++r) tell[r] = kNotProduced;
+    {
+      const kmi_status st_x = kmi::comm_all_to_all_counts2(comm, tell.data(), mine, rc.data(), &largest);
+      if (st_x != KMI_OK) { idx->owner_lp = lp_before; return st_local != KMI_OK ? st_local : st_x; }   // (the exchange itself failed: nothing more to agree on)
+    }
+    for (int r = 0; r < p; ++r) peer_error = peer_error || rc[r] == kHardError;
+    if (st_local != KMI_OK || peer_error) break;
     bool all_ok = produced != 0;
-    for (int r = 0; r < p; ++r) all_ok = all_ok && rc[r] != ~0ull;
+    for (int r = 0; r < p; ++r) all_ok = all_ok && rc[r] != kNotProduced;
     if (!all_ok) { failed.push_back(c); continue; }
     uint64_t n_in = 0;
     for (int r = 0; r < p; ++r) n_in += rc[r];
+    // (from here to the payload exchange only allocation can fail: a rank that cannot hold what it is sent has no way left to say so)
     if (pool_pos + n_in > pool_cap) {   // the estimate was short (a very uneven input): a pool twice the need, what arrived so far moves over
       KMI_TRY(kmi::comm_exchange_wait(comm));
-      const uint64_t ncap = 2 * (pool_pos + n_in) + 65536;
+      const uint64_t ncap = 2 * (pool_pos + n_in) + ctx->dist_pool_slack;
+      ++ctx->dist_pool_regrows;
       KMI_TRY(ws_get(ctx, pool_in_b ? WS_DIST_D : WS_DIST_B, ncap * 16, &pv));
       if (pool_pos) KMI_HIP(ctx, hipMemcpyAsync(pv, pool, pool_pos * 16, hipMemcpyDeviceToDevice, ctx->stream));
       pool = (uint64_t *)pv; pool_cap = ncap; pool_in_b = !pool_in_b;
@@ -4421,24 +4455,40 @@ static kmi_status build_dist_superkmer(kmi_index *idx, kmi_comm *comm, const uin
     pool_pos += n_in;
   }
   KMI_TRY(kmi::comm_exchange_join(comm));
-  if (pool_pos) KMI_TRY(sk_consume(idx, (uint32_t)W, pool, pool_pos, (uint32_t)p));
+  if (st_local != KMI_OK || peer_error) {
+    // what arrived before the error is dropped: the index is as it was (the transfers queued so far have been joined)
+    (void)hipStreamSynchronize(ctx->stream);
+    idx->owner_lp = lp_before;
+    if (st_local != KMI_OK) return st_local;
+    return set_err(ctx, KMI_ERR_PEER, "the build over ranks was given up: another rank reported an error in its share of the input");
+  }
+  {
+    kmi_status st_c = pool_pos ? sk_consume(idx, (uint32_t)W, pool, pool_pos, (uint32_t)p) : KMI_OK;
+    // chunks some rank could not produce as records follow as k-mers, collectively: first agree that every rank is still there
+    if (!failed.empty()) st_c = dist_agree(comm, st_c);
+    if (st_c != KMI_OK) { if (!pool_pos || !idx->n_entries) idx->owner_lp = lp_before; return st_c; }
+  }
   idx->owner_lp = lp;
   // chunks some rank could not produce as records: their k-mers, routed to the same owners (collective: every rank has the same list)
   for (uint32_t c : failed) {
     const size_t cb = (size_t)(cuts[c + 1] - cuts[c]);
     const uint32_t nw = idx->shape.n_words;
     uint64_t nt = 0, ns = 0, total = 0;
-    const uint8_t *src = d_bytes + cuts[c];
-    if (cb) { KMI_TRY(align_input(ctx, &src, cb)); KMI_TRY(extract_count(ctx, &idx->cfg, src, cb, &nt, &ns)); }
-    void *d_keys, *d_send, *d_recv;
-    KMI_TRY(ws_get(ctx, WS_OUTPUT, (nt + 64) * nw * sizeof(uint64_t), &d_keys));
-    KMI_TRY(ws_get(ctx, WS_DIST_A, (nt + 64) * nw * sizeof(uint64_t), &d_send));
-    send_cap[0] = 0;
-    for (int r = 0; r < p; ++r) sc[r] = 0;
-    if (nt) {
-      KMI_TRY(extract_run(ctx, &idx->cfg, src, cb, file_offset + cuts[c], (uint64_t *)d_keys, nullptr, (size_t)nt, true, true, &nt, &ns));
-      KMI_TRY(kmi_route_owner_dev(ctx, &idx->cfg, (const uint64_t *)d_keys, (size_t)nt, (uint32_t)p, (uint64_t *)d_send, sc.data()));
-    }
+    void *d_keys = nullptr, *d_send = nullptr, *d_recv = nullptr;
+    auto route_chunk = [&]() -> kmi_status {
+      const uint8_t *src = d_bytes + cuts[c];
+      if (cb) { KMI_TRY(align_input(ctx, &src, cb)); KMI_TRY(extract_count(ctx, &idx->cfg, src, cb, &nt, &ns)); }
+      KMI_TRY(ws_get(ctx, WS_OUTPUT, (nt + 64) * nw * sizeof(uint64_t), &d_keys));
+      KMI_TRY(ws_get(ctx, WS_DIST_A, (nt + 64) * nw * sizeof(uint64_t), &d_send));
+      send_cap[0] = 0;
+      for (int r = 0; r < p; ++r) sc[r] = 0;
+      if (nt) {
+        KMI_TRY(extract_run(ctx, &idx->cfg, src, cb, file_offset + cuts[c], (uint64_t *)d_keys, nullptr, (size_t)nt, true, true, &nt, &ns));
+        KMI_TRY(kmi_route_owner_dev(ctx, &idx->cfg, (const uint64_t *)d_keys, (size_t)nt, (uint32_t)p, (uint64_t *)d_send, sc.data()));
+      }
+      return KMI_OK;
+    };
+    KMI_TRY(dist_agree(comm, route_chunk()));
     std::vector<uint64_t> rcv;
     KMI_TRY(dist_exchange(comm, d_send, sc.data(), nw * sizeof(uint64_t), WS_DIST_D, &d_recv, rcv, &total));
     KMI_TRY(index_insert(idx, (const uint64_t *)d_recv, (size_t)total, false));

@@ -97,6 +97,9 @@ struct kmi_ctx {
   float sk_inv_dup = 0.f;        // sk_reduce: distinct k-mers per k-mer occurrence of the last build (a bucket's expected fill; 0: unknown)
   bool sk_reduce2 = false;       // KMI_SK_REDUCE=2: sk_reduce2 (wavefront-private tables over sorted bins, kmi_reduce2.h) ahead of sk_reduce -- measured slower
   uint32_t sk_r2_win = 0;        // records of sk_reduce2's batch window (KMI_R2_WIN: test knob; 0: by the last build's duplication)
+  uint32_t dist_pool_regrows = 0;     // times a build over ranks had to enlarge its receive pool (kmi_ctx_debug_counter: tests)
+  uint32_t dist_pool_pct = 100;       // the estimate itself, in percent (KMI_DIST_POOL_PCT: tests make it too small)
+  uint64_t dist_pool_slack = 65536;   // records a rank's receive pool holds beyond the estimate of its share (KMI_DIST_POOL_SLACK: tests shrink it so that the pool has to grow)
   uint32_t dist_chunks = 4;      // record-aligned chunks of a rank's share in the build over ranks (exchange of one beside the front end of the next; KMI_DIST_CHUNKS)
   bool sk_slack = true;          // fine buckets with room instead of a counting pass (sk_scatter_fine_slack_kernel); KMI_SK_SLACK=0: always count
   bool front_fused = true;       // FASTQ front end of the super-k-mer build in one pass (kmi_front.h); KMI_FRONT=general: scan + list + minimizer

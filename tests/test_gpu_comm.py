@@ -51,6 +51,37 @@ def test_unique_id_and_self_exchange(dist_ctx):
     ctx.free(d_a); ctx.free(d_b)
 
 
+def test_peer_message_in_pieces(dist_ctx, monkeypatch):
+    """a peer message above the piece size (1 GiB less a page in production: the RCCL build of this image was seen to corrupt larger
+    ones) travels as several grouped send / receive rounds whose number every rank derives from the largest message anywhere.
+    KMI_COMM_PIECE shrinks the piece to 4 KB, so an 800 KB message goes in 196 rounds -- with checksums, twice, and then through
+    a whole build whose records travel the same way."""
+    import kmerind_amd as K
+    from kmerind_amd import _lib as L
+    ctx, comm = dist_ctx
+    monkeypatch.setenv("KMI_COMM_PIECE", "4096")
+    n = 100_003
+    a = np.arange(n, dtype=np.uint64) * np.uint64(0xD6E8FEB86659FD93) + np.uint64(7)
+    d_a, d_b = ctx.alloc(a.nbytes), ctx.alloc(a.nbytes)
+    ctx.to_device(d_a, a)
+    sc, rc = np.array([n], np.uint64), np.array([n], np.uint64)
+    for _ in range(2):
+        ctx.check(L.lib.kmi_comm_all_to_all_v(comm, C.c_void_p(d_a), sc.ctypes.data_as(C.c_void_p), C.c_void_p(d_b), rc.ctypes.data_as(C.c_void_p), 8))
+        b = np.zeros_like(a)
+        ctx.to_host(b, d_b)
+        assert (a == b).all()
+    ctx.free(d_a); ctx.free(d_b)
+    s = orc.kspec(31, orc.DNA)
+    data = K.synth_fastq(seed=5, genome_len=20_000, n_reads=2_000)
+    idx = K.CountIndex(ctx, K.make_config(31, "DNA", strand="canonical"))
+    ctx.check(L.lib.kmi_index_build_dist_host(idx.h, comm, data.ctypes.data_as(C.c_void_p), data.size, 0))
+    om = orc.CountMap(s, orc.CANONICAL)
+    om.insert(orc.extract(s, data, orc.FASTQ)["kmers"])
+    a, b = orc.sorted_pairs(*idx.to_vector()), orc.sorted_pairs(*om.export())
+    assert a[0].shape == b[0].shape and (a[0] == b[0]).all() and (a[1] == b[1]).all()
+    idx.close()
+
+
 @pytest.mark.parametrize("strand", ["canonical", "single"])
 def test_count_index_collectives_over_rccl(dist_ctx, strand):
     import kmerind_amd as K

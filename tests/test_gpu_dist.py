@@ -33,8 +33,11 @@ def _worker(rank, world, port, data, k, strand, mode, ret):
         if mode == "superkmer-fallback":          # the front end reports "cannot take this input": every chunk goes as k-mers
             os.environ["KMI_SK_DBG"] = "7"
             mode = "superkmer"
+        alphabet = "DNA"
+        if mode.endswith("-dna5"):                # a three-bit alphabet: the super-k-mer exchange does not apply, "auto" has to fall back
+            mode, alphabet = mode[:-5], "DNA5"
         ctx = K.Context(0, rank=rank, nranks=world)
-        cfg = K.make_config(k, "DNA", strand=strand)
+        cfg = K.make_config(k, alphabet, strand=strand)
         didx = kdist.DistributedCountIndex(ctx, cfg, stage_through_host=True, device=dev)
         parts = fileio.partition_fastq(data, world * 2)             # two build calls per rank: the index grows incrementally
         for j in range(2):
@@ -48,9 +51,11 @@ def _worker(rank, world, port, data, k, strand, mode, ret):
         keys, cnts = didx.index.to_vector()
         # distributed queries: every rank asks for its own mix of present / absent keys
         rng = np.random.default_rng(100 + rank)
-        s = orc.kspec(k)
+        s = orc.kspec(k, orc.DNA5 if alphabet == "DNA5" else orc.DNA)
         present = orc.extract(s, data, orc.FASTQ)["kmers"][rng.integers(0, 1000, size=300)]
         absent = rng.integers(0, 1 << (2 * k), size=(200, 1), dtype=np.uint64)
+        if alphabet == "DNA5":                    # (random bits are not DNA5 k-mers; absent keys here: k-mers of another genome)
+            absent = orc.extract(s, bytes(K.synth_fastq(seed=99, genome_len=5_000, n_reads=20)), orc.FASTQ)["kmers"][:200]
         q = np.concatenate([present, absent])
         ck, cv = didx.count(q)
         fk, fv = didx.find(q)
@@ -65,7 +70,8 @@ def _worker(rank, world, port, data, k, strand, mode, ret):
 
 
 @pytest.mark.parametrize("k,strand,mode", [(31, "canonical", "combine"), (21, "single", "combine"), (31, "canonical", "superkmer"),
-                                           (21, "single", "superkmer"), (25, "canonical", "auto"), (31, "canonical", "superkmer-fallback")])
+                                           (21, "single", "superkmer"), (25, "canonical", "auto"), (31, "canonical", "superkmer-fallback"),
+                                           (15, "canonical", "auto"), (21, "canonical", "auto-dna5")])
 def test_distributed_count_index_two_ranks_one_gpu(k, strand, mode):
     """combine: (k-mer, count) pairs to KeyToRank(k-mer); superkmer: 16-byte super-k-mer records to the owner of the
     minimizer's bucket (what "auto" picks for FASTQ and one-word DNA k-mers). Two build calls per rank, so the second one meets
@@ -76,8 +82,10 @@ def test_distributed_count_index_two_ranks_one_gpu(k, strand, mode):
     mgr = mp.Manager()
     ret = mgr.dict()
     mp.spawn(_worker, args=(world, _free_port(), data, k, strand, mode, ret), nprocs=world, join=True)
-    s = orc.kspec(k)
+    dna5 = mode.endswith("-dna5")
+    s = orc.kspec(k, orc.DNA5 if dna5 else orc.DNA)
     st = orc.CANONICAL if strand == "canonical" else orc.SINGLE
+    no_sk = dna5 or k < 17                     # shapes the super-k-mer exchange does not take: "auto" combines or routes occurrences
     ref = orc.CountMap(s, st)
     ref.insert(orc.extract(s, data, orc.FASTQ)["kmers"])
     rk, rc = ref.export()
@@ -88,8 +96,8 @@ def test_distributed_count_index_two_ranks_one_gpu(k, strand, mode):
     erased = set()
     for r in range(world):
         assert ret[r][2] == ref.size()
-        assert ret[r][9] == ("combine" if mode == "combine" else "superkmer")
-        if mode == "combine":
+        assert ret[r][9] in (("combine", "raw") if no_sk else ("combine",) if mode == "combine" else ("superkmer",)), ret[r][9]
+        if mode == "combine" or no_sk:
             assert (orc.key_to_rank(s, orc.MURMUR, st, ret[r][0], world) == r).all()
         else:        # owner = the minimizer bucket's rank: every key on exactly one rank (the union was compared above)
             assert ret[r][0].shape[0] > 0 and np.unique(keys, axis=0).shape[0] == keys.shape[0]
