@@ -495,14 +495,33 @@ def extra_rates(ctx, cfg, idx, d_bytes, nbytes, n_kmers, dev, torch, host=None):
     # (a) the FIRST build of a fresh context, allocations included; (b) a build of the warm context with the hints forgotten
     cold = {}
     try:
-        ctx2 = K.Context(device=ctx.device, stream=ctx.stream)
-        idx4 = K.CountIndex(ctx2, cfg)
-        torch.cuda.synchronize(dev)
-        t0 = time.perf_counter()
-        idx4.build_device(d_bytes.data_ptr(), nbytes)
-        torch.cuda.synchronize(dev)
-        cold["first_build_of_a_fresh_context_ms"] = round((time.perf_counter() - t0) * 1e3, 2)
-        idx4.close(); ctx2.close()
+        def fresh_context_build():
+            """first build of a new context beside the warm one; returns (ms, ms inside hipMalloc / hipFree, GB that reached hipMalloc, cached blocks reused)"""
+            ctx2 = K.Context(device=ctx.device, stream=ctx.stream)
+            idx4 = K.CountIndex(ctx2, cfg)
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            idx4.build_device(d_bytes.data_ptr(), nbytes)
+            torch.cuda.synchronize(dev)
+            ms = (time.perf_counter() - t0) * 1e3
+            v = C.c_uint64()
+            c = []
+            for w in (1, 2, 4):
+                ctx2.check(L.lib.kmi_ctx_debug_counter(ctx2.h, w, C.byref(v)))
+                c.append(v.value)
+            idx4.close(); ctx2.close()
+            return ms, c[0] / 1e3, c[1] / 1e9, c[2]
+        # (a1) every block of its workspace comes from hipMalloc: what that costs is the node's business (1.4 ms for 30 GB on an idle
+        # box, hundreds of ms on a loaded one) and is reported beside the total; (a2) the next context finds the blocks the first
+        # one left in the library's process-wide cache (kmi_release_cached_memory): no hipMalloc in its first build
+        ms, in_malloc, gb, _ = fresh_context_build()
+        cold["first_build_of_a_fresh_context_ms"] = round(ms, 2)
+        cold["of_which_inside_hipmalloc_ms"] = round(in_malloc, 2)
+        cold["hipmalloc_gb"] = round(gb, 2)
+        ms, in_malloc, gb, reused = fresh_context_build()
+        cold["first_build_of_a_recycled_context_ms"] = round(ms, 2)
+        cold["recycled_context_blocks_from_cache"] = int(reused)
+        L.lib.kmi_release_cached_memory(-1, None)
 
         def no_hints():
             idx.clear()

@@ -96,8 +96,13 @@ kmi_status kmi_ctx_destroy(kmi_ctx *ctx);
  * from): the next build runs as the first one of a context would, with the workspace blocks still in place */
 kmi_status kmi_ctx_reset_hints(kmi_ctx *ctx);
 /* counters the library keeps for its tests and for diagnosis (no reference counterpart). which = 0: times a build over ranks had to
- * enlarge its receive pool (kmi_index_build_dist_dev) */
+ * enlarge its receive pool (kmi_index_build_dist_dev); 1: microseconds this context has spent inside hipMalloc / hipFree; 2: bytes
+ * and 3: calls that reached hipMalloc; 4: blocks taken from the process-wide cache instead */
 kmi_status kmi_ctx_debug_counter(const kmi_ctx *ctx, uint32_t which, uint64_t *value);
+/* A destroyed context leaves its large device blocks (workspace, spare index arrays: >= 1 MB each, 96 GB / 64 blocks at most) in a
+ * process-wide cache per device, where the next context of that device finds them: its first build then does not wait for
+ * hipMalloc ("first build"). This frees them (device < 0: of every device). */
+kmi_status kmi_release_cached_memory(int device, uint64_t *bytes_released /* may be NULL */);
 const char *kmi_last_error(const kmi_ctx *ctx);
 /* derived Kmer shape (padding.hpp:67-90): words per k-mer, hashed byte length */
 kmi_status kmi_kmer_shape(const kmi_config *cfg, uint32_t *n_words, uint32_t *n_bits, uint32_t *n_bytes);

@@ -116,6 +116,7 @@ SIGNATURES = {
     "kmi_comm_unique_id": (C.c_int, [_P]),
     "kmi_comm_create": (C.c_int, [_P, _P, C.POINTER(_P)]),
     "kmi_ctx_debug_counter": (C.c_int, [_P, _u32, C.POINTER(_u64)]),
+    "kmi_release_cached_memory": (C.c_int, [C.c_int, C.POINTER(_u64)]),
     "kmi_comm_create_transport": (C.c_int, [_P, _P, C.POINTER(_P)]),
     "kmi_comm_destroy": (C.c_int, [_P]),
     "kmi_comm_all_to_all_counts": (C.c_int, [_P, _P, _P]),

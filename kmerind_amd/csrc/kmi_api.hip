@@ -4,6 +4,9 @@
 #include <algorithm>
 
 #include "kmi_block.h"
+#include <chrono>
+#include <mutex>
+
 #include "kmi_internal.h"
 
 namespace kmi {
@@ -11,11 +14,73 @@ namespace kmi {
 // ---------------------------------------------------------------------------
 // workspace + profiling
 // ---------------------------------------------------------------------------
+// ---- the process-wide block cache (see kmi_internal.h) -------------------------------------------------------------------
+namespace {
+struct CachedBlock { int device; void *p; size_t bytes; };
+std::mutex g_cache_mu;
+std::vector<CachedBlock> g_cache;
+constexpr size_t kCacheMaxBytes = 96ull << 30, kCacheMaxBlocks = 64, kCacheMinBlock = 1ull << 20;
+inline uint64_t now_us() { return (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+// hipFree of every cached block of the device (all devices: -1); returns the bytes released
+size_t cache_flush(int device) {
+  std::lock_guard<std::mutex> lk(g_cache_mu);
+  size_t freed = 0;
+  for (size_t i = 0; i < g_cache.size();) {
+    if (device < 0 || g_cache[i].device == device) { (void)hipFree(g_cache[i].p); freed += g_cache[i].bytes; g_cache.erase(g_cache.begin() + (long)i); }
+    else ++i;
+  }
+  return freed;
+}
+}  // namespace
+
+hipError_t dev_malloc(kmi_ctx *ctx, void **p, size_t bytes, size_t *got) {
+  const bool exact = got == nullptr;
+  if (bytes >= kCacheMinBlock) {
+    std::lock_guard<std::mutex> lk(g_cache_mu);
+    size_t best = g_cache.size();
+    for (size_t i = 0; i < g_cache.size(); ++i) {
+      const CachedBlock &b = g_cache[i];
+      if (b.device != ctx->device || b.bytes < bytes) continue;
+      if (exact ? b.bytes != bytes : b.bytes > bytes + bytes / 2) continue;
+      if (best == g_cache.size() || b.bytes < g_cache[best].bytes) best = i;
+    }
+    if (best != g_cache.size()) {
+      *p = g_cache[best].p;
+      if (got) *got = g_cache[best].bytes;
+      g_cache.erase(g_cache.begin() + (long)best);
+      ++ctx->alloc_reused;
+      return hipSuccess;
+    }
+  }
+  const uint64_t t0 = now_us();
+  hipError_t e = hipMalloc(p, bytes);
+  if (e != hipSuccess && cache_flush(ctx->device)) { (void)hipGetLastError(); e = hipMalloc(p, bytes); }   // the cache holds what this request needs
+  ctx->alloc_us += now_us() - t0; ctx->alloc_bytes += bytes; ++ctx->alloc_calls;
+  if (got) *got = bytes;
+  return e;
+}
+void dev_free(kmi_ctx *ctx, void *p) {
+  if (!p) return;
+  const uint64_t t0 = now_us();
+  (void)hipFree(p);
+  if (ctx) ctx->alloc_us += now_us() - t0;
+}
+void dev_retire(kmi_ctx *ctx, void *p, size_t bytes) {
+  if (!p) return;
+  if (bytes >= kCacheMinBlock) {
+    std::lock_guard<std::mutex> lk(g_cache_mu);
+    size_t total = bytes;
+    for (const auto &b : g_cache) total += b.bytes;
+    if (g_cache.size() < kCacheMaxBlocks && total <= kCacheMaxBytes) { g_cache.push_back({ctx->device, p, bytes}); return; }
+  }
+  dev_free(ctx, p);
+}
+
 kmi_status ws_get(kmi_ctx *ctx, WsSlot slot, size_t bytes, void **out) {
   kmi_ctx::Buf &b = ctx->ws[slot];
   if (bytes == 0) bytes = 256;
   if (b.cap < bytes) {
-    if (b.p) { KMI_HIP(ctx, hipStreamSynchronize(ctx->stream)); KMI_HIP(ctx, hipFree(b.p)); b.p = nullptr; b.cap = 0; }
+    if (b.p) { KMI_HIP(ctx, hipStreamSynchronize(ctx->stream)); dev_free(ctx, b.p); b.p = nullptr; b.cap = 0; }
     // a block an index gave back fits (ws_detach hands workspace buffers to indexes; they return through the spare list)
     for (size_t i = 0; i < ctx->spare.size(); ++i)
       if (ctx->spare[i].bytes >= bytes && ctx->spare[i].bytes / 2 <= bytes) {
@@ -25,7 +90,7 @@ kmi_status ws_get(kmi_ctx *ctx, WsSlot slot, size_t bytes, void **out) {
         return KMI_OK;
       }
     size_t cap = bytes + bytes / 16 + 4096;
-    hipError_t e = hipMalloc(&b.p, cap);
+    hipError_t e = dev_malloc(ctx, &b.p, cap, &cap);   // (a block another context of this process retired serves as well)
     if (e != hipSuccess) { b.p = nullptr; return set_err(ctx, KMI_ERR_NOMEM, "hipMalloc failed: %s", hipGetErrorString(e)); }
     b.cap = cap;
   }
@@ -44,7 +109,7 @@ bool ws_detach(kmi_ctx *ctx, WsSlot slot, const void *p, size_t *bytes) {
 
 void ws_release(kmi_ctx *ctx, WsSlot slot) {
   kmi_ctx::Buf &b = ctx->ws[slot];
-  if (b.p) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(b.p); b.p = nullptr; b.cap = 0; }
+  if (b.p) { (void)hipStreamSynchronize(ctx->stream); dev_free(ctx, b.p); b.p = nullptr; b.cap = 0; }
 }
 
 static hipEvent_t get_event(kmi_ctx *ctx) {
@@ -206,16 +271,27 @@ kmi_status kmi_ctx_debug_counter(const kmi_ctx *ctx, uint32_t which, uint64_t *v
   if (!ctx || !value) return KMI_ERR_INVALID;
   switch (which) {
     case 0: *value = ctx->dist_pool_regrows; return KMI_OK;
+    case 1: *value = ctx->alloc_us; return KMI_OK;
+    case 2: *value = ctx->alloc_bytes; return KMI_OK;
+    case 3: *value = ctx->alloc_calls; return KMI_OK;
+    case 4: *value = ctx->alloc_reused; return KMI_OK;
     default: return KMI_ERR_INVALID;
   }
+}
+
+kmi_status kmi_release_cached_memory(int device, uint64_t *bytes_released) {
+  const size_t n = cache_flush(device);
+  if (bytes_released) *bytes_released = n;
+  return KMI_OK;
 }
 
 kmi_status kmi_ctx_destroy(kmi_ctx *ctx) {
   if (!ctx) return KMI_OK;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
-  for (int s = 0; s < WS_NUM_SLOTS; ++s) if (ctx->ws[s].p) (void)hipFree(ctx->ws[s].p);
-  for (auto &b : ctx->spare) (void)hipFree(b.p);
+  // the large blocks wait in the process-wide cache for the next context of this device (kmi_release_cached_memory frees them)
+  for (int s = 0; s < WS_NUM_SLOTS; ++s) if (ctx->ws[s].p) dev_retire(ctx, ctx->ws[s].p, ctx->ws[s].cap);
+  for (auto &b : ctx->spare) dev_retire(ctx, b.p, b.bytes);
   ctx->spare.clear();
   for (ProfRec &r : ctx->prof_pending) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
   for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);

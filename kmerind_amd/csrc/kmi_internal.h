@@ -97,6 +97,7 @@ struct kmi_ctx {
   float sk_inv_dup = 0.f;        // sk_reduce: distinct k-mers per k-mer occurrence of the last build (a bucket's expected fill; 0: unknown)
   bool sk_reduce2 = false;       // KMI_SK_REDUCE=2: sk_reduce2 (wavefront-private tables over sorted bins, kmi_reduce2.h) ahead of sk_reduce -- measured slower
   uint32_t sk_r2_win = 0;        // records of sk_reduce2's batch window (KMI_R2_WIN: test knob; 0: by the last build's duplication)
+  uint64_t alloc_us = 0, alloc_bytes = 0, alloc_calls = 0, alloc_reused = 0;   // time inside hipMalloc / hipFree, bytes and calls that reached hipMalloc, blocks taken from the process-wide cache (kmi_ctx_debug_counter 1..4)
   uint32_t dist_pool_regrows = 0;     // times a build over ranks had to enlarge its receive pool (kmi_ctx_debug_counter: tests)
   uint32_t dist_pool_pct = 100;       // the estimate itself, in percent (KMI_DIST_POOL_PCT: tests make it too small)
   uint64_t dist_pool_slack = 65536;   // records a rank's receive pool holds beyond the estimate of its share (KMI_DIST_POOL_SLACK: tests shrink it so that the pool has to grow)
@@ -113,16 +114,24 @@ struct kmi_ctx {
 
 namespace kmi {
 
+// hipMalloc / hipFree of the library's large blocks, timed, behind a process-wide cache per device (kmi_api.hip): what a context
+// gives back when it is destroyed waits there for the next context of the same device instead of going through hipFree and
+// hipMalloc again -- on a loaded node a fresh context's first build otherwise pays hundreds of milliseconds for its workspace.
+// dev_malloc takes a cached block of at least `bytes` and at most 1.5 x that; *got receives the block's real size.
+hipError_t dev_malloc(kmi_ctx *ctx, void **p, size_t bytes, size_t *got = nullptr);
+void dev_free(kmi_ctx *ctx, void *p);                       // hipFree, timed
+void dev_retire(kmi_ctx *ctx, void *p, size_t bytes);       // into the process-wide cache (hipFree when that is full)
+
 // device blocks of the index arrays: exact-size reuse from the context's spare list, else hipMalloc
 inline hipError_t pool_alloc(kmi_ctx *ctx, void **p, size_t bytes) {
   if (bytes == 0) bytes = 256;
   for (size_t i = 0; i < ctx->spare.size(); ++i)
     if (ctx->spare[i].bytes == bytes) { *p = ctx->spare[i].p; ctx->spare.erase(ctx->spare.begin() + (long)i); return hipSuccess; }
-  hipError_t e = hipMalloc(p, bytes);
+  hipError_t e = dev_malloc(ctx, p, bytes);   // (index arrays are asked for by exact size: a cached block must match it)
   if (e != hipSuccess && !ctx->spare.empty()) {   // give the cached blocks back and retry once
-    for (auto &b : ctx->spare) (void)hipFree(b.p);
+    for (auto &b : ctx->spare) dev_free(ctx, b.p);
     ctx->spare.clear();
-    e = hipMalloc(p, bytes);
+    e = dev_malloc(ctx, p, bytes);
   }
   return e;
 }
@@ -136,8 +145,8 @@ inline void pool_free(kmi_ctx *ctx, void *p, size_t bytes) {
   if (ctx->spare.size() >= kMaxSpare) {
     size_t m = 0;
     for (size_t i = 1; i < ctx->spare.size(); ++i) if (ctx->spare[i].bytes < ctx->spare[m].bytes) m = i;
-    if (ctx->spare[m].bytes >= bytes) { (void)hipFree(p); return; }   // (the newcomer is the smallest)
-    (void)hipFree(ctx->spare[m].p);
+    if (ctx->spare[m].bytes >= bytes) { dev_free(ctx, p); return; }   // (the newcomer is the smallest)
+    dev_free(ctx, ctx->spare[m].p);
     ctx->spare.erase(ctx->spare.begin() + (long)m);
   }
   ctx->spare.push_back({p, bytes});
@@ -148,7 +157,7 @@ inline void pool_free(kmi_ctx *ctx, void *p, size_t bytes) {
   for (const auto &b : ctx->spare) total += b.bytes;
   while (total > kMaxSpareBytes && !ctx->spare.empty()) {
     total -= ctx->spare.front().bytes;
-    (void)hipFree(ctx->spare.front().p);
+    dev_free(ctx, ctx->spare.front().p);
     ctx->spare.erase(ctx->spare.begin());
   }
 }
