@@ -55,6 +55,10 @@ struct comm {
   // ncclSend / ncclRecv over device buffers). All ranks need the same 128-byte id: rank 0 calls make_unique_id() and the
   // application hands the bytes to the others (MPI_Bcast in the reference's world) before the Index is constructed.
   std::vector<char> unique_id;
+  // ... or the application's own messenger in place of RCCL (kmi_comm_create_transport): two collective callbacks over host buffers,
+  // e.g. MPI_Alltoallv / MPI_Allreduce on the communicator the reference's program already has. Every
+  // member then runs the library's own multi-rank code, staged through pinned memory around the callbacks.
+  kmi_transport transport{nullptr, nullptr, nullptr};
   static std::vector<char> make_unique_id() {
     std::vector<char> id(KMI_COMM_ID_BYTES);
     if (kmi_comm_unique_id(id.data()) != KMI_OK) throw std::runtime_error("kmerind_hip: RCCL is not available (kmi_comm_unique_id)");
@@ -426,9 +430,11 @@ class Index {
     ::kmerind::check(ctx, kmi_index_create(ctx, &cfg, &idx));
     // sat_plus of a 32-bit count runs on the device (narrower count types saturate when they are read, count_of)
     if (MapType::saturating && MapType::index_kind == KMI_INDEX_COUNT) ::kmerind::check(ctx, kmi_index_set_saturating(idx, 1));
-    if (comm.size() > 1 && !comm.exchange) {   // the exchange runs inside the library over RCCL (collective: every rank constructs)
+    if (comm.size() > 1 && comm.transport.all_to_all_v) {   // the library's collectives over the application's messenger
+      ::kmerind::check(ctx, kmi_comm_create_transport(ctx, &comm.transport, &rccl));
+    } else if (comm.size() > 1 && !comm.exchange) {   // the exchange runs inside the library over RCCL (collective: every rank constructs)
       if (comm.unique_id.size() != KMI_COMM_ID_BYTES)
-        throw std::invalid_argument("comm.size() > 1 needs comm.unique_id (kmerind::comm::make_unique_id() on rank 0, handed to every rank) or comm.exchange");
+        throw std::invalid_argument("comm.size() > 1 needs comm.unique_id (kmerind::comm::make_unique_id() on rank 0, handed to every rank), comm.transport or comm.exchange");
       ::kmerind::check(ctx, kmi_comm_create(ctx, comm.unique_id.data(), &rccl));
     } else if (comm.size() == 1) {
       // KMI_FORCE_DIST=1 (rehearsals on one GPU): a one-rank communicator, and every member takes the path it takes over ranks

@@ -235,6 +235,7 @@ kmi_status kmi_ctx_create(int device, int rank, int nranks, void *stream, kmi_ct
   if (const char *dg = getenv("KMI_SK_DBG")) ctx->sk_dbg = atoi(dg);
   if (const char *dc = getenv("KMI_DIST_CHUNKS")) { ctx->dist_chunks = (uint32_t)atoi(dc); if (ctx->dist_chunks < 1) ctx->dist_chunks = 1; if (ctx->dist_chunks > 64) ctx->dist_chunks = 64; }
   if (const char *sl = getenv("KMI_SK_SLACK")) ctx->sk_slack = atoi(sl) != 0;
+  if (const char *tp = getenv("KMI_TUPLES")) ctx->tuples_from_parse = strcmp(tp, "extract") != 0;
   if (const char *ps = getenv("KMI_DIST_POOL_SLACK")) ctx->dist_pool_slack = strtoull(ps, nullptr, 10);
   if (const char *pp = getenv("KMI_DIST_POOL_PCT")) { ctx->dist_pool_pct = (uint32_t)atoi(pp); if (ctx->dist_pool_pct < 1) ctx->dist_pool_pct = 1; }
   if (const char *r2 = getenv("KMI_SK_REDUCE")) ctx->sk_reduce2 = atoi(r2) == 2;

@@ -423,7 +423,6 @@ __device__ __forceinline__ float exp2f_libm(float x, const uint64_t *__restrict_
   return (float)y;
 }
 
-struct ReadDesc { uint64_t seq_pos, out_off; };   // slot = sequence index of the read; out_off = ~0: the read has no k-mer
 
 // Sixty-four reads per WAVEFRONT, one per lane, so the sequential float chain of every read (two operations per window, in
 // the reference's order) runs on all lanes at once. Everything around the chain is made wave-friendly:
@@ -922,9 +921,25 @@ static kmi_status fastq_scan_impl(kmi_ctx *ctx, const uint8_t *bytes_dev, size_t
   KMI_HIP(ctx, hipMemsetAsync(ctx->d_flags, 0, sizeof(uint32_t) * 16, ctx->stream));
   KMI_TRY((scan_impl<NW, BITS>(ctx, bytes_dev, n_bytes, shape, &r, false, check_lengths, seq_filter, rna)));
   out->pk_brk = r.packed.brk;
-  out->n_tiles = r.n_tiles; out->line_base = r.line_base; out->tile_off = r.out_off;
+  out->n_tiles = r.n_tiles; out->line_base = r.line_base; out->tile_off = r.out_off; out->hdr_base = r.hdr_base;
   out->pk_eol = r.packed.eol; out->pk_stream = r.packed.stream; out->n_bytes = r.packed.n_bytes; out->n_cover = r.packed.n_cover;
   return read_totals(ctx, &out->n_tuples, &out->n_seqs);
+}
+
+kmi_status fastq_quality_reads(kmi_ctx *ctx, const FastqScan &sc, ReadDesc **reads) {
+  void *pr;
+  KMI_TRY(ws_get(ctx, WS_READS, sizeof(ReadDesc) * (sc.n_seqs + 16), &pr));
+  KMI_HIP(ctx, hipMemsetAsync(pr, 0xff, sizeof(ReadDesc) * (sc.n_seqs + 16), ctx->stream));
+  *reads = (ReadDesc *)pr;
+  return KMI_OK;
+}
+kmi_status fastq_quality_launch(kmi_ctx *ctx, const uint8_t *bytes_dev, const FastqScan &sc, uint32_t k, const ReadDesc *reads, float *out_quals) {
+  ProfScope pq(ctx, "fastq_quality", sc.n_bytes);
+  hipLaunchKernelGGL(fastq_quality_kernel, dim3(2048), dim3(kQualThreads), qual_lds_bytes(k), ctx->stream, bytes_dev, (uint64_t)sc.n_bytes,
+                     reinterpret_cast<const uint32_t *>(sc.pk_eol), (uint64_t)(sc.n_cover / 32), k, qual_row_bytes(k), reads,
+                     (const uint64_t *)(ctx->d_totals + 2), out_quals, (uint64_t *)nullptr, 0u);
+  KMI_HIP(ctx, hipGetLastError());
+  return KMI_OK;
 }
 
 // verdict of the seq/qual length rule when the list pass carries it (call after a stream sync point is acceptable: it syncs)

@@ -662,8 +662,8 @@ template <int NW, int BITS> struct ListPassCfg {
   static uint32_t ent_stride(uint32_t k, bool split = false) { return (uint32_t)TILE / 8u + max_runs(k, split); }
   // run list (RUNS): one 32-bit entry per run of up to `seg` windows
   static uint32_t run_stride(uint32_t k, uint32_t seg, bool split = false) { return (uint32_t)TILE / seg + max_runs(k, split); }
-  static uint32_t wave_lds_bytes(uint32_t k, bool split = false) {   // bitmap window, event arrays, run table (two with a filter)
-    return (4u * WIN + 4u * CAP + 4u * max_runs(k, split) * (split ? 2u : 1u) + 15u) & ~15u;
+  static uint32_t wave_lds_bytes(uint32_t k, bool split = false, bool reads = false) {   // bitmap window, event arrays, run table (two with a filter; + the runs' line numbers for read descriptors)
+    return (4u * WIN + 4u * CAP + 4u * max_runs(k, split) * ((split ? 2u : 1u) + (reads ? 1u : 0u)) + 15u) & ~15u;
   }
 };
 
@@ -674,7 +674,12 @@ __global__ __launch_bounds__(kListThreads) void fastq_list_kernel(PackedInput in
                                                                  uint32_t wave_lds_bytes, const uint32_t *__restrict__ line_base,
                                                                  uint32_t *__restrict__ flags, void *__restrict__ ent_out,
                                                                  uint32_t *__restrict__ ent_cnt, uint32_t ent_stride,
-                                                                 uint32_t kSegWindows = 128u /* RUNS: windows per entry at most */) {
+                                                                 uint32_t kSegWindows = 128u /* RUNS: windows per entry at most */,
+                                                                 ReadDesc *__restrict__ reads = nullptr, const uint64_t *__restrict__ tile_off = nullptr) {
+  // reads / tile_off (position + quality builds, no sequence filter): the descriptor of every read whose first window starts in a
+  // tile -- slot = the read's sequence index, {buffer position of its first base, file-order index of its first k-mer} -- which is
+  // what fastq_quality_kernel starts from (until round 4 the extract pass wrote them). A crowded window (lines of a few bytes)
+  // does not make them: flag word 0, bit 3, and the caller takes the extract pass.
   uint16_t *const ent = reinterpret_cast<uint16_t *>(ent_out);
   uint32_t *const ent32 = reinterpret_cast<uint32_t *>(ent_out);
   // in.brk (sequence filters): the runs are cut where a break bit (an N by the filter's rule) falls inside them
@@ -686,6 +691,7 @@ __global__ __launch_bounds__(kListThreads) void fastq_list_kernel(PackedInput in
   uint16_t *S = reinterpret_cast<uint16_t *>(img + WIN);                                      // [CAP] line starts
   uint16_t *E = S + CAP;                                                                      // [CAP] line ends
   uint32_t *s_run = reinterpret_cast<uint32_t *>(E + CAP);                                    // [max_runs] first window | windows << 16
+  uint32_t *s_line = s_run + max_runs * (in.brk ? 2u : 1u);                                   // [max_runs] (reads) line number of the run | 1 << 31: the run opens its line
   const uint32_t *eolw = reinterpret_cast<const uint32_t *>(in.eol);
   const uint64_t n_words = in.n_cover / 32;
   const uint64_t n_waves = (uint64_t)gridDim.x * (kListThreads / kWave);
@@ -725,7 +731,7 @@ __global__ __launch_bounds__(kListThreads) void fastq_list_kernel(PackedInput in
   for (int i = 0; i < WPL; ++i) w_cur[i] = 0xffffffffu;
   if (tb < te) load_words(tb, w_cur);
   uint32_t lb = (tb < te) ? line_base[tb] : 0u;
-  bool bad = false;
+  bool bad = false, bad_reads = false;
   for (uint64_t t = tb; t < te; ++t) {
     const int64_t gw0 = (int64_t)(t * WORDS) - CTX;
 #pragma unroll
@@ -779,13 +785,14 @@ __global__ __launch_bounds__(kListThreads) void fastq_list_kernel(PackedInput in
         const int32_t j = (int32_t)(NSL + c) - 1;            // rank among the window's line starts; -1 = open at window start
         bool exists = c < ncand && (c >= 1u || (lb >= 1u && (j >= 0 || eoff)));
         const uint32_t role = (lb + c - 1u) & 3u;
-        uint32_t run = 0;
+        uint32_t run = 0, line_of_run = 0;
         if (exists && (role == 1u || role == 3u)) {
           const uint32_t s0 = (j >= 0) ? (uint32_t)S[j] : 0u;
           const int32_t je = j + (int32_t)eoff;
           const uint32_t e0 = (je >= 0 && (uint32_t)je < NE) ? (uint32_t)E[je] : NONE;   // NONE: no EOL up to k - 1 bytes past the tile
           if (role == 1u) {
             run = clip_run(s0, e0);
+            if (reads && run) line_of_run = (lb + c - 1u) | ((j >= 0 && s0 >= T0) ? 0x80000000u : 0u);
           } else if (c >= 1u) {                              // a quality line that starts in this tile
             if (j >= 2 && e0 != NONE) {
               const uint32_t len_seq = (uint32_t)E[je - 2] - (uint32_t)S[j - 2];
@@ -798,9 +805,11 @@ __global__ __launch_bounds__(kListThreads) void fastq_list_kernel(PackedInput in
         const uint32_t mine = run ? 1u : 0u;
         const uint32_t sc = wave_inclusive_scan(mine);
         if (run) s_run[n_runs + sc - 1u] = run;
+        if (reads && run) s_line[n_runs + sc - 1u] = line_of_run;
         n_runs += __shfl(sc, kWave - 1, kWave);
       }
     } else {
+      if (reads) bad_reads = true;
       // crowded window: the lanes walk the line starts of their own words (tile proper only) with bit scans
       const uint32_t first_idx = lb + ((inc - packed) & 0xffffu) - NSL;   // line index of this lane's first start (meaningful inside the tile)
       const bool carry_in = (lane == 0) && lb >= 1u && ((lb - 1u) & 3u) == 1u && (img[CTX] & 1u) == 0u &&
@@ -884,6 +893,20 @@ __global__ __launch_bounds__(kListThreads) void fastq_list_kernel(PackedInput in
     }
     uint32_t ebase = 0;   // entries of this tile so far
     uint16_t *etile = ent + (uint64_t)t * ent_stride;
+    if (reads && !in.brk && !bad_reads) {   // uniform: descriptors of the reads that open in this tile
+      uint32_t wbase = 0;   // windows of the tile's runs so far
+      for (uint32_t r0 = 0; r0 < n_runs; r0 += kWave) {
+        const bool have = r0 + lane < n_runs;
+        const uint32_t my_sc = have ? runs[r0 + lane] : 0u, my_ln = have ? s_line[r0 + lane] : 0u;
+        const uint32_t c = my_sc >> 16;
+        const uint32_t winc = wave_inclusive_scan(c);
+        if (have && (my_ln >> 31)) {
+          ReadDesc rd; rd.seq_pos = t * (uint64_t)TILE + (my_sc & 0xffffu); rd.out_off = tile_off[t] + wbase + winc - c;
+          reads[((my_ln & 0x7fffffffu) - 1u) >> 2] = rd;
+        }
+        wbase += __shfl(winc, kWave - 1, kWave);
+      }
+    }
     if constexpr (RUNS) {
       uint32_t *etile32 = ent32 + (uint64_t)t * ent_stride;
       for (uint32_t r0 = 0; r0 < n_runs; r0 += kWave) {
@@ -926,6 +949,7 @@ __global__ __launch_bounds__(kListThreads) void fastq_list_kernel(PackedInput in
     lb = lb_nxt;
   }
   if (bad) atomicOr(&flags[0], 4u);
+  if (bad_reads) atomicOr(&flags[0], 8u);
 }
 
 // geometry of the list-driven passes
@@ -3336,6 +3360,185 @@ static kmi_status alloc_mm_arrays(kmi_ctx *ctx, uint64_t total, int nw, int vw, 
   return KMI_OK;
 }
 
+}  // namespace kmi
+#include "kmi_tuples.h"
+namespace kmi {
+
+// The partition of a position / position + quality build straight from the parse (kmi_tuples.h): tuple_hist -> offsets ->
+// [quality values] -> tuple_scatter (records into the coarse buckets) -> scatter_fine. Same result as extract + partition_impl
+// (every (k-mer, id[, quality]) tuple in the fine bucket of its placement hash); the tuple arrays in file order never exist.
+// FASTQ: sc; FASTA: fa (with ids_by_rank). *n_out = tuples. split_keys / split_vals: as partition_impl (sized by the caller
+// through size_cb once the tuple count is known).
+template <int NW, int BITS, int VW, typename AllocFn>
+static kmi_status partition_from_parse(kmi_index *idx, const uint8_t *bytes_dev, const FastqScan *sc, const FastaScan *fa, uint64_t file_offset,
+                                       Partitioned *out, uint64_t *n_out, AllocFn alloc_split) {
+  kmi_ctx *ctx = idx->ctx;
+  using Cfg = ExCfg<NW, BITS>;
+  const bool fasta = fa != nullptr;
+  const bool canonical = idx->cfg.strand != KMI_STRAND_SINGLE;
+  const bool quality = VW == 2 && !fasta;
+  PackedInput in;
+  uint64_t n_tiles;
+  if (fasta) {
+    in.eol = fa->pk_break; in.stream = fa->pk_stream; in.n_bytes = fa->n_chars; in.n_cover = fa->n_cover; in.n_valid = fa->n_valid; in.brk = nullptr;
+    n_tiles = (fa->n_chars + Cfg::TILE - 1) / Cfg::TILE;
+  } else {
+    in.eol = sc->pk_eol; in.stream = sc->pk_stream; in.n_bytes = sc->n_bytes; in.n_cover = sc->n_cover; in.n_valid = sc->n_bytes; in.brk = sc->pk_brk;
+    n_tiles = sc->n_tiles;
+  }
+  PartWs w;
+  uint64_t n = fasta ? 0 : sc->n_tuples;
+  KMI_TRY(get_part_ws(ctx, (size_t)n, NW + VW, WS_KEYS_A, WS_KEYS_B, &w));
+  KMI_HIP(ctx, hipMemsetAsync(w.fine_hist, 0, sizeof(uint32_t) * kNumFine * kFineParts, ctx->stream));
+  ReadDesc *reads = nullptr;
+  if (quality) KMI_TRY(fastq_quality_reads(ctx, *sc, &reads));
+  if (!fasta) {
+    // FASTQ: the histogram pass of the fused count build -- the entry list (runs of up to eight windows of a
+    // read, fastq_list_kernel, which also carries the seq / qual length rule) and fastq_hist_list_kernel over it: no per-tile
+    // scans, rolled windows, the same tile ownership as tuple_scatter (2 ms where tuple_hist takes 7)
+    using LPC = ListPassCfg<NW, BITS>;
+    const bool split = sc->pk_brk != nullptr;
+    void *pl;
+    KMI_TRY(ws_get(ctx, WS_ENT_LIST, sizeof(uint16_t) * ((size_t)n_tiles * LPC::ent_stride(idx->shape.k, split) + 64), &pl)); uint16_t *ent = (uint16_t *)pl;
+    KMI_TRY(ws_get(ctx, WS_ENT_CNT, sizeof(uint32_t) * (n_tiles + 8), &pl)); uint32_t *ent_cnt = (uint32_t *)pl;
+    {
+      // (position + quality: the list pass also leaves the read descriptors the quality kernel starts from)
+      ProfScope ps(ctx, "fastq_list", n);
+      const uint32_t wave_lds = LPC::wave_lds_bytes(idx->shape.k, split, quality);
+      hipLaunchKernelGGL((fastq_list_kernel<NW, BITS>), dim3(kListGroups), dim3(kListThreads), wave_lds * (kListThreads / kWave), ctx->stream, in,
+                         n_tiles, idx->shape.k, LPC::max_runs(idx->shape.k, split), wave_lds, sc->line_base, ctx->d_flags, ent, ent_cnt,
+                         LPC::ent_stride(idx->shape.k, split), 128u, reads, sc->tile_off);
+    }
+    {
+      ProfScope ps(ctx, "fastq_hist", n);
+      hipLaunchKernelGGL((fastq_hist_list_kernel<NW, BITS>), dim3(kPartGroups), dim3(kHistThreads), 0, ctx->stream, in, n_tiles, idx->shape,
+                         canonical, (const uint16_t *)ent, (const uint32_t *)ent_cnt, LPC::ent_stride(idx->shape.k, split), w.fine_hist, w.wg_hist);
+    }
+  } else {
+    ProfScope ps(ctx, "tuple_hist", n);
+#define KMI_TUPLE_HIST(FA, RD)                                                                                                             \
+    hipLaunchKernelGGL((tuple_hist_kernel<NW, BITS, FA, RD>), dim3(kPartGroups), dim3(Cfg::NT), 0, ctx->stream, in, n_tiles, idx->shape, canonical, \
+                       fasta ? (const uint32_t *)nullptr : sc->line_base, fasta ? (const uint64_t *)nullptr : sc->tile_off, reads, w.fine_hist, w.wg_hist)
+    if (fasta) KMI_TUPLE_HIST(true, false); else if (quality) KMI_TUPLE_HIST(false, true); else KMI_TUPLE_HIST(false, false);
+#undef KMI_TUPLE_HIST
+  }
+  {
+    ProfScope ps(ctx, "fine_offsets", kNumFine);
+    launch_fine_offsets(ctx, w.fine_hist, w.fine_off, w.part_off, w.coarse_base);
+    hipLaunchKernelGGL(coarse_cursors_kernel, dim3(kNumCoarse / 4), dim3(256), 0, ctx->stream, (const uint32_t *)w.wg_hist, (uint32_t)kPartGroups,
+                       (const uint64_t *)w.coarse_base, w.wg_off);
+  }
+  KMI_HIP(ctx, hipGetLastError());
+  if (fasta) {   // the tuple count of a FASTA input is the histogram's total
+    KMI_HIP(ctx, hipMemcpyAsync(&n, w.fine_off + kNumFine, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+    KMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    PartWs w2;
+    KMI_TRY(get_part_ws(ctx, (size_t)n, NW + VW, WS_KEYS_A, WS_KEYS_B, &w2));   // (the record buffers at their real size; the tables stay where they are)
+    w.buf_a = w2.buf_a; w.buf_b = w2.buf_b;
+  }
+  *n_out = n;
+  if (n == 0) return KMI_OK;
+  float *dq = nullptr;
+  if (quality) {
+    uint32_t f0 = 0;   // (a window crowded with tiny lines made no descriptors: the caller takes the extract pass)
+    KMI_HIP(ctx, hipMemcpyAsync(&f0, ctx->d_flags, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    KMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (f0 & 8u) {
+      KMI_HIP(ctx, hipMemsetAsync(ctx->d_flags, 0, sizeof(uint32_t), ctx->stream));
+      *n_out = ~0ull;
+      return KMI_OK;
+    }
+    void *p;
+    KMI_TRY(ws_get(ctx, WS_INPUT2, (size_t)n * sizeof(float) + 64, &p)); dq = (float *)p;
+    KMI_TRY(fastq_quality_launch(ctx, bytes_dev, *sc, idx->shape.k, reads, dq));
+  }
+  uint64_t *split_keys = nullptr, *split_vals = nullptr;
+  KMI_TRY(alloc_split(n, &split_keys, &split_vals));
+  {
+    ProfScope ps(ctx, "tuple_scatter", n);
+#define KMI_TUPLE_SCATTER(FA)                                                                                                              \
+    hipLaunchKernelGGL((tuple_scatter_kernel<NW, BITS, VW, FA>), dim3(kPartGroups), dim3(Cfg::NT), 0, ctx->stream, in, n_tiles, idx->shape, canonical, \
+                       fasta ? (const uint32_t *)nullptr : sc->line_base, fasta ? (const uint64_t *)nullptr : sc->hdr_base,                \
+                       fasta ? (const uint64_t *)nullptr : sc->tile_off, file_offset, fasta ? fa->ids_by_rank : (const uint64_t *)nullptr, \
+                       (const float *)dq, (const uint64_t *)w.wg_off, w.buf_a, ctx->d_flags)
+    if (fasta) KMI_TUPLE_SCATTER(true); else KMI_TUPLE_SCATTER(false);
+#undef KMI_TUPLE_SCATTER
+  }
+  {
+    ProfScope ps(ctx, "scatter_fine", n);
+    hipLaunchKernelGGL((scatter_fine_kernel<NW, BITS, VW>), dim3(kNumCoarse * kFineParts), dim3(kPartThreads), 0, ctx->stream, w.buf_a,
+                       split_keys ? split_keys : w.buf_b, idx->shape, (const uint64_t *)w.fine_off, (const uint64_t *)w.part_off,
+                       (const uint64_t *)w.wg_off, (uint32_t)kPartGroups, (int)BUCKET_SUB, 0u, split_keys ? split_vals : (uint64_t *)nullptr);
+  }
+  KMI_HIP(ctx, hipGetLastError());
+  uint32_t fl = 0, fl0 = 0;
+  KMI_HIP(ctx, hipMemcpyAsync(&fl, ctx->d_flags + 3, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+  KMI_HIP(ctx, hipMemcpyAsync(&fl0, ctx->d_flags, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+  KMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (!fasta && (fl0 & 4u)) return fastq_length_verdict(ctx);   // (the list pass found a record whose sequence and quality lines differ in length)
+  if (fl) {
+    KMI_HIP(ctx, hipMemsetAsync(ctx->d_flags + 3, 0, sizeof(uint32_t), ctx->stream));
+    return set_err(ctx, KMI_ERR_OVERFLOW, "ShortSequenceKmerId increment overflow (k-mer more than 65535 bytes into its record)");
+  }
+  out->keys = split_keys ? split_keys : w.buf_b; out->fine_off = w.fine_off; out->scratch = nullptr;
+  return KMI_OK;
+}
+
+// Index::build_* of a position / position + quality index from the parse: as mm_insert_vw, with partition_from_parse
+template <int NW, int BITS, int VW>
+static kmi_status mm_build_vw(kmi_index *idx, const uint8_t *bytes_dev, const FastqScan *sc, const FastaScan *fa, uint64_t file_offset, bool *declined) {
+  kmi_ctx *ctx = idx->ctx;
+  Partitioned part;
+  uint64_t n = 0;
+  const bool fresh = !idx->has_data || idx->n_entries == 0;
+  uint64_t *nk = nullptr, *nv = nullptr, *noff = nullptr;
+  size_t kb = 0, vb = 0;
+  auto alloc_split = [&](uint64_t nt, uint64_t **sk, uint64_t **sv) -> kmi_status {
+    if (!fresh) return KMI_OK;   // (the records go to the workspace and are concatenated with the entries afterwards)
+    // an empty index: the fine partition of the records IS the index, so its last pass writes the key and value arrays directly
+    KMI_TRY(alloc_mm_arrays(ctx, nt, NW, VW, &nk, &nv, &noff, &kb, &vb));
+    *sk = nk; *sv = nv;
+    return KMI_OK;
+  };
+  kmi_status st = partition_from_parse<NW, BITS, VW>(idx, bytes_dev, sc, fa, file_offset, &part, &n, alloc_split);
+  if (st == KMI_OK && n == ~0ull) { *declined = true; return KMI_OK; }
+  if (st == KMI_OK && n == 0) return KMI_OK;
+  if (fresh) {
+    if (st == KMI_OK && hipMemcpyAsync(noff, part.fine_off, kOffBytes, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess) st = KMI_ERR_DEVICE;
+    if (st == KMI_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) st = KMI_ERR_DEVICE;
+    if (st != KMI_OK) { if (nk) { pool_free(ctx, nk, kb); pool_free(ctx, nv, vb); pool_free(ctx, noff, kOffBytes); } return st; }
+    free_index_arrays(idx);
+    idx->keys = nk; idx->mvals = nv; idx->bucket_off = noff; idx->n_entries = n; idx->has_data = true;
+    idx->keys_bytes = kb; idx->mvals_bytes = vb;
+    return KMI_OK;
+  }
+  KMI_TRY(st);
+  const uint64_t total = n + idx->n_entries;
+  KMI_TRY(alloc_mm_arrays(ctx, total, NW, VW, &nk, &nv, &noff, &kb, &vb));
+  {
+    ProfScope ps(ctx, "bucket_concat", n);
+    hipLaunchKernelGGL((bucket_concat_kernel<NW, VW>), dim3(kNumFine), dim3(256), 0, ctx->stream, (const uint64_t *)part.keys,
+                       (const uint64_t *)part.fine_off, (const uint64_t *)idx->keys, (const uint64_t *)idx->mvals,
+                       (const uint64_t *)(idx->has_data ? idx->bucket_off : nullptr), noff, nk, nv);
+  }
+  KMI_HIP(ctx, hipGetLastError());
+  KMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  free_index_arrays(idx);
+  idx->keys = nk; idx->mvals = nv; idx->bucket_off = noff; idx->n_entries = total; idx->has_data = true;
+  idx->keys_bytes = kb; idx->mvals_bytes = vb;
+  return KMI_OK;
+}
+template <int NW, int BITS>
+static kmi_status mm_build_impl(kmi_index *idx, const uint8_t *bytes_dev, const FastqScan *sc, const FastaScan *fa, uint64_t file_offset, bool *declined) {
+  if (idx->val_words == 1) return mm_build_vw<NW, BITS, 1>(idx, bytes_dev, sc, fa, file_offset, declined);
+  if (idx->val_words == 2) return mm_build_vw<NW, BITS, 2>(idx, bytes_dev, sc, fa, file_offset, declined);
+  return set_err(idx->ctx, KMI_ERR_INVALID, "not a multimap index");
+}
+static kmi_status index_build_records_from_parse(kmi_index *idx, const uint8_t *bytes_dev, const FastqScan *sc, const FastaScan *fa, uint64_t file_offset, bool *declined) {
+  *declined = false;
+  KMI_DISPATCH(idx->shape, mm_build_impl, idx, bytes_dev, sc, fa, file_offset, declined);
+}
+
 template <int NW, int BITS, int VW>
 static kmi_status mm_insert_vw(kmi_index *idx, const uint64_t *recs_dev, size_t n, bool transform, const float *in_q = nullptr,
                                const uint64_t *in_v = nullptr) {
@@ -4012,7 +4215,23 @@ kmi_status kmi_index_build_dev(kmi_index *idx, const uint8_t *bytes_dev, size_t 
     KMI_TRY(extract_run(ctx, &idx->cfg, bytes_dev, n_bytes, file_offset, (uint64_t *)dk, nullptr, (size_t)nt, true, true, &nt, &ns));
     return index_insert(idx, (const uint64_t *)dk, (size_t)nt, false);
   }
-  // PositionIndex / PositionQualityIndex: KmerPosition(Quality)TupleParser tuples -> multimap insert
+  // PositionIndex / PositionQualityIndex: KmerPosition(Quality)TupleParser tuples -> multimap insert. Partitioned straight from
+  // the parse (kmi_tuples.h); KMI_TUPLES=extract keeps the round-1 order (tuple arrays in file order, then the key partition)
+  if (ctx->tuples_from_parse) {
+    bool declined = false;
+    if (idx->cfg.seq_format == KMI_FMT_FASTQ) {
+      FastqScan sc;
+      KMI_TRY(fastq_scan(ctx, &idx->cfg, bytes_dev, n_bytes, &sc, false));   // (the list pass carries the seq / qual length rule)
+      if (sc.n_tuples == 0) return fastq_scan(ctx, &idx->cfg, bytes_dev, n_bytes, &sc, true);   // (no k-mer at all: only the record rules are left to check)
+      KMI_TRY(index_build_records_from_parse(idx, bytes_dev, &sc, nullptr, file_offset, &declined));
+    } else {
+      FastaScan fa;
+      KMI_TRY(fasta_scan(ctx, &idx->cfg, bytes_dev, n_bytes, file_offset, true, &fa));
+      if (fa.n_chars < idx->shape.k) return KMI_OK;
+      KMI_TRY(index_build_records_from_parse(idx, bytes_dev, nullptr, &fa, file_offset, &declined));
+    }
+    if (!declined) return KMI_OK;   // (declined: lines of a few bytes crowd a window of the list pass -- the extract pass below takes the input)
+  }
   const uint32_t nw = idx->shape.n_words, vw = idx->val_words;
   uint64_t nt = 0, ns = 0;
   KMI_TRY(extract_count(ctx, &idx->cfg, bytes_dev, n_bytes, &nt, &ns));

@@ -102,6 +102,7 @@ struct kmi_ctx {
   uint32_t dist_pool_pct = 100;       // the estimate itself, in percent (KMI_DIST_POOL_PCT: tests make it too small)
   uint64_t dist_pool_slack = 65536;   // records a rank's receive pool holds beyond the estimate of its share (KMI_DIST_POOL_SLACK: tests shrink it so that the pool has to grow)
   uint32_t dist_chunks = 4;      // record-aligned chunks of a rank's share in the build over ranks (exchange of one beside the front end of the next; KMI_DIST_CHUNKS)
+  bool tuples_from_parse = true; // position / position + quality builds partition their tuples straight from the parse (kmi_tuples.h); KMI_TUPLES=extract: extract, then partition
   bool sk_slack = true;          // fine buckets with room instead of a counting pass (sk_scatter_fine_slack_kernel); KMI_SK_SLACK=0: always count
   bool front_fused = true;       // FASTQ front end of the super-k-mer build in one pass (kmi_front.h); KMI_FRONT=general: scan + list + minimizer
   uint32_t front_waves = 0;      // resident wavefronts of the front kernel (ranges of a large input); 0: not asked yet
@@ -281,9 +282,11 @@ kmi_status extract_run(kmi_ctx *ctx, const kmi_config *cfg, const uint8_t *bytes
 kmi_status upload_quality_lut(kmi_ctx *ctx);
 
 // tile scan of a FASTQ partition; the packed arrays and per-tile line bases stay in the workspace
+struct ReadDesc { uint64_t seq_pos, out_off; };   // slot = sequence index of the read; out_off = ~0: the read has no k-mer
 struct FastqScan {
   uint64_t n_tiles, n_tuples, n_seqs, n_bytes, n_cover;
   const uint32_t *line_base;
+  const uint64_t *hdr_base;   // [n_tiles] 1 + position of the last record start before the tile (0: none)
   const uint64_t *tile_off;   // [n_tiles + 1] k-mer windows before each scan tile
   const uint8_t *pk_eol, *pk_stream;
   const uint8_t *pk_brk;      // window-break bitmap of a sequence filter, or null
@@ -292,6 +295,10 @@ struct FastqScan {
 // fastq_length_verdict afterwards
 kmi_status fastq_scan(kmi_ctx *ctx, const kmi_config *cfg, const uint8_t *bytes_dev, size_t n_bytes, FastqScan *out, bool check_lengths = true);
 kmi_status fastq_length_verdict(kmi_ctx *ctx);
+// the quality values of the scanned input's k-mers in file order (out_quals[t] for tuple t), from the read descriptors a pass over
+// the windows has filled (slot = sequence index): fastq_quality_kernel. alloc_reads: a cleared descriptor array for sc.n_seqs reads
+kmi_status fastq_quality_reads(kmi_ctx *ctx, const FastqScan &sc, ReadDesc **reads);
+kmi_status fastq_quality_launch(kmi_ctx *ctx, const uint8_t *bytes_dev, const FastqScan &sc, uint32_t k, const ReadDesc *reads, float *out_quals);
 
 // FASTA: byte-space passes -> compacted character stream (kmi_fasta.hip)
 struct FastaScan {
