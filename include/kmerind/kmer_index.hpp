@@ -363,7 +363,7 @@ inline std::vector<uint8_t> read_whole_file(const std::string &filename) {
 }
 // what ONE rank of p reads of a file (partitioned_file, file.hpp:1216-1430): its nominal byte range [n r / p, n (r + 1) / p) plus
 // `lookahead` bytes (where its last record ends and the next rank's first begins); *reaches_eof: the buffer ends with the file
-struct FileRange { std::vector<uint8_t> bytes; uint64_t offset = 0, nominal = 0; bool reaches_eof = false; };
+struct FileRange { std::vector<uint8_t> bytes; uint64_t offset = 0, nominal = 0; bool reaches_eof = false; int prev_byte = -1 /* the file byte before the range, -1 at the file start */; };
 inline FileRange read_file_range(const std::string &filename, int rank, int p, uint64_t lookahead) {
   FILE *f = std::fopen(filename.c_str(), "rb");
   if (!f) throw std::invalid_argument("cannot open " + filename);
@@ -376,6 +376,7 @@ inline FileRange read_file_range(const std::string &filename, int rank, int p, u
   FileRange r;
   r.offset = lo; r.nominal = hi - lo; r.reaches_eof = end == n;
   r.bytes.resize((size_t)(end - lo));
+  if (lo > 0) { std::fseek(f, (long)(lo - 1), SEEK_SET); r.prev_byte = std::fgetc(f); }
   std::fseek(f, (long)lo, SEEK_SET);
   if (end > lo && std::fread(r.bytes.data(), 1, (size_t)(end - lo), f) != (size_t)(end - lo)) { std::fclose(f); throw std::runtime_error("short read on " + filename); }
   std::fclose(f);
@@ -705,11 +706,16 @@ class Index {
       // (partitioned_file + FASTQParser::find_first_record, file.hpp:1216-1430, fastq_loader.hpp:269-364)
       need_rccl("build_posix / build_mmap / build_mpiio");
       if (fmt == KMI_FMT_FASTA) {
-        // FASTA: every rank reads the file whole (a block's bookkeeping -- which record it starts in, in which state -- needs what
-        // lies before it; the reference gets it from collectives over the blocks, fasta_loader.hpp:202-470) and keeps its block
-        std::vector<uint8_t> whole = detail::read_whole_file(filename);
-        ::kmerind::check(ctx, kmi_index_build_fasta_file_dist_host(idx, rccl, whole.data(), whole.size()));
-        return;
+        // FASTA: the rank's block of the equal split plus look-ahead; what the block cannot know from its own bytes -- which record
+        // it starts in, in which state -- comes from the other ranks' block summaries, one small gather inside the library
+        // (fasta_loader.hpp:202-470 gets it from collectives over the blocks' first and last lines)
+        for (uint64_t look = 1ull << 16;; look *= 16) {
+          detail::FileRange r = detail::read_file_range(filename, comm.rank(), comm.size(), look);
+          int need_more = 0;
+          ::kmerind::check(ctx, kmi_index_build_fasta_range_dist_host(idx, rccl, r.bytes.data(), r.bytes.size(), r.offset, r.nominal, r.reaches_eof ? 1 : 0,
+                                                                       r.prev_byte, &need_more));
+          if (!need_more) return;
+        }
       }
       if (fmt != KMI_FMT_FASTQ) throw std::invalid_argument("build_* with size() > 1 reads FASTQ or FASTA files");
       for (uint64_t look = 1ull << 20;; look *= 8) {

@@ -392,6 +392,19 @@ kmi_status kmi_index_build_range_dist_host(kmi_index *idx, kmi_comm *comm, const
 /* the same for a FASTA file: every rank passes the WHOLE file; it keeps block comm.rank() of an equal split (bookkeeping on the
  * device, kmi_fasta_partition_dev) and enters the collective build with it. Works for comm.size() == 1 too. */
 kmi_status kmi_index_build_fasta_file_dist_host(kmi_index *idx, kmi_comm *comm, const uint8_t *bytes, size_t n_bytes);
+/* ... and with every rank holding only ITS byte range of the file (file.hpp:1436-1610 hands each rank 1/p of the file): bytes =
+ * file bytes [buffer_offset, buffer_offset + n_bytes), of which the first nominal_bytes are the rank's block of the equal split
+ * (block r = [n r / p, n (r + 1) / p)) and the rest look-ahead; prev_byte = the file byte before the buffer, -1 at the file
+ * start. What a block cannot know from its own bytes -- the kind of line its first byte sits on, the records that start before it,
+ * whether the file opens with a header (fasta_loader.hpp:232-456) -- comes from the ranks' block summaries
+ * (kmi_fasta_block_summary_dev), gathered once over the communicator and composed left to right. *need_more = 1 (returned BEFORE
+ * anything collective): the k - 1 sequence characters the last windows of the block reach into do not end inside the look-ahead;
+ * read further and call again. The union over the ranks is the whole file's tuples, each once, with the ids of a whole-file parse. */
+kmi_status kmi_index_build_fasta_range_dist_host(kmi_index *idx, kmi_comm *comm, const uint8_t *bytes, size_t n_bytes, uint64_t buffer_offset,
+                                                 uint64_t nominal_bytes, int reaches_eof, int prev_byte, int *need_more);
+/* the line-kind machine over bytes [0, n_bytes) of a FASTA buffer in HBM as a transfer function: out6 = for the incoming states
+ * KMI_FA_OUTSIDE, HEADER, SEQUENCE in turn {state behind the bytes, records that start inside}. first_is_line_start: byte 0 opens a line */
+kmi_status kmi_fasta_block_summary_dev(kmi_ctx *ctx, const uint8_t *bytes_dev, size_t n_bytes, int first_is_line_start, uint64_t *out6);
 /* weighted insert and update() of the counting maps with comm.size() > 1: the pairs travel to the ranks that own their keys
  * (records: n x (n_words key words, one value word); *n_updated = pairs applied on THIS rank) */
 kmi_status kmi_index_insert_pairs_dist_host(kmi_index *idx, kmi_comm *comm, const uint64_t *records, size_t n);

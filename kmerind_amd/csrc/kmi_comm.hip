@@ -269,6 +269,30 @@ kmi_status comm_all_to_all_counts2(kmi_comm *c, const uint64_t *send_counts, uin
   return KMI_OK;
 }
 
+// every rank's `n` words to every rank (all[r * n ..] = rank r's): block summaries, verdicts -- a few words, host to host
+kmi_status comm_allgather_words(kmi_comm *c, const uint64_t *mine, size_t n, uint64_t *all) {
+  kmi_ctx *ctx = c->ctx;
+  const int p = c->nranks;
+  if (p == 1 && !ctx->force_dist) { memcpy(all, mine, sizeof(uint64_t) * n); return KMI_OK; }
+  std::vector<uint64_t> send((size_t)p * n);
+  for (int r = 0; r < p; ++r) memcpy(&send[(size_t)r * n], mine, sizeof(uint64_t) * n);
+  if (c->has_transport) return tp_words(c, send.data(), all, n);
+  void *d = nullptr;
+  const size_t bytes = sizeof(uint64_t) * (size_t)p * n;
+  KMI_TRY(ws_get(ctx, WS_MISC, 2 * bytes + 64, &d));
+  uint64_t *d_s = (uint64_t *)d, *d_r = d_s + (size_t)p * n;
+  KMI_HIP(ctx, hipMemcpyAsync(d_s, send.data(), bytes, hipMemcpyHostToDevice, ctx->stream));
+  KMI_NCCL(c, rccl().GroupStart());
+  for (int r = 0; r < p; ++r) {
+    KMI_NCCL(c, rccl().Send(d_s + (size_t)r * n, n * sizeof(uint64_t), kNcclUint8, r, c->nccl, ctx->stream));
+    KMI_NCCL(c, rccl().Recv(d_r + (size_t)r * n, n * sizeof(uint64_t), kNcclUint8, r, c->nccl, ctx->stream));
+  }
+  KMI_NCCL(c, rccl().GroupEnd());
+  KMI_HIP(ctx, hipMemcpyAsync(all, d_r, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  KMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return KMI_OK;
+}
+
 // all2allv that does not hold the context's stream: queued on the communicator's own stream behind everything the context's
 // stream holds now (the send buffer's producer), so the caller's next kernels run beside the transfer. No host synchronisation.
 // largest_bytes: the largest peer message anywhere (comm_all_to_all_counts2). An exchange larger than any that carried checksums

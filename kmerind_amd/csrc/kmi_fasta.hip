@@ -574,5 +574,39 @@ extern "C" kmi_status kmi_fasta_partition_dev(kmi_ctx *ctx, const uint8_t *bytes
   return KMI_OK;
 }
 
+// The line-kind machine over bytes [0, n_bytes) of a FASTA buffer in HBM, as a transfer function: for every state the machine can
+// enter the range in (KMI_FA_OUTSIDE / HEADER / SEQUENCE), the state it leaves it in and the records (header group -> sequence
+// group transitions) that start inside. What a rank tells the others about its block, so that every rank can work out where ITS
+// block starts (fasta_loader.hpp:232-456 does this with collectives over the ranks' first / last lines; file.hpp:1436-1610):
+// summaries compose left to right. out6 = {out[O], records[O], out[H], records[H], out[S], records[S]}.
+extern "C" kmi_status kmi_fasta_block_summary_dev(kmi_ctx *ctx, const uint8_t *bytes_dev, size_t n_bytes, int first_is_line_start, uint64_t *out6) {
+  using namespace kmi;
+  if (!ctx || !out6) return KMI_ERR_INVALID;
+  for (uint32_t in = 0; in < 3; ++in) { out6[2 * in] = in; out6[2 * in + 1] = 0; }
+  if (n_bytes == 0) return KMI_OK;
+  KMI_HIP(ctx, hipSetDevice(ctx->device));
+  const uint64_t n_tiles = (n_bytes + FaCfg::TILE - 1) / FaCfg::TILE;
+  const uint64_t n_blocks = (n_tiles + 1023) / 1024;
+  void *p;
+  KMI_TRY(ws_get(ctx, WS_TILE_INFO, sizeof(FaTileInfo) * (n_tiles + 1), &p)); FaTileInfo *info = (FaTileInfo *)p;
+  KMI_TRY(ws_get(ctx, WS_MISC, sizeof(FaTileSum) * (n_blocks + 1), &p)); FaTileSum *sums = (FaTileSum *)p;
+  {
+    ProfScope ps(ctx, "fasta_scan_tiles", n_bytes);
+    hipLaunchKernelGGL(fasta_scan_tiles_kernel, dim3((unsigned)n_tiles), dim3(FaCfg::NT), 0, ctx->stream, bytes_dev, (uint64_t)n_bytes,
+                       first_is_line_start != 0, info);
+    hipLaunchKernelGGL(fasta_offsets_reduce_kernel, dim3((unsigned)n_blocks), dim3(1024), 0, ctx->stream, (const FaTileInfo *)info, n_tiles, sums);
+  }
+  KMI_HIP(ctx, hipGetLastError());
+  std::vector<FaTileSum> h(n_blocks);
+  KMI_HIP(ctx, hipMemcpyAsync(h.data(), sums, sizeof(FaTileSum) * n_blocks, hipMemcpyDeviceToHost, ctx->stream));
+  KMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  for (uint32_t in = 0; in < 3; ++in) {
+    uint32_t st = in; uint64_t ev = 0;
+    for (uint64_t b = 0; b < n_blocks; ++b) { ev += h[b].nev[st]; st = (h[b].map >> (2u * st)) & 3u; }
+    out6[2 * in] = st; out6[2 * in + 1] = ev;
+  }
+  return KMI_OK;
+}
+
 namespace kmi {
 }  // namespace kmi

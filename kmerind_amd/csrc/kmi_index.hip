@@ -4823,6 +4823,71 @@ kmi_status kmi_index_build_fasta_file_dist_host(kmi_index *idx, kmi_comm *comm, 
   return st;
 }
 
+// FASTA over ranks by BYTE RANGE (file.hpp:1436-1610, fasta_loader.hpp:202-470): the rank brings only its block of an equal split of
+// the file plus look-ahead, and what it cannot know from its own bytes -- the kind of line its first byte sits on, the records that
+// start before it, whether the file opens with a header -- comes from the other ranks' block summaries (kmi_fasta_block_summary_dev:
+// the line-kind machine over a block as a transfer function), gathered once and composed left to right. bytes = file bytes
+// [buffer_offset, buffer_offset + n_bytes), the first nominal_bytes of them the rank's block; prev_byte = the file byte before the
+// buffer (-1 at the file start); *need_more = 1: the k - 1 sequence characters behind the block (the last windows' overlap) do not
+// end inside the look-ahead -- nothing collective has happened, the caller reads further and calls again.
+kmi_status kmi_index_build_fasta_range_dist_host(kmi_index *idx, kmi_comm *comm, const uint8_t *bytes, size_t n_bytes, uint64_t buffer_offset,
+                                                 uint64_t nominal_bytes, int reaches_eof, int prev_byte, int *need_more) {
+  KMI_TRY(dist_check(idx, comm));
+  kmi_ctx *ctx = idx->ctx;
+  if (!need_more) return KMI_ERR_INVALID;
+  *need_more = 0;
+  if (idx->cfg.seq_format != KMI_FMT_FASTA) return set_err(ctx, KMI_ERR_INVALID, "not a FASTA index");
+  if ((n_bytes && !bytes) || nominal_bytes > n_bytes) return set_err(ctx, KMI_ERR_INVALID, "bad buffer");
+  const uint32_t p = (uint32_t)kmi::comm_size(comm), r = (uint32_t)kmi::comm_rank(comm), k = idx->shape.k;
+  const bool first_ls = buffer_offset == 0 || prev_byte == (int)'\n';
+  void *d_bytes;
+  KMI_TRY(ws_get(ctx, WS_INPUT, n_bytes + 64, &d_bytes));
+  if (n_bytes) KMI_HIP(ctx, hipMemcpyAsync(d_bytes, bytes, n_bytes, hipMemcpyHostToDevice, ctx->stream));
+  uint64_t mine[8] = {0, 0, 1, 0, 2, 0, 0, 0};
+  KMI_TRY(kmi_fasta_block_summary_dev(ctx, (const uint8_t *)d_bytes, (size_t)nominal_bytes, first_ls ? 1 : 0, mine));
+  mine[6] = (buffer_offset == 0 && n_bytes) ? bytes[0] : 0;   // (rank 0: the file's first byte decides init_parser's index shift)
+  mine[7] = nominal_bytes;
+  // where the overlap ends: the (k - 1)-th sequence character at or behind the block's end, for every state the machine may be in there
+  auto step = [](uint32_t &state, uint8_t c) {
+    if (c == '>' || c == ';') state = KMI_FA_HEADER;
+    else state = (state == KMI_FA_OUTSIDE) ? (uint32_t)KMI_FA_OUTSIDE : (uint32_t)KMI_FA_SEQUENCE;
+  };
+  uint64_t end_for[3] = {nominal_bytes, nominal_bytes, nominal_bytes};
+  for (uint32_t st0 = 0; st0 < 3; ++st0) {
+    if (k <= 1 || nominal_bytes >= n_bytes) { end_for[st0] = nominal_bytes < n_bytes ? nominal_bytes : n_bytes; continue; }
+    uint32_t st = st0, need = k - 1u;
+    uint64_t i = nominal_bytes;
+    for (; i < n_bytes && need; ++i) {
+      const uint8_t c = bytes[i];
+      const bool ls = i == 0 ? first_ls : bytes[i - 1] == '\n';
+      if (ls) step(st, c);
+      if (st == KMI_FA_SEQUENCE && c != '\n' && c != '\r') --need;
+    }
+    if (need && !reaches_eof) { *need_more = 1; return KMI_OK; }
+    end_for[st0] = need ? n_bytes : i;
+  }
+  if (k > 1 && nominal_bytes >= n_bytes && !reaches_eof && p > 1 && r + 1 < p) { *need_more = 1; return KMI_OK; }   // (no look-ahead at all behind a block that is not the file's last)
+  // ---- collective from here on
+  std::vector<uint64_t> all((size_t)p * 8);
+  KMI_TRY(kmi::comm_allgather_words(comm, mine, 8, all.data()));
+  uint32_t st = KMI_FA_OUTSIDE; uint64_t ev = 0;
+  for (uint32_t q = 0; q < r; ++q) { const uint64_t *t = &all[(size_t)q * 8]; ev += t[2 * st + 1]; st = (uint32_t)t[2 * st]; }
+  uint64_t first = 0;
+  for (uint32_t q = 0; q < p; ++q) if (all[(size_t)q * 8 + 7]) { first = all[(size_t)q * 8 + 6]; break; }   // the first non-empty block opens the file
+  kmi_fasta_partition part; memset(&part, 0, sizeof(part));
+  part.valid_bytes = nominal_bytes;
+  part.start_state = buffer_offset == 0 ? (uint32_t)KMI_FA_OUTSIDE : st;
+  part.at_line_start = first_ls ? 1u : 0u;
+  part.records_before = ev;
+  part.index_shift = (first == '>' || first == ';') ? 0u : 1u;
+  const uint32_t st_end = (uint32_t)mine[2 * part.start_state];   // the machine's state behind the block
+  const uint64_t end = end_for[st_end] < nominal_bytes ? nominal_bytes : end_for[st_end];
+  KMI_TRY(kmi_ctx_set_fasta_partition(ctx, &part));
+  const kmi_status stb = kmi_index_build_dist_dev(idx, comm, (const uint8_t *)d_bytes, (size_t)(end < n_bytes ? end : n_bytes), buffer_offset);
+  (void)kmi_ctx_set_fasta_partition(ctx, nullptr);
+  return stb;
+}
+
 kmi_status kmi_index_build_dist_host(kmi_index *idx, kmi_comm *comm, const uint8_t *bytes, size_t n_bytes, uint64_t file_offset) {
   KMI_TRY(dist_check(idx, comm));
   kmi_ctx *ctx = idx->ctx;

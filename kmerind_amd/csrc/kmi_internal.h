@@ -263,6 +263,7 @@ kmi_status comm_all_to_all_counts(kmi_comm *c, const uint64_t *send_counts, uint
 kmi_status comm_all_to_all_v(kmi_comm *c, const void *send_dev, const uint64_t *send_counts, void *recv_dev, const uint64_t *recv_counts,
                              size_t elem_bytes);
 kmi_status comm_allreduce_sum(kmi_comm *c, uint64_t *value);
+kmi_status comm_allgather_words(kmi_comm *c, const uint64_t *mine, size_t n, uint64_t *all);
 kmi_status comm_all_to_all_counts2(kmi_comm *c, const uint64_t *send_counts, uint64_t my_largest_bytes, uint64_t *recv_counts, uint64_t *largest_bytes);
 kmi_status comm_all_to_all_v_async(kmi_comm *c, const void *send_dev, const uint64_t *send_counts, void *recv_dev, const uint64_t *recv_counts,
                                    size_t elem_bytes, uint64_t largest_bytes);

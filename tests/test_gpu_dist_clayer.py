@@ -295,3 +295,71 @@ def test_de_bruijn_nodes_c_layer_over_ranks():
     for r in range(world):
         assert ret[r][2] == om.size()
         assert (nodes(ret[r][4], ret[r][5]) == nodes(*om.find(ret[r][3], canonical=True))).all()
+
+
+def _fasta_worker(rank, world, port, data, k, alpha, look, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import kmerind_amd as K
+        from kmerind_amd import _lib as L
+        from kmerind_amd.transport import GroupComm
+        ctx = K.Context(0, rank=rank, nranks=world)
+        comm = GroupComm(ctx)
+        idx = K.PositionIndex(ctx, K.make_config(k, alpha, strand="canonical", seq_format="fasta", index_kind="position"))
+        n = len(data)
+        lo = n // world * rank + (n % world) * rank // world
+        hi = n if rank + 1 == world else n // world * (rank + 1) + (n % world) * (rank + 1) // world
+        rounds = 0
+        while True:                                  # what the facade's build_posix does: the block plus look-ahead, more when asked
+            end = min(n, hi + look)
+            buf = np.frombuffer(data[lo:end], dtype=np.uint8).copy()
+            need = C.c_int(0)
+            ptr = buf.ctypes.data_as(C.c_void_p) if buf.size else None
+            ctx.check(L.lib.kmi_index_build_fasta_range_dist_host(idx.h, comm.h, ptr, buf.size, lo, hi - lo, 1 if end == n else 0,
+                                                                  data[lo - 1] if lo > 0 else -1, C.byref(need)))
+            rounds += 1
+            if not need.value:
+                break
+            look *= 16
+        keys, vals = idx.to_vector()
+        ret[rank] = (keys.copy(), vals.copy(), rounds, comm.calls["bytes"])
+        idx.close()
+        comm.close()
+        ctx.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,k,alpha,which", [(2, 31, "DNA", "test.fasta"), (4, 21, "DNA5", "test2.fasta"), (3, 31, "DNA", "synthetic"),
+                                                 (4, 63, "DNA5", "synthetic"), (4, 15, "DNA", "tiny")])
+def test_fasta_position_index_by_byte_range_over_ranks(world, k, alpha, which):
+    """FASTA over ranks the way the reference shards it (file.hpp:1436-1610): every rank holds 1/p of the file's BYTES plus
+    look-ahead, wherever that cuts -- inside a header, inside a sequence line, before the first header -- and the block
+    bookkeeping comes from the ranks' block summaries (kmi_fasta_block_summary_dev) gathered inside
+    kmi_index_build_fasta_range_dist_host. The union of the ranks' (k-mer, LongSequenceKmerId) tuples is the oracle's parse of the
+    whole file: same k-mers, same sequence indices, same file offsets."""
+    from tests.test_gpu_fasta import _synthetic_fasta, GOLD
+    alpha_id = {"DNA": orc.DNA, "DNA5": orc.DNA5}[alpha]
+    if which == "synthetic":
+        data = _synthetic_fasta(np.random.default_rng(5 * k + world), 40, line=60, eol=b"\n", orphan=True)
+    elif which == "tiny":
+        data = b"ACGTACGTACGTACGTAAC\n>r1 x\nACGTTGCATGCATGCATGCAAGT\nTTGACCA\n;c\n>r2\n\nGGGTACGATCGATCGATGCATGCAC\n"
+    else:
+        data = open(os.path.join(GOLD, "data", which), "rb").read()
+    ret = mp.Manager().dict()
+    mp.spawn(_fasta_worker, args=(world, _free_port(), data, k, alpha, 16, ret), nprocs=world, join=True)   # 16 bytes of look-ahead: every rank has to ask for more
+    s = orc.kspec(k, alpha_id)
+    ex = orc.extract(s, data, orc.FASTA, want_ids=True)
+    ref = orc.MultiMap(s, orc.CANONICAL, 1)
+    ref.insert(ex["kmers"], ex["ids"].reshape(-1, 1))
+    rk, rv = ref.export()
+
+    def canon(keys, v):
+        rows = np.concatenate([np.asarray(keys).reshape(len(v), -1), np.asarray(v).reshape(len(v), -1)], axis=1)
+        return rows[np.lexsort([rows[:, c] for c in range(rows.shape[1] - 1, -1, -1)])]
+
+    got = canon(np.concatenate([ret[r][0] for r in range(world)]), np.concatenate([ret[r][1] for r in range(world)]))
+    exp = canon(rk, rv)
+    assert got.shape == exp.shape and (got == exp).all()
+    assert any(ret[r][2] > 1 for r in range(world)) or k <= 17     # the look-ahead had to grow on some rank
