@@ -2985,7 +2985,10 @@ static kmi_status sk_back_end(kmi_index *idx, const uint64_t *rec_a, uint64_t R,
     // persistent workgroups (one per CU: each takes the whole LDS) pull the buckets from a queue word
     uint32_t *queue = ctx->d_flags + 40;
     if (!slack) KMI_HIP(ctx, hipMemsetAsync(queue, 0, sizeof(uint32_t) * 8, ctx->stream));   // (+ the redo pass's queue word, the redo count, a spare)
-    const uint32_t wgs = ctx->n_cus ? ctx->n_cus : 256u;
+#ifndef KMI_SK_WGS_PER_CU
+#define KMI_SK_WGS_PER_CU 1
+#endif
+    const uint32_t wgs = (ctx->n_cus ? ctx->n_cus : 256u) * KMI_SK_WGS_PER_CU;
     // KMI_SK_REDUCE=2: sk_reduce2 (wavefront-private tables over the sorted bins of a bucket, kmi_reduce2.h) takes every bucket first;
     // what it puts on its redo list -- a bin that does not fit a private table, a bucket that does not fit the stage -- goes through
     // sk_reduce (shared tables, passes) behind it, which reads the list's length on the device. Built for the round-3 verdict and

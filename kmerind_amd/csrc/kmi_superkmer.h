@@ -750,7 +750,10 @@ struct SkTab2 {
 };
 
 template <bool CANON, int OWN_, bool SPECIAL>
-__global__ __launch_bounds__(KMI_SK_NT) void sk_reduce_kernel(const uint64_t *__restrict__ recs, const uint64_t *__restrict__ rec_off, uint32_t k,
+#ifndef KMI_SK_MIN_WAVES
+#define KMI_SK_MIN_WAVES 4   // wavefronts per SIMD the register budget has to allow
+#endif
+__global__ __launch_bounds__(KMI_SK_NT, KMI_SK_MIN_WAVES) void sk_reduce_kernel(const uint64_t *__restrict__ recs, const uint64_t *__restrict__ rec_off, uint32_t k,
                                                         const uint64_t *__restrict__ kmer_off /* k-mers before every bucket */,
                                                         uint64_t *__restrict__ tmp_keys, uint32_t *__restrict__ tmp_vals,
                                                         uint32_t *__restrict__ out_cnt, uint32_t *__restrict__ flags,

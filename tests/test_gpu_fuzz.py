@@ -101,3 +101,87 @@ def test_fasta_extract_and_build_follow_the_oracle_on_ragged_fasta(ctx, seed):
     a, b = orc.sorted_pairs(*idx.to_vector()), orc.sorted_pairs(*m.export())
     assert a[0].shape == b[0].shape and (a[0] == b[0]).all() and (a[1] == b[1]).all()
     idx.close()
+
+
+@pytest.fixture(scope="module")
+def small_range_ctx():
+    """a context whose one-pass front end cuts its input into byte ranges of 2 KB (KMI_FRONT_MIN_RANGE is read when the context is
+    made): range boundaries then fall everywhere -- inside headers, sequence lines, '+' lines, quality lines, between CR and LF"""
+    import os
+    import kmerind_amd as K
+    old = os.environ.get("KMI_FRONT_MIN_RANGE")
+    os.environ["KMI_FRONT_MIN_RANGE"] = "2048"
+    c = K.Context(0)
+    if old is None:
+        del os.environ["KMI_FRONT_MIN_RANGE"]
+    else:
+        os.environ["KMI_FRONT_MIN_RANGE"] = old
+    yield c
+    c.close()
+
+
+@pytest.mark.parametrize("k", [17, 21, 25, 31])
+@pytest.mark.parametrize("kind", ["fixed", "ragged", "crlf", "blank", "lowerN", "noeol"])
+def test_one_pass_front_end_fuzz_with_small_ranges(small_range_ctx, kind, k):
+    """kmi_front.h (the whole FASTQ front end in one pass, every wavefront on a byte range of its own with an INFERRED line index)
+    against the oracle: 32 seeds per (text kind, k), ranges of 2 KB, both strand models, 200 - 4000 reads. Whatever the path decides
+    -- take the input or hand it to the general front end -- the map must be the oracle's; over the seeds of a case both must happen
+    for the kinds that allow it (this was tools/exp/front_fuzz.py, an untracked script, in round 3)."""
+    import kmerind_amd as K
+    from tests.test_gpu_index import _fastq_variant, _same_map, STRAND
+    ctx = small_range_ctx
+    took = 0
+    for seed in range(32):
+        rng = np.random.default_rng(100_000 * k + 1000 * ["fixed", "ragged", "crlf", "blank", "lowerN", "noeol"].index(kind) + seed)
+        strand = "canonical" if seed % 2 == 0 else "single"
+        data = _fastq_variant(rng, int(rng.integers(200, 4000)), kind)
+        s = orc.kspec(k, orc.DNA)
+        idx = K.CountIndex(ctx, K.make_config(k, "DNA", strand=strand))
+        ctx.profile(True)
+        ctx.profile_reset()
+        idx.build(data)
+        names = {p["name"] for p in ctx.profile_get() if p["launches"]}
+        ctx.profile(False)
+        took += "sk_front" in names and "fastq_scan_tiles" not in names
+        om = orc.CountMap(s, STRAND[strand])
+        om.insert(orc.extract(s, data, orc.FASTQ)["kmers"])
+        _same_map(idx, om)
+        idx.close()
+    assert took > 0 or kind in ("blank",), (kind, k, took)      # the one-pass path really ran (blank lines may always send it away)
+
+
+@pytest.mark.parametrize("seed", list(range(12)))
+def test_position_builds_from_the_parse_follow_the_oracle_on_ragged_fastq(ctx, seed):
+    """kmi_tuples.h: the position and position + quality builds partition their tuples straight from the packed input (histogram from
+    the entry list, read descriptors from the list pass, ids and quality values made inside the scatter pass). Ragged FASTQ -- reads
+    shorter than k, reads longer than a scan tile, CRLF, no final newline -- against the oracle's multimap: k-mers, ShortSequenceKmerId
+    at a file offset, quality floats bit for bit; a second build lands in the existing entries."""
+    import kmerind_amd as K
+    data = _random_fastq(100 + seed)
+    k = [31, 21, 15, 28][seed % 4]
+    kind = "posqual" if seed % 2 else "position"
+    vw = 2 if kind == "posqual" else 1
+    off = 0 if seed % 3 else 123_456_789
+    s = orc.kspec(k, orc.DNA)
+    ex = orc.extract(s, data, orc.FASTQ, file_offset=off, want_ids=True, want_quals=(vw == 2))
+    vals = ex["ids"].reshape(-1, 1)
+    if vw == 2:
+        vals = np.concatenate([vals, ex["quals"].view(np.uint32).astype(np.uint64).reshape(-1, 1)], axis=1)
+    ref = orc.MultiMap(s, orc.CANONICAL, vw)
+    ref.insert(ex["kmers"], vals)
+    idx = K.PositionIndex(ctx, K.make_config(k, "DNA", strand="canonical", index_kind=kind))
+    idx.build(data, file_offset=off)
+
+    def canon(keys, v):
+        rows = np.concatenate([np.asarray(keys).reshape(len(keys), -1), np.asarray(v).reshape(len(keys), -1)], axis=1)
+        return rows[np.lexsort([rows[:, c] for c in range(rows.shape[1] - 1, -1, -1)])] if len(rows) else rows
+
+    gk, gv = idx.to_vector()
+    rk, rv = ref.export()
+    assert canon(gk, gv[:, :vw] if vw > 1 else gv).shape == canon(rk, rv).shape and (canon(gk, gv[:, :vw] if vw > 1 else gv) == canon(rk, rv)).all()
+    idx.build(data, file_offset=off)                               # the same tuples once more: every entry twice
+    ref.insert(ex["kmers"], vals)
+    gk, gv = idx.to_vector()
+    rk, rv = ref.export()
+    assert (canon(gk, gv[:, :vw] if vw > 1 else gv) == canon(rk, rv)).all()
+    idx.close()

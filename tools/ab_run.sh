@@ -1,8 +1,11 @@
 #!/bin/bash
-# scratch: the round-4 A/B runs on the GPU box (output under gpurun_out/<tag>/)
+# Same-box A/B runs of the bench (on the GPU box, from the repo root): every further argument is name:ENV=... (space separated
+# assignments), e.g.  tools/ab_run.sh r04_x "base:X=1" "variant:KMERIND_HIP_LIB=ab/libvariant.so KMI_SK_REDUCE=2"
+# (libraries from tools/ab_build.sh). One line per run: ms per step, distinct k-mers, per-kernel ms; logs under gpurun_out/<tag>/.
+# BENCH_ARGS="--genome 800000000" adds bench arguments.
 TAG=${1:-r04_x}; shift
 OUT=gpurun_out/$TAG; mkdir -p $OUT
-B="python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extra"
+B="python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extra $BENCH_ARGS"
 summ() { python - "$1" <<'PY'
 import json,sys
 for l in open(sys.argv[1]):
