@@ -544,12 +544,45 @@ class Index {
   // pair whose (transformed) key is stored, `count += op(stored_value, input_value)`, op changing the stored value in
   // place; keys that are not stored are skipped. The filter form visits every stored entry fop accepts with
   // `count += op(stored_value)`. Updater and Filter are host functors, so -- like the predicate forms -- they run on
-  // the host over the entries the device returns; the changed values go back as (key, value) pairs. Counting maps, one rank.
+  // the host over the entries the device returns; the changed values go back as (key, value) pairs. Counting maps.
   template <typename Updater> size_t update(std::vector<TupleType> &input, bool /*sorted_input*/, Updater const &op) {
     static_assert(MapType::index_kind == KMI_INDEX_COUNT, "update() is a member of the counting / reduction maps");
-    if (comm.size() > 1) throw std::invalid_argument("update() with a host functor and size() > 1: the pairs would have to visit their owners' hosts; use the kmerind::updater forms (add / max / min / assign), which run on the owners' devices");
-    if (input.empty() || local_size() == 0) return 0;
     constexpr unsigned nw = KmerType::nWords;
+    if (comm.size() > 1 || rccl) {
+      // over ranks (distributed_densehash_map.hpp:1975-2030: distribute, then the local update): the pairs travel to the owners of
+      // their keys (kmi_index_route_pairs_dist_host; collective, an empty input still enters it), and every owner applies the
+      // functor on its host to ITS entries (pairs of one key arrive grouped by source rank; inside a source their order is the
+      // routing scatter's, so a functor that is not commutative sees an unspecified order there) and writes the changed values back. The return value counts what the functor returned HERE, as the reference's local update does.
+      need_rccl("update");
+      std::vector<uint64_t> rec(input.size() * (nw + 1) + 1);
+      for (size_t i = 0; i < input.size(); ++i) {
+        std::memcpy(&rec[i * (nw + 1)], input[i].first.getData(), sizeof(uint64_t) * nw);
+        rec[i * (nw + 1) + nw] = weight_word(input[i])[0];
+      }
+      kmi_results mine{};
+      ::kmerind::check(ctx, kmi_index_route_pairs_dist_host(idx, rccl, rec.data(), input.size(), &mine));
+      size_t count = 0;
+      if (mine.n && local_size()) {
+        // this rank's entries for the keys that arrived (a local lookup: the keys are stored keys of this rank already)
+        kmi_results r{};
+        ::kmerind::check(ctx, kmi_index_find_host(idx, mine.keys, mine.n, &r));
+        constexpr unsigned ow = detail::stored_words<MapType, ValueType>();
+        std::map<KmerType, ValueType> cur;
+        for (uint64_t i = 0; i < r.n; ++i) cur[KmerType(r.keys + i * nw)] = detail::stored_value<MapType, ValueType>(r.values + i * ow);
+        kmi_results_free(&r);
+        std::map<KmerType, bool> touched;
+        for (uint64_t i = 0; i < mine.n; ++i) {
+          auto it = cur.find(KmerType(mine.keys + i * nw));
+          if (it == cur.end()) continue;
+          count += (size_t)op(it->second, detail::count_of<MapType, ValueType>(mine.values[i]));
+          touched[it->first] = true;
+        }
+        write_back(cur, touched);
+      }
+      kmi_results_free(&mine);
+      return count;
+    }
+    if (input.empty() || local_size() == 0) return 0;
     std::vector<KmerType> keys(input.size());
     for (size_t i = 0; i < input.size(); ++i) keys[i] = input[i].first;
     std::vector<TupleType> found = find(keys);

@@ -409,6 +409,10 @@ kmi_status kmi_fasta_block_summary_dev(kmi_ctx *ctx, const uint8_t *bytes_dev, s
  * (records: n x (n_words key words, one value word); *n_updated = pairs applied on THIS rank) */
 kmi_status kmi_index_insert_pairs_dist_host(kmi_index *idx, kmi_comm *comm, const uint64_t *records, size_t n);
 kmi_status kmi_index_update_pairs_dist_host(kmi_index *idx, kmi_comm *comm, const uint64_t *records, size_t n, uint32_t op, uint64_t *n_updated);
+/* the routing half on its own (imxx::distribute of the pairs, incremental_mxx.hpp:1039-1109): out = the pairs whose keys THIS rank owns,
+ * keys as the map stores them, grouped by source rank in rank order; the order inside one source's group is unspecified (out->keys:
+ * n_words per pair, out->values: one word; kmi_results_free). update() with a host functor over ranks (distributed_densehash_map.hpp:1975-2030) applies it to these. */
+kmi_status kmi_index_route_pairs_dist_host(kmi_index *idx, kmi_comm *comm, const uint64_t *records, size_t n, kmi_results *out);
 kmi_status kmi_index_count_dist_host(kmi_index *idx, kmi_comm *comm, const uint64_t *queries, size_t nq, kmi_results *out);
 kmi_status kmi_index_find_dist_host(kmi_index *idx, kmi_comm *comm, const uint64_t *queries, size_t nq, kmi_results *out);
 kmi_status kmi_index_erase_dist_host(kmi_index *idx, kmi_comm *comm, const uint64_t *queries, size_t nq, uint64_t *n_erased_local);

@@ -29,6 +29,7 @@ constexpr uint32_t kFrRunQ = 256;        // waiting runs (power of two): 64 are 
 constexpr uint32_t kFrStep = 4096;       // bytes per produce step: 64 lanes x 64
 constexpr uint32_t kFrRowDw = 12;        // a run's packed row: 192 bases (a run holds at most 128 + 31)
 constexpr uint32_t kFrNone = 0xffu;      // FrRange::l0 of a range that owns no line
+constexpr uint32_t kFrOverrun = 256u << 10;   // bytes a range may scan behind its own end before it hands the input over
 
 struct FrRange { uint32_t l0, n_lines, n_runs, n_items; };
 struct __attribute__((packed, aligned(1))) FrU4 { uint32_t x, y, z, w; };   // sixteen bytes at any address
@@ -173,6 +174,10 @@ __global__ __launch_bounds__(kFrThreads) void sk_front_kernel(const uint8_t *__r
         n_starts += NS; n_ends += NE; n_owned += NO;
         carry = (uint32_t)__builtin_amdgcn_readlane(eol_hi, kWave - 1) >> 31;   // (the builtin returns a signed int)
         p += kFrStep;
+        // a range is done two complete lines behind its last byte; a range that lies inside a line of megabytes (long-read FASTQ)
+        // would scan on to that line's end, and so would every other range inside the same line: work without a bound. Past
+        // kFrOverrun bytes behind its end the range gives up and the general path takes the input.
+        if (p > len + kFrOverrun) { why |= 32u; bail = true; break; }
         const bool at_eof = B + p > n_bytes;                 // (a step that reached past the end has produced the last line's end)
         wave_sync();                                         // the events are in the rings
         // ---- the line index of the first line (once)

@@ -2832,8 +2832,13 @@ static kmi_status sk_front_fast(kmi_ctx *ctx, const kmi_config *cfg, const KShap
   // idle through the host's round trip: its output then has to be sized by what the front end can produce at most (one item per
   // item slot), which is three times the usual -- done for inputs up to 8 GB, and when the caller did not bring the buffer.
   const uint64_t r_bound = (uint64_t)n_ranges * item_cap;
-  const bool early = !out && n_bytes <= (8ull << 30);
+  bool early = !out && n_bytes <= (8ull << 30);
   uint64_t *rec_a = out;
+  if (early) {
+    // (the early buffer is sized for the most the front end can produce, three times the usual: where that does not fit -- several
+    // indexes in one context, a smaller GPU -- the scatter pass waits for the host to size it by what was produced: ADVICE r3)
+    if (ws_get(ctx, WS_KEYS_A, (r_bound + 64) * 16, &p) == KMI_OK) rec_a = (uint64_t *)p; else { early = false; ctx->err.clear(); }
+  }
   auto launch_scatter = [&]() {
     ProfScope ps(ctx, "sk_scatter", n_bytes);
     if (canonical)
@@ -2855,7 +2860,6 @@ static kmi_status sk_front_fast(kmi_ctx *ctx, const kmi_config *cfg, const KShap
     // the host waits for the read-backs only (an event behind them), not for the scatter pass queued behind that: what it queues
     // next -- the back end's tables and kernels -- is on the stream before the scatter pass has finished
     if (!ctx->ev_mail) KMI_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_mail, hipEventDisableTiming));
-    KMI_TRY(ws_get(ctx, WS_KEYS_A, (r_bound + 64) * 16, &p)); rec_a = (uint64_t *)p;
     KMI_HIP(ctx, hipEventRecord(ctx->ev_mail, ctx->stream));
     launch_scatter();
     KMI_HIP(ctx, hipEventSynchronize(ctx->ev_mail));
@@ -4551,6 +4555,44 @@ kmi_status kmi_index_insert_pairs_dist_host(kmi_index *idx, kmi_comm *comm, cons
   kmi_status st = index_insert_pairs(idx, (const uint64_t *)d_recv, (size_t)total, true, false);   // (the strand transform is idempotent)
   idx->owner_lp = lp;
   return st;
+}
+
+// the routing half of the collectives above, on its own: every rank brings (k-mer, value) pairs, every rank gets back -- in host
+// memory -- the pairs whose keys IT owns, keys as the map stores them (strand transform applied), grouped by source rank (the order
+// inside a group is the routing scatter's, unspecified). What update() with a HOST functor needs over ranks (distributed_densehash_map.hpp:1975-2030: distribute,
+// then the local update): the facade applies the functor to the owner's entries on the owner's host.
+kmi_status kmi_index_route_pairs_dist_host(kmi_index *idx, kmi_comm *comm, const uint64_t *records, size_t n, kmi_results *out) {
+  KMI_TRY(dist_check(idx, comm));
+  kmi_ctx *ctx = idx->ctx;
+  if (!out) return KMI_ERR_INVALID;
+  memset(out, 0, sizeof(*out));
+  if (idx->val_words) return set_err(ctx, KMI_ERR_INVALID, "(k-mer, value) pairs of a counting map");
+  if (n && !records) return set_err(ctx, KMI_ERR_INVALID, "null buffer");
+  const uint32_t nw = idx->shape.n_words, rw = nw + 1;
+  void *d_recv = nullptr; uint64_t total = 0;
+  if (kmi::comm_size(comm) == 1 && !ctx->force_dist) {
+    // one rank: the pairs with their keys transformed (route_pairs with one destination does exactly that)
+    void *d_in, *d_send;
+    KMI_TRY(ws_get(ctx, WS_INPUT, (n + 8) * rw * sizeof(uint64_t), &d_in));
+    KMI_TRY(ws_get(ctx, WS_DIST_A, (n + 8) * rw * sizeof(uint64_t), &d_send));
+    if (n) KMI_HIP(ctx, hipMemcpyAsync(d_in, records, n * rw * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+    uint64_t sc1 = 0;
+    KMI_TRY(route_pairs(ctx, &idx->cfg, idx->shape, (const uint64_t *)d_in, n, 1u, false, (uint64_t *)d_send, &sc1));
+    d_recv = d_send; total = n;
+  } else KMI_TRY(pairs_to_owners(idx, comm, records, n, &d_recv, &total));
+  if (total == 0) return KMI_OK;
+  std::vector<uint64_t> h((size_t)total * rw);
+  KMI_HIP(ctx, hipMemcpyAsync(h.data(), d_recv, h.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+  KMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  out->keys = (uint64_t *)malloc((size_t)total * nw * sizeof(uint64_t));
+  out->values = (uint64_t *)malloc((size_t)total * sizeof(uint64_t));
+  if (!out->keys || !out->values) { kmi_results_free(out); return set_err(ctx, KMI_ERR_NOMEM, "host results"); }
+  for (uint64_t i = 0; i < total; ++i) {
+    memcpy(out->keys + i * nw, &h[i * rw], nw * sizeof(uint64_t));
+    out->values[i] = h[i * rw + nw];
+  }
+  out->n = total;
+  return KMI_OK;
 }
 
 kmi_status kmi_index_update_pairs_dist_host(kmi_index *idx, kmi_comm *comm, const uint64_t *records, size_t n, uint32_t op, uint64_t *n_updated) {

@@ -101,13 +101,18 @@ def _count_worker(rank, world, port, data, k, strand, case, ret):
         ctx.check(L.lib.kmi_index_find_dist_host(idx.h, comm.h, q.ctypes.data_as(C.c_void_p), q.shape[0], C.byref(r)))
         fk, fv = _results(L, r)
         keys1, cnts1 = idx.to_vector()
+        # ---- the routing half on its own (what update() with a host functor stands on): pairs to their keys' owners' HOSTS
+        rp = np.ascontiguousarray(np.concatenate([q[:300], (np.arange(300, dtype=np.uint64) + np.uint64(1000 * rank)).reshape(-1, 1)], axis=1))
+        r = L.Results()
+        ctx.check(L.lib.kmi_index_route_pairs_dist_host(idx.h, comm.h, rp.ctypes.data_as(C.c_void_p), rp.shape[0], C.byref(r)))
+        rk, rv = _results(L, r)
         er = np.ascontiguousarray(q[:60])
         ne = C.c_uint64()
         ctx.check(L.lib.kmi_index_erase_dist_host(idx.h, comm.h, er.ctypes.data_as(C.c_void_p), er.shape[0], C.byref(ne)))
         n2 = C.c_uint64()
         ctx.check(L.lib.kmi_index_size_dist(idx.h, comm.h, C.byref(n2)))
         ret[rank] = dict(keys0=keys0.copy(), cnts0=cnts0.copy(), keys1=keys1.copy(), cnts1=cnts1.copy(), size=n.value, q=q.copy(), ck=ck, cv=cv, fk=fk, fv=fv,
-                         size_after=n2.value, calls=dict(comm.calls), regrows=regrows.value, mine=mine.copy(), pairs=pairs.copy())
+                         size_after=n2.value, rp=rp.copy(), rk=rk, rv=rv, calls=dict(comm.calls), regrows=regrows.value, mine=mine.copy(), pairs=pairs.copy())
         idx.close()
         comm.close()
         ctx.free(d)
@@ -161,6 +166,15 @@ def test_count_index_c_layer_over_ranks(world, k, strand, case):
         ek, ev = om.find(x["q"])
         a, b = orc.sorted_pairs(x["fk"], x["fv"]), orc.sorted_pairs(ek, np.asarray(ev).astype(np.uint64))
         assert a[0].shape == b[0].shape and (a[0] == b[0]).all() and (a[1] == b[1]).all()
+    # routed pairs: all of them arrive somewhere, with the key the map stores; a stored key arrives at the rank that stores it
+    sent = np.concatenate([np.concatenate([(orc.canonical(s, x["rp"][:, :1]) if strand == "canonical" else x["rp"][:, :1]), x["rp"][:, 1:]], axis=1) for x in R])
+    got = np.concatenate([np.concatenate([x["rk"], x["rv"].reshape(-1, 1)], axis=1) for x in R])
+    assert sent.shape == got.shape and (sent[np.lexsort(sent.T[::-1])] == got[np.lexsort(got.T[::-1])]).all()
+    for x in R:
+        have = set(x["keys1"][:, 0].tolist())
+        others = set(np.concatenate([y["keys1"][:, 0] for y in R if y is not x]).tolist())
+        assert not (set(x["rk"][:, 0].tolist()) & others)
+        assert len(set(x["rk"][:, 0].tolist()) & have) > 0
     for x in R:
         om.erase(x["q"][:60])
     assert all(x["size_after"] == om.size() for x in R)
