@@ -881,9 +881,25 @@ struct KmerFileHelper {
     if (comm.size() > 1) {
       // this rank's partition of the file: its byte range plus look-ahead, cut at record starts by the four-line rule (no
       // communication: both neighbours apply the rule at the same file position); the ids carry the file offsets
-      if (c.seq_format == KMI_FMT_FASTA) {   // (every rank reads the file whole and keeps its block: see Index::build_file)
-        std::vector<uint8_t> whole = ::bliss::index::kmer::detail::read_whole_file(filename);
-        st = kmi_extract_fasta_block_host(ctx, &c, whole.data(), whole.size(), (uint32_t)comm.rank(), (uint32_t)comm.size(), &t);
+      if (c.seq_format == KMI_FMT_FASTA) {
+        // FASTA: with a communicator (comm.transport or comm.unique_id) every rank reads its byte range plus look-ahead and the
+        // blocks' summaries are gathered inside the library (collective: see Index::build_file); without one every rank reads
+        // the file whole and keeps its block -- no communication at all
+        kmi_comm *kc = nullptr;
+        if (comm.transport.all_to_all_v) st = kmi_comm_create_transport(ctx, &comm.transport, &kc);
+        else if (comm.unique_id.size() == KMI_COMM_ID_BYTES) st = kmi_comm_create(ctx, comm.unique_id.data(), &kc);
+        if (st == KMI_OK && kc) {
+          for (uint64_t look = 1ull << 16;; look *= 16) {
+            ::bliss::index::kmer::detail::FileRange r = ::bliss::index::kmer::detail::read_file_range(filename, comm.rank(), comm.size(), look);
+            int need_more = 0;
+            st = kmi_extract_fasta_range_dist_host(ctx, &c, kc, r.bytes.data(), r.bytes.size(), r.offset, r.nominal, r.reaches_eof ? 1 : 0, r.prev_byte, &need_more, &t);
+            if (st != KMI_OK || !need_more) break;
+          }
+          kmi_comm_destroy(kc);
+        } else if (st == KMI_OK) {
+          std::vector<uint8_t> whole = ::bliss::index::kmer::detail::read_whole_file(filename);
+          st = kmi_extract_fasta_block_host(ctx, &c, whole.data(), whole.size(), (uint32_t)comm.rank(), (uint32_t)comm.size(), &t);
+        }
       } else
       for (uint64_t look = 1ull << 20;; look *= 8) {
         ::bliss::index::kmer::detail::FileRange r = ::bliss::index::kmer::detail::read_file_range(filename, comm.rank(), comm.size(), look);

@@ -402,6 +402,12 @@ kmi_status kmi_index_build_fasta_file_dist_host(kmi_index *idx, kmi_comm *comm, 
  * read further and call again. The union over the ranks is the whole file's tuples, each once, with the ids of a whole-file parse. */
 kmi_status kmi_index_build_fasta_range_dist_host(kmi_index *idx, kmi_comm *comm, const uint8_t *bytes, size_t n_bytes, uint64_t buffer_offset,
                                                  uint64_t nominal_bytes, int reaches_eof, int prev_byte, int *need_more);
+/* read_file_* of a FASTA file on one rank of several by BYTE RANGE (kmi_extract_fasta_block_host with only the block in memory): the
+ * rank brings its block of an equal split of the file plus look-ahead (arguments as kmi_index_build_fasta_range_dist_host); the other
+ * blocks' summaries come over comm in one small gather (collective). */
+kmi_status kmi_extract_fasta_range_dist_host(kmi_ctx *ctx, const kmi_config *cfg, kmi_comm *comm, const uint8_t *bytes, size_t n_bytes,
+                                             uint64_t buffer_offset, uint64_t nominal_bytes, int reaches_eof, int prev_byte, int *need_more,
+                                             kmi_tuples *out);
 /* the line-kind machine over bytes [0, n_bytes) of a FASTA buffer in HBM as a transfer function: out6 = for the incoming states
  * KMI_FA_OUTSIDE, HEADER, SEQUENCE in turn {state behind the bytes, records that start inside}. first_is_line_start: byte 0 opens a line */
 kmi_status kmi_fasta_block_summary_dev(kmi_ctx *ctx, const uint8_t *bytes_dev, size_t n_bytes, int first_is_line_start, uint64_t *out6);

@@ -131,6 +131,7 @@ SIGNATURES = {
     "kmi_index_build_fasta_range_dist_host": (C.c_int, [_P, _P, _P, _sz, _u64, _u64, C.c_int, C.c_int, C.POINTER(C.c_int)]),
     "kmi_fasta_block_summary_dev": (C.c_int, [_P, _P, _sz, C.c_int, _P]),
     "kmi_extract_fasta_block_host": (C.c_int, [_P, _CFG, _P, _sz, _u32, _u32, C.POINTER(Tuples)]),
+    "kmi_extract_fasta_range_dist_host": (C.c_int, [_P, _CFG, _P, _P, _sz, _u64, _u64, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(Tuples)]),
     "kmi_index_insert_pairs_dist_host": (C.c_int, [_P, _P, _P, _sz]),
     "kmi_index_update_pairs_dist_host": (C.c_int, [_P, _P, _P, _sz, _u32, C.POINTER(_u64)]),
     "kmi_index_route_pairs_dist_host": (C.c_int, [_P, _P, _P, _sz, C.POINTER(Results)]),

@@ -4875,21 +4875,15 @@ kmi_status kmi_index_build_fasta_file_dist_host(kmi_index *idx, kmi_comm *comm, 
 // [buffer_offset, buffer_offset + n_bytes), the first nominal_bytes of them the rank's block; prev_byte = the file byte before the
 // buffer (-1 at the file start); *need_more = 1: the k - 1 sequence characters behind the block (the last windows' overlap) do not
 // end inside the look-ahead -- nothing collective has happened, the caller reads further and calls again.
-kmi_status kmi_index_build_fasta_range_dist_host(kmi_index *idx, kmi_comm *comm, const uint8_t *bytes, size_t n_bytes, uint64_t buffer_offset,
-                                                 uint64_t nominal_bytes, int reaches_eof, int prev_byte, int *need_more) {
-  KMI_TRY(dist_check(idx, comm));
-  kmi_ctx *ctx = idx->ctx;
-  if (!need_more) return KMI_ERR_INVALID;
-  *need_more = 0;
-  if (idx->cfg.seq_format != KMI_FMT_FASTA) return set_err(ctx, KMI_ERR_INVALID, "not a FASTA index");
-  if ((n_bytes && !bytes) || nominal_bytes > n_bytes) return set_err(ctx, KMI_ERR_INVALID, "bad buffer");
-  const uint32_t p = (uint32_t)kmi::comm_size(comm), r = (uint32_t)kmi::comm_rank(comm), k = idx->shape.k;
+// the bookkeeping of a block: *need_more (nothing collective has happened then), or the partition record and where the block's
+// windows end inside the buffer. d_bytes = the buffer on the device (already in flight on the context's stream).
+static kmi_status fasta_range_partition(kmi_ctx *ctx, kmi_comm *comm, uint32_t k, const uint8_t *bytes, const uint8_t *d_bytes, size_t n_bytes,
+                                        uint64_t buffer_offset, uint64_t nominal_bytes, int reaches_eof, int prev_byte, int *need_more,
+                                        kmi_fasta_partition *part_out, uint64_t *end_out) {
+  const uint32_t p = (uint32_t)kmi::comm_size(comm), r = (uint32_t)kmi::comm_rank(comm);
   const bool first_ls = buffer_offset == 0 || prev_byte == (int)'\n';
-  void *d_bytes;
-  KMI_TRY(ws_get(ctx, WS_INPUT, n_bytes + 64, &d_bytes));
-  if (n_bytes) KMI_HIP(ctx, hipMemcpyAsync(d_bytes, bytes, n_bytes, hipMemcpyHostToDevice, ctx->stream));
   uint64_t mine[8] = {0, 0, 1, 0, 2, 0, 0, 0};
-  KMI_TRY(kmi_fasta_block_summary_dev(ctx, (const uint8_t *)d_bytes, (size_t)nominal_bytes, first_ls ? 1 : 0, mine));
+  KMI_TRY(kmi_fasta_block_summary_dev(ctx, d_bytes, (size_t)nominal_bytes, first_ls ? 1 : 0, mine));
   mine[6] = (buffer_offset == 0 && n_bytes) ? bytes[0] : 0;   // (rank 0: the file's first byte decides init_parser's index shift)
   mine[7] = nominal_bytes;
   // where the overlap ends: the (k - 1)-th sequence character at or behind the block's end, for every state the machine may be in there
@@ -4927,10 +4921,54 @@ kmi_status kmi_index_build_fasta_range_dist_host(kmi_index *idx, kmi_comm *comm,
   part.index_shift = (first == '>' || first == ';') ? 0u : 1u;
   const uint32_t st_end = (uint32_t)mine[2 * part.start_state];   // the machine's state behind the block
   const uint64_t end = end_for[st_end] < nominal_bytes ? nominal_bytes : end_for[st_end];
+  *part_out = part;
+  *end_out = end < n_bytes ? end : n_bytes;
+  return KMI_OK;
+}
+
+kmi_status kmi_index_build_fasta_range_dist_host(kmi_index *idx, kmi_comm *comm, const uint8_t *bytes, size_t n_bytes, uint64_t buffer_offset,
+                                                 uint64_t nominal_bytes, int reaches_eof, int prev_byte, int *need_more) {
+  KMI_TRY(dist_check(idx, comm));
+  kmi_ctx *ctx = idx->ctx;
+  if (!need_more) return KMI_ERR_INVALID;
+  *need_more = 0;
+  if (idx->cfg.seq_format != KMI_FMT_FASTA) return set_err(ctx, KMI_ERR_INVALID, "not a FASTA index");
+  if ((n_bytes && !bytes) || nominal_bytes > n_bytes) return set_err(ctx, KMI_ERR_INVALID, "bad buffer");
+  void *d_bytes;
+  KMI_TRY(ws_get(ctx, WS_INPUT, n_bytes + 64, &d_bytes));
+  if (n_bytes) KMI_HIP(ctx, hipMemcpyAsync(d_bytes, bytes, n_bytes, hipMemcpyHostToDevice, ctx->stream));
+  kmi_fasta_partition part; uint64_t end = 0;
+  KMI_TRY(fasta_range_partition(ctx, comm, idx->shape.k, bytes, (const uint8_t *)d_bytes, n_bytes, buffer_offset, nominal_bytes, reaches_eof, prev_byte,
+                                need_more, &part, &end));
+  if (*need_more) return KMI_OK;
   KMI_TRY(kmi_ctx_set_fasta_partition(ctx, &part));
-  const kmi_status stb = kmi_index_build_dist_dev(idx, comm, (const uint8_t *)d_bytes, (size_t)(end < n_bytes ? end : n_bytes), buffer_offset);
+  const kmi_status stb = kmi_index_build_dist_dev(idx, comm, (const uint8_t *)d_bytes, (size_t)end, buffer_offset);
   (void)kmi_ctx_set_fasta_partition(ctx, nullptr);
   return stb;
+}
+
+// read_file_* of a FASTA file on one rank of several, by byte range (kmer_file_helper.hpp:550-633 over FASTALoader's partitions,
+// fasta_loader.hpp:202-470): the same bookkeeping, then the block's tuples to the host. Collective over comm (one small gather).
+kmi_status kmi_extract_fasta_range_dist_host(kmi_ctx *ctx, const kmi_config *cfg, kmi_comm *comm, const uint8_t *bytes, size_t n_bytes,
+                                             uint64_t buffer_offset, uint64_t nominal_bytes, int reaches_eof, int prev_byte, int *need_more,
+                                             kmi_tuples *out) {
+  if (!ctx || !cfg || !comm || !out || !need_more) return KMI_ERR_INVALID;
+  memset(out, 0, sizeof(*out));
+  *need_more = 0;
+  if (cfg->seq_format != KMI_FMT_FASTA) return set_err(ctx, KMI_ERR_INVALID, "not FASTA");
+  if ((n_bytes && !bytes) || nominal_bytes > n_bytes) return set_err(ctx, KMI_ERR_INVALID, "bad buffer");
+  KMI_HIP(ctx, hipSetDevice(ctx->device));
+  void *d_bytes;
+  KMI_TRY(ws_get(ctx, WS_INPUT2, n_bytes + 64, &d_bytes));
+  if (n_bytes) KMI_HIP(ctx, hipMemcpyAsync(d_bytes, bytes, n_bytes, hipMemcpyHostToDevice, ctx->stream));
+  kmi_fasta_partition part; uint64_t end = 0;
+  KMI_TRY(fasta_range_partition(ctx, comm, cfg->k, bytes, (const uint8_t *)d_bytes, n_bytes, buffer_offset, nominal_bytes, reaches_eof, prev_byte,
+                                need_more, &part, &end));
+  if (*need_more || end == 0) return KMI_OK;
+  KMI_TRY(kmi_ctx_set_fasta_partition(ctx, &part));
+  const kmi_status st = kmi_extract_host(ctx, cfg, bytes, (size_t)end, buffer_offset, out);
+  (void)kmi_ctx_set_fasta_partition(ctx, nullptr);
+  return st;
 }
 
 kmi_status kmi_index_build_dist_host(kmi_index *idx, kmi_comm *comm, const uint8_t *bytes, size_t n_bytes, uint64_t file_offset) {

@@ -337,7 +337,25 @@ def _fasta_worker(rank, world, port, data, k, alpha, look, ret):
                 break
             look *= 16
         keys, vals = idx.to_vector()
-        ret[rank] = (keys.copy(), vals.copy(), rounds, comm.calls["bytes"])
+        # read_file_* of the same block (kmi_extract_fasta_range_dist_host): the tuples themselves, in file order
+        cfg = K.make_config(k, alpha, seq_format="fasta", index_kind="position")
+        look2 = 16
+        while True:
+            end = min(n, hi + look2)
+            buf = np.frombuffer(data[lo:end], dtype=np.uint8).copy()
+            need = C.c_int(0)
+            t = L.Tuples()
+            ptr = buf.ctypes.data_as(C.c_void_p) if buf.size else None
+            ctx.check(L.lib.kmi_extract_fasta_range_dist_host(ctx.h, C.byref(cfg), comm.h, ptr, buf.size, lo, hi - lo, 1 if end == n else 0,
+                                                              data[lo - 1] if lo > 0 else -1, C.byref(need), C.byref(t)))
+            if not need.value:
+                break
+            look2 *= 16
+        nw = (k * (3 if alpha == "DNA5" else 2) + 63) // 64
+        tk = np.ctypeslib.as_array(t.kmers, shape=(t.n_tuples * nw,)).copy().reshape(-1, nw) if t.n_tuples else np.zeros((0, nw), np.uint64)
+        ti = np.ctypeslib.as_array(t.ids, shape=(t.n_tuples,)).copy() if t.n_tuples else np.zeros(0, np.uint64)
+        L.lib.kmi_tuples_free(C.byref(t))
+        ret[rank] = (keys.copy(), vals.copy(), rounds, comm.calls["bytes"], tk, ti)
         idx.close()
         comm.close()
         ctx.close()
@@ -377,3 +395,7 @@ def test_fasta_position_index_by_byte_range_over_ranks(world, k, alpha, which):
     exp = canon(rk, rv)
     assert got.shape == exp.shape and (got == exp).all()
     assert any(ret[r][2] > 1 for r in range(world)) or k <= 17     # the look-ahead had to grow on some rank
+    # read_file_*: the ranks' tuples, rank after rank, are the file's tuples in file order
+    tk = np.concatenate([ret[r][4] for r in range(world)])
+    ti = np.concatenate([ret[r][5] for r in range(world)])
+    assert tk.shape == ex["kmers"].shape and (tk == ex["kmers"]).all() and (ti == ex["ids"]).all()
