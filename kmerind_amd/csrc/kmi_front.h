@@ -67,7 +67,11 @@ __global__ __launch_bounds__(kFrThreads) void sk_front_kernel(const uint8_t *__r
                                                              uint32_t k, bool rna, uint32_t run_cap, uint32_t item_cap, uint32_t ranges_per_group,
                                                              FrRange *__restrict__ info, uint32_t *__restrict__ run_items, uint32_t *__restrict__ rows,
                                                              uint32_t *__restrict__ items, uint32_t *__restrict__ wg_hist,
-                                                             unsigned long long *__restrict__ n_windows, uint32_t *__restrict__ flags) {
+                                                             unsigned long long *__restrict__ n_windows, uint32_t *__restrict__ flags,
+                                                             uint32_t r_first = 0u, uint32_t r_end = 0xffffffffu) {
+  // r_first / r_end: this launch takes the ranges [r_first, min(r_end, n_ranges)) -- a build from host memory launches the kernel
+  // once per arrived chunk of the input, for the ranges whose bytes (and the bytes a range may scan behind its end) are there
+  if (r_end > n_ranges) r_end = n_ranges;
   using F = FrCfg<W>;
   constexpr int CAP = kSkListCap;
   constexpr uint32_t INF = 0xffffffffu, RM = kFrRing - 1u, QM = kFrRunQ - 1u;
@@ -89,7 +93,7 @@ __global__ __launch_bounds__(kFrThreads) void sk_front_kernel(const uint8_t *__r
 #else
 #define FQ_MARK(i)
 #endif
-  for (uint32_t r = blockIdx.x * (uint32_t)kFrWaves + wv; r < n_ranges; r += n_waves) {   // (uniform per wavefront)
+  for (uint32_t r = r_first + blockIdx.x * (uint32_t)kFrWaves + wv; r < r_end; r += n_waves) {   // (uniform per wavefront)
     const uint64_t B = (uint64_t)r * range_bytes;
     const uint32_t len = (uint32_t)((n_bytes - B < range_bytes) ? (n_bytes - B) : range_bytes);
     for (uint32_t i = lane; i < (uint32_t)kNumCoarse; i += kWave) hist[i] = 0;

@@ -2772,12 +2772,24 @@ static kmi_status sk_front_end(kmi_ctx *ctx, const kmi_config *cfg, const KShape
 // The same front end in one pass over the bytes (kmi_front.h): FASTQ without a sequence filter. *took = false: the fast path
 // declined (a shape it does not take, or something in the input it is not sure about) and nothing was changed -- the caller
 // runs fastq_scan + sk_front_end, which also words parse errors.
+// a build from host memory whose bytes have not been copied yet (kmi_index_build_host): whoever is about to read the input on the
+// context's stream and is not the one-pass front end (which feeds itself, chunk by chunk) queues the whole copy first
+static kmi_status feed_flush(kmi_ctx *ctx) {
+  if (!ctx->feed_host) return KMI_OK;
+  const uint8_t *h = ctx->feed_host;
+  ctx->feed_host = nullptr;
+  KMI_HIP(ctx, hipMemcpyAsync(ctx->feed_dev, h, ctx->feed_bytes, hipMemcpyHostToDevice, ctx->stream));
+  return KMI_OK;
+}
+
 template <int W>
 static kmi_status sk_front_fast(kmi_ctx *ctx, const kmi_config *cfg, const KShape &shape, const uint8_t *bytes_dev, size_t n_bytes, uint32_t lp, SkFront *f,
                                 bool *took, uint64_t *out = nullptr, size_t out_cap = 0, bool local_fmt = false) {
   *took = false;
   f->ok = false;
-  if (!ctx->front_fused || cfg->seq_format != KMI_FMT_FASTQ || cfg->seq_filter != KMI_SEQ_ALL || n_bytes < 64) return KMI_OK;
+  const bool fed = ctx->feed_host != nullptr && bytes_dev == ctx->feed_dev && n_bytes == ctx->feed_bytes;
+  if (!fed) KMI_TRY(feed_flush(ctx));
+  if (!ctx->front_fused || cfg->seq_format != KMI_FMT_FASTQ || cfg->seq_filter != KMI_SEQ_ALL || n_bytes < 64) return feed_flush(ctx);
   const uint32_t k = shape.k;
   const bool canonical = cfg->strand != KMI_STRAND_SINGLE;
   // ranges: one per resident wavefront of the front kernel when the input is large; never below the context's minimum
@@ -2786,13 +2798,15 @@ static kmi_status sk_front_fast(kmi_ctx *ctx, const kmi_config *cfg, const KShap
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, sk_front_kernel<19>, kFrThreads, 0) != hipSuccess || per_cu <= 0) per_cu = 2;
     ctx->front_waves = (uint32_t)per_cu * (ctx->n_cus ? ctx->n_cus : 256u) * (uint32_t)kFrWaves;
   }
-  uint64_t range_bytes = (n_bytes + ctx->front_waves - 1) / ctx->front_waves;
+  // (fed from host memory: sixteen times the ranges -- what runs after the last byte has arrived is one range per wavefront slot,
+  // and a range is worked through by one wavefront from end to end: 0.35 ms for 256 KB)
+  uint64_t range_bytes = (n_bytes + ctx->front_waves * (fed ? 16u : 1u) - 1) / (ctx->front_waves * (fed ? 16u : 1u));
   range_bytes = (range_bytes + kFrStep - 1) / kFrStep * kFrStep;
   if (range_bytes < ctx->front_min_range) range_bytes = ctx->front_min_range;
   if (range_bytes > (8ull << 20)) range_bytes = 8ull << 20;
   const uint64_t n_ranges64 = (n_bytes + range_bytes - 1) / range_bytes;
   const uint32_t rpg = (uint32_t)((n_ranges64 + kPartGroups - 1) / kPartGroups);
-  if (rpg > kFrMaxGroupRanges) return KMI_OK;
+  if (rpg > kFrMaxGroupRanges) return feed_flush(ctx);
   const uint32_t n_ranges = (uint32_t)n_ranges64;
   const uint32_t run_cap = (uint32_t)(range_bytes / 64) + 64u, item_cap = (uint32_t)(range_bytes / 8) + 64u;
   void *p;
@@ -2807,11 +2821,61 @@ static kmi_status sk_front_fast(kmi_ctx *ctx, const kmi_config *cfg, const KShap
   // (flags 0 .. 15, the k-mer total and the group histograms, in one launch)
   hipLaunchKernelGGL(sk_zero_kernel, dim3(128), dim3(1024), 0, ctx->stream, wg_hist, (uint32_t)(kPartGroups * kNumCoarse),
                      reinterpret_cast<uint32_t *>(ctx->d_totals + 6), 2u, (uint32_t *)nullptr, 0u, ctx->d_flags, 0u, 16u, 0u, 0u);
-  {
+  if (!fed) {
     ProfScope ps(ctx, "sk_front", n_bytes);
     const uint32_t wgs = (n_ranges + kFrWaves - 1) / kFrWaves;
     hipLaunchKernelGGL((sk_front_kernel<W>), dim3(wgs), dim3(kFrThreads), 0, ctx->stream, bytes_dev, (uint64_t)n_bytes, range_bytes, n_ranges, k, is_rna(cfg),
                        run_cap, item_cap, rpg, info, run_items, rows, items, wg_hist, (unsigned long long *)(ctx->d_totals + 6), ctx->d_flags);
+  } else {
+    // The input is still in host memory: its copy goes out in chunks on a stream of its own, all of them queued now, and behind every
+    // chunk the front end takes the ranges whose bytes have arrived -- a range reads up to kFrOverrun + three steps behind its own end
+    // (the lines it owns end there, and the two lines behind them; the next step's prefetch). Only the last chunk's ranges run after
+    // the last byte is here; everything else of the front end is hidden behind the copy (BenchmarkKmerIndex.cpp:526-533 times from
+    // bytes in host memory).
+    ProfScope ps(ctx, "sk_front_fed", n_bytes);
+    const uint8_t *host = ctx->feed_host;
+    ctx->feed_host = nullptr;
+    // chunk sizes: the front end works through a chunk about twenty times faster than the link delivers the next one, so every chunk
+    // is a sixteenth of the one before it -- three or four copies in all (sixteen equal chunks cost 1.2 ms more than one copy: a gap
+    // behind every copy, and the copies themselves a little slower)
+    constexpr size_t kMaxChunks = sizeof(ctx->feed_ev) / sizeof(ctx->feed_ev[0]) - 1;
+    size_t cut[kMaxChunks + 1];   // chunk c = bytes [cut[c], cut[c + 1])
+    size_t n_chunks = 0;
+    {
+      size_t ratio = 16;
+      if (const char *e = getenv("KMI_FEED_RATIO")) { const long v = atol(e); if (v >= 2 && v <= 64) ratio = (size_t)v; }
+      size_t at = 0;
+      cut[0] = 0;
+      while (n_chunks + 1 < kMaxChunks && n_bytes - at > ctx->feed_min_chunk) {
+        size_t len = (n_bytes - at) - (n_bytes - at) / ratio;
+        len = len / 4096 * 4096;
+        at += len; cut[++n_chunks] = at;
+      }
+      cut[++n_chunks] = n_bytes;
+    }
+    if (!ctx->copy_stream) KMI_HIP(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+    for (size_t c = 0; c <= n_chunks; ++c) if (!ctx->feed_ev[c]) KMI_HIP(ctx, hipEventCreateWithFlags(&ctx->feed_ev[c], hipEventDisableTiming));
+    // (the copy overwrites the input buffer: it starts behind what the build's stream has queued so far)
+    KMI_HIP(ctx, hipEventRecord(ctx->feed_ev[n_chunks], ctx->stream));
+    KMI_HIP(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->feed_ev[n_chunks], 0));
+    for (size_t c = 0; c < n_chunks; ++c) {
+      KMI_HIP(ctx, hipMemcpyAsync(const_cast<uint8_t *>(bytes_dev) + cut[c], host + cut[c], cut[c + 1] - cut[c], hipMemcpyHostToDevice, ctx->copy_stream));
+      KMI_HIP(ctx, hipEventRecord(ctx->feed_ev[c], ctx->copy_stream));
+    }
+    const uint64_t margin = (uint64_t)kFrOverrun + 3ull * kFrStep;
+    uint32_t r_done = 0;
+    for (size_t c = 0; c < n_chunks; ++c) {
+      KMI_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->feed_ev[c], 0));
+      const uint64_t arrived = cut[c + 1];
+      uint32_t r_end = n_ranges;
+      if (c + 1 < n_chunks) r_end = arrived > margin + range_bytes ? (uint32_t)((arrived - margin) / range_bytes) : 0u;   // ranges [0, r_end) end margin bytes before `arrived`
+      if (r_end > n_ranges) r_end = n_ranges;
+      if (r_end <= r_done) continue;
+      const uint32_t wgs = (r_end - r_done + kFrWaves - 1) / kFrWaves;
+      hipLaunchKernelGGL((sk_front_kernel<W>), dim3(wgs), dim3(kFrThreads), 0, ctx->stream, bytes_dev, (uint64_t)n_bytes, range_bytes, n_ranges, k, is_rna(cfg),
+                         run_cap, item_cap, rpg, info, run_items, rows, items, wg_hist, (unsigned long long *)(ctx->d_totals + 6), ctx->d_flags, r_done, r_end);
+      r_done = r_end;
+    }
   }
   {
     ProfScope ps(ctx, "sk_offsets", kNumCoarse);
@@ -4200,6 +4264,10 @@ kmi_status kmi_index_build_dev(kmi_index *idx, const uint8_t *bytes_dev, size_t 
   kmi_ctx *ctx = idx->ctx;
   KMI_HIP(ctx, hipSetDevice(ctx->device));
   if (n_bytes == 0) return KMI_OK;
+  // (bytes still in host memory, kmi_index_build_host: only the one-pass front end of the super-k-mer build feeds itself)
+  const bool sk_fastq = idx->val_words == 0 && idx->cfg.seq_format == KMI_FMT_FASTQ && idx->shape.n_words == 1 && idx->shape.bits == 2 && ctx->fused_superkmer &&
+                        sk_window_of(idx->shape.k) != 0u;
+  if (!sk_fastq) KMI_TRY(feed_flush(ctx));
   KMI_TRY(align_input(ctx, &bytes_dev, n_bytes));
   if (idx->val_words == 0 && idx->cfg.seq_format == KMI_FMT_FASTQ) return index_build_fused(idx, bytes_dev, n_bytes);
   if (idx->val_words == 0) {
@@ -4263,8 +4331,15 @@ kmi_status kmi_index_build_host(kmi_index *idx, const uint8_t *bytes, size_t n_b
   KMI_HIP(ctx, hipSetDevice(ctx->device));
   void *din;
   KMI_TRY(ws_get(ctx, WS_INPUT, n_bytes + 64, &din));
-  KMI_HIP(ctx, hipMemcpyAsync(din, bytes, n_bytes, hipMemcpyHostToDevice, ctx->stream));
-  return kmi_index_build_dev(idx, (const uint8_t *)din, n_bytes, file_offset);
+  // the copy is not queued here: the one-pass front end queues it in chunks and works on the ranges of a chunk while the next one is
+  // on its way (sk_front_fast); every other path queues it whole before it reads the input (feed_flush). Worth it from 64 MB on; the
+  // caller's buffer should be pinned (hipHostMalloc / hipHostRegister) -- a copy from pageable memory is staged by the runtime and
+  // overlaps with nothing.
+  if (ctx->host_overlap && n_bytes >= ctx->host_overlap_min) { ctx->feed_host = bytes; ctx->feed_dev = (uint8_t *)din; ctx->feed_bytes = n_bytes; }
+  else KMI_HIP(ctx, hipMemcpyAsync(din, bytes, n_bytes, hipMemcpyHostToDevice, ctx->stream));
+  const kmi_status st = kmi_index_build_dev(idx, (const uint8_t *)din, n_bytes, file_offset);
+  if (ctx->feed_host) { ctx->feed_host = nullptr; if (st == KMI_OK) return set_err(ctx, KMI_ERR_DEVICE, "the input was never copied"); }
+  return st;
 }
 
 kmi_status kmi_index_clear(kmi_index *idx) {

@@ -82,6 +82,14 @@ struct kmi_ctx {
   uint32_t n_cus = 0;            // compute units of the device (grids of persistent workgroups)
   uint64_t *d_totals = nullptr;  // [16] small device scalars + [256] coarse-bucket totals of the fine-offset scan
   hipEvent_t ev_mail = nullptr;  // marks "the read-backs queued so far have landed" (waited for instead of the whole stream)
+  // a build from HOST bytes whose copy has not been queued yet (kmi_index_build_host): the one-pass front end queues it in chunks
+  // on copy_stream and starts the byte ranges of a chunk behind it; every other reader of the input calls feed_flush first
+  const uint8_t *feed_host = nullptr; uint8_t *feed_dev = nullptr; size_t feed_bytes = 0;
+  hipStream_t copy_stream = nullptr;
+  hipEvent_t feed_ev[17] = {};
+  bool host_overlap = true;      // KMI_HOST_OVERLAP=0: one copy on the build's stream, then the build
+  size_t host_overlap_min = (size_t)64 << 20;   // ... and inputs below this many bytes always go that way (KMI_HOST_OVERLAP_MIN; tests lower it)
+  size_t feed_min_chunk = (size_t)8 << 20;      // a copy chunk is not split further below this (KMI_FEED_MIN_CHUNK)
   uint64_t *h_totals = nullptr;  // pinned mirror: 16 words of totals, then 1024 words for larger read-backs (one synchronisation for all of them)
   bool prof = false;
   std::vector<kmi::ProfRec> prof_pending;

@@ -902,3 +902,58 @@ def test_update_with_device_updaters(k, alpha, strand):
         assert gk.shape[0] == len(ref) and all(ref[tuple(a)] == int(b) for a, b in zip(gk.tolist(), gc.tolist()))
     idx.close()
     ctx.close()
+
+
+@pytest.mark.parametrize("k,strand,kind", [(31, "canonical", "plain"), (21, "single", "plain"), (31, "canonical", "malformed"), (31, "canonical", "fasta"),
+                                           (31, "canonical", "position")])
+def test_build_from_host_memory_in_chunks(monkeypatch, k, strand, kind):
+    """kmi_index_build_host does not copy the input before the build starts: the one-pass front end queues the copy in chunks on a
+    stream of its own and takes, behind every chunk, the byte ranges whose bytes (and the bytes a range may scan behind its end)
+    have arrived; every other path (another index kind, FASTA, an input the front end declines and hands to the general one) has
+    to queue the whole copy before it reads. The knobs make a 6 MB input go through several chunks and hundreds of ranges.
+    BenchmarkKmerIndex.cpp:526-533 starts its clock with the bytes in host memory."""
+    import kmerind_amd as K
+    monkeypatch.setenv("KMI_HOST_OVERLAP_MIN", "1")
+    monkeypatch.setenv("KMI_FEED_MIN_CHUNK", "65536")
+    monkeypatch.setenv("KMI_FEED_RATIO", "3")
+    monkeypatch.setenv("KMI_FRONT_MIN_RANGE", "8192")
+    c2 = K.Context(0)
+    s = orc.kspec(k, orc.DNA)
+    c2.profile(True)
+    c2.profile_reset()
+    if kind == "fasta":
+        from tests.test_gpu_fasta import _synthetic_fasta
+        data = np.frombuffer(_synthetic_fasta(np.random.default_rng(3), 60, line=70, eol=b"\n", orphan=False), dtype=np.uint8)
+        idx = K.CountIndex(c2, K.make_config(k, "DNA", strand=strand, seq_format="fasta"))
+        idx.build(data)
+        om = orc.CountMap(s, STRAND[strand])
+        om.insert(orc.extract(s, data, orc.FASTA)["kmers"])
+        _same_map(idx, om)
+    elif kind == "position":
+        data = K.synth_fastq(seed=5 * k, genome_len=80_000, n_reads=6_000)
+        idx = K.PositionIndex(c2, K.make_config(k, "DNA", strand=strand, index_kind="position"))
+        idx.build(data)
+        assert idx.local_size() == orc.extract(s, data, orc.FASTQ)["kmers"].shape[0]
+    else:
+        data = K.synth_fastq(seed=7 * k, genome_len=200_000, n_reads=20_000)
+        if kind == "malformed":   # a record whose quality line is short: the front end declines, the general path words the error
+            data = np.concatenate([data[:315 * 9000], np.frombuffer(b"@bad\nACGTACGTACGTACGTACGTACGTACGTACGTACGT\n+\nIIII\n", dtype=np.uint8), data[315 * 9000:]])
+        idx = K.CountIndex(c2, K.make_config(k, "DNA", strand=strand))
+        if kind == "malformed":
+            with pytest.raises(Exception):
+                idx.build(data)
+            assert idx.local_size() == 0
+        else:
+            idx.build(data)
+            names = {p["name"] for p in c2.profile_get() if p["launches"]}
+            assert "sk_front_fed" in names, names
+            om = orc.CountMap(s, STRAND[strand])
+            om.insert(orc.extract(s, data, orc.FASTQ)["kmers"])
+            _same_map(idx, om)
+            more = K.synth_fastq(seed=9 * k, genome_len=100_000, n_reads=3_000)   # into the existing entries
+            idx.build(more)
+            om.insert(orc.extract(s, more, orc.FASTQ)["kmers"])
+            _same_map(idx, om)
+    c2.profile(False)
+    idx.close()
+    c2.close()
