@@ -182,6 +182,130 @@ __global__ __launch_bounds__((DbgCfg<NW>::NT)) void dbg_accumulate_kernel(const 
   }
 }
 
+// The same sums from SUPER-K-MER records (the build through the count index's own front and back end, dbg_build_superkmer below).
+// A record (kmi_superkmer.h) is a stretch of a read: k + n - 1 bases as complement codes, base i at bits 2 i, in whichever of its
+// two orientations is the smaller number, + the base before its first and behind its last k-mer (kRecEdgeShift). Its k-mer j has the
+// neighbours base j - 1 and base j + k of the SAME record -- the two outside bases for j = 0 and j = n - 1 -- so nothing but the
+// record is read: edge_iterator.hpp:84-177 without a tuple per k-mer. The records of fine bucket b are still where the count
+// build's scatter pass left them; the nodes of b are the (dense) entries [idx_off[b], idx_off[b + 1]) of the node index, which the
+// build laid out by the same minimizer buckets. One lane per record rolls through its k-mers: window -> both strands -> the smaller
+// one is the node (the edges of a node kept reverse-complemented change sides and are complemented, de_bruijn_node_trait.hpp:
+// 122-124) -> row -> two counter adds. Counters and chunks of rows as in dbg_accumulate_kernel.
+__global__ __launch_bounds__((DbgCfg<1>::NT)) void sk_edges_accumulate_kernel(const uint64_t *__restrict__ idx_keys, const uint64_t *__restrict__ idx_off,
+                                                                           const uint64_t *__restrict__ recs, const uint64_t *__restrict__ rec_off,
+                                                                           const uint64_t *__restrict__ fine_region, const uint32_t *__restrict__ fine_cap,
+                                                                           const uint32_t *__restrict__ fine_cnt, uint32_t k, uint32_t *__restrict__ edges) {
+  using Cfg = DbgCfg<1>;
+  __shared__ uint64_t s_tk[Cfg::SLOTS];
+  __shared__ uint32_t s_tt[1];
+  __shared__ uint16_t s_row[Cfg::SLOTS];
+  __shared__ uint32_t s_cnt[Cfg::ROWS * 4];
+  __shared__ uint32_t s_mark[(Cfg::ROWS + 31) / 32];
+  __shared__ uint32_t s_ctl[8];
+  LdsTable<1> tab;
+  tab.keys = s_tk; tab.vals = nullptr; tab.tags = s_tt; tab.distinct = &s_ctl[0]; tab.overflow = &s_ctl[1];
+  tab.special = &s_ctl[2]; tab.special_set = &s_ctl[3]; tab.progress = &s_ctl[5];
+  tab.cap = Cfg::CAP; tab.slots = Cfg::SLOTS; tab.limit = 2u * Cfg::CAP;
+  uint32_t *s_fail = &s_ctl[6], *s_special_row = &s_ctl[7];
+  const uint32_t b = blockIdx.x;
+  const uint64_t ib = idx_off[b], ie = idx_off[b + 1];
+  if (ib == ie) return;
+  uint64_t rb, re;
+  if (fine_cnt) {
+    const uint32_t cap = fine_cap[b >> 7], cnt = fine_cnt[b];
+    rb = fine_region[b >> 7] + (uint64_t)(b & 127u) * cap; re = rb + (cnt < cap ? cnt : cap);
+  } else { rb = rec_off[b]; re = rec_off[b + 1]; }
+  if (rb == re) return;
+  uint64_t i0 = ib;
+  auto row_of = [&](uint64_t key) -> uint32_t {
+    const uint64_t kk[1] = {key};
+    const int s = table_find<1>(tab, kk, place_hash<1>(kk));
+    return s >= 0 ? (uint32_t)s_row[s] : (s == -2 ? *s_special_row : ~0u);
+  };
+  auto add = [&](uint32_t row, uint32_t t) {   // counter t of `row` += 1 (dbg_accumulate_kernel's add)
+    uint32_t *g = edges + (i0 + row) * 8u;
+    if (t & 1u) {
+      const uint32_t old = atomicAdd(&s_cnt[row * 4u + (t >> 1)], 1u << 16);
+      if ((old >> 16) + 1u > 0xFFFFu) { atomicOr(&s_mark[row >> 5], 1u << (row & 31u)); atomicAdd(&g[t], 65536u); }
+    } else {
+      const uint32_t old = atomicAdd(&s_cnt[row * 4u + (t >> 1)], 1u);
+      if ((old & 0xFFFFu) + 1u > 0xFFFFu) {
+        atomicOr(&s_mark[row >> 5], 1u << (row & 31u));
+        atomicAdd(&g[t], 65536u);
+        atomicAdd(&g[t + 1u], 0xFFFFFFFFu);
+        if ((uint64_t)old + 1u > 0xFFFFFFFFull) atomicAdd(&g[t + 1u], 65536u);
+      }
+    }
+  };
+  const uint32_t kb = 2u * k;
+  const uint64_t kmask = kb >= 64u ? ~0ull : ((1ull << kb) - 1ull);
+  const KShape shape = make_shape(k, 2u);
+  uint32_t chunk = Cfg::ROWS;
+  while (i0 < ie) {
+    const uint32_t nc = (uint32_t)((ie - i0) < (uint64_t)chunk ? (ie - i0) : (uint64_t)chunk);
+    for (uint32_t x = threadIdx.x; x < (uint32_t)Cfg::SLOTS; x += blockDim.x) s_tk[x] = kEmptyKey;
+    for (uint32_t x = threadIdx.x; x < nc * 4u; x += blockDim.x) s_cnt[x] = 0;
+    for (uint32_t x = threadIdx.x; x < (nc + 31u) / 32u; x += blockDim.x) s_mark[x] = 0;
+    if (threadIdx.x == 0) { s_ctl[0] = s_ctl[1] = s_ctl[2] = s_ctl[3] = s_ctl[5] = 0; *s_fail = 0; *s_special_row = ~0u; }
+    lds_barrier();
+    for (uint32_t j = threadIdx.x; j < nc; j += blockDim.x) {
+      const uint64_t kk[1] = {idx_keys[i0 + j]};
+      const int s = table_upsert<1>(tab, kk, place_hash<1>(kk));
+      if (s >= 0) s_row[s] = (uint16_t)j; else if (s == -2) *s_special_row = j; else *s_fail = 1;
+    }
+    lds_barrier();
+    if (*s_fail) {
+      lds_barrier();
+      chunk = chunk > 64u ? chunk / 2u : 32u;
+      continue;
+    }
+    for (uint64_t i = rb + threadIdx.x; i < re; i += blockDim.x) {
+      const ulonglong2 rec = reinterpret_cast<const ulonglong2 *>(recs)[i];
+      const uint32_t n = ((uint32_t)(rec.y >> kRecNShift) & 31u) + 1u;
+      const uint32_t lout = (uint32_t)(rec.y >> kRecEdgeShift) & 7u, rout = (uint32_t)(rec.y >> (kRecEdgeShift + 3)) & 7u;
+      const uint64_t hb = rec.y & 0xFFFFFFFFull;                       // the bases above bit 64 (edge records hold at most 96 bits of bases)
+      // window j = bits [2 j, 2 j + 2 k) of the record = the REVERSE strand of the k-mer that starts at base j (complement codes, first
+      // base lowest); x = what lies above the window: its lowest code is base j + k
+      uint64_t rc = rec.x & kmask;
+      uint64_t x = kb >= 64u ? hb : ((rec.x >> kb) | (hb << (64u - kb)));
+      uint64_t xh = kb >= 64u ? 0ull : (hb >> kb);
+      uint64_t r1[1] = {rc}, f1[1];
+      fwd_from_rc<1, 2>(r1, f1, shape);
+      uint64_t fw = f1[0];
+      uint32_t in_code = lout;                                          // 1 + base code of the base before the window (0: none)
+      for (uint32_t j = 0; j < n; ++j) {
+        const uint32_t nxt = (uint32_t)x & 3u;                         // complement code of base j + k
+        const uint32_t out_code = (j + 1u < n) ? 4u - nxt : rout;      // (base code = 3 - complement code)
+        const bool rev = rc < fw;                                      // the node is the reverse strand: edges change sides, complemented
+        const uint64_t key = rev ? rc : fw;
+        const uint32_t ci = rev ? (out_code ? 5u - out_code : 0u) : in_code;
+        const uint32_t co = rev ? (in_code ? 5u - in_code : 0u) : out_code;
+        if (ci | co) {
+          const uint32_t row = row_of(key);
+          if (row != ~0u) {
+            if (co) add(row, co - 1u);
+            if (ci) add(row, 4u + ci - 1u);
+          }
+        }
+        // the next window: one base on
+        in_code = 4u - ((uint32_t)rc & 3u);                            // base j becomes the base before window j + 1
+        rc = ((rc >> 2) | ((uint64_t)nxt << (kb - 2u))) & kmask;
+        fw = ((fw << 2) | (uint64_t)(3u - nxt)) & kmask;
+        x = (x >> 2) | (xh << 62); xh >>= 2;
+      }
+    }
+    lds_barrier();
+    for (uint32_t x = threadIdx.x; x < nc * 8u; x += blockDim.x) {
+      const uint32_t row = x >> 3, t = x & 7u;
+      const uint32_t c = (s_cnt[row * 4u + (t >> 1)] >> ((t & 1u) * 16u)) & 0xFFFFu;
+      if ((s_mark[row >> 5] >> (row & 31u)) & 1u) { if (c) atomicAdd(&edges[i0 * 8u + x], c); }
+      else edges[i0 * 8u + x] = c;
+    }
+    lds_barrier();
+    i0 += nc;
+  }
+}
+
 // find(): the node values of the hits. pos = entry positions (what the count index's find reports with find_emits_index);
 // out = kDbgValueWords words per node: counts[0..7] (exists_only: 0 / 1), counts[8] = occurrences (exists_only: 0), padding
 __global__ __launch_bounds__(256) void dbg_gather_kernel(const uint64_t *__restrict__ pos, uint64_t n, const uint32_t *__restrict__ edges,
@@ -260,12 +384,61 @@ static kmi_status dbg_parse(kmi_ctx *ctx, const kmi_config *cfg, const uint8_t *
   return KMI_OK;
 }
 
+// A graph built through super-k-mers keeps its nodes by minimizer bucket; whatever inserts tuples into it partitions them by the
+// placement hash, and the node index changes over (ensure_layout) -- the edge counts have to follow the nodes. The re-layout is a
+// pure permutation of (key, count) pairs: with the counts replaced by the entries' old positions for its duration, every entry
+// arrives with the place it came from, and one gather brings its count and its eight edge counters along.
+__global__ __launch_bounds__(256) void dbg_iota_kernel(uint32_t *__restrict__ v, uint64_t n) {
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) v[i] = (uint32_t)i;
+}
+__global__ __launch_bounds__(256) void dbg_follow_kernel(uint32_t *__restrict__ vals /* in: old positions, out: counts */, uint64_t n,
+                                                        const uint32_t *__restrict__ old_counts, const uint32_t *__restrict__ old_edges,
+                                                        uint32_t *__restrict__ edges) {
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n * 8u; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t p = i >> 3, t = i & 7u;
+    const uint32_t o = vals[p];
+    edges[i] = old_edges[(uint64_t)o * 8u + t];
+  }
+  // (second loop: the first one reads vals of every entry)
+}
+__global__ __launch_bounds__(256) void dbg_follow_counts_kernel(uint32_t *__restrict__ vals, uint64_t n, const uint32_t *__restrict__ old_counts) {
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) vals[i] = old_counts[vals[i]];
+}
+static kmi_status dbg_to_placement_layout(kmi_dbg *g) {
+  kmi_ctx *ctx = g->ctx;
+  kmi_index *idx = g->nodes;
+  if (idx->layout_w == 0u || !idx->has_data || idx->n_entries == 0) return KMI_OK;
+  KMI_TRY(ensure_dense(idx));
+  const uint64_t n = idx->n_entries;
+  if (n > 0xFFFFFFFFull) return set_err(ctx, KMI_ERR_OVERFLOW, "more than 2^32 nodes in one graph");
+  void *p;
+  KMI_TRY(ws_get(ctx, WS_DBG_OLD, (size_t)n * sizeof(uint32_t) + 64, &p));
+  uint32_t *old_counts = (uint32_t *)p;
+  KMI_HIP(ctx, hipMemcpyAsync(old_counts, idx->vals, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToDevice, ctx->stream));
+  hipLaunchKernelGGL(dbg_iota_kernel, dim3(2048), dim3(256), 0, ctx->stream, idx->vals, n);
+  KMI_TRY(ensure_layout(idx, 0u));
+  uint32_t *ne = nullptr;
+  const size_t eb = (size_t)n * 8 * sizeof(uint32_t);
+  if (pool_alloc(ctx, (void **)&ne, eb) != hipSuccess) return set_err(ctx, KMI_ERR_NOMEM, "hipMalloc failed for the edge counts");
+  {
+    ProfScope ps(ctx, "dbg_follow", n);
+    hipLaunchKernelGGL(dbg_follow_kernel, dim3(4096), dim3(256), 0, ctx->stream, idx->vals, n, (const uint32_t *)old_counts, (const uint32_t *)g->edges, ne);
+    hipLaunchKernelGGL(dbg_follow_counts_kernel, dim3(2048), dim3(256), 0, ctx->stream, idx->vals, n, (const uint32_t *)old_counts);
+  }
+  KMI_HIP(ctx, hipGetLastError());
+  KMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  pool_free(ctx, g->edges, g->edges_bytes);
+  g->edges = ne; g->edges_bytes = eb;
+  return KMI_OK;
+}
+
 // nodes.insert(tuples): records in node form (canonical key, 1 | edge << 32)
 template <int NW, int BITS>
 static kmi_status dbg_insert_impl(kmi_dbg *g, const uint64_t *recs_dev, size_t n) {
   kmi_ctx *ctx = g->ctx;
   kmi_index *idx = g->nodes;
   if (n == 0) return KMI_OK;
+  KMI_TRY(dbg_to_placement_layout(g));   // (a graph built through super-k-mers: the tuples below are partitioned by the placement hash)
   // the nodes that are there keep their edge counts but not their positions: their keys and bucket offsets are set aside
   const uint64_t n_old = idx->has_data ? idx->n_entries : 0;
   uint64_t *old_keys = nullptr, *old_off = nullptr;
@@ -296,6 +469,56 @@ static kmi_status dbg_insert_impl(kmi_dbg *g, const uint64_t *recs_dev, size_t n
   return KMI_OK;
 }
 static kmi_status dbg_insert(kmi_dbg *g, const uint64_t *recs_dev, size_t n) { KMI_DISPATCH(g->shape, dbg_insert_impl, g, recs_dev, n); }
+
+// The node build of an EMPTY graph from FASTQ through the count index's super-k-mer build (de_bruijn_construct_engine.hpp:90-158 +
+// de_bruijn_nodes_distributed::local_insert in one): the one-pass front end with edge records (sk_front_kernel, `edges`), the back
+// end as it is -- the node index with its occurrence counts --, then sk_edges_accumulate over the fine buckets' records, which are
+// still in the workspace. *done = false: not this path's input (several runs per read, a base that is not A C G T, a shape without
+// super-k-mers, anything the fast front end declines): the tuple path takes it.
+template <int W>
+static kmi_status dbg_build_superkmer_w(kmi_dbg *g, const uint8_t *bytes_dev, size_t n_bytes, bool *done) {
+  kmi_ctx *ctx = g->ctx;
+  kmi_index *idx = g->nodes;
+  SkFront f;
+  bool took = false;
+  ctx->edge_records = true;
+  kmi_status st = sk_front_fast<W>(ctx, &idx->cfg, idx->shape, bytes_dev, n_bytes, 0u, &f, &took, nullptr, 0, true);
+  ctx->edge_records = false;
+  if (st != KMI_OK || !took || !f.ok) return st;
+  *done = true;
+  if (f.n_kmers == 0) return KMI_OK;
+  KMI_TRY((sk_back_end<W>(idx, f.recs, f.n_records, f.h_cnt, f.h_base, f.wg_off, f.n_kmers, 0u, false, true)));
+  if (!ctx->sk_left.valid) return set_err(ctx, KMI_ERR_DEVICE, "the back end left no record of its fine buckets");
+  KMI_TRY(ensure_dense(idx));
+  const size_t eb = (size_t)(idx->n_entries ? idx->n_entries : 1) * 8 * sizeof(uint32_t);
+  uint32_t *ne = nullptr;
+  if (pool_alloc(ctx, (void **)&ne, eb) != hipSuccess) return set_err(ctx, KMI_ERR_NOMEM, "hipMalloc failed for the edge counts");
+  KMI_HIP(ctx, hipMemsetAsync(ne, 0, eb, ctx->stream));
+  {
+    ProfScope ps(ctx, "sk_edges_accumulate", f.n_kmers);
+    hipLaunchKernelGGL(sk_edges_accumulate_kernel, dim3(kNumFine), dim3(DbgCfg<1>::NT), 0, ctx->stream, (const uint64_t *)idx->keys, (const uint64_t *)idx->bucket_off,
+                       ctx->sk_left.recs, ctx->sk_left.rec_off, ctx->sk_left.region, ctx->sk_left.cap, ctx->sk_left.cnt, idx->shape.k, ne);
+  }
+  ctx->sk_left.valid = false;
+  KMI_HIP(ctx, hipGetLastError());
+  KMI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (g->edges) pool_free(ctx, g->edges, g->edges_bytes);
+  g->edges = ne; g->edges_bytes = eb;
+  return KMI_OK;
+}
+static kmi_status dbg_build_superkmer(kmi_dbg *g, const uint8_t *bytes_dev, size_t n_bytes, bool *done) {
+  *done = false;
+  kmi_ctx *ctx = g->ctx;
+  kmi_index *idx = g->nodes;
+  if (!ctx->dbg_superkmer || !ctx->fused_superkmer || !ctx->front_fused || g->cfg.seq_format != KMI_FMT_FASTQ || (idx->has_data && idx->n_entries) ||
+      idx->shape.n_words != 1 || idx->shape.bits != 2 || n_bytes < 64)
+    return KMI_OK;
+  const uint32_t w = sk_window_of(idx->shape.k);
+  if (!w) return KMI_OK;
+  KMI_TRY(align_input(ctx, &bytes_dev, n_bytes));
+  return w == 19u ? dbg_build_superkmer_w<19>(g, bytes_dev, n_bytes, done) : (w == 13u ? dbg_build_superkmer_w<13>(g, bytes_dev, n_bytes, done)
+       : (w == 11u ? dbg_build_superkmer_w<11>(g, bytes_dev, n_bytes, done) : dbg_build_superkmer_w<7>(g, bytes_dev, n_bytes, done)));
+}
 
 // nodes.erase(keys) (the erase of the distributed map the node map derives from, distributed_unordered_map.hpp:719-779): the nodes of
 // the query keys leave with their edge counts. The key array of the node index is compacted by the index's own erase; the

@@ -62,13 +62,24 @@ __device__ __forceinline__ uint32_t pack_dna4(uint32_t w) {
   return (p1 | (p1 >> 12)) & 0xFFu;
 }
 
+// 0x80 in every byte of w that is one of A C G T (either case)
+__device__ __forceinline__ uint32_t dna4_ok(uint32_t w) {
+  const uint32_t x = w & 0xDFDFDFDFu;
+  const uint32_t idx = (x >> 1) & 0x03030303u;
+  return zero_bytes(x ^ byte_perm(0u, 0x47544341u, idx));
+}
+
 template <int W>
 __global__ __launch_bounds__(kFrThreads) void sk_front_kernel(const uint8_t *__restrict__ bytes, uint64_t n_bytes, uint64_t range_bytes, uint32_t n_ranges,
                                                              uint32_t k, bool rna, uint32_t run_cap, uint32_t item_cap, uint32_t ranges_per_group,
                                                              FrRange *__restrict__ info, uint32_t *__restrict__ run_items, uint32_t *__restrict__ rows,
                                                              uint32_t *__restrict__ items, uint32_t *__restrict__ wg_hist,
                                                              unsigned long long *__restrict__ n_windows, uint32_t *__restrict__ flags,
-                                                             uint32_t r_first = 0u, uint32_t r_end = 0xffffffffu) {
+                                                             uint32_t r_first = 0u, uint32_t r_end = 0xffffffffu, uint32_t edges = 0u) {
+  // edges (the de Bruijn node build, kmi_debruijn.h): a record also carries the base before its first and the base behind its last
+  // k-mer (two 3-bit codes in the place of its last three bases: super-k-mers are cut three windows earlier), which the scatter pass
+  // takes from the run's row (the bases around the run itself ride in the row's last word) -- and every base has to be one of A C G T
+  // (an N is an A inside a k-mer but its own DNA16 code as a neighbour, edge_iterator.hpp:163-177: the general build decides then)
   // r_first / r_end: this launch takes the ranges [r_first, min(r_end, n_ranges)) -- a build from host memory launches the kernel
   // once per arrived chunk of the input, for the ranges whose bytes (and the bytes a range may scan behind its end) are there
   if (r_end > n_ranges) r_end = n_ranges;
@@ -84,7 +95,7 @@ __global__ __launch_bounds__(kFrThreads) void sk_front_kernel(const uint8_t *__r
   const uint32_t m = k - (uint32_t)W + 1u;
   const uint32_t mmask = (m >= 16u) ? 0xffffffffu : ((1u << (2u * m)) - 1u);
   const uint32_t topsh = 2u * m - 2u;
-  const uint32_t nmax = sk_nmax_of(k);
+  const uint32_t nmax = sk_nmax_of(k) - (edges ? kSkEdgeWindows : 0u);
   const uint32_t seg = (uint32_t)F::SEG;
   const uint32_t n_waves = gridDim.x * (uint32_t)kFrWaves;
 #ifdef KMI_FR_TIMING
@@ -259,6 +270,7 @@ __global__ __launch_bounds__(kFrThreads) void sk_front_kernel(const uint8_t *__r
       uint32_t rw[16];
 #pragma unroll
       for (int i = 0; i < 16; ++i) rw[i] = 0;
+      uint32_t other = 0;   // edges: 0x80 per byte of the run that is none of A C G T
       if (mine) {
         if (g0 + 16ull * F::NR <= n_bytes) {
 #pragma unroll
@@ -266,6 +278,15 @@ __global__ __launch_bounds__(kFrThreads) void sk_front_kernel(const uint8_t *__r
             FrU4 v = *reinterpret_cast<const FrU4 *>(bytes + g0 + 16 * q);   // (a read starts at any byte: unaligned 16-byte loads)
             if (rna) { v.x = swap_tu_dword(v.x); v.y = swap_tu_dword(v.y); v.z = swap_tu_dword(v.z); v.w = swap_tu_dword(v.w); }
             rw[q] = pack_dna4(v.x) | (pack_dna4(v.y) << 8) | (pack_dna4(v.z) << 16) | (pack_dna4(v.w) << 24);
+            if (edges) {   // uniform
+              const uint32_t nb = L + k - 1u, d[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const uint32_t at = 16u * (uint32_t)q + 4u * (uint32_t)e;
+                const uint32_t vm = nb >= at + 4u ? 0x80808080u : (nb <= at ? 0u : (0x80808080u & ((1u << (8u * (nb - at))) - 1u)));
+                other |= ~dna4_ok(d[e]) & vm;
+              }
+            }
           }
         } else {   // the last reads of the buffer: byte by byte, nothing read past the end
           const uint32_t nb = L + k - 1u;
@@ -274,11 +295,26 @@ __global__ __launch_bounds__(kFrThreads) void sk_front_kernel(const uint8_t *__r
             uint32_t c = bytes[g0 + i];
             if (rna) c = swap_tu_dword(c) & 0xffu;
             const uint32_t code = pack_dna4(c | 0x0A0A0A00u) & 3u;
+            if (edges) other |= ~dna4_ok(c | 0x41414100u) & 0x80u;
             const uint32_t wi = i >> 4, sh = (i & 15u) * 2u;
 #pragma unroll
             for (int q = 0; q < F::NR; ++q) rw[q] |= (wi == (uint32_t)q) ? (code << sh) : 0u;
           }
         }
+      }
+      if (edges) {   // uniform
+        // the bases around the run: the byte before its first base and the byte behind its last one are EOLs where the read begins and
+        // ends, and bases where the read goes on in another run; as 1 + base code (0: none) into the last word of the row
+        if (mine) {
+          const uint32_t nb = L + k - 1u;
+          uint32_t lb = bytes[g0 - 1u], rb = g0 + nb < n_bytes ? (uint32_t)bytes[g0 + nb] : (uint32_t)'\n';
+          if (rna) { lb = swap_tu_dword(lb) & 0xffu; rb = swap_tu_dword(rb) & 0xffu; }
+          const uint32_t lc = is_eol(lb) ? 0u : 4u - (pack_dna4(lb | 0x0A0A0A00u) & 3u), rc = is_eol(rb) ? 0u : 4u - (pack_dna4(rb | 0x0A0A0A00u) & 3u);
+          if (!is_eol(lb)) other |= ~dna4_ok(lb | 0x41414100u) & 0x80u;
+          if (!is_eol(rb)) other |= ~dna4_ok(rb | 0x41414100u) & 0x80u;
+          rw[kFrRowDw - 1] = lc | (rc << 3);
+        }
+        if (__any(other != 0u)) { why |= 1024u; bail = true; break; }
       }
       FQ_MARK(3)
       // the row leaves now (the walk below consumes its registers): three 16-byte stores per lane, consecutive rows
@@ -437,7 +473,9 @@ __global__ __launch_bounds__(kFrScThreads, 2) void sk_scatter_rows_kernel(const 
                                                                          uint32_t item_cap, uint32_t k, const uint32_t *__restrict__ run_items,
                                                                          const uint32_t *__restrict__ rows, const uint32_t *__restrict__ items,
                                                                          const uint64_t *__restrict__ wg_off, uint64_t *__restrict__ out, uint32_t lp,
-                                                                         bool local_fmt, const uint32_t *__restrict__ flags) {
+                                                                         bool local_fmt, const uint32_t *__restrict__ flags, uint32_t edges = 0u) {
+  // edges: the record's two outside bases (sk_front_kernel) go to bits 32..37 of word 1 as 1 + base code (A C G T = 0..3 in the
+  // record's own orientation; 0: the read ends there) -- see sk_edge_codes
   // local_fmt (the records go straight to this GPU's back end, no exchange): nobody reads a record's coarse bits again -- where it
   // lies says them -- so their place (bits 53..60 of word 1) and bit 61 take NINE further hash bits for sk_reduce2's bins; otherwise
   // the record keeps its 18 bucket bits as the owner will read them and bits 61..63 take three.
@@ -454,6 +492,8 @@ __global__ __launch_bounds__(kFrScThreads, 2) void sk_scatter_rows_kernel(const 
   __shared__ uint8_t s_xbits[ICAP];         // the low seven hash bits
   __shared__ uint32_t s_row[NT * kFrRowLds + 4];
   __shared__ uint32_t s_ibase[NT];      // first item of every run in s_items
+  __shared__ uint8_t s_runw[NT];        // windows of every run (edges)
+  __shared__ uint8_t s_runx[NT];        // the bases around every run: 1 + code of the one before | of the one behind << 3 (edges)
   __shared__ uint32_t s_cnt[kNumCoarse];
   __shared__ uint32_t s_cur[kNumCoarse];
   __shared__ uint64_t s_gbase[kNumCoarse];
@@ -495,6 +535,7 @@ __global__ __launch_bounds__(kFrScThreads, 2) void sk_scatter_rows_kernel(const 
       uint32_t *row = s_row + threadIdx.x * kFrRowLds;
       row[0] = q0.x; row[1] = q0.y; row[2] = q0.z; row[3] = q0.w; row[4] = q1.x; row[5] = q1.y; row[6] = q1.z; row[7] = q1.w;
       row[8] = q2.x; row[9] = q2.y; row[10] = 0;   // (words 10 and 11 of the row in memory hold no base)
+      if (edges) s_runx[threadIdx.x] = (uint8_t)q2.w;   // (... word 11 the two bases around the run, sk_front_kernel)
       // the items: sixteen bytes at a time (a list starts at any dword; what is read behind the run's items is not used). An item's
       // first window is the sum of the lengths before it.
       const uint32_t *src = g_items + (q * item_cap + (ri & 0x3ffffffu));
@@ -517,6 +558,11 @@ __global__ __launch_bounds__(kFrScThreads, 2) void sk_scatter_rows_kernel(const 
       }
     }
     s_ibase[threadIdx.x] = pre;
+    if (edges) {   // uniform: the run's windows = the sum of its items' lengths
+      uint32_t wsum = 0;
+      for (uint32_t j = 0; j < cnt; ++j) wsum += ((s_items[pre + j] >> 7) & 31u) + 1u;
+      s_runw[threadIdx.x] = (uint8_t)wsum;
+    }
     lds_barrier();
     // ---- bucket offsets of the round
     uint32_t c = 0, inc = 0;
@@ -557,8 +603,21 @@ __global__ __launch_bounds__(kFrScThreads, 2) void sk_scatter_rows_kernel(const 
       uint32_t hs = hsh >> 9, top3 = (hsh >> 6) & 7u;
       if (local_fmt) { hs = (hs & 0x3ffu) | (((hsh >> 1) & 0xffu) << 10); top3 = hsh & 1u; }
       uint64_t w0, w1;
-      sk_assemble_row<CANON>(s_row + rl * kFrRowLds, 2u * (item & 127u), k + n1, n1, hs, w0, w1);
+      bool flipped = false;
+      sk_assemble_row<CANON>(s_row + rl * kFrRowLds, 2u * (item & 127u), k + n1, n1, hs, w0, w1, &flipped);
       w1 |= (uint64_t)top3 << 61;
+      if (edges) {   // uniform
+        const uint32_t *row = s_row + rl * kFrRowLds;
+        const uint32_t wfirst = item & 127u, after = wfirst + n1 + k;   // base index behind the last k-mer
+        auto cc = [&](uint32_t i) -> uint32_t { return (row[i >> 4] >> (2u * (i & 15u))) & 3u; };   // complement code of the run's base i
+        // (the row holds complement codes in read direction: base code = 3 - cc; a record that travels reverse-complemented sees the
+        // complements of its neighbours, on the other side)
+        const uint32_t runx = s_runx[rl];
+        const uint32_t lc = wfirst ? 1u + (3u - cc(wfirst - 1u)) : (runx & 7u);
+        const uint32_t rc = wfirst + n1 + 1u < (uint32_t)s_runw[rl] ? 1u + (3u - cc(after)) : (runx >> 3);
+        const uint32_t left = flipped ? (rc ? 5u - rc : 0u) : lc, right = flipped ? (lc ? 5u - lc : 0u) : rc;
+        w1 |= (uint64_t)(left | (right << 3)) << kRecEdgeShift;
+      }
       reinterpret_cast<ulonglong2 *>(out)[s_gbase[h27 >> 19] + s] = make_ulonglong2(w0, w1);
     }
     rb += n_taken;

@@ -2825,7 +2825,8 @@ static kmi_status sk_front_fast(kmi_ctx *ctx, const kmi_config *cfg, const KShap
     ProfScope ps(ctx, "sk_front", n_bytes);
     const uint32_t wgs = (n_ranges + kFrWaves - 1) / kFrWaves;
     hipLaunchKernelGGL((sk_front_kernel<W>), dim3(wgs), dim3(kFrThreads), 0, ctx->stream, bytes_dev, (uint64_t)n_bytes, range_bytes, n_ranges, k, is_rna(cfg),
-                       run_cap, item_cap, rpg, info, run_items, rows, items, wg_hist, (unsigned long long *)(ctx->d_totals + 6), ctx->d_flags);
+                       run_cap, item_cap, rpg, info, run_items, rows, items, wg_hist, (unsigned long long *)(ctx->d_totals + 6), ctx->d_flags, 0u, 0xffffffffu,
+                       ctx->edge_records ? 1u : 0u);
   } else {
     // The input is still in host memory: its copy goes out in chunks on a stream of its own, all of them queued now, and behind every
     // chunk the front end takes the ranges whose bytes have arrived -- a range reads up to kFrOverrun + three steps behind its own end
@@ -2873,7 +2874,8 @@ static kmi_status sk_front_fast(kmi_ctx *ctx, const kmi_config *cfg, const KShap
       if (r_end <= r_done) continue;
       const uint32_t wgs = (r_end - r_done + kFrWaves - 1) / kFrWaves;
       hipLaunchKernelGGL((sk_front_kernel<W>), dim3(wgs), dim3(kFrThreads), 0, ctx->stream, bytes_dev, (uint64_t)n_bytes, range_bytes, n_ranges, k, is_rna(cfg),
-                         run_cap, item_cap, rpg, info, run_items, rows, items, wg_hist, (unsigned long long *)(ctx->d_totals + 6), ctx->d_flags, r_done, r_end);
+                         run_cap, item_cap, rpg, info, run_items, rows, items, wg_hist, (unsigned long long *)(ctx->d_totals + 6), ctx->d_flags, r_done, r_end,
+                         ctx->edge_records ? 1u : 0u);
       r_done = r_end;
     }
   }
@@ -2907,10 +2909,12 @@ static kmi_status sk_front_fast(kmi_ctx *ctx, const kmi_config *cfg, const KShap
     ProfScope ps(ctx, "sk_scatter", n_bytes);
     if (canonical)
       hipLaunchKernelGGL(sk_scatter_rows_kernel<true>, dim3(kPartGroups), dim3(kFrScThreads), 0, ctx->stream, (const FrRange *)info, n_ranges, rpg, run_cap, item_cap, k,
-                         (const uint32_t *)run_items, (const uint32_t *)rows, (const uint32_t *)items, (const uint64_t *)wg_off, rec_a, lp, local_fmt, (const uint32_t *)ctx->d_flags);
+                         (const uint32_t *)run_items, (const uint32_t *)rows, (const uint32_t *)items, (const uint64_t *)wg_off, rec_a, lp, local_fmt, (const uint32_t *)ctx->d_flags,
+                         ctx->edge_records ? 1u : 0u);
     else
       hipLaunchKernelGGL(sk_scatter_rows_kernel<false>, dim3(kPartGroups), dim3(kFrScThreads), 0, ctx->stream, (const FrRange *)info, n_ranges, rpg, run_cap, item_cap, k,
-                         (const uint32_t *)run_items, (const uint32_t *)rows, (const uint32_t *)items, (const uint64_t *)wg_off, rec_a, lp, local_fmt, (const uint32_t *)ctx->d_flags);
+                         (const uint32_t *)run_items, (const uint32_t *)rows, (const uint32_t *)items, (const uint64_t *)wg_off, rec_a, lp, local_fmt, (const uint32_t *)ctx->d_flags,
+                         ctx->edge_records ? 1u : 0u);
   };
   // what the host needs of the front end comes back into PINNED memory: four copies queued back to back and one synchronisation
   // (into pageable memory every copy was a host round trip of its own: 0.1 ms of an idle GPU per build)
@@ -2936,7 +2940,7 @@ static kmi_status sk_front_fast(kmi_ctx *ctx, const kmi_config *cfg, const KShap
     if (getenv("KMI_FRONT_DEBUG")) {
       uint32_t why = 0;
       (void)hipMemcpy(&why, ctx->d_flags + 10, sizeof(why), hipMemcpyDeviceToHost);
-      fprintf(stderr, "sk_front declined: reasons 0x%x (2 first byte, 4 crowded lines, 8 inference, 16 marker / length, 32 run queue, 64 run capacity, 128 items per run, 256 item capacity; 0 = the chain of line indices)\n", why);
+      fprintf(stderr, "sk_front declined: reasons 0x%x (2 first byte, 4 crowded lines, 8 inference, 16 marker / length, 32 run queue, 64 run capacity, 128 items per run, 256 item capacity, 512 / 1024 edge records: a read of several runs / a base that is not A C G T; 0 = the chain of line indices)\n", why);
     }
     KMI_HIP(ctx, hipMemsetAsync(ctx->d_flags + 9, 0, 2 * sizeof(uint32_t), ctx->stream));
     return KMI_OK;
@@ -2972,6 +2976,7 @@ static kmi_status sk_back_end(kmi_index *idx, const uint64_t *rec_a, uint64_t R,
   constexpr int NW = 1;
   kmi_ctx *ctx = idx->ctx;
   const bool slack = !exact && ctx->sk_slack && (!idx->has_data || idx->n_entries == 0) && R >= 4096;   // (room_x64 below: <= 6.1 x the records)
+  ctx->sk_left.valid = false;
   const uint32_t k = idx->shape.k;
   const bool canonical = idx->cfg.strand != KMI_STRAND_SINGLE;
   void *p;
@@ -3167,6 +3172,8 @@ static kmi_status sk_back_end(kmi_index *idx, const uint64_t *rec_a, uint64_t R,
     read_levels();
     idx->layout_w = layout;
     if (n) ctx->sk_inv_dup = (float)((double)idx->n_entries / (double)n);   // where the buckets of the next build start (sk_reduce_kernel)
+    ctx->sk_left.recs = rec_b; ctx->sk_left.rec_off = slack ? nullptr : fine_off; ctx->sk_left.region = d_region; ctx->sk_left.cap = d_cap;
+    ctx->sk_left.cnt = fine_cnt; ctx->sk_left.valid = true;
     return KMI_OK;
   }
   // the index holds entries already: the new ones become a scratch index, whose pairs are added to the old
@@ -5210,6 +5217,11 @@ kmi_status kmi_dbg_build_dev(kmi_dbg *g, const uint8_t *bytes_dev, size_t n_byte
   kmi_ctx *ctx = g->ctx;
   KMI_HIP(ctx, hipSetDevice(ctx->device));
   if (n_bytes == 0) return KMI_OK;
+  {   // an empty graph from clean FASTQ reads: through super-k-mer records (dbg_build_superkmer); else, and for what that declines, tuples
+    bool done = false;
+    KMI_TRY(dbg_build_superkmer(g, bytes_dev, n_bytes, &done));
+    if (done) return KMI_OK;
+  }
   uint64_t *recs = nullptr, nt = 0;
   KMI_TRY(dbg_parse(ctx, &g->cfg, bytes_dev, n_bytes, true, &recs, &nt));
   return dbg_insert(g, recs, (size_t)nt);

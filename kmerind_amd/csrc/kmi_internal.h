@@ -87,6 +87,11 @@ struct kmi_ctx {
   const uint8_t *feed_host = nullptr; uint8_t *feed_dev = nullptr; size_t feed_bytes = 0;
   hipStream_t copy_stream = nullptr;
   hipEvent_t feed_ev[17] = {};
+  // the de Bruijn node build through super-k-mers (kmi_debruijn.h): the front end makes records that carry their two outside bases, and
+  // the back end leaves word where the fine buckets' records lie (they stay in the workspace until the next build) for the edge pass
+  bool edge_records = false;
+  bool dbg_superkmer = true;     // KMI_DBG_SUPERKMER=0: the node build always takes the tuple path
+  struct { const uint64_t *recs = nullptr, *rec_off = nullptr, *region = nullptr; const uint32_t *cap = nullptr, *cnt = nullptr; bool valid = false; } sk_left;
   bool host_overlap = true;      // KMI_HOST_OVERLAP=0: one copy on the build's stream, then the build
   size_t host_overlap_min = (size_t)64 << 20;   // ... and inputs below this many bytes always go that way (KMI_HOST_OVERLAP_MIN; tests lower it)
   size_t feed_min_chunk = (size_t)8 << 20;      // a copy chunk is not split further below this (KMI_FEED_MIN_CHUNK)

@@ -29,6 +29,11 @@ namespace kmi {
 // record (16 bytes): word 0 = bases 0..31 of the complement-stream slice, word 1 = bases 32..50 (38 bits) | (n - 1) << 38 |
 // bucket bits << 43 (18 bits: coarse 8 | fine 7 | sub 3, most significant first)
 constexpr int kRecNShift = 38, kRecHashShift = 43;
+// records of the de Bruijn node build: three windows fewer per record (sk_nmax_of - kSkEdgeWindows), and the two outside bases where
+// the last three bases would be: bits 32..34 the base before the first k-mer, 35..37 the base behind the last one, each 1 + its code
+// (A C G T = 0..3 in the record's orientation), 0 = the read ends there
+constexpr int kRecEdgeShift = 32;
+constexpr uint32_t kSkEdgeWindows = 3;
 __device__ __forceinline__ uint32_t rec_hash18(uint64_t w1) { return (uint32_t)(w1 >> kRecHashShift) & 0x3ffffu; }
 __device__ __forceinline__ uint32_t rec_fine_sub(uint64_t w1) { return (rec_hash18(w1) >> 3) & 127u; }   // fine bucket inside its coarse bucket
 
@@ -344,7 +349,8 @@ __device__ __forceinline__ void sk_assemble(const uint32_t *__restrict__ st, uin
 // k-mers are the same canonical k-mers, so which mirror image travels does not matter to the count -- but with ONE form the
 // reduce finds the copies of both strands identical and expands them once (sk_reduce, T1).
 template <bool CANON>
-__device__ __forceinline__ void sk_assemble_row(const uint32_t *row, uint32_t bit, uint32_t nb, uint32_t n1, uint32_t h18, uint64_t &w0, uint64_t &w1) {
+__device__ __forceinline__ void sk_assemble_row(const uint32_t *row, uint32_t bit, uint32_t nb, uint32_t n1, uint32_t h18, uint64_t &w0, uint64_t &w1,
+                                                bool *flipped = nullptr) {
   const uint32_t d = bit >> 5, sh = bit & 31u;
   const uint32_t r0 = row[d], r1 = row[d + 1], r2 = row[d + 2], r3 = row[d + 3], r4 = row[d + 4];
   const uint32_t a0 = __builtin_amdgcn_alignbit(r1, r0, sh), a1 = __builtin_amdgcn_alignbit(r2, r1, sh);
@@ -367,6 +373,7 @@ __device__ __forceinline__ void sk_assemble_row(const uint32_t *row, uint32_t bi
     const bool take = c_hi < hi || (c_hi == hi && c_lo < w0);
     w0 = take ? c_lo : w0;
     hi = take ? c_hi : hi;
+    if (flipped) *flipped = take;
   }
   w1 = hi | ((uint64_t)n1 << kRecNShift) | ((uint64_t)h18 << kRecHashShift);
 }

@@ -376,3 +376,60 @@ def test_degenerate_inputs(ctx):
     gk, ge = g.parse(crlf)
     ok, oe = orc.dbg_parse(s, crlf)
     assert (gk == ok).all() and (ge == oe).all()
+
+
+@pytest.mark.parametrize("k,reads,genome", [(31, 6000, 30_000), (21, 4000, 8_000), (17, 3000, 3_000), (32, 3000, 20_000), (27, 5000, 400_000)])
+def test_nodes_through_super_kmer_records(k, reads, genome):
+    """An empty graph built from clean FASTQ reads (one run per read, A C G T only) goes through the count index's super-k-mer build:
+    the front end cuts records that carry the base before their first and behind their last k-mer, the back end makes the node
+    index, and sk_edges_accumulate adds the edges up from the records -- a k-mer's neighbours are its record's neighbouring bases
+    (kmi_debruijn.h; edge_iterator.hpp:84-177 + de_bruijn_nodes_distributed::local_insert). Same nodes and counts as the oracle's
+    tuple-by-tuple map; then tuples inserted into that graph (the node index changes its layout and the edge counts follow), find
+    under either strand, erase. Poly-A reads push one node's counters past 16 bits and give the k = 32 key that equals the table's
+    empty marker when they are poly-T."""
+    import kmerind_amd as K
+    c2 = K.Context(0)
+    s = orc.kspec(k)
+    data = bytes(K.synth_fastq(seed=3 * k, genome_len=genome, n_reads=reads))
+    if k in (31, 32):   # 700 reads of one base: 84 000 occurrences of one node, every one with the same two edges
+        base = b"A" if k == 31 else b"T"
+        data += b"".join(b"@p%d\n" % i + base * 150 + b"\n+\n" + b"I" * 150 + b"\n" for i in range(700))
+    c2.profile(True)
+    c2.profile_reset()
+    g = K.DeBruijnNodes(c2, K.make_config(k))
+    g.build(data)
+    names = {p["name"] for p in c2.profile_get() if p["launches"]}
+    assert "sk_edges_accumulate" in names and "dbg_accumulate" not in names, names
+    ok, oe = orc.dbg_parse(s, data)
+    om = orc.DbgMap(s)
+    om.insert(ok, oe)
+    assert g.local_size() == om.size()
+    assert (_nodes(*g.to_vector()) == _nodes(*om.export(canonical=True))).all()
+    rng = np.random.default_rng(k)
+    q = np.concatenate([ok[rng.integers(0, ok.shape[0], size=1500)], orc.revcomp(s, ok[rng.integers(0, ok.shape[0], size=500)]),
+                        rng.integers(0, 1 << min(2 * k, 63), size=(300, 1), dtype=np.uint64)])
+    assert (_nodes(*g.find(q)) == _nodes(*om.find(q, canonical=True))).all()
+    # tuples into the graph: the nodes move to the placement-hash layout, their edge counts with them
+    data2 = _with_n(bytes(K.synth_fastq(seed=5 * k, genome_len=genome, n_reads=reads // 3, first_read=reads)), k)
+    k2, e2 = orc.dbg_parse(s, data2)
+    om.insert(k2, e2)
+    g.insert(k2, e2)
+    assert g.local_size() == om.size()
+    assert (_nodes(*g.to_vector()) == _nodes(*om.export(canonical=True))).all()
+    assert (_nodes(*g.find(q)) == _nodes(*om.find(q, canonical=True))).all()
+    # a second graph: erase straight after the super-k-mer build (the index keeps its layout), then a build into what stayed
+    g2 = K.DeBruijnNodes(c2, K.make_config(k))
+    g2.build(data)
+    victims = np.ascontiguousarray(ok[rng.integers(0, ok.shape[0], size=800)])
+    gone = {tuple(r) for r in orc.canonical(s, victims).tolist()}
+    assert g2.erase(victims) == len(gone)
+    survivors = np.array([tuple(r) not in gone for r in orc.canonical(s, ok).tolist()])
+    om2 = orc.DbgMap(s)
+    om2.insert(ok[survivors], oe[survivors])
+    assert g2.local_size() == om2.size()
+    assert (_nodes(*g2.to_vector()) == _nodes(*om2.export(canonical=True))).all()
+    g2.build(data2)
+    om2.insert(k2, e2)
+    assert (_nodes(*g2.to_vector()) == _nodes(*om2.export(canonical=True))).all()
+    c2.profile(False)
+    g.close(); g2.close(); c2.close()
