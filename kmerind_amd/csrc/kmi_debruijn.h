@@ -222,18 +222,18 @@ __global__ __launch_bounds__((DbgCfg<1>::NT)) void sk_edges_accumulate_kernel(co
     const int s = table_find<1>(tab, kk, place_hash<1>(kk));
     return s >= 0 ? (uint32_t)s_row[s] : (s == -2 ? *s_special_row : ~0u);
   };
-  auto add = [&](uint32_t row, uint32_t t) {   // counter t of `row` += 1 (dbg_accumulate_kernel's add)
+  auto add = [&](uint32_t row, uint32_t t, uint32_t a) {   // counter t of `row` += a, a < 65536 (dbg_accumulate_kernel's add)
     uint32_t *g = edges + (i0 + row) * 8u;
     if (t & 1u) {
-      const uint32_t old = atomicAdd(&s_cnt[row * 4u + (t >> 1)], 1u << 16);
-      if ((old >> 16) + 1u > 0xFFFFu) { atomicOr(&s_mark[row >> 5], 1u << (row & 31u)); atomicAdd(&g[t], 65536u); }
+      const uint32_t old = atomicAdd(&s_cnt[row * 4u + (t >> 1)], a << 16);
+      if ((old >> 16) + a > 0xFFFFu) { atomicOr(&s_mark[row >> 5], 1u << (row & 31u)); atomicAdd(&g[t], 65536u); }
     } else {
-      const uint32_t old = atomicAdd(&s_cnt[row * 4u + (t >> 1)], 1u);
-      if ((old & 0xFFFFu) + 1u > 0xFFFFu) {
+      const uint32_t old = atomicAdd(&s_cnt[row * 4u + (t >> 1)], a);
+      if ((old & 0xFFFFu) + a > 0xFFFFu) {
         atomicOr(&s_mark[row >> 5], 1u << (row & 31u));
         atomicAdd(&g[t], 65536u);
         atomicAdd(&g[t + 1u], 0xFFFFFFFFu);
-        if ((uint64_t)old + 1u > 0xFFFFFFFFull) atomicAdd(&g[t + 1u], 65536u);
+        if ((uint64_t)old + a > 0xFFFFFFFFull) atomicAdd(&g[t + 1u], 65536u);
       }
     }
   };
@@ -273,25 +273,35 @@ __global__ __launch_bounds__((DbgCfg<1>::NT)) void sk_edges_accumulate_kernel(co
       fwd_from_rc<1, 2>(r1, f1, shape);
       uint64_t fw = f1[0];
       uint32_t in_code = lout;                                          // 1 + base code of the base before the window (0: none)
-      for (uint32_t j = 0; j < n; ++j) {
+      // one window: the node (the smaller strand) and the counters its two neighbours go to (8: none); then one base on
+      auto window = [&](uint32_t j, uint64_t &key, uint32_t &t_out, uint32_t &t_in) {
         const uint32_t nxt = (uint32_t)x & 3u;                         // complement code of base j + k
         const uint32_t out_code = (j + 1u < n) ? 4u - nxt : rout;      // (base code = 3 - complement code)
         const bool rev = rc < fw;                                      // the node is the reverse strand: edges change sides, complemented
-        const uint64_t key = rev ? rc : fw;
+        key = rev ? rc : fw;
         const uint32_t ci = rev ? (out_code ? 5u - out_code : 0u) : in_code;
         const uint32_t co = rev ? (in_code ? 5u - in_code : 0u) : out_code;
-        if (ci | co) {
-          const uint32_t row = row_of(key);
-          if (row != ~0u) {
-            if (co) add(row, co - 1u);
-            if (ci) add(row, 4u + ci - 1u);
-          }
-        }
-        // the next window: one base on
+        t_out = co ? co - 1u : 8u; t_in = ci ? 3u + ci : 8u;
         in_code = 4u - ((uint32_t)rc & 3u);                            // base j becomes the base before window j + 1
         rc = ((rc >> 2) | ((uint64_t)nxt << (kb - 2u))) & kmask;
         fw = ((fw << 2) | (uint64_t)(3u - nxt)) & kmask;
         x = (x >> 2) | (xh << 62); xh >>= 2;
+      };
+      // two windows at a time: both table walks start before either row is needed (a lane's turn is a chain of LDS round trips)
+      for (uint32_t j = 0; j < n; j += 2u) {
+        uint64_t ka, kc = 0; uint32_t oa, ia, oc = 8u, ic = 8u;
+        window(j, ka, oa, ia);
+        const bool two = j + 1u < n;
+        if (two) window(j + 1u, kc, oc, ic);
+        const bool va = (oa & ia) != 8u, vc = two && (oc & ic) != 8u;   // (8 & 8: no neighbour at all)
+        const uint64_t kka[1] = {ka}, kkc[1] = {kc};
+        uint32_t sa = slot_of(place_hash<1>(kka), (int)Cfg::CAP), sc = slot_of(place_hash<1>(kkc), (int)Cfg::CAP);
+        uint64_t ta = s_tk[sa], tc = s_tk[sc];
+        uint32_t ra = ~0u, rcw = ~0u;
+        if (va) { if (ka == kEmptyKey) ra = *s_special_row; else { while (ta != ka && ta != kEmptyKey) ta = s_tk[++sa]; if (ta == ka) ra = s_row[sa]; } }
+        if (vc) { if (kc == kEmptyKey) rcw = *s_special_row; else { while (tc != kc && tc != kEmptyKey) tc = s_tk[++sc]; if (tc == kc) rcw = s_row[sc]; } }
+        if (ra != ~0u) { if (oa != 8u) add(ra, oa, 1u); if (ia != 8u) add(ra, ia, 1u); }
+        if (rcw != ~0u) { if (oc != 8u) add(rcw, oc, 1u); if (ic != 8u) add(rcw, ic, 1u); }
       }
     }
     lds_barrier();

@@ -50,11 +50,12 @@ __device__ __forceinline__ uint32_t eol_flags(uint32_t w) {
   return zero_bytes((x & 0xF8F8F8F8u) | z);
 }
 // four bases -> four complement codes in the low byte; anything but A C G T (either case) counts as A, like DNA::FROM_ASCII
-__device__ __forceinline__ uint32_t pack_dna4(uint32_t w) {
+__device__ __forceinline__ uint32_t pack_dna4(uint32_t w, uint32_t *ok_out = nullptr) {
   const uint32_t x = w & 0xDFDFDFDFu;                          // fold case
   const uint32_t idx = (x >> 1) & 0x03030303u;                 // A 0, C 1, T 2, G 3
   const uint32_t expect = byte_perm(0u, 0x47544341u, idx);     // 'A','C','T','G'
   const uint32_t ok = zero_bytes(x ^ expect);                  // 0x80 per base byte
+  if (ok_out) *ok_out = ok;
   const uint32_t lut = byte_perm(0u, 0x01000203u, idx);        // complement codes: A 3, C 2, T 0, G 1
   const uint32_t v1 = ok >> 7, vm = v1 | (v1 << 1);
   const uint32_t cc = (lut & vm) | (0x03030303u & ~vm);
@@ -69,14 +70,15 @@ __device__ __forceinline__ uint32_t dna4_ok(uint32_t w) {
   return zero_bytes(x ^ byte_perm(0u, 0x47544341u, idx));
 }
 
-template <int W>
+template <int W, bool EDGES = false>
 __global__ __launch_bounds__(kFrThreads) void sk_front_kernel(const uint8_t *__restrict__ bytes, uint64_t n_bytes, uint64_t range_bytes, uint32_t n_ranges,
                                                              uint32_t k, bool rna, uint32_t run_cap, uint32_t item_cap, uint32_t ranges_per_group,
                                                              FrRange *__restrict__ info, uint32_t *__restrict__ run_items, uint32_t *__restrict__ rows,
                                                              uint32_t *__restrict__ items, uint32_t *__restrict__ wg_hist,
                                                              unsigned long long *__restrict__ n_windows, uint32_t *__restrict__ flags,
-                                                             uint32_t r_first = 0u, uint32_t r_end = 0xffffffffu, uint32_t edges = 0u) {
-  // edges (the de Bruijn node build, kmi_debruijn.h): a record also carries the base before its first and the base behind its last
+                                                             uint32_t r_first = 0u, uint32_t r_end = 0xffffffffu) {
+  constexpr bool edges = EDGES;   // (a kernel of its own: the checks it adds cost the build that does not need them a quarter of this kernel's time)
+  // EDGES (the de Bruijn node build, kmi_debruijn.h): a record also carries the base before its first and the base behind its last
   // k-mer (two 3-bit codes in the place of its last three bases: super-k-mers are cut three windows earlier), which the scatter pass
   // takes from the run's row (the bases around the run itself ride in the row's last word) -- and every base has to be one of A C G T
   // (an N is an A inside a k-mer but its own DNA16 code as a neighbour, edge_iterator.hpp:163-177: the general build decides then)
@@ -277,14 +279,15 @@ __global__ __launch_bounds__(kFrThreads) void sk_front_kernel(const uint8_t *__r
           for (int q = 0; q < F::NR; ++q) {
             FrU4 v = *reinterpret_cast<const FrU4 *>(bytes + g0 + 16 * q);   // (a read starts at any byte: unaligned 16-byte loads)
             if (rna) { v.x = swap_tu_dword(v.x); v.y = swap_tu_dword(v.y); v.z = swap_tu_dword(v.z); v.w = swap_tu_dword(v.w); }
-            rw[q] = pack_dna4(v.x) | (pack_dna4(v.y) << 8) | (pack_dna4(v.z) << 16) | (pack_dna4(v.w) << 24);
-            if (edges) {   // uniform
-              const uint32_t nb = L + k - 1u, d[4] = {v.x, v.y, v.z, v.w};
+            uint32_t okd[4];
+            rw[q] = pack_dna4(v.x, &okd[0]) | (pack_dna4(v.y, &okd[1]) << 8) | (pack_dna4(v.z, &okd[2]) << 16) | (pack_dna4(v.w, &okd[3]) << 24);
+            if (edges) {   // uniform: every byte of the run's nb bases has to be one of A C G T
+              const uint32_t nbits = 8u * (L + k - 1u);
 #pragma unroll
               for (int e = 0; e < 4; ++e) {
-                const uint32_t at = 16u * (uint32_t)q + 4u * (uint32_t)e;
-                const uint32_t vm = nb >= at + 4u ? 0x80808080u : (nb <= at ? 0u : (0x80808080u & ((1u << (8u * (nb - at))) - 1u)));
-                other |= ~dna4_ok(d[e]) & vm;
+                const uint32_t at = 8u * (16u * (uint32_t)q + 4u * (uint32_t)e);   // first bit of this dword in the run
+                const uint32_t vm = nbits >= at + 32u ? 0x80808080u : (nbits <= at ? 0u : (0x80808080u & ((1u << (nbits - at)) - 1u)));
+                other |= ~okd[e] & vm;
               }
             }
           }

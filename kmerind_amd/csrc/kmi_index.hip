@@ -2795,7 +2795,7 @@ static kmi_status sk_front_fast(kmi_ctx *ctx, const kmi_config *cfg, const KShap
   // ranges: one per resident wavefront of the front kernel when the input is large; never below the context's minimum
   if (!ctx->front_waves) {
     int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, sk_front_kernel<19>, kFrThreads, 0) != hipSuccess || per_cu <= 0) per_cu = 2;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, sk_front_kernel<19, false>, kFrThreads, 0) != hipSuccess || per_cu <= 0) per_cu = 2;
     ctx->front_waves = (uint32_t)per_cu * (ctx->n_cus ? ctx->n_cus : 256u) * (uint32_t)kFrWaves;
   }
   // (fed from host memory: sixteen times the ranges -- what runs after the last byte has arrived is one range per wavefront slot,
@@ -2824,9 +2824,12 @@ static kmi_status sk_front_fast(kmi_ctx *ctx, const kmi_config *cfg, const KShap
   if (!fed) {
     ProfScope ps(ctx, "sk_front", n_bytes);
     const uint32_t wgs = (n_ranges + kFrWaves - 1) / kFrWaves;
-    hipLaunchKernelGGL((sk_front_kernel<W>), dim3(wgs), dim3(kFrThreads), 0, ctx->stream, bytes_dev, (uint64_t)n_bytes, range_bytes, n_ranges, k, is_rna(cfg),
-                       run_cap, item_cap, rpg, info, run_items, rows, items, wg_hist, (unsigned long long *)(ctx->d_totals + 6), ctx->d_flags, 0u, 0xffffffffu,
-                       ctx->edge_records ? 1u : 0u);
+    if (ctx->edge_records)
+      hipLaunchKernelGGL((sk_front_kernel<W, true>), dim3(wgs), dim3(kFrThreads), 0, ctx->stream, bytes_dev, (uint64_t)n_bytes, range_bytes, n_ranges, k, is_rna(cfg),
+                         run_cap, item_cap, rpg, info, run_items, rows, items, wg_hist, (unsigned long long *)(ctx->d_totals + 6), ctx->d_flags, 0u, 0xffffffffu);
+    else
+      hipLaunchKernelGGL((sk_front_kernel<W, false>), dim3(wgs), dim3(kFrThreads), 0, ctx->stream, bytes_dev, (uint64_t)n_bytes, range_bytes, n_ranges, k, is_rna(cfg),
+                         run_cap, item_cap, rpg, info, run_items, rows, items, wg_hist, (unsigned long long *)(ctx->d_totals + 6), ctx->d_flags, 0u, 0xffffffffu);
   } else {
     // The input is still in host memory: its copy goes out in chunks on a stream of its own, all of them queued now, and behind every
     // chunk the front end takes the ranges whose bytes have arrived -- a range reads up to kFrOverrun + three steps behind its own end
@@ -2873,9 +2876,12 @@ static kmi_status sk_front_fast(kmi_ctx *ctx, const kmi_config *cfg, const KShap
       if (r_end > n_ranges) r_end = n_ranges;
       if (r_end <= r_done) continue;
       const uint32_t wgs = (r_end - r_done + kFrWaves - 1) / kFrWaves;
-      hipLaunchKernelGGL((sk_front_kernel<W>), dim3(wgs), dim3(kFrThreads), 0, ctx->stream, bytes_dev, (uint64_t)n_bytes, range_bytes, n_ranges, k, is_rna(cfg),
-                         run_cap, item_cap, rpg, info, run_items, rows, items, wg_hist, (unsigned long long *)(ctx->d_totals + 6), ctx->d_flags, r_done, r_end,
-                         ctx->edge_records ? 1u : 0u);
+      if (ctx->edge_records)
+        hipLaunchKernelGGL((sk_front_kernel<W, true>), dim3(wgs), dim3(kFrThreads), 0, ctx->stream, bytes_dev, (uint64_t)n_bytes, range_bytes, n_ranges, k, is_rna(cfg),
+                           run_cap, item_cap, rpg, info, run_items, rows, items, wg_hist, (unsigned long long *)(ctx->d_totals + 6), ctx->d_flags, r_done, r_end);
+      else
+        hipLaunchKernelGGL((sk_front_kernel<W, false>), dim3(wgs), dim3(kFrThreads), 0, ctx->stream, bytes_dev, (uint64_t)n_bytes, range_bytes, n_ranges, k, is_rna(cfg),
+                           run_cap, item_cap, rpg, info, run_items, rows, items, wg_hist, (unsigned long long *)(ctx->d_totals + 6), ctx->d_flags, r_done, r_end);
       r_done = r_end;
     }
   }
