@@ -191,6 +191,7 @@ __global__ __launch_bounds__((DbgCfg<NW>::NT)) void dbg_accumulate_kernel(const 
 // build laid out by the same minimizer buckets. One lane per record rolls through its k-mers: window -> both strands -> the smaller
 // one is the node (the edges of a node kept reverse-complemented change sides and are complemented, de_bruijn_node_trait.hpp:
 // 122-124) -> row -> two counter adds. Counters and chunks of rows as in dbg_accumulate_kernel.
+constexpr int kSkEdgeOwn = 64 * 10;   // unit marks of a wavefront's batch: 64 records of up to 9 units (18 k-mers) + slack
 __global__ __launch_bounds__((DbgCfg<1>::NT)) void sk_edges_accumulate_kernel(const uint64_t *__restrict__ idx_keys, const uint64_t *__restrict__ idx_off,
                                                                            const uint64_t *__restrict__ recs, const uint64_t *__restrict__ rec_off,
                                                                            const uint64_t *__restrict__ fine_region, const uint32_t *__restrict__ fine_cap,
@@ -201,6 +202,7 @@ __global__ __launch_bounds__((DbgCfg<1>::NT)) void sk_edges_accumulate_kernel(co
   __shared__ uint16_t s_row[Cfg::SLOTS];
   __shared__ uint32_t s_cnt[Cfg::ROWS * 4];
   __shared__ uint32_t s_mark[(Cfg::ROWS + 31) / 32];
+  __shared__ uint8_t s_own[(Cfg::NT / kWave) * kSkEdgeOwn];
   __shared__ uint32_t s_ctl[8];
   LdsTable<1> tab;
   tab.keys = s_tk; tab.vals = nullptr; tab.tags = s_tt; tab.distinct = &s_ctl[0]; tab.overflow = &s_ctl[1];
@@ -210,6 +212,7 @@ __global__ __launch_bounds__((DbgCfg<1>::NT)) void sk_edges_accumulate_kernel(co
   const uint32_t b = blockIdx.x;
   const uint64_t ib = idx_off[b], ie = idx_off[b + 1];
   if (ib == ie) return;
+  for (uint32_t x = threadIdx.x; x < (uint32_t)sizeof(s_own) / 4u; x += blockDim.x) reinterpret_cast<uint32_t *>(s_own)[x] = 0;
   uint64_t rb, re;
   if (fine_cnt) {
     const uint32_t cap = fine_cap[b >> 7], cnt = fine_cnt[b];
@@ -259,49 +262,80 @@ __global__ __launch_bounds__((DbgCfg<1>::NT)) void sk_edges_accumulate_kernel(co
       chunk = chunk > 64u ? chunk / 2u : 32u;
       continue;
     }
-    for (uint64_t i = rb + threadIdx.x; i < re; i += blockDim.x) {
-      const ulonglong2 rec = reinterpret_cast<const ulonglong2 *>(recs)[i];
-      const uint32_t n = ((uint32_t)(rec.y >> kRecNShift) & 31u) + 1u;
-      const uint32_t lout = (uint32_t)(rec.y >> kRecEdgeShift) & 7u, rout = (uint32_t)(rec.y >> (kRecEdgeShift + 3)) & 7u;
-      const uint64_t hb = rec.y & 0xFFFFFFFFull;                       // the bases above bit 64 (edge records hold at most 96 bits of bases)
-      // window j = bits [2 j, 2 j + 2 k) of the record = the REVERSE strand of the k-mer that starts at base j (complement codes, first
-      // base lowest); x = what lies above the window: its lowest code is base j + k
-      uint64_t rc = rec.x & kmask;
-      uint64_t x = kb >= 64u ? hb : ((rec.x >> kb) | (hb << (64u - kb)));
-      uint64_t xh = kb >= 64u ? 0ull : (hb >> kb);
-      uint64_t r1[1] = {rc}, f1[1];
-      fwd_from_rc<1, 2>(r1, f1, shape);
-      uint64_t fw = f1[0];
-      uint32_t in_code = lout;                                          // 1 + base code of the base before the window (0: none)
-      // one window: the node (the smaller strand) and the counters its two neighbours go to (8: none); then one base on
-      auto window = [&](uint32_t j, uint64_t &key, uint32_t &t_out, uint32_t &t_in) {
-        const uint32_t nxt = (uint32_t)x & 3u;                         // complement code of base j + k
-        const uint32_t out_code = (j + 1u < n) ? 4u - nxt : rout;      // (base code = 3 - complement code)
-        const bool rev = rc < fw;                                      // the node is the reverse strand: edges change sides, complemented
-        key = rev ? rc : fw;
-        const uint32_t ci = rev ? (out_code ? 5u - out_code : 0u) : in_code;
-        const uint32_t co = rev ? (in_code ? 5u - in_code : 0u) : out_code;
-        t_out = co ? co - 1u : 8u; t_in = ci ? 3u + ci : 8u;
-        in_code = 4u - ((uint32_t)rc & 3u);                            // base j becomes the base before window j + 1
-        rc = ((rc >> 2) | ((uint64_t)nxt << (kb - 2u))) & kmask;
-        fw = ((fw << 2) | (uint64_t)(3u - nxt)) & kmask;
-        x = (x >> 2) | (xh << 62); xh >>= 2;
-      };
-      // two windows at a time: both table walks start before either row is needed (a lane's turn is a chain of LDS round trips)
-      for (uint32_t j = 0; j < n; j += 2u) {
-        uint64_t ka, kc = 0; uint32_t oa, ia, oc = 8u, ic = 8u;
-        window(j, ka, oa, ia);
-        const bool two = j + 1u < n;
-        if (two) window(j + 1u, kc, oc, ic);
-        const bool va = (oa & ia) != 8u, vc = two && (oc & ic) != 8u;   // (8 & 8: no neighbour at all)
-        const uint64_t kka[1] = {ka}, kkc[1] = {kc};
-        uint32_t sa = slot_of(place_hash<1>(kka), (int)Cfg::CAP), sc = slot_of(place_hash<1>(kkc), (int)Cfg::CAP);
-        uint64_t ta = s_tk[sa], tc = s_tk[sc];
-        uint32_t ra = ~0u, rcw = ~0u;
-        if (va) { if (ka == kEmptyKey) ra = *s_special_row; else { while (ta != ka && ta != kEmptyKey) ta = s_tk[++sa]; if (ta == ka) ra = s_row[sa]; } }
-        if (vc) { if (kc == kEmptyKey) rcw = *s_special_row; else { while (tc != kc && tc != kEmptyKey) tc = s_tk[++sc]; if (tc == kc) rcw = s_row[sc]; } }
-        if (ra != ~0u) { if (oa != 8u) add(ra, oa, 1u); if (ia != 8u) add(ra, ia, 1u); }
-        if (rcw != ~0u) { if (oc != 8u) add(rcw, oc, 1u); if (ic != 8u) add(rcw, ic, 1u); }
+    // The records, 64 to a wavefront at a time, their k-mers dealt out as sk_reduce's expansion deals them out: a UNIT is two
+    // neighbouring k-mers of one record, the units of the batch are numbered through the records' prefix sums, and lane l of step t
+    // takes unit 64 t + l whatever record it belongs to -- the record is the last one that starts at or before the unit (marks in a
+    // byte array, a running maximum over the lanes), its words come over the lane crossbar. So every lane works in every step although
+    // the records hold 1 to 18 k-mers (one lane per record: a lane's turn was as long as its record and the others waited). The two
+    // k-mers of a unit start their table walks together.
+    {
+      const uint32_t lane = lane_id(), wv = wave_id();
+      uint8_t *const wown = s_own + wv * kSkEdgeOwn;
+      const uint32_t kmask_hi = kb >= 64u ? 0xffffffffu : ((1u << (kb - 32u)) - 1u), pad = 64u - kb, top_sh = kb - 34u;   // (k >= 17)
+      for (uint64_t r0 = rb + (uint64_t)wv * kWave; r0 < re; r0 += blockDim.x) {   // (uniform per wavefront)
+        ulonglong2 rec = make_ulonglong2(0, 0);
+        const bool have = r0 + lane < re;
+        if (have) rec = reinterpret_cast<const ulonglong2 *>(recs)[r0 + lane];
+        const uint32_t n = have ? ((uint32_t)(rec.y >> kRecNShift) & 31u) + 1u : 0u;
+        const uint32_t nu = (n + 1u) >> 1;
+        const uint32_t inc = wave_inclusive_sum_dpp(nu);
+        const uint32_t pre = inc - nu;
+        const uint32_t total = __builtin_amdgcn_readlane(inc, kWave - 1);
+        if (nu) wown[pre] = (uint8_t)(lane + 1u);
+        uint32_t carry = 0;
+        for (uint32_t g0 = 0; g0 < total; g0 += kWave) {
+          const uint32_t g = g0 + lane;
+          const bool act = g < total;
+          uint32_t o = act ? (uint32_t)wown[g] : 0u;
+          o = wave_inclusive_max_dpp(o);
+          o = o > carry ? o : carry;
+          carry = __builtin_amdgcn_readlane(o, kWave - 1);
+          const int rl = (int)((o ? o - 1u : 0u) << 2);   // byte address of the lane that holds the record
+          const uint32_t j = 2u * (g - (uint32_t)__builtin_amdgcn_ds_bpermute(rl, (int)pre));
+          const uint32_t a0 = (uint32_t)__builtin_amdgcn_ds_bpermute(rl, (int)(uint32_t)rec.x), a1 = (uint32_t)__builtin_amdgcn_ds_bpermute(rl, (int)(uint32_t)(rec.x >> 32));
+          const uint32_t a2 = (uint32_t)__builtin_amdgcn_ds_bpermute(rl, (int)(uint32_t)rec.y), a3 = (uint32_t)__builtin_amdgcn_ds_bpermute(rl, (int)(uint32_t)(rec.y >> 32));
+          const uint32_t rn = ((a3 >> (kRecNShift - 32)) & 31u) + 1u;                       // k-mers of the record
+          const uint32_t lout = (a3 >> (kRecEdgeShift - 32)) & 7u, rout = (a3 >> (kRecEdgeShift - 29)) & 7u;
+          const bool two = act && j + 1u < rn;
+          // complement code of base i of the record (bases sit below bit 96: words a0..a2)
+          auto cc = [&](uint32_t i) -> uint32_t { const uint32_t w = i >= 32u ? a2 : (i >= 16u ? a1 : a0); return (w >> (2u * (i & 15u))) & 3u; };
+          // k-mer j: 2 k bits from bit 2 j (j is even, at most 16: the window starts in word 0 or 1) -- sk_reduce's cut, on 32-bit registers
+          const bool w1sel = j >= 16u;
+          const uint32_t bit = (2u * j) & 31u;
+          const uint32_t b0 = w1sel ? a1 : a0, b1 = w1sel ? a2 : a1, b2 = w1sel ? (a3 & 0u) : a2;   // (nothing of word 3 is a base)
+          const uint32_t rc_lo = __builtin_amdgcn_alignbit(b1, b0, bit);
+          const uint32_t rc_hi = __builtin_amdgcn_alignbit(b2, b1, bit) & kmask_hi;
+          const uint32_t r_hi = __builtin_bitreverse32(rc_lo), r_lo = __builtin_bitreverse32(rc_hi);
+          const uint32_t s_hi = ~(((r_hi >> 1) & 0x55555555u) | ((r_hi << 1) & 0xAAAAAAAAu));
+          const uint32_t s_lo = ~(((r_lo >> 1) & 0x55555555u) | ((r_lo << 1) & 0xAAAAAAAAu));
+          const uint32_t fw_lo = __builtin_amdgcn_alignbit(s_hi, s_lo, pad), fw_hi = s_hi >> pad;
+          const uint32_t rc2_lo = __builtin_amdgcn_alignbit(b1, b0, bit + 2u);
+          const uint32_t rc2_hi = __builtin_amdgcn_alignbit(b2, b1, bit + 2u) & kmask_hi;
+          const uint32_t c_jk = (rc2_hi >> top_sh) & 3u;                                   // complement code of base j + k (the second k-mer's last base)
+          const uint32_t fw2_lo = (fw_lo << 2) | (c_jk ^ 3u);
+          const uint32_t fw2_hi = __builtin_amdgcn_alignbit(fw_hi, fw_lo, 30u) & kmask_hi;
+          const uint64_t rc = (uint64_t)rc_lo | ((uint64_t)rc_hi << 32), fw = (uint64_t)fw_lo | ((uint64_t)fw_hi << 32);
+          const uint64_t rc2 = (uint64_t)rc2_lo | ((uint64_t)rc2_hi << 32), fw2 = (uint64_t)fw2_lo | ((uint64_t)fw2_hi << 32);
+          // neighbours as 1 + base code (base code = 3 - complement code), 0: none
+          const uint32_t in_a = j ? 4u - cc(j - 1u) : lout;
+          const uint32_t out_a = (j + 1u < rn) ? 4u - c_jk : rout;
+          const uint32_t in_c = 4u - (rc_lo & 3u);                                         // base j
+          const uint32_t out_c = (j + 2u < rn) ? 4u - cc(j + k + 1u) : rout;
+          const bool rev_a = rc < fw, rev_c = rc2 < fw2;                                   // the node is the reverse strand: edges change sides, complemented
+          const uint64_t ka = rev_a ? rc : fw, kc = rev_c ? rc2 : fw2;
+          const uint32_t ia = rev_a ? (out_a ? 5u - out_a : 0u) : in_a, oa = rev_a ? (in_a ? 5u - in_a : 0u) : out_a;
+          const uint32_t ic = rev_c ? (out_c ? 5u - out_c : 0u) : in_c, oc = rev_c ? (in_c ? 5u - in_c : 0u) : out_c;
+          const bool va = act && (ia | oa), vc = two && (ic | oc);
+          const uint64_t kka[1] = {ka}, kkc[1] = {kc};
+          uint32_t sa = slot_of(place_hash<1>(kka), (int)Cfg::CAP), sc = slot_of(place_hash<1>(kkc), (int)Cfg::CAP);
+          uint64_t ta = s_tk[sa], tc = s_tk[sc];
+          uint32_t ra = ~0u, rcw = ~0u;
+          if (va) { if (ka == kEmptyKey) ra = *s_special_row; else { while (ta != ka && ta != kEmptyKey) ta = s_tk[++sa]; if (ta == ka) ra = s_row[sa]; } }
+          if (vc) { if (kc == kEmptyKey) rcw = *s_special_row; else { while (tc != kc && tc != kEmptyKey) tc = s_tk[++sc]; if (tc == kc) rcw = s_row[sc]; } }
+          if (ra != ~0u) { if (oa) add(ra, oa - 1u, 1u); if (ia) add(ra, 3u + ia, 1u); }
+          if (rcw != ~0u) { if (oc) add(rcw, oc - 1u, 1u); if (ic) add(rcw, 3u + ic, 1u); }
+        }
+        if (nu) wown[pre] = 0;   // the marks go back to zero for the next batch
       }
     }
     lds_barrier();
