@@ -2543,7 +2543,15 @@ static kmi_status adopt_tmp(kmi_index *idx, const uint64_t *tmp_keys, const uint
     idx->n_entries = total; idx->has_data = true; idx->keys_bytes = kb0; idx->vals_bytes = vb0;
     return KMI_OK;
   }
-  if (NW == 1 && allow_sparse && n_slots >= ctx->sparse_min && !src_b && ctx->ws[WS_TMP_KEYS].p == (const void *)tmp_keys &&
+  // (the sparse form holds the reduce's output buffers -- 12 bytes per k-mer OCCURRENCE, 14 GB at config 2 against 1.2 GB dense -- for the
+  // index's lifetime, and the next build allocates its own: it is taken only while the device has room for that second set. Several
+  // indexes in one context, or a smaller GPU, get the compaction pass instead of an out-of-memory error: ADVICE r3)
+  bool room = false;
+  if (NW == 1 && allow_sparse && n_slots >= ctx->sparse_min) {
+    size_t free_b = 0, total_b = 0;
+    room = hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b >= ctx->ws[WS_TMP_KEYS].cap + ctx->ws[WS_TMP_VALS].cap + ((size_t)1 << 30);
+  }
+  if (NW == 1 && allow_sparse && room && n_slots >= ctx->sparse_min && !src_b && ctx->ws[WS_TMP_KEYS].p == (const void *)tmp_keys &&
       ctx->ws[WS_TMP_VALS].p == (const void *)tmp_vals) {
     uint64_t *off = nullptr; uint32_t *cnt = nullptr;
     hipError_t e1 = pool_alloc(ctx, (void **)&off, kOffBytes);
