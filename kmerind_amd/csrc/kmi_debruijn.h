@@ -220,11 +220,6 @@ __global__ __launch_bounds__((DbgCfg<1>::NT)) void sk_edges_accumulate_kernel(co
   } else { rb = rec_off[b]; re = rec_off[b + 1]; }
   if (rb == re) return;
   uint64_t i0 = ib;
-  auto row_of = [&](uint64_t key) -> uint32_t {
-    const uint64_t kk[1] = {key};
-    const int s = table_find<1>(tab, kk, place_hash<1>(kk));
-    return s >= 0 ? (uint32_t)s_row[s] : (s == -2 ? *s_special_row : ~0u);
-  };
   auto add = [&](uint32_t row, uint32_t t, uint32_t a) {   // counter t of `row` += a, a < 65536 (dbg_accumulate_kernel's add)
     uint32_t *g = edges + (i0 + row) * 8u;
     if (t & 1u) {
@@ -253,7 +248,7 @@ __global__ __launch_bounds__((DbgCfg<1>::NT)) void sk_edges_accumulate_kernel(co
     lds_barrier();
     for (uint32_t j = threadIdx.x; j < nc; j += blockDim.x) {
       const uint64_t kk[1] = {idx_keys[i0 + j]};
-      const int s = table_upsert<1>(tab, kk, place_hash<1>(kk));
+      const int s = table_upsert<1>(tab, kk, sk_slot_hash(kk[0]));   // (the reduce's slot hash: 24-bit multiplies -- this table is private to the kernel)
       if (s >= 0) s_row[s] = (uint16_t)j; else if (s == -2) *s_special_row = j; else *s_fail = 1;
     }
     lds_barrier();
@@ -326,8 +321,7 @@ __global__ __launch_bounds__((DbgCfg<1>::NT)) void sk_edges_accumulate_kernel(co
           const uint32_t ia = rev_a ? (out_a ? 5u - out_a : 0u) : in_a, oa = rev_a ? (in_a ? 5u - in_a : 0u) : out_a;
           const uint32_t ic = rev_c ? (out_c ? 5u - out_c : 0u) : in_c, oc = rev_c ? (in_c ? 5u - in_c : 0u) : out_c;
           const bool va = act && (ia | oa), vc = two && (ic | oc);
-          const uint64_t kka[1] = {ka}, kkc[1] = {kc};
-          uint32_t sa = slot_of(place_hash<1>(kka), (int)Cfg::CAP), sc = slot_of(place_hash<1>(kkc), (int)Cfg::CAP);
+          uint32_t sa = slot_of(sk_slot_hash(ka), (int)Cfg::CAP), sc = slot_of(sk_slot_hash(kc), (int)Cfg::CAP);
           uint64_t ta = s_tk[sa], tc = s_tk[sc];
           uint32_t ra = ~0u, rcw = ~0u;
           if (va) { if (ka == kEmptyKey) ra = *s_special_row; else { while (ta != ka && ta != kEmptyKey) ta = s_tk[++sa]; if (ta == ka) ra = s_row[sa]; } }
@@ -435,16 +429,14 @@ static kmi_status dbg_parse(kmi_ctx *ctx, const kmi_config *cfg, const uint8_t *
 __global__ __launch_bounds__(256) void dbg_iota_kernel(uint32_t *__restrict__ v, uint64_t n) {
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) v[i] = (uint32_t)i;
 }
-__global__ __launch_bounds__(256) void dbg_follow_kernel(uint32_t *__restrict__ vals /* in: old positions, out: counts */, uint64_t n,
-                                                        const uint32_t *__restrict__ old_counts, const uint32_t *__restrict__ old_edges,
-                                                        uint32_t *__restrict__ edges) {
+__global__ __launch_bounds__(256) void dbg_follow_kernel(const uint32_t *__restrict__ vals /* the entries' old positions */, uint64_t n,
+                                                        const uint32_t *__restrict__ old_edges, uint32_t *__restrict__ edges) {
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n * 8u; i += (uint64_t)gridDim.x * blockDim.x) {
     const uint64_t p = i >> 3, t = i & 7u;
-    const uint32_t o = vals[p];
-    edges[i] = old_edges[(uint64_t)o * 8u + t];
+    edges[i] = old_edges[(uint64_t)vals[p] * 8u + t];
   }
-  // (second loop: the first one reads vals of every entry)
 }
+// (a launch of its own behind dbg_follow_kernel, which reads the old position of every entry)
 __global__ __launch_bounds__(256) void dbg_follow_counts_kernel(uint32_t *__restrict__ vals, uint64_t n, const uint32_t *__restrict__ old_counts) {
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) vals[i] = old_counts[vals[i]];
 }
@@ -466,7 +458,7 @@ static kmi_status dbg_to_placement_layout(kmi_dbg *g) {
   if (pool_alloc(ctx, (void **)&ne, eb) != hipSuccess) return set_err(ctx, KMI_ERR_NOMEM, "hipMalloc failed for the edge counts");
   {
     ProfScope ps(ctx, "dbg_follow", n);
-    hipLaunchKernelGGL(dbg_follow_kernel, dim3(4096), dim3(256), 0, ctx->stream, idx->vals, n, (const uint32_t *)old_counts, (const uint32_t *)g->edges, ne);
+    hipLaunchKernelGGL(dbg_follow_kernel, dim3(4096), dim3(256), 0, ctx->stream, (const uint32_t *)idx->vals, n, (const uint32_t *)g->edges, ne);
     hipLaunchKernelGGL(dbg_follow_counts_kernel, dim3(2048), dim3(256), 0, ctx->stream, idx->vals, n, (const uint32_t *)old_counts);
   }
   KMI_HIP(ctx, hipGetLastError());
