@@ -1332,7 +1332,8 @@ template <int NW> struct TabCfg {
   // the dependent LDS round trips of the probe walk, not by the load factor), and the large table takes twice the
   // distinct keys per pass (9120 per bucket, 3.0e8 per index) before a bucket needs a second pass.
   // (12160 + 64 slots x 12 B + 16 KB of per-wave miss queues = 160 KB)
-  static constexpr int CAP = (NW == 1) ? 12160 : (NW == 2 ? 4608 : (NW == 3 ? 3584 : 2816));   // home slots
+  static constexpr int CAP = (NW == 1) ? 12160 : (NW == 2 ? 6144 : (NW == 3 ? 4608 : 3712));   // home slots (tagged tables: 24 / 32 / 40 B per slot, 144 - 147 KB; a
+                                                                                              // bucket of config 2 at k = 63 holds 3050 distinct keys: 4608 slots ran it at a load of 0.66)
   // One-word tables probe linearly WITHOUT wrap-around: a probe sequence that starts near the end runs on
   // into PAD extra slots, so a probe step is "next address, read, compare" and nothing else. The very last
   // slot is never filled (an insert that would need it reports overflow), which ends every probe sequence.
@@ -1413,13 +1414,17 @@ template <int NW> __device__ __forceinline__ int table_upsert(const LdsTable<NW>
     while (probes < (int)CAP) {
       uint32_t tg = __atomic_load_n(&t.tags[slot], __ATOMIC_RELAXED);
       if (tg == kTagEmpty) {
+        if (__atomic_load_n(t.overflow, __ATOMIC_RELAXED)) return -1;   // the pass is lost already: no further claims
         uint32_t old = atomicCAS(&t.tags[slot], kTagEmpty, kTagLock);
         if (old == kTagEmpty) {
 #pragma unroll
           for (int w = 0; w < NW; ++w) t.keys[(uint64_t)slot * NW + w] = key[w];
           __threadfence_block();
           atomicExch(&t.tags[slot], tagv);
-          if (probes >= kMaxProbe) *t.overflow = 1;
+          // (the load limit holds for tagged tables too: without it a bucket of more distinct keys than slots filled its table to the
+          // last slot, and every key of the stream then walked all of it before the pass was given up -- O(keys x slots) per attempt:
+          // 11.9 s for config 2's reads over an 800 Mbp genome at k = 63)
+          if (atomicAdd(t.distinct, 1u) >= t.limit || probes >= kMaxProbe) *t.overflow = 1;
           return (int)slot;
         }
         continue;  // somebody else took it: look again
@@ -1894,6 +1899,10 @@ __global__ __launch_bounds__((TabCfg<NW>::NT)) void bucket_reduce_kernel(const u
         }
       } else {
         for_each_key<NW, BatchOf<NW>::U>(new_keys, nb, ne, [&](const uint64_t (&k)[NW], uint64_t) {
+          // (a lost pass ends here, not at the end of the stream. The pass count doubles from attempt to attempt: an estimate from how
+          // far the stream had got when the table was full was tried and cost more attempts than it saved -- 163 against 117 ms for
+          // 5.3e8 distinct 63-mers)
+          if (__atomic_load_n(tab.overflow, __ATOMIC_RELAXED)) return;
           const uint32_t h = place_hash<NW>(k);
           if (pass_of(h, npass) != pass) return;
           int s = table_upsert<NW>(tab, k, h);

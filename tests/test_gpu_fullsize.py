@@ -298,3 +298,31 @@ def test_config5_one_rank_share_position_quality_index_and_queries():
     assert hit <= 8                                                        # 3e9 of 2^61 canonical values: a handful at most
     idx.close()
     ctx.close()
+
+
+def test_two_word_keys_with_more_distinct_keys_per_bucket_than_a_table_holds():
+    """1.7e8 distinct 40-mers (two-word keys) in one insert: every one of the 32768 buckets holds about 5200 distinct keys, more than
+    a tagged LDS table takes in one pass (3 / 4 of 6144 slots), so every bucket goes through in two passes. Until round 4 the tagged
+    tables had no load limit: a bucket like this filled its table to the last slot and every further key walked all of it before the
+    attempt was given up -- config 2's reads over an 800 Mbp genome at k = 63 took 11.9 s (now 0.14 s). Keys by construction: the low
+    word counts up, so size and counts are known without an oracle pass; each key is inserted twice."""
+    import kmerind_amd as K
+    ctx = K.Context(0)
+    idx = K.CountIndex(ctx, K.make_config(40, "DNA", strand="single"))
+    n = 170_000_000
+    lo = np.arange(n, dtype=np.uint64)
+    keys = np.empty((n, 2), dtype=np.uint64)
+    keys[:, 0] = lo * np.uint64(7) + np.uint64(3)          # (the low word is distinct ...
+    keys[:, 1] = (lo >> np.uint64(3)) & np.uint64(0xFFFF)   # ... and the high word stays inside a 40-mer's 16 high bits)
+    d = ctx.alloc(keys.nbytes)
+    ctx.to_device(d, keys)
+    for _ in range(2):
+        idx.insert_device(d, n)
+    assert idx.local_size() == n
+    q = keys[np.random.default_rng(1).integers(0, n, size=200_000)]
+    ck, cc = idx.count(q)
+    assert ck.shape[0] == np.unique(q, axis=0).shape[0] and (np.asarray(cc) == 1).all()
+    fk, fv = idx.find(q)
+    assert (np.asarray(fv) == 2).all() and fk.shape[0] == ck.shape[0]
+    ctx.free(d)
+    idx.close(); ctx.close()
