@@ -1776,24 +1776,36 @@ template <int NW> __device__ __forceinline__ bool slot_used(const LdsTable<NW> &
   return NW == 1 ? (t.keys[slot] != kEmptyKey) : (t.tags[slot] != kTagEmpty);
 }
 
-// visit keys[b, e) with U independent loads per thread in flight; f(key words, index)
+// visit keys[b, e) with U independent loads per thread in flight; f(key words, index). The loads of the NEXT batch are issued before
+// the current one is worked on: a batch's work is a chain of LDS round trips per key, and the tagged tables leave a CU eight
+// wavefronts -- with the loads issued only when the previous batch was done, every batch began with a full trip to HBM that nothing
+// else could hide (the k = 63 reduce of config 2's reads ran at 39 G keys/s)
 template <int NW, int U, typename F>
 __device__ __forceinline__ void for_each_key(const uint64_t *__restrict__ keys, uint64_t b, uint64_t e, F f) {
+  uint64_t nxt[U][NW];
+  auto load = [&](uint64_t i0) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      uint64_t i = i0 + (uint64_t)u * blockDim.x + threadIdx.x;
+      i = i < e ? i : e - 1;   // (clamped, not guarded: nothing forces an early wait; b < e here)
+#pragma unroll
+      for (int w = 0; w < NW; ++w) nxt[u][w] = keys[i * NW + w];
+    }
+  };
+  if (b >= e) return;
+  load(b);
   for (uint64_t i0 = b; i0 < e; i0 += (uint64_t)blockDim.x * U) {
     uint64_t raw[U][NW];
-    bool ok[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int w = 0; w < NW; ++w) raw[u][w] = nxt[u][w];
+    if (i0 + (uint64_t)blockDim.x * U < e) load(i0 + (uint64_t)blockDim.x * U);
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const uint64_t i = i0 + (uint64_t)u * blockDim.x + threadIdx.x;
-      ok[u] = i < e;
-      if (ok[u]) {
-#pragma unroll
-        for (int w = 0; w < NW; ++w) raw[u][w] = keys[i * NW + w];
-      }
+      if (i < e) f(raw[u], i);
     }
-#pragma unroll
-    for (int u = 0; u < U; ++u)
-      if (ok[u]) f(raw[u], i0 + (uint64_t)u * blockDim.x + threadIdx.x);
   }
 }
 template <int NW> struct BatchOf { static constexpr int U = (NW == 1) ? kLoadBatch : (NW == 2 ? 4 : 2); };
@@ -1901,7 +1913,8 @@ __global__ __launch_bounds__((TabCfg<NW>::NT)) void bucket_reduce_kernel(const u
         for_each_key<NW, BatchOf<NW>::U>(new_keys, nb, ne, [&](const uint64_t (&k)[NW], uint64_t) {
           // (a lost pass ends here, not at the end of the stream. The pass count doubles from attempt to attempt: an estimate from how
           // far the stream had got when the table was full was tried and cost more attempts than it saved -- 163 against 117 ms for
-          // 5.3e8 distinct 63-mers)
+          // 5.3e8 distinct 63-mers. Reading the home slots of a batch's keys back to back before any of them is inserted -- the flat
+          // insert of the one-word tables -- did not move this kernel either: 19.9 ms with and without.)
           if (__atomic_load_n(tab.overflow, __ATOMIC_RELAXED)) return;
           const uint32_t h = place_hash<NW>(k);
           if (pass_of(h, npass) != pass) return;
