@@ -627,6 +627,179 @@ __global__ __launch_bounds__(kPartThreads) void scatter_fine_lines_kernel(const 
                           [=](uint64_t key) { const uint64_t kk[1] = {key}; return fine15_of_key<1>(kk, layout_w, k) & (uint32_t)(NB - 1); });
 }
 
+// P2 for RECORDS (key words + value words: the tuples of the position indexes), whole-line form. The plain form (scatter_range) writes
+// a tile's records of a fine bucket where the bucket's previous tile ended: runs of 16-32 records that begin and end inside 128-byte
+// lines, 3.4 TB/s where whole lines reach 5.7 (tools/write_runs.hip, modes 11 / 12) -- and this pass is a copy. Here, as in
+// scatter_lines_range, a bucket only ever emits whole groups of 16 ELEMENTS after the unaligned head of its stream: 16 elements are
+// NW whole lines of the key array and VW whole lines of the value array (or NW + VW lines of one record array) whatever the word counts
+// are, so one element count cuts both output streams at line boundaries. The tail of < 16 elements is carried into the next tile in
+// registers (16 slots per bucket spread over eight threads); the copy-out walks destination groups (16 lanes = one group).
+template <int RW> struct RecLinesCfg {
+  static constexpr int NB = kSubPerCoarse;
+  static constexpr int SCAP = (RW <= 2) ? 4096 : 3072;                                      // stage elements: tile + carry (64 / 72 / 96 KB)
+  static constexpr int T = (SCAP - (kLineKeys - 1) * NB) / kPartThreads * kPartThreads;    // new elements per tile (2048 / 1024 / 1024)
+  static constexpr int PT = T / kPartThreads;
+  static constexpr int MAXG = SCAP / kLineKeys + NB;
+  static constexpr int TPBK = kPartThreads / NB;                                           // threads per bucket for the carry (8)
+  static constexpr int CPT = kLineKeys / TPBK;                                             // carry slots per thread (2)
+  static_assert(kPartThreads % NB == 0 && kLineKeys % TPBK == 0 && T > 0, "whole-line geometry");
+};
+template <int NW, int VW, typename BktFn>
+__device__ __forceinline__ void scatter_lines_records(const uint64_t *__restrict__ in, uint64_t begin, uint64_t end, uint64_t *__restrict__ out,
+                                                      uint64_t *__restrict__ out_vals /* null: whole records to `out` */,
+                                                      uint64_t cursor /* of bucket threadIdx.x, threads < NB; in elements */, BktFn bktfn) {
+  constexpr int RW = NW + VW;
+  using LC = RecLinesCfg<RW>;
+  constexpr int NB = LC::NB, T = LC::T, PT = LC::PT, SCAP = LC::SCAP, MAXG = LC::MAXG, TPBK = LC::TPBK, CPT = LC::CPT;
+  __shared__ uint64_t s_stage[SCAP * RW];
+  __shared__ uint64_t s_cur0[NB];      // cursor of the bucket before this tile's emission
+  __shared__ uint32_t s_cnt[NB];       // carry + new elements of the tile, by LDS atomic
+  __shared__ uint32_t s_lofs[NB];      // first stage slot of the bucket
+  __shared__ uint32_t s_emit[NB];      // elements that leave this tile (up to the last group boundary)
+  __shared__ uint32_t s_old[NB];       // elements carried into this tile
+  __shared__ uint32_t s_rem[NB];       // elements carried out of this tile
+  __shared__ uint32_t s_lbase[NB];     // first destination group of the bucket
+  __shared__ uint32_t s_part[NB / kWave];
+  __shared__ uint32_t s_ng;
+  __shared__ uint8_t s_linebkt[MAXG];  // bucket of every destination group
+  if (begin >= end) return;
+  if (threadIdx.x < NB) { s_cnt[threadIdx.x] = 0; s_rem[threadIdx.x] = 0; s_emit[threadIdx.x] = 0; s_cur0[threadIdx.x] = cursor; }
+  const uint32_t cb = threadIdx.x / TPBK, cj = (threadIdx.x % TPBK) * CPT;   // carry: slots cj .. cj + CPT - 1 of bucket cb
+  uint64_t carry[CPT][RW];
+#pragma unroll
+  for (int i = 0; i < CPT; ++i)
+#pragma unroll
+    for (int w = 0; w < RW; ++w) carry[i][w] = 0;
+  uint32_t my_carry = 0;   // thread b < NB: elements it carries
+  lds_barrier();
+  uint64_t raw[PT][RW];
+  auto load_tile = [&](uint64_t t0) {   // unconditional (clamped) loads: nothing forces an early wait
+#pragma unroll
+    for (int j = 0; j < PT; ++j) {
+      uint64_t i = t0 + (uint64_t)j * kPartThreads + threadIdx.x;
+      i = (i < end) ? i : end - 1;
+#pragma unroll
+      for (int w = 0; w < RW; ++w) raw[j][w] = in[i * RW + w];
+    }
+  };
+  auto put = [&](uint64_t dpos, const uint64_t *src) {   // element dpos of the output arrays
+    if (out_vals) {
+#pragma unroll
+      for (int w = 0; w < NW; ++w) out[dpos * NW + w] = src[w];
+#pragma unroll
+      for (int w = 0; w < VW; ++w) out_vals[dpos * VW + w] = src[NW + w];
+    } else {
+#pragma unroll
+      for (int w = 0; w < RW; ++w) out[dpos * RW + w] = src[w];
+    }
+  };
+  load_tile(begin);
+  for (uint64_t t0 = begin; t0 < end; t0 += T) {
+    const uint32_t nt = (uint32_t)((end - t0 < (uint64_t)T) ? (end - t0) : (uint64_t)T);
+    uint64_t el[PT][RW];
+    uint32_t rnk[PT], bkt[PT];
+#pragma unroll
+    for (int j = 0; j < PT; ++j) {
+      const uint32_t li = j * kPartThreads + threadIdx.x;
+      rnk[j] = 0xffffffffu;
+      uint64_t key[NW];
+#pragma unroll
+      for (int w = 0; w < RW; ++w) el[j][w] = raw[j][w];
+#pragma unroll
+      for (int w = 0; w < NW; ++w) key[w] = raw[j][w];
+      bkt[j] = bktfn(key);
+      if (li < nt) rnk[j] = atomicAdd(&s_cnt[bkt[j]], 1u);   // rank behind the carried elements: s_cnt starts at the carry count
+    }
+    if (t0 + T < end) load_tile(t0 + T);   // in flight until the next iteration needs it
+    lds_barrier();
+    uint32_t cnt = 0, emit = 0, ng = 0, inc = 0;
+    if (threadIdx.x < NB) {   // whole waves
+      cnt = s_cnt[threadIdx.x];
+      const uint64_t aend = (cursor + cnt) & ~(uint64_t)(kLineKeys - 1);
+      emit = aend > cursor ? (uint32_t)(aend - cursor) : 0u;
+      ng = emit ? (uint32_t)((aend - (cursor & ~(uint64_t)(kLineKeys - 1))) / kLineKeys) : 0u;
+      inc = wave_inclusive_scan(cnt | (ng << 16));
+      if (lane_id() == kWave - 1) s_part[wave_id()] = inc;
+    }
+    lds_barrier();
+    if (threadIdx.x < NB) {
+      uint32_t pre = 0;
+#pragma unroll
+      for (uint32_t w = 0; w < NB / kWave; ++w) pre += (w < wave_id()) ? s_part[w] : 0u;
+      const uint32_t ex = pre + inc - (cnt | (ng << 16));
+      const uint32_t lo = ex & 0xffffu, lb = ex >> 16;
+      s_lofs[threadIdx.x] = lo; s_emit[threadIdx.x] = emit; s_old[threadIdx.x] = my_carry; s_cur0[threadIdx.x] = cursor;
+      s_lbase[threadIdx.x] = lb; s_rem[threadIdx.x] = cnt - emit;
+      for (uint32_t i = 0; i < ng; ++i) s_linebkt[lb + i] = (uint8_t)threadIdx.x;
+      if (threadIdx.x == NB - 1) s_ng = lb + ng;
+      s_cnt[threadIdx.x] = cnt - emit;   // the next tile ranks behind these
+      cursor += emit; my_carry = cnt - emit;
+    }
+    lds_barrier();
+    // stage: carried elements first, then the tile's, per bucket
+    {
+      const uint32_t oc = s_old[cb], lo = s_lofs[cb];
+#pragma unroll
+      for (int i = 0; i < CPT; ++i)
+        if (cj + i < oc) {
+#pragma unroll
+          for (int w = 0; w < RW; ++w) s_stage[(uint64_t)(lo + cj + i) * RW + w] = carry[i][w];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < PT; ++j)
+      if (rnk[j] != 0xffffffffu) {
+        const uint32_t pos = s_lofs[bkt[j]] + rnk[j];
+#pragma unroll
+        for (int w = 0; w < RW; ++w) s_stage[(uint64_t)pos * RW + w] = el[j][w];
+      }
+    lds_barrier();
+    // copy-out by destination group: 16 lanes = 16 elements of one bucket = whole lines of either output array
+    {
+      const uint32_t groups = s_ng, l16 = threadIdx.x & (kLineKeys - 1);
+      for (uint32_t g = threadIdx.x >> 4; g < groups; g += kPartThreads / kLineKeys) {
+        const uint32_t b = s_linebkt[g];
+        const uint64_t cur0 = s_cur0[b];
+        const uint64_t dpos = (cur0 & ~(uint64_t)(kLineKeys - 1)) + (uint64_t)(g - s_lbase[b]) * kLineKeys + l16;
+        if (dpos >= cur0 && dpos < cur0 + s_emit[b]) put(dpos, &s_stage[(uint64_t)(s_lofs[b] + (uint32_t)(dpos - cur0)) * RW]);
+      }
+      // what stays behind the last group boundary travels on in registers
+      const uint32_t rem = s_rem[cb], base = s_lofs[cb] + s_emit[cb];
+#pragma unroll
+      for (int i = 0; i < CPT; ++i)
+        if (cj + i < rem) {
+#pragma unroll
+          for (int w = 0; w < RW; ++w) carry[i][w] = s_stage[(uint64_t)(base + cj + i) * RW + w];
+        }
+    }
+    lds_barrier();   // the next tile rewrites the stage and the per-bucket tables
+  }
+  // the streams end with one partial group each
+  {
+    const uint32_t rem = s_rem[cb];
+    const uint64_t fc = s_cur0[cb] + s_emit[cb];
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) if (cj + i < rem) put(fc + cj + i, carry[i]);
+  }
+}
+
+// P2 of the position indexes' records: workgroup (c, h) as in scatter_fine_kernel
+template <int NW, int BITS, int VW>
+__global__ __launch_bounds__(kPartThreads) void scatter_fine_records_lines_kernel(const uint64_t *__restrict__ in, uint64_t *__restrict__ out, KShape shape,
+                                                                                 const uint64_t *__restrict__ fine_off, const uint64_t *__restrict__ part_off,
+                                                                                 const uint64_t *__restrict__ wg_off, uint32_t groups, uint32_t layout_w,
+                                                                                 uint64_t *__restrict__ out_vals) {
+  constexpr int NB = kSubPerCoarse;
+  const uint32_t gpp = groups / kFineParts;
+  const uint32_t c = blockIdx.x / kFineParts, h = blockIdx.x % kFineParts;
+  const uint64_t cursor = (threadIdx.x < NB) ? part_off[(uint64_t)h * kNumFine + c * NB + threadIdx.x] : 0ull;
+  const uint64_t begin = wg_off[(uint64_t)(h * gpp) * kNumCoarse + c];
+  const uint64_t end = (h + 1 < (uint32_t)kFineParts) ? wg_off[(uint64_t)((h + 1) * gpp) * kNumCoarse + c] : fine_off[(c + 1) * NB];
+  const uint32_t k = shape.k;
+  scatter_lines_records<NW, VW>(in, begin, end, out, out_vals, cursor,
+                                [=](const uint64_t (&key)[NW]) { return fine15_of_key<NW>(key, layout_w, k) & (uint32_t)(NB - 1); });
+}
+
 // ---------------------------------------------------------------------------
 // Fused build (Index::build_* on one rank): the k-mers are generated from the FASTQ tiles
 // inside the histogram pass (E1) and again inside the coarse scatter pass (E2), so the
@@ -3580,9 +3753,19 @@ static kmi_status partition_from_parse(kmi_index *idx, const uint8_t *bytes_dev,
   }
   {
     ProfScope ps(ctx, "scatter_fine", n);
-    hipLaunchKernelGGL((scatter_fine_kernel<NW, BITS, VW>), dim3(kNumCoarse * kFineParts), dim3(kPartThreads), 0, ctx->stream, w.buf_a,
-                       split_keys ? split_keys : w.buf_b, idx->shape, (const uint64_t *)w.fine_off, (const uint64_t *)w.part_off,
-                       (const uint64_t *)w.wg_off, (uint32_t)kPartGroups, (int)BUCKET_SUB, 0u, split_keys ? split_vals : (uint64_t *)nullptr);
+    if constexpr (NW + VW <= 4) {
+      if (ctx->lines_p2)
+        hipLaunchKernelGGL((scatter_fine_records_lines_kernel<NW, BITS, VW>), dim3(kNumCoarse * kFineParts), dim3(kPartThreads), 0, ctx->stream,
+                           (const uint64_t *)w.buf_a, split_keys ? split_keys : w.buf_b, idx->shape, (const uint64_t *)w.fine_off, (const uint64_t *)w.part_off,
+                           (const uint64_t *)w.wg_off, (uint32_t)kPartGroups, 0u, split_keys ? split_vals : (uint64_t *)nullptr);
+      else
+        hipLaunchKernelGGL((scatter_fine_kernel<NW, BITS, VW>), dim3(kNumCoarse * kFineParts), dim3(kPartThreads), 0, ctx->stream, w.buf_a,
+                           split_keys ? split_keys : w.buf_b, idx->shape, (const uint64_t *)w.fine_off, (const uint64_t *)w.part_off,
+                           (const uint64_t *)w.wg_off, (uint32_t)kPartGroups, (int)BUCKET_SUB, 0u, split_keys ? split_vals : (uint64_t *)nullptr);
+    } else
+      hipLaunchKernelGGL((scatter_fine_kernel<NW, BITS, VW>), dim3(kNumCoarse * kFineParts), dim3(kPartThreads), 0, ctx->stream, w.buf_a,
+                         split_keys ? split_keys : w.buf_b, idx->shape, (const uint64_t *)w.fine_off, (const uint64_t *)w.part_off,
+                         (const uint64_t *)w.wg_off, (uint32_t)kPartGroups, (int)BUCKET_SUB, 0u, split_keys ? split_vals : (uint64_t *)nullptr);
   }
   KMI_HIP(ctx, hipGetLastError());
   uint32_t fl = 0, fl0 = 0;

@@ -2,6 +2,7 @@
 // round of 2048 tuples at a time, as runs of consecutive tuples per stream (what tuple_scatter's staged rounds produce):
 //   mode 0: runs of 8 tuples starting on 128-byte lines     mode 1: runs of 8 starting anywhere (every run straddles two lines)
 //   mode 2: runs of 4..12 tuples (mean 8), starting wherever the previous one ended (what the kernel does today)
+//   mode 11 / 12: runs of 32 tuples (512 bytes) starting anywhere / on lines
 //   mode 3: runs of 16 aligned    mode 4: runs of 8 on 64-byte boundaries that are not 128-byte ones    mode 5: runs of 4 / 8 / 12 on 64-byte boundaries
 // hipcc -O3 --offload-arch=gfx950 tools/write_runs.hip -o /tmp/write_runs && /tmp/write_runs
 #include <hip/hip_runtime.h>
@@ -20,6 +21,7 @@ __global__ __launch_bounds__(NT) void k(ulonglong2 *out, uint64_t per_stream, ui
     uint32_t off = 0;
     if (mode == 1) off = 1u + (threadIdx.x * 2654435761u >> 7) % 7u;
     if (mode == 4 || mode == 5) off = 4u;
+    if (mode == 11) off = 1u + (threadIdx.x * 2654435761u >> 7) % 7u;
     s_cur[threadIdx.x] = wg_base + (uint64_t)threadIdx.x * per_stream + off;
   }
   __syncthreads();
@@ -30,6 +32,8 @@ __global__ __launch_bounds__(NT) void k(ulonglong2 *out, uint64_t per_stream, ui
       uint32_t l = 8;
       if (mode == 2) l = 4u + ((b * 40503u + r * 2654435761u) >> 13) % 9u;
       if (mode == 3) l = (b & 1) ? 0 : 16;
+      if (mode == 11 || mode == 12) l = 32;   // (with 64 streams of the 256: what a fine scatter of 16-byte records writes per tile)
+      if ((mode == 11 || mode == 12) && (b & 3u)) l = 0;
       if (mode == 6) l = 4;
       if (mode == 7) l = (b & 1) ? 4 : 12;
       if (mode == 8) l = 8u * (((b * 40503u + r * 2654435761u) >> 13) % 3u);   // 0, 8 or 16: whole lines
@@ -80,7 +84,7 @@ int main() {
       if (ms < best_fill) best_fill = ms;
     }
     printf("fill of the same bytes: %.2f ms, %.2f TB/s\n", best_fill, (double)total * 16 / best_fill / 1e9);
-    for (int mode = 0; mode < 11; ++mode) {
+    for (int mode = 0; mode < 13; ++mode) {
       float best = 1e9f;
       for (int it = 0; it < 4; ++it) {
         CK(hipEventRecord(e0));
