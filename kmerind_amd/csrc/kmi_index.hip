@@ -2685,6 +2685,11 @@ static kmi_status partition_impl(kmi_ctx *ctx, const kmi_config *cfg, KShape sha
       hipLaunchKernelGGL(scatter_fine_lines_kernel, dim3(kNumCoarse * kFineParts), dim3(kPartThreads), 0, ctx->stream, (const uint64_t *)w.buf_a,
                          w.buf_b, (const uint64_t *)w.fine_off, (const uint64_t *)w.part_off, (const uint64_t *)w.wg_off, (uint32_t)kPartGroups,
                          layout_w, shape.k);
+    else if (NW + VW <= 4 && ctx->lines_p2)   // whole lines (scatter_lines_records)
+      hipLaunchKernelGGL((scatter_fine_records_lines_kernel<NW, BITS, VW>), dim3(kNumCoarse * kFineParts), dim3(kPartThreads), 0, ctx->stream,
+                         (const uint64_t *)w.buf_a, (VW > 0 && split_keys) ? split_keys : w.buf_b, shape, (const uint64_t *)w.fine_off,
+                         (const uint64_t *)w.part_off, (const uint64_t *)w.wg_off, (uint32_t)kPartGroups, layout_w,
+                         (VW > 0 && split_keys) ? split_vals : (uint64_t *)nullptr);
     else
       hipLaunchKernelGGL((scatter_fine_kernel<NW, BITS, VW>), dim3(kNumCoarse * kFineParts), dim3(kPartThreads), 0, ctx->stream, w.buf_a,
                          (VW > 0 && split_keys) ? split_keys : w.buf_b, shape, (const uint64_t *)w.fine_off, (const uint64_t *)w.part_off,
@@ -2873,6 +2878,10 @@ static kmi_status build_fused_impl(kmi_index *idx, const uint8_t *bytes_dev, siz
       hipLaunchKernelGGL(scatter_fine_lines_kernel, dim3(kNumCoarse * kFineParts), dim3(kPartThreads), 0, ctx->stream, (const uint64_t *)w.buf_a,
                          w.buf_b, (const uint64_t *)w.fine_off, (const uint64_t *)w.part_off, (const uint64_t *)w.wg_off,
                          (uint32_t)fused_groups<NW>());
+    else if (NW <= 4 && ctx->lines_p2)
+      hipLaunchKernelGGL((scatter_fine_records_lines_kernel<NW, BITS, 0>), dim3(kNumCoarse * kFineParts), dim3(kPartThreads), 0, ctx->stream,
+                         (const uint64_t *)w.buf_a, w.buf_b, idx->shape, (const uint64_t *)w.fine_off, (const uint64_t *)w.part_off,
+                         (const uint64_t *)w.wg_off, (uint32_t)fused_groups<NW>(), 0u, (uint64_t *)nullptr);
     else
       hipLaunchKernelGGL((scatter_fine_kernel<NW, BITS>), dim3(kNumCoarse * kFineParts), dim3(kPartThreads), 0, ctx->stream, w.buf_a, w.buf_b,
                          idx->shape, (const uint64_t *)w.fine_off, (const uint64_t *)w.part_off, (const uint64_t *)w.wg_off,
