@@ -243,6 +243,7 @@ kmi_status kmi_ctx_create(int device, int rank, int nranks, void *stream, kmi_ct
   if (const char *fr = getenv("KMI_FRONT")) ctx->front_fused = strcmp(fr, "general") != 0;
   if (const char *ho = getenv("KMI_HOST_OVERLAP")) ctx->host_overlap = atoi(ho) != 0;
   if (const char *lp2 = getenv("KMI_LINES_P2")) ctx->lines_p2 = atoi(lp2) != 0;
+  if (const char *fl = getenv("KMI_SK_FINE_LINES")) ctx->sk_fine_lines = atoi(fl) != 0;
   if (const char *ds = getenv("KMI_DBG_SUPERKMER")) ctx->dbg_superkmer = atoi(ds) != 0;
   if (const char *hm = getenv("KMI_HOST_OVERLAP_MIN")) ctx->host_overlap_min = strtoull(hm, nullptr, 10);
   if (const char *fc = getenv("KMI_FEED_MIN_CHUNK")) { ctx->feed_min_chunk = strtoull(fc, nullptr, 10); if (ctx->feed_min_chunk < 4096) ctx->feed_min_chunk = 4096; }

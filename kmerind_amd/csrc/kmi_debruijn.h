@@ -271,7 +271,7 @@ __global__ __launch_bounds__((DbgCfg<1>::NT)) void sk_edges_accumulate_kernel(co
         ulonglong2 rec = make_ulonglong2(0, 0);
         const bool have = r0 + lane < re;
         if (have) rec = reinterpret_cast<const ulonglong2 *>(recs)[r0 + lane];
-        const uint32_t n = have ? ((uint32_t)(rec.y >> kRecNShift) & 31u) + 1u : 0u;
+        const uint32_t n = (have && rec.y != kSkPadW1) ? ((uint32_t)(rec.y >> kRecNShift) & 31u) + 1u : 0u;
         const uint32_t nu = (n + 1u) >> 1;
         const uint32_t inc = wave_inclusive_sum_dpp(nu);
         const uint32_t pre = inc - nu;

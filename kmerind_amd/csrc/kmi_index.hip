@@ -3240,9 +3240,14 @@ static kmi_status sk_back_end(kmi_index *idx, const uint64_t *rec_a, uint64_t R,
                        (uint32_t *)nullptr, 0u, ctx->d_flags, 16u, 35u, 40u, 48u);
     {
       ProfScope ps(ctx, "sk_scatter_fine", R);
-      hipLaunchKernelGGL(sk_scatter_fine_slack_kernel, dim3(kNumCoarse * kFineParts), dim3(kPartThreads), 0, ctx->stream, (const uint64_t *)rec_a, rec_b,
-                         (const uint64_t *)wg_off, (const uint64_t *)cend, (uint32_t)kPartGroups, (const uint64_t *)d_region, (const uint32_t *)d_cap,
-                         fine_cnt, fine_kmers, ctx->d_flags);
+      if (ctx->sk_fine_lines && !ctx->sk_reduce2)   // whole lines + pad records (sk_reduce2 reads a bucket into its stage as it lies: no pads for it)
+        hipLaunchKernelGGL(sk_scatter_fine_slack_lines_kernel, dim3(kNumCoarse * kFineParts), dim3(kPartThreads), 0, ctx->stream, (const uint64_t *)rec_a, rec_b,
+                           (const uint64_t *)wg_off, (const uint64_t *)cend, (uint32_t)kPartGroups, (const uint64_t *)d_region, (const uint32_t *)d_cap,
+                           fine_cnt, fine_kmers, ctx->d_flags);
+      else
+        hipLaunchKernelGGL(sk_scatter_fine_slack_kernel, dim3(kNumCoarse * kFineParts), dim3(kPartThreads), 0, ctx->stream, (const uint64_t *)rec_a, rec_b,
+                           (const uint64_t *)wg_off, (const uint64_t *)cend, (uint32_t)kPartGroups, (const uint64_t *)d_region, (const uint32_t *)d_cap,
+                           fine_cnt, fine_kmers, ctx->d_flags);
     }
     {
       ProfScope ps(ctx, "fine_offsets", kNumFine);

@@ -92,6 +92,7 @@ struct kmi_ctx {
   bool edge_records = false;
   bool dbg_superkmer = true;     // KMI_DBG_SUPERKMER=0: the node build always takes the tuple path
   struct { const uint64_t *recs = nullptr, *rec_off = nullptr, *region = nullptr; const uint32_t *cap = nullptr, *cnt = nullptr; bool valid = false; } sk_left;
+  bool sk_fine_lines = true;     // the super-k-mer build's fine pass writes whole lines + pad records (sk_scatter_fine_slack_lines_kernel); KMI_SK_FINE_LINES=0: the plain form
   bool lines_p2 = true;          // the fine pass of the position builds writes whole lines (scatter_lines_records); KMI_LINES_P2=0: the plain form
   bool host_overlap = true;      // KMI_HOST_OVERLAP=0: one copy on the build's stream, then the build
   size_t host_overlap_min = (size_t)64 << 20;   // ... and inputs below this many bytes always go that way (KMI_HOST_OVERLAP_MIN; tests lower it)

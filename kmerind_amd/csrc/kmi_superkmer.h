@@ -29,6 +29,7 @@ namespace kmi {
 // record (16 bytes): word 0 = bases 0..31 of the complement-stream slice, word 1 = bases 32..50 (38 bits) | (n - 1) << 38 |
 // bucket bits << 43 (18 bits: coarse 8 | fine 7 | sub 3, most significant first)
 constexpr int kRecNShift = 38, kRecHashShift = 43;
+constexpr uint64_t kSkPadW1 = ~0ull;   // second word of a PAD record (sk_scatter_fine_slack_lines_kernel): never a record's; readers of a fine bucket skip it
 // records of the de Bruijn node build: three windows fewer per record (sk_nmax_of - kSkEdgeWindows), and the two outside bases where
 // the last three bases would be: bits 32..34 the base before the first k-mer, 35..37 the base behind the last one, each 1 + its code
 // (A C G T = 0..3 in the record's orientation), 0 = the read ends there
@@ -601,6 +602,134 @@ __global__ __launch_bounds__(kPartThreads) void sk_scatter_fine_slack_kernel(con
   }
 }
 
+// The same pass writing WHOLE LINES. A tile's records of a fine bucket used to go where the bucket's counter stood: runs of about 32
+// records that begin and end inside 128-byte lines, which cost 1.7 x what whole lines cost (tools/write_runs.hip, modes 11 / 12). Here a
+// bucket's records leave in groups of 8 (one line): what a tile brings and what the workgroup still carries of that bucket is cut at the
+// last multiple of 8, room for exactly that many is taken from the bucket's counter -- so every allocation of every workgroup is a
+// multiple of 8 and, the regions starting on lines, every group is a whole line -- and the tail of < 8 records travels on in registers
+// (8 slots per bucket, one per thread of the bucket's eight). At its end a workgroup fills its tails up to 8 with PAD records (second
+// word all ones: never a record's, kSkPadW1), which every reader of a fine bucket skips -- at most 14 per bucket, 0.3 % of config 2's.
+constexpr int kSlackLineRecs = 8;                    // 16-byte records per 128-byte line
+constexpr int kSlackLT = 3072;                       // new records per tile: + 7 carried per bucket = 3968 staged records, 62 KB (two workgroups per CU)
+constexpr int kSlackLCap = kSlackLT + (kSlackLineRecs - 1) * kSubPerCoarse;
+__global__ __launch_bounds__(kPartThreads) void sk_scatter_fine_slack_lines_kernel(const uint64_t *__restrict__ recs, uint64_t *__restrict__ out,
+                                                                                 const uint64_t *__restrict__ wg_off, const uint64_t *__restrict__ coarse_end,
+                                                                                 uint32_t groups, const uint64_t *__restrict__ fine_region,
+                                                                                 const uint32_t *__restrict__ fine_cap, uint32_t *__restrict__ fine_cnt,
+                                                                                 uint32_t *__restrict__ fine_kmers, uint32_t *__restrict__ flags) {
+  constexpr int NB = kSubPerCoarse, T = kSlackLT, PT = T / kPartThreads, SCAP = kSlackLCap, L = kSlackLineRecs, MAXG = SCAP / L + NB;
+  static_assert(kPartThreads / NB == L && T % kPartThreads == 0, "one carry slot per thread: eight threads per bucket");
+  __shared__ ulonglong2 s_stage[SCAP];
+  __shared__ uint32_t s_cnt[NB];       // carry + new records of the tile
+  __shared__ uint32_t s_k[NB];         // k-mers of the tile's new records
+  __shared__ uint32_t s_lofs[NB];      // first stage slot of the bucket
+  __shared__ uint32_t s_emit[NB];      // records that leave this tile
+  __shared__ uint32_t s_old[NB];       // records carried into this tile
+  __shared__ uint32_t s_lbase[NB];     // first destination group of the bucket
+  __shared__ uint64_t s_dst[NB];       // where this tile's groups of the bucket go (~0: the bucket has outgrown its room)
+  __shared__ uint32_t s_part[NB / kWave];
+  __shared__ uint32_t s_ng;
+  __shared__ uint8_t s_linebkt[MAXG];
+  const uint32_t gpp = groups / kFineParts;
+  const uint32_t c = blockIdx.x / kFineParts, h = blockIdx.x % kFineParts;
+  const uint64_t b = wg_off[(uint64_t)(h * gpp) * kNumCoarse + c];
+  const uint64_t e = (h + 1 < (uint32_t)kFineParts) ? wg_off[(uint64_t)((h + 1) * gpp) * kNumCoarse + c] : coarse_end[c];
+  if (b >= e) return;
+  const uint64_t region = fine_region[c];
+  const uint32_t cap = fine_cap[c];
+  if (threadIdx.x < NB) { s_cnt[threadIdx.x] = 0; s_k[threadIdx.x] = 0; }
+  const uint32_t cb = threadIdx.x / L, cj = threadIdx.x % L;   // carry: slot cj of bucket cb
+  ulonglong2 carry = make_ulonglong2(0, 0);
+  uint32_t my_carry = 0;   // thread f < NB: records it carries of bucket f
+  lds_barrier();
+  const ulonglong2 *src = reinterpret_cast<const ulonglong2 *>(recs);
+  ulonglong2 raw[PT];
+  auto load_tile = [&](uint64_t t0) {
+#pragma unroll
+    for (int j = 0; j < PT; ++j) {
+      uint64_t i = t0 + (uint64_t)j * kPartThreads + threadIdx.x;
+      i = (i < e) ? i : e - 1;
+      raw[j] = src[i];
+    }
+  };
+  // room for `n` records (a multiple of 8) of fine bucket f: the position inside the region, or ~0 when the bucket has outgrown it
+  auto take = [&](uint32_t f, uint32_t n) -> uint64_t {
+    const uint32_t at = atomicAdd(&fine_cnt[c * NB + f], n);
+    if ((uint64_t)at + n > (uint64_t)cap) { atomicOr(&flags[34], 1u); return ~0ull; }
+    return region + (uint64_t)f * cap + at;
+  };
+  load_tile(b);
+  for (uint64_t t0 = b; t0 < e; t0 += T) {
+    const uint32_t nt = (uint32_t)((e - t0 < (uint64_t)T) ? (e - t0) : (uint64_t)T);
+    ulonglong2 rec[PT];
+    uint32_t bk[PT], rk[PT];
+#pragma unroll
+    for (int j = 0; j < PT; ++j) {
+      const uint32_t li = j * kPartThreads + threadIdx.x;
+      rec[j] = raw[j];
+      bk[j] = 0xffffffffu;
+      if (li < nt) {
+        bk[j] = rec_fine_sub(rec[j].y);
+        rk[j] = atomicAdd(&s_cnt[bk[j]], 1u);   // rank behind the carried records: s_cnt starts at the carry count
+        atomicAdd(&s_k[bk[j]], ((uint32_t)(rec[j].y >> kRecNShift) & 31u) + 1u);
+      }
+    }
+    if (t0 + T < e) load_tile(t0 + T);
+    lds_barrier();
+    uint32_t cnt = 0, emit = 0, ng = 0, inc = 0;
+    if (threadIdx.x < NB) {   // two whole waves
+      cnt = s_cnt[threadIdx.x];
+      const uint32_t km = s_k[threadIdx.x];
+      s_k[threadIdx.x] = 0;
+      emit = cnt & ~(uint32_t)(L - 1);
+      ng = emit / L;
+      inc = wave_inclusive_sum_dpp(cnt | (ng << 16));
+      if (lane_id() == kWave - 1) s_part[wave_id()] = inc;
+      if (km) atomicAdd(&fine_kmers[c * NB + threadIdx.x], km);
+      s_dst[threadIdx.x] = emit ? take(threadIdx.x, emit) : ~0ull;
+    }
+    lds_barrier();
+    if (threadIdx.x < NB) {
+      const uint32_t pre = wave_id() ? s_part[0] : 0u;
+      const uint32_t ex = pre + inc - (cnt | (ng << 16));
+      const uint32_t lo = ex & 0xffffu, lb = ex >> 16;
+      s_lofs[threadIdx.x] = lo; s_emit[threadIdx.x] = emit; s_old[threadIdx.x] = my_carry; s_lbase[threadIdx.x] = lb;
+      for (uint32_t i = 0; i < ng; ++i) s_linebkt[lb + i] = (uint8_t)threadIdx.x;
+      if (threadIdx.x == NB - 1) s_ng = lb + ng;
+      s_cnt[threadIdx.x] = cnt - emit;   // the next tile ranks behind these
+      my_carry = cnt - emit;
+    }
+    lds_barrier();
+    // stage: carried records first, then the tile's, per bucket
+    if (cj < s_old[cb]) s_stage[s_lofs[cb] + cj] = carry;
+#pragma unroll
+    for (int j = 0; j < PT; ++j)
+      if (bk[j] != 0xffffffffu) s_stage[s_lofs[bk[j]] + rk[j]] = rec[j];
+    lds_barrier();
+    {
+      const uint32_t n_groups = s_ng, l8 = threadIdx.x & (uint32_t)(L - 1);
+      for (uint32_t g = threadIdx.x / L; g < n_groups; g += kPartThreads / L) {
+        const uint32_t f = s_linebkt[g];
+        const uint64_t d = s_dst[f];
+        const uint32_t i = (g - s_lbase[f]) * L + l8;
+        if (d != ~0ull) reinterpret_cast<ulonglong2 *>(out)[d + i] = s_stage[s_lofs[f] + i];
+      }
+      // what stays behind the last group travels on in registers
+      const uint32_t rem = s_cnt[cb], base = s_lofs[cb] + s_emit[cb];
+      if (cj < rem) carry = s_stage[base + cj];
+    }
+    lds_barrier();   // the next tile rewrites the stage and the per-bucket tables
+  }
+  // the tails: filled up to a whole line with pad records
+  {
+    if (threadIdx.x < NB) s_dst[threadIdx.x] = my_carry ? take(threadIdx.x, (uint32_t)L) : ~0ull;
+    lds_barrier();
+    const uint32_t rem = s_cnt[cb];
+    const uint64_t d = s_dst[cb];
+    if (rem && d != ~0ull) reinterpret_cast<ulonglong2 *>(out)[d + cj] = cj < rem ? carry : make_ulonglong2(kEmptyKey, kSkPadW1);
+  }
+}
+
 // the words a build zeroes before its kernels start, in one launch instead of a fill per array (a fill is a kernel of its own:
 // five microseconds each on the stream, and a build has a dozen): up to three arrays of dwords and two short ranges of the flags
 __global__ __launch_bounds__(1024) void sk_zero_kernel(uint32_t *__restrict__ a, uint32_t na, uint32_t *__restrict__ b, uint32_t nb,
@@ -1025,7 +1154,7 @@ __global__ __launch_bounds__(KMI_SK_NT, KMI_SK_MIN_WAVES) void sk_reduce_kernel(
           const ulonglong2 rec = nxt;
           const bool have = r0 + lane < r_hi;
           if (r0 + kWave + lane < r_hi) nxt = src[r0 + kWave + lane];   // in flight while this batch is worked on
-          uint32_t n = have ? ((uint32_t)(rec.y >> kRecNShift) & 31u) + 1u : 0u;
+          uint32_t n = (have && rec.y != kSkPadW1) ? ((uint32_t)(rec.y >> kRecNShift) & 31u) + 1u : 0u;
           if ((rec_hash18(rec.y) & rmask) != rval) n = 0;
           bool direct = n != 0u;   // still to be placed
           if (use_t1) {

@@ -18,7 +18,7 @@ SHORT = [("fastq_scan_tiles_kernel", "fastq_scan_tiles"), ("fastq_list_kernel", 
          ("fastq_scatter_list_kernel", "fastq_scatter"), ("scatter_fine_lines_kernel", "scatter_fine"), ("bucket_reduce_kernel", "bucket_reduce"),
          ("bucket_compact_kernel", "bucket_compact"), ("fine_offsets_kernel", "fine_offsets"),
          ("sk_front_kernel", "sk_front"), ("sk_scatter_rows_kernel", "sk_scatter"),
-         ("sk_scatter_fine_slack_kernel", "sk_scatter_fine"), ("sk_minimizer_kernel", "sk_minimizer"), ("sk_scatter_kernel", "sk_scatter_general"), ("sk_fine_count_kernel", "sk_fine_count"),
+         ("sk_scatter_fine_slack_lines_kernel", "sk_scatter_fine"), ("sk_scatter_fine_slack_kernel", "sk_scatter_fine"), ("sk_minimizer_kernel", "sk_minimizer"), ("sk_scatter_kernel", "sk_scatter_general"), ("sk_fine_count_kernel", "sk_fine_count"),
          ("scatter_fine_kernel", "sk_scatter_fine"), ("sk_reduce_kernel", "sk_reduce")]
 
 
