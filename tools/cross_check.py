@@ -61,6 +61,24 @@ def main():
         a.close(); b.close()
         if not same:
             sys.exit(1)
+    # the whole-line fine pass of the record partitions against the plain form (position, position + quality, three-word keys)
+    os.environ["KMI_LINES_P2"] = "0"
+    ctx_p = K.Context(0)
+    del os.environ["KMI_LINES_P2"]
+    for r in range(max(rounds // 2, 1)):
+        n_reads = int(rng.integers(5_000, 300_000))
+        k, alpha, kind = [(31, "DNA", "position"), (31, "DNA", "posqual"), (63, "DNA5", "position"), (21, "DNA", "posqual"), (40, "DNA", "position")][r % 5]
+        data = np.asarray(K.synth_fastq(seed=12000 + r, genome_len=int(n_reads * 150 / rng.choice([1, 12])), n_reads=n_reads))
+        a = K.PositionIndex(ctx, K.make_config(k, alpha, index_kind=kind)); b = K.PositionIndex(ctx_p, K.make_config(k, alpha, index_kind=kind))
+        a.build(data); b.build(data)
+        ka, va = a.to_vector(); kb, vb = b.to_vector()
+        ra = np.concatenate([ka, va.reshape(ka.shape[0], -1)], axis=1); rb = np.concatenate([kb, vb.reshape(kb.shape[0], -1)], axis=1)
+        ra = ra[np.lexsort(ra.T[::-1])]; rb = rb[np.lexsort(rb.T[::-1])]
+        same = ra.shape == rb.shape and bool((ra == rb).all())
+        print("position round %2d: %7d reads, k = %2d %-4s %-8s %9d tuples  %s" % (r, n_reads, k, alpha, kind, ka.shape[0], "same" if same else "DIFFERENT"), flush=True)
+        a.close(); b.close()
+        if not same:
+            sys.exit(1)
     print("all rounds agree")
 
 
