@@ -3687,6 +3687,7 @@ static kmi_status partition_from_parse(kmi_index *idx, const uint8_t *bytes_dev,
     in.eol = sc->pk_eol; in.stream = sc->pk_stream; in.n_bytes = sc->n_bytes; in.n_cover = sc->n_cover; in.n_valid = sc->n_bytes; in.brk = sc->pk_brk;
     n_tiles = sc->n_tiles;
   }
+  uint64_t per_tiles = (n_tiles + kPartGroups - 1) / kPartGroups;   // scatter-pass tiles per workgroup (both passes walk the same ranges)
   PartWs w;
   uint64_t n = fasta ? 0 : sc->n_tuples;
   KMI_TRY(get_part_ws(ctx, (size_t)n, NW + VW, WS_KEYS_A, WS_KEYS_B, &w));
@@ -3716,12 +3717,14 @@ static kmi_status partition_from_parse(kmi_index *idx, const uint8_t *bytes_dev,
                          canonical, (const uint16_t *)ent, (const uint32_t *)ent_cnt, LPC::ent_stride(idx->shape.k, split), w.fine_hist, w.wg_hist);
     }
   } else {
+    // FASTA: tuple_hist over the compacted stream -- in tiles of 512 threads whatever the scatter pass's tile is (three-word shapes:
+    // twice its size), both passes over the same byte ranges per workgroup
     ProfScope ps(ctx, "tuple_hist", n);
-#define KMI_TUPLE_HIST(FA, RD)                                                                                                             \
-    hipLaunchKernelGGL((tuple_hist_kernel<NW, BITS, FA, RD>), dim3(kPartGroups), dim3(Cfg::NT), 0, ctx->stream, in, n_tiles, idx->shape, canonical, \
-                       fasta ? (const uint32_t *)nullptr : sc->line_base, fasta ? (const uint64_t *)nullptr : sc->tile_off, reads, w.fine_hist, w.wg_hist)
-    if (fasta) KMI_TUPLE_HIST(true, false); else if (quality) KMI_TUPLE_HIST(false, true); else KMI_TUPLE_HIST(false, false);
-#undef KMI_TUPLE_HIST
+    constexpr int NTH = 512, RATIO = NTH / Cfg::NT;
+    static_assert(NTH % Cfg::NT == 0, "the histogram pass's tile is a whole number of the scatter pass's");
+    per_tiles = (per_tiles + RATIO - 1) / RATIO * RATIO;
+    hipLaunchKernelGGL((tuple_hist_kernel<NW, BITS, true, false, NTH>), dim3(kPartGroups), dim3(NTH), 0, ctx->stream, in, (n_tiles + RATIO - 1) / RATIO, idx->shape,
+                       canonical, (const uint32_t *)nullptr, (const uint64_t *)nullptr, reads, w.fine_hist, w.wg_hist, per_tiles / RATIO);
   }
   {
     ProfScope ps(ctx, "fine_offsets", kNumFine);
@@ -3761,7 +3764,7 @@ static kmi_status partition_from_parse(kmi_index *idx, const uint8_t *bytes_dev,
     hipLaunchKernelGGL((tuple_scatter_kernel<NW, BITS, VW, FA>), dim3(kPartGroups), dim3(Cfg::NT), 0, ctx->stream, in, n_tiles, idx->shape, canonical, \
                        fasta ? (const uint32_t *)nullptr : sc->line_base, fasta ? (const uint64_t *)nullptr : sc->hdr_base,                \
                        fasta ? (const uint64_t *)nullptr : sc->tile_off, file_offset, fasta ? fa->ids_by_rank : (const uint64_t *)nullptr, \
-                       (const float *)dq, (const uint64_t *)w.wg_off, w.buf_a, ctx->d_flags)
+                       (const float *)dq, (const uint64_t *)w.wg_off, w.buf_a, ctx->d_flags, per_tiles)
     if (fasta) KMI_TUPLE_SCATTER(true); else KMI_TUPLE_SCATTER(false);
 #undef KMI_TUPLE_SCATTER
   }

@@ -24,12 +24,17 @@ namespace kmi {
 // windows a scatter round takes: 32 / 48 / 64 KB of records of 2 / 3 / 4 words
 template <int RW> struct TupCfg { static constexpr int RT = KMI_TUP_RT(RW); };   // (with the tile images 60 - 80 KB of LDS: two workgroups per CU)
 
-template <int NW, int BITS, bool FASTA, bool READS>
-__global__ __launch_bounds__((ExCfg<NW, BITS>::NT)) void tuple_hist_kernel(PackedInput in, uint64_t n_tiles, KShape shape, bool canonical,
-                                                                         const uint32_t *__restrict__ line_base, const uint64_t *__restrict__ tile_off,
-                                                                         ReadDesc *__restrict__ reads, uint32_t *__restrict__ fine_hist /* [kFineParts][kNumFine] */,
-                                                                         uint32_t *__restrict__ wg_hist /* [groups][kNumCoarse] */) {
-  using Cfg = ExCfg<NW, BITS>;
+// NTH (threads = bytes per tile / C): the histogram pass may take larger tiles than the scatter pass -- its per-tile work (the packed
+// tile into LDS, the scans, the window list) is paid per tile whatever the tile holds, and three-word shapes have tiles of 2 KB
+// (256 threads: their scatter pass needs the registers): with 512 threads the histogram of config 4 takes 6.2 instead of 11.0 ms.
+// `per` = tiles of THIS kernel's size per workgroup: the caller gives both passes the same byte ranges (the scatter pass writes at
+// cursors that come from this pass's per-workgroup counts).
+template <int NW, int BITS, bool FASTA, bool READS, int NTH = ExCfg<NW, BITS>::NT>
+__global__ __launch_bounds__(NTH) void tuple_hist_kernel(PackedInput in, uint64_t n_tiles, KShape shape, bool canonical,
+                                                       const uint32_t *__restrict__ line_base, const uint64_t *__restrict__ tile_off,
+                                                       ReadDesc *__restrict__ reads, uint32_t *__restrict__ fine_hist /* [kFineParts][kNumFine] */,
+                                                       uint32_t *__restrict__ wg_hist /* [groups][kNumCoarse] */, uint64_t per) {
+  using Cfg = ExCfgT<NW, BITS, ExCfg<NW, BITS>::C, NTH>;
   __shared__ uint32_t s_hist[kNumFine];
   __shared__ uint32_t s_eol[Cfg::EOL_DW];
   __shared__ uint32_t s_brk[Cfg::EOL_DW];
@@ -39,7 +44,6 @@ __global__ __launch_bounds__((ExCfg<NW, BITS>::NT)) void tuple_hist_kernel(Packe
   __shared__ uint16_t s_lsmask[READS ? Cfg::NT : 1];   // line-start bits of every chunk
   __shared__ uint16_t s_lcnt[READS ? Cfg::NT : 1];     // line starts of the tile before every chunk
   for (int i = threadIdx.x; i < kNumFine; i += Cfg::NT) s_hist[i] = 0;
-  const uint64_t per = (n_tiles + gridDim.x - 1) / gridDim.x;
   const uint64_t tb = (uint64_t)blockIdx.x * per;
   const uint64_t te = (tb + per < n_tiles) ? tb + per : n_tiles;
   for (uint64_t tile = tb; tile < te; ++tile) {
@@ -89,7 +93,7 @@ __global__ __launch_bounds__((ExCfg<NW, BITS>::NT)) void tuple_scatter_kernel(Pa
                                                                             const uint64_t *__restrict__ tile_off, uint64_t file_offset,
                                                                             const uint64_t *__restrict__ ids_by_rank, const float *__restrict__ in_q,
                                                                             const uint64_t *__restrict__ wg_off, uint64_t *__restrict__ out,
-                                                                            uint32_t *__restrict__ flags) {
+                                                                            uint32_t *__restrict__ flags, uint64_t per /* tiles per workgroup */) {
   using Cfg = ExCfg<NW, BITS>;
   constexpr int RW = NW + VW, RT = TupCfg<RW>::RT, NT = Cfg::NT, PT = RT / NT;
   static_assert(RT % NT == 0 && NT >= kNumCoarse, "round geometry");
@@ -108,7 +112,6 @@ __global__ __launch_bounds__((ExCfg<NW, BITS>::NT)) void tuple_scatter_kernel(Pa
   __shared__ uint16_t s_hexcl[FASTA ? 1 : Cfg::NT];   // 1 + tile position of the last record start in earlier chunks
   uint64_t cursor = (threadIdx.x < kNumCoarse) ? wg_off[(uint64_t)blockIdx.x * kNumCoarse + threadIdx.x] : 0ull;
   if (threadIdx.x < kNumCoarse) s_cnt[threadIdx.x] = 0;
-  const uint64_t per = (n_tiles + gridDim.x - 1) / gridDim.x;
   const uint64_t tb = (uint64_t)blockIdx.x * per;
   const uint64_t te = (tb + per < n_tiles) ? tb + per : n_tiles;
   for (uint64_t tile = tb; tile < te; ++tile) {
